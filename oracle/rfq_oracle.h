@@ -1,0 +1,101 @@
+/*
+ * rfq_oracle — CPU restatement of the OpenGene/repaq v0.5.1 RfqCodec path (ALGORITHM_VER 2).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under repaq_amd/ links, loads or calls this code; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and there only as
+ * the checker.  It is pinned against the reference itself: oracle/Makefile builds the reference
+ * binary (oracle/_ref/repaq) from /root/reference in place, tests/golden/make_golden.py generated
+ * the committed fixtures with it, and tests/test_oracle_vs_ref.py differential-tests this file
+ * against that binary whenever oracle/_ref/repaq exists.
+ *
+ * Every function cites the reference file:line it restates.
+ */
+#ifndef RFQ_ORACLE_H
+#define RFQ_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* header flag bits — src/rfqheader.h:24-42 */
+#define RFQO_H_LANE        (1u << 0)
+#define RFQO_H_TILE        (1u << 1)
+#define RFQO_H_X           (1u << 2)
+#define RFQO_H_Y           (1u << 3)
+#define RFQO_H_NAME2       (1u << 4)
+#define RFQO_H_PAIRED      (1u << 5)
+#define RFQO_H_PE_OVERLAP  (1u << 6)
+#define RFQO_H_QUAL_BY_COL (1u << 7)
+#define RFQO_H_DONT_QUAL   (1u << 8)
+#define RFQO_H_N_POS       (1u << 9)
+/* chunk flag bits — src/rfqchunk.h:25-50 */
+#define RFQO_C_READ_LEN_SAME   (1u << 0)
+#define RFQO_C_NAME1_LEN_SAME  (1u << 1)
+#define RFQO_C_NAME2_LEN_SAME  (1u << 2)
+#define RFQO_C_STRAND_LEN_SAME (1u << 3)
+#define RFQO_C_LANE_SAME       (1u << 4)
+#define RFQO_C_TILE_SAME       (1u << 5)
+#define RFQO_C_NAME1_SAME      (1u << 6)
+#define RFQO_C_NAME2_SAME      (1u << 7)
+#define RFQO_C_STRAND_SAME     (1u << 8)
+#define RFQO_C_PE_INTERLEAVED  (1u << 9)
+#define RFQO_C_NO_LB           (1u << 10)
+#define RFQO_C_NO_LB_R2        (1u << 11)
+
+/* paired modes of the file-level drivers */
+#define RFQO_SE             0
+#define RFQO_PE_TWO_FILES   1
+#define RFQO_PE_INTERLEAVED 2
+
+typedef struct {
+    uint8_t  version[5];
+    uint8_t  algo;
+    uint8_t  read_len_bytes;
+    uint16_t flags;
+    uint8_t  name2_diff_pos;
+    uint8_t  name2_diff_char;
+    uint8_t  n_base_qual;      /* 0xFF == -1: N positions are coded explicitly */
+    uint8_t  overlap_shift;    /* 0xE8 == -24 */
+    uint8_t  qual_bins;
+    uint8_t  qual_buf[256];
+    int      support_interleaved; /* not stored on disk (src/rfqheader.h:96) */
+} rfqo_header;
+
+typedef struct {
+    int      ok;               /* hasLaneTileXY */
+    uint32_t name1_len;        /* name1 = name[0, name1_len) */
+    uint32_t name2_off;        /* name2 = name[name2_off, len) */
+    uint32_t name2_len;
+    uint8_t  lane; uint16_t tile; uint32_t x, y;
+} rfqo_meta;
+
+/* ---- unit-level restatements (also used as known-answer test entry points) ---- */
+void     rfqo_parse_name(const uint8_t* name, uint32_t len, rfqo_meta* out);            /* src/fastqmeta.cpp:22-80 */
+int      rfqo_overlap(const uint8_t* r1, int len1, const uint8_t* r2, int len2);        /* src/rfqcodec.cpp:1391-1438 */
+int64_t  rfqo_encode_coords(const uint32_t* data, uint32_t num, uint8_t* out);          /* :1262-1330; -1 on >=2^21 */
+void     rfqo_decode_coords(const uint8_t* buf, uint32_t len, uint32_t* data, uint32_t num); /* :1332-1389 */
+uint32_t rfqo_pos_encode(const uint8_t* buf, uint32_t len, uint8_t q, uint8_t* out, uint8_t* mask); /* :625-710 */
+void     rfqo_pos_decode(const uint8_t* stream, uint32_t slen, uint8_t q, uint8_t* out, uint32_t out_len); /* :957-1007 */
+void     rfqo_revcomp(uint8_t* seq, uint8_t* qual, int len);                            /* src/read.cpp:77-115 */
+
+size_t   rfqo_header_write(const rfqo_header* h, uint8_t* out);                         /* src/rfqheader.cpp:84-97 */
+int      rfqo_header_read(const uint8_t* in, size_t n, rfqo_header* h, size_t* used, char* err); /* :19-43 */
+
+/* ---- file-level drivers (Repaq::compress/compressPE/decompress/decompressPE) ---- */
+/* Returns 0 on success; on failure writes the reference's error_exit text into err[256].
+ * *out is malloc'd; caller frees with rfqo_free. */
+int  rfqo_encode_file(const uint8_t* fq1, size_t n1, const uint8_t* fq2, size_t n2, int paired,
+                      uint32_t chunk_bases, uint8_t** out, size_t* out_len, char* err);
+int  rfqo_decode_file(const uint8_t* rfq, size_t n, int split_pe,
+                      uint8_t** out1, size_t* n1, uint8_t** out2, size_t* n2, char* err);
+void rfqo_free(void* p);
+
+/* chunk table of an .rfq image: offsets[i] = byte offset of chunk i, offsets[n_chunks] = end.
+ * Returns n_chunks or -1.  (The reader ignores mSize, src/rfqchunk.cpp:163.) */
+int64_t rfqo_chunk_table(const uint8_t* rfq, size_t n, uint64_t* offsets, size_t cap, char* err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
