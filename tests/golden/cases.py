@@ -1,0 +1,204 @@
+"""Hand-built edge-case FASTQ inputs shared by the golden maker (make_golden.py), the oracle-vs-reference
+differential test and the GPU parity tests.  Each case: name -> dict(fq1, fq2, paired, k).
+Everything is synthesised here; no reference data is involved."""
+import random
+
+SE, PE2, PEI = 0, 1, 2
+
+
+def rec(name, seq, qual, strand="+"):
+    return (name, seq, strand, qual)
+
+
+def fastq(records, eol="\n", final_eol=True):
+    out = []
+    for (n, s, st, q) in records:
+        out += [n, s, st, q]
+    txt = eol.join(out) + (eol if final_eol else "")
+    return txt.encode("latin-1")
+
+
+def illumina(i, mate=1, lane=1, tile=1101, x=None, y=None, idx="ACGT"):
+    x = 1000 + 7 * i if x is None else x
+    y = 2000 + (i // 50) if y is None else y
+    return "@A00250:26:H3YTWDSXX:%d:%d:%d:%d %d:N:0:%s" % (lane, tile, x, y, mate, idx)
+
+
+def rseq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def rqual(rng, n, vals="FFFFFFFFFFFFFFFFFFFF::,"):
+    return "".join(rng.choice(vals) for _ in range(n))
+
+
+def comp(s):
+    m = {"A": "T", "T": "A", "C": "G", "G": "C"}
+    return "".join(m.get(c, "N") for c in reversed(s))
+
+
+def build_cases():
+    C = {}
+    rng = random.Random(12345)
+
+    # --- SURVEY.md Appendix D.5 / D.6 ---
+    k1 = [rec("@A00250:26:H3YTWDSXX:1:1101:1000:2000 1:N:0:ACGT", "ACGTNACGTACGTACGTACGTAAAA", "FFFF#FFF:FFFFFFFFFF,FFFFF"),
+          rec("@A00250:26:H3YTWDSXX:1:1101:1032:2000 1:N:0:ACGT", "GGGGGGGGTTTTTTTTCCCCCCCCA", "FFFFFFFFFFFFFFFFFFFFFFFF:")]
+    k2 = [rec("@A00250:26:H3YTWDSXX:1:1101:1000:2000 2:N:0:ACGT", "CCCCTTTTACGTACGTACGTACGTN", ",FFFFFFFFFFFFFFFFFFFFFFF#"),
+          rec("@A00250:26:H3YTWDSXX:1:1101:1032:2000 2:N:0:ACGT", "ACACACACACACACACACACACACA", "FFFFFFFFFFFFFFFFFFFFFFFFF")]
+    C["d5_tiny_se"] = dict(fq1=fastq(k1), paired=SE)
+    C["d6_tiny_pe"] = dict(fq1=fastq(k1), fq2=fastq(k2), paired=PE2)
+    inter = [k1[0], k2[0], k1[1], k2[1]]
+    C["d6_tiny_pe_interleaved_in"] = dict(fq1=fastq(inter), paired=PEI)
+
+    # --- line endings / trailing newline / truncation quirks (src/fastqreader.cpp:94-196) ---
+    base = [rec(illumina(i), rseq(rng, 40), rqual(rng, 40)) for i in range(30)]
+    C["se_crlf"] = dict(fq1=fastq(base, eol="\r\n"), paired=SE)
+    C["se_cr_only"] = dict(fq1=fastq(base, eol="\r"), paired=SE)
+    C["se_no_final_newline"] = dict(fq1=fastq(base, final_eol=False), paired=SE)
+    C["se_crlf_no_final"] = dict(fq1=fastq(base, eol="\r\n", final_eol=False), paired=SE)
+    blank = fastq(base[:10]) + b"\n" + fastq(base[10:])
+    C["se_blank_line_after_record"] = dict(fq1=blank, paired=SE)       # "\n\n": one blank line is swallowed
+    blank2 = fastq(base[:10]) + b"\n\n" + fastq(base[10:])
+    C["se_two_blank_lines_truncate"] = dict(fq1=blank2, paired=SE)      # reader stops at the empty name line
+    C["se_partial_last_record"] = dict(fq1=fastq(base) + b"@partial\nACGT\n", paired=SE)
+    C["se_single_read"] = dict(fq1=fastq(base[:1]), paired=SE)
+    r2 = [rec(illumina(i, mate=2), rseq(rng, 40), rqual(rng, 40)) for i in range(30)]
+    C["pe_r2_no_final_newline"] = dict(fq1=fastq(base), fq2=fastq(r2, final_eol=False), paired=PE2)
+    C["pe_r1_no_final_newline"] = dict(fq1=fastq(base, final_eol=False), fq2=fastq(r2), paired=PE2)
+    C["pe_r2_shorter_file"] = dict(fq1=fastq(base), fq2=fastq(r2[:20]), paired=PE2)
+
+    # --- name parsing quirks (src/fastqmeta.cpp:22-80) ---
+    names = [
+        "@A:B:C:4:55:66:77 1:N:0:X", "@A:B:C:D:E rest of it", "@A:B:C:1:2:3:4:5:6 tail", "@A:B:C:1:2:3:4", "@A:B:C:1:2:3",
+        "@noColonsAtAll", "@ leading space", "@A:B:C:007:0012:+33:-4 x", "@A:B:C:300:70000:99999999999:4294967299 big",
+        "@A:B:C:1:2: 3:\t4 ws", "@A:B:C:::: empty", "@A:B:C:1:2:3:4\ttab 1:N", "@A:B:C:1x:2y:3z:4w q", "@a b:c:d:e:f:g:h",
+        "@A:B:C:1:2:3 onlysix:colons", "@A:B:C:12:1101:2047:2048 1:N:0:ACGT+TTGA", "@:::::::", "@A:B:C:1:2:3:9223372036854775808 of",
+    ]
+    recs = [rec(n, rseq(rng, 30), rqual(rng, 30)) for n in names]
+    C["se_name_quirks"] = dict(fq1=fastq(recs), paired=SE)
+    # each quirk name alone decides hasLaneTileXY for its own file
+    for j, n in enumerate(names):
+        C["se_name_quirk_%02d" % j] = dict(fq1=fastq([rec(n, rseq(rng, 20), rqual(rng, 20)) for _ in range(3)]), paired=SE)
+    mixed = [rec(illumina(i), rseq(rng, 30), rqual(rng, 30)) for i in range(10)] + [rec("@V300012345L1C001R0010000005/1 desc", rseq(rng, 30), rqual(rng, 30))]
+    C["se_mixed_illumina_then_bgi"] = dict(fq1=fastq(mixed), paired=SE)
+    C["se_mixed_bgi_then_illumina"] = dict(fq1=fastq(mixed[::-1]), paired=SE)
+    longname = "@" + "L" * 300 + ":1:2:3:4:5:6 tail"
+    C["se_name_over_255"] = dict(fq1=fastq([rec(longname, rseq(rng, 20), rqual(rng, 20)), rec(illumina(1), rseq(rng, 20), rqual(rng, 20))]), paired=SE)
+    strands = [rec(illumina(i), rseq(rng, 25), rqual(rng, 25), strand=("+" if i % 3 else "+" + illumina(i)[1:])) for i in range(12)]
+    C["se_strand_varies"] = dict(fq1=fastq(strands), paired=SE)
+    C["se_name1_varies"] = dict(fq1=fastq([rec(illumina(i).replace("A00250", "A0025%d" % (i % 3)) if i % 2 else illumina(i).replace("A00250", "AX"), rseq(rng, 25), rqual(rng, 25)) for i in range(12)]), paired=SE)
+    C["se_lane_tile_vary"] = dict(fq1=fastq([rec(illumina(i, lane=1 + i % 3, tile=1101 + i % 5), rseq(rng, 25), rqual(rng, 25)) for i in range(40)]), paired=SE)
+    C["se_name2_varies"] = dict(fq1=fastq([rec(illumina(i, idx="ACGT" if i % 4 else "TTTTTT"), rseq(rng, 25), rqual(rng, 25)) for i in range(20)]), paired=SE)
+
+    # --- coordinates (src/rfqcodec.cpp:1262-1330) ---
+    xs = [1000] * 40 + [1001, 1065, 1130, 1130, 40000, 7, 7, 7, 2097151, 32767, 32768, 32832, 32833] + [5] * 70 + [6]
+    C["se_coord_patterns"] = dict(fq1=fastq([rec(illumina(i, x=x, y=(i * 977) % 50000), rseq(rng, 20), rqual(rng, 20)) for i, x in enumerate(xs)]), paired=SE)
+    C["se_coord_too_large"] = dict(fq1=fastq([rec(illumina(0, x=2097152), rseq(rng, 20), rqual(rng, 20))]), paired=SE)
+
+    # --- read lengths ---
+    C["se_varlen"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 5 + (i * 37) % 120), "F" * (5 + (i * 37) % 120)) for i in range(60)]), paired=SE)
+    C["se_len_over_255"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 200 + 100 * (i % 3)), rqual(rng, 200 + 100 * (i % 3))) for i in range(9)]), paired=SE)
+    C["se_len_over_65535"] = dict(fq1=fastq([rec(illumina(0), rseq(rng, 66000), rqual(rng, 66000)), rec(illumina(1), rseq(rng, 100), rqual(rng, 100))]), paired=SE)
+
+    # --- bases / N rules (src/rfqheader.cpp:130-237) ---
+    def with_n(s, q, positions, nq="#"):
+        s = list(s); q = list(q)
+        for p in positions:
+            s[p] = "N"; q[p] = nq
+        return "".join(s), "".join(q)
+    many_n = []
+    for i in range(60):
+        s, q = with_n(rseq(rng, 50), rqual(rng, 50), [3, 17, 40])
+        many_n.append(rec(illumina(i), s, q))
+    C["se_implied_n_path"] = dict(fq1=fastq(many_n), paired=SE)                 # >=100 N, all '#': mNBaseQual stays '#'
+    mn2 = list(many_n); s, q = with_n(rseq(rng, 50), rqual(rng, 50), [5], nq=",")
+    mn2[30] = rec(illumina(30), s, q)
+    C["se_n_two_quals"] = dict(fq1=fastq(mn2), paired=SE)                        # second N quality -> ENCODE_N_POS
+    mn3 = list(many_n); mn3[40] = rec(illumina(40), "ACGT" * 12 + "AC", "F" * 20 + "#" + "F" * 29)
+    C["se_nqual_on_non_n_after_first_n"] = dict(fq1=fastq(mn3), paired=SE)
+    mn4 = [rec(illumina(0), "ACGT" * 12 + "AC", "#" * 50)] + many_n
+    C["se_nqual_on_non_n_before_first_n"] = dict(fq1=fastq(mn4), paired=SE)      # not detected by the reference: stays implied-N
+    C["se_all_n_reads"] = dict(fq1=fastq([rec(illumina(i), "N" * 40, "#" * 40) for i in range(5)]), paired=SE)
+    C["se_lowercase_error"] = dict(fq1=fastq([rec(illumina(0), "ACGTacgtACGT", "FFFFFFFFFFFF")]), paired=SE)
+    C["se_lowercase_g_error"] = dict(fq1=fastq([rec(illumina(0), "ACGTgACGT", "FFFFFFFFF")]), paired=SE)
+    C["se_iupac_error"] = dict(fq1=fastq([rec(illumina(0), "ACGTRYACGT", "FFFFFFFFFF")]), paired=SE)
+
+    # --- quality tables ---
+    q70 = "".join(chr(33 + i) for i in range(70))
+    C["se_70_quality_values"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 70), q70[i % 7:] + q70[: i % 7]) for i in range(40)]), paired=SE)   # DONT_ENCODE_QUAL
+    q63 = "".join(chr(33 + i) for i in range(63))
+    C["se_63_quality_values"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 63), q63[i % 5:] + q63[: i % 5]) for i in range(40)]), paired=SE)
+    q64 = "".join(chr(33 + i) for i in range(64))
+    C["se_64_quality_values"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 64), q64) for i in range(10)]), paired=SE)
+    C["se_one_quality_value"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 30), "I" * 30) for i in range(10)]), paired=SE)
+    C["se_tie_major"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 30), "I" * 15 + "5" * 15) for i in range(10)]), paired=SE)
+    # position-coder patterns: matches at 0,1,2; runs > 32; gaps > 128 and > 16384
+    big = ["F"] * 40000
+    for p in [0, 1, 2, 3, 203, 204] + list(range(300, 340)) + [20300] + list(range(25000, 25100)) + [39999]:
+        big[p] = ","
+    for p in [1, 5, 6, 7, 8, 30000, 30001]:
+        big[p] = ":" if big[p] == "F" else big[p]
+    bigq = "".join(big)
+    C["se_pos_coder_patterns"] = dict(fq1=fastq([rec(illumina(i), rseq(rng, 4000), bigq[i * 4000:(i + 1) * 4000]) for i in range(10)]), paired=SE)
+    C["se_qual_starts_with_normal_run"] = dict(fq1=fastq([rec(illumina(0), rseq(rng, 80), "," * 40 + "F" * 40), rec(illumina(1), rseq(rng, 80), "F" * 80), rec(illumina(2), rseq(rng, 80), "F" * 80)]), paired=SE)
+
+    # --- paired-end: overlap / interleave rules (src/rfqcodec.cpp:59-145, 212-287, 371-403, 1391-1438) ---
+    def pair(i, ins, rl=60, n_at=None, name2a="1:N:0:ACGT", name2b="2:N:0:ACGT", xb=None):
+        frag = rseq(rng, max(ins, 1))
+        s1 = (frag[:rl] + rseq(rng, rl))[:rl]
+        s2 = (comp(frag)[:rl] + rseq(rng, rl))[:rl]
+        q1, q2 = rqual(rng, rl), rqual(rng, rl)
+        if n_at is not None:
+            s1, q1 = with_n(s1, q1, [n_at])
+        n1 = illumina(i).rsplit(" ", 1)[0] + " " + name2a
+        n2 = illumina(i, x=xb).rsplit(" ", 1)[0] + " " + name2b
+        return rec(n1, s1, q1), rec(n2, s2, q2)
+    pe = [pair(i, ins) for i, ins in enumerate([100, 108, 109, 120, 60, 61, 40, 30, 20, 12, 11, 200, 70, 119, 118, 90] * 3)]
+    C["pe_overlap_sweep"] = dict(fq1=fastq([a for a, _ in pe]), fq2=fastq([b for _, b in pe]), paired=PE2)
+    C["pe_overlap_sweep_interleaved_in"] = dict(fq1=fastq([r for ab in pe for r in ab]), paired=PEI)
+    pe_n = [pair(i, 80, n_at=50) for i in range(20)]
+    C["pe_overlap_with_n"] = dict(fq1=fastq([a for a, _ in pe_n]), fq2=fastq([b for _, b in pe_n]), paired=PE2)
+    pe_bad = [pair(i, 90, name2b="2:Y:1:ACGT") for i in range(10)]
+    C["pe_name2_two_diffs"] = dict(fq1=fastq([a for a, _ in pe_bad]), fq2=fastq([b for _, b in pe_bad]), paired=PE2)          # no interleave support
+    pe_same = [pair(i, 90, name2b="1:N:0:ACGT") for i in range(10)]
+    C["pe_name2_identical"] = dict(fq1=fastq([a for a, _ in pe_same]), fq2=fastq([b for _, b in pe_same]), paired=PE2)        # diff char '\0'
+    flip = [pair(i, 90) for i in range(12)]
+    flip[7] = pair(7, 90, name2b="2:N:0:TTTT")
+    C["pe_interleave_flips_mid_chunk_name2"] = dict(fq1=fastq([a for a, _ in flip]), fq2=fastq([b for _, b in flip]), paired=PE2)   # Q12
+    flip2 = [pair(i, 90) for i in range(12)]
+    flip2[5] = pair(5, 90, xb=4242)
+    C["pe_interleave_flips_mid_chunk_x"] = dict(fq1=fastq([a for a, _ in flip2]), fq2=fastq([b for _, b in flip2]), paired=PE2)
+    flip3 = [pair(i, 90, name2a="1:N:0:ACGT" if i % 5 else "1:N:0:GGGG", name2b="2:N:0:ACGT" if i % 5 else "2:N:0:GGGG") for i in range(12)]
+    flip3[8] = pair(8, 90, name2b="2:N:0:CCCC")
+    C["pe_interleave_flip_with_name2_variation"] = dict(fq1=fastq([a for a, _ in flip3]), fq2=fastq([b for _, b in flip3]), paired=PE2)
+    short = []
+    for i, (l1, l2) in enumerate([(30, 30), (11, 30), (30, 11), (12, 12), (5, 5), (40, 25), (25, 40)] * 2):
+        frag = rseq(rng, 45)
+        short.append((rec(illumina(i), frag[:l1], rqual(rng, l1)), rec(illumina(i, mate=2), comp(frag)[:l2], rqual(rng, l2))))
+    C["pe_unequal_lengths"] = dict(fq1=fastq([a for a, _ in short]), fq2=fastq([b for _, b in short]), paired=PE2)
+    bgi = [(rec("@V300012345L1C001R00100%05d/1" % i, rseq(rng, 50), rqual(rng, 50, "%&'()*+,-./0123")),
+            rec("@V300012345L1C001R00100%05d/2" % i, rseq(rng, 50), rqual(rng, 50, "%&'()*+,-./0123"))) for i in range(25)]
+    C["pe_bgi_names"] = dict(fq1=fastq([a for a, _ in bgi]), fq2=fastq([b for _, b in bgi]), paired=PE2)
+    # long homopolymer pairs: many candidate overlaps, forward-first / smallest-o rule
+    homo = [(rec(illumina(i), "A" * 50, "F" * 50), rec(illumina(i, mate=2), "T" * 50, "F" * 50)) for i in range(4)]
+    homo += [(rec(illumina(9), "ACGTACGTACGTACGTAAAA", "F" * 20), rec(illumina(9, mate=2), comp("ACGTACGTACGTAAAATTTT"), "F" * 20))]   # D.4: overlap 16
+    C["pe_homopolymer_overlap"] = dict(fq1=fastq([a for a, _ in homo]), fq2=fastq([b for _, b in homo]), paired=PE2)
+    return C
+
+
+CASES = build_cases()
+
+
+def pos_buffers():
+    """(buffer, q) inputs for the position-coder known-answer vectors in unit.json (SURVEY.md D.3 first)."""
+    rng = random.Random(777001)
+    d3 = bytearray(b"F" * 40000)
+    for p in [0, 1, 2, 3, 203, 204] + list(range(300, 340)) + [20300]:
+        d3[p] = ord(",")
+    sets = [(bytes(d3), ord(","))]
+    for dens in (2, 10, 50, 300, 5000):
+        sets.append((bytes(rng.choice(b",F") if rng.randrange(dens) == 0 else ord("F") for _ in range(30000)), ord(",")))
+    sets += [(b",,,,,F", ord(",")), (b"F,,,,,", ord(",")), (b",", ord(",")), (b"F", ord(",")), (b"," * 100, ord(",")),
+             (b"F" + b"," * 100, ord(",")), (b"FF" + b"," * 64 + b"F", ord(",")), (b"NNACGTNNNN" * 7, ord("N"))]
+    return sets
