@@ -1,0 +1,136 @@
+/*
+ * rfq_hip.h — C-ABI of librfq_hip.so, the MI355X (gfx950) engine for repaq's RfqCodec path.
+ *
+ * The reference (OpenGene/repaq v0.5.1) has no FFI: its seam is the C++ class RfqCodec
+ * (src/rfqcodec.h:17-43) driven by Repaq::compress / compressPE / decompress / decompressPE (src/repaq.cpp:262-762).  A GPU engine cannot take
+ * vector<Read*>, so each entry point below replaces one RfqCodec/Repaq call at BATCH granularity over raw bytes:
+ * FASTQ text in HBM -> .rfq chunk images in HBM and back, bit-identical to what the reference writes.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types; every d_* pointer is DEVICE memory (hipMalloc or a torch CUDA
+ *     tensor's data_ptr()), 16-byte aligned; h_* pointers are host memory.
+ *   - return 0 (RFQ_OK) or a negative RFQ_E_* code; rfq_last_error(ctx) then holds the reference's error_exit text
+ *     (src/util.h:246-249) where the reference has one for the condition.
+ *   - one rfq_ctx per (host thread, GPU); distinct contexts may be used concurrently.  A context owns its workspace
+ *     and its result buffers; result pointers stay valid until the next call on the same context.
+ *   - there is NO CPU fallback: without a usable GPU rfq_create fails with RFQ_E_NO_DEVICE.
+ */
+#ifndef RFQ_HIP_H
+#define RFQ_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFQ_OK              0
+#define RFQ_E_NO_DEVICE    -1   /* no GPU / hip runtime error at create */
+#define RFQ_E_HIP          -2   /* a hip call failed (message has the hip error string) */
+#define RFQ_E_ARG          -3   /* bad argument */
+#define RFQ_E_TEXT         -4   /* FASTQ text the device reader does not handle yet: '\r', empty lines (src/fastqreader.cpp:94-196 quirks) */
+#define RFQ_E_DATA         -5   /* the reference would error_exit on this input (message = its text) */
+#define RFQ_E_FORMAT       -6   /* not a valid .rfq / different ALGORITHM_VER (src/rfqheader.cpp:23-25,40-42) */
+#define RFQ_E_UNPINNED     -7   /* input is in a reference-UB zone: refused rather than guessed */
+#define RFQ_E_NOSPACE      -8   /* caller-provided output buffer too small (required size is reported) */
+#define RFQ_E_STATE        -9   /* call order (e.g. encode continuation without a header) */
+
+/* how the FASTQ streams pair up — Repaq::run, src/repaq.cpp:12-20 */
+#define RFQ_SE             0    /* -i           : compress()    */
+#define RFQ_PE_TWO_FILES   1    /* -i/-I        : compressPE()  */
+#define RFQ_PE_INTERLEAVED 2    /* --interleaved_in             */
+
+#define RFQ_HEADER_MAX     (17 + 255)
+
+typedef struct rfq_ctx rfq_ctx;
+
+/* RfqCodec::RfqCodec / ~RfqCodec (src/rfqcodec.cpp:9-14).  device_id: HIP ordinal. */
+int         rfq_create(rfq_ctx** out, int device_id);
+void        rfq_destroy(rfq_ctx* ctx);
+const char* rfq_last_error(const rfq_ctx* ctx);
+/* all work of this context is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream) */
+int         rfq_set_stream(rfq_ctx* ctx, void* hip_stream);
+
+/* RfqCodec::setHeader (src/rfqcodec.cpp:16-18) from the on-disk header bytes (RfqHeader::read, src/rfqheader.cpp:19-43).
+ * mSupportInterleaved is not stored on disk; it is re-derived from BIT_ENCODE_PE_BY_OVERLAP, which makeHeader sets
+ * exactly when it is true (src/rfqcodec.cpp:117-122). */
+int rfq_set_header(rfq_ctx* ctx, const uint8_t* h_header, size_t header_len);
+/* the header currently set / made: RfqHeader::write (src/rfqheader.cpp:84-97) */
+int rfq_get_header(rfq_ctx* ctx, uint8_t* h_out /* >= RFQ_HEADER_MAX */, size_t* header_len);
+void rfq_clear_header(rfq_ctx* ctx);
+
+typedef struct {
+    const uint8_t* d_fq1; size_t n1;      /* stream 1 (R1, or the only / interleaved stream)                          */
+    const uint8_t* d_fq2; size_t n2;      /* stream 2 (R2) for RFQ_PE_TWO_FILES, else NULL/0                          */
+    int32_t  paired;                      /* RFQ_SE / RFQ_PE_TWO_FILES / RFQ_PE_INTERLEAVED                            */
+    uint32_t chunk_bases;                 /* Options::chunkSize = max(100,-k)*1000 (src/main.cpp:69); any value >= 1   */
+    int32_t  final;                       /* 1: this is the end of the input: also emit the tail chunk
+                                             (src/repaq.cpp:590-624).  0: stop after the last full chunk and report how
+                                             many bytes were consumed so the caller can carry the rest into the next
+                                             batch.                                                                   */
+    int32_t  emit_header;                 /* 1: prefix the result with the file header (first batch of a file)        */
+    /* line-break bits (src/repaq.cpp:571-572,683-692): a chunk whose last record ends at absolute
+     * file offset >= nolb_from{1,2} gets BIT_HAS_NO_LINE_BREAK_AT_END{,_R2}.  The caller (the Repaq::compress counterpart)
+     * passes file_off = offset of this batch in the file and nolb_from = start of the final 1 MiB reader block when the
+     * file lacks a trailing '\n', or UINT64_MAX.  */
+    uint64_t file_off1, file_off2;
+    uint64_t nolb_from1, nolb_from2;
+    uint8_t* d_out; size_t out_cap;       /* optional caller buffer for the .rfq bytes; NULL = context-owned result    */
+} rfq_encode_args;
+
+typedef struct {
+    const uint8_t* d_rfq;                 /* device pointer to [header?][chunk][chunk]...                              */
+    size_t   rfq_len;
+    uint32_t n_chunks;
+    uint64_t n_reads;                     /* reads encoded (PE: both mates counted, like RfqChunk::mReads)            */
+    uint64_t n_bases;
+    size_t   consumed1, consumed2;        /* bytes of each stream covered by the emitted chunks                        */
+    const uint64_t* h_chunk_off;          /* host array [n_chunks+1]: byte offset of each chunk image in d_rfq         */
+} rfq_encode_result;
+
+/* RfqCodec::makeHeader (first call without a header; src/rfqcodec.cpp:20-145) + RfqCodec::encodeChunk + RfqChunk::write
+ * for every chunk of the batch (src/rfqcodec.cpp:147-586, src/rfqchunk.cpp:230-311), with the chunk cut rule of
+ * Repaq::compress (src/repaq.cpp:546-553): cut after the read that brings the running base count to >= chunk_bases. */
+int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_encode_result* res);
+
+typedef struct {
+    const uint8_t* d_rfq; size_t n;       /* .rfq bytes in HBM                                                          */
+    int32_t  has_header;                  /* 1: the image starts with the file header (it is parsed and set)           */
+    int32_t  split_pe;                    /* 1: decompressPE (even reads -> out1, odd -> out2; src/repaq.cpp:367-373);
+                                             0: decompress (everything to out1 in chunk order; Q14)                    */
+    int32_t  final;                       /* 1: the image ends the file: apply the NO_LINE_BREAK bits of the last chunk
+                                             (src/repaq.cpp:301-328,375-413)                                           */
+    int32_t  reserved;
+    uint8_t* d_out1; size_t cap1;         /* optional caller buffers; NULL = context-owned results                     */
+    uint8_t* d_out2; size_t cap2;
+} rfq_decode_args;
+
+typedef struct {
+    const uint8_t* d_fq1; size_t n1;
+    const uint8_t* d_fq2; size_t n2;
+    uint32_t n_chunks;
+    uint64_t n_reads, n_bases;
+    size_t   consumed;                    /* bytes of the image covered by whole chunks                                */
+} rfq_decode_result;
+
+/* RfqChunk::read + RfqCodec::decodeChunk + Read::toString for every chunk of the image
+ * (src/rfqchunk.cpp:161-228, src/rfqcodec.cpp:826-1260, src/read.cpp:170-172). */
+int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* args, rfq_decode_result* res);
+
+/* stage timings of the last batch call, in milliseconds, measured with HIP events on the context's stream.
+ * names[i] is a static string; returns the number of stages written (<= cap). */
+int rfq_last_timings(const rfq_ctx* ctx, const char** names, float* ms, int cap);
+
+/* device-memory helpers for hosts that do not bring their own allocator (the C++ driver, ctypes tests): thin wrappers
+ * over hipMalloc / hipFree / hipMemcpy on the context's device.  Buffers from rfq_dev_malloc are 256-byte aligned. */
+int rfq_dev_malloc(rfq_ctx* ctx, void** d_ptr, size_t n);
+int rfq_dev_free(rfq_ctx* ctx, void* d_ptr);
+int rfq_copy_h2d(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n);
+int rfq_copy_d2h(rfq_ctx* ctx, void* h_dst, const void* d_src, size_t n);
+
+/* library / build info: "rfq_hip <version> gfx950" (or "... simt-emulation" for the test build) */
+const char* rfq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

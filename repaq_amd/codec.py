@@ -1,0 +1,120 @@
+"""Host-side mirror of the reference's RfqCodec seam (src/rfqcodec.h:17-43) over the C-ABI.
+
+    reference                                   here
+    RfqCodec codec;                             codec = RfqCodec(device=0)
+    codec.setHeader(h)                          codec.setHeader(header_bytes)
+    h = codec.makeHeader(reads)  (chunk 0)      implicit in the first encode (header from the first chunk), codec.header()
+    chunk = codec.encodeChunk(reads); write     codec.encode(d_fq1, n1, ...) -> EncodeResult (all chunks of the batch)
+    reads = codec.decodeChunk(chunk)            codec.decode(d_rfq, n, ...)  -> DecodeResult (FASTQ text of all chunks)
+
+Pointers are device pointers (e.g. torch.uint8 CUDA tensors' data_ptr()).  The *_bytes helpers move host bytes through
+rfq_dev_malloc / rfq_copy_* for tests and small tools."""
+import ctypes as C
+
+from . import _capi as A
+from ._capi import RfqError, SE, PE_TWO_FILES, PE_INTERLEAVED, U64_MAX  # noqa: F401
+
+
+class RfqCodec:
+    def __init__(self, device=0, library=None):
+        self._L = A.load(library)
+        h = C.c_void_p()
+        rc = self._L.rfq_create(C.byref(h), device)
+        if rc != A.RFQ_OK:
+            raise RfqError(rc, "rfq_create(device=%d) failed: no usable MI355X / HIP device (there is no CPU fallback)" % device)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rfq_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != A.RFQ_OK:
+            raise RfqError(rc, self._L.rfq_last_error(self._h).decode("latin-1"))
+
+    def version(self):
+        return self._L.rfq_version().decode()
+
+    def set_stream(self, stream_ptr):
+        self._check(self._L.rfq_set_stream(self._h, stream_ptr))
+
+    # --- RfqCodec::setHeader / header accessors
+    def setHeader(self, header_bytes: bytes):
+        self._check(self._L.rfq_set_header(self._h, header_bytes, len(header_bytes)))
+
+    def clearHeader(self):
+        self._L.rfq_clear_header(self._h)
+
+    def header(self) -> bytes:
+        buf = C.create_string_buffer(A.HEADER_MAX); n = C.c_size_t()
+        self._check(self._L.rfq_get_header(self._h, buf, C.byref(n)))
+        return buf.raw[: n.value]
+
+    # --- RfqCodec::encodeChunk for every chunk of a batch
+    def encode(self, d_fq1, n1, d_fq2=None, n2=0, paired=SE, chunk_bases=1_000_000, final=True, emit_header=True,
+               file_off1=0, file_off2=0, nolb_from1=U64_MAX, nolb_from2=U64_MAX, d_out=None, out_cap=0):
+        a = A.EncodeArgs(d_fq1, n1, d_fq2, n2, paired, chunk_bases, 1 if final else 0, 1 if emit_header else 0,
+                         file_off1, file_off2, nolb_from1, nolb_from2, d_out, out_cap)
+        r = A.EncodeResult()
+        self._check(self._L.rfq_encode_batch(self._h, C.byref(a), C.byref(r)))
+        return r
+
+    # --- RfqCodec::decodeChunk for every chunk of an image
+    def decode(self, d_rfq, n, has_header=True, split_pe=False, final=True, d_out1=None, cap1=0, d_out2=None, cap2=0):
+        a = A.DecodeArgs(d_rfq, n, 1 if has_header else 0, 1 if split_pe else 0, 1 if final else 0, 0, d_out1, cap1, d_out2, cap2)
+        r = A.DecodeResult()
+        self._check(self._L.rfq_decode_batch(self._h, C.byref(a), C.byref(r)))
+        return r
+
+    def timings(self):
+        names = (C.c_char_p * 32)(); ms = (C.c_float * 32)()
+        n = self._L.rfq_last_timings(self._h, names, ms, 32)
+        return [(names[i].decode(), ms[i]) for i in range(n)]
+
+    # --- host-bytes conveniences (tests, small tools)
+    def dev_put(self, data: bytes):
+        p = C.c_void_p()
+        self._check(self._L.rfq_dev_malloc(self._h, C.byref(p), max(len(data), 1) + 64))
+        self._check(self._L.rfq_copy_h2d(self._h, p, data, len(data)))
+        return p
+
+    def dev_get(self, d_ptr, n) -> bytes:
+        buf = C.create_string_buffer(max(n, 1))
+        self._check(self._L.rfq_copy_d2h(self._h, buf, d_ptr, n))
+        return buf.raw[:n]
+
+    def dev_free(self, p):
+        self._L.rfq_dev_free(self._h, p)
+
+    def encode_bytes(self, fq1: bytes, fq2: bytes = b"", paired=SE, chunk_bases=1_000_000, **kw) -> bytes:
+        d1 = self.dev_put(fq1); d2 = self.dev_put(fq2) if paired == PE_TWO_FILES else None
+        try:
+            r = self.encode(d1, len(fq1), d2, len(fq2) if d2 else 0, paired, chunk_bases, **kw)
+            return self.dev_get(r.d_rfq, r.rfq_len) if r.rfq_len else b""
+        finally:
+            self.dev_free(d1)
+            if d2:
+                self.dev_free(d2)
+
+    def decode_bytes(self, rfq: bytes, split_pe=False, **kw):
+        d = self.dev_put(rfq)
+        try:
+            r = self.decode(d, len(rfq), split_pe=split_pe, **kw)
+            a = self.dev_get(r.d_fq1, r.n1) if r.n1 else b""
+            b = self.dev_get(r.d_fq2, r.n2) if (split_pe and r.n2) else b""
+            return (a, b) if split_pe else a
+        finally:
+            self.dev_free(d)
+
+
+def nolb_threshold(file_size: int, ends_with_newline: bool) -> int:
+    """Offset from which chunks carry BIT_HAS_NO_LINE_BREAK_AT_END: the start of the reference reader's final 1 MiB block
+    when the file lacks a trailing newline (src/fastqreader.cpp:31-46), else 'never'."""
+    if ends_with_newline or file_size == 0:
+        return U64_MAX
+    if file_size % (1 << 20) == 0:
+        return 0   # reference reads mBuf[-1] (UB); observed: the flag ends up set on chunks emitted after the last block
+    return ((file_size - 1) >> 20) << 20

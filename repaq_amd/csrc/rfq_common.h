@@ -1,0 +1,153 @@
+// rfq_common.h — shared definitions for the gfx950 RFQ engine: on-disk flag bits, the device-side header/chunk
+// descriptors, wave64 primitives and a small multi-block scan.  Wave size is 64 everywhere (CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// ---- on-disk bits (reference src/rfqheader.h:24-42, src/rfqchunk.h:25-50) ----
+#define H_LANE        (1u << 0)
+#define H_TILE        (1u << 1)
+#define H_X           (1u << 2)
+#define H_Y           (1u << 3)
+#define H_NAME2       (1u << 4)
+#define H_PAIRED      (1u << 5)
+#define H_PE_OVERLAP  (1u << 6)
+#define H_QUAL_BY_COL (1u << 7)
+#define H_DONT_QUAL   (1u << 8)
+#define H_N_POS       (1u << 9)
+#define C_READ_LEN_SAME   (1u << 0)
+#define C_NAME1_LEN_SAME  (1u << 1)
+#define C_NAME2_LEN_SAME  (1u << 2)
+#define C_STRAND_LEN_SAME (1u << 3)
+#define C_LANE_SAME       (1u << 4)
+#define C_TILE_SAME       (1u << 5)
+#define C_NAME1_SAME      (1u << 6)
+#define C_NAME2_SAME      (1u << 7)
+#define C_STRAND_SAME     (1u << 8)
+#define C_PE_INTERLEAVED  (1u << 9)
+#define C_NO_LB           (1u << 10)
+#define C_NO_LB_R2        (1u << 11)
+
+#define WAVE 64
+#define NL_BLOCK_BYTES 16384u        // one workgroup of the newline pass covers 16 KiB = 256 lanes x 64 B
+#define MAX_STREAMS 66               // <= 64 normal quality values + N positions + exceptions
+
+// device error bits accumulated in DevStatus::err
+#define DE_HAS_CR          (1u << 0)  // '\r' in the text
+#define DE_EMPTY_LINE      (1u << 1)  // an empty line inside the record range (reference truncates there)
+#define DE_QUAL_SHORT      (1u << 2)  // quality line shorter than sequence line (reference reads past the string)
+#define DE_BAD_QUAL        (1u << 3)  // quality byte >= 128 in chunk 0 ("bad quality value")
+#define DE_BAD_BASE        (1u << 4)  // non-ACGTN base in chunk 0
+#define DE_COORD_RANGE     (1u << 5)  // X/Y >= 2^21
+#define DE_QUAL_OVERFLOW   (1u << 6)  // quality payload > 1.5 x bases: overflows the reference's scratch (UB)
+#define DE_NO_QUAL_BINS    (1u << 7)  // "bad quality string"
+#define DE_CORRUPT         (1u << 8)  // decode: inconsistent chunk image
+
+// Device-resident file header + derived tables (RfqHeader, src/rfqheader.h:44-108)
+struct DevHeader {
+    uint8_t  bytes[17 + 255];   // on-disk image (RfqHeader::write)
+    uint32_t len;               // 17 + qual_bins
+    uint32_t flags;             // mFlags
+    uint32_t read_len_bytes;
+    uint32_t support_interleaved;
+    uint32_t name2_diff_pos, name2_diff_char;
+    uint32_t n_base_qual;       // 0..255 (0xFF == -1)
+    int32_t  overlap_shift;     // -24
+    uint32_t major;             // majorQual()
+    uint32_t n_normal;          // normalQualBins()
+    uint8_t  normal[256];       // normalQualBuf()
+    uint8_t  stream_of[256];    // quality byte -> index into normal[] (0xFF = none)
+    uint8_t  is_exception[256]; // 1: neither major nor a normal value -> 5-byte exception record
+    uint32_t valid;
+};
+
+// One record of device status shared by all kernels of a batch (zeroed per call)
+struct DevStatus {
+    uint32_t err;               // DE_* bits
+    uint32_t err_read;          // read index (interleaved order) tied to the first data error, or value for coords
+    uint64_t err_key;           // ordering key for "first error"
+    uint64_t coord_key;         // (chunk << 34 | axis << 33 | index) of the first out-of-range X/Y, ~0 if none
+    uint64_t total_scratch;     // bytes of stream scratch needed
+    uint64_t image_bound;       // upper bound of all chunk images (from stream capacities)
+    uint32_t n_chunks;
+    uint32_t max_chunk_reads;
+    uint32_t max_chunk_bases;
+    uint32_t n_units_used;      // units (reads or pairs) covered by emitted chunks
+    uint64_t total_image;       // bytes of all chunk images
+    uint64_t total_bases;
+};
+
+struct U4 { uint32_t a, b, c, d; };
+__device__ __host__ __forceinline__ U4 operator+(const U4& x, const U4& y) { U4 r; r.a = x.a + y.a; r.b = x.b + y.b; r.c = x.c + y.c; r.d = x.d + y.d; return r; }
+__device__ __host__ __forceinline__ U4 operator-(const U4& x, const U4& y) { U4 r; r.a = x.a - y.a; r.b = x.b - y.b; r.c = x.c - y.c; r.d = x.d - y.d; return r; }
+
+// ---------------------------------------------------------------- wave64 primitives
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+template <class T> __device__ __forceinline__ T wave_incl_sum(T v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { T t = __shfl_up(v, (unsigned)d); if (l >= d) v = t + v; }
+    return v;
+}
+__device__ __forceinline__ U4 wave_incl_sum(U4 v) {
+    v.a = wave_incl_sum(v.a); v.b = wave_incl_sum(v.b); v.c = wave_incl_sum(v.c); v.d = wave_incl_sum(v.d);
+    return v;
+}
+template <class T> __device__ __forceinline__ T wave_incl_max(T v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { T t = __shfl_up(v, (unsigned)d); if (l >= d && t > v) v = t; }
+    return v;
+}
+template <class T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+template <class T> __device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { T t = __shfl_xor(v, d); if (t < v) v = t; }
+    return v;
+}
+template <class T> __device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { T t = __shfl_xor(v, d); if (t > v) v = t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_and(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v &= __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d);
+    return v;
+}
+
+// Exclusive prefix sum over a workgroup of NT threads (NT multiple of 64, <= 1024); returns the exclusive prefix of
+// this thread and writes the workgroup total to *total.  Every thread of the workgroup must call it.
+template <class T> __device__ __forceinline__ T block_excl_sum(T v, T* total) {
+    __shared__ T wsum[16];
+    __shared__ T wtot;
+    const int l = lane_id(), w = wave_id(), nw = (int)(blockDim.x >> 6);
+    T inc = wave_incl_sum(v);
+    if (l == 63) wsum[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { T run = T(); for (int i = 0; i < nw; i++) { T t = wsum[i]; wsum[i] = run; run = run + t; } wtot = run; }
+    __syncthreads();
+    T res = (wsum[w] + inc) - v;
+    if (total) *total = wtot;
+    __syncthreads();
+    return res;
+}
+
+
+// little-endian stores to unaligned byte addresses
+__device__ __forceinline__ void st_u16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+__device__ __forceinline__ void st_u32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }

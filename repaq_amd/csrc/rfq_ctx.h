@@ -1,0 +1,108 @@
+// rfq_ctx.h — host-side context: growable device buffers, error plumbing, stage timers, scan launcher.
+#pragma once
+#include "rfq_common.h"
+#include "../../include/rfq_hip.h"
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdarg>
+
+struct DBuf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 4 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want; return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct StageTimer {
+    struct Stage { const char* name; hipEvent_t a, b; };
+    std::vector<Stage> stages; size_t used = 0; std::vector<float> ms; std::vector<const char*> names;
+    void reset() { used = 0; }
+    void begin(const char* name, hipStream_t s) {
+        if (used == stages.size()) { Stage st; st.name = name; (void)hipEventCreate(&st.a); (void)hipEventCreate(&st.b); stages.push_back(st); }
+        stages[used].name = name; (void)hipEventRecord(stages[used].a, s);
+    }
+    void end(hipStream_t s) { (void)hipEventRecord(stages[used].b, s); used++; }
+    void collect() {   // stream must be synchronised
+        ms.assign(used, 0.f); names.assign(used, nullptr);
+        for (size_t i = 0; i < used; i++) { (void)hipEventElapsedTime(&ms[i], stages[i].a, stages[i].b); names[i] = stages[i].name; }
+    }
+    void destroy() { for (auto& s : stages) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); } stages.clear(); }
+};
+
+struct rfq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    std::string err;
+    // header
+    DBuf d_hdr;                 // DevHeader
+    DevHeader h_hdr; bool have_hdr = false;
+    DBuf d_status; DevStatus h_status;
+    // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
+    DBuf b[64];
+    DBuf out_img, out_fq1, out_fq2;
+    std::vector<uint64_t> chunk_off;
+    StageTimer timer;
+};
+
+static inline int rfq_fail(rfq_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return rfq_fail(ctx, RFQ_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+#define KCHK(ctx, what) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return rfq_fail(ctx, RFQ_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------- multi-block exclusive scan (3 launches)
+#define SCAN_TPB 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_TPB * SCAN_ITEMS)
+
+template <class T> __global__ void k_scan_reduce(const T* __restrict__ in, T* __restrict__ partial, uint64_t n) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T acc = T();
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) acc = acc + in[base + i];
+    T tot; (void)block_excl_sum<T>(acc, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+template <class T> __global__ void k_scan_partials(T* __restrict__ partial, uint32_t nb, T* __restrict__ grand) {
+    __shared__ T carry;
+    if (threadIdx.x == 0) carry = T();
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_TPB) {
+        uint32_t i = b0 + threadIdx.x;
+        T v = i < nb ? partial[i] : T();
+        T tot; T ex = block_excl_sum<T>(v, &tot);
+        T c = carry;
+        if (i < nb) partial[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && grand) *grand = carry;
+}
+// out[i] = exclusive prefix; out may alias in.  When out has n+1 entries pass write_total=1 to store the total at out[n].
+template <class T> __global__ void k_scan_apply(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ partial, uint64_t n, int write_total) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS]; T acc = T();
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = base + i < n ? in[base + i] : T(); acc = acc + v[i]; }
+    T tot; T ex = block_excl_sum<T>(acc, &tot);
+    T run = partial[blockIdx.x] + ex;
+    for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run = run + v[i]; }
+    if (write_total && base < n && base + SCAN_ITEMS >= n) out[n] = run;
+}
+// tmp must hold ceil(n / SCAN_TILE) + 1 elements of T
+template <class T> static inline void scan_exclusive(hipStream_t s, const T* in, T* out, uint64_t n, T* tmp, int write_total) {
+    if (n == 0) { if (write_total) (void)hipMemsetAsync(out, 0, sizeof(T), s); return; }
+    const uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, tmp, n);
+    hipLaunchKernelGGL((k_scan_partials<T>), dim3(1), dim3(SCAN_TPB), 0, s, tmp, nb, (T*)nullptr);
+    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, out, (const T*)tmp, n, write_total);
+}

@@ -1,0 +1,295 @@
+// rfq_encode.hip — host orchestration of the gfx950 FASTQ -> RFQ path (rfq_encode_batch of include/rfq_hip.h).
+// Replaces, per batch: Repaq::compress / compressPE chunking (src/repaq.cpp:530-762), RfqCodec::makeHeader
+// (src/rfqcodec.cpp:20-145), RfqCodec::encodeChunk (:147-586) and RfqChunk::write (src/rfqchunk.cpp:230-311).
+#include "rfq_ctx.h"
+#include "rfq_encode_kernels.h"
+#include <algorithm>
+#include <cstring>
+
+enum EncBuf {   // indices into rfq_ctx::b
+    B_BITMAP0 = 0, B_BITMAP1, B_BLK0, B_BLK1, B_LO0, B_LO1, B_SCANTMP,
+    B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
+    B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
+    B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_ENC_END
+};
+
+static int fetch_bytes(rfq_ctx* ctx, const uint8_t* d, size_t n, std::string& out) {
+    out.resize(n);
+    if (n) HIPCHK(ctx, hipMemcpy(&out[0], d, n, hipMemcpyDeviceToHost));
+    return RFQ_OK;
+}
+// text of line k of read g (host copy), for the reference's error messages
+static int fetch_line(rfq_ctx* ctx, const Text& T, uint32_t g, int k, std::string& out) {
+    int s = 0; uint32_t r = g; if (T.paired == 1) { s = (int)(g & 1u); r = g >> 1; }
+    uint32_t lo2[2];
+    HIPCHK(ctx, hipMemcpy(lo2, T.lo[s] + 4 * (size_t)r + k, 8, hipMemcpyDeviceToHost));
+    return fetch_bytes(ctx, T.fq[s] + lo2[0], lo2[1] - 1 - lo2[0], out);
+}
+
+// RfqHeader::read (src/rfqheader.cpp:19-43) + the derived tables, on device and mirrored on the host
+int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n) {
+    if (n < 17) return rfq_fail(c, RFQ_E_FORMAT, "Not a valid repaq file!");
+    if (h[8] != 2) return rfq_fail(c, RFQ_E_FORMAT, "The data is encoded by different version of repaq, please try repaq v%.5s. \nSee: https://github.com/OpenGene/repaq/releases", (const char*)h + 3);
+    const size_t len = 17u + h[16];
+    if (n < len) return rfq_fail(c, RFQ_E_FORMAT, "Not a valid repaq file!");
+    if (h[0] != 'R' || h[1] != 'F' || h[2] != 'Q') return rfq_fail(c, RFQ_E_FORMAT, "Not a valid repaq file!");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->d_hdr.ensure(sizeof(DevHeader)));
+    DevHeader tmp; memset(&tmp, 0, sizeof tmp); memcpy(tmp.bytes, h, len);
+    HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, &tmp, sizeof tmp, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_hdr_from_bytes, dim3(1), dim3(64), 0, c->stream, c->d_hdr.as<DevHeader>());
+    KCHK(c, "k_hdr_from_bytes");
+    HIPCHK(c, hipMemcpyAsync(&c->h_hdr, c->d_hdr.p, sizeof(DevHeader), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_hdr = true;
+    return RFQ_OK;
+}
+
+
+extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res) {
+    if (!ctx || !a || !res) return RFQ_E_ARG;
+    memset(res, 0, sizeof *res);
+    ctx->err.clear();
+    if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
+    if (a->chunk_bases == 0) return rfq_fail(ctx, RFQ_E_ARG, "chunk_bases must be >= 1");
+    const int nstreams = a->paired == RFQ_PE_TWO_FILES ? 2 : 1;
+    const uint8_t* fq[2] = { a->d_fq1, nstreams == 2 ? a->d_fq2 : nullptr };
+    const size_t nbytes[2] = { a->n1, nstreams == 2 ? a->n2 : 0 };
+    for (int s = 0; s < nstreams; s++) {
+        if (nbytes[s] >= 0xFFFFFFF0ull) return rfq_fail(ctx, RFQ_E_ARG, "a FASTQ stream of one batch must be < 4 GiB (got %zu bytes); split at record boundaries", nbytes[s]);
+        if (nbytes[s] && !fq[s]) return rfq_fail(ctx, RFQ_E_ARG, "null FASTQ pointer");
+        if (((uintptr_t)fq[s]) & 15u) return rfq_fail(ctx, RFQ_E_ARG, "FASTQ device pointers must be 16-byte aligned");
+    }
+    hipStream_t S = ctx->stream;
+    DBuf* B = ctx->b;
+    ctx->timer.reset();
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    // ---- status block
+    DevStatus hs; memset(&hs, 0, sizeof hs); hs.err_key = ~0ull; hs.coord_key = ~0ull;
+    HIPCHK(ctx, ctx->d_status.ensure(sizeof(DevStatus)));
+    DevStatus* dst = ctx->d_status.as<DevStatus>();
+    HIPCHK(ctx, hipMemcpyAsync(dst, &hs, sizeof hs, hipMemcpyHostToDevice, S));
+
+    // ---- phase 1: newline bitmap + counts
+    ctx->timer.begin("index", S);
+    uint32_t nblk[2] = { 0, 0 }; uint64_t nwords[2] = { 0, 0 };
+    size_t scantmp = 1024;
+    for (int s = 0; s < nstreams; s++) {
+        nwords[s] = (nbytes[s] + 63) / 64; nblk[s] = (uint32_t)((nwords[s] + 255) / 256);
+        HIPCHK(ctx, B[B_BITMAP0 + s].ensure(nwords[s] * 8 + 64));
+        HIPCHK(ctx, B[B_BLK0 + s].ensure(((size_t)nblk[s] + 2) * 4));
+        scantmp = std::max(scantmp, ((size_t)nblk[s] / SCAN_TILE + 2) * 16);
+    }
+    HIPCHK(ctx, B[B_SCANTMP].ensure(scantmp));
+    for (int s = 0; s < nstreams; s++) {
+        if (!nblk[s]) continue;
+        hipLaunchKernelGGL(k_nl_bitmap, dim3(nblk[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), dst);
+        KCHK(ctx, "k_nl_bitmap");
+        scan_exclusive<uint32_t>(S, B[B_BLK0 + s].as<uint32_t>(), B[B_BLK0 + s].as<uint32_t>(), nblk[s], B[B_SCANTMP].as<uint32_t>(), 1);
+    }
+    uint32_t n_newlines[2] = { 0, 0 }; uint8_t lastbyte[2] = { '\n', '\n' };
+    for (int s = 0; s < nstreams; s++) {
+        if (!nblk[s]) continue;
+        HIPCHK(ctx, hipMemcpyAsync(&n_newlines[s], B[B_BLK0 + s].as<uint32_t>() + nblk[s], 4, hipMemcpyDeviceToHost, S));
+        HIPCHK(ctx, hipMemcpyAsync(&lastbyte[s], fq[s] + nbytes[s] - 1, 1, hipMemcpyDeviceToHost, S));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    if (hs.err & DE_HAS_CR) return rfq_fail(ctx, RFQ_E_TEXT, "FASTQ text contains '\\r' line endings; the device reader handles '\\n'-terminated text only");
+    uint32_t nlines[2] = { 0, 0 }, nrec[2] = { 0, 0 };
+    for (int s = 0; s < nstreams; s++) {
+        const int unterm = nbytes[s] > 0 && lastbyte[s] != '\n';
+        nlines[s] = n_newlines[s] + (unterm ? 1u : 0u); nrec[s] = nlines[s] / 4;
+        HIPCHK(ctx, B[B_LO0 + s].ensure(((size_t)nlines[s] + 4) * 4));
+        if (nblk[s]) {
+            hipLaunchKernelGGL(k_line_offsets, dim3(nblk[s]), dim3(256), 0, S, B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), (uint32_t)nbytes[s], B[B_LO0 + s].as<uint32_t>());
+            hipLaunchKernelGGL(k_line_tail, dim3(1), dim3(64), 0, S, B[B_LO0 + s].as<uint32_t>(), n_newlines[s], (uint32_t)nbytes[s], unterm);
+            KCHK(ctx, "k_line_offsets");
+        }
+    }
+    ctx->timer.end(S);
+
+    // ---- phase 2: read table, chunk cuts
+    Text T; memset(&T, 0, sizeof T);
+    for (int s = 0; s < 2; s++) { T.fq[s] = fq[s]; T.n[s] = (uint32_t)nbytes[s]; T.lo[s] = s < nstreams ? B[B_LO0 + s].as<uint32_t>() : nullptr; }
+    T.paired = a->paired; T.upr = a->paired == RFQ_SE ? 1u : 2u;
+    uint32_t n_units = a->paired == RFQ_SE ? nrec[0] : (a->paired == RFQ_PE_TWO_FILES ? std::min(nrec[0], nrec[1]) : nrec[0] / 2);
+    const uint32_t n_reads = n_units * T.upr; T.n_reads = n_reads;
+    res->d_rfq = nullptr;
+    if (n_units == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
+    const bool is_pe = a->paired != RFQ_SE;
+
+    ctx->timer.begin("read_table+cut", S);
+    const size_t nr = (size_t)n_reads + 2;
+    HIPCHK(ctx, B[B_LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N1LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N2OFF].ensure(nr * 4));
+    HIPCHK(ctx, B[B_X].ensure(nr * 4)); HIPCHK(ctx, B[B_Y].ensure(nr * 4)); HIPCHK(ctx, B[B_TILE].ensure(nr * 2)); HIPCHK(ctx, B[B_LANE].ensure(nr)); HIPCHK(ctx, B[B_OK].ensure(nr));
+    HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
+    HIPCHK(ctx, B[B_PV].ensure(nr * 16)); HIPCHK(ctx, B[B_PVIN].ensure(nr * 16));
+    HIPCHK(ctx, B[B_ULEN].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_P].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_MINMAX].ensure(64));
+    HIPCHK(ctx, B[B_SCANTMP].ensure(std::max(scantmp, (nr / SCAN_TILE + 2) * 16)));
+    ReadTab R;
+    R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>(); R.y = B[B_Y].as<uint32_t>();
+    R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>(); R.stored = B[B_STORED].as<uint32_t>();
+    R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
+    const uint32_t mm_init[2] = { 0xFFFFFFFFu, 0u };
+    HIPCHK(ctx, hipMemcpyAsync(B[B_MINMAX].p, mm_init, 8, hipMemcpyHostToDevice, S));
+    hipLaunchKernelGGL(k_read_table, dim3((n_units + 255) / 256), dim3(256), 0, S, T, R, B[B_ULEN].as<uint64_t>(), n_units, B[B_MINMAX].as<uint32_t>(), dst);
+    KCHK(ctx, "k_read_table");
+    scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1);
+    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1);
+    const uint64_t cap64 = (uint64_t)(nbytes[0] + nbytes[1]) / (2ull * a->chunk_bases) + 3;
+    const uint32_t cap_chunks = (uint32_t)std::min<uint64_t>(cap64, (uint64_t)n_units + 1);
+    HIPCHK(ctx, B[B_FIRST].ensure(((size_t)cap_chunks + 2) * 4));
+    ChunkTab C; memset(&C, 0, sizeof C);
+    C.first = B[B_FIRST].as<uint32_t>();
+    hipLaunchKernelGGL(k_partition, dim3(1), dim3(64), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->final ? 1 : 0,
+                       (const uint32_t*)B[B_MINMAX].as<uint32_t>(), C.first, cap_chunks + 1, dst);
+    KCHK(ctx, "k_partition");
+    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    ctx->timer.end(S);
+    if (hs.err & DE_EMPTY_LINE) return rfq_fail(ctx, RFQ_E_TEXT, "FASTQ text has an empty line inside a record (the reference reader stops there, src/fastqreader.cpp:180-191); not handled on device");
+    if (hs.err & DE_QUAL_SHORT) return rfq_fail(ctx, RFQ_E_UNPINNED, "a quality line is shorter than its sequence line (the reference reads past the string: undefined)");
+    const uint32_t n_chunks = hs.n_chunks;
+    if (n_chunks > cap_chunks) return rfq_fail(ctx, RFQ_E_HIP, "internal: chunk table overflow (%u > %u)", n_chunks, cap_chunks);
+    if (n_chunks == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
+    const uint32_t units_used = hs.n_units_used, reads_used = units_used * T.upr;
+    const uint64_t total_bases = hs.total_bases;
+
+    // ---- phase 3: header (first batch), chunk analysis, gather, plan
+    const size_t nc = (size_t)n_chunks + 2;
+    HIPCHK(ctx, B[B_CFLAGS].ensure(nc * 4)); HIPCHK(ctx, B[B_IL].ensure(nc * 4)); HIPCHK(ctx, B[B_HIST].ensure(nc * 256 * 4)); HIPCHK(ctx, B[B_NCOUNT].ensure(nc * 4));
+    HIPCHK(ctx, B[B_SCAP].ensure(nc * MAX_STREAMS * 4)); HIPCHK(ctx, B[B_SOFF].ensure(nc * MAX_STREAMS * 8)); HIPCHK(ctx, B[B_SSIZE].ensure(nc * MAX_STREAMS * 4));
+    HIPCHK(ctx, B[B_XSIZE].ensure(nc * 4)); HIPCHK(ctx, B[B_YSIZE].ensure(nc * 4)); HIPCHK(ctx, B[B_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[B_SBASE].ensure(nc * 8));
+    HIPCHK(ctx, B[B_IMGSIZE].ensure(nc * 8)); HIPCHK(ctx, B[B_IMGOFF].ensure(nc * 8)); HIPCHK(ctx, B[B_CTOTAL].ensure(nc * 8)); HIPCHK(ctx, B[B_CBASE].ensure(nc * 8));
+    HIPCHK(ctx, B[B_LAYOUT].ensure(nc * sizeof(Layout))); HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats))); HIPCHK(ctx, B[B_OVB].ensure(nr / 2 + 16));
+    const size_t catbytes = (size_t)total_bases + 64 * nc + 256;
+    HIPCHK(ctx, B[B_QCAT].ensure(catbytes)); HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
+    HIPCHK(ctx, ctx->d_hdr.ensure(sizeof(DevHeader)));
+    C.flags = B[B_CFLAGS].as<uint32_t>(); C.il = B[B_IL].as<uint32_t>(); C.hist = B[B_HIST].as<uint32_t>(); C.ncount = B[B_NCOUNT].as<uint32_t>();
+    C.scap = B[B_SCAP].as<uint32_t>(); C.soff = B[B_SOFF].as<uint64_t>(); C.ssize = B[B_SSIZE].as<uint32_t>(); C.xsize = B[B_XSIZE].as<uint32_t>(); C.ysize = B[B_YSIZE].as<uint32_t>();
+    C.qbase = B[B_QBASE].as<uint64_t>(); C.sbase = B[B_SBASE].as<uint64_t>(); C.img_size = B[B_IMGSIZE].as<uint64_t>(); C.img_off = B[B_IMGOFF].as<uint64_t>();
+    DevHeader* D = ctx->d_hdr.as<DevHeader>();
+    Layout* L = B[B_LAYOUT].as<Layout>();
+    int8_t* ovb = B[B_OVB].as<int8_t>();
+    const uint32_t max_reads = std::max(hs.max_chunk_reads, 1u);
+
+    ctx->timer.begin("header", S);
+    hipLaunchKernelGGL(k_chunk_ids, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, C, R);
+    const bool make_header = !ctx->have_hdr;
+    if (make_header) {
+        HdrStats* H = B[B_HSTATS].as<HdrStats>();
+        const uint32_t c0_reads = std::max(1u, std::min(max_reads, reads_used));
+        const uint32_t hb = std::min<uint32_t>(1024, (c0_reads + 3) / 4);
+        hipLaunchKernelGGL(k_hdr_init, dim3(1), dim3(128), 0, S, H);
+        hipLaunchKernelGGL(k_hdr_stats, dim3(hb), dim3(256), 0, S, T, R, (const uint32_t*)C.first, H);
+        hipLaunchKernelGGL(k_hdr_q0, dim3(1), dim3(64), 0, S, T, H);
+        hipLaunchKernelGGL(k_hdr_pass2, dim3(hb), dim3(256), 0, S, T, R, (const uint32_t*)C.first, H);
+        if (is_pe) hipLaunchKernelGGL(k_hdr_pe, dim3((c0_reads / 2 + 255) / 256), dim3(256), 0, S, T, R, (const uint32_t*)C.first, H);
+        hipLaunchKernelGGL(k_hdr_finalize, dim3(1), dim3(64), 0, S, T, H, D, is_pe ? 1 : 0, dst);
+        KCHK(ctx, "k_hdr_*");
+    }
+    ctx->timer.end(S);
+
+    ctx->timer.begin("chunk_flags+overlap", S);
+    hipLaunchKernelGGL(k_chunk_flags, dim3(n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, is_pe ? 1 : 0);
+    if (is_pe) { const uint32_t np = reads_used / 2; hipLaunchKernelGGL(k_overlap, dim3(std::min<uint32_t>((np + 3) / 4, 65535u * 4u)), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np); }
+    hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, B[B_PVIN].as<U4>(), n_reads);
+    scan_exclusive<U4>(S, B[B_PVIN].as<U4>(), R.pv, n_reads, B[B_SCANTMP].as<U4>(), 1);
+    hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks);
+    KCHK(ctx, "k_chunk_flags");
+    ctx->timer.end(S);
+
+    ctx->timer.begin("gather", S);
+    HIPCHK(ctx, hipMemsetAsync(C.hist, 0, nc * 256 * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S));
+    {
+        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 3) / 4, std::max(1u, 8192u / n_chunks)));
+        hipLaunchKernelGGL(k_gather, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>());
+    }
+    hipLaunchKernelGGL(k_stream_plan, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks);
+    scan_exclusive<uint64_t>(S, B[B_CTOTAL].as<uint64_t>(), B[B_CBASE].as<uint64_t>(), n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+    hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
+    scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+    hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 0, dst);
+    KCHK(ctx, "k_gather");
+    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+    if (make_header) HIPCHK(ctx, hipMemcpyAsync(&ctx->h_hdr, D, sizeof(DevHeader), hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    ctx->timer.end(S);
+    if (hs.err & (DE_BAD_QUAL | DE_BAD_BASE)) {
+        // RfqHeader::makeQualityTable error_exit texts, src/rfqheader.cpp:140-166
+        const uint32_t g = hs.err_read, i = (uint32_t)hs.err_key; std::string ln;
+        if (hs.err & DE_BAD_QUAL) { if (fetch_line(ctx, T, g, 3, ln)) return RFQ_E_HIP; return rfq_fail(ctx, RFQ_E_DATA, "bad quality value: %d", (int)(int8_t)ln[i]); }
+        if (fetch_line(ctx, T, g, 1, ln)) return RFQ_E_HIP;
+        const char b = ln[i];
+        if (b == 'a' || b == 't' || b == 'c') return rfq_fail(ctx, RFQ_E_DATA, "repaq doesn't support FASTQ with lowercase bases (a/t/c/g)\nbut we get:\n%s", ln.c_str());
+        return rfq_fail(ctx, RFQ_E_DATA, "repaq only supports FASTQ with uppercase bases (A/T/C/G/N)\nbut we get:\n%s", ln.c_str());
+    }
+    if (hs.err & DE_NO_QUAL_BINS) return rfq_fail(ctx, RFQ_E_DATA, "bad quality string, is this a valid FASTQ file?");
+    if (make_header) { if (!ctx->h_hdr.valid) return rfq_fail(ctx, RFQ_E_HIP, "internal: header was not finalised"); ctx->have_hdr = true; }
+    const DevHeader& HH = ctx->h_hdr;
+
+    // ---- phase 4: code streams, exact layout, assemble
+    HIPCHK(ctx, B[B_SCRATCH].ensure((size_t)hs.total_scratch + 256));
+    HIPCHK(ctx, B[B_XS].ensure(3 * nr + 64)); HIPCHK(ctx, B[B_YS].ensure(3 * nr + 64));
+    const uint64_t hdr_bytes = a->emit_header ? HH.len : 0;
+    uint8_t* img; uint64_t img_cap;
+    if (a->d_out) { img = a->d_out; img_cap = a->out_cap; }
+    else { HIPCHK(ctx, ctx->out_img.ensure((size_t)(hs.image_bound + hdr_bytes + 64))); img = ctx->out_img.as<uint8_t>(); img_cap = ctx->out_img.cap; }
+    if (hdr_bytes) {
+        if (img_cap < hdr_bytes) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small for the header");
+        HIPCHK(ctx, hipMemcpyAsync(img, HH.bytes, hdr_bytes, hipMemcpyHostToDevice, S));
+    }
+    ctx->timer.begin("pos_coder", S);
+    hipLaunchKernelGGL(k_pos_coder, dim3(MAX_STREAMS, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(),
+                       B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(), dst);
+    KCHK(ctx, "k_pos_coder");
+    ctx->timer.end(S);
+    ctx->timer.begin("coords+layout", S);
+    hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
+    hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
+    scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+    hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 1, dst);
+    KCHK(ctx, "k_coords");
+    ctx->timer.end(S);
+    ctx->timer.begin("assemble", S);
+    {
+        const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
+        hipLaunchKernelGGL(k_assemble, dim3(bpc, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L,
+                           (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(),
+                           (const uint8_t*)B[B_XS].as<uint8_t>(), (const uint8_t*)B[B_YS].as<uint8_t>(), (const int8_t*)ovb, img, img_cap, hdr_bytes,
+                           a->file_off1, a->file_off2, a->nolb_from1, a->nolb_from2, dst);
+        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 3) / 4, std::max(1u, 4096u / n_chunks)));
+        hipLaunchKernelGGL(k_assemble_names, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L, img, img_cap, hdr_bytes);
+        KCHK(ctx, "k_assemble");
+    }
+    ctx->timer.end(S);
+    ctx->chunk_off.resize((size_t)n_chunks + 1);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->chunk_off.data(), C.img_off, ((size_t)n_chunks + 1) * 8, hipMemcpyDeviceToHost, S));
+    uint32_t cons[2] = { 0, 0 };
+    for (int s = 0; s < nstreams; s++) {
+        const uint32_t recs = a->paired == RFQ_PE_INTERLEAVED ? reads_used : (a->paired == RFQ_PE_TWO_FILES ? units_used : reads_used);
+        HIPCHK(ctx, hipMemcpyAsync(&cons[s], B[B_LO0 + s].as<uint32_t>() + 4 * (size_t)recs, 4, hipMemcpyDeviceToHost, S));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    ctx->timer.collect();
+    if (hs.err & DE_COORD_RANGE) {
+        // RfqCodec::encodeCoords error_exit, src/rfqcodec.cpp:1315-1317: first offender in (chunk, x-before-y, index) order
+        const uint32_t c = (uint32_t)(hs.coord_key >> 34), axis = (uint32_t)((hs.coord_key >> 33) & 1u), i = (uint32_t)(hs.coord_key & 0xFFFFFFFFu);
+        uint32_t f = 0, ilv = 0, v = 0;
+        HIPCHK(ctx, hipMemcpy(&f, C.first + c, 4, hipMemcpyDeviceToHost)); HIPCHK(ctx, hipMemcpy(&ilv, C.il + c, 4, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(&v, (axis ? R.y : R.x) + f + (size_t)i * (ilv ? 2 : 1), 4, hipMemcpyDeviceToHost));
+        return rfq_fail(ctx, RFQ_E_DATA, "The X/Y coordinate cannot be larger than 2M, but we get: %u", v);
+    }
+    if (hs.err & DE_QUAL_OVERFLOW) return rfq_fail(ctx, RFQ_E_UNPINNED, "quality payload exceeds the reference's 1.5x scratch buffer (reference heap overflow, SURVEY.md App. C Q6)");
+    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_HIP, "internal: a stream exceeded its scratch capacity");
+    if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %llu bytes", (unsigned long long)(hs.total_image + hdr_bytes));
+    for (auto& o : ctx->chunk_off) o += hdr_bytes;
+    res->d_rfq = img; res->rfq_len = (size_t)(hs.total_image + hdr_bytes); res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases;
+    res->consumed1 = cons[0] > nbytes[0] ? nbytes[0] : cons[0];
+    res->consumed2 = nstreams == 2 ? (cons[1] > nbytes[1] ? nbytes[1] : cons[1]) : 0;
+    res->h_chunk_off = ctx->chunk_off.data();
+    return RFQ_OK;
+}

@@ -1,0 +1,879 @@
+// rfq_encode_kernels.h — gfx950 kernels of the FASTQ -> RFQ encode path (included by rfq_encode.hip only).
+//
+// Pipeline (one batch = whole FASTQ stream(s) resident in HBM; reference call sites in brackets):
+//   index    k_nl_bitmap -> scan -> k_line_offsets            newline bitmap, global line ranks, line-start table
+//            [FastqReader::getLine/read, src/fastqreader.cpp:94-196, for '\n'-terminated text]
+//   table    k_read_table                                     per-read lengths + FastqMeta::parse [src/fastqmeta.cpp:22-80]
+//   cut      scan + k_partition                               chunk boundaries [Repaq::compress, src/repaq.cpp:546-553]
+//   header   k_hdr_*                                          RfqCodec::makeHeader + makeQualityTable on chunk 0
+//   chunk    k_chunk_flags, k_overlap, scans, k_gather, k_stream_plan, k_pos_coder, k_coords, k_chunk_layout,
+//            k_assemble*                                      RfqCodec::encodeChunk + RfqChunk::write
+#pragma once
+#include "rfq_common.h"
+
+struct Text {                    // the FASTQ streams of a batch and their line tables
+    const uint8_t* fq[2];
+    uint32_t n[2];
+    const uint32_t* lo[2];       // lo[s][i] = start of line i; lo[s][i+1]-1 = its terminator (virtual at n for an unterminated tail)
+    int paired;                  // RFQ_SE / RFQ_PE_TWO_FILES / RFQ_PE_INTERLEAVED
+    uint32_t n_reads;            // reads in interleaved order (PE: 2 * pairs)
+    uint32_t upr;                // reads per partition unit (1 SE, 2 PE)
+};
+__device__ __forceinline__ void read_loc(const Text& T, uint32_t g, int& s, uint32_t& r) {
+    if (T.paired == 1) { s = (int)(g & 1u); r = g >> 1; } else { s = 0; r = g; }
+}
+__device__ __forceinline__ uint32_t line_beg(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return T.lo[s][4 * (size_t)r + k]; }
+__device__ __forceinline__ uint32_t line_len(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); const uint32_t* p = T.lo[s] + 4 * (size_t)r + k; return p[1] - 1 - p[0]; }
+__device__ __forceinline__ const uint8_t* line_ptr(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return T.fq[s] + T.lo[s][4 * (size_t)r + k]; }
+
+struct ReadTab {                 // per-read arrays, indexed by g (interleaved order)
+    uint32_t* len;               // sequence length
+    uint32_t* name1_len;
+    uint32_t* name2_off;         // name2 = name[name2_off, name_len)
+    uint32_t* x; uint32_t* y;
+    uint16_t* tile; uint8_t* lane; uint8_t* ok;
+    uint32_t* chunk;             // chunk id
+    uint32_t* stored;            // bases kept in the sequence stream (after overlap trimming)
+    uint8_t*  eq2;               // name2 == name2 of the chunk's read 0
+    uint32_t* pq;                // exclusive prefix of len          (n_reads + 1 entries)
+    U4*       pv;                // exclusive prefix of (name1_len, name2_len, strand_len, stored) (n_reads + 1)
+};
+
+struct ChunkTab {                // per-chunk arrays
+    uint32_t* first;             // first read of chunk c; first[n_chunks] = end
+    uint32_t* flags;             // RfqChunk::mFlags (without line-break bits)
+    uint32_t* il;                // final canBePeInterleaved
+    uint32_t* hist;              // [c][256] quality histogram of the chunk
+    uint32_t* ncount;            // 'N' bases in the stored sequence
+    uint32_t* scap;              // [c][MAX_STREAMS] scratch capacity of each stream
+    uint64_t* soff;              // [c][MAX_STREAMS] scratch offset of each stream
+    uint32_t* ssize;             // [c][MAX_STREAMS] bytes written by the stream coder
+    uint32_t* xsize; uint32_t* ysize;
+    uint64_t* qbase; uint64_t* sbase;   // 64-byte aligned bases of the chunk in qcat / scat
+    uint64_t* img_size;          // bytes of the chunk image
+    uint64_t* img_off;           // exclusive prefix (n_chunks + 1)
+};
+
+// =============================================================== index
+// 64 bytes per lane -> one u64 newline mask; 256 lanes = 16 KiB per workgroup.
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t w, uint32_t pat) {   // bit k set iff byte k of w == pat byte
+    uint32_t v = w ^ pat;
+    uint32_t t = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);   // 0x80 in every zero byte, exact
+    return (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+__device__ __forceinline__ uint32_t eq_mask16(const uint4& q, uint32_t pat) {
+    return eq_mask4(q.x, pat) | (eq_mask4(q.y, pat) << 4) | (eq_mask4(q.z, pat) << 8) | (eq_mask4(q.w, pat) << 12);
+}
+__global__ void k_nl_bitmap(const uint8_t* __restrict__ fq, uint32_t n, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ blkcnt, DevStatus* st) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t base = w * 64;
+    uint64_t m = 0; uint32_t cr = 0;
+    if (base + 64 <= n) {
+        const uint4* p = (const uint4*)(fq + base);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { uint4 q = p[k]; m |= (uint64_t)eq_mask16(q, 0x0A0A0A0Au) << (16 * k); cr |= eq_mask16(q, 0x0D0D0D0Du); }
+    } else if (base < n) {
+        for (uint32_t i = 0; i < 64 && base + i < n; i++) { uint8_t c = fq[base + i]; if (c == '\n') m |= 1ull << i; if (c == '\r') cr = 1; }
+    }
+    if (base < n) bitmap[w] = m;
+    uint32_t tot; (void)block_excl_sum<uint32_t>((uint32_t)__popcll(m), &tot);
+    if (threadIdx.x == 0) blkcnt[blockIdx.x] = tot;
+    if (__any(cr != 0) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_HAS_CR);
+}
+// lo[rank+1] = position after the rank-th newline; lo[0] = 0.
+__global__ void k_line_offsets(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ blkbase, uint32_t n, uint32_t* __restrict__ lo) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t base = w * 64;
+    uint64_t m = base < n ? bitmap[w] : 0ull;
+    uint32_t ex = block_excl_sum<uint32_t>((uint32_t)__popcll(m), (uint32_t*)nullptr);
+    uint32_t rank = blkbase[blockIdx.x] + ex;
+    while (m) { int b = __ffsll((long long)m) - 1; m &= m - 1; lo[rank + 1] = (uint32_t)(base + (uint32_t)b + 1); rank++; }
+    if (w == 0) lo[0] = 0;
+}
+__global__ void k_line_tail(uint32_t* lo, uint32_t n_newlines, uint32_t n, int unterminated) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && unterminated) lo[n_newlines + 1] = n + 1;
+}
+
+// =============================================================== read table + name parse
+// glibc atoi: (int)strtol — leading isspace, sign, digits, saturating at LONG_MIN/LONG_MAX.
+__device__ __forceinline__ int dev_atoi(const uint8_t* s, uint32_t n) {
+    uint32_t i = 0;
+    while (i < n && (s[i] == ' ' || (s[i] >= 9 && s[i] <= 13))) i++;
+    bool neg = false;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; i++; }
+    const unsigned long long lim = neg ? 0x8000000000000000ull : 0x7FFFFFFFFFFFFFFFull;
+    unsigned long long acc = 0; bool sat = false;
+    for (; i < n && s[i] >= '0' && s[i] <= '9'; i++) {
+        unsigned d = (unsigned)(s[i] - '0');
+        if (sat || acc > (lim - d) / 10) { sat = true; acc = lim; } else acc = acc * 10 + d;
+    }
+    unsigned long long v = neg ? (0ull - acc) : acc;
+    return (int)(uint32_t)v;
+}
+struct Meta { uint32_t ok, name1_len, name2_off, x, y; uint16_t tile; uint8_t lane; };
+// FastqMeta::parse, src/fastqmeta.cpp:22-80
+__device__ __forceinline__ Meta dev_parse_name(const uint8_t* str, uint32_t len) {
+    int colon = 0, last_colon = 0, cstart = 0, cend = 0;
+    uint8_t lane = 0; uint16_t tile = 0; uint32_t x = 0, y = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        const uint8_t c = str[i];
+        if (c == ':') colon++;
+        if ((c == ':' || c == ' ') && colon >= 4 && colon <= 7) {
+            const int val = dev_atoi(str + last_colon + 1, i - (uint32_t)last_colon - 1);
+            if (colon == 4) { lane = (uint8_t)val; cstart = last_colon + 1; }
+            else if (colon == 5) tile = (uint16_t)val;
+            else if (colon == 6) { if (c == ':') x = (uint32_t)val; }
+            else y = (uint32_t)val;
+            if (c == ' ' && colon == 6) y = (uint32_t)val;
+        }
+        if (c == ':') last_colon = (int)i;
+        if (c == ' ' || (c == ':' && colon == 7)) { cend = (int)i; break; }
+    }
+    Meta m;
+    if (cstart > 0 && cend > 0) { m.ok = 1; m.lane = lane; m.tile = tile; m.x = x; m.y = y; m.name1_len = (uint32_t)(cstart - 1); m.name2_off = (uint32_t)cend; }
+    else { m.ok = 0; m.lane = 0; m.tile = 0; m.x = 0; m.y = 0; m.name1_len = len; m.name2_off = len; }
+    return m;
+}
+// one thread per partition unit (a read, or a pair); validates the 4-line records it owns
+__global__ void k_read_table(Text T, ReadTab R, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t* __restrict__ len_minmax, DevStatus* st) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t err = 0; uint64_t tot = 0;
+    if (u < n_units) {
+        for (uint32_t j = 0; j < T.upr; j++) {
+            const uint32_t g = u * T.upr + j;
+            const uint32_t nl = line_len(T, g, 0), sl = line_len(T, g, 1), tl = line_len(T, g, 2), ql = line_len(T, g, 3);
+            if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
+            if (ql < sl) err |= DE_QUAL_SHORT;
+            Meta m = dev_parse_name(line_ptr(T, g, 0), nl);
+            R.len[g] = sl; R.stored[g] = sl;
+            R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
+            tot += sl;
+        }
+        ulen[u] = tot;
+    }
+    // uniform-length fast path of the partitioner needs min/max unit length
+    uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
+    mn = wave_min(mn); mx = wave_max(mx); err = wave_or(err);
+    if (lane_id() == 0) { atomicMin(&len_minmax[0], mn); atomicMax(&len_minmax[1], mx); if (err) atomicOr(&st->err, err); }
+}
+
+// =============================================================== chunk partition (one wave)
+// P = inclusive prefix of unit lengths.  Chunk = minimal run of units whose bases reach chunk_bases (src/repaq.cpp:552-553).
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict__ P, uint32_t lo, uint32_t hi, uint64_t target) {
+    // smallest e in [lo, hi) with P[e] >= target, or hi.  64-ary search, wave-uniform.
+    const int l = lane_id();
+    while (hi - lo > 64) {
+        const uint32_t span = hi - lo, stride = (span + 63) / 64;
+        uint64_t idx = (uint64_t)lo + (uint64_t)(l + 1) * stride - 1; if (idx >= hi) idx = hi - 1;
+        const unsigned long long b = __ballot(P[idx] >= target);
+        if (!b) return hi;
+        const int j = __ffsll((long long)b) - 1;
+        uint64_t nhi = (uint64_t)lo + (uint64_t)(j + 1) * stride; if (nhi > hi) nhi = hi;
+        lo = lo + (uint32_t)j * stride; hi = (uint32_t)nhi;
+    }
+    const uint32_t i = lo + (uint32_t)l;
+    const unsigned long long b = __ballot(i < hi && P[i] >= target);
+    if (!b) return hi;
+    return lo + (uint32_t)(__ffsll((long long)b) - 1);
+}
+__global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, int final_batch,
+                            const uint32_t* __restrict__ len_minmax, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
+    const int l = lane_id();
+    uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0;
+    if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
+        // every unit has the same length L: a chunk is K = ceil(chunk_bases / L) units
+        const uint32_t L = len_minmax[0]; const uint32_t K = (uint32_t)(((uint64_t)chunk_bases + L - 1) / L);
+        const uint32_t full = n_units / K, rem = n_units - full * K;
+        const uint32_t nch = full + ((rem && final_batch) ? 1u : 0u);
+        for (uint32_t i = (uint32_t)l; i <= nch && i < cap_chunks; i += 64) { uint64_t f = (uint64_t)i * K; if (f > n_units) f = n_units; first[i] = (uint32_t)f * upr; }
+        c = nch; start = (rem && !final_batch) ? full * K : n_units;
+        max_units = full ? K : rem; max_bases = (uint64_t)max_units * L;
+    } else {
+        uint32_t guess = 0;
+        while (start < n_units) {
+            const uint64_t target = prevP + chunk_bases;
+            uint32_t e = n_units; bool found = false;
+            if (guess > 32 && start + guess - 32 < n_units) {            // probe a 64-wide window around the previous chunk's size
+                const uint32_t w0 = start + guess - 32; const uint32_t i = w0 + (uint32_t)l;
+                const unsigned long long b = __ballot(i < n_units && P[i] >= target);
+                if (b && !(b & 1ull)) { e = w0 + (uint32_t)(__ffsll((long long)b) - 1); found = true; }
+            }
+            if (!found) e = wave_lower_bound(P, start, n_units, target);
+            if (e >= n_units) { if (!final_batch) break; e = n_units - 1; }
+            if (c < cap_chunks && l == 0) first[c] = start * upr;
+            const uint64_t pe = P[e];
+            if (pe - prevP > max_bases) max_bases = pe - prevP;
+            if (e + 1 - start > max_units) max_units = e + 1 - start;
+            guess = e + 1 - start; prevP = pe; start = e + 1; c++;
+        }
+        if (c < cap_chunks && l == 0) first[c] = start * upr;
+    }
+    if (l == 0) {
+        st->n_chunks = c; st->n_units_used = start; st->max_chunk_reads = max_units * upr;
+        st->max_chunk_bases = (uint32_t)(max_bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : max_bases);
+        st->total_bases = start ? P[start - 1] : 0;
+    }
+}
+__global__ void k_chunk_ids(ChunkTab C, ReadTab R) {
+    const uint32_t c = blockIdx.y; const uint32_t f = C.first[c], e = C.first[c + 1];
+    const uint32_t g = f + blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < e) R.chunk[g] = c;
+}
+
+// =============================================================== header from chunk 0
+// RfqCodec::makeHeader (src/rfqcodec.cpp:20-145) + RfqHeader::makeQualityTable (src/rfqheader.cpp:130-237).
+struct HdrStats {
+    uint32_t hist[128];
+    uint32_t n_count;           // N bases in chunk 0
+    uint32_t all_ok;            // AND of hasLaneTileXY (stored as "any not ok" = 0 -> ok)
+    uint32_t any_not_ok;
+    uint32_t max_len;
+    uint64_t first_n_key;       // (read << 32 | offset) of the first N base, ~0 if none
+    uint64_t first_err_key;     // first position with a bad quality / bad base, ~0 if none
+    uint32_t q0;                // quality of the first N
+    uint32_t need_npos;         // N with another quality, or a non-N base carrying q0 after the first N
+    uint32_t pe_support;        // PE: starts 1, cleared by any failing pair
+    uint32_t dpos, dch;         // name2 diff of pair 0
+};
+__global__ void k_hdr_init(HdrStats* H) {
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) H->hist[i] = 0;
+    if (threadIdx.x == 0) { H->n_count = 0; H->all_ok = 1; H->any_not_ok = 0; H->max_len = 0; H->first_n_key = ~0ull; H->first_err_key = ~0ull; H->q0 = 0; H->need_npos = 0; H->pe_support = 1; H->dpos = 0; H->dch = 0; }
+}
+// pass 1: one wave per read of chunk 0 (grid-stride)
+__global__ void k_hdr_stats(Text T, ReadTab R, const uint32_t* __restrict__ first, HdrStats* H) {
+    __shared__ uint32_t sh[128];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    const uint32_t nreads = first[1];
+    const int l = lane_id(); const uint32_t wpb = blockDim.x >> 6;
+    uint32_t ncnt = 0, notok = 0, mxl = 0; uint64_t fn = ~0ull, fe = ~0ull;
+    for (uint32_t g = blockIdx.x * wpb + (uint32_t)wave_id(); g < nreads; g += gridDim.x * wpb) {
+        const uint32_t len = R.len[g]; const uint8_t* sq = line_ptr(T, g, 1); const uint8_t* ql = line_ptr(T, g, 3);
+        if (!R.ok[g]) notok = 1;
+        if (len > mxl) mxl = len;
+        for (uint32_t i = (uint32_t)l; i < len; i += 64) {
+            const uint8_t q = ql[i], b = sq[i]; const uint64_t key = ((uint64_t)g << 32) | i;
+            if (q >= 128) { if (key < fe) fe = key; }
+            else atomicAdd(&sh[q], 1u);
+            if (b == 'N') { ncnt++; if (key < fn) fn = key; }
+            else if (b != 'A' && b != 'C' && b != 'G' && b != 'T') { if (key < fe) fe = key; }
+        }
+    }
+    ncnt = wave_sum(ncnt); notok = wave_or(notok); mxl = wave_max(mxl); fn = wave_min(fn); fe = wave_min(fe);
+    if (l == 0) {
+        if (ncnt) atomicAdd(&H->n_count, ncnt);
+        if (notok) atomicOr(&H->any_not_ok, 1u);
+        atomicMax(&H->max_len, mxl);
+        if (fn != ~0ull) atomicMin((unsigned long long*)&H->first_n_key, (unsigned long long)fn);
+        if (fe != ~0ull) atomicMin((unsigned long long*)&H->first_err_key, (unsigned long long)fe);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) if (sh[i]) atomicAdd(&H->hist[i], sh[i]);
+}
+__global__ void k_hdr_q0(Text T, HdrStats* H) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (H->first_n_key != ~0ull) { const uint32_t g = (uint32_t)(H->first_n_key >> 32), i = (uint32_t)H->first_n_key; H->q0 = line_ptr(T, g, 3)[i]; }
+}
+// pass 2: (a) an N whose quality differs from q0, (b) a non-N base with quality q0 located after the first N
+__global__ void k_hdr_pass2(Text T, ReadTab R, const uint32_t* __restrict__ first, HdrStats* H) {
+    const uint64_t fnk = H->first_n_key;
+    if (fnk == ~0ull) return;                                   // uniform: no N at all
+    const uint32_t q0 = H->q0; const uint32_t nreads = first[1];
+    const int l = lane_id(); const uint32_t wpb = blockDim.x >> 6; uint32_t need = 0;
+    for (uint32_t g = blockIdx.x * wpb + (uint32_t)wave_id(); g < nreads; g += gridDim.x * wpb) {
+        const uint32_t len = R.len[g]; const uint8_t* sq = line_ptr(T, g, 1); const uint8_t* ql = line_ptr(T, g, 3);
+        for (uint32_t i = (uint32_t)l; i < len; i += 64) {
+            const uint8_t q = ql[i], b = sq[i]; const uint64_t key = ((uint64_t)g << 32) | i;
+            if (b == 'N') { if (q != q0) need = 1; }
+            else if (q == q0 && key > fnk) need = 1;
+        }
+    }
+    need = wave_or(need);
+    if (l == 0 && need) atomicOr(&H->need_npos, 1u);
+}
+// (a with a[pos] = ch when ch != 0) == b   — the name2 mate rule of src/rfqcodec.cpp:105-113 and :237-245
+__device__ __forceinline__ bool name2_eq_replaced(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen, uint32_t pos, uint32_t ch) {
+    if (alen != blen) return false;
+    for (uint32_t i = 0; i < alen; i++) { uint8_t c = a[i]; if (ch != 0 && i == pos) c = (uint8_t)ch; if (c != b[i]) return false; }
+    return true;
+}
+__device__ __forceinline__ bool bytes_eq(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen) {
+    if (alen != blen) return false;
+    for (uint32_t i = 0; i < alen; i++) if (a[i] != b[i]) return false;
+    return true;
+}
+// PE: one thread per pair of chunk 0 (src/rfqcodec.cpp:89-114)
+__global__ void k_hdr_pe(Text T, ReadTab R, const uint32_t* __restrict__ first, HdrStats* H) {
+    const uint32_t npairs = first[1] / 2; const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    // pair 0 fixes (dpos, dch); every thread derives it (a name2 is a handful of bytes)
+    const uint8_t* a0 = line_ptr(T, 0, 0) + R.name2_off[0]; const uint32_t al0 = line_len(T, 0, 0) - R.name2_off[0];
+    const uint8_t* b0 = line_ptr(T, 1, 0) + R.name2_off[1]; const uint32_t bl0 = line_len(T, 1, 0) - R.name2_off[1];
+    uint32_t dpos = 0, dch = 0;
+    for (uint32_t i = 0; i < al0; i++) { const uint8_t c2 = i < bl0 ? b0[i] : 0; if (a0[i] != c2) { dpos = i; dch = c2; break; } }
+    bool bad = false;
+    if (p < npairs) {
+        const uint32_t g = 2 * p;
+        const uint8_t* a = line_ptr(T, g, 0) + R.name2_off[g]; const uint32_t al = line_len(T, g, 0) - R.name2_off[g];
+        const uint8_t* b = line_ptr(T, g + 1, 0) + R.name2_off[g + 1]; const uint32_t bl = line_len(T, g + 1, 0) - R.name2_off[g + 1];
+        if (p == 0 && al != bl) bad = true;
+        if (al < dpos) bad = true;
+        else if (!name2_eq_replaced(a, al, b, bl, dpos, dch)) bad = true;
+    }
+    if (__any(bad) && lane_id() == 0) atomicAnd(&H->pe_support, 0u);
+    if (p == 0) { H->dpos = dpos; H->dch = dch; }
+}
+// derived tables shared by "made" and "set" headers: majorQual / normalQualBins / normalQualBuf (src/rfqheader.cpp:263,308-328)
+__device__ __forceinline__ void hdr_derive(DevHeader* D) {
+    const uint8_t* b = D->bytes;
+    D->read_len_bytes = b[9]; D->flags = (uint32_t)b[10] | ((uint32_t)b[11] << 8);
+    D->name2_diff_pos = b[12]; D->name2_diff_char = b[13]; D->n_base_qual = b[14]; D->overlap_shift = (int32_t)(int8_t)b[15];
+    const uint32_t bins = b[16]; D->len = 17 + bins;
+    D->support_interleaved = (D->flags & H_PE_OVERLAP) ? 1u : 0u;
+    const uint8_t* qb = b + 17;
+    D->major = bins ? qb[0] : 0;
+    const int mq = (int)(int8_t)D->major, nq = (int)(int8_t)D->n_base_qual;
+    const uint32_t nb = (mq == nq) ? bins : (bins ? bins - 1 : 0);
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < 256; i++) { D->stream_of[i] = 0xFF; D->is_exception[i] = 1; D->normal[i] = 0; }
+    for (uint32_t i = 0; i < bins; i++) {
+        const int v = qb[i];
+        if (v != mq || v == nq) { if (cnt < nb) { D->normal[cnt] = (uint8_t)v; } cnt++; if (cnt > nb) break; }
+    }
+    D->n_normal = nb;
+    // a byte equal to several normal entries is claimed by the FIRST stream only for the mask; later equal entries would
+    // re-emit the same positions (the reference loops per entry).  Entries are distinct by construction (histogram bins).
+    for (uint32_t i = 0; i < nb; i++) { const uint8_t v = D->normal[i]; if (D->stream_of[v] == 0xFF) D->stream_of[v] = (uint8_t)i; D->is_exception[v] = 0; }
+    D->is_exception[D->major & 0xFF] = 0;
+    D->valid = 1;
+}
+__global__ void k_hdr_from_bytes(DevHeader* D) { if (threadIdx.x == 0 && blockIdx.x == 0) hdr_derive(D); }
+__global__ void k_hdr_finalize(Text T, HdrStats* H, DevHeader* D, int is_pe, DevStatus* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (H->first_err_key != ~0ull) {
+        const uint32_t g = (uint32_t)(H->first_err_key >> 32), i = (uint32_t)H->first_err_key;
+        const uint8_t q = line_ptr(T, g, 3)[i];
+        st->err |= (q >= 128) ? DE_BAD_QUAL : DE_BAD_BASE; st->err_read = g; st->err_key = H->first_err_key;
+        return;
+    }
+    uint8_t* b = D->bytes;
+    b[0] = 'R'; b[1] = 'F'; b[2] = 'Q'; b[3] = '0'; b[4] = '.'; b[5] = '5'; b[6] = '.'; b[7] = '1'; b[8] = 2;
+    uint32_t flags = 0; int nbq = '#';
+    const bool ltxy = H->any_not_ok == 0;
+    if (ltxy) flags |= H_LANE | H_TILE | H_X | H_Y | H_NAME2;
+    uint32_t dpos = 0, dch = 0;
+    if (is_pe) { flags |= H_PAIRED; if (ltxy && H->pe_support) { flags |= H_PE_OVERLAP; dpos = H->dpos; dch = H->dch; } }
+    // N-quality inference (src/rfqheader.cpp:145-184)
+    if (H->n_count > 0) nbq = (int)H->q0;
+    if (H->need_npos) { flags |= H_N_POS; nbq = -1; }
+    if (H->n_count < 100) { flags |= H_N_POS; nbq = -1; }
+    uint32_t bins = 0, maxnum = 0; int major = 0; bool has_n = false;
+    for (int i = 0; i < 128; i++) { if (H->hist[i] > 0) { bins++; if (i == nbq) has_n = true; } if (H->hist[i] > maxnum) { maxnum = H->hist[i]; major = i; } }
+    if (bins == 0) { st->err |= DE_NO_QUAL_BINS; return; }
+    if (bins >= 64) flags |= H_DONT_QUAL;
+    if (!has_n) bins += 1;
+    b[17] = (uint8_t)major; uint32_t cur = 1;
+    for (int i = 0; i < 128; i++) { if (i == major) continue; if (H->hist[i] > 0) b[17 + cur++] = (uint8_t)i; }
+    if (!has_n) b[17 + bins - 1] = (uint8_t)nbq;
+    if (bins <= 64) flags |= H_QUAL_BY_COL;
+    b[9] = H->max_len > 255 ? 2 : 1;                       // never 4: src/rfqcodec.cpp:48-53 (second `if` is not `else if`)
+    b[10] = (uint8_t)flags; b[11] = (uint8_t)(flags >> 8); b[12] = (uint8_t)dpos; b[13] = (uint8_t)dch; b[14] = (uint8_t)nbq; b[15] = (uint8_t)(-24); b[16] = (uint8_t)bins;
+    hdr_derive(D);
+}
+
+// =============================================================== per-chunk analysis (RfqCodec::encodeChunk pass 1, src/rfqcodec.cpp:181-287)
+struct Layout {                  // byte offsets of every section inside one chunk image (RfqChunk::write order, src/rfqchunk.cpp:230-311)
+    uint32_t off_readlens, off_n1lens, off_n2lens, off_stlens, off_lanes, off_tiles, off_x, off_y, off_n1, off_n2, off_st, off_seq, off_qual, off_ov, off_npos;
+    uint32_t total, msize, seq_size, qual_size, npos_size, n1_size, n2_size, st_size, x_size, y_size, n_reads, flags;
+};
+__device__ __forceinline__ uint32_t name2_len_of(const Text& T, const ReadTab& R, uint32_t g) { return line_len(T, g, 0) - R.name2_off[g]; }
+
+// one workgroup (256) per chunk
+__global__ void k_chunk_flags(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe) {
+    __shared__ uint32_t s_bits[4]; __shared__ uint32_t s_fail[4]; __shared__ uint32_t s_n2[4];
+    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1];
+    const int l = lane_id(), w = wave_id();
+    const uint32_t len0 = R.len[f], n1l0 = R.name1_len[f], n2l0 = name2_len_of(T, R, f), stl0 = line_len(T, f, 2);
+    const uint8_t* name0 = line_ptr(T, f, 0); const uint8_t* n20 = name0 + R.name2_off[f]; const uint8_t* st0 = line_ptr(T, f, 2);
+    const uint8_t lane0 = R.lane[f]; const uint16_t tile0 = R.tile[f];
+    const bool can0 = is_pe && D->support_interleaved;
+    const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
+    uint32_t bits = 0xFF, fail = 0xFFFFFFFFu;
+    for (uint32_t g = f + threadIdx.x; g < e; g += blockDim.x) {
+        const uint32_t nl = line_len(T, g, 0); const uint8_t* nm = line_ptr(T, g, 0);
+        const uint32_t n1l = R.name1_len[g], n2o = R.name2_off[g], n2l = nl - n2o, stl = line_len(T, g, 2);
+        uint32_t b = 0;
+        if (R.len[g] == len0) b |= 1u << 0;
+        if (n1l == n1l0) b |= 1u << 1;
+        if (n2l == n2l0) b |= 1u << 2;
+        if (stl == stl0) b |= 1u << 3;
+        if (bytes_eq(st0, stl0, line_ptr(T, g, 2), stl)) b |= 1u << 4;
+        if (R.lane[g] == lane0) b |= 1u << 5;
+        if (R.tile[g] == tile0) b |= 1u << 6;
+        if (bytes_eq(name0, n1l0, nm, n1l)) b |= 1u << 7;
+        bits &= b;
+        R.eq2[g] = bytes_eq(n20, n2l0, nm + n2o, n2l) ? 1 : 0;
+        const uint32_t rel = g - f;
+        if (can0 && (rel & 1u)) {
+            const uint32_t m = g - 1; const uint8_t* mn = line_ptr(T, m, 0) + R.name2_off[m]; const uint32_t ml = name2_len_of(T, R, m);
+            const bool fa = !name2_eq_replaced(mn, ml, nm + n2o, n2l, dpos, dch);
+            const bool fb = R.lane[m] != R.lane[g] || R.tile[m] != R.tile[g] || R.x[m] != R.x[g] || R.y[m] != R.y[g];
+            if (fa || fb) { const uint32_t key = (rel << 1) | (fa ? 0u : 1u); if (key < fail) fail = key; }
+        }
+    }
+    bits = wave_and(bits); fail = wave_min(fail);
+    if (l == 0) { s_bits[w] = bits; s_fail[w] = fail; }
+    __syncthreads();
+    const uint32_t nw = blockDim.x >> 6;
+    bits = 0xFF; fail = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < nw; i++) { bits &= s_bits[i]; if (s_fail[i] < fail) fail = s_fail[i]; }
+    // name2Same with the order-dependent rule of src/rfqcodec.cpp:233-250 (Q12)
+    const bool failed = can0 && fail != 0xFFFFFFFFu; const uint32_t frel = fail >> 1; const bool kind_a = !(fail & 1u);
+    uint32_t n2same = 1;
+    for (uint32_t g = f + threadIdx.x; g < e; g += blockDim.x) {
+        const uint32_t rel = g - f; bool counts;
+        if (!can0) counts = true;
+        else if (!failed) counts = !(rel & 1u);
+        else counts = (rel < frel) ? !(rel & 1u) : (rel == frel ? kind_a : true);
+        if (counts && !R.eq2[g]) n2same = 0;
+    }
+    n2same = wave_and(n2same);
+    if (l == 0) s_n2[w] = n2same;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t i = 0; i < nw; i++) n2same &= s_n2[i];
+        const bool il = can0 && !failed;
+        uint32_t fl = 0;
+        if (il) fl |= C_PE_INTERLEAVED;
+        if (bits & (1u << 0)) fl |= C_READ_LEN_SAME;
+        if (bits & (1u << 1)) fl |= C_NAME1_LEN_SAME;
+        if (bits & (1u << 2)) fl |= C_NAME2_LEN_SAME;
+        if (bits & (1u << 3)) fl |= C_STRAND_LEN_SAME;
+        if (bits & (1u << 4)) fl |= C_STRAND_SAME;
+        if (bits & (1u << 5)) fl |= C_LANE_SAME;
+        if (bits & (1u << 6)) fl |= C_TILE_SAME;
+        if (bits & (1u << 7)) fl |= C_NAME1_SAME;
+        if (n2same) fl |= C_NAME2_SAME;
+        C.flags[c] = fl; C.il[c] = il ? 1u : 0u;
+    }
+}
+
+// reverse-complement rule of Read::changeToReverseComplement (src/read.cpp:77-115)
+__device__ __forceinline__ uint8_t comp_base(uint8_t b) {
+    switch (b) { case 'A': case 'a': return 'T'; case 'T': case 't': return 'A'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; default: return 'N'; }
+}
+// RfqCodec::overlap (src/rfqcodec.cpp:1391-1438) for one pair per wave: lane = candidate overlap length.
+// r1 = R1 as in the file, r2 = R2 as in the file (its reverse complement is formed on the fly).
+__device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int len1, const uint8_t* __restrict__ r2, int len2) {
+    const int l = lane_id(); const int minlen = len1 < len2 ? len1 : len2;
+    for (int base = 12; base <= minlen; base += 64) {          // forward: R1 tail == RC(R2) head
+        const int o = base + l; bool ok = o <= minlen;
+        if (ok) for (int i = 0; i < o; i++) if (r1[len1 - o + i] != comp_base(r2[len2 - 1 - i])) { ok = false; break; }
+        const unsigned long long b = __ballot(ok);
+        if (b) return base + (__ffsll((long long)b) - 1);
+    }
+    for (int base = 12; base <= minlen; base += 64) {          // backward: RC(R2) tail == R1 head
+        const int o = base + l; bool ok = o <= minlen;
+        if (ok) for (int i = 0; i < o; i++) if (comp_base(r2[o - 1 - i]) != r1[i]) { ok = false; break; }
+        const unsigned long long b = __ballot(ok);
+        if (b) return -(base + (__ffsll((long long)b) - 1));
+    }
+    return 0;
+}
+// one wave per pair (grid-stride); only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
+__global__ void k_overlap(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int8_t* __restrict__ ovb, uint32_t n_pairs) {
+    const uint32_t wpb = blockDim.x >> 6; const int shift = D->overlap_shift; const bool enc = (D->flags & H_PE_OVERLAP) != 0;
+    for (uint32_t p = blockIdx.x * wpb + (uint32_t)wave_id(); p < n_pairs; p += gridDim.x * wpb) {
+        const uint32_t g = 2 * p; const uint32_t c = R.chunk[g];
+        if (!C.il[c] || !enc) continue;                          // wave-uniform
+        const int len1 = (int)R.len[g], len2 = (int)R.len[g + 1];
+        int ov = wave_overlap(line_ptr(T, g, 1), len1, line_ptr(T, g + 1, 1), len2);
+        if (ov + shift > 127) ov = 0;
+        if (ov + shift < -127) ov = 0;
+        if (lane_id() == 0) { ovb[p] = (int8_t)(ov + shift); R.stored[g + 1] = (uint32_t)(len2 - (ov < 0 ? -ov : ov)); }
+    }
+}
+__global__ void k_pv_in(Text T, ReadTab R, U4* __restrict__ v, uint32_t n_reads) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_reads) { U4 t; t.a = R.name1_len[g]; t.b = name2_len_of(T, R, g); t.c = line_len(T, g, 2); t.d = R.stored[g]; v[g] = t; }
+}
+__global__ void k_chunk_bases(ReadTab R, ChunkTab C, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_chunks) { const uint32_t f = C.first[c]; C.qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c; C.sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
+}
+
+// =============================================================== gather (RfqCodec::encodeChunk pass 2, src/rfqcodec.cpp:371-407)
+// One wave per read.  qcat = full-length qualities in chunk order (R2 reversed when interleaved); scat = stored bases
+// (R2 reverse-complemented and overlap-trimmed when interleaved).  Also builds the chunk's quality histogram.
+__global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict__ ovb, const DevHeader* __restrict__ D,
+                         uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat) {
+    __shared__ uint32_t sh[256]; __shared__ uint32_t s_n;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) sh[i] = 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t c = blockIdx.y, f = C.first[c], e = C.first[c + 1];
+    const uint32_t wpb = blockDim.x >> 6; const int l = lane_id();
+    const bool il = C.il[c] != 0; const bool enc = il && (D->flags & H_PE_OVERLAP);
+    const int shift = D->overlap_shift;
+    uint8_t* qd = qcat + C.qbase[c]; uint8_t* sd = scat + C.sbase[c];
+    const uint32_t pq0 = R.pq[f], ps0 = R.pv[f].d;
+    uint32_t ncnt = 0;
+    for (uint32_t g = f + blockIdx.x * wpb + (uint32_t)wave_id(); g < e; g += gridDim.x * wpb) {
+        const uint32_t len = R.len[g]; const uint8_t* sq = line_ptr(T, g, 1); const uint8_t* ql = line_ptr(T, g, 3);
+        const bool rc = il && ((g - f) & 1u);
+        int ov = 0; if (rc && enc) ov = (int)ovb[g >> 1] - shift;
+        uint8_t* qo = qd + (R.pq[g] - pq0); uint8_t* so = sd + (R.pv[g].d - ps0);
+        for (uint32_t i = (uint32_t)l; i < len; i += 64) { const uint8_t q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = q; atomicAdd(&sh[q], 1u); }
+        // stored bases: ov == 0 whole read; ov > 0 skip the first ov bases of RC(R2); ov < 0 drop the last |ov|
+        const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u; const uint32_t keep = len - (uint32_t)(ov < 0 ? -ov : ov);
+        for (uint32_t i = (uint32_t)l; i < keep; i += 64) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b; if (b == 'N') ncnt++; }
+    }
+    ncnt = wave_sum(ncnt);
+    if (l == 0 && ncnt) atomicAdd(&s_n, ncnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) if (sh[i]) atomicAdd(&C.hist[(size_t)c * 256 + i], sh[i]);
+    if (threadIdx.x == 0 && s_n) atomicAdd(&C.ncount[c], s_n);
+}
+
+// scratch capacity of every stream of a chunk: a value with k matches in len positions codes to at most
+// k + len/128 + 3*len/16384 bytes (one byte per token, +1 for each gap > 128, +3 for each gap > 16384).
+__global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint64_t* __restrict__ ctotal, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t f = C.first[c], e = C.first[c + 1];
+    const uint32_t len = R.pq[e] - R.pq[f], slen = R.pv[e].d - R.pv[f].d;
+    const uint32_t nn = D->n_normal; uint64_t run = 0;
+    const bool bycol = (D->flags & H_QUAL_BY_COL) && !(D->flags & H_DONT_QUAL);
+    const uint32_t* h = C.hist + (size_t)c * 256;
+    for (uint32_t j = 0; j < MAX_STREAMS; j++) {
+        uint32_t cap = 0;
+        if (j < nn) { if (bycol) cap = h[D->normal[j]] + len / 128 + 3 * (len / 16384) + 16; }
+        else if (j == nn) { if (D->flags & H_N_POS) cap = C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16; }
+        else if (j == nn + 1) { if (bycol) { uint32_t ex = 0; for (int v = 0; v < 256; v++) if (D->is_exception[v]) ex += h[v]; cap = 5 * ex + 16; } }
+        C.scap[(size_t)c * MAX_STREAMS + j] = cap; C.soff[(size_t)c * MAX_STREAMS + j] = run; C.ssize[(size_t)c * MAX_STREAMS + j] = 0;
+        run += (cap + 15u) & ~15u;
+    }
+    ctotal[c] = run;
+}
+
+// =============================================================== position coder (encodeSingleQualByCol, src/rfqcodec.cpp:625-710)
+// One wave codes one (chunk, stream).  A step covers 4096 positions: lane l owns the 64 positions [4096*step + 64*l, +64)
+// as a u64 match mask.  Closed form of the reference's state machine for a maximal streak of matches [a, E]:
+//   position a          gap token, d = a - (previous match or -1): 1 byte (d <= 128), 2 bytes (d <= 16384) or 4 bytes
+//   position 1 if a==0  gap token 0x00                                   (the `cur > 1` rule, Q3)
+//   positions a+b+32k   run token 0xC0 | (min(32, E - i + 1) - 1), b = (a == 0 ? 2 : 1)
+// Every token but the streak-start gap is one byte, so byte offsets need only the previous-match distance (a max-scan)
+// and the streak start (last zero position + 1, another max-scan); run lengths look at most 31 positions ahead.
+enum { PC_MATCH = 0, PC_EXCEPT = 1 };
+
+__device__ __forceinline__ uint64_t pc_load_mask(const uint8_t* __restrict__ B, uint32_t len, uint32_t p0, int mode, uint32_t q, const DevHeader* __restrict__ D) {
+    if (p0 >= len) return 0ull;
+    uint64_t m = 0;
+    const uint4* p = (const uint4*)(B + p0);
+    if (mode == PC_MATCH) {
+        const uint32_t pat = q * 0x01010101u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) m |= (uint64_t)eq_mask16(p[k], pat) << (16 * k);
+    } else {
+        for (int k = 0; k < 64; k++) if (D->is_exception[B[p0 + k]]) m |= 1ull << k;
+    }
+    if (len - p0 < 64) m &= (1ull << (len - p0)) - 1ull;
+    return m;
+}
+__device__ __forceinline__ uint32_t ones_from(uint64_t m, int s) {          // length of the run of ones starting at bit s (bit s is set)
+    const uint64_t inv = ~(m >> s);                                             // zero-extended: a zero appears within 64 - s bits unless s == 0 and m is all ones
+    return inv ? (uint32_t)(__ffsll((long long)inv) - 1) : 64u;
+}
+// B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Returns the stream size (wave-uniform).
+__device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ B, uint32_t len, int mode, uint32_t q, const DevHeader* __restrict__ D,
+                                                   uint8_t* __restrict__ out, uint32_t cap) {
+    const int l = lane_id();
+    uint32_t outpos = 0;
+    long long prev_carry = -1, zero_carry = -1;
+    const uint32_t nsteps = (len + 4095u) / 4096u;
+    uint64_t m_cur = nsteps ? pc_load_mask(B, len, 64u * (uint32_t)l, mode, q, D) : 0ull;
+    for (uint32_t step = 0; step < nsteps; step++) {
+        const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
+        const uint64_t m_next = (step + 1 < nsteps) ? pc_load_mask(B, len, p0 + 4096u, mode, q, D) : 0ull;
+        const uint64_t m = m_cur;
+        if (!__any(m != 0)) {                                              // nothing to code in these 4096 positions
+            zero_carry = (long long)(step * 4096u + 4095u); m_cur = m_next; continue;
+        }
+        // last match / last zero before my word (max-scans + carries from earlier steps)
+        long long mylast = m ? (long long)p0 + 63 - __clzll((long long)m) : -1;
+        long long myzero = (~m) ? (long long)p0 + 63 - __clzll((long long)~m) : -1;
+        const long long incl_last = wave_incl_max(mylast), incl_zero = wave_incl_max(myzero);
+        long long prev_in = __shfl_up(incl_last, 1u), zero_in = __shfl_up(incl_zero, 1u);
+        if (l == 0) { prev_in = -1; zero_in = -1; }
+        if (prev_carry > prev_in) prev_in = prev_carry;
+        if (zero_carry > zero_in) zero_in = zero_carry;
+        // matches continuing right after my word (for run lengths): leading ones of the next lane's word
+        const uint32_t lead = (m == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);
+        const uint32_t lead_n = (m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m_next) - 1);
+        uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
+        if (l == 63) after = after63;
+        uint32_t bytes = 0;
+        if (mode == PC_EXCEPT) bytes = 5u * (uint32_t)__popcll(m);
+        else {
+            uint64_t mm = m; long long prev = prev_in;
+            while (mm) {
+                const int s = __ffsll((long long)mm) - 1; const uint32_t run = ones_from(mm, s); const int e = s + (int)run - 1;
+                const long long abs_s = (long long)p0 + s, abs_e = (long long)p0 + e;
+                const long long a = s > 0 ? abs_s : zero_in + 1;
+                if (a == abs_s) { const long long d = abs_s - prev; bytes += d <= 128 ? 1u : (d <= 16384 ? 2u : 4u); if (a == 0 && run >= 2) bytes += 1; }
+                const long long b0 = a + (a == 0 ? 2 : 1);
+                long long i = b0; if (i < abs_s) i += ((abs_s - i + 31) / 32) * 32;
+                if (i <= abs_e) bytes += (uint32_t)((abs_e - i) / 32 + 1);
+                prev = abs_e;
+                mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
+            }
+        }
+        const uint32_t incl = wave_incl_sum(bytes);
+        uint32_t o = outpos + incl - bytes;
+        const uint32_t tot = __shfl(incl, 63);
+        if (outpos + tot <= cap) {
+            if (mode == PC_EXCEPT) {
+                uint64_t mm = m;
+                while (mm) { const int s = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)s]; st_u32(out + o + 1, p0 + (uint32_t)s); o += 5; }
+            } else {
+                uint64_t mm = m; long long prev = prev_in;
+                while (mm) {
+                    const int s = __ffsll((long long)mm) - 1; const uint32_t run = ones_from(mm, s); const int e = s + (int)run - 1;
+                    const long long abs_s = (long long)p0 + s, abs_e = (long long)p0 + e;
+                    const long long a = s > 0 ? abs_s : zero_in + 1;
+                    const uint32_t aft = (e == 63) ? after : 0u;
+                    if (a == abs_s) {
+                        const long long d = abs_s - prev; const uint32_t v = (uint32_t)(d - 1);
+                        if (d <= 128) out[o++] = (uint8_t)v;
+                        else if (d <= 16384) { out[o++] = (uint8_t)((v >> 8) | 0x80u); out[o++] = (uint8_t)v; }
+                        else { out[o++] = (uint8_t)((v >> 24) | 0xE0u); out[o++] = (uint8_t)(v >> 16); out[o++] = (uint8_t)(v >> 8); out[o++] = (uint8_t)v; }
+                        if (a == 0 && run >= 2) out[o++] = 0;
+                    }
+                    const long long b0 = a + (a == 0 ? 2 : 1);
+                    long long i = b0; if (i < abs_s) i += ((abs_s - i + 31) / 32) * 32;
+                    for (; i <= abs_e; i += 32) { long long rem = abs_e - i + 1 + (long long)aft; if (rem > 32) rem = 32; out[o++] = (uint8_t)(0xC0u | (uint32_t)(rem - 1)); }
+                    prev = abs_e;
+                    mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
+                }
+            }
+        }
+        outpos += tot;
+        const long long pl = __shfl(incl_last, 63), zl = __shfl(incl_zero, 63);
+        if (pl > prev_carry) prev_carry = pl;
+        if (zl > zero_carry) zero_carry = zl;
+        m_cur = m_next;
+    }
+    return outpos;
+}
+// grid (MAX_STREAMS, n_chunks), one wave per block
+__global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, DevStatus* st) {
+    const uint32_t j = blockIdx.x, c = blockIdx.y; const uint32_t nn = D->n_normal;
+    const size_t k = (size_t)c * MAX_STREAMS + j;
+    const uint32_t cap = C.scap[k];
+    if (cap == 0) return;                                                  // stream not present (uniform: one wave per block)
+    const uint32_t f = C.first[c], e = C.first[c + 1];
+    uint8_t* out = scratch + cbase[c] + C.soff[k];
+    uint32_t sz;
+    if (j < nn) sz = wave_pos_encode(qcat + C.qbase[c], R.pq[e] - R.pq[f], PC_MATCH, D->normal[j], D, out, cap);
+    else if (j == nn) sz = wave_pos_encode(scat + C.sbase[c], R.pv[e].d - R.pv[f].d, PC_MATCH, (uint32_t)'N', D, out, cap);
+    else sz = wave_pos_encode(qcat + C.qbase[c], R.pq[e] - R.pq[f], PC_EXCEPT, 0, D, out, cap);
+    if (lane_id() == 0) { C.ssize[k] = sz; if (sz > cap) atomicOr(&st->err, (uint32_t)DE_CORRUPT); }
+}
+
+// =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
+// One wave per (axis, chunk).  `last` always equals the previous element, so every token is local: a repeat element
+// closes a 0xC0|k token when it is the 32nd of its group or the next element is not a repeat.
+__global__ void k_coords(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint8_t* __restrict__ xs, uint8_t* __restrict__ ys, DevStatus* st) {
+    const uint32_t axis = blockIdx.x, c = blockIdx.y;
+    if (!(D->flags & (axis ? H_Y : H_X))) return;
+    const uint32_t f = C.first[c], e = C.first[c + 1]; const bool il = C.il[c] != 0;
+    const uint32_t stride = il ? 2u : 1u, num = (e - f) / stride;
+    const uint32_t* V = (axis ? R.y : R.x) + f;
+    uint8_t* out = (axis ? ys : xs) + 3ull * f;
+    const int l = lane_id();
+    uint32_t outpos = 0, carry_prev = 1000u, carry_rep = 0; long long carry_start = -1;
+    for (uint32_t base = 0; base < num; base += 64) {
+        const uint32_t i = base + (uint32_t)l; const bool valid = i < num;
+        const uint32_t v = valid ? V[(size_t)i * stride] : 0u;
+        uint32_t p = __shfl_up(v, 1u); if (l == 0) p = carry_prev;
+        const uint32_t rep = (valid && v == p) ? 1u : 0u;
+        const bool rep_next = (i + 1 < num) && V[(size_t)(i + 1) * stride] == v;
+        uint32_t rep_prev = __shfl_up(rep, 1u); if (l == 0) rep_prev = carry_rep;
+        long long sidx = (rep && !rep_prev) ? (long long)i : -1;
+        sidx = wave_incl_max(sidx); if (carry_start > sidx) sidx = carry_start;
+        uint32_t bytes = 0, kind = 0;                                       // kind 1: repeat close, 2: +diff, 3: 15-bit, 4: 21-bit
+        if (valid) {
+            if (rep) { const uint32_t k = (uint32_t)((long long)i - sidx); if (((k + 1) & 31u) == 0 || !rep_next) { bytes = 1; kind = 1; } }
+            else {
+                const int diff = (int)(v - p);
+                if (diff > 0 && diff <= 64) { bytes = 1; kind = 2; }
+                else if (v <= 32767u) { bytes = 2; kind = 3; }
+                else if (v < (1u << 21)) { bytes = 3; kind = 4; }
+                else { atomicOr(&st->err, (uint32_t)DE_COORD_RANGE); atomicMin((unsigned long long*)&st->coord_key, ((unsigned long long)c << 34) | ((unsigned long long)axis << 33) | (unsigned long long)i); }
+            }
+        }
+        const uint32_t incl = wave_incl_sum(bytes); uint32_t o = outpos + incl - bytes;
+        if (kind == 1) out[o] = (uint8_t)(0xC0u | (((uint32_t)((long long)i - sidx)) & 31u));
+        else if (kind == 2) out[o] = (uint8_t)(0x80u | (uint32_t)((int)(v - p) - 1));
+        else if (kind == 3) { out[o] = (uint8_t)(v >> 8); out[o + 1] = (uint8_t)v; }
+        else if (kind == 4) { out[o] = (uint8_t)((v >> 16) | 0xE0u); out[o + 1] = (uint8_t)(v >> 8); out[o + 2] = (uint8_t)v; }
+        outpos += __shfl(incl, 63);
+        carry_prev = __shfl(v, 63); carry_rep = __shfl(rep, 63); carry_start = __shfl(sidx, 63);
+    }
+    if (l == 0) { if (axis) C.ysize[c] = outpos; else C.xsize[c] = outpos; }
+}
+
+// =============================================================== chunk image (RfqChunk::calcTotalBufSize + write, src/rfqchunk.cpp:141-159,230-311)
+// mode 0: upper bound of the image size from stream capacities (before coding); mode 1: exact layout (after coding).
+__global__ void k_chunk_layout(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, Layout* __restrict__ L, uint32_t n_chunks, int exact, DevStatus* st) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t f = C.first[c], e = C.first[c + 1], s = e - f, fl = C.flags[c], hf = D->flags, rlb = D->read_len_bytes, nn = D->n_normal;
+    const bool il = (fl & C_PE_INTERLEAVED) != 0; const uint32_t h = il ? s / 2 : s;
+    const U4 a = R.pv[f], b = R.pv[e];
+    const uint32_t len = R.pq[e] - R.pq[f], seqCopied = b.d - a.d;
+    Layout o;
+    o.n_reads = s; o.flags = fl;
+    const uint32_t readLenBuf = (fl & C_READ_LEN_SAME) ? rlb : rlb * s;
+    const uint32_t n1Len = (fl & C_NAME1_LEN_SAME) ? 1 : s, n2Len = (fl & C_NAME2_LEN_SAME) ? 1 : s, stLen = (fl & C_STRAND_LEN_SAME) ? 1 : s;
+    o.n1_size = (fl & C_NAME1_SAME) ? R.name1_len[f] : b.a - a.a;
+    o.n2_size = (fl & C_NAME2_SAME) ? (R.pv[f + 1].b - a.b) : b.b - a.b;
+    o.st_size = (fl & C_STRAND_SAME) ? (R.pv[f + 1].c - a.c) : b.c - a.c;
+    o.seq_size = (seqCopied + 3) / 4;
+    const size_t k0 = (size_t)c * MAX_STREAMS;
+    uint32_t qsz = 0;
+    if (hf & H_DONT_QUAL) qsz = len;
+    else if (hf & H_QUAL_BY_COL) { qsz = 4 * nn; for (uint32_t j = 0; j < nn; j++) qsz += exact ? C.ssize[k0 + j] : C.scap[k0 + j]; qsz += exact ? C.ssize[k0 + nn + 1] : C.scap[k0 + nn + 1]; }
+    o.qual_size = qsz;
+    o.npos_size = (hf & H_N_POS) ? (exact ? C.ssize[k0 + nn] : C.scap[k0 + nn]) : 0;
+    o.x_size = (hf & H_X) ? (exact ? C.xsize[c] : 3 * h) : 0; o.y_size = (hf & H_Y) ? (exact ? C.ysize[c] : 3 * h) : 0;
+    uint32_t k = 18 + ((hf & H_N_POS) ? 4 : 0);
+    o.off_readlens = k; k += readLenBuf;
+    o.off_n1lens = k; k += n1Len;
+    o.off_n2lens = k; if (hf & H_NAME2) k += n2Len;
+    o.off_stlens = k; k += stLen;
+    o.off_lanes = k; if (hf & H_LANE) k += (fl & C_LANE_SAME) ? 1 : h;
+    o.off_tiles = k; if (hf & H_TILE) k += 2 * ((fl & C_TILE_SAME) ? 1 : h);
+    o.off_x = k; if (hf & H_X) k += 4 + o.x_size;
+    o.off_y = k; if (hf & H_Y) k += 4 + o.y_size;
+    o.off_n1 = k; k += o.n1_size;
+    o.off_n2 = k; if (hf & H_NAME2) k += o.n2_size;
+    o.off_st = k; k += o.st_size;
+    o.off_seq = k; k += o.seq_size;
+    o.off_qual = k; k += o.qual_size;
+    o.off_ov = k; if (il && (hf & H_PE_OVERLAP)) k += s / 2;
+    o.off_npos = k; if (hf & H_N_POS) k += o.npos_size;
+    o.total = k;
+    // mSize with the reference's accounting bug (Q1): tile bytes land in mLaneBufSize, mTileBufSize stays 0; the
+    // name2-length / name2 / "tile" bytes are counted even when the header lacks NAME2 / TILE; lane bytes never are.
+    const uint32_t laneBug = (fl & C_TILE_SAME) ? 2u : (il ? (2u * s) / 2u : 2u * s);
+    uint32_t ms = 18 + readLenBuf + n1Len + n2Len + stLen + laneBug + o.n1_size + o.n2_size + o.st_size + o.seq_size + o.qual_size;
+    if (il && (hf & H_PE_OVERLAP)) ms += s / 2;
+    if (hf & H_N_POS) ms += 4 + o.npos_size;
+    if (hf & H_X) ms += 4 + o.x_size;
+    if (hf & H_Y) ms += 4 + o.y_size;
+    o.msize = ms;
+    L[c] = o; C.img_size[c] = k;
+    if (exact && (hf & H_QUAL_BY_COL) && !(hf & H_DONT_QUAL)) {
+        // reference scratch is int(totalReadLen * 1.5) bytes (src/rfqcodec.cpp:413): a larger payload overflows its heap
+        const uint32_t lim = (uint32_t)((double)len * 1.5);
+        if (qsz > lim) atomicOr(&st->err, (uint32_t)DE_QUAL_OVERFLOW);
+    }
+}
+
+// grid (blocks_per_chunk, n_chunks): fixed fields, per-read arrays, coordinate streams, "same" names, packed bases,
+// quality payload, overlap bytes, N positions.
+__global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L,
+                           const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat, const uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
+                           const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
+                           uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2, DevStatus* st) {
+    const uint32_t c = blockIdx.y; const Layout o = L[c];
+    const uint64_t at = img_base + C.img_off[c];
+    if (at + o.total > img_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&st->err, 1u << 31); return; }
+    uint8_t* out = img + at;
+    const uint32_t f = C.first[c], s = o.n_reads, fl = o.flags, hf = D->flags, rlb = D->read_len_bytes, nn = D->n_normal;
+    const bool il = (fl & C_PE_INTERLEAVED) != 0; const uint32_t h = il ? s / 2 : s, hs = il ? 2u : 1u;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, NT = gridDim.x * blockDim.x;
+    const size_t k0 = (size_t)c * MAX_STREAMS;
+    if (t == 0) {
+        // line-break bits: set once the reference's reader has loaded the final (short) 1 MiB block (Q10)
+        uint32_t flags = fl;
+        const uint32_t last = f + s - 1;
+        if (T.paired == 1) {
+            const uint64_t e1 = off1 + (uint64_t)T.lo[0][4 * (size_t)(last >> 1) + 4] - 1, e2 = off2 + (uint64_t)T.lo[1][4 * (size_t)(last >> 1) + 4] - 1;
+            if (e1 >= nolb1) flags |= C_NO_LB;
+            if (e2 >= nolb2) flags |= C_NO_LB_R2;
+        } else {
+            const uint64_t e1 = off1 + (uint64_t)T.lo[0][4 * (size_t)last + 4] - 1;
+            if (e1 >= nolb1) { flags |= C_NO_LB; if (T.paired == 2) flags |= C_NO_LB_R2; }
+        }
+        st_u32(out, o.msize); st_u32(out + 4, s); st_u16(out + 8, flags); st_u32(out + 10, o.seq_size); st_u32(out + 14, o.qual_size);
+        if (hf & H_N_POS) st_u32(out + 18, o.npos_size);
+        if (fl & C_READ_LEN_SAME) { const uint32_t l0 = R.len[f]; for (uint32_t b = 0; b < rlb; b++) out[o.off_readlens + b] = (uint8_t)(l0 >> (8 * b)); }
+        if (fl & C_NAME1_LEN_SAME) out[o.off_n1lens] = (uint8_t)R.name1_len[f];
+        if ((hf & H_NAME2) && (fl & C_NAME2_LEN_SAME)) out[o.off_n2lens] = (uint8_t)name2_len_of(T, R, f);
+        if (fl & C_STRAND_LEN_SAME) out[o.off_stlens] = (uint8_t)line_len(T, f, 2);
+        if ((hf & H_LANE) && (fl & C_LANE_SAME)) out[o.off_lanes] = R.lane[f];
+        if ((hf & H_TILE) && (fl & C_TILE_SAME)) st_u16(out + o.off_tiles, R.tile[f]);
+        if (hf & H_X) st_u32(out + o.off_x, o.x_size);
+        if (hf & H_Y) st_u32(out + o.off_y, o.y_size);
+        if ((hf & H_QUAL_BY_COL) && !(hf & H_DONT_QUAL)) for (uint32_t j = 0; j < nn; j++) st_u32(out + o.off_qual + 4 * j, C.ssize[k0 + j]);
+    }
+    // per-read arrays
+    if (!(fl & C_READ_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) { const uint32_t v = R.len[f + i]; uint8_t* p = out + o.off_readlens + (size_t)i * rlb; for (uint32_t b = 0; b < rlb; b++) p[b] = (uint8_t)(v >> (8 * b)); }
+    if (!(fl & C_NAME1_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) out[o.off_n1lens + i] = (uint8_t)R.name1_len[f + i];
+    if ((hf & H_NAME2) && !(fl & C_NAME2_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) out[o.off_n2lens + i] = (uint8_t)name2_len_of(T, R, f + i);
+    if (!(fl & C_STRAND_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) out[o.off_stlens + i] = (uint8_t)line_len(T, f + i, 2);
+    if ((hf & H_LANE) && !(fl & C_LANE_SAME)) for (uint32_t i = t; i < h; i += NT) out[o.off_lanes + i] = R.lane[f + (size_t)i * hs];
+    if ((hf & H_TILE) && !(fl & C_TILE_SAME)) for (uint32_t i = t; i < h; i += NT) st_u16(out + o.off_tiles + 2 * (size_t)i, R.tile[f + (size_t)i * hs]);
+    if (hf & H_X) { const uint8_t* src = xs + 3ull * f; for (uint32_t i = t; i < o.x_size; i += NT) out[o.off_x + 4 + i] = src[i]; }
+    if (hf & H_Y) { const uint8_t* src = ys + 3ull * f; for (uint32_t i = t; i < o.y_size; i += NT) out[o.off_y + 4 + i] = src[i]; }
+    // names / strand that are stored once
+    if (fl & C_NAME1_SAME) { const uint8_t* src = line_ptr(T, f, 0); for (uint32_t i = t; i < o.n1_size; i += NT) out[o.off_n1 + i] = src[i]; }
+    if ((hf & H_NAME2) && (fl & C_NAME2_SAME)) { const uint8_t* src = line_ptr(T, f, 0) + R.name2_off[f]; for (uint32_t i = t; i < o.n2_size; i += NT) out[o.off_n2 + i] = src[i]; }
+    if (fl & C_STRAND_SAME) { const uint8_t* src = line_ptr(T, f, 2); for (uint32_t i = t; i < o.st_size; i += NT) out[o.off_st + i] = src[i]; }
+    // 2-bit bases: G=0 A=1 T=2 C=3, anything else 0 (src/rfqcodec.cpp:590-604)
+    {
+        const uint8_t* sb = scat + C.sbase[c]; const uint32_t n = R.pv[f + s].d - R.pv[f].d;
+        for (uint32_t i = t; i < o.seq_size; i += NT) {
+            uint32_t v = 0;
+            for (uint32_t b = 0; b < 4; b++) { const uint32_t p = 4 * i + b; if (p < n) { const uint8_t ch = sb[p]; const uint32_t code = ch == 'A' ? 1u : (ch == 'T' ? 2u : (ch == 'C' ? 3u : 0u)); v |= code << (2 * b); } }
+            out[o.off_seq + i] = (uint8_t)v;
+        }
+    }
+    // quality payload
+    if (hf & H_DONT_QUAL) { const uint8_t* src = qcat + C.qbase[c]; for (uint32_t i = t; i < o.qual_size; i += NT) out[o.off_qual + i] = src[i]; }
+    else if (hf & H_QUAL_BY_COL) {
+        uint32_t dst = o.off_qual + 4 * nn; const uint8_t* sc = scratch + cbase[c];
+        for (uint32_t j = 0; j <= nn; j++) {
+            const uint32_t js = j < nn ? j : nn + 1;                      // normal streams in header order, then the exception records
+            const uint32_t sz = C.ssize[k0 + js]; const uint8_t* src = sc + C.soff[k0 + js];
+            for (uint32_t i = t; i < sz; i += NT) out[dst + i] = src[i];
+            dst += sz;
+        }
+    }
+    if (il && (hf & H_PE_OVERLAP)) for (uint32_t i = t; i < s / 2; i += NT) out[o.off_ov + i] = (uint8_t)ovb[(f >> 1) + i];
+    if (hf & H_N_POS) { const uint8_t* src = scratch + cbase[c] + C.soff[k0 + nn]; for (uint32_t i = t; i < o.npos_size; i += NT) out[o.off_npos + i] = src[i]; }
+}
+// names / strands that differ inside the chunk: one wave per read copies its pieces to their prefix-sum offsets
+__global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L, uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base) {
+    const uint32_t c = blockIdx.y; const uint32_t fl = C.flags[c];
+    const bool need1 = !(fl & C_NAME1_SAME), need2 = (D->flags & H_NAME2) && !(fl & C_NAME2_SAME), need3 = !(fl & C_STRAND_SAME);
+    if (!need1 && !need2 && !need3) return;
+    const Layout o = L[c]; const uint64_t at = img_base + C.img_off[c];
+    if (at + o.total > img_cap) return;
+    uint8_t* out = img + at;
+    const uint32_t f = C.first[c], e = f + o.n_reads; const uint32_t wpb = blockDim.x >> 6; const int l = lane_id();
+    const U4 a = R.pv[f];
+    for (uint32_t g = f + blockIdx.x * wpb + (uint32_t)wave_id(); g < e; g += gridDim.x * wpb) {
+        const U4 p = R.pv[g]; const uint8_t* nm = line_ptr(T, g, 0);
+        if (need1) { const uint32_t n = R.name1_len[g]; uint8_t* d = out + o.off_n1 + (p.a - a.a); for (uint32_t i = (uint32_t)l; i < n; i += 64) d[i] = nm[i]; }
+        if (need2) { const uint32_t n = name2_len_of(T, R, g); const uint8_t* src = nm + R.name2_off[g]; uint8_t* d = out + o.off_n2 + (p.b - a.b); for (uint32_t i = (uint32_t)l; i < n; i += 64) d[i] = src[i]; }
+        if (need3) { const uint32_t n = line_len(T, g, 2); const uint8_t* src = line_ptr(T, g, 2); uint8_t* d = out + o.off_st + (p.c - a.c); for (uint32_t i = (uint32_t)l; i < n; i += 64) d[i] = src[i]; }
+    }
+}
+__global__ void k_enc_totals(ChunkTab C, const uint64_t* __restrict__ ctotal_prefix, uint32_t n_chunks, int which, DevStatus* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (which == 0) { st->total_scratch = ctotal_prefix[n_chunks]; st->image_bound = C.img_off[n_chunks]; }
+    else st->total_image = C.img_off[n_chunks];
+}

@@ -1,0 +1,73 @@
+"""CPU: kernel LOGIC of the encode path under the SIMT interpreter (tests/emu) — the same .hip sources compiled by g++,
+every HIP thread a fiber, wave64 collectives as rendezvous.  This is test infrastructure for a GPU-less box; parity
+proper is tests/test_gpu_*.py on the MI355X.  Sizes are kept small: the interpreter is ~1000x slower than the GPU."""
+import json
+import os
+
+import pytest
+
+import _engine as E
+import _oracle as O
+from cases import CASES
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES_J = json.load(open(os.path.join(G, "cases.json")))
+
+
+@pytest.fixture(scope="module")
+def codec():
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    assert "simt-emulation" in c.version()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_case_matches_reference_golden(codec, name):
+    E.check_case(codec, name, CASES[name], CASES_J[name])
+
+
+MULTI = [
+    ("se150", O.NOVA_SE150, 600, 2, 20000, O.SE, {}),
+    ("se150_manyN", O.NOVA_SE150, 600, 2, 20000, O.SE, dict(nppm=5000)),
+    ("se_var", O.SE_VAR, 600, 3, 15000, O.SE, {}),
+    ("pe150", O.NOVA_PE150, 300, 4, 20000, O.PE_TWO_FILES, {}),
+    ("pe150_interleaved_in", O.NOVA_PE150, 300, 4, 20000, O.PE_INTERLEAVED, dict(interleaved=True)),
+    ("bgi_q40", O.BGI_PE100, 300, 5, 10000, O.PE_TWO_FILES, dict(n_quals=40)),
+    ("se150_no_final_newline", O.NOVA_SE150, 500, 6, 7777, O.SE, dict(nonl=1)),
+    ("pe150_r2_no_final_newline", O.NOVA_PE150, 300, 7, 9000, O.PE_TWO_FILES, dict(nonl=2, nppm=3000)),
+    ("se150_single_chunk", O.NOVA_SE150, 700, 8, 1_000_000, O.SE, {}),
+]
+
+
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI, ids=[m[0] for m in MULTI])
+def test_multichunk_matches_oracle(codec, label, prof, reads, seed, cb, paired, kw):
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+
+
+def test_batched_encode_with_carry_over_equals_one_shot(codec):
+    """Repaq::compress reads a stream; the host driver feeds it in batches: non-final batches stop at the last full chunk and
+    report consumed bytes, the remainder is carried into the next batch.  Concatenation must equal the one-shot image."""
+    fq1, _ = O.gen(O.NOVA_SE150, 900, seed=21)
+    cb = 12000
+    want = O.encode_file(fq1, b"", O.SE, cb)
+    codec.clearHeader()
+    out = b""; pos = 0; step = 100_000; first = True
+    while pos < len(fq1):
+        end = min(len(fq1), pos + step); final = end == len(fq1)
+        # cut the batch at a record boundary: keep whole 4-line records only (host driver's job)
+        buf = fq1[pos:end]
+        if not final:
+            nl = [i for i, b in enumerate(buf) if b == 10]
+            keep = nl[(len(nl) // 4) * 4 - 1] + 1
+            buf = buf[:keep]
+        d = codec.dev_put(buf)
+        r = codec.encode(d, len(buf), None, 0, O.SE, cb, final=final, emit_header=first, file_off1=pos)
+        out += codec.dev_get(r.d_rfq, r.rfq_len) if r.rfq_len else b""
+        codec.dev_free(d)
+        assert r.consumed1 > 0 or final
+        pos += r.consumed1 if not final else len(buf)
+        first = False
+    assert out == want
