@@ -31,7 +31,9 @@
 
 #define WAVE 64
 #define NL_BLOCK_BYTES 16384u        // one workgroup of the newline pass covers 16 KiB = 256 lanes x 64 B
-#define MAX_STREAMS 66               // <= 64 normal quality values + N positions + exceptions
+#define MAX_STREAMS 66               // stream slots of a chunk: [0,64) normal quality values (by-col coding implies <= 64 bins),
+#define NPOS_SLOT 64                 //   slot 64 = N positions, slot 65 = exception records
+#define EXC_SLOT 65
 
 // device error bits accumulated in DevStatus::err
 #define DE_HAS_CR          (1u << 0)  // '\r' in the text
@@ -151,3 +153,8 @@ __device__ __forceinline__ void st_u16(uint8_t* p, uint32_t v) { p[0] = (uint8_t
 __device__ __forceinline__ void st_u32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// complement rule of Read::changeToReverseComplement (src/read.cpp:77-115): either case maps to the upper-case complement, anything else to N
+__device__ __forceinline__ uint8_t comp_base(uint8_t b) {
+    switch (b) { case 'A': case 'a': return 'T'; case 'T': case 't': return 'A'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; default: return 'N'; }
+}

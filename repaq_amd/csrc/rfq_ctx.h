@@ -46,7 +46,7 @@ struct rfq_ctx {
     DevHeader h_hdr; bool have_hdr = false;
     DBuf d_status; DevStatus h_status;
     // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
-    DBuf b[64];
+    DBuf b[96];
     DBuf out_img, out_fq1, out_fq2;
     std::vector<uint64_t> chunk_off;
     StageTimer timer;

@@ -1,6 +1,135 @@
-// rfq_decode.hip — RFQ -> FASTQ path (stub until the decode kernels land; fails loudly).
+// rfq_decode.hip — host orchestration of the gfx950 RFQ -> FASTQ path (rfq_decode_batch of include/rfq_hip.h).
+// Replaces, per image: RfqHeader::read (src/rfqheader.cpp:19-43), RfqChunk::read (src/rfqchunk.cpp:161-228),
+// RfqCodec::decodeChunk (src/rfqcodec.cpp:826-1260) and the text emission of Repaq::decompress / decompressPE
+// (src/repaq.cpp:262-417; final-newline rule :301-328,375-413).
 #include "rfq_ctx.h"
+#include "rfq_decode_kernels.h"
+#include <algorithm>
+#include <cstring>
+
+int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
+
+enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
+    DB_CHUNKS = 64, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_END
+};
+static_assert(DB_END <= 96, "rfq_ctx::b too small");
+
 extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_decode_result* res) {
     if (!ctx || !a || !res) return RFQ_E_ARG;
-    return rfq_fail(ctx, RFQ_E_STATE, "rfq_decode_batch: not built yet");
+    memset(res, 0, sizeof *res);
+    ctx->err.clear();
+    if (a->n && !a->d_rfq) return rfq_fail(ctx, RFQ_E_ARG, "null rfq pointer");
+    hipStream_t S = ctx->stream; DBuf* B = ctx->b;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->timer.reset();
+    uint64_t start = 0;
+    if (a->has_header) {
+        uint8_t hb[RFQ_HEADER_MAX]; const size_t take = std::min<size_t>(a->n, sizeof hb);
+        if (take) HIPCHK(ctx, hipMemcpy(hb, a->d_rfq, take, hipMemcpyDeviceToHost));
+        int rc = rfq_upload_header(ctx, hb, take);
+        if (rc) return rc;
+        start = ctx->h_hdr.len;
+    } else if (!ctx->have_hdr) return rfq_fail(ctx, RFQ_E_STATE, "decode without a header: pass has_header=1 or call rfq_set_header first");
+    const DevHeader& HH = ctx->h_hdr;
+    if (a->split_pe && !(HH.flags & H_PAIRED)) return rfq_fail(ctx, RFQ_E_DATA, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>");
+    if (!(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL))) return rfq_fail(ctx, RFQ_E_FORMAT, "run-length quality coding (legacy) is not produced by repaq v0.5.1 and is not decoded on device");
+    if (HH.read_len_bytes != 1 && HH.read_len_bytes != 2 && HH.read_len_bytes != 4) return rfq_fail(ctx, RFQ_E_DATA, "header incorrect: read length bytes should be 1/2/4");
+    const DevHeader* D = ctx->d_hdr.as<DevHeader>();
+
+    // ---- walk the chunk chain
+    ctx->timer.begin("walk", S);
+    HIPCHK(ctx, B[DB_STATUS].ensure(sizeof(DecStatus)));
+    DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs;
+    uint32_t cap = (uint32_t)std::max<size_t>(B[DB_CHUNKS].cap / sizeof(DChunk), 4096);
+    for (;;) {
+        HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
+        HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
+        hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
+        KCHK(ctx, "k_dec_walk");
+        HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+        HIPCHK(ctx, hipStreamSynchronize(S));
+        if (!hs.overflow) break;
+        cap = hs.n_chunks + 1024;
+    }
+    ctx->timer.end(S);
+    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "truncated or corrupt rfq chunk at byte %llu", (unsigned long long)hs.consumed);
+    const uint32_t n_chunks = hs.n_chunks; const uint64_t n_reads64 = hs.total_reads;
+    res->consumed = (size_t)hs.consumed; res->n_chunks = n_chunks; res->n_reads = n_reads64;
+    if (n_chunks == 0) return RFQ_OK;
+    const uint32_t n_reads = (uint32_t)n_reads64, max_reads = std::max(hs.max_reads, 1u);
+    const DChunk* CH = B[DB_CHUNKS].as<DChunk>();
+    const uint32_t last_flags = hs.last_flags;
+
+    // ---- read table + prefixes
+    ctx->timer.begin("read_table", S);
+    const size_t nr = (size_t)n_reads + 2, nc = (size_t)n_chunks + 2;
+    HIPCHK(ctx, B[DB_LEN].ensure(nr * 4)); HIPCHK(ctx, B[DB_CHUNKID].ensure(nr * 4)); HIPCHK(ctx, B[DB_OV].ensure(nr * 4));
+    HIPCHK(ctx, B[DB_PVIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_PV].ensure(nr * 16)); HIPCHK(ctx, B[DB_PQ].ensure(nr * 4));
+    HIPCHK(ctx, B[DB_TIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_TP].ensure(nr * 16));
+    HIPCHK(ctx, B[DB_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[DB_SBASE].ensure(nc * 8));
+    HIPCHK(ctx, B[DB_XV].ensure(nr * 4)); HIPCHK(ctx, B[DB_YV].ensure(nr * 4));
+    HIPCHK(ctx, B[DB_SCAN].ensure((nr / SCAN_TILE + 2) * 16 + 1024));
+    DReadTab R; R.len = B[DB_LEN].as<uint32_t>(); R.chunk = B[DB_CHUNKID].as<uint32_t>(); R.ov = B[DB_OV].as<int32_t>();
+    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>();
+    hipLaunchKernelGGL(k_dec_readtab, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, dst);
+    KCHK(ctx, "k_dec_readtab");
+    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
+    scan_exclusive<U4>(S, R.pvin, R.pv, n_reads, B[DB_SCAN].as<U4>(), 1);
+    uint32_t total_bases = 0; U4 pv_tot;
+    HIPCHK(ctx, hipMemcpyAsync(&total_bases, R.pq + n_reads, 4, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipMemcpyAsync(&pv_tot, R.pv + n_reads, 16, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    ctx->timer.end(S);
+    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");
+    res->n_bases = total_bases;
+
+    // ---- streams
+    ctx->timer.begin("streams", S);
+    const size_t qbytes = (size_t)total_bases + 64 * nc + 256, sbytes = (size_t)pv_tot.d + 64 * nc + 256;
+    HIPCHK(ctx, B[DB_QDEC].ensure(qbytes)); HIPCHK(ctx, B[DB_SDEC].ensure(sbytes));
+    uint64_t* qbase = B[DB_QBASE].as<uint64_t>(); uint64_t* sbase = B[DB_SBASE].as<uint64_t>();
+    uint8_t* qdec = B[DB_QDEC].as<uint8_t>(); uint8_t* sdec = B[DB_SDEC].as<uint8_t>();
+    hipLaunchKernelGGL(k_dec_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, CH, R, qbase, sbase, n_chunks);
+    hipLaunchKernelGGL(k_dec_fill, dim3(2048), dim3(256), 0, S, qdec, (uint64_t)qbytes, D);
+    const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
+    hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec);
+    hipLaunchKernelGGL(k_dec_pos, dim3(MAX_STREAMS, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec, dst);
+    hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
+    hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
+    KCHK(ctx, "k_dec_streams");
+    ctx->timer.end(S);
+
+    // ---- text
+    ctx->timer.begin("text", S);
+    const int split = a->split_pe ? 1 : 0;
+    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split);
+    scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
+    U4 tt;
+    HIPCHK(ctx, hipMemcpyAsync(&tt, R.tp + n_reads, 16, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
+    // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
+    uint8_t *o1, *o2; uint64_t cap1, cap2;
+    if (a->d_out1) { o1 = a->d_out1; cap1 = a->cap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
+    if (a->d_out2) { o2 = a->d_out2; cap2 = a->cap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
+    {
+        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 3) / 4, std::max(1u, 8192u / n_chunks)));
+        hipLaunchKernelGGL(k_dec_emit, dim3(bx, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(),
+                           (const uint64_t*)qbase, (const uint64_t*)sbase, (const uint8_t*)qdec, (const uint8_t*)sdec, split, o1, cap1, o2, cap2, dst);
+        KCHK(ctx, "k_dec_emit");
+    }
+    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    ctx->timer.end(S);
+    ctx->timer.collect();
+    if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %u / %u bytes", tt.a, tt.b);
+    size_t n1 = tt.a, n2 = tt.b;
+    if (a->final) {   // Repaq::decompress*: drop the final '\n' when the last chunk carries the NO_LINE_BREAK bit
+        if ((last_flags & C_NO_LB) && n1) n1--;
+        if (split && (last_flags & C_NO_LB_R2) && n2) n2--;
+    }
+    res->d_fq1 = o1; res->n1 = n1; res->d_fq2 = split ? o2 : nullptr; res->n2 = split ? n2 : 0;
+    return RFQ_OK;
 }

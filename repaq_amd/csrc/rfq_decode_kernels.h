@@ -1,0 +1,337 @@
+// rfq_decode_kernels.h — gfx950 kernels of the RFQ -> FASTQ decode path (included by rfq_decode.hip only).
+//
+//   walk     k_dec_walk                 RfqChunk::read for every chunk: section offsets (the reader ignores mSize,
+//                                       src/rfqchunk.cpp:161-228), running read base
+//   table    k_dec_readtab + scans      per-read lengths, overlap values, stored lengths, name/strand piece lengths
+//   streams  k_dec_unpack, k_dec_pos, k_dec_except, k_dec_coords
+//                                       decodeSeqQual / decodeSingleQualByCol / decodeQualByCol / decodeCoords
+//                                       (src/rfqcodec.cpp:826-1047,1332-1389)
+//   text     k_dec_textlen + scan, k_dec_emit
+//                                       decodeChunk's per-read loop + Read::toString (src/rfqcodec.cpp:1141-1254, src/read.cpp:170)
+#pragma once
+#include "rfq_common.h"
+
+struct DChunk {                  // one parsed chunk (offsets relative to the chunk start)
+    uint64_t off;                // byte offset of the chunk in the image
+    uint32_t reads, flags, seq_size, qual_size, npos_size, x_size, y_size;
+    uint32_t o_readlens, o_n1lens, o_n2lens, o_stlens, o_lanes, o_tiles, o_x, o_y, o_n1, o_n2, o_st, o_seq, o_qual, o_ov, o_npos, total;
+    uint32_t n1_size, n2_size, st_size;
+    uint32_t rbase;              // reads in earlier chunks
+};
+struct DecStatus {
+    uint32_t err, n_chunks, max_reads, overflow;
+    uint64_t total_reads, consumed, total_bases, total_stored, text1, text2;
+    uint32_t last_flags, pad;
+};
+
+// sum of n bytes by one wave (wave-uniform result)
+__device__ __forceinline__ uint32_t wave_sum_bytes(const uint8_t* __restrict__ p, uint32_t n) {
+    uint32_t acc = 0;
+    for (uint32_t i = (uint32_t)lane_id(); i < n; i += 64) acc += p[i];
+    return wave_sum(acc);
+}
+// One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays).
+__global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st) {
+    const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
+    uint64_t k = start; uint32_t c = 0, maxr = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
+    if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
+    while (!err) {
+        if (n - k < 18) break;                                   // clean EOF (or trailing garbage shorter than a chunk head)
+        const uint8_t* p = img + k;
+        DChunk d; d.off = k;
+        d.reads = ld_u32(p + 4); d.flags = ld_u16(p + 8); d.seq_size = ld_u32(p + 10); d.qual_size = ld_u32(p + 14);
+        if (d.reads == 0) break;
+        const uint64_t left = n - k; uint64_t q = 18;
+        d.npos_size = 0; if (hf & H_N_POS) { if (left < q + 4) { err = DE_CORRUPT; break; } d.npos_size = ld_u32(p + q); q += 4; }
+        const uint32_t s = d.reads, fl = d.flags; const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s;
+        d.o_readlens = (uint32_t)q; q += (uint64_t)((fl & C_READ_LEN_SAME) ? 1u : s) * rlb;
+        if (q > left) { err = DE_CORRUPT; break; }
+#define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
+            const uint32_t m_ = (fl & (LENFLAG)) ? 1u : s; OFF = (uint32_t)q; if (q + m_ > left) { err = DE_CORRUPT; break; } \
+            uint32_t sum_ = (fl & (LENFLAG)) ? (uint32_t)p[q] : wave_sum_bytes(p + q, m_); \
+            if ((fl & (LENFLAG)) && !(fl & (SAMEFLAG))) sum_ *= s; SIZE = sum_; q += m_; }
+        RFQ_LENARR(d.o_n1lens, d.n1_size, C_NAME1_LEN_SAME, C_NAME1_SAME)
+        d.o_n2lens = (uint32_t)q; d.n2_size = 0;
+        if (hf & H_NAME2) RFQ_LENARR(d.o_n2lens, d.n2_size, C_NAME2_LEN_SAME, C_NAME2_SAME)
+        RFQ_LENARR(d.o_stlens, d.st_size, C_STRAND_LEN_SAME, C_STRAND_SAME)
+#undef RFQ_LENARR
+        d.o_lanes = (uint32_t)q; if (hf & H_LANE) q += (fl & C_LANE_SAME) ? 1u : h;
+        d.o_tiles = (uint32_t)q; if (hf & H_TILE) q += 2ull * ((fl & C_TILE_SAME) ? 1u : h);
+        d.x_size = 0; d.y_size = 0;
+        d.o_x = (uint32_t)q; if (hf & H_X) { if (q + 4 > left) { err = DE_CORRUPT; break; } d.x_size = ld_u32(p + q); q += 4ull + d.x_size; }
+        if (q > left) { err = DE_CORRUPT; break; }
+        d.o_y = (uint32_t)q; if (hf & H_Y) { if (q + 4 > left) { err = DE_CORRUPT; break; } d.y_size = ld_u32(p + q); q += 4ull + d.y_size; }
+        d.o_n1 = (uint32_t)q; q += d.n1_size;
+        d.o_n2 = (uint32_t)q; if (hf & H_NAME2) q += d.n2_size;
+        d.o_st = (uint32_t)q; q += d.st_size;
+        d.o_seq = (uint32_t)q; q += d.seq_size;
+        d.o_qual = (uint32_t)q; q += d.qual_size;
+        d.o_ov = (uint32_t)q; if ((fl & C_PE_INTERLEAVED) && (hf & H_PE_OVERLAP)) q += s / 2;
+        d.o_npos = (uint32_t)q; if (hf & H_N_POS) q += d.npos_size;
+        if (q > left || q > 0xFFFFFFFFull) { err = DE_CORRUPT; break; }
+        d.total = (uint32_t)q; d.rbase = (uint32_t)rb;
+        if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
+        if (s > maxr) maxr = s;
+        lastfl = fl; rb += s; k += q; c++;
+        if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
+    }
+    if (l == 0) { st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; }
+}
+
+struct DReadTab {
+    uint32_t* len; uint32_t* chunk; int32_t* ov; U4* pvin; U4* pv; uint32_t* pq; U4* tin; U4* tp;
+};
+__device__ __forceinline__ uint32_t dec_read_len(const uint8_t* cp, const DChunk& d, uint32_t rlb, uint32_t r) {
+    const uint8_t* p = cp + d.o_readlens + (size_t)((d.flags & C_READ_LEN_SAME) ? 0u : r) * rlb;
+    return rlb == 1 ? p[0] : (rlb == 2 ? ld_u16(p) : ld_u32(p));
+}
+// grid (ceil(max_reads/256), n_chunks)
+__global__ void k_dec_readtab(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R, DecStatus* st) {
+    const DChunk d = CH[blockIdx.y]; const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.reads) return;
+    const uint8_t* cp = img + d.off; const uint32_t g = d.rbase + r, fl = d.flags, hf = D->flags;
+    const uint32_t len = dec_read_len(cp, d, D->read_len_bytes, r);
+    U4 v;
+    v.a = (fl & C_NAME1_SAME) ? 0u : cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
+    v.b = ((hf & H_NAME2) && !(fl & C_NAME2_SAME)) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
+    v.c = (fl & C_STRAND_SAME) ? 0u : cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
+    int ov = 0; uint32_t stored = len;
+    if ((fl & C_PE_INTERLEAVED) && (hf & H_PE_OVERLAP) && (r & 1u)) {
+        ov = (int)(int8_t)cp[d.o_ov + r / 2] - D->overlap_shift;
+        const uint32_t a = (uint32_t)(ov < 0 ? -ov : ov);
+        const uint32_t prevlen = dec_read_len(cp, d, D->read_len_bytes, r - 1);
+        if (a > len || a > prevlen) { atomicOr(&st->err, (uint32_t)DE_CORRUPT); ov = 0; } else stored = len - a;
+    }
+    v.d = stored;
+    R.len[g] = len; R.chunk[g] = blockIdx.y; R.ov[g] = ov; R.pvin[g] = v;
+}
+// aligned bases of each chunk inside the concatenated quality / stored-sequence buffers
+__global__ void k_dec_bases(const DChunk* __restrict__ CH, DReadTab R, uint64_t* __restrict__ qbase, uint64_t* __restrict__ sbase, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_chunks) { const uint32_t f = CH[c].rbase; qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c; sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
+}
+
+// 2-bit unpack (src/rfqcodec.cpp:833-853): grid (blocks, n_chunks)
+__global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec) {
+    const DChunk d = CH[blockIdx.y]; const uint32_t f = d.rbase;
+    const uint32_t n = R.pv[f + d.reads].d - R.pv[f].d;          // stored bases of the chunk
+    const uint8_t* src = img + d.off + d.o_seq; uint8_t* dst = sdec + sbase[blockIdx.y];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (n + 3) / 4; i += gridDim.x * blockDim.x) {
+        const bool have = i < d.seq_size; const uint32_t v = have ? src[i] : 0u;     // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
+        for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t p = 4 * i + b; if (p >= n) break;
+            const uint32_t code = (v >> (2 * b)) & 3u;
+            dst[p] = have ? (code == 0 ? 'G' : (code == 1 ? 'A' : (code == 2 ? 'T' : 'C'))) : 'N';
+        }
+    }
+}
+
+// ---- token-boundary automaton: state = bytes of the current token still to skip (0 = next byte starts a token).
+// A byte's transition is s>0 ? s-1 : len(byte)-1; composition of 4-entry tables is associative -> wave scan.
+__device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) {     // (then o first)[s] = then[first[s]]
+    uint32_t r = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) r |= ((then >> (2 * ((first >> (2 * s)) & 3u))) & 3u) << (2 * s);
+    return r;
+}
+// returns the state BEFORE this lane's byte; carry = state after the wave's last byte
+__device__ __forceinline__ uint32_t wave_token_states(uint32_t tok_len, bool valid, uint32_t& carry) {
+    const int l = lane_id();
+    uint32_t f = valid ? ((tok_len - 1u) | (0u << 2) | (1u << 4) | (2u << 6)) : (0u | (1u << 2) | (2u << 4) | (3u << 6));
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(f, (unsigned)d); if (l >= d) f = fn_compose(t, f); }
+    const uint32_t after = (f >> (2 * carry)) & 3u;
+    uint32_t before = __shfl_up(after, 1u); if (l == 0) before = carry;
+    carry = __shfl(after, 63);
+    return before;
+}
+// decodeSingleQualByCol (src/rfqcodec.cpp:957-1007): one wave per (stream, chunk); writes q at every coded position.
+__device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, uint32_t slen, uint8_t q, uint8_t* __restrict__ out, uint32_t out_len) {
+    const int l = lane_id(); uint32_t carry = 0; long long last = -1;
+    for (uint32_t base = 0; base < slen; base += 64) {
+        const uint32_t i = base + (uint32_t)l; const bool valid = i < slen;
+        const uint32_t b0 = valid ? sp[i] : 0u;
+        const uint32_t tl = (b0 & 0x80u) == 0 ? 1u : ((b0 & 0x40u) == 0 ? 2u : ((b0 & 0x20u) == 0 ? 1u : 4u));
+        const uint32_t before = wave_token_states(tl, valid, carry);
+        const bool start = valid && before == 0;
+        long long adv = 0; uint32_t run = 0;
+        if (start) {
+            if ((b0 & 0x80u) == 0) adv = (long long)b0 + 1;
+            else if ((b0 & 0x40u) == 0) adv = (long long)(((b0 & 0x3Fu) << 8) | (i + 1 < slen ? sp[i + 1] : 0u)) + 1;
+            else if ((b0 & 0x20u) == 0) { run = (b0 & 0x1Fu) + 1; adv = run; }
+            else {
+                const uint32_t b1 = i + 1 < slen ? sp[i + 1] : 0u, b2 = i + 2 < slen ? sp[i + 2] : 0u, b3 = i + 3 < slen ? sp[i + 3] : 0u;
+                adv = (long long)(int32_t)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
+            }
+        }
+        const long long incl = wave_incl_sum(adv); const long long end = last + incl;     // position of this token's last covered base
+        if (start) {
+            if (run) { for (uint32_t k = 0; k < run; k++) { const long long p = end - (long long)run + 1 + k; if (p >= 0 && p < (long long)out_len) out[p] = q; } }
+            else if (end >= 0 && end < (long long)out_len) out[end] = q;
+        }
+        last += __shfl(incl, 63);
+    }
+}
+// grid (MAX_STREAMS, n_chunks): normal quality streams -> qdec, N positions -> sdec
+__global__ void k_dec_pos(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                          const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ qdec, uint8_t* __restrict__ sdec, DecStatus* st) {
+    const uint32_t j = blockIdx.x, c = blockIdx.y, nn = D->n_normal, hf = D->flags;
+    const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint32_t f = d.rbase;
+    if (j == NPOS_SLOT) {
+        if (!(hf & H_N_POS)) return;
+        wave_pos_decode(cp + d.o_npos, d.npos_size, (uint8_t)'N', sdec + sbase[c], R.pv[f + d.reads].d - R.pv[f].d);
+        return;
+    }
+    if (j >= nn || j >= NPOS_SLOT || (hf & H_DONT_QUAL) || !(hf & H_QUAL_BY_COL)) return;
+    if (4ull * nn > d.qual_size) { if (lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return; }
+    const uint8_t* qp = cp + d.o_qual; uint64_t off = 4ull * nn;
+    for (uint32_t i = 0; i < j; i++) off += ld_u32(qp + 4 * i);
+    const uint32_t sl = ld_u32(qp + 4 * j);
+    if (off + sl > d.qual_size) { if (lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return; }
+    wave_pos_decode(qp + off, sl, D->normal[j], qdec + qbase[c], R.pq[f + d.reads] - R.pq[f]);
+}
+// exception records (q, u32 LE position) after the streams (src/rfqcodec.cpp:1034-1043); raw copy when DONT_ENCODE_QUAL (:905-910)
+__global__ void k_dec_except(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                             const uint64_t* __restrict__ qbase, uint8_t* __restrict__ qdec) {
+    const uint32_t c = blockIdx.y, nn = D->n_normal, hf = D->flags;
+    const DChunk d = CH[c]; const uint8_t* qp = img + d.off + d.o_qual; const uint32_t f = d.rbase;
+    const uint32_t len = R.pq[f + d.reads] - R.pq[f]; uint8_t* dst = qdec + qbase[c];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, NT = gridDim.x * blockDim.x;
+    if (hf & H_DONT_QUAL) { for (uint32_t i = t; i < d.qual_size && i < len; i += NT) dst[i] = qp[i]; return; }
+    if (!(hf & H_QUAL_BY_COL) || 4ull * nn > d.qual_size) return;
+    uint64_t off = 4ull * nn;
+    for (uint32_t i = 0; i < nn; i++) off += ld_u32(qp + 4 * i);
+    if (off > d.qual_size) return;
+    const uint32_t nrec = (uint32_t)((d.qual_size - off) / 5);
+    for (uint32_t i = t; i < nrec; i += NT) { const uint8_t* r = qp + off + 5ull * i; const uint32_t pos = ld_u32(r + 1); if (pos < len) dst[pos] = r[0]; }
+}
+// quality prefill with the major value (src/rfqcodec.cpp:1089)
+__global__ void k_dec_fill(uint8_t* __restrict__ p, uint64_t n, const DevHeader* __restrict__ D) {
+    const uint32_t v = D->major & 0xFFu; const uint4 q = make_uint4(v * 0x01010101u, v * 0x01010101u, v * 0x01010101u, v * 0x01010101u);
+    uint4* p4 = (uint4*)p; const uint64_t n4 = n / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) p4[i] = q;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15u)) p[n4 * 16 + threadIdx.x] = (uint8_t)v;
+}
+
+// decodeCoords (src/rfqcodec.cpp:1332-1389): one wave per (axis, chunk)
+__global__ void k_dec_coords(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, uint32_t* __restrict__ xv, uint32_t* __restrict__ yv) {
+    const uint32_t axis = blockIdx.x, c = blockIdx.y;
+    if (!(D->flags & (axis ? H_Y : H_X))) return;
+    const DChunk d = CH[c]; const uint8_t* sp = img + d.off + (axis ? d.o_y : d.o_x) + 4; const uint32_t slen = axis ? d.y_size : d.x_size;
+    const uint32_t num = (d.flags & C_PE_INTERLEAVED) ? d.reads / 2 : d.reads;
+    uint32_t* out = (axis ? yv : xv) + d.rbase;
+    const int l = lane_id(); uint32_t carry = 0, cur = 1000u, produced = 0;
+    for (uint32_t base = 0; base < slen; base += 64) {
+        const uint32_t i = base + (uint32_t)l; const bool valid = i < slen;
+        const uint32_t b0 = valid ? sp[i] : 0u;
+        const uint32_t tl = (b0 & 0x80u) == 0 ? 2u : ((b0 & 0xE0u) == 0xE0u ? 3u : 1u);
+        const uint32_t before = wave_token_states(tl, valid, carry);
+        const bool start = valid && before == 0;
+        uint32_t cnt = 0, isabs = 0, val = 0;                      // val: absolute value, or the +diff
+        if (start) {
+            if ((b0 & 0x80u) == 0) { isabs = 1; val = (b0 << 8) | (i + 1 < slen ? sp[i + 1] : 0u); cnt = 1; }
+            else if ((b0 & 0x40u) == 0) { val = (b0 & 0x3Fu) + 1; cnt = 1; }
+            else if ((b0 & 0x20u) == 0) { val = 0; cnt = (b0 & 0x1Fu) + 1; }
+            else { isabs = 1; val = ((b0 & 0x1Fu) << 16) | ((i + 1 < slen ? sp[i + 1] : 0u) << 8) | (i + 2 < slen ? sp[i + 2] : 0u); cnt = 1; }
+        }
+        // segmented prefix: value after this token = last absolute at or before it + diffs since
+        uint32_t v = val, a = isabs;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t tv = __shfl_up(v, (unsigned)dd), ta = __shfl_up(a, (unsigned)dd); if (l >= dd && !a) { v += tv; a = ta; } }
+        const uint32_t value = a ? v : cur + v;
+        const uint32_t incl = wave_incl_sum(cnt); const uint32_t o = produced + incl - cnt;
+        if (start) for (uint32_t k = 0; k < cnt; k++) if (o + k < num) out[o + k] = value;
+        produced += __shfl(incl, 63); cur = __shfl(value, 63);
+    }
+}
+
+// ---- text
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) { uint32_t n = 1; while (v >= 10) { v /= 10; n++; } return n; }
+__device__ __forceinline__ uint32_t dec_put(uint8_t* dst, uint32_t v) { const uint32_t n = dec_digits(v); for (uint32_t k = 0; k < n; k++) { dst[n - 1 - k] = (uint8_t)('0' + v % 10); v /= 10; } return n; }
+struct DName { uint32_t n1, n2, st, lane, tile, x, y; };
+__device__ __forceinline__ DName dec_name_parts(const uint8_t* cp, const DChunk& d, const DevHeader* D, const uint32_t* xv, const uint32_t* yv, uint32_t r) {
+    const uint32_t fl = d.flags, hf = D->flags; DName m;
+    m.n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
+    m.n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
+    m.st = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
+    const uint32_t xy = (fl & C_PE_INTERLEAVED) ? r / 2 : r;
+    m.lane = (hf & H_LANE) ? cp[d.o_lanes + ((fl & C_LANE_SAME) ? 0u : xy)] : 0u;
+    m.tile = (hf & H_TILE) ? ld_u16(cp + d.o_tiles + 2 * (size_t)((fl & C_TILE_SAME) ? 0u : xy)) : 0u;
+    m.x = (hf & H_X) ? xv[d.rbase + xy] : 0u; m.y = (hf & H_Y) ? yv[d.rbase + xy] : 0u;
+    return m;
+}
+// text bytes of every read; tin[g] = (bytes into out1, bytes into out2, 0, 0)
+__global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                              const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, int split) {
+    const DChunk d = CH[blockIdx.y]; const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.reads) return;
+    const uint8_t* cp = img + d.off; const uint32_t g = d.rbase + r, hf = D->flags;
+    const DName m = dec_name_parts(cp, d, D, xv, yv, r);
+    uint32_t nl = m.n1 + m.n2;
+    if (hf & H_LANE) nl += 1 + dec_digits(m.lane);
+    if (hf & H_TILE) nl += 1 + dec_digits(m.tile);
+    if (hf & H_X) nl += 1 + dec_digits(m.x);
+    if (hf & H_Y) nl += 1 + dec_digits(m.y);
+    const uint32_t len = R.len[g]; const uint32_t text = nl + 1 + len + 1 + m.st + 1 + len + 1;
+    U4 t; t.a = (split && (r & 1u)) ? 0u : text; t.b = (split && (r & 1u)) ? text : 0u; t.c = 0; t.d = 0;
+    R.tin[g] = t;
+}
+// one wave per read writes its four lines (name re-assembly src/rfqcodec.cpp:1157-1231, RC of odd reads :1248-1252)
+__global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                           const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
+                           const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, int split,
+                           uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st) {
+    const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
+    const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
+    const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual;
+    const uint32_t wpb = blockDim.x >> 6; const int l = lane_id();
+    const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
+    const uint8_t* qb = qdec + qbase[c]; const uint8_t* sb = sdec + sbase[c];
+    for (uint32_t r = blockIdx.x * wpb + (uint32_t)wave_id(); r < d.reads; r += gridDim.x * wpb) {
+        const uint32_t g = f + r; const U4 tp = R.tp[g]; const U4 pv = R.pv[g];
+        const bool odd = (r & 1u) != 0; const bool to2 = split && odd;
+        uint8_t* o = to2 ? out2 : out1; const uint64_t at = to2 ? tp.b : tp.a; const uint64_t cap = to2 ? cap2 : cap1;
+        const uint32_t len = R.len[g];
+        const DName m = dec_name_parts(cp, d, D, xv, yv, r);
+        // --- name line (lane 0 formats the short numeric middle; all lanes copy name1 / name2)
+        const uint8_t* n1p = cp + d.o_n1 + ((fl & C_NAME1_SAME) ? 0u : (pv.a - pv0.a));
+        const uint8_t* n2p = cp + d.o_n2 + ((fl & C_NAME2_SAME) ? 0u : (pv.b - pv0.b));
+        const uint8_t* stp = cp + d.o_st + ((fl & C_STRAND_SAME) ? 0u : (pv.c - pv0.c));
+        uint32_t mid = 0;
+        if (hf & H_LANE) mid += 1 + dec_digits(m.lane);
+        if (hf & H_TILE) mid += 1 + dec_digits(m.tile);
+        if (hf & H_X) mid += 1 + dec_digits(m.x);
+        if (hf & H_Y) mid += 1 + dec_digits(m.y);
+        const uint64_t total = (uint64_t)m.n1 + mid + m.n2 + 1 + len + 1 + m.st + 1 + len + 1;
+        if (at + total > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
+        uint8_t* w = o + at;
+        for (uint32_t i = (uint32_t)l; i < m.n1; i += 64) w[i] = n1p[i];
+        if (l == 0) {
+            uint8_t* q = w + m.n1;
+            if (hf & H_LANE) { *q++ = ':'; q += dec_put(q, m.lane); }
+            if (hf & H_TILE) { *q++ = ':'; q += dec_put(q, m.tile); }
+            if (hf & H_X) { *q++ = ':'; q += dec_put(q, m.x); }
+            if (hf & H_Y) { *q++ = ':'; q += dec_put(q, m.y); }
+        }
+        uint8_t* w2 = w + m.n1 + mid;
+        const bool patch = (fl & C_NAME2_SAME) && il && odd && D->name2_diff_char != 0;
+        for (uint32_t i = (uint32_t)l; i < m.n2; i += 64) w2[i] = (patch && i == D->name2_diff_pos) ? (uint8_t)D->name2_diff_char : n2p[i];
+        if (l == 0) w2[m.n2] = '\n';
+        // --- sequence + quality.  Interleaved-orientation base j of this read (overlap re-expansion, src/rfqcodec.cpp:865-897):
+        uint8_t* ws = w2 + m.n2 + 1; uint8_t* wst = ws + len + 1; uint8_t* wq = wst + m.st + 1;
+        const uint32_t sp = pv.d - pv0.d, qp = R.pq[g] - pq0; const int ov = R.ov[g];
+        const uint32_t prevlen = odd ? R.len[g - 1] : 0u; const bool rc = il && odd;
+        for (uint32_t k = (uint32_t)l; k < len; k += 64) {
+            const uint32_t j = rc ? len - 1 - k : k;
+            uint8_t b;
+            if (ov > 0) b = j < (uint32_t)ov ? sb[sp - (uint32_t)ov + j] : sb[sp + j - (uint32_t)ov];
+            else if (ov < 0) { const uint32_t keep = len - (uint32_t)(-ov); b = j < keep ? sb[sp + j] : sb[sp - prevlen + (j - keep)]; }
+            else b = sb[sp + j];
+            const uint8_t q = qb[qp + j];
+            if (implied_n && q == nq) b = 'N';                      // src/rfqcodec.cpp:1093-1100
+            ws[k] = rc ? comp_base(b) : b; wq[k] = q;
+        }
+        for (uint32_t i = (uint32_t)l; i < m.st; i += 64) wst[i] = stp[i];
+        if (l == 0) { ws[len] = '\n'; wst[m.st] = '\n'; wq[len] = '\n'; }
+    }
+}

@@ -457,10 +457,6 @@ __global__ void k_chunk_flags(Text T, ReadTab R, ChunkTab C, const DevHeader* __
     }
 }
 
-// reverse-complement rule of Read::changeToReverseComplement (src/read.cpp:77-115)
-__device__ __forceinline__ uint8_t comp_base(uint8_t b) {
-    switch (b) { case 'A': case 'a': return 'T'; case 'T': case 't': return 'A'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; default: return 'N'; }
-}
 // RfqCodec::overlap (src/rfqcodec.cpp:1391-1438) for one pair per wave: lane = candidate overlap length.
 // r1 = R1 as in the file, r2 = R2 as in the file (its reverse complement is formed on the fly).
 __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int len1, const uint8_t* __restrict__ r2, int len2) {
@@ -541,14 +537,14 @@ __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict
     if (c >= n_chunks) return;
     const uint32_t f = C.first[c], e = C.first[c + 1];
     const uint32_t len = R.pq[e] - R.pq[f], slen = R.pv[e].d - R.pv[f].d;
-    const uint32_t nn = D->n_normal; uint64_t run = 0;
+    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT; uint64_t run = 0;
     const bool bycol = (D->flags & H_QUAL_BY_COL) && !(D->flags & H_DONT_QUAL);
     const uint32_t* h = C.hist + (size_t)c * 256;
     for (uint32_t j = 0; j < MAX_STREAMS; j++) {
         uint32_t cap = 0;
-        if (j < nn) { if (bycol) cap = h[D->normal[j]] + len / 128 + 3 * (len / 16384) + 16; }
-        else if (j == nn) { if (D->flags & H_N_POS) cap = C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16; }
-        else if (j == nn + 1) { if (bycol) { uint32_t ex = 0; for (int v = 0; v < 256; v++) if (D->is_exception[v]) ex += h[v]; cap = 5 * ex + 16; } }
+        if (j < NPOS_SLOT) { if (bycol && j < nn) cap = h[D->normal[j]] + len / 128 + 3 * (len / 16384) + 16; }
+        else if (j == NPOS_SLOT) { if (D->flags & H_N_POS) cap = C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16; }
+        else { if (bycol) { uint32_t ex = 0; for (int v = 0; v < 256; v++) if (D->is_exception[v]) ex += h[v]; cap = 5 * ex + 16; } }
         C.scap[(size_t)c * MAX_STREAMS + j] = cap; C.soff[(size_t)c * MAX_STREAMS + j] = run; C.ssize[(size_t)c * MAX_STREAMS + j] = 0;
         run += (cap + 15u) & ~15u;
     }
@@ -667,15 +663,15 @@ __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ 
 // grid (MAX_STREAMS, n_chunks), one wave per block
 __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, DevStatus* st) {
-    const uint32_t j = blockIdx.x, c = blockIdx.y; const uint32_t nn = D->n_normal;
+    const uint32_t j = blockIdx.x, c = blockIdx.y;
     const size_t k = (size_t)c * MAX_STREAMS + j;
     const uint32_t cap = C.scap[k];
     if (cap == 0) return;                                                  // stream not present (uniform: one wave per block)
     const uint32_t f = C.first[c], e = C.first[c + 1];
     uint8_t* out = scratch + cbase[c] + C.soff[k];
     uint32_t sz;
-    if (j < nn) sz = wave_pos_encode(qcat + C.qbase[c], R.pq[e] - R.pq[f], PC_MATCH, D->normal[j], D, out, cap);
-    else if (j == nn) sz = wave_pos_encode(scat + C.sbase[c], R.pv[e].d - R.pv[f].d, PC_MATCH, (uint32_t)'N', D, out, cap);
+    if (j < NPOS_SLOT) sz = wave_pos_encode(qcat + C.qbase[c], R.pq[e] - R.pq[f], PC_MATCH, D->normal[j], D, out, cap);
+    else if (j == NPOS_SLOT) sz = wave_pos_encode(scat + C.sbase[c], R.pv[e].d - R.pv[f].d, PC_MATCH, (uint32_t)'N', D, out, cap);
     else sz = wave_pos_encode(qcat + C.qbase[c], R.pq[e] - R.pq[f], PC_EXCEPT, 0, D, out, cap);
     if (lane_id() == 0) { C.ssize[k] = sz; if (sz > cap) atomicOr(&st->err, (uint32_t)DE_CORRUPT); }
 }
@@ -743,9 +739,9 @@ __global__ void k_chunk_layout(ReadTab R, ChunkTab C, const DevHeader* __restric
     const size_t k0 = (size_t)c * MAX_STREAMS;
     uint32_t qsz = 0;
     if (hf & H_DONT_QUAL) qsz = len;
-    else if (hf & H_QUAL_BY_COL) { qsz = 4 * nn; for (uint32_t j = 0; j < nn; j++) qsz += exact ? C.ssize[k0 + j] : C.scap[k0 + j]; qsz += exact ? C.ssize[k0 + nn + 1] : C.scap[k0 + nn + 1]; }
+    else if (hf & H_QUAL_BY_COL) { qsz = 4 * nn; for (uint32_t j = 0; j < nn && j < NPOS_SLOT; j++) qsz += exact ? C.ssize[k0 + j] : C.scap[k0 + j]; qsz += exact ? C.ssize[k0 + EXC_SLOT] : C.scap[k0 + EXC_SLOT]; }
     o.qual_size = qsz;
-    o.npos_size = (hf & H_N_POS) ? (exact ? C.ssize[k0 + nn] : C.scap[k0 + nn]) : 0;
+    o.npos_size = (hf & H_N_POS) ? (exact ? C.ssize[k0 + NPOS_SLOT] : C.scap[k0 + NPOS_SLOT]) : 0;
     o.x_size = (hf & H_X) ? (exact ? C.xsize[c] : 3 * h) : 0; o.y_size = (hf & H_Y) ? (exact ? C.ysize[c] : 3 * h) : 0;
     uint32_t k = 18 + ((hf & H_N_POS) ? 4 : 0);
     o.off_readlens = k; k += readLenBuf;
@@ -846,14 +842,14 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
     else if (hf & H_QUAL_BY_COL) {
         uint32_t dst = o.off_qual + 4 * nn; const uint8_t* sc = scratch + cbase[c];
         for (uint32_t j = 0; j <= nn; j++) {
-            const uint32_t js = j < nn ? j : nn + 1;                      // normal streams in header order, then the exception records
+            const uint32_t js = j < nn ? j : (uint32_t)EXC_SLOT;          // normal streams in header order, then the exception records
             const uint32_t sz = C.ssize[k0 + js]; const uint8_t* src = sc + C.soff[k0 + js];
             for (uint32_t i = t; i < sz; i += NT) out[dst + i] = src[i];
             dst += sz;
         }
     }
     if (il && (hf & H_PE_OVERLAP)) for (uint32_t i = t; i < s / 2; i += NT) out[o.off_ov + i] = (uint8_t)ovb[(f >> 1) + i];
-    if (hf & H_N_POS) { const uint8_t* src = scratch + cbase[c] + C.soff[k0 + nn]; for (uint32_t i = t; i < o.npos_size; i += NT) out[o.off_npos + i] = src[i]; }
+    if (hf & H_N_POS) { const uint8_t* src = scratch + cbase[c] + C.soff[k0 + NPOS_SLOT]; for (uint32_t i = t; i < o.npos_size; i += NT) out[o.off_npos + i] = src[i]; }
 }
 // names / strands that differ inside the chunk: one wave per read copies its pieces to their prefix-sum offsets
 __global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L, uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base) {

@@ -1,0 +1,74 @@
+"""CPU: kernel LOGIC of the decode path under the SIMT interpreter (see test_emu_encode.py for what that is)."""
+import pytest
+
+import _engine as E
+import _oracle as O
+from cases import CASES
+
+
+@pytest.fixture(scope="module")
+def codec():
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    yield c
+    c.close()
+
+
+def _oracle_rfq(case):
+    try:
+        return O.encode_file(case["fq1"], case.get("fq2", b""), case["paired"], case.get("k", 1000) * 1000)
+    except O.OracleError:
+        return None
+
+
+DECODABLE = sorted(n for n in CASES if n != "se_name_over_255" and _oracle_rfq(CASES[n]) is not None)   # >255-byte names: reference UB
+
+
+@pytest.mark.parametrize("name", DECODABLE)
+def test_case_decodes_like_oracle(codec, name):
+    rfq = _oracle_rfq(CASES[name]); split = CASES[name]["paired"] != 0
+    assert codec.decode_bytes(rfq, split_pe=split) == O.decode_file(rfq, split)
+    if split:   # Repaq::decompress on a PE file: one interleaved stream (Q14)
+        assert codec.decode_bytes(rfq, split_pe=False) == O.decode_file(rfq, False)
+
+
+MULTI = [
+    ("se150", O.NOVA_SE150, 600, 2, 20000, O.SE, {}),
+    ("se150_manyN", O.NOVA_SE150, 600, 2, 20000, O.SE, dict(nppm=5000)),
+    ("se_var", O.SE_VAR, 600, 3, 15000, O.SE, {}),
+    ("pe150", O.NOVA_PE150, 300, 4, 20000, O.PE_TWO_FILES, {}),
+    ("bgi_q40", O.BGI_PE100, 300, 5, 10000, O.PE_TWO_FILES, dict(n_quals=40)),
+    ("se150_no_final_newline", O.NOVA_SE150, 500, 6, 7777, O.SE, dict(nonl=1)),
+    ("pe150_r2_no_final_newline", O.NOVA_PE150, 300, 7, 9000, O.PE_TWO_FILES, dict(nonl=2, nppm=3000)),
+]
+
+
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI, ids=[m[0] for m in MULTI])
+def test_multichunk_round_trip(codec, label, prof, reads, seed, cb, paired, kw):
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    rfq = O.encode_file(fq1, fq2, paired, cb)
+    d = codec.decode_bytes(rfq, split_pe=(paired != O.SE))
+    assert d == ((fq1, fq2) if paired != O.SE else fq1)
+
+
+def test_encode_then_decode_on_device_round_trip(codec):
+    fq1, fq2 = O.gen(O.NOVA_PE150, 250, seed=33)
+    rfq = E.encode(codec, fq1, fq2, O.PE_TWO_FILES, 15000)
+    assert codec.decode_bytes(rfq, split_pe=True) == (fq1, fq2)
+
+
+def test_decode_rejects_other_algorithm_version(codec):
+    from repaq_amd import RfqError
+    rfq = bytearray(O.encode_file(CASES["d5_tiny_se"]["fq1"])); rfq[8] = 1
+    with pytest.raises(RfqError) as e:
+        codec.decode_bytes(bytes(rfq))
+    assert e.value.code == -6 and "different version of repaq" in e.value.message
+    with pytest.raises(RfqError):
+        codec.decode_bytes(b"XYZ0.5.1" + bytes(rfq[8:]).replace(b"\x01", b"\x02", 1))
+
+
+def test_decode_truncated_image_fails_cleanly(codec):
+    from repaq_amd import RfqError
+    rfq = O.encode_file(CASES["pe_overlap_sweep"]["fq1"], CASES["pe_overlap_sweep"]["fq2"], O.PE_TWO_FILES)
+    with pytest.raises(RfqError):
+        codec.decode_bytes(rfq[: len(rfq) - 7], split_pe=True)
