@@ -52,6 +52,13 @@ def load(path=None):
     path = path or os.environ.get("RFQ_HIP_LIBRARY") or DEFAULT_LIB
     if path in _libs:
         return _libs[path]
+    try:
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HSA runtimes in one process cannot both
+        # open the GPU, so when torch is around let it load its runtime first; librfq_hip.so then binds to the same one
+        # (same SONAME).  Hosts without torch (the C++ driver) simply use /opt/rocm's.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(path):
         raise ImportError("librfq_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); repaq_amd has no CPU fallback" % path)

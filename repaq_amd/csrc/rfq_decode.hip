@@ -10,7 +10,7 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 64, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_END
+    DB_CHUNKS = 64, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_END
 };
 static_assert(DB_END <= 96, "rfq_ctx::b too small");
 
@@ -67,10 +67,10 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     HIPCHK(ctx, B[DB_PVIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_PV].ensure(nr * 16)); HIPCHK(ctx, B[DB_PQ].ensure(nr * 4));
     HIPCHK(ctx, B[DB_TIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_TP].ensure(nr * 16));
     HIPCHK(ctx, B[DB_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[DB_SBASE].ensure(nc * 8));
-    HIPCHK(ctx, B[DB_XV].ensure(nr * 4)); HIPCHK(ctx, B[DB_YV].ensure(nr * 4));
+    HIPCHK(ctx, B[DB_XV].ensure(nr * 4)); HIPCHK(ctx, B[DB_YV].ensure(nr * 4)); HIPCHK(ctx, B[DB_MID].ensure(nr * 40));
     HIPCHK(ctx, B[DB_SCAN].ensure((nr / SCAN_TILE + 2) * 16 + 1024));
     DReadTab R; R.len = B[DB_LEN].as<uint32_t>(); R.chunk = B[DB_CHUNKID].as<uint32_t>(); R.ov = B[DB_OV].as<int32_t>();
-    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>();
+    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>(); R.mid = B[DB_MID].as<uint8_t>();
     hipLaunchKernelGGL(k_dec_readtab, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, dst);
     KCHK(ctx, "k_dec_readtab");
     scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
@@ -120,9 +120,9 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
                            (const uint64_t*)qbase, (const uint64_t*)sbase, (const uint8_t*)qdec, (const uint8_t*)sdec, split, o1, cap1, o2, cap2, dst);
         KCHK(ctx, "k_dec_emit");
     }
+    ctx->timer.end(S);
     HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
     HIPCHK(ctx, hipStreamSynchronize(S));
-    ctx->timer.end(S);
     ctx->timer.collect();
     if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %u / %u bytes", tt.a, tt.b);
     size_t n1 = tt.a, n2 = tt.b;

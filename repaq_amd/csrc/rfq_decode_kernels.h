@@ -80,6 +80,7 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
 
 struct DReadTab {
     uint32_t* len; uint32_t* chunk; int32_t* ov; U4* pvin; U4* pv; uint32_t* pq; U4* tin; U4* tp;
+    uint8_t* mid;                // [g][40]: the formatted ":lane:tile:x:y" middle of the name (<= 4+6+11+11 bytes); mid[g*40+39] = its length
 };
 __device__ __forceinline__ uint32_t dec_read_len(const uint8_t* cp, const DChunk& d, uint32_t rlb, uint32_t r) {
     const uint8_t* p = cp + d.o_readlens + (size_t)((d.flags & C_READ_LEN_SAME) ? 0u : r) * rlb;
@@ -267,11 +268,15 @@ __global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __r
     if (r >= d.reads) return;
     const uint8_t* cp = img + d.off; const uint32_t g = d.rbase + r, hf = D->flags;
     const DName m = dec_name_parts(cp, d, D, xv, yv, r);
-    uint32_t nl = m.n1 + m.n2;
-    if (hf & H_LANE) nl += 1 + dec_digits(m.lane);
-    if (hf & H_TILE) nl += 1 + dec_digits(m.tile);
-    if (hf & H_X) nl += 1 + dec_digits(m.x);
-    if (hf & H_Y) nl += 1 + dec_digits(m.y);
+    uint8_t buf[36]; uint32_t k = 0;                                 // ":255:65535:4294967295:4294967295" is 32 bytes
+    if (hf & H_LANE) { buf[k++] = ':'; k += dec_put(buf + k, m.lane); }
+    if (hf & H_TILE) { buf[k++] = ':'; k += dec_put(buf + k, m.tile); }
+    if (hf & H_X) { buf[k++] = ':'; k += dec_put(buf + k, m.x); }
+    if (hf & H_Y) { buf[k++] = ':'; k += dec_put(buf + k, m.y); }
+    uint8_t* mp = R.mid + (size_t)g * 40;
+    for (uint32_t i = 0; i < k; i++) mp[i] = buf[i];
+    mp[39] = (uint8_t)k;
+    const uint32_t nl = m.n1 + m.n2 + k;
     const uint32_t len = R.len[g]; const uint32_t text = nl + 1 + len + 1 + m.st + 1 + len + 1;
     U4 t; t.a = (split && (r & 1u)) ? 0u : text; t.b = (split && (r & 1u)) ? text : 0u; t.c = 0; t.d = 0;
     R.tin[g] = t;
@@ -297,22 +302,12 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         const uint8_t* n1p = cp + d.o_n1 + ((fl & C_NAME1_SAME) ? 0u : (pv.a - pv0.a));
         const uint8_t* n2p = cp + d.o_n2 + ((fl & C_NAME2_SAME) ? 0u : (pv.b - pv0.b));
         const uint8_t* stp = cp + d.o_st + ((fl & C_STRAND_SAME) ? 0u : (pv.c - pv0.c));
-        uint32_t mid = 0;
-        if (hf & H_LANE) mid += 1 + dec_digits(m.lane);
-        if (hf & H_TILE) mid += 1 + dec_digits(m.tile);
-        if (hf & H_X) mid += 1 + dec_digits(m.x);
-        if (hf & H_Y) mid += 1 + dec_digits(m.y);
+        const uint8_t* mp = R.mid + (size_t)g * 40; const uint32_t mid = mp[39];
         const uint64_t total = (uint64_t)m.n1 + mid + m.n2 + 1 + len + 1 + m.st + 1 + len + 1;
         if (at + total > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
         uint8_t* w = o + at;
         for (uint32_t i = (uint32_t)l; i < m.n1; i += 64) w[i] = n1p[i];
-        if (l == 0) {
-            uint8_t* q = w + m.n1;
-            if (hf & H_LANE) { *q++ = ':'; q += dec_put(q, m.lane); }
-            if (hf & H_TILE) { *q++ = ':'; q += dec_put(q, m.tile); }
-            if (hf & H_X) { *q++ = ':'; q += dec_put(q, m.x); }
-            if (hf & H_Y) { *q++ = ':'; q += dec_put(q, m.y); }
-        }
+        if ((uint32_t)l < mid) w[m.n1 + (uint32_t)l] = mp[l];
         uint8_t* w2 = w + m.n1 + mid;
         const bool patch = (fl & C_NAME2_SAME) && il && odd && D->name2_diff_char != 0;
         for (uint32_t i = (uint32_t)l; i < m.n2; i += 64) w2[i] = (patch && i == D->name2_diff_pos) ? (uint8_t)D->name2_diff_char : n2p[i];
