@@ -62,11 +62,10 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    from repaq_amd import dist as D
+    rank, world, local = D.env_rank()
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        D.init("nccl", device=torch.device("cuda", local))      # "nccl" is RCCL on ROCm; used for barrier / max / sum only
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -132,25 +131,15 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        nb = torch.tensor([float(n)], dtype=torch.float64, device=dev)
-        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
-        total_bytes = float(nb.item())
-    else:
-        total_bytes = float(n)
+    dt, total_bytes = D.reduce_max_sum(dt, n, device=dev)      # MAX over ranks of the time, SUM of the bytes
 
     if rank == 0:
         K = args.steps
@@ -183,7 +172,7 @@ def main():
         print(json.dumps(out))
     codec.close()
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

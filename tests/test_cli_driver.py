@@ -1,0 +1,70 @@
+"""The C++ host driver (repaq's -c/-d/--compare command line over the C-ABI).  CPU: linked against the SIMT-emulation
+test library to exercise flag handling, batching with carry-over and the compare JSON; GPU: the real binary."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import _engine as E
+import _oracle as O
+
+EMU_BIN = os.path.join(E.EMU_DIR, "repaq_hip_emu")
+GPU_BIN = os.path.join(E.ROOT, "repaq_amd", "bin", "repaq_hip")
+
+
+def _run(binary, args, **kw):
+    return subprocess.run([binary] + args, capture_output=True, **kw)
+
+
+def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
+    fq1, _ = O.gen(O.NOVA_SE150, reads_se, seed=41, nonl=1)
+    p = tmp_path / "a.fq"; p.write_bytes(fq1)
+    out = tmp_path / "a.rfq"
+    r = _run(binary, ["-c", "-i", str(p), "-o", str(out), "-k", "100", "--batch_mb", str(batch_mb)])
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == O.encode_file(fq1, b"", O.SE, 100_000)
+    back = tmp_path / "back.fq"
+    r = _run(binary, ["-d", "-i", str(out), "-o", str(back)])
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == fq1
+    r = _run(binary, ["-p", "-i", str(p), "-r", str(out), "-j", str(tmp_path / "cmp.json")])
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout)
+    assert j["result"] == "passed" and j["fastq_reads"] == reads_se and j["rfq_reads"] == reads_se and j["fastq_bases"] == reads_se * 150
+    assert json.loads((tmp_path / "cmp.json").read_text()) == j
+    # PE: -i/-I -> one .rfq, -o/-O back
+    a, b = O.gen(O.NOVA_PE150, pairs, seed=42)
+    pa, pb = tmp_path / "r1.fq", tmp_path / "r2.fq"; pa.write_bytes(a); pb.write_bytes(b)
+    pe = tmp_path / "pe.rfq"
+    r = _run(binary, ["-i", str(pa), "-I", str(pb), "-o", str(pe), "-k", "100", "--batch_mb", str(batch_mb)])   # compress is the default mode
+    assert r.returncode == 0, r.stderr
+    assert pe.read_bytes() == O.encode_file(a, b, O.PE_TWO_FILES, 100_000)
+    o1, o2 = tmp_path / "o1.fq", tmp_path / "o2.fq"
+    assert _run(binary, ["-d", "-i", str(pe), "-o", str(o1), "-O", str(o2)]).returncode == 0
+    assert (o1.read_bytes(), o2.read_bytes()) == (a, b)
+    # a corrupted base makes --compare fail with the reference's message shape
+    bad = bytearray(a); k = bad.index(b"\n") + 5; bad[k] = ord("A") if bad[k] != ord("A") else ord("C")
+    pbad = tmp_path / "r1_bad.fq"; pbad.write_bytes(bytes(bad))
+    r = _run(binary, ["-p", "-i", str(pbad), "-I", str(pb), "-r", str(pe)])
+    j = json.loads(r.stdout)
+    assert j["result"] == "failed" and "different sequence in the 1 read" in j["msg"]
+    # flag validation texts (src/options.cpp:36-111)
+    r = _run(binary, ["-c", "-i", str(p)])
+    assert r.returncode == 255 and b"Please specify output file by <out1>" in r.stderr
+    r = _run(binary, ["-c", "-d", "-i", str(p), "-o", str(out)])
+    assert r.returncode == 255 and b"you can only choose any one mode" in r.stderr
+
+
+def test_cli_on_simt_emulation(tmp_path):
+    E.build_emu()
+    subprocess.check_call(["make", "-s", "-C", E.EMU_DIR, "all"])
+    _suite(EMU_BIN, tmp_path, reads_se=4000, pairs=1500, batch_mb=1)
+
+
+@pytest.mark.gpu
+def test_cli_on_gpu(tmp_path):
+    import __graft_entry__ as g
+    g.build_host_tools()
+    assert os.path.exists(GPU_BIN)
+    _suite(GPU_BIN, tmp_path, reads_se=60000, pairs=30000, batch_mb=8)
