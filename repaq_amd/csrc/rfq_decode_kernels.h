@@ -147,28 +147,48 @@ __device__ __forceinline__ uint32_t wave_token_states(uint32_t tok_len, bool val
     return before;
 }
 // decodeSingleQualByCol (src/rfqcodec.cpp:957-1007): one wave per (stream, chunk); writes q at every coded position.
+// A step covers 256 stream bytes, 4 consecutive bytes per lane: the lane composes its 4 transition tables locally, ONE wave
+// scan gives the automaton state in front of every lane, ONE sum-scan the position in front of it.
+__device__ __forceinline__ uint32_t pos_tok_len(uint32_t b0) { return (b0 & 0x80u) == 0 ? 1u : ((b0 & 0x40u) == 0 ? 2u : ((b0 & 0x20u) == 0 ? 1u : 4u)); }
 __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, uint32_t slen, uint8_t q, uint8_t* __restrict__ out, uint32_t out_len) {
-    const int l = lane_id(); uint32_t carry = 0; long long last = -1;
-    for (uint32_t base = 0; base < slen; base += 64) {
-        const uint32_t i = base + (uint32_t)l; const bool valid = i < slen;
-        const uint32_t b0 = valid ? sp[i] : 0u;
-        const uint32_t tl = (b0 & 0x80u) == 0 ? 1u : ((b0 & 0x40u) == 0 ? 2u : ((b0 & 0x20u) == 0 ? 1u : 4u));
-        const uint32_t before = wave_token_states(tl, valid, carry);
-        const bool start = valid && before == 0;
-        long long adv = 0; uint32_t run = 0;
-        if (start) {
-            if ((b0 & 0x80u) == 0) adv = (long long)b0 + 1;
-            else if ((b0 & 0x40u) == 0) adv = (long long)(((b0 & 0x3Fu) << 8) | (i + 1 < slen ? sp[i + 1] : 0u)) + 1;
-            else if ((b0 & 0x20u) == 0) { run = (b0 & 0x1Fu) + 1; adv = run; }
-            else {
-                const uint32_t b1 = i + 1 < slen ? sp[i + 1] : 0u, b2 = i + 2 < slen ? sp[i + 2] : 0u, b3 = i + 3 < slen ? sp[i + 3] : 0u;
-                adv = (long long)(int32_t)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
+    const int l = lane_id(); uint32_t carry = 0; int last = -1;            // positions < 2^31 (see the encoder)
+    const uint32_t ID = 0u | (1u << 2) | (2u << 4) | (3u << 6);
+    for (uint32_t base = 0; base < slen; base += 256) {
+        const uint32_t i0 = base + 4u * (uint32_t)l;
+        uint32_t bt[4], fn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)k; const bool valid = i < slen; bt[k] = valid ? sp[i] : 0u; fn[k] = valid ? ((pos_tok_len(bt[k]) - 1u) | (0u << 2) | (1u << 4) | (2u << 6)) : ID; }
+        uint32_t F = fn_compose(fn_compose(fn_compose(fn[0], fn[1]), fn[2]), fn[3]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(F, (unsigned)d); if (l >= d) F = fn_compose(t, F); }
+        const uint32_t after = (F >> (2 * carry)) & 3u;                      // state after my 4 bytes
+        uint32_t st = __shfl_up(after, 1u); if (l == 0) st = carry;         // state in front of my first byte
+        carry = __shfl(after, 63);
+        int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + (uint32_t)k, b0 = bt[k]; const bool valid = i < slen;
+            start[k] = valid && st == 0; adv[k] = 0; run[k] = 0;
+            if (start[k]) {
+                if ((b0 & 0x80u) == 0) adv[k] = (int)b0 + 1;
+                else if ((b0 & 0x40u) == 0) adv[k] = (int)(((b0 & 0x3Fu) << 8) | (i + 1 < slen ? sp[i + 1] : 0u)) + 1;
+                else if ((b0 & 0x20u) == 0) { run[k] = (b0 & 0x1Fu) + 1; adv[k] = (int)run[k]; }
+                else {
+                    const uint32_t b1 = i + 1 < slen ? sp[i + 1] : 0u, b2 = i + 2 < slen ? sp[i + 2] : 0u, b3 = i + 3 < slen ? sp[i + 3] : 0u;
+                    adv[k] = (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
+                }
             }
+            lane_adv += adv[k];
+            if (valid) st = (fn[k] >> (2 * st)) & 3u;
         }
-        const long long incl = wave_incl_sum(adv); const long long end = last + incl;     // position of this token's last covered base
-        if (start) {
-            if (run) { for (uint32_t k = 0; k < run; k++) { const long long p = end - (long long)run + 1 + k; if (p >= 0 && p < (long long)out_len) out[p] = q; } }
-            else if (end >= 0 && end < (long long)out_len) out[end] = q;
+        const int incl = wave_incl_sum(lane_adv);
+        int end = last + incl - lane_adv;                                    // last covered position in front of my tokens
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!start[k]) continue;
+            end += adv[k];
+            if (run[k]) { for (uint32_t t = 0; t < run[k]; t++) { const int p = end - (int)run[k] + 1 + (int)t; if (p >= 0 && (uint32_t)p < out_len) out[p] = q; } }
+            else if (end >= 0 && (uint32_t)end < out_len) out[end] = q;
         }
         last += __shfl(incl, 63);
     }
@@ -292,41 +312,56 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
     const uint32_t wpb = blockDim.x >> 6; const int l = lane_id();
     const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
     const uint8_t* qb = qdec + qbase[c]; const uint8_t* sb = sdec + sbase[c];
-    for (uint32_t r = blockIdx.x * wpb + (uint32_t)wave_id(); r < d.reads; r += gridDim.x * wpb) {
-        const uint32_t g = f + r; const U4 tp = R.tp[g]; const U4 pv = R.pv[g];
-        const bool odd = (r & 1u) != 0; const bool to2 = split && odd;
-        uint8_t* o = to2 ? out2 : out1; const uint64_t at = to2 ? tp.b : tp.a; const uint64_t cap = to2 ? cap2 : cap1;
-        const uint32_t len = R.len[g];
-        const DName m = dec_name_parts(cp, d, D, xv, yv, r);
-        // --- name line (lane 0 formats the short numeric middle; all lanes copy name1 / name2)
-        const uint8_t* n1p = cp + d.o_n1 + ((fl & C_NAME1_SAME) ? 0u : (pv.a - pv0.a));
-        const uint8_t* n2p = cp + d.o_n2 + ((fl & C_NAME2_SAME) ? 0u : (pv.b - pv0.b));
-        const uint8_t* stp = cp + d.o_st + ((fl & C_STRAND_SAME) ? 0u : (pv.c - pv0.c));
-        const uint8_t* mp = R.mid + (size_t)g * 40; const uint32_t mid = mp[39];
-        const uint64_t total = (uint64_t)m.n1 + mid + m.n2 + 1 + len + 1 + m.st + 1 + len + 1;
-        if (at + total > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
-        uint8_t* w = o + at;
-        for (uint32_t i = (uint32_t)l; i < m.n1; i += 64) w[i] = n1p[i];
-        if ((uint32_t)l < mid) w[m.n1 + (uint32_t)l] = mp[l];
-        uint8_t* w2 = w + m.n1 + mid;
-        const bool patch = (fl & C_NAME2_SAME) && il && odd && D->name2_diff_char != 0;
-        for (uint32_t i = (uint32_t)l; i < m.n2; i += 64) w2[i] = (patch && i == D->name2_diff_pos) ? (uint8_t)D->name2_diff_char : n2p[i];
-        if (l == 0) w2[m.n2] = '\n';
-        // --- sequence + quality.  Interleaved-orientation base j of this read (overlap re-expansion, src/rfqcodec.cpp:865-897):
-        uint8_t* ws = w2 + m.n2 + 1; uint8_t* wst = ws + len + 1; uint8_t* wq = wst + m.st + 1;
-        const uint32_t sp = pv.d - pv0.d, qp = R.pq[g] - pq0; const int ov = R.ov[g];
-        const uint32_t prevlen = odd ? R.len[g - 1] : 0u; const bool rc = il && odd;
-        for (uint32_t k = (uint32_t)l; k < len; k += 64) {
-            const uint32_t j = rc ? len - 1 - k : k;
-            uint8_t b;
-            if (ov > 0) b = j < (uint32_t)ov ? sb[sp - (uint32_t)ov + j] : sb[sp + j - (uint32_t)ov];
-            else if (ov < 0) { const uint32_t keep = len - (uint32_t)(-ov); b = j < keep ? sb[sp + j] : sb[sp - prevlen + (j - keep)]; }
-            else b = sb[sp + j];
-            const uint8_t q = qb[qp + j];
-            if (implied_n && q == nq) b = 'N';                      // src/rfqcodec.cpp:1093-1100
-            ws[k] = rc ? comp_base(b) : b; wq[k] = q;
+    // a wave takes 64 consecutive reads: lane j fetches read j's metadata (offsets, piece lengths), then the wave emits read
+    // after read with everything broadcast by shuffles
+    for (uint32_t rb = (blockIdx.x * wpb + (uint32_t)wave_id()) * 64u; rb < d.reads; rb += gridDim.x * wpb * 64u) {
+        const uint32_t rl = rb + (uint32_t)l; const bool v = rl < d.reads;
+        uint32_t m_at = 0, m_len = 0, m_n1 = 0, m_n2 = 0, m_st = 0, m_mid = 0, m_o1 = 0, m_o2 = 0, m_o3 = 0, m_sp = 0, m_qp = 0, m_prev = 0; int m_ov = 0;
+        if (v) {
+            const uint32_t g = f + rl; const U4 tp = R.tp[g]; const U4 pv = R.pv[g];
+            m_at = (split && (rl & 1u)) ? tp.b : tp.a; m_len = R.len[g]; m_ov = R.ov[g]; m_prev = (rl & 1u) ? R.len[g - 1] : 0u;
+            m_n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : rl)];
+            m_n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : rl)] : 0u;
+            m_st = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : rl)];
+            m_mid = R.mid[(size_t)g * 40 + 39];
+            m_o1 = (fl & C_NAME1_SAME) ? 0u : (pv.a - pv0.a); m_o2 = (fl & C_NAME2_SAME) ? 0u : (pv.b - pv0.b); m_o3 = (fl & C_STRAND_SAME) ? 0u : (pv.c - pv0.c);
+            m_sp = pv.d - pv0.d; m_qp = R.pq[g] - pq0;
         }
-        for (uint32_t i = (uint32_t)l; i < m.st; i += 64) wst[i] = stp[i];
-        if (l == 0) { ws[len] = '\n'; wst[m.st] = '\n'; wq[len] = '\n'; }
+        const uint32_t cnt = d.reads - rb < 64u ? d.reads - rb : 64u;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t r = rb + j, g = f + r; const int jj = (int)j;
+            const bool odd = (r & 1u) != 0; const bool to2 = split && odd;
+            uint8_t* o = to2 ? out2 : out1; const uint64_t cap = to2 ? cap2 : cap1;
+            const uint64_t at = __shfl(m_at, jj); const uint32_t len = __shfl(m_len, jj);
+            const uint32_t n1 = __shfl(m_n1, jj), n2 = __shfl(m_n2, jj), stl = __shfl(m_st, jj), mid = __shfl(m_mid, jj);
+            const uint8_t* n1p = cp + d.o_n1 + __shfl(m_o1, jj); const uint8_t* n2p = cp + d.o_n2 + __shfl(m_o2, jj); const uint8_t* stp = cp + d.o_st + __shfl(m_o3, jj);
+            const uint32_t sp = __shfl(m_sp, jj), qp = __shfl(m_qp, jj), prevlen = __shfl(m_prev, jj); const int ov = __shfl(m_ov, jj);
+            const uint64_t total = (uint64_t)n1 + mid + n2 + 1 + len + 1 + stl + 1 + len + 1;
+            if (at + total > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
+            uint8_t* w = o + at;
+            // --- name line: name1, the pre-formatted ":lane:tile:x:y" (k_dec_textlen), name2 (mate digit patched when stored once)
+            for (uint32_t i = (uint32_t)l; i < n1; i += 64) w[i] = n1p[i];
+            const uint8_t* mp = R.mid + (size_t)g * 40;
+            if ((uint32_t)l < mid) w[n1 + (uint32_t)l] = mp[l];
+            uint8_t* w2 = w + n1 + mid;
+            const bool patch = (fl & C_NAME2_SAME) && il && odd && D->name2_diff_char != 0;
+            for (uint32_t i = (uint32_t)l; i < n2; i += 64) w2[i] = (patch && i == D->name2_diff_pos) ? (uint8_t)D->name2_diff_char : n2p[i];
+            if (l == 0) w2[n2] = '\n';
+            // --- sequence + quality.  Interleaved-orientation base j of this read (overlap re-expansion, src/rfqcodec.cpp:865-897):
+            uint8_t* ws = w2 + n2 + 1; uint8_t* wst = ws + len + 1; uint8_t* wq = wst + stl + 1;
+            const bool rc = il && odd;
+            for (uint32_t k = (uint32_t)l; k < len; k += 64) {
+                const uint32_t p = rc ? len - 1 - k : k;
+                uint8_t b;
+                if (ov > 0) b = p < (uint32_t)ov ? sb[sp - (uint32_t)ov + p] : sb[sp + p - (uint32_t)ov];
+                else if (ov < 0) { const uint32_t keep = len - (uint32_t)(-ov); b = p < keep ? sb[sp + p] : sb[sp - prevlen + (p - keep)]; }
+                else b = sb[sp + p];
+                const uint8_t q = qb[qp + p];
+                if (implied_n && q == nq) b = 'N';                      // src/rfqcodec.cpp:1093-1100
+                ws[k] = rc ? comp_base(b) : b; wq[k] = q;
+            }
+            for (uint32_t i = (uint32_t)l; i < stl; i += 64) wst[i] = stp[i];
+            if (l == 0) { ws[len] = '\n'; wst[stl] = '\n'; wq[len] = '\n'; }
+        }
     }
 }

@@ -134,7 +134,8 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
     const uint32_t mm_init[2] = { 0xFFFFFFFFu, 0u };
     HIPCHK(ctx, hipMemcpyAsync(B[B_MINMAX].p, mm_init, 8, hipMemcpyHostToDevice, S));
-    hipLaunchKernelGGL(k_read_table, dim3((n_units + 255) / 256), dim3(256), 0, S, T, R, B[B_ULEN].as<uint64_t>(), n_units, B[B_MINMAX].as<uint32_t>(), dst);
+    hipLaunchKernelGGL(k_read_table, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, n_reads, dst);
+    hipLaunchKernelGGL(k_unit_len, dim3((n_units + 255) / 256), dim3(256), 0, S, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
     KCHK(ctx, "k_read_table");
     scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1);
     scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1);

@@ -134,32 +134,51 @@ __device__ __forceinline__ Meta dev_parse_name(const uint8_t* str, uint32_t len)
     else { m.ok = 0; m.lane = 0; m.tile = 0; m.x = 0; m.y = 0; m.name1_len = len; m.name2_off = len; }
     return m;
 }
-// one thread per partition unit (a read, or a pair); validates the 4-line records it owns
-__global__ void k_read_table(Text T, ReadTab R, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t* __restrict__ len_minmax, DevStatus* st) {
+// One thread per read.  Names are staged through LDS first: per-lane byte walks over 64 different cache lines thrash
+// the 32 KiB L1 (each byte load re-fetches a line), so the wave copies the 64 names row by row with coalesced loads
+// (lane i takes byte i of read j's name) and every lane then parses its own row from LDS (row stride 132 B = 33 banks).
+#define NAME_CAP 128
+#define NAME_STRIDE 132
+__global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, DevStatus* st) {
+    __shared__ uint8_t s_names[4 * 64 * NAME_STRIDE];
+    const int l = lane_id(), w = wave_id();
+    const uint32_t g = (blockIdx.x * (blockDim.x >> 6) + (uint32_t)w) * 64u + (uint32_t)l;
+    const bool valid = g < n_reads;
+    uint32_t nb = 0, nl = 0, sl = 0, tl = 0, ql = 0; int s = 0;
+    if (valid) {
+        uint32_t r; read_loc(T, g, s, r);
+        const uint32_t* p = T.lo[s] + 4 * (size_t)r;
+        const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
+        nb = p0; nl = p1 - 1 - p0; sl = p2 - 1 - p1; tl = p3 - 1 - p2; ql = p4 - 1 - p3;
+    }
+    uint8_t* rows = s_names + (size_t)w * 64 * NAME_STRIDE;
+    for (int j = 0; j < 64; j++) {
+        const uint32_t jb = __shfl(nb, j), jl = __shfl(nl, j); const int js = __shfl(s, j);
+        const uint32_t take = jl < NAME_CAP ? jl : NAME_CAP;
+        const uint8_t* src = T.fq[js] + jb;
+        for (uint32_t i = (uint32_t)l; i < take; i += 64) rows[j * NAME_STRIDE + i] = src[i];
+    }
+    __syncthreads();
+    uint32_t err = 0;
+    if (valid) {
+        if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
+        if (ql < sl) err |= DE_QUAL_SHORT;
+        const Meta m = nl <= NAME_CAP ? dev_parse_name(rows + l * NAME_STRIDE, nl) : dev_parse_name(T.fq[s] + nb, nl);
+        R.len[g] = sl; R.stored[g] = sl;
+        R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
+    }
+    err = wave_or(err);
+    if (l == 0 && err) atomicOr(&st->err, err);
+}
+// bases per partition unit (a read, or a pair) + min / max for the partitioner's uniform-length fast path
+__global__ void k_unit_len(const uint32_t* __restrict__ len, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ len_minmax) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t err = 0; uint64_t tot = 0;
-    if (u < n_units) {
-        for (uint32_t j = 0; j < T.upr; j++) {
-            const uint32_t g = u * T.upr + j;
-            const uint32_t nl = line_len(T, g, 0), sl = line_len(T, g, 1), tl = line_len(T, g, 2), ql = line_len(T, g, 3);
-            if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
-            if (ql < sl) err |= DE_QUAL_SHORT;
-            Meta m = dev_parse_name(line_ptr(T, g, 0), nl);
-            R.len[g] = sl; R.stored[g] = sl;
-            R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
-            tot += sl;
-        }
-        ulen[u] = tot;
-    }
-    // uniform-length fast path of the partitioner needs min/max unit length
+    uint64_t tot = 0;
+    if (u < n_units) { for (uint32_t j = 0; j < upr; j++) tot += len[(size_t)u * upr + j]; ulen[u] = tot; }
     uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
-    mn = wave_min(mn); mx = wave_max(mx); err = wave_or(err);
+    mn = wave_min(mn); mx = wave_max(mx);
     // same-address atomics serialise at ~11 ns each (MI355X_MICROARCH.md "fanin"): only issue one when it can change the word
-    if (lane_id() == 0) {
-        if (mn < len_minmax[0]) atomicMin(&len_minmax[0], mn);
-        if (mx > len_minmax[1]) atomicMax(&len_minmax[1], mx);
-        if (err) atomicOr(&st->err, err);
-    }
+    if (lane_id() == 0) { if (mn < len_minmax[0]) atomicMin(&len_minmax[0], mn); if (mx > len_minmax[1]) atomicMax(&len_minmax[1], mx); }
 }
 
 // =============================================================== chunk partition (one wave)
@@ -518,25 +537,41 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     uint8_t* qd = qcat + C.qbase[c]; uint8_t* sd = scat + C.sbase[c];
     const uint32_t pq0 = R.pq[f], ps0 = R.pv[f].d;
     uint32_t ncnt = 0;
-    for (uint32_t g = f + blockIdx.x * wpb + (uint32_t)wave_id(); g < e; g += gridDim.x * wpb) {
-        const uint32_t len = R.len[g]; const uint8_t* sq = line_ptr(T, g, 1); const uint8_t* ql = line_ptr(T, g, 3);
-        const bool rc = il && ((g - f) & 1u);
-        int ov = 0; if (rc && enc) ov = (int)ovb[g >> 1] - shift;
-        uint8_t* qo = qd + (R.pq[g] - pq0); uint8_t* so = sd + (R.pv[g].d - ps0);
-        for (uint32_t i0 = 0; i0 < len; i0 += 64) {
-            const uint32_t i = i0 + (uint32_t)l; const bool act = i < len;
-            uint32_t q = 0; if (act) { q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = (uint8_t)q; }
-            unsigned long long todo = __ballot(act);
-            while (todo) {                                   // a wave of NovaSeq qualities holds 1-4 distinct values: count each with one ballot
-                const int src = __ffsll((long long)todo) - 1; const uint32_t v = __shfl(q, src);
-                const unsigned long long same = __ballot(act && q == v);
-                if (l == src) atomicAdd(&sh[v], (uint32_t)__popcll(same));
-                todo &= ~same;
+    // a wave takes 64 consecutive reads: every lane fetches one read's metadata (one coalesced round of loads), then the
+    // wave copies read after read with the metadata broadcast by shuffles — no dependent lo[] -> text -> offset chain per read
+    for (uint32_t gb = f + (blockIdx.x * wpb + (uint32_t)wave_id()) * 64u; gb < e; gb += gridDim.x * wpb * 64u) {
+        const uint32_t gl = gb + (uint32_t)l; const bool v = gl < e;
+        uint32_t m_len = 0, m_sq = 0, m_ql = 0, m_qo = 0, m_so = 0; int m_ov = 0, m_rc = 0, m_s = 0;
+        if (v) {
+            uint32_t r; read_loc(T, gl, m_s, r); const uint32_t* p = T.lo[m_s] + 4 * (size_t)r;
+            m_sq = p[1]; m_ql = p[3]; m_len = R.len[gl]; m_qo = R.pq[gl] - pq0; m_so = R.pv[gl].d - ps0;
+            m_rc = (il && ((gl - f) & 1u)) ? 1 : 0;
+            if (m_rc && enc) m_ov = (int)ovb[gl >> 1] - shift;
+        }
+        const uint32_t cnt = e - gb < 64u ? e - gb : 64u;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t len = __shfl(m_len, (int)j); const int strm = __shfl(m_s, (int)j);
+            const uint8_t* __restrict__ sq = T.fq[strm] + __shfl(m_sq, (int)j); const uint8_t* __restrict__ ql = T.fq[strm] + __shfl(m_ql, (int)j);
+            uint8_t* __restrict__ qo = qd + __shfl(m_qo, (int)j); uint8_t* __restrict__ so = sd + __shfl(m_so, (int)j);
+            const bool rc = __shfl(m_rc, (int)j) != 0; const int ov = __shfl(m_ov, (int)j);
+            // stored bases: ov == 0 whole read; ov > 0 skip the first ov bases of RC(R2); ov < 0 drop the last |ov|
+            const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u; const uint32_t keep = len - (uint32_t)(ov < 0 ? -ov : ov);
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                const uint32_t i = i0 + (uint32_t)l; const bool act = i < len; const bool sact = i < keep;
+                uint32_t q = 0, b = 0;
+                if (act) q = rc ? ql[len - 1 - i] : ql[i];
+                if (sact) { const uint32_t jj = i + skip; b = rc ? comp_base(sq[len - 1 - jj]) : sq[jj]; }
+                if (act) qo[i] = (uint8_t)q;
+                if (sact) { so[i] = (uint8_t)b; if (b == 'N') ncnt++; }
+                unsigned long long todo = __ballot(act);
+                while (todo) {                                   // a wave of NovaSeq qualities holds 1-4 distinct values: count each with one ballot
+                    const int src = __ffsll((long long)todo) - 1; const uint32_t vq = __shfl(q, src);
+                    const unsigned long long same = __ballot(act && q == vq);
+                    if (l == src) atomicAdd(&sh[vq], (uint32_t)__popcll(same));
+                    todo &= ~same;
+                }
             }
         }
-        // stored bases: ov == 0 whole read; ov > 0 skip the first ov bases of RC(R2); ov < 0 drop the last |ov|
-        const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u; const uint32_t keep = len - (uint32_t)(ov < 0 ? -ov : ov);
-        for (uint32_t i = (uint32_t)l; i < keep; i += 64) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b; if (b == 'N') ncnt++; }
     }
     ncnt = wave_sum(ncnt);
     if (l == 0 && ncnt) atomicAdd(&s_n, ncnt);
@@ -617,50 +652,70 @@ __device__ __forceinline__ uint32_t ones_from(uint64_t m, int s) {          // l
     const uint64_t inv = ~(m >> s);                                             // zero-extended: a zero appears within 64 - s bits unless s == 0 and m is all ones
     return inv ? (uint32_t)(__ffsll((long long)inv) - 1) : 64u;
 }
+// Token generator for one lane's 64-position word: calls sink.put(byte) for every token byte, in stream order.
+//   m        match mask of the word, p0 its first position
+//   prev_in  last match position before the word (-1: none), zero_in  last non-match position before it (-1: none)
+//   after    matches continuing right after the word (leading ones of the next word, <= 64)
+struct PackSink {                       // counts, and keeps the first 8 bytes in a register (most words code to <= 8 bytes)
+    uint64_t pk = 0; uint32_t n = 0;
+    __device__ __forceinline__ void put(uint32_t b) { if (n < 8) pk |= (uint64_t)(b & 0xFFu) << (8 * n); n++; }
+};
+struct StoreSink {
+    uint8_t* p;
+    __device__ __forceinline__ void put(uint32_t b) { *p++ = (uint8_t)b; }
+};
+template <class Sink> __device__ __forceinline__ void pc_gen_tokens(uint64_t m, uint32_t p0, int prev_in, int zero_in, uint32_t after, Sink& sink) {
+    uint64_t mm = m; int prev = prev_in;
+    while (mm) {
+        const int s = __ffsll((long long)mm) - 1; const uint32_t run = ones_from(mm, s); const int e = s + (int)run - 1;
+        const int abs_s = (int)p0 + s, abs_e = (int)p0 + e;
+        const int a = s > 0 ? abs_s : zero_in + 1;                          // start of the streak this run belongs to
+        const uint32_t aft = (e == 63) ? after : 0u;
+        if (a == abs_s) {                                                    // streak starts here: gap token
+            const int d = abs_s - prev; const uint32_t v = (uint32_t)(d - 1);
+            if (d <= 128) sink.put(v);
+            else if (d <= 16384) { sink.put((v >> 8) | 0x80u); sink.put(v); }
+            else { sink.put((v >> 24) | 0xE0u); sink.put(v >> 16); sink.put(v >> 8); sink.put(v); }
+            if (a == 0 && run >= 2) sink.put(0);                             // position 1 of a streak starting at 0 (`cur > 1`, Q3)
+        }
+        const int b0 = a + (a == 0 ? 2 : 1);
+        int i = b0; if (i < abs_s) i += ((abs_s - i + 31) / 32) * 32;
+        for (; i <= abs_e; i += 32) { int rem = abs_e - i + 1 + (int)aft; if (rem > 32) rem = 32; sink.put(0xC0u | (uint32_t)(rem - 1)); }
+        prev = abs_e;
+        mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
+    }
+}
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Returns the stream size (wave-uniform).
 __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ B, uint32_t len, int mode, uint32_t q, const DevHeader* __restrict__ D,
                                                    uint8_t* __restrict__ out, uint32_t cap) {
     const int l = lane_id();
+    const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
     uint32_t outpos = 0;
-    int prev_carry = -1, zero_carry = -1;                        // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
+    int prev_carry = -1, zero_carry = -1;                                   // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
     const uint32_t nsteps = (len + 4095u) / 4096u;
     uint64_t m_cur = nsteps ? pc_load_mask(B, len, 64u * (uint32_t)l, mode, q, D) : 0ull;
     for (uint32_t step = 0; step < nsteps; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
         const uint64_t m_next = (step + 1 < nsteps) ? pc_load_mask(B, len, p0 + 4096u, mode, q, D) : 0ull;
         const uint64_t m = m_cur;
-        if (!__any(m != 0)) {                                              // nothing to code in these 4096 positions
-            zero_carry = (int)(step * 4096u + 4095u); m_cur = m_next; continue;
-        }
-        // last match / last zero before my word (max-scans + carries from earlier steps)
-        int mylast = m ? (int)p0 + 63 - __clzll((long long)m) : -1;
-        int myzero = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1;
-        const int incl_last = wave_incl_max(mylast), incl_zero = wave_incl_max(myzero);
-        int prev_in = __shfl_up(incl_last, 1u), zero_in = __shfl_up(incl_zero, 1u);
-        if (l == 0) { prev_in = -1; zero_in = -1; }
-        if (prev_carry > prev_in) prev_in = prev_carry;
-        if (zero_carry > zero_in) zero_in = zero_carry;
+        const unsigned long long has1 = __ballot(m != 0);
+        if (!has1) { zero_carry = (int)(step * 4096u + 4095u); m_cur = m_next; continue; }    // nothing to code in these 4096 positions
+        const unsigned long long has0 = __ballot(~m != 0);
+        // last match / last non-match before my word: the nearest earlier lane that has one (ballot + one permute), else the carry
+        const int mylast = m ? (int)p0 + 63 - __clzll((long long)m) : -1;
+        const int myzero = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1;
+        const unsigned long long b1 = has1 & below, b0m = has0 & below;
+        const int src1 = b1 ? 63 - __clzll((long long)b1) : 0, src0 = b0m ? 63 - __clzll((long long)b0m) : 0;
+        const int got1 = __shfl(mylast, src1), got0 = __shfl(myzero, src0);
+        const int prev_in = b1 ? got1 : prev_carry, zero_in = b0m ? got0 : zero_carry;
         // matches continuing right after my word (for run lengths): leading ones of the next lane's word
         const uint32_t lead = (m == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);
         const uint32_t lead_n = (m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m_next) - 1);
         uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
         if (l == 63) after = after63;
-        uint32_t bytes = 0;
+        uint32_t bytes; uint64_t pk = 0;
         if (mode == PC_EXCEPT) bytes = 5u * (uint32_t)__popcll(m);
-        else {
-            uint64_t mm = m; int prev = prev_in;
-            while (mm) {
-                const int s = __ffsll((long long)mm) - 1; const uint32_t run = ones_from(mm, s); const int e = s + (int)run - 1;
-                const int abs_s = (int)p0 + s, abs_e = (int)p0 + e;
-                const int a = s > 0 ? abs_s : zero_in + 1;
-                if (a == abs_s) { const int d = abs_s - prev; bytes += d <= 128 ? 1u : (d <= 16384 ? 2u : 4u); if (a == 0 && run >= 2) bytes += 1; }
-                const int b0 = a + (a == 0 ? 2 : 1);
-                int i = b0; if (i < abs_s) i += ((abs_s - i + 31) / 32) * 32;
-                if (i <= abs_e) bytes += (uint32_t)((abs_e - i) / 32 + 1);
-                prev = abs_e;
-                mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
-            }
-        }
+        else { PackSink ps; pc_gen_tokens(m, p0, prev_in, zero_in, after, ps); bytes = ps.n; pk = ps.pk; }
         const uint32_t incl = wave_incl_sum(bytes);
         uint32_t o = outpos + incl - bytes;
         const uint32_t tot = __shfl(incl, 63);
@@ -668,32 +723,15 @@ __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ 
             if (mode == PC_EXCEPT) {
                 uint64_t mm = m;
                 while (mm) { const int s = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)s]; st_u32(out + o + 1, p0 + (uint32_t)s); o += 5; }
-            } else {
-                uint64_t mm = m; int prev = prev_in;
-                while (mm) {
-                    const int s = __ffsll((long long)mm) - 1; const uint32_t run = ones_from(mm, s); const int e = s + (int)run - 1;
-                    const int abs_s = (int)p0 + s, abs_e = (int)p0 + e;
-                    const int a = s > 0 ? abs_s : zero_in + 1;
-                    const uint32_t aft = (e == 63) ? after : 0u;
-                    if (a == abs_s) {
-                        const int d = abs_s - prev; const uint32_t v = (uint32_t)(d - 1);
-                        if (d <= 128) out[o++] = (uint8_t)v;
-                        else if (d <= 16384) { out[o++] = (uint8_t)((v >> 8) | 0x80u); out[o++] = (uint8_t)v; }
-                        else { out[o++] = (uint8_t)((v >> 24) | 0xE0u); out[o++] = (uint8_t)(v >> 16); out[o++] = (uint8_t)(v >> 8); out[o++] = (uint8_t)v; }
-                        if (a == 0 && run >= 2) out[o++] = 0;
-                    }
-                    const int b0 = a + (a == 0 ? 2 : 1);
-                    int i = b0; if (i < abs_s) i += ((abs_s - i + 31) / 32) * 32;
-                    for (; i <= abs_e; i += 32) { int rem = abs_e - i + 1 + (int)aft; if (rem > 32) rem = 32; out[o++] = (uint8_t)(0xC0u | (uint32_t)(rem - 1)); }
-                    prev = abs_e;
-                    mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
-                }
-            }
+            } else if (bytes <= 8) {
+                for (uint32_t k = 0; k < bytes; k++) out[o + k] = (uint8_t)(pk >> (8 * k));
+            } else { StoreSink ss; ss.p = out + o; pc_gen_tokens(m, p0, prev_in, zero_in, after, ss); }   // dense word: regenerate straight to memory
         }
         outpos += tot;
-        const int pl = __shfl(incl_last, 63), zl = __shfl(incl_zero, 63);
+        // carries: the last lane that has a match / a non-match in this step
+        const int pl = __shfl(mylast, 63 - __clzll((long long)has1));
         if (pl > prev_carry) prev_carry = pl;
-        if (zl > zero_carry) zero_carry = zl;
+        if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > zero_carry) zero_carry = zl; }
         m_cur = m_next;
     }
     return outpos;
