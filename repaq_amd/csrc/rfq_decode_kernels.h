@@ -350,15 +350,30 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
             // --- sequence + quality.  Interleaved-orientation base j of this read (overlap re-expansion, src/rfqcodec.cpp:865-897):
             uint8_t* ws = w2 + n2 + 1; uint8_t* wst = ws + len + 1; uint8_t* wq = wst + stl + 1;
             const bool rc = il && odd;
-            for (uint32_t k = (uint32_t)l; k < len; k += 64) {
-                const uint32_t p = rc ? len - 1 - k : k;
-                uint8_t b;
-                if (ov > 0) b = p < (uint32_t)ov ? sb[sp - (uint32_t)ov + p] : sb[sp + p - (uint32_t)ov];
-                else if (ov < 0) { const uint32_t keep = len - (uint32_t)(-ov); b = p < keep ? sb[sp + p] : sb[sp - prevlen + (p - keep)]; }
-                else b = sb[sp + p];
-                const uint8_t q = qb[qp + p];
-                if (implied_n && q == nq) b = 'N';                      // src/rfqcodec.cpp:1093-1100
-                ws[k] = rc ? comp_base(b) : b; wq[k] = q;
+            for (uint32_t k0 = 0; k0 < len; k0 += 256) {
+                // 4 strides (8 loads) in flight before the first store: in-order waves otherwise pay one memory latency per stride
+                uint8_t bb[4], qq[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)l; bb[u] = 0; qq[u] = 0;
+                    if (k < len) {
+                        const uint32_t p = rc ? len - 1 - k : k;
+                        uint8_t b;
+                        if (ov > 0) b = p < (uint32_t)ov ? sb[sp - (uint32_t)ov + p] : sb[sp + p - (uint32_t)ov];
+                        else if (ov < 0) { const uint32_t keep = len - (uint32_t)(-ov); b = p < keep ? sb[sp + p] : sb[sp - prevlen + (p - keep)]; }
+                        else b = sb[sp + p];
+                        bb[u] = b; qq[u] = qb[qp + p];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)l;
+                    if (k < len) {
+                        uint8_t b = bb[u]; const uint8_t q = qq[u];
+                        if (implied_n && q == nq) b = 'N';                  // src/rfqcodec.cpp:1093-1100
+                        ws[k] = rc ? comp_base(b) : b; wq[k] = q;
+                    }
+                }
             }
             for (uint32_t i = (uint32_t)l; i < stl; i += 64) wst[i] = stp[i];
             if (l == 0) { ws[len] = '\n'; wst[stl] = '\n'; wq[len] = '\n'; }

@@ -99,7 +99,9 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     if (hs.err & DE_HAS_CR) return rfq_fail(ctx, RFQ_E_TEXT, "FASTQ text contains '\\r' line endings; the device reader handles '\\n'-terminated text only");
     uint32_t nlines[2] = { 0, 0 }, nrec[2] = { 0, 0 };
     for (int s = 0; s < nstreams; s++) {
-        const int unterm = nbytes[s] > 0 && lastbyte[s] != '\n';
+        // an unterminated tail is the file's last line only in the final batch; in a non-final batch it is a line cut by the
+        // batch boundary and belongs to the next batch
+        const int unterm = a->final && nbytes[s] > 0 && lastbyte[s] != '\n';
         nlines[s] = n_newlines[s] + (unterm ? 1u : 0u); nrec[s] = nlines[s] / 4;
         HIPCHK(ctx, B[B_LO0 + s].ensure(((size_t)nlines[s] + 4) * 4));
         if (nblk[s]) {
@@ -126,16 +128,16 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     HIPCHK(ctx, B[B_X].ensure(nr * 4)); HIPCHK(ctx, B[B_Y].ensure(nr * 4)); HIPCHK(ctx, B[B_TILE].ensure(nr * 2)); HIPCHK(ctx, B[B_LANE].ensure(nr)); HIPCHK(ctx, B[B_OK].ensure(nr));
     HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
     HIPCHK(ctx, B[B_PV].ensure(nr * 16)); HIPCHK(ctx, B[B_PVIN].ensure(nr * 16));
-    HIPCHK(ctx, B[B_ULEN].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_P].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_MINMAX].ensure(64));
+    HIPCHK(ctx, B[B_ULEN].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_P].ensure(((size_t)n_units + 2) * 8));
     HIPCHK(ctx, B[B_SCANTMP].ensure(std::max(scantmp, (nr / SCAN_TILE + 2) * 16)));
     ReadTab R;
     R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>(); R.y = B[B_Y].as<uint32_t>();
     R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>(); R.stored = B[B_STORED].as<uint32_t>();
     R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
-    const uint32_t mm_init[2] = { 0xFFFFFFFFu, 0u };
-    HIPCHK(ctx, hipMemcpyAsync(B[B_MINMAX].p, mm_init, 8, hipMemcpyHostToDevice, S));
     hipLaunchKernelGGL(k_read_table, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, n_reads, dst);
-    hipLaunchKernelGGL(k_unit_len, dim3((n_units + 255) / 256), dim3(256), 0, S, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
+    const uint32_t ublocks = (n_units + 255) / 256;
+    HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 8));
+    hipLaunchKernelGGL(k_unit_len, dim3(ublocks), dim3(256), 0, S, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
     KCHK(ctx, "k_read_table");
     scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1);
     scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1);
@@ -145,7 +147,7 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     ChunkTab C; memset(&C, 0, sizeof C);
     C.first = B[B_FIRST].as<uint32_t>();
     hipLaunchKernelGGL(k_partition, dim3(1), dim3(64), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->final ? 1 : 0,
-                       (const uint32_t*)B[B_MINMAX].as<uint32_t>(), C.first, cap_chunks + 1, dst);
+                       (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst);
     KCHK(ctx, "k_partition");
     HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
     HIPCHK(ctx, hipStreamSynchronize(S));

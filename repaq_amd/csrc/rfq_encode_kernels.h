@@ -170,15 +170,21 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, DevStatus* st)
     err = wave_or(err);
     if (l == 0 && err) atomicOr(&st->err, err);
 }
-// bases per partition unit (a read, or a pair) + min / max for the partitioner's uniform-length fast path
-__global__ void k_unit_len(const uint32_t* __restrict__ len, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ len_minmax) {
+// bases per partition unit (a read, or a pair) + per-block min / max for the partitioner's uniform-length fast path
+// (no atomics: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
+__global__ void k_unit_len(const uint32_t* __restrict__ len, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax) {
+    __shared__ uint32_t s_mn[4], s_mx[4];
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t tot = 0;
     if (u < n_units) { for (uint32_t j = 0; j < upr; j++) tot += len[(size_t)u * upr + j]; ulen[u] = tot; }
     uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
     mn = wave_min(mn); mx = wave_max(mx);
-    // same-address atomics serialise at ~11 ns each (MI355X_MICROARCH.md "fanin"): only issue one when it can change the word
-    if (lane_id() == 0) { if (mn < len_minmax[0]) atomicMin(&len_minmax[0], mn); if (mx > len_minmax[1]) atomicMax(&len_minmax[1], mx); }
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; }
+        blk_minmax[2 * blockIdx.x] = mn; blk_minmax[2 * blockIdx.x + 1] = mx;
+    }
 }
 
 // =============================================================== chunk partition (one wave)
@@ -201,8 +207,11 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
     return lo + (uint32_t)(__ffsll((long long)b) - 1);
 }
 __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, int final_batch,
-                            const uint32_t* __restrict__ len_minmax, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
+                            const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
     const int l = lane_id();
+    uint32_t len_minmax[2];
+    { uint32_t mn = 0xFFFFFFFFu, mx = 0; for (uint32_t i = (uint32_t)l; i < n_blk; i += 64) { const uint32_t a = blk_minmax[2 * i], b = blk_minmax[2 * i + 1]; if (a < mn) mn = a; if (b > mx) mx = b; }
+      len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); }
     uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0;
     if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
         // every unit has the same length L: a chunk is K = ceil(chunk_bases / L) units
@@ -556,19 +565,28 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
             const bool rc = __shfl(m_rc, (int)j) != 0; const int ov = __shfl(m_ov, (int)j);
             // stored bases: ov == 0 whole read; ov > 0 skip the first ov bases of RC(R2); ov < 0 drop the last |ov|
             const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u; const uint32_t keep = len - (uint32_t)(ov < 0 ? -ov : ov);
-            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
-                const uint32_t i = i0 + (uint32_t)l; const bool act = i < len; const bool sact = i < keep;
-                uint32_t q = 0, b = 0;
-                if (act) q = rc ? ql[len - 1 - i] : ql[i];
-                if (sact) { const uint32_t jj = i + skip; b = rc ? comp_base(sq[len - 1 - jj]) : sq[jj]; }
-                if (act) qo[i] = (uint8_t)q;
-                if (sact) { so[i] = (uint8_t)b; if (b == 'N') ncnt++; }
-                unsigned long long todo = __ballot(act);
-                while (todo) {                                   // a wave of NovaSeq qualities holds 1-4 distinct values: count each with one ballot
-                    const int src = __ffsll((long long)todo) - 1; const uint32_t vq = __shfl(q, src);
-                    const unsigned long long same = __ballot(act && q == vq);
-                    if (l == src) atomicAdd(&sh[vq], (uint32_t)__popcll(same));
-                    todo &= ~same;
+            for (uint32_t i0 = 0; i0 < len; i0 += 256) {
+                // in-order waves wait for a load before its store: issue 4 strides (8 loads) first, then the stores / counts
+                uint32_t q[4], b[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + 64u * (uint32_t)k + (uint32_t)l;
+                    q[k] = i < len ? (rc ? ql[len - 1 - i] : ql[i]) : 0u;
+                    b[k] = i < keep ? (rc ? comp_base(sq[len - 1 - (i + skip)]) : sq[i + skip]) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + 64u * (uint32_t)k + (uint32_t)l; const bool act = i < len;
+                    if (i0 + 64u * (uint32_t)k >= len) break;                  // wave-uniform
+                    if (act) qo[i] = (uint8_t)q[k];
+                    if (i < keep) { so[i] = (uint8_t)b[k]; if (b[k] == 'N') ncnt++; }
+                    unsigned long long todo = __ballot(act);
+                    while (todo) {                               // a wave of NovaSeq qualities holds 1-4 distinct values: count each with one ballot
+                        const int src = __ffsll((long long)todo) - 1; const uint32_t vq = __shfl(q[k], src);
+                        const unsigned long long same = __ballot(act && q[k] == vq);
+                        if (l == src) atomicAdd(&sh[vq], (uint32_t)__popcll(same));
+                        todo &= ~same;
+                    }
                 }
             }
         }
@@ -611,10 +629,17 @@ __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict
 // and the streak start (last zero position + 1, another max-scan); run lengths look at most 31 positions ahead.
 enum { PC_MATCH = 0, PC_EXCEPT = 1 };
 
-__device__ __forceinline__ uint64_t pc_load_mask(const uint8_t* __restrict__ B, uint32_t len, uint32_t p0, int mode, uint32_t q, const DevHeader* __restrict__ D) {
+struct Raw64 { uint4 v[4]; };
+__device__ __forceinline__ Raw64 pc_load_raw(const uint8_t* __restrict__ B, uint32_t len, uint32_t p0) {
+    Raw64 r; const uint4 z = make_uint4(0, 0, 0, 0);
+    if (p0 < len) { const uint4* p = (const uint4*)(B + p0); r.v[0] = p[0]; r.v[1] = p[1]; r.v[2] = p[2]; r.v[3] = p[3]; }
+    else { r.v[0] = z; r.v[1] = z; r.v[2] = z; r.v[3] = z; }
+    return r;
+}
+__device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uint32_t p0, int mode, uint32_t q, const DevHeader* __restrict__ D) {
     if (p0 >= len) return 0ull;
     uint64_t m = 0;
-    const uint4* p = (const uint4*)(B + p0);
+    const uint4* p = r.v;
     if (mode == PC_MATCH) {
         const uint32_t pat = q * 0x01010101u;
 #pragma unroll
@@ -634,6 +659,7 @@ __device__ __forceinline__ uint64_t pc_load_mask(const uint8_t* __restrict__ B, 
         } else {
             uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             for (uint32_t v = 0; v < 256; v++) if (!D->is_exception[v]) { const uint64_t bit = 1ull << (v & 63u); if (v < 64) a0 |= bit; else if (v < 128) a1 |= bit; else if (v < 192) a2 |= bit; else a3 |= bit; }
+#pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint4 w = p[k]; const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
 #pragma unroll
@@ -693,13 +719,21 @@ __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ 
     uint32_t outpos = 0;
     int prev_carry = -1, zero_carry = -1;                                   // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
     const uint32_t nsteps = (len + 4095u) / 4096u;
-    uint64_t m_cur = nsteps ? pc_load_mask(B, len, 64u * (uint32_t)l, mode, q, D) : 0ull;
+    // software pipeline, two steps deep: raw bytes of step+2 are in flight while step is coded; a step's raw bytes become a mask
+    // only one step after they were requested, so the wave never waits on the load it has just issued
+    Raw64 raw_n = pc_load_raw(B, len, 4096u + 64u * (uint32_t)l);
+    uint64_t m_cur = nsteps ? pc_mask_of(pc_load_raw(B, len, 64u * (uint32_t)l), len, 64u * (uint32_t)l, mode, q, D) : 0ull;
+    uint64_t m_next = nsteps > 1 ? pc_mask_of(raw_n, len, 4096u + 64u * (uint32_t)l, mode, q, D) : 0ull;
+    raw_n = pc_load_raw(B, len, 8192u + 64u * (uint32_t)l);
     for (uint32_t step = 0; step < nsteps; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
-        const uint64_t m_next = (step + 1 < nsteps) ? pc_load_mask(B, len, p0 + 4096u, mode, q, D) : 0ull;
         const uint64_t m = m_cur;
         const unsigned long long has1 = __ballot(m != 0);
-        if (!has1) { zero_carry = (int)(step * 4096u + 4095u); m_cur = m_next; continue; }    // nothing to code in these 4096 positions
+        if (!has1) {                                                            // nothing to code in these 4096 positions
+            zero_carry = (int)(step * 4096u + 4095u);
+            m_cur = m_next; m_next = pc_mask_of(raw_n, len, p0 + 8192u, mode, q, D); raw_n = pc_load_raw(B, len, p0 + 12288u);
+            continue;
+        }
         const unsigned long long has0 = __ballot(~m != 0);
         // last match / last non-match before my word: the nearest earlier lane that has one (ballot + one permute), else the carry
         const int mylast = m ? (int)p0 + 63 - __clzll((long long)m) : -1;
@@ -732,7 +766,7 @@ __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ 
         const int pl = __shfl(mylast, 63 - __clzll((long long)has1));
         if (pl > prev_carry) prev_carry = pl;
         if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > zero_carry) zero_carry = zl; }
-        m_cur = m_next;
+        m_cur = m_next; m_next = pc_mask_of(raw_n, len, p0 + 8192u, mode, q, D); raw_n = pc_load_raw(B, len, p0 + 12288u);
     }
     return outpos;
 }
@@ -904,13 +938,24 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
     if (fl & C_NAME1_SAME) { const uint8_t* src = line_ptr(T, f, 0); for (uint32_t i = t; i < o.n1_size; i += NT) out[o.off_n1 + i] = src[i]; }
     if ((hf & H_NAME2) && (fl & C_NAME2_SAME)) { const uint8_t* src = line_ptr(T, f, 0) + R.name2_off[f]; for (uint32_t i = t; i < o.n2_size; i += NT) out[o.off_n2 + i] = src[i]; }
     if (fl & C_STRAND_SAME) { const uint8_t* src = line_ptr(T, f, 2); for (uint32_t i = t; i < o.st_size; i += NT) out[o.off_st + i] = src[i]; }
-    // 2-bit bases: G=0 A=1 T=2 C=3, anything else 0 (src/rfqcodec.cpp:590-604)
+    // 2-bit bases: G=0 A=1 T=2 C=3, anything else 0 (src/rfqcodec.cpp:590-604).  16 bases (one aligned uint4 of scat) -> 4 bytes.
     {
         const uint8_t* sb = scat + C.sbase[c]; const uint32_t n = R.pv[f + s].d - R.pv[f].d;
-        for (uint32_t i = t; i < o.seq_size; i += NT) {
-            uint32_t v = 0;
-            for (uint32_t b = 0; b < 4; b++) { const uint32_t p = 4 * i + b; if (p < n) { const uint8_t ch = sb[p]; const uint32_t code = ch == 'A' ? 1u : (ch == 'T' ? 2u : (ch == 'C' ? 3u : 0u)); v |= code << (2 * b); } }
-            out[o.off_seq + i] = (uint8_t)v;
+        const uint4* sb4 = (const uint4*)sb; const uint32_t ngroups = (n + 15) / 16;
+        for (uint32_t gi = t; gi < ngroups; gi += NT) {
+            const uint4 w = sb4[gi]; const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t p = 16 * gi + 4 * (uint32_t)k + (uint32_t)b; const uint32_t ch = (ww[k] >> (8 * b)) & 0xFFu;
+                    const uint32_t code = p < n ? (ch == 'A' ? 1u : (ch == 'T' ? 2u : (ch == 'C' ? 3u : 0u))) : 0u;
+                    v |= code << (2 * b);
+                }
+                const uint32_t oi = 4 * gi + (uint32_t)k;
+                if (oi < o.seq_size) out[o.off_seq + oi] = (uint8_t)v;
+            }
         }
     }
     // quality payload
@@ -919,8 +964,13 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
         uint32_t dst = o.off_qual + 4 * nn; const uint8_t* sc = scratch + cbase[c];
         for (uint32_t j = 0; j <= nn; j++) {
             const uint32_t js = j < nn ? j : (uint32_t)EXC_SLOT;          // normal streams in header order, then the exception records
-            const uint32_t sz = C.ssize[k0 + js]; const uint8_t* src = sc + C.soff[k0 + js];
-            for (uint32_t i = t; i < sz; i += NT) out[dst + i] = src[i];
+            const uint32_t sz = C.ssize[k0 + js]; const uint8_t* src = sc + C.soff[k0 + js];      // 16-byte aligned (k_stream_plan)
+            const uint4* src4 = (const uint4*)src;
+            for (uint32_t gi = t; gi < (sz + 15) / 16; gi += NT) {
+                const uint4 w = src4[gi]; const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+                for (int k = 0; k < 16; k++) { const uint32_t i = 16 * gi + (uint32_t)k; if (i < sz) out[dst + i] = (uint8_t)(ww[k >> 2] >> (8 * (k & 3))); }
+            }
             dst += sz;
         }
     }
