@@ -158,3 +158,35 @@ __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { return (uint32_t)
 __device__ __forceinline__ uint8_t comp_base(uint8_t b) {
     switch (b) { case 'A': case 'a': return 'T'; case 'T': case 't': return 'A'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; default: return 'N'; }
 }
+
+// branch-free variant for inner loops (selects, no jump table): same mapping
+__device__ __forceinline__ uint32_t comp_base_sel(uint32_t b) {
+    const uint32_t u = b & 0xDFu;                                   // fold case for letters
+    uint32_t r = 'N';
+    r = (u == 'A') ? 'T' : r; r = (u == 'T') ? 'A' : r; r = (u == 'C') ? 'G' : r; r = (u == 'G') ? 'C' : r;
+    // only exact letters count: b & 0xDF also maps e.g. 0x61-0x20... 'a'(0x61)->'A' ok; but 0x01|... non-letters like 0x41^0x20=0x61 handled; reject bytes whose fold changed a non-letter
+    return ((b | 0x20u) >= 'a' && (b | 0x20u) <= 'z') ? r : 'N';
+}
+
+// 16 consecutive bytes starting at an arbitrary LDS byte address, as four little-endian words: five aligned word reads + funnel shifts
+// (v_alignbyte_b32) instead of sixteen byte reads and ~100 packing instructions.  May read up to 3 bytes past the 16.
+__device__ __forceinline__ void lds_get16(const uint8_t* base, uint32_t a, uint32_t (&w)[4]) {
+    const uint32_t* p = (const uint32_t*)(base + (a & ~3u)); const uint32_t sh = (a & 3u) * 8u;
+    const uint32_t x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4];
+    w[0] = (uint32_t)((((uint64_t)x1 << 32) | x0) >> sh); w[1] = (uint32_t)((((uint64_t)x2 << 32) | x1) >> sh);
+    w[2] = (uint32_t)((((uint64_t)x3 << 32) | x2) >> sh); w[3] = (uint32_t)((((uint64_t)x4 << 32) | x3) >> sh);
+}
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
+// byte-wise full mask (0xFF per byte of w equal to the pattern byte)
+__device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {
+    const uint32_t v = w ^ pat; const uint32_t t = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);   // 0x80 per equal byte
+    return (t >> 7) * 0xFFu;
+}
+// complement of four packed bases, comp_base() semantics (either case -> upper-case complement, anything else -> 'N')
+__device__ __forceinline__ uint32_t comp4(uint32_t w) {
+    const uint32_t u = w & 0xDFDFDFDFu;                                   // fold case; non-letters that alias are filtered below
+    const uint32_t letter = eq_bytes_full((w | 0x20202020u) & 0xE0E0E0E0u, 0x60606060u);   // 0x60..0x7F after |0x20: candidates
+    const uint32_t mA = eq_bytes_full(u, 0x41414141u), mT = eq_bytes_full(u, 0x54545454u), mC = eq_bytes_full(u, 0x43434343u), mG = eq_bytes_full(u, 0x47474747u);
+    const uint32_t any = (mA | mT | mC | mG) & letter;
+    return ((mA & 0x54545454u) | (mT & 0x41414141u) | (mC & 0x47474747u) | (mG & 0x43434343u)) & any | (~any & 0x4E4E4E4Eu);
+}

@@ -5,6 +5,7 @@
 #include "rfq_encode_kernels.h"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 enum EncBuf {   // indices into rfq_ctx::b
     B_BITMAP0 = 0, B_BITMAP1, B_BLK0, B_BLK1, B_LO0, B_LO1, B_SCANTMP,
@@ -63,6 +64,7 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     hipStream_t S = ctx->stream;
     DBuf* B = ctx->b;
     ctx->timer.reset();
+    static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // kernel ablation switches for profiling runs (results are invalid when set)
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
     // ---- status block
@@ -166,7 +168,7 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     HIPCHK(ctx, B[B_SCAP].ensure(nc * MAX_STREAMS * 4)); HIPCHK(ctx, B[B_SOFF].ensure(nc * MAX_STREAMS * 8)); HIPCHK(ctx, B[B_SSIZE].ensure(nc * MAX_STREAMS * 4));
     HIPCHK(ctx, B[B_XSIZE].ensure(nc * 4)); HIPCHK(ctx, B[B_YSIZE].ensure(nc * 4)); HIPCHK(ctx, B[B_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[B_SBASE].ensure(nc * 8));
     HIPCHK(ctx, B[B_IMGSIZE].ensure(nc * 8)); HIPCHK(ctx, B[B_IMGOFF].ensure(nc * 8)); HIPCHK(ctx, B[B_CTOTAL].ensure(nc * 8)); HIPCHK(ctx, B[B_CBASE].ensure(nc * 8));
-    HIPCHK(ctx, B[B_LAYOUT].ensure(nc * sizeof(Layout))); HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats))); HIPCHK(ctx, B[B_OVB].ensure(nr / 2 + 16));
+    HIPCHK(ctx, B[B_LAYOUT].ensure(nc * sizeof(Layout))); HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats) + 8192)); HIPCHK(ctx, B[B_OVB].ensure(nr / 2 + 16));
     const size_t catbytes = (size_t)total_bases + 64 * nc + 256;
     HIPCHK(ctx, B[B_QCAT].ensure(catbytes)); HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
     HIPCHK(ctx, ctx->d_hdr.ensure(sizeof(DevHeader)));
@@ -207,8 +209,11 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     ctx->timer.begin("gather", S);
     HIPCHK(ctx, hipMemsetAsync(C.hist, 0, nc * 256 * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S));
     {
-        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 3) / 4, std::max(1u, 8192u / n_chunks)));
-        hipLaunchKernelGGL(k_gather, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>());
+        // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 128; enough workgroups to fill 256 CUs x 2
+        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + GT_READS - 1) / GT_READS, std::max(1u, 8192u / n_chunks)));
+        hipLaunchKernelGGL(k_gather, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune);
+        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
+            if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
     }
     hipLaunchKernelGGL(k_stream_plan, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks);
     scan_exclusive<uint64_t>(S, B[B_CTOTAL].as<uint64_t>(), B[B_CBASE].as<uint64_t>(), n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);

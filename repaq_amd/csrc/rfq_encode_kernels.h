@@ -531,71 +531,199 @@ __global__ void k_chunk_bases(ReadTab R, ChunkTab C, uint32_t n_chunks) {
 }
 
 // =============================================================== gather (RfqCodec::encodeChunk pass 2, src/rfqcodec.cpp:371-407)
-// One wave per read.  qcat = full-length qualities in chunk order (R2 reversed when interleaved); scat = stored bases
-// (R2 reverse-complemented and overlap-trimmed when interleaved).  Also builds the chunk's quality histogram.
+// qcat = full-length qualities in chunk order (R2 reversed when interleaved); scat = stored bases (R2 reverse-complemented and
+// overlap-trimmed when interleaved).  Also builds the chunk's quality histogram and N count.
+//
+// Byte-granular global accesses cost ~30-40 cycles per wave instruction on gfx950 (measured: the byte-copy version of this kernel
+// ran at 0.9 TB/s), so a workgroup stages the CONTIGUOUS text of up to 128 consecutive reads in LDS with aligned 16 B/lane loads,
+// does all byte shuffling (line extraction, reversal, complement, trimming) from LDS, and writes the two output tiles — also
+// contiguous — with aligned 16 B/lane stores.
+#define GT_READS 64
+#define GT_CAP 28672u
+struct GatherTile {
+    const uint8_t* text;           // LDS copy of the staged spans
+    const uint32_t* dst;           // [cnt+1] chunk-relative start of every read in the output buffer
+    const uint32_t* src;           // [cnt] LDS offset of the read's line
+    const uint32_t* len; const uint32_t* skip; const uint32_t* keep; const uint8_t* rc;
+    uint32_t cnt;
+};
+__device__ __forceinline__ uint32_t tile_find(const uint32_t* dst, uint32_t cnt, uint32_t p) {   // last r with dst[r] <= p
+    // equal-length reads (the usual case): one division finds the read; verify with two LDS reads, else binary search
+    const uint32_t d0 = dst[0], step = dst[1] - d0;
+    if (step) { const uint32_t g = (p - d0) / step; if (g < cnt && dst[g] <= p && p < dst[g + 1]) return g; }
+    uint32_t lo = 0, hi = cnt;                                  // invariant: dst[lo] <= p < dst[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dst[mid] <= p) lo = mid; else hi = mid; }
+    return lo;
+}
+// one output byte at a time, walking the read table: r / off are carried by the caller
+template <bool SEQ> __device__ __forceinline__ uint8_t tile_next(const GatherTile& t, uint32_t& r, uint32_t& off) {
+    while (off >= (SEQ ? t.keep[r] : t.len[r])) { off -= (SEQ ? t.keep[r] : t.len[r]); r++; }
+    const uint32_t L = t.len[r], j = SEQ ? off + t.skip[r] : off;
+    const uint8_t b = t.text[t.src[r] + (t.rc[r] ? L - 1 - j : j)];
+    off++;
+    return (SEQ && t.rc[r]) ? comp_base(b) : b;
+}
+// out[0..n) <- tile bytes [p0, p0+n): unaligned head / tail by bytes, the body as aligned uint4 stores.  count(byte) is called per byte.
+template <bool SEQ, class Count> __device__ __forceinline__ void tile_emit(const GatherTile& t, uint8_t* __restrict__ out, uint32_t p0, uint32_t n, Count& count, int tune = 0) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)out & 15u)) & 15u); if (head > n) head = n;
+    const uint32_t body = (n - head) / 16, tail0 = head + 16 * body;
+    for (uint32_t gi = tid; gi < body; gi += nt) {
+        const uint32_t p = p0 + head + 16 * gi;
+        uint32_t r = tile_find(t.dst, t.cnt, p), off = p - t.dst[r];
+        // One code path for every group (a "fast path + byte-wise slow path" split makes whole waves pay for both): take pieces of
+        // up to 16 bytes from consecutive reads — each one aligned word reads + funnel shifts — and splice them with 128-bit shifts.
+        unsigned long long alo = 0, ahi = 0; uint32_t filled = 0;
+        while (filled < 16) {
+            const uint32_t seg = SEQ ? t.keep[r] : t.len[r];
+            if (off >= seg) { off -= seg; r++; continue; }
+            uint32_t take = seg - off; if (take > 16 - filled) take = 16 - filled;
+            const uint32_t L = t.len[r], j0 = SEQ ? off + t.skip[r] : off; const bool rc = t.rc[r] != 0;
+            uint32_t w[4];
+            if (!rc) lds_get16(t.text, t.src[r] + j0, w);
+            else {                                                        // output byte k = source byte (L-1-j0) - k: fetch 16 bytes forward, reverse
+                uint32_t fwd[4]; lds_get16(t.text, t.src[r] + (L - 1 - j0) - 15u, fwd);
+                w[0] = bswap32(fwd[3]); w[1] = bswap32(fwd[2]); w[2] = bswap32(fwd[1]); w[3] = bswap32(fwd[0]);
+                if (SEQ) { w[0] = comp4(w[0]); w[1] = comp4(w[1]); w[2] = comp4(w[2]); w[3] = comp4(w[3]); }
+            }
+            unsigned long long plo = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32), phi = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+            if (take < 16) {                                              // keep the first `take` bytes
+                if (take >= 8) phi = take == 8 ? 0ull : (phi & ((1ull << (8 * (take - 8))) - 1ull));
+                else { phi = 0ull; plo = take ? (plo & ((1ull << (8 * take)) - 1ull)) : 0ull; }
+            }
+            if (filled) {                                                 // shift left by `filled` bytes
+                if (filled < 8) { phi = (phi << (8 * filled)) | (plo >> (64 - 8 * filled)); plo <<= 8 * filled; }
+                else { phi = filled == 8 ? plo : (plo << (8 * (filled - 8))); plo = 0ull; }
+            }
+            alo |= plo; ahi |= phi; filled += take; off += take;
+        }
+        const uint32_t w0 = (uint32_t)alo, w1 = (uint32_t)(alo >> 32), w2 = (uint32_t)ahi, w3 = (uint32_t)(ahi >> 32);
+        if (!(tune & 16)) count.group(w0, w1, w2, w3);
+        if (!(tune & 32)) *(uint4*)(out + head + 16 * gi) = make_uint4(w0, w1, w2, w3);
+    }
+    if (tid == 0 && head) { uint32_t r = tile_find(t.dst, t.cnt, p0), off = p0 - t.dst[r]; for (uint32_t k = 0; k < head; k++) { const uint8_t b = tile_next<SEQ>(t, r, off); out[k] = b; count(b); } }
+    if (tid == nt - 1 && n > tail0) { const uint32_t p = p0 + tail0; uint32_t r = tile_find(t.dst, t.cnt, p), off = p - t.dst[r]; for (uint32_t k = tail0; k < n; k++) { const uint8_t b = tile_next<SEQ>(t, r, off); out[k] = b; count(b); } }
+}
+// histogram / N counters: group() takes 16 packed bytes (SWAR: no per-byte branches), operator() one byte
+struct QualCount {
+    uint32_t* sh; uint32_t major; uint32_t hot;
+    __device__ __forceinline__ void operator()(uint8_t q) { if (q == major) hot++; else atomicAdd(&sh[q], 1u); }
+    __device__ __forceinline__ void group(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+        const uint32_t pat = major * 0x01010101u;
+        const uint32_t m = eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12);
+        hot += (uint32_t)__popc(m);
+        uint32_t rest = ~m & 0xFFFFu;                              // the ~8 % that are not the major value
+        const unsigned long long lo = (unsigned long long)w0 | ((unsigned long long)w1 << 32), hi = (unsigned long long)w2 | ((unsigned long long)w3 << 32);
+        while (rest) { const int k = __ffs((int)rest) - 1; rest &= rest - 1; const uint32_t q = (uint32_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu); atomicAdd(&sh[q], 1u); }
+    }
+};
+struct NCount {
+    uint32_t n;
+    __device__ __forceinline__ void operator()(uint8_t b) { if (b == 'N') n++; }
+    __device__ __forceinline__ void group(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+        const uint32_t pat = (uint32_t)'N' * 0x01010101u;
+        n += (uint32_t)__popc(eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12));
+    }
+};
+
 __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict__ ovb, const DevHeader* __restrict__ D,
-                         uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat) {
-    __shared__ uint32_t sh[256]; __shared__ uint32_t s_n;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) sh[i] = 0;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
+                         uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat, unsigned long long* dbg, int tune) {
+    long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0; long long a_fit = 0, a_meta = 0, a_stage = 0, a_q = 0, a_s = 0;
+    __shared__ uint4 s_text4[GT_CAP / 16 + 6];
+    __shared__ uint32_t s_qsrc[GT_READS], s_ssrc[GT_READS], s_len[GT_READS], s_skip[GT_READS], s_keep[GT_READS], s_qdst[GT_READS + 1], s_sdst[GT_READS + 1];
+    __shared__ uint8_t s_rc[GT_READS];
+    __shared__ uint32_t sh[256]; __shared__ uint32_t s_n, s_cnt;
+    uint8_t* s_text = (uint8_t*)(s_text4 + 1);                            // 16 bytes of slack in front: reversed 16-byte fetches may start before a line
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 256; i += blockDim.x) sh[i] = 0;
+    if (tid == 0) s_n = 0;
     const uint32_t c = blockIdx.y, f = C.first[c], e = C.first[c + 1];
-    const uint32_t wpb = blockDim.x >> 6; const int l = lane_id();
-    const bool il = C.il[c] != 0; const bool enc = il && (D->flags & H_PE_OVERLAP);
-    const int shift = D->overlap_shift;
+    const bool il = C.il[c] != 0; const bool enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
     uint8_t* qd = qcat + C.qbase[c]; uint8_t* sd = scat + C.sbase[c];
     const uint32_t pq0 = R.pq[f], ps0 = R.pv[f].d;
-    uint32_t ncnt = 0;
-    // a wave takes 64 consecutive reads: every lane fetches one read's metadata (one coalesced round of loads), then the
-    // wave copies read after read with the metadata broadcast by shuffles — no dependent lo[] -> text -> offset chain per read
-    for (uint32_t gb = f + (blockIdx.x * wpb + (uint32_t)wave_id()) * 64u; gb < e; gb += gridDim.x * wpb * 64u) {
-        const uint32_t gl = gb + (uint32_t)l; const bool v = gl < e;
-        uint32_t m_len = 0, m_sq = 0, m_ql = 0, m_qo = 0, m_so = 0; int m_ov = 0, m_rc = 0, m_s = 0;
-        if (v) {
-            uint32_t r; read_loc(T, gl, m_s, r); const uint32_t* p = T.lo[m_s] + 4 * (size_t)r;
-            m_sq = p[1]; m_ql = p[3]; m_len = R.len[gl]; m_qo = R.pq[gl] - pq0; m_so = R.pv[gl].d - ps0;
-            m_rc = (il && ((gl - f) & 1u)) ? 1 : 0;
-            if (m_rc && enc) m_ov = (int)ovb[gl >> 1] - shift;
+    const bool two = T.paired == 1; const uint32_t upr = T.upr;
+    uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup
+    const uint32_t gs = f + blockIdx.x * per; const uint32_t ge = gs + per < e ? gs + per : e;
+    QualCount qc; qc.sh = sh; qc.major = D->major & 0xFFu; qc.hot = 0; NCount nc; nc.n = 0;
+    uint32_t cur = gs;
+    while (cur < ge) {                                                   // block-uniform
+        tk0 = clock64();
+        // ---- how many consecutive reads fit in the LDS tile (monotone predicate -> count)
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        uint32_t a0[2] = { 0, 0 };                                         // 16-aligned global begin of each stream's span
+        if (two) { a0[0] = T.lo[0][4 * (size_t)(cur >> 1)] & ~15u; a0[1] = T.lo[1][4 * (size_t)(cur >> 1)] & ~15u; }
+        else a0[0] = T.lo[0][4 * (size_t)cur] & ~15u;
+        bool fits = false;
+        if (tid < GT_READS && cur + tid < ge) {
+            uint32_t need;
+            if (two) { const uint32_t recs = (tid + 2) >> 1; const size_t r1 = (size_t)(cur >> 1) + recs;
+                       need = ((T.lo[0][4 * r1] - a0[0] + 15u) & ~15u) + 16u + (T.lo[1][4 * r1] - a0[1]); }
+            else need = T.lo[0][4 * (size_t)(cur + tid + 1)] - a0[0];
+            fits = need + 16u <= GT_CAP;
         }
-        const uint32_t cnt = e - gb < 64u ? e - gb : 64u;
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t len = __shfl(m_len, (int)j); const int strm = __shfl(m_s, (int)j);
-            const uint8_t* __restrict__ sq = T.fq[strm] + __shfl(m_sq, (int)j); const uint8_t* __restrict__ ql = T.fq[strm] + __shfl(m_ql, (int)j);
-            uint8_t* __restrict__ qo = qd + __shfl(m_qo, (int)j); uint8_t* __restrict__ so = sd + __shfl(m_so, (int)j);
-            const bool rc = __shfl(m_rc, (int)j) != 0; const int ov = __shfl(m_ov, (int)j);
-            // stored bases: ov == 0 whole read; ov > 0 skip the first ov bases of RC(R2); ov < 0 drop the last |ov|
-            const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u; const uint32_t keep = len - (uint32_t)(ov < 0 ? -ov : ov);
-            for (uint32_t i0 = 0; i0 < len; i0 += 256) {
-                // in-order waves wait for a load before its store: issue 4 strides (8 loads) first, then the stores / counts
-                uint32_t q[4], b[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = i0 + 64u * (uint32_t)k + (uint32_t)l;
-                    q[k] = i < len ? (rc ? ql[len - 1 - i] : ql[i]) : 0u;
-                    b[k] = i < keep ? (rc ? comp_base(sq[len - 1 - (i + skip)]) : sq[i + skip]) : 0u;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = i0 + 64u * (uint32_t)k + (uint32_t)l; const bool act = i < len;
-                    if (i0 + 64u * (uint32_t)k >= len) break;                  // wave-uniform
-                    if (act) qo[i] = (uint8_t)q[k];
-                    if (i < keep) { so[i] = (uint8_t)b[k]; if (b[k] == 'N') ncnt++; }
-                    unsigned long long todo = __ballot(act);
-                    while (todo) {                               // a wave of NovaSeq qualities holds 1-4 distinct values: count each with one ballot
-                        const int src = __ffsll((long long)todo) - 1; const uint32_t vq = __shfl(q[k], src);
-                        const unsigned long long same = __ballot(act && q[k] == vq);
-                        if (l == src) atomicAdd(&sh[vq], (uint32_t)__popcll(same));
-                        todo &= ~same;
-                    }
-                }
+        {   // monotone predicate: the count is the number of fitting indices; one LDS atomic per wave
+            const unsigned long long fb = __ballot(fits);
+            if (lane_id() == 0 && fb) atomicAdd(&s_cnt, (uint32_t)__popcll(fb));
+        }
+        __syncthreads();
+        const uint32_t cnt = s_cnt;
+        if (cnt == 0) {
+            // a single read (pair) larger than the tile: byte-wise copy straight from global memory (rare: reads > ~28 kb)
+            for (uint32_t g = cur; g < cur + upr && g < ge; g++) {
+                const uint32_t len = R.len[g]; const uint8_t* sq = line_ptr(T, g, 1); const uint8_t* ql = line_ptr(T, g, 3);
+                const bool rc = il && ((g - f) & 1u); int ov = 0; if (rc && enc) ov = (int)ovb[g >> 1] - shift;
+                const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u, keep = len - (uint32_t)(ov < 0 ? -ov : ov);
+                uint8_t* qo = qd + (R.pq[g] - pq0); uint8_t* so = sd + (R.pv[g].d - ps0);
+                for (uint32_t i = tid; i < len; i += blockDim.x) { const uint8_t q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = q; qc(q); }
+                for (uint32_t i = tid; i < keep; i += blockDim.x) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b; nc(b); }
+            }
+            cur += upr; __syncthreads(); continue;
+        }
+        tk1 = clock64(); a_fit += tk1 - tk0;
+        // ---- per-read metadata -> LDS
+        uint32_t span_end[2] = { 0, 0 };
+        if (two) { const size_t r1 = (size_t)((cur + cnt) >> 1); span_end[0] = T.lo[0][4 * r1]; span_end[1] = T.lo[1][4 * r1]; }
+        else span_end[0] = T.lo[0][4 * (size_t)(cur + cnt)];
+        const uint32_t base1 = two ? (((span_end[0] - a0[0] + 15u) & ~15u) + 16u) : 0u;   // LDS offset of stream 1's span
+        if (tid < cnt) {
+            const uint32_t g = cur + tid; int st; uint32_t rr; read_loc(T, g, st, rr);
+            const uint32_t* p = T.lo[st] + 4 * (size_t)rr; const uint32_t lb = st ? base1 : 0u;
+            const uint32_t len = R.len[g]; const bool rc = il && ((g - f) & 1u);
+            int ov = 0; if (rc && enc) ov = (int)ovb[g >> 1] - shift;
+            s_ssrc[tid] = lb + (p[1] - a0[st]); s_qsrc[tid] = lb + (p[3] - a0[st]); s_len[tid] = len; s_rc[tid] = rc ? 1 : 0;
+            s_skip[tid] = ov > 0 ? (uint32_t)ov : 0u; s_keep[tid] = len - (uint32_t)(ov < 0 ? -ov : ov);
+            s_qdst[tid] = R.pq[g] - pq0; s_sdst[tid] = R.pv[g].d - ps0;
+        }
+        if (tid == cnt) { s_qdst[cnt] = R.pq[cur + cnt] - pq0; s_sdst[cnt] = R.pv[cur + cnt].d - ps0; }
+        tk2 = clock64(); a_meta += tk2 - tk1;
+        // ---- stage the spans: aligned 16-byte loads (the very last group of a stream may not be fully inside the buffer)
+        for (int st = 0; st < (two ? 2 : 1); st++) {
+            const uint32_t nb = span_end[st] - a0[st]; const uint32_t ng = (nb + 15) / 16; const uint32_t lb = st ? base1 : 0u;
+            const uint8_t* src = T.fq[st] + a0[st];
+            for (uint32_t i = tid; i < ng; i += blockDim.x) {
+                if ((uint64_t)a0[st] + 16ull * i + 16ull <= (uint64_t)T.n[st]) s_text4[1 + lb / 16 + i] = *(const uint4*)(src + 16 * (size_t)i);
+                else for (uint32_t k = 0; k < 16 && a0[st] + 16 * i + k < T.n[st]; k++) s_text[lb + 16 * i + k] = src[16 * (size_t)i + k];
             }
         }
+        __syncthreads();
+        tk3 = clock64(); a_stage += tk3 - tk2;
+        GatherTile t; t.text = s_text; t.len = s_len; t.skip = s_skip; t.keep = s_keep; t.rc = s_rc; t.cnt = cnt;
+        t.dst = s_qdst; t.src = s_qsrc;
+        tile_emit<false>(t, qd + s_qdst[0], s_qdst[0], s_qdst[cnt] - s_qdst[0], qc, tune);
+        tk4 = clock64(); a_q += tk4 - tk3;
+        t.dst = s_sdst; t.src = s_ssrc;
+        tile_emit<true>(t, sd + s_sdst[0], s_sdst[0], s_sdst[cnt] - s_sdst[0], nc, tune);
+        __syncthreads();
+        tk5 = clock64(); a_s += tk5 - tk4;
+        cur += cnt;
     }
-    ncnt = wave_sum(ncnt);
-    if (l == 0 && ncnt) atomicAdd(&s_n, ncnt);
+    const uint32_t hot = wave_sum(qc.hot), nn = wave_sum(nc.n);
+    if (lane_id() == 0) { if (hot) atomicAdd(&sh[qc.major], hot); if (nn) atomicAdd(&s_n, nn); }
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) if (sh[i]) atomicAdd(&C.hist[(size_t)c * 256 + i], sh[i]);
-    if (threadIdx.x == 0 && s_n) atomicAdd(&C.ncount[c], s_n);
+    for (uint32_t i = tid; i < 256; i += blockDim.x) if (sh[i]) atomicAdd(&C.hist[(size_t)c * 256 + i], sh[i]);
+    if (tid == 0 && s_n) atomicAdd(&C.ncount[c], s_n);
+    if (tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a_fit); atomicAdd(&dbg[1], (unsigned long long)a_meta); atomicAdd(&dbg[2], (unsigned long long)a_stage); atomicAdd(&dbg[3], (unsigned long long)a_q); atomicAdd(&dbg[4], (unsigned long long)a_s); atomicAdd(&dbg[5], 1ull); }
 }
 
 // scratch capacity of every stream of a chunk: a value with k matches in len positions codes to at most

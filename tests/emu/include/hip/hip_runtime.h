@@ -144,6 +144,8 @@ static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline long long clock64() { return 0; }
+static inline long long wall_clock64() { return 0; }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() {}
 
