@@ -115,9 +115,9 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     if (a->d_out1) { o1 = a->d_out1; cap1 = a->cap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
     if (a->d_out2) { o2 = a->d_out2; cap2 = a->cap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
     {
-        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 3) / 4, std::max(1u, 8192u / n_chunks)));
-        hipLaunchKernelGGL(k_dec_emit, dim3(bx, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(),
-                           (const uint64_t*)qbase, (const uint64_t*)sbase, (const uint8_t*)qdec, (const uint8_t*)sdec, split, o1, cap1, o2, cap2, dst);
+        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
+        hipLaunchKernelGGL(k_dec_emit, dim3(bx, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
+                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, split, o1, cap1, o2, cap2, dst);
         KCHK(ctx, "k_dec_emit");
     }
     ctx->timer.end(S);

@@ -301,82 +301,137 @@ __global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __r
     U4 t; t.a = (split && (r & 1u)) ? 0u : text; t.b = (split && (r & 1u)) ? text : 0u; t.c = 0; t.d = 0;
     R.tin[g] = t;
 }
-// one wave per read writes its four lines (name re-assembly src/rfqcodec.cpp:1157-1231, RC of odd reads :1248-1252)
+// ---- text emission (name re-assembly src/rfqcodec.cpp:1157-1231, overlap re-expansion :865-897, implied N :1093-1100, RC of odd
+// reads :1248-1252, Read::toString src/read.cpp:170).
+// One wave writes one read's four lines.  w = destination, sb / qb = stored bases / qualities addressed so that sb[sp], qb[qp] are
+// the read's first stored base / quality (either global memory or the LDS copies of a tile).
+struct EmitRead {
+    uint32_t len, n1, n2, stl, mid, sp, qp, prevlen; int ov; bool rc, patch;
+    const uint8_t *n1p, *n2p, *stp, *mp;
+};
+__device__ __forceinline__ void emit_one(uint8_t* w, const EmitRead& e, const uint8_t* sb, const uint8_t* qb, bool implied_n, uint32_t nq,
+                                         uint32_t dpos, uint32_t dch, int l) {
+    for (uint32_t i = (uint32_t)l; i < e.n1; i += 64) w[i] = e.n1p[i];
+    if ((uint32_t)l < e.mid) w[e.n1 + (uint32_t)l] = e.mp[l];
+    uint8_t* w2 = w + e.n1 + e.mid;
+    for (uint32_t i = (uint32_t)l; i < e.n2; i += 64) w2[i] = (e.patch && i == dpos) ? (uint8_t)dch : e.n2p[i];
+    if (l == 0) w2[e.n2] = '\n';
+    uint8_t* ws = w2 + e.n2 + 1; uint8_t* wst = ws + e.len + 1; uint8_t* wq = wst + e.stl + 1;
+    const uint32_t len = e.len; const int ov = e.ov;
+    for (uint32_t k = (uint32_t)l; k < len; k += 64) {
+        const uint32_t p = e.rc ? len - 1 - k : k;                     // position in interleaved orientation
+        uint8_t b;
+        if (ov > 0) b = p < (uint32_t)ov ? sb[e.sp - (uint32_t)ov + p] : sb[e.sp + p - (uint32_t)ov];
+        else if (ov < 0) { const uint32_t keep = len - (uint32_t)(-ov); b = p < keep ? sb[e.sp + p] : sb[e.sp - e.prevlen + (p - keep)]; }
+        else b = sb[e.sp + p];
+        const uint8_t q = qb[e.qp + p];
+        if (implied_n && q == nq) b = 'N';
+        ws[k] = e.rc ? comp_base(b) : b; wq[k] = q;
+    }
+    for (uint32_t i = (uint32_t)l; i < e.stl; i += 64) wst[i] = e.stp[i];
+    if (l == 0) { ws[len] = '\n'; wst[e.stl] = '\n'; wq[len] = '\n'; }
+}
+// global [gbeg, gend) -> LDS so that LDS offset == (global address & 15) + (addr - gbeg): aligned 16-byte loads; the last group is
+// fetched byte-wise when it would cross `glimit` (end of the allocation's valid bytes)
+__device__ __forceinline__ void stage_span(uint4* lds4, const uint8_t* gbase, uint64_t gbeg, uint64_t gend, uint64_t glimit) {
+    const uint64_t a0 = gbeg & ~15ull; const uint32_t ng = (uint32_t)((gend - a0 + 15) / 16);
+    uint8_t* lds = (uint8_t*)lds4;
+    for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) {
+        const uint64_t ga = a0 + 16ull * i;
+        if (ga + 16 <= glimit) lds4[i] = *(const uint4*)(gbase + ga);
+        else for (uint32_t k = 0; k < 16 && ga + k < glimit; k++) lds[16 * i + k] = gbase[ga + k];
+    }
+}
+// LDS tile -> global [gbeg, gend): the tile sits at LDS offset (gbeg & 15) so body groups are aligned on both sides
+__device__ __forceinline__ void flush_span(const uint4* lds4, uint8_t* gbase, uint64_t gbeg, uint64_t gend) {
+    if (gend <= gbeg) return;
+    const uint8_t* lds = (const uint8_t*)lds4; const uint64_t a0 = gbeg & ~15ull;
+    const uint64_t first_full = (gbeg + 15) & ~15ull, last_full = gend & ~15ull;
+    if (first_full < last_full) { const uint32_t ng = (uint32_t)((last_full - first_full) / 16), g0 = (uint32_t)((first_full - a0) / 16);
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) *(uint4*)(gbase + first_full + 16ull * i) = lds4[g0 + i]; }
+    const uint64_t he = first_full < gend ? first_full : gend;
+    for (uint64_t x = gbeg + threadIdx.x; x < he; x += blockDim.x) gbase[x] = lds[x - a0];
+    if (last_full >= first_full) for (uint64_t x = last_full + threadIdx.x; x < gend; x += blockDim.x) gbase[x] = lds[x - a0];
+}
+#define ET_READS 32
+#define ET_OCAP 16384u            // output tile bytes (split: half per stream)
+#define ET_SCAP 6144u             // staged qualities / stored bases
 __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
-                           const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
-                           const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, int split,
+                           const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
+                           const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, int split,
                            uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st) {
+    __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
+    __shared__ uint4 s_q4[ET_SCAP / 16 + 4], s_s4[ET_SCAP / 16 + 4], s_mid4[ET_READS * 40 / 16 + 4];
+    __shared__ uint32_t s_cnt;
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
-    const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual;
-    const uint32_t wpb = blockDim.x >> 6; const int l = lane_id();
+    const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
+    const uint32_t wpb = blockDim.x >> 6; const int l = lane_id(); const uint32_t tid = threadIdx.x;
     const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
-    const uint8_t* qb = qdec + qbase[c]; const uint8_t* sb = sdec + sbase[c];
-    // a wave takes 64 consecutive reads: lane j fetches read j's metadata (offsets, piece lengths), then the wave emits read
-    // after read with everything broadcast by shuffles
-    for (uint32_t rb = (blockIdx.x * wpb + (uint32_t)wave_id()) * 64u; rb < d.reads; rb += gridDim.x * wpb * 64u) {
-        const uint32_t rl = rb + (uint32_t)l; const bool v = rl < d.reads;
-        uint32_t m_at = 0, m_len = 0, m_n1 = 0, m_n2 = 0, m_st = 0, m_mid = 0, m_o1 = 0, m_o2 = 0, m_o3 = 0, m_sp = 0, m_qp = 0, m_prev = 0; int m_ov = 0;
-        if (v) {
-            const uint32_t g = f + rl; const U4 tp = R.tp[g]; const U4 pv = R.pv[g];
-            m_at = (split && (rl & 1u)) ? tp.b : tp.a; m_len = R.len[g]; m_ov = R.ov[g]; m_prev = (rl & 1u) ? R.len[g - 1] : 0u;
-            m_n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : rl)];
-            m_n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : rl)] : 0u;
-            m_st = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : rl)];
-            m_mid = R.mid[(size_t)g * 40 + 39];
-            m_o1 = (fl & C_NAME1_SAME) ? 0u : (pv.a - pv0.a); m_o2 = (fl & C_NAME2_SAME) ? 0u : (pv.b - pv0.b); m_o3 = (fl & C_STRAND_SAME) ? 0u : (pv.c - pv0.c);
-            m_sp = pv.d - pv0.d; m_qp = R.pq[g] - pq0;
+    const uint64_t qg0 = qbase[c], sg0 = sbase[c];                        // chunk bases inside qdec / sdec
+    uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;
+    const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
+    const uint32_t ocap = split ? ET_OCAP / 2 : ET_OCAP;
+    uint32_t cur = rs;
+    while (cur < re) {                                                       // block-uniform
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const uint32_t g0 = f + cur; const U4 tp0 = R.tp[g0]; const uint32_t q0 = R.pq[g0] - pq0, s0 = R.pv[g0].d - pv0.d;
+        bool fits = false;
+        if (tid < ET_READS && cur + tid < re) {
+            uint32_t m = (tid + 2u) & ~1u; if (cur + m > re) m = re - cur;     // whole pairs (a lone last read of an SE chunk is fine)
+            const uint32_t g1 = f + cur + m; const U4 tp1 = R.tp[g1];
+            const uint32_t qn = R.pq[g1] - pq0 - q0, sn = R.pv[g1].d - pv0.d - s0;
+            fits = (tp1.a - tp0.a) + 16u <= ocap && (tp1.b - tp0.b) + 16u <= ocap && qn + 32u <= ET_SCAP && sn + 32u <= ET_SCAP;
         }
-        const uint32_t cnt = d.reads - rb < 64u ? d.reads - rb : 64u;
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t r = rb + j, g = f + r; const int jj = (int)j;
+        { const unsigned long long fb = __ballot(fits); if (l == 0 && fb) atomicAdd(&s_cnt, (uint32_t)__popcll(fb)); }
+        __syncthreads();
+        uint32_t cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
+        const bool tiled = cnt > 0;
+        if (!tiled) { cnt = 2; if (cur + cnt > re) cnt = re - cur; }      // oversized read / pair: straight to global memory, byte-wise
+        const uint32_t g1 = g0 + cnt; const U4 tp1 = R.tp[g1];
+        const uint64_t qa = qg0 + q0, qe = qg0 + (R.pq[g1] - pq0), sa = sg0 + s0, se = sg0 + (R.pv[g1].d - pv0.d);
+        if (tiled) {
+            stage_span(s_q4, qdec, qa, qe, qdec_bytes);
+            stage_span(s_s4, sdec, sa, se, sdec_bytes);
+            stage_span(s_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1);
+        }
+        __syncthreads();
+        const uint8_t* q_l = (const uint8_t*)s_q4 + (qa & 15ull); const uint8_t* s_l = (const uint8_t*)s_s4 + (sa & 15ull);
+        const uint8_t* m_l = (const uint8_t*)s_mid4 + (((uint64_t)g0 * 40) & 15ull);
+        uint8_t* oA = (uint8_t*)s_out4 + (tp0.a & 15u); uint8_t* oB = (uint8_t*)s_out4 + ET_OCAP / 2 + (tp0.b & 15u);
+        for (uint32_t j = (uint32_t)wave_id(); j < cnt; j += wpb) {
+            const uint32_t r = cur + j, g = g0 + j; const U4 tp = R.tp[g]; const U4 pv = R.pv[g];
             const bool odd = (r & 1u) != 0; const bool to2 = split && odd;
-            uint8_t* o = to2 ? out2 : out1; const uint64_t cap = to2 ? cap2 : cap1;
-            const uint64_t at = __shfl(m_at, jj); const uint32_t len = __shfl(m_len, jj);
-            const uint32_t n1 = __shfl(m_n1, jj), n2 = __shfl(m_n2, jj), stl = __shfl(m_st, jj), mid = __shfl(m_mid, jj);
-            const uint8_t* n1p = cp + d.o_n1 + __shfl(m_o1, jj); const uint8_t* n2p = cp + d.o_n2 + __shfl(m_o2, jj); const uint8_t* stp = cp + d.o_st + __shfl(m_o3, jj);
-            const uint32_t sp = __shfl(m_sp, jj), qp = __shfl(m_qp, jj), prevlen = __shfl(m_prev, jj); const int ov = __shfl(m_ov, jj);
-            const uint64_t total = (uint64_t)n1 + mid + n2 + 1 + len + 1 + stl + 1 + len + 1;
-            if (at + total > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
-            uint8_t* w = o + at;
-            // --- name line: name1, the pre-formatted ":lane:tile:x:y" (k_dec_textlen), name2 (mate digit patched when stored once)
-            for (uint32_t i = (uint32_t)l; i < n1; i += 64) w[i] = n1p[i];
-            const uint8_t* mp = R.mid + (size_t)g * 40;
-            if ((uint32_t)l < mid) w[n1 + (uint32_t)l] = mp[l];
-            uint8_t* w2 = w + n1 + mid;
-            const bool patch = (fl & C_NAME2_SAME) && il && odd && D->name2_diff_char != 0;
-            for (uint32_t i = (uint32_t)l; i < n2; i += 64) w2[i] = (patch && i == D->name2_diff_pos) ? (uint8_t)D->name2_diff_char : n2p[i];
-            if (l == 0) w2[n2] = '\n';
-            // --- sequence + quality.  Interleaved-orientation base j of this read (overlap re-expansion, src/rfqcodec.cpp:865-897):
-            uint8_t* ws = w2 + n2 + 1; uint8_t* wst = ws + len + 1; uint8_t* wq = wst + stl + 1;
-            const bool rc = il && odd;
-            for (uint32_t k0 = 0; k0 < len; k0 += 256) {
-                // 4 strides (8 loads) in flight before the first store: in-order waves otherwise pay one memory latency per stride
-                uint8_t bb[4], qq[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)l; bb[u] = 0; qq[u] = 0;
-                    if (k < len) {
-                        const uint32_t p = rc ? len - 1 - k : k;
-                        uint8_t b;
-                        if (ov > 0) b = p < (uint32_t)ov ? sb[sp - (uint32_t)ov + p] : sb[sp + p - (uint32_t)ov];
-                        else if (ov < 0) { const uint32_t keep = len - (uint32_t)(-ov); b = p < keep ? sb[sp + p] : sb[sp - prevlen + (p - keep)]; }
-                        else b = sb[sp + p];
-                        bb[u] = b; qq[u] = qb[qp + p];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)l;
-                    if (k < len) {
-                        uint8_t b = bb[u]; const uint8_t q = qq[u];
-                        if (implied_n && q == nq) b = 'N';                  // src/rfqcodec.cpp:1093-1100
-                        ws[k] = rc ? comp_base(b) : b; wq[k] = q;
-                    }
-                }
+            EmitRead e;
+            e.len = R.len[g]; e.ov = R.ov[g]; e.prevlen = odd ? R.len[g - 1] : 0u;
+            e.n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
+            e.n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
+            e.stl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
+            e.n1p = cp + d.o_n1 + ((fl & C_NAME1_SAME) ? 0u : (pv.a - pv0.a)); e.n2p = cp + d.o_n2 + ((fl & C_NAME2_SAME) ? 0u : (pv.b - pv0.b));
+            e.stp = cp + d.o_st + ((fl & C_STRAND_SAME) ? 0u : (pv.c - pv0.c));
+            e.rc = il && odd; e.patch = (fl & C_NAME2_SAME) && il && odd && dch != 0;
+            const uint64_t at = to2 ? tp.b : tp.a; const uint64_t cap = to2 ? cap2 : cap1;
+            const uint64_t total = (uint64_t)e.n1 + e.n2 + 1 + e.len + 1 + e.stl + 1 + e.len + 1;   // + mid below
+            if (tiled) {
+                e.mp = m_l + 40u * j; e.mid = e.mp[39];
+                e.sp = (pv.d - pv0.d) - s0; e.qp = (R.pq[g] - pq0) - q0;
+                if (at + total + e.mid > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
+                uint8_t* w = to2 ? oB + (tp.b - tp0.b) : oA + (tp.a - tp0.a);
+                emit_one(w, e, s_l, q_l, implied_n, nq, dpos, dch, l);
+            } else {
+                e.mp = R.mid + (size_t)g * 40; e.mid = e.mp[39];
+                e.sp = pv.d - pv0.d; e.qp = R.pq[g] - pq0;
+                if (at + total + e.mid > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
+                emit_one((to2 ? out2 : out1) + at, e, sdec + sg0, qdec + qg0, implied_n, nq, dpos, dch, l);
             }
-            for (uint32_t i = (uint32_t)l; i < stl; i += 64) wst[i] = stp[i];
-            if (l == 0) { ws[len] = '\n'; wst[stl] = '\n'; wq[len] = '\n'; }
         }
+        __syncthreads();
+        if (tiled) {
+            if (tp1.a <= cap1) flush_span(s_out4, out1, tp0.a, tp1.a);
+            if (split && tp1.b <= cap2) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
+        }
+        __syncthreads();
+        cur += cnt;
     }
 }
