@@ -190,3 +190,11 @@ __device__ __forceinline__ uint32_t comp4(uint32_t w) {
     const uint32_t any = (mA | mT | mC | mG) & letter;
     return ((mA & 0x54545454u) | (mT & 0x41414141u) | (mC & 0x47474747u) | (mG & 0x43434343u)) & any | (~any & 0x4E4E4E4Eu);
 }
+
+// LDS hand-off between lanes of ONE wave (rows private to the wave): order the wave's LDS writes before its later LDS reads.
+// (DS operations of a wave execute in order; this pins the compiler's ordering and is free at run time.)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

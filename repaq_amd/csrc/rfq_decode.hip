@@ -6,6 +6,7 @@
 #include "rfq_decode_kernels.h"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
@@ -20,6 +21,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     ctx->err.clear();
     if (a->n && !a->d_rfq) return rfq_fail(ctx, RFQ_E_ARG, "null rfq pointer");
     hipStream_t S = ctx->stream; DBuf* B = ctx->b;
+    static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // profiling aid: phase cycle counters (dbg words alias the head of the mid buffer: text is invalid when set)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->timer.reset();
     uint64_t start = 0;
@@ -41,15 +43,27 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     HIPCHK(ctx, B[DB_STATUS].ensure(sizeof(DecStatus)));
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs;
     uint32_t cap = (uint32_t)std::max<size_t>(B[DB_CHUNKS].cap / sizeof(DChunk), 4096);
+    bool speculate = true;
     for (;;) {
         HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
         HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
-        hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
+        if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
+        else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
         KCHK(ctx, "k_dec_walk");
         HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
         HIPCHK(ctx, hipStreamSynchronize(S));
-        if (!hs.overflow) break;
-        cap = hs.n_chunks + 1024;
+        if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
+        if (!speculate) break;
+        if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image: walk it properly
+        if (hs.n_chunks) {
+            hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst);
+            KCHK(ctx, "k_dec_parse");
+            DecStatus h2; HIPCHK(ctx, hipMemcpyAsync(&h2, dst, sizeof h2, hipMemcpyDeviceToHost, S));
+            HIPCHK(ctx, hipStreamSynchronize(S));
+            if (h2.pad) { speculate = false; continue; }                   // an extent did not verify: foreign writer or corrupt image
+        }
+        if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
+        break;
     }
     ctx->timer.end(S);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "truncated or corrupt rfq chunk at byte %llu", (unsigned long long)hs.consumed);
@@ -116,8 +130,10 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     if (a->d_out2) { o2 = a->d_out2; cap2 = a->cap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
     {
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
+        if (tune) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
         hipLaunchKernelGGL(k_dec_emit, dim3(bx, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
-                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, split, o1, cap1, o2, cap2, dst);
+                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
+        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
         KCHK(ctx, "k_dec_emit");
     }
     ctx->timer.end(S);

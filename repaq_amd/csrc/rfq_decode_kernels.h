@@ -30,52 +30,95 @@ __device__ __forceinline__ uint32_t wave_sum_bytes(const uint8_t* __restrict__ p
     for (uint32_t i = (uint32_t)lane_id(); i < n; i += 64) acc += p[i];
     return wave_sum(acc);
 }
-// One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays).
+// RfqChunk::read for the chunk at byte k (wave-cooperative: length arrays are summed by the whole wave).
+// Returns 0 = ok, 1 = clean end of image (short tail / mReads == 0), 2 = corrupt.
+__device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint64_t n, uint64_t k, uint32_t hf, uint32_t rlb, DChunk& d) {
+    if (n - k < 18) return 1;
+    const uint8_t* p = img + k;
+    d.off = k;
+    d.reads = ld_u32(p + 4); d.flags = ld_u16(p + 8); d.seq_size = ld_u32(p + 10); d.qual_size = ld_u32(p + 14);
+    if (d.reads == 0) return 1;
+    const uint64_t left = n - k; uint64_t q = 18;
+    d.npos_size = 0; if (hf & H_N_POS) { if (left < q + 4) return 2; d.npos_size = ld_u32(p + q); q += 4; }
+    const uint32_t s = d.reads, fl = d.flags; const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s;
+    d.o_readlens = (uint32_t)q; q += (uint64_t)((fl & C_READ_LEN_SAME) ? 1u : s) * rlb;
+    if (q > left) return 2;
+#define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
+        const uint32_t m_ = (fl & (LENFLAG)) ? 1u : s; OFF = (uint32_t)q; if (q + m_ > left) return 2; \
+        uint32_t sum_ = (fl & (LENFLAG)) ? (uint32_t)p[q] : wave_sum_bytes(p + q, m_); \
+        if ((fl & (LENFLAG)) && !(fl & (SAMEFLAG))) sum_ *= s; SIZE = sum_; q += m_; }
+    RFQ_LENARR(d.o_n1lens, d.n1_size, C_NAME1_LEN_SAME, C_NAME1_SAME)
+    d.o_n2lens = (uint32_t)q; d.n2_size = 0;
+    if (hf & H_NAME2) RFQ_LENARR(d.o_n2lens, d.n2_size, C_NAME2_LEN_SAME, C_NAME2_SAME)
+    RFQ_LENARR(d.o_stlens, d.st_size, C_STRAND_LEN_SAME, C_STRAND_SAME)
+#undef RFQ_LENARR
+    d.o_lanes = (uint32_t)q; if (hf & H_LANE) q += (fl & C_LANE_SAME) ? 1u : h;
+    d.o_tiles = (uint32_t)q; if (hf & H_TILE) q += 2ull * ((fl & C_TILE_SAME) ? 1u : h);
+    d.x_size = 0; d.y_size = 0;
+    d.o_x = (uint32_t)q; if (hf & H_X) { if (q + 4 > left) return 2; d.x_size = ld_u32(p + q); q += 4ull + d.x_size; }
+    if (q > left) return 2;
+    d.o_y = (uint32_t)q; if (hf & H_Y) { if (q + 4 > left) return 2; d.y_size = ld_u32(p + q); q += 4ull + d.y_size; }
+    d.o_n1 = (uint32_t)q; q += d.n1_size;
+    d.o_n2 = (uint32_t)q; if (hf & H_NAME2) q += d.n2_size;
+    d.o_st = (uint32_t)q; q += d.st_size;
+    d.o_seq = (uint32_t)q; q += d.seq_size;
+    d.o_qual = (uint32_t)q; q += d.qual_size;
+    d.o_ov = (uint32_t)q; if ((fl & C_PE_INTERLEAVED) && (hf & H_PE_OVERLAP)) q += s / 2;
+    d.o_npos = (uint32_t)q; if (hf & H_N_POS) q += d.npos_size;
+    if (q > left || q > 0xFFFFFFFFull) return 2;
+    d.total = (uint32_t)q;
+    return 0;
+}
+// One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays; the reader ignores mSize).
 __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st) {
     const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
     uint64_t k = start; uint32_t c = 0, maxr = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
     if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
     while (!err) {
-        if (n - k < 18) break;                                   // clean EOF (or trailing garbage shorter than a chunk head)
-        const uint8_t* p = img + k;
-        DChunk d; d.off = k;
-        d.reads = ld_u32(p + 4); d.flags = ld_u16(p + 8); d.seq_size = ld_u32(p + 10); d.qual_size = ld_u32(p + 14);
-        if (d.reads == 0) break;
-        const uint64_t left = n - k; uint64_t q = 18;
-        d.npos_size = 0; if (hf & H_N_POS) { if (left < q + 4) { err = DE_CORRUPT; break; } d.npos_size = ld_u32(p + q); q += 4; }
-        const uint32_t s = d.reads, fl = d.flags; const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s;
-        d.o_readlens = (uint32_t)q; q += (uint64_t)((fl & C_READ_LEN_SAME) ? 1u : s) * rlb;
-        if (q > left) { err = DE_CORRUPT; break; }
-#define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
-            const uint32_t m_ = (fl & (LENFLAG)) ? 1u : s; OFF = (uint32_t)q; if (q + m_ > left) { err = DE_CORRUPT; break; } \
-            uint32_t sum_ = (fl & (LENFLAG)) ? (uint32_t)p[q] : wave_sum_bytes(p + q, m_); \
-            if ((fl & (LENFLAG)) && !(fl & (SAMEFLAG))) sum_ *= s; SIZE = sum_; q += m_; }
-        RFQ_LENARR(d.o_n1lens, d.n1_size, C_NAME1_LEN_SAME, C_NAME1_SAME)
-        d.o_n2lens = (uint32_t)q; d.n2_size = 0;
-        if (hf & H_NAME2) RFQ_LENARR(d.o_n2lens, d.n2_size, C_NAME2_LEN_SAME, C_NAME2_SAME)
-        RFQ_LENARR(d.o_stlens, d.st_size, C_STRAND_LEN_SAME, C_STRAND_SAME)
-#undef RFQ_LENARR
-        d.o_lanes = (uint32_t)q; if (hf & H_LANE) q += (fl & C_LANE_SAME) ? 1u : h;
-        d.o_tiles = (uint32_t)q; if (hf & H_TILE) q += 2ull * ((fl & C_TILE_SAME) ? 1u : h);
-        d.x_size = 0; d.y_size = 0;
-        d.o_x = (uint32_t)q; if (hf & H_X) { if (q + 4 > left) { err = DE_CORRUPT; break; } d.x_size = ld_u32(p + q); q += 4ull + d.x_size; }
-        if (q > left) { err = DE_CORRUPT; break; }
-        d.o_y = (uint32_t)q; if (hf & H_Y) { if (q + 4 > left) { err = DE_CORRUPT; break; } d.y_size = ld_u32(p + q); q += 4ull + d.y_size; }
-        d.o_n1 = (uint32_t)q; q += d.n1_size;
-        d.o_n2 = (uint32_t)q; if (hf & H_NAME2) q += d.n2_size;
-        d.o_st = (uint32_t)q; q += d.st_size;
-        d.o_seq = (uint32_t)q; q += d.seq_size;
-        d.o_qual = (uint32_t)q; q += d.qual_size;
-        d.o_ov = (uint32_t)q; if ((fl & C_PE_INTERLEAVED) && (hf & H_PE_OVERLAP)) q += s / 2;
-        d.o_npos = (uint32_t)q; if (hf & H_N_POS) q += d.npos_size;
-        if (q > left || q > 0xFFFFFFFFull) { err = DE_CORRUPT; break; }
-        d.total = (uint32_t)q; d.rbase = (uint32_t)rb;
+        DChunk d; const int rc = parse_chunk(img, n, k, hf, rlb, d);
+        if (rc == 1) break;
+        if (rc == 2) { err = DE_CORRUPT; break; }
+        d.rbase = (uint32_t)rb;
         if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
-        if (s > maxr) maxr = s;
-        lastfl = fl; rb += s; k += q; c++;
+        if (d.reads > maxr) maxr = d.reads;
+        lastfl = d.flags; rb += d.reads; k += d.total; c++;
         if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
     }
     if (l == 0) { st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; }
+}
+// Speculative walk: images written by repaq (or this engine) carry mSize = true size - Delta(flags) (the accounting bug Q1 is a
+// pure function of the header and chunk flags), so the chain needs ONE dependent 10-byte read per chunk instead of a full parse.
+// k_dec_parse then parses every candidate in parallel and verifies that its true extent equals the speculated one; any mismatch
+// (a foreign writer, a corrupt image) makes the host fall back to k_dec_walk.
+__global__ void k_dec_spec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st) {
+    const uint32_t hf = D->flags; const int l = lane_id();
+    uint64_t k = start; uint32_t c = 0, maxr = 0, lastfl = 0, ovf = 0, bad = 0; uint64_t rb = 0;
+    for (;;) {
+        if (n - k < 18) break;
+        const uint8_t* p = img + k;
+        const uint32_t ms = ld_u32(p), s = ld_u32(p + 4), fl = ld_u16(p + 8);
+        if (s == 0) break;
+        const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s;
+        long long total = (long long)ms;
+        if (hf & H_LANE) total += (fl & C_LANE_SAME) ? 1 : (long long)h;                         // lane bytes are never counted in mSize
+        if (!(hf & H_TILE)) total -= (fl & C_TILE_SAME) ? 2 : 2ll * h;                           // "tile" bytes are counted even when absent
+        if (!(hf & H_NAME2)) total -= (fl & C_NAME2_LEN_SAME) ? 1 : (long long)s;                // so are the name2 lengths (name2 bytes assumed empty)
+        if (total < 18 || (unsigned long long)total > n - k) { bad = 1; break; }
+        if (c < cap) { if (l == 0) { out[c].off = k; out[c].total = (uint32_t)total; out[c].rbase = (uint32_t)rb; out[c].reads = s; } } else ovf = 1;
+        if (s > maxr) maxr = s;
+        lastfl = fl; rb += s; k += (unsigned long long)total; c++;
+        if (rb > 0xFFFFFFF0ull) { bad = 1; break; }
+    }
+    if (l == 0) { st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->pad = bad; }
+}
+// one wave per speculated chunk: full parse + verification of the extent
+__global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const DevHeader* __restrict__ D, DChunk* __restrict__ CH, DecStatus* st) {
+    const uint32_t c = blockIdx.x; const uint32_t hf = D->flags, rlb = D->read_len_bytes;
+    const uint64_t k = CH[c].off; const uint32_t want = CH[c].total, rbase = CH[c].rbase, reads = CH[c].reads;
+    DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
+    if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
+    d.rbase = rbase;
+    if (lane_id() == 0) CH[c] = d;
 }
 
 struct DReadTab {
@@ -342,6 +385,37 @@ __device__ __forceinline__ void stage_span(uint4* lds4, const uint8_t* gbase, ui
         else for (uint32_t k = 0; k < 16 && ga + k < glimit; k++) lds[16 * i + k] = gbase[ga + k];
     }
 }
+// Several spans at once: every thread issues up to 4 loads (one pass over the concatenated group index space) before its first
+// LDS store, so the tile's six small spans cost ONE memory latency instead of six.
+struct StageSpan { const uint8_t* g; uint64_t a0; uint32_t ng; uint4* l; uint64_t lim; };
+__device__ __forceinline__ StageSpan make_span(uint4* lds4, const uint8_t* gbase, uint64_t gbeg, uint64_t gend, uint64_t glimit, bool on) {
+    StageSpan s; s.g = gbase; s.a0 = gbeg & ~15ull; s.ng = on ? (uint32_t)((gend - s.a0 + 15) / 16) : 0u; s.l = lds4; s.lim = glimit; return s;
+}
+template <int N> __device__ __forceinline__ void stage_spans(const StageSpan (&sp)[N]) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) total += sp[k].ng;
+    for (uint32_t base = threadIdx.x; base < total; base += 4 * blockDim.x) {
+        uint4 v[4]; uint4* dst[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t i = base + (uint32_t)u * blockDim.x; ok[u] = i < total; dst[u] = nullptr; v[u] = make_uint4(0, 0, 0, 0);
+            if (ok[u]) {
+                int k = 0;
+#pragma unroll
+                for (int t = 0; t < N - 1; t++) if (k == t && i >= sp[t].ng) { i -= sp[t].ng; k = t + 1; }
+                const uint8_t* g = sp[0].g; uint64_t a0 = sp[0].a0, lim = sp[0].lim; uint4* l = sp[0].l;
+#pragma unroll
+                for (int t = 1; t < N; t++) if (k == t) { g = sp[t].g; a0 = sp[t].a0; lim = sp[t].lim; l = sp[t].l; }
+                const uint64_t ga = a0 + 16ull * i; dst[u] = l + i;
+                if (ga + 16 <= lim) v[u] = *(const uint4*)(g + ga);
+                else { uint32_t w[4] = { 0, 0, 0, 0 }; for (uint32_t b = 0; b < 16 && ga + b < lim; b++) w[b >> 2] |= (uint32_t)g[ga + b] << (8 * (b & 3)); v[u] = make_uint4(w[0], w[1], w[2], w[3]); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (ok[u]) *dst[u] = v[u];
+    }
+}
 // LDS tile -> global [gbeg, gend): the tile sits at LDS offset (gbeg & 15) so body groups are aligned on both sides
 __device__ __forceinline__ void flush_span(const uint4* lds4, uint8_t* gbase, uint64_t gbeg, uint64_t gend) {
     if (gend <= gbeg) return;
@@ -356,13 +430,18 @@ __device__ __forceinline__ void flush_span(const uint4* lds4, uint8_t* gbase, ui
 #define ET_READS 32
 #define ET_OCAP 16384u            // output tile bytes (split: half per stream)
 #define ET_SCAP 6144u             // staged qualities / stored bases
+#define ET_N1CAP 4096u            // staged name1 / name2 / strand pieces of the tile (fall back to global memory when larger)
+#define ET_N2CAP 1024u
+#define ET_STCAP 512u
 __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
-                           const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, int split,
-                           uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st) {
+                           const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, uint64_t img_bytes, int split,
+                           uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st, unsigned long long* dbg) {
+    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
     __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
     __shared__ uint4 s_q4[ET_SCAP / 16 + 4], s_s4[ET_SCAP / 16 + 4], s_mid4[ET_READS * 40 / 16 + 4];
-    __shared__ uint32_t s_cnt;
+    __shared__ uint4 s_n14[ET_N1CAP / 16 + 4], s_n24[ET_N2CAP / 16 + 4], s_st4[ET_STCAP / 16 + 4];
+    __shared__ uint32_t s_cnt; __shared__ uint32_t s_meta[(ET_READS + 1) * 16];
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
     const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
@@ -374,64 +453,96 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
     const uint32_t ocap = split ? ET_OCAP / 2 : ET_OCAP;
     uint32_t cur = rs;
     while (cur < re) {                                                       // block-uniform
+        k0 = clock64();
+        // ---- phase 1: scalars of the next <= ET_READS reads (+1 end sentinel) -> LDS, one parallel round of global loads
+        const uint32_t g0 = f + cur;
         if (tid == 0) s_cnt = 0;
+        if (tid <= ET_READS && cur + tid <= re) {
+            const uint32_t r = cur + tid, g = g0 + tid; const U4 tp = R.tp[g]; const U4 pv = R.pv[g]; const bool odd = (r & 1u) != 0;
+            uint32_t* m = s_meta + 16 * tid;
+            m[12] = tp.a; m[13] = tp.b; m[14] = pv.d - pv0.d; m[15] = R.pq[g] - pq0;          // prefix values (also valid for the sentinel)
+            m[7] = pv.a - pv0.a; m[8] = pv.b - pv0.b; m[9] = pv.c - pv0.c;
+            if (r < re) {
+                m[0] = (split && odd) ? tp.b : tp.a; m[1] = R.len[g]; m[2] = (uint32_t)R.ov[g]; m[3] = odd ? R.len[g - 1] : 0u;
+                m[4] = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
+                m[5] = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
+                m[6] = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
+            }
+        }
         __syncthreads();
-        const uint32_t g0 = f + cur; const U4 tp0 = R.tp[g0]; const uint32_t q0 = R.pq[g0] - pq0, s0 = R.pv[g0].d - pv0.d;
+        k1 = clock64(); a1 += k1 - k0;
+        // ---- phase 2: how many reads fit (from LDS)
+        const uint32_t* mb = s_meta;                                          // entry 0 = first read of the tile
         bool fits = false;
         if (tid < ET_READS && cur + tid < re) {
-            uint32_t m = (tid + 2u) & ~1u; if (cur + m > re) m = re - cur;     // whole pairs (a lone last read of an SE chunk is fine)
-            const uint32_t g1 = f + cur + m; const U4 tp1 = R.tp[g1];
-            const uint32_t qn = R.pq[g1] - pq0 - q0, sn = R.pv[g1].d - pv0.d - s0;
-            fits = (tp1.a - tp0.a) + 16u <= ocap && (tp1.b - tp0.b) + 16u <= ocap && qn + 32u <= ET_SCAP && sn + 32u <= ET_SCAP;
+            uint32_t mm = (tid + 2u) & ~1u; if (cur + mm > re) mm = re - cur;  // whole pairs (a lone last read of an SE chunk is fine)
+            const uint32_t* me = s_meta + 16 * mm;
+            fits = (me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 32u <= ET_SCAP && (me[14] - mb[14]) + 32u <= ET_SCAP;
         }
         { const unsigned long long fb = __ballot(fits); if (l == 0 && fb) atomicAdd(&s_cnt, (uint32_t)__popcll(fb)); }
         __syncthreads();
         uint32_t cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
         const bool tiled = cnt > 0;
         if (!tiled) { cnt = 2; if (cur + cnt > re) cnt = re - cur; }      // oversized read / pair: straight to global memory, byte-wise
-        const uint32_t g1 = g0 + cnt; const U4 tp1 = R.tp[g1];
-        const uint64_t qa = qg0 + q0, qe = qg0 + (R.pq[g1] - pq0), sa = sg0 + s0, se = sg0 + (R.pv[g1].d - pv0.d);
-        if (tiled) {
-            stage_span(s_q4, qdec, qa, qe, qdec_bytes);
-            stage_span(s_s4, sdec, sa, se, sdec_bytes);
-            stage_span(s_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1);
+        const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + 16 * cnt;
+        U4 tp0, tp1; tp0.a = mb[12]; tp0.b = mb[13]; tp1.a = me[12]; tp1.b = me[13];
+        const uint32_t q0 = mb[15], s0 = mb[14];
+        const uint64_t qa = qg0 + q0, qe = qg0 + me[15], sa = sg0 + s0, se = sg0 + me[14];
+        k2 = clock64(); a2 += k2 - k1;
+        // ---- phase 3: stage the tile's sources with aligned 16-byte loads.  name1 / name2 / strand: one copy when the chunk stores
+        // them once, else the contiguous run of the tile's reads
+        const uint64_t ib = d.off;                                         // global byte offsets inside the image
+        const uint32_t a7 = (fl & C_NAME1_SAME) ? 0u : mb[7], a8 = (fl & C_NAME2_SAME) ? 0u : mb[8], a9 = (fl & C_STRAND_SAME) ? 0u : mb[9];
+        const uint64_t n1a = ib + d.o_n1 + a7, n1e = (fl & C_NAME1_SAME) ? n1a + d.n1_size : ib + d.o_n1 + me[7];
+        const uint64_t n2a = ib + d.o_n2 + a8, n2e = (fl & C_NAME2_SAME) ? n2a + d.n2_size : ib + d.o_n2 + me[8];
+        const uint64_t sta = ib + d.o_st + a9, ste = (fl & C_STRAND_SAME) ? sta + d.st_size : ib + d.o_st + me[9];
+        const bool n1l = tiled && n1e - n1a + 32 <= ET_N1CAP, n2l = tiled && n2e - n2a + 32 <= ET_N2CAP, stl_ = tiled && ste - sta + 32 <= ET_STCAP;
+        {
+            const StageSpan sp[6] = { make_span(s_q4, qdec, qa, qe, qdec_bytes, tiled), make_span(s_s4, sdec, sa, se, sdec_bytes, tiled),
+                                      make_span(s_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, tiled),
+                                      make_span(s_n14, img, n1a, n1e, img_bytes, n1l), make_span(s_n24, img, n2a, n2e, img_bytes, n2l), make_span(s_st4, img, sta, ste, img_bytes, stl_) };
+            stage_spans<6>(sp);
         }
         __syncthreads();
+        k3 = clock64(); a3 += k3 - k2;
+        // ---- phase 4: one wave per read composes its four lines inside the LDS output tile
         const uint8_t* q_l = (const uint8_t*)s_q4 + (qa & 15ull); const uint8_t* s_l = (const uint8_t*)s_s4 + (sa & 15ull);
         const uint8_t* m_l = (const uint8_t*)s_mid4 + (((uint64_t)g0 * 40) & 15ull);
         uint8_t* oA = (uint8_t*)s_out4 + (tp0.a & 15u); uint8_t* oB = (uint8_t*)s_out4 + ET_OCAP / 2 + (tp0.b & 15u);
         for (uint32_t j = (uint32_t)wave_id(); j < cnt; j += wpb) {
-            const uint32_t r = cur + j, g = g0 + j; const U4 tp = R.tp[g]; const U4 pv = R.pv[g];
+            const uint32_t r = cur + j, g = g0 + j; const uint32_t* m = s_meta + 16 * j;
             const bool odd = (r & 1u) != 0; const bool to2 = split && odd;
             EmitRead e;
-            e.len = R.len[g]; e.ov = R.ov[g]; e.prevlen = odd ? R.len[g - 1] : 0u;
-            e.n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
-            e.n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
-            e.stl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
-            e.n1p = cp + d.o_n1 + ((fl & C_NAME1_SAME) ? 0u : (pv.a - pv0.a)); e.n2p = cp + d.o_n2 + ((fl & C_NAME2_SAME) ? 0u : (pv.b - pv0.b));
-            e.stp = cp + d.o_st + ((fl & C_STRAND_SAME) ? 0u : (pv.c - pv0.c));
+            e.len = m[1]; e.ov = (int)m[2]; e.prevlen = m[3]; e.n1 = m[4]; e.n2 = m[5]; e.stl = m[6];
+            const uint32_t o7 = (fl & C_NAME1_SAME) ? 0u : m[7], o8 = (fl & C_NAME2_SAME) ? 0u : m[8], o9 = (fl & C_STRAND_SAME) ? 0u : m[9];
+            e.n1p = n1l ? (const uint8_t*)s_n14 + (n1a & 15ull) + (o7 - a7) : cp + d.o_n1 + o7;
+            e.n2p = n2l ? (const uint8_t*)s_n24 + (n2a & 15ull) + (o8 - a8) : cp + d.o_n2 + o8;
+            e.stp = stl_ ? (const uint8_t*)s_st4 + (sta & 15ull) + (o9 - a9) : cp + d.o_st + o9;
             e.rc = il && odd; e.patch = (fl & C_NAME2_SAME) && il && odd && dch != 0;
-            const uint64_t at = to2 ? tp.b : tp.a; const uint64_t cap = to2 ? cap2 : cap1;
+            const uint64_t at = m[0]; const uint64_t cap = to2 ? cap2 : cap1;
             const uint64_t total = (uint64_t)e.n1 + e.n2 + 1 + e.len + 1 + e.stl + 1 + e.len + 1;   // + mid below
             if (tiled) {
                 e.mp = m_l + 40u * j; e.mid = e.mp[39];
-                e.sp = (pv.d - pv0.d) - s0; e.qp = (R.pq[g] - pq0) - q0;
+                e.sp = m[14] - s0; e.qp = m[15] - q0;
                 if (at + total + e.mid > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
-                uint8_t* w = to2 ? oB + (tp.b - tp0.b) : oA + (tp.a - tp0.a);
+                uint8_t* w = to2 ? oB + ((uint32_t)at - tp0.b) : oA + ((uint32_t)at - tp0.a);
                 emit_one(w, e, s_l, q_l, implied_n, nq, dpos, dch, l);
             } else {
                 e.mp = R.mid + (size_t)g * 40; e.mid = e.mp[39];
-                e.sp = pv.d - pv0.d; e.qp = R.pq[g] - pq0;
+                e.sp = m[14]; e.qp = m[15];
                 if (at + total + e.mid > cap) { if (l == 0) atomicOr(&st->err, 1u << 31); continue; }
                 emit_one((to2 ? out2 : out1) + at, e, sdec + sg0, qdec + qg0, implied_n, nq, dpos, dch, l);
             }
         }
         __syncthreads();
+        k4 = clock64(); a4 += k4 - k3;
+        // ---- phase 5: aligned 16-byte stores of the finished tile (no barrier after it: three barriers precede the next compose)
         if (tiled) {
             if (tp1.a <= cap1) flush_span(s_out4, out1, tp0.a, tp1.a);
             if (split && tp1.b <= cap2) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
         }
-        __syncthreads();
+        k5 = clock64(); a5 += k5 - k4;
         cur += cnt;
     }
+    if (tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a1); atomicAdd(&dbg[1], (unsigned long long)a2); atomicAdd(&dbg[2], (unsigned long long)a3); atomicAdd(&dbg[3], (unsigned long long)a4); atomicAdd(&dbg[4], (unsigned long long)a5); atomicAdd(&dbg[5], 1ull); }
 }

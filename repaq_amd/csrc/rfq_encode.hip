@@ -198,7 +198,13 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     ctx->timer.end(S);
 
     ctx->timer.begin("chunk_flags+overlap", S);
-    hipLaunchKernelGGL(k_chunk_flags, dim3(n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, is_pe ? 1 : 0);
+    {   // per-chunk AND / MIN accumulators start at all-ones
+        uint32_t* cbits = B[B_SCAP].as<uint32_t>(); uint32_t* cfail = cbits + nc;      // borrowed: B_SCAP is written later by k_stream_plan
+        HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
+        const uint32_t fbx = std::max(1u, std::min<uint32_t>((max_reads + 255) / 256, std::max(1u, 4096u / n_chunks)));
+        hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, is_pe ? 1 : 0, cbits, cfail);
+        hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail);
+    }
     if (is_pe) { const uint32_t np = reads_used / 2; hipLaunchKernelGGL(k_overlap, dim3(std::min<uint32_t>((np + 3) / 4, 65535u * 4u)), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np); }
     hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, B[B_PVIN].as<U4>(), n_reads);
     scan_exclusive<U4>(S, B[B_PVIN].as<U4>(), R.pv, n_reads, B[B_SCANTMP].as<U4>(), 1);

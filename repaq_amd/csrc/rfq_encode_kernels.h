@@ -139,6 +139,25 @@ __device__ __forceinline__ Meta dev_parse_name(const uint8_t* str, uint32_t len)
 // (lane i takes byte i of read j's name) and every lane then parses its own row from LDS (row stride 132 B = 33 banks).
 #define NAME_CAP 128
 #define NAME_STRIDE 132
+// Stage the names of a wave's 64 reads into LDS rows: lane i copies byte i of read j's name.  Eight rows' loads are issued
+// before the first LDS write (an in-order wave otherwise pays one full memory latency per row).  nb / nl / s: per-lane name
+// start, name length and stream of the lane's own read.
+__device__ __forceinline__ void stage_name_rows(const Text& T, uint8_t* rows, uint32_t nb, uint32_t nl, int s, int l) {
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+        uint32_t take[8]; const uint8_t* src[8]; uint8_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t jb = __shfl(nb, j0 + u), jl = __shfl(nl, j0 + u); const int js = __shfl(s, j0 + u);
+            take[u] = jl < NAME_CAP ? jl : NAME_CAP; src[u] = T.fq[js] + jb;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (uint32_t)l < take[u] ? src[u][l] : (uint8_t)0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if ((uint32_t)l < take[u]) rows[(j0 + u) * NAME_STRIDE + l] = v[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) for (uint32_t i = 64u + (uint32_t)l; i < take[u]; i += 64) rows[(j0 + u) * NAME_STRIDE + i] = src[u][i];   // names > 64 bytes
+    }
+}
 __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, DevStatus* st) {
     __shared__ uint8_t s_names[4 * 64 * NAME_STRIDE];
     const int l = lane_id(), w = wave_id();
@@ -152,12 +171,7 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, DevStatus* st)
         nb = p0; nl = p1 - 1 - p0; sl = p2 - 1 - p1; tl = p3 - 1 - p2; ql = p4 - 1 - p3;
     }
     uint8_t* rows = s_names + (size_t)w * 64 * NAME_STRIDE;
-    for (int j = 0; j < 64; j++) {
-        const uint32_t jb = __shfl(nb, j), jl = __shfl(nl, j); const int js = __shfl(s, j);
-        const uint32_t take = jl < NAME_CAP ? jl : NAME_CAP;
-        const uint8_t* src = T.fq[js] + jb;
-        for (uint32_t i = (uint32_t)l; i < take; i += 64) rows[j * NAME_STRIDE + i] = src[i];
-    }
+    stage_name_rows(T, rows, nb, nl, s, l);
     __syncthreads();
     uint32_t err = 0;
     if (valid) {
@@ -420,49 +434,64 @@ struct Layout {                  // byte offsets of every section inside one chu
 };
 __device__ __forceinline__ uint32_t name2_len_of(const Text& T, const ReadTab& R, uint32_t g) { return line_len(T, g, 0) - R.name2_off[g]; }
 
-// one workgroup (256) per chunk
-__global__ void k_chunk_flags(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe) {
-    __shared__ uint32_t s_bits[4]; __shared__ uint32_t s_fail[4]; __shared__ uint32_t s_n2[4];
-    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1];
-    const int l = lane_id(), w = wave_id();
-    const uint32_t len0 = R.len[f], n1l0 = R.name1_len[f], n2l0 = name2_len_of(T, R, f), stl0 = line_len(T, f, 2);
-    const uint8_t* name0 = line_ptr(T, f, 0); const uint8_t* n20 = name0 + R.name2_off[f]; const uint8_t* st0 = line_ptr(T, f, 2);
-    const uint8_t lane0 = R.lane[f]; const uint16_t tile0 = R.tile[f];
-    const bool can0 = is_pe && D->support_interleaved;
-    const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
+// Pass A — grid (blocks, n_chunks): a wave takes 64 consecutive reads of the chunk, stages their names row by row in LDS with
+// coalesced loads (as k_read_table does), and every lane compares its read with the chunk's read 0 (row 64) and, for odd reads of a
+// PE chunk, with its mate (the previous row).  Results are AND / MIN-combined per chunk with one atomic per wave.
+__global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail) {
+    __shared__ uint8_t s_names[4 * 65 * NAME_STRIDE];
+    const uint32_t c = blockIdx.y, f = C.first[c], e = C.first[c + 1];
+    const int l = lane_id(), w = wave_id(); const uint32_t wpb = blockDim.x >> 6;
+    uint8_t* rows = s_names + (size_t)w * 65 * NAME_STRIDE;
+    const bool can0 = is_pe && D->support_interleaved; const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
+    // read 0 of the chunk: name row 64, scalars in registers
+    const uint32_t nl0 = line_len(T, f, 0); const uint8_t* nm0g = line_ptr(T, f, 0);
+    const uint32_t n1l0 = R.name1_len[f], n2o0 = R.name2_off[f], n2l0 = nl0 - n2o0, len0 = R.len[f], stl0 = line_len(T, f, 2);
+    const uint8_t* st0 = line_ptr(T, f, 2); const uint8_t lane0 = R.lane[f]; const uint16_t tile0 = R.tile[f];
+    { const uint32_t take = nl0 < NAME_CAP ? nl0 : NAME_CAP; for (uint32_t i = (uint32_t)l; i < take; i += 64) rows[64 * NAME_STRIDE + i] = nm0g[i]; }
+    const uint8_t* nm0 = nl0 <= NAME_CAP ? rows + 64 * NAME_STRIDE : nm0g;
     uint32_t bits = 0xFF, fail = 0xFFFFFFFFu;
-    for (uint32_t g = f + threadIdx.x; g < e; g += blockDim.x) {
-        const uint32_t nl = line_len(T, g, 0); const uint8_t* nm = line_ptr(T, g, 0);
-        const uint32_t n1l = R.name1_len[g], n2o = R.name2_off[g], n2l = nl - n2o, stl = line_len(T, g, 2);
-        uint32_t b = 0;
-        if (R.len[g] == len0) b |= 1u << 0;
-        if (n1l == n1l0) b |= 1u << 1;
-        if (n2l == n2l0) b |= 1u << 2;
-        if (stl == stl0) b |= 1u << 3;
-        if (bytes_eq(st0, stl0, line_ptr(T, g, 2), stl)) b |= 1u << 4;
-        if (R.lane[g] == lane0) b |= 1u << 5;
-        if (R.tile[g] == tile0) b |= 1u << 6;
-        if (bytes_eq(name0, n1l0, nm, n1l)) b |= 1u << 7;
-        bits &= b;
-        R.eq2[g] = bytes_eq(n20, n2l0, nm + n2o, n2l) ? 1 : 0;
-        const uint32_t rel = g - f;
-        if (can0 && (rel & 1u)) {
-            const uint32_t m = g - 1; const uint8_t* mn = line_ptr(T, m, 0) + R.name2_off[m]; const uint32_t ml = name2_len_of(T, R, m);
-            const bool fa = !name2_eq_replaced(mn, ml, nm + n2o, n2l, dpos, dch);
-            const bool fb = R.lane[m] != R.lane[g] || R.tile[m] != R.tile[g] || R.x[m] != R.x[g] || R.y[m] != R.y[g];
-            if (fa || fb) { const uint32_t key = (rel << 1) | (fa ? 0u : 1u); if (key < fail) fail = key; }
+    for (uint32_t gb = f + (blockIdx.x * wpb + (uint32_t)w) * 64u; gb < e; gb += gridDim.x * wpb * 64u) {      // wave-uniform
+        const uint32_t g = gb + (uint32_t)l; const bool v = g < e;
+        uint32_t nb = 0, nl = 0, stb = 0, stl = 0; int s = 0;
+        if (v) { uint32_t r; read_loc(T, g, s, r); const uint32_t* p = T.lo[s] + 4 * (size_t)r; nb = p[0]; nl = p[1] - 1 - nb; stb = p[2]; stl = p[3] - 1 - stb; }
+        wave_lds_sync();                                                     // rows are private to the wave: previous group's rows are no longer read
+        stage_name_rows(T, rows, nb, nl, s, l);
+        wave_lds_sync();
+        if (v) {
+            const uint8_t* nm = nl <= NAME_CAP ? rows + l * NAME_STRIDE : T.fq[s] + nb;
+            const uint32_t n1l = R.name1_len[g], n2o = R.name2_off[g], n2l = nl - n2o;
+            uint32_t b = 0;
+            if (R.len[g] == len0) b |= 1u << 0;
+            if (n1l == n1l0) b |= 1u << 1;
+            if (n2l == n2l0) b |= 1u << 2;
+            if (stl == stl0) b |= 1u << 3;
+            if (bytes_eq(st0, stl0, T.fq[s] + stb, stl)) b |= 1u << 4;
+            if (R.lane[g] == lane0) b |= 1u << 5;
+            if (R.tile[g] == tile0) b |= 1u << 6;
+            if (bytes_eq(nm0, n1l0, nm, n1l)) b |= 1u << 7;
+            bits &= b;
+            R.eq2[g] = bytes_eq(nm0 + n2o0, n2l0, nm + n2o, n2l) ? 1 : 0;
+            const uint32_t rel = g - f;
+            if (can0 && (rel & 1u)) {                                        // mate = previous row (groups start at even reads)
+                const uint32_t m = g - 1; const uint32_t mnl = line_len(T, m, 0), mo = R.name2_off[m];
+                const uint8_t* mn = (mnl <= NAME_CAP ? rows + (l - 1) * NAME_STRIDE : line_ptr(T, m, 0)) + mo;
+                const bool fa = !name2_eq_replaced(mn, mnl - mo, nm + n2o, n2l, dpos, dch);
+                const bool fb = R.lane[m] != R.lane[g] || R.tile[m] != R.tile[g] || R.x[m] != R.x[g] || R.y[m] != R.y[g];
+                if (fa || fb) { const uint32_t key = (rel << 1) | (fa ? 0u : 1u); if (key < fail) fail = key; }
+            }
         }
     }
     bits = wave_and(bits); fail = wave_min(fail);
-    if (l == 0) { s_bits[w] = bits; s_fail[w] = fail; }
-    __syncthreads();
-    const uint32_t nw = blockDim.x >> 6;
-    bits = 0xFF; fail = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < nw; i++) { bits &= s_bits[i]; if (s_fail[i] < fail) fail = s_fail[i]; }
-    // name2Same with the order-dependent rule of src/rfqcodec.cpp:233-250 (Q12)
+    if (l == 0) { if (bits != 0xFF) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
+}
+// Pass B — one wave per chunk: name2Same with the order-dependent rule of src/rfqcodec.cpp:233-250 (Q12), then the flag word
+__global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, const uint32_t* __restrict__ cbits, const uint32_t* __restrict__ cfail) {
+    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
+    const bool can0 = is_pe && D->support_interleaved;
+    const uint32_t bits = cbits[c] & 0xFFu, fail = cfail[c];
     const bool failed = can0 && fail != 0xFFFFFFFFu; const uint32_t frel = fail >> 1; const bool kind_a = !(fail & 1u);
     uint32_t n2same = 1;
-    for (uint32_t g = f + threadIdx.x; g < e; g += blockDim.x) {
+    for (uint32_t g = f + (uint32_t)l; g < e; g += 64) {
         const uint32_t rel = g - f; bool counts;
         if (!can0) counts = true;
         else if (!failed) counts = !(rel & 1u);
@@ -470,10 +499,7 @@ __global__ void k_chunk_flags(Text T, ReadTab R, ChunkTab C, const DevHeader* __
         if (counts && !R.eq2[g]) n2same = 0;
     }
     n2same = wave_and(n2same);
-    if (l == 0) s_n2[w] = n2same;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (uint32_t i = 0; i < nw; i++) n2same &= s_n2[i];
+    if (l == 0) {
         const bool il = can0 && !failed;
         uint32_t fl = 0;
         if (il) fl |= C_PE_INTERLEAVED;

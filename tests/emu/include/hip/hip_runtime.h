@@ -146,6 +146,9 @@ static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline long long clock64() { return 0; }
 static inline long long wall_clock64() { return 0; }
+// wave-level barrier / fence builtins: a rendezvous of the wave's lanes in the interpreter
+static inline void __builtin_amdgcn_wave_barrier() { (void)emu::collective(emu::OP_BALLOT, 0, 0, 0); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() {}
 
