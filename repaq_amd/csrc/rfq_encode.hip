@@ -11,7 +11,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_BITMAP0 = 0, B_BITMAP1, B_BLK0, B_BLK1, B_LO0, B_LO1, B_SCANTMP,
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
-    B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_ENC_END
+    B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC, B_ENC_END
 };
 
 static int fetch_bytes(rfq_ctx* ctx, const uint8_t* d, size_t n, std::string& out) {
@@ -256,8 +256,19 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
         HIPCHK(ctx, hipMemcpyAsync(img, HH.bytes, hdr_bytes, hipMemcpyHostToDevice, S));
     }
     ctx->timer.begin("pos_coder", S);
-    hipLaunchKernelGGL(k_pos_coder, dim3(MAX_STREAMS, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(),
-                       B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(), dst);
+    {
+        const uint32_t max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
+        const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
+        HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 8));
+#define RFQ_PC_ARGS R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), \
+                    (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, n_chunks, dst
+        const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * MAX_STREAMS * n_seg;
+        if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
+        hipLaunchKernelGGL((k_pos_coder<0>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);
+        hipLaunchKernelGGL((k_pos_coder<1>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);
+        hipLaunchKernelGGL((k_pos_coder<2>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);
+#undef RFQ_PC_ARGS
+    }
     KCHK(ctx, "k_pos_coder");
     ctx->timer.end(S);
     ctx->timer.begin("coords+layout", S);

@@ -865,21 +865,26 @@ template <class Sink> __device__ __forceinline__ void pc_gen_tokens(uint64_t m, 
         mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
     }
 }
-// B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Returns the stream size (wave-uniform).
-__device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ B, uint32_t len, int mode, uint32_t q, const DevHeader* __restrict__ D,
-                                                   uint8_t* __restrict__ out, uint32_t cap) {
+// A (chunk, stream) is cut into segments of PC_SEG_STEPS steps (131072 positions) coded by independent waves: with one wave per
+// stream the kernel's run time was that of its slowest wave (256 dependent steps).  A segment needs the state at its first
+// position — the last match and the last non-match before it — taken from a light summary pass over all segments, and its byte
+// offset inside the stream, which needs the byte counts of the earlier segments: summary, count, emit (three launches).
+#define PC_SEG_STEPS 32u
+// B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) with the given entry
+// state; returns the segment's byte count (wave-uniform).  EMIT writes the bytes at out[0..).
+template <bool EMIT> __device__ __forceinline__ uint32_t wave_pos_encode_seg(const uint8_t* __restrict__ B, uint32_t len, int mode, uint32_t q, const DevHeader* __restrict__ D,
+                                                   uint8_t* __restrict__ out, uint32_t room, uint32_t step0, uint32_t step1, int prev_carry, int zero_carry) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
-    uint32_t outpos = 0;
-    int prev_carry = -1, zero_carry = -1;                                   // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
-    const uint32_t nsteps = (len + 4095u) / 4096u;
+    uint32_t outpos = 0;                                                    // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
     // software pipeline, two steps deep: raw bytes of step+2 are in flight while step is coded; a step's raw bytes become a mask
     // only one step after they were requested, so the wave never waits on the load it has just issued
-    Raw64 raw_n = pc_load_raw(B, len, 4096u + 64u * (uint32_t)l);
-    uint64_t m_cur = nsteps ? pc_mask_of(pc_load_raw(B, len, 64u * (uint32_t)l), len, 64u * (uint32_t)l, mode, q, D) : 0ull;
-    uint64_t m_next = nsteps > 1 ? pc_mask_of(raw_n, len, 4096u + 64u * (uint32_t)l, mode, q, D) : 0ull;
-    raw_n = pc_load_raw(B, len, 8192u + 64u * (uint32_t)l);
-    for (uint32_t step = 0; step < nsteps; step++) {
+    const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;
+    Raw64 raw_n = pc_load_raw(B, len, q0 + 4096u);
+    uint64_t m_cur = pc_mask_of(pc_load_raw(B, len, q0), len, q0, mode, q, D);
+    uint64_t m_next = pc_mask_of(raw_n, len, q0 + 4096u, mode, q, D);
+    raw_n = pc_load_raw(B, len, q0 + 8192u);
+    for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
         const uint64_t m = m_cur;
         const unsigned long long has1 = __ballot(m != 0);
@@ -896,7 +901,8 @@ __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ 
         const int src1 = b1 ? 63 - __clzll((long long)b1) : 0, src0 = b0m ? 63 - __clzll((long long)b0m) : 0;
         const int got1 = __shfl(mylast, src1), got0 = __shfl(myzero, src0);
         const int prev_in = b1 ? got1 : prev_carry, zero_in = b0m ? got0 : zero_carry;
-        // matches continuing right after my word (for run lengths): leading ones of the next lane's word
+        // matches continuing right after my word (for run lengths): leading ones of the next lane's word (the next step's first word
+        // for lane 63 — also when that step belongs to the next segment)
         const uint32_t lead = (m == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);
         const uint32_t lead_n = (m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m_next) - 1);
         uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
@@ -907,7 +913,7 @@ __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ 
         const uint32_t incl = wave_incl_sum(bytes);
         uint32_t o = outpos + incl - bytes;
         const uint32_t tot = __shfl(incl, 63);
-        if (outpos + tot <= cap) {
+        if (EMIT && outpos + tot <= room) {
             if (mode == PC_EXCEPT) {
                 uint64_t mm = m;
                 while (mm) { const int s = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)s]; st_u32(out + o + 1, p0 + (uint32_t)s); o += 5; }
@@ -924,20 +930,68 @@ __device__ __forceinline__ uint32_t wave_pos_encode(const uint8_t* __restrict__ 
     }
     return outpos;
 }
-// grid (MAX_STREAMS, n_chunks), one wave per block
-__global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
-                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, DevStatus* st) {
-    const uint32_t j = blockIdx.x, c = blockIdx.y;
+// last match / last non-match inside steps [step0, step1) (or -1): the summary pass, loads pipelined like the coder's
+__device__ __forceinline__ void wave_pos_summary(const uint8_t* __restrict__ B, uint32_t len, int mode, uint32_t q, const DevHeader* __restrict__ D,
+                                                 uint32_t step0, uint32_t step1, int& last1, int& last0) {
+    const int l = lane_id(); last1 = -1; last0 = -1;
+    const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;
+    Raw64 raw_n = pc_load_raw(B, len, q0 + 4096u);
+    uint64_t m_cur = pc_mask_of(pc_load_raw(B, len, q0), len, q0, mode, q, D);
+    for (uint32_t step = step0; step < step1; step++) {
+        const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
+        const Raw64 raw_c = raw_n; raw_n = pc_load_raw(B, len, p0 + 8192u);
+        const uint64_t m = m_cur;
+        const unsigned long long h1 = __ballot(m != 0), h0 = __ballot(~m != 0);
+        if (h1) { const int v = m ? (int)p0 + 63 - __clzll((long long)m) : -1; last1 = __shfl(v, 63 - __clzll((long long)h1)); }
+        if (h0) { const int v = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1; last0 = __shfl(v, 63 - __clzll((long long)h0)); }
+        m_cur = pc_mask_of(raw_c, len, p0 + 4096u, mode, q, D);
+    }
+}
+// 1-D grid of ceil(n_chunks / 8) * 8 * MAX_STREAMS * n_seg workgroups, one wave each; three passes over the same grid:
+//   PASS 0  summary  segc[2*si+{0,1}] = last match / last non-match of the segment
+//   PASS 1  count    entry state = nearest earlier segment that has one; segb[si] = bytes of the segment
+//   PASS 2  emit     offset = sum of earlier segb; writes the bytes
+// si = (c * MAX_STREAMS + j) * n_seg + seg.  Streams whose value does not occur in the chunk (histogram) are skipped outright.
+template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg, uint32_t n_chunks, DevStatus* st) {
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
+    // (stream, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's megabyte of qualities is pulled into
+    // ONE private L2 and re-read there by its other streams instead of being fetched from HBM by up to eight L2s.
+    const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = MAX_STREAMS * n_seg;
+    const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, j = rest % MAX_STREAMS, seg = rest / MAX_STREAMS;
+    if (c >= n_chunks) return;
     const size_t k = (size_t)c * MAX_STREAMS + j;
     const uint32_t cap = C.scap[k];
     if (cap == 0) return;                                                  // stream not present (uniform: one wave per block)
+    const uint32_t occurrences = j < NPOS_SLOT ? C.hist[(size_t)c * 256 + D->normal[j]] : (j == NPOS_SLOT ? C.ncount[c] : (cap - 16u) / 5u);
+    if (occurrences == 0) return;                                          // nothing to code: ssize stays 0 (k_stream_plan)
     const uint32_t f = C.first[c], e = C.first[c + 1];
-    uint8_t* out = scratch + cbase[c] + C.soff[k];
-    uint32_t sz;
-    if (j < NPOS_SLOT) sz = wave_pos_encode(qcat + C.qbase[c], R.pq[e] - R.pq[f], PC_MATCH, D->normal[j], D, out, cap);
-    else if (j == NPOS_SLOT) sz = wave_pos_encode(scat + C.sbase[c], R.pv[e].d - R.pv[f].d, PC_MATCH, (uint32_t)'N', D, out, cap);
-    else sz = wave_pos_encode(qcat + C.qbase[c], R.pq[e] - R.pq[f], PC_EXCEPT, 0, D, out, cap);
-    if (lane_id() == 0) { C.ssize[k] = sz; if (sz > cap) atomicOr(&st->err, (uint32_t)DE_CORRUPT); }
+    const bool useq = j == NPOS_SLOT;
+    const uint8_t* B = useq ? scat + C.sbase[c] : qcat + C.qbase[c];
+    const uint32_t len = useq ? R.pv[e].d - R.pv[f].d : R.pq[e] - R.pq[f];
+    const int mode = j == EXC_SLOT ? PC_EXCEPT : PC_MATCH; const uint32_t q = j < NPOS_SLOT ? D->normal[j] : (uint32_t)'N';
+    const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
+    const size_t s0i = k * n_seg, si = s0i + seg;
+    if (step0 >= nsteps) { if (PASS == 0 && lane_id() == 0) { segb[si] = 0; segc[2 * si] = -1; segc[2 * si + 1] = -1; } return; }
+    const uint32_t step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
+    if (PASS == 0) {
+        int l1, l0; wave_pos_summary(B, len, mode, q, D, step0, step1, l1, l0);
+        if (lane_id() == 0) { segc[2 * si] = l1; segc[2 * si + 1] = l0; segb[si] = 0; }
+        return;
+    }
+    int prev = -1, zero = -1;                                               // entry state: nearest earlier segment that saw a match / a non-match
+    for (int s = (int)seg - 1; s >= 0 && prev < 0; s--) prev = segc[2 * (s0i + (uint32_t)s)];
+    for (int s = (int)seg - 1; s >= 0 && zero < 0; s--) zero = segc[2 * (s0i + (uint32_t)s) + 1];
+    if (PASS == 1) {
+        const uint32_t sz = wave_pos_encode_seg<false>(B, len, mode, q, D, nullptr, 0u, step0, step1, prev, zero);
+        if (lane_id() == 0) segb[si] = sz;
+    } else {
+        uint32_t off = 0; for (uint32_t s = 0; s < seg; s++) off += segb[s0i + s];
+        const uint32_t own = segb[si];
+        uint8_t* out = scratch + cbase[c] + C.soff[k];
+        if (off + own <= cap) (void)wave_pos_encode_seg<true>(B, len, mode, q, D, out + off, own, step0, step1, prev, zero);
+        if (step1 == nsteps && lane_id() == 0) { C.ssize[k] = off + own; if (off + own > cap) atomicOr(&st->err, (uint32_t)DE_CORRUPT); }
+    }
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)

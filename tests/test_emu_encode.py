@@ -71,3 +71,35 @@ def test_batched_encode_with_carry_over_equals_one_shot(codec):
         pos += r.consumed1 if not final else len(buf)
         first = False
     assert out == want
+
+
+def _segment_boundary_fastq(n_reads=1800, rl=150):
+    """One ~270 kbase chunk (3 position-coder segments of 131072): streaks of a normal quality value that straddle the segment
+    boundaries, a value that only occurs far before a boundary (long backward carry scan) and one that never occurs after read 3."""
+    import random
+    rng = random.Random(4242)
+    recs = []
+    for i in range(n_reads):
+        q = ["F"] * rl
+        pos0 = i * rl
+        for k in range(rl):
+            p = pos0 + k
+            if 131072 - 200 <= p < 131072 + 300 or 262144 - 40 <= p < 262144 + 33:
+                q[k] = ","                      # streaks across both segment boundaries
+            elif rng.random() < 0.03:
+                q[k] = ":"
+        if i == 2:
+            q[5] = "#"                          # '#' exists only here: every later segment scans back to the chunk start
+        if i in (700, 701):
+            q[10] = "5"
+        seq = [rng.choice("ACGT") for _ in range(rl)]
+        if i == 2:
+            seq[5] = "N"
+        recs.append("@A00250:26:H3YTWDSXX:1:1101:%d:%d 1:N:0:ACGT\n%s\n+\n%s\n" % (1000 + i, 2000 + i // 7, "".join(seq), "".join(q)))
+    return "".join(recs).encode()
+
+
+def test_position_coder_segments(codec):
+    fq = _segment_boundary_fastq()
+    assert E.encode(codec, fq, b"", O.SE, 1_000_000) == O.encode_file(fq, b"", O.SE, 1_000_000)
+    assert E.encode(codec, fq, b"", O.SE, 140_000) == O.encode_file(fq, b"", O.SE, 140_000)
