@@ -152,9 +152,20 @@ def main():
         alg = float(n + state["rfq_len"])                    # B_fastq + B_rfq per batch
         roof = None
         if dom:
+            # HBM bytes of the dominant stage from the committed PMC passes (tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE collected in
+            # separate rocprofv3 --pmc runs of this same command, KB units, FETCH_SIZE x2 on gfx950) — only valid for the default workload
+            traffic = None
+            STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
+                             "chunk_flags+overlap": ["k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
+                             "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder<0>", "k_pos_coder<1>", "k_pos_coder<2>"],
+                             "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"]}
+            pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if args.reads == 2_800_000 and args.chunk_kb == 1000 and os.path.exists(pj):
+                pmc = json.load(open(pj))
+                traffic = int(sum(pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in STAGE_KERNELS.get(dom, []) if k in pmc))
             ach = alg / (enc_stage[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(enc_stage[dom], 4),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(enc_stage[dom], 4),
                     "whole_encode_frac": round(alg / (sum(enc_stage.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out = {
             "metric": "raw FASTQ MB/s encode+decode" if state.get("decode_ok") else "raw FASTQ MB/s encode (decode pending)",

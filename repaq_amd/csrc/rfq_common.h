@@ -198,3 +198,32 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// index of the tile entry that contains position p: dst[0..cnt] are ascending starts (dst[cnt] = end)
+__device__ __forceinline__ uint32_t tile_find(const uint32_t* dst, uint32_t cnt, uint32_t p) {   // last r with dst[r] <= p
+    // equal-length reads (the usual case): one division finds the read; verify with two LDS reads, else binary search
+    const uint32_t d0 = dst[0], step = dst[1] - d0;
+    if (step) { const uint32_t g = (p - d0) / step; if (g < cnt && dst[g] <= p && p < dst[g + 1]) return g; }
+    uint32_t lo = 0, hi = cnt;                                  // invariant: dst[lo] <= p < dst[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dst[mid] <= p) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// 128-bit splice helpers for "16 output bytes from several source pieces": keep the first `take` bytes of (lo, hi), shift left
+// by `filled` bytes, OR into the accumulator
+__device__ __forceinline__ void splice16(unsigned long long& alo, unsigned long long& ahi, unsigned long long plo, unsigned long long phi, uint32_t take, uint32_t filled) {
+    if (take < 16) {
+        if (take >= 8) phi = take == 8 ? 0ull : (phi & ((1ull << (8 * (take - 8))) - 1ull));
+        else { phi = 0ull; plo = take ? (plo & ((1ull << (8 * take)) - 1ull)) : 0ull; }
+    }
+    if (filled) {
+        if (filled < 8) { phi = (phi << (8 * filled)) | (plo >> (64 - 8 * filled)); plo <<= 8 * filled; }
+        else { phi = filled == 8 ? plo : (plo << (8 * (filled - 8))); plo = 0ull; }
+    }
+    alo |= plo; ahi |= phi;
+}
+// 16 bytes ending at LDS address a (inclusive), reversed: out byte k = base[a - k]
+__device__ __forceinline__ void lds_get16_rev(const uint8_t* base, uint32_t a, uint32_t (&w)[4]) {
+    uint32_t f[4]; lds_get16(base, a - 15u, f);
+    w[0] = bswap32(f[3]); w[1] = bswap32(f[2]); w[2] = bswap32(f[1]); w[3] = bswap32(f[0]);
+}

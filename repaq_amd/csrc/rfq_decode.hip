@@ -126,6 +126,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
     // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
     uint8_t *o1, *o2; uint64_t cap1, cap2;
+    if ((a->d_out1 && ((uintptr_t)a->d_out1 & 15u)) || (a->d_out2 && ((uintptr_t)a->d_out2 & 15u))) return rfq_fail(ctx, RFQ_E_ARG, "output device pointers must be 16-byte aligned");
     if (a->d_out1) { o1 = a->d_out1; cap1 = a->cap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
     if (a->d_out2) { o2 = a->d_out2; cap2 = a->cap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
     {

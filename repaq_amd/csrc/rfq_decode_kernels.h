@@ -155,18 +155,25 @@ __global__ void k_dec_bases(const DChunk* __restrict__ CH, DReadTab R, uint64_t*
     if (c < n_chunks) { const uint32_t f = CH[c].rbase; qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c; sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
 }
 
-// 2-bit unpack (src/rfqcodec.cpp:833-853): grid (blocks, n_chunks)
+// 2-bit unpack (src/rfqcodec.cpp:833-853): grid (blocks, n_chunks).  One thread turns 4 packed bytes into 16 bases and stores them
+// as one aligned uint4 (the chunk's base in sdec is 64-byte aligned); byte stores cost ~30 cycles per wave instruction.
+__device__ __forceinline__ uint32_t unpack4(uint32_t byte) {              // 4 bases of one packed byte -> 4 ASCII bytes (G A T C = 0 1 2 3)
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) { const uint32_t code = (byte >> (2 * b)) & 3u; w |= (code == 0 ? (uint32_t)'G' : (code == 1 ? (uint32_t)'A' : (code == 2 ? (uint32_t)'T' : (uint32_t)'C'))) << (8 * b); }
+    return w;
+}
 __global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec) {
     const DChunk d = CH[blockIdx.y]; const uint32_t f = d.rbase;
     const uint32_t n = R.pv[f + d.reads].d - R.pv[f].d;          // stored bases of the chunk
     const uint8_t* src = img + d.off + d.o_seq; uint8_t* dst = sdec + sbase[blockIdx.y];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (n + 3) / 4; i += gridDim.x * blockDim.x) {
-        const bool have = i < d.seq_size; const uint32_t v = have ? src[i] : 0u;     // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
-        for (uint32_t b = 0; b < 4; b++) {
-            const uint32_t p = 4 * i + b; if (p >= n) break;
-            const uint32_t code = (v >> (2 * b)) & 3u;
-            dst[p] = have ? (code == 0 ? 'G' : (code == 1 ? 'A' : (code == 2 ? 'T' : 'C'))) : 'N';
-        }
+    const uint32_t ngroups = (n + 15) / 16;
+    for (uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += gridDim.x * blockDim.x) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t i = 4 * gi + (uint32_t)k; w[k] = i < d.seq_size ? unpack4(src[i]) : 0x4E4E4E4Eu; }   // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
+        if (16 * gi + 16 <= n) *(uint4*)(dst + 16 * (size_t)gi) = make_uint4(w[0], w[1], w[2], w[3]);
+        else for (uint32_t p = 16 * gi; p < n; p++) dst[p] = (uint8_t)(w[(p >> 2) & 3u] >> (8 * (p & 3u)));
     }
 }
 

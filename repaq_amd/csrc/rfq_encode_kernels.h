@@ -573,14 +573,6 @@ struct GatherTile {
     const uint32_t* len; const uint32_t* skip; const uint32_t* keep; const uint8_t* rc;
     uint32_t cnt;
 };
-__device__ __forceinline__ uint32_t tile_find(const uint32_t* dst, uint32_t cnt, uint32_t p) {   // last r with dst[r] <= p
-    // equal-length reads (the usual case): one division finds the read; verify with two LDS reads, else binary search
-    const uint32_t d0 = dst[0], step = dst[1] - d0;
-    if (step) { const uint32_t g = (p - d0) / step; if (g < cnt && dst[g] <= p && p < dst[g + 1]) return g; }
-    uint32_t lo = 0, hi = cnt;                                  // invariant: dst[lo] <= p < dst[hi]
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dst[mid] <= p) lo = mid; else hi = mid; }
-    return lo;
-}
 // one output byte at a time, walking the read table: r / off are carried by the caller
 template <bool SEQ> __device__ __forceinline__ uint8_t tile_next(const GatherTile& t, uint32_t& r, uint32_t& off) {
     while (off >= (SEQ ? t.keep[r] : t.len[r])) { off -= (SEQ ? t.keep[r] : t.len[r]); r++; }
