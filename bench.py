@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--chunk-kb", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encode-only", action="store_true")
+    ap.add_argument("--pe", action="store_true", help="profiling aid: PE150 two-file workload (configs[2] shape, reads/2 pairs) instead of the SE150 headline workload")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (kernel ablation runs with RFQ_TUNE set)")
     args = ap.parse_args()
 
@@ -76,9 +77,15 @@ def main():
     codec = RfqCodec(device=local)     # raises loudly without the HIP library / a GPU: there is no fallback
 
     seed = 2 + rank
-    fq1, _ = O.gen(O.NOVA_SE150, args.reads, seed=seed, nppm=20)
-    n = len(fq1)
+    from repaq_amd import PE_TWO_FILES
+    if args.pe:
+        fq1, fq2 = O.gen(O.NOVA_PE150, args.reads // 2, seed=seed + 1, nppm=20)
+    else:
+        fq1, fq2 = O.gen(O.NOVA_SE150, args.reads, seed=seed, nppm=20)
+    n = len(fq1) + len(fq2)
     d_fq = torch.frombuffer(bytearray(fq1), dtype=torch.uint8).to(dev)
+    d_fq2 = torch.frombuffer(bytearray(fq2), dtype=torch.uint8).to(dev) if fq2 else None
+    paired = PE_TWO_FILES if args.pe else SE
     chunk_bases = max(100, args.chunk_kb) * 1000
 
     have_decode = not args.encode_only
@@ -87,7 +94,7 @@ def main():
     def step(collect):
         codec.clearHeader()
         t0 = time.perf_counter()
-        r = codec.encode(d_fq.data_ptr(), n, None, 0, SE, chunk_bases)
+        r = codec.encode(d_fq.data_ptr(), len(fq1), d_fq2.data_ptr() if d_fq2 is not None else None, len(fq2), paired, chunk_bases)
         t1 = time.perf_counter()
         if collect:
             for name, ms in codec.timings():
@@ -96,7 +103,7 @@ def main():
         t2 = t1
         if state.get("decode_ok", True) and have_decode:
             try:
-                d = codec.decode(r.d_rfq, r.rfq_len, split_pe=False)
+                d = codec.decode(r.d_rfq, r.rfq_len, split_pe=bool(args.pe))
                 t2 = time.perf_counter()
                 state["decode_ok"] = True; state["dec_n"] = d.n1; state["d_fq"] = d.d_fq1
                 if collect:
@@ -117,12 +124,12 @@ def main():
         got = codec.dev_get(r.d_rfq, r.rfq_len)
         md5 = hashlib.md5(got).hexdigest()
         gold = [g for g in json.load(open(os.path.join(ROOT, "tests", "golden", "generated.json")))
-                if g["profile"] == O.NOVA_SE150 and g["reads"] == args.reads and g["seed"] == seed and g["nppm"] == 20 and g["k"] == args.chunk_kb and not g["nonl"]]
+                if not args.pe and g["profile"] == O.NOVA_SE150 and g["reads"] == args.reads and g["seed"] == seed and g["nppm"] == 20 and g["k"] == args.chunk_kb and not g["nonl"]]
         if gold:
             assert md5 == gold[0]["rfq_md5"], "GPU .rfq md5 %s != reference golden %s" % (md5, gold[0]["rfq_md5"])
             parity = "rfq md5 == reference golden (%s)" % md5
         else:
-            want = O.encode_file(fq1, b"", O.SE, chunk_bases)
+            want = O.encode_file(fq1, fq2, paired, chunk_bases)
             assert got == want, "GPU .rfq differs from the oracle"
             parity = "rfq bytes == oracle (%s)" % md5
         if state.get("decode_ok"):
@@ -179,7 +186,7 @@ def main():
                        "parity": parity, "stage_ms": {k: round(v, 3) for k, v in stage.items()}},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.pe:
             out["cpu_baseline"] = cpu_baseline(fq1, args.reads)
         print(json.dumps(out))
     codec.close()

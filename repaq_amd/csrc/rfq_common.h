@@ -184,11 +184,10 @@ __device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {
 }
 // complement of four packed bases, comp_base() semantics (either case -> upper-case complement, anything else -> 'N')
 __device__ __forceinline__ uint32_t comp4(uint32_t w) {
-    const uint32_t u = w & 0xDFDFDFDFu;                                   // fold case; non-letters that alias are filtered below
-    const uint32_t letter = eq_bytes_full((w | 0x20202020u) & 0xE0E0E0E0u, 0x60606060u);   // 0x60..0x7F after |0x20: candidates
+    const uint32_t u = w & 0xDFDFDFDFu;                                   // fold case: u == 'A' exactly for 'A' and 'a' (bit 5 is the only one dropped)
     const uint32_t mA = eq_bytes_full(u, 0x41414141u), mT = eq_bytes_full(u, 0x54545454u), mC = eq_bytes_full(u, 0x43434343u), mG = eq_bytes_full(u, 0x47474747u);
-    const uint32_t any = (mA | mT | mC | mG) & letter;
-    return ((mA & 0x54545454u) | (mT & 0x41414141u) | (mC & 0x47474747u) | (mG & 0x43434343u)) & any | (~any & 0x4E4E4E4Eu);
+    const uint32_t any = mA | mT | mC | mG;
+    return (mA & 0x54545454u) | (mT & 0x41414141u) | (mC & 0x47474747u) | (mG & 0x43434343u) | (~any & 0x4E4E4E4Eu);
 }
 
 // LDS hand-off between lanes of ONE wave (rows private to the wave): order the wave's LDS writes before its later LDS reads.

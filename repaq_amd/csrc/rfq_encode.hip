@@ -205,7 +205,7 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
         hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, is_pe ? 1 : 0, cbits, cfail);
         hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail);
     }
-    if (is_pe) { const uint32_t np = reads_used / 2; hipLaunchKernelGGL(k_overlap, dim3(std::min<uint32_t>((np + 3) / 4, 65535u * 4u)), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np); }
+    if (is_pe) { const uint32_t np = reads_used / 2; hipLaunchKernelGGL(k_overlap, dim3(std::min<uint32_t>((np + 63) / 64, 65535u * 4u)), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np); }
     hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, B[B_PVIN].as<U4>(), n_reads);
     scan_exclusive<U4>(S, B[B_PVIN].as<U4>(), R.pv, n_reads, B[B_SCANTMP].as<U4>(), 1);
     hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks);

@@ -534,17 +534,107 @@ __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int 
     }
     return 0;
 }
-// one wave per pair (grid-stride); only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
+// Same search with both reads staged word-wise in LDS (rows private to a wave): R1 as is, R2 complemented but NOT reversed
+// (c2); RC(R2)[i..i+4) is bswap32 of c2[len2-4-i .. len2-i).  A row keeps its global pointer's misalignment, so staging is
+// aligned word loads -> aligned word stores.  Candidates are filtered on their first four bytes, survivors are verified by
+// the whole wave, four bytes per lane.
+#define OV_CAP 320u                      // bases per read staged in LDS (longer reads take the global-memory path)
+#define OV_ROW (OV_CAP + 16u)            // 8 bytes of slack before the data (reads below the row are masked out), 4+ after
+__device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) {
+    const uint32_t* p = (const uint32_t*)(base + (a & ~3u)); const uint32_t sh = (a & 3u) * 8u;
+    return (uint32_t)((((uint64_t)p[1] << 32) | p[0]) >> sh);
+}
+struct OvPair { uint32_t r1, c2; int len1, len2; };           // LDS offsets of R1[0] and c2[0]
+__device__ __forceinline__ uint32_t ov_r1(const uint8_t* rows, const OvPair& P, uint32_t i) { return lds_get4(rows, P.r1 + i); }
+__device__ __forceinline__ uint32_t ov_rc(const uint8_t* rows, const OvPair& P, uint32_t i) { return bswap32(lds_get4(rows, P.c2 + (uint32_t)P.len2 - 4u - i)); }
+// R1[a..a+n) == RC(R2)[b..b+n): the whole wave compares, 4 bytes per lane per step
+__device__ __forceinline__ bool ov_equal(const uint8_t* rows, const OvPair& P, uint32_t a, uint32_t b, uint32_t n) {
+    const uint32_t l = (uint32_t)lane_id();
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + 4 * l; uint32_t x = 0;
+        if (i < n) { x = ov_r1(rows, P, a + i) ^ ov_rc(rows, P, b + i); if (n - i < 4) x &= (1u << (8 * (n - i))) - 1u; }
+        if (__ballot(x != 0)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ int wave_overlap_lds(const uint8_t* rows, const OvPair& P) {
+    const int l = lane_id(); const int minlen = P.len1 < P.len2 ? P.len1 : P.len2;
+    if (minlen < 12) return 0;
+    const uint32_t rc_head = ov_rc(rows, P, 0), r1_head = ov_r1(rows, P, 0);     // every candidate has o >= 12 > 4 bytes
+    for (int base = 12; base <= minlen; base += 64) {          // forward: R1 tail == RC(R2) head
+        const int o = base + l;
+        unsigned long long cand = __ballot(o <= minlen && ov_r1(rows, P, (uint32_t)(P.len1 - o)) == rc_head);
+        while (cand) {                                           // ascending o; wave-uniform
+            const int j = __ffsll((long long)cand) - 1; cand &= cand - 1; const uint32_t oo = (uint32_t)(base + j);
+            if (ov_equal(rows, P, (uint32_t)P.len1 - oo, 0u, oo)) return (int)oo;
+        }
+    }
+    for (int base = 12; base <= minlen; base += 64) {          // backward: RC(R2) tail == R1 head
+        const int o = base + l;
+        unsigned long long cand = __ballot(o <= minlen && ov_rc(rows, P, (uint32_t)(P.len2 - o)) == r1_head);
+        while (cand) {
+            const int j = __ffsll((long long)cand) - 1; cand &= cand - 1; const uint32_t oo = (uint32_t)(base + j);
+            if (ov_equal(rows, P, 0u, (uint32_t)P.len2 - oo, oo)) return -(int)oo;
+        }
+    }
+    return 0;
+}
+// 64 pairs per block: 64 threads fetch the pairs' metadata in one go, then each wave walks its 16 pairs with the next pair's
+// bases already in flight while the current one is searched.  Only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
+#define OV_PAIRS 64u
+struct OvRegs { uint32_t a[2], b[2]; };                        // aligned words l and l+64 of each read
+__device__ __forceinline__ void ov_fetch(OvRegs& r, const uint8_t* r1, int len1, const uint8_t* r2, int len2, int l) {
+    const uint32_t m1 = (uint32_t)((uintptr_t)r1 & 3u), m2 = (uint32_t)((uintptr_t)r2 & 3u);
+    const uint32_t* w1 = (const uint32_t*)(r1 - m1); const uint32_t* w2 = (const uint32_t*)(r2 - m2);
+    const uint32_t n1 = len1 > 0 ? (m1 + (uint32_t)len1 + 3u) >> 2 : 0u, n2 = len2 > 0 ? (m2 + (uint32_t)len2 + 3u) >> 2 : 0u;
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const uint32_t i = (uint32_t)l + 64u * k; r.a[k] = i < n1 ? w1[i] : 0u; r.b[k] = i < n2 ? w2[i] : 0u; }
+}
 __global__ void k_overlap(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int8_t* __restrict__ ovb, uint32_t n_pairs) {
-    const uint32_t wpb = blockDim.x >> 6; const int shift = D->overlap_shift; const bool enc = (D->flags & H_PE_OVERLAP) != 0;
-    for (uint32_t p = blockIdx.x * wpb + (uint32_t)wave_id(); p < n_pairs; p += gridDim.x * wpb) {
-        const uint32_t g = 2 * p; const uint32_t c = R.chunk[g];
-        if (!C.il[c] || !enc) continue;                          // wave-uniform
-        const int len1 = (int)R.len[g], len2 = (int)R.len[g + 1];
-        int ov = wave_overlap(line_ptr(T, g, 1), len1, line_ptr(T, g + 1, 1), len2);
-        if (ov + shift > 127) ov = 0;
-        if (ov + shift < -127) ov = 0;
-        if (lane_id() == 0) { ovb[p] = (int8_t)(ov + shift); R.stored[g + 1] = (uint32_t)(len2 - (ov < 0 ? -ov : ov)); }
+    __shared__ uint32_t s_rows4[4 * (2 * OV_ROW / 4)];
+    __shared__ const uint8_t* s_p1[OV_PAIRS]; __shared__ const uint8_t* s_p2[OV_PAIRS];
+    __shared__ int s_l1[OV_PAIRS], s_l2[OV_PAIRS];             // s_l1 < 0: pair not examined
+    const int shift = D->overlap_shift; const bool enc = (D->flags & H_PE_OVERLAP) != 0;
+    if (!enc) return;                                           // uniform
+    const int l = lane_id(); const int w = wave_id();
+    uint32_t* rows4 = s_rows4 + (size_t)w * (2 * OV_ROW / 4); const uint8_t* rows = (const uint8_t*)rows4;
+    for (uint32_t p0 = blockIdx.x * OV_PAIRS; p0 < n_pairs; p0 += gridDim.x * OV_PAIRS) {
+        __syncthreads();
+        if (threadIdx.x < OV_PAIRS) {
+            const uint32_t p = p0 + threadIdx.x; int l1 = -1, l2 = 0; const uint8_t* q1 = nullptr; const uint8_t* q2 = nullptr;
+            if (p < n_pairs) {
+                const uint32_t g = 2 * p;
+                if (C.il[R.chunk[g]]) { l1 = (int)R.len[g]; l2 = (int)R.len[g + 1]; q1 = line_ptr(T, g, 1); q2 = line_ptr(T, g + 1, 1); }
+            }
+            s_l1[threadIdx.x] = l1; s_l2[threadIdx.x] = l2; s_p1[threadIdx.x] = q1; s_p2[threadIdx.x] = q2;
+        }
+        __syncthreads();
+        const uint32_t k0 = (uint32_t)w * (OV_PAIRS / 4), k1 = k0 + OV_PAIRS / 4;
+        OvRegs nxt;
+        { const int l1 = s_l1[k0], l2 = s_l2[k0]; const bool st = l1 >= 0 && (uint32_t)l1 <= OV_CAP && (uint32_t)l2 <= OV_CAP;
+          ov_fetch(nxt, s_p1[k0], st ? l1 : 0, s_p2[k0], st ? l2 : 0, l); }
+        for (uint32_t k = k0; k < k1; k++) {
+            const int len1 = s_l1[k], len2 = s_l2[k]; const OvRegs cur = nxt;
+            const uint8_t* q1 = s_p1[k]; const uint8_t* q2 = s_p2[k];
+            if (k + 1 < k1) { const int l1 = s_l1[k + 1], l2 = s_l2[k + 1]; const bool st = l1 >= 0 && (uint32_t)l1 <= OV_CAP && (uint32_t)l2 <= OV_CAP;
+                              ov_fetch(nxt, s_p1[k + 1], st ? l1 : 0, s_p2[k + 1], st ? l2 : 0, l); }
+            if (len1 < 0) continue;                              // wave-uniform
+            int ov;
+            if ((uint32_t)len1 <= OV_CAP && (uint32_t)len2 <= OV_CAP) {
+                OvPair P; P.len1 = len1; P.len2 = len2;
+                P.r1 = 8u + (uint32_t)((uintptr_t)q1 & 3u); P.c2 = OV_ROW + 8u + (uint32_t)((uintptr_t)q2 & 3u);
+                wave_lds_sync();                                 // the previous pair's rows are no longer read
+                rows4[2 + l] = cur.a[0]; rows4[OV_ROW / 4 + 2 + l] = comp4(cur.b[0]);
+                if ((len1 > len2 ? len1 : len2) > 252 && l < 18) {   // words 64..81 (wave-uniform test: 3 + 252 bytes fit 64 words)
+                    rows4[2 + 64 + l] = cur.a[1]; rows4[OV_ROW / 4 + 2 + 64 + l] = comp4(cur.b[1]);
+                }
+                wave_lds_sync();
+                ov = wave_overlap_lds(rows, P);
+            } else ov = wave_overlap(q1, len1, q2, len2);
+            if (ov + shift > 127) ov = 0;
+            if (ov + shift < -127) ov = 0;
+            if (l == 0) { const uint32_t p = p0 + k; ovb[p] = (int8_t)(ov + shift); R.stored[2 * p + 1] = (uint32_t)(len2 - (ov < 0 ? -ov : ov)); }
+        }
     }
 }
 __global__ void k_pv_in(Text T, ReadTab R, U4* __restrict__ v, uint32_t n_reads) {
