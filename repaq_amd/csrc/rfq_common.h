@@ -176,6 +176,11 @@ __device__ __forceinline__ void lds_get16(const uint8_t* base, uint32_t a, uint3
     w[0] = (uint32_t)((((uint64_t)x1 << 32) | x0) >> sh); w[1] = (uint32_t)((((uint64_t)x2 << 32) | x1) >> sh);
     w[2] = (uint32_t)((((uint64_t)x3 << 32) | x2) >> sh); w[3] = (uint32_t)((((uint64_t)x4 << 32) | x3) >> sh);
 }
+// 4 bytes at byte offset a of a 4-byte-aligned LDS array (two aligned word reads + funnel shift; base[a+4..a+7] must be readable)
+__device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) {
+    const uint32_t* p = (const uint32_t*)(base + (a & ~3u)); const uint32_t sh = (a & 3u) * 8u;
+    return (uint32_t)((((uint64_t)p[1] << 32) | p[0]) >> sh);
+}
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 // byte-wise full mask (0xFF per byte of w equal to the pattern byte)
 __device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {

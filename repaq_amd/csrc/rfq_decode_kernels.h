@@ -434,12 +434,33 @@ __device__ __forceinline__ void flush_span(const uint4* lds4, uint8_t* gbase, ui
     for (uint64_t x = gbeg + threadIdx.x; x < he; x += blockDim.x) gbase[x] = lds[x - a0];
     if (last_full >= first_full) for (uint64_t x = last_full + threadIdx.x; x < gend; x += blockDim.x) gbase[x] = lds[x - a0];
 }
+// ---- piece copies inside an LDS tile.  A read's text is a sequence of PIECES (name1, ":lane:tile:x:y", name2, sequence [1-2 ranges],
+// strand, quality + four newlines); every piece is a byte range of one staged LDS array, copied forwards or (RC mates) backwards.
+// A thread builds ONE aligned destination word of one piece: t = piece offset of the word's byte 0 (-3..n-1).
+__device__ __forceinline__ uint32_t piece_word(const uint8_t* base, uint32_t src, uint32_t n, int t, bool rev) {
+    const int a = rev ? (int)n - 4 - t : t; const uint32_t neg = a < 0 ? (uint32_t)(-a) : 0u;        // neg <= 3
+    const uint32_t g = lds_get4(base, src + (uint32_t)(a < 0 ? 0 : a));
+    return rev ? bswap32(g) >> (8u * neg) : g << (8u * neg);
+}
+__device__ __forceinline__ void piece_store(uint8_t* out, uint32_t dst, uint32_t n, uint32_t k, int t, uint32_t w) {
+    uint8_t* o = out + (dst & ~3u) + 4u * k;
+    if (t >= 0 && t + 4 <= (int)n) *(uint32_t*)o = w;
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (t + i >= 0 && t + i < (int)n) o[i] = (uint8_t)(w >> (8 * i));
+    }
+}
+// idx -> (j, k) with k < W: float reciprocal + one-step correction (idx < 2^20)
+__device__ __forceinline__ void item_jk(uint32_t idx, uint32_t W, float rcp, uint32_t& j, uint32_t& k) {
+    j = (uint32_t)((float)idx * rcp); k = idx - j * W;
+    if ((int)k < 0) { j--; k += W; } else if (k >= W) { j++; k -= W; }
+}
 #define ET_READS 32
 #define ET_OCAP 16384u            // output tile bytes (split: half per stream)
 #define ET_SCAP 6144u             // staged qualities / stored bases
 #define ET_N1CAP 4096u            // staged name1 / name2 / strand pieces of the tile (fall back to global memory when larger)
 #define ET_N2CAP 1024u
-#define ET_STCAP 512u
+#define ET_STCAP 1024u
 __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
                            const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, uint64_t img_bytes, int split,
@@ -448,7 +469,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
     __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
     __shared__ uint4 s_q4[ET_SCAP / 16 + 4], s_s4[ET_SCAP / 16 + 4], s_mid4[ET_READS * 40 / 16 + 4];
     __shared__ uint4 s_n14[ET_N1CAP / 16 + 4], s_n24[ET_N2CAP / 16 + 4], s_st4[ET_STCAP / 16 + 4];
-    __shared__ uint32_t s_cnt; __shared__ uint32_t s_meta[(ET_READS + 1) * 16];
+    __shared__ uint32_t s_cnt; __shared__ uint32_t s_meta[(ET_READS + 1) * 16]; __shared__ uint32_t s_mx[8];   // s_mx: longest pieces among the candidates
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
     const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
@@ -474,7 +495,14 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                 m[4] = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
                 m[5] = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
                 m[6] = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
+                m[11] = R.mid[(size_t)g * 40 + 39]; m[10] = m[4] + m[11] + m[5] + 1;             // ":lane:tile:x:y" bytes; offset of the sequence line
             }
+        }
+        if (tid < 64) {                                                    // wave 0 holds every candidate (ET_READS <= 64)
+            const bool on = tid < ET_READS && cur + tid < re; const uint32_t* m = s_meta + 16 * tid;
+            const uint32_t v1 = wave_max(on ? m[4] : 0u), v2 = wave_max(on ? m[5] : 0u), v3 = wave_max(on ? m[6] : 0u), v4 = wave_max(on ? m[1] : 0u);
+            const uint32_t v5 = wave_max(on && (int)m[2] < 0 ? (uint32_t)(-(int)m[2]) : 0u);
+            if (tid == 0) { s_mx[0] = v1; s_mx[1] = v2; s_mx[2] = v3; s_mx[3] = v4; s_mx[4] = v5; }
         }
         __syncthreads();
         k1 = clock64(); a1 += k1 - k0;
@@ -484,7 +512,9 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         if (tid < ET_READS && cur + tid < re) {
             uint32_t mm = (tid + 2u) & ~1u; if (cur + mm > re) mm = re - cur;  // whole pairs (a lone last read of an SE chunk is fine)
             const uint32_t* me = s_meta + 16 * mm;
-            fits = (me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 32u <= ET_SCAP && (me[14] - mb[14]) + 32u <= ET_SCAP;
+            fits = (me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 32u <= ET_SCAP && (me[14] - mb[14]) + 32u <= ET_SCAP
+                && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)
+                && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP);
         }
         { const unsigned long long fb = __ballot(fits); if (l == 0 && fb) atomicAdd(&s_cnt, (uint32_t)__popcll(fb)); }
         __syncthreads();
@@ -512,10 +542,72 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         }
         __syncthreads();
         k3 = clock64(); a3 += k3 - k2;
-        // ---- phase 4: one wave per read composes its four lines inside the LDS output tile
+        // ---- phase 4: compose the tile's text in LDS
         const uint8_t* q_l = (const uint8_t*)s_q4 + (qa & 15ull); const uint8_t* s_l = (const uint8_t*)s_s4 + (sa & 15ull);
         const uint8_t* m_l = (const uint8_t*)s_mid4 + (((uint64_t)g0 * 40) & 15ull);
         uint8_t* oA = (uint8_t*)s_out4 + (tp0.a & 15u); uint8_t* oB = (uint8_t*)s_out4 + ET_OCAP / 2 + (tp0.b & 15u);
+        if (tiled && n1l && n2l && stl_) {
+            // piece-parallel: for each kind of piece one flat loop over (read j, destination word k) - every thread copies whole words
+            uint8_t* const out = (uint8_t*)s_out4;
+            const uint32_t qoff = (uint32_t)(qa & 15ull), soff = (uint32_t)(sa & 15ull), moff = (uint32_t)(((uint64_t)g0 * 40) & 15ull);
+            const uint32_t n1off = (uint32_t)(n1a & 15ull), n2off = (uint32_t)(n2a & 15ull), stoff = (uint32_t)(sta & 15ull);
+            const uint32_t recA = (tp0.a & 15u) - tp0.a, recB = ET_OCAP / 2 + (tp0.b & 15u) - tp0.b;       // + at = LDS offset of a record
+#define EMIT_PIECES(WORDS, ...) { const uint32_t W_ = (WORDS); const float rcp_ = 1.0f / (float)W_; \
+            for (uint32_t idx_ = tid; idx_ < cnt * W_; idx_ += blockDim.x) { uint32_t j, k; item_jk(idx_, W_, rcp_, j, k); \
+                const uint32_t* m = s_meta + 16 * j; const bool odd = ((cur + j) & 1u) != 0; \
+                const uint32_t rec = ((split && odd) ? recB : recA) + m[0]; const uint32_t mid = m[11]; \
+                __VA_ARGS__ } }
+            EMIT_PIECES((s_mx[0] + 3) / 4 + 1, {                            // name1
+                const uint32_t n = m[4], dst = rec; const int t = (int)(4u * k) - (int)(dst & 3u);
+                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_n14, n1off + ((fl & C_NAME1_SAME) ? 0u : m[7] - a7), n, t, false));
+            })
+            EMIT_PIECES(10u, {                                               // ":lane:tile:x:y" (<= 33 bytes)
+                const uint32_t n = mid, dst = rec + m[4]; const int t = (int)(4u * k) - (int)(dst & 3u);
+                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_mid4, moff + 40u * j, n, t, false));
+            })
+            EMIT_PIECES((s_mx[1] + 3) / 4 + 1, {                            // name2 (the mate's differing character patched in)
+                const uint32_t n = m[5], dst = rec + m[4] + mid; const int t = (int)(4u * k) - (int)(dst & 3u);
+                if (t < (int)n) {
+                    uint32_t w = piece_word((const uint8_t*)s_n24, n2off + ((fl & C_NAME2_SAME) ? 0u : m[8] - a8), n, t, false);
+                    if ((fl & C_NAME2_SAME) && il && odd && dch != 0 && (int)dpos >= t && (int)dpos < t + 4) { const uint32_t sh = 8u * (uint32_t)((int)dpos - t); w = (w & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
+                    piece_store(out, dst, n, k, t, w);
+                }
+            })
+            EMIT_PIECES((s_mx[2] + 3) / 4 + 1, {                            // strand
+                const uint32_t n = m[6], dst = rec + m[10] + m[1] + 1; const int t = (int)(4u * k) - (int)(dst & 3u);
+                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_st4, stoff + ((fl & C_STRAND_SAME) ? 0u : m[9] - a9), n, t, false));
+            })
+            EMIT_PIECES((s_mx[3] + 3) / 4 + 1, {                            // quality (back to front for an RC mate)
+                const uint32_t n = m[1], dst = rec + m[10] + n + 1 + m[6] + 1; const int t = (int)(4u * k) - (int)(dst & 3u);
+                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_q4, qoff + (m[15] - q0), n, t, il && odd));
+            })
+            // sequence: interleaved-orientation positions p in [0, xa) come from sA + p, p in [xa, len) from sB + (p - xa) (the part a
+            // negative overlap borrowed from the mate); an RC mate emits complemented, back to front
+#define EMIT_SEQ(WORDS, PART_B) EMIT_PIECES(WORDS, { \
+                const uint32_t len = m[1]; const int ov = (int)m[2]; const bool rc = il && odd; \
+                const uint32_t xa = ov < 0 ? len - (uint32_t)(-ov) : len; const uint32_t sp = m[14] - s0; \
+                const uint32_t n = (PART_B) ? len - xa : xa; const uint32_t p0 = (PART_B) ? xa : 0u; \
+                const uint32_t src = (PART_B) ? sp - m[3] : (ov > 0 ? sp - (uint32_t)ov : sp); \
+                const uint32_t dst = rec + m[10] + (rc ? len - p0 - n : p0); const int t = (int)(4u * k) - (int)(dst & 3u); \
+                if (t < (int)n) { \
+                    uint32_t w = piece_word((const uint8_t*)s_s4, soff + src, n, t, rc); \
+                    if (rc) w = comp4(w); \
+                    if (implied_n) { const uint32_t qw = piece_word((const uint8_t*)s_q4, qoff + (m[15] - q0) + p0, n, t, rc); \
+                                     const uint32_t mk = eq_bytes_full(qw, (nq & 0xFFu) * 0x01010101u); w = (w & ~mk) | (0x4E4E4E4Eu & mk); } \
+                    piece_store(out, dst, n, k, t, w); \
+                } })
+            EMIT_SEQ((s_mx[3] + 3) / 4 + 1, false)
+            if (s_mx[4]) EMIT_SEQ((s_mx[4] + 3) / 4 + 1, true)
+            for (uint32_t idx = tid; idx < 4 * cnt; idx += blockDim.x) {    // the four newlines; capacity check
+                const uint32_t j = idx >> 2, which = idx & 3u; const uint32_t* m = s_meta + 16 * j; const bool odd = ((cur + j) & 1u) != 0; const bool to2 = split && odd;
+                const uint32_t rec = (to2 ? recB : recA) + m[0];
+                const uint32_t e0 = m[10] - 1, e1 = e0 + 1 + m[1], e2 = e1 + 1 + m[6], e3 = e2 + 1 + m[1];
+                out[rec + (which == 0 ? e0 : which == 1 ? e1 : which == 2 ? e2 : e3)] = '\n';
+                if (which == 0 && (uint64_t)m[0] + e3 + 1 > (to2 ? cap2 : cap1)) atomicOr(&st->err, 1u << 31);
+            }
+#undef EMIT_SEQ
+#undef EMIT_PIECES
+        } else
         for (uint32_t j = (uint32_t)wave_id(); j < cnt; j += wpb) {
             const uint32_t r = cur + j, g = g0 + j; const uint32_t* m = s_meta + 16 * j;
             const bool odd = (r & 1u) != 0; const bool to2 = split && odd;

@@ -540,10 +540,6 @@ __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int 
 // the whole wave, four bytes per lane.
 #define OV_CAP 320u                      // bases per read staged in LDS (longer reads take the global-memory path)
 #define OV_ROW (OV_CAP + 16u)            // 8 bytes of slack before the data (reads below the row are masked out), 4+ after
-__device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) {
-    const uint32_t* p = (const uint32_t*)(base + (a & ~3u)); const uint32_t sh = (a & 3u) * 8u;
-    return (uint32_t)((((uint64_t)p[1] << 32) | p[0]) >> sh);
-}
 struct OvPair { uint32_t r1, c2; int len1, len2; };           // LDS offsets of R1[0] and c2[0]
 __device__ __forceinline__ uint32_t ov_r1(const uint8_t* rows, const OvPair& P, uint32_t i) { return lds_get4(rows, P.r1 + i); }
 __device__ __forceinline__ uint32_t ov_rc(const uint8_t* rows, const OvPair& P, uint32_t i) { return bswap32(lds_get4(rows, P.c2 + (uint32_t)P.len2 - 4u - i)); }
