@@ -155,8 +155,9 @@ def main():
         value = total_bytes * passes * K / dt / 1e6
         stage = {k: v / K for k, v in state["stage_ms"].items()}
         enc_stage = {k: v for k, v in stage.items() if not k.startswith("dec:")}
-        dom = max(enc_stage, key=enc_stage.get) if enc_stage else None
-        alg = float(n + state["rfq_len"])                    # B_fastq + B_rfq per batch
+        dec_stage = {k: v for k, v in stage.items() if k.startswith("dec:")}
+        dom = max(stage, key=stage.get) if stage else None    # the longest stage of either direction (HIP events on the codec's stream)
+        alg = float(n + state["rfq_len"])                    # B_fastq + B_rfq per batch, either direction
         roof = None
         if dom:
             # HBM bytes of the dominant stage from the committed PMC passes (tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE collected in
@@ -165,15 +166,21 @@ def main():
             STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
                              "chunk_flags+overlap": ["k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
                              "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder<0>", "k_pos_coder<1>", "k_pos_coder<2>"],
-                             "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"]}
+                             "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
+                             "dec:walk": ["k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
+                             "dec:streams": ["k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos", "k_dec_except", "k_dec_coords"],
+                             "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit"]}
             pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if args.reads == 2_800_000 and args.chunk_kb == 1000 and os.path.exists(pj):
+            if args.reads == 2_800_000 and args.chunk_kb == 1000 and not args.pe and os.path.exists(pj):
                 pmc = json.load(open(pj))
-                traffic = int(sum(pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in STAGE_KERNELS.get(dom, []) if k in pmc))
-            ach = alg / (enc_stage[dom] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(enc_stage[dom], 4),
-                    "whole_encode_frac": round(alg / (sum(enc_stage.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                ks = [k for k in STAGE_KERNELS.get(dom, []) if k in pmc]
+                traffic = int(sum(pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in ks)) if ks else None
+            ach = alg / (stage[dom] * 1e-3) / 1e9
+            enc_ms, dec_ms = sum(enc_stage.values()), sum(dec_stage.values())
+            roof = {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS.get(dom, [dom])), "stage": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(stage[dom], 4),
+                    "whole_encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if enc_ms else None,
+                    "whole_decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}
         out = {
             "metric": "raw FASTQ MB/s encode+decode" if state.get("decode_ok") else "raw FASTQ MB/s encode (decode pending)",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

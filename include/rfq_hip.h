@@ -27,7 +27,7 @@ extern "C" {
 #define RFQ_E_NO_DEVICE    -1   /* no GPU / hip runtime error at create */
 #define RFQ_E_HIP          -2   /* a hip call failed (message has the hip error string) */
 #define RFQ_E_ARG          -3   /* bad argument */
-#define RFQ_E_TEXT         -4   /* FASTQ text the device reader does not handle yet: '\r', empty lines (src/fastqreader.cpp:94-196 quirks) */
+#define RFQ_E_TEXT         -4   /* (no longer returned: '\r' line ends and blank lines take the normalising path, src/fastqreader.cpp:94-196) */
 #define RFQ_E_DATA         -5   /* the reference would error_exit on this input (message = its text) */
 #define RFQ_E_FORMAT       -6   /* not a valid .rfq / different ALGORITHM_VER (src/rfqheader.cpp:23-25,40-42) */
 #define RFQ_E_UNPINNED     -7   /* input is in a reference-UB zone: refused rather than guessed */
@@ -85,6 +85,10 @@ typedef struct {
     uint64_t n_bases;
     size_t   consumed1, consumed2;        /* bytes of each stream covered by the emitted chunks                        */
     const uint64_t* h_chunk_off;          /* host array [n_chunks+1]: byte offset of each chunk image in d_rfq         */
+    int32_t  input_ended;                 /* 1: the reader met an empty line inside a record: FastqReader::read returns NULL
+                                             there (src/fastqreader.cpp:180-191), so the result already holds the tail chunk
+                                             and the caller must not feed the rest of the input                          */
+    int32_t  reserved;
 } rfq_encode_result;
 
 /* RfqCodec::makeHeader (first call without a header; src/rfqcodec.cpp:20-145) + RfqCodec::encodeChunk + RfqChunk::write

@@ -744,6 +744,10 @@ static int decode_chunk(const rfqo_header* h, const chunk_t* c, int split, bb_t*
 int rfqo_decode_file(const uint8_t* rfq, size_t n, int split_pe, uint8_t** out1, size_t* n1, uint8_t** out2, size_t* n2, char* err) {
     rfqo_header h; size_t used = 0; err[0] = 0;
     *out1 = NULL; *n1 = 0; if (out2) { *out2 = NULL; *n2 = 0; }
+    if (n == 0) {   /* every istream::read fails and the constructor's defaults stand (valid magic, flags 0; src/rfqheader.cpp:7-17,19-43): no chunk follows */
+        if (split_pe) { snprintf(err, 256, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>"); return -1; }
+        return 0;
+    }
     if (rfqo_header_read(rfq, n, &h, &used, err)) return -1;
     if (split_pe && !(h.flags & RFQO_H_PAIRED)) { snprintf(err, 256, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>"); return -1; }
     bb_t outs[2] = { {0}, {0} }; size_t k = used; uint16_t last_flags = 0; int any = 0;

@@ -32,7 +32,8 @@ class EncodeArgs(C.Structure):
 
 class EncodeResult(C.Structure):
     _fields_ = [("d_rfq", C.c_void_p), ("rfq_len", C.c_size_t), ("n_chunks", C.c_uint32), ("n_reads", C.c_uint64), ("n_bases", C.c_uint64),
-                ("consumed1", C.c_size_t), ("consumed2", C.c_size_t), ("h_chunk_off", C.POINTER(C.c_uint64))]
+                ("consumed1", C.c_size_t), ("consumed2", C.c_size_t), ("h_chunk_off", C.POINTER(C.c_uint64)),
+                ("input_ended", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DecodeArgs(C.Structure):

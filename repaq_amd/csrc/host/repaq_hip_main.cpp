@@ -74,7 +74,7 @@ static void do_compress(const Options& o) {
             if (r.n_chunks) first = false;
         }
         rfq_dev_free(g.c, d1); if (d2) rfq_dev_free(g.c, d2);
-        if (final) break;
+        if (final || r.input_ended) break;          // input_ended: the reader stopped at an empty line (src/fastqreader.cpp:180-191)
         if (r.consumed1 == 0 && (!two || r.consumed2 == 0)) {
             // not a single full chunk in this batch: grow it (a chunk can be larger than the batch)
             const_cast<Options&>(o).batchBytes *= 2; continue;

@@ -78,6 +78,8 @@ struct DevStatus {
     uint32_t n_units_used;      // units (reads or pairs) covered by emitted chunks
     uint64_t total_image;       // bytes of all chunk images
     uint64_t total_bases;
+    uint32_t first_empty;       // first read (interleaved order) with an empty line, ~0 if none
+    uint32_t pad_;
 };
 
 struct U4 { uint32_t a, b, c, d; };

@@ -20,6 +20,12 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     memset(res, 0, sizeof *res);
     ctx->err.clear();
     if (a->n && !a->d_rfq) return rfq_fail(ctx, RFQ_E_ARG, "null rfq pointer");
+    if (a->n == 0 && a->has_header) {
+        // an empty .rfq: every read of RfqHeader::read fails and the constructor's defaults stand (valid magic, flags 0;
+        // src/rfqheader.cpp:7-17,19-43), no chunk follows: the reference writes an empty FASTQ
+        if (a->split_pe) return rfq_fail(ctx, RFQ_E_DATA, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>");
+        return RFQ_OK;
+    }
     hipStream_t S = ctx->stream; DBuf* B = ctx->b;
     static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // profiling aid: phase cycle counters (dbg words alias the head of the mid buffer: text is invalid when set)
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -115,7 +121,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     ctx->timer.end(S);
 
     // ---- text
-    ctx->timer.begin("text", S);
+    ctx->timer.begin("textlen", S);
     const int split = a->split_pe ? 1 : 0;
     hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split);
     scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
@@ -129,6 +135,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     if ((a->d_out1 && ((uintptr_t)a->d_out1 & 15u)) || (a->d_out2 && ((uintptr_t)a->d_out2 & 15u))) return rfq_fail(ctx, RFQ_E_ARG, "output device pointers must be 16-byte aligned");
     if (a->d_out1) { o1 = a->d_out1; cap1 = a->cap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
     if (a->d_out2) { o2 = a->d_out2; cap2 = a->cap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
+    ctx->timer.end(S);
+    ctx->timer.begin("emit", S);                                       // k_dec_emit alone: the path's largest kernel (bench.py roofline)
     {
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
         static const uint32_t etpb = getenv("RFQ_EMIT_TPB") ? (uint32_t)atoi(getenv("RFQ_EMIT_TPB")) : 256u;

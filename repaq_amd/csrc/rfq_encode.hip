@@ -11,7 +11,8 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_BITMAP0 = 0, B_BITMAP1, B_BLK0, B_BLK1, B_LO0, B_LO1, B_SCANTMP,
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
-    B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC, B_ENC_END
+    B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_ENC_END
 };
 
 static int fetch_bytes(rfq_ctx* ctx, const uint8_t* d, size_t n, std::string& out) {
@@ -47,10 +48,67 @@ int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n) {
 }
 
 
+// Mapping of a normalised stream (see k_norm_classify) back to the caller's text
+struct NormMap { const uint32_t* ot[2]; const uint32_t* onx[2]; size_t orig_n[2]; };
+#define RFQ_NEED_NORM 1            // internal: the '\n'-only indexer met '\r' or an empty line; redo on normalised text
+
+// FastqReader::getLine semantics for text with '\r' / blank lines: rewrite stream s as '\n'-terminated text + the line maps
+static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t file_off, bool final, int s, NormMap& nm, const uint8_t** out, size_t* out_n) {
+    hipStream_t S = ctx->stream; DBuf* B = ctx->b;
+    nm.orig_n[s] = n; nm.ot[s] = nm.onx[s] = nullptr; *out = nullptr; *out_n = 0;
+    if (n == 0) return RFQ_OK;
+    const uint64_t nwords = (n + 63) / 64; const uint32_t nblk = (uint32_t)((nwords + 255) / 256);
+    HIPCHK(ctx, B[B_TBITS].ensure(nwords * 8 + 64)); HIPCHK(ctx, B[B_SBITS].ensure(nwords * 8 + 64));
+    HIPCHK(ctx, B[B_NKEEP].ensure(((size_t)nblk + 2) * 4)); HIPCHK(ctx, B[B_NTERM].ensure(((size_t)nblk + 2) * 4));
+    HIPCHK(ctx, B[B_SCANTMP].ensure(std::max<size_t>(1024, ((size_t)nblk / SCAN_TILE + 2) * 16)));
+    NormIn in; in.fq = fq; in.n = (uint32_t)n; in.file_off = file_off; in.file_end = final ? file_off + n : ~0ull;
+    hipLaunchKernelGGL(k_norm_classify, dim3(nblk), dim3(256), 0, S, in, B[B_TBITS].as<uint64_t>(), B[B_SBITS].as<uint64_t>(), B[B_NKEEP].as<uint32_t>(), B[B_NTERM].as<uint32_t>());
+    KCHK(ctx, "k_norm_classify");
+    scan_exclusive<uint32_t>(S, B[B_NKEEP].as<uint32_t>(), B[B_NKEEP].as<uint32_t>(), nblk, B[B_SCANTMP].as<uint32_t>(), 1);
+    scan_exclusive<uint32_t>(S, B[B_NTERM].as<uint32_t>(), B[B_NTERM].as<uint32_t>(), nblk, B[B_SCANTMP].as<uint32_t>(), 1);
+    uint32_t keep = 0, terms = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&keep, B[B_NKEEP].as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipMemcpyAsync(&terms, B[B_NTERM].as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, B[B_NORM0 + s].ensure((size_t)keep + 64)); HIPCHK(ctx, B[B_OT0 + s].ensure(((size_t)terms + 4) * 4)); HIPCHK(ctx, B[B_ONX0 + s].ensure(((size_t)terms + 4) * 4));
+    hipLaunchKernelGGL(k_norm_emit, dim3(nblk), dim3(256), 0, S, in, (const uint64_t*)B[B_TBITS].as<uint64_t>(), (const uint64_t*)B[B_SBITS].as<uint64_t>(),
+                       (const uint32_t*)B[B_NKEEP].as<uint32_t>(), (const uint32_t*)B[B_NTERM].as<uint32_t>(), B[B_NORM0 + s].as<uint8_t>(), B[B_OT0 + s].as<uint32_t>(), B[B_ONX0 + s].as<uint32_t>());
+    hipLaunchKernelGGL(k_norm_tail, dim3(1), dim3(64), 0, S, B[B_OT0 + s].as<uint32_t>(), B[B_ONX0 + s].as<uint32_t>(), terms, (uint32_t)n);
+    KCHK(ctx, "k_norm_emit");
+    nm.ot[s] = B[B_OT0 + s].as<uint32_t>(); nm.onx[s] = B[B_ONX0 + s].as<uint32_t>();
+    *out = B[B_NORM0 + s].as<uint8_t>(); *out_n = keep;
+    return RFQ_OK;
+}
+
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended);
+
 extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res) {
     if (!ctx || !a || !res) return RFQ_E_ARG;
     memset(res, 0, sizeof *res);
     ctx->err.clear();
+    if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
+    int rc = encode_impl(ctx, a, res, nullptr, ~0u, false);
+    if (rc != RFQ_NEED_NORM) return rc;
+    // slow path: '\r' line ends or blank lines (src/fastqreader.cpp:94-196)
+    NormMap nm; memset(&nm, 0, sizeof nm);
+    rfq_encode_args a2 = *a;
+    const uint8_t* p; size_t pn;
+    if ((rc = normalize_stream(ctx, a->d_fq1, a->n1, a->file_off1, a->final != 0, 0, nm, &p, &pn)) != RFQ_OK) return rc;
+    a2.d_fq1 = p; a2.n1 = pn;
+    if (a->paired == RFQ_PE_TWO_FILES) {
+        if ((rc = normalize_stream(ctx, a->d_fq2, a->n2, a->file_off2, a->final != 0, 1, nm, &p, &pn)) != RFQ_OK) return rc;
+        a2.d_fq2 = p; a2.n2 = pn;
+    }
+    memset(res, 0, sizeof *res);
+    rc = encode_impl(ctx, &a2, res, &nm, ~0u, false);
+    if (rc == RFQ_NEED_NORM) return rfq_fail(ctx, RFQ_E_HIP, "internal: normalised text still needs normalisation");
+    return rc;
+}
+
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended) {
+    memset(res, 0, sizeof *res);
+    res->input_ended = ended ? 1 : 0;
+    const bool fin = a->final || ended;
     if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
     if (a->chunk_bases == 0) return rfq_fail(ctx, RFQ_E_ARG, "chunk_bases must be >= 1");
     const int nstreams = a->paired == RFQ_PE_TWO_FILES ? 2 : 1;
@@ -68,7 +126,7 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
     // ---- status block
-    DevStatus hs; memset(&hs, 0, sizeof hs); hs.err_key = ~0ull; hs.coord_key = ~0ull;
+    DevStatus hs; memset(&hs, 0, sizeof hs); hs.err_key = ~0ull; hs.coord_key = ~0ull; hs.first_empty = ~0u;
     HIPCHK(ctx, ctx->d_status.ensure(sizeof(DevStatus)));
     DevStatus* dst = ctx->d_status.as<DevStatus>();
     HIPCHK(ctx, hipMemcpyAsync(dst, &hs, sizeof hs, hipMemcpyHostToDevice, S));
@@ -98,7 +156,7 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     }
     HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
     HIPCHK(ctx, hipStreamSynchronize(S));
-    if (hs.err & DE_HAS_CR) return rfq_fail(ctx, RFQ_E_TEXT, "FASTQ text contains '\\r' line endings; the device reader handles '\\n'-terminated text only");
+    if (hs.err & DE_HAS_CR) return nm ? rfq_fail(ctx, RFQ_E_HIP, "internal: '\\r' in normalised text") : RFQ_NEED_NORM;
     uint32_t nlines[2] = { 0, 0 }, nrec[2] = { 0, 0 };
     for (int s = 0; s < nstreams; s++) {
         // an unterminated tail is the file's last line only in the final batch; in a non-final batch it is a line cut by the
@@ -116,9 +174,10 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
 
     // ---- phase 2: read table, chunk cuts
     Text T; memset(&T, 0, sizeof T);
-    for (int s = 0; s < 2; s++) { T.fq[s] = fq[s]; T.n[s] = (uint32_t)nbytes[s]; T.lo[s] = s < nstreams ? B[B_LO0 + s].as<uint32_t>() : nullptr; }
+    for (int s = 0; s < 2; s++) { T.fq[s] = fq[s]; T.n[s] = (uint32_t)nbytes[s]; T.lo[s] = s < nstreams ? B[B_LO0 + s].as<uint32_t>() : nullptr; T.ot[s] = nm && s < nstreams ? nm->ot[s] : nullptr; }
     T.paired = a->paired; T.upr = a->paired == RFQ_SE ? 1u : 2u;
     uint32_t n_units = a->paired == RFQ_SE ? nrec[0] : (a->paired == RFQ_PE_TWO_FILES ? std::min(nrec[0], nrec[1]) : nrec[0] / 2);
+    if (n_units > unit_cap) n_units = unit_cap;                       // the reader stopped at an empty line (src/fastqreader.cpp:180-191)
     const uint32_t n_reads = n_units * T.upr; T.n_reads = n_reads;
     res->d_rfq = nullptr;
     if (n_units == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
@@ -148,13 +207,18 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     HIPCHK(ctx, B[B_FIRST].ensure(((size_t)cap_chunks + 2) * 4));
     ChunkTab C; memset(&C, 0, sizeof C);
     C.first = B[B_FIRST].as<uint32_t>();
-    hipLaunchKernelGGL(k_partition, dim3(1), dim3(64), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->final ? 1 : 0,
+    hipLaunchKernelGGL(k_partition, dim3(1), dim3(64), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, fin ? 1 : 0,
                        (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst);
     KCHK(ctx, "k_partition");
     HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
     HIPCHK(ctx, hipStreamSynchronize(S));
     ctx->timer.end(S);
-    if (hs.err & DE_EMPTY_LINE) return rfq_fail(ctx, RFQ_E_TEXT, "FASTQ text has an empty line inside a record (the reference reader stops there, src/fastqreader.cpp:180-191); not handled on device");
+    if (hs.err & DE_EMPTY_LINE) {
+        // "\n\n" is a swallowed blank line, not an empty one: classify the text properly first.  On normalised text an empty line is
+        // where FastqReader::read returns NULL (src/fastqreader.cpp:180-191): the record and everything after it are never read.
+        if (!nm) return RFQ_NEED_NORM;
+        return encode_impl(ctx, a, res, nm, hs.first_empty / T.upr, true);
+    }
     if (hs.err & DE_QUAL_SHORT) return rfq_fail(ctx, RFQ_E_UNPINNED, "a quality line is shorter than its sequence line (the reference reads past the string: undefined)");
     const uint32_t n_chunks = hs.n_chunks;
     if (n_chunks > cap_chunks) return rfq_fail(ctx, RFQ_E_HIP, "internal: chunk table overflow (%u > %u)", n_chunks, cap_chunks);
@@ -295,7 +359,8 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     uint32_t cons[2] = { 0, 0 };
     for (int s = 0; s < nstreams; s++) {
         const uint32_t recs = a->paired == RFQ_PE_INTERLEAVED ? reads_used : (a->paired == RFQ_PE_TWO_FILES ? units_used : reads_used);
-        HIPCHK(ctx, hipMemcpyAsync(&cons[s], B[B_LO0 + s].as<uint32_t>() + 4 * (size_t)recs, 4, hipMemcpyDeviceToHost, S));
+        if (nm) { cons[s] = 0; if (recs) HIPCHK(ctx, hipMemcpyAsync(&cons[s], nm->onx[s] + 4 * (size_t)recs - 1, 4, hipMemcpyDeviceToHost, S)); }
+        else HIPCHK(ctx, hipMemcpyAsync(&cons[s], B[B_LO0 + s].as<uint32_t>() + 4 * (size_t)recs, 4, hipMemcpyDeviceToHost, S));
     }
     HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
     HIPCHK(ctx, hipStreamSynchronize(S));
@@ -313,8 +378,9 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
     if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %llu bytes", (unsigned long long)(hs.total_image + hdr_bytes));
     for (auto& o : ctx->chunk_off) o += hdr_bytes;
     res->d_rfq = img; res->rfq_len = (size_t)(hs.total_image + hdr_bytes); res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases;
-    res->consumed1 = cons[0] > nbytes[0] ? nbytes[0] : cons[0];
-    res->consumed2 = nstreams == 2 ? (cons[1] > nbytes[1] ? nbytes[1] : cons[1]) : 0;
+    const size_t lim[2] = { nm ? nm->orig_n[0] : nbytes[0], nm ? nm->orig_n[1] : nbytes[1] };
+    res->consumed1 = cons[0] > lim[0] ? lim[0] : cons[0];
+    res->consumed2 = nstreams == 2 ? (cons[1] > lim[1] ? lim[1] : cons[1]) : 0;
     res->h_chunk_off = ctx->chunk_off.data();
     return RFQ_OK;
 }

@@ -15,6 +15,7 @@ struct Text {                    // the FASTQ streams of a batch and their line 
     const uint8_t* fq[2];
     uint32_t n[2];
     const uint32_t* lo[2];       // lo[s][i] = start of line i; lo[s][i+1]-1 = its terminator (virtual at n for an unterminated tail)
+    const uint32_t* ot[2];       // normalised text only (else null): offset of line i's terminator in the caller's text
     int paired;                  // RFQ_SE / RFQ_PE_TWO_FILES / RFQ_PE_INTERLEAVED
     uint32_t n_reads;            // reads in interleaved order (PE: 2 * pairs)
     uint32_t upr;                // reads per partition unit (1 SE, 2 PE)
@@ -92,6 +93,70 @@ __global__ void k_line_offsets(const uint64_t* __restrict__ bitmap, const uint32
 }
 __global__ void k_line_tail(uint32_t* lo, uint32_t n_newlines, uint32_t n, int unterminated) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && unterminated) lo[n_newlines + 1] = n + 1;
+}
+
+// =============================================================== text normalisation (slow path: '\r' or blank lines present)
+// FastqReader::getLine (src/fastqreader.cpp:94-156): a line ends at '\r' or '\n'; ONE '\n' directly after a terminator is
+// swallowed ("\r\n", but also a single blank line) unless that terminator sits in the last two bytes of the reader's 1 MiB
+// block (`end < mBufDataLen - 1`).  Every byte is K (kept), T (terminator) or S (swallowed); the normalised stream keeps K,
+// writes '\n' for T and drops S, so the '\n'-only indexer above applies unchanged.  ot / onx map normalised line i back to
+// the original text: offset of its terminator, offset of the line after it.
+// Exactness: the class of a '\n' depends on its predecessors through the run of terminator characters before it; the walk
+// below looks back over at most 4 of them.  The third terminator of any such run already is an empty line, where the reader
+// stops for good (src/fastqreader.cpp:180-191), so classes beyond that point never reach the output.
+#define FQ_BLOCK_BYTES (1u << 20)
+struct NormIn { const uint8_t* fq; uint32_t n; uint64_t file_off, file_end; };
+__device__ __forceinline__ bool norm_exc(const NormIn& c, uint32_t j) {            // '\n' at j (j >= 1) cannot be swallowed
+    const uint64_t e = c.file_off + j - 1;                                           // absolute offset of the terminator
+    uint64_t bend = (e | (uint64_t)(FQ_BLOCK_BYTES - 1)) + 1; if (bend > c.file_end) bend = c.file_end;
+    return !(e + 1 < bend - 1);
+}
+__device__ __forceinline__ bool norm_state_at(const NormIn& c, uint32_t j) {       // is byte j-1 a terminator that may swallow byte j?
+    if (j == 0) return false;                                                        // a batch starts at a line start
+    uint32_t k = 0; while (k < 4 && k < j && c.fq[j - 1 - k] == '\n') k++;
+    bool st = (k < 4 && j - k > 0) ? c.fq[j - k - 1] == '\r' : false;
+    for (uint32_t i = j - k; i < j; i++) { if (st && !norm_exc(c, i)) st = false; else st = true; }
+    return st;
+}
+// 64 bytes per thread: T and S bitmaps + per-block counts of kept bytes and of terminators
+__global__ void k_norm_classify(NormIn c, uint64_t* __restrict__ tbits, uint64_t* __restrict__ sbits, uint32_t* __restrict__ blk_keep, uint32_t* __restrict__ blk_term) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; const uint64_t base = w * 64;
+    uint64_t tm = 0, sm = 0; uint32_t valid = 0;
+    if (base < c.n) {
+        valid = (uint32_t)(c.n - base < 64 ? c.n - base : 64);
+        bool st = norm_state_at(c, (uint32_t)base);
+        for (uint32_t i = 0; i < valid; i++) {
+            const uint8_t ch = c.fq[base + i];
+            if (ch == '\r') { tm |= 1ull << i; st = true; }
+            else if (ch == '\n') { if (st && !norm_exc(c, (uint32_t)base + i)) { sm |= 1ull << i; st = false; } else { tm |= 1ull << i; st = true; } }
+            else st = false;
+        }
+        tbits[w] = tm; sbits[w] = sm;
+    }
+    uint32_t tk, tt; (void)block_excl_sum<uint32_t>(valid - (uint32_t)__popcll(sm), &tk); (void)block_excl_sum<uint32_t>((uint32_t)__popcll(tm), &tt);
+    if (threadIdx.x == 0) { blk_keep[blockIdx.x] = tk; blk_term[blockIdx.x] = tt; }
+}
+__global__ void k_norm_emit(NormIn c, const uint64_t* __restrict__ tbits, const uint64_t* __restrict__ sbits, const uint32_t* __restrict__ keep_base, const uint32_t* __restrict__ term_base,
+                            uint8_t* __restrict__ out, uint32_t* __restrict__ ot, uint32_t* __restrict__ onx) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; const uint64_t base = w * 64;
+    uint64_t tm = 0, sm = 0; uint32_t valid = 0;
+    if (base < c.n) { valid = (uint32_t)(c.n - base < 64 ? c.n - base : 64); tm = tbits[w]; sm = sbits[w]; }
+    uint32_t kp = keep_base[blockIdx.x] + block_excl_sum<uint32_t>(valid - (uint32_t)__popcll(sm), (uint32_t*)nullptr);
+    uint32_t tr = term_base[blockIdx.x] + block_excl_sum<uint32_t>((uint32_t)__popcll(tm), (uint32_t*)nullptr);
+    for (uint32_t i = 0; i < valid; i++) {
+        if ((sm >> i) & 1ull) continue;
+        const bool t = ((tm >> i) & 1ull) != 0;
+        out[kp++] = t ? (uint8_t)'\n' : c.fq[base + i];
+        if (t) {
+            const uint32_t pos = (uint32_t)base + i;
+            bool sw = false;
+            if (pos + 1 < c.n) sw = i + 1 < 64 ? ((sm >> (i + 1)) & 1ull) != 0 : (sbits[w + 1] & 1ull) != 0;
+            ot[tr] = pos; onx[tr] = pos + 1 + (sw ? 1u : 0u); tr++;
+        }
+    }
+}
+__global__ void k_norm_tail(uint32_t* ot, uint32_t* onx, uint32_t n_terms, uint32_t n) {   // the virtual terminator of an unterminated last line
+    if (threadIdx.x == 0 && blockIdx.x == 0) { ot[n_terms] = n; onx[n_terms] = n; }
 }
 
 // =============================================================== read table + name parse
@@ -181,8 +246,9 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, DevStatus* st)
         R.len[g] = sl; R.stored[g] = sl;
         R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
     }
+    const uint32_t fe = wave_min((valid && (err & DE_EMPTY_LINE)) ? g : 0xFFFFFFFFu);
     err = wave_or(err);
-    if (l == 0 && err) atomicOr(&st->err, err);
+    if (l == 0 && err) { atomicOr(&st->err, err); if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); }
 }
 // bases per partition unit (a read, or a pair) + per-block min / max for the partitioner's uniform-length fast path
 // (no atomics: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
@@ -1192,11 +1258,13 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
         uint32_t flags = fl;
         const uint32_t last = f + s - 1;
         if (T.paired == 1) {
-            const uint64_t e1 = off1 + (uint64_t)T.lo[0][4 * (size_t)(last >> 1) + 4] - 1, e2 = off2 + (uint64_t)T.lo[1][4 * (size_t)(last >> 1) + 4] - 1;
+            const size_t q = 4 * (size_t)(last >> 1) + 3;                  // the pair's quality lines
+            const uint64_t e1 = off1 + (T.ot[0] ? (uint64_t)T.ot[0][q] : (uint64_t)T.lo[0][q + 1] - 1), e2 = off2 + (T.ot[1] ? (uint64_t)T.ot[1][q] : (uint64_t)T.lo[1][q + 1] - 1);
             if (e1 >= nolb1) flags |= C_NO_LB;
             if (e2 >= nolb2) flags |= C_NO_LB_R2;
         } else {
-            const uint64_t e1 = off1 + (uint64_t)T.lo[0][4 * (size_t)last + 4] - 1;
+            const size_t q = 4 * (size_t)last + 3;
+            const uint64_t e1 = off1 + (T.ot[0] ? (uint64_t)T.ot[0][q] : (uint64_t)T.lo[0][q + 1] - 1);
             if (e1 >= nolb1) { flags |= C_NO_LB; if (T.paired == 2) flags |= C_NO_LB_R2; }
         }
         st_u32(out, o.msize); st_u32(out + 4, s); st_u16(out + 8, flags); st_u32(out + 10, o.seq_size); st_u32(out + 14, o.qual_size);

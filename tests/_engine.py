@@ -29,7 +29,7 @@ def encode(codec, fq1, fq2=b"", paired=O.SE, chunk_bases=1_000_000):
     return codec.encode_bytes(fq1, fq2, paired, chunk_bases, **nolb_args(fq1, fq2, paired))
 
 
-# text quirks of src/fastqreader.cpp that the device reader refuses (RFQ_E_TEXT) instead of emulating — SURVEY.md §8(f) #1
+# text quirks of src/fastqreader.cpp ('\r', blank lines) — handled by the normalising path since SURVEY.md §8(f) #1 was built
 TEXT_QUIRK_CASES = {"se_crlf", "se_cr_only", "se_crlf_no_final", "se_blank_line_after_record", "se_two_blank_lines_truncate"}
 
 
@@ -38,13 +38,6 @@ def check_case(codec, name, case, golden):
     from repaq_amd import RfqError
     fq1, fq2, paired = case["fq1"], case.get("fq2", b""), case["paired"]
     cb = case.get("k", 1000) * 1000
-    if name in TEXT_QUIRK_CASES:
-        try:
-            encode(codec, fq1, fq2, paired, cb)
-        except RfqError as e:
-            assert e.code == -4, e
-            return "refused"
-        raise AssertionError("expected RFQ_E_TEXT for %s" % name)
     if "error" in golden:
         try:
             encode(codec, fq1, fq2, paired, cb)

@@ -161,6 +161,19 @@ def gen(profile: int, n_reads: int, seed: int = 1, nppm: int = 20, nonl: int = 0
     return b1.raw[: n1.value], b2.raw[: n2.value]
 
 
+def gen_np(profile: int, n_reads: int, seed: int = 1, nppm: int = 20, nonl: int = 0, interleaved: bool = False, n_quals: int = 13):
+    """gen() for multi-GB inputs: the generator writes straight into numpy uint8 arrays (no bytes copies)."""
+    import numpy as np
+    gen(profile, 1, seed)                      # loads the library / prototypes
+    p = _GenParams(seed, n_reads, profile, nppm, nonl, 1 if interleaved else 0, n_quals, 0)
+    n1 = C.c_size_t(); n2 = C.c_size_t()
+    _gen.fqgen_generate(C.byref(p), None, 0, None, 0, C.byref(n1), C.byref(n2))
+    a1 = np.empty(max(1, n1.value), dtype=np.uint8); a2 = np.empty(max(1, n2.value), dtype=np.uint8)
+    rc = _gen.fqgen_generate(C.byref(p), a1.ctypes.data_as(C.c_void_p), n1.value, a2.ctypes.data_as(C.c_void_p), n2.value, C.byref(n1), C.byref(n2))
+    assert rc == 0
+    return a1[: n1.value], a2[: n2.value]
+
+
 def have_ref() -> bool:
     return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
 

@@ -61,6 +61,40 @@ def build_cases():
     C["se_blank_line_after_record"] = dict(fq1=blank, paired=SE)       # "\n\n": one blank line is swallowed
     blank2 = fastq(base[:10]) + b"\n\n" + fastq(base[10:])
     C["se_two_blank_lines_truncate"] = dict(fq1=blank2, paired=SE)      # reader stops at the empty name line
+    # more reader quirks: pairs, mixed line ends, 1 MiB block edges (`end < mBufDataLen - 1`, src/fastqreader.cpp:94-156)
+    qr = random.Random(4242)                # own generator: the cases below keep their bytes
+    C["pe_crlf"] = dict(fq1=fastq(base, eol="\r\n"), fq2=fastq([rec(illumina(i, mate=2), rseq(qr, 40), rqual(qr, 40)) for i in range(30)], eol="\r\n"), paired=PE2)
+    r2q = [rec(illumina(i, mate=2), rseq(qr, 40), rqual(qr, 40)) for i in range(30)]
+    C["pe_crlf_r2_only"] = dict(fq1=fastq(base), fq2=fastq(r2q, eol="\r\n"), paired=PE2)
+    C["il_crlf"] = dict(fq1=fastq([r for ab in zip(base, r2q) for r in ab], eol="\r\n"), paired=PEI)
+    C["pe_three_newlines_in_r2"] = dict(fq1=fastq(base), fq2=fastq(r2q[:17]) + b"\n\n" + fastq(r2q[17:]), paired=PE2)     # pairs stop at the empty line of R2
+    mixed = b"".join(l.encode("latin-1") + qr.choice([b"\n", b"\r\n", b"\r", b"\n", b"\r\n"]) for r in base for l in r)
+    C["se_mixed_line_ends"] = dict(fq1=mixed, paired=SE)
+    C["se_leading_newline"] = dict(fq1=b"\n" + fastq(base), paired=SE)                                                   # empty name line at offset 0: nothing is read
+    C["se_blank_line_inside_record"] = dict(fq1=fastq(base[:5]) + base[5][0].encode() + b"\n\n" + base[5][1].encode() + b"\n+\n" + base[5][3].encode() + b"\n" + fastq(base[6:]), paired=SE)
+    bigrng = random.Random(99)
+    bigrecs = [rec(illumina(i, tile=1101 + i // 4000), rseq(bigrng, 40), rqual(bigrng, 40)) for i in range(9000)]
+
+    def shifted(eol, want_pos, term):
+        """CRLF/LF text of bigrecs whose first `term` byte at or after `want_pos` is moved exactly onto `want_pos` by padding read 0's name."""
+        txt = fastq(bigrecs, eol=eol)
+        p0 = txt.index(term, want_pos - 120)
+        pad = want_pos - p0
+        while pad < 0:
+            p0 = txt.index(term, p0 - 200 if p0 > 200 else 0); pad = want_pos - p0    # (not reached: lines are < 120 bytes)
+        recs = [rec(bigrecs[0][0] + "P" * pad, bigrecs[0][1], bigrecs[0][3])] + bigrecs[1:]
+        out = fastq(recs, eol=eol)
+        assert out[want_pos:want_pos + len(term)] == term, (out[want_pos - 2:want_pos + 3], pad)
+        return out
+    MiB = 1 << 20
+    C["se_crlf_cr_is_last_byte_of_block"] = dict(fq1=shifted("\r\n", MiB - 1, b"\r\n"), paired=SE, k=100)     # '\n' opens the next block: empty line, reader stops
+    C["se_crlf_cr_is_second_last_byte_of_block"] = dict(fq1=shifted("\r\n", MiB - 2, b"\r\n"), paired=SE, k=100)   # '\n' is the block's last byte: not swallowed
+    C["se_crlf_cr_is_third_last_byte_of_block"] = dict(fq1=shifted("\r\n", MiB - 3, b"\r\n"), paired=SE, k=100)   # ordinary "\r\n": whole file, 4 chunks
+    lf = shifted("\n", MiB - 1, b"\n")
+    C["se_blank_line_at_block_edge"] = dict(fq1=lf[:MiB] + b"\n" + lf[MiB:], paired=SE, k=100)               # "\n\n" split by the block edge: the second one is an empty line
+    lf2 = fastq(bigrecs)
+    cut = lf2.index(b"\n@", 600000) + 1
+    C["se_three_newlines_mid_file"] = dict(fq1=lf2[:cut] + b"\n\n" + lf2[cut:], paired=SE, k=100)            # chunks before the empty line + a truncated tail chunk
     C["se_partial_last_record"] = dict(fq1=fastq(base) + b"@partial\nACGT\n", paired=SE)
     C["se_single_read"] = dict(fq1=fastq(base[:1]), paired=SE)
     r2 = [rec(illumina(i, mate=2), rseq(rng, 40), rqual(rng, 40)) for i in range(30)]

@@ -33,6 +33,20 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     j = json.loads(r.stdout)
     assert j["result"] == "passed" and j["fastq_reads"] == reads_se and j["rfq_reads"] == reads_se and j["fastq_bases"] == reads_se * 150
     assert json.loads((tmp_path / "cmp.json").read_text()) == j
+    # reader quirks through the batching loop (consumed offsets map back through the normalised text): CRLF line ends, and an
+    # empty line mid-file after which nothing is read (src/fastqreader.cpp:94-196)
+    crlf = fq1.replace(b"\n", b"\r\n")
+    pc = tmp_path / "crlf.fq"; pc.write_bytes(crlf)
+    r = _run(binary, ["-c", "-i", str(pc), "-o", str(out), "-k", "100", "--batch_mb", str(batch_mb)])
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == O.encode_file(crlf, b"", O.SE, 100_000)
+    cut = fq1.index(b"\n@", len(fq1) * 2 // 3) + 1
+    stop = fq1[:cut] + b"\n\n" + fq1[cut:]
+    ps = tmp_path / "stop.fq"; ps.write_bytes(stop)
+    r = _run(binary, ["-c", "-i", str(ps), "-o", str(out), "-k", "100", "--batch_mb", str(batch_mb)])
+    assert r.returncode == 0, r.stderr
+    want = O.encode_file(stop, b"", O.SE, 100_000)
+    assert out.read_bytes() == want and len(want) < len(O.encode_file(fq1, b"", O.SE, 100_000))
     # PE: -i/-I -> one .rfq, -o/-O back
     a, b = O.gen(O.NOVA_PE150, pairs, seed=42)
     pa, pb = tmp_path / "r1.fq", tmp_path / "r2.fq"; pa.write_bytes(a); pb.write_bytes(b)

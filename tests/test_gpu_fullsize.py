@@ -1,0 +1,57 @@
+"""BASELINE.json configs[2] at full size on one GPU: PE150 2 x 4 GB (`-i/-I`), encode + decode round trip.
+The oracle cannot cover 8 GB in test time, so parity at this size rests on size-independent properties:
+  * the image's leading chunks are byte-identical to the oracle's encoding of the matching file prefix (chunks are
+    independent once the header exists),
+  * chunk / read / base counts follow the cut rule in closed form (uniform 150 bp reads: 3,334 pairs per chunk),
+  * decode(encode(x)) == x for both mates, compared on the device."""
+import hashlib
+import os
+
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+PAIRS = int(os.environ.get("RFQ_FULLSIZE_PAIRS", "11200000"))      # 2 x 4.0 GB; each stream must stay < 4 GiB per batch
+
+
+def test_cfg2_pe150_2x4GB_round_trip():
+    import torch
+    from repaq_amd import RfqCodec, PE_TWO_FILES
+    a1, a2 = O.gen_np(O.NOVA_PE150, PAIRS, seed=3)
+    n1, n2 = int(a1.size), int(a2.size)
+    assert n1 < 0xFFFFFFF0 and n2 < 0xFFFFFFF0
+    t1 = torch.from_numpy(a1).cuda(); t2 = torch.from_numpy(a2).cuda()
+    codec = RfqCodec(device=0)
+    r = codec.encode(t1.data_ptr(), n1, t2.data_ptr(), n2, PE_TWO_FILES, chunk_bases=1_000_000)
+    per = 3334                                                       # pairs per chunk: first count with 300 * pairs >= 1,000,000
+    assert r.n_reads == 2 * PAIRS and r.n_bases == 300 * PAIRS and r.n_chunks == (PAIRS + per - 1) // per
+    assert r.consumed1 == n1 and r.consumed2 == n2 and not r.input_ended
+    assert 0.08 < r.rfq_len / (n1 + n2) < 0.2
+    # leading chunks == oracle on the file prefix that ends on a chunk boundary
+    lead = 24
+    cut1 = _offset_of_record(a1, lead * per); cut2 = _offset_of_record(a2, lead * per)
+    want = O.encode_file(a1[:cut1].tobytes(), a2[:cut2].tobytes(), O.PE_TWO_FILES, 1_000_000)
+    off = r.h_chunk_off[lead]
+    assert off == len(want)
+    got = codec.dev_get(r.d_rfq, off)
+    assert hashlib.md5(got).hexdigest() == hashlib.md5(want).hexdigest()
+    # round trip into caller buffers, compared in HBM
+    o1 = torch.empty(n1 + 64, dtype=torch.uint8, device="cuda"); o2 = torch.empty(n2 + 64, dtype=torch.uint8, device="cuda")
+    d = codec.decode(r.d_rfq, r.rfq_len, split_pe=True, d_out1=o1.data_ptr(), cap1=n1 + 64, d_out2=o2.data_ptr(), cap2=n2 + 64)
+    assert d.n1 == n1 and d.n2 == n2 and d.n_reads == 2 * PAIRS
+    assert torch.equal(o1[:n1], t1) and torch.equal(o2[:n2], t2)
+    codec.close()
+
+
+def _offset_of_record(arr, rec):
+    """Byte offset of record `rec` in a '\\n'-terminated FASTQ held in a numpy array (4 lines per record)."""
+    import numpy as np
+    want = 4 * rec
+    # walk in slabs: count newlines until the wanted one
+    pos, seen, slab = 0, 0, 1 << 26
+    while True:
+        nl = np.flatnonzero(arr[pos:pos + slab] == 10)
+        if seen + nl.size >= want:
+            return pos + int(nl[want - seen - 1]) + 1
+        seen += nl.size; pos += slab
