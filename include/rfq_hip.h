@@ -130,6 +130,10 @@ int rfq_dev_malloc(rfq_ctx* ctx, void** d_ptr, size_t n);
 int rfq_dev_free(rfq_ctx* ctx, void* d_ptr);
 int rfq_copy_h2d(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n);
 int rfq_copy_d2h(rfq_ctx* ctx, void* h_dst, const void* d_src, size_t n);
+int rfq_copy_d2d(rfq_ctx* ctx, void* d_dst, const void* d_src, size_t n);
+/* page-locked host buffers (hipHostMalloc): H2D / D2H copies from them run at full PCIe rate */
+int rfq_host_alloc(rfq_ctx* ctx, void** h_ptr, size_t n);
+int rfq_host_free(rfq_ctx* ctx, void* h_ptr);
 
 /* library / build info: "rfq_hip <version> gfx950" (or "... simt-emulation" for the test build) */
 const char* rfq_version(void);

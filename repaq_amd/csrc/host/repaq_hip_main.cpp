@@ -1,14 +1,26 @@
 // repaq_hip — host driver with repaq's command line (src/main.cpp:29-51, README.md:136-161) over the C-ABI of
 // include/rfq_hip.h.  It is the counterpart of Repaq::compress / compressPE / decompress / decompressPE / compare*
-// (src/repaq.cpp): file I/O, batching with carry-over, header-once, line-break thresholds, PE even/odd outputs and the
-// compare JSON live here; every byte of codec work happens on the GPU.  Not supported in this build (refused loudly):
-// .gz text and the .xz wrapper (external zlib / xz, out of scope per SURVEY.md §2).
+// (src/repaq.cpp): stream I/O, batching with carry-over, header-once, line-break thresholds, PE even/odd outputs and the
+// compare JSON live here; every byte of codec work happens on the GPU (there is no CPU codec in this binary).
+//
+// I/O pipeline: a reader thread per input fills page-locked blocks two blocks ahead (plain files, stdin,
+// .gz through zlib like src/fastqreader.cpp:31-37, .xz through an `xz -d -c` pipe like src/main.cpp:160-177), the main thread
+// moves blocks to HBM and runs the codec, a writer thread per output drains page-locked result buffers in order (plain,
+// stdout, .gz through zlib like src/writer.cpp:39-51, .rfq.xz through an `xz -z -c` pipe like src/main.cpp:134-159).
+// Inputs and outputs of any size stream through: nothing is slurped, one batch is < 4 GiB per stream.
 #include "rfq_hip.h"
+#include <zlib.h>
+#include <sys/stat.h>
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 static void error_exit(const std::string& msg) { fprintf(stderr, "ERROR: %s\n", msg.c_str()); exit(-1); }   // src/util.h:246-249
@@ -17,155 +29,363 @@ static bool ends_with(const std::string& s, const std::string& e) { return s.siz
 struct Options {
     std::string in1, out1, in2, out2, rfqCompare, json;
     long chunkKb = 1000; bool compress = false, decompress = false, compare = false, useStdin = false, useStdout = false, interleaved = false;
-    int device = 0; size_t batchBytes = (size_t)1 << 30;
+    int device = 0; size_t batchBytes = (size_t)256 << 20; int threads = 1, compression = 3;
 };
 
-static bool read_all(const std::string& path, std::vector<uint8_t>& out) {
-    FILE* f = path == "/dev/stdin" ? stdin : fopen(path.c_str(), "rb");
-    if (!f) return false;
-    out.clear(); std::vector<uint8_t> buf(1 << 22); size_t n;
-    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) out.insert(out.end(), buf.begin(), buf.begin() + n);
-    if (f != stdin) fclose(f);
-    return true;
-}
-static void write_all(const std::string& path, const uint8_t* p, size_t n, bool append) {
-    FILE* f = path == "/dev/stdout" ? stdout : fopen(path.c_str(), append ? "ab" : "wb");
-    if (!f) error_exit("Failed to open file for writing: " + path);
-    if (n && fwrite(p, 1, n, f) != n) error_exit("Failed to write: " + path);
-    if (f != stdout) fclose(f); else fflush(stdout);
-}
-static uint64_t nolb_threshold(const std::vector<uint8_t>& v) {   // SURVEY.md App. C Q10, src/fastqreader.cpp:31-46
-    if (v.empty() || v.back() == '\n') return UINT64_MAX;
-    if (v.size() % ((size_t)1 << 20) == 0) return 0;
-    return ((uint64_t)(v.size() - 1) >> 20) << 20;
-}
+// ------------------------------------------------------------------------------------------------ byte sources / sinks
+struct ByteSource {                      // sequential bytes of a plain file, stdin, a .gz (zlib) or a .xz (xz -d -c pipe)
+    FILE* f = nullptr; gzFile gz = nullptr; bool piped = false; std::string path;
+    bool open(const std::string& p) {
+        path = p;
+        if (ends_with(p, ".gz")) { gz = gzopen(p.c_str(), "rb"); if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr; }
+        if (ends_with(p, ".xz")) { f = popen(("xz -d -c '" + p + "'").c_str(), "r"); piped = true; return f != nullptr; }
+        f = p == "/dev/stdin" ? stdin : fopen(p.c_str(), "rb");
+        return f != nullptr;
+    }
+    size_t read(uint8_t* dst, size_t cap) {          // fills `cap` unless the stream ends
+        size_t got = 0;
+        while (got < cap) {
+            long n;
+            if (gz) { n = gzread(gz, dst + got, (unsigned)std::min<size_t>(cap - got, 1u << 30)); if (n < 0) error_exit("Error to read gzip file"); }
+            else n = (long)fread(dst + got, 1, cap - got, f);
+            if (n <= 0) break;
+            got += (size_t)n;
+        }
+        return got;
+    }
+    void close() {
+        if (gz) gzclose(gz);
+        else if (piped) { if (f && pclose(f) != 0) error_exit("failed to call xz, please confirm that xz is installed in your system"); }
+        else if (f && f != stdin) fclose(f);
+        gz = nullptr; f = nullptr;
+    }
+};
+struct ByteSink {
+    FILE* f = nullptr; gzFile gz = nullptr; bool piped = false; std::string path;
+    void open(const std::string& p, const Options& o) {
+        path = p;
+        if (ends_with(p, ".gz")) {                                          // src/writer.cpp:39-44
+            gz = gzopen(p.c_str(), "wb"); if (!gz) error_exit("Failed to open file for writing: " + p);
+            gzsetparams(gz, o.compression, Z_DEFAULT_STRATEGY); gzbuffer(gz, 1024 * 1024); return;
+        }
+        if (ends_with(p, ".xz")) {                                          // src/main.cpp:134-159
+            std::string cmd = "xz -z -c";
+            if (o.threads > 1) cmd += " -T" + std::to_string(o.threads);
+            if (o.compression <= 4) cmd += " -" + std::to_string(o.compression + 5);
+            else { unsigned long dict = (64ul * 1024 * 1024) << (o.compression - 4); if (o.compression == 9) dict = 1536ul * 1024 * 1024; cmd += " --lzma2=\"dict=" + std::to_string(dict) + "\""; }
+            if (o.compression >= 4 && o.threads > 1) fprintf(stderr, "WARNING: when repaq compression level is >= 4, only single thread will be used for xz. Your options: compression = %d, thread = %d\n", o.compression, o.threads);
+            cmd += " > '" + p + "'";
+            f = popen(cmd.c_str(), "w"); piped = true;
+            if (!f) error_exit("failed to call xz, please confirm that xz is installed in your system");
+            return;
+        }
+        f = p == "/dev/stdout" ? stdout : fopen(p.c_str(), "wb");
+        if (!f) error_exit("Failed to open file for writing: " + p);
+    }
+    void write(const uint8_t* p, size_t n) {
+        while (n) {
+            const size_t k = std::min<size_t>(n, 1u << 30);
+            if (gz) { if (gzwrite(gz, p, (unsigned)k) != (int)k) error_exit("Failed to write: " + path); }
+            else if (fwrite(p, 1, k, f) != k) error_exit("Failed to write: " + path);
+            p += k; n -= k;
+        }
+    }
+    void close() {
+        if (gz) { gzflush(gz, Z_FINISH); gzclose(gz); }
+        else if (piped) { if (f && pclose(f) != 0) error_exit("failed to call xz, please confirm that xz is installed in your system"); }
+        else if (f == stdout) fflush(stdout);
+        else if (f) fclose(f);
+        gz = nullptr; f = nullptr;
+    }
+};
+
 struct Gpu {
     rfq_ctx* c = nullptr;
     explicit Gpu(int dev) { if (rfq_create(&c, dev) != RFQ_OK) error_exit("no usable MI355X / HIP device (repaq_hip has no CPU fallback)"); }
     ~Gpu() { rfq_destroy(c); }
     void check(int rc) { if (rc != RFQ_OK) error_exit(rfq_last_error(c)); }
-    void* put(const uint8_t* p, size_t n) { void* d = nullptr; check(rfq_dev_malloc(c, &d, n + 64)); check(rfq_copy_h2d(c, d, p, n)); return d; }
+    void* dev(size_t n) { void* d = nullptr; check(rfq_dev_malloc(c, &d, n + 64)); return d; }
+    uint8_t* pinned(size_t n) { void* h = nullptr; check(rfq_host_alloc(c, &h, n + 64)); return (uint8_t*)h; }
 };
 
-// Repaq::compress / compressPE (src/repaq.cpp:530-762): batches of whole lines, carry the unconsumed tail forward.
+// Reader thread: page-locked blocks of `block` bytes, read two blocks ahead so that the end of the input is known when the
+// block before the last two is handed out (the line-break thresholds and `final` need it).
+struct Block { uint8_t* p = nullptr; size_t n = 0; };
+class Prefetcher {
+    ByteSource src; Gpu& g; size_t block; std::thread th; std::mutex mu; std::condition_variable cv;
+    std::deque<Block> ready; std::vector<uint8_t*> freeb; bool eof = false; uint64_t total = 0; int last_byte = -1;
+    void run() {
+        for (;;) {
+            uint8_t* buf;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !freeb.empty(); }); buf = freeb.back(); freeb.pop_back(); }
+            const size_t n = src.read(buf, block);
+            std::unique_lock<std::mutex> lk(mu);
+            if (n) { total += n; last_byte = buf[n - 1]; ready.push_back(Block{ buf, n }); } else freeb.push_back(buf);
+            if (n < block) { eof = true; cv.notify_all(); return; }
+            cv.notify_all();
+        }
+    }
+public:
+    Prefetcher(Gpu& gpu, const std::string& path, size_t block_bytes) : g(gpu), block(block_bytes) {
+        if (!src.open(path)) error_exit("Failed to open file: " + path);
+        struct stat st;                                                     // small regular files: no point in pinning 4 x batch
+        if (!ends_with(path, ".gz") && !ends_with(path, ".xz") && path != "/dev/stdin" && stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode))
+            block = std::min(block, std::max<size_t>((size_t)st.st_size + 1, (size_t)1 << 20));
+        for (int i = 0; i < 4; i++) freeb.push_back(g.pinned(block));
+        th = std::thread([this] { run(); });
+    }
+    ~Prefetcher() { if (th.joinable()) th.join(); src.close(); }
+    // next block; false when the input is exhausted.  After it returns, end_known() tells whether the reader has seen the end
+    // of the input; if not, at least two more full blocks follow the one just returned.
+    bool next(Block& b) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return ready.size() >= 3 || eof; });
+        if (ready.empty()) return false;
+        b = ready.front(); ready.pop_front();
+        return true;
+    }
+    void release(const Block& b) { std::unique_lock<std::mutex> lk(mu); freeb.push_back(b.p); cv.notify_all(); }
+    bool end_known() { std::unique_lock<std::mutex> lk(mu); return eof; }
+    bool drained() { std::unique_lock<std::mutex> lk(mu); return eof && ready.empty(); }
+    uint64_t total_bytes() { std::unique_lock<std::mutex> lk(mu); return total; }
+    int final_byte() { std::unique_lock<std::mutex> lk(mu); return last_byte; }
+};
+
+// Writer thread: ordered queue of page-locked result buffers
+class AsyncWriter {
+    ByteSink sink; Gpu& g; std::thread th; std::mutex mu; std::condition_variable cv;
+    struct Item { uint8_t* p; size_t n, cap; }; std::deque<Item> q; std::vector<Item> pool; bool done = false; int in_flight = 0;
+    void run() {
+        for (;;) {
+            Item it;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !q.empty() || done; }); if (q.empty()) return; it = q.front(); q.pop_front(); }
+            sink.write(it.p, it.n);
+            std::unique_lock<std::mutex> lk(mu); pool.push_back(it); in_flight--; cv.notify_all();
+        }
+    }
+public:
+    AsyncWriter(Gpu& gpu, const std::string& path, const Options& o) : g(gpu) { sink.open(path, o); th = std::thread([this] { run(); }); }
+    // a page-locked buffer of >= n bytes (at most three in flight); fill it, then submit()
+    uint8_t* acquire(size_t n, size_t& cap) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return in_flight < 3; });
+        in_flight++;
+        for (size_t i = 0; i < pool.size(); i++) if (pool[i].cap >= n) { Item it = pool[i]; pool.erase(pool.begin() + i); cap = it.cap; return it.p; }
+        uint8_t* stale = nullptr; if (!pool.empty()) { stale = pool.back().p; pool.pop_back(); }
+        lk.unlock();
+        if (stale) rfq_host_free(g.c, stale);
+        cap = n + n / 4 + 4096; return g.pinned(cap);
+    }
+    void submit(uint8_t* p, size_t n, size_t cap) { std::unique_lock<std::mutex> lk(mu); q.push_back(Item{ p, n, cap }); cv.notify_all(); }
+    void finish() { { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_all(); } if (th.joinable()) th.join(); sink.close(); }
+    ~AsyncWriter() { if (th.joinable()) finish(); }
+};
+
+// Device text of one input stream: [carry of the previous batch | newly copied block(s)], 16-byte aligned at its base
+struct DevStream {
+    void* d[2] = { nullptr, nullptr }; size_t cap[2] = { 0, 0 }; int cur = 0; size_t have = 0; uint64_t file_off = 0; bool ended = false;
+    uint8_t* base() const { return (uint8_t*)d[cur]; }
+    // drop the first `consumed` bytes: the tail moves to the front of the other buffer (device-to-device)
+    void advance(Gpu& g, size_t consumed, size_t room) {
+        const size_t carry = have - consumed; const int nx = cur ^ 1;
+        if (cap[nx] < carry + room) { if (d[nx]) rfq_dev_free(g.c, d[nx]); cap[nx] = carry + room + (carry + room) / 8; d[nx] = g.dev(cap[nx]); }
+        if (carry) g.check(rfq_copy_d2d(g.c, d[nx], (uint8_t*)d[cur] + consumed, carry));
+        cur = nx; have = carry; file_off += consumed;
+    }
+    void append(Gpu& g, const Block& b) {
+        if (cap[cur] < have + b.n) {                                          // grow (first block, or the streams of a pair drift apart)
+            const size_t nc = have + b.n + (have + b.n) / 8; void* nd = g.dev(nc);
+            if (have) g.check(rfq_copy_d2d(g.c, nd, d[cur], have));
+            if (d[cur]) rfq_dev_free(g.c, d[cur]);
+            d[cur] = nd; cap[cur] = nc;
+        }
+        g.check(rfq_copy_h2d(g.c, (uint8_t*)d[cur] + have, b.p, b.n)); have += b.n;
+    }
+    void free_all(Gpu& g) { for (int i = 0; i < 2; i++) if (d[i]) rfq_dev_free(g.c, d[i]); }
+};
+
+// Repaq::compress / compressPE (src/repaq.cpp:530-762)
 static void do_compress(const Options& o) {
-    std::vector<uint8_t> t1, t2;
-    if (!read_all(o.in1, t1)) error_exit("Failed to open file: " + o.in1);
     const bool two = !o.in2.empty();
-    if (two && !read_all(o.in2, t2)) error_exit("Failed to open file: " + o.in2);
     const int paired = two ? RFQ_PE_TWO_FILES : (o.interleaved ? RFQ_PE_INTERLEAVED : RFQ_SE);
     Gpu g(o.device);
-    const uint64_t th1 = nolb_threshold(t1), th2 = two ? nolb_threshold(t2) : th1;
-    size_t p1 = 0, p2 = 0; bool first = true, wrote = false;
+    const size_t block = std::max<size_t>(o.batchBytes, (size_t)1 << 20);       // >= the reader's 1 MiB block: see nolb below
+    Prefetcher* in[2] = { new Prefetcher(g, o.in1, block), two ? new Prefetcher(g, o.in2, block) : nullptr };
+    AsyncWriter out(g, o.out1, o);
+    DevStream ds[2]; const int ns = two ? 2 : 1;
+    bool first = true; size_t want = block;                                    // bytes a stream should hold before a batch is tried
     for (;;) {
-        size_t e1 = std::min(t1.size(), p1 + o.batchBytes), e2 = two ? std::min(t2.size(), p2 + o.batchBytes) : 0;
-        const bool final = e1 == t1.size() && (!two || e2 == t2.size());
-        // the two streams must advance by the same number of records: the device pairs record i with record i and reports
-        // consumed bytes per stream, so any surplus on one side is simply carried over.
-        void* d1 = g.put(t1.data() + p1, e1 - p1); void* d2 = two ? g.put(t2.data() + p2, e2 - p2) : nullptr;
+        for (int s = 0; s < ns; s++) {
+            while (!ds[s].ended && ds[s].have < want) {
+                Block b; if (!in[s]->next(b)) { ds[s].ended = true; break; }
+                if (ds[s].have + b.n >= 0xFFFFFFF0ull) error_exit("a batch of one FASTQ stream must stay below 4 GiB (chunk larger than that, or paired files of very different length)");
+                ds[s].append(g, b); in[s]->release(b);
+                if (in[s]->drained()) ds[s].ended = true;
+            }
+        }
+        const bool final = ds[0].ended && (!two || ds[1].ended);
         rfq_encode_args a; memset(&a, 0, sizeof a);
-        a.d_fq1 = (const uint8_t*)d1; a.n1 = e1 - p1; a.d_fq2 = (const uint8_t*)d2; a.n2 = two ? e2 - p2 : 0; a.paired = paired;
+        a.d_fq1 = ds[0].base(); a.n1 = ds[0].have; a.d_fq2 = two ? ds[1].base() : nullptr; a.n2 = two ? ds[1].have : 0; a.paired = paired;
         a.chunk_bases = (uint32_t)(std::max(100L, o.chunkKb) * 1000); a.final = final ? 1 : 0; a.emit_header = first ? 1 : 0;
-        a.file_off1 = p1; a.file_off2 = p2; a.nolb_from1 = th1; a.nolb_from2 = th2;
+        a.file_off1 = ds[0].file_off; a.file_off2 = ds[1].file_off;
+        // FastqReader::hasNoLineBreakAtEnd (src/fastqreader.cpp:31-46): known once the reader thread has seen
+        // the end of the input; until then at least two full blocks (>= 2 MiB) follow this batch, so no chunk of it can reach the
+        // reader's final 1 MiB block
+        uint64_t th[2] = { UINT64_MAX, UINT64_MAX };
+        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t && in[s]->final_byte() != '\n') th[s] = ((t - 1) >> 20) << 20; }
+        a.nolb_from1 = th[0]; a.nolb_from2 = two ? th[1] : th[0];
         rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
         if (r.rfq_len) {
-            std::vector<uint8_t> img(r.rfq_len); g.check(rfq_copy_d2h(g.c, img.data(), r.d_rfq, r.rfq_len));
-            write_all(o.out1, img.data(), img.size(), wrote); wrote = true;
+            size_t cap; uint8_t* h = out.acquire(r.rfq_len, cap);
+            g.check(rfq_copy_d2h(g.c, h, r.d_rfq, r.rfq_len)); out.submit(h, r.rfq_len, cap);
             if (r.n_chunks) first = false;
         }
-        rfq_dev_free(g.c, d1); if (d2) rfq_dev_free(g.c, d2);
-        if (final || r.input_ended) break;          // input_ended: the reader stopped at an empty line (src/fastqreader.cpp:180-191)
-        if (r.consumed1 == 0 && (!two || r.consumed2 == 0)) {
-            // not a single full chunk in this batch: grow it (a chunk can be larger than the batch)
-            const_cast<Options&>(o).batchBytes *= 2; continue;
-        }
-        p1 += r.consumed1; p2 += r.consumed2;
+        if (final || r.input_ended) break;            // input_ended: the reader stopped at an empty line (src/fastqreader.cpp:180-191)
+        if (r.consumed1 == 0 && (!two || r.consumed2 == 0)) { want = std::max(ds[0].have, ds[1].have) + block; continue; }   // a chunk larger than the batch: read on
+        ds[0].advance(g, r.consumed1, block); if (two) ds[1].advance(g, r.consumed2, block);
+        want = block;
     }
-    if (!wrote) write_all(o.out1, nullptr, 0, false);   // empty input -> empty output, like the reference
+    out.finish();                                      // (an input without reads leaves an empty output, like the reference)
+    for (int s = 0; s < ns; s++) { ds[s].free_all(g); delete in[s]; }
 }
 
-struct Decoded { std::vector<uint8_t> a, b; uint64_t reads = 0, bases = 0; };
-static Decoded decode_file(Gpu& g, const std::string& path, bool split) {
-    std::vector<uint8_t> img; if (!read_all(path, img)) error_exit("Failed to open file: " + path);
-    void* d = g.put(img.data(), img.size());
-    rfq_decode_args a; memset(&a, 0, sizeof a);
-    a.d_rfq = (const uint8_t*)d; a.n = img.size(); a.has_header = 1; a.split_pe = split ? 1 : 0; a.final = 1;
-    rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
-    Decoded out; out.reads = r.n_reads; out.bases = r.n_bases;
-    out.a.resize(r.n1); if (r.n1) g.check(rfq_copy_d2h(g.c, out.a.data(), r.d_fq1, r.n1));
-    out.b.resize(r.n2); if (r.n2) g.check(rfq_copy_d2h(g.c, out.b.data(), r.d_fq2, r.n2));
-    rfq_dev_free(g.c, d);
-    return out;
+// Streaming decoder: .rfq blocks -> rfq_decode_batch over whole chunks -> device text handed to `emit_dev(out1, n1, out2, n2)`
+struct DecodeTotals { uint64_t reads = 0, bases = 0; };
+static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& path, bool split,
+                                  const std::function<void(const uint8_t*, size_t, const uint8_t*, size_t)>& emit_dev) {
+    // ~1/8 of the text batch: .rfq is 7-25 % of its FASTQ, so one call stays far below the 4 GiB-per-call text limit
+    const size_t block = std::max<size_t>(o.batchBytes / 8, (size_t)1 << 16);
+    Prefetcher in(g, path, block);
+    DevStream ds; bool first = true; size_t want = block; DecodeTotals tot;
+    for (;;) {
+        while (!ds.ended && ds.have < want) {
+            Block b; if (!in.next(b)) { ds.ended = true; break; }
+            ds.append(g, b); in.release(b);
+            if (in.drained()) ds.ended = true;
+        }
+        rfq_decode_args a; memset(&a, 0, sizeof a);
+        a.d_rfq = ds.base(); a.n = ds.have; a.has_header = first ? 1 : 0; a.split_pe = split ? 1 : 0; a.final = ds.ended ? 1 : 0;
+        rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
+        first = false;
+        tot.reads += r.n_reads; tot.bases += r.n_bases;
+        if (r.n1 || r.n2) emit_dev(r.d_fq1, r.n1, r.d_fq2, r.n2);
+        if (ds.ended) break;
+        if (r.consumed == 0) { want = ds.have + block; continue; }            // not one whole chunk yet
+        ds.advance(g, r.consumed, block); want = block;
+    }
+    ds.free_all(g);
+    return tot;
 }
 // Repaq::decompress / decompressPE (src/repaq.cpp:262-417)
 static void do_decompress(const Options& o) {
     Gpu g(o.device);
     const bool split = !o.out2.empty();
-    Decoded d = decode_file(g, o.in1, split);
-    write_all(o.out1, d.a.data(), d.a.size(), false);
-    if (split) write_all(o.out2, d.b.data(), d.b.size(), false);
+    AsyncWriter w1(g, o.out1, o); AsyncWriter* w2 = split ? new AsyncWriter(g, o.out2, o) : nullptr;
+    decode_stream(g, o, o.in1, split, [&](const uint8_t* d1, size_t n1, const uint8_t* d2, size_t n2) {
+        if (n1) { size_t cap; uint8_t* h = w1.acquire(n1, cap); g.check(rfq_copy_d2h(g.c, h, d1, n1)); w1.submit(h, n1, cap); }
+        if (split && n2) { size_t cap; uint8_t* h = w2->acquire(n2, cap); g.check(rfq_copy_d2h(g.c, h, d2, n2)); w2->submit(h, n2, cap); }
+    });
+    w1.finish(); if (w2) { w2->finish(); delete w2; }
 }
 
 // ---- compare mode (src/repaq.cpp:36-259): decode on the GPU, compare read by read with the FASTQ text, same JSON
 struct Rec { std::string f[4]; };
-static bool next_rec(const std::vector<uint8_t>& t, size_t& pos, Rec& r) {
-    for (int k = 0; k < 4; k++) {
-        if (pos >= t.size()) return false;
-        size_t e = pos; while (e < t.size() && t[e] != '\n' && t[e] != '\r') e++;
-        r.f[k].assign((const char*)t.data() + pos, e - pos);
-        if (e < t.size() && t[e] == '\r' && e + 1 < t.size() && t[e + 1] == '\n') e++;
-        pos = e + 1;
-        if (r.f[k].empty()) return false;
+struct TextCursor {                      // growing text + a refill callback; records are cut with FastqReader's line rules
+    std::vector<uint8_t> t; size_t pos = 0; bool ended = false; std::function<void(TextCursor&)> refill;
+    void compact() { if (pos > (1u << 24)) { t.erase(t.begin(), t.begin() + pos); pos = 0; } }
+    bool next(Rec& r) {
+        for (;;) {
+            size_t p = pos; int k = 0; bool need = false;
+            for (; k < 4; k++) {
+                if (p >= t.size()) { need = !ended; break; }
+                size_t e = p; while (e < t.size() && t[e] != '\n' && t[e] != '\r') e++;
+                if (e + 1 >= t.size() && !ended) { need = true; break; }      // the line (or its "\r\n") may continue in the next refill
+                r.f[k].assign((const char*)t.data() + p, e - p);
+                if (e < t.size() && t[e] == '\r' && e + 1 < t.size() && t[e + 1] == '\n') e++;
+                p = e + 1;
+                if (r.f[k].empty()) return false;
+            }
+            if (k == 4) { pos = p; return true; }
+            if (!need) return false;
+            compact(); refill(*this);
+        }
     }
-    return true;
-}
+};
 static void report(const Options& o, bool passed, const std::string& msg, long fqReads, long fqBases, long rfqReads, long rfqBases) {   // :235-259
     std::string j = "{\n";
     j += passed ? "\t\"result\":\"passed\",\n" : "\t\"result\":\"failed\",\n";
     j += "\t\"msg\":\"" + msg + "\",\n";
     j += "\t\"fastq_reads\":" + std::to_string(fqReads) + ",\n\t\"rfq_reads\":" + std::to_string(rfqReads) + ",\n";
     j += "\t\"fastq_bases\":" + std::to_string(fqBases) + ",\n\t\"rfq_bases\":" + std::to_string(rfqBases) + "\n}\n";
-    if (!o.json.empty()) write_all(o.json, (const uint8_t*)j.data(), j.size(), false);
-    fputs(j.c_str(), stdout);
+    if (!o.json.empty()) { FILE* f = fopen(o.json.c_str(), "wb"); if (!f) error_exit("Failed to open file for writing: " + o.json); fwrite(j.data(), 1, j.size(), f); fclose(f); }
+    fputs(j.c_str(), stdout); fflush(stdout);
 }
 static void do_compare(const Options& o) {
     Gpu g(o.device);
     const bool pe = !o.in2.empty();
-    Decoded d = decode_file(g, o.rfqCompare, pe);
-    std::vector<uint8_t> f1, f2;
-    if (!read_all(o.in1, f1)) error_exit("Failed to open file: " + o.in1);
-    if (pe && !read_all(o.in2, f2)) error_exit("Failed to open file: " + o.in2);
-    // decoded text always ends lines with '\n'; restore a dropped final newline so the record splitter sees whole records
-    size_t pa = 0, pb = 0, qa = 0, qb = 0; long fqReads = 0, fqBases = 0, rfqReads = 0, rfqBases = 0;
+    // decoded side: a producer thread decodes batch after batch into two bounded text queues
+    struct Q { std::mutex mu; std::condition_variable cv; std::deque<std::vector<uint8_t>> q; bool done = false, discard = false; } dq[2];
+    std::thread producer([&] {
+        decode_stream(g, o, o.rfqCompare, pe, [&](const uint8_t* d1, size_t n1, const uint8_t* d2, size_t n2) {
+            const uint8_t* dp[2] = { d1, d2 }; const size_t dn[2] = { n1, pe ? n2 : 0 };
+            for (int s = 0; s < 2; s++) if (dn[s]) {
+                { std::unique_lock<std::mutex> lk(dq[s].mu); if (dq[s].discard) continue; }
+                std::vector<uint8_t> v(dn[s]); g.check(rfq_copy_d2h(g.c, v.data(), dp[s], dn[s]));
+                std::unique_lock<std::mutex> lk(dq[s].mu); dq[s].cv.wait(lk, [&] { return dq[s].q.size() < 4 || dq[s].discard; });
+                if (!dq[s].discard) dq[s].q.push_back(std::move(v));
+                dq[s].cv.notify_all();
+            }
+        });
+        for (int s = 0; s < 2; s++) { std::unique_lock<std::mutex> lk(dq[s].mu); dq[s].done = true; dq[s].cv.notify_all(); }
+    });
+    TextCursor dec[2], fq[2]; ByteSource src[2];
+    for (int s = 0; s < 2; s++) dec[s].refill = [&dq, s](TextCursor& c) {
+        std::unique_lock<std::mutex> lk(dq[s].mu); dq[s].cv.wait(lk, [&] { return !dq[s].q.empty() || dq[s].done; });
+        if (dq[s].q.empty()) { c.ended = true; return; }
+        c.t.insert(c.t.end(), dq[s].q.front().begin(), dq[s].q.front().end()); dq[s].q.pop_front(); dq[s].cv.notify_all();
+    };
+    if (!src[0].open(o.in1)) error_exit("Failed to open file: " + o.in1);
+    if (pe && !src[1].open(o.in2)) error_exit("Failed to open file: " + o.in2);
+    for (int s = 0; s < (pe ? 2 : 1); s++) fq[s].refill = [&src, s](TextCursor& c) {
+        const size_t old = c.t.size(), want = (size_t)8 << 20; c.t.resize(old + want);
+        const size_t n = src[s].read(c.t.data() + old, want); c.t.resize(old + n); if (n < want) c.ended = true;
+    };
+    long fqReads = 0, fqBases = 0, rfqReads = 0, rfqBases = 0; bool reported = false;
     static const char* what[4] = { "name", "sequence", "strand", "quality" };
     for (;;) {
         Rec r; const bool second = pe && (rfqReads & 1);
-        if (!next_rec(second ? d.b : d.a, second ? pb : pa, r)) break;
+        if (!dec[second ? 1 : 0].next(r)) break;
         rfqReads++; rfqBases += (long)r.f[1].size();
         Rec q;
-        if (!next_rec(second ? f2 : f1, second ? qb : qa, q)) {
+        if (!fq[second ? 1 : 0].next(q)) {
             report(o, false, "The RFQ file has more reads than the FASTQ file. The RFQ file has >= " + std::to_string(rfqReads) + " reads, while the FASTQ file only has " + std::to_string(fqReads) + " reads", fqReads, fqBases, rfqReads, rfqBases);
-            return;
+            reported = true; break;
         }
         fqReads++; fqBases += (long)q.f[1].size();
-        for (int k = 0; k < 4; k++) if (r.f[k] != q.f[k]) {
+        for (int k = 0; k < 4 && !reported; k++) if (r.f[k] != q.f[k]) {
             report(o, false, std::string("The RFQ file and FASTQ file have different ") + what[k] + " in the " + std::to_string(rfqReads) + " read. " + r.f[k] + " | " + q.f[k], fqReads, fqBases, rfqReads, rfqBases);
-            return;
+            reported = true;
         }
+        if (reported) break;
     }
-    Rec q;
-    if (next_rec(f1, qa, q) || (pe && next_rec(f2, qb, q))) {
-        fqReads++;
-        report(o, false, "The FASTQ file has more reads than the RFQ file. The FASTQ file has >= " + std::to_string(fqReads) + " reads, while the RFQ file only has " + std::to_string(rfqReads) + " reads", fqReads, fqBases, rfqReads, rfqBases);
-        return;
+    if (!reported) {
+        Rec q;
+        if (fq[0].next(q) || (pe && fq[1].next(q))) {
+            fqReads++;
+            report(o, false, "The FASTQ file has more reads than the RFQ file. The FASTQ file has >= " + std::to_string(fqReads) + " reads, while the RFQ file only has " + std::to_string(rfqReads) + " reads", fqReads, fqBases, rfqReads, rfqBases);
+        } else report(o, true, "", fqReads, fqBases, rfqReads, rfqBases);
     }
-    report(o, true, "", fqReads, fqBases, rfqReads, rfqBases);
+    // a failed compare stops consuming early: let the producer run to its end without queueing
+    for (int s = 0; s < 2; s++) { std::unique_lock<std::mutex> lk(dq[s].mu); dq[s].discard = true; dq[s].q.clear(); dq[s].cv.notify_all(); }
+    producer.join();
+    src[0].close(); if (pe) src[1].close();
 }
 
 static void usage() {
     fputs("repaq_hip: repack FASTQ to .rfq on an MI355X (repaq v0.5.1 compatible)\n"
           "usage: repaq_hip [-c|-d|-p] -i in1 [-I in2] -o out1 [-O out2] [-k chunk_kb] [--stdin] [--stdout] [--interleaved_in]\n"
-          "                 [-r rfq_to_compare] [-j json] [--device N] [--batch_mb M]\n", stderr);
+          "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N] [--batch_mb M]\n"
+          "       FASTQ may be .gz (zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
 }
 int main(int argc, char** argv) {
     if (argc == 1) { usage(); return 0; }
@@ -193,13 +413,18 @@ int main(int argc, char** argv) {
         else if (a == "--stdout") o.useStdout = true;
         else if (a == "--interleaved_in") o.interleaved = true;
         else if (a == "-v" || a == "--verify" || a == "-f" || a == "--fast_verify") {}        // the reference ignores the verify result (Q15)
-        else if (a == "-t" || a == "--thread" || a == "-z" || a == "--compression") { (void)val(i, "thread"); }   // xz only
+        else if (a == "-t" || a == "--thread" || a.rfind("--thread=", 0) == 0) o.threads = atoi(val(i, "thread").c_str());
+        else if (a == "-z" || a == "--compression" || a.rfind("--compression=", 0) == 0) o.compression = atoi(val(i, "compression").c_str());
         else if (a == "--device") o.device = atoi(val(i, "device").c_str());
         else if (a == "--batch_mb") o.batchBytes = (size_t)atol(val(i, "batch_mb").c_str()) << 20;
         else { usage(); error_exit("unknown option: " + a); }
     }
     if ((int)o.compress + (int)o.decompress + (int)o.compare > 1) error_exit("repaq can run in compress/decompress/compare mode, you can only choose any one mode.");
     const bool dec = o.decompress, cmp = o.compare, enc = !dec && !cmp;
+    // src/main.cpp:100-113: STDIN / STDOUT override the file names
+    if (enc && o.useStdout && !o.out1.empty()) { fprintf(stderr, "Output to STDOUT, ignore --out1 = %s\n", o.out1.c_str()); o.out1.clear(); }
+    if (dec && o.useStdin && !o.in1.empty()) { fprintf(stderr, "Input from STDIN, ignore --in1 = %s\n", o.in1.c_str()); o.in1.clear(); }
+    if (cmp && o.useStdin && !o.rfqCompare.empty()) { fprintf(stderr, "Input from STDIN, ignore --rfq_to_compare = %s\n", o.rfqCompare.c_str()); o.rfqCompare.clear(); }
     // Options::validate (src/options.cpp:36-111)
     if (o.in1.empty()) {
         if (!o.in2.empty()) error_exit("read2 input is specified by <in2>, but read1 input is not specified by <in1>");
@@ -209,11 +434,14 @@ int main(int argc, char** argv) {
         if (!o.out2.empty()) error_exit("read2 output is specified by <out2>, but read1 output is not specified by <out1>");
         if (o.useStdout) o.out1 = "/dev/stdout"; else if (!cmp) error_exit("Please specify output file by <out1>, or enable --stdout if you want to read STDIN");
     }
-    for (const std::string* s : { &o.in1, &o.in2, &o.out1, &o.out2, &o.rfqCompare })
-        if (ends_with(*s, ".gz") || ends_with(*s, ".xz")) error_exit(".gz / .xz streams are outside this build (zlib and xz are external to the .rfq codec): " + *s);
+    if (o.compression < 1 || o.compression > 9) error_exit("compression level (-z) should be 1 ~ 9");
+    if ((ends_with(o.in1, ".xz") || ends_with(o.rfqCompare, ".xz")) && o.useStdin) error_exit("STDIN cannot be read when the input is a .xz file");   // src/main.cpp:123-131
+    if (ends_with(o.out1, ".xz") && o.useStdout) error_exit("STDOUT cannot be written when the output is a .xz file");
     const long cb = std::max(100L, o.chunkKb) * 1000;
     if (cb < 10000) error_exit("chunk size cannot be less than 10 kb");
     if (cb > 500000000) error_exit("chunk size cannot be greater than 500,000 kb");
+    if (o.batchBytes < ((size_t)1 << 20)) o.batchBytes = (size_t)1 << 20;
+    if (o.batchBytes > ((size_t)2 << 30)) o.batchBytes = (size_t)2 << 30;
     if (enc) {
         if (!o.out2.empty()) error_exit("In compress mode, only one RFQ output file is allowed, but you specified <out2>");
         if (ends_with(o.out1, ".fq") || ends_with(o.out1, ".fastq")) error_exit("In compress mode, the output should not be a FASTQ file. Expect a .rfq or .rfq.xz file, but got " + o.out1);

@@ -88,6 +88,19 @@ extern "C" int rfq_copy_h2d(rfq_ctx* c, void* d, const void* h, size_t n) {
     if (n) { HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return RFQ_OK;
 }
+extern "C" int rfq_copy_d2d(rfq_ctx* c, void* dst, const void* src, size_t n) {
+    if (!c) return RFQ_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) { HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    return RFQ_OK;
+}
+extern "C" int rfq_host_alloc(rfq_ctx* c, void** p, size_t n) {
+    if (!c || !p) return RFQ_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostMalloc(p, n ? n : 256, 0));
+    return RFQ_OK;
+}
+extern "C" int rfq_host_free(rfq_ctx* c, void* p) { if (!c) return RFQ_E_ARG; if (p) HIPCHK(c, hipHostFree(p)); return RFQ_OK; }
 extern "C" int rfq_copy_d2h(rfq_ctx* c, void* h, const void* d, size_t n) {
     if (!c) return RFQ_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));

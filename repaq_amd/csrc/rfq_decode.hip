@@ -54,7 +54,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
         HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
         if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
-        else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
+        else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
         KCHK(ctx, "k_dec_walk");
         HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
         HIPCHK(ctx, hipStreamSynchronize(S));
@@ -123,7 +123,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     // ---- text
     ctx->timer.begin("textlen", S);
     const int split = a->split_pe ? 1 : 0;
-    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split);
+    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
     scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
     U4 tt;
     HIPCHK(ctx, hipMemcpyAsync(&tt, R.tp + n_reads, 16, hipMemcpyDeviceToHost, S));
@@ -131,6 +131,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     HIPCHK(ctx, hipStreamSynchronize(S));
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
     // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
+    if (hs.text1 >= 0xFFFFFFF0ull || hs.text2 >= 0xFFFFFFF0ull)
+        return rfq_fail(ctx, RFQ_E_ARG, "one decode call must emit < 4 GiB of text per output stream (this image holds %llu / %llu bytes); pass fewer chunks per call", (unsigned long long)hs.text1, (unsigned long long)hs.text2);
     uint8_t *o1, *o2; uint64_t cap1, cap2;
     if ((a->d_out1 && ((uintptr_t)a->d_out1 & 15u)) || (a->d_out2 && ((uintptr_t)a->d_out2 & 15u))) return rfq_fail(ctx, RFQ_E_ARG, "output device pointers must be 16-byte aligned");
     if (a->d_out1) { o1 = a->d_out1; cap1 = a->cap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }

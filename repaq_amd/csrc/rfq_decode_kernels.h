@@ -70,14 +70,14 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
     return 0;
 }
 // One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays; the reader ignores mSize).
-__global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st) {
+__global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st, int final) {
     const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
     uint64_t k = start; uint32_t c = 0, maxr = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
     if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
     while (!err) {
         DChunk d; const int rc = parse_chunk(img, n, k, hf, rlb, d);
         if (rc == 1) break;
-        if (rc == 2) { err = DE_CORRUPT; break; }
+        if (rc == 2) { if (final) err = DE_CORRUPT; break; }            // not final: the chunk continues in the caller's next batch
         d.rbase = (uint32_t)rb;
         if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
         if (d.reads > maxr) maxr = d.reads;
@@ -332,10 +332,8 @@ __device__ __forceinline__ DName dec_name_parts(const uint8_t* cp, const DChunk&
     return m;
 }
 // text bytes of every read; tin[g] = (bytes into out1, bytes into out2, 0, 0)
-__global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
-                              const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, int split) {
-    const DChunk d = CH[blockIdx.y]; const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= d.reads) return;
+__device__ __forceinline__ uint32_t dec_textlen_one(const uint8_t* __restrict__ img, const DChunk& d, const DevHeader* __restrict__ D, const DReadTab& R,
+                                                    const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, int split, uint32_t r, bool& second) {
     const uint8_t* cp = img + d.off; const uint32_t g = d.rbase + r, hf = D->flags;
     const DName m = dec_name_parts(cp, d, D, xv, yv, r);
     uint8_t buf[36]; uint32_t k = 0;                                 // ":255:65535:4294967295:4294967295" is 32 bytes
@@ -348,8 +346,20 @@ __global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __r
     mp[39] = (uint8_t)k;
     const uint32_t nl = m.n1 + m.n2 + k;
     const uint32_t len = R.len[g]; const uint32_t text = nl + 1 + len + 1 + m.st + 1 + len + 1;
-    U4 t; t.a = (split && (r & 1u)) ? 0u : text; t.b = (split && (r & 1u)) ? text : 0u; t.c = 0; t.d = 0;
+    second = split && (r & 1u);
+    U4 t; t.a = second ? 0u : text; t.b = second ? text : 0u; t.c = 0; t.d = 0;
     R.tin[g] = t;
+    return text;
+}
+__global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                              const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, int split, DecStatus* st) {
+    const DChunk d = CH[blockIdx.y]; const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= d.reads) return;                  // block-uniform
+    uint32_t text = 0; bool second = false;
+    if (r < d.reads) text = dec_textlen_one(img, d, D, R, xv, yv, split, r, second);
+    // 64-bit totals: the per-read prefix sums that place the text are 32-bit, the host refuses a batch that would wrap them
+    const unsigned long long s1 = wave_sum<unsigned long long>(second ? 0ull : (unsigned long long)text), s2 = wave_sum<unsigned long long>(second ? (unsigned long long)text : 0ull);
+    if (lane_id() == 0) { if (s1) atomicAdd((unsigned long long*)&st->text1, s1); if (s2) atomicAdd((unsigned long long*)&st->text2, s2); }
 }
 // ---- text emission (name re-assembly src/rfqcodec.cpp:1157-1231, overlap re-expansion :865-897, implied N :1093-1100, RC of odd
 // reads :1248-1252, Read::toString src/read.cpp:170).

@@ -51,3 +51,29 @@ def check_case(codec, name, case, golden):
     if "rfq_hex" in golden:
         assert got.hex() == golden["rfq_hex"]
     return got
+
+
+def decode_in_slices(codec, rfq: bytes, split_pe: bool, step: int):
+    """Feed an image `step` bytes at a time (has_header on the first call, final on the last, unconsumed tail carried over): the
+    streaming contract of rfq_decode_batch that the C++ driver relies on."""
+    out1, out2 = bytearray(), bytearray()
+    pos, end, first = 0, min(step, len(rfq)), True
+    while True:
+        final = end == len(rfq)
+        buf = rfq[pos:end]
+        d = codec.dev_put(buf)
+        try:
+            r = codec.decode(d, len(buf), has_header=first, split_pe=split_pe, final=final)
+            if r.n1:
+                out1 += codec.dev_get(r.d_fq1, r.n1)
+            if split_pe and r.n2:
+                out2 += codec.dev_get(r.d_fq2, r.n2)
+            consumed = r.consumed
+        finally:
+            codec.dev_free(d)
+        first = False
+        if final:
+            break
+        pos += consumed
+        end = min(len(rfq), max(end, pos) + step)
+    return (bytes(out1), bytes(out2)) if split_pe else bytes(out1)

@@ -57,6 +57,35 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     o1, o2 = tmp_path / "o1.fq", tmp_path / "o2.fq"
     assert _run(binary, ["-d", "-i", str(pe), "-o", str(o1), "-O", str(o2)]).returncode == 0
     assert (o1.read_bytes(), o2.read_bytes()) == (a, b)
+    # .gz text in and out (zlib, src/fastqreader.cpp:31-37, src/writer.cpp:39-51), the .rfq.xz wrapper (external xz, src/main.cpp:134-177),
+    # --stdin / --stdout, and interleaved text for a PE image decoded to STDOUT
+    import gzip
+    import shutil
+    pg = tmp_path / "a.fq.gz"; pg.write_bytes(gzip.compress(fq1, 1))
+    og = tmp_path / "ag.rfq"
+    assert _run(binary, ["-c", "-i", str(pg), "-o", str(og), "-k", "100", "--batch_mb", str(batch_mb)]).returncode == 0
+    assert og.read_bytes() == O.encode_file(fq1, b"", O.SE, 100_000)
+    bg = tmp_path / "back.fq.gz"
+    assert _run(binary, ["-d", "-i", str(og), "-o", str(bg), "--batch_mb", str(batch_mb)]).returncode == 0
+    assert gzip.decompress(bg.read_bytes()) == fq1
+    if shutil.which("xz"):
+        ox = tmp_path / "a.rfq.xz"
+        r = _run(binary, ["-c", "-i", str(p), "-o", str(ox), "-k", "100", "-z", "1", "--batch_mb", str(batch_mb)])
+        assert r.returncode == 0, r.stderr
+        assert subprocess.run(["xz", "-d", "-c", str(ox)], capture_output=True, check=True).stdout == og.read_bytes()
+        bx = tmp_path / "backx.fq"
+        assert _run(binary, ["-d", "-i", str(ox), "-o", str(bx), "--batch_mb", str(batch_mb)]).returncode == 0
+        assert bx.read_bytes() == fq1
+    r = _run(binary, ["-c", "--stdin", "--stdout", "-k", "100", "--batch_mb", str(batch_mb)], input=fq1)
+    assert r.returncode == 0 and r.stdout == og.read_bytes(), r.stderr
+    r = _run(binary, ["-d", "--stdin", "--stdout", "--batch_mb", str(batch_mb)], input=og.read_bytes())
+    assert r.returncode == 0 and r.stdout == fq1, r.stderr
+    r = _run(binary, ["-d", "-i", str(pe), "--stdout", "--batch_mb", str(batch_mb)])
+    assert r.returncode == 0 and r.stdout == O.decode_file(pe.read_bytes(), False)
+    # an empty input leaves an empty .rfq, which decodes to an empty FASTQ (RfqHeader defaults, src/rfqheader.cpp:7-17)
+    pz = tmp_path / "empty.fq"; pz.write_bytes(b""); oz = tmp_path / "empty.rfq"; bz = tmp_path / "empty_back.fq"
+    assert _run(binary, ["-c", "-i", str(pz), "-o", str(oz)]).returncode == 0 and oz.read_bytes() == b""
+    assert _run(binary, ["-d", "-i", str(oz), "-o", str(bz)]).returncode == 0 and bz.read_bytes() == b""
     # a corrupted base makes --compare fail with the reference's message shape
     bad = bytearray(a); k = bad.index(b"\n") + 5; bad[k] = ord("A") if bad[k] != ord("A") else ord("C")
     pbad = tmp_path / "r1_bad.fq"; pbad.write_bytes(bytes(bad))

@@ -72,3 +72,14 @@ def test_decode_truncated_image_fails_cleanly(codec):
     rfq = O.encode_file(CASES["pe_overlap_sweep"]["fq1"], CASES["pe_overlap_sweep"]["fq2"], O.PE_TWO_FILES)
     with pytest.raises(RfqError):
         codec.decode_bytes(rfq[: len(rfq) - 7], split_pe=True)
+
+
+@pytest.mark.parametrize("step", [700, 5000, 60000])
+def test_decode_in_slices_equals_one_shot(codec, step):
+    """rfq_decode_batch on successive byte ranges (a chunk cut by the range end is carried into the next call)."""
+    fq1, fq2 = O.gen(O.NOVA_PE150, 400, seed=71, nonl=2)
+    rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 20000)
+    assert E.decode_in_slices(codec, rfq, True, step) == (fq1, fq2)
+    se, _ = O.gen(O.SE_VAR, 500, seed=72, nonl=1)
+    rfq = O.encode_file(se, b"", O.SE, 15000)
+    assert E.decode_in_slices(codec, rfq, False, step) == se
