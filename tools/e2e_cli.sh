@@ -1,0 +1,13 @@
+set -e
+cd $GRAFT_REPO_ROOT
+D=/dev/shm/e2e; mkdir -p $D
+./tools/fqgen --profile 0 --reads 11200000 --seed 5 -o $D/a.fq
+ls -l $D/a.fq | awk '{print "fastq bytes", $5}'
+B=repaq_amd/bin/repaq_hip
+for i in 1 2; do TIMEFORMAT="compress wall %R s"; time $B -c -i $D/a.fq -o $D/a.rfq; done
+ls -l $D/a.rfq | awk '{print "rfq bytes", $5}'
+for i in 1 2; do TIMEFORMAT="decompress wall %R s"; time $B -d -i $D/a.rfq -o $D/b.fq; done
+cmp $D/a.fq $D/b.fq && echo ROUNDTRIP_OK
+TIMEFORMAT="compare wall %R s"; time $B -p -i $D/a.fq -r $D/a.rfq | head -3
+TIMEFORMAT="compress 64MB batches wall %R s"; time $B -c -i $D/a.fq -o $D/a2.rfq --batch_mb 64; cmp $D/a.rfq $D/a2.rfq && echo BATCH_INDEPENDENT_OK
+rm -rf $D
