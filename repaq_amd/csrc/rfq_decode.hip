@@ -11,7 +11,7 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 64, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_END
+    DB_CHUNKS = 64, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_END
 };
 static_assert(DB_END <= 96, "rfq_ctx::b too small");
 
@@ -67,6 +67,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, hipMemcpyAsync(&h2, dst, sizeof h2, hipMemcpyDeviceToHost, S));
             HIPCHK(ctx, hipStreamSynchronize(S));
             if (h2.pad) { speculate = false; continue; }                   // an extent did not verify: foreign writer or corrupt image
+            hs.max_stream = h2.max_stream;
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
         break;
@@ -114,7 +115,18 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     hipLaunchKernelGGL(k_dec_fill, dim3(2048), dim3(256), 0, S, qdec, (uint64_t)qbytes, D);
     const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
     hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec);
-    hipLaunchKernelGGL(k_dec_pos, dim3(MAX_STREAMS, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec, dst);
+    if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
+        // position streams in POS_SEG-byte segments: summary -> link -> emit (see rfq_decode_kernels.h)
+        const uint32_t nstr = HH.n_normal + 1, maxseg = hs.max_stream / POS_SEG + 1; const size_t nseg = (size_t)n_chunks * nstr * maxseg;
+        HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 16 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure((size_t)n_chunks * nstr * 4 + 16));
+        HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16));
+        hipLaunchKernelGGL(k_dec_pos_sum, dim3(maxseg, nstr, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+                           B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), maxseg, dst, (uint64_t)a->n);
+        hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, S, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
+                           (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
+        hipLaunchKernelGGL(k_dec_pos_emit, dim3(maxseg, nstr, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+                           (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n);
+    }
     hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
     hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
     KCHK(ctx, "k_dec_streams");
@@ -131,6 +143,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     HIPCHK(ctx, hipStreamSynchronize(S));
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
     // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
+    hs.text1 = hs.text2 = 0; for (int i = 0; i < 64; i++) { hs.text1 += hs.text_slots[0][i]; hs.text2 += hs.text_slots[1][i]; }
     if (hs.text1 >= 0xFFFFFFF0ull || hs.text2 >= 0xFFFFFFF0ull)
         return rfq_fail(ctx, RFQ_E_ARG, "one decode call must emit < 4 GiB of text per output stream (this image holds %llu / %llu bytes); pass fewer chunks per call", (unsigned long long)hs.text1, (unsigned long long)hs.text2);
     uint8_t *o1, *o2; uint64_t cap1, cap2;
@@ -141,11 +154,11 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     ctx->timer.begin("emit", S);                                       // k_dec_emit alone: the path's largest kernel (bench.py roofline)
     {
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
-        static const uint32_t etpb = getenv("RFQ_EMIT_TPB") ? (uint32_t)atoi(getenv("RFQ_EMIT_TPB")) : 256u;
+        const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
         if (tune) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
         hipLaunchKernelGGL(k_dec_emit, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
                            (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
-        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
+        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu (wave0 own %llu, setup %llu) flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[6]/h[5], h[7]/h[5], h[4]/h[5]); }
         KCHK(ctx, "k_dec_emit");
     }
     ctx->timer.end(S);

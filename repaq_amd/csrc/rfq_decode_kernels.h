@@ -22,6 +22,8 @@ struct DecStatus {
     uint32_t err, n_chunks, max_reads, overflow;
     uint64_t total_reads, consumed, total_bases, total_stored, text1, text2;
     uint32_t last_flags, pad;
+    uint32_t max_stream, pad2;       // largest quality / N-position section of any chunk (bounds the position streams)
+    uint64_t text_slots[2][64];      // partial sums of the text bytes per output stream (k_dec_textlen)
 };
 
 // sum of n bytes by one wave (wave-uniform result)
@@ -72,7 +74,7 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
 // One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays; the reader ignores mSize).
 __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st, int final) {
     const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
-    uint64_t k = start; uint32_t c = 0, maxr = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
+    uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
     if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
     while (!err) {
         DChunk d; const int rc = parse_chunk(img, n, k, hf, rlb, d);
@@ -81,10 +83,11 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
         d.rbase = (uint32_t)rb;
         if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
         if (d.reads > maxr) maxr = d.reads;
+        if (d.qual_size > maxs) maxs = d.qual_size; if (d.npos_size > maxs) maxs = d.npos_size;
         lastfl = d.flags; rb += d.reads; k += d.total; c++;
         if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
     }
-    if (l == 0) { st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; }
+    if (l == 0) { st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; }
 }
 // Speculative walk: images written by repaq (or this engine) carry mSize = true size - Delta(flags) (the accounting bug Q1 is a
 // pure function of the header and chunk flags), so the chain needs ONE dependent 10-byte read per chunk instead of a full parse.
@@ -118,7 +121,7 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
     d.rbase = rbase;
-    if (lane_id() == 0) CH[c] = d;
+    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size > d.npos_size ? d.qual_size : d.npos_size); }
 }
 
 struct DReadTab {
@@ -200,36 +203,89 @@ __device__ __forceinline__ uint32_t wave_token_states(uint32_t tok_len, bool val
 // A step covers 256 stream bytes, 4 consecutive bytes per lane: the lane composes its 4 transition tables locally, ONE wave
 // scan gives the automaton state in front of every lane, ONE sum-scan the position in front of it.
 __device__ __forceinline__ uint32_t pos_tok_len(uint32_t b0) { return (b0 & 0x80u) == 0 ? 1u : ((b0 & 0x40u) == 0 ? 2u : ((b0 & 0x20u) == 0 ? 1u : 4u)); }
-__device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, uint32_t slen, uint8_t q, uint8_t* __restrict__ out, uint32_t out_len) {
-    const int l = lane_id(); uint32_t carry = 0; int last = -1;            // positions < 2^31 (see the encoder)
-    const uint32_t ID = 0u | (1u << 2) | (2u << 4) | (3u << 6);
-    for (uint32_t base = 0; base < slen; base += 256) {
+// aligned word at p, or its readable bytes when it straddles `lim` (the end of the image): no read ever leaves the caller's buffer
+__device__ __forceinline__ uint32_t ld_word_lim(const uint8_t* p, const uint8_t* lim) {
+    if (p + 4 <= lim) return *(const uint32_t*)p;
+    uint32_t v = 0; for (int k = 0; k < 4; k++) if (p + k < lim) v |= (uint32_t)p[k] << (8 * k);
+    return v;
+}
+// the 8 stream bytes from i0 on (bytes at or past slen read as 0): three aligned words + funnel shifts
+struct PosStep { uint32_t w0, w1, w2; };
+__device__ __forceinline__ PosStep pos_fetch(const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0, const uint8_t* lim) {
+    PosStep r; r.w0 = r.w1 = r.w2 = 0;
+    if (i0 < slen) {
+        const uint8_t* p = (const uint8_t*)((uintptr_t)(sp + i0) & ~(uintptr_t)3);
+        r.w0 = ld_word_lim(p, lim); r.w1 = ld_word_lim(p + 4, lim); r.w2 = ld_word_lim(p + 8, lim);
+    }
+    return r;
+}
+__device__ __forceinline__ unsigned long long pos_bytes8(const PosStep& r, const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0) {
+    if (i0 >= slen) return 0ull;
+    const uint32_t sh = (uint32_t)((uintptr_t)(sp + i0) & 3u) * 8u;
+    const uint32_t lo = (uint32_t)((((unsigned long long)r.w1 << 32) | r.w0) >> sh), hi = (uint32_t)((((unsigned long long)r.w2 << 32) | r.w1) >> sh);
+    unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    const uint32_t nv = slen - i0;                                           // valid bytes from i0
+    if (nv < 8) v &= (1ull << (8 * nv)) - 1ull;
+    return v;
+}
+// One step = 256 stream bytes, 4 per lane.  pos_front: the lane's bytes, their transition tables and Fin = the composed table of all
+// bytes of the step up to and including the lane's (one wave scan).
+struct PosFront { unsigned long long v; uint32_t bt[4], fn[4], Fin; };
+#define POS_ID (0u | (1u << 2) | (2u << 4) | (3u << 6))
+__device__ __forceinline__ PosFront pos_front(const PosStep& w, const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0, int l) {
+    PosFront f; f.v = pos_bytes8(w, sp, slen, i0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const bool valid = i0 + (uint32_t)k < slen; f.bt[k] = (uint32_t)(f.v >> (8 * k)) & 0xFFu; f.fn[k] = valid ? ((pos_tok_len(f.bt[k]) - 1u) | (0u << 2) | (1u << 4) | (2u << 6)) : POS_ID; }
+    uint32_t F = fn_compose(fn_compose(fn_compose(f.fn[0], f.fn[1]), f.fn[2]), f.fn[3]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(F, (unsigned)d); if (l >= d) F = fn_compose(t, F); }
+    f.Fin = F;
+    return f;
+}
+// positions covered by the tokens that START in the lane's 4 bytes when the automaton enters them in state st
+__device__ __forceinline__ int pos_lane_adv(const PosFront& f, uint32_t slen, uint32_t i0, uint32_t st) {
+    int a = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b0 = f.bt[k]; const bool valid = i0 + (uint32_t)k < slen;
+        const uint32_t b1 = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2 = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3 = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
+        if (valid && st == 0) {
+            if ((b0 & 0x80u) == 0) a += (int)b0 + 1;
+            else if ((b0 & 0x40u) == 0) a += (int)(((b0 & 0x3Fu) << 8) | b1) + 1;
+            else if ((b0 & 0x20u) == 0) a += (int)(b0 & 0x1Fu) + 1;
+            else a += (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
+        }
+        if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
+    }
+    return a;
+}
+// decodeSingleQualByCol over the stream bytes [b0, b1) entered in automaton state `carry` with `last` = last position covered so far
+__device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, uint32_t slen, uint32_t b0_, uint32_t b1_, uint32_t carry, int last,
+                                                uint8_t q, uint8_t* __restrict__ out, uint32_t out_len, const uint8_t* lim) {
+    const int l = lane_id();                                                 // positions < 2^31 (see the encoder)
+    PosStep nxt = pos_fetch(sp, slen, b0_ + 4u * (uint32_t)l, lim);
+    for (uint32_t base = b0_; base < b1_; base += 256) {
         const uint32_t i0 = base + 4u * (uint32_t)l;
-        uint32_t bt[4], fn[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)k; const bool valid = i < slen; bt[k] = valid ? sp[i] : 0u; fn[k] = valid ? ((pos_tok_len(bt[k]) - 1u) | (0u << 2) | (1u << 4) | (2u << 6)) : ID; }
-        uint32_t F = fn_compose(fn_compose(fn_compose(fn[0], fn[1]), fn[2]), fn[3]);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(F, (unsigned)d); if (l >= d) F = fn_compose(t, F); }
-        const uint32_t after = (F >> (2 * carry)) & 3u;                      // state after my 4 bytes
+        const PosStep cur = nxt;
+        if (base + 256 < b1_) nxt = pos_fetch(sp, slen, i0 + 256u, lim);    // the next step's words are in flight while this one is decoded
+        const PosFront f = pos_front(cur, sp, slen, i0, l);
+        const uint32_t after = (f.Fin >> (2 * carry)) & 3u;                  // state after my 4 bytes
         uint32_t st = __shfl_up(after, 1u); if (l == 0) st = carry;         // state in front of my first byte
         carry = __shfl(after, 63);
         int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t i = i0 + (uint32_t)k, b0 = bt[k]; const bool valid = i < slen;
+            const uint32_t b0 = f.bt[k]; const bool valid = i0 + (uint32_t)k < slen;
+            const uint32_t b1 = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2 = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3 = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
             start[k] = valid && st == 0; adv[k] = 0; run[k] = 0;
             if (start[k]) {
                 if ((b0 & 0x80u) == 0) adv[k] = (int)b0 + 1;
-                else if ((b0 & 0x40u) == 0) adv[k] = (int)(((b0 & 0x3Fu) << 8) | (i + 1 < slen ? sp[i + 1] : 0u)) + 1;
+                else if ((b0 & 0x40u) == 0) adv[k] = (int)(((b0 & 0x3Fu) << 8) | b1) + 1;
                 else if ((b0 & 0x20u) == 0) { run[k] = (b0 & 0x1Fu) + 1; adv[k] = (int)run[k]; }
-                else {
-                    const uint32_t b1 = i + 1 < slen ? sp[i + 1] : 0u, b2 = i + 2 < slen ? sp[i + 2] : 0u, b3 = i + 3 < slen ? sp[i + 3] : 0u;
-                    adv[k] = (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
-                }
+                else adv[k] = (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
             }
             lane_adv += adv[k];
-            if (valid) st = (fn[k] >> (2 * st)) & 3u;
+            if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
         }
         const int incl = wave_incl_sum(lane_adv);
         int end = last + incl - lane_adv;                                    // last covered position in front of my tokens
@@ -243,23 +299,81 @@ __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, 
         last += __shfl(incl, 63);
     }
 }
-// grid (MAX_STREAMS, n_chunks): normal quality streams -> qdec, N positions -> sdec
-__global__ void k_dec_pos(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
-                          const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ qdec, uint8_t* __restrict__ sdec, DecStatus* st) {
-    const uint32_t j = blockIdx.x, c = blockIdx.y, nn = D->n_normal, hf = D->flags;
-    const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint32_t f = d.rbase;
-    if (j == NPOS_SLOT) {
-        if (!(hf & H_N_POS)) return;
-        wave_pos_decode(cp + d.o_npos, d.npos_size, (uint8_t)'N', sdec + sbase[c], R.pv[f + d.reads].d - R.pv[f].d);
-        return;
+// A position stream is decoded in SEGMENTS of POS_SEG bytes by independent waves (a serial walk of a 50 KB stream is ~200 dependent
+// steps): k_dec_pos_sum reduces every segment to (transition table, positions covered per entry state), k_dec_pos_link walks those
+// summaries (one thread per stream), k_dec_pos_emit decodes every segment from its now-known entry state and position.
+#define POS_SEG 2048u
+struct PosStream { const uint8_t* sp; uint32_t slen; uint8_t q; uint8_t* out; uint32_t out_len; };
+// stream jj of chunk c: jj < nn = quality value stream, jj == nn = N positions.  slen = 0 when absent; corrupt length tables are flagged.
+__device__ __forceinline__ PosStream pos_stream_of(const uint8_t* __restrict__ img, const DChunk& d, const DevHeader* __restrict__ D, const DReadTab& R, uint32_t c,
+                                                   const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase, uint8_t* qdec, uint8_t* sdec, uint32_t jj, DecStatus* st) {
+    PosStream s; s.sp = nullptr; s.slen = 0; s.q = 0; s.out = nullptr; s.out_len = 0;
+    const uint32_t nn = D->n_normal, hf = D->flags, f = d.rbase; const uint8_t* cp = img + d.off;
+    if (jj == nn) {
+        if (!(hf & H_N_POS)) return s;
+        s.sp = cp + d.o_npos; s.slen = d.npos_size; s.q = (uint8_t)'N'; s.out = sdec + sbase[c]; s.out_len = R.pv[f + d.reads].d - R.pv[f].d;
+        return s;
     }
-    if (j >= nn || j >= NPOS_SLOT || (hf & H_DONT_QUAL) || !(hf & H_QUAL_BY_COL)) return;
-    if (4ull * nn > d.qual_size) { if (lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return; }
+    if (jj > nn || jj >= NPOS_SLOT || (hf & H_DONT_QUAL) || !(hf & H_QUAL_BY_COL)) return s;
+    if (4ull * nn > d.qual_size) { if (st && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return s; }
     const uint8_t* qp = cp + d.o_qual; uint64_t off = 4ull * nn;
-    for (uint32_t i = 0; i < j; i++) off += ld_u32(qp + 4 * i);
-    const uint32_t sl = ld_u32(qp + 4 * j);
-    if (off + sl > d.qual_size) { if (lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return; }
-    wave_pos_decode(qp + off, sl, D->normal[j], qdec + qbase[c], R.pq[f + d.reads] - R.pq[f]);
+    for (uint32_t i = 0; i < jj; i++) off += ld_u32(qp + 4 * i);
+    const uint32_t sl = ld_u32(qp + 4 * jj);
+    if (off + sl > d.qual_size) { if (st && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return s; }
+    s.sp = qp + off; s.slen = sl; s.q = D->normal[jj]; s.out = qdec + qbase[c]; s.out_len = R.pq[f + d.reads] - R.pq[f];
+    return s;
+}
+// grid (maxseg, nn + 1, n_chunks), one wave per segment
+__global__ void k_dec_pos_sum(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                              const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ qdec, uint8_t* __restrict__ sdec,
+                              uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes) {
+    const uint32_t g = blockIdx.x, jj = blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
+    const DChunk d = CH[c];
+    const PosStream s = pos_stream_of(img, d, D, R, c, qbase, sbase, qdec, sdec, jj, g == 0 ? st : nullptr);
+    if (g == 0 && l == 0) segN[(size_t)c * gridDim.y + jj] = (s.slen + POS_SEG - 1) / POS_SEG;
+    const uint32_t b0 = g * POS_SEG; if (b0 >= s.slen) return;
+    const uint32_t b1 = b0 + POS_SEG < s.slen ? b0 + POS_SEG : s.slen;
+    uint32_t Fcum = POS_ID; int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    PosStep nxt = pos_fetch(s.sp, s.slen, b0 + 4u * (uint32_t)l, lim);
+    for (uint32_t base = b0; base < b1; base += 256) {
+        const uint32_t i0 = base + 4u * (uint32_t)l;
+        const PosStep cur = nxt;
+        if (base + 256 < b1) nxt = pos_fetch(s.sp, s.slen, i0 + 256u, lim);
+        const PosFront f = pos_front(cur, s.sp, s.slen, i0, l);
+        uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
+        const uint32_t G = fn_compose(Fcum, Fex);                            // segment entry state -> state in front of my bytes
+        a0 += pos_lane_adv(f, s.slen, i0, (G >> 0) & 3u); a1 += pos_lane_adv(f, s.slen, i0, (G >> 2) & 3u);
+        a2 += pos_lane_adv(f, s.slen, i0, (G >> 4) & 3u); a3 += pos_lane_adv(f, s.slen, i0, (G >> 6) & 3u);
+        Fcum = fn_compose(Fcum, __shfl(f.Fin, 63));
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if (l == 0) {
+        const size_t idx = ((size_t)c * gridDim.y + jj) * maxseg + g;
+        segF[idx] = (uint8_t)Fcum; segA[4 * idx + 0] = a0; segA[4 * idx + 1] = a1; segA[4 * idx + 2] = a2; segA[4 * idx + 3] = a3;
+    }
+}
+// one thread per (chunk, stream): entry state and entry position of every segment
+__global__ void k_dec_pos_link(const uint8_t* __restrict__ segF, const int* __restrict__ segA, const uint32_t* __restrict__ segN,
+                               uint8_t* __restrict__ segS, int* __restrict__ segP, uint32_t maxseg, uint32_t n_streams) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_streams) return;
+    const uint32_t n = segN[t]; uint32_t st = 0; int last = -1;
+    for (uint32_t g = 0; g < n; g++) {
+        const size_t idx = (size_t)t * maxseg + g;
+        segS[idx] = (uint8_t)st; segP[idx] = last;
+        last += segA[4 * idx + st]; st = ((uint32_t)segF[idx] >> (2 * st)) & 3u;
+    }
+}
+// grid (maxseg, nn + 1, n_chunks): normal quality streams -> qdec, N positions -> sdec
+__global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                               const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ qdec, uint8_t* __restrict__ sdec,
+                               const uint8_t* __restrict__ segS, const int* __restrict__ segP, uint32_t maxseg, uint64_t img_bytes) {
+    const uint32_t g = blockIdx.x, jj = blockIdx.y, c = blockIdx.z; const uint8_t* lim = img + img_bytes;
+    const DChunk d = CH[c];
+    const PosStream s = pos_stream_of(img, d, D, R, c, qbase, sbase, qdec, sdec, jj, nullptr);
+    const uint32_t b0 = g * POS_SEG; if (b0 >= s.slen) return;
+    const uint32_t b1 = b0 + POS_SEG < s.slen ? b0 + POS_SEG : s.slen;
+    const size_t idx = ((size_t)c * gridDim.y + jj) * maxseg + g;
+    wave_pos_decode(s.sp, s.slen, b0, b1, segS[idx], segP[idx], s.q, s.out, s.out_len, lim);
 }
 // exception records (q, u32 LE position) after the streams (src/rfqcodec.cpp:1034-1043); raw copy when DONT_ENCODE_QUAL (:905-910)
 __global__ void k_dec_except(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
@@ -358,8 +472,16 @@ __global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __r
     uint32_t text = 0; bool second = false;
     if (r < d.reads) text = dec_textlen_one(img, d, D, R, xv, yv, split, r, second);
     // 64-bit totals: the per-read prefix sums that place the text are 32-bit, the host refuses a batch that would wrap them
+    // (one atomic per block, spread over 64 slots: same-address atomics from every wave would serialise at ~11 ns each)
+    __shared__ unsigned long long s_t[2][4];
     const unsigned long long s1 = wave_sum<unsigned long long>(second ? 0ull : (unsigned long long)text), s2 = wave_sum<unsigned long long>(second ? (unsigned long long)text : 0ull);
-    if (lane_id() == 0) { if (s1) atomicAdd((unsigned long long*)&st->text1, s1); if (s2) atomicAdd((unsigned long long*)&st->text2, s2); }
+    if (lane_id() == 0) { s_t[0][wave_id()] = s1; s_t[1][wave_id()] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0, b = 0; for (uint32_t i = 0; i < (blockDim.x >> 6); i++) { a += s_t[0][i]; b += s_t[1][i]; }
+        const uint32_t slot = (blockIdx.y * 7u + blockIdx.x) & 63u;
+        if (a) atomicAdd((unsigned long long*)&st->text_slots[0][slot], a); if (b) atomicAdd((unsigned long long*)&st->text_slots[1][slot], b);
+    }
 }
 // ---- text emission (name re-assembly src/rfqcodec.cpp:1157-1231, overlap re-expansion :865-897, implied N :1093-1100, RC of odd
 // reads :1248-1252, Read::toString src/read.cpp:170).
@@ -460,6 +582,33 @@ __device__ __forceinline__ void piece_store(uint8_t* out, uint32_t dst, uint32_t
         for (int i = 0; i < 4; i++) if (t + i >= 0 && t + i < (int)n) o[i] = (uint8_t)(w >> (8 * i));
     }
 }
+// the same for ONE aligned 16-byte destination group (long pieces: sequence, quality): t = piece offset of the group's byte 0
+// (-15..n-1).  The staged arrays keep 16 readable bytes in front of their data, so a group that starts before the piece (or a
+// reversed one that ends before it) reads in bounds; those bytes are never stored.
+__device__ __forceinline__ void piece16_fetch(const uint8_t* base, uint32_t src, uint32_t n, int t, bool rev, uint32_t (&w)[4]) {
+    if (!rev) lds_get16(base, (uint32_t)((int)src + t), w);
+    else lds_get16_rev(base, (uint32_t)((int)src + (int)n - 1 - t), w);
+}
+__device__ __forceinline__ void piece16_store(uint8_t* out, uint32_t dst, uint32_t n, uint32_t k, int t, const uint32_t (&w)[4]) {
+    uint8_t* o = out + (dst & ~15u) + 16u * k;
+    if (t >= 0 && t + 16 <= (int)n) { *(uint4*)o = make_uint4(w[0], w[1], w[2], w[3]); return; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ti = t + 4 * i;
+        if (ti >= 0 && ti + 4 <= (int)n) *(uint32_t*)(o + 4 * i) = w[i];
+        else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (ti + b >= 0 && ti + b < (int)n) o[4 * i + b] = (uint8_t)(w[i] >> (8 * b));
+        }
+    }
+}
+// complement of four bases drawn from {A,C,G,T,N} - the only bytes the decoder itself puts into its base buffer (2-bit unpack,
+// N positions): A<->T is x ^ 0x15, C<->G is x ^ 0x04, N stays (Read::changeToReverseComplement, src/read.cpp:77-115, on that alphabet)
+__device__ __forceinline__ uint32_t comp4_acgtn(uint32_t w) {
+    const uint32_t b1 = (w >> 1) & 0x01010101u, b3 = (w >> 3) & 0x01010101u;
+    const uint32_t cg = b1 & ~b3, at = b1 ^ 0x01010101u;
+    return w ^ (cg * 0x04u + at * 0x15u);
+}
 // idx -> (j, k) with k < W: float reciprocal + one-step correction (idx < 2^20)
 __device__ __forceinline__ void item_jk(uint32_t idx, uint32_t W, float rcp, uint32_t& j, uint32_t& k) {
     j = (uint32_t)((float)idx * rcp); k = idx - j * W;
@@ -475,11 +624,25 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                            const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
                            const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, uint64_t img_bytes, int split,
                            uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st, unsigned long long* dbg) {
-    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, aS = 0;
     __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
-    __shared__ uint4 s_q4[ET_SCAP / 16 + 4], s_s4[ET_SCAP / 16 + 4], s_mid4[ET_READS * 40 / 16 + 4];
-    __shared__ uint4 s_n14[ET_N1CAP / 16 + 4], s_n24[ET_N2CAP / 16 + 4], s_st4[ET_STCAP / 16 + 4];
-    __shared__ uint32_t s_cnt; __shared__ uint32_t s_meta[(ET_READS + 1) * 16]; __shared__ uint32_t s_mx[8];   // s_mx: longest pieces among the candidates
+    // staged sources in ONE pool (a piece is addressed by a byte offset into it): qualities | stored bases | name middles | name1 | name2 |
+    // strand pieces (region starts in uint4 units)
+#define EG_Q 0
+#define EG_S (EG_Q + ET_SCAP / 16 + 4)
+#define EG_MID (EG_S + ET_SCAP / 16 + 4)
+#define EG_N1 (EG_MID + ET_READS * 40 / 16 + 4)
+#define EG_N2 (EG_N1 + ET_N1CAP / 16 + 4)
+#define EG_ST (EG_N2 + ET_N2CAP / 16 + 4)
+#define EG_END (EG_ST + ET_STCAP / 16 + 4)
+    __shared__ uint4 s_src4[EG_END];
+#define s_q4 (s_src4 + EG_Q)
+#define s_s4 (s_src4 + EG_S)
+#define s_mid4 (s_src4 + EG_MID)
+#define s_n14 (s_src4 + EG_N1)
+#define s_n24 (s_src4 + EG_N2)
+#define s_st4 (s_src4 + EG_ST)
+    __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta[(ET_READS + 1) * 16]; __shared__ uint32_t s_mx[8];   // s_mx: longest pieces among the candidates
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
     const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
@@ -493,6 +656,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
     while (cur < re) {                                                       // block-uniform
         k0 = clock64();
         // ---- phase 1: scalars of the next <= ET_READS reads (+1 end sentinel) -> LDS, one parallel round of global loads
+        // (prefetching them for the next tile into registers was tried: the extra live registers cost a resident block per CU)
         const uint32_t g0 = f + cur;
         if (tid == 0) s_cnt = 0;
         if (tid <= ET_READS && cur + tid <= re) {
@@ -522,7 +686,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         if (tid < ET_READS && cur + tid < re) {
             uint32_t mm = (tid + 2u) & ~1u; if (cur + mm > re) mm = re - cur;  // whole pairs (a lone last read of an SE chunk is fine)
             const uint32_t* me = s_meta + 16 * mm;
-            fits = (me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 32u <= ET_SCAP && (me[14] - mb[14]) + 32u <= ET_SCAP
+            fits = (me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 48u <= ET_SCAP && (me[14] - mb[14]) + 48u <= ET_SCAP
                 && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)
                 && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP);
         }
@@ -545,7 +709,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         const uint64_t sta = ib + d.o_st + a9, ste = (fl & C_STRAND_SAME) ? sta + d.st_size : ib + d.o_st + me[9];
         const bool n1l = tiled && n1e - n1a + 32 <= ET_N1CAP, n2l = tiled && n2e - n2a + 32 <= ET_N2CAP, stl_ = tiled && ste - sta + 32 <= ET_STCAP;
         {
-            const StageSpan sp[6] = { make_span(s_q4, qdec, qa, qe, qdec_bytes, tiled), make_span(s_s4, sdec, sa, se, sdec_bytes, tiled),
+            const StageSpan sp[6] = { make_span(s_q4 + 1, qdec, qa, qe, qdec_bytes, tiled), make_span(s_s4 + 1, sdec, sa, se, sdec_bytes, tiled),   // +1: 16 readable bytes in front
                                       make_span(s_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, tiled),
                                       make_span(s_n14, img, n1a, n1e, img_bytes, n1l), make_span(s_n24, img, n2a, n2e, img_bytes, n2l), make_span(s_st4, img, sta, ste, img_bytes, stl_) };
             stage_spans<6>(sp);
@@ -553,70 +717,83 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         __syncthreads();
         k3 = clock64(); a3 += k3 - k2;
         // ---- phase 4: compose the tile's text in LDS
-        const uint8_t* q_l = (const uint8_t*)s_q4 + (qa & 15ull); const uint8_t* s_l = (const uint8_t*)s_s4 + (sa & 15ull);
+        const uint8_t* q_l = (const uint8_t*)(s_q4 + 1) + (qa & 15ull); const uint8_t* s_l = (const uint8_t*)(s_s4 + 1) + (sa & 15ull);
         const uint8_t* m_l = (const uint8_t*)s_mid4 + (((uint64_t)g0 * 40) & 15ull);
         uint8_t* oA = (uint8_t*)s_out4 + (tp0.a & 15u); uint8_t* oB = (uint8_t*)s_out4 + ET_OCAP / 2 + (tp0.b & 15u);
         if (tiled && n1l && n2l && stl_) {
             // piece-parallel: for each kind of piece one flat loop over (read j, destination word k) - every thread copies whole words
             uint8_t* const out = (uint8_t*)s_out4;
-            const uint32_t qoff = (uint32_t)(qa & 15ull), soff = (uint32_t)(sa & 15ull), moff = (uint32_t)(((uint64_t)g0 * 40) & 15ull);
+            const uint32_t qoff = 16u + (uint32_t)(qa & 15ull), soff = 16u + (uint32_t)(sa & 15ull), moff = (uint32_t)(((uint64_t)g0 * 40) & 15ull);
             const uint32_t n1off = (uint32_t)(n1a & 15ull), n2off = (uint32_t)(n2a & 15ull), stoff = (uint32_t)(sta & 15ull);
             const uint32_t recA = (tp0.a & 15u) - tp0.a, recB = ET_OCAP / 2 + (tp0.b & 15u) - tp0.b;       // + at = LDS offset of a record
-#define EMIT_PIECES(WORDS, ...) { const uint32_t W_ = (WORDS); const float rcp_ = 1.0f / (float)W_; \
-            for (uint32_t idx_ = tid; idx_ < cnt * W_; idx_ += blockDim.x) { uint32_t j, k; item_jk(idx_, W_, rcp_, j, k); \
-                const uint32_t* m = s_meta + 16 * j; const bool odd = ((cur + j) & 1u) != 0; \
-                const uint32_t rec = ((split && odd) ? recB : recA) + m[0]; const uint32_t mid = m[11]; \
-                __VA_ARGS__ } }
-            EMIT_PIECES((s_mx[0] + 3) / 4 + 1, {                            // name1
-                const uint32_t n = m[4], dst = rec; const int t = (int)(4u * k) - (int)(dst & 3u);
-                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_n14, n1off + ((fl & C_NAME1_SAME) ? 0u : m[7] - a7), n, t, false));
-            })
-            EMIT_PIECES(10u, {                                               // ":lane:tile:x:y" (<= 33 bytes)
-                const uint32_t n = mid, dst = rec + m[4]; const int t = (int)(4u * k) - (int)(dst & 3u);
-                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_mid4, moff + 40u * j, n, t, false));
-            })
-            EMIT_PIECES((s_mx[1] + 3) / 4 + 1, {                            // name2 (the mate's differing character patched in)
-                const uint32_t n = m[5], dst = rec + m[4] + mid; const int t = (int)(4u * k) - (int)(dst & 3u);
-                if (t < (int)n) {
-                    uint32_t w = piece_word((const uint8_t*)s_n24, n2off + ((fl & C_NAME2_SAME) ? 0u : m[8] - a8), n, t, false);
-                    if ((fl & C_NAME2_SAME) && il && odd && dch != 0 && (int)dpos >= t && (int)dpos < t + 4) { const uint32_t sh = 8u * (uint32_t)((int)dpos - t); w = (w & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
-                    piece_store(out, dst, n, k, t, w);
+            // one thread = one PIECE of one read (8 slots x ET_READS reads; quality and sequence are cut in two halves of whole 16-byte
+            // groups): the set-up (offsets, lengths, alignment) is paid once per piece and the copy itself is a short loop over aligned
+            // 16-byte destination groups with the next group's source words already in flight
+            const uint8_t* const pool = (const uint8_t*)s_src4;
+            for (uint32_t slot = tid; slot < 8u * ET_READS; slot += blockDim.x) {
+                const uint32_t rs_ = slot;
+                const uint32_t j = rs_ % ET_READS, kind = rs_ / ET_READS;         // 0,1 quality halves; 2,3 sequence halves; 4 borrowed part; 5 name1; 6 middle + newlines; 7 name2 + strand
+                if (j >= cnt) continue;
+                const uint32_t* m = s_meta + 16 * j; const bool odd = ((cur + j) & 1u) != 0, to2 = split && odd, rc = il && odd;
+                const uint32_t rec = (to2 ? recB : recA) + m[0], len = m[1], mid = m[11];
+                if (kind == 6) {                                              // the four newlines; capacity check
+                    const uint32_t e0 = m[10] - 1, e1 = e0 + 1 + len, e2 = e1 + 1 + m[6], e3 = e2 + 1 + len;
+                    out[rec + e0] = '\n'; out[rec + e1] = '\n'; out[rec + e2] = '\n'; out[rec + e3] = '\n';
+                    if ((uint64_t)m[0] + e3 + 1 > (to2 ? cap2 : cap1)) atomicOr(&st->err, 1u << 31);
                 }
-            })
-            EMIT_PIECES((s_mx[2] + 3) / 4 + 1, {                            // strand
-                const uint32_t n = m[6], dst = rec + m[10] + m[1] + 1; const int t = (int)(4u * k) - (int)(dst & 3u);
-                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_st4, stoff + ((fl & C_STRAND_SAME) ? 0u : m[9] - a9), n, t, false));
-            })
-            EMIT_PIECES((s_mx[3] + 3) / 4 + 1, {                            // quality (back to front for an RC mate)
-                const uint32_t n = m[1], dst = rec + m[10] + n + 1 + m[6] + 1; const int t = (int)(4u * k) - (int)(dst & 3u);
-                if (t < (int)n) piece_store(out, dst, n, k, t, piece_word((const uint8_t*)s_q4, qoff + (m[15] - q0), n, t, il && odd));
-            })
-            // sequence: interleaved-orientation positions p in [0, xa) come from sA + p, p in [xa, len) from sB + (p - xa) (the part a
-            // negative overlap borrowed from the mate); an RC mate emits complemented, back to front
-#define EMIT_SEQ(WORDS, PART_B) EMIT_PIECES(WORDS, { \
-                const uint32_t len = m[1]; const int ov = (int)m[2]; const bool rc = il && odd; \
-                const uint32_t xa = ov < 0 ? len - (uint32_t)(-ov) : len; const uint32_t sp = m[14] - s0; \
-                const uint32_t n = (PART_B) ? len - xa : xa; const uint32_t p0 = (PART_B) ? xa : 0u; \
-                const uint32_t src = (PART_B) ? sp - m[3] : (ov > 0 ? sp - (uint32_t)ov : sp); \
-                const uint32_t dst = rec + m[10] + (rc ? len - p0 - n : p0); const int t = (int)(4u * k) - (int)(dst & 3u); \
-                if (t < (int)n) { \
-                    uint32_t w = piece_word((const uint8_t*)s_s4, soff + src, n, t, rc); \
-                    if (rc) w = comp4(w); \
-                    if (implied_n) { const uint32_t qw = piece_word((const uint8_t*)s_q4, qoff + (m[15] - q0) + p0, n, t, rc); \
-                                     const uint32_t mk = eq_bytes_full(qw, (nq & 0xFFu) * 0x01010101u); w = (w & ~mk) | (0x4E4E4E4Eu & mk); } \
-                    piece_store(out, dst, n, k, t, w); \
-                } })
-            EMIT_SEQ((s_mx[3] + 3) / 4 + 1, false)
-            if (s_mx[4]) EMIT_SEQ((s_mx[4] + 3) / 4 + 1, true)
-            for (uint32_t idx = tid; idx < 4 * cnt; idx += blockDim.x) {    // the four newlines; capacity check
-                const uint32_t j = idx >> 2, which = idx & 3u; const uint32_t* m = s_meta + 16 * j; const bool odd = ((cur + j) & 1u) != 0; const bool to2 = split && odd;
-                const uint32_t rec = (to2 ? recB : recA) + m[0];
-                const uint32_t e0 = m[10] - 1, e1 = e0 + 1 + m[1], e2 = e1 + 1 + m[6], e3 = e2 + 1 + m[1];
-                out[rec + (which == 0 ? e0 : which == 1 ? e1 : which == 2 ? e2 : e3)] = '\n';
-                if (which == 0 && (uint64_t)m[0] + e3 + 1 > (to2 ? cap2 : cap1)) atomicOr(&st->err, 1u << 31);
+                for (int sub = 0; sub < (kind == 7 ? 2 : 1); sub++) {         // (slot 7 copies two short pieces)
+                    uint32_t n, dst, src, qsrc = 0; bool rev = false, seq = false; int pat = -1, half = -1;   // pat: piece offset of the byte to patch (name2)
+                    const uint32_t qs = 16u * EG_Q + qoff + (m[15] - q0);
+                    if (kind <= 1) { n = len; dst = rec + m[10] + len + 1 + m[6] + 1; src = qs; rev = rc; half = (int)kind; }     // quality (back to front for an RC mate)
+                    else if (kind <= 4) {
+                        // sequence: interleaved-orientation positions p in [0, xa) come from sA + p, p in [xa, len) from sB + (p - xa) (the
+                        // part a negative overlap borrowed from the mate); an RC mate emits complemented, back to front
+                        const int ov = (int)m[2]; const uint32_t xa = ov < 0 ? len - (uint32_t)(-ov) : len; const uint32_t sp = m[14] - s0;
+                        const bool partb = kind == 4; const uint32_t p0 = partb ? xa : 0u;
+                        n = partb ? len - xa : xa;
+                        src = 16u * EG_S + soff + (partb ? sp - m[3] : (ov > 0 ? sp - (uint32_t)ov : sp));
+                        dst = rec + m[10] + (rc ? len - p0 - n : p0); rev = rc; seq = true; qsrc = qs + p0; half = partb ? -1 : (int)kind - 2;
+                    }
+                    else if (kind == 5) { n = m[4]; dst = rec; src = 16u * EG_N1 + n1off + ((fl & C_NAME1_SAME) ? 0u : m[7] - a7); }
+                    else if (kind == 6) { n = mid; dst = rec + m[4]; src = 16u * EG_MID + moff + 40u * j; }
+                    else if (sub == 0) { n = m[5]; dst = rec + m[4] + mid; src = 16u * EG_N2 + n2off + ((fl & C_NAME2_SAME) ? 0u : m[8] - a8);
+                                         if ((fl & C_NAME2_SAME) && rc && dch != 0 && dpos < n) pat = (int)dpos; }      // the mate's differing character
+                    else { n = m[6]; dst = rec + m[10] + len + 1; src = 16u * EG_ST + stoff + ((fl & C_STRAND_SAME) ? 0u : m[9] - a9); }
+                    int t = -(int)(dst & 15u), tend = (int)n;
+                    if (half >= 0) { const int groups = ((int)n - t + 15) >> 4, cut = t + 16 * ((groups + 1) >> 1); if (half == 0) tend = cut < tend ? cut : tend; else t = cut; }
+                    uint8_t* o = out + (dst & ~15u) + (uint32_t)(t + (int)(dst & 15u));
+                    const long long kA = clock64(); if (tid == 0) aS += kA - k3;
+                    uint32_t w[4], nx[4];
+                    if (t < tend) lds_get16(pool, rev ? src + n - 16u - (uint32_t)t : src + (uint32_t)t, nx);
+                    for (; t < tend; t += 16, o += 16) {
+                        w[0] = nx[0]; w[1] = nx[1]; w[2] = nx[2]; w[3] = nx[3];
+                        if (t + 16 < tend) lds_get16(pool, rev ? src + n - 32u - (uint32_t)t : src + (uint32_t)(t + 16), nx);
+                        if (rev) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
+                        if (seq) {
+                            if (rev) { w[0] = comp4_acgtn(w[0]); w[1] = comp4_acgtn(w[1]); w[2] = comp4_acgtn(w[2]); w[3] = comp4_acgtn(w[3]); }
+                            if (implied_n) {
+                                uint32_t qw[4]; lds_get16(pool, rev ? qsrc + n - 16u - (uint32_t)t : qsrc + (uint32_t)t, qw);
+                                if (rev) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3; }
+#pragma unroll
+                                for (int i = 0; i < 4; i++) { const uint32_t mk = eq_bytes_full(qw[i], (nq & 0xFFu) * 0x01010101u); w[i] = (w[i] & ~mk) | (0x4E4E4E4Eu & mk); }
+                            }
+                        }
+                        if (pat >= t && pat < t + 16) { const int b = pat - t; const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& x = w[b >> 2]; x = (x & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
+                        if (t >= 0 && t + 16 <= (int)n) *(uint4*)o = make_uint4(w[0], w[1], w[2], w[3]);
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const int ti = t + 4 * i;
+                                if (ti >= 0 && ti + 4 <= (int)n) *(uint32_t*)(o + 4 * i) = w[i];
+                                else if (ti > -4 && ti < (int)n) {
+#pragma unroll
+                                    for (int bb = 0; bb < 4; bb++) if (ti + bb >= 0 && ti + bb < (int)n) o[4 * i + bb] = (uint8_t)(w[i] >> (8 * bb));
+                                }
+                            }
+                        }
+                    }
+                }
             }
-#undef EMIT_SEQ
-#undef EMIT_PIECES
         } else
         for (uint32_t j = (uint32_t)wave_id(); j < cnt; j += wpb) {
             const uint32_t r = cur + j, g = g0 + j; const uint32_t* m = s_meta + 16 * j;
@@ -643,6 +820,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                 emit_one((to2 ? out2 : out1) + at, e, sdec + sg0, qdec + qg0, implied_n, nq, dpos, dch, l);
             }
         }
+        { const long long k35 = clock64(); a6 += k35 - k3; }
         __syncthreads();
         k4 = clock64(); a4 += k4 - k3;
         // ---- phase 5: aligned 16-byte stores of the finished tile (no barrier after it: three barriers precede the next compose)
@@ -653,5 +831,5 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         k5 = clock64(); a5 += k5 - k4;
         cur += cnt;
     }
-    if (tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a1); atomicAdd(&dbg[1], (unsigned long long)a2); atomicAdd(&dbg[2], (unsigned long long)a3); atomicAdd(&dbg[3], (unsigned long long)a4); atomicAdd(&dbg[4], (unsigned long long)a5); atomicAdd(&dbg[5], 1ull); }
+    if (tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a1); atomicAdd(&dbg[1], (unsigned long long)a2); atomicAdd(&dbg[2], (unsigned long long)a3); atomicAdd(&dbg[3], (unsigned long long)a4); atomicAdd(&dbg[4], (unsigned long long)a5); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)a6); atomicAdd(&dbg[7], (unsigned long long)aS); }
 }
