@@ -325,8 +325,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
         HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 8));
 #define RFQ_PC_ARGS R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), \
-                    (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, n_chunks, dst
-        const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * MAX_STREAMS * n_seg;
+                    (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, n_chunks, n_qgroups, dst
+        const uint32_t n_qgroups = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
+        const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * (n_qgroups + 2) * n_seg;
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
         hipLaunchKernelGGL((k_pos_coder<0>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);
         hipLaunchKernelGGL((k_pos_coder<1>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);

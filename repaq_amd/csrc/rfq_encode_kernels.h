@@ -1009,133 +1009,176 @@ template <class Sink> __device__ __forceinline__ void pc_gen_tokens(uint64_t m, 
         mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
     }
 }
-// A (chunk, stream) is cut into segments of PC_SEG_STEPS steps (131072 positions) coded by independent waves: with one wave per
-// stream the kernel's run time was that of its slowest wave (256 dependent steps).  A segment needs the state at its first
+// A (chunk, stream) is cut into segments of PC_SEG_STEPS steps (32768 positions) coded by independent waves: a wave's steps are
+// a dependent chain at memory latency, so the kernel's run time is that of its longest chain (256 steps with one wave per stream;
+// 32-step segments measured 1.15 ms for the three passes, 8-step segments 0.93 ms, 4-step segments 0.96 ms).  A segment needs the state at its first
 // position — the last match and the last non-match before it — taken from a light summary pass over all segments, and its byte
 // offset inside the stream, which needs the byte counts of the earlier segments: summary, count, emit (three launches).
-#define PC_SEG_STEPS 32u
-// B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) with the given entry
-// state; returns the segment's byte count (wave-uniform).  EMIT writes the bytes at out[0..).
-template <bool EMIT> __device__ __forceinline__ uint32_t wave_pos_encode_seg(const uint8_t* __restrict__ B, uint32_t len, int mode, uint32_t q, const DevHeader* __restrict__ D,
-                                                   uint8_t* __restrict__ out, uint32_t room, uint32_t step0, uint32_t step1, int prev_carry, int zero_carry) {
+#define PC_SEG_STEPS 8u
+// One wave codes up to PC_G streams of the SAME buffer over the same segment: the 4096 raw bytes of a step are loaded once and turned
+// into one match mask per stream (the streams of a chunk used to re-read the chunk's qualities once each, in each of the three passes).
+#define PC_G 4
+struct PcStream {
+    bool on; int mode; uint32_t q;          // PC_MATCH value q, or PC_EXCEPT
+    uint64_t m_cur, m_next;                 // masks of the current and the next step (lane's 64 positions)
+    int prev_carry, zero_carry;             // last match / last non-match before the current step
+    uint32_t outpos; uint8_t* out; uint32_t room;
+    int last1, last0;                       // summary pass
+};
+// B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
+// with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  EMIT writes the bytes at S[t].out[0..).
+template <bool EMIT, int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
+                                                                           PcStream (&S)[G], uint32_t step0, uint32_t step1) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
-    uint32_t outpos = 0;                                                    // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
-    // software pipeline, two steps deep: raw bytes of step+2 are in flight while step is coded; a step's raw bytes become a mask
+    // software pipeline, two steps deep: raw bytes of step+2 are in flight while step is coded; a step's raw bytes become masks
     // only one step after they were requested, so the wave never waits on the load it has just issued
-    const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;
+    const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;                 // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
     Raw64 raw_n = pc_load_raw(B, len, q0 + 4096u);
-    uint64_t m_cur = pc_mask_of(pc_load_raw(B, len, q0), len, q0, mode, q, D);
-    uint64_t m_next = pc_mask_of(raw_n, len, q0 + 4096u, mode, q, D);
+    { const Raw64 r0 = pc_load_raw(B, len, q0);
+#pragma unroll
+      for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D); S[t].outpos = 0; } }
     raw_n = pc_load_raw(B, len, q0 + 8192u);
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
-        const uint64_t m = m_cur;
-        const unsigned long long has1 = __ballot(m != 0);
-        if (!has1) {                                                            // nothing to code in these 4096 positions
-            zero_carry = (int)(step * 4096u + 4095u);
-            m_cur = m_next; m_next = pc_mask_of(raw_n, len, p0 + 8192u, mode, q, D); raw_n = pc_load_raw(B, len, p0 + 12288u);
-            continue;
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            if (!S[t].on) continue;                                           // wave-uniform
+            PcStream& s = S[t];
+            const uint64_t m = s.m_cur;
+            const unsigned long long has1 = __ballot(m != 0);
+            if (!has1) { s.zero_carry = (int)(step * 4096u + 4095u); continue; }   // nothing to code in these 4096 positions
+            const unsigned long long has0 = __ballot(~m != 0);
+            // last match / last non-match before my word: the nearest earlier lane that has one (ballot + one permute), else the carry
+            const int mylast = m ? (int)p0 + 63 - __clzll((long long)m) : -1;
+            const int myzero = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1;
+            const unsigned long long b1 = has1 & below, b0m = has0 & below;
+            const int src1 = b1 ? 63 - __clzll((long long)b1) : 0, src0 = b0m ? 63 - __clzll((long long)b0m) : 0;
+            const int got1 = __shfl(mylast, src1), got0 = __shfl(myzero, src0);
+            const int prev_in = b1 ? got1 : s.prev_carry, zero_in = b0m ? got0 : s.zero_carry;
+            // matches continuing right after my word (for run lengths): leading ones of the next lane's word (the next step's first word
+            // for lane 63 - also when that step belongs to the next segment)
+            const uint32_t lead = (m == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);
+            const uint32_t lead_n = (s.m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~s.m_next) - 1);
+            uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
+            if (l == 63) after = after63;
+            uint32_t bytes; uint64_t pk = 0;
+            if (MODE == PC_EXCEPT) bytes = 5u * (uint32_t)__popcll(m);
+            else { PackSink ps; pc_gen_tokens(m, p0, prev_in, zero_in, after, ps); bytes = ps.n; pk = ps.pk; }
+            const uint32_t incl = wave_incl_sum(bytes);
+            uint32_t o = s.outpos + incl - bytes;
+            const uint32_t tot = __shfl(incl, 63);
+            if (EMIT && s.outpos + tot <= s.room) {
+                uint8_t* out = s.out;
+                if (MODE == PC_EXCEPT) {
+                    uint64_t mm = m;
+                    while (mm) { const int b = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)b]; st_u32(out + o + 1, p0 + (uint32_t)b); o += 5; }
+                } else if (bytes <= 8) {
+                    for (uint32_t k = 0; k < bytes; k++) out[o + k] = (uint8_t)(pk >> (8 * k));
+                } else { StoreSink ss; ss.p = out + o; pc_gen_tokens(m, p0, prev_in, zero_in, after, ss); }   // dense word: regenerate straight to memory
+            }
+            s.outpos += tot;
+            // carries: the last lane that has a match / a non-match in this step
+            const int pl = __shfl(mylast, 63 - __clzll((long long)has1));
+            if (pl > s.prev_carry) s.prev_carry = pl;
+            if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > s.zero_carry) s.zero_carry = zl; }
         }
-        const unsigned long long has0 = __ballot(~m != 0);
-        // last match / last non-match before my word: the nearest earlier lane that has one (ballot + one permute), else the carry
-        const int mylast = m ? (int)p0 + 63 - __clzll((long long)m) : -1;
-        const int myzero = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1;
-        const unsigned long long b1 = has1 & below, b0m = has0 & below;
-        const int src1 = b1 ? 63 - __clzll((long long)b1) : 0, src0 = b0m ? 63 - __clzll((long long)b0m) : 0;
-        const int got1 = __shfl(mylast, src1), got0 = __shfl(myzero, src0);
-        const int prev_in = b1 ? got1 : prev_carry, zero_in = b0m ? got0 : zero_carry;
-        // matches continuing right after my word (for run lengths): leading ones of the next lane's word (the next step's first word
-        // for lane 63 — also when that step belongs to the next segment)
-        const uint32_t lead = (m == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);
-        const uint32_t lead_n = (m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m_next) - 1);
-        uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
-        if (l == 63) after = after63;
-        uint32_t bytes; uint64_t pk = 0;
-        if (mode == PC_EXCEPT) bytes = 5u * (uint32_t)__popcll(m);
-        else { PackSink ps; pc_gen_tokens(m, p0, prev_in, zero_in, after, ps); bytes = ps.n; pk = ps.pk; }
-        const uint32_t incl = wave_incl_sum(bytes);
-        uint32_t o = outpos + incl - bytes;
-        const uint32_t tot = __shfl(incl, 63);
-        if (EMIT && outpos + tot <= room) {
-            if (mode == PC_EXCEPT) {
-                uint64_t mm = m;
-                while (mm) { const int s = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)s]; st_u32(out + o + 1, p0 + (uint32_t)s); o += 5; }
-            } else if (bytes <= 8) {
-                for (uint32_t k = 0; k < bytes; k++) out[o + k] = (uint8_t)(pk >> (8 * k));
-            } else { StoreSink ss; ss.p = out + o; pc_gen_tokens(m, p0, prev_in, zero_in, after, ss); }   // dense word: regenerate straight to memory
-        }
-        outpos += tot;
-        // carries: the last lane that has a match / a non-match in this step
-        const int pl = __shfl(mylast, 63 - __clzll((long long)has1));
-        if (pl > prev_carry) prev_carry = pl;
-        if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > zero_carry) zero_carry = zl; }
-        m_cur = m_next; m_next = pc_mask_of(raw_n, len, p0 + 8192u, mode, q, D); raw_n = pc_load_raw(B, len, p0 + 12288u);
+#pragma unroll
+        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D); }
+        raw_n = pc_load_raw(B, len, p0 + 12288u);
     }
-    return outpos;
 }
-// last match / last non-match inside steps [step0, step1) (or -1): the summary pass, loads pipelined like the coder's
-__device__ __forceinline__ void wave_pos_summary(const uint8_t* __restrict__ B, uint32_t len, int mode, uint32_t q, const DevHeader* __restrict__ D,
-                                                 uint32_t step0, uint32_t step1, int& last1, int& last0) {
-    const int l = lane_id(); last1 = -1; last0 = -1;
+// last match / last non-match inside steps [step0, step1) (or -1) of every active stream: the summary pass, loads pipelined like the coder's
+template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D, PcStream (&S)[G], uint32_t step0, uint32_t step1) {
+    const int l = lane_id();
     const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;
-    Raw64 raw_n = pc_load_raw(B, len, q0 + 4096u);
-    uint64_t m_cur = pc_mask_of(pc_load_raw(B, len, q0), len, q0, mode, q, D);
+    Raw64 raw_c = pc_load_raw(B, len, q0), raw_n = pc_load_raw(B, len, q0 + 4096u);
+#pragma unroll
+    for (int t = 0; t < G; t++) { S[t].last1 = -1; S[t].last0 = -1; }
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
-        const Raw64 raw_c = raw_n; raw_n = pc_load_raw(B, len, p0 + 8192u);
-        const uint64_t m = m_cur;
-        const unsigned long long h1 = __ballot(m != 0), h0 = __ballot(~m != 0);
-        if (h1) { const int v = m ? (int)p0 + 63 - __clzll((long long)m) : -1; last1 = __shfl(v, 63 - __clzll((long long)h1)); }
-        if (h0) { const int v = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1; last0 = __shfl(v, 63 - __clzll((long long)h0)); }
-        m_cur = pc_mask_of(raw_c, len, p0 + 4096u, mode, q, D);
+        const Raw64 raw_nn = pc_load_raw(B, len, p0 + 8192u);
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            if (!S[t].on) continue;
+            const uint64_t m = pc_mask_of(raw_c, len, p0, MODE, S[t].q, D);
+            const unsigned long long h1 = __ballot(m != 0), h0 = __ballot(~m != 0);
+            if (h1) { const int v = m ? (int)p0 + 63 - __clzll((long long)m) : -1; S[t].last1 = __shfl(v, 63 - __clzll((long long)h1)); }
+            if (h0) { const int v = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1; S[t].last0 = __shfl(v, 63 - __clzll((long long)h0)); }
+        }
+        raw_c = raw_n; raw_n = raw_nn;
     }
 }
-// 1-D grid of ceil(n_chunks / 8) * 8 * MAX_STREAMS * n_seg workgroups, one wave each; three passes over the same grid:
+// 1-D grid of ceil(n_chunks / 8) * 8 * (n_qgroups + 2) * n_seg workgroups, one wave each; three passes over the same grid:
 //   PASS 0  summary  segc[2*si+{0,1}] = last match / last non-match of the segment
 //   PASS 1  count    entry state = nearest earlier segment that has one; segb[si] = bytes of the segment
 //   PASS 2  emit     offset = sum of earlier segb; writes the bytes
-// si = (c * MAX_STREAMS + j) * n_seg + seg.  Streams whose value does not occur in the chunk (histogram) are skipped outright.
-template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
-                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg, uint32_t n_chunks, DevStatus* st) {
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
-    // (stream, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's megabyte of qualities is pulled into
-    // ONE private L2 and re-read there by its other streams instead of being fetched from HBM by up to eight L2s.
-    const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = MAX_STREAMS * n_seg;
-    const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, j = rest % MAX_STREAMS, seg = rest / MAX_STREAMS;
-    if (c >= n_chunks) return;
-    const size_t k = (size_t)c * MAX_STREAMS + j;
-    const uint32_t cap = C.scap[k];
-    if (cap == 0) return;                                                  // stream not present (uniform: one wave per block)
-    const uint32_t occurrences = j < NPOS_SLOT ? C.hist[(size_t)c * 256 + D->normal[j]] : (j == NPOS_SLOT ? C.ncount[c] : (cap - 16u) / 5u);
-    if (occurrences == 0) return;                                          // nothing to code: ssize stays 0 (k_stream_plan)
-    const uint32_t f = C.first[c], e = C.first[c + 1];
-    const bool useq = j == NPOS_SLOT;
-    const uint8_t* B = useq ? scat + C.sbase[c] : qcat + C.qbase[c];
-    const uint32_t len = useq ? R.pv[e].d - R.pv[f].d : R.pq[e] - R.pq[f];
-    const int mode = j == EXC_SLOT ? PC_EXCEPT : PC_MATCH; const uint32_t q = j < NPOS_SLOT ? D->normal[j] : (uint32_t)'N';
+// Group g < n_qgroups holds the quality-value streams 4g .. 4g+3, group n_qgroups the exception stream, group n_qgroups + 1 the
+// N-position stream (it reads the base buffer).  si = (c * MAX_STREAMS + j) * n_seg + seg.  Streams whose value does not occur in
+// the chunk (histogram) are skipped outright.
+template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg,
+                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, DevStatus* st) {
     const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
-    const size_t s0i = k * n_seg, si = s0i + seg;
-    if (step0 >= nsteps) { if (PASS == 0 && lane_id() == 0) { segb[si] = 0; segc[2 * si] = -1; segc[2 * si + 1] = -1; } return; }
     const uint32_t step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
+    PcStream S[G]; size_t kk[G]; bool any = false;
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        const uint32_t j = j0 + (uint32_t)t;
+        S[t].on = false; kk[t] = 0;
+        if (j >= jend) continue;
+        const size_t k = (size_t)c * MAX_STREAMS + j; kk[t] = k;
+        const uint32_t cap = C.scap[k];
+        if (cap == 0) continue;                                            // stream not present
+        const uint32_t occurrences = j < NPOS_SLOT ? C.hist[(size_t)c * 256 + D->normal[j]] : (j == NPOS_SLOT ? C.ncount[c] : (cap - 16u) / 5u);
+        if (occurrences == 0) continue;                                    // nothing to code: ssize stays 0 (k_stream_plan)
+        const size_t si = k * n_seg + seg;
+        if (step0 >= nsteps) { if (PASS == 0 && lane_id() == 0) { segb[si] = 0; segc[2 * si] = -1; segc[2 * si + 1] = -1; } continue; }
+        S[t].on = true; any = true;
+        S[t].mode = MODE; S[t].q = j < NPOS_SLOT ? D->normal[j] : (uint32_t)'N';
+        S[t].prev_carry = -1; S[t].zero_carry = -1; S[t].out = nullptr; S[t].room = 0; S[t].outpos = 0;
+    }
+    if (!any) return;                                                      // wave-uniform
     if (PASS == 0) {
-        int l1, l0; wave_pos_summary(B, len, mode, q, D, step0, step1, l1, l0);
-        if (lane_id() == 0) { segc[2 * si] = l1; segc[2 * si + 1] = l0; segb[si] = 0; }
+        wave_pos_summary_group<MODE, G>(B, len, D, S, step0, step1);
+#pragma unroll
+        for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) { const size_t si = kk[t] * n_seg + seg; segc[2 * si] = S[t].last1; segc[2 * si + 1] = S[t].last0; segb[si] = 0; }
         return;
     }
-    int prev = -1, zero = -1;                                               // entry state: nearest earlier segment that saw a match / a non-match
-    for (int s = (int)seg - 1; s >= 0 && prev < 0; s--) prev = segc[2 * (s0i + (uint32_t)s)];
-    for (int s = (int)seg - 1; s >= 0 && zero < 0; s--) zero = segc[2 * (s0i + (uint32_t)s) + 1];
-    if (PASS == 1) {
-        const uint32_t sz = wave_pos_encode_seg<false>(B, len, mode, q, D, nullptr, 0u, step0, step1, prev, zero);
-        if (lane_id() == 0) segb[si] = sz;
-    } else {
-        uint32_t off = 0; for (uint32_t s = 0; s < seg; s++) off += segb[s0i + s];
-        const uint32_t own = segb[si];
-        uint8_t* out = scratch + cbase[c] + C.soff[k];
-        if (off + own <= cap) (void)wave_pos_encode_seg<true>(B, len, mode, q, D, out + off, own, step0, step1, prev, zero);
-        if (step1 == nsteps && lane_id() == 0) { C.ssize[k] = off + own; if (off + own > cap) atomicOr(&st->err, (uint32_t)DE_CORRUPT); }
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        if (!S[t].on) continue;
+        const size_t s0i = kk[t] * n_seg;                                   // entry state: nearest earlier segment that saw a match / a non-match
+        int prev = -1, zero = -1;
+        for (int s = (int)seg - 1; s >= 0 && prev < 0; s--) prev = segc[2 * (s0i + (uint32_t)s)];
+        for (int s = (int)seg - 1; s >= 0 && zero < 0; s--) zero = segc[2 * (s0i + (uint32_t)s) + 1];
+        S[t].prev_carry = prev; S[t].zero_carry = zero;
+        if (PASS == 2) {
+            uint32_t off = 0; for (uint32_t s = 0; s < seg; s++) off += segb[s0i + s];
+            const uint32_t own = segb[s0i + seg], cap = C.scap[kk[t]];
+            S[t].out = scratch + cbase[c] + C.soff[kk[t]] + off; S[t].room = own;
+            if (step1 == nsteps && lane_id() == 0) { C.ssize[kk[t]] = off + own; if (off + own > cap) atomicOr(&st->err, (uint32_t)DE_CORRUPT); }
+            if (off + own > cap) S[t].room = 0;                             // never write past the stream's capacity (flagged above by its last segment)
+        }
     }
+    if (PASS == 1) {
+        wave_pos_encode_group<false, MODE, G>(B, len, D, S, step0, step1);
+#pragma unroll
+        for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) segb[kk[t] * n_seg + seg] = S[t].outpos;
+    } else wave_pos_encode_group<true, MODE, G>(B, len, D, S, step0, step1);
+}
+template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg, uint32_t n_chunks,
+                            uint32_t n_qgroups, DevStatus* st) {
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
+    // (group, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's data stays in ONE private L2.
+    const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = (n_qgroups + 2) * n_seg;
+    const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = rest % (n_qgroups + 2), seg = rest / (n_qgroups + 2);
+    if (c >= n_chunks) return;
+    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
+    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, grp * PC_G, nn, st);
+    else if (grp == n_qgroups) pc_run<PASS, PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, st);
+    else pc_run<PASS, PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, st);
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
