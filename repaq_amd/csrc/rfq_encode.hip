@@ -319,6 +319,13 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (img_cap < hdr_bytes) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small for the header");
         HIPCHK(ctx, hipMemcpyAsync(img, HH.bytes, hdr_bytes, hipMemcpyHostToDevice, S));
     }
+    // the coordinate coder (one dependent chain of ~100 steps per (axis, chunk)) runs beside the position coder on the aux stream
+    const bool fork_coords = ctx->aux_ready();
+    if (fork_coords) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, ctx->aux, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    }
     ctx->timer.begin("pos_coder", S);
     {
         const uint32_t max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
@@ -337,7 +344,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     KCHK(ctx, "k_pos_coder");
     ctx->timer.end(S);
     ctx->timer.begin("coords+layout", S);
-    hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
+    if (fork_coords) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0));
+    else hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
     hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
     hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 1, dst);
