@@ -801,7 +801,7 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0; long long a_fit = 0, a_meta = 0, a_stage = 0, a_q = 0, a_s = 0;
     __shared__ uint4 s_text4[GT_CAP / 16 + 6];
     __shared__ uint32_t s_qsrc[GT_READS], s_ssrc[GT_READS], s_len[GT_READS], s_skip[GT_READS], s_keep[GT_READS], s_qdst[GT_READS + 1], s_sdst[GT_READS + 1];
-    __shared__ uint8_t s_rc[GT_READS];
+    __shared__ uint8_t s_rc[GT_READS]; __shared__ uint32_t s_nx[GT_READS];
     __shared__ uint32_t sh[256]; __shared__ uint32_t s_n, s_cnt;
     uint8_t* s_text = (uint8_t*)(s_text4 + 1);                            // 16 bytes of slack in front: reversed 16-byte fetches may start before a line
     const uint32_t tid = threadIdx.x;
@@ -818,21 +818,31 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     uint32_t cur = gs;
     while (cur < ge) {                                                   // block-uniform
         tk0 = clock64();
-        // ---- how many consecutive reads fit in the LDS tile (monotone predicate -> count)
+        // ---- ONE round of global loads for up to GT_READS candidate reads (+ the end sentinel): what the fit test needs and what the
+        // tile needs; how many consecutive reads fit in the LDS tile is a monotone predicate -> count
         if (tid == 0) s_cnt = 0;
         __syncthreads();
         uint32_t a0[2] = { 0, 0 };                                         // 16-aligned global begin of each stream's span
         if (two) { a0[0] = T.lo[0][4 * (size_t)(cur >> 1)] & ~15u; a0[1] = T.lo[1][4 * (size_t)(cur >> 1)] & ~15u; }
         else a0[0] = T.lo[0][4 * (size_t)cur] & ~15u;
-        bool fits = false;
-        if (tid < GT_READS && cur + tid < ge) {
-            uint32_t need;
-            if (two) { const uint32_t recs = (tid + 2) >> 1; const size_t r1 = (size_t)(cur >> 1) + recs;
-                       need = ((T.lo[0][4 * r1] - a0[0] + 15u) & ~15u) + 16u + (T.lo[1][4 * r1] - a0[1]); }
-            else need = T.lo[0][4 * (size_t)(cur + tid + 1)] - a0[0];
-            fits = need + 16u <= GT_CAP;
+        bool fits = false; int m_st = 0; uint32_t m_p1 = 0, m_p3 = 0, m_len = 0, m_qdst = 0, m_sdst = 0; int m_ov = 0; bool m_rc = false;
+        if (tid <= GT_READS && cur + tid <= ge) {
+            const uint32_t g = cur + tid;
+            m_qdst = R.pq[g] - pq0; m_sdst = R.pv[g].d - ps0;             // (valid for the sentinel too)
+            if (tid < GT_READS && g < ge) {
+                uint32_t rr; read_loc(T, g, m_st, rr);
+                const uint32_t* p = T.lo[m_st] + 4 * (size_t)rr;
+                m_p1 = p[1]; m_p3 = p[3]; s_nx[tid] = p[4];                  // start of the record after mine, in my stream
+                m_len = R.len[g]; m_rc = il && ((g - f) & 1u);
+                if (m_rc && enc) m_ov = (int)ovb[g >> 1] - shift;
+                uint32_t need;
+                if (two) { const uint32_t recs = (tid + 2) >> 1; const size_t r1 = (size_t)(cur >> 1) + recs;
+                           need = ((T.lo[0][4 * r1] - a0[0] + 15u) & ~15u) + 16u + (T.lo[1][4 * r1] - a0[1]); }
+                else need = s_nx[tid] - a0[0];
+                fits = need + 16u <= GT_CAP;
+            }
         }
-        {   // monotone predicate: the count is the number of fitting indices; one LDS atomic per wave
+        {   // one LDS atomic per wave
             const unsigned long long fb = __ballot(fits);
             if (lane_id() == 0 && fb) atomicAdd(&s_cnt, (uint32_t)__popcll(fb));
         }
@@ -851,29 +861,37 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
             cur += upr; __syncthreads(); continue;
         }
         tk1 = clock64(); a_fit += tk1 - tk0;
-        // ---- per-read metadata -> LDS
+        // ---- per-read metadata -> LDS (from the registers loaded above)
         uint32_t span_end[2] = { 0, 0 };
-        if (two) { const size_t r1 = (size_t)((cur + cnt) >> 1); span_end[0] = T.lo[0][4 * r1]; span_end[1] = T.lo[1][4 * r1]; }
-        else span_end[0] = T.lo[0][4 * (size_t)(cur + cnt)];
+        if (two) { span_end[0] = s_nx[cnt - 2]; span_end[1] = s_nx[cnt - 1]; }   // cnt is even for two files: the last pair's records end the spans
+        else span_end[0] = s_nx[cnt - 1];
         const uint32_t base1 = two ? (((span_end[0] - a0[0] + 15u) & ~15u) + 16u) : 0u;   // LDS offset of stream 1's span
         if (tid < cnt) {
-            const uint32_t g = cur + tid; int st; uint32_t rr; read_loc(T, g, st, rr);
-            const uint32_t* p = T.lo[st] + 4 * (size_t)rr; const uint32_t lb = st ? base1 : 0u;
-            const uint32_t len = R.len[g]; const bool rc = il && ((g - f) & 1u);
-            int ov = 0; if (rc && enc) ov = (int)ovb[g >> 1] - shift;
-            s_ssrc[tid] = lb + (p[1] - a0[st]); s_qsrc[tid] = lb + (p[3] - a0[st]); s_len[tid] = len; s_rc[tid] = rc ? 1 : 0;
-            s_skip[tid] = ov > 0 ? (uint32_t)ov : 0u; s_keep[tid] = len - (uint32_t)(ov < 0 ? -ov : ov);
-            s_qdst[tid] = R.pq[g] - pq0; s_sdst[tid] = R.pv[g].d - ps0;
+            const uint32_t lb = m_st ? base1 : 0u;
+            s_ssrc[tid] = lb + (m_p1 - a0[m_st]); s_qsrc[tid] = lb + (m_p3 - a0[m_st]); s_len[tid] = m_len; s_rc[tid] = m_rc ? 1 : 0;
+            s_skip[tid] = m_ov > 0 ? (uint32_t)m_ov : 0u; s_keep[tid] = m_len - (uint32_t)(m_ov < 0 ? -m_ov : m_ov);
         }
-        if (tid == cnt) { s_qdst[cnt] = R.pq[cur + cnt] - pq0; s_sdst[cnt] = R.pv[cur + cnt].d - ps0; }
+        if (tid <= cnt) { s_qdst[tid] = m_qdst; s_sdst[tid] = m_sdst; }
         tk2 = clock64(); a_meta += tk2 - tk1;
         // ---- stage the spans: aligned 16-byte loads (the very last group of a stream may not be fully inside the buffer)
         for (int st = 0; st < (two ? 2 : 1); st++) {
             const uint32_t nb = span_end[st] - a0[st]; const uint32_t ng = (nb + 15) / 16; const uint32_t lb = st ? base1 : 0u;
             const uint8_t* src = T.fq[st] + a0[st];
-            for (uint32_t i = tid; i < ng; i += blockDim.x) {
-                if ((uint64_t)a0[st] + 16ull * i + 16ull <= (uint64_t)T.n[st]) s_text4[1 + lb / 16 + i] = *(const uint4*)(src + 16 * (size_t)i);
-                else for (uint32_t k = 0; k < 16 && a0[st] + 16 * i + k < T.n[st]; k++) s_text[lb + 16 * i + k] = src[16 * (size_t)i + k];
+            // four loads in flight per thread before the first LDS store: a tile costs two memory latencies instead of seven
+            for (uint32_t i0 = tid; i0 < ng; i0 += 4 * blockDim.x) {
+                uint4 v[4]; bool full[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * blockDim.x; v[u] = make_uint4(0, 0, 0, 0);
+                    full[u] = i < ng && (uint64_t)a0[st] + 16ull * i + 16ull <= (uint64_t)T.n[st];
+                    if (full[u]) v[u] = *(const uint4*)(src + 16 * (size_t)i);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+                    if (full[u]) s_text4[1 + lb / 16 + i] = v[u];
+                    else if (i < ng) for (uint32_t k = 0; k < 16 && a0[st] + 16 * i + k < T.n[st]; k++) s_text[lb + 16 * i + k] = src[16 * (size_t)i + k];
+                }
             }
         }
         __syncthreads();
