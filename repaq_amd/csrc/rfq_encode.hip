@@ -285,7 +285,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
             if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
     }
-    hipLaunchKernelGGL(k_stream_plan, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks);
+    hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks);
     scan_exclusive<uint64_t>(S, B[B_CTOTAL].as<uint64_t>(), B[B_CBASE].as<uint64_t>(), n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
     hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);

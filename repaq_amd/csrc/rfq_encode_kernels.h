@@ -917,22 +917,29 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
 // scratch capacity of every stream of a chunk: a value with k matches in len positions codes to at most
 // k + len/128 + 3*len/16384 bytes (one byte per token, +1 for each gap > 128, +3 for each gap > 16384).
 __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint64_t* __restrict__ ctotal, uint32_t n_chunks) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per chunk: lane j plans slot j (slots 64 / 65 by lanes 0 / 1 afterwards); offsets by a wave scan
+    const uint32_t c = blockIdx.x; const int l = lane_id();
     if (c >= n_chunks) return;
     const uint32_t f = C.first[c], e = C.first[c + 1];
     const uint32_t len = R.pq[e] - R.pq[f], slen = R.pv[e].d - R.pv[f].d;
-    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT; uint64_t run = 0;
+    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT;
     const bool bycol = (D->flags & H_QUAL_BY_COL) && !(D->flags & H_DONT_QUAL);
     const uint32_t* h = C.hist + (size_t)c * 256;
-    for (uint32_t j = 0; j < MAX_STREAMS; j++) {
-        uint32_t cap = 0;
-        if (j < NPOS_SLOT) { if (bycol && j < nn) cap = h[D->normal[j]] + len / 128 + 3 * (len / 16384) + 16; }
-        else if (j == NPOS_SLOT) { if (D->flags & H_N_POS) cap = C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16; }
-        else { if (bycol) { uint32_t ex = 0; for (int v = 0; v < 256; v++) if (D->is_exception[v]) ex += h[v]; cap = 5 * ex + 16; } }
-        C.scap[(size_t)c * MAX_STREAMS + j] = cap; C.soff[(size_t)c * MAX_STREAMS + j] = run; C.ssize[(size_t)c * MAX_STREAMS + j] = 0;
-        run += (cap + 15u) & ~15u;
+    uint32_t exl = 0;
+    if (bycol) for (int v = l; v < 256; v += 64) if (D->is_exception[v]) exl += h[v];
+    const uint32_t ex = wave_sum(exl);
+    uint32_t cap = (bycol && (uint32_t)l < nn) ? h[D->normal[l]] + len / 128 + 3 * (len / 16384) + 16 : 0u;
+    const uint32_t al = (cap + 15u) & ~15u;
+    const uint32_t incl = wave_incl_sum(al);
+    const size_t k = (size_t)c * MAX_STREAMS;
+    C.scap[k + l] = cap; C.soff[k + l] = incl - al; C.ssize[k + l] = 0;
+    const uint32_t run64 = __shfl(incl, 63);
+    if (l < 2) {
+        const uint32_t capn = (D->flags & H_N_POS) ? C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16 : 0u, cape = bycol ? 5 * ex + 16 : 0u;
+        const uint32_t aln = (capn + 15u) & ~15u, ale = (cape + 15u) & ~15u;
+        if (l == 0) { C.scap[k + NPOS_SLOT] = capn; C.soff[k + NPOS_SLOT] = run64; C.ssize[k + NPOS_SLOT] = 0; }
+        else { C.scap[k + EXC_SLOT] = cape; C.soff[k + EXC_SLOT] = run64 + aln; C.ssize[k + EXC_SLOT] = 0; ctotal[c] = (uint64_t)run64 + aln + ale; }
     }
-    ctotal[c] = run;
 }
 
 // =============================================================== position coder (encodeSingleQualByCol, src/rfqcodec.cpp:625-710)
@@ -1300,6 +1307,25 @@ __global__ void k_chunk_layout(ReadTab R, ChunkTab C, const DevHeader* __restric
     }
 }
 
+// dst[0..n) = src[0..n) by the threads t, t+NT, ... : bytes up to dst's 4-byte boundary, then ALIGNED dword stores fed by aligned dword
+// loads + a funnel shift (src may sit at any phase), four of them in flight per thread, then the tail bytes.  src must be readable
+// up to the next multiple of 4 past n (all callers copy out of 16-byte padded scratch buffers or out of the text itself).
+__device__ __forceinline__ void copy_to_image(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, uint32_t t, uint32_t NT) {
+    uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u); if (head > n) head = n;
+    if (t < head) dst[t] = src[t];
+    const uint32_t body = (n - head) / 4;
+    const uint8_t* sp = src + head; const uint32_t sh = (uint32_t)((uintptr_t)sp & 3u) * 8u;
+    const uint32_t* sw = (const uint32_t*)(sp - ((uintptr_t)sp & 3u)); uint32_t* dw = (uint32_t*)(dst + head);
+    for (uint32_t k0 = t; k0 < body; k0 += 4 * NT) {
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t k = k0 + (uint32_t)u * NT; lo[u] = hi[u] = 0; if (k < body) { lo[u] = sw[k]; if (sh) hi[u] = sw[k + 1]; } }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t k = k0 + (uint32_t)u * NT; if (k < body) dw[k] = sh ? (uint32_t)((((uint64_t)hi[u] << 32) | lo[u]) >> sh) : lo[u]; }
+    }
+    const uint32_t done = head + 4 * body;
+    if (t < n - done) dst[done + t] = src[done + t];
+}
 // grid (blocks_per_chunk, n_chunks): fixed fields, per-read arrays, coordinate streams, "same" names, packed bases,
 // quality payload, overlap bytes, N positions.
 __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L,
@@ -1347,50 +1373,54 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
     if (!(fl & C_STRAND_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) out[o.off_stlens + i] = (uint8_t)line_len(T, f + i, 2);
     if ((hf & H_LANE) && !(fl & C_LANE_SAME)) for (uint32_t i = t; i < h; i += NT) out[o.off_lanes + i] = R.lane[f + (size_t)i * hs];
     if ((hf & H_TILE) && !(fl & C_TILE_SAME)) for (uint32_t i = t; i < h; i += NT) st_u16(out + o.off_tiles + 2 * (size_t)i, R.tile[f + (size_t)i * hs]);
-    if (hf & H_X) { const uint8_t* src = xs + 3ull * f; for (uint32_t i = t; i < o.x_size; i += NT) out[o.off_x + 4 + i] = src[i]; }
-    if (hf & H_Y) { const uint8_t* src = ys + 3ull * f; for (uint32_t i = t; i < o.y_size; i += NT) out[o.off_y + 4 + i] = src[i]; }
+    if (hf & H_X) copy_to_image(out + o.off_x + 4, xs + 3ull * f, o.x_size, t, NT);
+    if (hf & H_Y) copy_to_image(out + o.off_y + 4, ys + 3ull * f, o.y_size, t, NT);
     // names / strand that are stored once
     if (fl & C_NAME1_SAME) { const uint8_t* src = line_ptr(T, f, 0); for (uint32_t i = t; i < o.n1_size; i += NT) out[o.off_n1 + i] = src[i]; }
     if ((hf & H_NAME2) && (fl & C_NAME2_SAME)) { const uint8_t* src = line_ptr(T, f, 0) + R.name2_off[f]; for (uint32_t i = t; i < o.n2_size; i += NT) out[o.off_n2 + i] = src[i]; }
     if (fl & C_STRAND_SAME) { const uint8_t* src = line_ptr(T, f, 2); for (uint32_t i = t; i < o.st_size; i += NT) out[o.off_st + i] = src[i]; }
-    // 2-bit bases: G=0 A=1 T=2 C=3, anything else 0 (src/rfqcodec.cpp:590-604).  16 bases (one aligned uint4 of scat) -> 4 bytes.
+    // 2-bit bases: G=0 A=1 T=2 C=3, anything else 0 (src/rfqcodec.cpp:590-604).  16 bases -> one ALIGNED dword of the image: the first
+    // (4 - address & 3) & 3 bytes go out as bytes, which shifts the 16-base groups by a multiple of 4 bases, i.e. dword-aligned in scat.
     {
         const uint8_t* sb = scat + C.sbase[c]; const uint32_t n = R.pv[f + s].d - R.pv[f].d;
-        const uint4* sb4 = (const uint4*)sb; const uint32_t ngroups = (n + 15) / 16;
-        for (uint32_t gi = t; gi < ngroups; gi += NT) {
-            const uint4 w = sb4[gi]; const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+        uint8_t* od = out + o.off_seq; const uint32_t nbytes = o.seq_size;
+        uint32_t head = (uint32_t)((4u - ((uintptr_t)od & 3u)) & 3u); if (head > nbytes) head = nbytes;
+        auto pack4 = [&](uint32_t w, uint32_t p) -> uint32_t {            // 4 bases at positions p..p+3 -> one byte
+            uint32_t v = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t v = 0;
+            for (int b = 0; b < 4; b++) { const uint32_t ch = (w >> (8 * b)) & 0xFFu; const uint32_t code = p + (uint32_t)b < n ? (ch == 'A' ? 1u : (ch == 'T' ? 2u : (ch == 'C' ? 3u : 0u))) : 0u; v |= code << (2 * b); }
+            return v;
+        };
+        const uint32_t* sw = (const uint32_t*)sb;                           // scat chunk bases are 64-byte aligned, padded to 64
+        if (t < head) od[t] = (uint8_t)pack4(sw[t], 4 * t);
+        const uint32_t body = (nbytes - head) / 4; uint32_t* dw = (uint32_t*)(od + head);
+        for (uint32_t k0 = t; k0 < body; k0 += 2 * NT) {                  // two dwords (32 bases) per thread in flight
+            uint32_t w[2][4];
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const uint32_t p = 16 * gi + 4 * (uint32_t)k + (uint32_t)b; const uint32_t ch = (ww[k] >> (8 * b)) & 0xFFu;
-                    const uint32_t code = p < n ? (ch == 'A' ? 1u : (ch == 'T' ? 2u : (ch == 'C' ? 3u : 0u))) : 0u;
-                    v |= code << (2 * b);
-                }
-                const uint32_t oi = 4 * gi + (uint32_t)k;
-                if (oi < o.seq_size) out[o.off_seq + oi] = (uint8_t)v;
-            }
+            for (int u = 0; u < 2; u++) { const uint32_t k = k0 + (uint32_t)u * NT;
+#pragma unroll
+                for (int i = 0; i < 4; i++) w[u][i] = k < body ? sw[head + 4 * k + (uint32_t)i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const uint32_t k = k0 + (uint32_t)u * NT; if (k >= body) continue;
+                const uint32_t p = 4 * (head + 4 * k);
+                dw[k] = pack4(w[u][0], p) | (pack4(w[u][1], p + 4) << 8) | (pack4(w[u][2], p + 8) << 16) | (pack4(w[u][3], p + 12) << 24); }
         }
+        const uint32_t done = head + 4 * body;
+        if (t < nbytes - done) od[done + t] = (uint8_t)pack4(sw[done + t], 4 * (done + t));
     }
     // quality payload
-    if (hf & H_DONT_QUAL) { const uint8_t* src = qcat + C.qbase[c]; for (uint32_t i = t; i < o.qual_size; i += NT) out[o.off_qual + i] = src[i]; }
+    if (hf & H_DONT_QUAL) copy_to_image(out + o.off_qual, qcat + C.qbase[c], o.qual_size, t, NT);
     else if (hf & H_QUAL_BY_COL) {
         uint32_t dst = o.off_qual + 4 * nn; const uint8_t* sc = scratch + cbase[c];
         for (uint32_t j = 0; j <= nn; j++) {
             const uint32_t js = j < nn ? j : (uint32_t)EXC_SLOT;          // normal streams in header order, then the exception records
             const uint32_t sz = C.ssize[k0 + js]; const uint8_t* src = sc + C.soff[k0 + js];      // 16-byte aligned (k_stream_plan)
-            const uint4* src4 = (const uint4*)src;
-            for (uint32_t gi = t; gi < (sz + 15) / 16; gi += NT) {
-                const uint4 w = src4[gi]; const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-                for (int k = 0; k < 16; k++) { const uint32_t i = 16 * gi + (uint32_t)k; if (i < sz) out[dst + i] = (uint8_t)(ww[k >> 2] >> (8 * (k & 3))); }
-            }
+            copy_to_image(out + dst, src, sz, t, NT);
             dst += sz;
         }
     }
     if (il && (hf & H_PE_OVERLAP)) for (uint32_t i = t; i < s / 2; i += NT) out[o.off_ov + i] = (uint8_t)ovb[(f >> 1) + i];
-    if (hf & H_N_POS) { const uint8_t* src = scratch + cbase[c] + C.soff[k0 + NPOS_SLOT]; for (uint32_t i = t; i < o.npos_size; i += NT) out[o.off_npos + i] = src[i]; }
+    if (hf & H_N_POS) copy_to_image(out + o.off_npos, scratch + cbase[c] + C.soff[k0 + NPOS_SLOT], o.npos_size, t, NT);
 }
 // names / strands that differ inside the chunk: one wave per read copies its pieces to their prefix-sum offsets
 __global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L, uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base) {
