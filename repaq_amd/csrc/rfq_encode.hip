@@ -187,7 +187,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     const size_t nr = (size_t)n_reads + 2;
     HIPCHK(ctx, B[B_LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N1LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N2OFF].ensure(nr * 4));
     HIPCHK(ctx, B[B_X].ensure(nr * 4)); HIPCHK(ctx, B[B_Y].ensure(nr * 4)); HIPCHK(ctx, B[B_TILE].ensure(nr * 2)); HIPCHK(ctx, B[B_LANE].ensure(nr)); HIPCHK(ctx, B[B_OK].ensure(nr));
-    HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
+    HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(2 * nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
     HIPCHK(ctx, B[B_PV].ensure(nr * 16)); HIPCHK(ctx, B[B_PVIN].ensure(nr * 16));
     HIPCHK(ctx, B[B_ULEN].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_P].ensure(((size_t)n_units + 2) * 8));
     HIPCHK(ctx, B[B_SCANTMP].ensure(std::max(scantmp, (nr / SCAN_TILE + 2) * 16)));
@@ -195,7 +195,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>(); R.y = B[B_Y].as<uint32_t>();
     R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>(); R.stored = B[B_STORED].as<uint32_t>();
     R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
-    hipLaunchKernelGGL(k_read_table, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, n_reads, dst);
+    // SE: the chunk flags come from per-read adjacency bits written here (the buffer of R.eq2, which only the PE flag kernels use)
+    uint16_t* adj = is_pe ? nullptr : B[B_EQ2].as<uint16_t>();
+    hipLaunchKernelGGL(k_read_table, dim3((n_reads + 4 * RT_NEW - 1) / (4 * RT_NEW)), dim3(256), 0, S, T, R, n_reads, adj, dst);
     const uint32_t ublocks = (n_units + 255) / 256;
     HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 8));
     hipLaunchKernelGGL(k_unit_len, dim3(ublocks), dim3(256), 0, S, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
@@ -262,7 +264,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.end(S);
 
     ctx->timer.begin("chunk_flags+overlap", S);
-    {   // per-chunk AND / MIN accumulators start at all-ones
+    if (!is_pe) hipLaunchKernelGGL(k_chunk_flags_se, dim3(n_chunks), dim3(64), 0, S, C, (const uint16_t*)adj);
+    else {   // per-chunk AND / MIN accumulators start at all-ones
         uint32_t* cbits = B[B_SCAP].as<uint32_t>(); uint32_t* cfail = cbits + nc;      // borrowed: B_SCAP is written later by k_stream_plan
         HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
         const uint32_t fbx = std::max(1u, std::min<uint32_t>((max_reads + 255) / 256, std::max(1u, 4096u / n_chunks)));

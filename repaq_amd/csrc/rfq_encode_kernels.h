@@ -223,32 +223,95 @@ __device__ __forceinline__ void stage_name_rows(const Text& T, uint8_t* rows, ui
         for (int u = 0; u < 8; u++) for (uint32_t i = 64u + (uint32_t)l; i < take[u]; i += 64) rows[(j0 + u) * NAME_STRIDE + i] = src[u][i];   // names > 64 bytes
     }
 }
-__global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, DevStatus* st) {
-    __shared__ uint8_t s_names[4 * 64 * NAME_STRIDE];
+__device__ __forceinline__ bool bytes_eq(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen);
+// equality of rows[a .. a+n) and rows[b .. b+n) (LDS, any alignment), 4 bytes per step
+__device__ __forceinline__ bool lds_bytes_eq(const uint8_t* rows, uint32_t a, uint32_t b, uint32_t n) {
+    for (uint32_t i = 0; i < n; i += 4) {
+        uint32_t x = lds_get4(rows, a + i) ^ lds_get4(rows, b + i);
+        if (n - i < 4) x &= (1u << (8 * (n - i))) - 1u;
+        if (x) return false;
+    }
+    return true;
+}
+// A wave takes 64 consecutive reads, its first one being the previous wave's last (63 new reads per wave): every read but the
+// batch's first then has its predecessor in the same wave, and the "equal to the chunk's read 0" tests of RfqCodec::encodeChunk's
+// pass 1 (src/rfqcodec.cpp:220-250) - equality is transitive - become per-read ADJACENCY bits (adj[g]: read g vs read g-1, bit
+// layout of k_chunk_flags_a plus bit 8 = name2 equal) that a chunk later AND-reduces over its reads but the first.  adj may be null.
+#define RT_NEW 63u
+__global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __restrict__ adj, DevStatus* st) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_names[4 * 64 * NAME_STRIDE + 16];
     const int l = lane_id(), w = wave_id();
-    const uint32_t g = (blockIdx.x * (blockDim.x >> 6) + (uint32_t)w) * 64u + (uint32_t)l;
+    const uint32_t g = (blockIdx.x * (blockDim.x >> 6) + (uint32_t)w) * RT_NEW + (uint32_t)l;
     const bool valid = g < n_reads;
-    uint32_t nb = 0, nl = 0, sl = 0, tl = 0, ql = 0; int s = 0;
+    uint32_t nb = 0, nl = 0, sl = 0, tl = 0, ql = 0, tb = 0; int s = 0;
     if (valid) {
         uint32_t r; read_loc(T, g, s, r);
         const uint32_t* p = T.lo[s] + 4 * (size_t)r;
         const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
-        nb = p0; nl = p1 - 1 - p0; sl = p2 - 1 - p1; tl = p3 - 1 - p2; ql = p4 - 1 - p3;
+        nb = p0; nl = p1 - 1 - p0; sl = p2 - 1 - p1; tl = p3 - 1 - p2; ql = p4 - 1 - p3; tb = p2;
     }
     uint8_t* rows = s_names + (size_t)w * 64 * NAME_STRIDE;
+    // the strand line's first four bytes (almost always just "+"), fetched beside the names
+    uint32_t st4 = 0;
+    if (adj && valid) { const uint8_t* sp = T.fq[s] + tb; for (uint32_t i = 0; i < 4 && i < tl; i++) st4 |= (uint32_t)sp[i] << (8 * i); }
     stage_name_rows(T, rows, nb, nl, s, l);
     __syncthreads();
-    uint32_t err = 0;
+    uint32_t err = 0; Meta m; m.ok = 0; m.name1_len = 0; m.name2_off = 0; m.x = 0; m.y = 0; m.tile = 0; m.lane = 0;
     if (valid) {
         if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
         if (ql < sl) err |= DE_QUAL_SHORT;
-        const Meta m = nl <= NAME_CAP ? dev_parse_name(rows + l * NAME_STRIDE, nl) : dev_parse_name(T.fq[s] + nb, nl);
+        m = nl <= NAME_CAP ? dev_parse_name(rows + l * NAME_STRIDE, nl) : dev_parse_name(T.fq[s] + nb, nl);
         R.len[g] = sl; R.stored[g] = sl;
         R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
+    }
+    if (adj) {                                                            // wave-uniform
+        const uint32_t n1 = m.name1_len, n2o = m.name2_off, n2 = nl - n2o;
+        const uint32_t psl = __shfl_up(sl, 1u), pnl = __shfl_up(nl, 1u), pn1 = __shfl_up(n1, 1u), pn2o = __shfl_up(n2o, 1u), ptl = __shfl_up(tl, 1u), pst4 = __shfl_up(st4, 1u);
+        const uint32_t plane = __shfl_up((uint32_t)m.lane, 1u), ptile = __shfl_up((uint32_t)m.tile, 1u), pnb = __shfl_up(nb, 1u), ptb = __shfl_up(tb, 1u); const int ps = __shfl_up(s, 1u);
+        if (valid && l > 0) {
+            const uint32_t pn2 = pnl - pn2o; uint32_t b = 0;
+            if (sl == psl) b |= 1u << 0;
+            if (n1 == pn1) b |= 1u << 1;
+            if (n2 == pn2) b |= 1u << 2;
+            if (tl == ptl) b |= 1u << 3;
+            if (tl == ptl) {                                               // strand bytes
+                bool eq = st4 == pst4;
+                if (eq && tl > 4) { const uint8_t* a = T.fq[s] + tb; const uint8_t* c = T.fq[ps] + ptb; for (uint32_t i = 4; i < tl && eq; i++) eq = a[i] == c[i]; }
+                if (eq) b |= 1u << 4;
+            }
+            if ((uint32_t)m.lane == plane) b |= 1u << 5;
+            if ((uint32_t)m.tile == ptile) b |= 1u << 6;
+            const bool inl = nl <= NAME_CAP && pnl <= NAME_CAP;              // both names staged in LDS (else compare in global memory)
+            const uint32_t ra = (uint32_t)l * NAME_STRIDE, rb = (uint32_t)(l - 1) * NAME_STRIDE;
+            const uint8_t* ga = T.fq[s] + nb; const uint8_t* gb = T.fq[ps] + pnb;
+            if (n1 == pn1 && (inl ? lds_bytes_eq(rows, ra, rb, n1) : bytes_eq(ga, n1, gb, pn1))) b |= 1u << 7;
+            if (n2 == pn2 && (inl ? lds_bytes_eq(rows, ra + n2o, rb + pn2o, n2) : bytes_eq(ga + n2o, n2, gb + pn2o, pn2))) b |= 1u << 8;
+            adj[g] = (uint16_t)b;
+        }
     }
     const uint32_t fe = wave_min((valid && (err & DE_EMPTY_LINE)) ? g : 0xFFFFFFFFu);
     err = wave_or(err);
     if (l == 0 && err) { atomicOr(&st->err, err); if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); }
+}
+// SE chunks (no mates, no interleave rule): the flag word from the adjacency bits, one wave per chunk
+__global__ void k_chunk_flags_se(ChunkTab C, const uint16_t* __restrict__ adj) {
+    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
+    uint32_t bits = 0x1FFu;
+    for (uint32_t g = f + 1 + (uint32_t)l; g < e; g += 64) bits &= adj[g];
+    bits = wave_and(bits);
+    if (l == 0) {
+        uint32_t fl = 0;
+        if (bits & (1u << 0)) fl |= C_READ_LEN_SAME;
+        if (bits & (1u << 1)) fl |= C_NAME1_LEN_SAME;
+        if (bits & (1u << 2)) fl |= C_NAME2_LEN_SAME;
+        if (bits & (1u << 3)) fl |= C_STRAND_LEN_SAME;
+        if (bits & (1u << 4)) fl |= C_STRAND_SAME;
+        if (bits & (1u << 5)) fl |= C_LANE_SAME;
+        if (bits & (1u << 6)) fl |= C_TILE_SAME;
+        if (bits & (1u << 7)) fl |= C_NAME1_SAME;
+        if (bits & (1u << 8)) fl |= C_NAME2_SAME;
+        C.flags[c] = fl; C.il[c] = 0u;
+    }
 }
 // bases per partition unit (a read, or a pair) + per-block min / max for the partitioner's uniform-length fast path
 // (no atomics: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
