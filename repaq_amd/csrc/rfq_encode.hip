@@ -12,8 +12,10 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ENC_END
 };
+
+static_assert(B_ENC_END <= 64, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
 
 static int fetch_bytes(rfq_ctx* ctx, const uint8_t* d, size_t n, std::string& out) {
     out.resize(n);
@@ -239,6 +241,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_QCAT].ensure(catbytes)); HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
     HIPCHK(ctx, ctx->d_hdr.ensure(sizeof(DevHeader)));
     C.flags = B[B_CFLAGS].as<uint32_t>(); C.il = B[B_IL].as<uint32_t>(); C.hist = B[B_HIST].as<uint32_t>(); C.ncount = B[B_NCOUNT].as<uint32_t>();
+    HIPCHK(ctx, B[B_NMAP].ensure(nc * NMAP_WORDS * 4)); C.nmap = B[B_NMAP].as<uint32_t>();
     C.scap = B[B_SCAP].as<uint32_t>(); C.soff = B[B_SOFF].as<uint64_t>(); C.ssize = B[B_SSIZE].as<uint32_t>(); C.xsize = B[B_XSIZE].as<uint32_t>(); C.ysize = B[B_YSIZE].as<uint32_t>();
     C.qbase = B[B_QBASE].as<uint64_t>(); C.sbase = B[B_SBASE].as<uint64_t>(); C.img_size = B[B_IMGSIZE].as<uint64_t>(); C.img_off = B[B_IMGOFF].as<uint64_t>();
     DevHeader* D = ctx->d_hdr.as<DevHeader>();
@@ -280,7 +283,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.end(S);
 
     ctx->timer.begin("gather", S);
-    HIPCHK(ctx, hipMemsetAsync(C.hist, 0, nc * 256 * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S));
+    HIPCHK(ctx, hipMemsetAsync(C.hist, 0, nc * 256 * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
     {
         // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 128; enough workgroups to fill 256 CUs x 2
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + GT_READS - 1) / GT_READS, std::max(1u, 8192u / n_chunks)));

@@ -46,6 +46,7 @@ struct ChunkTab {                // per-chunk arrays
     uint32_t* il;                // final canBePeInterleaved
     uint32_t* hist;              // [c][256] quality histogram of the chunk
     uint32_t* ncount;            // 'N' bases in the stored sequence
+    uint32_t* nmap;              // [c][NMAP_WORDS] bit b set: the chunk's stored bases contain an 'N' in 4096-base steps [b << shift, (b+1) << shift)
     uint32_t* scap;              // [c][MAX_STREAMS] scratch capacity of each stream
     uint64_t* soff;              // [c][MAX_STREAMS] scratch offset of each stream
     uint32_t* ssize;             // [c][MAX_STREAMS] bytes written by the stream coder
@@ -831,17 +832,23 @@ template <bool SEQ, class Count> __device__ __forceinline__ void tile_emit(const
             alo |= plo; ahi |= phi; filled += take; off += take;
         }
         const uint32_t w0 = (uint32_t)alo, w1 = (uint32_t)(alo >> 32), w2 = (uint32_t)ahi, w3 = (uint32_t)(ahi >> 32);
-        if (!(tune & 16)) count.group(w0, w1, w2, w3);
+        if (!(tune & 16)) count.group(p, w0, w1, w2, w3);
         if (!(tune & 32)) *(uint4*)(out + head + 16 * gi) = make_uint4(w0, w1, w2, w3);
     }
-    if (tid == 0 && head) { uint32_t r = tile_find(t.dst, t.cnt, p0), off = p0 - t.dst[r]; for (uint32_t k = 0; k < head; k++) { const uint8_t b = tile_next<SEQ>(t, r, off); out[k] = b; count(b); } }
-    if (tid == nt - 1 && n > tail0) { const uint32_t p = p0 + tail0; uint32_t r = tile_find(t.dst, t.cnt, p), off = p - t.dst[r]; for (uint32_t k = tail0; k < n; k++) { const uint8_t b = tile_next<SEQ>(t, r, off); out[k] = b; count(b); } }
+    if (tid == 0 && head) { uint32_t r = tile_find(t.dst, t.cnt, p0), off = p0 - t.dst[r]; for (uint32_t k = 0; k < head; k++) { const uint8_t b = tile_next<SEQ>(t, r, off); out[k] = b; count(p0 + k, b); } }
+    if (tid == nt - 1 && n > tail0) { const uint32_t p = p0 + tail0; uint32_t r = tile_find(t.dst, t.cnt, p), off = p - t.dst[r]; for (uint32_t k = tail0; k < n; k++) { const uint8_t b = tile_next<SEQ>(t, r, off); out[k] = b; count(p0 + k, b); } }
 }
+// Where the N bases of a chunk are, at the granularity of the position coder's 4096-base steps (256 bits per chunk; chunks of more
+// than 256 steps fold 2^shift steps into a bit): the N-position coder skips the steps - nearly all of them - that hold no N.
+#define NMAP_WORDS 8u
+__device__ __forceinline__ uint32_t nmap_shift(uint32_t n_bases) { const uint32_t steps = (n_bases + 4095u) / 4096u; uint32_t sh = 0; while ((steps >> sh) > 32u * NMAP_WORDS) sh++; return sh; }
+__device__ __forceinline__ void nmap_mark(uint32_t* m, uint32_t shift, uint32_t pos) { const uint32_t b = (pos >> 12) >> shift; atomicOr(&m[b >> 5], 1u << (b & 31u)); }
+__device__ __forceinline__ bool nmap_test(const uint32_t* m, uint32_t shift, uint32_t step) { const uint32_t b = step >> shift; return (m[b >> 5] >> (b & 31u)) & 1u; }
 // histogram / N counters: group() takes 16 packed bytes (SWAR: no per-byte branches), operator() one byte
 struct QualCount {
     uint32_t* sh; uint32_t major; uint32_t hot;
-    __device__ __forceinline__ void operator()(uint8_t q) { if (q == major) hot++; else atomicAdd(&sh[q], 1u); }
-    __device__ __forceinline__ void group(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    __device__ __forceinline__ void operator()(uint32_t, uint8_t q) { if (q == major) hot++; else atomicAdd(&sh[q], 1u); }
+    __device__ __forceinline__ void group(uint32_t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
         const uint32_t pat = major * 0x01010101u;
         const uint32_t m = eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12);
         hot += (uint32_t)__popc(m);
@@ -850,12 +857,13 @@ struct QualCount {
         while (rest) { const int k = __ffs((int)rest) - 1; rest &= rest - 1; const uint32_t q = (uint32_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu); atomicAdd(&sh[q], 1u); }
     }
 };
-struct NCount {
-    uint32_t n;
-    __device__ __forceinline__ void operator()(uint8_t b) { if (b == 'N') n++; }
-    __device__ __forceinline__ void group(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+struct NCount {                          // p = chunk-relative position of the byte / of the group's first byte (a group never crosses a 4096 boundary)
+    uint32_t n; uint32_t* nmap; uint32_t shift;
+    __device__ __forceinline__ void operator()(uint32_t p, uint8_t b) { if (b == 'N') { n++; nmap_mark(nmap, shift, p); } }
+    __device__ __forceinline__ void group(uint32_t p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
         const uint32_t pat = (uint32_t)'N' * 0x01010101u;
-        n += (uint32_t)__popc(eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12));
+        const uint32_t k = (uint32_t)__popc(eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12));
+        if (k) { n += k; nmap_mark(nmap, shift, p); }
     }
 };
 
@@ -877,7 +885,7 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     const bool two = T.paired == 1; const uint32_t upr = T.upr;
     uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup
     const uint32_t gs = f + blockIdx.x * per; const uint32_t ge = gs + per < e ? gs + per : e;
-    QualCount qc; qc.sh = sh; qc.major = D->major & 0xFFu; qc.hot = 0; NCount nc; nc.n = 0;
+    QualCount qc; qc.sh = sh; qc.major = D->major & 0xFFu; qc.hot = 0; NCount nc; nc.n = 0; nc.nmap = C.nmap + (size_t)c * NMAP_WORDS; nc.shift = nmap_shift(R.pv[e].d - ps0);
     uint32_t cur = gs;
     while (cur < ge) {                                                   // block-uniform
         tk0 = clock64();
@@ -918,8 +926,8 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
                 const bool rc = il && ((g - f) & 1u); int ov = 0; if (rc && enc) ov = (int)ovb[g >> 1] - shift;
                 const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u, keep = len - (uint32_t)(ov < 0 ? -ov : ov);
                 uint8_t* qo = qd + (R.pq[g] - pq0); uint8_t* so = sd + (R.pv[g].d - ps0);
-                for (uint32_t i = tid; i < len; i += blockDim.x) { const uint8_t q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = q; qc(q); }
-                for (uint32_t i = tid; i < keep; i += blockDim.x) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b; nc(b); }
+                for (uint32_t i = tid; i < len; i += blockDim.x) { const uint8_t q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = q; qc(0u, q); }
+                for (uint32_t i = tid; i < keep; i += blockDim.x) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b; nc(R.pv[g].d - ps0 + i, b); }
             }
             cur += upr; __syncthreads(); continue;
         }
@@ -1116,17 +1124,21 @@ struct PcStream {
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
 // with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  EMIT writes the bytes at S[t].out[0..).
 template <bool EMIT, int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
-                                                                           PcStream (&S)[G], uint32_t step0, uint32_t step1) {
+                                                                           PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
     // software pipeline, two steps deep: raw bytes of step+2 are in flight while step is coded; a step's raw bytes become masks
     // only one step after they were requested, so the wave never waits on the load it has just issued
     const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;                 // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
-    Raw64 raw_n = pc_load_raw(B, len, q0 + 4096u);
-    { const Raw64 r0 = pc_load_raw(B, len, q0);
+    // (N positions: a step whose bit in the chunk's N map is clear holds no match - its 4096 bytes are not even loaded)
+    auto load = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (nmap && !nmap_test(nmap, nshift, step_)) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; } return pc_load_raw(B, len, p_); };
+    const uint32_t nst = (len + 4095u) / 4096u;
+    auto loadc = [&](uint32_t step_, uint32_t p_) -> Raw64 { return load(step_ < nst ? step_ : nst - 1u, step_ < nst ? p_ : len); };
+    Raw64 raw_n = loadc(step0 + 1, q0 + 4096u);
+    { const Raw64 r0 = loadc(step0, q0);
 #pragma unroll
       for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D); S[t].outpos = 0; } }
-    raw_n = pc_load_raw(B, len, q0 + 8192u);
+    raw_n = loadc(step0 + 2, q0 + 8192u);
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
 #pragma unroll
@@ -1173,19 +1185,20 @@ template <bool EMIT, int MODE, int G> __device__ __forceinline__ void wave_pos_e
         }
 #pragma unroll
         for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D); }
-        raw_n = pc_load_raw(B, len, p0 + 12288u);
+        raw_n = loadc(step + 3, p0 + 12288u);
     }
 }
 // last match / last non-match inside steps [step0, step1) (or -1) of every active stream: the summary pass, loads pipelined like the coder's
-template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D, PcStream (&S)[G], uint32_t step0, uint32_t step1) {
+template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D, PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift) {
     const int l = lane_id();
-    const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;
-    Raw64 raw_c = pc_load_raw(B, len, q0), raw_n = pc_load_raw(B, len, q0 + 4096u);
+    const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l; const uint32_t nst = (len + 4095u) / 4096u;
+    auto loadc = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (step_ >= nst || (nmap && !nmap_test(nmap, nshift, step_))) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; } return pc_load_raw(B, len, p_); };
+    Raw64 raw_c = loadc(step0, q0), raw_n = loadc(step0 + 1, q0 + 4096u);
 #pragma unroll
     for (int t = 0; t < G; t++) { S[t].last1 = -1; S[t].last0 = -1; }
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
-        const Raw64 raw_nn = pc_load_raw(B, len, p0 + 8192u);
+        const Raw64 raw_nn = loadc(step + 2, p0 + 8192u);
 #pragma unroll
         for (int t = 0; t < G; t++) {
             if (!S[t].on) continue;
@@ -1206,7 +1219,8 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_grou
 // the chunk (histogram) are skipped outright.
 template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg,
-                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, DevStatus* st) {
+                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st) {
+    const uint32_t nshift = nmap ? nmap_shift(len) : 0u;
     const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
     const uint32_t step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
     PcStream S[G]; size_t kk[G]; bool any = false;
@@ -1228,7 +1242,7 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
     }
     if (!any) return;                                                      // wave-uniform
     if (PASS == 0) {
-        wave_pos_summary_group<MODE, G>(B, len, D, S, step0, step1);
+        wave_pos_summary_group<MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
 #pragma unroll
         for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) { const size_t si = kk[t] * n_seg + seg; segc[2 * si] = S[t].last1; segc[2 * si + 1] = S[t].last0; segb[si] = 0; }
         return;
@@ -1250,10 +1264,10 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
         }
     }
     if (PASS == 1) {
-        wave_pos_encode_group<false, MODE, G>(B, len, D, S, step0, step1);
+        wave_pos_encode_group<false, MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
 #pragma unroll
         for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) segb[kk[t] * n_seg + seg] = S[t].outpos;
-    } else wave_pos_encode_group<true, MODE, G>(B, len, D, S, step0, step1);
+    } else wave_pos_encode_group<true, MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
 }
 template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg, uint32_t n_chunks,
@@ -1264,9 +1278,9 @@ template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const Dev
     const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = rest % (n_qgroups + 2), seg = rest / (n_qgroups + 2);
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
-    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, grp * PC_G, nn, st);
-    else if (grp == n_qgroups) pc_run<PASS, PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, st);
-    else pc_run<PASS, PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, st);
+    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
+    else if (grp == n_qgroups) pc_run<PASS, PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st);
+    else pc_run<PASS, PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
