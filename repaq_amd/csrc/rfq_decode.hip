@@ -120,7 +120,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
     hipLaunchKernelGGL(k_dec_fill, dim3(2048), dim3(256), 0, S, qdec, (uint64_t)qbytes, D);
     const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
-    hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec);
+    hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
     if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
         // position streams in POS_SEG-byte segments: summary -> link -> emit (see rfq_decode_kernels.h)
         const uint32_t nstr = HH.n_normal + 1, maxseg = hs.max_stream / POS_SEG + 1; const size_t nseg = (size_t)n_chunks * nstr * maxseg;
@@ -130,7 +130,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
                            B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), maxseg, dst, (uint64_t)a->n);
         hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
                            (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
-        hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
+        // (the coordinate decoder follows the unpack on the main stream: fill + unpack + coords balance summary + link on the aux stream)
+        hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
         if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
         hipLaunchKernelGGL(k_dec_pos_emit, dim3(maxseg, nstr, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
                            (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n);

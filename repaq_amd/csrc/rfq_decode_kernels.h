@@ -160,23 +160,37 @@ __global__ void k_dec_bases(const DChunk* __restrict__ CH, DReadTab R, uint64_t*
 
 // 2-bit unpack (src/rfqcodec.cpp:833-853): grid (blocks, n_chunks).  One thread turns 4 packed bytes into 16 bases and stores them
 // as one aligned uint4 (the chunk's base in sdec is 64-byte aligned); byte stores cost ~30 cycles per wave instruction.
+__device__ __forceinline__ uint32_t ld_word_lim(const uint8_t* p, const uint8_t* lim);
 __device__ __forceinline__ uint32_t unpack4(uint32_t byte) {              // 4 bases of one packed byte -> 4 ASCII bytes (G A T C = 0 1 2 3)
     uint32_t w = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) { const uint32_t code = (byte >> (2 * b)) & 3u; w |= (code == 0 ? (uint32_t)'G' : (code == 1 ? (uint32_t)'A' : (code == 2 ? (uint32_t)'T' : (uint32_t)'C'))) << (8 * b); }
     return w;
 }
-__global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec) {
+__global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec, uint64_t img_bytes) {
+    __shared__ uint32_t s_lut[256];                                  // packed byte -> its four bases
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = unpack4(i);
+    __syncthreads();
     const DChunk d = CH[blockIdx.y]; const uint32_t f = d.rbase;
     const uint32_t n = R.pv[f + d.reads].d - R.pv[f].d;          // stored bases of the chunk
-    const uint8_t* src = img + d.off + d.o_seq; uint8_t* dst = sdec + sbase[blockIdx.y];
-    const uint32_t ngroups = (n + 15) / 16;
-    for (uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += gridDim.x * blockDim.x) {
-        uint32_t w[4];
+    const uint8_t* src = img + d.off + d.o_seq; uint8_t* dst = sdec + sbase[blockIdx.y]; const uint8_t* lim = img + img_bytes;
+    const uint32_t ngroups = (n + 15) / 16, NT = gridDim.x * blockDim.x;
+    // a group's four packed bytes sit at any phase: two aligned words + a funnel shift; four groups per thread in flight
+    const uint32_t ph = (uint32_t)((uintptr_t)src & 3u); const uint8_t* sa = src - ph; const uint32_t sh = ph * 8u;
+    for (uint32_t g0 = blockIdx.x * blockDim.x + threadIdx.x; g0 < ngroups; g0 += 4 * NT) {
+        uint32_t lo[4], hi[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t i = 4 * gi + (uint32_t)k; w[k] = i < d.seq_size ? unpack4(src[i]) : 0x4E4E4E4Eu; }   // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
-        if (16 * gi + 16 <= n) *(uint4*)(dst + 16 * (size_t)gi) = make_uint4(w[0], w[1], w[2], w[3]);
-        else for (uint32_t p = 16 * gi; p < n; p++) dst[p] = (uint8_t)(w[(p >> 2) & 3u] >> (8 * (p & 3u)));
+        for (int u = 0; u < 4; u++) { const uint32_t gi = g0 + (uint32_t)u * NT; lo[u] = hi[u] = 0; if (gi < ngroups) { lo[u] = ld_word_lim(sa + 4 * (size_t)gi, lim); if (ph) hi[u] = ld_word_lim(sa + 4 * (size_t)gi + 4, lim); } }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t gi = g0 + (uint32_t)u * NT; if (gi >= ngroups) continue;
+            const uint32_t pk = ph ? (uint32_t)((((uint64_t)hi[u] << 32) | lo[u]) >> sh) : lo[u];
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t i = 4 * gi + (uint32_t)k; w[k] = i < d.seq_size ? s_lut[(pk >> (8 * k)) & 0xFFu] : 0x4E4E4E4Eu; }   // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
+            if (16 * gi + 16 <= n) *(uint4*)(dst + 16 * (size_t)gi) = make_uint4(w[0], w[1], w[2], w[3]);
+            else for (uint32_t p = 16 * gi; p < n; p++) dst[p] = (uint8_t)(w[(p >> 2) & 3u] >> (8 * (p & 3u)));
+        }
     }
 }
 
