@@ -75,9 +75,14 @@ static inline int rfq_fail(rfq_ctx* c, int code, const char* fmt, ...) {
 #define SCAN_TILE (SCAN_TPB * SCAN_ITEMS)
 
 template <class T> __global__ void k_scan_reduce(const T* __restrict__ in, T* __restrict__ partial, uint64_t n) {
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    // (a sum does not care about order: item i of thread t is element i * SCAN_TPB + t of the tile, so every load is coalesced)
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x;
+    T v[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) v[i] = base + (uint64_t)i * SCAN_TPB < n ? in[base + (uint64_t)i * SCAN_TPB] : T();
     T acc = T();
-    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) acc = acc + in[base + i];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) acc = acc + v[i];
     T tot; (void)block_excl_sum<T>(acc, &tot);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }

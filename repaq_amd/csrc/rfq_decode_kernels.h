@@ -629,6 +629,7 @@ __device__ __forceinline__ void item_jk(uint32_t idx, uint32_t W, float rcp, uin
     if ((int)k < 0) { j--; k += W; } else if (k >= W) { j++; k -= W; }
 }
 #define ET_READS 32
+#define EM_ROW 17                 // words per read in s_meta: 16 used + 1 pad, so that lanes reading the same field of consecutive reads hit 32 different banks
 #define ET_OCAP 16384u            // output tile bytes (split: half per stream)
 #define ET_SCAP 6144u             // staged qualities / stored bases
 #define ET_N1CAP 4096u            // staged name1 / name2 / strand pieces of the tile (fall back to global memory when larger)
@@ -656,7 +657,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
 #define s_n14 (s_src4 + EG_N1)
 #define s_n24 (s_src4 + EG_N2)
 #define s_st4 (s_src4 + EG_ST)
-    __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta[(ET_READS + 1) * 16]; __shared__ uint32_t s_mx[8];   // s_mx: longest pieces among the candidates
+    __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta[(ET_READS + 1) * EM_ROW]; __shared__ uint32_t s_mx[8];   // s_mx: longest pieces among the candidates
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
     const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
@@ -675,7 +676,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         if (tid == 0) s_cnt = 0;
         if (tid <= ET_READS && cur + tid <= re) {
             const uint32_t r = cur + tid, g = g0 + tid; const U4 tp = R.tp[g]; const U4 pv = R.pv[g]; const bool odd = (r & 1u) != 0;
-            uint32_t* m = s_meta + 16 * tid;
+            uint32_t* m = s_meta + EM_ROW * tid;
             m[12] = tp.a; m[13] = tp.b; m[14] = pv.d - pv0.d; m[15] = R.pq[g] - pq0;          // prefix values (also valid for the sentinel)
             m[7] = pv.a - pv0.a; m[8] = pv.b - pv0.b; m[9] = pv.c - pv0.c;
             if (r < re) {
@@ -687,7 +688,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
             }
         }
         if (tid < 64) {                                                    // wave 0 holds every candidate (ET_READS <= 64)
-            const bool on = tid < ET_READS && cur + tid < re; const uint32_t* m = s_meta + 16 * tid;
+            const bool on = tid < ET_READS && cur + tid < re; const uint32_t* m = s_meta + EM_ROW * tid;
             const uint32_t v1 = wave_max(on ? m[4] : 0u), v2 = wave_max(on ? m[5] : 0u), v3 = wave_max(on ? m[6] : 0u), v4 = wave_max(on ? m[1] : 0u);
             const uint32_t v5 = wave_max(on && (int)m[2] < 0 ? (uint32_t)(-(int)m[2]) : 0u);
             if (tid == 0) { s_mx[0] = v1; s_mx[1] = v2; s_mx[2] = v3; s_mx[3] = v4; s_mx[4] = v5; }
@@ -699,7 +700,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         bool fits = false;
         if (tid < ET_READS && cur + tid < re) {
             uint32_t mm = (tid + 2u) & ~1u; if (cur + mm > re) mm = re - cur;  // whole pairs (a lone last read of an SE chunk is fine)
-            const uint32_t* me = s_meta + 16 * mm;
+            const uint32_t* me = s_meta + EM_ROW * mm;
             fits = (me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 48u <= ET_SCAP && (me[14] - mb[14]) + 48u <= ET_SCAP
                 && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)
                 && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP);
@@ -709,7 +710,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         uint32_t cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
         const bool tiled = cnt > 0;
         if (!tiled) { cnt = 2; if (cur + cnt > re) cnt = re - cur; }      // oversized read / pair: straight to global memory, byte-wise
-        const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + 16 * cnt;
+        const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + EM_ROW * cnt;
         U4 tp0, tp1; tp0.a = mb[12]; tp0.b = mb[13]; tp1.a = me[12]; tp1.b = me[13];
         const uint32_t q0 = mb[15], s0 = mb[14];
         const uint64_t qa = qg0 + q0, qe = qg0 + me[15], sa = sg0 + s0, se = sg0 + me[14];
@@ -748,7 +749,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                 const uint32_t rs_ = slot;
                 const uint32_t j = rs_ % ET_READS, kind = rs_ / ET_READS;         // 0,1 quality halves; 2,3 sequence halves; 4 borrowed part; 5 name1; 6 middle + newlines; 7 name2 + strand
                 if (j >= cnt) continue;
-                const uint32_t* m = s_meta + 16 * j; const bool odd = ((cur + j) & 1u) != 0, to2 = split && odd, rc = il && odd;
+                const uint32_t* m = s_meta + EM_ROW * j; const bool odd = ((cur + j) & 1u) != 0, to2 = split && odd, rc = il && odd;
                 const uint32_t rec = (to2 ? recB : recA) + m[0], len = m[1], mid = m[11];
                 if (kind == 6) {                                              // the four newlines; capacity check
                     const uint32_t e0 = m[10] - 1, e1 = e0 + 1 + len, e2 = e1 + 1 + m[6], e3 = e2 + 1 + len;
@@ -810,7 +811,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
             }
         } else
         for (uint32_t j = (uint32_t)wave_id(); j < cnt; j += wpb) {
-            const uint32_t r = cur + j, g = g0 + j; const uint32_t* m = s_meta + 16 * j;
+            const uint32_t r = cur + j, g = g0 + j; const uint32_t* m = s_meta + EM_ROW * j;
             const bool odd = (r & 1u) != 0; const bool to2 = split && odd;
             EmitRead e;
             e.len = m[1]; e.ov = (int)m[2]; e.prevlen = m[3]; e.n1 = m[4]; e.n2 = m[5]; e.stl = m[6];
