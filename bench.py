@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encode-only", action="store_true")
     ap.add_argument("--pe", action="store_true", help="profiling aid: PE150 two-file workload (configs[2] shape, reads/2 pairs) instead of the SE150 headline workload")
+    ap.add_argument("--bgi", action="store_true", help="profiling aid: BGI-style PE100 two-file workload (configs[4] shape: long names, 40 quality values, N runs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (kernel ablation runs with RFQ_TUNE set)")
     args = ap.parse_args()
 
@@ -78,7 +79,10 @@ def main():
 
     seed = 2 + rank
     from repaq_amd import PE_TWO_FILES
-    if args.pe:
+    if args.bgi:
+        args.pe = True
+        fq1, fq2 = O.gen(O.BGI_PE100, args.reads // 2, seed=seed + 2, nppm=20, n_quals=40)
+    elif args.pe:
         fq1, fq2 = O.gen(O.NOVA_PE150, args.reads // 2, seed=seed + 1, nppm=20)
     else:
         fq1, fq2 = O.gen(O.NOVA_SE150, args.reads, seed=seed, nppm=20)
@@ -164,11 +168,11 @@ def main():
             # separate rocprofv3 --pmc runs of this same command, KB units, FETCH_SIZE x2 on gfx950) — only valid for the default workload
             traffic = None
             STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
-                             "chunk_flags+overlap": ["k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
+                             "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
                              "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder<0>", "k_pos_coder<1>", "k_pos_coder<2>"],
                              "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
                              "dec:walk": ["k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
-                             "dec:streams": ["k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos", "k_dec_except", "k_dec_coords"],
+                             "dec:streams": ["k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_coords", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_except"],
                              "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit"]}
             pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if args.reads == 2_800_000 and args.chunk_kb == 1000 and not args.pe and os.path.exists(pj):

@@ -12,7 +12,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 64, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -189,7 +189,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     const size_t nr = (size_t)n_reads + 2;
     HIPCHK(ctx, B[B_LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N1LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N2OFF].ensure(nr * 4));
     HIPCHK(ctx, B[B_X].ensure(nr * 4)); HIPCHK(ctx, B[B_Y].ensure(nr * 4)); HIPCHK(ctx, B[B_TILE].ensure(nr * 2)); HIPCHK(ctx, B[B_LANE].ensure(nr)); HIPCHK(ctx, B[B_OK].ensure(nr));
-    HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(2 * nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
+    HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
     HIPCHK(ctx, B[B_PV].ensure(nr * 16)); HIPCHK(ctx, B[B_PVIN].ensure(nr * 16));
     HIPCHK(ctx, B[B_ULEN].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_P].ensure(((size_t)n_units + 2) * 8));
     HIPCHK(ctx, B[B_SCANTMP].ensure(std::max(scantmp, (nr / SCAN_TILE + 2) * 16)));
@@ -197,9 +197,10 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>(); R.y = B[B_Y].as<uint32_t>();
     R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>(); R.stored = B[B_STORED].as<uint32_t>();
     R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
-    // SE: the chunk flags come from per-read adjacency bits written here (the buffer of R.eq2, which only the PE flag kernels use)
-    uint16_t* adj = is_pe ? nullptr : B[B_EQ2].as<uint16_t>();
-    hipLaunchKernelGGL(k_read_table, dim3((n_reads + 4 * RT_NEW - 1) / (4 * RT_NEW)), dim3(256), 0, S, T, R, n_reads, adj, dst);
+    // the chunk flags come from per-read adjacency bits (and, PE, per-pair mate summaries) written here
+    HIPCHK(ctx, B[B_ADJ].ensure(2 * nr)); HIPCHK(ctx, B[B_PINFO].ensure(2 * nr + 16));
+    uint16_t* adj = B[B_ADJ].as<uint16_t>(); uint32_t* pinfo = is_pe ? B[B_PINFO].as<uint32_t>() : nullptr;
+    hipLaunchKernelGGL(k_read_table, dim3((n_reads + 4 * RT_NEW - 1) / (4 * RT_NEW)), dim3(256), 0, S, T, R, n_reads, adj, pinfo, dst);
     const uint32_t ublocks = (n_units + 255) / 256;
     HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 8));
     hipLaunchKernelGGL(k_unit_len, dim3(ublocks), dim3(256), 0, S, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
@@ -268,12 +269,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
 
     ctx->timer.begin("chunk_flags+overlap", S);
     if (!is_pe) hipLaunchKernelGGL(k_chunk_flags_se, dim3(n_chunks), dim3(64), 0, S, C, (const uint16_t*)adj);
-    else {   // per-chunk AND / MIN accumulators start at all-ones
-        uint32_t* cbits = B[B_SCAP].as<uint32_t>(); uint32_t* cfail = cbits + nc;      // borrowed: B_SCAP is written later by k_stream_plan
+    else {
+        // PE: adjacency path first; chunks where the interleave test fails mid-chunk (rare) go through the read-0 kernels, which exit at
+        // once for every other chunk.  Their per-chunk AND / MIN accumulators start at all-ones.
+        uint32_t* cbits = B[B_SCAP].as<uint32_t>(); uint32_t* cfail = cbits + nc; uint32_t* redo = cfail + nc;   // borrowed: B_SCAP is written later by k_stream_plan
         HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
+        hipLaunchKernelGGL(k_chunk_flags_pe, dim3(n_chunks), dim3(64), 0, S, T, R, C, (const DevHeader*)D, (const uint16_t*)adj, (const uint32_t*)pinfo, redo);
         const uint32_t fbx = std::max(1u, std::min<uint32_t>((max_reads + 255) / 256, std::max(1u, 4096u / n_chunks)));
-        hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, is_pe ? 1 : 0, cbits, cfail);
-        hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail);
+        hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, 1, cbits, cfail, (const uint32_t*)redo);
+        hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, 1, (const uint32_t*)cbits, (const uint32_t*)cfail, (const uint32_t*)redo);
     }
     if (is_pe) { const uint32_t np = reads_used / 2; hipLaunchKernelGGL(k_overlap, dim3(std::min<uint32_t>((np + 63) / 64, 65535u * 4u)), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np); }
     hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, B[B_PVIN].as<U4>(), n_reads);

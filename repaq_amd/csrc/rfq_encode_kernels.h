@@ -234,12 +234,15 @@ __device__ __forceinline__ bool lds_bytes_eq(const uint8_t* rows, uint32_t a, ui
     }
     return true;
 }
-// A wave takes 64 consecutive reads, its first one being the previous wave's last (63 new reads per wave): every read but the
-// batch's first then has its predecessor in the same wave, and the "equal to the chunk's read 0" tests of RfqCodec::encodeChunk's
+// A wave takes 64 consecutive reads, its first two being the previous wave's last two (62 new reads per wave, so that mates stay in
+// the same wave and lane parity = read parity): every read but the batch's first then has its predecessor in the same wave, and the "equal to the chunk's read 0" tests of RfqCodec::encodeChunk's
 // pass 1 (src/rfqcodec.cpp:220-250) - equality is transitive - become per-read ADJACENCY bits (adj[g]: read g vs read g-1, bit
-// layout of k_chunk_flags_a plus bit 8 = name2 equal) that a chunk later AND-reduces over its reads but the first.  adj may be null.
-#define RT_NEW 63u
-__global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __restrict__ adj, DevStatus* st) {
+// layout of k_chunk_flags_a plus bit 8 = name2 equal to read g-1's, bit 9 = name2 equal to read g-2's) that a chunk later AND-reduces
+// over its reads but the first.  PE: pinfo[g >> 1] summarises the mate tests of pair (g-1, g) that do not need the file header yet:
+//   bit 0 name2 lengths equal, bits 1-2 number of differing name2 bytes (0, 1, 2 = more), bit 3 lane / tile / x / y differ,
+//   bits 8-15 position of the first difference, bits 16-23 the R2 byte there.  adj / pinfo may be null.
+#define RT_NEW 62u
+__global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __restrict__ adj, uint32_t* __restrict__ pinfo, DevStatus* st) {
     __shared__ __attribute__((aligned(16))) uint8_t s_names[4 * 64 * NAME_STRIDE + 16];
     const int l = lane_id(), w = wave_id();
     const uint32_t g = (blockIdx.x * (blockDim.x >> 6) + (uint32_t)w) * RT_NEW + (uint32_t)l;
@@ -269,6 +272,8 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
         const uint32_t n1 = m.name1_len, n2o = m.name2_off, n2 = nl - n2o;
         const uint32_t psl = __shfl_up(sl, 1u), pnl = __shfl_up(nl, 1u), pn1 = __shfl_up(n1, 1u), pn2o = __shfl_up(n2o, 1u), ptl = __shfl_up(tl, 1u), pst4 = __shfl_up(st4, 1u);
         const uint32_t plane = __shfl_up((uint32_t)m.lane, 1u), ptile = __shfl_up((uint32_t)m.tile, 1u), pnb = __shfl_up(nb, 1u), ptb = __shfl_up(tb, 1u); const int ps = __shfl_up(s, 1u);
+        const uint32_t px = __shfl_up(m.x, 1u), py = __shfl_up(m.y, 1u);
+        const uint32_t qnl = __shfl_up(nl, 2u), qn2o = __shfl_up(n2o, 2u), qnb = __shfl_up(nb, 2u); const int qs = __shfl_up(s, 2u);   // same-parity predecessor
         if (valid && l > 0) {
             const uint32_t pn2 = pnl - pn2o; uint32_t b = 0;
             if (sl == psl) b |= 1u << 0;
@@ -287,7 +292,24 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
             const uint8_t* ga = T.fq[s] + nb; const uint8_t* gb = T.fq[ps] + pnb;
             if (n1 == pn1 && (inl ? lds_bytes_eq(rows, ra, rb, n1) : bytes_eq(ga, n1, gb, pn1))) b |= 1u << 7;
             if (n2 == pn2 && (inl ? lds_bytes_eq(rows, ra + n2o, rb + pn2o, n2) : bytes_eq(ga + n2o, n2, gb + pn2o, pn2))) b |= 1u << 8;
+            if (l > 1 && pinfo) {                                              // PE: the previous pair's mate of the same side
+                const uint32_t qn2 = qnl - qn2o; const bool inl2 = nl <= NAME_CAP && qnl <= NAME_CAP;
+                if (n2 == qn2 && (inl2 ? lds_bytes_eq(rows, ra + n2o, (uint32_t)(l - 2) * NAME_STRIDE + qn2o, n2) : bytes_eq(ga + n2o, n2, T.fq[qs] + qnb + qn2o, qn2))) b |= 1u << 9;
+            }
             adj[g] = (uint16_t)b;
+            if (pinfo && (g & 1u)) {                                           // (g-1, g) is a pair: a = R1's name2, b = R2's name2
+                uint32_t info = 0, nd = 0, pd = 0, bch = 0;
+                if (n2 == pn2) {
+                    info |= 1u;
+                    for (uint32_t i = 0; i < n2 && nd < 2; i++) {
+                        const uint8_t ca = inl ? rows[rb + pn2o + i] : gb[pn2o + i], cb = inl ? rows[ra + n2o + i] : ga[n2o + i];
+                        if (ca != cb) { if (nd == 0) { pd = i; bch = cb; } nd++; }
+                    }
+                }
+                if ((uint32_t)m.lane != plane || (uint32_t)m.tile != ptile || m.x != px || m.y != py) info |= 1u << 3;
+                info |= (nd > 2 ? 2u : nd) << 1; info |= (pd & 0xFFu) << 8; info |= (bch & 0xFFu) << 16;
+                pinfo[g >> 1] = info;
+            }
         }
     }
     const uint32_t fe = wave_min((valid && (err & DE_EMPTY_LINE)) ? g : 0xFFFFFFFFu);
@@ -567,7 +589,8 @@ __device__ __forceinline__ uint32_t name2_len_of(const Text& T, const ReadTab& R
 // Pass A — grid (blocks, n_chunks): a wave takes 64 consecutive reads of the chunk, stages their names row by row in LDS with
 // coalesced loads (as k_read_table does), and every lane compares its read with the chunk's read 0 (row 64) and, for odd reads of a
 // PE chunk, with its mate (the previous row).  Results are AND / MIN-combined per chunk with one atomic per wave.
-__global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail) {
+__global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only) {
+    if (only && !only[blockIdx.y]) return;                                // only the chunks the adjacency path could not settle
     __shared__ uint8_t s_names[4 * 65 * NAME_STRIDE];
     const uint32_t c = blockIdx.y, f = C.first[c], e = C.first[c + 1];
     const int l = lane_id(), w = wave_id(); const uint32_t wpb = blockDim.x >> 6;
@@ -615,7 +638,8 @@ __global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* 
     if (l == 0) { if (bits != 0xFF) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
 }
 // Pass B — one wave per chunk: name2Same with the order-dependent rule of src/rfqcodec.cpp:233-250 (Q12), then the flag word
-__global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, const uint32_t* __restrict__ cbits, const uint32_t* __restrict__ cfail) {
+__global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, const uint32_t* __restrict__ cbits, const uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only) {
+    if (only && !only[blockIdx.x]) return;
     const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
     const bool can0 = is_pe && D->support_interleaved;
     const uint32_t bits = cbits[c] & 0xFFu, fail = cfail[c];
@@ -643,6 +667,46 @@ __global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restri
         if (bits & (1u << 7)) fl |= C_NAME1_SAME;
         if (n2same) fl |= C_NAME2_SAME;
         C.flags[c] = fl; C.il[c] = il ? 1u : 0u;
+    }
+}
+
+// PE chunks from the adjacency bits and the pair summaries of k_read_table, one wave per chunk.  A chunk whose interleave test
+// fails somewhere (mates that do not match: the order-dependent name2 rule of src/rfqcodec.cpp:233-250, Q12) is left to
+// k_chunk_flags_a / _b (redo[c] = 1); everywhere else: all reads agree with read 0 <=> every read agrees with its predecessor,
+// and "every R1 name2 equals read 0's" <=> every R1 name2 equals the previous pair's.
+__global__ void k_chunk_flags_pe(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint16_t* __restrict__ adj, const uint32_t* __restrict__ pinfo, uint32_t* __restrict__ redo) {
+    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
+    const bool can0 = D->support_interleaved != 0; const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
+    uint32_t bits = 0xFFu, eq_all = 1, eq_even = 1, failed = 0;
+    for (uint32_t g = f + (uint32_t)l; g < e; g += 64) {
+        const uint32_t rel = g - f;
+        if (rel) { const uint32_t a = adj[g]; bits &= a & 0xFFu; eq_all &= (a >> 8) & 1u; if (rel >= 2 && !(rel & 1u)) eq_even &= (a >> 9) & 1u; }
+        if (can0 && (rel & 1u)) {
+            const uint32_t info = pinfo[g >> 1], nd = (info >> 1) & 3u;
+            bool ok = false;                                                 // (R1's name2 with [dpos] = dch) == R2's name2
+            if (info & 1u) {
+                if (nd == 1) ok = dch != 0 && ((info >> 8) & 0xFFu) == dpos && ((info >> 16) & 0xFFu) == dch;
+                else if (nd == 0) { ok = true; if (dch != 0 && dpos < name2_len_of(T, R, g)) ok = line_ptr(T, g, 0)[R.name2_off[g] + dpos] == (uint8_t)dch; }
+            }
+            if (!ok || (info & 8u)) failed = 1;
+        }
+    }
+    bits = wave_and(bits); eq_all = wave_and(eq_all); eq_even = wave_and(eq_even); failed = wave_or(failed);
+    if (l == 0) {
+        if (can0 && failed) { redo[c] = 1; return; }
+        redo[c] = 0;
+        uint32_t fl = 0;
+        if (can0) fl |= C_PE_INTERLEAVED;
+        if (bits & (1u << 0)) fl |= C_READ_LEN_SAME;
+        if (bits & (1u << 1)) fl |= C_NAME1_LEN_SAME;
+        if (bits & (1u << 2)) fl |= C_NAME2_LEN_SAME;
+        if (bits & (1u << 3)) fl |= C_STRAND_LEN_SAME;
+        if (bits & (1u << 4)) fl |= C_STRAND_SAME;
+        if (bits & (1u << 5)) fl |= C_LANE_SAME;
+        if (bits & (1u << 6)) fl |= C_TILE_SAME;
+        if (bits & (1u << 7)) fl |= C_NAME1_SAME;
+        if (can0 ? eq_even : eq_all) fl |= C_NAME2_SAME;
+        C.flags[c] = fl; C.il[c] = can0 ? 1u : 0u;
     }
 }
 
