@@ -67,8 +67,13 @@ def main():
     import torch
     from repaq_amd import dist as D
     rank, world, local = D.env_rank()
+    # test aid for 1-GPU boxes: RFQ_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0 and rendezvouses over gloo, so that the N>1 control
+    # flow (barriers, max-over-ranks time, aggregate value) can be exercised where RCCL refuses two ranks on one device
+    single = os.environ.get("RFQ_BENCH_SINGLE_DEVICE") == "1"
+    if single:
+        local = 0
     if world > 1:
-        D.init("nccl", device=torch.device("cuda", local))      # "nccl" is RCCL on ROCm; used for barrier / max / sum only
+        D.init("gloo" if single else "nccl", device=None if single else torch.device("cuda", local))   # "nccl" is RCCL on ROCm; barrier / max / sum only
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -151,7 +156,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
-    dt, total_bytes = D.reduce_max_sum(dt, n, device=dev)      # MAX over ranks of the time, SUM of the bytes
+    dt, total_bytes = D.reduce_max_sum(dt, n, device=None if single else dev)      # MAX over ranks of the time, SUM of the bytes
 
     if rank == 0:
         K = args.steps
@@ -190,8 +195,11 @@ def main():
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic NovaSeq SE150 %.2f GB FASTQ per GPU (fqgen profile 0, %d reads, seed 2+rank, N 20 ppm), -k %d"
-                       % (n / 1e9, args.reads, args.chunk_kb), "chunks_per_gpu": state["chunks"], "rfq_over_fastq": round(state["rfq_len"] / n, 4),
+            "config": {"workload": (("configs[4] shape (profiling aid): synthetic BGI-style PE100, 40 quality values, %.2f GB FASTQ per GPU (fqgen profile 3, %d pairs), -k %d" if args.bgi else
+                                     "configs[2] shape (profiling aid): synthetic NovaSeq PE150 two files, %.2f GB FASTQ per GPU (fqgen profile 1, %d pairs), -k %d")
+                                    % (n / 1e9, args.reads // 2, args.chunk_kb)) if args.pe else
+                                   "configs[1]: synthetic NovaSeq SE150 %.2f GB FASTQ per GPU (fqgen profile 0, %d reads, seed 2+rank, N 20 ppm), -k %d"
+                                   % (n / 1e9, args.reads, args.chunk_kb), "chunks_per_gpu": state["chunks"], "rfq_over_fastq": round(state["rfq_len"] / n, 4),
                        "encode_MBps_per_gpu": round(n * K / (state["enc_ms"] * 1e-3) / 1e6, 1) if state["enc_ms"] else None,
                        "decode_MBps_per_gpu": round(n * K / (state["dec_ms"] * 1e-3) / 1e6, 1) if state.get("decode_ok") and state["dec_ms"] else None,
                        "parity": parity, "stage_ms": {k: round(v, 3) for k, v in stage.items()}},

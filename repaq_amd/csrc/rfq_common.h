@@ -215,19 +215,6 @@ __device__ __forceinline__ uint32_t tile_find(const uint32_t* dst, uint32_t cnt,
     return lo;
 }
 
-// 128-bit splice helpers for "16 output bytes from several source pieces": keep the first `take` bytes of (lo, hi), shift left
-// by `filled` bytes, OR into the accumulator
-__device__ __forceinline__ void splice16(unsigned long long& alo, unsigned long long& ahi, unsigned long long plo, unsigned long long phi, uint32_t take, uint32_t filled) {
-    if (take < 16) {
-        if (take >= 8) phi = take == 8 ? 0ull : (phi & ((1ull << (8 * (take - 8))) - 1ull));
-        else { phi = 0ull; plo = take ? (plo & ((1ull << (8 * take)) - 1ull)) : 0ull; }
-    }
-    if (filled) {
-        if (filled < 8) { phi = (phi << (8 * filled)) | (plo >> (64 - 8 * filled)); plo <<= 8 * filled; }
-        else { phi = filled == 8 ? plo : (plo << (8 * (filled - 8))); plo = 0ull; }
-    }
-    alo |= plo; ahi |= phi;
-}
 // 16 bytes ending at LDS address a (inclusive), reversed: out byte k = base[a - k]
 __device__ __forceinline__ void lds_get16_rev(const uint8_t* base, uint32_t a, uint32_t (&w)[4]) {
     uint32_t f[4]; lds_get16(base, a - 15u, f);

@@ -580,53 +580,12 @@ __device__ __forceinline__ void flush_span(const uint4* lds4, uint8_t* gbase, ui
     for (uint64_t x = gbeg + threadIdx.x; x < he; x += blockDim.x) gbase[x] = lds[x - a0];
     if (last_full >= first_full) for (uint64_t x = last_full + threadIdx.x; x < gend; x += blockDim.x) gbase[x] = lds[x - a0];
 }
-// ---- piece copies inside an LDS tile.  A read's text is a sequence of PIECES (name1, ":lane:tile:x:y", name2, sequence [1-2 ranges],
-// strand, quality + four newlines); every piece is a byte range of one staged LDS array, copied forwards or (RC mates) backwards.
-// A thread builds ONE aligned destination word of one piece: t = piece offset of the word's byte 0 (-3..n-1).
-__device__ __forceinline__ uint32_t piece_word(const uint8_t* base, uint32_t src, uint32_t n, int t, bool rev) {
-    const int a = rev ? (int)n - 4 - t : t; const uint32_t neg = a < 0 ? (uint32_t)(-a) : 0u;        // neg <= 3
-    const uint32_t g = lds_get4(base, src + (uint32_t)(a < 0 ? 0 : a));
-    return rev ? bswap32(g) >> (8u * neg) : g << (8u * neg);
-}
-__device__ __forceinline__ void piece_store(uint8_t* out, uint32_t dst, uint32_t n, uint32_t k, int t, uint32_t w) {
-    uint8_t* o = out + (dst & ~3u) + 4u * k;
-    if (t >= 0 && t + 4 <= (int)n) *(uint32_t*)o = w;
-    else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) if (t + i >= 0 && t + i < (int)n) o[i] = (uint8_t)(w >> (8 * i));
-    }
-}
-// the same for ONE aligned 16-byte destination group (long pieces: sequence, quality): t = piece offset of the group's byte 0
-// (-15..n-1).  The staged arrays keep 16 readable bytes in front of their data, so a group that starts before the piece (or a
-// reversed one that ends before it) reads in bounds; those bytes are never stored.
-__device__ __forceinline__ void piece16_fetch(const uint8_t* base, uint32_t src, uint32_t n, int t, bool rev, uint32_t (&w)[4]) {
-    if (!rev) lds_get16(base, (uint32_t)((int)src + t), w);
-    else lds_get16_rev(base, (uint32_t)((int)src + (int)n - 1 - t), w);
-}
-__device__ __forceinline__ void piece16_store(uint8_t* out, uint32_t dst, uint32_t n, uint32_t k, int t, const uint32_t (&w)[4]) {
-    uint8_t* o = out + (dst & ~15u) + 16u * k;
-    if (t >= 0 && t + 16 <= (int)n) { *(uint4*)o = make_uint4(w[0], w[1], w[2], w[3]); return; }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int ti = t + 4 * i;
-        if (ti >= 0 && ti + 4 <= (int)n) *(uint32_t*)(o + 4 * i) = w[i];
-        else {
-#pragma unroll
-            for (int b = 0; b < 4; b++) if (ti + b >= 0 && ti + b < (int)n) o[4 * i + b] = (uint8_t)(w[i] >> (8 * b));
-        }
-    }
-}
 // complement of four bases drawn from {A,C,G,T,N} - the only bytes the decoder itself puts into its base buffer (2-bit unpack,
 // N positions): A<->T is x ^ 0x15, C<->G is x ^ 0x04, N stays (Read::changeToReverseComplement, src/read.cpp:77-115, on that alphabet)
 __device__ __forceinline__ uint32_t comp4_acgtn(uint32_t w) {
     const uint32_t b1 = (w >> 1) & 0x01010101u, b3 = (w >> 3) & 0x01010101u;
     const uint32_t cg = b1 & ~b3, at = b1 ^ 0x01010101u;
     return w ^ (cg * 0x04u + at * 0x15u);
-}
-// idx -> (j, k) with k < W: float reciprocal + one-step correction (idx < 2^20)
-__device__ __forceinline__ void item_jk(uint32_t idx, uint32_t W, float rcp, uint32_t& j, uint32_t& k) {
-    j = (uint32_t)((float)idx * rcp); k = idx - j * W;
-    if ((int)k < 0) { j--; k += W; } else if (k >= W) { j++; k -= W; }
 }
 #define ET_READS 32
 #define EM_ROW 17                 // words per read in s_meta: 16 used + 1 pad, so that lanes reading the same field of consecutive reads hit 32 different banks
