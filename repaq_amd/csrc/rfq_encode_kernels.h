@@ -904,6 +904,18 @@ template <bool SEQ, class Count> __device__ __forceinline__ void tile_emit(const
 }
 // Where the N bases of a chunk are, at the granularity of the position coder's 4096-base steps (256 bits per chunk; chunks of more
 // than 256 steps fold 2^shift steps into a bit): the N-position coder skips the steps - nearly all of them - that hold no N.
+#define PC_SEG_STEPS 8u          // position-coder segment = 8 steps of 4096 positions
+#define PC_SEG_POS (PC_SEG_STEPS * 4096u)
+#define PC_SEG_PAD 40u           // per-segment slack reserved in a stream's scratch (see pc_seg_cap)
+// Bytes reserved for ONE segment of a stream inside the stream's scratch area (16-byte aligned).  MATCH: every token but a gap
+// token is one byte per match; gaps > 128 (> 16384) positions cost one (three) more and at most seglen/128 + 1 (seglen/16384 + 1)
+// of them end inside the segment; + the `cur > 1` token.  EXCEPT: five bytes per record.  The sum over a stream's segments stays
+// below the stream capacity of k_stream_plan (which adds PC_SEG_PAD per segment to the whole-stream bound).
+__device__ __forceinline__ uint32_t pc_seg_cap(bool except, uint32_t cnt, uint32_t seglen) {
+    const uint32_t c = except ? 5u * cnt + 24u : cnt + seglen / 128u + 3u * (seglen / 16384u) + 24u;
+    return (c + 15u) & ~15u;
+}
+__device__ __forceinline__ uint32_t pc_n_seg(uint32_t len) { return ((len + 4095u) / 4096u + PC_SEG_STEPS - 1u) / PC_SEG_STEPS; }
 #define NMAP_WORDS 8u
 __device__ __forceinline__ uint32_t nmap_shift(uint32_t n_bases) { const uint32_t steps = (n_bases + 4095u) / 4096u; uint32_t sh = 0; while ((steps >> sh) > 32u * NMAP_WORDS) sh++; return sh; }
 __device__ __forceinline__ void nmap_mark(uint32_t* m, uint32_t shift, uint32_t pos) { const uint32_t b = (pos >> 12) >> shift; atomicOr(&m[b >> 5], 1u << (b & 31u)); }
@@ -1063,14 +1075,15 @@ __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict
     uint32_t exl = 0;
     if (bycol) for (int v = l; v < 256; v += 64) if (D->is_exception[v]) exl += h[v];
     const uint32_t ex = wave_sum(exl);
-    uint32_t cap = (bycol && (uint32_t)l < nn) ? h[D->normal[l]] + len / 128 + 3 * (len / 16384) + 16 : 0u;
+    const uint32_t pad = PC_SEG_PAD * pc_n_seg(len), pads = PC_SEG_PAD * pc_n_seg(slen);
+    uint32_t cap = (bycol && (uint32_t)l < nn) ? h[D->normal[l]] + len / 128 + 3 * (len / 16384) + 16 + pad : 0u;
     const uint32_t al = (cap + 15u) & ~15u;
     const uint32_t incl = wave_incl_sum(al);
     const size_t k = (size_t)c * MAX_STREAMS;
     C.scap[k + l] = cap; C.soff[k + l] = incl - al; C.ssize[k + l] = 0;
     const uint32_t run64 = __shfl(incl, 63);
     if (l < 2) {
-        const uint32_t capn = (D->flags & H_N_POS) ? C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16 : 0u, cape = bycol ? 5 * ex + 16 : 0u;
+        const uint32_t capn = (D->flags & H_N_POS) ? C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16 + pads : 0u, cape = bycol ? 5 * ex + 16 + pad : 0u;
         const uint32_t aln = (capn + 15u) & ~15u, ale = (cape + 15u) & ~15u;
         if (l == 0) { C.scap[k + NPOS_SLOT] = capn; C.soff[k + NPOS_SLOT] = run64; C.ssize[k + NPOS_SLOT] = 0; }
         else { C.scap[k + EXC_SLOT] = cape; C.soff[k + EXC_SLOT] = run64 + aln; C.ssize[k + EXC_SLOT] = 0; ctotal[c] = (uint64_t)run64 + aln + ale; }
@@ -1174,7 +1187,6 @@ template <class Sink> __device__ __forceinline__ void pc_gen_tokens(uint64_t m, 
 // 32-step segments measured 1.15 ms for the three passes, 8-step segments 0.93 ms, 4-step segments 0.96 ms).  A segment needs the state at its first
 // position — the last match and the last non-match before it — taken from a light summary pass over all segments, and its byte
 // offset inside the stream, which needs the byte counts of the earlier segments: summary, count, emit (three launches).
-#define PC_SEG_STEPS 8u
 // One wave codes up to PC_G streams of the SAME buffer over the same segment: the 4096 raw bytes of a step are loaded once and turned
 // into one match mask per stream (the streams of a chunk used to re-read the chunk's qualities once each, in each of the three passes).
 #define PC_G 4
@@ -1183,7 +1195,7 @@ struct PcStream {
     uint64_t m_cur, m_next;                 // masks of the current and the next step (lane's 64 positions)
     int prev_carry, zero_carry;             // last match / last non-match before the current step
     uint32_t outpos; uint8_t* out; uint32_t room;
-    int last1, last0;                       // summary pass
+    int last1, last0; uint32_t cnt;         // summary pass: last match / non-match, number of matches
 };
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
 // with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  EMIT writes the bytes at S[t].out[0..).
@@ -1259,7 +1271,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_grou
     auto loadc = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (step_ >= nst || (nmap && !nmap_test(nmap, nshift, step_))) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; } return pc_load_raw(B, len, p_); };
     Raw64 raw_c = loadc(step0, q0), raw_n = loadc(step0 + 1, q0 + 4096u);
 #pragma unroll
-    for (int t = 0; t < G; t++) { S[t].last1 = -1; S[t].last0 = -1; }
+    for (int t = 0; t < G; t++) { S[t].last1 = -1; S[t].last0 = -1; S[t].cnt = 0; }
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
         const Raw64 raw_nn = loadc(step + 2, p0 + 8192u);
@@ -1267,6 +1279,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_grou
         for (int t = 0; t < G; t++) {
             if (!S[t].on) continue;
             const uint64_t m = pc_mask_of(raw_c, len, p0, MODE, S[t].q, D);
+            S[t].cnt += (uint32_t)__popcll(m);                                 // (per lane; summed over the wave by the caller)
             const unsigned long long h1 = __ballot(m != 0), h0 = __ballot(~m != 0);
             if (h1) { const int v = m ? (int)p0 + 63 - __clzll((long long)m) : -1; S[t].last1 = __shfl(v, 63 - __clzll((long long)h1)); }
             if (h0) { const int v = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1; S[t].last0 = __shfl(v, 63 - __clzll((long long)h0)); }
@@ -1274,15 +1287,15 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_grou
         raw_c = raw_n; raw_n = raw_nn;
     }
 }
-// 1-D grid of ceil(n_chunks / 8) * 8 * (n_qgroups + 2) * n_seg workgroups, one wave each; three passes over the same grid:
-//   PASS 0  summary  segc[2*si+{0,1}] = last match / last non-match of the segment
-//   PASS 1  count    entry state = nearest earlier segment that has one; segb[si] = bytes of the segment
-//   PASS 2  emit     offset = sum of earlier segb; writes the bytes
+// 1-D grid of ceil(n_chunks / 8) * 8 * (n_qgroups + 2) * n_seg workgroups, one wave each; two passes over the same grid:
+//   PASS 0  summary  segc[2*si+{0,1}] = last match / last non-match of the segment, segm[si] = its number of matches
+//   PASS 2  code     entry state = nearest earlier segment that has one; the bytes go to the segment's own slot of the stream's
+//                    scratch area (slot sizes from the match counts, pc_seg_cap), segb[si] = bytes written.  k_assemble joins the slots.
 // Group g < n_qgroups holds the quality-value streams 4g .. 4g+3, group n_qgroups the exception stream, group n_qgroups + 1 the
 // N-position stream (it reads the base buffer).  si = (c * MAX_STREAMS + j) * n_seg + seg.  Streams whose value does not occur in
 // the chunk (histogram) are skipped outright.
 template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
-                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t* __restrict__ segm, uint32_t n_seg,
                             uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st) {
     const uint32_t nshift = nmap ? nmap_shift(len) : 0u;
     const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
@@ -1296,10 +1309,10 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
         const size_t k = (size_t)c * MAX_STREAMS + j; kk[t] = k;
         const uint32_t cap = C.scap[k];
         if (cap == 0) continue;                                            // stream not present
-        const uint32_t occurrences = j < NPOS_SLOT ? C.hist[(size_t)c * 256 + D->normal[j]] : (j == NPOS_SLOT ? C.ncount[c] : (cap - 16u) / 5u);
-        if (occurrences == 0) continue;                                    // nothing to code: ssize stays 0 (k_stream_plan)
+        const uint32_t occurrences = j < NPOS_SLOT ? C.hist[(size_t)c * 256 + D->normal[j]] : (j == NPOS_SLOT ? C.ncount[c] : (cap - 16u - PC_SEG_PAD * pc_n_seg(len)) / 5u);
+        if (occurrences == 0) continue;                                    // nothing to code: the segment byte counts stay 0
         const size_t si = k * n_seg + seg;
-        if (step0 >= nsteps) { if (PASS == 0 && lane_id() == 0) { segb[si] = 0; segc[2 * si] = -1; segc[2 * si + 1] = -1; } continue; }
+        if (step0 >= nsteps) { if (PASS == 0 && lane_id() == 0) { segm[si] = 0; segc[2 * si] = -1; segc[2 * si + 1] = -1; } continue; }
         S[t].on = true; any = true;
         S[t].mode = MODE; S[t].q = j < NPOS_SLOT ? D->normal[j] : (uint32_t)'N';
         S[t].prev_carry = -1; S[t].zero_carry = -1; S[t].out = nullptr; S[t].room = 0; S[t].outpos = 0;
@@ -1308,7 +1321,7 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
     if (PASS == 0) {
         wave_pos_summary_group<MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
 #pragma unroll
-        for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) { const size_t si = kk[t] * n_seg + seg; segc[2 * si] = S[t].last1; segc[2 * si + 1] = S[t].last0; segb[si] = 0; }
+        for (int t = 0; t < G; t++) if (S[t].on) { const uint32_t cnt = wave_sum(S[t].cnt); if (lane_id() == 0) { const size_t si = kk[t] * n_seg + seg; segc[2 * si] = S[t].last1; segc[2 * si + 1] = S[t].last0; segm[si] = cnt; } }
         return;
     }
 #pragma unroll
@@ -1319,22 +1332,30 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
         for (int s = (int)seg - 1; s >= 0 && prev < 0; s--) prev = segc[2 * (s0i + (uint32_t)s)];
         for (int s = (int)seg - 1; s >= 0 && zero < 0; s--) zero = segc[2 * (s0i + (uint32_t)s) + 1];
         S[t].prev_carry = prev; S[t].zero_carry = zero;
-        if (PASS == 2) {
-            uint32_t off = 0; for (uint32_t s = 0; s < seg; s++) off += segb[s0i + s];
-            const uint32_t own = segb[s0i + seg], cap = C.scap[kk[t]];
-            S[t].out = scratch + cbase[c] + C.soff[kk[t]] + off; S[t].room = own;
-            if (step1 == nsteps && lane_id() == 0) { C.ssize[kk[t]] = off + own; if (off + own > cap) atomicOr(&st->err, (uint32_t)DE_CORRUPT); }
-            if (off + own > cap) S[t].room = 0;                             // never write past the stream's capacity (flagged above by its last segment)
-        }
+        // the segment's slot inside the stream's scratch area: after the slots of the earlier segments (capacities from their match counts)
+        uint32_t off = 0;
+        for (uint32_t s = 0; s < seg; s++) off += pc_seg_cap(MODE == PC_EXCEPT, segm[s0i + s], PC_SEG_POS);
+        const uint32_t own = pc_seg_cap(MODE == PC_EXCEPT, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
+        S[t].out = scratch + cbase[c] + C.soff[kk[t]] + off; S[t].room = off + own <= C.scap[kk[t]] ? own : 0u;
     }
-    if (PASS == 1) {
-        wave_pos_encode_group<false, MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
+    wave_pos_encode_group<true, MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
 #pragma unroll
-        for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) segb[kk[t] * n_seg + seg] = S[t].outpos;
-    } else wave_pos_encode_group<true, MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
+    for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) {
+        segb[kk[t] * n_seg + seg] = S[t].outpos;
+        if (S[t].outpos > S[t].room) atomicOr(&st->err, (uint32_t)DE_CORRUPT);   // (would mean pc_seg_cap is wrong: nothing was written past the slot)
+    }
+}
+// bytes of every stream of a chunk = sum of its segments' byte counts; one wave per chunk
+__global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint32_t n_seg) {
+    const uint32_t c = blockIdx.x; const int l = lane_id();
+    for (uint32_t j = (uint32_t)l; j < MAX_STREAMS; j += 64) {
+        const size_t k = (size_t)c * MAX_STREAMS + j; uint32_t tot = 0;
+        if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) tot += segb[k * n_seg + s];
+        C.ssize[k] = tot;
+    }
 }
 template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
-                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t n_seg, uint32_t n_chunks,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
                             uint32_t n_qgroups, DevStatus* st) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
     // (group, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's data stays in ONE private L2.
@@ -1342,9 +1363,9 @@ template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const Dev
     const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = rest % (n_qgroups + 2), seg = rest / (n_qgroups + 2);
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
-    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
-    else if (grp == n_qgroups) pc_run<PASS, PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st);
-    else pc_run<PASS, PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
+    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
+    else if (grp == n_qgroups) pc_run<PASS, PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st);
+    else pc_run<PASS, PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
@@ -1472,7 +1493,8 @@ __device__ __forceinline__ void copy_to_image(uint8_t* __restrict__ dst, const u
 __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L,
                            const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat, const uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
                            const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
-                           uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2, DevStatus* st) {
+                           uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2,
+                           const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, DevStatus* st) {
     const uint32_t c = blockIdx.y; const Layout o = L[c];
     const uint64_t at = img_base + C.img_off[c];
     if (at + o.total > img_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&st->err, 1u << 31); return; }
@@ -1552,16 +1574,31 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
     // quality payload
     if (hf & H_DONT_QUAL) copy_to_image(out + o.off_qual, qcat + C.qbase[c], o.qual_size, t, NT);
     else if (hf & H_QUAL_BY_COL) {
-        uint32_t dst = o.off_qual + 4 * nn; const uint8_t* sc = scratch + cbase[c];
-        for (uint32_t j = 0; j <= nn; j++) {
-            const uint32_t js = j < nn ? j : (uint32_t)EXC_SLOT;          // normal streams in header order, then the exception records
-            const uint32_t sz = C.ssize[k0 + js]; const uint8_t* src = sc + C.soff[k0 + js];      // 16-byte aligned (k_stream_plan)
-            copy_to_image(out + dst, src, sz, t, NT);
-            dst += sz;
+        // a stream sits in its scratch area as one slot per coder segment (pc_seg_cap); the image wants the slots' bytes back to back,
+        // normal streams in header order, then the exception records.  One wave per (stream, segment) piece.
+        const uint8_t* sc = scratch + cbase[c]; const uint32_t qlen = R.pq[f + s] - R.pq[f];
+        const uint32_t nw = NT >> 6, wv = t >> 6; const uint32_t l = t & 63u;
+        for (uint32_t pc = wv; pc < (nn + 1) * n_seg; pc += nw) {
+            const uint32_t jj = pc / n_seg, seg = pc - jj * n_seg, js = jj < nn ? jj : (uint32_t)EXC_SLOT; const size_t si0 = (k0 + js) * n_seg;
+            const uint32_t sz = C.scap[k0 + js] ? segb[si0 + seg] : 0u;
+            if (!sz) continue;                                               // wave-uniform
+            uint32_t dst = o.off_qual + 4 * nn, so = 0;
+            for (uint32_t j2 = 0; j2 < jj; j2++) dst += C.ssize[k0 + j2];
+            for (uint32_t s2 = 0; s2 < seg; s2++) { dst += segb[si0 + s2]; so += pc_seg_cap(js == EXC_SLOT, segm[si0 + s2], PC_SEG_POS); }
+            (void)qlen;
+            copy_to_image(out + dst, sc + C.soff[k0 + js] + so, sz, l, 64u);
         }
     }
     if (il && (hf & H_PE_OVERLAP)) for (uint32_t i = t; i < s / 2; i += NT) out[o.off_ov + i] = (uint8_t)ovb[(f >> 1) + i];
-    if (hf & H_N_POS) copy_to_image(out + o.off_npos, scratch + cbase[c] + C.soff[k0 + NPOS_SLOT], o.npos_size, t, NT);
+    if ((hf & H_N_POS) && C.scap[k0 + NPOS_SLOT]) {
+        const size_t si0 = (k0 + NPOS_SLOT) * n_seg; const uint32_t nw = NT >> 6, wv = t >> 6; const uint32_t l = t & 63u;
+        for (uint32_t seg = wv; seg < n_seg; seg += nw) {
+            const uint32_t sz = segb[si0 + seg]; if (!sz) continue;
+            uint32_t dst = o.off_npos, so = 0;
+            for (uint32_t s2 = 0; s2 < seg; s2++) { dst += segb[si0 + s2]; so += pc_seg_cap(false, segm[si0 + s2], PC_SEG_POS); }
+            copy_to_image(out + dst, scratch + cbase[c] + C.soff[k0 + NPOS_SLOT] + so, sz, l, 64u);
+        }
+    }
 }
 // names / strands that differ inside the chunk: one wave per read copies its pieces to their prefix-sum offsets
 __global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L, uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base) {
