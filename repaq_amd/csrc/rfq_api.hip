@@ -39,6 +39,7 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     delete c;
 }
 

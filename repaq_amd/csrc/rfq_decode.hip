@@ -112,33 +112,32 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     uint64_t* qbase = B[DB_QBASE].as<uint64_t>(); uint64_t* sbase = B[DB_SBASE].as<uint64_t>();
     uint8_t* qdec = B[DB_QDEC].as<uint8_t>(); uint8_t* sdec = B[DB_SDEC].as<uint8_t>();
     hipLaunchKernelGGL(k_dec_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, CH, R, qbase, sbase, n_chunks);
-    // Two chains run side by side: the bandwidth-bound prefill + 2-bit unpack on the main stream; on the aux stream the latency-bound
-    // coordinate decoder and the position-stream summaries (neither touches qdec / sdec).  They join before the position streams are
-    // scattered into the prefilled buffers.
+    // Two chains run side by side (rfq_ctx::aux, fork / join by events):
+    //   main  prefill of qdec, coordinate decoder, [summaries linked] quality position streams scattered into qdec, exception records
+    //   aux   position-stream summaries + link, 2-bit unpack into sdec, N positions scattered into sdec
     const bool forked = ctx->aux_ready();
     hipStream_t A = forked ? ctx->aux : S;
     if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
-    hipLaunchKernelGGL(k_dec_fill, dim3(2048), dim3(256), 0, S, qdec, (uint64_t)qbytes, D);
     const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
-    hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
+    hipLaunchKernelGGL(k_dec_fill, dim3(2048), dim3(256), 0, S, qdec, (uint64_t)qbytes, D);
+    hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
     if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
         // position streams in POS_SEG-byte segments: summary -> link -> emit (see rfq_decode_kernels.h)
-        const uint32_t nstr = HH.n_normal + 1, maxseg = hs.max_stream / POS_SEG + 1; const size_t nseg = (size_t)n_chunks * nstr * maxseg;
+        const uint32_t nn = HH.n_normal, nstr = nn + 1, maxseg = hs.max_stream / POS_SEG + 1; const size_t nseg = (size_t)n_chunks * nstr * maxseg;
         HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 16 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure((size_t)n_chunks * nstr * 4 + 16));
         HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16));
         hipLaunchKernelGGL(k_dec_pos_sum, dim3(maxseg, nstr, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
                            B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), maxseg, dst, (uint64_t)a->n);
         hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
                            (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
-        // (the coordinate decoder follows the unpack on the main stream: fill + unpack + coords balance summary + link on the aux stream)
-        hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
-        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
-        hipLaunchKernelGGL(k_dec_pos_emit, dim3(maxseg, nstr, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
-                           (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n);
-    } else {
-        hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
-        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
-    }
+        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_mid, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0)); }
+        hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
+        if (nn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(maxseg, nn, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+                                   (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, 0u, nstr);
+        if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_pos_emit, dim3(maxseg, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+                                                   (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, nn, nstr);
+    } else hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
+    if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
     KCHK(ctx, "k_dec_streams");
     ctx->timer.end(S);

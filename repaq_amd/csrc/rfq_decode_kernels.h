@@ -380,13 +380,14 @@ __global__ void k_dec_pos_link(const uint8_t* __restrict__ segF, const int* __re
 // grid (maxseg, nn + 1, n_chunks): normal quality streams -> qdec, N positions -> sdec
 __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                                const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ qdec, uint8_t* __restrict__ sdec,
-                               const uint8_t* __restrict__ segS, const int* __restrict__ segP, uint32_t maxseg, uint64_t img_bytes) {
-    const uint32_t g = blockIdx.x, jj = blockIdx.y, c = blockIdx.z; const uint8_t* lim = img + img_bytes;
+                               const uint8_t* __restrict__ segS, const int* __restrict__ segP, uint32_t maxseg, uint64_t img_bytes, uint32_t jj0, uint32_t nstr) {
+    // grid (maxseg, streams jj0 .. jj0 + gridDim.y - 1, n_chunks): the quality streams and the N-position stream are launched apart
+    const uint32_t g = blockIdx.x, jj = jj0 + blockIdx.y, c = blockIdx.z; const uint8_t* lim = img + img_bytes;
     const DChunk d = CH[c];
     const PosStream s = pos_stream_of(img, d, D, R, c, qbase, sbase, qdec, sdec, jj, nullptr);
     const uint32_t b0 = g * POS_SEG; if (b0 >= s.slen) return;
     const uint32_t b1 = b0 + POS_SEG < s.slen ? b0 + POS_SEG : s.slen;
-    const size_t idx = ((size_t)c * gridDim.y + jj) * maxseg + g;
+    const size_t idx = ((size_t)c * nstr + jj) * maxseg + g;
     wave_pos_decode(s.sp, s.slen, b0, b1, segS[idx], segP[idx], s.q, s.out, s.out_len, lim);
 }
 // exception records (q, u32 LE position) after the streams (src/rfqcodec.cpp:1034-1043); raw copy when DONT_ENCODE_QUAL (:905-910)
