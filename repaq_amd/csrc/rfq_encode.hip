@@ -250,20 +250,26 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     int8_t* ovb = B[B_OVB].as<int8_t>();
     const uint32_t max_reads = std::max(hs.max_chunk_reads, 1u);
 
+    // SE: nothing before the gather needs the file header, so the (small, serial) header kernels of a first batch run on the aux
+    // stream beside chunk ids / flags / prefix scans; PE needs it for the interleave test right away.
+    const bool make_header = !ctx->have_hdr;
+    const bool hdr_aside = make_header && !is_pe && ctx->aux_ready();
+    hipStream_t HS = hdr_aside ? ctx->aux : S;
+    if (hdr_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(HS, ctx->ev_fork, 0)); }
     ctx->timer.begin("header", S);
     hipLaunchKernelGGL(k_chunk_ids, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, C, R);
-    const bool make_header = !ctx->have_hdr;
     if (make_header) {
         HdrStats* H = B[B_HSTATS].as<HdrStats>();
         const uint32_t c0_reads = std::max(1u, std::min(max_reads, reads_used));
         const uint32_t hb = std::min<uint32_t>(1024, (c0_reads + 3) / 4);
-        hipLaunchKernelGGL(k_hdr_init, dim3(1), dim3(128), 0, S, H);
-        hipLaunchKernelGGL(k_hdr_stats, dim3(hb), dim3(256), 0, S, T, R, (const uint32_t*)C.first, H);
-        hipLaunchKernelGGL(k_hdr_q0, dim3(1), dim3(64), 0, S, T, H);
-        hipLaunchKernelGGL(k_hdr_pass2, dim3(hb), dim3(256), 0, S, T, R, (const uint32_t*)C.first, H);
-        if (is_pe) hipLaunchKernelGGL(k_hdr_pe, dim3((c0_reads / 2 + 255) / 256), dim3(256), 0, S, T, R, (const uint32_t*)C.first, H);
-        hipLaunchKernelGGL(k_hdr_finalize, dim3(1), dim3(64), 0, S, T, H, D, is_pe ? 1 : 0, dst);
+        hipLaunchKernelGGL(k_hdr_init, dim3(1), dim3(128), 0, HS, H);
+        hipLaunchKernelGGL(k_hdr_stats, dim3(hb), dim3(256), 0, HS, T, R, (const uint32_t*)C.first, H);
+        hipLaunchKernelGGL(k_hdr_q0, dim3(1), dim3(64), 0, HS, T, H);
+        hipLaunchKernelGGL(k_hdr_pass2, dim3(hb), dim3(256), 0, HS, T, R, (const uint32_t*)C.first, H);
+        if (is_pe) hipLaunchKernelGGL(k_hdr_pe, dim3((c0_reads / 2 + 255) / 256), dim3(256), 0, HS, T, R, (const uint32_t*)C.first, H);
+        hipLaunchKernelGGL(k_hdr_finalize, dim3(1), dim3(64), 0, HS, T, H, D, is_pe ? 1 : 0, dst);
         KCHK(ctx, "k_hdr_*");
+        if (hdr_aside) HIPCHK(ctx, hipEventRecord(ctx->ev_mid, HS));
     }
     ctx->timer.end(S);
 
@@ -284,6 +290,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     scan_exclusive<U4>(S, B[B_PVIN].as<U4>(), R.pv, n_reads, B[B_SCANTMP].as<U4>(), 1);
     hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks);
     KCHK(ctx, "k_chunk_flags");
+    if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));      // the gather needs the header (major quality, flags)
     ctx->timer.end(S);
 
     ctx->timer.begin("gather", S);
