@@ -67,7 +67,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, hipMemcpyAsync(&h2, dst, sizeof h2, hipMemcpyDeviceToHost, S));
             HIPCHK(ctx, hipStreamSynchronize(S));
             if (h2.pad) { speculate = false; continue; }                   // an extent did not verify: foreign writer or corrupt image
-            hs.max_stream = h2.max_stream;
+            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos;
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
         break;
@@ -123,19 +123,26 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
     if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
         // position streams in POS_SEG-byte segments: summary -> link -> emit (see rfq_decode_kernels.h)
-        const uint32_t nn = HH.n_normal, nstr = nn + 1, maxseg = hs.max_stream / POS_SEG + 1; const size_t nseg = (size_t)n_chunks * nstr * maxseg;
+        // (grid sizes from the largest quality / N-position section: a file with raw qualities has no quality streams to walk)
+        const bool bycol = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL), hasn = (HH.flags & H_N_POS) != 0;
+        const uint32_t nn = bycol ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u, nstr = HH.n_normal + 1;
+        const uint32_t mq = nn ? hs.max_stream / POS_SEG + 1 : 0u, mn = hasn ? hs.max_npos / POS_SEG + 1 : 0u, maxseg = std::max(1u, std::max(mq, mn));
+        const size_t nseg = (size_t)n_chunks * nstr * maxseg;
         HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 16 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure((size_t)n_chunks * nstr * 4 + 16));
         HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16));
-        hipLaunchKernelGGL(k_dec_pos_sum, dim3(maxseg, nstr, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
-                           B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), maxseg, dst, (uint64_t)a->n);
+        HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, (size_t)n_chunks * nstr * 4, A));
+#define RFQ_SUM_ARGS a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), maxseg, dst, (uint64_t)a->n
+        if (nn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mq, nn, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, 0u, nstr);
+        if (hasn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mn, 1, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, HH.n_normal, nstr);
+#undef RFQ_SUM_ARGS
         hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
                            (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
         if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_mid, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0)); }
         hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
-        if (nn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(maxseg, nn, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+        if (nn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mq, nn, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
                                    (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, 0u, nstr);
-        if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_pos_emit, dim3(maxseg, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
-                                                   (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, nn, nstr);
+        if (hasn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mn, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+                                     (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, HH.n_normal, nstr);
     } else hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
     if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);

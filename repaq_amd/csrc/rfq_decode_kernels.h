@@ -22,7 +22,7 @@ struct DecStatus {
     uint32_t err, n_chunks, max_reads, overflow;
     uint64_t total_reads, consumed, total_bases, total_stored, text1, text2;
     uint32_t last_flags, pad;
-    uint32_t max_stream, pad2;       // largest quality / N-position section of any chunk (bounds the position streams)
+    uint32_t max_stream, max_npos;   // largest quality section / N-position section of any chunk (bound the position streams)
     uint64_t text_slots[2][64];      // partial sums of the text bytes per output stream (k_dec_textlen)
 };
 
@@ -74,7 +74,7 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
 // One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays; the reader ignores mSize).
 __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st, int final) {
     const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
-    uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
+    uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, maxn = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
     if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
     while (!err) {
         DChunk d; const int rc = parse_chunk(img, n, k, hf, rlb, d);
@@ -83,11 +83,11 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
         d.rbase = (uint32_t)rb;
         if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
         if (d.reads > maxr) maxr = d.reads;
-        if (d.qual_size > maxs) maxs = d.qual_size; if (d.npos_size > maxs) maxs = d.npos_size;
+        if (d.qual_size > maxs) maxs = d.qual_size; if (d.npos_size > maxn) maxn = d.npos_size;
         lastfl = d.flags; rb += d.reads; k += d.total; c++;
         if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
     }
-    if (l == 0) { st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; }
+    if (l == 0) { st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
 }
 // Speculative walk: images written by repaq (or this engine) carry mSize = true size - Delta(flags) (the accounting bug Q1 is a
 // pure function of the header and chunk flags), so the chain needs ONE dependent 10-byte read per chunk instead of a full parse.
@@ -121,7 +121,7 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
     d.rbase = rbase;
-    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size > d.npos_size ? d.qual_size : d.npos_size); }
+    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); }
 }
 
 struct DReadTab {
@@ -340,11 +340,13 @@ __device__ __forceinline__ PosStream pos_stream_of(const uint8_t* __restrict__ i
 // grid (maxseg, nn + 1, n_chunks), one wave per segment
 __global__ void k_dec_pos_sum(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                               const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ qdec, uint8_t* __restrict__ sdec,
-                              uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes) {
-    const uint32_t g = blockIdx.x, jj = blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
+                              uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes,
+                              uint32_t jj0, uint32_t nstr) {
+    // grid (segments, streams jj0 .. jj0 + gridDim.y - 1, n_chunks); index arrays are [chunk][nstr][maxseg]
+    const uint32_t g = blockIdx.x, jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
     const DChunk d = CH[c];
     const PosStream s = pos_stream_of(img, d, D, R, c, qbase, sbase, qdec, sdec, jj, g == 0 ? st : nullptr);
-    if (g == 0 && l == 0) segN[(size_t)c * gridDim.y + jj] = (s.slen + POS_SEG - 1) / POS_SEG;
+    if (g == 0 && l == 0) segN[(size_t)c * nstr + jj] = (s.slen + POS_SEG - 1) / POS_SEG;
     const uint32_t b0 = g * POS_SEG; if (b0 >= s.slen) return;
     const uint32_t b1 = b0 + POS_SEG < s.slen ? b0 + POS_SEG : s.slen;
     uint32_t Fcum = POS_ID; int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -362,7 +364,7 @@ __global__ void k_dec_pos_sum(const uint8_t* __restrict__ img, const DChunk* __r
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
     if (l == 0) {
-        const size_t idx = ((size_t)c * gridDim.y + jj) * maxseg + g;
+        const size_t idx = ((size_t)c * nstr + jj) * maxseg + g;
         segF[idx] = (uint8_t)Fcum; segA[4 * idx + 0] = a0; segA[4 * idx + 1] = a1; segA[4 * idx + 2] = a2; segA[4 * idx + 3] = a3;
     }
 }
