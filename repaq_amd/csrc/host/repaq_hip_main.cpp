@@ -29,7 +29,7 @@ static bool ends_with(const std::string& s, const std::string& e) { return s.siz
 struct Options {
     std::string in1, out1, in2, out2, rfqCompare, json;
     long chunkKb = 1000; bool compress = false, decompress = false, compare = false, useStdin = false, useStdout = false, interleaved = false;
-    int device = 0; size_t batchBytes = (size_t)256 << 20; int threads = 1, compression = 3;
+    int device = 0; size_t batchBytes = (size_t)16 << 20; int threads = 1, compression = 3;   // 16 MB batches: the stages of the I/O pipeline overlap best (tools/batch_sweep.sh)
 };
 
 // ------------------------------------------------------------------------------------------------ byte sources / sinks
