@@ -75,6 +75,11 @@ typedef struct {
     uint64_t file_off1, file_off2;
     uint64_t nolb_from1, nolb_from2;
     uint8_t* d_out; size_t out_cap;       /* optional caller buffer for the .rfq bytes; NULL = context-owned result    */
+    int32_t  flush_all;                   /* 1: the batch ends exactly on a chunk boundary found by rfq_scan_batch: encode
+                                             every record of it (like final) without treating its end as the end of the
+                                             input (an unterminated last line is not a line; the 1 MiB reader-block rule
+                                             still sees the file continue).  For workers of a multi-GPU host queue.     */
+    int32_t  reserved2;
 } rfq_encode_args;
 
 typedef struct {
@@ -95,6 +100,23 @@ typedef struct {
  * for every chunk of the batch (src/rfqcodec.cpp:147-586, src/rfqchunk.cpp:230-311), with the chunk cut rule of
  * Repaq::compress (src/repaq.cpp:546-553): cut after the read that brings the running base count to >= chunk_bases. */
 int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_encode_result* res);
+
+/* The plan pass of a chunk-parallel encode: line index, read lengths and the cut rule of Repaq::compress
+ * (src/repaq.cpp:546-553) only — no header, no coding.  h_end1/2[c] = offset in the caller's stream(s) just past the last
+ * record of chunk c (for RFQ_PE_TWO_FILES one array per file, else h_end2 is NULL); a host work queue hands the byte ranges
+ * [h_end[c0-1], h_end[c1-1]) to other contexts / GPUs, which encode them with flush_all = 1 and the header of the first
+ * range (rfq_get_header -> rfq_set_header); the concatenated images equal the one-shot image.  Takes the same arguments as
+ * rfq_encode_batch (final = 0: only full chunks are planned, consumed* says where the next scan starts). */
+typedef struct {
+    uint32_t n_chunks;
+    uint64_t n_reads;
+    size_t   consumed1, consumed2;
+    const uint64_t* h_end1;               /* host arrays [n_chunks], valid until the next call on the context           */
+    const uint64_t* h_end2;
+    int32_t  input_ended;                 /* as in rfq_encode_result                                                   */
+    int32_t  reserved;
+} rfq_scan_result;
+int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_scan_result* res);
 
 typedef struct {
     const uint8_t* d_rfq; size_t n;       /* .rfq bytes in HBM                                                          */

@@ -27,13 +27,19 @@ class RfqError(RuntimeError):
 class EncodeArgs(C.Structure):
     _fields_ = [("d_fq1", C.c_void_p), ("n1", C.c_size_t), ("d_fq2", C.c_void_p), ("n2", C.c_size_t), ("paired", C.c_int32),
                 ("chunk_bases", C.c_uint32), ("final", C.c_int32), ("emit_header", C.c_int32), ("file_off1", C.c_uint64),
-                ("file_off2", C.c_uint64), ("nolb_from1", C.c_uint64), ("nolb_from2", C.c_uint64), ("d_out", C.c_void_p), ("out_cap", C.c_size_t)]
+                ("file_off2", C.c_uint64), ("nolb_from1", C.c_uint64), ("nolb_from2", C.c_uint64), ("d_out", C.c_void_p), ("out_cap", C.c_size_t),
+                ("flush_all", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class EncodeResult(C.Structure):
     _fields_ = [("d_rfq", C.c_void_p), ("rfq_len", C.c_size_t), ("n_chunks", C.c_uint32), ("n_reads", C.c_uint64), ("n_bases", C.c_uint64),
                 ("consumed1", C.c_size_t), ("consumed2", C.c_size_t), ("h_chunk_off", C.POINTER(C.c_uint64)),
                 ("input_ended", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ScanResult(C.Structure):
+    _fields_ = [("n_chunks", C.c_uint32), ("n_reads", C.c_uint64), ("consumed1", C.c_size_t), ("consumed2", C.c_size_t),
+                ("h_end1", C.POINTER(C.c_uint64)), ("h_end2", C.POINTER(C.c_uint64)), ("input_ended", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DecodeArgs(C.Structure):
@@ -74,6 +80,7 @@ def load(path=None):
     L.rfq_clear_header.argtypes = [C.c_void_p]; L.rfq_clear_header.restype = None
     L.rfq_encode_batch.argtypes = [C.c_void_p, C.POINTER(EncodeArgs), C.POINTER(EncodeResult)]
     L.rfq_decode_batch.argtypes = [C.c_void_p, C.POINTER(DecodeArgs), C.POINTER(DecodeResult)]
+    L.rfq_scan_batch.argtypes = [C.c_void_p, C.POINTER(EncodeArgs), C.POINTER(ScanResult)]
     L.rfq_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     L.rfq_dev_malloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
     L.rfq_dev_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -87,5 +94,5 @@ def load(path=None):
 
 
 EXPORTS = ["rfq_version", "rfq_create", "rfq_destroy", "rfq_last_error", "rfq_set_stream", "rfq_set_header", "rfq_get_header", "rfq_clear_header",
-           "rfq_encode_batch", "rfq_decode_batch", "rfq_last_timings", "rfq_dev_malloc", "rfq_dev_free", "rfq_copy_h2d", "rfq_copy_d2h",
+           "rfq_encode_batch", "rfq_scan_batch", "rfq_decode_batch", "rfq_last_timings", "rfq_dev_malloc", "rfq_dev_free", "rfq_copy_h2d", "rfq_copy_d2h",
            "rfq_copy_d2d", "rfq_host_alloc", "rfq_host_free"]

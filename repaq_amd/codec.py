@@ -55,12 +55,21 @@ class RfqCodec:
 
     # --- RfqCodec::encodeChunk for every chunk of a batch
     def encode(self, d_fq1, n1, d_fq2=None, n2=0, paired=SE, chunk_bases=1_000_000, final=True, emit_header=True,
-               file_off1=0, file_off2=0, nolb_from1=U64_MAX, nolb_from2=U64_MAX, d_out=None, out_cap=0):
+               file_off1=0, file_off2=0, nolb_from1=U64_MAX, nolb_from2=U64_MAX, d_out=None, out_cap=0, flush_all=False):
         a = A.EncodeArgs(d_fq1, n1, d_fq2, n2, paired, chunk_bases, 1 if final else 0, 1 if emit_header else 0,
-                         file_off1, file_off2, nolb_from1, nolb_from2, d_out, out_cap)
+                         file_off1, file_off2, nolb_from1, nolb_from2, d_out, out_cap, 1 if flush_all else 0, 0)
         r = A.EncodeResult()
         self._check(self._L.rfq_encode_batch(self._h, C.byref(a), C.byref(r)))
         return r
+
+    # --- the plan pass of a chunk-parallel encode: where every chunk ends in the input stream(s)
+    def scan(self, d_fq1, n1, d_fq2=None, n2=0, paired=SE, chunk_bases=1_000_000, final=True, file_off1=0, file_off2=0):
+        a = A.EncodeArgs(d_fq1, n1, d_fq2, n2, paired, chunk_bases, 1 if final else 0, 0, file_off1, file_off2, U64_MAX, U64_MAX, None, 0, 0, 0)
+        r = A.ScanResult()
+        self._check(self._L.rfq_scan_batch(self._h, C.byref(a), C.byref(r)))
+        ends1 = [r.h_end1[i] for i in range(r.n_chunks)]
+        ends2 = [r.h_end2[i] for i in range(r.n_chunks)] if (paired == PE_TWO_FILES and r.n_chunks) else []
+        return r, ends1, ends2
 
     # --- RfqCodec::decodeChunk for every chunk of an image
     def decode(self, d_rfq, n, has_header=True, split_pe=False, final=True, d_out1=None, cap1=0, d_out2=None, cap2=0):

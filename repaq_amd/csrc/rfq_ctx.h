@@ -59,6 +59,7 @@ struct rfq_ctx {
     DBuf b[96];
     DBuf out_img, out_fq1, out_fq2;
     std::vector<uint64_t> chunk_off;
+    std::vector<uint64_t> scan_end[2];     // rfq_scan_batch: end offset of every chunk in each input stream
     StageTimer timer;
 };
 

@@ -82,14 +82,14 @@ static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t 
     return RFQ_OK;
 }
 
-static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended);
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only);
 
-extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res) {
+static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, bool scan_only) {
     if (!ctx || !a || !res) return RFQ_E_ARG;
     memset(res, 0, sizeof *res);
     ctx->err.clear();
     if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
-    int rc = encode_impl(ctx, a, res, nullptr, ~0u, false);
+    int rc = encode_impl(ctx, a, res, nullptr, ~0u, false, scan_only);
     if (rc != RFQ_NEED_NORM) return rc;
     // slow path: '\r' line ends or blank lines (src/fastqreader.cpp:94-196)
     NormMap nm; memset(&nm, 0, sizeof nm);
@@ -102,15 +102,27 @@ extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_enco
         a2.d_fq2 = p; a2.n2 = pn;
     }
     memset(res, 0, sizeof *res);
-    rc = encode_impl(ctx, &a2, res, &nm, ~0u, false);
+    rc = encode_impl(ctx, &a2, res, &nm, ~0u, false, scan_only);
     if (rc == RFQ_NEED_NORM) return rfq_fail(ctx, RFQ_E_HIP, "internal: normalised text still needs normalisation");
     return rc;
 }
+extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res) { return encode_or_scan(ctx, a, res, false); }
+extern "C" int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_scan_result* out) {
+    if (!out) return RFQ_E_ARG;
+    memset(out, 0, sizeof *out);
+    rfq_encode_result r;
+    const int rc = encode_or_scan(ctx, a, &r, true);
+    if (rc != RFQ_OK) return rc;
+    out->n_chunks = r.n_chunks; out->n_reads = r.n_reads; out->consumed1 = r.consumed1; out->consumed2 = r.consumed2; out->input_ended = r.input_ended;
+    out->h_end1 = r.n_chunks ? ctx->scan_end[0].data() : nullptr;
+    out->h_end2 = (r.n_chunks && a->paired == RFQ_PE_TWO_FILES) ? ctx->scan_end[1].data() : nullptr;
+    return RFQ_OK;
+}
 
-static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended) {
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only) {
     memset(res, 0, sizeof *res);
     res->input_ended = ended ? 1 : 0;
-    const bool fin = a->final || ended;
+    const bool fin = a->final || ended || a->flush_all;
     if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
     if (a->chunk_bases == 0) return rfq_fail(ctx, RFQ_E_ARG, "chunk_bases must be >= 1");
     const int nstreams = a->paired == RFQ_PE_TWO_FILES ? 2 : 1;
@@ -222,7 +234,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // "\n\n" is a swallowed blank line, not an empty one: classify the text properly first.  On normalised text an empty line is
         // where FastqReader::read returns NULL (src/fastqreader.cpp:180-191): the record and everything after it are never read.
         if (!nm) return RFQ_NEED_NORM;
-        return encode_impl(ctx, a, res, nm, hs.first_empty / T.upr, true);
+        return encode_impl(ctx, a, res, nm, hs.first_empty / T.upr, true, scan_only);
     }
     if (hs.err & DE_QUAL_SHORT) return rfq_fail(ctx, RFQ_E_UNPINNED, "a quality line is shorter than its sequence line (the reference reads past the string: undefined)");
     const uint32_t n_chunks = hs.n_chunks;
@@ -230,6 +242,25 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (n_chunks == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
     const uint32_t units_used = hs.n_units_used, reads_used = units_used * T.upr;
     const uint64_t total_bases = hs.total_bases;
+    if (scan_only) {
+        // rfq_scan_batch stops here: where every chunk ends in the caller's stream(s)
+        HIPCHK(ctx, B[B_P].ensure(((size_t)n_chunks + 2) * 16));              // (the unit prefix is no longer needed)
+        uint64_t* e1 = B[B_P].as<uint64_t>(); uint64_t* e2 = e1 + n_chunks + 1;
+        hipLaunchKernelGGL(k_chunk_ends, dim3((n_chunks + 255) / 256), dim3(256), 0, S, T, (const uint32_t*)C.first, n_chunks,
+                           nm ? nm->onx[0] : nullptr, (nm && nstreams == 2) ? nm->onx[1] : nullptr, e1, e2);
+        KCHK(ctx, "k_chunk_ends");
+        ctx->scan_end[0].assign(n_chunks, 0); ctx->scan_end[1].assign(nstreams == 2 ? n_chunks : 0, 0);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->scan_end[0].data(), e1, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, S));
+        if (nstreams == 2) HIPCHK(ctx, hipMemcpyAsync(ctx->scan_end[1].data(), e2, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, S));
+        HIPCHK(ctx, hipStreamSynchronize(S));
+        const size_t lim0 = nm ? nm->orig_n[0] : nbytes[0], lim1 = nm ? nm->orig_n[1] : nbytes[1];
+        for (auto& v : ctx->scan_end[0]) if (v > lim0) v = lim0;             // (a virtual terminator past an unterminated last line)
+        for (auto& v : ctx->scan_end[1]) if (v > lim1) v = lim1;
+        res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases;
+        res->consumed1 = (size_t)ctx->scan_end[0].back(); res->consumed2 = nstreams == 2 ? (size_t)ctx->scan_end[1].back() : 0;
+        ctx->timer.collect();
+        return RFQ_OK;
+    }
 
     // ---- phase 3: header (first batch), chunk analysis, gather, plan
     const size_t nc = (size_t)n_chunks + 2;

@@ -336,6 +336,16 @@ __global__ void k_chunk_flags_se(ChunkTab C, const uint16_t* __restrict__ adj) {
         C.flags[c] = fl; C.il[c] = 0u;
     }
 }
+// rfq_scan_batch: offset just past the last record of every chunk, per input stream, in the caller's coordinates (onx: normalised text)
+__global__ void k_chunk_ends(Text T, const uint32_t* __restrict__ first, uint32_t n_chunks, const uint32_t* __restrict__ onx0, const uint32_t* __restrict__ onx1,
+                             uint64_t* __restrict__ end1, uint64_t* __restrict__ end2) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= n_chunks) return;
+    const uint32_t g = first[c + 1];                                        // reads (interleaved order) before the end of chunk c
+    const uint32_t rec = T.paired == 1 ? g >> 1 : g;                        // records consumed in each stream
+    const size_t li = 4 * (size_t)rec;
+    end1[c] = onx0 ? (rec ? (uint64_t)onx0[li - 1] : 0ull) : (uint64_t)T.lo[0][li];
+    if (T.paired == 1) end2[c] = onx1 ? (rec ? (uint64_t)onx1[li - 1] : 0ull) : (uint64_t)T.lo[1][li];
+}
 // bases per partition unit (a read, or a pair) + per-block min / max for the partitioner's uniform-length fast path
 // (no atomics: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
 __global__ void k_unit_len(const uint32_t* __restrict__ len, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax) {

@@ -77,3 +77,42 @@ def decode_in_slices(codec, rfq: bytes, split_pe: bool, step: int):
         pos += consumed
         end = min(len(rfq), max(end, pos) + step)
     return (bytes(out1), bytes(out2)) if split_pe else bytes(out1)
+
+
+def scan_and_encode_in_ranges(make_codec, fq1, fq2, paired, chunk_bases, parts):
+    """The multi-GPU host queue in miniature: one context plans the chunk ends (rfq_scan_batch), `parts` other contexts each encode a
+    contiguous range of chunks (flush_all, header of the first range set on the others); returns the concatenated image."""
+    from repaq_amd import PE_TWO_FILES, nolb_threshold
+    two = paired == PE_TWO_FILES
+    scanner = make_codec()
+    d1 = scanner.dev_put(fq1); d2 = scanner.dev_put(fq2) if two else None
+    r, e1, e2 = scanner.scan(d1, len(fq1), d2, len(fq2) if two else 0, paired, chunk_bases, final=True)
+    scanner.dev_free(d1)
+    if d2:
+        scanner.dev_free(d2)
+    scanner.close()
+    nc = r.n_chunks
+    th1 = nolb_threshold(len(fq1), fq1.endswith(b"\n")); th2 = nolb_threshold(len(fq2), fq2.endswith(b"\n")) if two else th1
+    out, hdr, base = b"", None, max(1, nc // parts)
+    for w in range(parts):
+        c0, c1 = w * base, (nc if w == parts - 1 else min(nc, (w + 1) * base))
+        if c1 <= c0:
+            continue
+        last = c1 == nc
+        s1, t1 = (e1[c0 - 1] if c0 else 0), (len(fq1) if last else e1[c1 - 1])
+        s2, t2 = ((e2[c0 - 1] if c0 else 0), (len(fq2) if last else e2[c1 - 1])) if two else (0, 0)
+        wk = make_codec()
+        if hdr is not None:
+            wk.setHeader(hdr)
+        p1, p2 = fq1[s1:t1], (fq2[s2:t2] if two else b"")
+        a1 = wk.dev_put(p1); a2 = wk.dev_put(p2) if two else None
+        rr = wk.encode(a1, len(p1), a2, len(p2) if two else 0, paired, chunk_bases, final=last, emit_header=(hdr is None), file_off1=s1, file_off2=s2,
+                       nolb_from1=th1, nolb_from2=th2, flush_all=not last)
+        out += wk.dev_get(rr.d_rfq, rr.rfq_len) if rr.rfq_len else b""
+        if hdr is None:
+            hdr = wk.header()
+        wk.dev_free(a1)
+        if a2:
+            wk.dev_free(a2)
+        wk.close()
+    return out, nc

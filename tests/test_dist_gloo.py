@@ -20,23 +20,27 @@ WORKER = textwrap.dedent('''
     fq1, _ = O.gen(O.NOVA_SE150, 900, seed=77)
     cb = 15000
     want = O.encode_file(fq1, b"", O.SE, cb)
-    offs = O.chunk_table(want)                       # chunk boundaries in the image (the oracle stands in for the plan pass here)
-    n_chunks = len(offs) - 1
-    # record ranges of each chunk: a chunk ends after the read that reaches cb bases (150-base reads -> 100 reads per chunk)
-    rpc = (cb + 149) // 150
+    # the plan pass (rfq_scan_batch): every rank finds where each chunk ends in the text, then takes its range of chunks
+    d = codec.dev_put(fq1)
+    r, ends, _ = codec.scan(d, len(fq1), None, 0, O.SE, cb, final=True)
+    codec.dev_free(d)
+    n_chunks = r.n_chunks
+    assert n_chunks == len(O.chunk_table(want)) - 1
     ranges = D.split_chunk_ranges(n_chunks, world)
     b, e = ranges[rank]
-    rec_bytes = [i for i, ch in enumerate(fq1) if ch == 10]
-    def rec_off(r):                                  # byte offset of record r
-        return 0 if r == 0 else rec_bytes[4 * r - 1] + 1
-    total_recs = len(rec_bytes) // 4
+    lo, hi = (ends[b - 1] if b else 0), (len(fq1) if e == n_chunks else ends[e - 1])
+    part = fq1[lo:hi]
+    def enc(emit_header):
+        dp = codec.dev_put(part)
+        rr = codec.encode(dp, len(part), None, 0, O.SE, cb, final=(e == n_chunks), emit_header=emit_header, file_off1=lo, flush_all=(e != n_chunks))
+        out = codec.dev_get(rr.d_rfq, rr.rfq_len)
+        codec.dev_free(dp)
+        return out
     if rank == 0:                                    # rank 0 encodes its range first: that makes the header from chunk 0
-        part = fq1[rec_off(b * rpc): rec_off(min(e * rpc, total_recs))]
-        img = codec.encode_bytes(part, b"", O.SE, cb, emit_header=True)
+        img = enc(True)
     hdr = D.share_header(codec)
     if rank != 0:
-        part = fq1[rec_off(b * rpc): rec_off(min(e * rpc, total_recs))]
-        img = codec.encode_bytes(part, b"", O.SE, cb, emit_header=False)
+        img = enc(False)
     gathered = [None] * world
     torch.distributed.all_gather_object(gathered, img)
     tmax, bsum = D.reduce_max_sum(0.5 + rank, len(part))

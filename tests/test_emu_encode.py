@@ -103,3 +103,21 @@ def test_position_coder_segments(codec):
     fq = _segment_boundary_fastq()
     assert E.encode(codec, fq, b"", O.SE, 1_000_000) == O.encode_file(fq, b"", O.SE, 1_000_000)
     assert E.encode(codec, fq, b"", O.SE, 140_000) == O.encode_file(fq, b"", O.SE, 140_000)
+
+
+@pytest.mark.parametrize("label", ["se_nonl", "pe_nonl2", "se_crlf", "interleaved"])
+def test_scan_then_chunk_parallel_encode_equals_one_shot(label):
+    """rfq_scan_batch plans the chunk ends; separate contexts encode chunk ranges with flush_all; the concatenation is the one-shot image."""
+    from repaq_amd import RfqCodec, PE_TWO_FILES, PE_INTERLEAVED, SE
+    mk = lambda: RfqCodec(device=0, library=E.EMU_LIB)
+    if label == "se_nonl":
+        fq1, fq2 = O.gen(O.NOVA_SE150, 3000, seed=5, nonl=1); paired = SE
+    elif label == "pe_nonl2":
+        fq1, fq2 = O.gen(O.NOVA_PE150, 2000, seed=6, nonl=2); paired = PE_TWO_FILES
+    elif label == "se_crlf":
+        fq1, fq2 = O.gen(O.SE_VAR, 2500, seed=7); fq1 = fq1.replace(b"\n", b"\r\n"); paired = SE
+    else:
+        fq1, fq2 = O.gen(O.NOVA_PE150, 1500, seed=8, interleaved=True); paired = PE_INTERLEAVED
+    for parts in (2, 5):
+        got, nc = E.scan_and_encode_in_ranges(mk, fq1, fq2, paired, 100_000, parts)
+        assert nc >= 3 and got == O.encode_file(fq1, fq2, paired, 100_000)
