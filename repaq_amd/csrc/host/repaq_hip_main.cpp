@@ -18,6 +18,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -29,6 +30,7 @@ static bool ends_with(const std::string& s, const std::string& e) { return s.siz
 struct Options {
     std::string in1, out1, in2, out2, rfqCompare, json;
     long chunkKb = 1000; bool compress = false, decompress = false, compare = false, useStdin = false, useStdout = false, interleaved = false;
+    std::vector<int> devices;              // --devices a,b,...: chunk-parallel compress of ONE input over several GPUs (host work queue)
     int device = 0; size_t batchBytes = (size_t)16 << 20; int threads = 1, compression = 3;   // 16 MB batches: the stages of the I/O pipeline overlap best (tools/batch_sweep.sh)
 };
 
@@ -249,6 +251,112 @@ static void do_compress(const Options& o) {
     for (int s = 0; s < ns; s++) { ds[s].free_all(g); delete in[s]; }
 }
 
+// Chunk-parallel compress of one input over several GPUs (a host work queue, no collective).  The main thread streams
+// the text to the first device and PLANS every batch there (rfq_scan_batch: where each chunk ends); the batch's chunks are dealt out
+// in contiguous ranges to one worker thread per device, which pulls its byte range device-to-device, encodes it with flush_all and
+// hands the image to an ordered writer.  Only the <= 272-byte header (made by the very first range) crosses between workers.
+struct WorkItem { uint64_t seq; const uint8_t* d1; size_t n1; const uint8_t* d2; size_t n2; uint64_t off1, off2, th1, th2; bool final; };
+static void do_compress_multi(const Options& o) {
+    const bool two = !o.in2.empty();
+    const int paired = two ? RFQ_PE_TWO_FILES : (o.interleaved ? RFQ_PE_INTERLEAVED : RFQ_SE);
+    const uint32_t chunk_bases = (uint32_t)(std::max(100L, o.chunkKb) * 1000);
+    Gpu gs(o.devices[0]);                                                    // scanner context
+    const size_t block = std::max<size_t>(o.batchBytes, (size_t)1 << 20);
+    Prefetcher* in[2] = { new Prefetcher(gs, o.in1, block), two ? new Prefetcher(gs, o.in2, block) : nullptr };
+    const int ns = two ? 2 : 1; DevStream ds[2];
+    // shared state
+    std::mutex mu; std::condition_variable cv;
+    std::deque<WorkItem> queue; bool no_more = false; uint64_t copied = 0;   // items whose input the workers have pulled off the scanner's buffers
+    std::vector<uint8_t> header; bool header_ready = false;
+    std::map<uint64_t, std::vector<uint8_t>> done; uint64_t next_write = 0, total_items = 0; bool all_queued = false;
+    ByteSink sink; sink.open(o.out1, o);
+    std::thread writer([&] {
+        for (;;) {
+            std::vector<uint8_t> buf;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.count(next_write) || (all_queued && next_write == total_items); });
+              if (all_queued && next_write == total_items) return;
+              buf = std::move(done[next_write]); done.erase(next_write); next_write++; cv.notify_all(); }
+            if (!buf.empty()) sink.write(buf.data(), buf.size());
+        }
+    });
+    std::vector<std::thread> workers;
+    for (size_t w = 0; w < o.devices.size(); w++) workers.emplace_back([&, w] {
+        Gpu g(o.devices[w]); void* b1 = nullptr; void* b2 = nullptr; size_t c1 = 0, c2 = 0; bool have_hdr = false;
+        for (;;) {
+            WorkItem it;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = queue.front(); queue.pop_front(); }
+            if (c1 < it.n1 + 64) { if (b1) rfq_dev_free(g.c, b1); c1 = it.n1 + it.n1 / 4 + 64; b1 = g.dev(c1); }
+            if (two && c2 < it.n2 + 64) { if (b2) rfq_dev_free(g.c, b2); c2 = it.n2 + it.n2 / 4 + 64; b2 = g.dev(c2); }
+            g.check(rfq_copy_d2d(g.c, b1, it.d1, it.n1)); if (two) g.check(rfq_copy_d2d(g.c, b2, it.d2, it.n2));
+            { std::unique_lock<std::mutex> lk(mu); copied++; cv.notify_all();
+              if (it.seq != 0 && !have_hdr) { cv.wait(lk, [&] { return header_ready; }); } }
+            if (it.seq != 0 && !have_hdr) { g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
+            rfq_encode_args a; memset(&a, 0, sizeof a);
+            a.d_fq1 = (const uint8_t*)b1; a.n1 = it.n1; a.d_fq2 = two ? (const uint8_t*)b2 : nullptr; a.n2 = two ? it.n2 : 0; a.paired = paired; a.chunk_bases = chunk_bases;
+            a.final = it.final ? 1 : 0; a.flush_all = it.final ? 0 : 1; a.emit_header = it.seq == 0 ? 1 : 0;
+            a.file_off1 = it.off1; a.file_off2 = it.off2; a.nolb_from1 = it.th1; a.nolb_from2 = it.th2;
+            rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
+            std::vector<uint8_t> img(r.rfq_len); if (r.rfq_len) g.check(rfq_copy_d2h(g.c, img.data(), r.d_rfq, r.rfq_len));
+            if (it.seq == 0) {                                               // the header every other range is coded under
+                uint8_t hb[RFQ_HEADER_MAX]; size_t hn = 0; have_hdr = true;
+                if (r.n_chunks) g.check(rfq_get_header(g.c, hb, &hn));
+                std::unique_lock<std::mutex> lk(mu); header.assign(hb, hb + hn); header_ready = true; cv.notify_all();
+            }
+            std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.size() < 4 * o.devices.size() || it.seq == next_write; });
+            done[it.seq] = std::move(img); cv.notify_all();
+        }
+        if (b1) rfq_dev_free(g.c, b1); if (b2) rfq_dev_free(g.c, b2);
+    });
+    uint64_t seq = 0; size_t want = block;
+    for (;;) {
+        for (int s = 0; s < ns; s++) {
+            while (!ds[s].ended && ds[s].have < want) {
+                Block b; if (!in[s]->next(b)) { ds[s].ended = true; break; }
+                if (ds[s].have + b.n >= 0xFFFFFFF0ull) error_exit("a batch of one FASTQ stream must stay below 4 GiB (chunk larger than that, or paired files of very different length)");
+                ds[s].append(gs, b); in[s]->release(b);
+                if (in[s]->drained()) ds[s].ended = true;
+            }
+        }
+        const bool final = ds[0].ended && (!two || ds[1].ended);
+        rfq_encode_args a; memset(&a, 0, sizeof a);
+        a.d_fq1 = ds[0].base(); a.n1 = ds[0].have; a.d_fq2 = two ? ds[1].base() : nullptr; a.n2 = two ? ds[1].have : 0; a.paired = paired;
+        a.chunk_bases = chunk_bases; a.final = final ? 1 : 0; a.file_off1 = ds[0].file_off; a.file_off2 = ds[1].file_off;
+        rfq_scan_result sr; gs.check(rfq_scan_batch(gs.c, &a, &sr));
+        uint64_t th[2] = { UINT64_MAX, UINT64_MAX };
+        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t && in[s]->final_byte() != '\n') th[s] = ((t - 1) >> 20) << 20; }
+        const bool last_batch = final || sr.input_ended;
+        if (sr.n_chunks == 0 && !last_batch) { want = std::max(ds[0].have, ds[1].have) + block; continue; }
+        // deal the chunks out in contiguous ranges, one per device (fewer when the batch holds fewer chunks)
+        const uint32_t parts = sr.n_chunks ? (uint32_t)std::min<size_t>(o.devices.size(), sr.n_chunks) : 1u;
+        uint64_t first_seq = seq;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            for (uint32_t p = 0; p < parts; p++) {
+                const uint32_t c0 = (uint32_t)((uint64_t)sr.n_chunks * p / parts), c1 = (uint32_t)((uint64_t)sr.n_chunks * (p + 1) / parts);
+                const bool tail = p + 1 == parts;
+                const uint64_t s1 = c0 ? sr.h_end1[c0 - 1] : 0, s2 = (two && c0) ? sr.h_end2[c0 - 1] : 0;
+                // the last range of the last batch runs to the end of the data (final semantics see every byte, like the one-shot encode)
+                const uint64_t e1 = (tail && last_batch && !sr.input_ended) ? ds[0].have : (c1 ? sr.h_end1[c1 - 1] : 0);
+                const uint64_t e2 = two ? ((tail && last_batch && !sr.input_ended) ? ds[1].have : (c1 ? sr.h_end2[c1 - 1] : 0)) : 0;
+                WorkItem it; it.seq = seq++; it.d1 = ds[0].base() + s1; it.n1 = (size_t)(e1 - s1); it.d2 = two ? ds[1].base() + s2 : nullptr; it.n2 = (size_t)(e2 - s2);
+                it.off1 = ds[0].file_off + s1; it.off2 = ds[1].file_off + s2; it.th1 = th[0]; it.th2 = two ? th[1] : th[0];
+                it.final = tail && last_batch && !sr.input_ended;
+                queue.push_back(it);
+            }
+            cv.notify_all();
+            cv.wait(lk, [&] { return copied == seq; });                      // the ranges are off the scanner's buffers: they may be recycled
+        }
+        (void)first_seq;
+        if (last_batch) break;
+        ds[0].advance(gs, sr.consumed1, block); if (two) ds[1].advance(gs, sr.consumed2, block);
+        want = block;
+    }
+    { std::unique_lock<std::mutex> lk(mu); no_more = true; total_items = seq; all_queued = true; cv.notify_all(); }
+    for (auto& t : workers) t.join();
+    writer.join(); sink.close();
+    for (int s = 0; s < ns; s++) { ds[s].free_all(gs); delete in[s]; }
+}
+
 // Streaming decoder: .rfq blocks -> rfq_decode_batch over whole chunks -> device text handed to `emit_dev(out1, n1, out2, n2)`
 struct DecodeTotals { uint64_t reads = 0, bases = 0; };
 static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& path, bool split,
@@ -384,7 +492,7 @@ static void do_compare(const Options& o) {
 static void usage() {
     fputs("repaq_hip: repack FASTQ to .rfq on an MI355X (repaq v0.5.1 compatible)\n"
           "usage: repaq_hip [-c|-d|-p] -i in1 [-I in2] -o out1 [-O out2] [-k chunk_kb] [--stdin] [--stdout] [--interleaved_in]\n"
-          "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N] [--batch_mb M]\n"
+          "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N | --devices a,b,...] [--batch_mb M]\n"
           "       FASTQ may be .gz (zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
 }
 int main(int argc, char** argv) {
@@ -416,6 +524,7 @@ int main(int argc, char** argv) {
         else if (a == "-t" || a == "--thread" || a.rfind("--thread=", 0) == 0) o.threads = atoi(val(i, "thread").c_str());
         else if (a == "-z" || a == "--compression" || a.rfind("--compression=", 0) == 0) o.compression = atoi(val(i, "compression").c_str());
         else if (a == "--device") o.device = atoi(val(i, "device").c_str());
+        else if (a == "--devices" || a.rfind("--devices=", 0) == 0) { const std::string v = val(i, "devices"); size_t p0 = 0; while (p0 <= v.size()) { const size_t q = v.find(',', p0); const std::string t = v.substr(p0, q == std::string::npos ? std::string::npos : q - p0); if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (q == std::string::npos) break; p0 = q + 1; } }
         else if (a == "--batch_mb") o.batchBytes = (size_t)atol(val(i, "batch_mb").c_str()) << 20;
         else { usage(); error_exit("unknown option: " + a); }
     }
@@ -446,7 +555,7 @@ int main(int argc, char** argv) {
         if (!o.out2.empty()) error_exit("In compress mode, only one RFQ output file is allowed, but you specified <out2>");
         if (ends_with(o.out1, ".fq") || ends_with(o.out1, ".fastq")) error_exit("In compress mode, the output should not be a FASTQ file. Expect a .rfq or .rfq.xz file, but got " + o.out1);
         if (ends_with(o.in1, ".rfq")) error_exit("In compress mode, the input should not be a RFQ file. Expect a .fq or .fq.gz file, but got " + o.in1);
-        do_compress(o);
+        if (o.devices.size() > 1) do_compress_multi(o); else { if (o.devices.size() == 1) o.device = o.devices[0]; do_compress(o); }
     } else if (dec) {
         if (!o.in2.empty()) error_exit("In decompress mode, only one RFQ input file is allowed, but you specified <in2>");
         if (ends_with(o.in1, ".fq") || ends_with(o.in1, ".fastq")) error_exit("In decompress mode, the input should not be a FASTQ file. Expect a .rfq or .rfq.xz file, but got " + o.in1);

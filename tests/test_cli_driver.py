@@ -82,6 +82,18 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     assert r.returncode == 0 and r.stdout == fq1, r.stderr
     r = _run(binary, ["-d", "-i", str(pe), "--stdout", "--batch_mb", str(batch_mb)])
     assert r.returncode == 0 and r.stdout == O.decode_file(pe.read_bytes(), False)
+    # --devices a,b,c: one input planned on the first device (rfq_scan_batch), its chunk ranges encoded on one context per listed device
+    # (flush_all) and written in order — the image must be the one-shot image whatever the split
+    om = tmp_path / "multi.rfq"
+    for src, ref in ((p, og.read_bytes()), (pc, O.encode_file(crlf, b"", O.SE, 100_000)), (ps, want), (p, og.read_bytes())):
+        r = _run(binary, ["-c", "-i", str(src), "-o", str(om), "-k", "100", "--batch_mb", str(batch_mb), "--devices", "0,0,0"])
+        assert r.returncode == 0, r.stderr
+        assert om.read_bytes() == ref
+    r = _run(binary, ["-c", "-i", str(pa), "-I", str(pb), "-o", str(om), "-k", "100", "--batch_mb", str(batch_mb), "--devices", "0,0"])
+    assert r.returncode == 0, r.stderr
+    assert om.read_bytes() == pe.read_bytes()
+    r = _run(binary, ["-c", "--stdin", "--stdout", "-k", "100", "--batch_mb", str(4 * batch_mb), "--devices=0,0,0,0"], input=fq1)
+    assert r.returncode == 0 and r.stdout == og.read_bytes(), r.stderr
     # an empty input leaves an empty .rfq, which decodes to an empty FASTQ (RfqHeader defaults, src/rfqheader.cpp:7-17)
     pz = tmp_path / "empty.fq"; pz.write_bytes(b""); oz = tmp_path / "empty.rfq"; bz = tmp_path / "empty_back.fq"
     assert _run(binary, ["-c", "-i", str(pz), "-o", str(oz)]).returncode == 0 and oz.read_bytes() == b""

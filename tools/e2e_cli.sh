@@ -5,6 +5,7 @@ D=/dev/shm/e2e; mkdir -p $D
 ls -l $D/a.fq | awk '{print "fastq bytes", $5}'
 B=repaq_amd/bin/repaq_hip
 for i in 1 2; do TIMEFORMAT="compress wall %R s"; time $B -c -i $D/a.fq -o $D/a.rfq; done
+TIMEFORMAT="compress --devices 0,0 (two contexts, one GPU) wall %R s"; time $B -c -i $D/a.fq -o $D/a3.rfq --devices 0,0; cmp $D/a.rfq $D/a3.rfq && echo MULTI_CONTEXT_OK; rm -f $D/a3.rfq
 ls -l $D/a.rfq | awk '{print "rfq bytes", $5}'
 for i in 1 2; do TIMEFORMAT="decompress wall %R s"; time $B -d -i $D/a.rfq -o $D/b.fq; done
 cmp $D/a.fq $D/b.fq && echo ROUNDTRIP_OK
