@@ -157,6 +157,12 @@ int rfq_copy_d2d(rfq_ctx* ctx, void* d_dst, const void* d_src, size_t n);
 int rfq_host_alloc(rfq_ctx* ctx, void** h_ptr, size_t n);
 int rfq_host_free(rfq_ctx* ctx, void* h_ptr);
 
+/* --compare on the device (Repaq::compare / comparePE, src/repaq.cpp:36-233): the first offset at which two device texts differ,
+ * *first_diff = n when they are identical.  A decoded batch equal byte for byte to the same span of the FASTQ text passes the
+ * reference's four per-read tests (name, sequence, strand, quality; :85-108) for every read in it; the host cuts records only in
+ * a batch that differs, to word the reference's message. */
+int rfq_compare_bytes(rfq_ctx* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first_diff);
+
 /* library / build info: "rfq_hip <version> gfx950" (or "... simt-emulation" for the test build) */
 const char* rfq_version(void);
 

@@ -78,6 +78,12 @@ class RfqCodec:
         self._check(self._L.rfq_decode_batch(self._h, C.byref(a), C.byref(r)))
         return r
 
+    # --- --compare on the device: first offset at which two device texts differ (n when identical)
+    def first_diff(self, d_a, d_b, n) -> int:
+        out = C.c_uint64(0)
+        self._check(self._L.rfq_compare_bytes(self._h, d_a, d_b, n, C.byref(out)))
+        return out.value
+
     def timings(self):
         names = (C.c_char_p * 32)(); ms = (C.c_float * 32)()
         n = self._L.rfq_last_timings(self._h, names, ms, 32)

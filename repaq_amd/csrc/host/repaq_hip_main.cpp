@@ -115,11 +115,11 @@ struct Gpu {
 struct Block { uint8_t* p = nullptr; size_t n = 0; };
 class Prefetcher {
     ByteSource src; Gpu& g; size_t block; std::thread th; std::mutex mu; std::condition_variable cv;
-    std::deque<Block> ready; std::vector<uint8_t*> freeb; bool eof = false; uint64_t total = 0; int last_byte = -1;
+    std::deque<Block> ready; std::vector<uint8_t*> freeb; bool eof = false, stop = false; uint64_t total = 0; int last_byte = -1;
     void run() {
         for (;;) {
             uint8_t* buf;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !freeb.empty(); }); buf = freeb.back(); freeb.pop_back(); }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !freeb.empty() || stop; }); if (stop) { eof = true; cv.notify_all(); return; } buf = freeb.back(); freeb.pop_back(); }
             const size_t n = src.read(buf, block);
             std::unique_lock<std::mutex> lk(mu);
             if (n) { total += n; last_byte = buf[n - 1]; ready.push_back(Block{ buf, n }); } else freeb.push_back(buf);
@@ -136,7 +136,8 @@ public:
         for (int i = 0; i < 4; i++) freeb.push_back(g.pinned(block));
         th = std::thread([this] { run(); });
     }
-    ~Prefetcher() { if (th.joinable()) th.join(); src.close(); }
+    // (a caller that stops early — an empty line ends the input, a failed compare — leaves blocks unread: wake the reader up)
+    ~Prefetcher() { { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); } if (th.joinable()) th.join(); src.close(); }
     // next block; false when the input is exhausted.  After it returns, end_known() tells whether the reader has seen the end
     // of the input; if not, at least two more full blocks follow the one just returned.
     bool next(Block& b) {
@@ -360,7 +361,8 @@ static void do_compress_multi(const Options& o) {
 // Streaming decoder: .rfq blocks -> rfq_decode_batch over whole chunks -> device text handed to `emit_dev(out1, n1, out2, n2)`
 struct DecodeTotals { uint64_t reads = 0, bases = 0; };
 static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& path, bool split,
-                                  const std::function<void(const uint8_t*, size_t, const uint8_t*, size_t)>& emit_dev) {
+                                  const std::function<void(const uint8_t*, size_t, const uint8_t*, size_t)>& emit_dev,
+                                  const std::function<void(const rfq_decode_result&)>& on_batch = nullptr) {
     // ~1/8 of the text batch: .rfq is 7-25 % of its FASTQ, so one call stays far below the 4 GiB-per-call text limit
     const size_t block = std::max<size_t>(o.batchBytes / 8, (size_t)1 << 16);
     Prefetcher in(g, path, block);
@@ -376,6 +378,7 @@ static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& p
         rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
         first = false;
         tot.reads += r.n_reads; tot.bases += r.n_bases;
+        if (on_batch) on_batch(r);
         if (r.n1 || r.n2) emit_dev(r.d_fq1, r.n1, r.d_fq2, r.n2);
         if (ds.ended) break;
         if (r.consumed == 0) { want = ds.have + block; continue; }            // not one whole chunk yet
@@ -400,20 +403,29 @@ static void do_decompress(const Options& o) {
 struct Rec { std::string f[4]; };
 struct TextCursor {                      // growing text + a refill callback; records are cut with FastqReader's line rules
     std::vector<uint8_t> t; size_t pos = 0; bool ended = false; std::function<void(TextCursor&)> refill;
-    void compact() { if (pos > (1u << 24)) { t.erase(t.begin(), t.begin() + pos); pos = 0; } }
+    uint64_t off0 = 0;                   // offset of t[0] in its (decompressed) file: the reader works in 1 MiB blocks of it
+    void compact() { if (pos > (1u << 24)) { t.erase(t.begin(), t.begin() + pos); off0 += pos; pos = 0; } }
+    // FastqReader::getLine + read (src/fastqreader.cpp:94-196): a line ends at '\r' or '\n'; one '\n' right after the terminator is
+    // skipped too, unless it is the last byte of the reader's 1 MiB block (for the last block: of the file) or opens the next block
+    // (`end < mBufDataLen-1`, :112-114); a record with an empty line ends the input
     bool next(Rec& r) {
         for (;;) {
-            size_t p = pos; int k = 0; bool need = false;
+            size_t p = pos; int k = 0; bool need = false, empty = false;
             for (; k < 4; k++) {
-                if (p >= t.size()) { need = !ended; break; }
+                if (p >= t.size()) { if (!ended) { need = true; break; } r.f[k].clear(); empty = true; continue; }
                 size_t e = p; while (e < t.size() && t[e] != '\n' && t[e] != '\r') e++;
-                if (e + 1 >= t.size() && !ended) { need = true; break; }      // the line (or its "\r\n") may continue in the next refill
+                if (e + 2 >= t.size() && !ended) { need = true; break; }      // the rule looks one byte past the candidate '\n'
                 r.f[k].assign((const char*)t.data() + p, e - p);
-                if (e < t.size() && t[e] == '\r' && e + 1 < t.size() && t[e + 1] == '\n') e++;
-                p = e + 1;
-                if (r.f[k].empty()) return false;
+                size_t nx = e + 1;
+                if (nx < t.size() && t[nx] == '\n') {
+                    const uint64_t at = off0 + nx;
+                    const bool opens_block = (at & 0xFFFFF) == 0, closes_block = ((at + 1) & 0xFFFFF) == 0 || nx + 1 == t.size();
+                    if (!opens_block && !closes_block) nx++;
+                }
+                p = std::min(nx, t.size());
+                if (r.f[k].empty()) empty = true;
             }
-            if (k == 4) { pos = p; return true; }
+            if (k == 4) { pos = p; return !empty; }
             if (!need) return false;
             compact(); refill(*this);
         }
@@ -430,12 +442,56 @@ static void report(const Options& o, bool passed, const std::string& msg, long f
 }
 static void do_compare(const Options& o) {
     Gpu g(o.device);
-    const bool pe = !o.in2.empty();
-    // decoded side: a producer thread decodes batch after batch into two bounded text queues
+    const bool pe = !o.in2.empty(); const int ns = pe ? 2 : 1;
+    // Fast path, on the device: every decoded batch is compared byte for byte with the same span of the FASTQ
+    // text uploaded beside it (rfq_compare_bytes); identical bytes mean identical reads, so only counters move.  The first batch
+    // that differs (a real mismatch, or text the reader would have normalised: "\r\n", blank lines) hands both sides over to the
+    // record-by-record comparison below, which words the reference's message; so does the end of the image, for the
+    // "FASTQ has more reads" test.
+    const size_t block = std::max<size_t>(o.batchBytes, (size_t)1 << 20);
+    Prefetcher* pf[2] = { new Prefetcher(g, o.in1, block), pe ? new Prefetcher(g, o.in2, block) : nullptr };
+    DevStream fs[2]; bool fast = true;
+    long fqReads = 0, fqBases = 0, rfqReads = 0, rfqBases = 0; bool reported = false;
+    TextCursor dec[2], fq[2];
+    std::mutex hm; std::condition_variable hcv; bool handed = false;
+    auto handover = [&] {                                                     // the FASTQ side from here on belongs to the main thread
+        for (int s = 0; s < ns; s++) {
+            fq[s].off0 = fs[s].file_off;
+            if (fs[s].have) { fq[s].t.resize(fs[s].have); g.check(rfq_copy_d2h(g.c, fq[s].t.data(), fs[s].base(), fs[s].have)); }
+            fs[s].free_all(g); fs[s] = DevStream();
+        }
+        fast = false;
+        std::unique_lock<std::mutex> lk(hm); handed = true; hcv.notify_all();
+    };
+    // decoded side: a producer thread decodes batch after batch; once off the fast path it fills two bounded text queues
     struct Q { std::mutex mu; std::condition_variable cv; std::deque<std::vector<uint8_t>> q; bool done = false, discard = false; } dq[2];
     std::thread producer([&] {
+        rfq_decode_result cur; memset(&cur, 0, sizeof cur);
         decode_stream(g, o, o.rfqCompare, pe, [&](const uint8_t* d1, size_t n1, const uint8_t* d2, size_t n2) {
             const uint8_t* dp[2] = { d1, d2 }; const size_t dn[2] = { n1, pe ? n2 : 0 };
+            if (fast) {
+                bool same = true;
+                for (int s = 0; s < ns && same; s++) {
+                    while (!fs[s].ended && fs[s].have < dn[s]) {
+                        Block b; if (!pf[s]->next(b)) { fs[s].ended = true; break; }
+                        if (fs[s].have + b.n >= 0xFFFFFFF0ull) { pf[s]->release(b); same = false; break; }
+                        fs[s].append(g, b); pf[s]->release(b);
+                        if (pf[s]->drained()) fs[s].ended = true;
+                    }
+                    if (!same || fs[s].have < dn[s]) { same = false; break; }
+                    uint64_t at = 0; g.check(rfq_compare_bytes(g.c, dp[s], fs[s].base(), dn[s], &at));
+                    same = at == dn[s];
+                    // text that stops without a line break (the file's last read, NO_LINE_BREAK bit): whether the FASTQ ends there too,
+                    // or goes on with a break or with more of the line, is for the record cutter to say
+                    if (same && dn[s]) { uint8_t last = 0; g.check(rfq_copy_d2h(g.c, &last, dp[s] + dn[s] - 1, 1)); same = last == '\n'; }
+                }
+                if (same) {
+                    rfqReads += (long)cur.n_reads; fqReads += (long)cur.n_reads; rfqBases += (long)cur.n_bases; fqBases += (long)cur.n_bases;
+                    for (int s = 0; s < ns; s++) fs[s].advance(g, dn[s], block);
+                    return;
+                }
+                handover();
+            }
             for (int s = 0; s < 2; s++) if (dn[s]) {
                 { std::unique_lock<std::mutex> lk(dq[s].mu); if (dq[s].discard) continue; }
                 std::vector<uint8_t> v(dn[s]); g.check(rfq_copy_d2h(g.c, v.data(), dp[s], dn[s]));
@@ -443,50 +499,54 @@ static void do_compare(const Options& o) {
                 if (!dq[s].discard) dq[s].q.push_back(std::move(v));
                 dq[s].cv.notify_all();
             }
-        });
+        }, [&](const rfq_decode_result& r) { cur = r; });
+        if (fast) handover();
         for (int s = 0; s < 2; s++) { std::unique_lock<std::mutex> lk(dq[s].mu); dq[s].done = true; dq[s].cv.notify_all(); }
     });
-    TextCursor dec[2], fq[2]; ByteSource src[2];
     for (int s = 0; s < 2; s++) dec[s].refill = [&dq, s](TextCursor& c) {
         std::unique_lock<std::mutex> lk(dq[s].mu); dq[s].cv.wait(lk, [&] { return !dq[s].q.empty() || dq[s].done; });
         if (dq[s].q.empty()) { c.ended = true; return; }
         c.t.insert(c.t.end(), dq[s].q.front().begin(), dq[s].q.front().end()); dq[s].q.pop_front(); dq[s].cv.notify_all();
     };
-    if (!src[0].open(o.in1)) error_exit("Failed to open file: " + o.in1);
-    if (pe && !src[1].open(o.in2)) error_exit("Failed to open file: " + o.in2);
-    for (int s = 0; s < (pe ? 2 : 1); s++) fq[s].refill = [&src, s](TextCursor& c) {
-        const size_t old = c.t.size(), want = (size_t)8 << 20; c.t.resize(old + want);
-        const size_t n = src[s].read(c.t.data() + old, want); c.t.resize(old + n); if (n < want) c.ended = true;
+    for (int s = 0; s < ns; s++) fq[s].refill = [&pf, s](TextCursor& c) {
+        Block b; if (!pf[s]->next(b)) { c.ended = true; return; }
+        c.t.insert(c.t.end(), b.p, b.p + b.n); pf[s]->release(b);
     };
-    long fqReads = 0, fqBases = 0, rfqReads = 0, rfqBases = 0; bool reported = false;
+    { std::unique_lock<std::mutex> lk(hm); hcv.wait(lk, [&] { return handed; }); }
     static const char* what[4] = { "name", "sequence", "strand", "quality" };
+    // compare (:36-128) counts and words in reads; comparePE (:130-233) draws a whole pair from the two files when it meets the
+    // first read of a pair (FastqReaderPair::read: NULL as soon as either file is out of reads) and words in pairs, rfqReads / 2
+    const std::string unit = pe ? " pair. " : " read. ", units = pe ? " pairs" : " reads";
+    auto cnt = [&](long reads) { return std::to_string(pe ? reads / 2 : reads); };
+    Rec pair[2]; bool have_pair = false;
     for (;;) {
         Rec r; const bool second = pe && (rfqReads & 1);
         if (!dec[second ? 1 : 0].next(r)) break;
         rfqReads++; rfqBases += (long)r.f[1].size();
-        Rec q;
-        if (!fq[second ? 1 : 0].next(q)) {
-            report(o, false, "The RFQ file has more reads than the FASTQ file. The RFQ file has >= " + std::to_string(rfqReads) + " reads, while the FASTQ file only has " + std::to_string(fqReads) + " reads", fqReads, fqBases, rfqReads, rfqBases);
+        if (!second) have_pair = fq[0].next(pair[0]) && (!pe || fq[1].next(pair[1]));
+        if (!have_pair) {
+            report(o, false, "The RFQ file has more reads than the FASTQ file. The RFQ file has >= " + cnt(rfqReads) + units + ", while the FASTQ file only has " + cnt(fqReads) + units, fqReads, fqBases, rfqReads, rfqBases);
             reported = true; break;
         }
+        const Rec& q = pair[second ? 1 : 0];
         fqReads++; fqBases += (long)q.f[1].size();
         for (int k = 0; k < 4 && !reported; k++) if (r.f[k] != q.f[k]) {
-            report(o, false, std::string("The RFQ file and FASTQ file have different ") + what[k] + " in the " + std::to_string(rfqReads) + " read. " + r.f[k] + " | " + q.f[k], fqReads, fqBases, rfqReads, rfqBases);
+            report(o, false, std::string("The RFQ file and FASTQ file have different ") + what[k] + " in the " + cnt(rfqReads) + unit + r.f[k] + " | " + q.f[k], fqReads, fqBases, rfqReads, rfqBases);
             reported = true;
         }
         if (reported) break;
     }
     if (!reported) {
         Rec q;
-        if (fq[0].next(q) || (pe && fq[1].next(q))) {
+        if (fq[0].next(q) && (!pe || fq[1].next(q))) {
             fqReads++;
-            report(o, false, "The FASTQ file has more reads than the RFQ file. The FASTQ file has >= " + std::to_string(fqReads) + " reads, while the RFQ file only has " + std::to_string(rfqReads) + " reads", fqReads, fqBases, rfqReads, rfqBases);
+            report(o, false, "The FASTQ file has more reads than the RFQ file. The FASTQ file has >= " + cnt(fqReads) + units + ", while the RFQ file only has " + cnt(rfqReads) + units, fqReads, fqBases, rfqReads, rfqBases);
         } else report(o, true, "", fqReads, fqBases, rfqReads, rfqBases);
     }
     // a failed compare stops consuming early: let the producer run to its end without queueing
     for (int s = 0; s < 2; s++) { std::unique_lock<std::mutex> lk(dq[s].mu); dq[s].discard = true; dq[s].q.clear(); dq[s].cv.notify_all(); }
     producer.join();
-    src[0].close(); if (pe) src[1].close();
+    for (int s = 0; s < ns; s++) delete pf[s];
 }
 
 static void usage() {

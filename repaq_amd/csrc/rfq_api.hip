@@ -1,6 +1,7 @@
 // rfq_api.hip — context management and header plumbing of the C-ABI (include/rfq_hip.h).
 #include "rfq_ctx.h"
 #include <cstring>
+#include <algorithm>
 #include <new>
 
 extern "C" const char* rfq_version(void) {
@@ -33,7 +34,7 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& b : c->b) b.release();
-    c->d_hdr.release(); c->d_status.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release();
+    c->d_hdr.release(); c->d_status.release(); c->d_cmp.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release();
     c->timer.destroy();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -96,6 +97,47 @@ extern "C" int rfq_copy_d2d(rfq_ctx* c, void* dst, const void* src, size_t n) {
     if (!c) return RFQ_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (n) { HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    return RFQ_OK;
+}
+// First byte at which two device texts differ (n when they are equal).  --compare on the device: a decoded batch
+// that is byte-identical to the same span of the FASTQ file has, read for read, equal name / sequence / strand / quality
+// (Repaq::compare's four tests, src/repaq.cpp:85-108); only a differing batch is cut into records by the caller to word the message.
+// Pure HBM stream: 2 x n bytes read, one atomicMin per thread that saw a difference.
+__global__ __launch_bounds__(256) void k_first_diff(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t n, unsigned long long* __restrict__ out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long best = ~0ull;
+    if (((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0) {
+        const uint64_t n16 = n >> 4;
+        const uint4* a4 = (const uint4*)a; const uint4* b4 = (const uint4*)b;
+        for (uint64_t i = tid; i < n16; i += stride) {
+            const uint4 x = a4[i], y = b4[i];
+            const uint32_t d[4] = { x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w };
+            if (d[0] | d[1] | d[2] | d[3]) {
+                for (int w = 0; w < 4; w++) if (d[w]) { best = i * 16 + w * 4 + ((__ffs((int)d[w]) - 1) >> 3); break; }
+                break;                                                        // ascending i: the first hit of this thread is its smallest
+            }
+        }
+        if (tid == 0) for (uint64_t i = n16 << 4; i < n; i++) if (a[i] != b[i]) { if (i < best) best = i; break; }
+    } else {
+        for (uint64_t i = tid; i < n; i += stride) if (a[i] != b[i]) { best = i; break; }
+    }
+    if (best != ~0ull) atomicMin(out, best);
+}
+extern "C" int rfq_compare_bytes(rfq_ctx* c, const void* d_a, const void* d_b, size_t n, uint64_t* first_diff) {
+    if (!c || !first_diff || (n && (!d_a || !d_b))) return RFQ_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    *first_diff = n;
+    if (!n) return RFQ_OK;
+    HIPCHK(c, c->d_cmp.ensure(8));
+    unsigned long long init = ~0ull, got = 0;
+    HIPCHK(c, hipMemcpyAsync(c->d_cmp.p, &init, 8, hipMemcpyHostToDevice, c->stream));
+    const uint64_t items = (n >> 4) + 1;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((items + 255) / 256, 256u * 16u);
+    hipLaunchKernelGGL(k_first_diff, dim3(blocks), dim3(256), 0, c->stream, (const uint8_t*)d_a, (const uint8_t*)d_b, (uint64_t)n, c->d_cmp.as<unsigned long long>());
+    KCHK(c, "k_first_diff");
+    HIPCHK(c, hipMemcpyAsync(&got, c->d_cmp.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (got != ~0ull) *first_diff = (uint64_t)got;
     return RFQ_OK;
 }
 extern "C" int rfq_host_alloc(rfq_ctx* c, void** p, size_t n) {

@@ -55,6 +55,7 @@ struct rfq_ctx {
     DBuf d_hdr;                 // DevHeader
     DevHeader h_hdr; bool have_hdr = false;
     DBuf d_status; DevStatus h_status;
+    DBuf d_cmp;                 // rfq_compare_bytes: one u64 (first differing offset)
     // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
     DBuf b[96];
     DBuf out_img, out_fq1, out_fq2;

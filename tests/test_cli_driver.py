@@ -103,12 +103,75 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     pbad = tmp_path / "r1_bad.fq"; pbad.write_bytes(bytes(bad))
     r = _run(binary, ["-p", "-i", str(pbad), "-I", str(pb), "-r", str(pe)])
     j = json.loads(r.stdout)
-    assert j["result"] == "failed" and "different sequence in the 1 read" in j["msg"]
+    assert j["result"] == "failed" and "different sequence in the 0 pair" in j["msg"]     # comparePE words rfqReads / 2 (src/repaq.cpp:195)
     # flag validation texts (src/options.cpp:36-111)
     r = _run(binary, ["-c", "-i", str(p)])
     assert r.returncode == 255 and b"Please specify output file by <out1>" in r.stderr
     r = _run(binary, ["-c", "-d", "-i", str(p), "-o", str(out)])
     assert r.returncode == 255 and b"you can only choose any one mode" in r.stderr
+
+
+def _compare_suite(binary, tmp_path, batch_mb):
+    """--compare (src/repaq.cpp:36-259): batches equal on the device move only counters; a differing batch is cut into records to word
+    the reference's message.  Every scenario's JSON is checked against the compiled reference binary when it is present."""
+    import gzip
+    fq, _ = O.gen(O.NOVA_SE150, 6000, seed=77, nonl=1)
+    recs = fq.split(b"\n"); assert len(recs) == 24000
+    def edit(read, field, fn):
+        r = list(recs); r[read * 4 + field] = fn(r[read * 4 + field]); return b"\n".join(r)
+    flip = lambda b: (b"A" if b[:1] != b"A" else b"C") + b[1:]
+    a, b = O.gen(O.NOVA_PE150, 2500, seed=78)
+    brecs = b.split(b"\n")
+    b_bad = list(brecs); b_bad[2100 * 4 + 3] = flip(b_bad[2100 * 4 + 3]); b_bad = b"\n".join(b_bad)
+    b_short = b"\n".join(brecs[:2000 * 4]) + b"\n"
+    rfq_se = O.encode_file(fq, b"", O.SE, 100_000); rfq_pe = O.encode_file(a, b, O.PE_TWO_FILES, 100_000)
+    (tmp_path / "se.rfq").write_bytes(rfq_se); (tmp_path / "pe.rfq").write_bytes(rfq_pe)
+    # "\r" as the last byte of the reader's first 1 MiB block, its "\n" opening the next: that "\n" reads as an empty line and ends the input
+    crlf = fq.replace(b"\n", b"\r\n"); at = crlf.index(b"\r\n", (1 << 20) - 400)
+    lines = crlf.split(b"\r\n"); d = (1 << 20) - 1 - at; k = 0
+    while d:                                               # push that "\r" onto the block's last byte by padding a few names
+        lines[k * 4] += b"p" * min(d, 100); d -= min(d, 100); k += 1
+    split = b"\r\n".join(lines)
+    assert split[(1 << 20) - 1:(1 << 20) + 1] == b"\r\n"
+    rfq_split = O.encode_file(split, b"", O.SE, 100_000); n_split = len(O.decode_file(rfq_split, False).split(b"\n")) // 4
+    assert 0 < n_split < 6000
+    (tmp_path / "split.rfq").write_bytes(rfq_split)
+    scen = {                                           # name -> (fq1, fq2 | None, rfq file, passed, message fragment)
+        "same": (fq, None, "se.rfq", True, ""),
+        "crlf": (fq.replace(b"\n", b"\r\n"), None, "se.rfq", True, ""),
+        "with_final_newline": (fq + b"\n", None, "se.rfq", True, ""),
+        "name_late": (edit(5000, 0, lambda x: x + b"x"), None, "se.rfq", False, "different name in the 5001 read"),
+        "seq_first": (edit(0, 1, flip), None, "se.rfq", False, "different sequence in the 1 read"),
+        "strand_mid": (edit(3000, 2, lambda x: x + b"k"), None, "se.rfq", False, "different strand in the 3001 read"),
+        "qual_last": (edit(5999, 3, flip), None, "se.rfq", False, "different quality in the 6000 read"),
+        "fastq_longer": (fq + b"\n" + b"\n".join(recs[:4]) + b"\n", None, "se.rfq", False, "The FASTQ file has more reads than the RFQ file. The FASTQ file has >= 6001"),
+        "fastq_shorter": (b"\n".join(recs[:5990 * 4]) + b"\n", None, "se.rfq", False, "The RFQ file has more reads than the FASTQ file. The RFQ file has >= 5991"),
+        "pe_same": (a, b, "pe.rfq", True, ""),
+        "pe_r2_quality": (a, b_bad, "pe.rfq", False, "different quality in the 2101 pair"),
+        "pe_r2_shorter": (a, b_short, "pe.rfq", False, "The RFQ file has more reads than the FASTQ file. The RFQ file has >= 2000 pairs, while the FASTQ file only has 2000 pairs"),
+        "gz": (gzip.compress(fq, 1), None, "se.rfq", True, ""),
+        "pe_r1_longer_only": (a + b"\n".join(a.split(b"\n")[:4]) + b"\n", b, "pe.rfq", True, ""),      # FastqReaderPair::read needs both mates
+        "pe_both_longer": (a + b"\n".join(a.split(b"\n")[:4]) + b"\n", b + b"\n".join(brecs[:4]) + b"\n", "pe.rfq", False, "The FASTQ file has >= 2500 pairs, while the RFQ file only has 2500 pairs"),
+        "one_blank_line_is_skipped": (b"\n".join(recs[:3000 * 4]) + b"\n\n" + b"\n".join(recs[3000 * 4:]), None, "se.rfq", True, ""),   # getLine swallows one "\n" after a terminator
+        "two_blank_lines_stop_reader": (b"\n".join(recs[:3000 * 4]) + b"\n\n\n" + b"\n".join(recs[3000 * 4:]), None, "se.rfq", False, "The RFQ file has >= 3001 reads, while the FASTQ file only has 3000 reads"),
+        "crlf_cut_by_reader_block": (split, None, "split.rfq", True, ""),
+        "truncated_last_quality": (fq[:-7], None, "se.rfq", False, "different quality in the 6000 read"),
+    }
+    for name, (f1, f2, rfq, passed, frag) in scen.items():
+        p1 = tmp_path / ("c1.fq.gz" if name == "gz" else "c1.fq"); p1.write_bytes(f1)
+        args = ["-p", "-i", str(p1), "-r", str(tmp_path / rfq), "--batch_mb", str(batch_mb)]
+        if f2 is not None:
+            p2 = tmp_path / "c2.fq"; p2.write_bytes(f2); args += ["-I", str(p2)]
+        r = _run(binary, args)
+        assert r.returncode == 0, (name, r.stderr)
+        j = json.loads(r.stdout)
+        assert (j["result"] == "passed") == passed and frag in j["msg"], (name, j)
+        if passed:
+            n = n_split if rfq == "split.rfq" else 6000 if f2 is None else 5000
+            assert j["fastq_reads"] == j["rfq_reads"] == n and j["fastq_bases"] == j["rfq_bases"] == n * 150, (name, j)
+        if O.have_ref():
+            ref = subprocess.run([O.REF_BIN] + [x for x in args if x not in ("--batch_mb", str(batch_mb))], capture_output=True)
+            assert json.loads(ref.stdout) == j, (name, ref.stdout, r.stdout)
 
 
 def test_cli_on_simt_emulation(tmp_path):
@@ -117,9 +180,22 @@ def test_cli_on_simt_emulation(tmp_path):
     _suite(EMU_BIN, tmp_path, reads_se=4000, pairs=1500, batch_mb=1)
 
 
+def test_cli_compare_on_simt_emulation(tmp_path):
+    E.build_emu()
+    subprocess.check_call(["make", "-s", "-C", E.EMU_DIR, "all"])
+    _compare_suite(EMU_BIN, tmp_path, batch_mb=1)
+
+
 @pytest.mark.gpu
 def test_cli_on_gpu(tmp_path):
     import __graft_entry__ as g
     g.build_host_tools()
     assert os.path.exists(GPU_BIN)
     _suite(GPU_BIN, tmp_path, reads_se=60000, pairs=30000, batch_mb=8)
+
+
+@pytest.mark.gpu
+def test_cli_compare_on_gpu(tmp_path):
+    import __graft_entry__ as g
+    g.build_host_tools()
+    _compare_suite(GPU_BIN, tmp_path, batch_mb=1)

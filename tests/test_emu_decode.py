@@ -92,3 +92,30 @@ def test_full_size_chunk_position_streams_span_many_segments(codec, prof, reads,
     fq1, fq2 = O.gen(prof, reads, seed=9, **kw)
     rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES if fq2 else O.SE, 1_000_000)
     assert codec.decode_bytes(rfq, split_pe=bool(fq2)) == ((fq1, fq2) if fq2 else fq1)
+
+
+def _first_diff_cases():
+    import random
+    rng = random.Random(9)
+    base = bytes(rng.randrange(256) for _ in range(70_001))
+    yield base, base, 0                                   # identical (odd length: 16-byte body + byte tail)
+    for at in (0, 1, 15, 16, 17, 4095, 4096, 65_535, 69_999, 70_000):
+        b = bytearray(base); b[at] ^= 0x40
+        if at < 60_000:
+            b[at + 3000] ^= 1                               # a later difference must not win
+        yield base, bytes(b), 0
+    b = bytearray(base); b[333] ^= 2
+    yield base, bytes(b), 5                               # mis-aligned operands take the byte path
+    yield b"", b"", 0
+
+
+def test_first_diff_of_two_device_texts(codec):
+    """rfq_compare_bytes (--compare on the device, SURVEY.md §8f #3): first differing offset, n when identical."""
+    for a, b, skew in _first_diff_cases():
+        n = len(a) - skew
+        want = next((i for i in range(n) if a[skew + i] != b[i]), n)
+        da, db = codec.dev_put(a), codec.dev_put(b)
+        try:
+            assert codec.first_diff(da.value + skew, db, n) == want
+        finally:
+            codec.dev_free(da); codec.dev_free(db)
