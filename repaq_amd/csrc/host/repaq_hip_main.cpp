@@ -19,6 +19,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -30,6 +31,7 @@ static bool ends_with(const std::string& s, const std::string& e) { return s.siz
 struct Options {
     std::string in1, out1, in2, out2, rfqCompare, json;
     long chunkKb = 1000; bool compress = false, decompress = false, compare = false, useStdin = false, useStdout = false, interleaved = false;
+    bool completeCheck = false, fastCheck = false;   // -v / -f: decode what was just encoded and compare it with the input (src/repaq.cpp:430-528)
     std::vector<int> devices;              // --devices a,b,...: chunk-parallel compress of ONE input over several GPUs (host work queue)
     int device = 0; size_t batchBytes = (size_t)16 << 20; int threads = 1, compression = 3;   // 16 MB batches: the stages of the I/O pipeline overlap best (tools/batch_sweep.sh)
 };
@@ -207,6 +209,79 @@ struct DevStream {
     void free_all(Gpu& g) { for (int i = 0; i < 2; i++) if (d[i]) rfq_dev_free(g.c, d[i]); }
 };
 
+struct Rec { std::string f[4]; };
+struct TextCursor {                      // growing text + a refill callback; records are cut with FastqReader's line rules
+    std::vector<uint8_t> t; size_t pos = 0; bool ended = false; std::function<void(TextCursor&)> refill;
+    uint64_t off0 = 0;                   // offset of t[0] in its (decompressed) file: the reader works in 1 MiB blocks of it
+    void compact() { if (pos > (1u << 24)) { t.erase(t.begin(), t.begin() + pos); off0 += pos; pos = 0; } }
+    // FastqReader::getLine + read (src/fastqreader.cpp:94-196): a line ends at '\r' or '\n'; one '\n' right after the terminator is
+    // skipped too, unless it is the last byte of the reader's 1 MiB block (for the last block: of the file) or opens the next block
+    // (`end < mBufDataLen-1`, :112-114); a record with an empty line ends the input
+    bool next(Rec& r) {
+        for (;;) {
+            size_t p = pos; int k = 0; bool need = false, empty = false;
+            for (; k < 4; k++) {
+                if (p >= t.size()) { if (!ended) { need = true; break; } r.f[k].clear(); empty = true; continue; }
+                size_t e = p; while (e < t.size() && t[e] != '\n' && t[e] != '\r') e++;
+                if (e + 2 >= t.size() && !ended) { need = true; break; }      // the rule looks one byte past the candidate '\n'
+                r.f[k].assign((const char*)t.data() + p, e - p);
+                size_t nx = e + 1;
+                if (nx < t.size() && t[nx] == '\n') {
+                    const uint64_t at = off0 + nx;
+                    const bool opens_block = (at & 0xFFFFF) == 0, closes_block = ((at + 1) & 0xFFFFF) == 0 || nx + 1 == t.size();
+                    if (!opens_block && !closes_block) nx++;
+                }
+                p = std::min(nx, t.size());
+                if (r.f[k].empty()) empty = true;
+            }
+            if (k == 4) { pos = p; return !empty; }
+            if (!need) return false;
+            compact(); refill(*this);
+        }
+    }
+};
+// -v / -f (Repaq::completeCheckAndOutput, src/repaq.cpp:430-528), on the device: the image a batch was just encoded to is decoded on a
+// second context and compared byte for byte with the text it came from (rfq_compare_bytes).  Only when the bytes differ (text the
+// reader normalises: "\r\n", blank lines, a trailing partial record — or a real codec fault) are both sides cut into records; a
+// differing read is reported on stderr in the reference's words and, like there, the output is written regardless (App. C Q15);
+// a differing read COUNT ends the run with the reference's error.
+struct Verifier {
+    Gpu gv; bool have_hdr = false; long pass = 0; const Options& o;
+    Verifier(const Options& opt, int device) : gv(device), o(opt) {}
+    bool wanted() { const bool w = o.completeCheck || (o.fastCheck && pass % 10 == 0); pass++; return w; }
+    void check(Gpu& g, const rfq_encode_result& r, bool image_has_header, bool final, bool two,
+               const uint8_t* in1, size_t n1, const uint8_t* in2, size_t n2, uint64_t off1, uint64_t off2) {
+        if (!r.n_chunks) return;
+        if (!image_has_header && !have_hdr) { uint8_t hb[RFQ_HEADER_MAX]; size_t hn = 0; g.check(rfq_get_header(g.c, hb, &hn)); gv.check(rfq_set_header(gv.c, hb, hn)); }
+        have_hdr = true;
+        rfq_decode_args a; memset(&a, 0, sizeof a);
+        a.d_rfq = r.d_rfq; a.n = r.rfq_len; a.has_header = image_has_header ? 1 : 0; a.split_pe = two ? 1 : 0; a.final = final ? 1 : 0;
+        rfq_decode_result d; gv.check(rfq_decode_batch(gv.c, &a, &d));
+        const uint8_t* got[2] = { d.d_fq1, d.d_fq2 }; const size_t gn[2] = { d.n1, two ? d.n2 : 0 };
+        const uint8_t* exp[2] = { in1, in2 }; const size_t en[2] = { n1, two ? n2 : 0 }; const uint64_t eo[2] = { off1, off2 };
+        bool same = true;
+        for (int s = 0; s < (two ? 2 : 1) && same; s++) {
+            uint64_t at = 0; same = gn[s] == en[s];
+            if (same) { gv.check(rfq_compare_bytes(gv.c, got[s], exp[s], en[s], &at)); same = at == en[s]; }
+        }
+        if (same) return;
+        for (int s = 0; s < (two ? 2 : 1); s++) {
+            TextCursor ce, cg; ce.ended = cg.ended = true; ce.off0 = eo[s];
+            ce.t.resize(en[s]); if (en[s]) gv.check(rfq_copy_d2h(gv.c, ce.t.data(), exp[s], en[s]));
+            cg.t.resize(gn[s]); if (gn[s]) gv.check(rfq_copy_d2h(gv.c, cg.t.data(), got[s], gn[s]));
+            // (the text handed in may run past the last chunk of a non-final batch; the decoded side says how many reads to draw)
+            Rec x, y;
+            while (cg.next(y)) {
+                if (!ce.next(x)) error_exit("encoding error in chunk, the output will be wrong, quit now!");
+                for (int k = 0; k < 4; k++) if (x.f[k] != y.f[k]) {
+                    fprintf(stderr, "integrity check failure \nexpected: \n%s\ngot:\n%s\n", x.f[k].c_str(), y.f[k].c_str());
+                    return;
+                }
+            }
+        }
+    }
+};
+
 // Repaq::compress / compressPE (src/repaq.cpp:530-762)
 static void do_compress(const Options& o) {
     const bool two = !o.in2.empty();
@@ -217,6 +292,7 @@ static void do_compress(const Options& o) {
     AsyncWriter out(g, o.out1, o);
     DevStream ds[2]; const int ns = two ? 2 : 1;
     bool first = true; size_t want = block;                                    // bytes a stream should hold before a batch is tried
+    Verifier* ver = (o.completeCheck || o.fastCheck) ? new Verifier(o, o.device) : nullptr;
     for (;;) {
         for (int s = 0; s < ns; s++) {
             while (!ds[s].ended && ds[s].have < want) {
@@ -238,6 +314,8 @@ static void do_compress(const Options& o) {
         for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t && in[s]->final_byte() != '\n') th[s] = ((t - 1) >> 20) << 20; }
         a.nolb_from1 = th[0]; a.nolb_from2 = two ? th[1] : th[0];
         rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
+        if (ver && r.n_chunks && ver->wanted())
+            ver->check(g, r, first, final || r.input_ended, two, ds[0].base(), final ? ds[0].have : r.consumed1, two ? ds[1].base() : nullptr, two ? (final ? ds[1].have : r.consumed2) : 0, ds[0].file_off, ds[1].file_off);
         if (r.rfq_len) {
             size_t cap; uint8_t* h = out.acquire(r.rfq_len, cap);
             g.check(rfq_copy_d2h(g.c, h, r.d_rfq, r.rfq_len)); out.submit(h, r.rfq_len, cap);
@@ -249,6 +327,7 @@ static void do_compress(const Options& o) {
         want = block;
     }
     out.finish();                                      // (an input without reads leaves an empty output, like the reference)
+    delete ver;
     for (int s = 0; s < ns; s++) { ds[s].free_all(g); delete in[s]; }
 }
 
@@ -283,6 +362,7 @@ static void do_compress_multi(const Options& o) {
     std::vector<std::thread> workers;
     for (size_t w = 0; w < o.devices.size(); w++) workers.emplace_back([&, w] {
         Gpu g(o.devices[w]); void* b1 = nullptr; void* b2 = nullptr; size_t c1 = 0, c2 = 0; bool have_hdr = false;
+        std::unique_ptr<Verifier> ver; if (o.completeCheck || o.fastCheck) ver.reset(new Verifier(o, o.devices[w]));
         for (;;) {
             WorkItem it;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = queue.front(); queue.pop_front(); }
@@ -297,6 +377,7 @@ static void do_compress_multi(const Options& o) {
             a.final = it.final ? 1 : 0; a.flush_all = it.final ? 0 : 1; a.emit_header = it.seq == 0 ? 1 : 0;
             a.file_off1 = it.off1; a.file_off2 = it.off2; a.nolb_from1 = it.th1; a.nolb_from2 = it.th2;
             rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
+            if (ver && r.n_chunks && ver->wanted()) ver->check(g, r, it.seq == 0, it.final, two, (const uint8_t*)b1, it.n1, (const uint8_t*)b2, two ? it.n2 : 0, it.off1, it.off2);
             std::vector<uint8_t> img(r.rfq_len); if (r.rfq_len) g.check(rfq_copy_d2h(g.c, img.data(), r.d_rfq, r.rfq_len));
             if (it.seq == 0) {                                               // the header every other range is coded under
                 uint8_t hb[RFQ_HEADER_MAX]; size_t hn = 0; have_hdr = true;
@@ -400,37 +481,6 @@ static void do_decompress(const Options& o) {
 }
 
 // ---- compare mode (src/repaq.cpp:36-259): decode on the GPU, compare read by read with the FASTQ text, same JSON
-struct Rec { std::string f[4]; };
-struct TextCursor {                      // growing text + a refill callback; records are cut with FastqReader's line rules
-    std::vector<uint8_t> t; size_t pos = 0; bool ended = false; std::function<void(TextCursor&)> refill;
-    uint64_t off0 = 0;                   // offset of t[0] in its (decompressed) file: the reader works in 1 MiB blocks of it
-    void compact() { if (pos > (1u << 24)) { t.erase(t.begin(), t.begin() + pos); off0 += pos; pos = 0; } }
-    // FastqReader::getLine + read (src/fastqreader.cpp:94-196): a line ends at '\r' or '\n'; one '\n' right after the terminator is
-    // skipped too, unless it is the last byte of the reader's 1 MiB block (for the last block: of the file) or opens the next block
-    // (`end < mBufDataLen-1`, :112-114); a record with an empty line ends the input
-    bool next(Rec& r) {
-        for (;;) {
-            size_t p = pos; int k = 0; bool need = false, empty = false;
-            for (; k < 4; k++) {
-                if (p >= t.size()) { if (!ended) { need = true; break; } r.f[k].clear(); empty = true; continue; }
-                size_t e = p; while (e < t.size() && t[e] != '\n' && t[e] != '\r') e++;
-                if (e + 2 >= t.size() && !ended) { need = true; break; }      // the rule looks one byte past the candidate '\n'
-                r.f[k].assign((const char*)t.data() + p, e - p);
-                size_t nx = e + 1;
-                if (nx < t.size() && t[nx] == '\n') {
-                    const uint64_t at = off0 + nx;
-                    const bool opens_block = (at & 0xFFFFF) == 0, closes_block = ((at + 1) & 0xFFFFF) == 0 || nx + 1 == t.size();
-                    if (!opens_block && !closes_block) nx++;
-                }
-                p = std::min(nx, t.size());
-                if (r.f[k].empty()) empty = true;
-            }
-            if (k == 4) { pos = p; return !empty; }
-            if (!need) return false;
-            compact(); refill(*this);
-        }
-    }
-};
 static void report(const Options& o, bool passed, const std::string& msg, long fqReads, long fqBases, long rfqReads, long rfqBases) {   // :235-259
     std::string j = "{\n";
     j += passed ? "\t\"result\":\"passed\",\n" : "\t\"result\":\"failed\",\n";
@@ -580,7 +630,8 @@ int main(int argc, char** argv) {
         else if (a == "--stdin") o.useStdin = true;
         else if (a == "--stdout") o.useStdout = true;
         else if (a == "--interleaved_in") o.interleaved = true;
-        else if (a == "-v" || a == "--verify" || a == "-f" || a == "--fast_verify") {}        // the reference ignores the verify result (Q15)
+        else if (a == "-v" || a == "--verify") o.completeCheck = true;
+        else if (a == "-f" || a == "--fast_verify") o.fastCheck = true;
         else if (a == "-t" || a == "--thread" || a.rfind("--thread=", 0) == 0) o.threads = atoi(val(i, "thread").c_str());
         else if (a == "-z" || a == "--compression" || a.rfind("--compression=", 0) == 0) o.compression = atoi(val(i, "compression").c_str());
         else if (a == "--device") o.device = atoi(val(i, "device").c_str());

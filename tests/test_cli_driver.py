@@ -82,6 +82,14 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     assert r.returncode == 0 and r.stdout == fq1, r.stderr
     r = _run(binary, ["-d", "-i", str(pe), "--stdout", "--batch_mb", str(batch_mb)])
     assert r.returncode == 0 and r.stdout == O.decode_file(pe.read_bytes(), False)
+    # -v / -f: every (tenth) batch is decoded again on a second context and compared with its text; silent and byte-identical output when
+    # the codec is right, for plain text (device compare), for CRLF text (record cutter) and for pairs (src/repaq.cpp:430-528, App. C Q18)
+    ov = tmp_path / "v.rfq"
+    for flag, src, extra, ref in (("-v", p, [], og.read_bytes()), ("-f", p, [], og.read_bytes()), ("-v", pc, [], O.encode_file(crlf, b"", O.SE, 100_000)),
+                                  ("-v", ps, [], want), ("-v", pa, ["-I", str(pb)], pe.read_bytes()), ("-v", p, ["--devices", "0,0"], og.read_bytes())):
+        r = _run(binary, ["-c", flag, "-i", str(src), "-o", str(ov), "-k", "100", "--batch_mb", str(batch_mb)] + extra)
+        assert r.returncode == 0 and r.stderr == b"", r.stderr
+        assert ov.read_bytes() == ref
     # --devices a,b,c: one input planned on the first device (rfq_scan_batch), its chunk ranges encoded on one context per listed device
     # (flush_all) and written in order — the image must be the one-shot image whatever the split
     om = tmp_path / "multi.rfq"
