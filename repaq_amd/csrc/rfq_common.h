@@ -170,19 +170,15 @@ __device__ __forceinline__ uint32_t comp_base_sel(uint32_t b) {
     return ((b | 0x20u) >= 'a' && (b | 0x20u) <= 'z') ? r : 'N';
 }
 
-// 16 consecutive bytes starting at an arbitrary LDS byte address, as four little-endian words: five aligned word reads + funnel shifts
-// (v_alignbyte_b32) instead of sixteen byte reads and ~100 packing instructions.  May read up to 3 bytes past the 16.
+// 16 / 4 consecutive bytes starting at an arbitrary LDS byte address, as little-endian words: ONE ds_read_b128 / ds_read_b32 at a
+// byte-granular address (gfx950 LDS runs in unaligned access mode; the compiler emits the wide read for an align-1 type).  The
+// earlier form - five aligned word reads + v_alignbit funnel shifts - cost ~10 instructions per group in VALU-bound copy loops.
+struct __attribute__((packed, aligned(1))) LdsU16 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(1))) LdsU4 { uint32_t a; };
 __device__ __forceinline__ void lds_get16(const uint8_t* base, uint32_t a, uint32_t (&w)[4]) {
-    const uint32_t* p = (const uint32_t*)(base + (a & ~3u)); const uint32_t sh = (a & 3u) * 8u;
-    const uint32_t x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4];
-    w[0] = (uint32_t)((((uint64_t)x1 << 32) | x0) >> sh); w[1] = (uint32_t)((((uint64_t)x2 << 32) | x1) >> sh);
-    w[2] = (uint32_t)((((uint64_t)x3 << 32) | x2) >> sh); w[3] = (uint32_t)((((uint64_t)x4 << 32) | x3) >> sh);
+    const LdsU16 v = *(const LdsU16*)(base + a); w[0] = v.a; w[1] = v.b; w[2] = v.c; w[3] = v.d;
 }
-// 4 bytes at byte offset a of a 4-byte-aligned LDS array (two aligned word reads + funnel shift; base[a+4..a+7] must be readable)
-__device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) {
-    const uint32_t* p = (const uint32_t*)(base + (a & ~3u)); const uint32_t sh = (a & 3u) * 8u;
-    return (uint32_t)((((uint64_t)p[1] << 32) | p[0]) >> sh);
-}
+__device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) { return ((const LdsU4*)(base + a))->a; }
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 // byte-wise full mask (0xFF per byte of w equal to the pattern byte)
 __device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {

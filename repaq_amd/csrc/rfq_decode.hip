@@ -173,7 +173,9 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
         const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
         if (tune) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
-        hipLaunchKernelGGL(k_dec_emit, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
+        if (tune) hipLaunchKernelGGL(k_dec_emit<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
+                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
+        else hipLaunchKernelGGL(k_dec_emit<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
                            (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
         if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu (wave0 own %llu, setup %llu) flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[6]/h[5], h[7]/h[5], h[4]/h[5]); }
         KCHK(ctx, "k_dec_emit");

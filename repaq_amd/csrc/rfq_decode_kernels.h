@@ -541,36 +541,43 @@ __device__ __forceinline__ void stage_span(uint4* lds4, const uint8_t* gbase, ui
         else for (uint32_t k = 0; k < 16 && ga + k < glimit; k++) lds[16 * i + k] = gbase[ga + k];
     }
 }
-// Several spans at once: every thread issues up to 4 loads (one pass over the concatenated group index space) before its first
-// LDS store, so the tile's six small spans cost ONE memory latency instead of six.
+// Several spans at once: all their loads are in flight together, so the tile's six small spans cost ONE memory latency instead of six.
 struct StageSpan { const uint8_t* g; uint64_t a0; uint32_t ng; uint4* l; uint64_t lim; };
 __device__ __forceinline__ StageSpan make_span(uint4* lds4, const uint8_t* gbase, uint64_t gbeg, uint64_t gend, uint64_t glimit, bool on) {
     StageSpan s; s.g = gbase; s.a0 = gbeg & ~15ull; s.ng = on ? (uint32_t)((gend - s.a0 + 15) / 16) : 0u; s.l = lds4; s.lim = glimit; return s;
 }
-template <int N> __device__ __forceinline__ void stage_spans(const StageSpan (&sp)[N]) {
-    uint32_t total = 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) total += sp[k].ng;
-    for (uint32_t base = threadIdx.x; base < total; base += 4 * blockDim.x) {
-        uint4 v[4]; uint4* dst[4]; bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            uint32_t i = base + (uint32_t)u * blockDim.x; ok[u] = i < total; dst[u] = nullptr; v[u] = make_uint4(0, 0, 0, 0);
-            if (ok[u]) {
-                int k = 0;
-#pragma unroll
-                for (int t = 0; t < N - 1; t++) if (k == t && i >= sp[t].ng) { i -= sp[t].ng; k = t + 1; }
-                const uint8_t* g = sp[0].g; uint64_t a0 = sp[0].a0, lim = sp[0].lim; uint4* l = sp[0].l;
-#pragma unroll
-                for (int t = 1; t < N; t++) if (k == t) { g = sp[t].g; a0 = sp[t].a0; lim = sp[t].lim; l = sp[t].l; }
-                const uint64_t ga = a0 + 16ull * i; dst[u] = l + i;
-                if (ga + 16 <= lim) v[u] = *(const uint4*)(g + ga);
-                else { uint32_t w[4] = { 0, 0, 0, 0 }; for (uint32_t b = 0; b < 16 && ga + b < lim; b++) w[b >> 2] |= (uint32_t)g[ga + b] << (8 * (b & 3)); v[u] = make_uint4(w[0], w[1], w[2], w[3]); }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (ok[u]) *dst[u] = v[u];
+// Span by span, every thread taking groups tid, tid + blockDim, ... of each: which span a load belongs to is then known at compile
+// time (the earlier "one flat index space" form spent ~60 VALU instructions per group on selecting the span's base / limit /
+// destination, ~300 per wave and tile in a VALU-bound kernel).  UMAX = groups per thread the caller's capacities allow for the
+// span (a slower loop covers anything beyond).  A span that ends >= 16 bytes before its buffer's limit loads without per-group
+// limit tests.
+static __device__ __noinline__ void stage_span_slow(const uint8_t* g, uint64_t a0, uint32_t ng, uint4* l, uint64_t lim, uint32_t from) {   // byte-wise near the buffer's limit
+    for (uint32_t i = threadIdx.x + from; i < ng; i += blockDim.x) {
+        const uint64_t ga = a0 + 16ull * i; uint32_t w[4] = { 0, 0, 0, 0 };
+        for (uint32_t b = 0; b < 16 && ga + b < lim; b++) w[b >> 2] |= (uint32_t)g[ga + b] << (8 * (b & 3));
+        l[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+// The aligned body of a span goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: each lane names its own 16 global bytes, the
+// wave's 64 groups land contiguously at a wave-uniform LDS address): no staging registers, no ds_write pass, nothing to wait for
+// until the barrier - staging through registers made this VALU- and register-bound kernel spill.  U = groups per thread the
+// caller's capacities allow (a slower loop covers anything beyond, and a span that ends < 16 bytes before its buffer's limit).
+template <int U> __device__ __forceinline__ void span_dma(const StageSpan& sp) {
+    const bool inside = sp.a0 + 16ull * sp.ng <= sp.lim;                     // block-uniform
+    const uint8_t* const gp = sp.g + sp.a0; const uint32_t w0 = threadIdx.x & ~63u;
+    if (inside) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = threadIdx.x + (uint32_t)u * blockDim.x;
+            if (i < sp.ng) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + 16u * i),
+                                                            (__attribute__((address_space(3))) void*)(sp.l + (w0 + (uint32_t)u * blockDim.x)), 16, 0, 0);
+        }
+        if (sp.ng > (uint32_t)U * blockDim.x) stage_span_slow(sp.g, sp.a0, sp.ng, sp.l, sp.lim, (uint32_t)U * blockDim.x);   // (never with the tile sizes above)
+    } else stage_span_slow(sp.g, sp.a0, sp.ng, sp.l, sp.lim, 0u);
+}
+// the emit tile's six spans: two big ones (UB groups per thread) and four small ones (one group per thread)
+template <int UB> __device__ __forceinline__ void stage_spans6(const StageSpan (&sp)[6]) {
+    span_dma<UB>(sp[0]); span_dma<UB>(sp[1]); span_dma<1>(sp[2]); span_dma<1>(sp[3]); span_dma<1>(sp[4]); span_dma<1>(sp[5]);
 }
 // LDS tile -> global [gbeg, gend): the tile sits at LDS offset (gbeg & 15) so body groups are aligned on both sides
 __device__ __forceinline__ void flush_span(const uint4* lds4, uint8_t* gbase, uint64_t gbeg, uint64_t gend) {
@@ -593,11 +600,11 @@ __device__ __forceinline__ uint32_t comp4_acgtn(uint32_t w) {
 #define ET_READS 32
 #define EM_ROW 17                 // words per read in s_meta: 16 used + 1 pad, so that lanes reading the same field of consecutive reads hit 32 different banks
 #define ET_OCAP 16384u            // output tile bytes (split: half per stream)
-#define ET_SCAP 6144u             // staged qualities / stored bases
-#define ET_N1CAP 4096u            // staged name1 / name2 / strand pieces of the tile (fall back to global memory when larger)
+#define ET_SCAP 5632u             // staged qualities / stored bases
+#define ET_N1CAP 3072u            // staged name1 / name2 / strand pieces of the tile (fall back to global memory when larger)
 #define ET_N2CAP 1024u
 #define ET_STCAP 1024u
-__global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
                            const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, uint64_t img_bytes, int split,
                            uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st, unsigned long long* dbg) {
@@ -619,7 +626,8 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
 #define s_n14 (s_src4 + EG_N1)
 #define s_n24 (s_src4 + EG_N2)
 #define s_st4 (s_src4 + EG_ST)
-    __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta[(ET_READS + 1) * EM_ROW]; __shared__ uint32_t s_mx[8];   // s_mx: longest pieces among the candidates
+    // scalars of the tile's reads: two buffers, the next tile's are fetched while this one's sources are staged
+    __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta2[2][(ET_READS + 1) * EM_ROW];
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
     const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
@@ -629,34 +637,35 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
     uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;
     const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
     const uint32_t ocap = split ? ET_OCAP / 2 : ET_OCAP;
-    uint32_t cur = rs;
+    // scalars of the <= ET_READS reads from `from` on (+1 end sentinel) -> `mrow`: one parallel round of global loads by the first
+    // ET_READS + 1 threads.  It runs for tile t+1 inside the staging phase of tile t (same wait as the staged sources), so that a
+    // tile's chain is one global-load latency, not two; holding them in registers across the compose phase instead was tried
+    // and cost a resident block per CU
+#define EMIT_META_VARS U4 tp_, pv_; uint32_t pq_ = 0, len_ = 0, ov_ = 0, pl_ = 0, n1_ = 0, n2_ = 0, sl_ = 0, md_ = 0, r_ = 0; bool odd_ = false; tp_.a = tp_.b = 0; pv_.a = pv_.b = pv_.c = pv_.d = 0;
+#define EMIT_META_LOAD(from)                                                                                                          \
+        { r_ = (from) + tid; const uint32_t g_ = f + r_; odd_ = (r_ & 1u) != 0;                                                       \
+          tp_ = R.tp[g_]; pv_ = R.pv[g_]; pq_ = R.pq[g_];                                                                             \
+          if (r_ < re) {                                                                                                              \
+              len_ = R.len[g_]; ov_ = (uint32_t)R.ov[g_]; pl_ = odd_ ? R.len[g_ - 1] : 0u;                                            \
+              n1_ = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r_)];                                                             \
+              n2_ = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r_)] : 0u;                                       \
+              sl_ = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r_)]; md_ = R.mid[(size_t)g_ * 40 + 39];                         \
+          } }
+#define EMIT_META_STORE(mrow)                                                                                                         \
+        { uint32_t* m = (mrow) + EM_ROW * tid;                                                                                        \
+          m[12] = tp_.a; m[13] = tp_.b; m[14] = pv_.d - pv0.d; m[15] = pq_ - pq0;          /* prefix values (also valid for the sentinel) */ \
+          m[7] = pv_.a - pv0.a; m[8] = pv_.b - pv0.b; m[9] = pv_.c - pv0.c;                                                           \
+          if (r_ < re) { m[0] = (split && odd_) ? tp_.b : tp_.a; m[1] = len_; m[2] = ov_; m[3] = pl_; m[4] = n1_; m[5] = n2_; m[6] = sl_;   \
+                         m[11] = md_; m[10] = n1_ + md_ + n2_ + 1; } }                     /* ":lane:tile:x:y" bytes; offset of the sequence line */
+    uint32_t cur = rs; uint32_t pb = 0;
+    if (DBG) k0 = clock64();
+    { EMIT_META_VARS if (cur < re && tid <= ET_READS && cur + tid <= re) { EMIT_META_LOAD(cur) EMIT_META_STORE(s_meta2[0]) } }
+    __syncthreads();
+    if (DBG) { k1 = clock64(); a1 += k1 - k0; }
     while (cur < re) {                                                       // block-uniform
-        k0 = clock64();
-        // ---- phase 1: scalars of the next <= ET_READS reads (+1 end sentinel) -> LDS, one parallel round of global loads
-        // (prefetching them for the next tile into registers was tried: the extra live registers cost a resident block per CU)
+        uint32_t* const s_meta = s_meta2[pb]; uint32_t* const s_next = s_meta2[pb ^ 1u];
+        if (DBG) k1 = clock64();
         const uint32_t g0 = f + cur;
-        if (tid == 0) s_cnt = 0;
-        if (tid <= ET_READS && cur + tid <= re) {
-            const uint32_t r = cur + tid, g = g0 + tid; const U4 tp = R.tp[g]; const U4 pv = R.pv[g]; const bool odd = (r & 1u) != 0;
-            uint32_t* m = s_meta + EM_ROW * tid;
-            m[12] = tp.a; m[13] = tp.b; m[14] = pv.d - pv0.d; m[15] = R.pq[g] - pq0;          // prefix values (also valid for the sentinel)
-            m[7] = pv.a - pv0.a; m[8] = pv.b - pv0.b; m[9] = pv.c - pv0.c;
-            if (r < re) {
-                m[0] = (split && odd) ? tp.b : tp.a; m[1] = R.len[g]; m[2] = (uint32_t)R.ov[g]; m[3] = odd ? R.len[g - 1] : 0u;
-                m[4] = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
-                m[5] = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
-                m[6] = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
-                m[11] = R.mid[(size_t)g * 40 + 39]; m[10] = m[4] + m[11] + m[5] + 1;             // ":lane:tile:x:y" bytes; offset of the sequence line
-            }
-        }
-        if (tid < 64) {                                                    // wave 0 holds every candidate (ET_READS <= 64)
-            const bool on = tid < ET_READS && cur + tid < re; const uint32_t* m = s_meta + EM_ROW * tid;
-            const uint32_t v1 = wave_max(on ? m[4] : 0u), v2 = wave_max(on ? m[5] : 0u), v3 = wave_max(on ? m[6] : 0u), v4 = wave_max(on ? m[1] : 0u);
-            const uint32_t v5 = wave_max(on && (int)m[2] < 0 ? (uint32_t)(-(int)m[2]) : 0u);
-            if (tid == 0) { s_mx[0] = v1; s_mx[1] = v2; s_mx[2] = v3; s_mx[3] = v4; s_mx[4] = v5; }
-        }
-        __syncthreads();
-        k1 = clock64(); a1 += k1 - k0;
         // ---- phase 2: how many reads fit (from LDS)
         const uint32_t* mb = s_meta;                                          // entry 0 = first read of the tile
         bool fits = false;
@@ -667,7 +676,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                 && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)
                 && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP);
         }
-        { const unsigned long long fb = __ballot(fits); if (l == 0 && fb) atomicAdd(&s_cnt, (uint32_t)__popcll(fb)); }
+        if (tid < 64) { const unsigned long long fb = __ballot(fits); if (l == 0) s_cnt = (uint32_t)__popcll(fb); }    // ET_READS <= 64: wave 0 holds every candidate
         __syncthreads();
         uint32_t cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
         const bool tiled = cnt > 0;
@@ -676,7 +685,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         U4 tp0, tp1; tp0.a = mb[12]; tp0.b = mb[13]; tp1.a = me[12]; tp1.b = me[13];
         const uint32_t q0 = mb[15], s0 = mb[14];
         const uint64_t qa = qg0 + q0, qe = qg0 + me[15], sa = sg0 + s0, se = sg0 + me[14];
-        k2 = clock64(); a2 += k2 - k1;
+        if (DBG) { k2 = clock64(); a2 += k2 - k1; }
         // ---- phase 3: stage the tile's sources with aligned 16-byte loads.  name1 / name2 / strand: one copy when the chunk stores
         // them once, else the contiguous run of the tile's reads
         const uint64_t ib = d.off;                                         // global byte offsets inside the image
@@ -686,13 +695,17 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
         const uint64_t sta = ib + d.o_st + a9, ste = (fl & C_STRAND_SAME) ? sta + d.st_size : ib + d.o_st + me[9];
         const bool n1l = tiled && n1e - n1a + 32 <= ET_N1CAP, n2l = tiled && n2e - n2a + 32 <= ET_N2CAP, stl_ = tiled && ste - sta + 32 <= ET_STCAP;
         {
+            const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
+            EMIT_META_VARS
+            if (nextm) EMIT_META_LOAD(cur + cnt)
             const StageSpan sp[6] = { make_span(s_q4 + 1, qdec, qa, qe, qdec_bytes, tiled), make_span(s_s4 + 1, sdec, sa, se, sdec_bytes, tiled),   // +1: 16 readable bytes in front
                                       make_span(s_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, tiled),
                                       make_span(s_n14, img, n1a, n1e, img_bytes, n1l), make_span(s_n24, img, n2a, n2e, img_bytes, n2l), make_span(s_st4, img, sta, ste, img_bytes, stl_) };
-            stage_spans<6>(sp);
+            stage_spans6<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(sp);                 // groups per thread at 256 threads
+            if (nextm) EMIT_META_STORE(s_next)
         }
         __syncthreads();
-        k3 = clock64(); a3 += k3 - k2;
+        if (DBG) { k3 = clock64(); a3 += k3 - k2; }
         // ---- phase 4: compose the tile's text in LDS
         const uint8_t* q_l = (const uint8_t*)(s_q4 + 1) + (qa & 15ull); const uint8_t* s_l = (const uint8_t*)(s_s4 + 1) + (sa & 15ull);
         const uint8_t* m_l = (const uint8_t*)s_mid4 + (((uint64_t)g0 * 40) & 15ull);
@@ -739,7 +752,7 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                     int t = -(int)(dst & 15u), tend = (int)n;
                     if (half >= 0) { const int groups = ((int)n - t + 15) >> 4, cut = t + 16 * ((groups + 1) >> 1); if (half == 0) tend = cut < tend ? cut : tend; else t = cut; }
                     uint8_t* o = out + (dst & ~15u) + (uint32_t)(t + (int)(dst & 15u));
-                    const long long kA = clock64(); if (tid == 0) aS += kA - k3;
+                    if (DBG) { const long long kA = clock64(); if (tid == 0) aS += kA - k3; }
                     uint32_t w[4], nx[4];
                     if (t < tend) lds_get16(pool, rev ? src + n - 16u - (uint32_t)t : src + (uint32_t)t, nx);
                     for (; t < tend; t += 16, o += 16) {
@@ -797,16 +810,19 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                 emit_one((to2 ? out2 : out1) + at, e, sdec + sg0, qdec + qg0, implied_n, nq, dpos, dch, l);
             }
         }
-        { const long long k35 = clock64(); a6 += k35 - k3; }
+        if (DBG) { const long long k35 = clock64(); a6 += k35 - k3; }
         __syncthreads();
-        k4 = clock64(); a4 += k4 - k3;
+        if (DBG) { k4 = clock64(); a4 += k4 - k3; }
         // ---- phase 5: aligned 16-byte stores of the finished tile (no barrier after it: three barriers precede the next compose)
         if (tiled) {
             if (tp1.a <= cap1) flush_span(s_out4, out1, tp0.a, tp1.a);
             if (split && tp1.b <= cap2) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
         }
-        k5 = clock64(); a5 += k5 - k4;
-        cur += cnt;
+        if (DBG) { k5 = clock64(); a5 += k5 - k4; }
+        cur += cnt; pb ^= 1u;
     }
-    if (tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a1); atomicAdd(&dbg[1], (unsigned long long)a2); atomicAdd(&dbg[2], (unsigned long long)a3); atomicAdd(&dbg[3], (unsigned long long)a4); atomicAdd(&dbg[4], (unsigned long long)a5); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)a6); atomicAdd(&dbg[7], (unsigned long long)aS); }
+#undef EMIT_META_VARS
+#undef EMIT_META_LOAD
+#undef EMIT_META_STORE
+    if (DBG && tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a1); atomicAdd(&dbg[1], (unsigned long long)a2); atomicAdd(&dbg[2], (unsigned long long)a3); atomicAdd(&dbg[3], (unsigned long long)a4); atomicAdd(&dbg[4], (unsigned long long)a5); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)a6); atomicAdd(&dbg[7], (unsigned long long)aS); }
 }

@@ -24,6 +24,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
@@ -125,6 +126,9 @@ template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T
 }  // namespace emu
 
 #define threadIdx (emu::blk->f[emu::blk->cur].tid)
+// LDS-DMA (global_load_lds): every active lane copies `size` bytes from ITS global address to (wave-uniform LDS base) + lane * size.
+// The interpreter runs a lane at a time, so the copy is immediate; the address-space qualifiers of the product code are ignored by g++.
+static inline void __builtin_amdgcn_global_load_lds(const void* g, void* l, unsigned size, int off, int aux) { (void)aux; memcpy((char*)l + off + size * (threadIdx.x & 63u), g, size); }
 #define blockIdx (emu::blk->bid)
 #define blockDim (emu::blk->bdim)
 #define gridDim (emu::blk->gdim)
