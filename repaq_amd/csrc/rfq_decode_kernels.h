@@ -597,6 +597,46 @@ __device__ __forceinline__ uint32_t comp4_acgtn(uint32_t w) {
     const uint32_t cg = b1 & ~b3, at = b1 ^ 0x01010101u;
     return w ^ (cg * 0x04u + at * 0x15u);
 }
+// One piece of the emit tile: 16-byte groups [g0, g1) of the piece's ceil(n / 16), copied from the LDS source pool to the LDS output
+// tile.  Both sides are byte-granular ds_read_b128 / ds_write_b128 (LDS runs in unaligned access mode), so a group is simply bytes
+// [16g, 16g + 16) of the piece; the last group of a piece >= 16 bytes is moved back to end exactly at n (it rewrites a few bytes of
+// its predecessor with the same values), a piece < 16 bytes is stored as 8 + 4 + 2 + 1.  No head / tail edge cases per word - the
+// destination-aligned form spent most of its instructions there.  SEQ: bases (complement for a reversed piece, implied N where
+// the quality equals the header's N quality); REV: the piece may be emitted back to front; PAT: one byte of the piece is replaced
+// (the mate's differing name character).
+struct __attribute__((packed, aligned(1))) LdsW8 { uint32_t a, b; };
+struct __attribute__((packed, aligned(1))) LdsW2 { uint16_t a; };
+template <bool SEQ, bool REV, bool PAT>
+__device__ __forceinline__ void emit_copy(uint8_t* o, const uint8_t* pool, uint32_t src, uint32_t n, uint32_t g0, uint32_t g1, bool rev_,
+                                          uint32_t qsrc, bool implied_n, uint32_t nq, int pat, uint32_t dch) {
+    const bool rev = REV && rev_;
+    for (uint32_t g = g0; g < g1; g++) {
+        uint32_t p0 = 16u * g; const bool small = n < 16u;
+        if (p0 + 16u > n && !small) p0 = n - 16u;
+        uint32_t w[4];
+        // bytes [p0, p0 + 16) of the piece: forward from src + p0; reversed they are the 16 source bytes ENDING at src + n - p0
+        lds_get16(pool, rev ? src + n - p0 - 16u : src + p0, w);
+        if (REV && rev) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
+        if (SEQ) {
+            if (rev) { w[0] = comp4_acgtn(w[0]); w[1] = comp4_acgtn(w[1]); w[2] = comp4_acgtn(w[2]); w[3] = comp4_acgtn(w[3]); }
+            if (implied_n) {
+                uint32_t qw[4]; lds_get16(pool, rev ? qsrc + n - p0 - 16u : qsrc + p0, qw);
+                if (rev) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const uint32_t mk = eq_bytes_full(qw[i], (nq & 0xFFu) * 0x01010101u); w[i] = (w[i] & ~mk) | (0x4E4E4E4Eu & mk); }
+            }
+        }
+        if (PAT && pat >= (int)p0 && pat < (int)p0 + 16) { const int b = pat - (int)p0; const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& x = w[b >> 2]; x = (x & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
+        uint8_t* q = o + p0;
+        if (!small) { LdsU16 v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(LdsU16*)q = v; }
+        else {
+            if (n & 8u) { LdsW8 v; v.a = w[0]; v.b = w[1]; *(LdsW8*)q = v; q += 8; w[0] = w[2]; w[1] = w[3]; }
+            if (n & 4u) { LdsU4 v; v.a = w[0]; *(LdsU4*)q = v; q += 4; w[0] = w[1]; }
+            if (n & 2u) { LdsW2 v; v.a = (uint16_t)w[0]; *(LdsW2*)q = v; q += 2; w[0] >>= 16; }
+            if (n & 1u) *q = (uint8_t)w[0];
+        }
+    }
+}
 #define ET_READS 32
 #define EM_ROW 17                 // words per read in s_meta: 16 used + 1 pad, so that lanes reading the same field of consecutive reads hit 32 different banks
 #define ET_OCAP 16384u            // output tile bytes (split: half per stream)
@@ -732,7 +772,7 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
                     if ((uint64_t)m[0] + e3 + 1 > (to2 ? cap2 : cap1)) atomicOr(&st->err, 1u << 31);
                 }
                 for (int sub = 0; sub < (kind == 7 ? 2 : 1); sub++) {         // (slot 7 copies two short pieces)
-                    uint32_t n, dst, src, qsrc = 0; bool rev = false, seq = false; int pat = -1, half = -1;   // pat: piece offset of the byte to patch (name2)
+                    uint32_t n, dst, src, qsrc = 0; bool rev = false; int pat = -1, half = -1;   // pat: piece offset of the byte to patch (name2)
                     const uint32_t qs = 16u * EG_Q + qoff + (m[15] - q0);
                     if (kind <= 1) { n = len; dst = rec + m[10] + len + 1 + m[6] + 1; src = qs; rev = rc; half = (int)kind; }     // quality (back to front for an RC mate)
                     else if (kind <= 4) {
@@ -742,46 +782,22 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
                         const bool partb = kind == 4; const uint32_t p0 = partb ? xa : 0u;
                         n = partb ? len - xa : xa;
                         src = 16u * EG_S + soff + (partb ? sp - m[3] : (ov > 0 ? sp - (uint32_t)ov : sp));
-                        dst = rec + m[10] + (rc ? len - p0 - n : p0); rev = rc; seq = true; qsrc = qs + p0; half = partb ? -1 : (int)kind - 2;
+                        dst = rec + m[10] + (rc ? len - p0 - n : p0); rev = rc; qsrc = qs + p0; half = partb ? -1 : (int)kind - 2;
                     }
                     else if (kind == 5) { n = m[4]; dst = rec; src = 16u * EG_N1 + n1off + ((fl & C_NAME1_SAME) ? 0u : m[7] - a7); }
                     else if (kind == 6) { n = mid; dst = rec + m[4]; src = 16u * EG_MID + moff + 40u * j; }
                     else if (sub == 0) { n = m[5]; dst = rec + m[4] + mid; src = 16u * EG_N2 + n2off + ((fl & C_NAME2_SAME) ? 0u : m[8] - a8);
                                          if ((fl & C_NAME2_SAME) && rc && dch != 0 && dpos < n) pat = (int)dpos; }      // the mate's differing character
                     else { n = m[6]; dst = rec + m[10] + len + 1; src = 16u * EG_ST + stoff + ((fl & C_STRAND_SAME) ? 0u : m[9] - a9); }
-                    int t = -(int)(dst & 15u), tend = (int)n;
-                    if (half >= 0) { const int groups = ((int)n - t + 15) >> 4, cut = t + 16 * ((groups + 1) >> 1); if (half == 0) tend = cut < tend ? cut : tend; else t = cut; }
-                    uint8_t* o = out + (dst & ~15u) + (uint32_t)(t + (int)(dst & 15u));
+                    uint32_t gb = 0, ge = (n + 15u) >> 4;                       // the piece's 16-byte groups; a half takes the first / the second part
+                    if (half == 0) ge = (ge + 1u) >> 1; else if (half == 1) gb = (ge + 1u) >> 1;
+                    uint8_t* const o = out + dst;
                     if (DBG) { const long long kA = clock64(); if (tid == 0) aS += kA - k3; }
-                    uint32_t w[4], nx[4];
-                    if (t < tend) lds_get16(pool, rev ? src + n - 16u - (uint32_t)t : src + (uint32_t)t, nx);
-                    for (; t < tend; t += 16, o += 16) {
-                        w[0] = nx[0]; w[1] = nx[1]; w[2] = nx[2]; w[3] = nx[3];
-                        if (t + 16 < tend) lds_get16(pool, rev ? src + n - 32u - (uint32_t)t : src + (uint32_t)(t + 16), nx);
-                        if (rev) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
-                        if (seq) {
-                            if (rev) { w[0] = comp4_acgtn(w[0]); w[1] = comp4_acgtn(w[1]); w[2] = comp4_acgtn(w[2]); w[3] = comp4_acgtn(w[3]); }
-                            if (implied_n) {
-                                uint32_t qw[4]; lds_get16(pool, rev ? qsrc + n - 16u - (uint32_t)t : qsrc + (uint32_t)t, qw);
-                                if (rev) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3; }
-#pragma unroll
-                                for (int i = 0; i < 4; i++) { const uint32_t mk = eq_bytes_full(qw[i], (nq & 0xFFu) * 0x01010101u); w[i] = (w[i] & ~mk) | (0x4E4E4E4Eu & mk); }
-                            }
-                        }
-                        if (pat >= t && pat < t + 16) { const int b = pat - t; const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& x = w[b >> 2]; x = (x & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
-                        if (t >= 0 && t + 16 <= (int)n) *(uint4*)o = make_uint4(w[0], w[1], w[2], w[3]);
-                        else {
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const int ti = t + 4 * i;
-                                if (ti >= 0 && ti + 4 <= (int)n) *(uint32_t*)(o + 4 * i) = w[i];
-                                else if (ti > -4 && ti < (int)n) {
-#pragma unroll
-                                    for (int bb = 0; bb < 4; bb++) if (ti + bb >= 0 && ti + bb < (int)n) o[4 * i + bb] = (uint8_t)(w[i] >> (8 * bb));
-                                }
-                            }
-                        }
-                    }
+                    // the copy loop, specialised for what the piece can need (a wave holds two kinds: the tests below are nearly wave-uniform)
+                    if (kind <= 1) emit_copy<false, true, false>(o, pool, src, n, gb, ge, rev, 0u, false, nq, -1, dch);
+                    else if (kind <= 4) emit_copy<true, true, false>(o, pool, src, n, gb, ge, rev, qsrc, implied_n, nq, -1, dch);
+                    else if (pat < 0) emit_copy<false, false, false>(o, pool, src, n, gb, ge, false, 0u, false, nq, -1, dch);
+                    else emit_copy<false, false, true>(o, pool, src, n, gb, ge, false, 0u, false, nq, pat, dch);
                 }
             }
         } else
