@@ -329,7 +329,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     {
         // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 128; enough workgroups to fill 256 CUs x 2
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + GT_READS - 1) / GT_READS, std::max(1u, 8192u / n_chunks)));
-        hipLaunchKernelGGL(k_gather, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune);
+        if (tune) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune);
+        else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune);
         if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
             if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
     }

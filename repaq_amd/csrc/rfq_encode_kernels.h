@@ -953,9 +953,9 @@ struct NCount {                          // p = chunk-relative position of the b
     }
 };
 
-__global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict__ ovb, const DevHeader* __restrict__ D,
+template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict__ ovb, const DevHeader* __restrict__ D,
                          uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat, unsigned long long* dbg, int tune) {
-    long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0; long long a_fit = 0, a_meta = 0, a_stage = 0, a_q = 0, a_s = 0;
+    long long tk0 = DBG ? clock64() : 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0; long long a_fit = 0, a_meta = 0, a_stage = 0, a_q = 0, a_s = 0;
     __shared__ uint4 s_text4[GT_CAP / 16 + 6];
     __shared__ uint32_t s_qsrc[GT_READS], s_ssrc[GT_READS], s_len[GT_READS], s_skip[GT_READS], s_keep[GT_READS], s_qdst[GT_READS + 1], s_sdst[GT_READS + 1];
     __shared__ uint8_t s_rc[GT_READS]; __shared__ uint32_t s_nx[GT_READS];
@@ -974,7 +974,7 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     QualCount qc; qc.sh = sh; qc.major = D->major & 0xFFu; qc.hot = 0; NCount nc; nc.n = 0; nc.nmap = C.nmap + (size_t)c * NMAP_WORDS; nc.shift = nmap_shift(R.pv[e].d - ps0);
     uint32_t cur = gs;
     while (cur < ge) {                                                   // block-uniform
-        tk0 = clock64();
+        if (DBG) tk0 = clock64();
         // ---- ONE round of global loads for up to GT_READS candidate reads (+ the end sentinel): what the fit test needs and what the
         // tile needs; how many consecutive reads fit in the LDS tile is a monotone predicate -> count
         if (tid == 0) s_cnt = 0;
@@ -1017,7 +1017,7 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
             }
             cur += upr; __syncthreads(); continue;
         }
-        tk1 = clock64(); a_fit += tk1 - tk0;
+        if (DBG) { tk1 = clock64(); a_fit += tk1 - tk0; }
         // ---- per-read metadata -> LDS (from the registers loaded above)
         uint32_t span_end[2] = { 0, 0 };
         if (two) { span_end[0] = s_nx[cnt - 2]; span_end[1] = s_nx[cnt - 1]; }   // cnt is even for two files: the last pair's records end the spans
@@ -1029,38 +1029,30 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
             s_skip[tid] = m_ov > 0 ? (uint32_t)m_ov : 0u; s_keep[tid] = m_len - (uint32_t)(m_ov < 0 ? -m_ov : m_ov);
         }
         if (tid <= cnt) { s_qdst[tid] = m_qdst; s_sdst[tid] = m_sdst; }
-        tk2 = clock64(); a_meta += tk2 - tk1;
+        if (DBG) { tk2 = clock64(); a_meta += tk2 - tk1; }
         // ---- stage the spans: aligned 16-byte loads (the very last group of a stream may not be fully inside the buffer)
         for (int st = 0; st < (two ? 2 : 1); st++) {
             const uint32_t nb = span_end[st] - a0[st]; const uint32_t ng = (nb + 15) / 16; const uint32_t lb = st ? base1 : 0u;
             const uint8_t* src = T.fq[st] + a0[st];
-            // four loads in flight per thread before the first LDS store: a tile costs two memory latencies instead of seven
-            for (uint32_t i0 = tid; i0 < ng; i0 += 4 * blockDim.x) {
-                uint4 v[4]; bool full[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * blockDim.x; v[u] = make_uint4(0, 0, 0, 0);
-                    full[u] = i < ng && (uint64_t)a0[st] + 16ull * i + 16ull <= (uint64_t)T.n[st];
-                    if (full[u]) v[u] = *(const uint4*)(src + 16 * (size_t)i);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * blockDim.x;
-                    if (full[u]) s_text4[1 + lb / 16 + i] = v[u];
-                    else if (i < ng) for (uint32_t k = 0; k < 16 && a0[st] + 16 * i + k < T.n[st]; k++) s_text[lb + 16 * i + k] = src[16 * (size_t)i + k];
-                }
-            }
+            // LDS-DMA (global_load_lds_dwordx4): every lane names its own 16 global bytes, a wave's 64 groups land contiguously at a
+            // wave-uniform LDS address - no staging registers, no ds_write pass; everything is in flight until the barrier.  Only
+            // the very last group of a stream may reach past the buffer: it is copied byte-wise.
+            const uint32_t nfull = (uint64_t)a0[st] + 16ull * ng <= (uint64_t)T.n[st] ? ng : ng - 1u;
+            uint4* const l4 = s_text4 + 1 + lb / 16;
+            for (uint32_t i = tid; i < nfull; i += blockDim.x)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i), (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
+            if (nfull < ng && tid == 0) for (uint32_t k = 0; k < 16 && a0[st] + 16 * nfull + k < T.n[st]; k++) s_text[lb + 16 * nfull + k] = src[16 * (size_t)nfull + k];
         }
         __syncthreads();
-        tk3 = clock64(); a_stage += tk3 - tk2;
+        if (DBG) { tk3 = clock64(); a_stage += tk3 - tk2; }
         GatherTile t; t.text = s_text; t.len = s_len; t.skip = s_skip; t.keep = s_keep; t.rc = s_rc; t.cnt = cnt;
         t.dst = s_qdst; t.src = s_qsrc;
-        tile_emit<false>(t, qd + s_qdst[0], s_qdst[0], s_qdst[cnt] - s_qdst[0], qc, tune);
-        tk4 = clock64(); a_q += tk4 - tk3;
+        tile_emit<false>(t, qd + s_qdst[0], s_qdst[0], s_qdst[cnt] - s_qdst[0], qc, DBG ? tune : 0);
+        if (DBG) { tk4 = clock64(); a_q += tk4 - tk3; }
         t.dst = s_sdst; t.src = s_ssrc;
-        tile_emit<true>(t, sd + s_sdst[0], s_sdst[0], s_sdst[cnt] - s_sdst[0], nc, tune);
+        tile_emit<true>(t, sd + s_sdst[0], s_sdst[0], s_sdst[cnt] - s_sdst[0], nc, DBG ? tune : 0);
         __syncthreads();
-        tk5 = clock64(); a_s += tk5 - tk4;
+        if (DBG) { tk5 = clock64(); a_s += tk5 - tk4; }
         cur += cnt;
     }
     const uint32_t hot = wave_sum(qc.hot), nn = wave_sum(nc.n);
@@ -1068,7 +1060,7 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     __syncthreads();
     for (uint32_t i = tid; i < 256; i += blockDim.x) if (sh[i]) atomicAdd(&C.hist[(size_t)c * 256 + i], sh[i]);
     if (tid == 0 && s_n) atomicAdd(&C.ncount[c], s_n);
-    if (tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a_fit); atomicAdd(&dbg[1], (unsigned long long)a_meta); atomicAdd(&dbg[2], (unsigned long long)a_stage); atomicAdd(&dbg[3], (unsigned long long)a_q); atomicAdd(&dbg[4], (unsigned long long)a_s); atomicAdd(&dbg[5], 1ull); }
+    if (DBG && tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a_fit); atomicAdd(&dbg[1], (unsigned long long)a_meta); atomicAdd(&dbg[2], (unsigned long long)a_stage); atomicAdd(&dbg[3], (unsigned long long)a_q); atomicAdd(&dbg[4], (unsigned long long)a_s); atomicAdd(&dbg[5], 1ull); }
 }
 
 // scratch capacity of every stream of a chunk: a value with k matches in len positions codes to at most
