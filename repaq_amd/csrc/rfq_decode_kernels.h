@@ -708,17 +708,26 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
         const uint32_t g0 = f + cur;
         // ---- phase 2: how many reads fit (from LDS)
         const uint32_t* mb = s_meta;                                          // entry 0 = first read of the tile
+#define EMIT_FITS(me) ((me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 48u <= ET_SCAP && (me[14] - mb[14]) + 48u <= ET_SCAP \
+                && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)                          \
+                && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP))
+        // the usual case - all ET_READS candidates (or all that are left) fit - is one test every thread makes for itself on the same
+        // LDS words: no vote, no barrier.  Only a tile of unusually long reads goes through the per-candidate vote.
+        const uint32_t all = re - cur < ET_READS ? re - cur : ET_READS;
+        uint32_t cnt;
+        { const uint32_t* ma = s_meta + EM_ROW * all; cnt = EMIT_FITS(ma) ? all : 0xFFFFFFFFu; }
+        if (cnt == 0xFFFFFFFFu) {                                          // block-uniform
         bool fits = false;
         if (tid < ET_READS && cur + tid < re) {
             uint32_t mm = (tid + 2u) & ~1u; if (cur + mm > re) mm = re - cur;  // whole pairs (a lone last read of an SE chunk is fine)
             const uint32_t* me = s_meta + EM_ROW * mm;
-            fits = (me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 48u <= ET_SCAP && (me[14] - mb[14]) + 48u <= ET_SCAP
-                && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)
-                && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP);
+            fits = EMIT_FITS(me);
         }
         if (tid < 64) { const unsigned long long fb = __ballot(fits); if (l == 0) s_cnt = (uint32_t)__popcll(fb); }    // ET_READS <= 64: wave 0 holds every candidate
         __syncthreads();
-        uint32_t cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
+        cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
+        }
+#undef EMIT_FITS
         const bool tiled = cnt > 0;
         if (!tiled) { cnt = 2; if (cur + cnt > re) cnt = re - cur; }      // oversized read / pair: straight to global memory, byte-wise
         const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + EM_ROW * cnt;
