@@ -225,6 +225,33 @@ __device__ __forceinline__ void stage_name_rows(const Text& T, uint8_t* rows, ui
     }
 }
 __device__ __forceinline__ bool bytes_eq(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen);
+// k_read_table's staging: EIGHT lanes per name, each one aligned 16-byte group of the 128-byte window that starts at the name's
+// 16-byte-aligned address - a wave stages its 64 names with 8 global_load_dwordx4 (all in flight together) instead of 64 rounds
+// of byte loads.  A group is stored with one byte-granular ds_write_b128 at (row + 16 + 16 * part - (name start & 15)), so the
+// name itself begins at row + 16 whatever its alignment was (the bytes in front of it land in the row's own 16-byte pad).
+// Row stride 148 B = 37 banks: lanes walking their own rows byte by byte do not collide.
+#define RT_NAME_CAP 112           // 15 + 112 < 128: any name this long sits inside its 128-byte window
+#define RT_ROW 148
+__device__ __forceinline__ void stage_name_rows_wide(const Text& T, uint8_t* rows, uint32_t nb, uint32_t nl, int s, int l) {
+    const uint32_t part = (uint32_t)l & 7u;
+    uint4 v[8]; bool ok[8]; uint32_t da[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int j = it * 8 + (l >> 3);
+        const uint32_t jb = __shfl(nb, j), jl = __shfl(nl, j); const int js = __shfl(s, j);
+        const uint32_t a = (jb & ~15u) + 16u * part;                         // the group's offset in its stream
+        ok[it] = jl != 0 && jl <= RT_NAME_CAP && a < jb + jl;                // it holds bytes of the name
+        da[it] = (uint32_t)j * RT_ROW + 16u + 16u * part - (jb & 15u);
+        v[it] = make_uint4(0, 0, 0, 0);
+        if (ok[it]) {
+            const uint8_t* g = T.fq[js] + a;
+            if ((uint64_t)a + 16ull <= (uint64_t)T.n[js]) { const LdsU16 t = *(const LdsU16*)g; v[it] = make_uint4(t.a, t.b, t.c, t.d); }
+            else { uint32_t w[4] = { 0, 0, 0, 0 }; for (uint32_t b = 0; b < 16 && a + b < T.n[js]; b++) w[b >> 2] |= (uint32_t)g[b] << (8 * (b & 3)); v[it] = make_uint4(w[0], w[1], w[2], w[3]); }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) if (ok[it]) { LdsU16 t; t.a = v[it].x; t.b = v[it].y; t.c = v[it].z; t.d = v[it].w; *(LdsU16*)(rows + da[it]) = t; }
+}
 // equality of rows[a .. a+n) and rows[b .. b+n) (LDS, any alignment), 4 bytes per step
 __device__ __forceinline__ bool lds_bytes_eq(const uint8_t* rows, uint32_t a, uint32_t b, uint32_t n) {
     for (uint32_t i = 0; i < n; i += 4) {
@@ -243,7 +270,7 @@ __device__ __forceinline__ bool lds_bytes_eq(const uint8_t* rows, uint32_t a, ui
 //   bits 8-15 position of the first difference, bits 16-23 the R2 byte there.  adj / pinfo may be null.
 #define RT_NEW 62u
 __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __restrict__ adj, uint32_t* __restrict__ pinfo, DevStatus* st) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_names[4 * 64 * NAME_STRIDE + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_names[4 * 64 * RT_ROW + 16];
     const int l = lane_id(), w = wave_id();
     const uint32_t g = (blockIdx.x * (blockDim.x >> 6) + (uint32_t)w) * RT_NEW + (uint32_t)l;
     const bool valid = g < n_reads;
@@ -254,17 +281,17 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
         const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
         nb = p0; nl = p1 - 1 - p0; sl = p2 - 1 - p1; tl = p3 - 1 - p2; ql = p4 - 1 - p3; tb = p2;
     }
-    uint8_t* rows = s_names + (size_t)w * 64 * NAME_STRIDE;
+    uint8_t* rows = s_names + (size_t)w * 64 * RT_ROW + 16;              // (+16: a row's name begins 16 bytes into the row)
     // the strand line's first four bytes (almost always just "+"), fetched beside the names
     uint32_t st4 = 0;
     if (adj && valid) { const uint8_t* sp = T.fq[s] + tb; for (uint32_t i = 0; i < 4 && i < tl; i++) st4 |= (uint32_t)sp[i] << (8 * i); }
-    stage_name_rows(T, rows, nb, nl, s, l);
+    stage_name_rows_wide(T, rows - 16, nb, nl, s, l);
     __syncthreads();
     uint32_t err = 0; Meta m; m.ok = 0; m.name1_len = 0; m.name2_off = 0; m.x = 0; m.y = 0; m.tile = 0; m.lane = 0;
     if (valid) {
         if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
         if (ql < sl) err |= DE_QUAL_SHORT;
-        m = nl <= NAME_CAP ? dev_parse_name(rows + l * NAME_STRIDE, nl) : dev_parse_name(T.fq[s] + nb, nl);
+        m = nl <= RT_NAME_CAP ? dev_parse_name(rows + l * RT_ROW, nl) : dev_parse_name(T.fq[s] + nb, nl);
         R.len[g] = sl; R.stored[g] = sl;
         R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
     }
@@ -287,14 +314,14 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
             }
             if ((uint32_t)m.lane == plane) b |= 1u << 5;
             if ((uint32_t)m.tile == ptile) b |= 1u << 6;
-            const bool inl = nl <= NAME_CAP && pnl <= NAME_CAP;              // both names staged in LDS (else compare in global memory)
-            const uint32_t ra = (uint32_t)l * NAME_STRIDE, rb = (uint32_t)(l - 1) * NAME_STRIDE;
+            const bool inl = nl <= RT_NAME_CAP && pnl <= RT_NAME_CAP;        // both names staged in LDS (else compare in global memory)
+            const uint32_t ra = (uint32_t)l * RT_ROW, rb = (uint32_t)(l - 1) * RT_ROW;
             const uint8_t* ga = T.fq[s] + nb; const uint8_t* gb = T.fq[ps] + pnb;
             if (n1 == pn1 && (inl ? lds_bytes_eq(rows, ra, rb, n1) : bytes_eq(ga, n1, gb, pn1))) b |= 1u << 7;
             if (n2 == pn2 && (inl ? lds_bytes_eq(rows, ra + n2o, rb + pn2o, n2) : bytes_eq(ga + n2o, n2, gb + pn2o, pn2))) b |= 1u << 8;
             if (l > 1 && pinfo) {                                              // PE: the previous pair's mate of the same side
-                const uint32_t qn2 = qnl - qn2o; const bool inl2 = nl <= NAME_CAP && qnl <= NAME_CAP;
-                if (n2 == qn2 && (inl2 ? lds_bytes_eq(rows, ra + n2o, (uint32_t)(l - 2) * NAME_STRIDE + qn2o, n2) : bytes_eq(ga + n2o, n2, T.fq[qs] + qnb + qn2o, qn2))) b |= 1u << 9;
+                const uint32_t qn2 = qnl - qn2o; const bool inl2 = nl <= RT_NAME_CAP && qnl <= RT_NAME_CAP;
+                if (n2 == qn2 && (inl2 ? lds_bytes_eq(rows, ra + n2o, (uint32_t)(l - 2) * RT_ROW + qn2o, n2) : bytes_eq(ga + n2o, n2, T.fq[qs] + qnb + qn2o, qn2))) b |= 1u << 9;
             }
             adj[g] = (uint16_t)b;
             if (pinfo && (g & 1u)) {                                           // (g-1, g) is a pair: a = R1's name2, b = R2's name2
