@@ -11,7 +11,8 @@ import sys
 def per_kernel(path, counter):
     cur = sqlite3.connect(path).cursor()
     rows = cur.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name", (counter,)).fetchall()
-    return {r[0].split("(")[0].replace("void ", ""): (r[1], r[2]) for r in rows}
+    # (kernels templated on a debug switch are reported under their plain name: k_dec_emit<false> -> k_dec_emit)
+    return {r[0].split("(")[0].replace("void ", "").replace("<false>", "").replace("<true>", ""): (r[1], r[2]) for r in rows}
 
 
 def main():
