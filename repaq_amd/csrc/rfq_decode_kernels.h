@@ -99,14 +99,18 @@ __global__ void k_dec_spec_walk(const uint8_t* __restrict__ img, uint64_t n, uin
     for (;;) {
         if (n - k < 18) break;
         const uint8_t* p = img + k;
-        const uint32_t ms = ld_u32(p), s = ld_u32(p + 4), fl = ld_u16(p + 8);
-        if (s == 0) break;
+        // mSize, read count and flags come from ONE byte-granular 16-byte load (>= 18 bytes are left) and ONE test decides whether
+        // the walk goes on: the chain is one memory latency per chunk (as three loads with the read count tested first, the
+        // compiler paid a second round trip for the other two)
+        const LdsU16 hd = *(const LdsU16*)p;
+        const uint32_t ms = hd.a, s = hd.b, fl = hd.c & 0xFFFFu;
         const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s;
         long long total = (long long)ms;
         if (hf & H_LANE) total += (fl & C_LANE_SAME) ? 1 : (long long)h;                         // lane bytes are never counted in mSize
         if (!(hf & H_TILE)) total -= (fl & C_TILE_SAME) ? 2 : 2ll * h;                           // "tile" bytes are counted even when absent
         if (!(hf & H_NAME2)) total -= (fl & C_NAME2_LEN_SAME) ? 1 : (long long)s;                // so are the name2 lengths (name2 bytes assumed empty)
-        if (total < 18 || (unsigned long long)total > n - k) { bad = 1; break; }
+        const bool wrong = (total < 18) | ((unsigned long long)total > n - k);
+        if ((s == 0) | wrong) { if (s != 0) bad = 1; break; }
         if (c < cap) { if (l == 0) { out[c].off = k; out[c].total = (uint32_t)total; out[c].rbase = (uint32_t)rb; out[c].reads = s; } } else ovf = 1;
         if (s > maxr) maxr = s;
         lastfl = fl; rb += s; k += (unsigned long long)total; c++;
