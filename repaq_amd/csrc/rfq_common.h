@@ -185,12 +185,16 @@ __device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {
     const uint32_t v = w ^ pat; const uint32_t t = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);   // 0x80 per equal byte
     return (t >> 7) * 0xFFu;
 }
-// complement of four packed bases, comp_base() semantics (either case -> upper-case complement, anything else -> 'N')
+// complement of four packed bases, comp_base() semantics (either case -> upper-case complement, anything else -> 'N').
+// Case-folded, bits 1-2 of a base are a perfect hash (A 0, C 1, T 2, G 3): v_perm_b32 looks the four bytes up in a 4-entry
+// complement table in ONE instruction, a second look-up in the identity table tells which bytes really were A/C/G/T.
 __device__ __forceinline__ uint32_t comp4(uint32_t w) {
     const uint32_t u = w & 0xDFDFDFDFu;                                   // fold case: u == 'A' exactly for 'A' and 'a' (bit 5 is the only one dropped)
-    const uint32_t mA = eq_bytes_full(u, 0x41414141u), mT = eq_bytes_full(u, 0x54545454u), mC = eq_bytes_full(u, 0x43434343u), mG = eq_bytes_full(u, 0x47474747u);
-    const uint32_t any = mA | mT | mC | mG;
-    return (mA & 0x54545454u) | (mT & 0x41414141u) | (mC & 0x47474747u) | (mG & 0x43434343u) | (~any & 0x4E4E4E4Eu);
+    const uint32_t idx = (u >> 1) & 0x03030303u;
+    const uint32_t c = __builtin_amdgcn_perm(0u, 0x43414754u, idx);      // [A,C,T,G] -> T,G,A,C
+    const uint32_t o = __builtin_amdgcn_perm(0u, 0x47544341u, idx);      // [A,C,T,G] -> A,C,T,G
+    const uint32_t ok = eq_bytes_full(o, u);
+    return (c & ok) | (0x4E4E4E4Eu & ~ok);
 }
 
 // LDS hand-off between lanes of ONE wave (rows private to the wave): order the wave's LDS writes before its later LDS reads.

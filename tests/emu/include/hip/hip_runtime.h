@@ -151,6 +151,12 @@ static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned lo
 static inline long long clock64() { return 0; }
 static inline long long wall_clock64() { return 0; }
 // wave-level barrier / fence builtins: a rendezvous of the wave's lanes in the interpreter
+// v_perm_b32: result byte i = byte (sel byte i) of the 8-byte value {hi, lo} (selectors 0-3 lo, 4-7 hi; >= 0x0C constants, unused here)
+static inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo; uint32_t r = 0;
+    for (int i = 0; i < 4; i++) { const uint32_t k = (sel >> (8 * i)) & 0xFFu; r |= (uint32_t)((k < 8 ? (v >> (8 * k)) & 0xFFu : (k == 0x0C ? 0u : 0xFFu))) << (8 * i); }
+    return r;
+}
 static inline void __builtin_amdgcn_wave_barrier() { (void)emu::collective(emu::OP_BALLOT, 0, 0, 0); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
