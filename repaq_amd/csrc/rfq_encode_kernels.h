@@ -1583,6 +1583,14 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
             for (int b = 0; b < 4; b++) { const uint32_t ch = (w >> (8 * b)) & 0xFFu; const uint32_t code = p + (uint32_t)b < n ? (ch == 'A' ? 1u : (ch == 'T' ? 2u : (ch == 'C' ? 3u : 0u))) : 0u; v |= code << (2 * b); }
             return v;
         };
+        // four bases -> one byte without per-base branches: bits 1-2 of a base are a perfect hash (A 0, C 1, T 2, G 3), v_perm_b32 looks
+        // the codes up, a second look-up in the identity table zeroes everything that is not exactly A/C/G/T, one multiply gathers the
+        // four 2-bit fields.  Only for words that lie wholly below n (the pad behind a chunk's bases may hold anything).
+        auto pack4_fast = [&](uint32_t w) -> uint32_t {
+            const uint32_t idx = (w >> 1) & 0x03030303u;
+            const uint32_t code = __builtin_amdgcn_perm(0u, 0x00020301u, idx) & eq_bytes_full(__builtin_amdgcn_perm(0u, 0x47544341u, idx), w);
+            return (code * 0x01041040u) >> 24;
+        };
         const uint32_t* sw = (const uint32_t*)sb;                           // scat chunk bases are 64-byte aligned, padded to 64
         if (t < head) od[t] = (uint8_t)pack4(sw[t], 4 * t);
         const uint32_t body = (nbytes - head) / 4; uint32_t* dw = (uint32_t*)(od + head);
@@ -1595,7 +1603,8 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
 #pragma unroll
             for (int u = 0; u < 2; u++) { const uint32_t k = k0 + (uint32_t)u * NT; if (k >= body) continue;
                 const uint32_t p = 4 * (head + 4 * k);
-                dw[k] = pack4(w[u][0], p) | (pack4(w[u][1], p + 4) << 8) | (pack4(w[u][2], p + 8) << 16) | (pack4(w[u][3], p + 12) << 24); }
+                if (p + 16u <= n) dw[k] = pack4_fast(w[u][0]) | (pack4_fast(w[u][1]) << 8) | (pack4_fast(w[u][2]) << 16) | (pack4_fast(w[u][3]) << 24);
+                else dw[k] = pack4(w[u][0], p) | (pack4(w[u][1], p + 4) << 8) | (pack4(w[u][2], p + 8) << 16) | (pack4(w[u][3], p + 12) << 24); }
         }
         const uint32_t done = head + 4 * body;
         if (t < nbytes - done) od[done + t] = (uint8_t)pack4(sw[done + t], 4 * (done + t));
