@@ -279,7 +279,12 @@ __device__ __forceinline__ int pos_lane_adv(const PosFront& f, uint32_t slen, ui
 }
 // decodeSingleQualByCol over the stream bytes [b0, b1) entered in automaton state `carry` with `last` = last position covered so far
 __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, uint32_t slen, uint32_t b0_, uint32_t b1_, uint32_t carry, int last,
-                                                uint8_t q, uint8_t* __restrict__ out, uint32_t out_len, const uint8_t* lim) {
+                                                uint8_t q, uint8_t* __restrict__ out, uint32_t out_len, const uint8_t* lim, int* tp) {
+    // tp: 256 ints of LDS private to the wave.  A lane decodes four consecutive stream bytes, so in "store my k-th token" the 64
+    // lanes hit 64 different cache lines (their tokens are ~4 gaps apart).  The single-position tokens of a step are therefore
+    // compacted into tp in stream order and stored TRANSPOSED - lane l takes tokens l, l + 64, ... - so that one store
+    // instruction covers neighbouring positions (k_dec_pos_emit 355 -> 310 us).  Staging the segment's bytes in LDS as well, so
+    // that no load waits behind the stores, was measured too: no gain.
     const int l = lane_id();                                                 // positions < 2^31 (see the encoder)
     PosStep nxt = pos_fetch(sp, slen, b0_ + 4u * (uint32_t)l, lim);
     for (uint32_t base = b0_; base < b1_; base += 256) {
@@ -307,13 +312,20 @@ __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, 
         }
         const int incl = wave_incl_sum(lane_adv);
         int end = last + incl - lane_adv;                                    // last covered position in front of my tokens
+        uint32_t singles = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (start[k] && !run[k]) singles++;
+        const uint32_t sincl = wave_incl_sum(singles); uint32_t so = sincl - singles; const uint32_t stot = __shfl(sincl, 63);
+        wave_lds_sync();                                                     // the previous step's tp is no longer read
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (!start[k]) continue;
             end += adv[k];
             if (run[k]) { for (uint32_t t = 0; t < run[k]; t++) { const int p = end - (int)run[k] + 1 + (int)t; if (p >= 0 && (uint32_t)p < out_len) out[p] = q; } }
-            else if (end >= 0 && (uint32_t)end < out_len) out[end] = q;
+            else tp[so++] = end;
         }
+        wave_lds_sync();
+        for (uint32_t j = (uint32_t)l; j < stot; j += 64) { const int p = tp[j]; if (p >= 0 && (uint32_t)p < out_len) out[p] = q; }
         last += __shfl(incl, 63);
     }
 }
@@ -394,7 +406,8 @@ __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __
     const uint32_t b0 = g * POS_SEG; if (b0 >= s.slen) return;
     const uint32_t b1 = b0 + POS_SEG < s.slen ? b0 + POS_SEG : s.slen;
     const size_t idx = ((size_t)c * nstr + jj) * maxseg + g;
-    wave_pos_decode(s.sp, s.slen, b0, b1, segS[idx], segP[idx], s.q, s.out, s.out_len, lim);
+    __shared__ int s_tp[256];                                           // (one wave per block)
+    wave_pos_decode(s.sp, s.slen, b0, b1, segS[idx], segP[idx], s.q, s.out, s.out_len, lim, s_tp);
 }
 // exception records (q, u32 LE position) after the streams (src/rfqcodec.cpp:1034-1043); raw copy when DONT_ENCODE_QUAL (:905-910)
 __global__ void k_dec_except(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
