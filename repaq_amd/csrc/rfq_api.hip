@@ -37,6 +37,7 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     c->d_hdr.release(); c->d_status.release(); c->d_cmp.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release();
     c->timer.destroy();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);

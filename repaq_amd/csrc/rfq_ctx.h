@@ -2,6 +2,7 @@
 #pragma once
 #include "rfq_common.h"
 #include "../../include/rfq_hip.h"
+#include <cstring>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -51,6 +52,25 @@ struct rfq_ctx {
         return true;
     }
     std::string err;
+    // Small device -> host read-backs (status words, totals, chunk offsets) land in ONE page-locked block and are handed to their
+    // destinations after the stream is synchronised: with a pageable destination every hipMemcpyAsync is a staged, effectively
+    // synchronous copy (three in a row cost ~60 us of idle GPU between the decoder's kernels).
+    uint8_t* pin = nullptr; size_t pin_cap = 0, pin_used = 0;
+    struct Pend { void* host; size_t off, n; }; std::vector<Pend> pend;
+    hipError_t fetch(void* host, const void* dev, size_t n, hipStream_t s) {
+        if (!n) return hipSuccess;
+        if (!pin) { if (hipHostMalloc((void**)&pin, 1 << 16, 0) != hipSuccess) { pin = nullptr; (void)hipGetLastError(); } else pin_cap = 1 << 16; }
+        const size_t off = (pin_used + 15) & ~(size_t)15;
+        if (!pin || off + n > pin_cap) return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, s);     // too large for the block: straight to its destination
+        pend.push_back(Pend{ host, off, n }); pin_used = off + n;
+        return hipMemcpyAsync(pin + off, dev, n, hipMemcpyDeviceToHost, s);
+    }
+    hipError_t fetch_sync(hipStream_t s) {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) for (const Pend& q : pend) memcpy(q.host, pin + q.off, q.n);
+        pend.clear(); pin_used = 0;
+        return e;
+    }
     // header
     DBuf d_hdr;                 // DevHeader
     DevHeader h_hdr; bool have_hdr = false;

@@ -30,6 +30,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // profiling aid: phase cycle counters (dbg words alias the head of the mid buffer: text is invalid when set)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->timer.reset();
+    ctx->pend.clear(); ctx->pin_used = 0;                                   // (read-backs an earlier call left behind on an error path)
     uint64_t start = 0;
     if (a->has_header) {
         uint8_t hb[RFQ_HEADER_MAX]; const size_t take = std::min<size_t>(a->n, sizeof hb);
@@ -56,16 +57,16 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
         else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
         KCHK(ctx, "k_dec_walk");
-        HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-        HIPCHK(ctx, hipStreamSynchronize(S));
+        HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
         if (!speculate) break;
         if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image: walk it properly
         if (hs.n_chunks) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst);
             KCHK(ctx, "k_dec_parse");
-            DecStatus h2; HIPCHK(ctx, hipMemcpyAsync(&h2, dst, sizeof h2, hipMemcpyDeviceToHost, S));
-            HIPCHK(ctx, hipStreamSynchronize(S));
+            DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
+            HIPCHK(ctx, ctx->fetch_sync(S));
             if (h2.pad) { speculate = false; continue; }                   // an extent did not verify: foreign writer or corrupt image
             hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos;
         }
@@ -97,10 +98,10 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
     scan_exclusive<U4>(S, R.pvin, R.pv, n_reads, B[DB_SCAN].as<U4>(), 1);
     uint32_t total_bases = 0; U4 pv_tot;
-    HIPCHK(ctx, hipMemcpyAsync(&total_bases, R.pq + n_reads, 4, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipMemcpyAsync(&pv_tot, R.pv + n_reads, 16, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&total_bases, R.pq + n_reads, 4, S));
+    HIPCHK(ctx, ctx->fetch(&pv_tot, R.pv + n_reads, 16, S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     ctx->timer.end(S);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");
     res->n_bases = total_bases;
@@ -155,9 +156,9 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
     scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
     U4 tt;
-    HIPCHK(ctx, hipMemcpyAsync(&tt, R.tp + n_reads, 16, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&tt, R.tp + n_reads, 16, S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
     // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
     hs.text1 = hs.text2 = 0; for (int i = 0; i < 64; i++) { hs.text1 += hs.text_slots[0][i]; hs.text2 += hs.text_slots[1][i]; }
@@ -181,8 +182,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         KCHK(ctx, "k_dec_emit");
     }
     ctx->timer.end(S);
-    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     ctx->timer.collect();
     if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %u / %u bytes", tt.a, tt.b);
     size_t n1 = tt.a, n2 = tt.b;

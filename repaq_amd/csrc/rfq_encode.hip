@@ -43,8 +43,8 @@ int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n) {
     HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, &tmp, sizeof tmp, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_hdr_from_bytes, dim3(1), dim3(64), 0, c->stream, c->d_hdr.as<DevHeader>());
     KCHK(c, "k_hdr_from_bytes");
-    HIPCHK(c, hipMemcpyAsync(&c->h_hdr, c->d_hdr.p, sizeof(DevHeader), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->fetch(&c->h_hdr, c->d_hdr.p, sizeof(DevHeader), c->stream));
+    HIPCHK(c, c->fetch_sync(c->stream));
     c->have_hdr = true;
     return RFQ_OK;
 }
@@ -69,9 +69,9 @@ static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t 
     scan_exclusive<uint32_t>(S, B[B_NKEEP].as<uint32_t>(), B[B_NKEEP].as<uint32_t>(), nblk, B[B_SCANTMP].as<uint32_t>(), 1);
     scan_exclusive<uint32_t>(S, B[B_NTERM].as<uint32_t>(), B[B_NTERM].as<uint32_t>(), nblk, B[B_SCANTMP].as<uint32_t>(), 1);
     uint32_t keep = 0, terms = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&keep, B[B_NKEEP].as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipMemcpyAsync(&terms, B[B_NTERM].as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&keep, B[B_NKEEP].as<uint32_t>() + nblk, 4, S));
+    HIPCHK(ctx, ctx->fetch(&terms, B[B_NTERM].as<uint32_t>() + nblk, 4, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     HIPCHK(ctx, B[B_NORM0 + s].ensure((size_t)keep + 64)); HIPCHK(ctx, B[B_OT0 + s].ensure(((size_t)terms + 4) * 4)); HIPCHK(ctx, B[B_ONX0 + s].ensure(((size_t)terms + 4) * 4));
     hipLaunchKernelGGL(k_norm_emit, dim3(nblk), dim3(256), 0, S, in, (const uint64_t*)B[B_TBITS].as<uint64_t>(), (const uint64_t*)B[B_SBITS].as<uint64_t>(),
                        (const uint32_t*)B[B_NKEEP].as<uint32_t>(), (const uint32_t*)B[B_NTERM].as<uint32_t>(), B[B_NORM0 + s].as<uint8_t>(), B[B_OT0 + s].as<uint32_t>(), B[B_ONX0 + s].as<uint32_t>());
@@ -136,6 +136,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     hipStream_t S = ctx->stream;
     DBuf* B = ctx->b;
     ctx->timer.reset();
+    ctx->pend.clear(); ctx->pin_used = 0;                                   // (read-backs an earlier call left behind on an error path)
     static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // kernel ablation switches for profiling runs (results are invalid when set)
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
@@ -165,11 +166,11 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     uint32_t n_newlines[2] = { 0, 0 }; uint8_t lastbyte[2] = { '\n', '\n' };
     for (int s = 0; s < nstreams; s++) {
         if (!nblk[s]) continue;
-        HIPCHK(ctx, hipMemcpyAsync(&n_newlines[s], B[B_BLK0 + s].as<uint32_t>() + nblk[s], 4, hipMemcpyDeviceToHost, S));
-        HIPCHK(ctx, hipMemcpyAsync(&lastbyte[s], fq[s] + nbytes[s] - 1, 1, hipMemcpyDeviceToHost, S));
+        HIPCHK(ctx, ctx->fetch(&n_newlines[s], B[B_BLK0 + s].as<uint32_t>() + nblk[s], 4, S));
+        HIPCHK(ctx, ctx->fetch(&lastbyte[s], fq[s] + nbytes[s] - 1, 1, S));
     }
-    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     if (hs.err & DE_HAS_CR) return nm ? rfq_fail(ctx, RFQ_E_HIP, "internal: '\\r' in normalised text") : RFQ_NEED_NORM;
     uint32_t nlines[2] = { 0, 0 }, nrec[2] = { 0, 0 };
     for (int s = 0; s < nstreams; s++) {
@@ -227,8 +228,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     hipLaunchKernelGGL(k_partition, dim3(1), dim3(64), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, fin ? 1 : 0,
                        (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst);
     KCHK(ctx, "k_partition");
-    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     ctx->timer.end(S);
     if (hs.err & DE_EMPTY_LINE) {
         // "\n\n" is a swallowed blank line, not an empty one: classify the text properly first.  On normalised text an empty line is
@@ -250,9 +251,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
                            nm ? nm->onx[0] : nullptr, (nm && nstreams == 2) ? nm->onx[1] : nullptr, e1, e2);
         KCHK(ctx, "k_chunk_ends");
         ctx->scan_end[0].assign(n_chunks, 0); ctx->scan_end[1].assign(nstreams == 2 ? n_chunks : 0, 0);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->scan_end[0].data(), e1, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, S));
-        if (nstreams == 2) HIPCHK(ctx, hipMemcpyAsync(ctx->scan_end[1].data(), e2, (size_t)n_chunks * 8, hipMemcpyDeviceToHost, S));
-        HIPCHK(ctx, hipStreamSynchronize(S));
+        HIPCHK(ctx, ctx->fetch(ctx->scan_end[0].data(), e1, (size_t)n_chunks * 8, S));
+        if (nstreams == 2) HIPCHK(ctx, ctx->fetch(ctx->scan_end[1].data(), e2, (size_t)n_chunks * 8, S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
         const size_t lim0 = nm ? nm->orig_n[0] : nbytes[0], lim1 = nm ? nm->orig_n[1] : nbytes[1];
         for (auto& v : ctx->scan_end[0]) if (v > lim0) v = lim0;             // (a virtual terminator past an unterminated last line)
         for (auto& v : ctx->scan_end[1]) if (v > lim1) v = lim1;
@@ -340,9 +341,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
     hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 0, dst);
     KCHK(ctx, "k_gather");
-    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-    if (make_header) HIPCHK(ctx, hipMemcpyAsync(&ctx->h_hdr, D, sizeof(DevHeader), hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     ctx->timer.end(S);
     if (hs.err & (DE_BAD_QUAL | DE_BAD_BASE)) {
         // RfqHeader::makeQualityTable error_exit texts, src/rfqheader.cpp:140-166
@@ -417,15 +418,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     ctx->timer.end(S);
     ctx->chunk_off.resize((size_t)n_chunks + 1);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->chunk_off.data(), C.img_off, ((size_t)n_chunks + 1) * 8, hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, ctx->fetch(ctx->chunk_off.data(), C.img_off, ((size_t)n_chunks + 1) * 8, S));
     uint32_t cons[2] = { 0, 0 };
     for (int s = 0; s < nstreams; s++) {
         const uint32_t recs = a->paired == RFQ_PE_INTERLEAVED ? reads_used : (a->paired == RFQ_PE_TWO_FILES ? units_used : reads_used);
-        if (nm) { cons[s] = 0; if (recs) HIPCHK(ctx, hipMemcpyAsync(&cons[s], nm->onx[s] + 4 * (size_t)recs - 1, 4, hipMemcpyDeviceToHost, S)); }
-        else HIPCHK(ctx, hipMemcpyAsync(&cons[s], B[B_LO0 + s].as<uint32_t>() + 4 * (size_t)recs, 4, hipMemcpyDeviceToHost, S));
+        if (nm) { cons[s] = 0; if (recs) HIPCHK(ctx, ctx->fetch(&cons[s], nm->onx[s] + 4 * (size_t)recs - 1, 4, S)); }
+        else HIPCHK(ctx, ctx->fetch(&cons[s], B[B_LO0 + s].as<uint32_t>() + 4 * (size_t)recs, 4, S));
     }
-    HIPCHK(ctx, hipMemcpyAsync(&hs, dst, sizeof hs, hipMemcpyDeviceToHost, S));
-    HIPCHK(ctx, hipStreamSynchronize(S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     ctx->timer.collect();
     if (hs.err & DE_COORD_RANGE) {
         // RfqCodec::encodeCoords error_exit, src/rfqcodec.cpp:1315-1317: first offender in (chunk, x-before-y, index) order
