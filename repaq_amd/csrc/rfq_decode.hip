@@ -57,17 +57,21 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
         else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
         KCHK(ctx, "k_dec_walk");
+        // the verifying parse rides behind the speculative walk without a host round trip in between (its grid covers the first
+        // PARSE_AHEAD chunks; the walk's own verdict is in the status words it reads)
+        const uint32_t PARSE_AHEAD = 4096;
+        if (speculate) { hipLaunchKernelGGL(k_dec_parse, dim3(std::min(cap, PARSE_AHEAD)), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, 0u); KCHK(ctx, "k_dec_parse"); }
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
         if (!speculate) break;
-        if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image: walk it properly
-        if (hs.n_chunks) {
-            hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst);
+        if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
+        if (hs.n_chunks > PARSE_AHEAD) {
+            hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
             KCHK(ctx, "k_dec_parse");
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
-            if (h2.pad) { speculate = false; continue; }                   // an extent did not verify: foreign writer or corrupt image
+            if (h2.pad) { speculate = false; continue; }
             hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos;
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk

@@ -119,8 +119,11 @@ __global__ void k_dec_spec_walk(const uint8_t* __restrict__ img, uint64_t n, uin
     if (l == 0) { st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->pad = bad; }
 }
 // one wave per speculated chunk: full parse + verification of the extent
-__global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const DevHeader* __restrict__ D, DChunk* __restrict__ CH, DecStatus* st) {
-    const uint32_t c = blockIdx.x; const uint32_t hf = D->flags, rlb = D->read_len_bytes;
+// (launched right behind the walk, before the host knows how many chunks it found: a fixed grid starting at chunk `first`, blocks past
+// the walk's count - read from the status words - leave at once; nothing runs when the walk itself gave up or overflowed its table)
+__global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const DevHeader* __restrict__ D, DChunk* __restrict__ CH, DecStatus* st, uint32_t first) {
+    const uint32_t c = first + blockIdx.x; const uint32_t hf = D->flags, rlb = D->read_len_bytes;
+    if (c >= st->n_chunks || st->overflow) return;
     const uint64_t k = CH[c].off; const uint32_t want = CH[c].total, rbase = CH[c].rbase, reads = CH[c].reads;
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
