@@ -161,15 +161,6 @@ __device__ __forceinline__ uint8_t comp_base(uint8_t b) {
     switch (b) { case 'A': case 'a': return 'T'; case 'T': case 't': return 'A'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; default: return 'N'; }
 }
 
-// branch-free variant for inner loops (selects, no jump table): same mapping
-__device__ __forceinline__ uint32_t comp_base_sel(uint32_t b) {
-    const uint32_t u = b & 0xDFu;                                   // fold case for letters
-    uint32_t r = 'N';
-    r = (u == 'A') ? 'T' : r; r = (u == 'T') ? 'A' : r; r = (u == 'C') ? 'G' : r; r = (u == 'G') ? 'C' : r;
-    // only exact letters count: b & 0xDF also maps e.g. 0x61-0x20... 'a'(0x61)->'A' ok; but 0x01|... non-letters like 0x41^0x20=0x61 handled; reject bytes whose fold changed a non-letter
-    return ((b | 0x20u) >= 'a' && (b | 0x20u) <= 'z') ? r : 'N';
-}
-
 // 16 / 4 consecutive bytes starting at an arbitrary LDS byte address, as little-endian words: ONE ds_read_b128 / ds_read_b32 at a
 // byte-granular address (gfx950 LDS runs in unaligned access mode; the compiler emits the wide read for an align-1 type).  The
 // earlier form - five aligned word reads + v_alignbit funnel shifts - cost ~10 instructions per group in VALU-bound copy loops.
@@ -215,8 +206,3 @@ __device__ __forceinline__ uint32_t tile_find(const uint32_t* dst, uint32_t cnt,
     return lo;
 }
 
-// 16 bytes ending at LDS address a (inclusive), reversed: out byte k = base[a - k]
-__device__ __forceinline__ void lds_get16_rev(const uint8_t* base, uint32_t a, uint32_t (&w)[4]) {
-    uint32_t f[4]; lds_get16(base, a - 15u, f);
-    w[0] = bswap32(f[3]); w[1] = bswap32(f[2]); w[2] = bswap32(f[1]); w[3] = bswap32(f[0]);
-}
