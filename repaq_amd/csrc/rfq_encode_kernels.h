@@ -229,9 +229,9 @@ __device__ __forceinline__ bool bytes_eq(const uint8_t* a, uint32_t alen, const 
 // 16-byte-aligned address - a wave stages its 64 names with 8 global_load_dwordx4 (all in flight together) instead of 64 rounds
 // of byte loads.  A group is stored with one byte-granular ds_write_b128 at (row + 16 + 16 * part - (name start & 15)), so the
 // name itself begins at row + 16 whatever its alignment was (the bytes in front of it land in the row's own 16-byte pad).
-// Row stride 148 B = 37 banks: lanes walking their own rows byte by byte do not collide.
-#define RT_NAME_CAP 112           // 15 + 112 < 128: any name this long sits inside its 128-byte window
-#define RT_ROW 148
+// Row stride 116 B = 29 banks: lanes walking their own rows byte by byte do not collide; 29.7 KB per block = five blocks per CU.
+#define RT_NAME_CAP 80            // 15 + 80 < 96: a name this long sits inside the first six 16-byte groups of its window
+#define RT_ROW 116
 __device__ __forceinline__ void stage_name_rows_wide(const Text& T, uint8_t* rows, uint32_t nb, uint32_t nl, int s, int l) {
     const uint32_t part = (uint32_t)l & 7u;
     uint4 v[8]; bool ok[8]; uint32_t da[8];
