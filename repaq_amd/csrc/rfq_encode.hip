@@ -12,10 +12,10 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_MASK, B_ENC_END
 };
 
-static_assert(B_ENC_END <= 64, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
+static_assert(B_ENC_END <= 72, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
 
 static int fetch_bytes(rfq_ctx* ctx, const uint8_t* d, size_t n, std::string& out) {
     out.resize(n);
@@ -384,8 +384,12 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 8)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
         HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S));   // absent streams / segments count 0
 #define RFQ_PC_ARGS R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), \
-                    (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), B[B_SEGC].as<int>(), B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, n_qgroups, dst
+                    (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), B[B_SEGC].as<int>(), B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, n_qgroups, dst, maskbuf
         const uint32_t n_qgroups = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
+        // the summary pass keeps every step's match masks (8 B per lane, step and stream = 1/8 of the qualities per stream) for the coding
+        // pass when the header has few quality values; with tens of values the masks would outweigh the data and are recomputed
+        const uint32_t nmk = std::min<uint32_t>(HH.n_normal, NPOS_SLOT); uint64_t* maskbuf = nullptr;
+        if (nmk && nmk <= 8) { HIPCHK(ctx, B[B_MASK].ensure((size_t)n_chunks * nmk * n_seg * PC_SEG_STEPS * 64 * 8)); maskbuf = B[B_MASK].as<uint64_t>(); }
         const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * (n_qgroups + 2) * n_seg;
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
         hipLaunchKernelGGL((k_pos_coder<0>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);

@@ -1225,10 +1225,11 @@ struct PcStream {
     int prev_carry, zero_carry;             // last match / last non-match before the current step
     uint32_t outpos; uint8_t* out; uint32_t room;
     int last1, last0; uint32_t cnt;         // summary pass: last match / non-match, number of matches
+    uint64_t* mk;                           // [step][lane] match masks of the stream: written by the summary pass, read by the coding pass (nullptr: recomputed)
 };
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
 // with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  EMIT writes the bytes at S[t].out[0..).
-template <bool EMIT, int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
+template <bool EMIT, int MODE, int G, bool MK> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
                                                                            PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
@@ -1239,11 +1240,19 @@ template <bool EMIT, int MODE, int G> __device__ __forceinline__ void wave_pos_e
     auto load = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (nmap && !nmap_test(nmap, nshift, step_)) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; } return pc_load_raw(B, len, p_); };
     const uint32_t nst = (len + 4095u) / 4096u;
     auto loadc = [&](uint32_t step_, uint32_t p_) -> Raw64 { return load(step_ < nst ? step_ : nst - 1u, step_ < nst ? p_ : len); };
-    Raw64 raw_n = loadc(step0 + 1, q0 + 4096u);
-    { const Raw64 r0 = loadc(step0, q0);
+    // MK: the summary pass left every step's masks in S[t].mk - the pipeline carries masks (two steps ahead) instead of raw bytes
+    auto ldm = [&](int t, uint32_t step_) -> uint64_t { return step_ < nst ? S[t].mk[(size_t)step_ * 64u + (uint32_t)l] : 0ull; };
+    Raw64 raw_n; uint64_t m_nn[G];
+    if (MK) {
 #pragma unroll
-      for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D); S[t].outpos = 0; } }
-    raw_n = loadc(step0 + 2, q0 + 8192u);
+        for (int t = 0; t < G; t++) { m_nn[t] = 0; if (S[t].on) { S[t].m_cur = ldm(t, step0); S[t].m_next = ldm(t, step0 + 1); m_nn[t] = ldm(t, step0 + 2); S[t].outpos = 0; } }
+    } else {
+        raw_n = loadc(step0 + 1, q0 + 4096u);
+        { const Raw64 r0 = loadc(step0, q0);
+#pragma unroll
+          for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D); S[t].outpos = 0; } }
+        raw_n = loadc(step0 + 2, q0 + 8192u);
+    }
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
 #pragma unroll
@@ -1288,9 +1297,14 @@ template <bool EMIT, int MODE, int G> __device__ __forceinline__ void wave_pos_e
             if (pl > s.prev_carry) s.prev_carry = pl;
             if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > s.zero_carry) s.zero_carry = zl; }
         }
+        if (MK) {
 #pragma unroll
-        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D); }
-        raw_n = loadc(step + 3, p0 + 12288u);
+            for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = m_nn[t]; m_nn[t] = ldm(t, step + 3); }
+        } else {
+#pragma unroll
+            for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D); }
+            raw_n = loadc(step + 3, p0 + 12288u);
+        }
     }
 }
 // last match / last non-match inside steps [step0, step1) (or -1) of every active stream: the summary pass, loads pipelined like the coder's
@@ -1308,6 +1322,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_grou
         for (int t = 0; t < G; t++) {
             if (!S[t].on) continue;
             const uint64_t m = pc_mask_of(raw_c, len, p0, MODE, S[t].q, D);
+            if (S[t].mk) S[t].mk[(size_t)step * 64u + (uint32_t)l] = m;   // the coding pass takes the mask from here: it neither re-reads the 4096 bytes nor redoes ~165 SWAR instructions per stream
             S[t].cnt += (uint32_t)__popcll(m);                                 // (per lane; summed over the wave by the caller)
             const unsigned long long h1 = __ballot(m != 0), h0 = __ballot(~m != 0);
             if (h1) { const int v = m ? (int)p0 + 63 - __clzll((long long)m) : -1; S[t].last1 = __shfl(v, 63 - __clzll((long long)h1)); }
@@ -1325,7 +1340,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_grou
 // the chunk (histogram) are skipped outright.
 template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t* __restrict__ segm, uint32_t n_seg,
-                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st) {
+                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st, uint64_t* __restrict__ maskbuf = nullptr, uint32_t nmk = 0) {
     const uint32_t nshift = nmap ? nmap_shift(len) : 0u;
     const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
     const uint32_t step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
@@ -1333,7 +1348,7 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
 #pragma unroll
     for (int t = 0; t < G; t++) {
         const uint32_t j = j0 + (uint32_t)t;
-        S[t].on = false; kk[t] = 0;
+        S[t].on = false; kk[t] = 0; S[t].mk = nullptr;
         if (j >= jend) continue;
         const size_t k = (size_t)c * MAX_STREAMS + j; kk[t] = k;
         const uint32_t cap = C.scap[k];
@@ -1345,6 +1360,7 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
         S[t].on = true; any = true;
         S[t].mode = MODE; S[t].q = j < NPOS_SLOT ? D->normal[j] : (uint32_t)'N';
         S[t].prev_carry = -1; S[t].zero_carry = -1; S[t].out = nullptr; S[t].room = 0; S[t].outpos = 0;
+        S[t].mk = (maskbuf && j < nmk) ? maskbuf + ((size_t)c * nmk + j) * ((size_t)n_seg * PC_SEG_STEPS * 64u) : nullptr;
     }
     if (!any) return;                                                      // wave-uniform
     if (PASS == 0) {
@@ -1367,7 +1383,8 @@ template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(cons
         const uint32_t own = pc_seg_cap(MODE == PC_EXCEPT, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
         S[t].out = scratch + cbase[c] + C.soff[kk[t]] + off; S[t].room = off + own <= C.scap[kk[t]] ? own : 0u;
     }
-    wave_pos_encode_group<true, MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
+    if (maskbuf && MODE == PC_MATCH && j0 < nmk) wave_pos_encode_group<true, MODE, G, true>(B, len, D, S, step0, step1, nmap, nshift);   // (a group's streams all have masks or none)
+    else wave_pos_encode_group<true, MODE, G, false>(B, len, D, S, step0, step1, nmap, nshift);
 #pragma unroll
     for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) {
         segb[kk[t] * n_seg + seg] = S[t].outpos;
@@ -1385,14 +1402,14 @@ __global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint3
 }
 template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
-                            uint32_t n_qgroups, DevStatus* st) {
+                            uint32_t n_qgroups, DevStatus* st, uint64_t* __restrict__ maskbuf) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
     // (group, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's data stays in ONE private L2.
     const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = (n_qgroups + 2) * n_seg;
     const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = rest % (n_qgroups + 2), seg = rest / (n_qgroups + 2);
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
-    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
+    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st, maskbuf, nn);
     else if (grp == n_qgroups) pc_run<PASS, PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st);
     else pc_run<PASS, PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
