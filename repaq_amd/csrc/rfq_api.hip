@@ -42,6 +42,8 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+    if (c->aux2) (void)hipStreamDestroy(c->aux2);
+    if (c->ev_f) (void)hipEventDestroy(c->ev_f);
     delete c;
 }
 

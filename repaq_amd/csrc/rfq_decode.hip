@@ -124,7 +124,11 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     hipStream_t A = forked ? ctx->aux : S;
     if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
     const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
-    hipLaunchKernelGGL(k_dec_fill, dim3(2048), dim3(256), 0, S, qdec, (uint64_t)qbytes, D);
+    // the prefill is pure bandwidth, the coordinate decoder and the stream summaries are pure latency: third chain
+    hipStream_t F = forked ? ctx->aux2 : S;
+    if (forked) HIPCHK(ctx, hipStreamWaitEvent(F, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_dec_fill, dim3((uint32_t)std::min<size_t>(8192, (qbytes / 16 + 255) / 256 + 1)), dim3(256), 0, F, qdec, (uint64_t)qbytes, D);   // (many short blocks: slots keep turning over for the two other chains)
+    if (forked) HIPCHK(ctx, hipEventRecord(ctx->ev_f, F));
     hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
     if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
         // position streams in POS_SEG-byte segments: summary -> link -> emit (see rfq_decode_kernels.h)
@@ -142,14 +146,14 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
 #undef RFQ_SUM_ARGS
         hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
                            (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
-        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_mid, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0)); }
+        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_mid, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
         hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
         if (nn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mq, nn, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
                                    (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, 0u, nstr);
         if (hasn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mn, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
                                      (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, HH.n_normal, nstr);
     } else hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
-    if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
+    if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
     hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
     KCHK(ctx, "k_dec_streams");
     ctx->timer.end(S);
