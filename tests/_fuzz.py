@@ -1,0 +1,107 @@
+"""Seeded random FASTQ inputs for differential tests of the HIP path against the oracle: shapes the hand-made goldens and the generated
+configs do not sweep systematically — read lengths around the 16-byte group sizes of the LDS copy loops (1, 15, 16, 17, 31, 33 ...),
+names that parse / do not parse / are longer than the staged rows, strand lines with text, 1-41 quality values with exceptions,
+N-rich reads, pairs that overlap by a random amount (forward or reverse), reads of random length, several chunks or one."""
+import random
+
+import _oracle as O
+
+COMP = {65: 84, 84: 65, 67: 71, 71: 67, 78: 78}
+
+
+def _rc(s: bytes) -> bytes:
+    return bytes(COMP[b] for b in reversed(s))
+
+
+def case(seed: int):
+    """-> (fq1, fq2, paired, chunk_bases)"""
+    r = random.Random(seed)
+    paired = r.choice([O.SE, O.SE, O.PE_TWO_FILES, O.PE_INTERLEAVED])
+    fixed = r.random() < 0.6
+    L = r.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 48, 100, 151, 151, 250, 300])
+    big = r.random() < 0.25                                      # enough bases for several chunks at -k 100
+    n = r.randint(700, 1500) * max(1, 160 // max(L, 40)) if big else r.randint(1, 120)
+    quals = bytes(r.sample(range(34, 76), r.choice([1, 2, 4, 4, 8, 41 if r.random() < 0.3 else 6])))
+    qw = [r.random() ** 3 + 0.01 for _ in quals]
+    exc = r.random() < 0.2
+    nprob = r.choice([0.0, 0.0, 0.002, 0.15])
+    style = r.choice(["illumina", "illumina", "illumina_nocomment", "free", "same", "long"])
+    strand_text = r.random() < 0.2
+    lane = r.randint(1, 8); tile = r.randint(1101, 2678); x = r.randint(1000, 30000); y = r.randint(1000, 200000)
+    recs1, recs2 = [], []
+    for i in range(n):
+        ln = L if fixed else r.randint(1, L)
+        seq = bytearray(r.choice(b"ACGT") for _ in range(ln))
+        for k in range(ln):
+            if r.random() < nprob:
+                seq[k] = 78
+        q = bytearray(r.choices(quals, qw, k=ln))
+        if exc and r.random() < 0.3:
+            q[r.randrange(ln)] = r.randrange(33, 80)
+        if r.random() < 0.6:
+            x += r.randint(0, 40)
+        else:
+            x = r.randint(1000, 30000); y += r.randint(1, 300)
+        if r.random() < 0.02:
+            tile += 1; y = r.randint(1000, 3000)
+        if style == "free":
+            name = b"@r%d.%s" % (i, bytes(r.choice(b"abcXYZ_-") for _ in range(r.randint(0, 20))))
+        elif style == "same":
+            name = b"@same"
+        else:
+            name = b"@M0%d:%d:FC%s:%d:%d:%d:%d" % (r.randint(1, 3), 26, b"H3YTW" * (8 if style == "long" else 1), lane, tile, x, y)
+        c1 = c2 = b""
+        if style in ("illumina", "long"):
+            idx = bytes(r.choice(b"ACGT") for _ in range(r.choice([0, 6, 8])))
+            c1 = b" 1:N:0:" + idx; c2 = b" 2:N:0:" + idx
+        st = b"+" + (name[1:] if strand_text else b"")
+        recs1.append(name + c1 + b"\n" + bytes(seq) + b"\n" + st + b"\n" + bytes(q) + b"\n")
+        if paired != O.SE:
+            # the mate: reverse complement of a window that overlaps R1's tail (or head) by a random amount, or an unrelated read
+            ln2 = L if fixed else r.randint(1, L)
+            mode = r.random()
+            if mode < 0.5 and ln >= 12:
+                ov = r.randint(min(12, ln), ln); tail = bytes(seq[ln - ov:]) + bytes(r.choice(b"ACGT") for _ in range(max(0, ln2 - ov)))
+                s2 = _rc(tail[:ln2]) if len(tail) >= ln2 else _rc(tail + bytes(r.choice(b"ACGT") for _ in range(ln2 - len(tail))))
+            elif mode < 0.65 and ln >= 12:
+                ov = r.randint(min(12, ln), ln); head = bytes(r.choice(b"ACGT") for _ in range(max(0, ln2 - ov))) + bytes(seq[:ov])
+                s2 = _rc(head[-ln2:]) if len(head) >= ln2 else _rc(bytes(r.choice(b"ACGT") for _ in range(ln2 - len(head))) + head)
+            else:
+                s2 = bytes(r.choice(b"ACGT") for _ in range(ln2))
+            s2 = bytes(s2[:ln2]); q2 = bytes(r.choices(quals, qw, k=len(s2)))
+            n2 = name if r.random() > 0.03 else name + b"x"
+            recs2.append(n2 + c2 + b"\n" + s2 + b"\n" + st + b"\n" + q2 + b"\n")
+    if paired == O.PE_INTERLEAVED:
+        fq1 = b"".join(a + b for a, b in zip(recs1, recs2)); fq2 = b""
+    else:
+        fq1 = b"".join(recs1); fq2 = b"".join(recs2)
+    if r.random() < 0.3 and fq1:
+        fq1 = fq1[:-1]                                           # no final line break
+    if r.random() < 0.2 and fq2:
+        fq2 = fq2[:-1]
+    return fq1, fq2, paired, 100_000
+
+
+def check(codec, encode, seed):
+    """encode == oracle (or the same error text), decode(oracle image) == oracle decode."""
+    from repaq_amd import RfqError
+    fq1, fq2, paired, cb = case(seed)
+    try:
+        want = O.encode_file(fq1, fq2, paired, cb)
+    except O.OracleError as e:
+        try:
+            encode(codec, fq1, fq2, paired, cb)
+        except RfqError as g:
+            # (the one input class both sides REFUSE rather than reproduce - the reference overflows its heap there, App. C Q6 - is worded differently)
+            unpinned = "1.5x scratch buffer" in g.message and "1.5x scratch buffer" in str(e)
+            assert unpinned or g.message.strip() == str(e).strip(), (seed, g.message, str(e))
+            return "error"
+        raise AssertionError("seed %d: the oracle refuses this input (%s), the engine encoded it" % (seed, e))
+    got = encode(codec, fq1, fq2, paired, cb)
+    assert got == want, "seed %d: image differs (%d vs %d bytes)" % (seed, len(got), len(want))
+    if want:
+        split = paired != O.SE
+        assert codec.decode_bytes(want, split_pe=split) == O.decode_file(want, split), "seed %d: decode differs" % seed
+        if split:
+            assert codec.decode_bytes(want, split_pe=False) == O.decode_file(want, False), "seed %d: interleaved decode differs" % seed
+    return "ok"

@@ -1,0 +1,37 @@
+"""Differential fuzz of the HIP path against the oracle on seeded random inputs (tests/_fuzz.py): a few seeds under the SIMT
+interpreter on CPU, a few hundred through the product library on the GPU.  The oracle itself is checked against the reference
+binary on the same seeds where oracle/_ref/repaq exists."""
+import pytest
+
+import _engine as E
+import _fuzz as F
+import _oracle as O
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_on_simt_emulation(seed):
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    try:
+        F.check(c, E.encode, seed)
+    finally:
+        c.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref/repaq)")
+@pytest.mark.parametrize("seed", range(0, 40))
+def test_oracle_equals_reference_binary_on_fuzz_inputs(seed, tmp_path):
+    fq1, fq2, paired, cb = F.case(seed)
+    assert O.encode_file(fq1, fq2, paired, cb) == O.ref_encode(fq1, fq2, paired, cb // 1000, tmpdir=str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_fuzz_on_gpu():
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.PRODUCT_LIB)
+    assert "gfx950" in c.version()
+    try:
+        outcomes = [F.check(c, E.encode, seed) for seed in range(300)]
+    finally:
+        c.close()
+    assert outcomes.count("ok") > 250
