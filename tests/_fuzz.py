@@ -79,6 +79,14 @@ def case(seed: int):
         fq1 = fq1[:-1]                                           # no final line break
     if r.random() < 0.2 and fq2:
         fq2 = fq2[:-1]
+    # reader quirks (src/fastqreader.cpp:94-196): "\r\n" line ends; one blank line after a record (swallowed); two (reading stops there)
+    t = r.random()
+    if t < 0.10:
+        fq1 = fq1.replace(b"\n", b"\r\n"); fq2 = fq2.replace(b"\n", b"\r\n")
+    elif t < 0.16 and recs1:
+        k = r.randrange(len(recs1)); cut = sum(len(x) for x in recs1[:k + 1]) if paired != O.PE_INTERLEAVED else None
+        if cut is not None and cut <= len(fq1):
+            fq1 = fq1[:cut] + (b"\n" if r.random() < 0.5 else b"\n\n") + fq1[cut:]
     return fq1, fq2, paired, 100_000
 
 
