@@ -175,9 +175,12 @@ __device__ __forceinline__ uint32_t unpack4(uint32_t byte) {              // 4 b
     return w;
 }
 __global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec, uint64_t img_bytes) {
-    __shared__ uint32_t s_lut[256];                                  // packed byte -> its four bases
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = unpack4(i);
-    __syncthreads();
+    // packed byte -> its four bases without a table: two shift-and-mask steps spread the four 2-bit codes over four bytes, v_perm_b32
+    // looks them up in the 4-entry G A T C table (an LDS table cost a bank-conflicted read per byte and a fill per block)
+    auto unpack4v = [](uint32_t b) -> uint32_t {
+        const uint32_t y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u;
+        return __builtin_amdgcn_perm(0u, 0x43544147u, idx);
+    };
     const DChunk d = CH[blockIdx.y]; const uint32_t f = d.rbase;
     const uint32_t n = R.pv[f + d.reads].d - R.pv[f].d;          // stored bases of the chunk
     const uint8_t* src = img + d.off + d.o_seq; uint8_t* dst = sdec + sbase[blockIdx.y]; const uint8_t* lim = img + img_bytes;
@@ -194,7 +197,7 @@ __global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __re
             const uint32_t pk = ph ? (uint32_t)((((uint64_t)hi[u] << 32) | lo[u]) >> sh) : lo[u];
             uint32_t w[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t i = 4 * gi + (uint32_t)k; w[k] = i < d.seq_size ? s_lut[(pk >> (8 * k)) & 0xFFu] : 0x4E4E4E4Eu; }   // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
+            for (int k = 0; k < 4; k++) { const uint32_t i = 4 * gi + (uint32_t)k; w[k] = i < d.seq_size ? unpack4v((pk >> (8 * k)) & 0xFFu) : 0x4E4E4E4Eu; }   // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
             if (16 * gi + 16 <= n) *(uint4*)(dst + 16 * (size_t)gi) = make_uint4(w[0], w[1], w[2], w[3]);
             else for (uint32_t p = 16 * gi; p < n; p++) dst[p] = (uint8_t)(w[(p >> 2) & 3u] >> (8 * (p & 3u)));
         }
