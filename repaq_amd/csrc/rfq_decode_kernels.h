@@ -168,12 +168,6 @@ __global__ void k_dec_bases(const DChunk* __restrict__ CH, DReadTab R, uint64_t*
 // 2-bit unpack (src/rfqcodec.cpp:833-853): grid (blocks, n_chunks).  One thread turns 4 packed bytes into 16 bases and stores them
 // as one aligned uint4 (the chunk's base in sdec is 64-byte aligned); byte stores cost ~30 cycles per wave instruction.
 __device__ __forceinline__ uint32_t ld_word_lim(const uint8_t* p, const uint8_t* lim);
-__device__ __forceinline__ uint32_t unpack4(uint32_t byte) {              // 4 bases of one packed byte -> 4 ASCII bytes (G A T C = 0 1 2 3)
-    uint32_t w = 0;
-#pragma unroll
-    for (int b = 0; b < 4; b++) { const uint32_t code = (byte >> (2 * b)) & 3u; w |= (code == 0 ? (uint32_t)'G' : (code == 1 ? (uint32_t)'A' : (code == 2 ? (uint32_t)'T' : (uint32_t)'C'))) << (8 * b); }
-    return w;
-}
 __global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec, uint64_t img_bytes) {
     // packed byte -> its four bases without a table: two shift-and-mask steps spread the four 2-bit codes over four bytes, v_perm_b32
     // looks them up in the 4-entry G A T C table (an LDS table cost a bank-conflicted read per byte and a fill per block)
