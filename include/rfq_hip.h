@@ -128,6 +128,12 @@ typedef struct {
     int32_t  reserved;
     uint8_t* d_out1; size_t cap1;         /* optional caller buffers; NULL = context-owned results                     */
     uint8_t* d_out2; size_t cap2;
+    /* optional chunk index (the .rfq format has none: RfqChunk::read finds chunk c+1 only by parsing chunk c, src/rfqchunk.cpp:161-228,
+     * a dependent load per chunk).  A host that has the offsets - it encoded the image (rfq_encode_result.h_chunk_off), or it walked
+     * the chunk headers while the image was on its way to the GPU - passes them: h_chunk_off[0 .. n_chunk_off] = byte offset of every
+     * chunk in d_rfq and, last, the end of the last chunk.  Every extent is still verified on the device by a full parse of its chunk;
+     * a table that does not verify is ignored (the chain is walked instead).  NULL / 0 = walk.                                      */
+    const uint64_t* h_chunk_off; uint32_t n_chunk_off; uint32_t reserved3;
 } rfq_decode_args;
 
 typedef struct {

@@ -11,7 +11,7 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 72, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_END
+    DB_CHUNKS = 72, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_END
 };
 static_assert(DB_END <= 96, "rfq_ctx::b too small");
 
@@ -51,18 +51,32 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs;
     uint32_t cap = (uint32_t)std::max<size_t>(B[DB_CHUNKS].cap / sizeof(DChunk), 4096);
     bool speculate = true;
+    // 0: the caller's chunk index (verified below), 1: the speculative mSize chain (verified), 2: the exact serial walk
+    bool use_table = a->h_chunk_off && a->n_chunk_off && a->h_chunk_off[0] == start && a->h_chunk_off[a->n_chunk_off] <= a->n;
     for (;;) {
+        if (use_table && a->n_chunk_off + 1u > cap) cap = a->n_chunk_off + 1u;
         HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
         HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
-        if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
+        if (use_table) {
+            const size_t tb = ((size_t)a->n_chunk_off + 1) * 8;
+            HIPCHK(ctx, B[DB_OFFT].ensure(tb));
+            HIPCHK(ctx, hipMemcpyAsync(B[DB_OFFT].p, a->h_chunk_off, tb, hipMemcpyHostToDevice, S));
+            hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), a->n_chunk_off, B[DB_CHUNKS].as<DChunk>(), dst);
+        }
+        else if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
         else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
         KCHK(ctx, "k_dec_walk");
         // the verifying parse rides behind the speculative walk without a host round trip in between (its grid covers the first
         // PARSE_AHEAD chunks; the walk's own verdict is in the status words it reads)
-        const uint32_t PARSE_AHEAD = 4096;
+        const uint32_t PARSE_AHEAD = use_table ? std::max(a->n_chunk_off, 1u) : 4096u;
         if (speculate) { hipLaunchKernelGGL(k_dec_parse, dim3(std::min(cap, PARSE_AHEAD)), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, 0u); KCHK(ctx, "k_dec_parse"); }
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
+        if (use_table) {
+            // the table must cover whole chunks up to the end of the image (or up to a tail too short to be a chunk): anything else walks
+            if (hs.pad || (hs.consumed != a->n && a->n - hs.consumed >= 18)) { use_table = false; continue; }
+            break;
+        }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
         if (!speculate) break;
         if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly

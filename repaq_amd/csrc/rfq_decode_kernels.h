@@ -118,12 +118,39 @@ __global__ void k_dec_spec_walk(const uint8_t* __restrict__ img, uint64_t n, uin
     }
     if (l == 0) { st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->pad = bad; }
 }
+// The chain from a chunk index the caller supplied (rfq_decode_args.h_chunk_off): the read counts of all chunks are fetched in
+// parallel (one workgroup, 256 chunks per round, running read base by a block scan) - no dependent load per chunk.  k_dec_parse
+// verifies every extent exactly as it does behind the speculative walk.
+__global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const uint64_t* __restrict__ off, uint32_t nch, DChunk* __restrict__ out, DecStatus* st) {
+    __shared__ uint64_t s_carry; __shared__ uint32_t s_bad, s_maxr;
+    if (threadIdx.x == 0) { s_carry = 0; s_bad = 0; s_maxr = 0; }
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nch; b0 += blockDim.x) {
+        const uint32_t c = b0 + threadIdx.x; uint32_t reads = 0; uint64_t k = 0, e = 0; bool bad = false;
+        if (c < nch) {
+            k = off[c]; e = off[c + 1];
+            if (e > n || k + 18 > e || e - k > 0xFFFFFFFFull) bad = true; else { reads = ld_u32(img + k + 4); if (reads == 0) bad = true; }
+        }
+        uint32_t tot; const uint32_t ex = block_excl_sum<uint32_t>(bad ? 0u : reads, &tot);
+        const uint64_t carry = s_carry;
+        if (c < nch && !bad) { out[c].off = k; out[c].total = (uint32_t)(e - k); out[c].rbase = (uint32_t)(carry + ex); out[c].reads = reads; atomicMax(&s_maxr, reads); }
+        if (bad) atomicOr(&s_bad, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t rb = s_carry; uint32_t bad = s_bad | (rb > 0xFFFFFFF0ull ? 1u : 0u);
+        st->n_chunks = nch; st->max_reads = s_maxr; st->total_reads = rb; st->consumed = off[nch]; st->overflow = 0; st->pad = bad;
+        st->last_flags = (!bad && nch) ? ld_u16(img + off[nch - 1] + 8) : 0u;
+    }
+}
 // one wave per speculated chunk: full parse + verification of the extent
 // (launched right behind the walk, before the host knows how many chunks it found: a fixed grid starting at chunk `first`, blocks past
 // the walk's count - read from the status words - leave at once; nothing runs when the walk itself gave up or overflowed its table)
 __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const DevHeader* __restrict__ D, DChunk* __restrict__ CH, DecStatus* st, uint32_t first) {
     const uint32_t c = first + blockIdx.x; const uint32_t hf = D->flags, rlb = D->read_len_bytes;
-    if (c >= st->n_chunks || st->overflow) return;
+    if (c >= st->n_chunks || st->overflow || st->pad) return;             // (pad: the chain / the caller's table already failed - its entries are not to be trusted)
     const uint64_t k = CH[c].off; const uint32_t want = CH[c].total, rbase = CH[c].rbase, reads = CH[c].reads;
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }

@@ -12,7 +12,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_MASK, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 72, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -327,11 +327,19 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
 
     ctx->timer.begin("gather", S);
     HIPCHK(ctx, hipMemsetAsync(C.hist, 0, nc * 256 * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
+    // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
+    const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
+    const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
+    HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
+    HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
     {
-        // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 128; enough workgroups to fill 256 CUs x 2
+        // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 64; enough workgroups to fill 256 CUs x 2
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + GT_READS - 1) / GT_READS, std::max(1u, 8192u / n_chunks)));
-        if (tune) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune);
-        else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune);
+#define RFQ_GATHER_ARGS T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, \
+                        tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune
+        if (tune) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
+        else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
+#undef RFQ_GATHER_ARGS
         if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
             if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
     }
@@ -376,27 +384,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, ctx->aux, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
-    uint32_t pc_n_seg_host = 1;
     ctx->timer.begin("pos_coder", S);
     {
-        const uint32_t max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
-        const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
-        HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 8)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
-        HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S));   // absent streams / segments count 0
-#define RFQ_PC_ARGS R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), \
-                    (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), B[B_SEGC].as<int>(), B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, n_qgroups, dst, maskbuf
         const uint32_t n_qgroups = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
-        // the summary pass keeps every step's match masks (8 B per lane, step and stream = 1/8 of the qualities per stream) for the coding
-        // pass when the header has few quality values; with tens of values the masks would outweigh the data and are recomputed
-        const uint32_t nmk = std::min<uint32_t>(HH.n_normal, NPOS_SLOT); uint64_t* maskbuf = nullptr;
-        if (nmk && nmk <= 8) { HIPCHK(ctx, B[B_MASK].ensure((size_t)n_chunks * nmk * n_seg * PC_SEG_STEPS * 64 * 8)); maskbuf = B[B_MASK].as<uint64_t>(); }
         const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * (n_qgroups + 2) * n_seg;
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
-        hipLaunchKernelGGL((k_pos_coder<0>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);
-        hipLaunchKernelGGL((k_pos_coder<2>), dim3((uint32_t)pc_blocks), dim3(64), 0, S, RFQ_PC_ARGS);
+        hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, S, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(),
+                           B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(),
+                           n_seg, n_chunks, n_qgroups, dst);
         hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const uint32_t*)B[B_SEGB].as<uint32_t>(), n_seg);
-        pc_n_seg_host = n_seg;
-#undef RFQ_PC_ARGS
     }
     KCHK(ctx, "k_pos_coder");
     ctx->timer.end(S);
@@ -415,7 +411,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
                            (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(),
                            (const uint8_t*)B[B_XS].as<uint8_t>(), (const uint8_t*)B[B_YS].as<uint8_t>(), (const int8_t*)ovb, img, img_cap, hdr_bytes,
                            a->file_off1, a->file_off2, a->nolb_from1, a->nolb_from2,
-                           (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), pc_n_seg_host, dst);
+                           (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, dst);
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 3) / 4, std::max(1u, 4096u / n_chunks)));
         hipLaunchKernelGGL(k_assemble_names, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L, img, img_cap, hdr_bytes);
         KCHK(ctx, "k_assemble");

@@ -765,102 +765,158 @@ __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int 
     }
     return 0;
 }
-// Same search with both reads staged word-wise in LDS (rows private to a wave): R1 as is, R2 complemented but NOT reversed
-// (c2); RC(R2)[i..i+4) is bswap32 of c2[len2-4-i .. len2-i).  A row keeps its global pointer's misalignment, so staging is
-// aligned word loads -> aligned word stores.  Candidates are filtered on their first four bytes, survivors are verified by
-// the whole wave, four bytes per lane.
-#define OV_CAP 320u                      // bases per read staged in LDS (longer reads take the global-memory path)
-#define OV_ROW (OV_CAP + 16u)            // 8 bytes of slack before the data (reads below the row are masked out), 4+ after
-struct OvPair { uint32_t r1, c2; int len1, len2; };           // LDS offsets of R1[0] and c2[0]
-__device__ __forceinline__ uint32_t ov_r1(const uint8_t* rows, const OvPair& P, uint32_t i) { return lds_get4(rows, P.r1 + i); }
-__device__ __forceinline__ uint32_t ov_rc(const uint8_t* rows, const OvPair& P, uint32_t i) { return bswap32(lds_get4(rows, P.c2 + (uint32_t)P.len2 - 4u - i)); }
-// R1[a..a+n) == RC(R2)[b..b+n): the whole wave compares, 4 bytes per lane per step
-__device__ __forceinline__ bool ov_equal(const uint8_t* rows, const OvPair& P, uint32_t a, uint32_t b, uint32_t n) {
-    const uint32_t l = (uint32_t)lane_id();
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
-        const uint32_t i = i0 + 4 * l; uint32_t x = 0;
-        if (i < n) { x = ov_r1(rows, P, a + i) ^ ov_rc(rows, P, b + i); if (n - i < 4) x &= (1u << (8 * (n - i))) - 1u; }
-        if (__ballot(x != 0)) return false;
-    }
-    return true;
+// The same search in 2-bit space, ONE PAIR PER LANE.  A wave packs its 64 pairs into LDS rows - R1 as it is, R2 already reverse-
+// complemented (RC2[i] = comp(R2[len2-1-i]): 16 bases taken from the END of R2, byte-reversed, complement codes) - as 2 bits per base
+// (G 0, A 1, T 2, C 3, anything else 0) plus one "is N" bit per base.  RfqCodec::overlap compares characters: R1's are compared as
+// they stand, RC2's are in {A,C,G,T,N} (Read::changeToReverseComplement maps everything else to N), so two bases are equal iff their
+// codes and their N bits are equal - except a base of R1 outside A/C/G/T/N, which equals nothing (such pairs, and reads longer than
+// the rows, take wave_overlap above).  Every lane then walks ITS pair's candidates o = 12, 13, ...: a candidate passes the filter
+// when the first 12 bases of the window (24 code bits: one byte-granular ds_read_b32 + bit-field extract) equal the 12-base head of the
+// other read; the few that pass are verified by the whole wave (4 bases per lane, codes and N bits).  Forward before backward,
+// smallest o first (src/rfqcodec.cpp:1391-1438).  The former wave-per-pair search cost ~600 wave-instructions per pair.
+#define OV2_CAP 256u              // bases per read held in a row (64 lanes x 4 bases verify one candidate in one step)
+#define OV2_CROW 68u              // code row: 64 bytes + 4 of slack for the last unaligned word; 17 dwords, so that lanes reading their own rows at one offset hit 64 different banks
+#define OV2_NROW 36u              // N-bit row: 32 bytes + 4; 9 dwords
+#define OV2_WAVE_BYTES (128u * (OV2_CROW + OV2_NROW))
+#define OV2_BATCH 8               // candidates filtered per round
+__device__ __forceinline__ uint32_t bfe_u32(uint32_t v, uint32_t off, uint32_t wid) { return (v >> off) & ((1u << wid) - 1u); }
+// 16 bytes at base + off (any alignment); bytes outside [0, n) read as 0
+static __device__ __noinline__ uint4 ld16_edge(const uint8_t* __restrict__ base, long long off, uint64_t n) {
+    uint32_t w[4] = { 0, 0, 0, 0 };
+    for (int b = 0; b < 16; b++) { const long long a = off + b; if (a >= 0 && (uint64_t)a < n) w[b >> 2] |= (uint32_t)base[a] << (8 * (b & 3)); }
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
-__device__ __forceinline__ int wave_overlap_lds(const uint8_t* rows, const OvPair& P) {
-    const int l = lane_id(); const int minlen = P.len1 < P.len2 ? P.len1 : P.len2;
-    if (minlen < 12) return 0;
-    const uint32_t rc_head = ov_rc(rows, P, 0), r1_head = ov_r1(rows, P, 0);     // every candidate has o >= 12 > 4 bytes
-    for (int base = 12; base <= minlen; base += 64) {          // forward: R1 tail == RC(R2) head
-        const int o = base + l;
-        unsigned long long cand = __ballot(o <= minlen && ov_r1(rows, P, (uint32_t)(P.len1 - o)) == rc_head);
-        while (cand) {                                           // ascending o; wave-uniform
-            const int j = __ffsll((long long)cand) - 1; cand &= cand - 1; const uint32_t oo = (uint32_t)(base + j);
-            if (ov_equal(rows, P, (uint32_t)P.len1 - oo, 0u, oo)) return (int)oo;
-        }
-    }
-    for (int base = 12; base <= minlen; base += 64) {          // backward: RC(R2) tail == R1 head
-        const int o = base + l;
-        unsigned long long cand = __ballot(o <= minlen && ov_rc(rows, P, (uint32_t)(P.len2 - o)) == r1_head);
-        while (cand) {
-            const int j = __ffsll((long long)cand) - 1; cand &= cand - 1; const uint32_t oo = (uint32_t)(base + j);
-            if (ov_equal(rows, P, 0u, (uint32_t)P.len2 - oo, oo)) return -(int)oo;
-        }
-    }
-    return 0;
+__device__ __forceinline__ void ld16_guard(const uint8_t* __restrict__ base, long long off, uint64_t n, uint32_t (&w)[4]) {
+    if (off >= 0 && (uint64_t)off + 16ull <= n) { const LdsU16 v = *(const LdsU16*)(base + off); w[0] = v.a; w[1] = v.b; w[2] = v.c; w[3] = v.d; }
+    else { const uint4 v = ld16_edge(base, off, n); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 }
-// 64 pairs per block: 64 threads fetch the pairs' metadata in one go, then each wave walks its 16 pairs with the next pair's
-// bases already in flight while the current one is searched.  Only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
-#define OV_PAIRS 64u
-struct OvRegs { uint32_t a[2], b[2]; };                        // aligned words l and l+64 of each read
-__device__ __forceinline__ void ov_fetch(OvRegs& r, const uint8_t* r1, int len1, const uint8_t* r2, int len2, int l) {
-    const uint32_t m1 = (uint32_t)((uintptr_t)r1 & 3u), m2 = (uint32_t)((uintptr_t)r2 & 3u);
-    const uint32_t* w1 = (const uint32_t*)(r1 - m1); const uint32_t* w2 = (const uint32_t*)(r2 - m2);
-    const uint32_t n1 = len1 > 0 ? (m1 + (uint32_t)len1 + 3u) >> 2 : 0u, n2 = len2 > 0 ? (m2 + (uint32_t)len2 + 3u) >> 2 : 0u;
+// four bases -> (four 2-bit codes in one byte, four N bits, "a byte that is neither A/C/G/T nor N" flags as 0xFF per byte)
+__device__ __forceinline__ void ov2_pack_r1(uint32_t w, uint32_t& code, uint32_t& nbits, uint32_t& bad) {
+    const uint32_t idx = (w >> 1) & 0x03030303u;
+    const uint32_t ok = eq_bytes_full(__builtin_amdgcn_perm(0u, 0x47544341u, idx), w);
+    code = ((__builtin_amdgcn_perm(0u, 0x00020301u, idx) & ok) * 0x01041040u) >> 24;
+    nbits = 0; bad = 0;
+    if (ok != 0xFFFFFFFFu) { const uint32_t isn = eq_bytes_full(w, 0x4E4E4E4Eu); nbits = ((isn & 0x01010101u) * 0x01020408u) >> 24; bad = ~ok & ~isn; }
+}
+// the complement's codes (Read::changeToReverseComplement: either case of A/C/G/T, anything else becomes N)
+__device__ __forceinline__ void ov2_pack_rc(uint32_t w, uint32_t& code, uint32_t& nbits) {
+    const uint32_t u = w & 0xDFDFDFDFu, idx = (u >> 1) & 0x03030303u;
+    const uint32_t ok = eq_bytes_full(__builtin_amdgcn_perm(0u, 0x47544341u, idx), u);
+    code = ((__builtin_amdgcn_perm(0u, 0x03010002u, idx) & ok) * 0x01041040u) >> 24;      // [A,C,T,G] -> codes of T,G,A,C
+    nbits = ((~ok & 0x01010101u) * 0x01020408u) >> 24;
+}
+// window[pa .. pa+o) of row (ac, an) == head[0 .. o) of row (bc, bn): the whole wave, 4 bases per lane
+__device__ __forceinline__ bool ov2_verify(const uint8_t* ac, const uint8_t* an, const uint8_t* bc, const uint8_t* bn, uint32_t pa, uint32_t o, int l) {
+    const uint32_t b0 = 4u * (uint32_t)l; uint32_t diff = 0;
+    if (b0 < o) {
+        const uint32_t nb = o - b0 < 4u ? o - b0 : 4u, q = pa + b0;
+        const uint32_t ca = bfe_u32(lds_get4(ac, (2u * q) >> 3), (2u * q) & 7u, 8u), cb = bc[l];
+        const uint32_t na = bfe_u32(lds_get4(an, q >> 3), q & 7u, 4u), nbm = ((uint32_t)bn[l >> 1] >> (4u * ((uint32_t)l & 1u))) & 0xFu;
+        diff = ((ca ^ cb) & ((1u << (2u * nb)) - 1u)) | ((na ^ nbm) & ((1u << nb) - 1u));
+    }
+    return !__any(diff != 0);
+}
+// 256 pairs per block, 64 per wave.  Only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
+__global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int8_t* __restrict__ ovb, uint32_t n_pairs) {
+    __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4)]; __shared__ uint32_t s_bad[4][2];
+    if (!(D->flags & H_PE_OVERLAP)) return;                     // uniform
+    const int shift = D->overlap_shift; const int l = lane_id(), w = wave_id();
+    uint8_t* const c1 = (uint8_t*)(s_rows + (size_t)w * (OV2_WAVE_BYTES / 4)); uint8_t* const c2 = c1 + 64u * OV2_CROW;
+    uint8_t* const n1 = c2 + 64u * OV2_CROW; uint8_t* const n2 = n1 + 64u * OV2_NROW;
+    for (uint32_t p0 = (blockIdx.x * 4u + (uint32_t)w) * 64u; p0 < n_pairs; p0 += gridDim.x * 256u) {       // wave-uniform
+        const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0;
+        if (p < n_pairs) {
+            const uint32_t g = 2u * p;
+            if (C.il[R.chunk[g]]) { len1 = (int)R.len[g]; len2 = (int)R.len[g + 1]; uint32_t r; read_loc(T, g, s1, r); q1 = T.lo[s1][4 * (size_t)r + 1]; read_loc(T, g + 1, s2, r); q2 = T.lo[s2][4 * (size_t)r + 1]; }
+        }
+        const bool slow = len1 >= 0 && ((uint32_t)len1 > OV2_CAP || (uint32_t)len2 > OV2_CAP), fast = len1 >= 0 && !slow;
+        const int mx = wave_max(fast ? (len1 > len2 ? len1 : len2) : 0);
+        if (l < 2) s_bad[w][l] = 0;
+        wave_lds_sync();                                        // the previous round's rows are no longer read
+        // ---- pack: task t = (row, 16-base group); rows 0..63 R1, 64..127 RC2; four loads in flight per lane
+        const uint32_t G = ((uint32_t)mx + 15u) >> 4, ntasks = 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 2048, G <= 16
+        for (uint32_t t0 = 0; t0 < ntasks; t0 += 256u) {
+            uint32_t v[4][4]; uint32_t row[4], k[4]; int L[4]; bool on[4];
 #pragma unroll
-    for (int k = 0; k < 2; k++) { const uint32_t i = (uint32_t)l + 64u * k; r.a[k] = i < n1 ? w1[i] : 0u; r.b[k] = i < n2 ? w2[i] : 0u; }
-}
-__global__ void k_overlap(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int8_t* __restrict__ ovb, uint32_t n_pairs) {
-    __shared__ uint32_t s_rows4[4 * (2 * OV_ROW / 4)];
-    __shared__ const uint8_t* s_p1[OV_PAIRS]; __shared__ const uint8_t* s_p2[OV_PAIRS];
-    __shared__ int s_l1[OV_PAIRS], s_l2[OV_PAIRS];             // s_l1 < 0: pair not examined
-    const int shift = D->overlap_shift; const bool enc = (D->flags & H_PE_OVERLAP) != 0;
-    if (!enc) return;                                           // uniform
-    const int l = lane_id(); const int w = wave_id();
-    uint32_t* rows4 = s_rows4 + (size_t)w * (2 * OV_ROW / 4); const uint8_t* rows = (const uint8_t*)rows4;
-    for (uint32_t p0 = blockIdx.x * OV_PAIRS; p0 < n_pairs; p0 += gridDim.x * OV_PAIRS) {
-        __syncthreads();
-        if (threadIdx.x < OV_PAIRS) {
-            const uint32_t p = p0 + threadIdx.x; int l1 = -1, l2 = 0; const uint8_t* q1 = nullptr; const uint8_t* q2 = nullptr;
-            if (p < n_pairs) {
-                const uint32_t g = 2 * p;
-                if (C.il[R.chunk[g]]) { l1 = (int)R.len[g]; l2 = (int)R.len[g + 1]; q1 = line_ptr(T, g, 1); q2 = line_ptr(T, g + 1, 1); }
-            }
-            s_l1[threadIdx.x] = l1; s_l2[threadIdx.x] = l2; s_p1[threadIdx.x] = q1; s_p2[threadIdx.x] = q2;
-        }
-        __syncthreads();
-        const uint32_t k0 = (uint32_t)w * (OV_PAIRS / 4), k1 = k0 + OV_PAIRS / 4;
-        OvRegs nxt;
-        { const int l1 = s_l1[k0], l2 = s_l2[k0]; const bool st = l1 >= 0 && (uint32_t)l1 <= OV_CAP && (uint32_t)l2 <= OV_CAP;
-          ov_fetch(nxt, s_p1[k0], st ? l1 : 0, s_p2[k0], st ? l2 : 0, l); }
-        for (uint32_t k = k0; k < k1; k++) {
-            const int len1 = s_l1[k], len2 = s_l2[k]; const OvRegs cur = nxt;
-            const uint8_t* q1 = s_p1[k]; const uint8_t* q2 = s_p2[k];
-            if (k + 1 < k1) { const int l1 = s_l1[k + 1], l2 = s_l2[k + 1]; const bool st = l1 >= 0 && (uint32_t)l1 <= OV_CAP && (uint32_t)l2 <= OV_CAP;
-                              ov_fetch(nxt, s_p1[k + 1], st ? l1 : 0, s_p2[k + 1], st ? l2 : 0, l); }
-            if (len1 < 0) continue;                              // wave-uniform
-            int ov;
-            if ((uint32_t)len1 <= OV_CAP && (uint32_t)len2 <= OV_CAP) {
-                OvPair P; P.len1 = len1; P.len2 = len2;
-                P.r1 = 8u + (uint32_t)((uintptr_t)q1 & 3u); P.c2 = OV_ROW + 8u + (uint32_t)((uintptr_t)q2 & 3u);
-                wave_lds_sync();                                 // the previous pair's rows are no longer read
-                rows4[2 + l] = cur.a[0]; rows4[OV_ROW / 4 + 2 + l] = comp4(cur.b[0]);
-                if ((len1 > len2 ? len1 : len2) > 252 && l < 18) {   // words 64..81 (wave-uniform test: 3 + 252 bytes fit 64 words)
-                    rows4[2 + 64 + l] = cur.a[1]; rows4[OV_ROW / 4 + 2 + 64 + l] = comp4(cur.b[1]);
+            for (int u = 0; u < 4; u++) {
+                const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)l; row[u] = t < ntasks ? (t * ginv) >> 16 : 0u; k[u] = t - row[u] * G;
+                const int src = (int)(row[u] & 63u); const bool second = row[u] >= 64u;
+                const int a1 = __shfl(len1, src), a2 = __shfl(len2, src); const uint32_t o1 = __shfl(q1, src), o2 = __shfl(q2, src);
+                const int z1 = __shfl(s1, src), z2 = __shfl(s2, src); const bool f = __shfl(fast ? 1 : 0, src) != 0;
+                L[u] = second ? a2 : a1; on[u] = t < ntasks && f && (int)(16u * k[u]) < L[u];
+                v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0;
+                if (on[u]) {
+                    const int z = second ? z2 : z1;        // (RC2's last group starts before the line: those bytes land beyond len2 and are never compared)
+                    const long long at = second ? (long long)o2 + L[u] - 16ll * (long long)k[u] - 16ll : (long long)o1 + 16ll * (long long)k[u];
+                    ld16_guard(T.fq[z], at, (uint64_t)T.n[z], v[u]);
                 }
-                wave_lds_sync();
-                ov = wave_overlap_lds(rows, P);
-            } else ov = wave_overlap(q1, len1, q2, len2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!on[u]) continue;
+                const bool second = row[u] >= 64u; const uint32_t pr = row[u] & 63u;
+                uint32_t cw = 0, nw = 0;
+                if (!second) {
+                    uint32_t bad = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { uint32_t c, nb, b; ov2_pack_r1(v[u][i], c, nb, b); cw |= c << (8 * i); nw |= nb << (4 * i);
+                        if (b) { const int left = L[u] - (int)(16u * k[u]) - 4 * i; if (left < 4) b &= left > 0 ? (1u << (8 * left)) - 1u : 0u; bad |= b; } }
+                    if (bad) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
+                    *(uint32_t*)(c1 + pr * OV2_CROW + 4u * k[u]) = cw; *(uint16_t*)(n1 + pr * OV2_NROW + 2u * k[u]) = (uint16_t)nw;
+                } else {
+                    const uint32_t x[4] = { bswap32(v[u][3]), bswap32(v[u][2]), bswap32(v[u][1]), bswap32(v[u][0]) };
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { uint32_t c, nb; ov2_pack_rc(x[i], c, nb); cw |= c << (8 * i); nw |= nb << (4 * i); }
+                    *(uint32_t*)(c2 + pr * OV2_CROW + 4u * k[u]) = cw; *(uint16_t*)(n2 + pr * OV2_NROW + 2u * k[u]) = (uint16_t)nw;
+                }
+            }
+        }
+        wave_lds_sync();
+        const bool bad = fast && ((s_bad[w][l >> 5] >> (l & 31)) & 1u);
+        const bool go = fast && !bad; const int minlen = len1 < len2 ? len1 : len2;
+        const uint8_t* const r1c = c1 + (uint32_t)l * OV2_CROW; const uint8_t* const r2c = c2 + (uint32_t)l * OV2_CROW;
+        int ov = 0; bool done = !go || minlen < 12;
+        const int omax = wave_max(done ? 0 : minlen);
+        const uint32_t head1 = lds_get4(r1c, 0) & 0xFFFFFFu, head2 = lds_get4(r2c, 0) & 0xFFFFFFu;
+#pragma unroll 1
+        for (int dir = 0; dir < 2; dir++) {                     // 0: R1 tail == RC2 head (+o), 1: RC2 tail == R1 head (-o)
+            const uint8_t* const wc = dir ? r2c : r1c; const int wl = dir ? len2 : len1; const uint32_t head = dir ? head1 : head2;
+            if (!__any(!done)) break;
+            const int wlc = go ? wl : 0;
+            for (int o0 = 12; o0 <= omax; o0 += OV2_BATCH) {
+                // branch-free filter of OV2_BATCH candidates: all their LDS reads are in flight together
+                uint32_t wv[OV2_BATCH], hits = 0;
+#pragma unroll
+                for (int u = 0; u < OV2_BATCH; u++) { const int pp = wlc - (o0 + u); wv[u] = lds_get4(wc, (uint32_t)(pp < 0 ? 0 : pp) >> 2); }
+#pragma unroll
+                for (int u = 0; u < OV2_BATCH; u++) { const int pp = wlc - (o0 + u); hits |= ((bfe_u32(wv[u], 2u * ((uint32_t)pp & 3u), 24u) == head) & (o0 + u <= minlen) ? 1u : 0u) << u; }
+                if (done) hits = 0;
+                if (!__any(hits != 0)) continue;
+                for (int u = 0; u < OV2_BATCH; u++) {
+                    unsigned long long m = __ballot(!done && ((hits >> u) & 1u));
+                    while (m) {                                  // wave-uniform
+                        const int j = __ffsll((long long)m) - 1; m &= m - 1;
+                        const int jl = dir ? __shfl(len2, j) : __shfl(len1, j); const uint32_t o = (uint32_t)(o0 + u);
+                        const uint8_t* ac = (dir ? c2 : c1) + (uint32_t)j * OV2_CROW; const uint8_t* an = (dir ? n2 : n1) + (uint32_t)j * OV2_NROW;
+                        const uint8_t* bc = (dir ? c1 : c2) + (uint32_t)j * OV2_CROW; const uint8_t* bn = (dir ? n1 : n2) + (uint32_t)j * OV2_NROW;
+                        const bool ok = ov2_verify(ac, an, bc, bn, (uint32_t)jl - o, o, l);
+                        if (ok && l == j) { done = true; ov = dir ? -(int)o : (int)o; }
+                    }
+                }
+            }
+        }
+        // reads longer than a row, or an R1 holding a character outside A/C/G/T/N: the byte-wise search, one pair at a time
+        unsigned long long sm = __ballot(slow || bad);
+        while (sm) {
+            const int j = __ffsll((long long)sm) - 1; sm &= sm - 1;
+            const uint8_t* a = T.fq[__shfl(s1, j)] + __shfl(q1, j); const uint8_t* b = T.fq[__shfl(s2, j)] + __shfl(q2, j);
+            const int r = wave_overlap(a, __shfl(len1, j), b, __shfl(len2, j));
+            if (l == j) ov = r;
+        }
+        if (len1 >= 0) {
             if (ov + shift > 127) ov = 0;
             if (ov + shift < -127) ov = 0;
-            if (l == 0) { const uint32_t p = p0 + k; ovb[p] = (int8_t)(ov + shift); R.stored[2 * p + 1] = (uint32_t)(len2 - (ov < 0 ? -ov : ov)); }
+            ovb[p] = (int8_t)(ov + shift); R.stored[2 * (size_t)p + 1] = (uint32_t)(len2 - (ov < 0 ? -ov : ov));
         }
     }
 }
@@ -882,7 +938,7 @@ __global__ void k_chunk_bases(ReadTab R, ChunkTab C, uint32_t n_chunks) {
 // does all byte shuffling (line extraction, reversal, complement, trimming) from LDS, and writes the two output tiles — also
 // contiguous — with aligned 16 B/lane stores.
 #define GT_READS 64
-#define GT_CAP 28672u
+#define GT_CAP 25600u             // (LDS: tile + per-segment counters = 31.3 KB, five blocks per CU)
 struct GatherTile {
     const uint8_t* text;           // LDS copy of the staged spans
     const uint32_t* dst;           // [cnt+1] chunk-relative start of every read in the output buffer
@@ -957,39 +1013,55 @@ __device__ __forceinline__ uint32_t pc_n_seg(uint32_t len) { return ((len + 4095
 __device__ __forceinline__ uint32_t nmap_shift(uint32_t n_bases) { const uint32_t steps = (n_bases + 4095u) / 4096u; uint32_t sh = 0; while ((steps >> sh) > 32u * NMAP_WORDS) sh++; return sh; }
 __device__ __forceinline__ void nmap_mark(uint32_t* m, uint32_t shift, uint32_t pos) { const uint32_t b = (pos >> 12) >> shift; atomicOr(&m[b >> 5], 1u << (b & 31u)); }
 __device__ __forceinline__ bool nmap_test(const uint32_t* m, uint32_t shift, uint32_t step) { const uint32_t b = step >> shift; return (m[b >> 5] >> (b & 31u)) & 1u; }
-// histogram / N counters: group() takes 16 packed bytes (SWAR: no per-byte branches), operator() one byte
+// histogram / N counters: group() takes 16 packed bytes (SWAR: no per-byte branches), operator() one byte.  Besides the chunk's
+// histogram they keep what the position coder needs to start any of its 32768-position segments without a pass of its own: how often
+// each value occurs in the segment (the size of the segment's slot in the stream's scratch area) and where it occurs last (the
+// "previous match" of the segments after it).  A tile holds < 32768 positions, i.e. parts of at most two segments.
 struct QualCount {
-    uint32_t* sh; uint32_t major; uint32_t hot;
-    __device__ __forceinline__ void operator()(uint32_t, uint8_t q) { if (q == major) hot++; else atomicAdd(&sh[q], 1u); }
-    __device__ __forceinline__ void group(uint32_t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    uint32_t* cnt; int* last;            // LDS [2][256]: occurrences / last position of every non-major value in the tile's two segments
+    uint32_t major; uint32_t hot; uint32_t seg0; bool hot_ok;   // hot_ok: the major value has no stream of its own (it has one when it is also the N quality)
+    __device__ __forceinline__ void one(uint32_t p, uint32_t q) { const uint32_t i = (((p / PC_SEG_POS) - seg0) & 1u) * 256u + q; atomicAdd(&cnt[i], 1u); atomicMax(&last[i], (int)p); }
+    __device__ __forceinline__ void operator()(uint32_t p, uint8_t q) { if (hot_ok && q == major) hot++; else one(p, q); }
+    __device__ __forceinline__ void group(uint32_t p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
         const uint32_t pat = major * 0x01010101u;
-        const uint32_t m = eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12);
+        const uint32_t m = hot_ok ? eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12) : 0u;
         hot += (uint32_t)__popc(m);
         uint32_t rest = ~m & 0xFFFFu;                              // the ~8 % that are not the major value
         const unsigned long long lo = (unsigned long long)w0 | ((unsigned long long)w1 << 32), hi = (unsigned long long)w2 | ((unsigned long long)w3 << 32);
-        while (rest) { const int k = __ffs((int)rest) - 1; rest &= rest - 1; const uint32_t q = (uint32_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu); atomicAdd(&sh[q], 1u); }
+        while (rest) { const int k = __ffs((int)rest) - 1; rest &= rest - 1; const uint32_t q = (uint32_t)(((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xFFu); one(p + (uint32_t)k, q); }
     }
 };
 struct NCount {                          // p = chunk-relative position of the byte / of the group's first byte (a group never crosses a 4096 boundary)
-    uint32_t n; uint32_t* nmap; uint32_t shift;
-    __device__ __forceinline__ void operator()(uint32_t p, uint8_t b) { if (b == 'N') { n++; nmap_mark(nmap, shift, p); } }
+    uint32_t n; uint32_t* nmap; uint32_t shift; uint32_t* segm; int* segc;   // segm / segc: the N-position stream's per-segment entries of the chunk
+    __device__ __forceinline__ void operator()(uint32_t p, uint8_t b) { if (b == 'N') { n++; nmap_mark(nmap, shift, p); atomicAdd(&segm[p / PC_SEG_POS], 1u); atomicMax(&segc[p / PC_SEG_POS], (int)p); } }
     __device__ __forceinline__ void group(uint32_t p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
         const uint32_t pat = (uint32_t)'N' * 0x01010101u;
-        const uint32_t k = (uint32_t)__popc(eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12));
-        if (k) { n += k; nmap_mark(nmap, shift, p); }
+        const uint32_t mk = eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12);
+        if (mk) { const uint32_t k = (uint32_t)__popc(mk); n += k; nmap_mark(nmap, shift, p); atomicAdd(&segm[p / PC_SEG_POS], k); atomicMax(&segc[p / PC_SEG_POS], (int)(p + 31u - (uint32_t)__clz((int)mk))); }
     }
 };
+// the tile's per-segment counters -> the chunk's histogram and the coder's per-(stream, segment) tables; the counters are left zeroed
+__device__ __forceinline__ void qual_flush(uint32_t* cnt, int* last, uint32_t seg0, uint32_t c, const ChunkTab& C, const DevHeader* __restrict__ D, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
+    for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) {
+        const uint32_t n = cnt[i]; if (!n) continue;
+        const uint32_t v = i & 255u, seg = seg0 + (i >> 8);
+        atomicAdd(&C.hist[(size_t)c * 256 + v], n);
+        const uint32_t j = D->is_exception[v] ? (uint32_t)EXC_SLOT : (uint32_t)D->stream_of[v];
+        if ((j < NPOS_SLOT || j == EXC_SLOT) && seg < n_seg) { const size_t si = ((size_t)c * MAX_STREAMS + j) * n_seg + seg; atomicAdd(&segm[si], n); if (j != EXC_SLOT) atomicMax(&segc[si], last[i]); }
+        cnt[i] = 0; last[i] = -1;
+    }
+}
 
 template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict__ ovb, const DevHeader* __restrict__ D,
-                         uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat, unsigned long long* dbg, int tune) {
+                         uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, unsigned long long* dbg, int tune) {
     long long tk0 = DBG ? clock64() : 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0; long long a_fit = 0, a_meta = 0, a_stage = 0, a_q = 0, a_s = 0;
     __shared__ uint4 s_text4[GT_CAP / 16 + 6];
     __shared__ uint32_t s_qsrc[GT_READS], s_ssrc[GT_READS], s_len[GT_READS], s_skip[GT_READS], s_keep[GT_READS], s_qdst[GT_READS + 1], s_sdst[GT_READS + 1];
     __shared__ uint8_t s_rc[GT_READS]; __shared__ uint32_t s_nx[GT_READS];
-    __shared__ uint32_t sh[256]; __shared__ uint32_t s_n, s_cnt;
+    __shared__ uint32_t sh[512]; __shared__ int sh_last[512]; __shared__ uint32_t s_n, s_cnt;
     uint8_t* s_text = (uint8_t*)(s_text4 + 1);                            // 16 bytes of slack in front: reversed 16-byte fetches may start before a line
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < 256; i += blockDim.x) sh[i] = 0;
+    for (uint32_t i = tid; i < 512; i += blockDim.x) { sh[i] = 0; sh_last[i] = -1; }
     if (tid == 0) s_n = 0;
     const uint32_t c = blockIdx.y, f = C.first[c], e = C.first[c + 1];
     const bool il = C.il[c] != 0; const bool enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
@@ -998,7 +1070,9 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
     const bool two = T.paired == 1; const uint32_t upr = T.upr;
     uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup
     const uint32_t gs = f + blockIdx.x * per; const uint32_t ge = gs + per < e ? gs + per : e;
-    QualCount qc; qc.sh = sh; qc.major = D->major & 0xFFu; qc.hot = 0; NCount nc; nc.n = 0; nc.nmap = C.nmap + (size_t)c * NMAP_WORDS; nc.shift = nmap_shift(R.pv[e].d - ps0);
+    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.major = D->major & 0xFFu; qc.hot = 0; qc.seg0 = 0; qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
+    NCount nc; nc.n = 0; nc.nmap = C.nmap + (size_t)c * NMAP_WORDS; nc.shift = nmap_shift(R.pv[e].d - ps0);
+    nc.segm = segm + ((size_t)c * MAX_STREAMS + NPOS_SLOT) * n_seg; nc.segc = segc + ((size_t)c * MAX_STREAMS + NPOS_SLOT) * n_seg;
     uint32_t cur = gs;
     while (cur < ge) {                                                   // block-uniform
         if (DBG) tk0 = clock64();
@@ -1039,7 +1113,12 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
                 const bool rc = il && ((g - f) & 1u); int ov = 0; if (rc && enc) ov = (int)ovb[g >> 1] - shift;
                 const uint32_t skip = ov > 0 ? (uint32_t)ov : 0u, keep = len - (uint32_t)(ov < 0 ? -ov : ov);
                 uint8_t* qo = qd + (R.pq[g] - pq0); uint8_t* so = sd + (R.pv[g].d - ps0);
-                for (uint32_t i = tid; i < len; i += blockDim.x) { const uint8_t q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = q; qc(0u, q); }
+                // (its positions may span many coder segments: non-major bytes go straight to the global tables)
+                for (uint32_t i = tid; i < len; i += blockDim.x) { const uint8_t q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = q;
+                    if (qc.hot_ok && q == qc.major) qc.hot++;
+                    else { const uint32_t pp = R.pq[g] - pq0 + i, sg = pp / PC_SEG_POS; atomicAdd(&C.hist[(size_t)c * 256 + q], 1u);
+                           const uint32_t j = D->is_exception[q] ? (uint32_t)EXC_SLOT : (uint32_t)D->stream_of[q];
+                           if ((j < NPOS_SLOT || j == EXC_SLOT) && sg < n_seg) { const size_t si = ((size_t)c * MAX_STREAMS + j) * n_seg + sg; atomicAdd(&segm[si], 1u); if (j != EXC_SLOT) atomicMax(&segc[si], (int)pp); } } }
                 for (uint32_t i = tid; i < keep; i += blockDim.x) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b; nc(R.pv[g].d - ps0 + i, b); }
             }
             cur += upr; __syncthreads(); continue;
@@ -1073,19 +1152,19 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
         __syncthreads();
         if (DBG) { tk3 = clock64(); a_stage += tk3 - tk2; }
         GatherTile t; t.text = s_text; t.len = s_len; t.skip = s_skip; t.keep = s_keep; t.rc = s_rc; t.cnt = cnt;
-        t.dst = s_qdst; t.src = s_qsrc;
+        t.dst = s_qdst; t.src = s_qsrc; qc.seg0 = s_qdst[0] / PC_SEG_POS;
         tile_emit<false>(t, qd + s_qdst[0], s_qdst[0], s_qdst[cnt] - s_qdst[0], qc, DBG ? tune : 0);
         if (DBG) { tk4 = clock64(); a_q += tk4 - tk3; }
         t.dst = s_sdst; t.src = s_ssrc;
         tile_emit<true>(t, sd + s_sdst[0], s_sdst[0], s_sdst[cnt] - s_sdst[0], nc, DBG ? tune : 0);
         __syncthreads();
+        qual_flush(sh, sh_last, qc.seg0, c, C, D, segm, segc, n_seg);       // (the next tile's counting starts three barriers from here)
         if (DBG) { tk5 = clock64(); a_s += tk5 - tk4; }
         cur += cnt;
     }
     const uint32_t hot = wave_sum(qc.hot), nn = wave_sum(nc.n);
-    if (lane_id() == 0) { if (hot) atomicAdd(&sh[qc.major], hot); if (nn) atomicAdd(&s_n, nn); }
+    if (lane_id() == 0) { if (hot) atomicAdd(&C.hist[(size_t)c * 256 + qc.major], hot); if (nn) atomicAdd(&s_n, nn); }
     __syncthreads();
-    for (uint32_t i = tid; i < 256; i += blockDim.x) if (sh[i]) atomicAdd(&C.hist[(size_t)c * 256 + i], sh[i]);
     if (tid == 0 && s_n) atomicAdd(&C.ncount[c], s_n);
     if (DBG && tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a_fit); atomicAdd(&dbg[1], (unsigned long long)a_meta); atomicAdd(&dbg[2], (unsigned long long)a_stage); atomicAdd(&dbg[3], (unsigned long long)a_q); atomicAdd(&dbg[4], (unsigned long long)a_s); atomicAdd(&dbg[5], 1ull); }
 }
@@ -1213,23 +1292,23 @@ template <class Sink> __device__ __forceinline__ void pc_gen_tokens(uint64_t m, 
 }
 // A (chunk, stream) is cut into segments of PC_SEG_STEPS steps (32768 positions) coded by independent waves: a wave's steps are
 // a dependent chain at memory latency, so the kernel's run time is that of its longest chain (256 steps with one wave per stream;
-// 32-step segments measured 1.15 ms for the three passes, 8-step segments 0.93 ms, 4-step segments 0.96 ms).  A segment needs the state at its first
-// position — the last match and the last non-match before it — taken from a light summary pass over all segments, and its byte
-// offset inside the stream, which needs the byte counts of the earlier segments: summary, count, emit (three launches).
+// 32-step segments measured 1.15 ms, 8-step segments 0.93 ms, 4-step segments 0.96 ms).  What a segment needs to start:
+//   * the last match before it        k_gather left every segment's last match in segc: the nearest earlier segment that has one
+//   * the last non-match before it    a short look-back over the bytes in front of the segment (almost always the byte right there)
+//   * where its bytes go              its own slot of the stream's scratch area, sized from the match counts k_gather left in segm
+// so ONE launch codes everything (the summary pass that used to read the qualities a first time is gone); k_assemble joins the slots.
 // One wave codes up to PC_G streams of the SAME buffer over the same segment: the 4096 raw bytes of a step are loaded once and turned
-// into one match mask per stream (the streams of a chunk used to re-read the chunk's qualities once each, in each of the three passes).
+// into one match mask per stream.
 #define PC_G 4
 struct PcStream {
     bool on; int mode; uint32_t q;          // PC_MATCH value q, or PC_EXCEPT
     uint64_t m_cur, m_next;                 // masks of the current and the next step (lane's 64 positions)
     int prev_carry, zero_carry;             // last match / last non-match before the current step
     uint32_t outpos; uint8_t* out; uint32_t room;
-    int last1, last0; uint32_t cnt;         // summary pass: last match / non-match, number of matches
-    uint64_t* mk;                           // [step][lane] match masks of the stream: written by the summary pass, read by the coding pass (nullptr: recomputed)
 };
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
-// with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  EMIT writes the bytes at S[t].out[0..).
-template <bool EMIT, int MODE, int G, bool MK> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
+// with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  The bytes go to S[t].out[0..).
+template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
                                                                            PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
@@ -1240,19 +1319,31 @@ template <bool EMIT, int MODE, int G, bool MK> __device__ __forceinline__ void w
     auto load = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (nmap && !nmap_test(nmap, nshift, step_)) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; } return pc_load_raw(B, len, p_); };
     const uint32_t nst = (len + 4095u) / 4096u;
     auto loadc = [&](uint32_t step_, uint32_t p_) -> Raw64 { return load(step_ < nst ? step_ : nst - 1u, step_ < nst ? p_ : len); };
-    // MK: the summary pass left every step's masks in S[t].mk - the pipeline carries masks (two steps ahead) instead of raw bytes
-    auto ldm = [&](int t, uint32_t step_) -> uint64_t { return step_ < nst ? S[t].mk[(size_t)step_ * 64u + (uint32_t)l] : 0ull; };
-    Raw64 raw_n; uint64_t m_nn[G];
-    if (MK) {
+    Raw64 raw_n = loadc(step0 + 1, q0 + 4096u);
+    Raw64 r0 = loadc(step0, q0);
+    if (MODE == PC_MATCH && step0 > 0) {
+        // the last non-match in front of the segment: walk back step by step until every stream has met one (the first step back does it
+        // unless a stream's value fills 4096 positions in a row)
+        bool need[G]; bool any = false;
 #pragma unroll
-        for (int t = 0; t < G; t++) { m_nn[t] = 0; if (S[t].on) { S[t].m_cur = ldm(t, step0); S[t].m_next = ldm(t, step0 + 1); m_nn[t] = ldm(t, step0 + 2); S[t].outpos = 0; } }
-    } else {
-        raw_n = loadc(step0 + 1, q0 + 4096u);
-        { const Raw64 r0 = loadc(step0, q0);
+        for (int t = 0; t < G; t++) { need[t] = S[t].on; any = any || need[t]; }
+        for (uint32_t sb = step0; any && sb > 0; ) {                        // wave-uniform
+            sb--; const uint32_t pb = sb * 4096u + 64u * (uint32_t)l;
+            const Raw64 rb = load(sb, pb);
+            any = false;
 #pragma unroll
-          for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D); S[t].outpos = 0; } }
-        raw_n = loadc(step0 + 2, q0 + 8192u);
+            for (int t = 0; t < G; t++) {
+                if (!need[t]) continue;
+                const uint64_t z = ~pc_mask_of(rb, len, pb, MODE, S[t].q, D);
+                const unsigned long long h0 = __ballot(z != 0);
+                if (h0) { const int v = z ? (int)pb + 63 - __clzll((long long)z) : -1; S[t].zero_carry = __shfl(v, 63 - __clzll((long long)h0)); need[t] = false; }
+                else any = true;
+            }
+        }
     }
+#pragma unroll
+    for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D); S[t].outpos = 0; }
+    raw_n = loadc(step0 + 2, q0 + 8192u);
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
 #pragma unroll
@@ -1282,7 +1373,7 @@ template <bool EMIT, int MODE, int G, bool MK> __device__ __forceinline__ void w
             const uint32_t incl = wave_incl_sum(bytes);
             uint32_t o = s.outpos + incl - bytes;
             const uint32_t tot = __shfl(incl, 63);
-            if (EMIT && s.outpos + tot <= s.room) {
+            if (s.outpos + tot <= s.room) {
                 uint8_t* out = s.out;
                 if (MODE == PC_EXCEPT) {
                     uint64_t mm = m;
@@ -1297,94 +1388,48 @@ template <bool EMIT, int MODE, int G, bool MK> __device__ __forceinline__ void w
             if (pl > s.prev_carry) s.prev_carry = pl;
             if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > s.zero_carry) s.zero_carry = zl; }
         }
-        if (MK) {
 #pragma unroll
-            for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = m_nn[t]; m_nn[t] = ldm(t, step + 3); }
-        } else {
-#pragma unroll
-            for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D); }
-            raw_n = loadc(step + 3, p0 + 12288u);
-        }
+        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D); }
+        raw_n = loadc(step + 3, p0 + 12288u);
     }
 }
-// last match / last non-match inside steps [step0, step1) (or -1) of every active stream: the summary pass, loads pipelined like the coder's
-template <int MODE, int G> __device__ __forceinline__ void wave_pos_summary_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D, PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift) {
-    const int l = lane_id();
-    const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l; const uint32_t nst = (len + 4095u) / 4096u;
-    auto loadc = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (step_ >= nst || (nmap && !nmap_test(nmap, nshift, step_))) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; } return pc_load_raw(B, len, p_); };
-    Raw64 raw_c = loadc(step0, q0), raw_n = loadc(step0 + 1, q0 + 4096u);
-#pragma unroll
-    for (int t = 0; t < G; t++) { S[t].last1 = -1; S[t].last0 = -1; S[t].cnt = 0; }
-    for (uint32_t step = step0; step < step1; step++) {
-        const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
-        const Raw64 raw_nn = loadc(step + 2, p0 + 8192u);
-#pragma unroll
-        for (int t = 0; t < G; t++) {
-            if (!S[t].on) continue;
-            const uint64_t m = pc_mask_of(raw_c, len, p0, MODE, S[t].q, D);
-            if (S[t].mk) S[t].mk[(size_t)step * 64u + (uint32_t)l] = m;   // the coding pass takes the mask from here: it neither re-reads the 4096 bytes nor redoes ~165 SWAR instructions per stream
-            S[t].cnt += (uint32_t)__popcll(m);                                 // (per lane; summed over the wave by the caller)
-            const unsigned long long h1 = __ballot(m != 0), h0 = __ballot(~m != 0);
-            if (h1) { const int v = m ? (int)p0 + 63 - __clzll((long long)m) : -1; S[t].last1 = __shfl(v, 63 - __clzll((long long)h1)); }
-            if (h0) { const int v = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1; S[t].last0 = __shfl(v, 63 - __clzll((long long)h0)); }
-        }
-        raw_c = raw_n; raw_n = raw_nn;
-    }
-}
-// 1-D grid of ceil(n_chunks / 8) * 8 * (n_qgroups + 2) * n_seg workgroups, one wave each; two passes over the same grid:
-//   PASS 0  summary  segc[2*si+{0,1}] = last match / last non-match of the segment, segm[si] = its number of matches
-//   PASS 2  code     entry state = nearest earlier segment that has one; the bytes go to the segment's own slot of the stream's
-//                    scratch area (slot sizes from the match counts, pc_seg_cap), segb[si] = bytes written.  k_assemble joins the slots.
-// Group g < n_qgroups holds the quality-value streams 4g .. 4g+3, group n_qgroups the exception stream, group n_qgroups + 1 the
-// N-position stream (it reads the base buffer).  si = (c * MAX_STREAMS + j) * n_seg + seg.  Streams whose value does not occur in
-// the chunk (histogram) are skipped outright.
-template <int PASS, int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
-                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t* __restrict__ segm, uint32_t n_seg,
-                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st, uint64_t* __restrict__ maskbuf = nullptr, uint32_t nmk = 0) {
+// 1-D grid of ceil(n_chunks / 8) * 8 * (n_qgroups + 2) * n_seg workgroups, one wave each.  Group g < n_qgroups holds the quality-value
+// streams 4g .. 4g+3, group n_qgroups the exception stream, group n_qgroups + 1 the N-position stream (it reads the base buffer).
+// si = (c * MAX_STREAMS + j) * n_seg + seg; segm[si] = matches in the segment, segc[si] = its last match (k_gather), segb[si] = bytes
+// written here.  Streams whose value does not occur in the chunk (histogram) are skipped outright.
+template <int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg,
+                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st) {
     const uint32_t nshift = nmap ? nmap_shift(len) : 0u;
     const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
     const uint32_t step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
+    if (step0 >= nsteps) return;
     PcStream S[G]; size_t kk[G]; bool any = false;
 #pragma unroll
     for (int t = 0; t < G; t++) {
         const uint32_t j = j0 + (uint32_t)t;
-        S[t].on = false; kk[t] = 0; S[t].mk = nullptr;
+        S[t].on = false; kk[t] = 0;
         if (j >= jend) continue;
         const size_t k = (size_t)c * MAX_STREAMS + j; kk[t] = k;
         const uint32_t cap = C.scap[k];
         if (cap == 0) continue;                                            // stream not present
-        const uint32_t occurrences = j < NPOS_SLOT ? C.hist[(size_t)c * 256 + D->normal[j]] : (j == NPOS_SLOT ? C.ncount[c] : (cap - 16u - PC_SEG_PAD * pc_n_seg(len)) / 5u);
-        if (occurrences == 0) continue;                                    // nothing to code: the segment byte counts stay 0
-        const size_t si = k * n_seg + seg;
-        if (step0 >= nsteps) { if (PASS == 0 && lane_id() == 0) { segm[si] = 0; segc[2 * si] = -1; segc[2 * si + 1] = -1; } continue; }
+        const size_t s0i = k * n_seg;
+        if (segm[s0i + seg] == 0) continue;                                // nothing to code in this segment: its byte count stays 0
         S[t].on = true; any = true;
         S[t].mode = MODE; S[t].q = j < NPOS_SLOT ? D->normal[j] : (uint32_t)'N';
-        S[t].prev_carry = -1; S[t].zero_carry = -1; S[t].out = nullptr; S[t].room = 0; S[t].outpos = 0;
-        S[t].mk = (maskbuf && j < nmk) ? maskbuf + ((size_t)c * nmk + j) * ((size_t)n_seg * PC_SEG_STEPS * 64u) : nullptr;
-    }
-    if (!any) return;                                                      // wave-uniform
-    if (PASS == 0) {
-        wave_pos_summary_group<MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
-#pragma unroll
-        for (int t = 0; t < G; t++) if (S[t].on) { const uint32_t cnt = wave_sum(S[t].cnt); if (lane_id() == 0) { const size_t si = kk[t] * n_seg + seg; segc[2 * si] = S[t].last1; segc[2 * si + 1] = S[t].last0; segm[si] = cnt; } }
-        return;
-    }
-#pragma unroll
-    for (int t = 0; t < G; t++) {
-        if (!S[t].on) continue;
-        const size_t s0i = kk[t] * n_seg;                                   // entry state: nearest earlier segment that saw a match / a non-match
-        int prev = -1, zero = -1;
-        for (int s = (int)seg - 1; s >= 0 && prev < 0; s--) prev = segc[2 * (s0i + (uint32_t)s)];
-        for (int s = (int)seg - 1; s >= 0 && zero < 0; s--) zero = segc[2 * (s0i + (uint32_t)s) + 1];
-        S[t].prev_carry = prev; S[t].zero_carry = zero;
+        S[t].outpos = 0;
+        // entry state: the nearest earlier segment that saw a match; the last non-match comes from the look-back (-1 for segment 0)
+        int prev = -1;
+        for (int s = (int)seg - 1; s >= 0 && prev < 0; s--) prev = segc[s0i + (uint32_t)s];
+        S[t].prev_carry = prev; S[t].zero_carry = -1;
         // the segment's slot inside the stream's scratch area: after the slots of the earlier segments (capacities from their match counts)
         uint32_t off = 0;
         for (uint32_t s = 0; s < seg; s++) off += pc_seg_cap(MODE == PC_EXCEPT, segm[s0i + s], PC_SEG_POS);
         const uint32_t own = pc_seg_cap(MODE == PC_EXCEPT, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
-        S[t].out = scratch + cbase[c] + C.soff[kk[t]] + off; S[t].room = off + own <= C.scap[kk[t]] ? own : 0u;
+        S[t].out = scratch + cbase[c] + C.soff[k] + off; S[t].room = off + own <= cap ? own : 0u;
     }
-    if (maskbuf && MODE == PC_MATCH && j0 < nmk) wave_pos_encode_group<true, MODE, G, true>(B, len, D, S, step0, step1, nmap, nshift);   // (a group's streams all have masks or none)
-    else wave_pos_encode_group<true, MODE, G, false>(B, len, D, S, step0, step1, nmap, nshift);
+    if (!any) return;                                                      // wave-uniform
+    wave_pos_encode_group<MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
 #pragma unroll
     for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) {
         segb[kk[t] * n_seg + seg] = S[t].outpos;
@@ -1400,18 +1445,18 @@ __global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint3
         C.ssize[k] = tot;
     }
 }
-template <int PASS> __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
-                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, int* __restrict__ segc, uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
-                            uint32_t n_qgroups, DevStatus* st, uint64_t* __restrict__ maskbuf) {
+__global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
+                            uint32_t n_qgroups, DevStatus* st) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
     // (group, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's data stays in ONE private L2.
     const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = (n_qgroups + 2) * n_seg;
     const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = rest % (n_qgroups + 2), seg = rest / (n_qgroups + 2);
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
-    if (grp < n_qgroups) pc_run<PASS, PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st, maskbuf, nn);
-    else if (grp == n_qgroups) pc_run<PASS, PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st);
-    else pc_run<PASS, PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
+    if (grp < n_qgroups) pc_run<PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
+    else if (grp == n_qgroups) pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st);
+    else pc_run<PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
