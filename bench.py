@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py — raw-FASTQ MB/s of the RFQ hot path on MI355X (BASELINE.json metric).
+"""bench.py — raw-FASTQ MB/s of the RFQ hot path on MI355X (BASELINE.json metric: encode + decode, bit-exact .rfq vs the reference).
 
-A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-encode FASTQ -> .rfq (and, once the decode kernels are in, decode .rfq -> FASTQ of the same batch).
-Workload at N=1: BASELINE.json configs[1] — synthetic NovaSeq SE150, 1 GB of FASTQ (2.8 M reads, fqgen profile 0,
-seed 2), default chunk size (-k 1000).  N>1: every rank owns one such batch (chunks are independent once the header
-exists; no collective on the data path) -> weak scaling; value = all ranks' FASTQ bytes / max-over-ranks time.
+A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM: FASTQ -> .rfq
+(rfq_encode_batch) and .rfq -> FASTQ (rfq_decode_batch) of the same batch, both results left in HBM.
+
+N = 1 (the driver's headline run): BASELINE.json configs[2] — synthetic NovaSeq PE150, two files of 4.0 GB (`-i/-I`, fqgen profile 1,
+11.2 M pairs, seed 3, -k 1000), one batch.  The .rfq's md5 is checked against the reference's own output (tests/golden/big.json,
+made by tests/golden/make_golden_big.py with the compiled reference), the decoded mates against the inputs, inside the run.
+Secondary lines (same JSON object, "secondary"): configs[1] (SE150 1 GB, md5 vs the reference golden) and the configs[4] shape
+(BGI-style PE100, 40 quality values).
+
+N > 1: ONE configs[3]-shaped PE150 input of N x (2 x 8 GB) farmed chunk-parallel: see run_multi().
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -25,29 +30,207 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
+# stage (HIP-event pair inside librfq_hip) -> the kernels it brackets (names as rocprofv3 reports them)
+STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
+                 "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
+                 "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder", "k_pos_sizes"],
+                 "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
+                 "dec:walk": ["k_dec_table", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
+                 "dec:streams": ["k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_coords", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_pos_index", "k_dec_except"],
+                 "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit"]}
 
-def cpu_baseline(fq1: bytes, reads: int):
-    """Reference repaq (oracle/_ref/repaq, single thread, -O3 as its Makefile builds it) on the same workload, on this
-    box's host cores; falls back to the plain-C port (oracle/liboracle.so) when the reference binary did not travel."""
+WORKLOADS = {
+    # key: (label, fqgen profile, units (reads or pairs), seed, extra gen kwargs, paired)
+    "cfg2": ("configs[2]: synthetic NovaSeq PE150 two files (-i/-I), 2 x %.2f GB FASTQ (fqgen profile 1, %d pairs, seed %d, N 20 ppm), -k %d, encode + decode", 1, 11_200_000, 3, {}),
+    "cfg1": ("configs[1]: synthetic NovaSeq SE150 %.2f GB FASTQ (fqgen profile 0, %d reads, seed %d, N 20 ppm), -k %d, encode + decode", 0, 2_800_000, 2, {}),
+    "cfg4": ("configs[4] shape: synthetic BGI-style PE100 two files, long names, 40 quality values, N runs, 2 x %.2f GB FASTQ (fqgen profile 3, %d pairs, seed %d), -k %d, encode + decode", 3, 1_400_000, 6, {"nppm": 0, "n_quals": 40}),
+}
+
+
+def offset_of_record(arr, rec):
+    """Byte offset of record `rec` in a '\\n'-terminated FASTQ held in a numpy array (4 lines per record)."""
+    import numpy as np
+    want = 4 * rec
+    if want == 0:
+        return 0
+    pos, seen, slab = 0, 0, 1 << 26
+    while pos < arr.size:
+        nl = np.flatnonzero(arr[pos:pos + slab] == 10)
+        if seen + nl.size >= want:
+            return pos + int(nl[want - seen - 1]) + 1
+        seen += nl.size; pos += slab
+    return int(arr.size)
+
+
+def cpu_baseline(a1, a2, paired, units, sample_units):
+    """Reference repaq (oracle/_ref/repaq: the reference's own sources compiled by oracle/Makefile, single thread, -O3 as its Makefile
+    builds it) on a BOUNDED SAMPLE of the same workload - its first `sample_units` reads / pairs - on this box's host cores; falls back
+    to the plain-C port (oracle/liboracle.so) when the reference binary did not travel."""
     import _oracle as O
-    cores = 1
-    mb = len(fq1) / 1e6
+    su = min(units, sample_units)
+    c1 = offset_of_record(a1, su); c2 = offset_of_record(a2, su) if paired else 0
+    mb = (c1 + c2) / 1e6
+    what = "first %d %s of the workload (%.0f MB of FASTQ)" % (su, "pairs" if paired else "reads", mb)
     if O.have_ref():
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            p = os.path.join(d, "in.fq"); o = os.path.join(d, "out.rfq"); q = os.path.join(d, "back.fq")
-            with open(p, "wb") as f:
-                f.write(fq1)
-            t0 = time.perf_counter(); subprocess.check_call([O.REF_BIN, "-c", "-i", p, "-o", o]); t1 = time.perf_counter()
-            subprocess.check_call([O.REF_BIN, "-d", "-i", o, "-o", q]); t2 = time.perf_counter()
-        enc, dec = mb / (t1 - t0), mb / (t2 - t1)
-        return {"value": round(mb * 2 / (t2 - t0), 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-                "sample": "whole workload: %d reads / %.0f MB, repaq -c then -d, files in /tmp" % (reads, mb),
-                "encode_MBps": round(enc, 1), "decode_MBps": round(dec, 1), "host_cpus": os.cpu_count()}
-    t0 = time.perf_counter(); rfq = O.encode_file(fq1, b"", O.SE, 1_000_000); t1 = time.perf_counter()
-    O.decode_file(rfq, False); t2 = time.perf_counter()
-    return {"value": round(mb * 2 / (t2 - t0), 1), "unit": "MB/s", "cores": cores, "kind": "port",
-            "sample": "whole workload: %d reads / %.0f MB, in-memory oracle encode then decode" % (reads, mb),
+            p1, p2, o, q1, q2 = (os.path.join(d, n) for n in ("r1.fq", "r2.fq", "o.rfq", "b1.fq", "b2.fq"))
+            a1[:c1].tofile(p1)
+            if paired:
+                a2[:c2].tofile(p2)
+            enc = [O.REF_BIN, "-c", "-i", p1, "-o", o] + (["-I", p2] if paired else [])
+            dec = [O.REF_BIN, "-d", "-i", o, "-o", q1] + (["-O", q2] if paired else [])
+            t0 = time.perf_counter(); subprocess.check_call(enc); t1 = time.perf_counter()
+            subprocess.check_call(dec); t2 = time.perf_counter()
+        return {"value": round(mb * 2 / (t2 - t0), 1), "unit": "MB/s", "cores": 1, "kind": "reference",
+                "sample": what + ": repaq -c then -d, one thread, files in /tmp",
+                "encode_MBps": round(mb / (t1 - t0), 1), "decode_MBps": round(mb / (t2 - t1), 1), "host_cpus": os.cpu_count()}
+    f1 = a1[:c1].tobytes(); f2 = a2[:c2].tobytes() if paired else b""
+    t0 = time.perf_counter(); rfq = O.encode_file(f1, f2, O.PE_TWO_FILES if paired else O.SE, 1_000_000); t1 = time.perf_counter()
+    O.decode_file(rfq, bool(paired)); t2 = time.perf_counter()
+    return {"value": round(mb * 2 / (t2 - t0), 1), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": what + ": in-memory oracle encode then decode, one thread",
             "encode_MBps": round(mb / (t1 - t0), 1), "decode_MBps": round(mb / (t2 - t1), 1), "host_cpus": os.cpu_count()}
+
+
+def golden_md5(key, units, seed, k):
+    """The reference's .rfq md5 for this exact input, if a golden was made for it (tests/golden/*.json), else None."""
+    try:
+        if key == "cfg2":
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "big.json"))).get("cfg2")
+            if g and g["pairs"] == units and g["seed"] == seed and k == g["k"]:
+                return g["rfq_md5"]
+        if key == "cfg1":
+            for g in json.load(open(os.path.join(ROOT, "tests", "golden", "generated.json"))):
+                if g["profile"] == 0 and g["reads"] == units and g["seed"] == seed and g["nppm"] == 20 and g["k"] == k and not g["nonl"]:
+                    return g["rfq_md5"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+class Workload:
+    """One synthetic input resident in HBM + the encode/decode step over it."""
+
+    def __init__(self, codec, dev, key, units, seed, chunk_kb, decode=True):
+        import torch
+        import _oracle as O
+        from repaq_amd import SE, PE_TWO_FILES
+        label, prof, dunits, dseed, kw = WORKLOADS[key]
+        self.key, self.units, self.seed, self.k = key, units or dunits, (dseed if seed is None else seed), chunk_kb
+        self.paired = prof in (1, 3)
+        self.a1, self.a2 = O.gen_np(prof, self.units, seed=self.seed, **kw)
+        self.n1, self.n2 = int(self.a1.size), int(self.a2.size) if self.paired else 0
+        self.n = self.n1 + self.n2
+        self.label = label % ((self.n / (2e9 if self.paired else 1e9)), self.units, self.seed, chunk_kb)
+        self.t1 = torch.from_numpy(self.a1).to(dev); self.t2 = torch.from_numpy(self.a2).to(dev) if self.paired else None
+        self.o1 = torch.empty(self.n1 + 64, dtype=torch.uint8, device=dev); self.o2 = torch.empty(self.n2 + 64, dtype=torch.uint8, device=dev) if self.paired else None
+        self.codec, self.mode, self.cb, self.do_decode = codec, (PE_TWO_FILES if self.paired else SE), max(100, chunk_kb) * 1000, decode
+        self.stage = {}; self.enc_s = 0.0; self.dec_s = 0.0; self.rfq_len = 0; self.chunks = 0; self.r = None
+
+    def step(self, collect):
+        c = self.codec
+        c.clearHeader()
+        t0 = time.perf_counter()
+        r = c.encode(self.t1.data_ptr(), self.n1, self.t2.data_ptr() if self.paired else None, self.n2, self.mode, self.cb)
+        t1 = time.perf_counter()
+        if collect:
+            for name, ms in c.timings():
+                self.stage[name] = self.stage.get(name, 0.0) + ms
+        self.r, self.rfq_len, self.chunks = r, r.rfq_len, r.n_chunks
+        t2 = t1
+        if self.do_decode:
+            # the host that has just encoded the image holds its chunk offsets and passes them on (rfq_decode_args.h_chunk_off): the
+            # .rfq format has no index, and walking the chain is a dependent load per chunk; every extent is still verified on the device
+            d = c.decode(r.d_rfq, r.rfq_len, split_pe=self.paired, d_out1=self.o1.data_ptr(), cap1=self.n1 + 64,
+                         d_out2=self.o2.data_ptr() if self.paired else None, cap2=(self.n2 + 64) if self.paired else 0,
+                         chunk_off=r.h_chunk_off, n_chunks=r.n_chunks)
+            t2 = time.perf_counter()
+            self.d = d
+            if collect:
+                for name, ms in c.timings():
+                    self.stage["dec:" + name] = self.stage.get("dec:" + name, 0.0) + ms
+        if collect:
+            self.enc_s += t1 - t0; self.dec_s += t2 - t1
+        return r
+
+    def check(self):
+        """Parity of what is being measured: .rfq md5 against the reference's golden (or the oracle on small inputs), decode == input."""
+        import torch
+        import _oracle as O
+        r = self.step(False)
+        got = self.codec.dev_get(r.d_rfq, r.rfq_len)
+        md5 = hashlib.md5(got).hexdigest()
+        gold = golden_md5(self.key, self.units, self.seed, self.k)
+        if gold:
+            assert md5 == gold, "GPU .rfq md5 %s != reference golden %s" % (md5, gold)
+            parity = "rfq md5 == reference golden (%s)" % md5
+        elif self.n <= 300_000_000:
+            want = O.encode_file(self.a1.tobytes(), self.a2.tobytes() if self.paired else b"", self.mode, self.cb)
+            assert got == want, "GPU .rfq differs from the oracle"
+            parity = "rfq bytes == oracle (%s)" % md5
+        else:
+            # no golden at this size: the leading chunks against the oracle's encoding of a file prefix (the cut rule and every chunk
+            # image but the prefix's tail chunk are the same for the prefix and the whole file: chunks are independent, SURVEY.md §8(e))
+            u = min(self.units, 200_000)
+            c1 = offset_of_record(self.a1, u); c2 = offset_of_record(self.a2, u) if self.paired else 0
+            want = O.encode_file(self.a1[:c1].tobytes(), self.a2[:c2].tobytes() if self.paired else b"", self.mode, self.cb)
+            offs = O.chunk_table(want); cut = offs[-2] if len(offs) > 2 else 0
+            assert cut > 0 and got[:cut] == want[:cut], "GPU .rfq differs from the oracle in the leading chunks"
+            parity = "leading %d chunks == oracle, rfq md5 %s (no reference golden at this size)" % (len(offs) - 2, md5)
+        if self.do_decode:
+            assert self.d.n1 == self.n1 and torch.equal(self.o1[:self.n1], self.t1), "decoded R1 differs from the input FASTQ"
+            if self.paired:
+                assert self.d.n2 == self.n2 and torch.equal(self.o2[:self.n2], self.t2), "decoded R2 differs from the input FASTQ"
+            parity += "; decode == input (both mates)" if self.paired else "; decode == input"
+        return parity
+
+    def run(self, steps, warmup, sync, barrier):
+        for _ in range(warmup):
+            self.step(False)
+        barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(True)
+        sync(); barrier()
+        return time.perf_counter() - t0
+
+    def summary(self, steps):
+        stage = {k: v / steps for k, v in self.stage.items()}
+        enc_ms = sum(v for k, v in stage.items() if not k.startswith("dec:")); dec_ms = sum(v for k, v in stage.items() if k.startswith("dec:"))
+        return stage, enc_ms, dec_ms
+
+
+def roofline_of(w, stage, enc_ms, dec_ms, traffic_key):
+    """The dominant kernel (longest HIP-event stage of either direction) against the HBM roofline, on ALGORITHMIC bytes (SURVEY.md
+    §8(d): B_fastq + B_rfq per direction of a batch)."""
+    if not stage:
+        return None
+    dom = max(stage, key=stage.get)
+    alg = float(w.n + w.rfq_len)
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(pj):
+        pmc = json.load(open(pj)).get(traffic_key)
+        if pmc and pmc.get("units") == w.units:
+            ks = [k for k in STAGE_KERNELS.get(dom, []) if k in pmc["kernels"]]
+            traffic = int(sum(pmc["kernels"][k]["fetch_bytes"] + pmc["kernels"][k]["write_bytes"] for k in ks)) if ks else None
+    ach = alg / (stage[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS.get(dom, [dom])), "stage": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(stage[dom], 4),
+            "note": "achieved = one direction's algorithmic bytes (B_fastq + B_rfq) / the dominant kernel's HIP-event time: an upper bound for that kernel; "
+                    "whole_*_frac divide the same bytes by the whole direction's device time; traffic = that kernel's HBM bytes per launch from the committed "
+                    "rocprofv3 PMC passes of this workload (profiles/r02_pmc_traffic.json), null if none was collected at this size",
+            "whole_encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if enc_ms else None,
+            "whole_decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}
+
+
+def line_of(w, steps, dt, total_bytes, parity):
+    stage, enc_ms, dec_ms = w.summary(steps)
+    passes = 2 if w.do_decode else 1
+    return {"workload": w.label, "value_MBps": round(total_bytes * passes * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "chunks": w.chunks, "rfq_over_fastq": round(w.rfq_len / w.n, 4),
+            "encode_MBps": round(w.n * steps / w.enc_s / 1e6, 1) if w.enc_s else None, "decode_MBps": round(w.n * steps / w.dec_s / 1e6, 1) if w.dec_s else None,
+            "parity": parity, "stage_ms": {k: round(v, 3) for k, v in stage.items()}}, stage, enc_ms, dec_ms
 
 
 def main():
@@ -55,162 +238,68 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=2_800_000, help="reads per GPU (2.8 M x 357 B = 1 GB of FASTQ)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2", help="N=1 headline workload (default: BASELINE.json configs[2])")
+    ap.add_argument("--units", type=int, default=0, help="reads (SE) / pairs (PE) of the headline workload; 0 = the config's own size")
+    ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--chunk-kb", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads / pairs of the workload the CPU baseline is timed on")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] secondary lines")
     ap.add_argument("--encode-only", action="store_true")
-    ap.add_argument("--pe", action="store_true", help="profiling aid: PE150 two-file workload (configs[2] shape, reads/2 pairs) instead of the SE150 headline workload")
-    ap.add_argument("--bgi", action="store_true", help="profiling aid: BGI-style PE100 two-file workload (configs[4] shape: long names, 40 quality values, N runs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (kernel ablation runs with RFQ_TUNE set)")
+    ap.add_argument("--share-pairs", type=int, default=22_400_000, help="N>1: pairs per GPU share (configs[3]: 2 x 8 GB per GPU)")
     args = ap.parse_args()
 
     import torch
     from repaq_amd import dist as D
     rank, world, local = D.env_rank()
-    # test aid for 1-GPU boxes: RFQ_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0 and rendezvouses over gloo, so that the N>1 control
-    # flow (barriers, max-over-ranks time, aggregate value) can be exercised where RCCL refuses two ranks on one device
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world)
+    # test aid for 1-GPU boxes: RFQ_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0, so that the N>1 control flow can be exercised there
     single = os.environ.get("RFQ_BENCH_SINGLE_DEVICE") == "1"
     if single:
         local = 0
     if world > 1:
-        D.init("gloo" if single else "nccl", device=None if single else torch.device("cuda", local))   # "nccl" is RCCL on ROCm; barrier / max / sum only
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world)
+        D.init("gloo")          # host-side rendezvous only (barriers, max-over-ranks time, the <= 272-byte header, chunk hashes): no RCCL on this path
+        from repaq_amd import farm
+        return farm.run_bench(args, rank, world, local)
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
-    import _oracle as O
-    from repaq_amd import RfqCodec, SE
+    from repaq_amd import RfqCodec
     codec = RfqCodec(device=local)     # raises loudly without the HIP library / a GPU: there is no fallback
 
-    seed = 2 + rank
-    from repaq_amd import PE_TWO_FILES
-    if args.bgi:
-        args.pe = True
-        fq1, fq2 = O.gen(O.BGI_PE100, args.reads // 2, seed=seed + 2, nppm=20, n_quals=40)
-    elif args.pe:
-        fq1, fq2 = O.gen(O.NOVA_PE150, args.reads // 2, seed=seed + 1, nppm=20)
-    else:
-        fq1, fq2 = O.gen(O.NOVA_SE150, args.reads, seed=seed, nppm=20)
-    n = len(fq1) + len(fq2)
-    d_fq = torch.frombuffer(bytearray(fq1), dtype=torch.uint8).to(dev)
-    d_fq2 = torch.frombuffer(bytearray(fq2), dtype=torch.uint8).to(dev) if fq2 else None
-    paired = PE_TWO_FILES if args.pe else SE
-    chunk_bases = max(100, args.chunk_kb) * 1000
-
-    have_decode = not args.encode_only
-    state = {"rfq_len": 0, "chunks": 0, "stage_ms": {}, "dec_ms": 0.0, "enc_ms": 0.0}
-
-    def step(collect):
-        codec.clearHeader()
-        t0 = time.perf_counter()
-        r = codec.encode(d_fq.data_ptr(), len(fq1), d_fq2.data_ptr() if d_fq2 is not None else None, len(fq2), paired, chunk_bases)
-        t1 = time.perf_counter()
-        if collect:
-            for name, ms in codec.timings():
-                state["stage_ms"][name] = state["stage_ms"].get(name, 0.0) + ms
-        state["rfq_len"], state["chunks"] = r.rfq_len, r.n_chunks
-        t2 = t1
-        if state.get("decode_ok", True) and have_decode:
-            try:
-                d = codec.decode(r.d_rfq, r.rfq_len, split_pe=bool(args.pe))
-                t2 = time.perf_counter()
-                state["decode_ok"] = True; state["dec_n"] = d.n1; state["d_fq"] = d.d_fq1
-                if collect:
-                    for name, ms in codec.timings():
-                        state["stage_ms"]["dec:" + name] = state["stage_ms"].get("dec:" + name, 0.0) + ms
-            except Exception as e:
-                if "not built yet" not in str(e):
-                    raise
-                state["decode_ok"] = False
-        if collect:
-            state["enc_ms"] += (t1 - t0) * 1e3; state["dec_ms"] += (t2 - t1) * 1e3
-        return r
-
-    # parity of the measured configuration (rank 0): md5 of the .rfq against the reference's golden md5
-    r = step(False)
-    parity = "unchecked"
-    if rank == 0 and not args.no_verify:
-        got = codec.dev_get(r.d_rfq, r.rfq_len)
-        md5 = hashlib.md5(got).hexdigest()
-        gold = [g for g in json.load(open(os.path.join(ROOT, "tests", "golden", "generated.json")))
-                if not args.pe and g["profile"] == O.NOVA_SE150 and g["reads"] == args.reads and g["seed"] == seed and g["nppm"] == 20 and g["k"] == args.chunk_kb and not g["nonl"]]
-        if gold:
-            assert md5 == gold[0]["rfq_md5"], "GPU .rfq md5 %s != reference golden %s" % (md5, gold[0]["rfq_md5"])
-            parity = "rfq md5 == reference golden (%s)" % md5
-        else:
-            want = O.encode_file(fq1, fq2, paired, chunk_bases)
-            assert got == want, "GPU .rfq differs from the oracle"
-            parity = "rfq bytes == oracle (%s)" % md5
-        if state.get("decode_ok"):
-            back = codec.dev_get(state["d_fq"], state["dec_n"])
-            assert back == fq1, "decode round trip differs from the input FASTQ"
-            parity += "; decode == input"
-
-    for _ in range(args.warmup):
-        step(False)
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    D.barrier()
-    dt = time.perf_counter() - t0
-    dt, total_bytes = D.reduce_max_sum(dt, n, device=None if single else dev)      # MAX over ranks of the time, SUM of the bytes
-
-    if rank == 0:
-        K = args.steps
-        passes = 2 if state.get("decode_ok") else 1          # FASTQ bytes consumed by encode + produced by decode
-        value = total_bytes * passes * K / dt / 1e6
-        stage = {k: v / K for k, v in state["stage_ms"].items()}
-        enc_stage = {k: v for k, v in stage.items() if not k.startswith("dec:")}
-        dec_stage = {k: v for k, v in stage.items() if k.startswith("dec:")}
-        dom = max(stage, key=stage.get) if stage else None    # the longest stage of either direction (HIP events on the codec's stream)
-        alg = float(n + state["rfq_len"])                    # B_fastq + B_rfq per batch, either direction
-        roof = None
-        if dom:
-            # HBM bytes of the dominant stage from the committed PMC passes (tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE collected in
-            # separate rocprofv3 --pmc runs of this same command, KB units, FETCH_SIZE x2 on gfx950) — only valid for the default workload
-            traffic = None
-            STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
-                             "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
-                             "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder<0>", "k_pos_coder<1>", "k_pos_coder<2>"],
-                             "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
-                             "dec:walk": ["k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
-                             "dec:streams": ["k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_coords", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_except"],
-                             "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit"]}
-            pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if args.reads == 2_800_000 and args.chunk_kb == 1000 and not args.pe and os.path.exists(pj):
-                pmc = json.load(open(pj))
-                ks = [k for k in STAGE_KERNELS.get(dom, []) if k in pmc]
-                traffic = int(sum(pmc[k]["fetch_bytes"] + pmc[k]["write_bytes"] for k in ks)) if ks else None
-            ach = alg / (stage[dom] * 1e-3) / 1e9
-            enc_ms, dec_ms = sum(enc_stage.values()), sum(dec_stage.values())
-            roof = {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS.get(dom, [dom])), "stage": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(stage[dom], 4),
-                    "whole_encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if enc_ms else None,
-                    "whole_decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}
-        out = {
-            "metric": "raw FASTQ MB/s encode+decode" if state.get("decode_ok") else "raw FASTQ MB/s encode (decode pending)",
-            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": (("configs[4] shape (profiling aid): synthetic BGI-style PE100, 40 quality values, %.2f GB FASTQ per GPU (fqgen profile 3, %d pairs), -k %d" if args.bgi else
-                                     "configs[2] shape (profiling aid): synthetic NovaSeq PE150 two files, %.2f GB FASTQ per GPU (fqgen profile 1, %d pairs), -k %d")
-                                    % (n / 1e9, args.reads // 2, args.chunk_kb)) if args.pe else
-                                   "configs[1]: synthetic NovaSeq SE150 %.2f GB FASTQ per GPU (fqgen profile 0, %d reads, seed 2+rank, N 20 ppm), -k %d"
-                                   % (n / 1e9, args.reads, args.chunk_kb), "chunks_per_gpu": state["chunks"], "rfq_over_fastq": round(state["rfq_len"] / n, 4),
-                       "encode_MBps_per_gpu": round(n * K / (state["enc_ms"] * 1e-3) / 1e6, 1) if state["enc_ms"] else None,
-                       "decode_MBps_per_gpu": round(n * K / (state["dec_ms"] * 1e-3) / 1e6, 1) if state.get("decode_ok") and state["dec_ms"] else None,
-                       "parity": parity, "stage_ms": {k: round(v, 3) for k, v in stage.items()}},
-            "roofline": roof,
-        }
-        if world == 1 and not args.no_cpu_baseline and not args.pe:
-            out["cpu_baseline"] = cpu_baseline(fq1, args.reads)
-        print(json.dumps(out))
+    sync = torch.cuda.synchronize
+    w = Workload(codec, dev, args.workload, args.units, args.seed, args.chunk_kb, decode=not args.encode_only)
+    parity = "unchecked" if args.no_verify else w.check()
+    dt = w.run(args.steps, args.warmup, sync, lambda: None)
+    head, stage, enc_ms, dec_ms = line_of(w, args.steps, dt, w.n, parity)
+    out = {
+        "metric": "raw FASTQ MB/s encode+decode" if w.do_decode else "raw FASTQ MB/s encode",
+        "value": head["value_MBps"], "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": w.label, "chunks_per_gpu": w.chunks, "rfq_over_fastq": head["rfq_over_fastq"],
+                   "encode_MBps_per_gpu": head["encode_MBps"], "decode_MBps_per_gpu": head["decode_MBps"], "parity": parity, "stage_ms": head["stage_ms"]},
+        "roofline": roofline_of(w, stage, enc_ms, dec_ms, args.workload),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w.a1, w.a2, w.paired, w.units, args.cpu_sample)
+    if not args.no_secondary and args.workload == "cfg2" and not args.units:
+        sec = {}
+        del w
+        torch.cuda.empty_cache()
+        for key in ("cfg1", "cfg4"):
+            w2 = Workload(codec, dev, key, 0, None, args.chunk_kb, decode=not args.encode_only)
+            p2 = "unchecked" if args.no_verify else w2.check()
+            dt2 = w2.run(3, 1, sync, lambda: None)
+            l2, st2, e2, d2 = line_of(w2, 3, dt2, w2.n, p2)
+            l2["roofline"] = roofline_of(w2, st2, e2, d2, key)
+            sec[key] = l2
+            del w2
+            torch.cuda.empty_cache()
+        out["secondary"] = sec
+    print(json.dumps(out))
     codec.close()
-    if world > 1:
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

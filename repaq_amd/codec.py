@@ -136,5 +136,7 @@ def nolb_threshold(file_size: int, ends_with_newline: bool) -> int:
     if ends_with_newline or file_size == 0:
         return U64_MAX
     if file_size % (1 << 20) == 0:
-        return 0   # reference reads mBuf[-1] (UB); observed: the flag ends up set on chunks emitted after the last block
+        # every block was a full one: the flag is raised by the empty read that follows the unterminated last line, i.e. while the last
+        # record is being assembled - only the chunk that holds it carries the bit (the virtual terminator sits at offset file_size)
+        return file_size
     return ((file_size - 1) >> 20) << 20

@@ -86,13 +86,17 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
             if (h2.pad) { speculate = false; continue; }
-            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos;
+            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
         break;
     }
     ctx->timer.end(S);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "truncated or corrupt rfq chunk at byte %llu", (unsigned long long)hs.consumed);
+    // 64-bit total of the read lengths: bases, qualities and text are placed by 32-bit prefix sums below (a corrupt length table
+    // must be refused before any buffer is sized from a wrapped sum)
+    { uint64_t tb = 0; for (int i = 0; i < 16; i++) tb += hs.base_slots[i];
+      if (tb >= 0xFFFFFFF0ull) return rfq_fail(ctx, RFQ_E_ARG, "one decode call must cover < 4 Gi bases (this image's length tables sum to %llu); pass fewer chunks per call", (unsigned long long)tb); }
     const uint32_t n_chunks = hs.n_chunks; const uint64_t n_reads64 = hs.total_reads;
     res->consumed = (size_t)hs.consumed; res->n_chunks = n_chunks; res->n_reads = n_reads64;
     if (n_chunks == 0) return RFQ_OK;

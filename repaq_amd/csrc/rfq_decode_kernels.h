@@ -17,6 +17,7 @@ struct DChunk {                  // one parsed chunk (offsets relative to the ch
     uint32_t o_readlens, o_n1lens, o_n2lens, o_stlens, o_lanes, o_tiles, o_x, o_y, o_n1, o_n2, o_st, o_seq, o_qual, o_ov, o_npos, total;
     uint32_t n1_size, n2_size, st_size;
     uint32_t rbase;              // reads in earlier chunks
+    uint64_t bases;              // sum of the chunk's read lengths (64-bit: a corrupt length table must not wrap the 32-bit prefix sums)
 };
 struct DecStatus {
     uint32_t err, n_chunks, max_reads, overflow;
@@ -24,6 +25,7 @@ struct DecStatus {
     uint32_t last_flags, pad;
     uint32_t max_stream, max_npos;   // largest quality section / N-position section of any chunk (bound the position streams)
     uint64_t text_slots[2][64];      // partial sums of the text bytes per output stream (k_dec_textlen)
+    uint64_t base_slots[16];         // partial sums of the read lengths of all chunks (parse_chunk)
 };
 
 // sum of n bytes by one wave (wave-uniform result)
@@ -45,6 +47,13 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
     const uint32_t s = d.reads, fl = d.flags; const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s;
     d.o_readlens = (uint32_t)q; q += (uint64_t)((fl & C_READ_LEN_SAME) ? 1u : s) * rlb;
     if (q > left) return 2;
+    {   // sum of the read lengths, 64-bit (the per-read prefix sums that place bases and qualities are 32-bit; the host refuses a batch that would wrap them)
+        const uint8_t* lp = p + d.o_readlens; unsigned long long sum = 0;
+        auto rl = [&](uint32_t r) -> uint32_t { const uint8_t* x = lp + (size_t)r * rlb; return rlb == 1 ? x[0] : (rlb == 2 ? ld_u16(x) : ld_u32(x)); };
+        if (fl & C_READ_LEN_SAME) sum = (unsigned long long)rl(0) * s;
+        else { for (uint32_t r = (uint32_t)lane_id(); r < s; r += 64) sum += rl(r); sum = wave_sum<unsigned long long>(sum); }
+        d.bases = sum;
+    }
 #define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
         const uint32_t m_ = (fl & (LENFLAG)) ? 1u : s; OFF = (uint32_t)q; if (q + m_ > left) return 2; \
         uint32_t sum_ = (fl & (LENFLAG)) ? (uint32_t)p[q] : wave_sum_bytes(p + q, m_); \
@@ -74,7 +83,7 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
 // One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays; the reader ignores mSize).
 __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st, int final) {
     const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
-    uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, maxn = 0, lastfl = 0; uint64_t rb = 0; uint32_t err = 0, ovf = 0;
+    uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, maxn = 0, lastfl = 0; uint64_t rb = 0, tb = 0; uint32_t err = 0, ovf = 0;
     if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
     while (!err) {
         DChunk d; const int rc = parse_chunk(img, n, k, hf, rlb, d);
@@ -84,10 +93,10 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
         if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
         if (d.reads > maxr) maxr = d.reads;
         if (d.qual_size > maxs) maxs = d.qual_size; if (d.npos_size > maxn) maxn = d.npos_size;
-        lastfl = d.flags; rb += d.reads; k += d.total; c++;
+        lastfl = d.flags; rb += d.reads; k += d.total; c++; tb += d.bases;
         if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
     }
-    if (l == 0) { st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
+    if (l == 0) { st->base_slots[0] = tb; st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
 }
 // Speculative walk: images written by repaq (or this engine) carry mSize = true size - Delta(flags) (the accounting bug Q1 is a
 // pure function of the header and chunk flags), so the chain needs ONE dependent 10-byte read per chunk instead of a full parse.
@@ -155,7 +164,7 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
     d.rbase = rbase;
-    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); }
+    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); atomicAdd((unsigned long long*)&st->base_slots[c & 15u], (unsigned long long)d.bases); }
 }
 
 struct DReadTab {

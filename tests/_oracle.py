@@ -167,7 +167,12 @@ def gen_np(profile: int, n_reads: int, seed: int = 1, nppm: int = 20, nonl: int 
     gen(profile, 1, seed)                      # loads the library / prototypes
     p = _GenParams(seed, n_reads, profile, nppm, nonl, 1 if interleaved else 0, n_quals, 0)
     n1 = C.c_size_t(); n2 = C.c_size_t()
-    _gen.fqgen_generate(C.byref(p), None, 0, None, 0, C.byref(n1), C.byref(n2))
+    if profile in (NOVA_SE150, NOVA_PE150):
+        # one pass: a NovaSeq-profile record is at most 54 (name) + 150 + 1 + 150 + 4 line ends = 359 bytes (untouched pages cost nothing)
+        per = 360 * (2 if interleaved else 1)
+        n1.value = n_reads * per + 64; n2.value = (n_reads * per + 64) if (profile == NOVA_PE150 and not interleaved) else 0
+    else:
+        _gen.fqgen_generate(C.byref(p), None, 0, None, 0, C.byref(n1), C.byref(n2))
     a1 = np.empty(max(1, n1.value), dtype=np.uint8); a2 = np.empty(max(1, n2.value), dtype=np.uint8)
     rc = _gen.fqgen_generate(C.byref(p), a1.ctypes.data_as(C.c_void_p), n1.value, a2.ctypes.data_as(C.c_void_p), n2.value, C.byref(n1), C.byref(n2))
     assert rc == 0

@@ -95,6 +95,20 @@ def build_cases():
     lf2 = fastq(bigrecs)
     cut = lf2.index(b"\n@", 600000) + 1
     C["se_three_newlines_mid_file"] = dict(fq1=lf2[:cut] + b"\n\n" + lf2[cut:], paired=SE, k=100)            # chunks before the empty line + a truncated tail chunk
+    # a file of exactly 1 MiB without a final line break: the reader's last full block does not raise the flag, the empty
+    # read that follows the unterminated last line does (src/fastqreader.cpp:31-46) - only the chunk holding the last record carries the bit
+    def exact_mib(recs, mate_fix=None):
+        m = len(recs)
+        while len(fastq(recs[:m], final_eol=False)) > MiB:
+            m -= 1
+        need = MiB - len(fastq(recs[:m], final_eol=False))
+        out = fastq([rec(recs[0][0] + "P" * need, recs[0][1], recs[0][3])] + recs[1:m], final_eol=False)
+        assert len(out) == MiB and out[-1:] != b"\n"
+        return out, m
+    em, em_n = exact_mib(bigrecs)
+    C["se_exact_mib_no_final_newline"] = dict(fq1=em, paired=SE, k=100)
+    r2big = [rec(illumina(i, mate=2, tile=1101 + i // 4000), rseq(bigrng, 40), rqual(bigrng, 40)) for i in range(em_n)]
+    C["pe_exact_mib_r1_no_final_newline"] = dict(fq1=em, fq2=fastq(r2big), paired=PE2, k=100)
     C["se_partial_last_record"] = dict(fq1=fastq(base) + b"@partial\nACGT\n", paired=SE)
     C["se_single_read"] = dict(fq1=fastq(base[:1]), paired=SE)
     r2 = [rec(illumina(i, mate=2), rseq(rng, 40), rqual(rng, 40)) for i in range(30)]

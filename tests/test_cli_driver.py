@@ -102,6 +102,14 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     assert om.read_bytes() == pe.read_bytes()
     r = _run(binary, ["-c", "--stdin", "--stdout", "-k", "100", "--batch_mb", str(4 * batch_mb), "--devices=0,0,0,0"], input=fq1)
     assert r.returncode == 0 and r.stdout == og.read_bytes(), r.stderr
+    # a file of exactly 1 MiB without a final line break: only the chunk that holds the last record carries the line-break bit (ADVICE r1;
+    # the driver computes the threshold itself, one-shot and under --devices)
+    from cases import CASES
+    em = CASES["se_exact_mib_no_final_newline"]["fq1"]; pm = tmp_path / "mib.fq"; pm.write_bytes(em)
+    for extra in ([], ["--devices", "0,0,0"]):
+        r = _run(binary, ["-c", "-i", str(pm), "-o", str(om), "-k", "100", "--batch_mb", str(batch_mb)] + extra)
+        assert r.returncode == 0, r.stderr
+        assert om.read_bytes() == O.encode_file(em, b"", O.SE, 100_000)
     # an empty input leaves an empty .rfq, which decodes to an empty FASTQ (RfqHeader defaults, src/rfqheader.cpp:7-17)
     pz = tmp_path / "empty.fq"; pz.write_bytes(b""); oz = tmp_path / "empty.rfq"; bz = tmp_path / "empty_back.fq"
     assert _run(binary, ["-c", "-i", str(pz), "-o", str(oz)]).returncode == 0 and oz.read_bytes() == b""

@@ -122,23 +122,4 @@ def test_first_diff_of_two_device_texts(codec):
 
 
 def test_decode_with_chunk_index(codec):
-    """rfq_decode_args.h_chunk_off: a caller that has the chunk offsets skips the chunk walk; every extent is still verified on the
-    device, and an index that does not verify (shifted, truncated, out of range) is ignored - the chain is walked as without one."""
-    fq1, fq2 = O.gen(O.NOVA_PE150, 400, seed=35)
-    rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 15000)
-    offs = O.chunk_table(rfq)
-    assert len(offs) > 5
-
-    def run(table):
-        d = codec.dev_put(rfq)
-        try:
-            r = codec.decode(d, len(rfq), split_pe=True, chunk_off=table)
-            return r.n_chunks, codec.dev_get(r.d_fq1, r.n1), codec.dev_get(r.d_fq2, r.n2)
-        finally:
-            codec.dev_free(d)
-
-    assert run(offs) == (len(offs) - 1, fq1, fq2)
-    assert run([o + (1 if 0 < i < len(offs) - 1 else 0) for i, o in enumerate(offs)]) == (len(offs) - 1, fq1, fq2)    # shifted entries
-    assert run(offs[:-2]) == (len(offs) - 1, fq1, fq2)                                                             # covers only a prefix
-    assert run(offs[:-1] + [len(rfq) + 100]) == (len(offs) - 1, fq1, fq2)                                           # past the image
-    assert run([offs[0], offs[0] + 5]) == (len(offs) - 1, fq1, fq2)                                                 # too short to be a chunk
+    E.decode_with_chunk_index(codec)

@@ -124,44 +124,4 @@ def test_scan_then_chunk_parallel_encode_equals_one_shot(label):
 
 
 def test_overlap_search_paths(codec):
-    """k_overlap's three paths against the oracle: packed 2-bit rows (reads <= 256 bases; N inside and beside the overlap, lower-case
-    bases in R2, homopolymers that pass the 12-base filter at many candidates), the byte-wise search for reads > 256 bases, and the
-    byte-wise search for an R1 that holds a character outside A/C/G/T/N in a later chunk (the header only vets chunk 0)."""
-    import random
-    rng = random.Random(99)
-    comp = {65: 84, 84: 65, 67: 71, 71: 67, 78: 78}
-
-    def rc(s):
-        return bytes(comp.get(b, 78) for b in reversed(s))
-
-    r1, r2 = [], []
-    for i in range(900):
-        ln = rng.choice([150, 150, 151, 100, 256, 257, 300, 40, 13, 12, 11])
-        kind = rng.random()
-        seq = bytearray(rng.choice(b"ACGT") for _ in range(ln))
-        if kind < 0.15:
-            seq = bytearray(rng.choice(b"AC") * 1 for _ in range(ln)) if rng.random() < 0.5 else bytearray(b"A" * ln)   # low complexity: many filter hits
-        if rng.random() < 0.3:
-            for _ in range(rng.randint(1, 6)):
-                seq[rng.randrange(ln)] = 78
-        ln2 = rng.choice([ln, ln, max(1, ln - 7), ln + 9])
-        mode = rng.random()
-        if mode < 0.45 and ln >= 12:
-            ov = rng.randint(12, ln); frag = bytes(seq[ln - ov:]) + bytes(rng.choice(b"ACGT") for _ in range(max(0, ln2 - ov))); s2 = rc(frag[:ln2])
-        elif mode < 0.7 and ln >= 12:
-            ov = rng.randint(12, ln); frag = bytes(rng.choice(b"ACGT") for _ in range(max(0, ln2 - ov))) + bytes(seq[:ov]); s2 = rc(frag[-ln2:])
-        else:
-            s2 = bytes(rng.choice(b"ACGT") for _ in range(ln2))
-        s2 = bytearray(s2)
-        if i > 500 and rng.random() < 0.1 and len(s2):
-            k = rng.randrange(len(s2)); s2[k] = ord(chr(s2[k]).lower())          # complement rule takes either case
-        if i > 500 and rng.random() < 0.1 and len(s2):
-            s2[rng.randrange(len(s2))] = ord("X")                                # -> N in RC(R2)
-        if i > 500 and rng.random() < 0.1:
-            seq[rng.randrange(ln)] = rng.choice(b"acgtnX.")                       # R1 as it stands: equals nothing in RC(R2)
-        name = b"@A00250:26:H3YTWDSXX:1:1101:%d:%d" % (1000 + i, 2000 + i // 7)
-        r1.append(name + b" 1:N:0:ACGT\n" + bytes(seq) + b"\n+\n" + b"F" * ln + b"\n")
-        r2.append(name + b" 2:N:0:ACGT\n" + bytes(s2) + b"\n+\n" + b"F" * len(s2) + b"\n")
-    fq1, fq2 = b"".join(r1), b"".join(r2)
-    want = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 30000)
-    assert E.encode(codec, fq1, fq2, O.PE_TWO_FILES, 30000) == want
+    E.overlap_search_paths(codec)

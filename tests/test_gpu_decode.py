@@ -134,3 +134,8 @@ def test_first_diff_of_two_device_texts(codec):
             assert codec.first_diff(da.value + skew, db, n) == want
         finally:
             codec.dev_free(da); codec.dev_free(db)
+
+
+def test_decode_with_chunk_index(codec):
+    """rfq_decode_args.h_chunk_off: verified on the device, ignored when it does not verify (see tests/_engine.py)."""
+    E.decode_with_chunk_index(codec)

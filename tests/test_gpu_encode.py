@@ -124,3 +124,8 @@ def test_scan_then_chunk_parallel_encode_equals_one_shot(label):
     for parts in (2, 5):
         got, nc = E.scan_and_encode_in_ranges(mk, fq1, fq2, paired, 100_000, parts)
         assert nc >= 3 and got == O.encode_file(fq1, fq2, paired, 100_000)
+
+
+def test_overlap_search_paths(codec):
+    """k_overlap: packed 2-bit rows, the > 256-base path and the odd-character path (see tests/_engine.py)."""
+    E.overlap_search_paths(codec)

@@ -1,10 +1,12 @@
 """BASELINE.json configs[2] at full size on one GPU: PE150 2 x 4 GB (`-i/-I`), encode + decode round trip.
 The oracle cannot cover 8 GB in test time, so parity at this size rests on size-independent properties:
+  * the whole image's md5 equals the md5 of what the compiled reference wrote for the same two files (tests/golden/big.json),
   * the image's leading chunks are byte-identical to the oracle's encoding of the matching file prefix (chunks are
     independent once the header exists),
   * chunk / read / base counts follow the cut rule in closed form (uniform 150 bp reads: 3,334 pairs per chunk),
   * decode(encode(x)) == x for both mates, compared on the device."""
 import hashlib
+import json
 import os
 
 import pytest
@@ -36,6 +38,11 @@ def test_cfg2_pe150_2x4GB_round_trip():
     assert off == len(want)
     got = codec.dev_get(r.d_rfq, off)
     assert hashlib.md5(got).hexdigest() == hashlib.md5(want).hexdigest()
+    # the whole image against the reference's own output for this input (tests/golden/big.json, make_golden_big.py)
+    big = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big.json"))).get("cfg2")
+    if big and big["pairs"] == PAIRS and big["seed"] == 3:
+        assert [n1, n2] == big["fq_bytes"] and r.rfq_len == big["rfq_len"]
+        assert hashlib.md5(codec.dev_get(r.d_rfq, r.rfq_len)).hexdigest() == big["rfq_md5"]
     # round trip into caller buffers, compared in HBM
     o1 = torch.empty(n1 + 64, dtype=torch.uint8, device="cuda"); o2 = torch.empty(n2 + 64, dtype=torch.uint8, device="cuda")
     d = codec.decode(r.d_rfq, r.rfq_len, split_pe=True, d_out1=o1.data_ptr(), cap1=n1 + 64, d_out2=o2.data_ptr(), cap2=n2 + 64)

@@ -1,16 +1,23 @@
 #!/bin/bash
-# Round measurement on the GPU box: default bench line (with the reference CPU baseline), rocprofv3 kernel trace of the same command,
-# the two PMC passes (FETCH_SIZE / WRITE_SIZE, separately, --kernel-trace only), the PE150 profile, the end-to-end CLI timing.
-# usage (on the box): bash tools/measure_round.sh <tag>      -> everything lands in gpurun_out/<tag>/
+# Round measurement on the GPU box: the default bench line (configs[2] PE150 2 x 4 GB, reference CPU baseline on a sample, secondary configs[1] /
+# configs[4] lines), rocprofv3 kernel trace of the same workload, the two PMC passes (FETCH_SIZE / WRITE_SIZE, separately, --kernel-trace only).
+# usage (on the box): bash tools/measure_round.sh <tag> [quick]     -> everything lands in gpurun_out/<tag>/
 set -u
-TAG=${1:-round}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-round}; QUICK=${2:-}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $ROOT
-timeout 600 python bench.py > $OUT/bench.json.log 2> $OUT/bench.err
+timeout 900 python bench.py > $OUT/bench.json.log 2> $OUT/bench.err
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o se -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_write.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_pe -o pe -- python $ROOT/bench.py --pe --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_pe_under_rocprof.json.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o cfg2 -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json.log 2>&1
+if [ -z "$QUICK" ]; then
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-verify > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-verify > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_cfg1 -o cfg1 -- python $ROOT/bench.py --workload cfg1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg1_under_rocprof.json.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_cfg4 -o cfg4 -- python $ROOT/bench.py --workload cfg4 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4_under_rocprof.json.log 2>&1
+fi
 cd $ROOT
-timeout 500 bash tools/e2e_cli.sh > $OUT/e2e_cli.txt 2>&1
-ls -R $OUT | head -40
+for d in trace trace_cfg1 trace_cfg4; do f=$(find $OUT/$d -name "*.db" 2>/dev/null | head -1); [ -n "$f" ] && python tools/rocprof_summary.py $f > $OUT/${d}_kernel_stats.txt 2>&1; done
+ff=$(find $OUT/pmc_fetch -name "*.db" 2>/dev/null | head -1); fw=$(find $OUT/pmc_write -name "*.db" 2>/dev/null | head -1)
+[ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_summary.py $ff $fw $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
+# the raw databases are large: keep the summaries, drop the traces
+find $OUT -name "*.db" -size +20M -delete
+ls -R $OUT | head -60
