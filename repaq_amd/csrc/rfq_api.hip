@@ -34,7 +34,7 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& b : c->b) b.release();
-    c->d_hdr.release(); c->d_status.release(); c->d_cmp.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release();
+    c->d_hdr.release(); c->d_status.release(); c->d_cmp.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release(); c->out_acc.release(); c->out_acc1.release(); c->out_acc2.release();
     c->timer.destroy();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->pin) (void)hipHostFree(c->pin);

@@ -18,6 +18,16 @@ struct DBuf {
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want; return hipSuccess;
     }
+    // grow, keeping the first `keep` bytes (device-to-device copy on stream s)
+    hipError_t ensure_keep(size_t n, size_t keep, hipStream_t s) {
+        if (n <= cap) return hipSuccess;
+        void* q = nullptr; const size_t want = n + n / 2 + 4096;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) return e;
+        if (p && keep) { e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) { (void)hipFree(q); return e; } }
+        if (p) (void)hipFree(p);
+        p = q; cap = want; return hipSuccess;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
@@ -81,7 +91,7 @@ struct rfq_ctx {
     DBuf d_cmp;                 // rfq_compare_bytes: one u64 (first differing offset)
     // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
     DBuf b[96];
-    DBuf out_img, out_fq1, out_fq2;
+    DBuf out_img, out_fq1, out_fq2, out_acc, out_acc1, out_acc2;       // out_acc*: the results of a sliced encode / decode call, appended
     std::vector<uint64_t> chunk_off;
     std::vector<uint64_t> scan_end[2];     // rfq_scan_batch: end offset of every chunk in each input stream
     StageTimer timer;

@@ -15,6 +15,130 @@ enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one 
 };
 static_assert(DB_END <= 96, "rfq_ctx::b too small");
 
+#define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
+struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos; };
+// RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
+// out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
+static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
+                        uint8_t** p1, uint8_t** p2, size_t* n1, size_t* n2, uint64_t* nbases) {
+    hipStream_t S = ctx->stream; DBuf* B = ctx->b;
+    static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;
+    const DevHeader& HH = ctx->h_hdr; const DevHeader* D = ctx->d_hdr.as<DevHeader>();
+    DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs; memset(&hs, 0, sizeof hs);
+    hs.max_stream = g.max_stream; hs.max_npos = g.max_npos;
+    const uint32_t n_chunks = g.n_chunks, n_reads = g.n_reads, max_reads = std::max(g.max_reads, 1u);
+    const DChunk* CH = g.CH;
+    HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
+    // ---- read table + prefixes
+    ctx->timer.begin("read_table", S);
+    const size_t nr = (size_t)n_reads + 2, nc = (size_t)n_chunks + 2;
+    HIPCHK(ctx, B[DB_LEN].ensure(nr * 4)); HIPCHK(ctx, B[DB_CHUNKID].ensure(nr * 4)); HIPCHK(ctx, B[DB_OV].ensure(nr * 4));
+    HIPCHK(ctx, B[DB_PVIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_PV].ensure(nr * 16)); HIPCHK(ctx, B[DB_PQ].ensure(nr * 4));
+    HIPCHK(ctx, B[DB_TIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_TP].ensure(nr * 16));
+    HIPCHK(ctx, B[DB_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[DB_SBASE].ensure(nc * 8));
+    HIPCHK(ctx, B[DB_XV].ensure(nr * 4)); HIPCHK(ctx, B[DB_YV].ensure(nr * 4)); HIPCHK(ctx, B[DB_MID].ensure(nr * 40));
+    HIPCHK(ctx, B[DB_SCAN].ensure((nr / SCAN_TILE + 2) * 16 + 1024));
+    DReadTab R; R.len = B[DB_LEN].as<uint32_t>(); R.chunk = B[DB_CHUNKID].as<uint32_t>(); R.ov = B[DB_OV].as<int32_t>();
+    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>(); R.mid = B[DB_MID].as<uint8_t>();
+    hipLaunchKernelGGL(k_dec_readtab, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, dst);
+    KCHK(ctx, "k_dec_readtab");
+    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
+    scan_exclusive<U4>(S, R.pvin, R.pv, n_reads, B[DB_SCAN].as<U4>(), 1);
+    uint32_t total_bases = 0; U4 pv_tot;
+    HIPCHK(ctx, ctx->fetch(&total_bases, R.pq + n_reads, 4, S));
+    HIPCHK(ctx, ctx->fetch(&pv_tot, R.pv + n_reads, 16, S));
+    { DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S)); HIPCHK(ctx, ctx->fetch_sync(S)); hs.err = h2.err; }
+    ctx->timer.end(S);
+    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");
+    *nbases = total_bases;
+
+    // ---- streams
+    ctx->timer.begin("streams", S);
+    const size_t qbytes = (size_t)total_bases + 64 * nc + 256, sbytes = (size_t)pv_tot.d + 64 * nc + 256;
+    HIPCHK(ctx, B[DB_QDEC].ensure(qbytes)); HIPCHK(ctx, B[DB_SDEC].ensure(sbytes));
+    uint64_t* qbase = B[DB_QBASE].as<uint64_t>(); uint64_t* sbase = B[DB_SBASE].as<uint64_t>();
+    uint8_t* qdec = B[DB_QDEC].as<uint8_t>(); uint8_t* sdec = B[DB_SDEC].as<uint8_t>();
+    hipLaunchKernelGGL(k_dec_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, CH, R, qbase, sbase, n_chunks);
+    // Two chains run side by side (rfq_ctx::aux, fork / join by events):
+    //   main  prefill of qdec, coordinate decoder, [summaries linked] quality position streams scattered into qdec, exception records
+    //   aux   position-stream summaries + link, 2-bit unpack into sdec, N positions scattered into sdec
+    const bool forked = ctx->aux_ready();
+    hipStream_t A = forked ? ctx->aux : S;
+    if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
+    const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
+    // the prefill is pure bandwidth, the coordinate decoder and the stream summaries are pure latency: third chain
+    hipStream_t F = forked ? ctx->aux2 : S;
+    if (forked) HIPCHK(ctx, hipStreamWaitEvent(F, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_dec_fill, dim3((uint32_t)std::min<size_t>(8192, (qbytes / 16 + 255) / 256 + 1)), dim3(256), 0, F, qdec, (uint64_t)qbytes, D);   // (many short blocks: slots keep turning over for the two other chains)
+    if (forked) HIPCHK(ctx, hipEventRecord(ctx->ev_f, F));
+    hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
+    if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
+        // position streams in POS_SEG-byte segments: summary -> link -> emit (see rfq_decode_kernels.h)
+        // (grid sizes from the largest quality / N-position section: a file with raw qualities has no quality streams to walk)
+        const bool bycol = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL), hasn = (HH.flags & H_N_POS) != 0;
+        const uint32_t nn = bycol ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u, nstr = HH.n_normal + 1;
+        const uint32_t mq = nn ? hs.max_stream / POS_SEG + 1 : 0u, mn = hasn ? hs.max_npos / POS_SEG + 1 : 0u, maxseg = std::max(1u, std::max(mq, mn));
+        const size_t nseg = (size_t)n_chunks * nstr * maxseg;
+        HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 16 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure((size_t)n_chunks * nstr * 4 + 16));
+        HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16));
+        HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, (size_t)n_chunks * nstr * 4, A));
+#define RFQ_SUM_ARGS a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), maxseg, dst, (uint64_t)a->n
+        if (nn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mq, nn, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, 0u, nstr);
+        if (hasn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mn, 1, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, HH.n_normal, nstr);
+#undef RFQ_SUM_ARGS
+        hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
+                           (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
+        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_mid, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
+        hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
+        if (nn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mq, nn, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+                                   (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, 0u, nstr);
+        if (hasn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mn, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+                                     (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, HH.n_normal, nstr);
+    } else hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
+    if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
+    hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
+    KCHK(ctx, "k_dec_streams");
+    ctx->timer.end(S);
+
+    // ---- text
+    ctx->timer.begin("textlen", S);
+    const int split = a->split_pe ? 1 : 0;
+    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
+    scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
+    U4 tt;
+    HIPCHK(ctx, ctx->fetch(&tt, R.tp + n_reads, 16, S));
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
+    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
+    // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
+    hs.text1 = hs.text2 = 0; for (int i = 0; i < 64; i++) { hs.text1 += hs.text_slots[0][i]; hs.text2 += hs.text_slots[1][i]; }
+    if (hs.text1 >= 0xFFFFFFF0ull || hs.text2 >= 0xFFFFFFF0ull) return RFQ_RANGE_TOO_BIG;       // (the caller decodes the range in two halves)
+    uint8_t *o1, *o2; uint64_t cap1, cap2;
+    if ((out1 && ((uintptr_t)out1 & 15u)) || (out2 && ((uintptr_t)out2 & 15u))) return rfq_fail(ctx, RFQ_E_ARG, "output device pointers must be 16-byte aligned");
+    if (out1) { o1 = out1; cap1 = ocap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
+    if (out2) { o2 = out2; cap2 = ocap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
+    ctx->timer.end(S);
+    ctx->timer.begin("emit", S);                                       // k_dec_emit alone: the path's largest kernel (bench.py roofline)
+    {
+        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
+        const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
+        if (tune) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
+        if (tune) hipLaunchKernelGGL(k_dec_emit<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
+                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
+        else hipLaunchKernelGGL(k_dec_emit<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
+                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
+        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu (wave0 own %llu, setup %llu) flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[6]/h[5], h[7]/h[5], h[4]/h[5]); }
+        KCHK(ctx, "k_dec_emit");
+    }
+    ctx->timer.end(S);
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
+    ctx->timer.collect();
+    if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %u / %u bytes", tt.a, tt.b);
+    *n1 = tt.a; *n2 = split ? tt.b : 0; *p1 = o1; *p2 = o2;
+    return RFQ_OK;
+}
+
 extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_decode_result* res) {
     if (!ctx || !a || !res) return RFQ_E_ARG;
     memset(res, 0, sizeof *res);
@@ -95,124 +219,77 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "truncated or corrupt rfq chunk at byte %llu", (unsigned long long)hs.consumed);
     // 64-bit total of the read lengths: bases, qualities and text are placed by 32-bit prefix sums below (a corrupt length table
     // must be refused before any buffer is sized from a wrapped sum)
-    { uint64_t tb = 0; for (int i = 0; i < 16; i++) tb += hs.base_slots[i];
-      if (tb >= 0xFFFFFFF0ull) return rfq_fail(ctx, RFQ_E_ARG, "one decode call must cover < 4 Gi bases (this image's length tables sum to %llu); pass fewer chunks per call", (unsigned long long)tb); }
+    uint64_t tb = 0; for (int i = 0; i < 16; i++) tb += hs.base_slots[i];
     const uint32_t n_chunks = hs.n_chunks; const uint64_t n_reads64 = hs.total_reads;
     res->consumed = (size_t)hs.consumed; res->n_chunks = n_chunks; res->n_reads = n_reads64;
     if (n_chunks == 0) return RFQ_OK;
-    const uint32_t n_reads = (uint32_t)n_reads64, max_reads = std::max(hs.max_reads, 1u);
-    const DChunk* CH = B[DB_CHUNKS].as<DChunk>();
-    const uint32_t last_flags = hs.last_flags;
-
-    // ---- read table + prefixes
-    ctx->timer.begin("read_table", S);
-    const size_t nr = (size_t)n_reads + 2, nc = (size_t)n_chunks + 2;
-    HIPCHK(ctx, B[DB_LEN].ensure(nr * 4)); HIPCHK(ctx, B[DB_CHUNKID].ensure(nr * 4)); HIPCHK(ctx, B[DB_OV].ensure(nr * 4));
-    HIPCHK(ctx, B[DB_PVIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_PV].ensure(nr * 16)); HIPCHK(ctx, B[DB_PQ].ensure(nr * 4));
-    HIPCHK(ctx, B[DB_TIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_TP].ensure(nr * 16));
-    HIPCHK(ctx, B[DB_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[DB_SBASE].ensure(nc * 8));
-    HIPCHK(ctx, B[DB_XV].ensure(nr * 4)); HIPCHK(ctx, B[DB_YV].ensure(nr * 4)); HIPCHK(ctx, B[DB_MID].ensure(nr * 40));
-    HIPCHK(ctx, B[DB_SCAN].ensure((nr / SCAN_TILE + 2) * 16 + 1024));
-    DReadTab R; R.len = B[DB_LEN].as<uint32_t>(); R.chunk = B[DB_CHUNKID].as<uint32_t>(); R.ov = B[DB_OV].as<int32_t>();
-    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>(); R.mid = B[DB_MID].as<uint8_t>();
-    hipLaunchKernelGGL(k_dec_readtab, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, dst);
-    KCHK(ctx, "k_dec_readtab");
-    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
-    scan_exclusive<U4>(S, R.pvin, R.pv, n_reads, B[DB_SCAN].as<U4>(), 1);
-    uint32_t total_bases = 0; U4 pv_tot;
-    HIPCHK(ctx, ctx->fetch(&total_bases, R.pq + n_reads, 4, S));
-    HIPCHK(ctx, ctx->fetch(&pv_tot, R.pv + n_reads, 16, S));
-    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-    HIPCHK(ctx, ctx->fetch_sync(S));
-    ctx->timer.end(S);
-    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");
-    res->n_bases = total_bases;
-
-    // ---- streams
-    ctx->timer.begin("streams", S);
-    const size_t qbytes = (size_t)total_bases + 64 * nc + 256, sbytes = (size_t)pv_tot.d + 64 * nc + 256;
-    HIPCHK(ctx, B[DB_QDEC].ensure(qbytes)); HIPCHK(ctx, B[DB_SDEC].ensure(sbytes));
-    uint64_t* qbase = B[DB_QBASE].as<uint64_t>(); uint64_t* sbase = B[DB_SBASE].as<uint64_t>();
-    uint8_t* qdec = B[DB_QDEC].as<uint8_t>(); uint8_t* sdec = B[DB_SDEC].as<uint8_t>();
-    hipLaunchKernelGGL(k_dec_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, CH, R, qbase, sbase, n_chunks);
-    // Two chains run side by side (rfq_ctx::aux, fork / join by events):
-    //   main  prefill of qdec, coordinate decoder, [summaries linked] quality position streams scattered into qdec, exception records
-    //   aux   position-stream summaries + link, 2-bit unpack into sdec, N positions scattered into sdec
-    const bool forked = ctx->aux_ready();
-    hipStream_t A = forked ? ctx->aux : S;
-    if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
-    const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
-    // the prefill is pure bandwidth, the coordinate decoder and the stream summaries are pure latency: third chain
-    hipStream_t F = forked ? ctx->aux2 : S;
-    if (forked) HIPCHK(ctx, hipStreamWaitEvent(F, ctx->ev_fork, 0));
-    hipLaunchKernelGGL(k_dec_fill, dim3((uint32_t)std::min<size_t>(8192, (qbytes / 16 + 255) / 256 + 1)), dim3(256), 0, F, qdec, (uint64_t)qbytes, D);   // (many short blocks: slots keep turning over for the two other chains)
-    if (forked) HIPCHK(ctx, hipEventRecord(ctx->ev_f, F));
-    hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
-    if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
-        // position streams in POS_SEG-byte segments: summary -> link -> emit (see rfq_decode_kernels.h)
-        // (grid sizes from the largest quality / N-position section: a file with raw qualities has no quality streams to walk)
-        const bool bycol = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL), hasn = (HH.flags & H_N_POS) != 0;
-        const uint32_t nn = bycol ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u, nstr = HH.n_normal + 1;
-        const uint32_t mq = nn ? hs.max_stream / POS_SEG + 1 : 0u, mn = hasn ? hs.max_npos / POS_SEG + 1 : 0u, maxseg = std::max(1u, std::max(mq, mn));
-        const size_t nseg = (size_t)n_chunks * nstr * maxseg;
-        HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 16 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure((size_t)n_chunks * nstr * 4 + 16));
-        HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16));
-        HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, (size_t)n_chunks * nstr * 4, A));
-#define RFQ_SUM_ARGS a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), maxseg, dst, (uint64_t)a->n
-        if (nn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mq, nn, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, 0u, nstr);
-        if (hasn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mn, 1, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, HH.n_normal, nstr);
-#undef RFQ_SUM_ARGS
-        hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
-                           (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
-        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_mid, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
-        hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
-        if (nn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mq, nn, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
-                                   (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, 0u, nstr);
-        if (hasn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mn, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
-                                     (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, HH.n_normal, nstr);
-    } else hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
-    if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
-    hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
-    KCHK(ctx, "k_dec_streams");
-    ctx->timer.end(S);
-
-    // ---- text
-    ctx->timer.begin("textlen", S);
-    const int split = a->split_pe ? 1 : 0;
-    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
-    scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
-    U4 tt;
-    HIPCHK(ctx, ctx->fetch(&tt, R.tp + n_reads, 16, S));
-    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-    HIPCHK(ctx, ctx->fetch_sync(S));
-    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
-    // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
-    hs.text1 = hs.text2 = 0; for (int i = 0; i < 64; i++) { hs.text1 += hs.text_slots[0][i]; hs.text2 += hs.text_slots[1][i]; }
-    if (hs.text1 >= 0xFFFFFFF0ull || hs.text2 >= 0xFFFFFFF0ull)
-        return rfq_fail(ctx, RFQ_E_ARG, "one decode call must emit < 4 GiB of text per output stream (this image holds %llu / %llu bytes); pass fewer chunks per call", (unsigned long long)hs.text1, (unsigned long long)hs.text2);
-    uint8_t *o1, *o2; uint64_t cap1, cap2;
-    if ((a->d_out1 && ((uintptr_t)a->d_out1 & 15u)) || (a->d_out2 && ((uintptr_t)a->d_out2 & 15u))) return rfq_fail(ctx, RFQ_E_ARG, "output device pointers must be 16-byte aligned");
-    if (a->d_out1) { o1 = a->d_out1; cap1 = a->cap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
-    if (a->d_out2) { o2 = a->d_out2; cap2 = a->cap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
-    ctx->timer.end(S);
-    ctx->timer.begin("emit", S);                                       // k_dec_emit alone: the path's largest kernel (bench.py roofline)
-    {
-        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
-        const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
-        if (tune) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
-        if (tune) hipLaunchKernelGGL(k_dec_emit<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
-                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
-        else hipLaunchKernelGGL(k_dec_emit<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
-                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
-        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu (wave0 own %llu, setup %llu) flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[6]/h[5], h[7]/h[5], h[4]/h[5]); }
-        KCHK(ctx, "k_dec_emit");
+    const uint32_t last_flags = hs.last_flags; const int split = a->split_pe ? 1 : 0;
+    DChunk* CHm = B[DB_CHUNKS].as<DChunk>();
+    // (RFQ_SLICE_BASES: test aid - ranges of that many bases, so that the slicing logic runs on small images)
+    static const uint64_t slice_env = getenv("RFQ_SLICE_BASES") ? (uint64_t)atoll(getenv("RFQ_SLICE_BASES")) : 0;
+    const uint64_t slice_bases = slice_env ? slice_env : 1000000000ull, one_pass = slice_env ? slice_env : 1600000000ull;
+    size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
+    int rc = RFQ_RANGE_TOO_BIG;
+    if (tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
+        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos;
+        rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
+        if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
     }
-    ctx->timer.end(S);
-    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-    HIPCHK(ctx, ctx->fetch_sync(S));
-    ctx->timer.collect();
-    if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %u / %u bytes", tt.a, tt.b);
-    size_t n1 = tt.a, n2 = tt.b;
+    if (rc == RFQ_RANGE_TOO_BIG) {
+        // Reads, bases and text of one pass are placed by 32-bit prefix sums: a larger image is decoded range by range (contiguous chunks of
+        // about slice_bases bases; a range whose text still does not fit is halved), every range into the context's own buffers and from
+        // there to its place in the result.
+        std::vector<DChunk> hc(n_chunks);
+        HIPCHK(ctx, hipMemcpy(hc.data(), CHm, (size_t)n_chunks * sizeof(DChunk), hipMemcpyDeviceToHost));
+        std::vector<std::pair<uint32_t, uint32_t>> todo;                    // stack of [c0, c1), first range on top
+        { std::vector<std::pair<uint32_t, uint32_t>> fw; uint32_t c0 = 0; uint64_t acc = 0, rd = 0;
+          for (uint32_t c = 0; c < n_chunks; c++) {
+              if (c > c0 && (acc + hc[c].bases > slice_bases || rd + hc[c].reads > 0x7FFFFFF0ull)) { fw.emplace_back(c0, c); c0 = c; acc = 0; rd = 0; }
+              acc += hc[c].bases; rd += hc[c].reads;
+          }
+          fw.emplace_back(c0, n_chunks);
+          for (size_t i = fw.size(); i-- > 0;) todo.push_back(fw[i]); }
+        size_t w1 = 0, w2 = 0; n1 = n2 = 0; nb = 0;
+        std::vector<std::pair<const char*, float>> acc_ms;
+        ctx->timer.collect();                                                // (the walk, and whatever a failed one-pass attempt got through)
+        for (size_t i = 0; i < ctx->timer.names.size() && i < 1; i++) acc_ms.emplace_back(ctx->timer.names[i], ctx->timer.ms[i]);
+        while (!todo.empty()) {
+            const auto r = todo.back(); todo.pop_back();
+            const uint32_t c0 = r.first, c1 = r.second; uint64_t reads = 0; for (uint32_t c = c0; c < c1; c++) reads += hc[c].reads;
+            hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
+            KCHK(ctx, "k_dec_rebase");
+            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos;
+            uint8_t *q1 = nullptr, *q2 = nullptr; size_t m1 = 0, m2 = 0; uint64_t mb = 0;
+            ctx->timer.reset();
+            rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);
+            if (rc == RFQ_RANGE_TOO_BIG) {
+                if (c1 - c0 < 2) return rfq_fail(ctx, RFQ_E_ARG, "a single chunk decodes to 4 GiB of text or more");
+                const uint32_t mid = c0 + (c1 - c0) / 2; todo.emplace_back(mid, c1); todo.emplace_back(c0, mid); continue;
+            }
+            if (rc != RFQ_OK) return rc;
+            for (size_t i = 0; i < ctx->timer.names.size(); i++) {
+                bool hit = false;
+                for (auto& q : acc_ms) if (q.first == ctx->timer.names[i]) { q.second += ctx->timer.ms[i]; hit = true; break; }
+                if (!hit) acc_ms.emplace_back(ctx->timer.names[i], ctx->timer.ms[i]);
+            }
+            for (int k = 0; k < (split ? 2 : 1); k++) {
+                uint8_t* src = k ? q2 : q1; const size_t m = k ? m2 : m1; size_t& w = k ? w2 : w1; uint8_t* dcall = k ? a->d_out2 : a->d_out1; const size_t dcap = k ? a->cap2 : a->cap1;
+                if (!m) continue;
+                uint8_t* to;
+                if (dcall) { if (w + m > dcap) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small"); to = dcall + w; }
+                else { DBuf& ab = k ? ctx->out_acc2 : ctx->out_acc1; HIPCHK(ctx, ab.ensure_keep(w + m + 64, w, S)); to = ab.as<uint8_t>() + w; }
+                HIPCHK(ctx, hipMemcpyAsync(to, src, m, hipMemcpyDeviceToDevice, S));
+                w += m;
+            }
+            HIPCHK(ctx, hipStreamSynchronize(S));
+            nb += mb;
+        }
+        n1 = w1; n2 = w2;
+        o1 = a->d_out1 ? a->d_out1 : ctx->out_acc1.as<uint8_t>(); o2 = a->d_out2 ? a->d_out2 : ctx->out_acc2.as<uint8_t>();
+        ctx->timer.names.clear(); ctx->timer.ms.clear();
+        for (auto& q : acc_ms) { ctx->timer.names.push_back(q.first); ctx->timer.ms.push_back(q.second); }
+    }
+    res->n_bases = nb;
     if (a->final) {   // Repaq::decompress*: drop the final '\n' when the last chunk carries the NO_LINE_BREAK bit
         if ((last_flags & C_NO_LB) && n1) n1--;
         if (split && (last_flags & C_NO_LB_R2) && n2) n2--;

@@ -16,7 +16,8 @@ struct DChunk {                  // one parsed chunk (offsets relative to the ch
     uint32_t reads, flags, seq_size, qual_size, npos_size, x_size, y_size;
     uint32_t o_readlens, o_n1lens, o_n2lens, o_stlens, o_lanes, o_tiles, o_x, o_y, o_n1, o_n2, o_st, o_seq, o_qual, o_ov, o_npos, total;
     uint32_t n1_size, n2_size, st_size;
-    uint32_t rbase;              // reads in earlier chunks
+    uint32_t rbase;              // reads in earlier chunks of the range being decoded
+    uint32_t rbase_abs;          // reads in earlier chunks of the image (rbase is re-based per range by k_dec_rebase)
     uint64_t bases;              // sum of the chunk's read lengths (64-bit: a corrupt length table must not wrap the 32-bit prefix sums)
 };
 struct DecStatus {
@@ -89,7 +90,7 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
         DChunk d; const int rc = parse_chunk(img, n, k, hf, rlb, d);
         if (rc == 1) break;
         if (rc == 2) { if (final) err = DE_CORRUPT; break; }            // not final: the chunk continues in the caller's next batch
-        d.rbase = (uint32_t)rb;
+        d.rbase = (uint32_t)rb; d.rbase_abs = (uint32_t)rb;
         if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
         if (d.reads > maxr) maxr = d.reads;
         if (d.qual_size > maxs) maxs = d.qual_size; if (d.npos_size > maxn) maxn = d.npos_size;
@@ -154,6 +155,11 @@ __global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const u
         st->last_flags = (!bad && nch) ? ld_u16(img + off[nch - 1] + 8) : 0u;
     }
 }
+// a range of chunks is decoded as a batch of its own: its reads count from 0
+__global__ void k_dec_rebase(DChunk* __restrict__ CH, uint32_t n, uint32_t base) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) CH[c].rbase = CH[c].rbase_abs - base;
+}
 // one wave per speculated chunk: full parse + verification of the extent
 // (launched right behind the walk, before the host knows how many chunks it found: a fixed grid starting at chunk `first`, blocks past
 // the walk's count - read from the status words - leave at once; nothing runs when the walk itself gave up or overflowed its table)
@@ -163,7 +169,7 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
     const uint64_t k = CH[c].off; const uint32_t want = CH[c].total, rbase = CH[c].rbase, reads = CH[c].reads;
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
-    d.rbase = rbase;
+    d.rbase = rbase; d.rbase_abs = rbase;
     if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); atomicAdd((unsigned long long*)&st->base_slots[c & 15u], (unsigned long long)d.bases); }
 }
 

@@ -82,19 +82,21 @@ static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t 
     return RFQ_OK;
 }
 
-static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only);
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only, const uint32_t* skip);
 
-static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, bool scan_only) {
-    if (!ctx || !a || !res) return RFQ_E_ARG;
+// One call's worth of text (< 4 GiB per stream; the stream pointers may sit at any byte address: they are rounded down to 16 bytes and the
+// bytes in front are skipped by the indexer)
+static int encode_one(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, bool scan_only) {
     memset(res, 0, sizeof *res);
-    ctx->err.clear();
-    if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
-    int rc = encode_impl(ctx, a, res, nullptr, ~0u, false, scan_only);
+    rfq_encode_args al = *a; uint32_t skip[2] = { 0, 0 };
+    if (a->n1 && a->d_fq1) { skip[0] = (uint32_t)((uintptr_t)a->d_fq1 & 15u); al.d_fq1 = a->d_fq1 - skip[0]; al.n1 = a->n1 + skip[0]; al.file_off1 = a->file_off1 - skip[0]; }
+    if (a->paired == RFQ_PE_TWO_FILES && a->n2 && a->d_fq2) { skip[1] = (uint32_t)((uintptr_t)a->d_fq2 & 15u); al.d_fq2 = a->d_fq2 - skip[1]; al.n2 = a->n2 + skip[1]; al.file_off2 = a->file_off2 - skip[1]; }
+    int rc = encode_impl(ctx, &al, res, nullptr, ~0u, false, scan_only, skip);
     if (rc != RFQ_NEED_NORM) return rc;
     // slow path: '\r' line ends or blank lines (src/fastqreader.cpp:94-196)
     NormMap nm; memset(&nm, 0, sizeof nm);
     rfq_encode_args a2 = *a;
-    const uint8_t* p; size_t pn;
+    const uint8_t* p; size_t pn; const uint32_t noskip[2] = { 0, 0 };
     if ((rc = normalize_stream(ctx, a->d_fq1, a->n1, a->file_off1, a->final != 0, 0, nm, &p, &pn)) != RFQ_OK) return rc;
     a2.d_fq1 = p; a2.n1 = pn;
     if (a->paired == RFQ_PE_TWO_FILES) {
@@ -102,9 +104,70 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
         a2.d_fq2 = p; a2.n2 = pn;
     }
     memset(res, 0, sizeof *res);
-    rc = encode_impl(ctx, &a2, res, &nm, ~0u, false, scan_only);
+    rc = encode_impl(ctx, &a2, res, &nm, ~0u, false, scan_only, noskip);
     if (rc == RFQ_NEED_NORM) return rfq_fail(ctx, RFQ_E_HIP, "internal: normalised text still needs normalisation");
     return rc;
+}
+
+// Texts of 4 GiB and more per stream (offsets inside one call are 32-bit): the call is cut into slices of RFQ_SLICE bytes per stream.  A slice
+// that is not the last one stops at its last full chunk (final = 0) and the next slice starts right behind the bytes it consumed - in
+// place, nothing is copied.  Chunk images are appended in order, so the result is the one-shot image.
+#define RFQ_SLICE ((size_t)3 << 30)
+static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, bool scan_only) {
+    if (!ctx || !a || !res) return RFQ_E_ARG;
+    memset(res, 0, sizeof *res);
+    ctx->err.clear();
+    if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
+    const bool two = a->paired == RFQ_PE_TWO_FILES;
+    // (RFQ_SLICE_BYTES: test aid - slices of that many bytes, so that the slicing logic runs on small inputs)
+    static const size_t slice_env = getenv("RFQ_SLICE_BYTES") ? (size_t)atoll(getenv("RFQ_SLICE_BYTES")) : 0;
+    const size_t slice = slice_env ? slice_env : RFQ_SLICE, lim = slice_env ? slice_env : 0xFFFFFFF0ull - 16;
+    if (a->n1 < lim && (!two || a->n2 < lim)) return encode_one(ctx, a, res, scan_only);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t pos1 = 0, pos2 = 0, written = 0; bool first = true;
+    std::vector<uint64_t> offs(1, 0), e1, e2; std::vector<std::pair<const char*, float>> acc;
+    uint32_t chunks = 0; uint64_t reads = 0, bases = 0; int ended = 0;
+    for (;;) {
+        const size_t r1 = a->n1 - pos1, r2 = two ? a->n2 - pos2 : 0;
+        const size_t t1 = std::min(r1, slice), t2 = std::min(r2, slice);
+        const bool last = t1 == r1 && t2 == r2;
+        rfq_encode_args s = *a;
+        s.d_fq1 = a->d_fq1 + pos1; s.n1 = t1; s.file_off1 = a->file_off1 + pos1;
+        if (two) { s.d_fq2 = a->d_fq2 + pos2; s.n2 = t2; s.file_off2 = a->file_off2 + pos2; }
+        s.final = last ? a->final : 0; s.flush_all = last ? a->flush_all : 0; s.emit_header = first ? a->emit_header : 0;
+        if (a->d_out) { s.d_out = a->d_out + written; s.out_cap = a->out_cap > written ? a->out_cap - written : 0; }
+        rfq_encode_result r;
+        const int rc = encode_one(ctx, &s, &r, scan_only);
+        if (rc != RFQ_OK) return rc;
+        for (size_t i = 0; i < ctx->timer.names.size(); i++) {
+            bool hit = false;
+            for (auto& q : acc) if (q.first == ctx->timer.names[i]) { q.second += ctx->timer.ms[i]; hit = true; break; }
+            if (!hit) acc.emplace_back(ctx->timer.names[i], ctx->timer.ms[i]);
+        }
+        if (scan_only) {
+            for (uint32_t c = 0; c < r.n_chunks; c++) { e1.push_back(ctx->scan_end[0][c] + pos1); if (two) e2.push_back(ctx->scan_end[1][c] + pos2); }
+        } else if (r.rfq_len) {
+            if (!a->d_out) {            // the slice's image sits in the context's result buffer: append it to the call's
+                HIPCHK(ctx, ctx->out_acc.ensure_keep(written + r.rfq_len + 64, written, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->out_acc.as<uint8_t>() + written, r.d_rfq, r.rfq_len, hipMemcpyDeviceToDevice, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            for (uint32_t c = 1; c <= r.n_chunks; c++) offs.push_back(written + r.h_chunk_off[c]);
+            if (first && r.n_chunks) offs[0] = r.h_chunk_off[0];
+            written += r.rfq_len;
+        }
+        chunks += r.n_chunks; reads += r.n_reads; bases += r.n_bases; pos1 += r.consumed1; pos2 += r.consumed2; first = false;
+        if (r.input_ended) { ended = 1; break; }
+        if (last) break;
+        if (r.consumed1 == 0) return rfq_fail(ctx, RFQ_E_ARG, "no whole chunk inside %zu bytes of text: chunk_bases is too large for a sliced call", slice);
+    }
+    ctx->timer.names.clear(); ctx->timer.ms.clear();
+    for (auto& q : acc) { ctx->timer.names.push_back(q.first); ctx->timer.ms.push_back(q.second); }
+    res->n_chunks = chunks; res->n_reads = reads; res->n_bases = bases; res->consumed1 = pos1; res->consumed2 = pos2; res->input_ended = ended;
+    if (scan_only) { ctx->scan_end[0] = e1; ctx->scan_end[1] = e2; return RFQ_OK; }
+    ctx->chunk_off = offs; res->h_chunk_off = ctx->chunk_off.data();
+    res->rfq_len = written; res->d_rfq = written ? (a->d_out ? a->d_out : ctx->out_acc.as<uint8_t>()) : nullptr;
+    return RFQ_OK;
 }
 extern "C" int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res) { return encode_or_scan(ctx, a, res, false); }
 extern "C" int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_scan_result* out) {
@@ -119,7 +182,7 @@ extern "C" int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_scan_r
     return RFQ_OK;
 }
 
-static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only) {
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only, const uint32_t* skip) {
     memset(res, 0, sizeof *res);
     res->input_ended = ended ? 1 : 0;
     const bool fin = a->final || ended || a->flush_all;
@@ -127,7 +190,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (a->chunk_bases == 0) return rfq_fail(ctx, RFQ_E_ARG, "chunk_bases must be >= 1");
     const int nstreams = a->paired == RFQ_PE_TWO_FILES ? 2 : 1;
     const uint8_t* fq[2] = { a->d_fq1, nstreams == 2 ? a->d_fq2 : nullptr };
-    const size_t nbytes[2] = { a->n1, nstreams == 2 ? a->n2 : 0 };
+    // skip[s] (< 16): leading bytes of stream s that are not part of it (see k_nl_bitmap); a stream that holds nothing else is empty
+    const size_t nbytes[2] = { a->n1 > skip[0] ? a->n1 : 0, nstreams == 2 ? (a->n2 > skip[1] ? a->n2 : 0) : 0 };
     for (int s = 0; s < nstreams; s++) {
         if (nbytes[s] >= 0xFFFFFFF0ull) return rfq_fail(ctx, RFQ_E_ARG, "a FASTQ stream of one batch must be < 4 GiB (got %zu bytes); split at record boundaries", nbytes[s]);
         if (nbytes[s] && !fq[s]) return rfq_fail(ctx, RFQ_E_ARG, "null FASTQ pointer");
@@ -159,7 +223,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_SCANTMP].ensure(scantmp));
     for (int s = 0; s < nstreams; s++) {
         if (!nblk[s]) continue;
-        hipLaunchKernelGGL(k_nl_bitmap, dim3(nblk[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), dst);
+        hipLaunchKernelGGL(k_nl_bitmap, dim3(nblk[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], skip[s], B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), dst);
         KCHK(ctx, "k_nl_bitmap");
         scan_exclusive<uint32_t>(S, B[B_BLK0 + s].as<uint32_t>(), B[B_BLK0 + s].as<uint32_t>(), nblk[s], B[B_SCANTMP].as<uint32_t>(), 1);
     }
@@ -180,7 +244,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         nlines[s] = n_newlines[s] + (unterm ? 1u : 0u); nrec[s] = nlines[s] / 4;
         HIPCHK(ctx, B[B_LO0 + s].ensure(((size_t)nlines[s] + 4) * 4));
         if (nblk[s]) {
-            hipLaunchKernelGGL(k_line_offsets, dim3(nblk[s]), dim3(256), 0, S, B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), (uint32_t)nbytes[s], B[B_LO0 + s].as<uint32_t>());
+            hipLaunchKernelGGL(k_line_offsets, dim3(nblk[s]), dim3(256), 0, S, B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), (uint32_t)nbytes[s], skip[s], B[B_LO0 + s].as<uint32_t>());
             hipLaunchKernelGGL(k_line_tail, dim3(1), dim3(64), 0, S, B[B_LO0 + s].as<uint32_t>(), n_newlines[s], (uint32_t)nbytes[s], unterm);
             KCHK(ctx, "k_line_offsets");
         }
@@ -235,7 +299,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // "\n\n" is a swallowed blank line, not an empty one: classify the text properly first.  On normalised text an empty line is
         // where FastqReader::read returns NULL (src/fastqreader.cpp:180-191): the record and everything after it are never read.
         if (!nm) return RFQ_NEED_NORM;
-        return encode_impl(ctx, a, res, nm, hs.first_empty / T.upr, true, scan_only);
+        return encode_impl(ctx, a, res, nm, hs.first_empty / T.upr, true, scan_only, skip);
     }
     if (hs.err & DE_QUAL_SHORT) return rfq_fail(ctx, RFQ_E_UNPINNED, "a quality line is shorter than its sequence line (the reference reads past the string: undefined)");
     const uint32_t n_chunks = hs.n_chunks;
@@ -255,8 +319,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (nstreams == 2) HIPCHK(ctx, ctx->fetch(ctx->scan_end[1].data(), e2, (size_t)n_chunks * 8, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
         const size_t lim0 = nm ? nm->orig_n[0] : nbytes[0], lim1 = nm ? nm->orig_n[1] : nbytes[1];
-        for (auto& v : ctx->scan_end[0]) if (v > lim0) v = lim0;             // (a virtual terminator past an unterminated last line)
-        for (auto& v : ctx->scan_end[1]) if (v > lim1) v = lim1;
+        for (auto& v : ctx->scan_end[0]) { if (v > lim0) v = lim0; if (!nm) v -= skip[0]; }   // (a virtual terminator past an unterminated last line; offsets count from the stream's own first byte)
+        for (auto& v : ctx->scan_end[1]) { if (v > lim1) v = lim1; if (!nm) v -= skip[1]; }
         res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases;
         res->consumed1 = (size_t)ctx->scan_end[0].back(); res->consumed2 = nstreams == 2 ? (size_t)ctx->scan_end[1].back() : 0;
         ctx->timer.collect();
@@ -442,8 +506,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     for (auto& o : ctx->chunk_off) o += hdr_bytes;
     res->d_rfq = img; res->rfq_len = (size_t)(hs.total_image + hdr_bytes); res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases;
     const size_t lim[2] = { nm ? nm->orig_n[0] : nbytes[0], nm ? nm->orig_n[1] : nbytes[1] };
-    res->consumed1 = cons[0] > lim[0] ? lim[0] : cons[0];
-    res->consumed2 = nstreams == 2 ? (cons[1] > lim[1] ? lim[1] : cons[1]) : 0;
+    res->consumed1 = (cons[0] > lim[0] ? lim[0] : cons[0]) - (nm ? 0 : skip[0]);
+    res->consumed2 = nstreams == 2 ? (cons[1] > lim[1] ? lim[1] : cons[1]) - (nm ? 0 : skip[1]) : 0;
     res->h_chunk_off = ctx->chunk_off.data();
     return RFQ_OK;
 }

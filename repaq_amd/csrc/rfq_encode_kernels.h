@@ -20,12 +20,18 @@ struct Text {                    // the FASTQ streams of a batch and their line 
     uint32_t n_reads;            // reads in interleaved order (PE: 2 * pairs)
     uint32_t upr;                // reads per partition unit (1 SE, 2 PE)
 };
+// element s of the two-entry arrays above for a stream index that is only known per lane: a select between two kernel arguments (indexing
+// the argument struct dynamically makes the compiler fetch the pointer from memory - a dependent load in front of every access)
+__device__ __forceinline__ const uint8_t* t_fq(const Text& T, int s) { return s ? T.fq[1] : T.fq[0]; }
+__device__ __forceinline__ const uint32_t* t_lo(const Text& T, int s) { return s ? T.lo[1] : T.lo[0]; }
+__device__ __forceinline__ const uint32_t* t_ot(const Text& T, int s) { return s ? T.ot[1] : T.ot[0]; }
+__device__ __forceinline__ uint32_t t_n(const Text& T, int s) { return s ? T.n[1] : T.n[0]; }
 __device__ __forceinline__ void read_loc(const Text& T, uint32_t g, int& s, uint32_t& r) {
     if (T.paired == 1) { s = (int)(g & 1u); r = g >> 1; } else { s = 0; r = g; }
 }
-__device__ __forceinline__ uint32_t line_beg(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return T.lo[s][4 * (size_t)r + k]; }
-__device__ __forceinline__ uint32_t line_len(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); const uint32_t* p = T.lo[s] + 4 * (size_t)r + k; return p[1] - 1 - p[0]; }
-__device__ __forceinline__ const uint8_t* line_ptr(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return T.fq[s] + T.lo[s][4 * (size_t)r + k]; }
+__device__ __forceinline__ uint32_t line_beg(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return t_lo(T, s)[4 * (size_t)r + k]; }
+__device__ __forceinline__ uint32_t line_len(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r + k; return p[1] - 1 - p[0]; }
+__device__ __forceinline__ const uint8_t* line_ptr(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return t_fq(T, s) + t_lo(T, s)[4 * (size_t)r + k]; }
 
 struct ReadTab {                 // per-read arrays, indexed by g (interleaved order)
     uint32_t* len;               // sequence length
@@ -66,31 +72,35 @@ __device__ __forceinline__ uint32_t eq_mask4(uint32_t w, uint32_t pat) {   // bi
 __device__ __forceinline__ uint32_t eq_mask16(const uint4& q, uint32_t pat) {
     return eq_mask4(q.x, pat) | (eq_mask4(q.y, pat) << 4) | (eq_mask4(q.z, pat) << 8) | (eq_mask4(q.w, pat) << 12);
 }
-__global__ void k_nl_bitmap(const uint8_t* __restrict__ fq, uint32_t n, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ blkcnt, DevStatus* st) {
+// skip (< 16): leading bytes of the stream that do not belong to it (the stream starts at an unaligned address inside a larger text: the
+// pointer was rounded down to 16 bytes); they hold no line end and line 0 starts behind them.
+__global__ void k_nl_bitmap(const uint8_t* __restrict__ fq, uint32_t n, uint32_t skip, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ blkcnt, DevStatus* st) {
     const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t base = w * 64;
-    uint64_t m = 0; uint32_t cr = 0;
+    uint64_t m = 0, crm = 0; uint32_t cr = 0;
     if (base + 64 <= n) {
         const uint4* p = (const uint4*)(fq + base);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { uint4 q = p[k]; m |= (uint64_t)eq_mask16(q, 0x0A0A0A0Au) << (16 * k); cr |= eq_mask16(q, 0x0D0D0D0Du); }
+        for (int k = 0; k < 4; k++) { uint4 q = p[k]; m |= (uint64_t)eq_mask16(q, 0x0A0A0A0Au) << (16 * k); crm |= (uint64_t)eq_mask16(q, 0x0D0D0D0Du) << (16 * k); }
     } else if (base < n) {
-        for (uint32_t i = 0; i < 64 && base + i < n; i++) { uint8_t c = fq[base + i]; if (c == '\n') m |= 1ull << i; if (c == '\r') cr = 1; }
+        for (uint32_t i = 0; i < 64 && base + i < n; i++) { uint8_t c = fq[base + i]; if (c == '\n') m |= 1ull << i; if (c == '\r') crm |= 1ull << i; }
     }
+    if (w == 0 && skip) { const uint64_t keep = ~((1ull << skip) - 1ull); m &= keep; crm &= keep; }
+    cr = crm != 0;
     if (base < n) bitmap[w] = m;
     uint32_t tot; (void)block_excl_sum<uint32_t>((uint32_t)__popcll(m), &tot);
     if (threadIdx.x == 0) blkcnt[blockIdx.x] = tot;
     if (__any(cr != 0) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_HAS_CR);
 }
 // lo[rank+1] = position after the rank-th newline; lo[0] = 0.
-__global__ void k_line_offsets(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ blkbase, uint32_t n, uint32_t* __restrict__ lo) {
+__global__ void k_line_offsets(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ blkbase, uint32_t n, uint32_t skip, uint32_t* __restrict__ lo) {
     const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t base = w * 64;
     uint64_t m = base < n ? bitmap[w] : 0ull;
     uint32_t ex = block_excl_sum<uint32_t>((uint32_t)__popcll(m), (uint32_t*)nullptr);
     uint32_t rank = blkbase[blockIdx.x] + ex;
     while (m) { int b = __ffsll((long long)m) - 1; m &= m - 1; lo[rank + 1] = (uint32_t)(base + (uint32_t)b + 1); rank++; }
-    if (w == 0) lo[0] = 0;
+    if (w == 0) lo[0] = skip;
 }
 __global__ void k_line_tail(uint32_t* lo, uint32_t n_newlines, uint32_t n, int unterminated) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && unterminated) lo[n_newlines + 1] = n + 1;
@@ -214,7 +224,7 @@ __device__ __forceinline__ void stage_name_rows(const Text& T, uint8_t* rows, ui
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t jb = __shfl(nb, j0 + u), jl = __shfl(nl, j0 + u); const int js = __shfl(s, j0 + u);
-            take[u] = jl < NAME_CAP ? jl : NAME_CAP; src[u] = T.fq[js] + jb;
+            take[u] = jl < NAME_CAP ? jl : NAME_CAP; src[u] = t_fq(T, js) + jb;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = (uint32_t)l < take[u] ? src[u][l] : (uint8_t)0;
@@ -244,9 +254,9 @@ __device__ __forceinline__ void stage_name_rows_wide(const Text& T, uint8_t* row
         da[it] = (uint32_t)j * RT_ROW + 16u + 16u * part - (jb & 15u);
         v[it] = make_uint4(0, 0, 0, 0);
         if (ok[it]) {
-            const uint8_t* g = T.fq[js] + a;
-            if ((uint64_t)a + 16ull <= (uint64_t)T.n[js]) { const LdsU16 t = *(const LdsU16*)g; v[it] = make_uint4(t.a, t.b, t.c, t.d); }
-            else { uint32_t w[4] = { 0, 0, 0, 0 }; for (uint32_t b = 0; b < 16 && a + b < T.n[js]; b++) w[b >> 2] |= (uint32_t)g[b] << (8 * (b & 3)); v[it] = make_uint4(w[0], w[1], w[2], w[3]); }
+            const uint8_t* g = t_fq(T, js) + a;
+            if ((uint64_t)a + 16ull <= (uint64_t)t_n(T, js)) { const LdsU16 t = *(const LdsU16*)g; v[it] = make_uint4(t.a, t.b, t.c, t.d); }
+            else { uint32_t w[4] = { 0, 0, 0, 0 }; for (uint32_t b = 0; b < 16 && a + b < t_n(T, js); b++) w[b >> 2] |= (uint32_t)g[b] << (8 * (b & 3)); v[it] = make_uint4(w[0], w[1], w[2], w[3]); }
         }
     }
 #pragma unroll
@@ -277,21 +287,21 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
     uint32_t nb = 0, nl = 0, sl = 0, tl = 0, ql = 0, tb = 0; int s = 0;
     if (valid) {
         uint32_t r; read_loc(T, g, s, r);
-        const uint32_t* p = T.lo[s] + 4 * (size_t)r;
+        const uint32_t* p = t_lo(T, s) + 4 * (size_t)r;
         const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
         nb = p0; nl = p1 - 1 - p0; sl = p2 - 1 - p1; tl = p3 - 1 - p2; ql = p4 - 1 - p3; tb = p2;
     }
     uint8_t* rows = s_names + (size_t)w * 64 * RT_ROW + 16;              // (+16: a row's name begins 16 bytes into the row)
     // the strand line's first four bytes (almost always just "+"), fetched beside the names
     uint32_t st4 = 0;
-    if (adj && valid) { const uint8_t* sp = T.fq[s] + tb; for (uint32_t i = 0; i < 4 && i < tl; i++) st4 |= (uint32_t)sp[i] << (8 * i); }
+    if (adj && valid) { const uint8_t* sp = t_fq(T, s) + tb; for (uint32_t i = 0; i < 4 && i < tl; i++) st4 |= (uint32_t)sp[i] << (8 * i); }
     stage_name_rows_wide(T, rows - 16, nb, nl, s, l);
     __syncthreads();
     uint32_t err = 0; Meta m; m.ok = 0; m.name1_len = 0; m.name2_off = 0; m.x = 0; m.y = 0; m.tile = 0; m.lane = 0;
     if (valid) {
         if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
         if (ql < sl) err |= DE_QUAL_SHORT;
-        m = nl <= RT_NAME_CAP ? dev_parse_name(rows + l * RT_ROW, nl) : dev_parse_name(T.fq[s] + nb, nl);
+        m = nl <= RT_NAME_CAP ? dev_parse_name(rows + l * RT_ROW, nl) : dev_parse_name(t_fq(T, s) + nb, nl);
         R.len[g] = sl; R.stored[g] = sl;
         R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
     }
@@ -309,19 +319,19 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
             if (tl == ptl) b |= 1u << 3;
             if (tl == ptl) {                                               // strand bytes
                 bool eq = st4 == pst4;
-                if (eq && tl > 4) { const uint8_t* a = T.fq[s] + tb; const uint8_t* c = T.fq[ps] + ptb; for (uint32_t i = 4; i < tl && eq; i++) eq = a[i] == c[i]; }
+                if (eq && tl > 4) { const uint8_t* a = t_fq(T, s) + tb; const uint8_t* c = t_fq(T, ps) + ptb; for (uint32_t i = 4; i < tl && eq; i++) eq = a[i] == c[i]; }
                 if (eq) b |= 1u << 4;
             }
             if ((uint32_t)m.lane == plane) b |= 1u << 5;
             if ((uint32_t)m.tile == ptile) b |= 1u << 6;
             const bool inl = nl <= RT_NAME_CAP && pnl <= RT_NAME_CAP;        // both names staged in LDS (else compare in global memory)
             const uint32_t ra = (uint32_t)l * RT_ROW, rb = (uint32_t)(l - 1) * RT_ROW;
-            const uint8_t* ga = T.fq[s] + nb; const uint8_t* gb = T.fq[ps] + pnb;
+            const uint8_t* ga = t_fq(T, s) + nb; const uint8_t* gb = t_fq(T, ps) + pnb;
             if (n1 == pn1 && (inl ? lds_bytes_eq(rows, ra, rb, n1) : bytes_eq(ga, n1, gb, pn1))) b |= 1u << 7;
             if (n2 == pn2 && (inl ? lds_bytes_eq(rows, ra + n2o, rb + pn2o, n2) : bytes_eq(ga + n2o, n2, gb + pn2o, pn2))) b |= 1u << 8;
             if (l > 1 && pinfo) {                                              // PE: the previous pair's mate of the same side
                 const uint32_t qn2 = qnl - qn2o; const bool inl2 = nl <= RT_NAME_CAP && qnl <= RT_NAME_CAP;
-                if (n2 == qn2 && (inl2 ? lds_bytes_eq(rows, ra + n2o, (uint32_t)(l - 2) * RT_ROW + qn2o, n2) : bytes_eq(ga + n2o, n2, T.fq[qs] + qnb + qn2o, qn2))) b |= 1u << 9;
+                if (n2 == qn2 && (inl2 ? lds_bytes_eq(rows, ra + n2o, (uint32_t)(l - 2) * RT_ROW + qn2o, n2) : bytes_eq(ga + n2o, n2, t_fq(T, qs) + qnb + qn2o, qn2))) b |= 1u << 9;
             }
             adj[g] = (uint16_t)b;
             if (pinfo && (g & 1u)) {                                           // (g-1, g) is a pair: a = R1's name2, b = R2's name2
@@ -643,19 +653,19 @@ __global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* 
     for (uint32_t gb = f + (blockIdx.x * wpb + (uint32_t)w) * 64u; gb < e; gb += gridDim.x * wpb * 64u) {      // wave-uniform
         const uint32_t g = gb + (uint32_t)l; const bool v = g < e;
         uint32_t nb = 0, nl = 0, stb = 0, stl = 0; int s = 0;
-        if (v) { uint32_t r; read_loc(T, g, s, r); const uint32_t* p = T.lo[s] + 4 * (size_t)r; nb = p[0]; nl = p[1] - 1 - nb; stb = p[2]; stl = p[3] - 1 - stb; }
+        if (v) { uint32_t r; read_loc(T, g, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r; nb = p[0]; nl = p[1] - 1 - nb; stb = p[2]; stl = p[3] - 1 - stb; }
         wave_lds_sync();                                                     // rows are private to the wave: previous group's rows are no longer read
         stage_name_rows(T, rows, nb, nl, s, l);
         wave_lds_sync();
         if (v) {
-            const uint8_t* nm = nl <= NAME_CAP ? rows + l * NAME_STRIDE : T.fq[s] + nb;
+            const uint8_t* nm = nl <= NAME_CAP ? rows + l * NAME_STRIDE : t_fq(T, s) + nb;
             const uint32_t n1l = R.name1_len[g], n2o = R.name2_off[g], n2l = nl - n2o;
             uint32_t b = 0;
             if (R.len[g] == len0) b |= 1u << 0;
             if (n1l == n1l0) b |= 1u << 1;
             if (n2l == n2l0) b |= 1u << 2;
             if (stl == stl0) b |= 1u << 3;
-            if (bytes_eq(st0, stl0, T.fq[s] + stb, stl)) b |= 1u << 4;
+            if (bytes_eq(st0, stl0, t_fq(T, s) + stb, stl)) b |= 1u << 4;
             if (R.lane[g] == lane0) b |= 1u << 5;
             if (R.tile[g] == tile0) b |= 1u << 6;
             if (bytes_eq(nm0, n1l0, nm, n1l)) b |= 1u << 7;
@@ -786,10 +796,6 @@ static __device__ __noinline__ uint4 ld16_edge(const uint8_t* __restrict__ base,
     for (int b = 0; b < 16; b++) { const long long a = off + b; if (a >= 0 && (uint64_t)a < n) w[b >> 2] |= (uint32_t)base[a] << (8 * (b & 3)); }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
-__device__ __forceinline__ void ld16_guard(const uint8_t* __restrict__ base, long long off, uint64_t n, uint32_t (&w)[4]) {
-    if (off >= 0 && (uint64_t)off + 16ull <= n) { const LdsU16 v = *(const LdsU16*)(base + off); w[0] = v.a; w[1] = v.b; w[2] = v.c; w[3] = v.d; }
-    else { const uint4 v = ld16_edge(base, off, n); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-}
 // four bases -> (four 2-bit codes in one byte, four N bits, "a byte that is neither A/C/G/T nor N" flags as 0xFF per byte)
 __device__ __forceinline__ void ov2_pack_r1(uint32_t w, uint32_t& code, uint32_t& nbits, uint32_t& bad) {
     const uint32_t idx = (w >> 1) & 0x03030303u;
@@ -827,7 +833,7 @@ __global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, 
         const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0;
         if (p < n_pairs) {
             const uint32_t g = 2u * p;
-            if (C.il[R.chunk[g]]) { len1 = (int)R.len[g]; len2 = (int)R.len[g + 1]; uint32_t r; read_loc(T, g, s1, r); q1 = T.lo[s1][4 * (size_t)r + 1]; read_loc(T, g + 1, s2, r); q2 = T.lo[s2][4 * (size_t)r + 1]; }
+            if (C.il[R.chunk[g]]) { len1 = (int)R.len[g]; len2 = (int)R.len[g + 1]; uint32_t r; read_loc(T, g, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, g + 1, s2, r); q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }
         }
         const bool slow = len1 >= 0 && ((uint32_t)len1 > OV2_CAP || (uint32_t)len2 > OV2_CAP), fast = len1 >= 0 && !slow;
         const int mx = wave_max(fast ? (len1 > len2 ? len1 : len2) : 0);
@@ -836,20 +842,28 @@ __global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, 
         // ---- pack: task t = (row, 16-base group); rows 0..63 R1, 64..127 RC2; four loads in flight per lane
         const uint32_t G = ((uint32_t)mx + 15u) >> 4, ntasks = 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 2048, G <= 16
         for (uint32_t t0 = 0; t0 < ntasks; t0 += 256u) {
-            uint32_t v[4][4]; uint32_t row[4], k[4]; int L[4]; bool on[4];
+            uint32_t v[4][4]; uint32_t row[4], k[4]; int L[4]; bool on[4], edge[4]; const uint8_t* src[4]; long long at[4]; uint32_t lim[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)l; row[u] = t < ntasks ? (t * ginv) >> 16 : 0u; k[u] = t - row[u] * G;
-                const int src = (int)(row[u] & 63u); const bool second = row[u] >= 64u;
-                const int a1 = __shfl(len1, src), a2 = __shfl(len2, src); const uint32_t o1 = __shfl(q1, src), o2 = __shfl(q2, src);
-                const int z1 = __shfl(s1, src), z2 = __shfl(s2, src); const bool f = __shfl(fast ? 1 : 0, src) != 0;
+                const int srcl = (int)(row[u] & 63u); const bool second = row[u] >= 64u;
+                const int a1 = __shfl(len1, srcl), a2 = __shfl(len2, srcl); const uint32_t o1 = __shfl(q1, srcl), o2 = __shfl(q2, srcl);
+                const int z1 = __shfl(s1, srcl), z2 = __shfl(s2, srcl); const bool f = __shfl(fast ? 1 : 0, srcl) != 0;
                 L[u] = second ? a2 : a1; on[u] = t < ntasks && f && (int)(16u * k[u]) < L[u];
+                const int z = second ? z2 : z1; src[u] = t_fq(T, z); lim[u] = t_n(T, z);
+                // (RC2's last group starts before the line: those bytes land beyond len2 and are never compared)
+                at[u] = second ? (long long)o2 + L[u] - 16ll * (long long)k[u] - 16ll : (long long)o1 + 16ll * (long long)k[u];
+                edge[u] = on[u] && !(at[u] >= 0 && (unsigned long long)at[u] + 16ull <= (unsigned long long)lim[u]);
+            }
+            // the four wide loads of a lane are in flight together; a group that touches the first / last bytes of the text is fetched byte-wise
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
                 v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0;
-                if (on[u]) {
-                    const int z = second ? z2 : z1;        // (RC2's last group starts before the line: those bytes land beyond len2 and are never compared)
-                    const long long at = second ? (long long)o2 + L[u] - 16ll * (long long)k[u] - 16ll : (long long)o1 + 16ll * (long long)k[u];
-                    ld16_guard(T.fq[z], at, (uint64_t)T.n[z], v[u]);
-                }
+                if (on[u] && !edge[u]) { const LdsU16 x = *(const LdsU16*)(src[u] + at[u]); v[u][0] = x.a; v[u][1] = x.b; v[u][2] = x.c; v[u][3] = x.d; }
+            }
+            if (__any(edge[0] || edge[1] || edge[2] || edge[3])) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], at[u], (uint64_t)lim[u]); v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -909,7 +923,7 @@ __global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, 
         unsigned long long sm = __ballot(slow || bad);
         while (sm) {
             const int j = __ffsll((long long)sm) - 1; sm &= sm - 1;
-            const uint8_t* a = T.fq[__shfl(s1, j)] + __shfl(q1, j); const uint8_t* b = T.fq[__shfl(s2, j)] + __shfl(q2, j);
+            const uint8_t* a = t_fq(T, __shfl(s1, j)) + __shfl(q1, j); const uint8_t* b = t_fq(T, __shfl(s2, j)) + __shfl(q2, j);
             const int r = wave_overlap(a, __shfl(len1, j), b, __shfl(len2, j));
             if (l == j) ov = r;
         }
@@ -1089,7 +1103,7 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
             m_qdst = R.pq[g] - pq0; m_sdst = R.pv[g].d - ps0;             // (valid for the sentinel too)
             if (tid < GT_READS && g < ge) {
                 uint32_t rr; read_loc(T, g, m_st, rr);
-                const uint32_t* p = T.lo[m_st] + 4 * (size_t)rr;
+                const uint32_t* p = t_lo(T, m_st) + 4 * (size_t)rr;
                 m_p1 = p[1]; m_p3 = p[3]; s_nx[tid] = p[4];                  // start of the record after mine, in my stream
                 m_len = R.len[g]; m_rc = il && ((g - f) & 1u);
                 if (m_rc && enc) m_ov = (int)ovb[g >> 1] - shift;
@@ -1139,15 +1153,15 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
         // ---- stage the spans: aligned 16-byte loads (the very last group of a stream may not be fully inside the buffer)
         for (int st = 0; st < (two ? 2 : 1); st++) {
             const uint32_t nb = span_end[st] - a0[st]; const uint32_t ng = (nb + 15) / 16; const uint32_t lb = st ? base1 : 0u;
-            const uint8_t* src = T.fq[st] + a0[st];
+            const uint8_t* src = t_fq(T, st) + a0[st];
             // LDS-DMA (global_load_lds_dwordx4): every lane names its own 16 global bytes, a wave's 64 groups land contiguously at a
             // wave-uniform LDS address - no staging registers, no ds_write pass; everything is in flight until the barrier.  Only
             // the very last group of a stream may reach past the buffer: it is copied byte-wise.
-            const uint32_t nfull = (uint64_t)a0[st] + 16ull * ng <= (uint64_t)T.n[st] ? ng : ng - 1u;
+            const uint32_t nfull = (uint64_t)a0[st] + 16ull * ng <= (uint64_t)t_n(T, st) ? ng : ng - 1u;
             uint4* const l4 = s_text4 + 1 + lb / 16;
             for (uint32_t i = tid; i < nfull; i += blockDim.x)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i), (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
-            if (nfull < ng && tid == 0) for (uint32_t k = 0; k < 16 && a0[st] + 16 * nfull + k < T.n[st]; k++) s_text[lb + 16 * nfull + k] = src[16 * (size_t)nfull + k];
+            if (nfull < ng && tid == 0) for (uint32_t k = 0; k < 16 && a0[st] + 16 * nfull + k < t_n(T, st); k++) s_text[lb + 16 * nfull + k] = src[16 * (size_t)nfull + k];
         }
         __syncthreads();
         if (DBG) { tk3 = clock64(); a_stage += tk3 - tk2; }

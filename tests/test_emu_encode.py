@@ -125,3 +125,13 @@ def test_scan_then_chunk_parallel_encode_equals_one_shot(label):
 
 def test_overlap_search_paths(codec):
     E.overlap_search_paths(codec)
+
+
+def test_sliced_calls_equal_one_shot():
+    """Texts of >= 4 GiB per stream are encoded slice by slice, images of > ~1.6 G bases decoded range by range (32-bit offsets inside one
+    pass).  RFQ_SLICE_BYTES / RFQ_SLICE_BASES shrink the slices so that the same code runs on small inputs (subprocess: read once)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RFQ_SLICE_BYTES="150000", RFQ_SLICE_BASES="60000", PYTHONPATH=os.pathsep.join([E.ROOT, os.path.join(E.ROOT, "tests"), os.path.join(E.ROOT, "tests", "golden")]))
+    r = subprocess.run([sys.executable, os.path.join(E.ROOT, "tests", "_slice_probe.py"), E.build_emu()], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "SLICES_OK 5" in r.stdout, r.stdout + r.stderr

@@ -62,3 +62,37 @@ def _offset_of_record(arr, rec):
         if seen + nl.size >= want:
             return pos + int(nl[want - seen - 1]) + 1
         seen += nl.size; pos += slab
+
+
+def test_cfg3_share_pe150_2x8GB_chunk_table():
+    """One GPU's share of BASELINE.json configs[3] (PE150 2 x 64 GB over 8 GPUs = 2 x 8 GB per GPU) as ONE logical encode and decode: the
+    text is >= 4 GiB per stream, so the call runs slice by slice inside the library.  Every chunk image is checked against the
+    reference's own encoding of the same two files (crc32 + size of each of the 6,719 chunks, tests/golden/big.json), the whole image
+    against its md5, and decode(encode(x)) == x for both mates in HBM."""
+    import zlib
+    import torch
+    from repaq_amd import RfqCodec, PE_TWO_FILES
+    big = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big.json"))).get("cfg3_share")
+    if not big:
+        pytest.skip("no cfg3 share golden committed")
+    a1, a2 = O.gen_np(O.NOVA_PE150, big["pairs"], seed=big["seed"])
+    n1, n2 = int(a1.size), int(a2.size)
+    assert [n1, n2] == big["fq_bytes"] and n1 > (1 << 32)
+    t1 = torch.from_numpy(a1).cuda(); t2 = torch.from_numpy(a2).cuda()
+    del a1, a2
+    codec = RfqCodec(device=0)
+    r = codec.encode(t1.data_ptr(), n1, t2.data_ptr(), n2, PE_TWO_FILES, chunk_bases=1_000_000)
+    assert r.n_chunks == big["n_chunks"] and r.rfq_len == big["rfq_len"] and r.consumed1 == n1 and r.consumed2 == n2 and r.n_reads == 2 * big["pairs"]
+    offs = [r.h_chunk_off[i] for i in range(r.n_chunks + 1)]
+    assert offs[0] == big["header_len"] and [offs[i + 1] - offs[i] for i in range(r.n_chunks)] == big["chunk_len"]
+    img = codec.dev_get(r.d_rfq, r.rfq_len)
+    bad = [i for i in range(r.n_chunks) if "%08x" % (zlib.crc32(img[offs[i]:offs[i + 1]]) & 0xFFFFFFFF) != big["chunk_crc32"][i]]
+    assert not bad, "chunks differ from the reference: %s ..." % bad[:8]
+    assert hashlib.md5(img).hexdigest() == big["rfq_md5"]
+    del img
+    # decode range by range into caller buffers, with the encoder's chunk index; compared in HBM
+    o1 = torch.empty(n1 + 64, dtype=torch.uint8, device="cuda"); o2 = torch.empty(n2 + 64, dtype=torch.uint8, device="cuda")
+    d = codec.decode(r.d_rfq, r.rfq_len, split_pe=True, d_out1=o1.data_ptr(), cap1=n1 + 64, d_out2=o2.data_ptr(), cap2=n2 + 64, chunk_off=r.h_chunk_off, n_chunks=r.n_chunks)
+    assert d.n1 == n1 and d.n2 == n2 and d.n_reads == 2 * big["pairs"] and d.n_chunks == r.n_chunks
+    assert torch.equal(o1[:n1], t1) and torch.equal(o2[:n2], t2)
+    codec.close()
