@@ -170,6 +170,8 @@ __device__ __forceinline__ void lds_get16(const uint8_t* base, uint32_t a, uint3
     const LdsU16 v = *(const LdsU16*)(base + a); w[0] = v.a; w[1] = v.b; w[2] = v.c; w[3] = v.d;
 }
 __device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) { return ((const LdsU4*)(base + a))->a; }
+struct __attribute__((packed, aligned(1))) LdsU8 { unsigned long long a; };
+__device__ __forceinline__ unsigned long long lds_get8(const uint8_t* base, uint32_t a) { return ((const LdsU8*)(base + a))->a; }
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 // byte-wise full mask (0xFF per byte of w equal to the pattern byte)
 __device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {

@@ -227,7 +227,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     DChunk* CHm = B[DB_CHUNKS].as<DChunk>();
     // (RFQ_SLICE_BASES: test aid - ranges of that many bases, so that the slicing logic runs on small images)
     static const uint64_t slice_env = getenv("RFQ_SLICE_BASES") ? (uint64_t)atoll(getenv("RFQ_SLICE_BASES")) : 0;
-    const uint64_t slice_bases = slice_env ? slice_env : 1000000000ull, one_pass = slice_env ? slice_env : 1600000000ull;
+    const uint64_t slice_bases = slice_env ? slice_env : 1500000000ull, one_pass = slice_env ? slice_env : 0xFFFFFFF0ull;   // (a pass whose text turns out to be >= 4 GiB is redone in ranges)
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
     if (tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {

@@ -381,7 +381,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, 1, cbits, cfail, (const uint32_t*)redo);
         hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, 1, (const uint32_t*)cbits, (const uint32_t*)cfail, (const uint32_t*)redo);
     }
-    if (is_pe) { const uint32_t np = reads_used / 2; hipLaunchKernelGGL(k_overlap, dim3(std::min<uint32_t>((np + 63) / 64, 65535u * 4u)), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np); }
+    if (is_pe) {
+        const uint32_t np = reads_used / 2; const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
+        if (tune & 64) {     // per-phase cycle counters (profiling aid)
+            unsigned long long* dbg = (unsigned long long*)B[B_HSTATS].p + 600; (void)hipMemsetAsync(dbg, 0, 64, S);
+            hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np, dbg, 0);
+            unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+            if (h[5]) fprintf(stderr, "[overlap dbg] waves=%llu avg cycles/wave: meta=%llu pack=%llu fwd=%llu bwd=%llu slow+write=%llu verifies/wave=%.1f\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5], (double)h[6]/h[5]);
+        } else hipLaunchKernelGGL(k_overlap<false>, dim3(ob), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np, (unsigned long long*)nullptr, (tune >> 8) & 7);   // (tune bits 8-10: ablation switches, results invalid)
+    }
     hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, B[B_PVIN].as<U4>(), n_reads);
     scan_exclusive<U4>(S, B[B_PVIN].as<U4>(), R.pv, n_reads, B[B_SCANTMP].as<U4>(), 1);
     hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks);

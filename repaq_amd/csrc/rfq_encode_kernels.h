@@ -788,7 +788,7 @@ __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int 
 #define OV2_CROW 68u              // code row: 64 bytes + 4 of slack for the last unaligned word; 17 dwords, so that lanes reading their own rows at one offset hit 64 different banks
 #define OV2_NROW 36u              // N-bit row: 32 bytes + 4; 9 dwords
 #define OV2_WAVE_BYTES (128u * (OV2_CROW + OV2_NROW))
-#define OV2_BATCH 8               // candidates filtered per round
+#define OV2_BATCH 16              // candidates filtered per round (one 64-bit window of the row)
 __device__ __forceinline__ uint32_t bfe_u32(uint32_t v, uint32_t off, uint32_t wid) { return (v >> off) & ((1u << wid) - 1u); }
 // 16 bytes at base + off (any alignment); bytes outside [0, n) read as 0
 static __device__ __noinline__ uint4 ld16_edge(const uint8_t* __restrict__ base, long long off, uint64_t n) {
@@ -823,102 +823,128 @@ __device__ __forceinline__ bool ov2_verify(const uint8_t* ac, const uint8_t* an,
     return !__any(diff != 0);
 }
 // 256 pairs per block, 64 per wave.  Only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
-__global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int8_t* __restrict__ ovb, uint32_t n_pairs) {
+template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int8_t* __restrict__ ovb, uint32_t n_pairs, unsigned long long* dbg, int abl) {
     __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4)]; __shared__ uint32_t s_bad[4][2];
+    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a_meta = 0, a_pack = 0, a_fwd = 0, a_bwd = 0, a_slow = 0; uint32_t n_ver = 0;
     if (!(D->flags & H_PE_OVERLAP)) return;                     // uniform
     const int shift = D->overlap_shift; const int l = lane_id(), w = wave_id();
     uint8_t* const c1 = (uint8_t*)(s_rows + (size_t)w * (OV2_WAVE_BYTES / 4)); uint8_t* const c2 = c1 + 64u * OV2_CROW;
     uint8_t* const n1 = c2 + 64u * OV2_CROW; uint8_t* const n2 = n1 + 64u * OV2_NROW;
     for (uint32_t p0 = (blockIdx.x * 4u + (uint32_t)w) * 64u; p0 < n_pairs; p0 += gridDim.x * 256u) {       // wave-uniform
+        if (DBG) k0 = clock64();
         const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0;
         if (p < n_pairs) {
             const uint32_t g = 2u * p;
-            if (C.il[R.chunk[g]]) { len1 = (int)R.len[g]; len2 = (int)R.len[g + 1]; uint32_t r; read_loc(T, g, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, g + 1, s2, r); q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }
+            if (!(abl & 4) && C.il[R.chunk[g]]) { len1 = (int)R.len[g]; len2 = (int)R.len[g + 1]; uint32_t r; read_loc(T, g, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, g + 1, s2, r); q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }
         }
         const bool slow = len1 >= 0 && ((uint32_t)len1 > OV2_CAP || (uint32_t)len2 > OV2_CAP), fast = len1 >= 0 && !slow;
         const int mx = wave_max(fast ? (len1 > len2 ? len1 : len2) : 0);
         if (l < 2) s_bad[w][l] = 0;
-        wave_lds_sync();                                        // the previous round's rows are no longer read
-        // ---- pack: task t = (row, 16-base group); rows 0..63 R1, 64..127 RC2; four loads in flight per lane
-        const uint32_t G = ((uint32_t)mx + 15u) >> 4, ntasks = 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 2048, G <= 16
-        for (uint32_t t0 = 0; t0 < ntasks; t0 += 256u) {
-            uint32_t v[4][4]; uint32_t row[4], k[4]; int L[4]; bool on[4], edge[4]; const uint8_t* src[4]; long long at[4]; uint32_t lim[4];
+        // the rows are OR-ed together from 16-base pieces below: start from zero (the previous round's rows are no longer read)
+        wave_lds_sync();
+        { uint4* z = (uint4*)c1; for (uint32_t i = (uint32_t)l; i < OV2_WAVE_BYTES / 16u; i += 64u) z[i] = make_uint4(0, 0, 0, 0); }
+        wave_lds_sync();
+        if (DBG) { k1 = clock64(); a_meta += k1 - k0; }
+        // ---- pack: task t = (row, ALIGNED 16-byte group of the text that holds part of the row's sequence line); rows 0..63 R1, 64..127 RC2.
+        // Consecutive lanes take consecutive groups of one line: every load is an aligned, coalesced dwordx4 (a dwordx4 at an odd address -
+        // one per 16 bases of the line itself - keeps the texture addresser busy for hundreds of cycles).  A group's 16 bases land at an
+        // arbitrary base position of the row: their codes (32 bits) and N bits (16 bits) are shifted into place and OR-ed into the row.
+        const uint32_t G = ((uint32_t)mx + 15u + 15u) >> 4, ntasks = 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 4096, G <= 17
+        for (uint32_t t0 = 0; t0 < ((abl & 2) ? 0u : ntasks); t0 += 256u) {
+            uint32_t v[4][4]; uint32_t row[4]; int L[4], pos0[4]; bool on[4], edge[4]; const uint8_t* src[4]; uint32_t at[4], lim[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)l; row[u] = t < ntasks ? (t * ginv) >> 16 : 0u; k[u] = t - row[u] * G;
+                const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)l; row[u] = t < ntasks ? (t * ginv) >> 16 : 0u; const uint32_t j = t - row[u] * G;
                 const int srcl = (int)(row[u] & 63u); const bool second = row[u] >= 64u;
                 const int a1 = __shfl(len1, srcl), a2 = __shfl(len2, srcl); const uint32_t o1 = __shfl(q1, srcl), o2 = __shfl(q2, srcl);
                 const int z1 = __shfl(s1, srcl), z2 = __shfl(s2, srcl); const bool f = __shfl(fast ? 1 : 0, srcl) != 0;
-                L[u] = second ? a2 : a1; on[u] = t < ntasks && f && (int)(16u * k[u]) < L[u];
+                L[u] = second ? a2 : a1; const uint32_t q = second ? o2 : o1, m = q & 15u;
+                at[u] = (q & ~15u) + 16u * j;                              // the group's offset in its stream
+                on[u] = t < ntasks && f && at[u] < q + (uint32_t)L[u];
                 const int z = second ? z2 : z1; src[u] = t_fq(T, z); lim[u] = t_n(T, z);
-                // (RC2's last group starts before the line: those bytes land beyond len2 and are never compared)
-                at[u] = second ? (long long)o2 + L[u] - 16ll * (long long)k[u] - 16ll : (long long)o1 + 16ll * (long long)k[u];
-                edge[u] = on[u] && !(at[u] >= 0 && (unsigned long long)at[u] + 16ull <= (unsigned long long)lim[u]);
+                // base position (in the row) of the group's first byte once the row's orientation is applied: R1 as it stands, R2 back to front
+                pos0[u] = second ? L[u] - 16 * (int)j + (int)m - 16 : 16 * (int)j - (int)m;
+                edge[u] = on[u] && (unsigned long long)at[u] + 16ull > (unsigned long long)lim[u];
             }
-            // the four wide loads of a lane are in flight together; a group that touches the first / last bytes of the text is fetched byte-wise
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0;
-                if (on[u] && !edge[u]) { const LdsU16 x = *(const LdsU16*)(src[u] + at[u]); v[u][0] = x.a; v[u][1] = x.b; v[u][2] = x.c; v[u][3] = x.d; }
+                if (on[u] && !edge[u]) { const uint4 x = *(const uint4*)(src[u] + at[u]); v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; }
             }
             if (__any(edge[0] || edge[1] || edge[2] || edge[3])) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], at[u], (uint64_t)lim[u]); v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; }
+                for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], (long long)at[u], (uint64_t)lim[u]); v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (!on[u]) continue;
                 const bool second = row[u] >= 64u; const uint32_t pr = row[u] & 63u;
-                uint32_t cw = 0, nw = 0;
+                uint32_t cw = 0, nw = 0, badb = 0;                          // 16 codes, 16 N bits, 16 "neither A/C/G/T nor N" bits - byte b of the (re-oriented) group at bit b
                 if (!second) {
-                    uint32_t bad = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { uint32_t c, nb, b; ov2_pack_r1(v[u][i], c, nb, b); cw |= c << (8 * i); nw |= nb << (4 * i);
-                        if (b) { const int left = L[u] - (int)(16u * k[u]) - 4 * i; if (left < 4) b &= left > 0 ? (1u << (8 * left)) - 1u : 0u; bad |= b; } }
-                    if (bad) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
-                    *(uint32_t*)(c1 + pr * OV2_CROW + 4u * k[u]) = cw; *(uint16_t*)(n1 + pr * OV2_NROW + 2u * k[u]) = (uint16_t)nw;
+                    for (int i = 0; i < 4; i++) { uint32_t c, nb, bd; ov2_pack_r1(v[u][i], c, nb, bd); cw |= c << (8 * i); nw |= nb << (4 * i); if (bd) badb |= (((bd & 0x01010101u) * 0x01020408u) >> 24) << (4 * i); }
                 } else {
                     const uint32_t x[4] = { bswap32(v[u][3]), bswap32(v[u][2]), bswap32(v[u][1]), bswap32(v[u][0]) };
 #pragma unroll
                     for (int i = 0; i < 4; i++) { uint32_t c, nb; ov2_pack_rc(x[i], c, nb); cw |= c << (8 * i); nw |= nb << (4 * i); }
-                    *(uint32_t*)(c2 + pr * OV2_CROW + 4u * k[u]) = cw; *(uint16_t*)(n2 + pr * OV2_NROW + 2u * k[u]) = (uint16_t)nw;
                 }
+                // keep the bases whose position lies inside the read, drop the `lo` leading ones, shift into place
+                const int lo = pos0[u] < 0 ? -pos0[u] : 0, hi = L[u] - pos0[u] < 16 ? L[u] - pos0[u] : 16;
+                if (hi <= lo) continue;
+                const uint32_t vm = ((hi >= 16 ? 0xFFFFu : (1u << hi) - 1u) >> lo) << lo;
+                uint32_t sp = vm; sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu; sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
+                cw = (cw & (sp * 3u)) >> (2 * lo); nw = (nw & vm) >> lo;
+                if (badb & vm) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
+                const uint32_t p = (uint32_t)(pos0[u] + lo);
+                uint32_t* const crow = (uint32_t*)((second ? c2 : c1) + pr * OV2_CROW); uint32_t* const nrow = (uint32_t*)((second ? n2 : n1) + pr * OV2_NROW);
+                const unsigned long long cv = (unsigned long long)cw << ((2u * p) & 31u), nv = (unsigned long long)nw << (p & 31u);
+                if ((uint32_t)cv) atomicOr(&crow[(2u * p) >> 5], (uint32_t)cv);
+                if ((uint32_t)(cv >> 32)) atomicOr(&crow[((2u * p) >> 5) + 1u], (uint32_t)(cv >> 32));
+                if ((uint32_t)nv) atomicOr(&nrow[p >> 5], (uint32_t)nv);
+                if ((uint32_t)(nv >> 32)) atomicOr(&nrow[(p >> 5) + 1u], (uint32_t)(nv >> 32));
             }
         }
         wave_lds_sync();
+        if (DBG) { k2 = clock64(); a_pack += k2 - k1; }
         const bool bad = fast && ((s_bad[w][l >> 5] >> (l & 31)) & 1u);
         const bool go = fast && !bad; const int minlen = len1 < len2 ? len1 : len2;
         const uint8_t* const r1c = c1 + (uint32_t)l * OV2_CROW; const uint8_t* const r2c = c2 + (uint32_t)l * OV2_CROW;
-        int ov = 0; bool done = !go || minlen < 12;
+        int ov = 0; bool done = !go || minlen < 12 || (abl & 1);
         const int omax = wave_max(done ? 0 : minlen);
         const uint32_t head1 = lds_get4(r1c, 0) & 0xFFFFFFu, head2 = lds_get4(r2c, 0) & 0xFFFFFFu;
 #pragma unroll 1
         for (int dir = 0; dir < 2; dir++) {                     // 0: R1 tail == RC2 head (+o), 1: RC2 tail == R1 head (-o)
             const uint8_t* const wc = dir ? r2c : r1c; const int wl = dir ? len2 : len1; const uint32_t head = dir ? head1 : head2;
+            if (DBG) { k3 = clock64(); if (dir) a_fwd += k3 - k2; }
             if (!__any(!done)) break;
             const int wlc = go ? wl : 0;
             for (int o0 = 12; o0 <= omax; o0 += OV2_BATCH) {
-                // branch-free filter of OV2_BATCH candidates: all their LDS reads are in flight together
-                uint32_t wv[OV2_BATCH], hits = 0;
+                // the filter of OV2_BATCH = 16 candidates from ONE 64-bit window of the row: candidate o0 + u tests the 24 code bits from base
+                // wl - o0 - u on; the lowest start (u = 15) and the highest (u = 0) are 30 bits apart, + 24 bits + the start's 6-bit phase < 64
+                const int pb = wlc - o0 - (OV2_BATCH - 1); const uint32_t byte = (uint32_t)(pb < 0 ? 0 : pb) >> 2;
+                const unsigned long long w64 = lds_get8(wc, byte);
+                const int sh0 = 2 * (wlc - o0) - 8 * (int)byte;             // bit offset of candidate u = 0 inside the window; u-th: sh0 - 2u
+                uint32_t hits = 0;
 #pragma unroll
-                for (int u = 0; u < OV2_BATCH; u++) { const int pp = wlc - (o0 + u); wv[u] = lds_get4(wc, (uint32_t)(pp < 0 ? 0 : pp) >> 2); }
-#pragma unroll
-                for (int u = 0; u < OV2_BATCH; u++) { const int pp = wlc - (o0 + u); hits |= ((bfe_u32(wv[u], 2u * ((uint32_t)pp & 3u), 24u) == head) & (o0 + u <= minlen) ? 1u : 0u) << u; }
+                for (int u = 0; u < OV2_BATCH; u++) { const uint32_t c = (uint32_t)(w64 >> ((uint32_t)(sh0 - 2 * u) & 63u)); hits |= ((((c ^ head) & 0xFFFFFFu) == 0u) ? 1u : 0u) << u; }
+                const int nval = minlen - o0 + 1;                           // candidates of the batch that exist for this pair (o <= minlen)
+                hits &= nval >= OV2_BATCH ? 0xFFFFu : (nval > 0 ? (1u << nval) - 1u : 0u);
                 if (done) hits = 0;
-                if (!__any(hits != 0)) continue;
-                for (int u = 0; u < OV2_BATCH; u++) {
-                    unsigned long long m = __ballot(!done && ((hits >> u) & 1u));
-                    while (m) {                                  // wave-uniform
-                        const int j = __ffsll((long long)m) - 1; m &= m - 1;
-                        const int jl = dir ? __shfl(len2, j) : __shfl(len1, j); const uint32_t o = (uint32_t)(o0 + u);
-                        const uint8_t* ac = (dir ? c2 : c1) + (uint32_t)j * OV2_CROW; const uint8_t* an = (dir ? n2 : n1) + (uint32_t)j * OV2_NROW;
-                        const uint8_t* bc = (dir ? c1 : c2) + (uint32_t)j * OV2_CROW; const uint8_t* bn = (dir ? n1 : n2) + (uint32_t)j * OV2_NROW;
-                        const bool ok = ov2_verify(ac, an, bc, bn, (uint32_t)jl - o, o, l);
-                        if (ok && l == j) { done = true; ov = dir ? -(int)o : (int)o; }
-                    }
+                // the few that pass are verified by the whole wave, a lane's candidates in ascending order
+                for (;;) {
+                    const unsigned long long m = __ballot(hits != 0);
+                    if (!m) break;                                       // wave-uniform
+                    const int j = __ffsll((long long)m) - 1;
+                    const int uj = __shfl(__ffs((int)hits) - 1, j); const uint32_t o = (uint32_t)(o0 + uj);
+                    const int jl = dir ? __shfl(len2, j) : __shfl(len1, j);
+                    const uint8_t* ac = (dir ? c2 : c1) + (uint32_t)j * OV2_CROW; const uint8_t* an = (dir ? n2 : n1) + (uint32_t)j * OV2_NROW;
+                    const uint8_t* bc = (dir ? c1 : c2) + (uint32_t)j * OV2_CROW; const uint8_t* bn = (dir ? n1 : n2) + (uint32_t)j * OV2_NROW;
+                    const bool ok = ov2_verify(ac, an, bc, bn, (uint32_t)jl - o, o, l); if (DBG) n_ver++;
+                    if (l == j) { if (ok) { done = true; ov = dir ? -(int)o : (int)o; hits = 0; } else hits &= hits - 1u; }
                 }
             }
         }
+        if (DBG) { k4 = clock64(); a_bwd += k4 - k3; }
         // reads longer than a row, or an R1 holding a character outside A/C/G/T/N: the byte-wise search, one pair at a time
         unsigned long long sm = __ballot(slow || bad);
         while (sm) {
@@ -932,7 +958,9 @@ __global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, 
             if (ov + shift < -127) ov = 0;
             ovb[p] = (int8_t)(ov + shift); R.stored[2 * (size_t)p + 1] = (uint32_t)(len2 - (ov < 0 ? -ov : ov));
         }
+        if (DBG) { k5 = clock64(); a_slow += k5 - k4; }
     }
+    if (DBG && dbg && l == 0) { atomicAdd(&dbg[0], (unsigned long long)a_meta); atomicAdd(&dbg[1], (unsigned long long)a_pack); atomicAdd(&dbg[2], (unsigned long long)a_fwd); atomicAdd(&dbg[3], (unsigned long long)a_bwd); atomicAdd(&dbg[4], (unsigned long long)a_slow); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)n_ver); }
 }
 __global__ void k_pv_in(Text T, ReadTab R, U4* __restrict__ v, uint32_t n_reads) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
