@@ -10,7 +10,7 @@ made by tests/golden/make_golden_big.py with the compiled reference), the decode
 Secondary lines (same JSON object, "secondary"): configs[1] (SE150 1 GB, md5 vs the reference golden) and the configs[4] shape
 (BGI-style PE100, 40 quality values).
 
-N > 1: ONE configs[3]-shaped PE150 input of N x (2 x 8 GB) farmed chunk-parallel: see run_multi().
+N > 1: ONE configs[3]-shaped PE150 input of N x (2 x 8 GB) encoded chunk-parallel by the N GPUs: see run_multi().
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -233,6 +233,151 @@ def line_of(w, steps, dt, total_bytes, parity):
             "parity": parity, "stage_ms": {k: round(v, 3) for k, v in stage.items()}}, stage, enc_ms, dec_ms
 
 
+SEG_PAIRS, SEG_SEED0, SEGS_PER_GPU, HEAD_PAIRS = 2_800_000, 4000, 8, 4000
+
+
+def run_multi(args, rank, world, local):
+    """N > 1: ONE configs[3]-shaped input - NovaSeq PE150, N x (2 x 8 GB) - encoded chunk-parallel and decoded again, every GPU working on
+    the part of the text that is resident in its own HBM.
+
+    The logical input is the concatenation of 8 N segments (segment s = fqgen profile 1, 2.8 M pairs, seed 4000 + s; N = 8: 2 x 64 GB).
+    Rank r generates segments 8r .. 8r+7 (its share: 2 x 8 GB) plus the first 4000 pairs of segment 8r+8 (the head the chunk that
+    straddles the share boundary runs into).  Setup (untimed): the plan chain (repaq_amd.dist.plan_shares: where each rank's first
+    chunk starts - one small host message per rank), and rank 0's header to every rank (<= 272 bytes).  A step (timed): every rank
+    encodes its byte range with rfq_encode_batch (the call runs slice by slice inside the library: >= 4 GiB per stream) and decodes
+    its own chunk images back; no collective, no RCCL - rendezvous is gloo over the host.  The N images in rank order ARE the .rfq:
+    rank 0 checks every chunk of it (crc32 + size, gathered over the host) against the reference's own encoding of the same logical
+    input (tests/golden/cfg3.json), every rank checks its decoded text against its input."""
+    import struct
+    import zlib
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import _oracle as O
+    from repaq_amd import RfqCodec, PE_TWO_FILES, dist as D
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    codec = RfqCodec(device=local)
+    seg_pairs, per = args.seg_pairs, args.segs_per_gpu
+    cb = max(100, args.chunk_kb) * 1000
+    # ---- this rank's share (+ the head of the next one), generated straight into one buffer per stream
+    parts1, parts2 = [], []
+    for s_ in range(per * rank, per * rank + per):
+        a, b = O.gen_np(O.NOVA_PE150, seg_pairs, seed=SEG_SEED0 + s_)
+        parts1.append(a); parts2.append(b)
+    share1, share2 = sum(int(x.size) for x in parts1), sum(int(x.size) for x in parts2)
+    if rank < world - 1:
+        a, b = O.gen_np(O.NOVA_PE150, min(HEAD_PAIRS, seg_pairs), seed=SEG_SEED0 + per * (rank + 1))
+        parts1.append(a); parts2.append(b)
+    h1 = torch.from_numpy(np.concatenate(parts1)); h2 = torch.from_numpy(np.concatenate(parts2))
+    del parts1, parts2, a, b
+    avail1, avail2 = int(h1.numel()), int(h2.numel())
+    t1 = h1.to(dev); t2 = h2.to(dev)
+    del h1, h2
+    lens = [None] * world
+    dist.all_gather_object(lens, (share1, share2))
+    off1, off2 = sum(x[0] for x in lens[:rank]), sum(x[1] for x in lens[:rank])
+    # ---- plan chain, header
+    cut1, cut2, n1, n2 = D.plan_shares(codec, rank, world, t1.data_ptr(), share1, avail1, t2.data_ptr(), share2, avail2, PE_TWO_FILES, cb)
+    last = rank == world - 1
+    o1 = torch.empty(n1 + 64, dtype=torch.uint8, device=dev); o2 = torch.empty(n2 + 64, dtype=torch.uint8, device=dev)
+    state = {"stage": {}, "enc_s": 0.0, "dec_s": 0.0}
+
+    def step(collect):
+        if rank == 0:
+            codec.clearHeader()
+        t_a = time.perf_counter()
+        r = codec.encode(t1.data_ptr() + cut1, n1, t2.data_ptr() + cut2, n2, PE_TWO_FILES, cb, final=last, emit_header=(rank == 0),
+                         file_off1=off1 + cut1, file_off2=off2 + cut2, flush_all=not last)
+        t_b = time.perf_counter()
+        if collect:
+            for name, ms in codec.timings():
+                state["stage"][name] = state["stage"].get(name, 0.0) + ms
+        d = None
+        if not args.encode_only:
+            d = codec.decode(r.d_rfq, r.rfq_len, has_header=(rank == 0), split_pe=True, final=last, d_out1=o1.data_ptr(), cap1=n1 + 64, d_out2=o2.data_ptr(), cap2=n2 + 64,
+                             chunk_off=r.h_chunk_off, n_chunks=r.n_chunks)
+            if collect:
+                for name, ms in codec.timings():
+                    state["stage"]["dec:" + name] = state["stage"].get("dec:" + name, 0.0) + ms
+        t_c = time.perf_counter()
+        if collect:
+            state["enc_s"] += t_b - t_a; state["dec_s"] += t_c - t_b
+        return r, d
+
+    if rank == 0:
+        step(False)                                  # makes the header from chunk 0 (RfqCodec::makeHeader, src/rfqcodec.cpp:59-145)
+    hdr = D.share_header(codec)
+    # ---- parity of what is being measured
+    r, d = step(False)
+    parity = "unchecked"
+    if not args.no_verify:
+        assert r.consumed1 == n1 and r.consumed2 == n2, "rank %d: the range was not encoded whole" % rank
+        img = codec.dev_get(r.d_rfq, r.rfq_len)
+        offs = [r.h_chunk_off[i] for i in range(r.n_chunks + 1)]
+        mine = [(zlib.crc32(img[offs[i]:offs[i + 1]]) & 0xFFFFFFFF, offs[i + 1] - offs[i]) for i in range(r.n_chunks)]
+        del img
+        if d is not None:
+            assert d.n1 == n1 and d.n2 == n2 and torch.equal(o1[:n1], t1[cut1:cut1 + n1]) and torch.equal(o2[:n2], t2[cut2:cut2 + n2]), "rank %d: decoded text differs from the input" % rank
+        allc = [None] * world
+        dist.all_gather_object(allc, mine)
+        if rank == 0:
+            chunks = [c for part in allc for c in part]
+            parity = "%d chunks over %d ranks" % (len(chunks), world)
+            try:
+                g = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3.json")))
+            except OSError:
+                g = None
+            if g and g["seg_pairs"] == seg_pairs and g["seed0"] == SEG_SEED0 and g["segments"] >= per * world and cb == 1_000_000:
+                assert hdr.hex() == g["header_hex"], "header differs from the reference's"
+                G = g["group"]; whole = len(chunks) if g["segments"] == per * world else len(chunks) - 1       # (a shorter input ends in a tail chunk of its own)
+                if g["segments"] == per * world:
+                    assert len(chunks) == g["n_chunks"], "chunk count differs from the reference's"
+                ok = 0
+                for gi in range(whole // G):
+                    hh = hashlib.md5()
+                    for c in chunks[gi * G:(gi + 1) * G]:
+                        hh.update(struct.pack("<II", c[0], c[1]))
+                    assert hh.hexdigest()[:16] == g["group_md5"][gi], "chunks %d..%d differ from the reference's" % (gi * G, gi * G + G - 1)
+                    ok += G
+                parity += ": header and %d chunk images (crc32 + size, groups of %d) == reference golden" % (ok, G)
+            else:
+                parity += " (no reference golden for this shape)"
+            parity += "; every rank: decode == its input text" if d is not None else ""
+    # ---- timed
+    for _ in range(args.warmup):
+        step(False)
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize(); D.barrier()
+    dt = time.perf_counter() - t0
+    dt, total = D.reduce_max_sum(dt, n1 + n2)
+    rfq_total = D.reduce_max_sum(0.0, r.rfq_len)[1]
+    if rank == 0:
+        K = args.steps; passes = 1 if args.encode_only else 2
+        stage = {k: v / K for k, v in state["stage"].items()}
+        enc_ms = sum(v for k, v in stage.items() if not k.startswith("dec:")); dec_ms = sum(v for k, v in stage.items() if k.startswith("dec:"))
+        alg = float(n1 + n2 + r.rfq_len); dom = max(stage, key=stage.get) if stage else None
+        out = {"metric": "raw FASTQ MB/s encode+decode" if passes == 2 else "raw FASTQ MB/s encode",
+               "value": round(total * passes * K / dt / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+               "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "configs[3] shape: ONE synthetic NovaSeq PE150 input of %d x (2 x %.2f GB) = 2 x %.1f GB FASTQ (%d segments: fqgen profile 1, %d pairs, seed %d + s), -k %d, "
+                                      "chunk-parallel over %d GPUs (each encodes + decodes the byte range resident in its HBM; plan chain + header over the host, no RCCL)"
+                                      % (world, share1 / 1e9, total / 2e9, per * world, seg_pairs, SEG_SEED0, args.chunk_kb, world),
+                          "rfq_over_fastq": round(rfq_total / total, 4), "parity": parity,
+                          "rank0": {"chunks": r.n_chunks, "encode_MBps": round((n1 + n2) * K / state["enc_s"] / 1e6, 1), "decode_MBps": round((n1 + n2) * K / state["dec_s"] / 1e6, 1) if state["dec_s"] else None,
+                                    "stage_ms": {k: round(v, 3) for k, v in stage.items()}}},
+               "roofline": None if not dom else {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS.get(dom, [dom])), "stage": dom, "achieved": round(alg / (stage[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": round(alg / (stage[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "note": "rank 0's share, per GPU; see the N = 1 line for the definitions",
+                                                 "whole_encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if enc_ms else None,
+                                                 "whole_decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}}
+        print(json.dumps(out))
+    codec.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,7 +392,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] secondary lines")
     ap.add_argument("--encode-only", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (kernel ablation runs with RFQ_TUNE set)")
-    ap.add_argument("--share-pairs", type=int, default=22_400_000, help="N>1: pairs per GPU share (configs[3]: 2 x 8 GB per GPU)")
+    ap.add_argument("--seg-pairs", type=int, default=SEG_PAIRS, help="N>1: pairs per segment of the logical input (test aid: smaller inputs)")
+    ap.add_argument("--segs-per-gpu", type=int, default=SEGS_PER_GPU, help="N>1: segments per GPU share (configs[3]: 8 x 2.8 M pairs = 2 x 8 GB per GPU)")
     args = ap.parse_args()
 
     import torch
@@ -260,8 +406,7 @@ def main():
         local = 0
     if world > 1:
         D.init("gloo")          # host-side rendezvous only (barriers, max-over-ranks time, the <= 272-byte header, chunk hashes): no RCCL on this path
-        from repaq_amd import farm
-        return farm.run_bench(args, rank, world, local)
+        return run_multi(args, rank, world, local)
 
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

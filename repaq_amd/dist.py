@@ -61,6 +61,44 @@ def share_header(codec, device=None):
     return h
 
 
+def plan_shares(codec, rank, world, d1, share1, avail1, d2=None, share2=0, avail2=0, paired=0, chunk_bases=1_000_000):
+    """The distributed plan of a chunk-parallel encode of ONE input whose text is spread over the ranks.
+
+    Rank r holds, resident in its HBM, its own share of every stream (`share*` bytes: whole records, the logical file is the shares in
+    rank order) followed by the first bytes of the next rank's share (`avail*` >= `share*` bytes readable in all; the last rank has
+    none).  Chunks are cut greedily from the start of the file (Repaq::compress, src/repaq.cpp:546-553), so where rank r's first chunk
+    starts depends on every earlier share: the ranks run the plan pass (rfq_scan_batch: line index, read lengths, cut rule - no
+    coding) one after the other, each from its own first cut over its share plus the head of the next, and hand the offset of the chunk
+    boundary that falls at or behind the share's end to the next rank.  One small host message per rank; no data-path collective.
+
+    Returns (cut1, cut2, len1, len2): this rank encodes bytes [cut, cut + len) of its resident buffers - with flush_all on every rank
+    but the last (its range ends on a chunk boundary), final on the last."""
+    import torch
+    import torch.distributed as dist
+    two = paired == 1
+    cut = [0, 0]; own = [share1, share2]
+    for src in range(world):
+        nxt = torch.zeros(2, dtype=torch.int64)
+        if rank == src:
+            last = src == world - 1
+            n1 = (share1 if last else avail1) - cut[0]; n2 = ((share2 if last else avail2) - cut[1]) if two else 0
+            if not last:
+                r, e1, e2 = codec.scan(d1 + cut[0], n1, (d2 + cut[1]) if two else None, n2, paired, chunk_bases, final=False)
+                k = next((i for i, e in enumerate(e1) if e >= share1 - cut[0]), None)
+                if k is None:
+                    raise RuntimeError("rank %d: the head of the next share (%d bytes) does not reach the end of the chunk that straddles the share boundary" % (rank, avail1 - share1))
+                own = [e1[k], e2[k] if two else 0]
+                nxt[0] = e1[k] - (share1 - cut[0]); nxt[1] = (e2[k] - (share2 - cut[1])) if two else 0
+            else:
+                own = [n1, n2]
+        if src < world - 1:
+            if world > 1:
+                dist.broadcast(nxt, src=src)
+            if rank == src + 1:
+                cut = [int(nxt[0]), int(nxt[1])]
+    return cut[0], cut[1], own[0], own[1]
+
+
 def split_chunk_ranges(n_chunks, world):
     """Contiguous, near-equal ranges of chunk indices: [(begin, end)] per rank (the host work queue in its static form)."""
     base, rem = divmod(n_chunks, world)
