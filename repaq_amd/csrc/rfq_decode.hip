@@ -11,12 +11,12 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 72, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_END
+    DB_CHUNKS = 72, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_END
 };
-static_assert(DB_END <= 96, "rfq_ctx::b too small");
+static_assert(DB_END <= 104, "rfq_ctx::b too small");
 
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
-struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos; };
+struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec; };
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
 // out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
@@ -53,11 +53,43 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     *nbases = total_bases;
 
     // ---- streams
+    // Fused path (rfq_decode_kernels.h "fused path"): the emitter builds qualities and bases tile by tile in LDS from the packed bytes and the
+    // position tokens; what runs here is the coordinate decoder and, beside it, the one-step stream summaries + their link / cell index.
+    // Taken for files with few quality streams whose reads and exception lists fit a tile; RFQ_TUNE bit 11 forces the materialising path.
+    const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
+    const bool fused = !(tune & 2048) && (!bycol_h || HH.n_normal <= POS2_MAX_STREAMS) && g.max_len <= 2600u && g.max_nrec <= 4096u;
+    uint32_t f_maxseg = 1, f_ncell = 1; const uint32_t f_nstr = HH.n_normal + 1;
+    if (fused) {
+        ctx->timer.begin("streams", S);
+        const bool hasn = (HH.flags & H_N_POS) != 0; const uint32_t nn = bycol_h ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u;
+        const bool forked = ctx->aux_ready(); hipStream_t A = forked ? ctx->aux : S;
+        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
+        hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
+        if (nn || hasn) {
+            const uint32_t mq = nn ? g.max_stream / POS2_SEG + 1 : 0u, mn = hasn ? g.max_npos / POS2_SEG + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
+            f_ncell = g.max_bases / POS2_CELL + 2;
+            const size_t nseg = (size_t)n_chunks * f_nstr * f_maxseg, ncl = (size_t)n_chunks * f_nstr * f_ncell;
+            HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 16 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure((size_t)n_chunks * f_nstr * 4 + 16));
+            HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_CELL].ensure(ncl * 4 + 16));
+            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, (size_t)n_chunks * f_nstr * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
+#define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
+            if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);
+            if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr);
+#undef RFQ_SUM2_ARGS
+            hipLaunchKernelGGL(k_dec_pos_link2, dim3((n_chunks * f_nstr + 3) / 4), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
+                               (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_CELL].as<uint32_t>(), f_maxseg, f_ncell, n_chunks * f_nstr);
+        }
+        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
+        KCHK(ctx, "k_dec_streams");
+        ctx->timer.end(S);
+    }
+    uint64_t* qbase = nullptr; uint64_t* sbase = nullptr; uint8_t* qdec = nullptr; uint8_t* sdec = nullptr; size_t qbytes = 0, sbytes = 0;
+    if (!fused) {
     ctx->timer.begin("streams", S);
-    const size_t qbytes = (size_t)total_bases + 64 * nc + 256, sbytes = (size_t)pv_tot.d + 64 * nc + 256;
+    qbytes = (size_t)total_bases + 64 * nc + 256; sbytes = (size_t)pv_tot.d + 64 * nc + 256;
     HIPCHK(ctx, B[DB_QDEC].ensure(qbytes)); HIPCHK(ctx, B[DB_SDEC].ensure(sbytes));
-    uint64_t* qbase = B[DB_QBASE].as<uint64_t>(); uint64_t* sbase = B[DB_SBASE].as<uint64_t>();
-    uint8_t* qdec = B[DB_QDEC].as<uint8_t>(); uint8_t* sdec = B[DB_SDEC].as<uint8_t>();
+    qbase = B[DB_QBASE].as<uint64_t>(); sbase = B[DB_SBASE].as<uint64_t>();
+    qdec = B[DB_QDEC].as<uint8_t>(); sdec = B[DB_SDEC].as<uint8_t>();
     hipLaunchKernelGGL(k_dec_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, CH, R, qbase, sbase, n_chunks);
     // Two chains run side by side (rfq_ctx::aux, fork / join by events):
     //   main  prefill of qdec, coordinate decoder, [summaries linked] quality position streams scattered into qdec, exception records
@@ -100,6 +132,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     KCHK(ctx, "k_dec_streams");
     ctx->timer.end(S);
 
+    }
+
     // ---- text
     ctx->timer.begin("textlen", S);
     const int split = a->split_pe ? 1 : 0;
@@ -122,12 +156,17 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     {
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
         const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
-        if (tune) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
-        if (tune) hipLaunchKernelGGL(k_dec_emit<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
+        if (fused) {
+            hipLaunchKernelGGL(k_dec_emit2<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst,
+                               (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), (const uint32_t*)B[DB_SEGN].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(),
+                               f_maxseg, f_ncell, f_nstr, (unsigned long long*)nullptr);
+        } else
+        if (tune & 7) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
+        if (fused) {} else if (tune & 7) hipLaunchKernelGGL(k_dec_emit<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
                            (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
         else hipLaunchKernelGGL(k_dec_emit<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
                            (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
-        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu (wave0 own %llu, setup %llu) flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[6]/h[5], h[7]/h[5], h[4]/h[5]); }
+        if (!fused && (tune & 7)) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu (wave0 own %llu, setup %llu) flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[6]/h[5], h[7]/h[5], h[4]/h[5]); }
         KCHK(ctx, "k_dec_emit");
     }
     ctx->timer.end(S);
@@ -210,7 +249,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
             if (h2.pad) { speculate = false; continue; }
-            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
+            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
         break;
@@ -231,7 +270,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
     if (tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
-        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos;
+        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec;
         rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
         if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
     }
@@ -258,7 +297,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             const uint32_t c0 = r.first, c1 = r.second; uint64_t reads = 0; for (uint32_t c = c0; c < c1; c++) reads += hc[c].reads;
             hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
             KCHK(ctx, "k_dec_rebase");
-            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos;
+            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec;
             uint8_t *q1 = nullptr, *q2 = nullptr; size_t m1 = 0, m2 = 0; uint64_t mb = 0;
             ctx->timer.reset();
             rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);

@@ -19,6 +19,7 @@ struct DChunk {                  // one parsed chunk (offsets relative to the ch
     uint32_t rbase;              // reads in earlier chunks of the range being decoded
     uint32_t rbase_abs;          // reads in earlier chunks of the image (rbase is re-based per range by k_dec_rebase)
     uint64_t bases;              // sum of the chunk's read lengths (64-bit: a corrupt length table must not wrap the 32-bit prefix sums)
+    uint32_t max_len, pad_;      // longest read of the chunk
 };
 struct DecStatus {
     uint32_t err, n_chunks, max_reads, overflow;
@@ -27,6 +28,8 @@ struct DecStatus {
     uint32_t max_stream, max_npos;   // largest quality section / N-position section of any chunk (bound the position streams)
     uint64_t text_slots[2][64];      // partial sums of the text bytes per output stream (k_dec_textlen)
     uint64_t base_slots[16];         // partial sums of the read lengths of all chunks (parse_chunk)
+    uint32_t max_len, max_bases;     // longest read / largest chunk (bases, clamped to 2^32 - 1) of the image
+    uint32_t max_nrec, pad2;         // most exception records of any chunk (by-column quality payloads)
 };
 
 // sum of n bytes by one wave (wave-uniform result)
@@ -51,9 +54,10 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
     {   // sum of the read lengths, 64-bit (the per-read prefix sums that place bases and qualities are 32-bit; the host refuses a batch that would wrap them)
         const uint8_t* lp = p + d.o_readlens; unsigned long long sum = 0;
         auto rl = [&](uint32_t r) -> uint32_t { const uint8_t* x = lp + (size_t)r * rlb; return rlb == 1 ? x[0] : (rlb == 2 ? ld_u16(x) : ld_u32(x)); };
-        if (fl & C_READ_LEN_SAME) sum = (unsigned long long)rl(0) * s;
-        else { for (uint32_t r = (uint32_t)lane_id(); r < s; r += 64) sum += rl(r); sum = wave_sum<unsigned long long>(sum); }
-        d.bases = sum;
+        uint32_t mx = 0;
+        if (fl & C_READ_LEN_SAME) { mx = rl(0); sum = (unsigned long long)mx * s; }
+        else { for (uint32_t r = (uint32_t)lane_id(); r < s; r += 64) { const uint32_t v = rl(r); sum += v; if (v > mx) mx = v; } sum = wave_sum<unsigned long long>(sum); mx = wave_max(mx); }
+        d.bases = sum; d.max_len = mx; d.pad_ = 0;
     }
 #define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
         const uint32_t m_ = (fl & (LENFLAG)) ? 1u : s; OFF = (uint32_t)q; if (q + m_ > left) return 2; \
@@ -84,7 +88,7 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
 // One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays; the reader ignores mSize).
 __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st, int final) {
     const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
-    uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, maxn = 0, lastfl = 0; uint64_t rb = 0, tb = 0; uint32_t err = 0, ovf = 0;
+    uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, maxn = 0, lastfl = 0, maxl = 0, maxb = 0; uint64_t rb = 0, tb = 0; uint32_t err = 0, ovf = 0;
     if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
     while (!err) {
         DChunk d; const int rc = parse_chunk(img, n, k, hf, rlb, d);
@@ -95,9 +99,10 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
         if (d.reads > maxr) maxr = d.reads;
         if (d.qual_size > maxs) maxs = d.qual_size; if (d.npos_size > maxn) maxn = d.npos_size;
         lastfl = d.flags; rb += d.reads; k += d.total; c++; tb += d.bases;
+        if (d.max_len > maxl) maxl = d.max_len; { const uint32_t b32 = d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases; if (b32 > maxb) maxb = b32; }
         if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
     }
-    if (l == 0) { st->base_slots[0] = tb; st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
+    if (l == 0) { st->max_len = maxl; st->max_bases = maxb; st->base_slots[0] = tb; st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
 }
 // Speculative walk: images written by repaq (or this engine) carry mSize = true size - Delta(flags) (the accounting bug Q1 is a
 // pure function of the header and chunk flags), so the chain needs ONE dependent 10-byte read per chunk instead of a full parse.
@@ -170,7 +175,11 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
     d.rbase = rbase; d.rbase_abs = rbase;
-    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); atomicAdd((unsigned long long*)&st->base_slots[c & 15u], (unsigned long long)d.bases); }
+    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); atomicAdd((unsigned long long*)&st->base_slots[c & 15u], (unsigned long long)d.bases);
+                          atomicMax(&st->max_len, d.max_len); atomicMax(&st->max_bases, d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases);
+                          if ((hf & H_QUAL_BY_COL) && !(hf & H_DONT_QUAL) && 4ull * D->n_normal <= d.qual_size) {
+                              const uint8_t* qp = img + d.off + d.o_qual; uint64_t off = 4ull * D->n_normal; for (uint32_t i = 0; i < D->n_normal; i++) off += ld_u32(qp + 4 * i);
+                              if (off <= d.qual_size) atomicMax(&st->max_nrec, (uint32_t)((d.qual_size - off) / 5)); } }
 }
 
 struct DReadTab {
@@ -451,6 +460,124 @@ __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __
     __shared__ int s_tp[256];                                           // (one wave per block)
     wave_pos_decode(s.sp, s.slen, b0, b1, segS[idx], segP[idx], s.q, s.out, s.out_len, lim, s_tp);
 }
+// ================================================================== fused path: the emitter applies the position tokens itself
+// (files with <= POS2_MAX_STREAMS quality streams - every NovaSeq-binned file): no expanded qualities / bases in HBM (qdec / sdec), no
+// prefill, no one-line-per-token scatter.  A stream is summarised in ONE-STEP segments of 256 bytes (k_dec_pos_sum2: transition table +
+// positions covered per entry state), a wave per stream links them by a scan (k_dec_pos_link2: entry state and entry position of
+// every segment) and records, for every POS2_CELL positions, the first segment that reaches the cell; k_dec_emit2 starts each tile's
+// streams from there.
+#define POS2_SEG 256u
+#define POS2_CELL 1024u
+#define POS2_MAX_STREAMS 8u
+struct PosSrc { const uint8_t* sp; uint32_t slen; uint8_t q; };
+// stream jj of a chunk: jj < nn = quality value stream, jj == nn = N positions.  slen = 0 when absent; corrupt length tables are flagged.
+__device__ __forceinline__ PosSrc pos_src_of(const uint8_t* __restrict__ img, const DChunk& d, const DevHeader* __restrict__ D, uint32_t jj, DecStatus* st) {
+    PosSrc s; s.sp = nullptr; s.slen = 0; s.q = 0;
+    const uint32_t nn = D->n_normal, hf = D->flags; const uint8_t* cp = img + d.off;
+    if (jj == nn) { if (hf & H_N_POS) { s.sp = cp + d.o_npos; s.slen = d.npos_size; s.q = (uint8_t)'N'; } return s; }
+    if (jj > nn || jj >= NPOS_SLOT || (hf & H_DONT_QUAL) || !(hf & H_QUAL_BY_COL)) return s;
+    if (4ull * nn > d.qual_size) { if (st && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return s; }
+    const uint8_t* qp = cp + d.o_qual; uint64_t off = 4ull * nn;
+    for (uint32_t i = 0; i < jj; i++) off += ld_u32(qp + 4 * i);
+    const uint32_t sl = ld_u32(qp + 4 * jj);
+    if (off + sl > d.qual_size) { if (st && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); return s; }
+    s.sp = qp + off; s.slen = sl; s.q = D->normal[jj];
+    return s;
+}
+// grid (ceil(maxseg / 4), streams, n_chunks) x 256 threads: one wave per 256-byte segment; index arrays are [chunk][nstr][maxseg]
+__global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
+                               uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes, uint32_t jj0, uint32_t nstr) {
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
+    const DChunk d = CH[c];
+    const PosSrc s = pos_src_of(img, d, D, jj, g == 0 ? st : nullptr);
+    if (g == 0 && l == 0) segN[(size_t)c * nstr + jj] = (s.slen + POS2_SEG - 1) / POS2_SEG;
+    const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
+    const uint32_t i0 = b0 + 4u * (uint32_t)l;
+    const PosStep w = pos_fetch(s.sp, s.slen, i0, lim);
+    const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
+    uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;       // segment entry state -> state in front of my bytes
+    int a0 = pos_lane_adv(f, s.slen, i0, (Fex >> 0) & 3u), a1 = pos_lane_adv(f, s.slen, i0, (Fex >> 2) & 3u);
+    int a2 = pos_lane_adv(f, s.slen, i0, (Fex >> 4) & 3u), a3 = pos_lane_adv(f, s.slen, i0, (Fex >> 6) & 3u);
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    const uint32_t F = __shfl(f.Fin, 63);
+    if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)F; segA[4 * idx + 0] = a0; segA[4 * idx + 1] = a1; segA[4 * idx + 2] = a2; segA[4 * idx + 3] = a3; }
+}
+// one wave per (chunk, stream): entry state / entry position of every segment by a scan over (transition table, positions per entry state)
+// pairs - (F1, A1) then (F2, A2) is (F2 o F1, s -> A1[s] + A2[F1[s]]) - and the cell index: cellseg[cell] = first segment whose tokens
+// reach position cell * POS2_CELL or beyond (0xFFFFFFFF: none does).
+struct PosLink { uint32_t F; int a[4]; };
+__device__ __forceinline__ PosLink poslink_then(const PosLink& x, const PosLink& y) {   // x first, then y
+    PosLink r; r.F = fn_compose(x.F, y.F);
+#pragma unroll
+    for (int s = 0; s < 4; s++) { const uint32_t t = (x.F >> (2 * s)) & 3u; r.a[s] = x.a[s] + (t == 0 ? y.a[0] : (t == 1 ? y.a[1] : (t == 2 ? y.a[2] : y.a[3]))); }
+    return r;
+}
+__global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __restrict__ segA, const uint32_t* __restrict__ segN, uint8_t* __restrict__ segS, int* __restrict__ segP,
+                                uint32_t* __restrict__ cellseg, uint32_t maxseg, uint32_t ncell, uint32_t n_streams) {
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(); if (t >= n_streams) return;
+    const int l = lane_id(); const uint32_t n = segN[t];
+    uint32_t cs = 0; int cp = -1;                                          // state / last covered position in front of the block of 64 segments
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t g = base + (uint32_t)l; const size_t idx = (size_t)t * maxseg + g;
+        PosLink me; me.F = POS_ID; me.a[0] = me.a[1] = me.a[2] = me.a[3] = 0;
+        if (g < n) { me.F = segF[idx]; me.a[0] = segA[4 * idx]; me.a[1] = segA[4 * idx + 1]; me.a[2] = segA[4 * idx + 2]; me.a[3] = segA[4 * idx + 3]; }
+        PosLink inc = me;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            PosLink up; up.F = __shfl_up(inc.F, (unsigned)dd); up.a[0] = __shfl_up(inc.a[0], (unsigned)dd); up.a[1] = __shfl_up(inc.a[1], (unsigned)dd); up.a[2] = __shfl_up(inc.a[2], (unsigned)dd); up.a[3] = __shfl_up(inc.a[3], (unsigned)dd);
+            if (l >= dd) inc = poslink_then(up, inc);
+        }
+        PosLink ex; ex.F = __shfl_up(inc.F, 1u); ex.a[0] = __shfl_up(inc.a[0], 1u); ex.a[1] = __shfl_up(inc.a[1], 1u); ex.a[2] = __shfl_up(inc.a[2], 1u); ex.a[3] = __shfl_up(inc.a[3], 1u);
+        if (l == 0) { ex.F = POS_ID; ex.a[0] = ex.a[1] = ex.a[2] = ex.a[3] = 0; }
+        const uint32_t st = (ex.F >> (2 * cs)) & 3u;                       // my segment's entry state
+        const int ep = cp + (cs == 0 ? ex.a[0] : (cs == 1 ? ex.a[1] : (cs == 2 ? ex.a[2] : ex.a[3])));     // ... and entry position (last position covered before it)
+        if (g < n) {
+            segS[idx] = (uint8_t)st; segP[idx] = ep;
+            const int en = ep + (st == 0 ? me.a[0] : (st == 1 ? me.a[1] : (st == 2 ? me.a[2] : me.a[3])));   // last position covered by my segment
+            if (en >= 0) {
+                uint32_t c0 = ep < 0 ? 0u : (uint32_t)ep / POS2_CELL + 1u; const uint32_t c1 = (uint32_t)en / POS2_CELL;
+                for (; c0 <= c1 && c0 < ncell; c0++) cellseg[(size_t)t * ncell + c0] = g;
+            }
+        }
+        const uint32_t Fl = __shfl(inc.F, 63); const int al0 = __shfl(inc.a[0], 63), al1 = __shfl(inc.a[1], 63), al2 = __shfl(inc.a[2], 63), al3 = __shfl(inc.a[3], 63);
+        cp += cs == 0 ? al0 : (cs == 1 ? al1 : (cs == 2 ? al2 : al3)); cs = (Fl >> (2 * cs)) & 3u;
+    }
+}
+// decodeSingleQualByCol (src/rfqcodec.cpp:957-1007) for ONE 256-byte step of a stream into an LDS tile: positions p of [t0, t0 + tlen) get
+// tile[p - t0] = q.  carry / last: automaton state and last covered position in front of the step; both are advanced.
+__device__ __forceinline__ void tile_pos_step(const PosStep& w, const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0, uint32_t& carry, int& last,
+                                              uint8_t q, uint8_t* tile, int t0, int tlen, int l) {
+    const PosFront f = pos_front(w, sp, slen, i0, l);
+    const uint32_t after = (f.Fin >> (2 * carry)) & 3u;
+    uint32_t st = __shfl_up(after, 1u); if (l == 0) st = carry;
+    carry = __shfl(after, 63);
+    int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b0 = f.bt[k]; const bool valid = i0 + (uint32_t)k < slen;
+        const uint32_t b1 = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2 = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3 = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
+        start[k] = valid && st == 0; adv[k] = 0; run[k] = 0;
+        if (start[k]) {
+            if ((b0 & 0x80u) == 0) adv[k] = (int)b0 + 1;
+            else if ((b0 & 0x40u) == 0) adv[k] = (int)(((b0 & 0x3Fu) << 8) | b1) + 1;
+            else if ((b0 & 0x20u) == 0) { run[k] = (b0 & 0x1Fu) + 1; adv[k] = (int)run[k]; }
+            else adv[k] = (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
+        }
+        lane_adv += adv[k];
+        if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
+    }
+    const int incl = wave_incl_sum(lane_adv);
+    int end = last + incl - lane_adv;                                        // last covered position in front of my tokens
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!start[k]) continue;
+        end += adv[k];
+        const int lo = run[k] ? end - (int)run[k] + 1 : end;
+        for (int p = lo < t0 ? t0 : lo; p <= end && p < t0 + tlen; p++) tile[p - t0] = q;
+    }
+    last += __shfl(incl, 63);
+}
+
 // exception records (q, u32 LE position) after the streams (src/rfqcodec.cpp:1034-1043); raw copy when DONT_ENCODE_QUAL (:905-910)
 __global__ void k_dec_except(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                              const uint64_t* __restrict__ qbase, uint8_t* __restrict__ qdec) {
@@ -909,4 +1036,246 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
 #undef EMIT_META_LOAD
 #undef EMIT_META_STORE
     if (DBG && tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a1); atomicAdd(&dbg[1], (unsigned long long)a2); atomicAdd(&dbg[2], (unsigned long long)a3); atomicAdd(&dbg[3], (unsigned long long)a4); atomicAdd(&dbg[4], (unsigned long long)a5); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)a6); atomicAdd(&dbg[7], (unsigned long long)aS); }
+}
+
+// ================================================================== fused emitter (see "fused path" above)
+// k_dec_emit's tile with its two largest sources BUILT in LDS instead of staged from HBM:
+//   qualities   prefilled with the major value, then every quality stream's tokens (one wave per stream, starting at the segment the cell
+//               index names, two steps prefetched beside the staging) and the exception records are scattered into the tile;
+//               DONT_ENCODE_QUAL files stage their raw qualities straight from the image
+//   bases       the tile's packed bytes (1/4 of the bases) staged by LDS-DMA, unpacked LDS -> LDS, N positions scattered from their stream
+// Everything after that - one thread = one piece, byte-granular ds_read_b128 / ds_write_b128, aligned flush - is k_dec_emit's compose phase.
+#define EG2_PK EG_END
+#define EG2_END (EG2_PK + ET_SCAP / 64 + 4)
+struct TileStream { const uint8_t* sp; uint32_t slen, nseg; size_t base; uint32_t q; bool isn; };   // base: index of segment 0 in segS / segP
+template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                           uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
+                           const uint8_t* __restrict__ segS, const int* __restrict__ segP, const uint32_t* __restrict__ segN, const uint32_t* __restrict__ cellseg,
+                           uint32_t maxseg, uint32_t ncell, uint32_t nstr, unsigned long long* dbg) {
+    __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
+    __shared__ uint4 s_src4[EG2_END];
+    __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta2[2][(ET_READS + 1) * EM_ROW];
+    __shared__ uint32_t s_g[2][POS2_MAX_STREAMS + 2];
+    const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint8_t* lim = img + img_bytes;
+    const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
+    const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
+    const int l = lane_id(), w = wave_id(); const uint32_t tid = threadIdx.x;
+    const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
+    uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;
+    const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
+    const uint32_t ocap = split ? ET_OCAP / 2 : ET_OCAP;
+    const bool raw = (hf & H_DONT_QUAL) != 0, bycol = !raw && (hf & H_QUAL_BY_COL);
+    const uint32_t nn = bycol ? (D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT) : 0u; const bool hasn = (hf & H_N_POS) != 0;
+    const uint32_t T = nn + (hasn ? 1u : 0u);                                // streams of the tile: t < nn quality value t, t == nn the N positions
+    const uint32_t major4 = (D->major & 0xFFu) * 0x01010101u;
+    const uint32_t qlen_c = R.pq[f + d.reads] - pq0, slen_c = R.pv[f + d.reads].d - pv0.d;      // qualities / stored bases of the chunk
+    // this wave's streams (t = w, w + 4, w + 8): where their bytes are, their segment tables
+    TileStream TS[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const uint32_t t = (uint32_t)w + 4u * (uint32_t)u; TS[u].sp = nullptr; TS[u].slen = 0; TS[u].nseg = 0; TS[u].base = 0; TS[u].q = 0; TS[u].isn = false;
+        if (t < T) { const uint32_t jj = t < nn ? t : D->n_normal; const PosSrc ps = pos_src_of(img, d, D, jj, nullptr);
+                     TS[u].sp = ps.sp; TS[u].slen = ps.slen; TS[u].q = ps.q; TS[u].isn = t >= nn; TS[u].nseg = (ps.slen + POS2_SEG - 1) / POS2_SEG; TS[u].base = ((size_t)c * nstr + jj) * maxseg; }
+    }
+    // exception records behind the streams (src/rfqcodec.cpp:1034-1043)
+    uint32_t nrec = 0; const uint8_t* xrec = nullptr;
+    if (bycol && 4ull * D->n_normal <= d.qual_size) {
+        const uint8_t* qp = cp + d.o_qual; uint64_t off = 4ull * D->n_normal;
+        for (uint32_t i = 0; i < D->n_normal; i++) off += ld_u32(qp + 4 * i);
+        if (off <= d.qual_size) { nrec = (uint32_t)((d.qual_size - off) / 5); xrec = qp + off; }
+    }
+    // cell of a tile start -> first segment of stream t that reaches it (the lookup for the NEXT tile rides beside this tile's staging)
+    auto cell_lookup = [&](uint32_t t, uint32_t qpos, uint32_t spos) -> uint32_t {
+        const uint32_t jj = t < nn ? t : D->n_normal; uint32_t cell = (t < nn ? qpos : spos) / POS2_CELL; if (cell >= ncell) cell = ncell - 1u;
+        return cellseg[((size_t)c * nstr + jj) * ncell + cell];
+    };
+#define EMIT_META_VARS U4 tp_, pv_; uint32_t pq_ = 0, len_ = 0, ov_ = 0, pl_ = 0, n1_ = 0, n2_ = 0, sl_ = 0, md_ = 0, r_ = 0; bool odd_ = false; tp_.a = tp_.b = 0; pv_.a = pv_.b = pv_.c = pv_.d = 0;
+#define EMIT_META_LOAD(from)                                                                                                          \
+        { r_ = (from) + tid; const uint32_t g_ = f + r_; odd_ = (r_ & 1u) != 0;                                                       \
+          tp_ = R.tp[g_]; pv_ = R.pv[g_]; pq_ = R.pq[g_];                                                                             \
+          if (r_ < re) {                                                                                                              \
+              len_ = R.len[g_]; ov_ = (uint32_t)R.ov[g_]; pl_ = odd_ ? R.len[g_ - 1] : 0u;                                            \
+              n1_ = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r_)];                                                             \
+              n2_ = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r_)] : 0u;                                       \
+              sl_ = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r_)]; md_ = R.mid[(size_t)g_ * 40 + 39];                         \
+          } }
+#define EMIT_META_STORE(mrow)                                                                                                         \
+        { uint32_t* m = (mrow) + EM_ROW * tid;                                                                                        \
+          m[12] = tp_.a; m[13] = tp_.b; m[14] = pv_.d - pv0.d; m[15] = pq_ - pq0;                                                     \
+          m[7] = pv_.a - pv0.a; m[8] = pv_.b - pv0.b; m[9] = pv_.c - pv0.c;                                                           \
+          if (r_ < re) { m[0] = (split && odd_) ? tp_.b : tp_.a; m[1] = len_; m[2] = ov_; m[3] = pl_; m[4] = n1_; m[5] = n2_; m[6] = sl_;   \
+                         m[11] = md_; m[10] = n1_ + md_ + n2_ + 1; } }
+    uint32_t cur = rs; uint32_t pb = 0;
+    { EMIT_META_VARS if (cur < re && tid <= ET_READS && cur + tid <= re) { EMIT_META_LOAD(cur) EMIT_META_STORE(s_meta2[0]) }
+      if (cur < re && tid < T) s_g[0][tid] = cell_lookup(tid, R.pq[f + cur] - pq0, R.pv[f + cur].d - pv0.d); }
+    __syncthreads();
+    while (cur < re) {                                                       // block-uniform
+        uint32_t* const s_meta = s_meta2[pb]; uint32_t* const s_next = s_meta2[pb ^ 1u];
+        const uint32_t g0 = f + cur;
+        const uint32_t* mb = s_meta;
+#define EMIT_FITS(me) ((me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 48u <= ET_SCAP && (me[14] - mb[14]) + 48u <= ET_SCAP \
+                && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)                          \
+                && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP))
+        const uint32_t all = re - cur < ET_READS ? re - cur : ET_READS;
+        uint32_t cnt;
+        { const uint32_t* ma = s_meta + EM_ROW * all; cnt = EMIT_FITS(ma) ? all : 0xFFFFFFFFu; }
+        if (cnt == 0xFFFFFFFFu) {                                          // block-uniform
+            bool fits = false;
+            if (tid < ET_READS && cur + tid < re) {
+                uint32_t mm = (tid + 2u) & ~1u; if (cur + mm > re) mm = re - cur;
+                const uint32_t* me = s_meta + EM_ROW * mm;
+                fits = EMIT_FITS(me);
+            }
+            if (tid < 64) { const unsigned long long fb = __ballot(fits); if (l == 0) s_cnt = (uint32_t)__popcll(fb); }
+            __syncthreads();
+            cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
+        }
+#undef EMIT_FITS
+        if (cnt == 0) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); break; }   // (a pair beyond the tile: the host keeps such images off this kernel)
+        const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + EM_ROW * cnt;
+        U4 tp0, tp1; tp0.a = mb[12]; tp0.b = mb[13]; tp1.a = me[12]; tp1.b = me[13];
+        const uint32_t q0 = mb[15], s0 = mb[14], q1 = me[15], s1 = me[14];
+        // ---- stage: packed bases, name pieces, middles (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
+        const uint64_t ib = d.off;
+        const uint32_t a7 = (fl & C_NAME1_SAME) ? 0u : mb[7], a8 = (fl & C_NAME2_SAME) ? 0u : mb[8], a9 = (fl & C_STRAND_SAME) ? 0u : mb[9];
+        const uint64_t n1a = ib + d.o_n1 + a7, n1e = (fl & C_NAME1_SAME) ? n1a + d.n1_size : ib + d.o_n1 + me[7];
+        const uint64_t n2a = ib + d.o_n2 + a8, n2e = (fl & C_NAME2_SAME) ? n2a + d.n2_size : ib + d.o_n2 + me[8];
+        const uint64_t sta = ib + d.o_st + a9, ste = (fl & C_STRAND_SAME) ? sta + d.st_size : ib + d.o_st + me[9];
+        uint64_t pka = ib + d.o_seq + (s0 >> 2), pke = ib + d.o_seq + ((s1 + 3u) >> 2); { const uint64_t pend = ib + d.o_seq + d.seq_size; if (pke > pend) pke = pend; if (pka > pke) pka = pke; }
+        uint64_t rqa = ib + d.o_qual + q0, rqe = ib + d.o_qual + q1; { const uint64_t qend = ib + d.o_qual + d.qual_size; if (rqe > qend) rqe = qend; if (rqa > rqe) rqa = rqe; }
+        // first two steps of this wave's first two streams: requested now, decoded after the barrier
+        PosStep pw[2][2]; uint32_t pg[2], pst[2]; int ppos[2]; bool pon[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t t = (uint32_t)w + 4u * (uint32_t)u; pon[u] = false; pg[u] = 0; pst[u] = 0; ppos[u] = -1;
+            pw[u][0].w0 = pw[u][0].w1 = pw[u][0].w2 = 0; pw[u][1] = pw[u][0];
+            if (t < T) {
+                const uint32_t g = s_g[pb][t];
+                if (g < TS[u].nseg) { pon[u] = true; pg[u] = g; pst[u] = segS[TS[u].base + g]; ppos[u] = segP[TS[u].base + g];
+                                      pw[u][0] = pos_fetch(TS[u].sp, TS[u].slen, g * POS2_SEG + 4u * (uint32_t)l, lim); pw[u][1] = pos_fetch(TS[u].sp, TS[u].slen, (g + 1u) * POS2_SEG + 4u * (uint32_t)l, lim); }
+            }
+        }
+        {
+            const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
+            EMIT_META_VARS
+            if (nextm) EMIT_META_LOAD(cur + cnt)
+            uint32_t gnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) gnext = cell_lookup(tid, q1, s1);
+            const StageSpan sp[6] = { make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, raw), make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true),
+                                      make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true),
+                                      make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), make_span(s_src4 + EG_N2, img, n2a, n2e, img_bytes, true), make_span(s_src4 + EG_ST, img, sta, ste, img_bytes, true) };
+            stage_spans6<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(sp);
+            // qualities start as the major value (src/rfqcodec.cpp:1089): no source to wait for
+            if (bycol) { uint4* qt = s_src4 + EG_Q + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
+            if (nextm) EMIT_META_STORE(s_next)
+            if (tid < T) s_g[pb ^ 1u][tid] = gnext;
+        }
+        __syncthreads();
+        uint8_t* const q_t = (uint8_t*)(s_src4 + EG_Q + 1) + (raw ? (uint32_t)(rqa & 15ull) : 0u);        // quality of chunk position q0 + i at q_t[i]
+        uint8_t* const s_t = (uint8_t*)(s_src4 + EG_S + 1);                                              // stored base s0 + i at s_t[i]
+        // ---- bases: 16 per thread, packed bytes -> G A T C (src/rfqcodec.cpp:833-853); beyond mSeqBuf the 'N' prefill of allSeq stays
+        {
+            const uint8_t* pk = (const uint8_t*)(s_src4 + EG2_PK) + (uint32_t)(pka & 15ull); const uint32_t r2 = 2u * (s0 & 3u), ng = (s1 - s0 + 15u) >> 4;
+            const uint32_t have = (uint32_t)(pke - pka);                     // staged packed bytes
+            auto unpack4v = [](uint32_t b) -> uint32_t { const uint32_t y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u; return __builtin_amdgcn_perm(0u, 0x43544147u, idx); };
+            for (uint32_t k = tid; k < ng; k += blockDim.x) {
+                const unsigned long long v = lds_get8(pk, 4u * k); const uint32_t pk32 = (uint32_t)(v >> r2);
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = unpack4v((pk32 >> (8 * i)) & 0xFFu);
+                if (4u * k + 5u > have) {                                    // the tile's last bytes: bases past the packed buffer read as 'N'
+#pragma unroll
+                    for (int i = 0; i < 4; i++) for (int b = 0; b < 4; b++) { const uint32_t bi = ((s0 & 3u) + 16u * k + 4u * (uint32_t)i + (uint32_t)b) >> 2; if (bi >= have) o[i] = (o[i] & ~(0xFFu << (8 * b))) | (0x4Eu << (8 * b)); }
+                }
+                *(uint4*)(s_t + 16u * k) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        // ---- quality streams (a wave per stream) and exception records into the quality tile
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const uint32_t t = (uint32_t)w + 4u * (uint32_t)u;
+            if (t >= nn) continue;                                           // wave-uniform (the N stream waits for the bases)
+            uint32_t g, carry; int last; bool on;
+            if (u < 2) { on = pon[u]; g = pg[u]; carry = pst[u]; last = ppos[u]; }
+            else { g = s_g[pb][t]; on = g < TS[u].nseg; carry = 0; last = -1; if (on) { carry = segS[TS[u].base + g]; last = segP[TS[u].base + g]; } }
+            for (uint32_t k = 0; on && g < TS[u].nseg && last < (int)q1 - 1; k++, g++) {
+                const uint32_t i0 = g * POS2_SEG + 4u * (uint32_t)l;
+                const PosStep ws = (u < 2 && k < 2) ? pw[u < 2 ? u : 0][k < 2 ? k : 0] : pos_fetch(TS[u].sp, TS[u].slen, i0, lim);
+                tile_pos_step(ws, TS[u].sp, TS[u].slen, i0, carry, last, (uint8_t)TS[u].q, q_t, (int)q0, (int)(q1 - q0), l);
+            }
+        }
+        if (nrec) {
+            // (every tile looks at all of the chunk's records: the host keeps images with many of them off this kernel)
+            for (uint32_t i = tid; i < nrec; i += blockDim.x) { const uint8_t* r = xrec + 5ull * i; const uint32_t pos = ld_u32(r + 1); if (pos >= q0 && pos < q1 && pos < qlen_c) q_t[pos - q0] = r[0]; }
+        }
+        if (hasn) {
+            __syncthreads();                                               // the bases are in place
+            const uint32_t tn = nn, un = tn >> 2;                            // the N stream belongs to wave tn & 3, slot tn >> 2
+            if ((uint32_t)w == (tn & 3u)) {
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if ((uint32_t)u != un) continue;
+                    uint32_t g, carry; int last; bool on;
+                    if (u < 2) { on = pon[u]; g = pg[u]; carry = pst[u]; last = ppos[u]; }
+                    else { g = s_g[pb][tn]; on = g < TS[u].nseg; carry = 0; last = -1; if (on) { carry = segS[TS[u].base + g]; last = segP[TS[u].base + g]; } }
+                    for (uint32_t k = 0; on && g < TS[u].nseg && last < (int)s1 - 1; k++, g++) {
+                        const uint32_t i0 = g * POS2_SEG + 4u * (uint32_t)l;
+                        const PosStep ws = (u < 2 && k < 2) ? pw[u < 2 ? u : 0][k < 2 ? k : 0] : pos_fetch(TS[u].sp, TS[u].slen, i0, lim);
+                        tile_pos_step(ws, TS[u].sp, TS[u].slen, i0, carry, last, (uint8_t)'N', s_t, (int)s0, (int)((s1 < slen_c ? s1 : slen_c) - s0), l);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- compose the tile's text in LDS: one thread = one piece (k_dec_emit)
+        {
+            uint8_t* const out = (uint8_t*)s_out4;
+            const uint32_t qoff = 16u + (raw ? (uint32_t)(rqa & 15ull) : 0u), soff = 16u, moff = (uint32_t)(((uint64_t)g0 * 40) & 15ull);
+            const uint32_t n1off = (uint32_t)(n1a & 15ull), n2off = (uint32_t)(n2a & 15ull), stoff = (uint32_t)(sta & 15ull);
+            const uint32_t recA = (tp0.a & 15u) - tp0.a, recB = ET_OCAP / 2 + (tp0.b & 15u) - tp0.b;
+            const uint8_t* const pool = (const uint8_t*)s_src4;
+            for (uint32_t slot = tid; slot < 8u * ET_READS; slot += blockDim.x) {
+                const uint32_t j = slot % ET_READS, kind = slot / ET_READS;
+                if (j >= cnt) continue;
+                const uint32_t* m = s_meta + EM_ROW * j; const bool odd = ((cur + j) & 1u) != 0, to2 = split && odd, rc = il && odd;
+                const uint32_t rec = (to2 ? recB : recA) + m[0], len = m[1], mid = m[11];
+                if (kind == 6) {
+                    const uint32_t e0 = m[10] - 1, e1 = e0 + 1 + len, e2 = e1 + 1 + m[6], e3 = e2 + 1 + len;
+                    out[rec + e0] = '\n'; out[rec + e1] = '\n'; out[rec + e2] = '\n'; out[rec + e3] = '\n';
+                    if ((uint64_t)m[0] + e3 + 1 > (to2 ? cap2 : cap1)) atomicOr(&st->err, 1u << 31);
+                }
+                for (int sub = 0; sub < (kind == 7 ? 2 : 1); sub++) {
+                    uint32_t n, dst, src, qsrc = 0; bool rev = false; int pat = -1, half = -1;
+                    const uint32_t qs = 16u * EG_Q + qoff + (m[15] - q0);
+                    if (kind <= 1) { n = len; dst = rec + m[10] + len + 1 + m[6] + 1; src = qs; rev = rc; half = (int)kind; }
+                    else if (kind <= 4) {
+                        const int ov = (int)m[2]; const uint32_t xa = ov < 0 ? len - (uint32_t)(-ov) : len; const uint32_t sp = m[14] - s0;
+                        const bool partb = kind == 4; const uint32_t p0 = partb ? xa : 0u;
+                        n = partb ? len - xa : xa;
+                        src = 16u * EG_S + soff + (partb ? sp - m[3] : (ov > 0 ? sp - (uint32_t)ov : sp));
+                        dst = rec + m[10] + (rc ? len - p0 - n : p0); rev = rc; qsrc = qs + p0; half = partb ? -1 : (int)kind - 2;
+                    }
+                    else if (kind == 5) { n = m[4]; dst = rec; src = 16u * EG_N1 + n1off + ((fl & C_NAME1_SAME) ? 0u : m[7] - a7); }
+                    else if (kind == 6) { n = mid; dst = rec + m[4]; src = 16u * EG_MID + moff + 40u * j; }
+                    else if (sub == 0) { n = m[5]; dst = rec + m[4] + mid; src = 16u * EG_N2 + n2off + ((fl & C_NAME2_SAME) ? 0u : m[8] - a8);
+                                         if ((fl & C_NAME2_SAME) && rc && dch != 0 && dpos < n) pat = (int)dpos; }
+                    else { n = m[6]; dst = rec + m[10] + len + 1; src = 16u * EG_ST + stoff + ((fl & C_STRAND_SAME) ? 0u : m[9] - a9); }
+                    uint32_t gb = 0, ge = (n + 15u) >> 4;
+                    if (half == 0) ge = (ge + 1u) >> 1; else if (half == 1) gb = (ge + 1u) >> 1;
+                    uint8_t* const o = out + dst;
+                    if (kind <= 1) emit_copy<false, true, false>(o, pool, src, n, gb, ge, rev, 0u, false, nq, -1, dch);
+                    else if (kind <= 4) emit_copy<true, true, false>(o, pool, src, n, gb, ge, rev, qsrc, implied_n, nq, -1, dch);
+                    else if (pat < 0) emit_copy<false, false, false>(o, pool, src, n, gb, ge, false, 0u, false, nq, -1, dch);
+                    else emit_copy<false, false, true>(o, pool, src, n, gb, ge, false, 0u, false, nq, pat, dch);
+                }
+            }
+        }
+        __syncthreads();
+        if (tp1.a <= cap1) flush_span(s_out4, out1, tp0.a, tp1.a);
+        if (split && tp1.b <= cap2) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
+        cur += cnt; pb ^= 1u;
+    }
+#undef EMIT_META_VARS
+#undef EMIT_META_LOAD
+#undef EMIT_META_STORE
+    (void)dbg;
 }
