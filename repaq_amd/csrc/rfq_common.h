@@ -172,6 +172,10 @@ __device__ __forceinline__ void lds_get16(const uint8_t* base, uint32_t a, uint3
 __device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) { return ((const LdsU4*)(base + a))->a; }
 struct __attribute__((packed, aligned(1))) LdsU8 { unsigned long long a; };
 __device__ __forceinline__ unsigned long long lds_get8(const uint8_t* base, uint32_t a) { return ((const LdsU8*)(base + a))->a; }
+// a wave-uniform value the compiler cannot prove uniform (it was loaded through a vector address, or derives from the wave's index): into an SGPR
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
+template <class P> __device__ __forceinline__ P* uniptr(P* p) { return (P*)(uintptr_t)uni64((uint64_t)(uintptr_t)p); }
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 // byte-wise full mask (0xFF per byte of w equal to the pattern byte)
 __device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {

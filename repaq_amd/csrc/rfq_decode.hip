@@ -11,10 +11,21 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 72, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_END
+    DB_CHUNKS = 72, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_SEGK, DB_NENT, DB_LOFF, DB_PLIST, DB_END
 };
 static_assert(DB_END <= 104, "rfq_ctx::b too small");
 
+// fused path: k_dec_pos_list for the quality streams and the N-position stream (the arena is whatever B[DB_PLIST] holds)
+static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk* CH, uint32_t n_chunks, uint32_t maxseg, uint32_t ncell, uint32_t nstr,
+                            uint32_t mq, uint32_t mn, uint32_t nn, bool hasn, hipStream_t LS) {
+    DBuf* B = ctx->b; const DevHeader* D = ctx->d_hdr.as<DevHeader>(); const DecStatus* dst = B[DB_STATUS].as<DecStatus>();
+    const unsigned long long cap = B[DB_PLIST].cap / 4;
+#define RFQ_LIST_ARGS a->d_rfq, CH, D, (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), (const uint32_t*)B[DB_SEGK].as<uint32_t>(), \
+                      (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), B[DB_PLIST].as<uint32_t>(), cap, B[DB_CELL].as<uint32_t>(), maxseg, ncell, (uint64_t)a->n
+    if (nn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, 0u, nstr, dst);
+    if (hasn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, ctx->h_hdr.n_normal, nstr, dst);
+#undef RFQ_LIST_ARGS
+}
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
 struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec; };
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
@@ -58,7 +69,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // Taken for files with few quality streams whose reads and exception lists fit a tile; RFQ_TUNE bit 11 forces the materialising path.
     const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
     const bool fused = !(tune & 2048) && (!bycol_h || HH.n_normal <= POS2_MAX_STREAMS) && g.max_len <= 2600u && g.max_nrec <= 4096u;
-    uint32_t f_maxseg = 1, f_ncell = 1; const uint32_t f_nstr = HH.n_normal + 1;
+    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false; const uint32_t f_nstr = HH.n_normal + 1;
     if (fused) {
         ctx->timer.begin("streams", S);
         const bool hasn = (HH.flags & H_N_POS) != 0; const uint32_t nn = bycol_h ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u;
@@ -68,16 +79,23 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         if (nn || hasn) {
             const uint32_t mq = nn ? g.max_stream / POS2_SEG + 1 : 0u, mn = hasn ? g.max_npos / POS2_SEG + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
             f_ncell = g.max_bases / POS2_CELL + 2;
-            const size_t nseg = (size_t)n_chunks * f_nstr * f_maxseg, ncl = (size_t)n_chunks * f_nstr * f_ncell;
-            HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 16 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure((size_t)n_chunks * f_nstr * 4 + 16));
-            HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_CELL].ensure(ncl * 4 + 16));
-            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, (size_t)n_chunks * f_nstr * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
+            const size_t nst = (size_t)n_chunks * f_nstr, nseg = nst * f_maxseg, ncl = nst * f_ncell;
+            HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 32 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure(nst * 4 + 16));
+            HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_SEGK].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_CELL].ensure(ncl * 4 + 16));
+            HIPCHK(ctx, B[DB_NENT].ensure(nst * 4 + 16)); HIPCHK(ctx, B[DB_LOFF].ensure(nst * 8 + 16));
+            // the arena of the position lists: a position belongs to at most one stream, the coded ones are a few percent of the bases; if a
+            // file needs more than the arena holds, k_dec_pos_list leaves it alone and the pass is repeated below with the right size
+            HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(((uint64_t)total_bases + pv_tot.d) / 4 + 1024) * 4));
+            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
 #define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
             if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);
             if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr);
 #undef RFQ_SUM2_ARGS
-            hipLaunchKernelGGL(k_dec_pos_link2, dim3((n_chunks * f_nstr + 3) / 4), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
-                               (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_CELL].as<uint32_t>(), f_maxseg, f_ncell, n_chunks * f_nstr);
+            hipLaunchKernelGGL(k_dec_pos_link2, dim3((uint32_t)((nst + 3) / 4)), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
+                               (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_SEGK].as<uint32_t>(), B[DB_NENT].as<uint32_t>(), f_maxseg, (uint32_t)nst);
+            hipLaunchKernelGGL(k_dec_pos_off, dim3(1), dim3(256), 0, A, (const uint32_t*)B[DB_NENT].as<uint32_t>(), B[DB_LOFF].as<unsigned long long>(), (uint32_t)nst, dst);
+            launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, A);
+            f_lists = true; f_mq = mq; f_mn = mn; f_nn = nn; f_hasn = hasn;
         }
         if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
         KCHK(ctx, "k_dec_streams");
@@ -145,6 +163,11 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     HIPCHK(ctx, ctx->fetch_sync(S));
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
     // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
+    if (fused && f_lists && hs.list_need > B[DB_PLIST].cap / 4) {            // the lists did not fit the arena: now that their size is known, build them
+        HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(hs.list_need + 1024) * 4));
+        launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, f_mq, f_mn, f_nn, f_hasn, S);
+        KCHK(ctx, "k_dec_pos_list");
+    }
     hs.text1 = hs.text2 = 0; for (int i = 0; i < 64; i++) { hs.text1 += hs.text_slots[0][i]; hs.text2 += hs.text_slots[1][i]; }
     if (hs.text1 >= 0xFFFFFFF0ull || hs.text2 >= 0xFFFFFFF0ull) return RFQ_RANGE_TOO_BIG;       // (the caller decodes the range in two halves)
     uint8_t *o1, *o2; uint64_t cap1, cap2;
@@ -156,11 +179,16 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     {
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
         const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
-        if (fused) {
-            hipLaunchKernelGGL(k_dec_emit2<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst,
-                               (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), (const uint32_t*)B[DB_SEGN].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(),
-                               f_maxseg, f_ncell, f_nstr, (unsigned long long*)nullptr);
-        } else
+#define RFQ_EMIT2_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
+                       (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr
+        if (fused && (tune & 7)) {
+            unsigned long long* dbg = (unsigned long long*)B[DB_SCAN].p; (void)hipMemsetAsync(dbg, 0, 64, S);       // (the scan scratch is idle here)
+            hipLaunchKernelGGL(k_dec_emit2<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, dbg, 0);
+            unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+            if (h[6]) fprintf(stderr, "[emit2 dbg] waves=%llu avg cycles/wave: stage=%llu unpack=%llu tokens=%llu nstream=%llu compose=%llu flush=%llu steps/wave=%.1f\n", h[6], h[0]/h[6], h[1]/h[6], h[2]/h[6], h[3]/h[6], h[4]/h[6], h[5]/h[6], (double)h[7]/h[6]);
+        } else if (fused) hipLaunchKernelGGL(k_dec_emit2<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, (unsigned long long*)nullptr, (tune >> 12) & 15);   // (tune bits 12-15: ablation switches, text invalid)
+#undef RFQ_EMIT2_ARGS
+        else
         if (tune & 7) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
         if (fused) {} else if (tune & 7) hipLaunchKernelGGL(k_dec_emit<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
                            (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);

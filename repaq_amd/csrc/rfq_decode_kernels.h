@@ -30,6 +30,7 @@ struct DecStatus {
     uint64_t base_slots[16];         // partial sums of the read lengths of all chunks (parse_chunk)
     uint32_t max_len, max_bases;     // longest read / largest chunk (bases, clamped to 2^32 - 1) of the image
     uint32_t max_nrec, pad2;         // most exception records of any chunk (by-column quality payloads)
+    unsigned long long list_need;    // fused path: entries of all position lists (k_dec_pos_off)
 };
 
 // sum of n bytes by one wave (wave-uniform result)
@@ -460,12 +461,16 @@ __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __
     __shared__ int s_tp[256];                                           // (one wave per block)
     wave_pos_decode(s.sp, s.slen, b0, b1, segS[idx], segP[idx], s.q, s.out, s.out_len, lim, s_tp);
 }
-// ================================================================== fused path: the emitter applies the position tokens itself
-// (files with <= POS2_MAX_STREAMS quality streams - every NovaSeq-binned file): no expanded qualities / bases in HBM (qdec / sdec), no
-// prefill, no one-line-per-token scatter.  A stream is summarised in ONE-STEP segments of 256 bytes (k_dec_pos_sum2: transition table +
-// positions covered per entry state), a wave per stream links them by a scan (k_dec_pos_link2: entry state and entry position of
-// every segment) and records, for every POS2_CELL positions, the first segment that reaches the cell; k_dec_emit2 starts each tile's
-// streams from there.
+// ================================================================== fused path: no expanded qualities / bases in HBM
+// (files with <= POS2_MAX_STREAMS quality streams - every NovaSeq-binned file).  The position streams are turned into POSITION LISTS: one
+// u32 per coded position, in stream order, all streams of all chunks in one arena (a position belongs to at most one stream, so a list is a
+// few percent of the bases).  The emitter prefills a tile's qualities with the major value in LDS, scatters the list entries that fall into
+// the tile, unpacks the tile's bases LDS -> LDS from the packed bytes and scatters the N list: no qdec / sdec, no prefill, unpack or
+// one-line-per-token scatter kernels.  Three light passes build the lists, one wave per 256-byte segment of a stream:
+//   k_dec_pos_sum2   per segment and entry state of the token automaton: exit state, positions advanced, positions emitted
+//   k_dec_pos_link2  per stream, a wave scan over those summaries: entry state / entry position / entry list index of every segment
+//   k_dec_pos_list   decodes every segment from its now-known entry and writes its positions; records for every POS2_CELL positions the
+//                    index of the first list entry at or beyond the cell (the emitter starts there)
 #define POS2_SEG 256u
 #define POS2_CELL 1024u
 #define POS2_MAX_STREAMS 8u
@@ -484,7 +489,25 @@ __device__ __forceinline__ PosSrc pos_src_of(const uint8_t* __restrict__ img, co
     s.sp = qp + off; s.slen = sl; s.q = D->normal[jj];
     return s;
 }
-// grid (ceil(maxseg / 4), streams, n_chunks) x 256 threads: one wave per 256-byte segment; index arrays are [chunk][nstr][maxseg]
+// tokens that START in the lane's 4 bytes when the automaton enters them in state st: positions advanced (adv) and positions emitted (cnt:
+// one per gap token, the run length per run token)
+__device__ __forceinline__ void pos_lane_adv_cnt(const PosFront& f, uint32_t slen, uint32_t i0, uint32_t st, int& adv, int& cnt) {
+    adv = 0; cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b0 = f.bt[k]; const bool valid = i0 + (uint32_t)k < slen;
+        const uint32_t b1 = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2 = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3 = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
+        if (valid && st == 0) {
+            if ((b0 & 0x80u) == 0) { adv += (int)b0 + 1; cnt++; }
+            else if ((b0 & 0x40u) == 0) { adv += (int)(((b0 & 0x3Fu) << 8) | b1) + 1; cnt++; }
+            else if ((b0 & 0x20u) == 0) { adv += (int)(b0 & 0x1Fu) + 1; cnt += (int)(b0 & 0x1Fu) + 1; }
+            else { adv += (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1; cnt++; }
+        }
+        if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
+    }
+}
+// grid (ceil(maxseg / 4), streams, n_chunks) x 256 threads: one wave per segment; index arrays are [chunk][nstr][maxseg]; segA[8 * idx + s] =
+// positions advanced, segA[8 * idx + 4 + s] = positions emitted for entry state s
 __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
                                uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes, uint32_t jj0, uint32_t nstr) {
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
@@ -496,86 +519,124 @@ __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __
     const PosStep w = pos_fetch(s.sp, s.slen, i0, lim);
     const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
     uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;       // segment entry state -> state in front of my bytes
-    int a0 = pos_lane_adv(f, s.slen, i0, (Fex >> 0) & 3u), a1 = pos_lane_adv(f, s.slen, i0, (Fex >> 2) & 3u);
-    int a2 = pos_lane_adv(f, s.slen, i0, (Fex >> 4) & 3u), a3 = pos_lane_adv(f, s.slen, i0, (Fex >> 6) & 3u);
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    int a[4], n[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { pos_lane_adv_cnt(f, s.slen, i0, (Fex >> (2 * e)) & 3u, a[e], n[e]); a[e] = wave_sum(a[e]); n[e] = wave_sum(n[e]); }
     const uint32_t F = __shfl(f.Fin, 63);
-    if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)F; segA[4 * idx + 0] = a0; segA[4 * idx + 1] = a1; segA[4 * idx + 2] = a2; segA[4 * idx + 3] = a3; }
+    if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)F;
+#pragma unroll
+                  for (int e = 0; e < 4; e++) { segA[8 * idx + e] = a[e]; segA[8 * idx + 4 + e] = n[e]; } }
 }
-// one wave per (chunk, stream): entry state / entry position of every segment by a scan over (transition table, positions per entry state)
-// pairs - (F1, A1) then (F2, A2) is (F2 o F1, s -> A1[s] + A2[F1[s]]) - and the cell index: cellseg[cell] = first segment whose tokens
-// reach position cell * POS2_CELL or beyond (0xFFFFFFFF: none does).
-struct PosLink { uint32_t F; int a[4]; };
+// one wave per (chunk, stream): entry state / position / list index of every segment by a scan over (transition table, advance and count
+// per entry state): x then y is (y.F o x.F, s -> x.a[s] + y.a[x.F[s]]); also the stream's number of list entries
+struct PosLink { uint32_t F; int a[4], n[4]; };
+__device__ __forceinline__ int sel4(const int (&v)[4], uint32_t t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ PosLink poslink_then(const PosLink& x, const PosLink& y) {   // x first, then y
     PosLink r; r.F = fn_compose(x.F, y.F);
 #pragma unroll
-    for (int s = 0; s < 4; s++) { const uint32_t t = (x.F >> (2 * s)) & 3u; r.a[s] = x.a[s] + (t == 0 ? y.a[0] : (t == 1 ? y.a[1] : (t == 2 ? y.a[2] : y.a[3]))); }
+    for (int s = 0; s < 4; s++) { const uint32_t t = (x.F >> (2 * s)) & 3u; r.a[s] = x.a[s] + sel4(y.a, t); r.n[s] = x.n[s] + sel4(y.n, t); }
     return r;
 }
+__device__ __forceinline__ PosLink poslink_shfl_up(const PosLink& v, unsigned dd) {
+    PosLink u; u.F = __shfl_up(v.F, dd);
+#pragma unroll
+    for (int s = 0; s < 4; s++) { u.a[s] = __shfl_up(v.a[s], dd); u.n[s] = __shfl_up(v.n[s], dd); }
+    return u;
+}
 __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __restrict__ segA, const uint32_t* __restrict__ segN, uint8_t* __restrict__ segS, int* __restrict__ segP,
-                                uint32_t* __restrict__ cellseg, uint32_t maxseg, uint32_t ncell, uint32_t n_streams) {
+                                uint32_t* __restrict__ segK, uint32_t* __restrict__ nent, uint32_t maxseg, uint32_t n_streams) {
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(); if (t >= n_streams) return;
     const int l = lane_id(); const uint32_t n = segN[t];
-    uint32_t cs = 0; int cp = -1;                                          // state / last covered position in front of the block of 64 segments
+    uint32_t cs = 0; int cp = -1; uint32_t ck = 0;                          // state / last covered position / list entries in front of the block of 64 segments
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t g = base + (uint32_t)l; const size_t idx = (size_t)t * maxseg + g;
-        PosLink me; me.F = POS_ID; me.a[0] = me.a[1] = me.a[2] = me.a[3] = 0;
-        if (g < n) { me.F = segF[idx]; me.a[0] = segA[4 * idx]; me.a[1] = segA[4 * idx + 1]; me.a[2] = segA[4 * idx + 2]; me.a[3] = segA[4 * idx + 3]; }
+        PosLink me; me.F = POS_ID;
+#pragma unroll
+        for (int s = 0; s < 4; s++) { me.a[s] = 0; me.n[s] = 0; }
+        if (g < n) { me.F = segF[idx];
+#pragma unroll
+                     for (int s = 0; s < 4; s++) { me.a[s] = segA[8 * idx + s]; me.n[s] = segA[8 * idx + 4 + s]; } }
         PosLink inc = me;
 #pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            PosLink up; up.F = __shfl_up(inc.F, (unsigned)dd); up.a[0] = __shfl_up(inc.a[0], (unsigned)dd); up.a[1] = __shfl_up(inc.a[1], (unsigned)dd); up.a[2] = __shfl_up(inc.a[2], (unsigned)dd); up.a[3] = __shfl_up(inc.a[3], (unsigned)dd);
-            if (l >= dd) inc = poslink_then(up, inc);
-        }
-        PosLink ex; ex.F = __shfl_up(inc.F, 1u); ex.a[0] = __shfl_up(inc.a[0], 1u); ex.a[1] = __shfl_up(inc.a[1], 1u); ex.a[2] = __shfl_up(inc.a[2], 1u); ex.a[3] = __shfl_up(inc.a[3], 1u);
-        if (l == 0) { ex.F = POS_ID; ex.a[0] = ex.a[1] = ex.a[2] = ex.a[3] = 0; }
-        const uint32_t st = (ex.F >> (2 * cs)) & 3u;                       // my segment's entry state
-        const int ep = cp + (cs == 0 ? ex.a[0] : (cs == 1 ? ex.a[1] : (cs == 2 ? ex.a[2] : ex.a[3])));     // ... and entry position (last position covered before it)
-        if (g < n) {
-            segS[idx] = (uint8_t)st; segP[idx] = ep;
-            const int en = ep + (st == 0 ? me.a[0] : (st == 1 ? me.a[1] : (st == 2 ? me.a[2] : me.a[3])));   // last position covered by my segment
-            if (en >= 0) {
-                uint32_t c0 = ep < 0 ? 0u : (uint32_t)ep / POS2_CELL + 1u; const uint32_t c1 = (uint32_t)en / POS2_CELL;
-                for (; c0 <= c1 && c0 < ncell; c0++) cellseg[(size_t)t * ncell + c0] = g;
-            }
-        }
-        const uint32_t Fl = __shfl(inc.F, 63); const int al0 = __shfl(inc.a[0], 63), al1 = __shfl(inc.a[1], 63), al2 = __shfl(inc.a[2], 63), al3 = __shfl(inc.a[3], 63);
-        cp += cs == 0 ? al0 : (cs == 1 ? al1 : (cs == 2 ? al2 : al3)); cs = (Fl >> (2 * cs)) & 3u;
+        for (int dd = 1; dd < 64; dd <<= 1) { const PosLink up = poslink_shfl_up(inc, (unsigned)dd); if (l >= dd) inc = poslink_then(up, inc); }
+        PosLink ex = poslink_shfl_up(inc, 1u);
+        if (l == 0) { ex.F = POS_ID;
+#pragma unroll
+                      for (int s = 0; s < 4; s++) { ex.a[s] = 0; ex.n[s] = 0; } }
+        if (g < n) { segS[idx] = (uint8_t)((ex.F >> (2 * cs)) & 3u); segP[idx] = cp + sel4(ex.a, cs); segK[idx] = ck + (uint32_t)sel4(ex.n, cs); }
+        const uint32_t Fl = __shfl(inc.F, 63); int al[4], nl[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { al[s] = __shfl(inc.a[s], 63); nl[s] = __shfl(inc.n[s], 63); }
+        cp += sel4(al, cs); ck += (uint32_t)sel4(nl, cs); cs = (Fl >> (2 * cs)) & 3u;
     }
+    if (l == 0) nent[t] = ck;
 }
-// decodeSingleQualByCol (src/rfqcodec.cpp:957-1007) for ONE 256-byte step of a stream into an LDS tile: positions p of [t0, t0 + tlen) get
-// tile[p - t0] = q.  carry / last: automaton state and last covered position in front of the step; both are advanced.
-__device__ __forceinline__ void tile_pos_step(const PosStep& w, const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0, uint32_t& carry, int& last,
-                                              uint8_t q, uint8_t* tile, int t0, int tlen, int l) {
-    const PosFront f = pos_front(w, sp, slen, i0, l);
-    const uint32_t after = (f.Fin >> (2 * carry)) & 3u;
-    uint32_t st = __shfl_up(after, 1u); if (l == 0) st = carry;
-    carry = __shfl(after, 63);
-    int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0;
+// exclusive prefix of the streams' entry counts (one workgroup; n_streams is some thousands) -> where each list starts in the arena; the total
+// goes to st->list_need (the host grows the arena and repeats k_dec_pos_list when it did not fit)
+__global__ void k_dec_pos_off(const uint32_t* __restrict__ nent, unsigned long long* __restrict__ loff, uint32_t n_streams, DecStatus* st) {
+    __shared__ unsigned long long s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_streams; b0 += blockDim.x) {
+        const uint32_t i = b0 + threadIdx.x; const unsigned long long v = i < n_streams ? nent[i] : 0ull;
+        unsigned long long tot; const unsigned long long ex = block_excl_sum<unsigned long long>(v, &tot);
+        const unsigned long long c = s_carry;
+        if (i < n_streams) loff[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st->list_need = s_carry;
+}
+// decodeSingleQualByCol (src/rfqcodec.cpp:957-1007) for one segment from its entry (state, last covered position, list index): the positions
+// it codes go to plist[loff + k ...] in stream order; cellidx[cell] = index (within the stream's list) of the first entry >= cell * POS2_CELL
+__global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
+                               const uint8_t* __restrict__ segS, const int* __restrict__ segP, const uint32_t* __restrict__ segK, const unsigned long long* __restrict__ loff,
+                               uint32_t* __restrict__ plist, unsigned long long cap, uint32_t* __restrict__ cellidx, uint32_t maxseg, uint32_t ncell, uint64_t img_bytes, uint32_t jj0, uint32_t nstr, const DecStatus* st) {
+    if (st->list_need > cap) return;                                      // (uniform) the arena is too small: the host repeats the pass
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
+    const DChunk d = CH[c];
+    const PosSrc s = pos_src_of(img, d, D, jj, nullptr);
+    const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
+    const size_t t = (size_t)c * nstr + jj, idx = t * maxseg + g;
+    const uint32_t carry = segS[idx]; const int last = segP[idx]; const uint32_t k0 = segK[idx];
+    uint32_t* const out = plist + loff[t]; uint32_t* const cells = cellidx + t * ncell;
+    const uint32_t i0 = b0 + 4u * (uint32_t)l;
+    const PosStep w = pos_fetch(s.sp, s.slen, i0, lim);
+    const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
+    uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
+    uint32_t st0 = (Fex >> (2 * carry)) & 3u;                              // state in front of my first byte
+    int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0, lane_cnt = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t b0 = f.bt[k]; const bool valid = i0 + (uint32_t)k < slen;
+        const uint32_t bb = f.bt[k]; const bool valid = i0 + (uint32_t)k < s.slen;
         const uint32_t b1 = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2 = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3 = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
-        start[k] = valid && st == 0; adv[k] = 0; run[k] = 0;
+        start[k] = valid && st0 == 0; adv[k] = 0; run[k] = 0;
         if (start[k]) {
-            if ((b0 & 0x80u) == 0) adv[k] = (int)b0 + 1;
-            else if ((b0 & 0x40u) == 0) adv[k] = (int)(((b0 & 0x3Fu) << 8) | b1) + 1;
-            else if ((b0 & 0x20u) == 0) { run[k] = (b0 & 0x1Fu) + 1; adv[k] = (int)run[k]; }
-            else adv[k] = (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
+            if ((bb & 0x80u) == 0) adv[k] = (int)bb + 1;
+            else if ((bb & 0x40u) == 0) adv[k] = (int)(((bb & 0x3Fu) << 8) | b1) + 1;
+            else if ((bb & 0x20u) == 0) { run[k] = (bb & 0x1Fu) + 1; adv[k] = (int)run[k]; }
+            else adv[k] = (int)(((bb & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
+            lane_cnt += run[k] ? (int)run[k] : 1;
         }
         lane_adv += adv[k];
-        if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
+        if (valid) st0 = (f.fn[k] >> (2 * st0)) & 3u;
     }
-    const int incl = wave_incl_sum(lane_adv);
-    int end = last + incl - lane_adv;                                        // last covered position in front of my tokens
+    const int ia = wave_incl_sum(lane_adv), ic = wave_incl_sum(lane_cnt);
+    int end = last + ia - lane_adv; uint32_t k = k0 + (uint32_t)(ic - lane_cnt);   // last covered position / list index in front of my tokens
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (!start[k]) continue;
-        end += adv[k];
-        const int lo = run[k] ? end - (int)run[k] + 1 : end;
-        for (int p = lo < t0 ? t0 : lo; p <= end && p < t0 + tlen; p++) tile[p - t0] = q;
+    for (int q = 0; q < 4; q++) {
+        if (!start[q]) continue;
+        const int prev = end; end += adv[q];
+        const int lo = run[q] ? end - (int)run[q] + 1 : end;
+        int pp = prev;                                                       // the position of list entry k - 1 (-1: none)
+        for (int p = lo; p <= end; p++, k++) {
+            out[k] = (uint32_t)p;
+            uint32_t c0 = pp < 0 ? 0u : (uint32_t)pp / POS2_CELL + 1u; const uint32_t c1 = (uint32_t)p / POS2_CELL;
+            for (; c0 <= c1 && c0 < ncell; c0++) cells[c0] = k;
+            pp = p;
+        }
     }
-    last += __shfl(incl, 63);
 }
 
 // exception records (q, u32 LE position) after the streams (src/rfqcodec.cpp:1034-1043); raw copy when DONT_ENCODE_QUAL (:905-910)
@@ -1047,19 +1108,21 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
 // Everything after that - one thread = one piece, byte-granular ds_read_b128 / ds_write_b128, aligned flush - is k_dec_emit's compose phase.
 #define EG2_PK EG_END
 #define EG2_END (EG2_PK + ET_SCAP / 64 + 4)
-struct TileStream { const uint8_t* sp; uint32_t slen, nseg; size_t base; uint32_t q; bool isn; };   // base: index of segment 0 in segS / segP
+#define EL2_LP 2                  // list entries per thread and stream requested up front (512 per stream and tile)
 template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
-                           const uint8_t* __restrict__ segS, const int* __restrict__ segP, const uint32_t* __restrict__ segN, const uint32_t* __restrict__ cellseg,
-                           uint32_t maxseg, uint32_t ncell, uint32_t nstr, unsigned long long* dbg) {
+                           const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
+                           uint32_t ncell, uint32_t nstr, unsigned long long* dbg, int abl) {
     __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
     __shared__ uint4 s_src4[EG2_END];
     __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta2[2][(ET_READS + 1) * EM_ROW];
     __shared__ uint32_t s_g[2][POS2_MAX_STREAMS + 2];
+    __shared__ unsigned long long s_loff[POS2_MAX_STREAMS + 2]; __shared__ uint32_t s_nent[POS2_MAX_STREAMS + 2], s_val[POS2_MAX_STREAMS + 2], s_kb[2][POS2_MAX_STREAMS + 2], s_nl0;
+    long long c0 = 0, c1 = 0, a_stage = 0, a_unpack = 0, a_tok = 0, a_n = 0, a_comp = 0, a_flush = 0, a_steps = 0;
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint8_t* lim = img + img_bytes;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
     const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
-    const int l = lane_id(), w = wave_id(); const uint32_t tid = threadIdx.x;
+    const int l = lane_id(), w = (int)uni32((uint32_t)wave_id()); const uint32_t tid = threadIdx.x;
     const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
     uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;
     const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
@@ -1069,25 +1132,23 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
     const uint32_t T = nn + (hasn ? 1u : 0u);                                // streams of the tile: t < nn quality value t, t == nn the N positions
     const uint32_t major4 = (D->major & 0xFFu) * 0x01010101u;
     const uint32_t qlen_c = R.pq[f + d.reads] - pq0, slen_c = R.pv[f + d.reads].d - pv0.d;      // qualities / stored bases of the chunk
-    // this wave's streams (t = w, w + 4, w + 8): where their bytes are, their segment tables
-    TileStream TS[3];
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-        const uint32_t t = (uint32_t)w + 4u * (uint32_t)u; TS[u].sp = nullptr; TS[u].slen = 0; TS[u].nseg = 0; TS[u].base = 0; TS[u].q = 0; TS[u].isn = false;
-        if (t < T) { const uint32_t jj = t < nn ? t : D->n_normal; const PosSrc ps = pos_src_of(img, d, D, jj, nullptr);
-                     TS[u].sp = ps.sp; TS[u].slen = ps.slen; TS[u].q = ps.q; TS[u].isn = t >= nn; TS[u].nseg = (ps.slen + POS2_SEG - 1) / POS2_SEG; TS[u].base = ((size_t)c * nstr + jj) * maxseg; }
-    }
+    // the chunk's position lists: where they start in the arena, how long they are, what they write
+    if (tid < T) { const uint32_t jj = tid < nn ? tid : D->n_normal; const size_t t_ = (size_t)c * nstr + jj; s_loff[tid] = loff[t_]; s_nent[tid] = nent[t_]; s_val[tid] = tid < nn ? (uint32_t)D->normal[tid] : (uint32_t)'N'; }
     // exception records behind the streams (src/rfqcodec.cpp:1034-1043)
     uint32_t nrec = 0; const uint8_t* xrec = nullptr;
     if (bycol && 4ull * D->n_normal <= d.qual_size) {
         const uint8_t* qp = cp + d.o_qual; uint64_t off = 4ull * D->n_normal;
         for (uint32_t i = 0; i < D->n_normal; i++) off += ld_u32(qp + 4 * i);
+        off = uni64(off);
         if (off <= d.qual_size) { nrec = (uint32_t)((d.qual_size - off) / 5); xrec = qp + off; }
     }
-    // cell of a tile start -> first segment of stream t that reaches it (the lookup for the NEXT tile rides beside this tile's staging)
-    auto cell_lookup = [&](uint32_t t, uint32_t qpos, uint32_t spos) -> uint32_t {
-        const uint32_t jj = t < nn ? t : D->n_normal; uint32_t cell = (t < nn ? qpos : spos) / POS2_CELL; if (cell >= ncell) cell = ncell - 1u;
-        return cellseg[((size_t)c * nstr + jj) * ncell + cell];
+    // cell of a tile start -> index of the first entry of list t at or beyond the cell (the lookup for the NEXT tile rides beside this tile's staging)
+    // ... and, `bound`: of the first entry beyond anything a tile that starts there can hold (a tile spans < ET_SCAP positions): the entries a
+    // tile needs are known exactly before it asks for them
+    auto cell_lookup = [&](uint32_t t, uint32_t qpos, uint32_t spos, bool bound) -> uint32_t {
+        const uint32_t jj = t < nn ? t : D->n_normal; uint32_t cell = ((t < nn ? qpos : spos) + (bound ? ET_SCAP : 0u)) / POS2_CELL + (bound ? 1u : 0u);
+        if (cell >= ncell) return bound ? 0xFFFFFFFFu : cellidx[((size_t)c * nstr + jj) * ncell + ncell - 1u];
+        return cellidx[((size_t)c * nstr + jj) * ncell + cell];
     };
 #define EMIT_META_VARS U4 tp_, pv_; uint32_t pq_ = 0, len_ = 0, ov_ = 0, pl_ = 0, n1_ = 0, n2_ = 0, sl_ = 0, md_ = 0, r_ = 0; bool odd_ = false; tp_.a = tp_.b = 0; pv_.a = pv_.b = pv_.c = pv_.d = 0;
 #define EMIT_META_LOAD(from)                                                                                                          \
@@ -1107,10 +1168,11 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
                          m[11] = md_; m[10] = n1_ + md_ + n2_ + 1; } }
     uint32_t cur = rs; uint32_t pb = 0;
     { EMIT_META_VARS if (cur < re && tid <= ET_READS && cur + tid <= re) { EMIT_META_LOAD(cur) EMIT_META_STORE(s_meta2[0]) }
-      if (cur < re && tid < T) s_g[0][tid] = cell_lookup(tid, R.pq[f + cur] - pq0, R.pv[f + cur].d - pv0.d); }
+      if (cur < re && tid < T) { const uint32_t qp_ = R.pq[f + cur] - pq0, sp_ = R.pv[f + cur].d - pv0.d; s_g[0][tid] = cell_lookup(tid, qp_, sp_, false); s_kb[0][tid] = cell_lookup(tid, qp_, sp_, true); } }
     __syncthreads();
     while (cur < re) {                                                       // block-uniform
         uint32_t* const s_meta = s_meta2[pb]; uint32_t* const s_next = s_meta2[pb ^ 1u];
+        if (DBG) c0 = clock64();
         const uint32_t g0 = f + cur;
         const uint32_t* mb = s_meta;
 #define EMIT_FITS(me) ((me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 48u <= ET_SCAP && (me[14] - mb[14]) + 48u <= ET_SCAP \
@@ -1131,45 +1193,56 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
         }
 #undef EMIT_FITS
+        cnt = uni32(cnt);
         if (cnt == 0) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); break; }   // (a pair beyond the tile: the host keeps such images off this kernel)
         const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + EM_ROW * cnt;
-        U4 tp0, tp1; tp0.a = mb[12]; tp0.b = mb[13]; tp1.a = me[12]; tp1.b = me[13];
-        const uint32_t q0 = mb[15], s0 = mb[14], q1 = me[15], s1 = me[14];
+        U4 tp0, tp1; tp0.a = uni32(mb[12]); tp0.b = uni32(mb[13]); tp1.a = uni32(me[12]); tp1.b = uni32(me[13]);
+        const uint32_t q0 = uni32(mb[15]), s0 = uni32(mb[14]), q1 = uni32(me[15]), s1 = uni32(me[14]);
         // ---- stage: packed bases, name pieces, middles (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
         const uint64_t ib = d.off;
-        const uint32_t a7 = (fl & C_NAME1_SAME) ? 0u : mb[7], a8 = (fl & C_NAME2_SAME) ? 0u : mb[8], a9 = (fl & C_STRAND_SAME) ? 0u : mb[9];
-        const uint64_t n1a = ib + d.o_n1 + a7, n1e = (fl & C_NAME1_SAME) ? n1a + d.n1_size : ib + d.o_n1 + me[7];
-        const uint64_t n2a = ib + d.o_n2 + a8, n2e = (fl & C_NAME2_SAME) ? n2a + d.n2_size : ib + d.o_n2 + me[8];
-        const uint64_t sta = ib + d.o_st + a9, ste = (fl & C_STRAND_SAME) ? sta + d.st_size : ib + d.o_st + me[9];
+        const uint32_t a7 = (fl & C_NAME1_SAME) ? 0u : uni32(mb[7]), a8 = (fl & C_NAME2_SAME) ? 0u : uni32(mb[8]), a9 = (fl & C_STRAND_SAME) ? 0u : uni32(mb[9]);
+        const uint32_t e7 = uni32(me[7]), e8 = uni32(me[8]), e9 = uni32(me[9]);
+        const uint64_t n1a = ib + d.o_n1 + a7, n1e = (fl & C_NAME1_SAME) ? n1a + d.n1_size : ib + d.o_n1 + e7;
+        const uint64_t n2a = ib + d.o_n2 + a8, n2e = (fl & C_NAME2_SAME) ? n2a + d.n2_size : ib + d.o_n2 + e8;
+        const uint64_t sta = ib + d.o_st + a9, ste = (fl & C_STRAND_SAME) ? sta + d.st_size : ib + d.o_st + e9;
         uint64_t pka = ib + d.o_seq + (s0 >> 2), pke = ib + d.o_seq + ((s1 + 3u) >> 2); { const uint64_t pend = ib + d.o_seq + d.seq_size; if (pke > pend) pke = pend; if (pka > pke) pka = pke; }
         uint64_t rqa = ib + d.o_qual + q0, rqe = ib + d.o_qual + q1; { const uint64_t qend = ib + d.o_qual + d.qual_size; if (rqe > qend) rqe = qend; if (rqa > rqe) rqa = rqe; }
-        // first two steps of this wave's first two streams: requested now, decoded after the barrier
-        PosStep pw[2][2]; uint32_t pg[2], pst[2]; int ppos[2]; bool pon[2];
+        // the LDS-DMA of the tile's sources goes out FIRST (it returns nothing into registers, so nothing the compiler does to the loads
+        // below - it makes some of them wait for each other - can hold it back), then the prefill, then the register loads
+        {
+            const StageSpan sp[6] = { make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, raw), make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true),
+                                      make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true),
+                                      make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), make_span(s_src4 + EG_N2, img, n2a, n2e, img_bytes, true), make_span(s_src4 + EG_ST, img, sta, ste, img_bytes, true) };
+            stage_spans6<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(sp);
+            // qualities start as the major value (src/rfqcodec.cpp:1089): no source to wait for
+            if (bycol && !(abl & 1)) { uint4* qt = s_src4 + EG_Q + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
+        }
+        // the tile's list entries: EL2_LP x 256 entries per stream from the cell's first entry on, requested now, scattered after the barriers
+        // (a list denser than that is finished by a loop); entries >= the stream's count read as "beyond"
+        uint32_t pe[POS2_MAX_STREAMS + 1][EL2_LP];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t t = (uint32_t)w + 4u * (uint32_t)u; pon[u] = false; pg[u] = 0; pst[u] = 0; ppos[u] = -1;
-            pw[u][0].w0 = pw[u][0].w1 = pw[u][0].w2 = 0; pw[u][1] = pw[u][0];
-            if (t < T) {
-                const uint32_t g = s_g[pb][t];
-                if (g < TS[u].nseg) { pon[u] = true; pg[u] = g; pst[u] = segS[TS[u].base + g]; ppos[u] = segP[TS[u].base + g];
-                                      pw[u][0] = pos_fetch(TS[u].sp, TS[u].slen, g * POS2_SEG + 4u * (uint32_t)l, lim); pw[u][1] = pos_fetch(TS[u].sp, TS[u].slen, (g + 1u) * POS2_SEG + 4u * (uint32_t)l, lim); }
+        for (uint32_t ts = 0; ts < POS2_MAX_STREAMS + 1; ts++) {              // slot POS2_MAX_STREAMS holds the N list (table entry nn)
+#pragma unroll
+            for (int i = 0; i < EL2_LP; i++) pe[ts][i] = 0xFFFFFFFFu;
+            const uint32_t t = ts < POS2_MAX_STREAMS ? ts : nn;
+            if (ts < POS2_MAX_STREAMS ? ts < nn : hasn) {
+                const uint32_t k0 = s_g[pb][t]; uint32_t ke = s_kb[pb][t]; if (ke > s_nent[t]) ke = s_nent[t];    // entries [k0, ke) can fall into the tile
+                const uint32_t* lp = plist + s_loff[t];
+#pragma unroll
+                for (int i = 0; i < EL2_LP; i++) { const uint32_t kk = k0 + tid + 256u * (uint32_t)i; if (k0 != 0xFFFFFFFFu && kk < ke && !(abl & 8)) pe[ts][i] = lp[kk]; }
             }
         }
         {
             const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
             EMIT_META_VARS
             if (nextm) EMIT_META_LOAD(cur + cnt)
-            uint32_t gnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) gnext = cell_lookup(tid, q1, s1);
-            const StageSpan sp[6] = { make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, raw), make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true),
-                                      make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true),
-                                      make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), make_span(s_src4 + EG_N2, img, n2a, n2e, img_bytes, true), make_span(s_src4 + EG_ST, img, sta, ste, img_bytes, true) };
-            stage_spans6<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(sp);
-            // qualities start as the major value (src/rfqcodec.cpp:1089): no source to wait for
-            if (bycol) { uint4* qt = s_src4 + EG_Q + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
+            uint32_t gnext = 0xFFFFFFFFu, bnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) { gnext = cell_lookup(tid, q1, s1, false); bnext = cell_lookup(tid, q1, s1, true); }
             if (nextm) EMIT_META_STORE(s_next)
-            if (tid < T) s_g[pb ^ 1u][tid] = gnext;
+            if (tid < T) { s_g[pb ^ 1u][tid] = gnext; s_kb[pb ^ 1u][tid] = bnext; }
+            if (tid == 0) s_nl0 = pe[POS2_MAX_STREAMS][0];                  // the tile's first N position (most tiles have none: they skip that phase)
         }
         __syncthreads();
+        if (DBG) { c1 = clock64(); a_stage += c1 - c0; c0 = c1; }
         uint8_t* const q_t = (uint8_t*)(s_src4 + EG_Q + 1) + (raw ? (uint32_t)(rqa & 15ull) : 0u);        // quality of chunk position q0 + i at q_t[i]
         uint8_t* const s_t = (uint8_t*)(s_src4 + EG_S + 1);                                              // stored base s0 + i at s_t[i]
         // ---- bases: 16 per thread, packed bytes -> G A T C (src/rfqcodec.cpp:833-853); beyond mSeqBuf the 'N' prefill of allSeq stays
@@ -1177,7 +1250,7 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             const uint8_t* pk = (const uint8_t*)(s_src4 + EG2_PK) + (uint32_t)(pka & 15ull); const uint32_t r2 = 2u * (s0 & 3u), ng = (s1 - s0 + 15u) >> 4;
             const uint32_t have = (uint32_t)(pke - pka);                     // staged packed bytes
             auto unpack4v = [](uint32_t b) -> uint32_t { const uint32_t y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u; return __builtin_amdgcn_perm(0u, 0x43544147u, idx); };
-            for (uint32_t k = tid; k < ng; k += blockDim.x) {
+            for (uint32_t k = tid; k < ((abl & 2) ? 0u : ng); k += blockDim.x) {
                 const unsigned long long v = lds_get8(pk, 4u * k); const uint32_t pk32 = (uint32_t)(v >> r2);
                 uint32_t o[4];
 #pragma unroll
@@ -1189,43 +1262,40 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
                 *(uint4*)(s_t + 16u * k) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
-        // ---- quality streams (a wave per stream) and exception records into the quality tile
+        if (DBG) { c1 = clock64(); a_unpack += c1 - c0; c0 = c1; }
+        // ---- quality lists and exception records into the quality tile (the prefill was done before the barrier)
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const uint32_t t = (uint32_t)w + 4u * (uint32_t)u;
-            if (t >= nn) continue;                                           // wave-uniform (the N stream waits for the bases)
-            uint32_t g, carry; int last; bool on;
-            if (u < 2) { on = pon[u]; g = pg[u]; carry = pst[u]; last = ppos[u]; }
-            else { g = s_g[pb][t]; on = g < TS[u].nseg; carry = 0; last = -1; if (on) { carry = segS[TS[u].base + g]; last = segP[TS[u].base + g]; } }
-            for (uint32_t k = 0; on && g < TS[u].nseg && last < (int)q1 - 1; k++, g++) {
-                const uint32_t i0 = g * POS2_SEG + 4u * (uint32_t)l;
-                const PosStep ws = (u < 2 && k < 2) ? pw[u < 2 ? u : 0][k < 2 ? k : 0] : pos_fetch(TS[u].sp, TS[u].slen, i0, lim);
-                tile_pos_step(ws, TS[u].sp, TS[u].slen, i0, carry, last, (uint8_t)TS[u].q, q_t, (int)q0, (int)(q1 - q0), l);
+        for (uint32_t t = 0; t < POS2_MAX_STREAMS; t++) {
+            if (t >= nn || (abl & 4)) break;
+            const uint32_t val = s_val[t];
+#pragma unroll
+            for (int i = 0; i < EL2_LP; i++) { const uint32_t p = pe[t][i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)val; }
+            // (block-uniform) a list denser than EL2_LP rounds per tile: the rest of [k0, ke) on demand
+            const uint32_t k0 = s_g[pb][t]; uint32_t ke = s_kb[pb][t]; if (ke > s_nent[t]) ke = s_nent[t];
+            if (k0 != 0xFFFFFFFFu && k0 + 256u * EL2_LP < ke) {
+                const uint32_t* lp = plist + s_loff[t];
+                for (uint32_t kk = k0 + 256u * EL2_LP + tid; kk < ke; kk += 256u) { const uint32_t p = lp[kk]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)val; }
             }
         }
         if (nrec) {
             // (every tile looks at all of the chunk's records: the host keeps images with many of them off this kernel)
             for (uint32_t i = tid; i < nrec; i += blockDim.x) { const uint8_t* r = xrec + 5ull * i; const uint32_t pos = ld_u32(r + 1); if (pos >= q0 && pos < q1 && pos < qlen_c) q_t[pos - q0] = r[0]; }
         }
-        if (hasn) {
+        if (DBG) { c1 = clock64(); a_tok += c1 - c0; c0 = c1; }
+        const uint32_t send = s1 < slen_c ? s1 : slen_c;
+        if (hasn && s_nl0 < send) {                                        // (block-uniform; s_nl0 was written before the first barrier)
             __syncthreads();                                               // the bases are in place
-            const uint32_t tn = nn, un = tn >> 2;                            // the N stream belongs to wave tn & 3, slot tn >> 2
-            if ((uint32_t)w == (tn & 3u)) {
+            const uint32_t t = nn;
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    if ((uint32_t)u != un) continue;
-                    uint32_t g, carry; int last; bool on;
-                    if (u < 2) { on = pon[u]; g = pg[u]; carry = pst[u]; last = ppos[u]; }
-                    else { g = s_g[pb][tn]; on = g < TS[u].nseg; carry = 0; last = -1; if (on) { carry = segS[TS[u].base + g]; last = segP[TS[u].base + g]; } }
-                    for (uint32_t k = 0; on && g < TS[u].nseg && last < (int)s1 - 1; k++, g++) {
-                        const uint32_t i0 = g * POS2_SEG + 4u * (uint32_t)l;
-                        const PosStep ws = (u < 2 && k < 2) ? pw[u < 2 ? u : 0][k < 2 ? k : 0] : pos_fetch(TS[u].sp, TS[u].slen, i0, lim);
-                        tile_pos_step(ws, TS[u].sp, TS[u].slen, i0, carry, last, (uint8_t)'N', s_t, (int)s0, (int)((s1 < slen_c ? s1 : slen_c) - s0), l);
-                    }
-                }
+            for (int i = 0; i < EL2_LP; i++) { const uint32_t p = pe[POS2_MAX_STREAMS][i]; if (p >= s0 && p < send) s_t[p - s0] = (uint8_t)'N'; }
+            const uint32_t k0 = s_g[pb][t]; uint32_t ke = s_kb[pb][t]; if (ke > s_nent[t]) ke = s_nent[t];
+            if (k0 != 0xFFFFFFFFu && k0 + 256u * EL2_LP < ke) {
+                const uint32_t* lp = plist + s_loff[t];
+                for (uint32_t kk = k0 + 256u * EL2_LP + tid; kk < ke; kk += 256u) { const uint32_t p = lp[kk]; if (p >= s0 && p < send) s_t[p - s0] = (uint8_t)'N'; }
             }
         }
         __syncthreads();
+        if (DBG) { c1 = clock64(); a_n += c1 - c0; c0 = c1; }
         // ---- compose the tile's text in LDS: one thread = one piece (k_dec_emit)
         {
             uint8_t* const out = (uint8_t*)s_out4;
@@ -1270,12 +1340,15 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             }
         }
         __syncthreads();
+        if (DBG) { c1 = clock64(); a_comp += c1 - c0; c0 = c1; }
         if (tp1.a <= cap1) flush_span(s_out4, out1, tp0.a, tp1.a);
         if (split && tp1.b <= cap2) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
+        if (DBG) { c1 = clock64(); a_flush += c1 - c0; }
         cur += cnt; pb ^= 1u;
     }
 #undef EMIT_META_VARS
 #undef EMIT_META_LOAD
 #undef EMIT_META_STORE
-    (void)dbg;
+    if (DBG && dbg && l == 0) { atomicAdd(&dbg[0], (unsigned long long)a_stage); atomicAdd(&dbg[1], (unsigned long long)a_unpack); atomicAdd(&dbg[2], (unsigned long long)a_tok); atomicAdd(&dbg[3], (unsigned long long)a_n);
+                                atomicAdd(&dbg[4], (unsigned long long)a_comp); atomicAdd(&dbg[5], (unsigned long long)a_flush); atomicAdd(&dbg[6], 1ull); atomicAdd(&dbg[7], (unsigned long long)a_steps); }
 }

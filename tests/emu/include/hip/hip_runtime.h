@@ -157,6 +157,8 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t 
     for (int i = 0; i < 4; i++) { const uint32_t k = (sel >> (8 * i)) & 0xFFu; r |= (uint32_t)((k < 8 ? (v >> (8 * k)) & 0xFFu : (k == 0x0C ? 0u : 0xFFu))) << (8 * i); }
     return r;
 }
+// v_readfirstlane_b32 is only applied to wave-uniform values in the product code: identity here
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline void __builtin_amdgcn_wave_barrier() { (void)emu::collective(emu::OP_BALLOT, 0, 0, 0); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
