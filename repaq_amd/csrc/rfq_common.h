@@ -201,14 +201,3 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-// index of the tile entry that contains position p: dst[0..cnt] are ascending starts (dst[cnt] = end)
-__device__ __forceinline__ uint32_t tile_find(const uint32_t* dst, uint32_t cnt, uint32_t p) {   // last r with dst[r] <= p
-    // equal-length reads (the usual case): one division finds the read; verify with two LDS reads, else binary search
-    const uint32_t d0 = dst[0], step = dst[1] - d0;
-    if (step) { const uint32_t g = (p - d0) / step; if (g < cnt && dst[g] <= p && p < dst[g + 1]) return g; }
-    uint32_t lo = 0, hi = cnt;                                  // invariant: dst[lo] <= p < dst[hi]
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (dst[mid] <= p) lo = mid; else hi = mid; }
-    return lo;
-}
-

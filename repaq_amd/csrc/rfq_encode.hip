@@ -329,7 +329,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
 
     // ---- phase 3: header (first batch), chunk analysis, gather, plan
     const size_t nc = (size_t)n_chunks + 2;
-    HIPCHK(ctx, B[B_CFLAGS].ensure(nc * 4)); HIPCHK(ctx, B[B_IL].ensure(nc * 4)); HIPCHK(ctx, B[B_HIST].ensure(nc * 256 * 4)); HIPCHK(ctx, B[B_NCOUNT].ensure(nc * 4));
+    HIPCHK(ctx, B[B_CFLAGS].ensure(nc * 4)); HIPCHK(ctx, B[B_IL].ensure(nc * 4)); HIPCHK(ctx, B[B_NCOUNT].ensure(nc * 4));
     HIPCHK(ctx, B[B_SCAP].ensure(nc * MAX_STREAMS * 4)); HIPCHK(ctx, B[B_SOFF].ensure(nc * MAX_STREAMS * 8)); HIPCHK(ctx, B[B_SSIZE].ensure(nc * MAX_STREAMS * 4));
     HIPCHK(ctx, B[B_XSIZE].ensure(nc * 4)); HIPCHK(ctx, B[B_YSIZE].ensure(nc * 4)); HIPCHK(ctx, B[B_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[B_SBASE].ensure(nc * 8));
     HIPCHK(ctx, B[B_IMGSIZE].ensure(nc * 8)); HIPCHK(ctx, B[B_IMGOFF].ensure(nc * 8)); HIPCHK(ctx, B[B_CTOTAL].ensure(nc * 8)); HIPCHK(ctx, B[B_CBASE].ensure(nc * 8));
@@ -337,7 +337,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     const size_t catbytes = (size_t)total_bases + 64 * nc + 256;
     HIPCHK(ctx, B[B_QCAT].ensure(catbytes)); HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
     HIPCHK(ctx, ctx->d_hdr.ensure(sizeof(DevHeader)));
-    C.flags = B[B_CFLAGS].as<uint32_t>(); C.il = B[B_IL].as<uint32_t>(); C.hist = B[B_HIST].as<uint32_t>(); C.ncount = B[B_NCOUNT].as<uint32_t>();
+    C.flags = B[B_CFLAGS].as<uint32_t>(); C.il = B[B_IL].as<uint32_t>(); C.ncount = B[B_NCOUNT].as<uint32_t>();
     HIPCHK(ctx, B[B_NMAP].ensure(nc * NMAP_WORDS * 4)); C.nmap = B[B_NMAP].as<uint32_t>();
     C.scap = B[B_SCAP].as<uint32_t>(); C.soff = B[B_SOFF].as<uint64_t>(); C.ssize = B[B_SSIZE].as<uint32_t>(); C.xsize = B[B_XSIZE].as<uint32_t>(); C.ysize = B[B_YSIZE].as<uint32_t>();
     C.qbase = B[B_QBASE].as<uint64_t>(); C.sbase = B[B_SBASE].as<uint64_t>(); C.img_size = B[B_IMGSIZE].as<uint64_t>(); C.img_off = B[B_IMGOFF].as<uint64_t>();
@@ -398,7 +398,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.end(S);
 
     ctx->timer.begin("gather", S);
-    HIPCHK(ctx, hipMemsetAsync(C.hist, 0, nc * 256 * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
+    HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
     // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
     const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
     const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
@@ -409,13 +409,13 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + GT_READS - 1) / GT_READS, std::max(1u, 8192u / n_chunks)));
 #define RFQ_GATHER_ARGS T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, \
                         tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune
-        if (tune) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
+        if (tune & 7) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
         else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
 #undef RFQ_GATHER_ARGS
-        if (tune) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
+        if (tune & 7) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
             if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
     }
-    hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks);
+    hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg);
     scan_exclusive<uint64_t>(S, B[B_CTOTAL].as<uint64_t>(), B[B_CBASE].as<uint64_t>(), n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
     hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
