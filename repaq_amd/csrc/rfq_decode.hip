@@ -27,7 +27,7 @@ static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk
 #undef RFQ_LIST_ARGS
 }
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
-struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec; };
+struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one; };
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
 // out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
@@ -68,7 +68,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // position tokens; what runs here is the coordinate decoder and, beside it, the one-step stream summaries + their link / cell index.
     // Taken for files with few quality streams whose reads and exception lists fit a tile; RFQ_TUNE bit 11 forces the materialising path.
     const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
-    const bool fused = !(tune & 2048) && (!bycol_h || HH.n_normal <= POS2_MAX_STREAMS) && g.max_len <= 2600u && g.max_nrec <= 4096u;
+    const bool fused = !(tune & 2048) && g.max_len <= 2000u && g.max_nrec <= 4096u;
     uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false; const uint32_t f_nstr = HH.n_normal + 1;
     if (fused) {
         ctx->timer.begin("streams", S);
@@ -77,7 +77,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
         hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
         if (nn || hasn) {
-            const uint32_t mq = nn ? g.max_stream / POS2_SEG + 1 : 0u, mn = hasn ? g.max_npos / POS2_SEG + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
+            const uint32_t mq = nn ? g.max_one / POS2_SEG + 1 : 0u, mn = hasn ? g.max_npos / POS2_SEG + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
             f_ncell = g.max_bases / POS2_CELL + 2;
             const size_t nst = (size_t)n_chunks * f_nstr, nseg = nst * f_maxseg, ncl = nst * f_ncell;
             HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 32 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure(nst * 4 + 16));
@@ -269,7 +269,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             break;
         }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
-        if (!speculate) break;
+        if (!speculate) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
         if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
         if (hs.n_chunks > PARSE_AHEAD) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
@@ -277,7 +277,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
             if (h2.pad) { speculate = false; continue; }
-            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
+            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
         break;
@@ -298,7 +298,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
     if (tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
-        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec;
+        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one;
         rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
         if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
     }
@@ -325,7 +325,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             const uint32_t c0 = r.first, c1 = r.second; uint64_t reads = 0; for (uint32_t c = c0; c < c1; c++) reads += hc[c].reads;
             hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
             KCHK(ctx, "k_dec_rebase");
-            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec;
+            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one;
             uint8_t *q1 = nullptr, *q2 = nullptr; size_t m1 = 0, m2 = 0; uint64_t mb = 0;
             ctx->timer.reset();
             rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);

@@ -29,7 +29,7 @@ struct DecStatus {
     uint64_t text_slots[2][64];      // partial sums of the text bytes per output stream (k_dec_textlen)
     uint64_t base_slots[16];         // partial sums of the read lengths of all chunks (parse_chunk)
     uint32_t max_len, max_bases;     // longest read / largest chunk (bases, clamped to 2^32 - 1) of the image
-    uint32_t max_nrec, pad2;         // most exception records of any chunk (by-column quality payloads)
+    uint32_t max_nrec, max_one;      // most exception records of any chunk / longest single quality stream (by-column quality payloads)
     unsigned long long list_need;    // fused path: entries of all position lists (k_dec_pos_off)
 };
 
@@ -179,8 +179,9 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
     if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); atomicAdd((unsigned long long*)&st->base_slots[c & 15u], (unsigned long long)d.bases);
                           atomicMax(&st->max_len, d.max_len); atomicMax(&st->max_bases, d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases);
                           if ((hf & H_QUAL_BY_COL) && !(hf & H_DONT_QUAL) && 4ull * D->n_normal <= d.qual_size) {
-                              const uint8_t* qp = img + d.off + d.o_qual; uint64_t off = 4ull * D->n_normal; for (uint32_t i = 0; i < D->n_normal; i++) off += ld_u32(qp + 4 * i);
-                              if (off <= d.qual_size) atomicMax(&st->max_nrec, (uint32_t)((d.qual_size - off) / 5)); } }
+                              const uint8_t* qp = img + d.off + d.o_qual; uint64_t off = 4ull * D->n_normal; uint32_t mo = 0;
+                              for (uint32_t i = 0; i < D->n_normal; i++) { const uint32_t sl = ld_u32(qp + 4 * i); off += sl; if (sl > mo) mo = sl; }
+                              if (off <= d.qual_size) { atomicMax(&st->max_nrec, (uint32_t)((d.qual_size - off) / 5)); atomicMax(&st->max_one, mo); } } }
 }
 
 struct DReadTab {
@@ -462,7 +463,7 @@ __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __
     wave_pos_decode(s.sp, s.slen, b0, b1, segS[idx], segP[idx], s.q, s.out, s.out_len, lim, s_tp);
 }
 // ================================================================== fused path: no expanded qualities / bases in HBM
-// (files with <= POS2_MAX_STREAMS quality streams - every NovaSeq-binned file).  The position streams are turned into POSITION LISTS: one
+// (by-column and raw-quality files whose reads and exception lists fit a tile).  The position streams are turned into POSITION LISTS: one
 // u32 per coded position, in stream order, all streams of all chunks in one arena (a position belongs to at most one stream, so a list is a
 // few percent of the bases).  The emitter prefills a tile's qualities with the major value in LDS, scatters the list entries that fall into
 // the tile, unpacks the tile's bases LDS -> LDS from the packed bytes and scatters the N list: no qdec / sdec, no prefill, unpack or
@@ -473,7 +474,6 @@ __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __
 //                    index of the first list entry at or beyond the cell (the emitter starts there)
 #define POS2_SEG 256u
 #define POS2_CELL 1024u
-#define POS2_MAX_STREAMS 8u
 struct PosSrc { const uint8_t* sp; uint32_t slen; uint8_t q; };
 // stream jj of a chunk: jj < nn = quality value stream, jj == nn = N positions.  slen = 0 when absent; corrupt length tables are flagged.
 __device__ __forceinline__ PosSrc pos_src_of(const uint8_t* __restrict__ img, const DChunk& d, const DevHeader* __restrict__ D, uint32_t jj, DecStatus* st) {
@@ -886,7 +886,7 @@ __device__ __forceinline__ void emit_copy(uint8_t* o, const uint8_t* pool, uint3
 }
 #define ET_READS 32
 #define EM_ROW 17                 // words per read in s_meta: 16 used + 1 pad, so that lanes reading the same field of consecutive reads hit 32 different banks
-#define ET_OCAP 16384u            // output tile bytes (split: half per stream)
+#define ET_OCAP 12288u            // output tile bytes (split: half per stream): 32 records of 357 bytes are 11.4 KB
 #define ET_SCAP 5632u             // staged qualities / stored bases
 #define ET_N1CAP 3072u            // staged name1 / name2 / strand pieces of the tile (fall back to global memory when larger)
 #define ET_N2CAP 1024u
@@ -1108,7 +1108,8 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
 // Everything after that - one thread = one piece, byte-granular ds_read_b128 / ds_write_b128, aligned flush - is k_dec_emit's compose phase.
 #define EG2_PK EG_END
 #define EG2_END (EG2_PK + ET_SCAP / 64 + 4)
-#define EL2_LP 2                  // list entries per thread and stream requested up front (512 per stream and tile)
+#define EL2_LP 2                  // N-list entries per thread requested up front
+#define EL2_FL 4                  // quality-list items per thread requested up front (1024 per tile)
 template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
@@ -1116,8 +1117,10 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
     __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
     __shared__ uint4 s_src4[EG2_END];
     __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta2[2][(ET_READS + 1) * EM_ROW];
-    __shared__ uint32_t s_g[2][POS2_MAX_STREAMS + 2];
-    __shared__ unsigned long long s_loff[POS2_MAX_STREAMS + 2]; __shared__ uint32_t s_nent[POS2_MAX_STREAMS + 2], s_val[POS2_MAX_STREAMS + 2], s_kb[2][POS2_MAX_STREAMS + 2], s_nl0;
+    // per stream of the chunk (t < nn: quality value t, t == nn: the N positions): list start in the arena, entries, value; per tile (two
+    // buffers): first entry at the tile's cell (s_g), first entry beyond the tile (s_kb), prefix of the quality lists' entry counts (s_wp)
+    __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
+    __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2], s_wp[2][NPOS_SLOT + 2], s_nl0;
     long long c0 = 0, c1 = 0, a_stage = 0, a_unpack = 0, a_tok = 0, a_n = 0, a_comp = 0, a_flush = 0, a_steps = 0;
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint8_t* lim = img + img_bytes;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
@@ -1166,9 +1169,17 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
           m[7] = pv_.a - pv0.a; m[8] = pv_.b - pv0.b; m[9] = pv_.c - pv0.c;                                                           \
           if (r_ < re) { m[0] = (split && odd_) ? tp_.b : tp_.a; m[1] = len_; m[2] = ov_; m[3] = pl_; m[4] = n1_; m[5] = n2_; m[6] = sl_;   \
                          m[11] = md_; m[10] = n1_ + md_ + n2_ + 1; } }
+    // entries of quality list t that can fall into the tile: [k0, min(kb, entries)); their counts' prefix over t -> s_wp (by wave 0)
+#define EMIT2_PREFIX(buf, g_, b_)                                                                                                     \
+          if (tid < 64) { uint32_t n_ = 0; if (tid < nn && (g_) != 0xFFFFFFFFu) { const uint32_t ke_ = (b_) < s_nent[tid] ? (b_) : s_nent[tid]; if (ke_ > (g_)) n_ = ke_ - (g_); } \
+                          const uint32_t inc_ = wave_incl_sum(n_); if (tid < nn) s_wp[buf][tid + 1] = inc_; if (tid == 0) s_wp[buf][0] = 0; }
     uint32_t cur = rs; uint32_t pb = 0;
     { EMIT_META_VARS if (cur < re && tid <= ET_READS && cur + tid <= re) { EMIT_META_LOAD(cur) EMIT_META_STORE(s_meta2[0]) }
-      if (cur < re && tid < T) { const uint32_t qp_ = R.pq[f + cur] - pq0, sp_ = R.pv[f + cur].d - pv0.d; s_g[0][tid] = cell_lookup(tid, qp_, sp_, false); s_kb[0][tid] = cell_lookup(tid, qp_, sp_, true); } }
+      if (cur < re && tid < 128) {                                          // (waves 0 and 1: T <= 65)
+          uint32_t g_ = 0xFFFFFFFFu, b_ = 0xFFFFFFFFu;
+          if (tid < T) { const uint32_t qp_ = R.pq[f + cur] - pq0, sp_ = R.pv[f + cur].d - pv0.d; g_ = cell_lookup(tid, qp_, sp_, false); b_ = cell_lookup(tid, qp_, sp_, true); s_g[0][tid] = g_; s_kb[0][tid] = b_; }
+          EMIT2_PREFIX(0, g_, b_)
+      } }
     __syncthreads();
     while (cur < re) {                                                       // block-uniform
         uint32_t* const s_meta = s_meta2[pb]; uint32_t* const s_next = s_meta2[pb ^ 1u];
@@ -1217,20 +1228,28 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             // qualities start as the major value (src/rfqcodec.cpp:1089): no source to wait for
             if (bycol && !(abl & 1)) { uint4* qt = s_src4 + EG_Q + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         }
-        // the tile's list entries: EL2_LP x 256 entries per stream from the cell's first entry on, requested now, scattered after the barriers
-        // (a list denser than that is finished by a loop); entries >= the stream's count read as "beyond"
-        uint32_t pe[POS2_MAX_STREAMS + 1][EL2_LP];
+        // the tile's list entries, requested now and scattered after the barrier.  Quality lists: the entries [k0, ke) of all lists form one
+        // flat range of W items (prefix s_wp); item w belongs to the list t with s_wp[t] <= w < s_wp[t + 1]; a thread takes items tid, tid + 256,
+        // ... - EL2_FL of them up front (a tile of a NovaSeq-binned file has ~600 items, of a 40-value file ~3500: the rest on demand)
+        const uint32_t W = s_wp[pb][nn];
+        auto item = [&](uint32_t w_, uint32_t& val_) -> const uint32_t* {
+            uint32_t lo_ = 0, hi_ = nn;                                      // s_wp[lo_] <= w_ < s_wp[hi_]
+            while (hi_ - lo_ > 1u) { const uint32_t mid_ = (lo_ + hi_) >> 1; if (s_wp[pb][mid_] <= w_) lo_ = mid_; else hi_ = mid_; }
+            val_ = s_val[lo_];
+            return plist + s_loff[lo_] + s_g[pb][lo_] + (w_ - s_wp[pb][lo_]);
+        };
+        uint32_t fe[EL2_FL], fv[EL2_FL];
 #pragma unroll
-        for (uint32_t ts = 0; ts < POS2_MAX_STREAMS + 1; ts++) {              // slot POS2_MAX_STREAMS holds the N list (table entry nn)
+        for (int i = 0; i < EL2_FL; i++) { fe[i] = 0xFFFFFFFFu; fv[i] = 0; const uint32_t w_ = tid + 256u * (uint32_t)i; if (w_ < W && !(abl & 8)) fe[i] = *item(w_, fv[i]); }
+        // the N list (most tiles hold no N: its first entry tells, and the phase is skipped)
+        uint32_t pn[EL2_LP];
 #pragma unroll
-            for (int i = 0; i < EL2_LP; i++) pe[ts][i] = 0xFFFFFFFFu;
-            const uint32_t t = ts < POS2_MAX_STREAMS ? ts : nn;
-            if (ts < POS2_MAX_STREAMS ? ts < nn : hasn) {
-                const uint32_t k0 = s_g[pb][t]; uint32_t ke = s_kb[pb][t]; if (ke > s_nent[t]) ke = s_nent[t];    // entries [k0, ke) can fall into the tile
-                const uint32_t* lp = plist + s_loff[t];
+        for (int i = 0; i < EL2_LP; i++) pn[i] = 0xFFFFFFFFu;
+        if (hasn) {
+            const uint32_t k0 = s_g[pb][nn]; uint32_t ke = s_kb[pb][nn]; if (ke > s_nent[nn]) ke = s_nent[nn];
+            const uint32_t* lp = plist + s_loff[nn];
 #pragma unroll
-                for (int i = 0; i < EL2_LP; i++) { const uint32_t kk = k0 + tid + 256u * (uint32_t)i; if (k0 != 0xFFFFFFFFu && kk < ke && !(abl & 8)) pe[ts][i] = lp[kk]; }
-            }
+            for (int i = 0; i < EL2_LP; i++) { const uint32_t kk = k0 + tid + 256u * (uint32_t)i; if (k0 != 0xFFFFFFFFu && kk < ke) pn[i] = lp[kk]; }
         }
         {
             const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
@@ -1239,7 +1258,8 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             uint32_t gnext = 0xFFFFFFFFu, bnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) { gnext = cell_lookup(tid, q1, s1, false); bnext = cell_lookup(tid, q1, s1, true); }
             if (nextm) EMIT_META_STORE(s_next)
             if (tid < T) { s_g[pb ^ 1u][tid] = gnext; s_kb[pb ^ 1u][tid] = bnext; }
-            if (tid == 0) s_nl0 = pe[POS2_MAX_STREAMS][0];                  // the tile's first N position (most tiles have none: they skip that phase)
+            if (tid < 128) { EMIT2_PREFIX(pb ^ 1u, gnext, bnext) }
+            if (tid == 0) s_nl0 = pn[0];                                    // the tile's first N position
         }
         __syncthreads();
         if (DBG) { c1 = clock64(); a_stage += c1 - c0; c0 = c1; }
@@ -1264,18 +1284,10 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
         }
         if (DBG) { c1 = clock64(); a_unpack += c1 - c0; c0 = c1; }
         // ---- quality lists and exception records into the quality tile (the prefill was done before the barrier)
+        if (!(abl & 4)) {
 #pragma unroll
-        for (uint32_t t = 0; t < POS2_MAX_STREAMS; t++) {
-            if (t >= nn || (abl & 4)) break;
-            const uint32_t val = s_val[t];
-#pragma unroll
-            for (int i = 0; i < EL2_LP; i++) { const uint32_t p = pe[t][i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)val; }
-            // (block-uniform) a list denser than EL2_LP rounds per tile: the rest of [k0, ke) on demand
-            const uint32_t k0 = s_g[pb][t]; uint32_t ke = s_kb[pb][t]; if (ke > s_nent[t]) ke = s_nent[t];
-            if (k0 != 0xFFFFFFFFu && k0 + 256u * EL2_LP < ke) {
-                const uint32_t* lp = plist + s_loff[t];
-                for (uint32_t kk = k0 + 256u * EL2_LP + tid; kk < ke; kk += 256u) { const uint32_t p = lp[kk]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)val; }
-            }
+            for (int i = 0; i < EL2_FL; i++) { const uint32_t p = fe[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
+            for (uint32_t w_ = tid + 256u * EL2_FL; w_ < W; w_ += 256u) { uint32_t v_; const uint32_t p = *item(w_, v_); if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)v_; }
         }
         if (nrec) {
             // (every tile looks at all of the chunk's records: the host keeps images with many of them off this kernel)
@@ -1287,7 +1299,7 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             __syncthreads();                                               // the bases are in place
             const uint32_t t = nn;
 #pragma unroll
-            for (int i = 0; i < EL2_LP; i++) { const uint32_t p = pe[POS2_MAX_STREAMS][i]; if (p >= s0 && p < send) s_t[p - s0] = (uint8_t)'N'; }
+            for (int i = 0; i < EL2_LP; i++) { const uint32_t p = pn[i]; if (p >= s0 && p < send) s_t[p - s0] = (uint8_t)'N'; }
             const uint32_t k0 = s_g[pb][t]; uint32_t ke = s_kb[pb][t]; if (ke > s_nent[t]) ke = s_nent[t];
             if (k0 != 0xFFFFFFFFu && k0 + 256u * EL2_LP < ke) {
                 const uint32_t* lp = plist + s_loff[t];
