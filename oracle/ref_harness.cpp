@@ -11,6 +11,8 @@
 #include "rfqcodec.h"
 #undef private
 #include "fastqmeta.h"
+#include "fastqreader.h"
+#include <fstream>
 
 std::string command;   // referenced by the reference's util.h error path
 
@@ -21,7 +23,7 @@ static std::vector<unsigned char> slurp() {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness coords|decoords N|pos Q|overlap|parse\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness coords|decoords N|pos Q|overlap|parse|rle_image R1 R2|- OUT\n"); return 2; }
     std::string cmd = argv[1];
     RfqCodec codec;
     if (cmd == "coords") {            // stdin: u32 LE values -> stdout: encoded stream
@@ -47,6 +49,22 @@ int main(int argc, char** argv) {
         while (std::getline(std::cin, s)) {
             FastqMeta m = FastqMeta::parse(s);
             printf("%d|%s|%d|%d|%u|%u|%s\n", (int)m.hasLaneTileXY, m.namePart1.c_str(), (int)m.lane, (int)m.tile, m.x, m.y, m.namePart2.c_str());
+        }
+    } else if (cmd == "rle_image") {  // argv[2]=R1.fq argv[3]=R2.fq or "-" argv[4]=out.rfq: ONE chunk coded with the legacy run-length quality coder.
+        // RfqCodec::encodeSeqQual takes that branch when the header carries neither BIT_ENCODE_QUAL_BY_COL nor BIT_DONT_ENCODE_QUAL
+        // (src/rfqcodec.cpp:612-621); v0.5.1's makeQualityTable never leaves a header that way (App. C Q13), so the flag is cleared here
+        // on the header the reference itself made from the reads.  Everything else - header fields, chunk layout - is the reference's.
+        std::string r1 = argv[2], r2 = argv[3]; std::ofstream out(argv[4], std::ios::binary);
+        if (r2 == "-") {
+            FastqReader reader(r1); std::vector<Read*> reads; Read* r;
+            while ((r = reader.read()) != NULL) reads.push_back(r);
+            RfqHeader* h = codec.makeHeader(reads); h->mFlags &= ~BIT_ENCODE_QUAL_BY_COL; codec.setHeader(h);
+            RfqChunk* c = codec.encodeChunk(reads); h->write(out); c->write(out);
+        } else {
+            FastqReaderPair reader(r1, r2); std::vector<ReadPair*> pairs; ReadPair* p;
+            while ((p = reader.read()) != NULL) pairs.push_back(p);
+            RfqHeader* h = codec.makeHeader(pairs); h->mFlags &= ~BIT_ENCODE_QUAL_BY_COL; codec.setHeader(h);
+            RfqChunk* c = codec.encodeChunk(pairs); h->write(out); c->write(out);
         }
     } else return 2;
     return 0;

@@ -694,7 +694,29 @@ static int decode_chunk(const rfqo_header* h, const chunk_t* c, int split, bb_t*
                 rfqo_pos_decode(c->qual + consumed, l, nv[i], qual, seqLen); consumed += l;
             }
             while (!rc && consumed + 5 <= c->qual_size) { uint8_t q = c->qual[consumed]; uint32_t pos = rd32(c->qual + consumed + 1); consumed += 5; if (pos < seqLen) qual[pos] = q; }
-        } else { snprintf(err, 256, "run-length quality coding (legacy) is not produced by repaq v0.5.1"); rc = -1; }
+        } else if (c->qual_size) {
+            /* decodeQualByRunLenCoding, src/rfqcodec.cpp:919-955 (legacy: v0.5.1 never writes it, App. C Q13).  One byte per run: bit 0 clear =
+             * the major value, run = (byte >> 1) + 1 (majorQualNumBits is 7, src/rfqheader.cpp:255-257); bit 0 set = the value with "bit" code
+             * byte & mask, run = (byte >> (8 - n)) + 1, n = normalQualNumBits (computeNormalQualBits, :117-128).  Code -> value is
+             * mBit2QualTable (makeQualBitTable :103-115: entry i of the header's table has code 0, 1, 3, 5, ...; unlisted codes read the
+             * zeroed table).  The outer while re-reads the buffer until `len` qualities are out. */
+            int mx = (int)h->qual_bins * 2 - 3; if (mx < 1) mx = 1;
+            int nq = mx >= 64 ? 1 : mx >= 32 ? 2 : mx >= 16 ? 3 : mx >= 8 ? 4 : mx >= 4 ? 5 : mx >= 2 ? 6 : 7;
+            uint8_t bit2q[256]; memset(bit2q, 0, sizeof bit2q);
+            for (int i = 0; i < (int)h->qual_bins; i++) bit2q[(uint8_t)(i ? 2 * i - 1 : 0)] = h->qual_buf[i];
+            const uint8_t mask = (uint8_t)((1u << (8 - nq)) - 1u);
+            uint32_t decoded = 0;
+            while (decoded < seqLen) {
+                for (uint32_t i = 0; i < c->qual_size; i++) {
+                    const uint8_t e = c->qual[i]; uint8_t q; uint32_t num;
+                    if ((e & 1) == 0) { q = 0; num = e >> 1; } else { q = e & mask; num = e >> (8 - nq); }
+                    num += 1;
+                    for (uint32_t f = decoded; f < decoded + num && f < seqLen; f++) qual[f] = bit2q[q];
+                    decoded += num;
+                    if (decoded >= seqLen) break;
+                }
+            }
+        }
     }
     if (!rc && !(h->flags & RFQO_H_N_POS)) { uint8_t nq = h->n_base_qual; for (uint32_t i = 0; i < seqLen; i++) if (qual[i] == nq) seq[i] = 'N'; }   /* :1093-1100 */
     uint32_t xyNum = il ? s / 2 : s;

@@ -68,7 +68,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // position tokens; what runs here is the coordinate decoder and, beside it, the one-step stream summaries + their link / cell index.
     // Taken for files with few quality streams whose reads and exception lists fit a tile; RFQ_TUNE bit 11 forces the materialising path.
     const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
-    const bool fused = !(tune & 2048) && g.max_len <= 2000u && g.max_nrec <= 4096u;
+    const bool rle_h = !(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL));          // legacy run-length quality coding: k_dec_rle on the materialising path
+    const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u;
     uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false; const uint32_t f_nstr = HH.n_normal + 1;
     if (fused) {
         ctx->timer.begin("streams", S);
@@ -146,6 +147,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
                                      (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, HH.n_normal, nstr);
     } else hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
     if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
+    if (rle_h) hipLaunchKernelGGL(k_dec_rle, dim3(1, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
     hipLaunchKernelGGL(k_dec_except, dim3(bpc, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, qdec);
     KCHK(ctx, "k_dec_streams");
     ctx->timer.end(S);
@@ -232,7 +234,6 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     } else if (!ctx->have_hdr) return rfq_fail(ctx, RFQ_E_STATE, "decode without a header: pass has_header=1 or call rfq_set_header first");
     const DevHeader& HH = ctx->h_hdr;
     if (a->split_pe && !(HH.flags & H_PAIRED)) return rfq_fail(ctx, RFQ_E_DATA, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>");
-    if (!(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL))) return rfq_fail(ctx, RFQ_E_FORMAT, "run-length quality coding (legacy) is not produced by repaq v0.5.1 and is not decoded on device");
     if (HH.read_len_bytes != 1 && HH.read_len_bytes != 2 && HH.read_len_bytes != 4) return rfq_fail(ctx, RFQ_E_DATA, "header incorrect: read length bytes should be 1/2/4");
     const DevHeader* D = ctx->d_hdr.as<DevHeader>();
 

@@ -654,6 +654,39 @@ __global__ void k_dec_except(const uint8_t* __restrict__ img, const DChunk* __re
     const uint32_t nrec = (uint32_t)((d.qual_size - off) / 5);
     for (uint32_t i = t; i < nrec; i += NT) { const uint8_t* r = qp + off + 5ull * i; const uint32_t pos = ld_u32(r + 1); if (pos < len) dst[pos] = r[0]; }
 }
+// decodeQualByRunLenCoding (src/rfqcodec.cpp:919-955): the legacy run-length quality coding (v0.5.1 never writes it; such
+// images take the materialising path).  One byte per run: bit 0 clear = the major value, run = (byte >> 1) + 1 (majorQualNumBits is 7,
+// src/rfqheader.cpp:255-257); bit 0 set = the value whose "bit" code is byte & mask, run = (byte >> (8 - n)) + 1 with n = normalQualNumBits
+// (computeNormalQualBits, :117-128); code -> value is mBit2QualTable (makeQualBitTable, :103-115: entry i of the header's table has code 0, 1,
+// 3, 5, ...; codes the table does not list read its zeroed entries).  The reference re-reads the buffer until every quality is out.
+// grid (1, n_chunks): the workgroup walks the chunk's bytes 256 at a time, run starts by a block scan.
+__global__ void k_dec_rle(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+                          const uint64_t* __restrict__ qbase, uint8_t* __restrict__ qdec) {
+    __shared__ uint8_t s_b2q[256]; __shared__ uint32_t s_carry;
+    const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* qp = img + d.off + d.o_qual; const uint32_t f = d.rbase;
+    const uint32_t len = R.pq[f + d.reads] - R.pq[f]; uint8_t* dst = qdec + qbase[c];
+    const uint32_t bins = D->bytes[16]; int mx = (int)bins * 2 - 3; if (mx < 1) mx = 1;
+    const uint32_t nq = mx >= 64 ? 1u : mx >= 32 ? 2u : mx >= 16 ? 3u : mx >= 8 ? 4u : mx >= 4 ? 5u : mx >= 2 ? 6u : 7u, mask = (1u << (8u - nq)) - 1u;
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_b2q[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) s_b2q[(uint8_t)(i ? 2u * i - 1u : 0u)] = D->bytes[17 + i];
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    if (d.qual_size == 0 || len == 0) return;                             // (the reference would spin for ever on an empty buffer: the prefill stays)
+    for (uint32_t rounds = 0; ; rounds++) {                                // block-uniform
+        for (uint32_t b0 = 0; b0 < d.qual_size; b0 += blockDim.x) {
+            const uint32_t i = b0 + threadIdx.x; uint32_t run = 0, q = 0;
+            if (i < d.qual_size) { const uint32_t e = qp[i]; if ((e & 1u) == 0) { q = 0; run = (e >> 1) + 1u; } else { q = e & mask; run = (e >> (8u - nq)) + 1u; } }
+            uint32_t tot; const uint32_t ex = block_excl_sum<uint32_t>(run, &tot);
+            const uint32_t start = s_carry + ex; const uint8_t v = s_b2q[q];
+            for (uint32_t p = start; p < start + run && p < len; p++) dst[p] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) s_carry += tot;
+            __syncthreads();
+            if (s_carry >= len) return;
+        }
+    }
+}
 // quality prefill with the major value (src/rfqcodec.cpp:1089)
 __global__ void k_dec_fill(uint8_t* __restrict__ p, uint64_t n, const DevHeader* __restrict__ D) {
     const uint32_t v = D->major & 0xFFu; const uint4 q = make_uint4(v * 0x01010101u, v * 0x01010101u, v * 0x01010101u, v * 0x01010101u);

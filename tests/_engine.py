@@ -183,3 +183,20 @@ def decode_with_chunk_index(codec):
     assert run(offs[:-2]) == (len(offs) - 1, fq1, fq2)                                                             # covers only a prefix
     assert run(offs[:-1] + [len(rfq) + 100]) == (len(offs) - 1, fq1, fq2)                                           # past the image
     assert run([offs[0], offs[0] + 5]) == (len(offs) - 1, fq1, fq2)                                                 # too short to be a chunk
+
+
+def rle_goldens():
+    """tests/golden/rle.json: legacy run-length-coded images made by the reference's own encodeChunk (oracle/ref_harness.cpp rle_image) and the
+    md5 of what the reference binary decoded from them."""
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "rle.json")))
+
+
+def check_rle_decode(codec, name, g):
+    """decodeQualByRunLenCoding on the device: byte-equal to the oracle and md5-equal to the reference's own decode."""
+    img = bytes.fromhex(g["rfq_hex"]); split = bool(g["paired"])
+    got = codec.decode_bytes(img, split_pe=split)
+    assert got == O.decode_file(img, split), name
+    assert [hashlib.md5(x).hexdigest() for x in (got if split else (got,))] == g["decode_md5"], name
+    if split:
+        assert codec.decode_bytes(img, split_pe=False) == O.decode_file(img, False), name

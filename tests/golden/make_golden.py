@@ -63,6 +63,28 @@ def main():
         unit["parse"].append({"name": n, "ref": r})
     json.dump(unit, open(os.path.join(HERE, "unit.json"), "w"), indent=0, sort_keys=True)
 
+    # legacy run-length quality coding (src/rfqcodec.cpp:767-824, 919-955): v0.5.1 never WRITES it (App. C Q13), so the images
+    # come from the reference's own encodeChunk with BIT_ENCODE_QUAL_BY_COL cleared on the header it made (oracle/ref_harness.cpp rle_image);
+    # what the reference binary decodes from them is the golden
+    import tempfile
+    rle = {}
+    RLE_IN = {"d5_tiny_se": (CASES["d5_tiny_se"]["fq1"], b""), "d6_tiny_pe": (CASES["d6_tiny_pe"]["fq1"], CASES["d6_tiny_pe"]["fq2"]),
+              "se150_4q": (O.gen(O.NOVA_SE150, 120, seed=61)[0], b""), "se_var_manyN": (O.gen(O.SE_VAR, 150, seed=62, nppm=20000)[0], b""),
+              "pe150_manyN": O.gen(O.NOVA_PE150, 80, seed=63, nppm=20000), "bgi_13q": O.gen(O.BGI_PE100, 60, seed=64, n_quals=13), "bgi_40q": O.gen(O.BGI_PE100, 40, seed=65, n_quals=40)}
+    for name, (f1, f2) in RLE_IN.items():
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            p1, p2, o = os.path.join(d, "a_1.fq"), os.path.join(d, "a_2.fq"), os.path.join(d, "o.rfq")
+            open(p1, "wb").write(f1)
+            if f2:
+                open(p2, "wb").write(f2)
+            subprocess.run([O.REF_HARNESS, "rle_image", p1, p2 if f2 else "-", o], check=True, capture_output=True)
+            img = open(o, "rb").read()
+        dec = O.ref_decode(img, bool(f2))
+        rle[name] = {"rfq_hex": img.hex(), "paired": 1 if f2 else 0, "decode_md5": [hashlib.md5(x).hexdigest() for x in (dec if f2 else (dec,))],
+                     "roundtrip": (dec == (f1, f2)) if f2 else (dec == f1)}
+        print("rle", name, len(img), rle[name]["roundtrip"])
+    json.dump(rle, open(os.path.join(HERE, "rle.json"), "w"), indent=0, sort_keys=True)
+
     gen = []
     GEN = [  # (label, profile, reads, seed, nppm, nonl, interleaved, n_quals, paired, k)
         ("cfg0_se_var_50k", O.SE_VAR, 50000, 1, 20, 0, False, 13, O.SE, 1000),

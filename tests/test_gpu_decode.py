@@ -139,3 +139,8 @@ def test_first_diff_of_two_device_texts(codec):
 def test_decode_with_chunk_index(codec):
     """rfq_decode_args.h_chunk_off: verified on the device, ignored when it does not verify (see tests/_engine.py)."""
     E.decode_with_chunk_index(codec)
+
+
+@pytest.mark.parametrize("name", sorted(E.rle_goldens()))
+def test_legacy_run_length_quality_images_decode_like_the_reference(codec, name):
+    E.check_rle_decode(codec, name, E.rle_goldens()[name])

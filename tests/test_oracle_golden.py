@@ -102,3 +102,14 @@ def test_oracle_equals_reference_binary_randomised():
         paired = O.SE if prof in (O.NOVA_SE150, O.SE_VAR) else (O.PE_INTERLEAVED if il else O.PE_TWO_FILES)
         k = rng.choice([100, 137, 1000])
         assert O.encode_file(fq1, fq2, paired, k * 1000) == O.ref_encode(fq1, fq2, paired, k)
+
+
+def test_oracle_decodes_legacy_run_length_images_like_the_reference():
+    """decodeQualByRunLenCoding (src/rfqcodec.cpp:919-955) against what the reference binary decoded."""
+    import hashlib
+    import _engine as E
+    for name, g in E.rle_goldens().items():
+        img = bytes.fromhex(g["rfq_hex"]); split = bool(g["paired"])
+        got = O.decode_file(img, split)
+        assert [hashlib.md5(x).hexdigest() for x in (got if split else (got,))] == g["decode_md5"], name
+        assert g["roundtrip"]
