@@ -35,9 +35,11 @@ STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "rea
                  "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
                  "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder", "k_pos_sizes"],
                  "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
-                 "dec:walk": ["k_dec_table", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
-                 "dec:streams": ["k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_coords", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_pos_index", "k_dec_except"],
-                 "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit"]}
+                 "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
+                 "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list",
+                                 # (reads longer than 2000 bases, -k values whose chunks exceed 4096 records, and legacy RLE files take the materialising path)
+                                 "k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_pos_index", "k_dec_except", "k_dec_rle"],
+                 "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit2"]}
 
 WORKLOADS = {
     # key: (label, fqgen profile, units (reads or pairs), seed, extra gen kwargs, paired)
