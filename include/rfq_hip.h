@@ -8,7 +8,9 @@
  *
  * Conventions
  *   - plain pointers + sizes, no C++/torch types; every d_* pointer is DEVICE memory (hipMalloc or a torch CUDA
- *     tensor's data_ptr()), 16-byte aligned; h_* pointers are host memory.
+ *     tensor's data_ptr()); h_* pointers are host memory.  Input pointers (FASTQ text, .rfq image) may have any alignment and
+ *     any length: a stream of 4 GiB or more is worked through in slices inside the call, the result is the one image / the
+ *     one text.  Caller-provided OUTPUT buffers must be 16-byte aligned.
  *   - return 0 (RFQ_OK) or a negative RFQ_E_* code; rfq_last_error(ctx) then holds the reference's error_exit text
  *     (src/util.h:246-249) where the reference has one for the condition.
  *   - one rfq_ctx per (host thread, GPU); distinct contexts may be used concurrently.  A context owns its workspace
@@ -145,7 +147,8 @@ typedef struct {
 } rfq_decode_result;
 
 /* RfqChunk::read + RfqCodec::decodeChunk + Read::toString for every chunk of the image
- * (src/rfqchunk.cpp:161-228, src/rfqcodec.cpp:826-1260, src/read.cpp:170-172). */
+ * (src/rfqchunk.cpp:161-228, src/rfqcodec.cpp:826-1260, src/read.cpp:170-172).  Images whose header lacks
+ * BIT_ENCODE_QUAL_BY_COL (legacy run-length quality coding, src/rfqcodec.cpp:919-955; v0.5.1 never writes one) decode too. */
 int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* args, rfq_decode_result* res);
 
 /* stage timings of the last batch call, in milliseconds, measured with HIP events on the context's stream.
