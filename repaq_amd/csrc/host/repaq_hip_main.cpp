@@ -3,15 +3,20 @@
 // (src/repaq.cpp): stream I/O, batching with carry-over, header-once, line-break thresholds, PE even/odd outputs and the
 // compare JSON live here; every byte of codec work happens on the GPU (there is no CPU codec in this binary).
 //
-// I/O pipeline: a reader thread per input fills page-locked blocks two blocks ahead (plain files, stdin,
-// .gz through zlib like src/fastqreader.cpp:31-37, .xz through an `xz -d -c` pipe like src/main.cpp:160-177), the main thread
-// moves blocks to HBM and runs the codec, a writer thread per output drains page-locked result buffers in order (plain,
-// stdout, .gz through zlib like src/writer.cpp:39-51, .rfq.xz through an `xz -z -c` pipe like src/main.cpp:134-159).
-// Inputs and outputs of any size stream through: nothing is slurped, one batch is < 4 GiB per stream.
+// I/O pipeline: readers fill page-locked staging blocks (16 MB) ahead of the codec - a regular file by several
+// threads with pread, block i always before block i+1 is handed out; stdin, .gz through zlib like src/fastqreader.cpp:31-37 and .xz
+// through an `xz -d -c` pipe like src/main.cpp:160-177 by one thread, two blocks ahead so that the end of the input is known in time.
+// The main thread moves blocks into a device-resident batch (256 MB by default: the codec's fixed cost per call is paid per batch, not
+// per staging block), runs the codec and copies results out piece by piece into page-locked buffers; writers drain them - a regular
+// file by several threads with pwrite at each piece's offset, stdout / .gz (zlib like src/writer.cpp:39-51) / .rfq.xz (an `xz -z -c`
+// pipe like src/main.cpp:134-159) by one thread in order.  Inputs and outputs of any size stream through: nothing is slurped.
 #include "rfq_hip.h"
 #include <zlib.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -37,8 +42,17 @@ struct Options {
     long chunkKb = 1000; bool compress = false, decompress = false, compare = false, useStdin = false, useStdout = false, interleaved = false;
     bool completeCheck = false, fastCheck = false;   // -v / -f: decode what was just encoded and compare it with the input (src/repaq.cpp:430-528)
     std::vector<int> devices;              // --devices a,b,...: chunk-parallel compress of ONE input over several GPUs (host work queue)
-    int device = 0; size_t batchBytes = (size_t)16 << 20; int threads = 1, compression = 3;   // 16 MB batches: the stages of the I/O pipeline overlap best (tools/batch_sweep.sh)
+    int device = 0; int threads = 1, compression = 3;
+    size_t batchBytes = (size_t)256 << 20;  // device-resident text per codec call (per stream)
+    size_t blockBytes = (size_t)16 << 20;   // page-locked staging block (never larger than a batch)
+    int ioThreads = 8;                      // readers per regular input file (pread)
+    int writeThreads = 1;                   // writers per regular output file (pwrite); tmpfs does not scale with more, parallel file systems do
+    bool trace = false;                     // --trace: wall-clock marks of the pipeline on stderr
+    size_t block() const { return std::max<size_t>(std::min(blockBytes, batchBytes), (size_t)1 << 20); }   // >= the reader's 1 MiB block (line-break thresholds)
 };
+static const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+static bool g_trace = false;
+static void trace_mark(const char* what) { if (g_trace) fprintf(stderr, "[trace] %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count(), what); }
 
 // ------------------------------------------------------------------------------------------------ byte sources / sinks
 struct ByteSource {                      // sequential bytes of a plain file, stdin, a .gz (zlib) or a .xz (xz -d -c pipe)
@@ -116,78 +130,129 @@ struct Gpu {
     uint8_t* pinned(size_t n) { void* h = nullptr; check(rfq_host_alloc(c, &h, n + 64)); return (uint8_t*)h; }
 };
 
-// Reader thread: page-locked blocks of `block` bytes, read two blocks ahead so that the end of the input is known when the
-// block before the last two is handed out (the line-break thresholds and `final` need it).
+// Readers: page-locked blocks of `block` bytes, handed out in file order.
+//  * a regular file: its size is known up front (so is whether it ends with a line break), `threads` readers pread block after block;
+//    a reader claims a block index together with the buffer it will fill, so block i never waits for a buffer held by a later block;
+//  * anything sequential (stdin, .gz, .xz pipe): one reader, two blocks ahead - the end of the input is then known when the block
+//    before the last two is handed out (the line-break thresholds and `final` need it).
 struct Block { uint8_t* p = nullptr; size_t n = 0; };
 class Prefetcher {
-    ByteSource src; Gpu& g; size_t block; std::thread th; std::mutex mu; std::condition_variable cv;
-    std::deque<Block> ready; std::vector<uint8_t*> freeb; bool eof = false, stop = false; uint64_t total = 0; int last_byte = -1;
-    void run() {
+    ByteSource src; Gpu& g; size_t block; std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
+    std::map<uint64_t, Block> ready; uint64_t next_out = 0, next_claim = 0, n_blocks = 0; std::vector<uint8_t*> freeb; int to_alloc = 0;   // to_alloc: page-locked blocks not allocated yet (a reader allocates its own: pinning runs beside the first reads)
+    bool eof = false, stop = false, regular = false; uint64_t total = 0; int last_byte = -1; int fd = -1; int running = 0;
+    void run_seq() {
         for (;;) {
             uint8_t* buf;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !freeb.empty() || stop; }); if (stop) { eof = true; cv.notify_all(); return; } buf = freeb.back(); freeb.pop_back(); }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !freeb.empty() || to_alloc > 0 || stop; }); if (stop) { eof = true; cv.notify_all(); return; }
+              if (!freeb.empty()) { buf = freeb.back(); freeb.pop_back(); } else { to_alloc--; buf = nullptr; } }
+            if (!buf) buf = g.pinned(block);
             const size_t n = src.read(buf, block);
             std::unique_lock<std::mutex> lk(mu);
-            if (n) { total += n; last_byte = buf[n - 1]; ready.push_back(Block{ buf, n }); } else freeb.push_back(buf);
+            if (n) { total += n; last_byte = buf[n - 1]; ready[next_claim++] = Block{ buf, n }; } else freeb.push_back(buf);
             if (n < block) { eof = true; cv.notify_all(); return; }
             cv.notify_all();
         }
     }
-public:
-    Prefetcher(Gpu& gpu, const std::string& path, size_t block_bytes) : g(gpu), block(block_bytes) {
-        if (!src.open(path)) error_exit("Failed to open file: " + path);
-        struct stat st;                                                     // small regular files: no point in pinning 4 x batch
-        if (!ends_with(path, ".gz") && !ends_with(path, ".xz") && path != "/dev/stdin" && stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode))
-            block = std::min(block, std::max<size_t>((size_t)st.st_size + 1, (size_t)1 << 20));
-        for (int i = 0; i < 4; i++) freeb.push_back(g.pinned(block));
-        th = std::thread([this] { run(); });
+    void run_par() {
+        for (;;) {
+            uint8_t* buf; uint64_t idx;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || next_claim >= n_blocks || !freeb.empty() || to_alloc > 0; });
+              if (stop || next_claim >= n_blocks) { if (--running == 0) { eof = true; cv.notify_all(); } return; }
+              if (!freeb.empty()) { buf = freeb.back(); freeb.pop_back(); } else { to_alloc--; buf = nullptr; }
+              idx = next_claim++; }
+            if (!buf) buf = g.pinned(block);
+            const uint64_t off = idx * (uint64_t)block; const size_t want = (size_t)std::min<uint64_t>(block, total - off); size_t got = 0;
+            while (got < want) { const ssize_t k = pread(fd, buf + got, want - got, (off_t)(off + got)); if (k <= 0) break; got += (size_t)k; }
+            if (got != want) error_exit("Failed to read file: " + src.path);
+            std::unique_lock<std::mutex> lk(mu); ready[idx] = Block{ buf, got }; cv.notify_all();
+        }
     }
-    // (a caller that stops early — an empty line ends the input, a failed compare — leaves blocks unread: wake the reader up)
-    ~Prefetcher() { { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); } if (th.joinable()) th.join(); src.close(); }
-    // next block; false when the input is exhausted.  After it returns, end_known() tells whether the reader has seen the end
-    // of the input; if not, at least two more full blocks follow the one just returned.
+public:
+    Prefetcher(Gpu& gpu, const std::string& path, size_t block_bytes, int threads = 1) : g(gpu), block(block_bytes) {
+        struct stat st;
+        regular = !ends_with(path, ".gz") && !ends_with(path, ".xz") && path != "/dev/stdin" && stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+        int nbuf = 4;
+        if (regular) {
+            fd = ::open(path.c_str(), O_RDONLY); if (fd < 0) error_exit("Failed to open file: " + path);
+            src.path = path; total = (uint64_t)st.st_size;
+            block = std::min(block, std::max<size_t>((size_t)total + 1, (size_t)1 << 20));          // small files: no point in pinning full blocks
+            n_blocks = (total + block - 1) / block;
+            if (total) { uint8_t c = 0; if (pread(fd, &c, 1, (off_t)(total - 1)) == 1) last_byte = c; }
+            threads = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, threads), n_blocks));
+            nbuf = (int)std::min<uint64_t>((uint64_t)threads + 3, std::max<uint64_t>(n_blocks, 1));
+            if (n_blocks == 0) eof = true;
+        } else if (!src.open(path)) error_exit("Failed to open file: " + path);
+        to_alloc = nbuf;
+        if (regular) { running = n_blocks ? threads : 0; for (int i = 0; i < running; i++) th.emplace_back([this] { run_par(); }); }
+        else th.emplace_back([this] { run_seq(); });
+    }
+    // (a caller that stops early — an empty line ends the input, a failed compare — leaves blocks unread: wake the readers up)
+    ~Prefetcher() { { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); } for (auto& t : th) if (t.joinable()) t.join(); if (fd >= 0) ::close(fd); else src.close(); }
+    // next block; false when the input is exhausted.  After it returns, end_known() tells whether the end of the input is known;
+    // if not, at least two more full blocks follow the one just returned.
     bool next(Block& b) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return ready.size() >= 3 || eof; });
-        if (ready.empty()) return false;
-        b = ready.front(); ready.pop_front();
+        if (regular) { if (next_out >= n_blocks) return false; cv.wait(lk, [&] { return ready.count(next_out) != 0; }); }
+        else { cv.wait(lk, [&] { return ready.size() >= 3 || eof; }); if (ready.empty()) return false; }
+        auto it = ready.find(next_out); b = it->second; ready.erase(it); next_out++;
         return true;
     }
     void release(const Block& b) { std::unique_lock<std::mutex> lk(mu); freeb.push_back(b.p); cv.notify_all(); }
-    bool end_known() { std::unique_lock<std::mutex> lk(mu); return eof; }
-    bool drained() { std::unique_lock<std::mutex> lk(mu); return eof && ready.empty(); }
+    bool end_known() { std::unique_lock<std::mutex> lk(mu); return regular || eof; }
+    bool drained() { std::unique_lock<std::mutex> lk(mu); return regular ? next_out >= n_blocks : (eof && ready.empty()); }
     uint64_t total_bytes() { std::unique_lock<std::mutex> lk(mu); return total; }
     int final_byte() { std::unique_lock<std::mutex> lk(mu); return last_byte; }
 };
 
-// Writer thread: ordered queue of page-locked result buffers
+// Writers: results leave the device piece by piece through a small pool of page-locked buffers.  A regular output file is written by
+// several threads with pwrite (every piece knows its offset); anything sequential (stdout, .gz, xz pipe) by one thread in order.
 class AsyncWriter {
-    ByteSink sink; Gpu& g; std::thread th; std::mutex mu; std::condition_variable cv;
-    struct Item { uint8_t* p; size_t n, cap; }; std::deque<Item> q; std::vector<Item> pool; bool done = false; int in_flight = 0;
+    ByteSink sink; Gpu& g; std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
+    struct Item { uint8_t* p; size_t n, cap; uint64_t off; }; std::deque<Item> q; std::vector<Item> pool; bool done = false; int in_flight = 0, max_flight = 3;
+    size_t piece; bool regular = false; int fd = -1; uint64_t off = 0; std::string path;
     void run() {
         for (;;) {
             Item it;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !q.empty() || done; }); if (q.empty()) return; it = q.front(); q.pop_front(); }
-            sink.write(it.p, it.n);
+            if (regular) { size_t w = 0; while (w < it.n) { const ssize_t k = pwrite(fd, it.p + w, it.n - w, (off_t)(it.off + w)); if (k <= 0) error_exit("Failed to write: " + path); w += (size_t)k; } }
+            else sink.write(it.p, it.n);
             std::unique_lock<std::mutex> lk(mu); pool.push_back(it); in_flight--; cv.notify_all();
         }
     }
-public:
-    AsyncWriter(Gpu& gpu, const std::string& path, const Options& o) : g(gpu) { sink.open(path, o); th = std::thread([this] { run(); }); }
-    // a page-locked buffer of >= n bytes (at most three in flight); fill it, then submit()
+    // a page-locked buffer of >= n bytes (at most max_flight in flight); fill it, then submit()
     uint8_t* acquire(size_t n, size_t& cap) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return in_flight < 3; });
+        cv.wait(lk, [&] { return in_flight < max_flight; });
         in_flight++;
         for (size_t i = 0; i < pool.size(); i++) if (pool[i].cap >= n) { Item it = pool[i]; pool.erase(pool.begin() + i); cap = it.cap; return it.p; }
         uint8_t* stale = nullptr; if (!pool.empty()) { stale = pool.back().p; pool.pop_back(); }
         lk.unlock();
         if (stale) rfq_host_free(g.c, stale);
-        cap = n + n / 4 + 4096; return g.pinned(cap);
+        cap = std::min(piece, std::max<size_t>(n + n / 4 + 4096, (size_t)1 << 20)); if (cap < n) cap = n; return g.pinned(cap);
     }
-    void submit(uint8_t* p, size_t n, size_t cap) { std::unique_lock<std::mutex> lk(mu); q.push_back(Item{ p, n, cap }); cv.notify_all(); }
-    void finish() { { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_all(); } if (th.joinable()) th.join(); sink.close(); }
-    ~AsyncWriter() { if (th.joinable()) finish(); }
+    void submit(uint8_t* p, size_t n, size_t cap) { std::unique_lock<std::mutex> lk(mu); q.push_back(Item{ p, n, cap, off }); off += n; cv.notify_all(); }
+public:
+    AsyncWriter(Gpu& gpu, const std::string& p, const Options& o) : g(gpu), piece(o.block()), path(p) {
+        struct stat st; int threads = 1;
+        regular = !ends_with(p, ".gz") && !ends_with(p, ".xz") && p != "/dev/stdout" && (stat(p.c_str(), &st) != 0 || S_ISREG(st.st_mode));
+        if (regular) { fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) error_exit("Failed to open file for writing: " + p); threads = std::max(1, o.writeThreads); max_flight = threads + 2; }
+        else sink.open(p, o);
+        for (int i = 0; i < threads; i++) th.emplace_back([this] { run(); });
+    }
+    // n bytes of device memory -> the output, in order
+    void write_dev(const uint8_t* d, size_t n) {
+        for (size_t at = 0; at < n; at += piece) {
+            const size_t k = std::min(piece, n - at); size_t cap; uint8_t* h = acquire(k, cap);
+            g.check(rfq_copy_d2h(g.c, h, d + at, k)); submit(h, k, cap);
+        }
+    }
+    void finish() {
+        { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_all(); }
+        for (auto& t : th) if (t.joinable()) t.join();
+        th.clear();
+        if (regular) { if (fd >= 0 && ::close(fd) != 0) error_exit("Failed to write: " + path); fd = -1; } else sink.close();
+    }
+    ~AsyncWriter() { if (!th.empty()) finish(); }
 };
 
 // Device text of one input stream: [carry of the previous batch | newly copied block(s)], 16-byte aligned at its base
@@ -201,9 +266,9 @@ struct DevStream {
         if (carry) g.check(rfq_copy_d2d(g.c, d[nx], (uint8_t*)d[cur] + consumed, carry));
         cur = nx; have = carry; file_off += consumed;
     }
-    void append(Gpu& g, const Block& b) {
+    void append(Gpu& g, const Block& b, size_t room = 0) {
         if (cap[cur] < have + b.n) {                                          // grow (first block, or the streams of a pair drift apart)
-            const size_t nc = have + b.n + (have + b.n) / 8; void* nd = g.dev(nc);
+            const size_t nc = std::max(have + b.n + (have + b.n) / 8, room); void* nd = g.dev(nc);
             if (have) g.check(rfq_copy_d2d(g.c, nd, d[cur], have));
             if (d[cur]) rfq_dev_free(g.c, d[cur]);
             d[cur] = nd; cap[cur] = nc;
@@ -291,21 +356,22 @@ static void do_compress(const Options& o) {
     const bool two = !o.in2.empty();
     const int paired = two ? RFQ_PE_TWO_FILES : (o.interleaved ? RFQ_PE_INTERLEAVED : RFQ_SE);
     Gpu g(o.device);
-    const size_t block = std::max<size_t>(o.batchBytes, (size_t)1 << 20);       // >= the reader's 1 MiB block: see nolb below
-    Prefetcher* in[2] = { new Prefetcher(g, o.in1, block), two ? new Prefetcher(g, o.in2, block) : nullptr };
+    const size_t block = o.block(), batch = std::max(o.batchBytes, block);      // staging block (>= the reader's 1 MiB block: see nolb below) / device batch
+    Prefetcher* in[2] = { new Prefetcher(g, o.in1, block, o.ioThreads), two ? new Prefetcher(g, o.in2, block, o.ioThreads) : nullptr };
     AsyncWriter out(g, o.out1, o);
     DevStream ds[2]; const int ns = two ? 2 : 1;
-    bool first = true; size_t want = block;                                    // bytes a stream should hold before a batch is tried
+    bool first = true; size_t want = batch;                                    // bytes a stream should hold before a batch is tried
+    trace_mark("compress: pipeline up");
     Verifier* ver = (o.completeCheck || o.fastCheck) ? new Verifier(o, o.device) : nullptr;
     for (;;) {
         for (int s = 0; s < ns; s++) {
             while (!ds[s].ended && ds[s].have < want) {
                 Block b; if (!in[s]->next(b)) { ds[s].ended = true; break; }
-                if (ds[s].have + b.n >= 0xFFFFFFF0ull) error_exit("a batch of one FASTQ stream must stay below 4 GiB (chunk larger than that, or paired files of very different length)");
-                ds[s].append(g, b); in[s]->release(b);
+                ds[s].append(g, b, batch + block); in[s]->release(b);
                 if (in[s]->drained()) ds[s].ended = true;
             }
         }
+        trace_mark("compress: batch resident");
         const bool final = ds[0].ended && (!two || ds[1].ended);
         rfq_encode_args a; memset(&a, 0, sizeof a);
         a.d_fq1 = ds[0].base(); a.n1 = ds[0].have; a.d_fq2 = two ? ds[1].base() : nullptr; a.n2 = two ? ds[1].have : 0; a.paired = paired;
@@ -320,17 +386,16 @@ static void do_compress(const Options& o) {
         rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
         if (ver && r.n_chunks && ver->wanted())
             ver->check(g, r, first, final || r.input_ended, two, ds[0].base(), final ? ds[0].have : r.consumed1, two ? ds[1].base() : nullptr, two ? (final ? ds[1].have : r.consumed2) : 0, ds[0].file_off, ds[1].file_off);
-        if (r.rfq_len) {
-            size_t cap; uint8_t* h = out.acquire(r.rfq_len, cap);
-            g.check(rfq_copy_d2h(g.c, h, r.d_rfq, r.rfq_len)); out.submit(h, r.rfq_len, cap);
-            if (r.n_chunks) first = false;
-        }
+        trace_mark("compress: batch encoded");
+        if (r.rfq_len) { out.write_dev(r.d_rfq, r.rfq_len); if (r.n_chunks) first = false; }
         if (final || r.input_ended) break;            // input_ended: the reader stopped at an empty line (src/fastqreader.cpp:180-191)
-        if (r.consumed1 == 0 && (!two || r.consumed2 == 0)) { want = std::max(ds[0].have, ds[1].have) + block; continue; }   // a chunk larger than the batch: read on
-        ds[0].advance(g, r.consumed1, block); if (two) ds[1].advance(g, r.consumed2, block);
-        want = block;
+        if (r.consumed1 == 0 && (!two || r.consumed2 == 0)) { want = std::max(ds[0].have, ds[1].have) + batch; continue; }   // a chunk larger than the batch: read on
+        ds[0].advance(g, r.consumed1, batch + block); if (two) ds[1].advance(g, r.consumed2, batch + block);
+        want = batch;
     }
+    trace_mark("compress: all batches done");
     out.finish();                                      // (an input without reads leaves an empty output, like the reference)
+    trace_mark("compress: output closed");
     delete ver;
     for (int s = 0; s < ns; s++) { ds[s].free_all(g); delete in[s]; }
 }
@@ -345,8 +410,8 @@ static void do_compress_multi(const Options& o) {
     const int paired = two ? RFQ_PE_TWO_FILES : (o.interleaved ? RFQ_PE_INTERLEAVED : RFQ_SE);
     const uint32_t chunk_bases = (uint32_t)(std::max(100L, o.chunkKb) * 1000);
     Gpu gs(o.devices[0]);                                                    // scanner context
-    const size_t block = std::max<size_t>(o.batchBytes, (size_t)1 << 20);
-    Prefetcher* in[2] = { new Prefetcher(gs, o.in1, block), two ? new Prefetcher(gs, o.in2, block) : nullptr };
+    const size_t block = o.block(), batch = std::max(o.batchBytes, block);
+    Prefetcher* in[2] = { new Prefetcher(gs, o.in1, block, o.ioThreads), two ? new Prefetcher(gs, o.in2, block, o.ioThreads) : nullptr };
     const int ns = two ? 2 : 1; DevStream ds[2];
     // shared state
     std::mutex mu; std::condition_variable cv;
@@ -393,13 +458,12 @@ static void do_compress_multi(const Options& o) {
         }
         if (b1) rfq_dev_free(g.c, b1); if (b2) rfq_dev_free(g.c, b2);
     });
-    uint64_t seq = 0; size_t want = block;
+    uint64_t seq = 0; size_t want = batch;
     for (;;) {
         for (int s = 0; s < ns; s++) {
             while (!ds[s].ended && ds[s].have < want) {
                 Block b; if (!in[s]->next(b)) { ds[s].ended = true; break; }
-                if (ds[s].have + b.n >= 0xFFFFFFF0ull) error_exit("a batch of one FASTQ stream must stay below 4 GiB (chunk larger than that, or paired files of very different length)");
-                ds[s].append(gs, b); in[s]->release(b);
+                ds[s].append(gs, b, batch + block); in[s]->release(b);
                 if (in[s]->drained()) ds[s].ended = true;
             }
         }
@@ -411,7 +475,7 @@ static void do_compress_multi(const Options& o) {
         uint64_t th[2] = { UINT64_MAX, UINT64_MAX };
         for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t && in[s]->final_byte() != '\n') th[s] = nolb_threshold(t); }
         const bool last_batch = final || sr.input_ended;
-        if (sr.n_chunks == 0 && !last_batch) { want = std::max(ds[0].have, ds[1].have) + block; continue; }
+        if (sr.n_chunks == 0 && !last_batch) { want = std::max(ds[0].have, ds[1].have) + batch; continue; }
         // deal the chunks out in contiguous ranges, one per device (fewer when the batch holds fewer chunks)
         const uint32_t parts = sr.n_chunks ? (uint32_t)std::min<size_t>(o.devices.size(), sr.n_chunks) : 1u;
         uint64_t first_seq = seq;
@@ -434,8 +498,8 @@ static void do_compress_multi(const Options& o) {
         }
         (void)first_seq;
         if (last_batch) break;
-        ds[0].advance(gs, sr.consumed1, block); if (two) ds[1].advance(gs, sr.consumed2, block);
-        want = block;
+        ds[0].advance(gs, sr.consumed1, batch + block); if (two) ds[1].advance(gs, sr.consumed2, batch + block);
+        want = batch;
     }
     { std::unique_lock<std::mutex> lk(mu); no_more = true; total_items = seq; all_queued = true; cv.notify_all(); }
     for (auto& t : workers) t.join();
@@ -448,27 +512,30 @@ struct DecodeTotals { uint64_t reads = 0, bases = 0; };
 static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& path, bool split,
                                   const std::function<void(const uint8_t*, size_t, const uint8_t*, size_t)>& emit_dev,
                                   const std::function<void(const rfq_decode_result&)>& on_batch = nullptr) {
-    // ~1/8 of the text batch: .rfq is 7-25 % of its FASTQ, so one call stays far below the 4 GiB-per-call text limit
-    const size_t block = std::max<size_t>(o.batchBytes / 8, (size_t)1 << 16);
-    Prefetcher in(g, path, block);
-    DevStream ds; bool first = true; size_t want = block; DecodeTotals tot;
+    // image bytes per call ~ 1/8 of the text batch: .rfq is 7-25 % of its FASTQ, so the text of one call is about one batch
+    const size_t batch = std::max<size_t>(o.batchBytes / 8, (size_t)1 << 16), block = std::min(batch, o.block());
+    Prefetcher in(g, path, block, o.ioThreads);
+    DevStream ds; bool first = true; size_t want = batch; DecodeTotals tot;
     for (;;) {
         while (!ds.ended && ds.have < want) {
             Block b; if (!in.next(b)) { ds.ended = true; break; }
-            ds.append(g, b); in.release(b);
+            ds.append(g, b, batch + block); in.release(b);
             if (in.drained()) ds.ended = true;
         }
+        trace_mark("decode: batch resident");
         rfq_decode_args a; memset(&a, 0, sizeof a);
         a.d_rfq = ds.base(); a.n = ds.have; a.has_header = first ? 1 : 0; a.split_pe = split ? 1 : 0; a.final = ds.ended ? 1 : 0;
         rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
         first = false;
+        trace_mark("decode: batch decoded");
         tot.reads += r.n_reads; tot.bases += r.n_bases;
         if (on_batch) on_batch(r);
         if (r.n1 || r.n2) emit_dev(r.d_fq1, r.n1, r.d_fq2, r.n2);
         if (ds.ended) break;
-        if (r.consumed == 0) { want = ds.have + block; continue; }            // not one whole chunk yet
-        ds.advance(g, r.consumed, block); want = block;
+        if (r.consumed == 0) { want = ds.have + batch; continue; }            // not one whole chunk yet
+        ds.advance(g, r.consumed, batch + block); want = batch;
     }
+    trace_mark("decode: all batches done");
     ds.free_all(g);
     return tot;
 }
@@ -478,10 +545,11 @@ static void do_decompress(const Options& o) {
     const bool split = !o.out2.empty();
     AsyncWriter w1(g, o.out1, o); AsyncWriter* w2 = split ? new AsyncWriter(g, o.out2, o) : nullptr;
     decode_stream(g, o, o.in1, split, [&](const uint8_t* d1, size_t n1, const uint8_t* d2, size_t n2) {
-        if (n1) { size_t cap; uint8_t* h = w1.acquire(n1, cap); g.check(rfq_copy_d2h(g.c, h, d1, n1)); w1.submit(h, n1, cap); }
-        if (split && n2) { size_t cap; uint8_t* h = w2->acquire(n2, cap); g.check(rfq_copy_d2h(g.c, h, d2, n2)); w2->submit(h, n2, cap); }
+        if (n1) w1.write_dev(d1, n1);
+        if (split && n2) w2->write_dev(d2, n2);
     });
     w1.finish(); if (w2) { w2->finish(); delete w2; }
+    trace_mark("decompress: outputs closed");
 }
 
 // ---- compare mode (src/repaq.cpp:36-259): decode on the GPU, compare read by read with the FASTQ text, same JSON
@@ -502,8 +570,8 @@ static void do_compare(const Options& o) {
     // that differs (a real mismatch, or text the reader would have normalised: "\r\n", blank lines) hands both sides over to the
     // record-by-record comparison below, which words the reference's message; so does the end of the image, for the
     // "FASTQ has more reads" test.
-    const size_t block = std::max<size_t>(o.batchBytes, (size_t)1 << 20);
-    Prefetcher* pf[2] = { new Prefetcher(g, o.in1, block), pe ? new Prefetcher(g, o.in2, block) : nullptr };
+    const size_t block = o.block();
+    Prefetcher* pf[2] = { new Prefetcher(g, o.in1, block, o.ioThreads), pe ? new Prefetcher(g, o.in2, block, o.ioThreads) : nullptr };
     DevStream fs[2]; bool fast = true;
     long fqReads = 0, fqBases = 0, rfqReads = 0, rfqBases = 0; bool reported = false;
     TextCursor dec[2], fq[2];
@@ -528,7 +596,6 @@ static void do_compare(const Options& o) {
                 for (int s = 0; s < ns && same; s++) {
                     while (!fs[s].ended && fs[s].have < dn[s]) {
                         Block b; if (!pf[s]->next(b)) { fs[s].ended = true; break; }
-                        if (fs[s].have + b.n >= 0xFFFFFFF0ull) { pf[s]->release(b); same = false; break; }
                         fs[s].append(g, b); pf[s]->release(b);
                         if (pf[s]->drained()) fs[s].ended = true;
                     }
@@ -606,7 +673,8 @@ static void do_compare(const Options& o) {
 static void usage() {
     fputs("repaq_hip: repack FASTQ to .rfq on an MI355X (repaq v0.5.1 compatible)\n"
           "usage: repaq_hip [-c|-d|-p] -i in1 [-I in2] -o out1 [-O out2] [-k chunk_kb] [--stdin] [--stdout] [--interleaved_in]\n"
-          "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N | --devices a,b,...] [--batch_mb M]\n"
+          "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N | --devices a,b,...]\n"
+          "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--trace]\n"
           "       FASTQ may be .gz (zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
 }
 int main(int argc, char** argv) {
@@ -641,6 +709,10 @@ int main(int argc, char** argv) {
         else if (a == "--device") o.device = atoi(val(i, "device").c_str());
         else if (a == "--devices" || a.rfind("--devices=", 0) == 0) { const std::string v = val(i, "devices"); size_t p0 = 0; while (p0 <= v.size()) { const size_t q = v.find(',', p0); const std::string t = v.substr(p0, q == std::string::npos ? std::string::npos : q - p0); if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (q == std::string::npos) break; p0 = q + 1; } }
         else if (a == "--batch_mb") o.batchBytes = (size_t)atol(val(i, "batch_mb").c_str()) << 20;
+        else if (a == "--block_mb") o.blockBytes = (size_t)atol(val(i, "block_mb").c_str()) << 20;
+        else if (a == "--io_threads") o.ioThreads = std::max(1, atoi(val(i, "io_threads").c_str()));
+        else if (a == "--write_threads") o.writeThreads = std::max(1, atoi(val(i, "write_threads").c_str()));
+        else if (a == "--trace") { o.trace = true; g_trace = true; }
         else { usage(); error_exit("unknown option: " + a); }
     }
     if ((int)o.compress + (int)o.decompress + (int)o.compare > 1) error_exit("repaq can run in compress/decompress/compare mode, you can only choose any one mode.");
@@ -666,6 +738,7 @@ int main(int argc, char** argv) {
     if (cb > 500000000) error_exit("chunk size cannot be greater than 500,000 kb");
     if (o.batchBytes < ((size_t)1 << 20)) o.batchBytes = (size_t)1 << 20;
     if (o.batchBytes > ((size_t)2 << 30)) o.batchBytes = (size_t)2 << 30;
+    if (o.blockBytes < ((size_t)1 << 20)) o.blockBytes = (size_t)1 << 20;
     if (enc) {
         if (!o.out2.empty()) error_exit("In compress mode, only one RFQ output file is allowed, but you specified <out2>");
         if (ends_with(o.out1, ".fq") || ends_with(o.out1, ".fastq")) error_exit("In compress mode, the output should not be a FASTQ file. Expect a .rfq or .rfq.xz file, but got " + o.out1);
@@ -683,5 +756,7 @@ int main(int argc, char** argv) {
         if (o.in1.empty()) error_exit("Please specify input file by <in1>, or enable --stdin if you want to read STDIN");
         do_compare(o);
     }
-    return 0;
+    trace_mark("done");
+    // every output is closed and flushed: leave without the HIP runtime's static teardown (~80 ms of unmapping at exit)
+    fflush(stdout); fflush(stderr); _exit(0);
 }
