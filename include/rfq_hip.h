@@ -162,6 +162,8 @@ int rfq_dev_free(rfq_ctx* ctx, void* d_ptr);
 int rfq_copy_h2d(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n);
 int rfq_copy_d2h(rfq_ctx* ctx, void* h_dst, const void* d_src, size_t n);
 int rfq_copy_d2d(rfq_ctx* ctx, void* d_dst, const void* d_src, size_t n);
+/* d_dst on ctx's GPU <- d_src on src_ctx's GPU (hipMemcpyPeerAsync): how a worker of a multi-GPU host queue pulls its byte range */
+int rfq_copy_peer(rfq_ctx* ctx, void* d_dst, const rfq_ctx* src_ctx, const void* d_src, size_t n);
 /* page-locked host buffers (hipHostMalloc): H2D / D2H copies from them run at full PCIe rate */
 int rfq_host_alloc(rfq_ctx* ctx, void** h_ptr, size_t n);
 int rfq_host_free(rfq_ctx* ctx, void* h_ptr);

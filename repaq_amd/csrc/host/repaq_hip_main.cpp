@@ -437,7 +437,7 @@ static void do_compress_multi(const Options& o) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = queue.front(); queue.pop_front(); }
             if (c1 < it.n1 + 64) { if (b1) rfq_dev_free(g.c, b1); c1 = it.n1 + it.n1 / 4 + 64; b1 = g.dev(c1); }
             if (two && c2 < it.n2 + 64) { if (b2) rfq_dev_free(g.c, b2); c2 = it.n2 + it.n2 / 4 + 64; b2 = g.dev(c2); }
-            g.check(rfq_copy_d2d(g.c, b1, it.d1, it.n1)); if (two) g.check(rfq_copy_d2d(g.c, b2, it.d2, it.n2));
+            g.check(rfq_copy_peer(g.c, b1, gs.c, it.d1, it.n1)); if (two) g.check(rfq_copy_peer(g.c, b2, gs.c, it.d2, it.n2));   // the scanner's GPU -> mine
             { std::unique_lock<std::mutex> lk(mu); copied++; cv.notify_all();
               if (it.seq != 0 && !have_hdr) { cv.wait(lk, [&] { return header_ready; }); } }
             if (it.seq != 0 && !have_hdr) { g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }

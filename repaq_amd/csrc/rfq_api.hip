@@ -102,6 +102,18 @@ extern "C" int rfq_copy_d2d(rfq_ctx* c, void* dst, const void* src, size_t n) {
     if (n) { HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return RFQ_OK;
 }
+// dst on this context's device <- src on src_ctx's device (the chunk ranges a multi-GPU host queue deals out): a peer copy over xGMI,
+// which the runtime stages through the host when the two devices have no peer path
+extern "C" int rfq_copy_peer(rfq_ctx* c, void* dst, const rfq_ctx* src_ctx, const void* src, size_t n) {
+    if (!c || !src_ctx) return RFQ_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) {
+        if (src_ctx->device == c->device) HIPCHK(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, c->stream));
+        else HIPCHK(c, hipMemcpyPeerAsync(dst, c->device, src, src_ctx->device, n, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return RFQ_OK;
+}
 // First byte at which two device texts differ (n when they are equal).  --compare on the device: a decoded batch
 // that is byte-identical to the same span of the FASTQ file has, read for read, equal name / sequence / strand / quality
 // (Repaq::compare's four tests, src/repaq.cpp:85-108); only a differing batch is cut into records by the caller to word the message.
