@@ -184,10 +184,10 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
 #define RFQ_EMIT2_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
                        (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr
         if (fused && (tune & 7)) {
-            unsigned long long* dbg = (unsigned long long*)B[DB_SCAN].p; (void)hipMemsetAsync(dbg, 0, 64, S);       // (the scan scratch is idle here)
+            unsigned long long* dbg = (unsigned long long*)B[DB_SCAN].p; (void)hipMemsetAsync(dbg, 0, 128, S);      // (the scan scratch is idle here)
             hipLaunchKernelGGL(k_dec_emit2<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, dbg, 0);
-            unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
-            if (h[6]) fprintf(stderr, "[emit2 dbg] waves=%llu avg cycles/wave: stage=%llu unpack=%llu tokens=%llu nstream=%llu compose=%llu flush=%llu steps/wave=%.1f\n", h[6], h[0]/h[6], h[1]/h[6], h[2]/h[6], h[3]/h[6], h[4]/h[6], h[5]/h[6], (double)h[7]/h[6]);
+            unsigned long long h[16]; (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
+            if (h[6]) fprintf(stderr, "[emit2 dbg] waves=%llu avg cycles/wave: stage=%llu (fit+spans %llu, dma issue %llu, list requests %llu, next tile's metadata + cells %llu, barrier %llu) unpack=%llu tokens=%llu nstream=%llu compose=%llu flush=%llu\n", h[6], h[0]/h[6], h[8]/h[6], h[9]/h[6], h[10]/h[6], h[11]/h[6], h[12]/h[6], h[1]/h[6], h[2]/h[6], h[3]/h[6], h[4]/h[6], h[5]/h[6]);
         } else if (fused) hipLaunchKernelGGL(k_dec_emit2<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, (unsigned long long*)nullptr, (tune >> 12) & 15);   // (tune bits 12-15: ablation switches, text invalid)
 #undef RFQ_EMIT2_ARGS
         else

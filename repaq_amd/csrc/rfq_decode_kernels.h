@@ -472,7 +472,7 @@ __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __
 //   k_dec_pos_link2  per stream, a wave scan over those summaries: entry state / entry position / entry list index of every segment
 //   k_dec_pos_list   decodes every segment from its now-known entry and writes its positions; records for every POS2_CELL positions the
 //                    index of the first list entry at or beyond the cell (the emitter starts there)
-#define POS2_SEG 256u
+#define POS2_SEG 1024u            // bytes of a stream per wave: POS2_SEG / 256 steps of 4 bytes per lane
 #define POS2_CELL 1024u
 struct PosSrc { const uint8_t* sp; uint32_t slen; uint8_t q; };
 // stream jj of a chunk: jj < nn = quality value stream, jj == nn = N positions.  slen = 0 when absent; corrupt length tables are flagged.
@@ -515,15 +515,23 @@ __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __
     const PosSrc s = pos_src_of(img, d, D, jj, g == 0 ? st : nullptr);
     if (g == 0 && l == 0) segN[(size_t)c * nstr + jj] = (s.slen + POS2_SEG - 1) / POS2_SEG;
     const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
-    const uint32_t i0 = b0 + 4u * (uint32_t)l;
-    const PosStep w = pos_fetch(s.sp, s.slen, i0, lim);
-    const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
-    uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;       // segment entry state -> state in front of my bytes
-    int a[4], n[4];
+    const uint32_t b1 = b0 + POS2_SEG < s.slen ? b0 + POS2_SEG : s.slen;
+    uint32_t Fcum = POS_ID; int a[4] = { 0, 0, 0, 0 }, n[4] = { 0, 0, 0, 0 };
+    PosStep nxt = pos_fetch(s.sp, s.slen, b0 + 4u * (uint32_t)l, lim);
+    for (uint32_t base = b0; base < b1; base += 256u) {                    // (wave-uniform)
+        const uint32_t i0 = base + 4u * (uint32_t)l;
+        const PosStep w = nxt;
+        if (base + 256u < b1) nxt = pos_fetch(s.sp, s.slen, i0 + 256u, lim);
+        const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
+        uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
+        const uint32_t G = fn_compose(Fcum, Fex);                          // segment entry state -> state in front of my bytes
 #pragma unroll
-    for (int e = 0; e < 4; e++) { pos_lane_adv_cnt(f, s.slen, i0, (Fex >> (2 * e)) & 3u, a[e], n[e]); a[e] = wave_sum(a[e]); n[e] = wave_sum(n[e]); }
-    const uint32_t F = __shfl(f.Fin, 63);
-    if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)F;
+        for (int e = 0; e < 4; e++) { int a_, n_; pos_lane_adv_cnt(f, s.slen, i0, (G >> (2 * e)) & 3u, a_, n_); a[e] += a_; n[e] += n_; }
+        Fcum = fn_compose(Fcum, __shfl(f.Fin, 63));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { a[e] = wave_sum(a[e]); n[e] = wave_sum(n[e]); }
+    if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)Fcum;
 #pragma unroll
                   for (int e = 0; e < 4; e++) { segA[8 * idx + e] = a[e]; segA[8 * idx + 4 + e] = n[e]; } }
 }
@@ -599,43 +607,49 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
     const PosSrc s = pos_src_of(img, d, D, jj, nullptr);
     const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
     const size_t t = (size_t)c * nstr + jj, idx = t * maxseg + g;
-    const uint32_t carry = segS[idx]; const int last = segP[idx]; const uint32_t k0 = segK[idx];
+    uint32_t carry = segS[idx]; int last = segP[idx]; uint32_t k0 = segK[idx];
     uint32_t* const out = plist + loff[t]; uint32_t* const cells = cellidx + t * ncell;
-    const uint32_t i0 = b0 + 4u * (uint32_t)l;
-    const PosStep w = pos_fetch(s.sp, s.slen, i0, lim);
-    const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
-    uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
-    uint32_t st0 = (Fex >> (2 * carry)) & 3u;                              // state in front of my first byte
-    int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0, lane_cnt = 0;
+    const uint32_t b1 = b0 + POS2_SEG < s.slen ? b0 + POS2_SEG : s.slen;
+    PosStep nxt = pos_fetch(s.sp, s.slen, b0 + 4u * (uint32_t)l, lim);
+    for (uint32_t base = b0; base < b1; base += 256u) {                    // (wave-uniform) a step = 256 bytes; state, position and list index carry over
+        const uint32_t i0 = base + 4u * (uint32_t)l;
+        const PosStep w = nxt;
+        if (base + 256u < b1) nxt = pos_fetch(s.sp, s.slen, i0 + 256u, lim);
+        const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
+        uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
+        uint32_t st0 = (Fex >> (2 * carry)) & 3u;                          // state in front of my first byte
+        int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0, lane_cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t bb = f.bt[k]; const bool valid = i0 + (uint32_t)k < s.slen;
-        const uint32_t b1 = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2 = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3 = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
-        start[k] = valid && st0 == 0; adv[k] = 0; run[k] = 0;
-        if (start[k]) {
-            if ((bb & 0x80u) == 0) adv[k] = (int)bb + 1;
-            else if ((bb & 0x40u) == 0) adv[k] = (int)(((bb & 0x3Fu) << 8) | b1) + 1;
-            else if ((bb & 0x20u) == 0) { run[k] = (bb & 0x1Fu) + 1; adv[k] = (int)run[k]; }
-            else adv[k] = (int)(((bb & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
-            lane_cnt += run[k] ? (int)run[k] : 1;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t bb = f.bt[k]; const bool valid = i0 + (uint32_t)k < s.slen;
+            const uint32_t b1_ = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2_ = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3_ = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
+            start[k] = valid && st0 == 0; adv[k] = 0; run[k] = 0;
+            if (start[k]) {
+                if ((bb & 0x80u) == 0) adv[k] = (int)bb + 1;
+                else if ((bb & 0x40u) == 0) adv[k] = (int)(((bb & 0x3Fu) << 8) | b1_) + 1;
+                else if ((bb & 0x20u) == 0) { run[k] = (bb & 0x1Fu) + 1; adv[k] = (int)run[k]; }
+                else adv[k] = (int)(((bb & 0x1Fu) << 24) | (b1_ << 16) | (b2_ << 8) | b3_) + 1;
+                lane_cnt += run[k] ? (int)run[k] : 1;
+            }
+            lane_adv += adv[k];
+            if (valid) st0 = (f.fn[k] >> (2 * st0)) & 3u;
         }
-        lane_adv += adv[k];
-        if (valid) st0 = (f.fn[k] >> (2 * st0)) & 3u;
-    }
-    const int ia = wave_incl_sum(lane_adv), ic = wave_incl_sum(lane_cnt);
-    int end = last + ia - lane_adv; uint32_t k = k0 + (uint32_t)(ic - lane_cnt);   // last covered position / list index in front of my tokens
+        const int ia = wave_incl_sum(lane_adv), ic = wave_incl_sum(lane_cnt);
+        int end = last + ia - lane_adv; uint32_t k = k0 + (uint32_t)(ic - lane_cnt);   // last covered position / list index in front of my tokens
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if (!start[q]) continue;
-        const int prev = end; end += adv[q];
-        const int lo = run[q] ? end - (int)run[q] + 1 : end;
-        int pp = prev;                                                       // the position of list entry k - 1 (-1: none)
-        for (int p = lo; p <= end; p++, k++) {
-            out[k] = (uint32_t)p;
-            uint32_t c0 = pp < 0 ? 0u : (uint32_t)pp / POS2_CELL + 1u; const uint32_t c1 = (uint32_t)p / POS2_CELL;
-            for (; c0 <= c1 && c0 < ncell; c0++) cells[c0] = k;
-            pp = p;
+        for (int q = 0; q < 4; q++) {
+            if (!start[q]) continue;
+            const int prev = end; end += adv[q];
+            const int lo = run[q] ? end - (int)run[q] + 1 : end;
+            int pp = prev;                                                   // the position of list entry k - 1 (-1: none)
+            for (int p = lo; p <= end; p++, k++) {
+                out[k] = (uint32_t)p;
+                uint32_t c0 = pp < 0 ? 0u : (uint32_t)pp / POS2_CELL + 1u; const uint32_t c1 = (uint32_t)p / POS2_CELL;
+                for (; c0 <= c1 && c0 < ncell; c0++) cells[c0] = k;
+                pp = p;
+            }
         }
+        last += __shfl(ia, 63); k0 += (uint32_t)__shfl(ic, 63); carry = (__shfl(f.Fin, 63) >> (2 * carry)) & 3u;
     }
 }
 
@@ -1151,10 +1165,10 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
     __shared__ uint4 s_src4[EG2_END];
     __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta2[2][(ET_READS + 1) * EM_ROW];
     // per stream of the chunk (t < nn: quality value t, t == nn: the N positions): list start in the arena, entries, value; per tile (two
-    // buffers): first entry at the tile's cell (s_g), first entry beyond the tile (s_kb), prefix of the quality lists' entry counts (s_wp)
+    // buffers): first entry at the tile's cell (s_g), first entry beyond the tile (s_kb)
     __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
-    __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2], s_wp[2][NPOS_SLOT + 2], s_nl0;
-    long long c0 = 0, c1 = 0, a_stage = 0, a_unpack = 0, a_tok = 0, a_n = 0, a_comp = 0, a_flush = 0, a_steps = 0;
+    __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2], s_nl0;
+    long long c0 = 0, c1 = 0, cs = 0, a_s1 = 0, a_s2 = 0, a_s3 = 0, a_s4 = 0, a_s5 = 0, a_stage = 0, a_unpack = 0, a_tok = 0, a_n = 0, a_comp = 0, a_flush = 0, a_steps = 0;
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint8_t* lim = img + img_bytes;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
     const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
@@ -1202,16 +1216,11 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
           m[7] = pv_.a - pv0.a; m[8] = pv_.b - pv0.b; m[9] = pv_.c - pv0.c;                                                           \
           if (r_ < re) { m[0] = (split && odd_) ? tp_.b : tp_.a; m[1] = len_; m[2] = ov_; m[3] = pl_; m[4] = n1_; m[5] = n2_; m[6] = sl_;   \
                          m[11] = md_; m[10] = n1_ + md_ + n2_ + 1; } }
-    // entries of quality list t that can fall into the tile: [k0, min(kb, entries)); their counts' prefix over t -> s_wp (by wave 0)
-#define EMIT2_PREFIX(buf, g_, b_)                                                                                                     \
-          if (tid < 64) { uint32_t n_ = 0; if (tid < nn && (g_) != 0xFFFFFFFFu) { const uint32_t ke_ = (b_) < s_nent[tid] ? (b_) : s_nent[tid]; if (ke_ > (g_)) n_ = ke_ - (g_); } \
-                          const uint32_t inc_ = wave_incl_sum(n_); if (tid < nn) s_wp[buf][tid + 1] = inc_; if (tid == 0) s_wp[buf][0] = 0; }
     uint32_t cur = rs; uint32_t pb = 0;
     { EMIT_META_VARS if (cur < re && tid <= ET_READS && cur + tid <= re) { EMIT_META_LOAD(cur) EMIT_META_STORE(s_meta2[0]) }
       if (cur < re && tid < 128) {                                          // (waves 0 and 1: T <= 65)
           uint32_t g_ = 0xFFFFFFFFu, b_ = 0xFFFFFFFFu;
           if (tid < T) { const uint32_t qp_ = R.pq[f + cur] - pq0, sp_ = R.pv[f + cur].d - pv0.d; g_ = cell_lookup(tid, qp_, sp_, false); b_ = cell_lookup(tid, qp_, sp_, true); s_g[0][tid] = g_; s_kb[0][tid] = b_; }
-          EMIT2_PREFIX(0, g_, b_)
       } }
     __syncthreads();
     while (cur < re) {                                                       // block-uniform
@@ -1257,23 +1266,30 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             const StageSpan sp[6] = { make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, raw), make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true),
                                       make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true),
                                       make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), make_span(s_src4 + EG_N2, img, n2a, n2e, img_bytes, true), make_span(s_src4 + EG_ST, img, sta, ste, img_bytes, true) };
+            if (DBG) { cs = clock64(); a_s1 += cs - c0; }
             stage_spans6<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(sp);
+            if (DBG) { const long long t_ = clock64(); a_s2 += t_ - cs; cs = t_; }
             // qualities start as the major value (src/rfqcodec.cpp:1089): no source to wait for
             if (bycol && !(abl & 1)) { uint4* qt = s_src4 + EG_Q + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         }
-        // the tile's list entries, requested now and scattered after the barrier.  Quality lists: the entries [k0, ke) of all lists form one
-        // flat range of W items (prefix s_wp); item w belongs to the list t with s_wp[t] <= w < s_wp[t + 1]; a thread takes items tid, tid + 256,
-        // ... - EL2_FL of them up front (a tile of a NovaSeq-binned file has ~600 items, of a 40-value file ~3500: the rest on demand)
-        const uint32_t W = s_wp[pb][nn];
-        auto item = [&](uint32_t w_, uint32_t& val_) -> const uint32_t* {
-            uint32_t lo_ = 0, hi_ = nn;                                      // s_wp[lo_] <= w_ < s_wp[hi_]
-            while (hi_ - lo_ > 1u) { const uint32_t mid_ = (lo_ + hi_) >> 1; if (s_wp[pb][mid_] <= w_) lo_ = mid_; else hi_ = mid_; }
-            val_ = s_val[lo_];
-            return plist + s_loff[lo_] + s_g[pb][lo_] + (w_ - s_wp[pb][lo_]);
+        // the tile's list entries, requested now and scattered after the barrier.  Quality lists: wave w takes the lists t = w, w + 4, ...;
+        // a round = 64 consecutive entries of one list, one per lane (the entries [k0, ke) a tile needs are known exactly); EL2_FL rounds
+        // are requested up front, the rest on demand.  Everything that steers this - list, round, bounds - is wave-uniform.
+        uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const uint32_t* ls_p = plist;
+        auto ls_open = [&](uint32_t t_) {                                   // the tile's entries of list t_
+            const uint32_t g_ = uni32(s_g[pb][t_]), b_ = uni32(s_kb[pb][t_]), n_ = uni32(s_nent[t_]);
+            ls_k0 = g_ == 0xFFFFFFFFu ? 0u : g_; ls_ke = g_ == 0xFFFFFFFFu ? 0u : (b_ < n_ ? b_ : n_); ls_base = 0;
+            ls_val = uni32(s_val[t_]); ls_p = plist + uni64(s_loff[t_]);
         };
+        auto ls_round = [&](uint32_t& e_, uint32_t& v_) {                   // the next round of this wave's lists (e_ stays ~0 when there is none)
+            while (ls_t < nn && ls_k0 + ls_base >= ls_ke) { ls_t += 4u; if (ls_t < nn) ls_open(ls_t); }
+            if (ls_t < nn) { const uint32_t kk = ls_k0 + ls_base + (uint32_t)l; if (kk < ls_ke) e_ = ls_p[kk]; v_ = ls_val; ls_base += 64u; }
+        };
+        if (ls_t < nn && !(abl & 8)) ls_open(ls_t); else ls_t = nn;
         uint32_t fe[EL2_FL], fv[EL2_FL];
 #pragma unroll
-        for (int i = 0; i < EL2_FL; i++) { fe[i] = 0xFFFFFFFFu; fv[i] = 0; const uint32_t w_ = tid + 256u * (uint32_t)i; if (w_ < W && !(abl & 8)) fe[i] = *item(w_, fv[i]); }
+        for (int i = 0; i < EL2_FL; i++) { fe[i] = 0xFFFFFFFFu; fv[i] = 0; ls_round(fe[i], fv[i]); }
+        if (DBG) { const long long t_ = clock64(); a_s3 += t_ - cs; cs = t_; }
         // the N list (most tiles hold no N: its first entry tells, and the phase is skipped)
         uint32_t pn[EL2_LP];
 #pragma unroll
@@ -1291,11 +1307,11 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             uint32_t gnext = 0xFFFFFFFFu, bnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) { gnext = cell_lookup(tid, q1, s1, false); bnext = cell_lookup(tid, q1, s1, true); }
             if (nextm) EMIT_META_STORE(s_next)
             if (tid < T) { s_g[pb ^ 1u][tid] = gnext; s_kb[pb ^ 1u][tid] = bnext; }
-            if (tid < 128) { EMIT2_PREFIX(pb ^ 1u, gnext, bnext) }
             if (tid == 0) s_nl0 = pn[0];                                    // the tile's first N position
         }
+        if (DBG) { const long long t_ = clock64(); a_s4 += t_ - cs; cs = t_; }
         __syncthreads();
-        if (DBG) { c1 = clock64(); a_stage += c1 - c0; c0 = c1; }
+        if (DBG) { c1 = clock64(); a_s5 += c1 - cs; a_stage += c1 - c0; c0 = c1; }
         uint8_t* const q_t = (uint8_t*)(s_src4 + EG_Q + 1) + (raw ? (uint32_t)(rqa & 15ull) : 0u);        // quality of chunk position q0 + i at q_t[i]
         uint8_t* const s_t = (uint8_t*)(s_src4 + EG_S + 1);                                              // stored base s0 + i at s_t[i]
         // ---- bases: 16 per thread, packed bytes -> G A T C (src/rfqcodec.cpp:833-853); beyond mSeqBuf the 'N' prefill of allSeq stays
@@ -1320,7 +1336,14 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
         if (!(abl & 4)) {
 #pragma unroll
             for (int i = 0; i < EL2_FL; i++) { const uint32_t p = fe[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
-            for (uint32_t w_ = tid + 256u * EL2_FL; w_ < W; w_ += 256u) { uint32_t v_; const uint32_t p = *item(w_, v_); if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)v_; }
+            // (files with tens of quality values: the rest of the wave's rounds, four requests in flight)
+            while (ls_t < nn) {
+                uint32_t e_[4], v_[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { e_[i] = 0xFFFFFFFFu; v_[i] = 0; ls_round(e_[i], v_[i]); }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const uint32_t p = e_[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
+            }
         }
         if (nrec) {
             // (every tile looks at all of the chunk's records: the host keeps images with many of them off this kernel)
@@ -1395,5 +1418,6 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
 #undef EMIT_META_LOAD
 #undef EMIT_META_STORE
     if (DBG && dbg && l == 0) { atomicAdd(&dbg[0], (unsigned long long)a_stage); atomicAdd(&dbg[1], (unsigned long long)a_unpack); atomicAdd(&dbg[2], (unsigned long long)a_tok); atomicAdd(&dbg[3], (unsigned long long)a_n);
-                                atomicAdd(&dbg[4], (unsigned long long)a_comp); atomicAdd(&dbg[5], (unsigned long long)a_flush); atomicAdd(&dbg[6], 1ull); atomicAdd(&dbg[7], (unsigned long long)a_steps); }
+                                atomicAdd(&dbg[4], (unsigned long long)a_comp); atomicAdd(&dbg[5], (unsigned long long)a_flush); atomicAdd(&dbg[6], 1ull); atomicAdd(&dbg[7], (unsigned long long)a_steps);
+                                atomicAdd(&dbg[8], (unsigned long long)a_s1); atomicAdd(&dbg[9], (unsigned long long)a_s2); atomicAdd(&dbg[10], (unsigned long long)a_s3); atomicAdd(&dbg[11], (unsigned long long)a_s4); atomicAdd(&dbg[12], (unsigned long long)a_s5); }
 }
