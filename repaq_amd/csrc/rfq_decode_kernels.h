@@ -869,6 +869,27 @@ template <int U> __device__ __forceinline__ void span_dma(const StageSpan& sp) {
         if (sp.ng > (uint32_t)U * blockDim.x) stage_span_slow(sp.g, sp.a0, sp.ng, sp.l, sp.lim, (uint32_t)U * blockDim.x);   // (never with the tile sizes above)
     } else stage_span_slow(sp.g, sp.a0, sp.ng, sp.l, sp.lim, 0u);
 }
+// The same by ONE wave (lane l of it): R rounds of 64 groups.  A tile's small spans are dealt out one per wave - a wave then runs the
+// address arithmetic and the issue of its own span only.
+template <int R> __device__ __forceinline__ void span_dma_wave(const StageSpan& sp, int l) {
+    const bool inside = sp.a0 + 16ull * sp.ng <= sp.lim;                     // wave-uniform
+    const uint8_t* const gp = sp.g + sp.a0;
+    uint32_t done = 0;
+    if (inside) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t i = (uint32_t)l + 64u * (uint32_t)r;
+            if (i < sp.ng) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + 16u * i),
+                                                            (__attribute__((address_space(3))) void*)(sp.l + 64u * (uint32_t)r), 16, 0, 0);
+        }
+        done = 64u * (uint32_t)R;
+    }
+    for (uint32_t i = (uint32_t)l + done; i < sp.ng; i += 64u) {              // (near the buffer's limit, or beyond R rounds: byte-wise)
+        const uint64_t ga = sp.a0 + 16ull * i; uint32_t w[4] = { 0, 0, 0, 0 };
+        for (uint32_t b = 0; b < 16 && ga + b < sp.lim; b++) w[b >> 2] |= (uint32_t)sp.g[ga + b] << (8 * (b & 3));
+        sp.l[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
 // the emit tile's six spans: two big ones (UB groups per thread) and four small ones (one group per thread)
 template <int UB> __device__ __forceinline__ void stage_spans6(const StageSpan (&sp)[6]) {
     span_dma<UB>(sp[0]); span_dma<UB>(sp[1]); span_dma<1>(sp[2]); span_dma<1>(sp[3]); span_dma<1>(sp[4]); span_dma<1>(sp[5]);
@@ -1222,6 +1243,12 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
           uint32_t g_ = 0xFFFFFFFFu, b_ = 0xFFFFFFFFu;
           if (tid < T) { const uint32_t qp_ = R.pq[f + cur] - pq0, sp_ = R.pv[f + cur].d - pv0.d; g_ = cell_lookup(tid, qp_, sp_, false); b_ = cell_lookup(tid, qp_, sp_, true); s_g[0][tid] = g_; s_kb[0][tid] = b_; }
       } }
+    if (cur < re) {                                                          // pieces every read of the chunk shares: staged once
+        const uint64_t ib = d.off;
+        if (fl & C_NAME1_SAME) span_dma<1>(make_span(s_src4 + EG_N1, img, ib + d.o_n1, ib + d.o_n1 + d.n1_size, img_bytes, true));
+        if (fl & C_NAME2_SAME) span_dma<1>(make_span(s_src4 + EG_N2, img, ib + d.o_n2, ib + d.o_n2 + d.n2_size, img_bytes, true));
+        if (fl & C_STRAND_SAME) span_dma<1>(make_span(s_src4 + EG_ST, img, ib + d.o_st, ib + d.o_st + d.st_size, img_bytes, true));
+    }
     __syncthreads();
     while (cur < re) {                                                       // block-uniform
         uint32_t* const s_meta = s_meta2[pb]; uint32_t* const s_next = s_meta2[pb ^ 1u];
@@ -1263,11 +1290,15 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
         // the LDS-DMA of the tile's sources goes out FIRST (it returns nothing into registers, so nothing the compiler does to the loads
         // below - it makes some of them wait for each other - can hold it back), then the prefill, then the register loads
         {
-            const StageSpan sp[6] = { make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, raw), make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true),
-                                      make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true),
-                                      make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), make_span(s_src4 + EG_N2, img, n2a, n2e, img_bytes, true), make_span(s_src4 + EG_ST, img, sta, ste, img_bytes, true) };
-            if (DBG) { cs = clock64(); a_s1 += cs - c0; }
-            stage_spans6<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(sp);
+            // (a name1 / name2 / strand piece shared by the whole chunk was staged once, in front of the loop); one span per wave
+            if (raw) span_dma<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, true));
+            if (w == 0) span_dma_wave<(int)((ET_SCAP / 64 + 4 + 63) / 64)>(make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true), l);
+            else if (w == 1) span_dma_wave<(int)((ET_READS * 40 / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
+            else if (w == 2) { if (!(fl & C_NAME1_SAME)) span_dma_wave<(int)((ET_N1CAP / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), l); }
+            else {
+                if (!(fl & C_NAME2_SAME)) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_N2, img, n2a, n2e, img_bytes, true), l);
+                if (!(fl & C_STRAND_SAME)) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_ST, img, sta, ste, img_bytes, true), l);
+            }
             if (DBG) { const long long t_ = clock64(); a_s2 += t_ - cs; cs = t_; }
             // qualities start as the major value (src/rfqcodec.cpp:1089): no source to wait for
             if (bycol && !(abl & 1)) { uint4* qt = s_src4 + EG_Q + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
