@@ -187,10 +187,12 @@ __device__ __forceinline__ int dev_atoi(const uint8_t* s, uint32_t n) {
 }
 struct Meta { uint32_t ok, name1_len, name2_off, x, y; uint16_t tile; uint8_t lane; };
 // FastqMeta::parse, src/fastqmeta.cpp:22-80
-__device__ __forceinline__ Meta dev_parse_name(const uint8_t* str, uint32_t len) {
+// scan / done: only the first `scan` bytes are looked at; *done says whether that settled the result (the loop met its stop, or scan covers the name)
+__device__ __forceinline__ Meta dev_parse_name(const uint8_t* str, uint32_t len, uint32_t scan = 0xFFFFFFFFu, bool* done = nullptr) {
     int colon = 0, last_colon = 0, cstart = 0, cend = 0;
     uint8_t lane = 0; uint16_t tile = 0; uint32_t x = 0, y = 0;
-    for (uint32_t i = 0; i < len; i++) {
+    const uint32_t lim = len < scan ? len : scan; bool stopped = false;
+    for (uint32_t i = 0; i < lim; i++) {
         const uint8_t c = str[i];
         if (c == ':') colon++;
         if ((c == ':' || c == ' ') && colon >= 4 && colon <= 7) {
@@ -202,8 +204,9 @@ __device__ __forceinline__ Meta dev_parse_name(const uint8_t* str, uint32_t len)
             if (c == ' ' && colon == 6) y = (uint32_t)val;
         }
         if (c == ':') last_colon = (int)i;
-        if (c == ' ' || (c == ':' && colon == 7)) { cend = (int)i; break; }
+        if (c == ' ' || (c == ':' && colon == 7)) { cend = (int)i; stopped = true; break; }
     }
+    if (done) *done = stopped || lim == len;
     Meta m;
     if (cstart > 0 && cend > 0) { m.ok = 1; m.lane = lane; m.tile = tile; m.x = x; m.y = y; m.name1_len = (uint32_t)(cstart - 1); m.name2_off = (uint32_t)cend; }
     else { m.ok = 0; m.lane = 0; m.tile = 0; m.x = 0; m.y = 0; m.name1_len = len; m.name2_off = len; }
@@ -249,7 +252,7 @@ __device__ __forceinline__ void stage_name_rows_wide(const Text& T, uint8_t* row
         const int j = it * 8 + (l >> 3);
         const uint32_t jb = __shfl(nb, j), jl = __shfl(nl, j); const int js = __shfl(s, j);
         const uint32_t a = (jb & ~15u) + 16u * part;                         // the group's offset in its stream
-        ok[it] = jl != 0 && jl <= RT_NAME_CAP && a < jb + jl;                // it holds bytes of the name
+        ok[it] = jl != 0 && a < jb + (jl < RT_NAME_CAP ? jl : RT_NAME_CAP);  // it holds bytes of the name (of its first RT_NAME_CAP bytes: a longer name is parsed and compared from that prefix, and from global memory only where the prefix does not settle it)
         da[it] = (uint32_t)j * RT_ROW + 16u + 16u * part - (jb & 15u);
         v[it] = make_uint4(0, 0, 0, 0);
         if (ok[it]) {
@@ -300,7 +303,9 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
     if (valid) {
         if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
         if (ql < sl) err |= DE_QUAL_SHORT;
-        m = nl <= RT_NAME_CAP ? dev_parse_name(rows + l * RT_ROW, nl) : dev_parse_name(t_fq(T, s) + nb, nl);
+        bool settled = true;
+        m = dev_parse_name(rows + l * RT_ROW, nl, RT_NAME_CAP, &settled);
+        if (!settled) m = dev_parse_name(t_fq(T, s) + nb, nl);
         R.len[g] = sl; R.stored[g] = sl;
         R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
     }
@@ -323,14 +328,21 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
             }
             if ((uint32_t)m.lane == plane) b |= 1u << 5;
             if ((uint32_t)m.tile == ptile) b |= 1u << 6;
-            const bool inl = nl <= RT_NAME_CAP && pnl <= RT_NAME_CAP;        // both names staged in LDS (else compare in global memory)
+            // n bytes at offset oa / ob of two names: what both rows hold is compared in LDS, the rest (names longer than RT_NAME_CAP) in global memory
             const uint32_t ra = (uint32_t)l * RT_ROW, rb = (uint32_t)(l - 1) * RT_ROW;
             const uint8_t* ga = t_fq(T, s) + nb; const uint8_t* gb = t_fq(T, ps) + pnb;
-            if (n1 == pn1 && (inl ? lds_bytes_eq(rows, ra, rb, n1) : bytes_eq(ga, n1, gb, pn1))) b |= 1u << 7;
-            if (n2 == pn2 && (inl ? lds_bytes_eq(rows, ra + n2o, rb + pn2o, n2) : bytes_eq(ga + n2o, n2, gb + pn2o, pn2))) b |= 1u << 8;
+            auto names_eq = [&](uint32_t rowa, uint32_t oa, uint32_t la, const uint8_t* pa, uint32_t rowb, uint32_t ob, uint32_t lb_, const uint8_t* pb_, uint32_t n) -> bool {
+                const uint32_t sa = la < RT_NAME_CAP ? la : RT_NAME_CAP, sb = lb_ < RT_NAME_CAP ? lb_ : RT_NAME_CAP;
+                const uint32_t va = sa > oa ? sa - oa : 0u, vb = sb > ob ? sb - ob : 0u; uint32_t k = va < vb ? va : vb; if (k > n) k = n;
+                if (k && !lds_bytes_eq(rows, rowa + oa, rowb + ob, k)) return false;
+                return k == n || bytes_eq(pa + oa + k, n - k, pb_ + ob + k, n - k);
+            };
+            const bool inl = nl <= RT_NAME_CAP && pnl <= RT_NAME_CAP;        // both names wholly staged in LDS
+            if (n1 == pn1 && names_eq(ra, 0u, nl, ga, rb, 0u, pnl, gb, n1)) b |= 1u << 7;
+            if (n2 == pn2 && names_eq(ra, n2o, nl, ga, rb, pn2o, pnl, gb, n2)) b |= 1u << 8;
             if (l > 1 && pinfo) {                                              // PE: the previous pair's mate of the same side
-                const uint32_t qn2 = qnl - qn2o; const bool inl2 = nl <= RT_NAME_CAP && qnl <= RT_NAME_CAP;
-                if (n2 == qn2 && (inl2 ? lds_bytes_eq(rows, ra + n2o, (uint32_t)(l - 2) * RT_ROW + qn2o, n2) : bytes_eq(ga + n2o, n2, t_fq(T, qs) + qnb + qn2o, qn2))) b |= 1u << 9;
+                const uint32_t qn2 = qnl - qn2o;
+                if (n2 == qn2 && names_eq(ra, n2o, nl, ga, (uint32_t)(l - 2) * RT_ROW, qn2o, qnl, t_fq(T, qs) + qnb, n2)) b |= 1u << 9;
             }
             adj[g] = (uint16_t)b;
             if (pinfo && (g & 1u)) {                                           // (g-1, g) is a pair: a = R1's name2, b = R2's name2
@@ -338,7 +350,7 @@ __global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __re
                 if (n2 == pn2) {
                     info |= 1u;
                     for (uint32_t i = 0; i < n2 && nd < 2; i++) {
-                        const uint8_t ca = inl ? rows[rb + pn2o + i] : gb[pn2o + i], cb = inl ? rows[ra + n2o + i] : ga[n2o + i];
+                        const uint8_t ca = (inl || pn2o + i < RT_NAME_CAP) ? rows[rb + pn2o + i] : gb[pn2o + i], cb = (inl || n2o + i < RT_NAME_CAP) ? rows[ra + n2o + i] : ga[n2o + i];
                         if (ca != cb) { if (nd == 0) { pd = i; bch = cb; } nd++; }
                     }
                 }
@@ -1752,7 +1764,15 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
         }
     }
 }
-// names / strands that differ inside the chunk: one wave per read copies its pieces to their prefix-sum offsets
+// names / strands that differ inside the chunk: EIGHT lanes per read (a wave takes eight consecutive reads) copy its pieces to their prefix-sum
+// offsets in 16-byte groups, byte-granular on both sides (consecutive reads' pieces are neighbours in the image, so a wave's stores still cover
+// one contiguous span); the last group of a piece is moved back to end exactly at its end, pieces < 16 bytes go byte by byte
+struct __attribute__((packed, aligned(1))) GU16 { uint32_t a, b, c, d; };
+__device__ __forceinline__ void copy_piece8(uint8_t* __restrict__ d, const uint8_t* __restrict__ src, uint32_t n, uint32_t part) {
+    if (n < 16u) { for (uint32_t i = part; i < n; i += 8u) d[i] = src[i]; return; }
+    const uint32_t ng = (n + 15u) >> 4;
+    for (uint32_t g = part; g < ng; g += 8u) { uint32_t p0 = 16u * g; if (p0 + 16u > n) p0 = n - 16u; *(GU16*)(d + p0) = *(const GU16*)(src + p0); }
+}
 __global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L, uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base) {
     const uint32_t c = blockIdx.y; const uint32_t fl = C.flags[c];
     const bool need1 = !(fl & C_NAME1_SAME), need2 = (D->flags & H_NAME2) && !(fl & C_NAME2_SAME), need3 = !(fl & C_STRAND_SAME);
@@ -1761,12 +1781,13 @@ __global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader*
     if (at + o.total > img_cap) return;
     uint8_t* out = img + at;
     const uint32_t f = C.first[c], e = f + o.n_reads; const uint32_t wpb = blockDim.x >> 6; const int l = lane_id();
-    const U4 a = R.pv[f];
-    for (uint32_t g = f + blockIdx.x * wpb + (uint32_t)wave_id(); g < e; g += gridDim.x * wpb) {
+    const U4 a = R.pv[f]; const uint32_t part = (uint32_t)l & 7u, sub = (uint32_t)l >> 3;
+    for (uint32_t g0 = f + 8u * (blockIdx.x * wpb + (uint32_t)wave_id()); g0 < e; g0 += 8u * gridDim.x * wpb) {
+        const uint32_t g = g0 + sub; if (g >= e) continue;
         const U4 p = R.pv[g]; const uint8_t* nm = line_ptr(T, g, 0);
-        if (need1) { const uint32_t n = R.name1_len[g]; uint8_t* d = out + o.off_n1 + (p.a - a.a); for (uint32_t i = (uint32_t)l; i < n; i += 64) d[i] = nm[i]; }
-        if (need2) { const uint32_t n = name2_len_of(T, R, g); const uint8_t* src = nm + R.name2_off[g]; uint8_t* d = out + o.off_n2 + (p.b - a.b); for (uint32_t i = (uint32_t)l; i < n; i += 64) d[i] = src[i]; }
-        if (need3) { const uint32_t n = line_len(T, g, 2); const uint8_t* src = line_ptr(T, g, 2); uint8_t* d = out + o.off_st + (p.c - a.c); for (uint32_t i = (uint32_t)l; i < n; i += 64) d[i] = src[i]; }
+        if (need1) copy_piece8(out + o.off_n1 + (p.a - a.a), nm, R.name1_len[g], part);
+        if (need2) copy_piece8(out + o.off_n2 + (p.b - a.b), nm + R.name2_off[g], name2_len_of(T, R, g), part);
+        if (need3) copy_piece8(out + o.off_st + (p.c - a.c), line_ptr(T, g, 2), line_len(T, g, 2), part);
     }
 }
 __global__ void k_enc_totals(ChunkTab C, const uint64_t* __restrict__ ctotal_prefix, uint32_t n_chunks, int which, DevStatus* st) {
