@@ -485,7 +485,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
                            a->file_off1, a->file_off2, a->nolb_from1, a->nolb_from2,
                            (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, dst);
         // (a wave per eight reads, three dependent loads each: as many waves as there are groups of eight, not a serial walk per wave)
-        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 31) / 32, std::max(1u, (1u << 20) / n_chunks)));
+        // (most files share their names' fixed parts: the workgroups of such chunks leave at once, so the grid stays small - a workgroup loops over its share)
+        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 31) / 32, std::max(1u, 16384u / n_chunks)));
         hipLaunchKernelGGL(k_assemble_names, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L, img, img_cap, hdr_bytes);
         KCHK(ctx, "k_assemble");
     }

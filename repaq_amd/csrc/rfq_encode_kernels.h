@@ -1044,14 +1044,20 @@ struct NCount {                          // p = chunk-relative position of the b
         if (mk) { const uint32_t k = (uint32_t)__popc(mk); n += k; nmap_mark(nmap, shift, p); atomicAdd(&segm[p / PC_SEG_POS], k); atomicMax(&segc[p / PC_SEG_POS], (int)(p + 31u - (uint32_t)__clz((int)mk))); }
     }
 };
-// the tile's counters (summed over the replicas) -> the coder's per-(stream, segment) tables; the counters are left zeroed
+// the tile's counters (summed over the replicas) -> the coder's per-(stream, segment) tables; the counters are left zeroed.  One thread per
+// (counter, replica) - nrep * 2 * nslot <= 256 of them, a counter's replicas in neighbouring lanes - and a butterfly over the replicas: the
+// serial walk over 16 replicas by eight threads was a chain of 32 dependent LDS round trips at the end of every tile
 __device__ __forceinline__ void qual_flush(uint32_t* cnt, int* last, uint32_t nrep, uint32_t nslot, uint32_t seg0, uint32_t c, uint32_t nn, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
-    for (uint32_t i = threadIdx.x; i < 2u * nslot; i += blockDim.x) {
+    const uint32_t nitem = 2u * nslot;
+    for (uint32_t t = threadIdx.x; (t & ~63u) < nrep * nitem; t += blockDim.x) {   // (wave-uniform bound: a wave none of whose lanes has a counter is done)
+        const uint32_t r = t & (nrep - 1u), i = t / nrep;                 // nrep is a power of two <= 16
         uint32_t n = 0; int lp = -1;
-        for (uint32_t r = 0; r < nrep; r++) { const uint32_t k = r * 2u * nslot + i; n += cnt[k]; if (last[k] > lp) lp = last[k]; cnt[k] = 0; last[k] = -1; }
-        if (!n) continue;
-        const uint32_t sl = i % nslot, seg = seg0 + i / nslot, j = sl < nn ? sl : (uint32_t)EXC_SLOT;
-        if (seg < n_seg) { const size_t si = ((size_t)c * MAX_STREAMS + j) * n_seg + seg; atomicAdd(&segm[si], n); if (j != EXC_SLOT) atomicMax(&segc[si], lp); }
+        if (i < nitem) { const uint32_t k = r * nitem + i; n = cnt[k]; lp = last[k]; cnt[k] = 0; last[k] = -1; }
+        for (uint32_t d = 1; d < nrep; d <<= 1) { n += (uint32_t)__shfl_xor((int)n, (int)d); const int o = __shfl_xor(lp, (int)d); if (o > lp) lp = o; }
+        if (r == 0 && i < nitem && n) {
+            const uint32_t sl = i % nslot, seg = seg0 + i / nslot, j = sl < nn ? sl : (uint32_t)EXC_SLOT;
+            if (seg < n_seg) { const size_t si = ((size_t)c * MAX_STREAMS + j) * n_seg + seg; atomicAdd(&segm[si], n); if (j != EXC_SLOT) atomicMax(&segc[si], lp); }
+        }
     }
 }
 
