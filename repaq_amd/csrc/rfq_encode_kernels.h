@@ -1153,14 +1153,12 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
           } } }
     while (cur < ge) {                                                   // block-uniform
         if (DBG) tk0 = clock64();
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
         if (!have) GATHER_META_LOAD(cur)
         a0[0] = na0[0]; a0[1] = na0[1]; fits = nfits; m_st = nm_st; m_p1 = nm_p1; m_p3 = nm_p3; m_nx = nm_nx; m_len = nm_len; m_qdst = nm_qdst; m_sdst = nm_sdst; m_ov = nm_ov; m_rc = nm_rc; have = false;
         if (tid < GT_READS) s_nx[tid] = m_nx;
-        {   // one LDS atomic per wave
+        if (tid < 64) {   // the candidates are the first GT_READS threads: wave 0 counts them (no barrier is needed in front: every wave read the previous tile's count four barriers ago)
             const unsigned long long fb = __ballot(fits);
-            if (lane_id() == 0 && fb) atomicAdd(&s_cnt, (uint32_t)__popcll(fb));
+            if (tid == 0) s_cnt = (uint32_t)__popcll(fb);
         }
         __syncthreads();
         const uint32_t cnt = s_cnt;
