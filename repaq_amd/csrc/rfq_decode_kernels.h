@@ -1278,6 +1278,12 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
         const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + EM_ROW * cnt;
         U4 tp0, tp1; tp0.a = uni32(mb[12]); tp0.b = uni32(mb[13]); tp1.a = uni32(me[12]); tp1.b = uni32(me[13]);
         const uint32_t q0 = uni32(mb[15]), s0 = uni32(mb[14]), q1 = uni32(me[15]), s1 = uni32(me[14]);
+        // the NEXT tile's metadata and cells are asked for first: wave 0 needs them back before it can reach the barrier, and everything
+        // below (spans, LDS-DMA, list requests) is issue work that fits inside that latency
+        const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
+        EMIT_META_VARS
+        if (nextm) EMIT_META_LOAD(cur + cnt)
+        uint32_t gnext = 0xFFFFFFFFu, bnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) { gnext = cell_lookup(tid, q1, s1, false); bnext = cell_lookup(tid, q1, s1, true); }
         // ---- stage: packed bases, name pieces, middles (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
         const uint64_t ib = d.off;
         const uint32_t a7 = (fl & C_NAME1_SAME) ? 0u : uni32(mb[7]), a8 = (fl & C_NAME2_SAME) ? 0u : uni32(mb[8]), a9 = (fl & C_STRAND_SAME) ? 0u : uni32(mb[9]);
@@ -1331,15 +1337,10 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
 #pragma unroll
             for (int i = 0; i < EL2_LP; i++) { const uint32_t kk = k0 + tid + 256u * (uint32_t)i; if (k0 != 0xFFFFFFFFu && kk < ke) pn[i] = lp[kk]; }
         }
-        {
-            const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
-            EMIT_META_VARS
-            if (nextm) EMIT_META_LOAD(cur + cnt)
-            uint32_t gnext = 0xFFFFFFFFu, bnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) { gnext = cell_lookup(tid, q1, s1, false); bnext = cell_lookup(tid, q1, s1, true); }
-            if (nextm) EMIT_META_STORE(s_next)
-            if (tid < T) { s_g[pb ^ 1u][tid] = gnext; s_kb[pb ^ 1u][tid] = bnext; }
-            if (tid == 0) s_nl0 = pn[0];                                    // the tile's first N position
-        }
+        // what came back for the next tile -> LDS (requested at the top of this phase)
+        if (nextm) EMIT_META_STORE(s_next)
+        if (tid < T) { s_g[pb ^ 1u][tid] = gnext; s_kb[pb ^ 1u][tid] = bnext; }
+        if (tid == 0) s_nl0 = pn[0];                                        // the tile's first N position
         if (DBG) { const long long t_ = clock64(); a_s4 += t_ - cs; cs = t_; }
         __syncthreads();
         if (DBG) { c1 = clock64(); a_s5 += c1 - cs; a_stage += c1 - c0; c0 = c1; }
