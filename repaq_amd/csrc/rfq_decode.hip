@@ -188,7 +188,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             hipLaunchKernelGGL(k_dec_emit2<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, dbg, 0);
             unsigned long long h[16]; (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
             if (h[6]) fprintf(stderr, "[emit2 dbg] waves=%llu avg cycles/wave: stage=%llu (fit+spans %llu, dma issue %llu, list requests %llu, next tile's metadata + cells %llu, barrier %llu) unpack=%llu tokens=%llu nstream=%llu compose=%llu flush=%llu\n", h[6], h[0]/h[6], h[8]/h[6], h[9]/h[6], h[10]/h[6], h[11]/h[6], h[12]/h[6], h[1]/h[6], h[2]/h[6], h[3]/h[6], h[4]/h[6], h[5]/h[6]);
-        } else if (fused) hipLaunchKernelGGL(k_dec_emit2<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, (unsigned long long*)nullptr, (tune >> 12) & 15);   // (tune bits 12-15: ablation switches, text invalid)
+        } else if (fused) hipLaunchKernelGGL(k_dec_emit2<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, (unsigned long long*)nullptr, (tune >> 12) & 255);   // (tune bits 12-19: ablation switches, text invalid)
 #undef RFQ_EMIT2_ARGS
         else
         if (tune & 7) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);

@@ -1298,7 +1298,7 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
         {
             // (a name1 / name2 / strand piece shared by the whole chunk was staged once, in front of the loop); one span per wave
             if (raw) span_dma<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, true));
-            if (w == 0) span_dma_wave<(int)((ET_SCAP / 64 + 4 + 63) / 64)>(make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true), l);
+            if (abl & 64) {} else if (w == 0) span_dma_wave<(int)((ET_SCAP / 64 + 4 + 63) / 64)>(make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true), l);
             else if (w == 1) span_dma_wave<(int)((ET_READS * 40 / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
             else if (w == 2) { if (!(fl & C_NAME1_SAME)) span_dma_wave<(int)((ET_N1CAP / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), l); }
             else {
@@ -1403,7 +1403,7 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
             const uint32_t n1off = (uint32_t)(n1a & 15ull), n2off = (uint32_t)(n2a & 15ull), stoff = (uint32_t)(sta & 15ull);
             const uint32_t recA = (tp0.a & 15u) - tp0.a, recB = ET_OCAP / 2 + (tp0.b & 15u) - tp0.b;
             const uint8_t* const pool = (const uint8_t*)s_src4;
-            for (uint32_t slot = tid; slot < 8u * ET_READS; slot += blockDim.x) {
+            for (uint32_t slot = tid; slot < ((abl & 16) ? 0u : 8u * ET_READS); slot += blockDim.x) {
                 const uint32_t j = slot % ET_READS, kind = slot / ET_READS;
                 if (j >= cnt) continue;
                 const uint32_t* m = s_meta + EM_ROW * j; const bool odd = ((cur + j) & 1u) != 0, to2 = split && odd, rc = il && odd;
@@ -1441,8 +1441,8 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
         }
         __syncthreads();
         if (DBG) { c1 = clock64(); a_comp += c1 - c0; c0 = c1; }
-        if (tp1.a <= cap1) flush_span(s_out4, out1, tp0.a, tp1.a);
-        if (split && tp1.b <= cap2) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
+        if (tp1.a <= cap1 && !(abl & 32)) flush_span(s_out4, out1, tp0.a, tp1.a);
+        if (split && tp1.b <= cap2 && !(abl & 32)) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
         if (DBG) { c1 = clock64(); a_flush += c1 - c0; }
         cur += cnt; pb ^= 1u;
     }

@@ -1653,7 +1653,8 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
                            const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat, const uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
                            const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
                            uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2,
-                           const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, DevStatus* st) {
+                           const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, DevStatus* st,
+                           uint32_t tail_bases, uint32_t tail_units, uint32_t tail_extra, uint64_t tail_n1, uint64_t tail_n2) {
     const uint32_t c = blockIdx.y; const Layout o = L[c];
     const uint64_t at = img_base + C.img_off[c];
     if (at + o.total > img_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&st->err, 1u << 31); return; }
@@ -1664,16 +1665,29 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
     const size_t k0 = (size_t)c * MAX_STREAMS;
     if (t == 0) {
         // line-break bits: set once the reference's reader has loaded the final (short) 1 MiB block (Q10)
+        // A chunk is written right after its last record was read, so what counts is where that record ends.  The TAIL chunk of the input -
+        // fewer than chunk_bases bases, written by the final flush (src/repaq.cpp:590-624, 715-761) - is written only after the reader(s) went
+        // on and failed: a stream that had no further complete record has been read to its very end by then (a truncated last record
+        // included), a stream of a pair that had one more has been read through that record (FastqReaderPair::read asks both files,
+        // src/fastqreader.cpp:287-299).  tail_bases = chunk_bases when this call ends the input that way, else 0.
         uint32_t flags = fl;
         const uint32_t last = f + s - 1;
+        const bool tail = tail_bases && c + 1 == gridDim.y && R.pq[f + s] - R.pq[f] < tail_bases;
+        auto line_end = [&](int st_, size_t q) -> uint64_t { return T.ot[st_] ? (uint64_t)T.ot[st_][q] : (uint64_t)T.lo[st_][q + 1] - 1; };
         if (T.paired == 1) {
             const size_t q = 4 * (size_t)(last >> 1) + 3;                  // the pair's quality lines
-            const uint64_t e1 = off1 + (T.ot[0] ? (uint64_t)T.ot[0][q] : (uint64_t)T.lo[0][q + 1] - 1), e2 = off2 + (T.ot[1] ? (uint64_t)T.ot[1][q] : (uint64_t)T.lo[1][q + 1] - 1);
+            uint64_t e1 = off1 + line_end(0, q), e2 = off2 + line_end(1, q);
+            if (tail) {
+                const size_t qx = 4 * (size_t)tail_units + 3;              // the record after the last pair, where a file has one
+                e1 = (tail_extra & 1u) ? off1 + line_end(0, qx) : off1 + tail_n1;
+                e2 = (tail_extra & 2u) ? off2 + line_end(1, qx) : off2 + tail_n2;
+            }
             if (e1 >= nolb1) flags |= C_NO_LB;
             if (e2 >= nolb2) flags |= C_NO_LB_R2;
         } else {
             const size_t q = 4 * (size_t)last + 3;
-            const uint64_t e1 = off1 + (T.ot[0] ? (uint64_t)T.ot[0][q] : (uint64_t)T.lo[0][q + 1] - 1);
+            uint64_t e1 = off1 + line_end(0, q);
+            if (tail) e1 = off1 + tail_n1;
             if (e1 >= nolb1) { flags |= C_NO_LB; if (T.paired == 2) flags |= C_NO_LB_R2; }
         }
         st_u32(out, o.msize); st_u32(out + 4, s); st_u16(out + 8, flags); st_u32(out + 10, o.seq_size); st_u32(out + 14, o.qual_size);

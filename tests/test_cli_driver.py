@@ -190,6 +190,50 @@ def _compare_suite(binary, tmp_path, batch_mb):
             assert json.loads(ref.stdout) == j, (name, ref.stdout, r.stdout)
 
 
+
+def _io_pipeline_suite(binary, tmp_path, reads):
+    """The driver's parallel I/O: a regular file read by several pread threads in 1 MiB staging blocks (block i handed out before i + 1),
+    device batches of several blocks with carry-over, the output written by several pwrite threads at each piece's offset, an output
+    path that already holds a longer file (truncated), an exact-multiple-of-the-block file size, and a sequential source (stdin) beside it."""
+    fq1, _ = O.gen(O.NOVA_SE150, reads, seed=43)
+    want = O.encode_file(fq1, b"", O.SE, 100_000)
+    p = tmp_path / "io.fq"; p.write_bytes(fq1)
+    out = tmp_path / "io.rfq"; out.write_bytes(b"x" * (len(want) + 12345))          # stale, longer content
+    for extra in (["--batch_mb", "2", "--block_mb", "1", "--io_threads", "8", "--write_threads", "3"],
+                  ["--batch_mb", "1", "--block_mb", "1", "--io_threads", "2"], ["--batch_mb", "64", "--io_threads", "5"]):
+        r = _run(binary, ["-c", "-i", str(p), "-o", str(out), "-k", "100"] + extra)
+        assert r.returncode == 0, r.stderr
+        assert out.read_bytes() == want, extra
+    back = tmp_path / "io_back.fq"; back.write_bytes(b"y" * (len(fq1) + 777))
+    r = _run(binary, ["-d", "-i", str(out), "-o", str(back), "--batch_mb", "8", "--block_mb", "1", "--io_threads", "4", "--write_threads", "4"])
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == fq1
+    # a file whose size is an exact multiple of the staging block (the last block is full; no line break at the end: src/fastqreader.cpp:31-46)
+    n = (len(fq1) >> 20) << 20
+    cut = fq1[:n]
+    if cut and cut[-1:] != b"\n":
+        pm = tmp_path / "mib.fq"; pm.write_bytes(cut)
+        r = _run(binary, ["-c", "-i", str(pm), "-o", str(out), "-k", "100", "--batch_mb", "2", "--block_mb", "1", "--io_threads", "8"])
+        assert r.returncode == 0, r.stderr
+        assert out.read_bytes() == O.encode_file(cut, b"", O.SE, 100_000)
+    r = _run(binary, ["-c", "--stdin", "-o", str(out), "-k", "100", "--batch_mb", "2", "--block_mb", "1"], input=fq1)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == want
+    r = _run(binary, ["-p", "-i", str(p), "-r", str(out), "--batch_mb", "2", "--block_mb", "1", "--io_threads", "8"])
+    assert r.returncode == 0 and json.loads(r.stdout)["result"] == "passed", r.stdout
+
+
+def test_cli_io_pipeline_on_simt_emulation(tmp_path):
+    E.build_emu()
+    assert os.path.exists(EMU_BIN)
+    _io_pipeline_suite(EMU_BIN, tmp_path, reads=9000)
+
+
+@pytest.mark.gpu
+def test_cli_io_pipeline_on_gpu(tmp_path):
+    assert os.path.exists(GPU_BIN), "repaq_hip is built by __graft_entry__.build()"
+    _io_pipeline_suite(GPU_BIN, tmp_path, reads=120000)
+
 def test_cli_on_simt_emulation(tmp_path):
     E.build_emu()
     subprocess.check_call(["make", "-s", "-C", E.EMU_DIR, "all"])
