@@ -131,12 +131,15 @@ class RfqCodec:
 
 
 def nolb_threshold(file_size: int, ends_with_newline: bool) -> int:
-    """Offset from which chunks carry BIT_HAS_NO_LINE_BREAK_AT_END: the start of the reference reader's final 1 MiB block
-    when the file lacks a trailing newline (src/fastqreader.cpp:31-46), else 'never'."""
-    if ends_with_newline or file_size == 0:
+    """Offset from which the reference's reader has its "no line break at the end" flag up (src/fastqreader.cpp:31-46):
+    the start of its final, short 1 MiB block when the file lacks a trailing newline.  A file of exactly k MiB has no short block: the
+    flag goes up at the empty read behind the last full block - whatever the last byte is (the test reads the byte in front of the
+    buffer there: never a line break in practice) - so the threshold is the file size itself: it is met by an unterminated last record
+    and by the readers' last, failed attempt, i.e. by the input's tail chunk."""
+    if file_size == 0:
         return U64_MAX
     if file_size % (1 << 20) == 0:
-        # every block was a full one: the flag is raised by the empty read that follows the unterminated last line, i.e. while the last
-        # record is being assembled - only the chunk that holds it carries the bit (the virtual terminator sits at offset file_size)
         return file_size
+    if ends_with_newline:
+        return U64_MAX
     return ((file_size - 1) >> 20) << 20

@@ -33,10 +33,14 @@
 static void error_exit(const std::string& msg) { fprintf(stderr, "ERROR: %s\n", msg.c_str()); exit(-1); }   // src/util.h:246-249
 static bool ends_with(const std::string& s, const std::string& e) { return s.size() >= e.size() && s.compare(s.size() - e.size(), e.size(), e) == 0; }
 
-// Offset from which chunks carry BIT_HAS_NO_LINE_BREAK_AT_END for a file of t bytes that lacks a final line break: the start of the reader's final (short)
-// 1 MiB block (src/fastqreader.cpp:31-46).  A size that is an exact multiple of 1 MiB has no short block: the flag is raised by the empty read that
-// follows the unterminated last line, so only the chunk holding the last record carries the bit (its virtual terminator sits at offset t).
-static inline uint64_t nolb_threshold(uint64_t t) { return (t & ((1ull << 20) - 1)) ? ((t - 1) >> 20) << 20 : t; }
+// Offset from which the reference's reader has its "no line break at the end" flag up, for a file of t > 0 bytes ending in `last` (src/fastqreader.cpp:31-46):
+// the start of its final (short) 1 MiB block when the file lacks a final line break.  A size that is an exact multiple of 1 MiB has no short block: the flag
+// goes up at the empty read behind the last full block whatever the last byte is (the test reads the byte in front of the buffer there), so the threshold is
+// t itself - met by an unterminated last record and by the readers' last, failed attempt (the input's tail chunk).
+static inline uint64_t nolb_threshold(uint64_t t, int last) {
+    if ((t & ((1ull << 20) - 1)) == 0) return t;
+    return last != '\n' ? ((t - 1) >> 20) << 20 : UINT64_MAX;
+}
 struct Options {
     std::string in1, out1, in2, out2, rfqCompare, json;
     long chunkKb = 1000; bool compress = false, decompress = false, compare = false, useStdin = false, useStdout = false, interleaved = false;
@@ -381,7 +385,7 @@ static void do_compress(const Options& o) {
         // the end of the input; until then at least two full blocks (>= 2 MiB) follow this batch, so no chunk of it can reach the
         // reader's final 1 MiB block
         uint64_t th[2] = { UINT64_MAX, UINT64_MAX };
-        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t && in[s]->final_byte() != '\n') th[s] = nolb_threshold(t); }
+        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t) th[s] = nolb_threshold(t, in[s]->final_byte()); }
         a.nolb_from1 = th[0]; a.nolb_from2 = two ? th[1] : th[0];
         rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
         if (ver && r.n_chunks && ver->wanted())
@@ -473,7 +477,7 @@ static void do_compress_multi(const Options& o) {
         a.chunk_bases = chunk_bases; a.final = final ? 1 : 0; a.file_off1 = ds[0].file_off; a.file_off2 = ds[1].file_off;
         rfq_scan_result sr; gs.check(rfq_scan_batch(gs.c, &a, &sr));
         uint64_t th[2] = { UINT64_MAX, UINT64_MAX };
-        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t && in[s]->final_byte() != '\n') th[s] = nolb_threshold(t); }
+        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t) th[s] = nolb_threshold(t, in[s]->final_byte()); }
         const bool last_batch = final || sr.input_ended;
         if (sr.n_chunks == 0 && !last_batch) { want = std::max(ds[0].have, ds[1].have) + batch; continue; }
         // deal the chunks out in contiguous ranges, one per device (fewer when the batch holds fewer chunks)

@@ -478,17 +478,16 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.end(S);
     ctx->timer.begin("assemble", S);
     {
-        // the line-break bit of the input's tail chunk looks at how far the readers got before they gave up (see k_assemble): only when this
-        // call ends the input at its end - not at an empty line, not at a worker's chunk boundary
-        const uint32_t tail_bases = (a->final && !ended && !a->flush_all) ? a->chunk_bases : 0u;
-        const uint32_t tail_extra = (a->paired == RFQ_PE_TWO_FILES) ? ((nrec[0] > units_used ? 1u : 0u) | (nrec[1] > units_used ? 2u : 0u)) : 0u;
+        // the line-break bit of the input's tail chunk looks at how far the readers got on their last, failed attempt (see k_assemble): when this
+        // call ends the input - at its end or at an empty line - and not at a worker's chunk boundary
+        const uint32_t tail_bases = ((a->final && !a->flush_all) || ended) ? a->chunk_bases : 0u;
         const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
         hipLaunchKernelGGL(k_assemble, dim3(bpc, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L,
                            (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(),
                            (const uint8_t*)B[B_XS].as<uint8_t>(), (const uint8_t*)B[B_YS].as<uint8_t>(), (const int8_t*)ovb, img, img_cap, hdr_bytes,
                            a->file_off1, a->file_off2, a->nolb_from1, a->nolb_from2,
                            (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, dst,
-                           tail_bases, units_used, tail_extra, (uint64_t)(nm ? nm->orig_n[0] : nbytes[0]), (uint64_t)(nm ? nm->orig_n[1] : nbytes[1]));
+                           tail_bases, units_used, nlines[0], nlines[1], (uint64_t)(nm ? nm->orig_n[0] : nbytes[0]), (uint64_t)(nm ? nm->orig_n[1] : nbytes[1]));
         // (a wave per eight reads, three dependent loads each: as many waves as there are groups of eight, not a serial walk per wave)
         // (most files share their names' fixed parts: the workgroups of such chunks leave at once, so the grid stays small - a workgroup loops over its share)
         const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + 31) / 32, std::max(1u, 16384u / n_chunks)));

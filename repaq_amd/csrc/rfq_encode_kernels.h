@@ -1654,7 +1654,7 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
                            const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
                            uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2,
                            const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, DevStatus* st,
-                           uint32_t tail_bases, uint32_t tail_units, uint32_t tail_extra, uint64_t tail_n1, uint64_t tail_n2) {
+                           uint32_t tail_bases, uint32_t tail_units, uint32_t tail_nl1, uint32_t tail_nl2, uint64_t tail_n1, uint64_t tail_n2) {
     const uint32_t c = blockIdx.y; const Layout o = L[c];
     const uint64_t at = img_base + C.img_off[c];
     if (at + o.total > img_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&st->err, 1u << 31); return; }
@@ -1667,27 +1667,35 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
         // line-break bits: set once the reference's reader has loaded the final (short) 1 MiB block (Q10)
         // A chunk is written right after its last record was read, so what counts is where that record ends.  The TAIL chunk of the input -
         // fewer than chunk_bases bases, written by the final flush (src/repaq.cpp:590-624, 715-761) - is written only after the reader(s) went
-        // on and failed: a stream that had no further complete record has been read to its very end by then (a truncated last record
-        // included), a stream of a pair that had one more has been read through that record (FastqReaderPair::read asks both files,
-        // src/fastqreader.cpp:287-299).  tail_bases = chunk_bases when this call ends the input that way, else 0.
+        // on and FAILED: what counts there is how far that last attempt got.  FastqReader::read (src/fastqreader.cpp:166-196) takes three lines,
+        // gives up if one of them is empty, else takes the fourth; it reads to the end of the file when the lines run out (a truncated last
+        // record included).  FastqReaderPair::read (:287-299) asks both files - or the one file twice - before it looks at either answer.
+        // tail_bases = chunk_bases when this call ends the input (its end, or an empty line), else 0; tail_units = units encoded.
         uint32_t flags = fl;
         const uint32_t last = f + s - 1;
         const bool tail = tail_bases && c + 1 == gridDim.y && R.pq[f + s] - R.pq[f] < tail_bases;
         auto line_end = [&](int st_, size_t q) -> uint64_t { return T.ot[st_] ? (uint64_t)T.ot[st_][q] : (uint64_t)T.lo[st_][q + 1] - 1; };
+        auto attempt = [&](int st_, uint32_t l0, uint32_t nl, uint64_t n_, uint32_t& next) -> uint64_t {   // one read() from line l0 on: where it stops (relative to the stream)
+            if (l0 + 2u >= nl) { next = nl; return n_; }                                       // fewer than three lines left: read to the end
+            const uint32_t* lo_ = T.lo[st_]; bool e3 = false;
+            for (uint32_t k = 0; k < 3; k++) if (lo_[l0 + k + 1] - 1u - lo_[l0 + k] == 0u) e3 = true;
+            if (!e3 && l0 + 3u >= nl) { next = nl; return n_; }                                // the quality line is asked for at the end of the file
+            const uint32_t lastl = e3 ? l0 + 2u : l0 + 3u; next = lastl + 1u;
+            return line_end(st_, lastl);
+        };
         if (T.paired == 1) {
             const size_t q = 4 * (size_t)(last >> 1) + 3;                  // the pair's quality lines
             uint64_t e1 = off1 + line_end(0, q), e2 = off2 + line_end(1, q);
-            if (tail) {
-                const size_t qx = 4 * (size_t)tail_units + 3;              // the record after the last pair, where a file has one
-                e1 = (tail_extra & 1u) ? off1 + line_end(0, qx) : off1 + tail_n1;
-                e2 = (tail_extra & 2u) ? off2 + line_end(1, qx) : off2 + tail_n2;
-            }
+            if (tail) { uint32_t nx; e1 = off1 + attempt(0, 4u * tail_units, tail_nl1, tail_n1, nx); e2 = off2 + attempt(1, 4u * tail_units, tail_nl2, tail_n2, nx); }
             if (e1 >= nolb1) flags |= C_NO_LB;
             if (e2 >= nolb2) flags |= C_NO_LB_R2;
         } else {
             const size_t q = 4 * (size_t)last + 3;
             uint64_t e1 = off1 + line_end(0, q);
-            if (tail) e1 = off1 + tail_n1;
+            if (tail) {
+                uint32_t nx; e1 = off1 + attempt(0, 4u * tail_units * T.upr, tail_nl1, tail_n1, nx);
+                if (T.paired == 2) e1 = off1 + attempt(0, nx, tail_nl1, tail_n1, nx);          // the second mate is asked for whatever the first answered
+            }
             if (e1 >= nolb1) { flags |= C_NO_LB; if (T.paired == 2) flags |= C_NO_LB_R2; }
         }
         st_u32(out, o.msize); st_u32(out + 4, s); st_u16(out + 8, flags); st_u32(out + 10, o.seq_size); st_u32(out + 14, o.qual_size);

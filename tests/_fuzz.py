@@ -113,3 +113,89 @@ def check(codec, encode, seed):
         if split:
             assert codec.decode_bytes(want, split_pe=False) == O.decode_file(want, False), "seed %d: interleaved decode differs" % seed
     return "ok"
+
+
+MiB = 1 << 20
+
+
+def block_case(seed: int):
+    """-> (fq1, fq2, paired, chunk_bases): inputs of one to three reader blocks (the reference reads 1 MiB at a time, src/fastqreader.cpp:31-46)
+    whose ENDS and block edges are what varies - sizes of exactly k MiB and a byte or two off, a final line break or none, a last record cut
+    off at a random byte, "\r\n" and blank lines laid across a block edge, mate files of different length.  The line-break bits of the chunks,
+    where reading stops and what the tail chunk holds all hang on these."""
+    r = random.Random(7000 + seed)
+    paired = r.choice([O.SE, O.SE, O.PE_TWO_FILES, O.PE_TWO_FILES, O.PE_INTERLEAVED])
+    prof = r.choice([O.NOVA_SE150, O.SE_VAR]) if paired == O.SE else O.NOVA_PE150
+    blocks = r.choice([1, 1, 2, 3])
+    per = 360 if prof != O.SE_VAR else 250
+    reads = (blocks * MiB) // per + 600
+    a, b = O.gen(prof, reads if paired != O.PE_INTERLEAVED else reads // 2, seed=900 + seed, nppm=r.choice([0, 20, 3000]), interleaved=paired == O.PE_INTERLEAVED)
+
+    def shape(t: bytes) -> bytes:
+        # the size: exactly k MiB, a byte or two beside it, or anywhere; reached by cutting (a cut lands where it lands: mid-name, mid-sequence,
+        # on a line break ...) or, for a clean end, by cutting at a record boundary
+        target = blocks * MiB + r.choice([0, 0, 0, -2, -1, 1, 2, 17, r.randint(-5000, 5000), r.randint(3, MiB // 2)])
+        target = max(400, min(target, len(t)))
+        how = r.random()
+        if how < 0.35:
+            t = t[:target]                                            # cut anywhere
+        elif how < 0.7:
+            e = t.rfind(b"\n@", 0, target) + 1                        # whole records ...
+            t = t[:e]
+            if r.random() < 0.5:
+                t = t[:-1]                                            # ... without the final line break
+            if r.random() < 0.5 and len(t) < target and target - len(t) < 150:
+                k = t.index(b"\n")                                    # ... padded (inside the first name) to the target size
+                t = t[:k] + b"p" * (target - len(t)) + t[k:]
+        else:
+            e = t.rfind(b"\n@", 0, target) + 1
+            j = t.find(b"\n", e) + 1                                  # a record's name line kept, its sequence line cut short
+            t = t[:min(len(t), j + r.randint(0, 60))]
+        # line-end quirks across a block edge
+        q = r.random()
+        if q < 0.2 and len(t) > MiB:
+            edge = MiB * r.randint(1, max(1, len(t) // MiB))
+            lo = t.rfind(b"\n", 0, min(edge, len(t) - 1)); hi = t.find(b"\n", min(edge, len(t) - 1))
+            if lo > 0 and hi > 0:
+                seg = t[lo - 400 if lo > 400 else 0:hi + 400].replace(b"\n", b"\r\n")
+                t = t[:lo - 400 if lo > 400 else 0] + seg + t[hi + 400:]
+        elif q < 0.3 and len(t) > MiB:
+            edge = MiB * r.randint(1, max(1, len(t) // MiB))
+            lo = t.rfind(b"\n@", 0, min(edge, len(t) - 1))
+            if lo > 0:
+                t = t[:lo + 1] + b"\n" * r.choice([1, 1, 2]) + t[lo + 1:]
+        return t
+    if paired == O.PE_TWO_FILES:
+        fq1, fq2 = shape(a), shape(b)
+        if r.random() < 0.4:                                          # one mate file much shorter
+            cut = r.randint(len(fq2) // 3, len(fq2))
+            if r.random() < 0.5:
+                fq2 = fq2[:cut]
+            else:
+                fq1 = fq1[:min(len(fq1), cut)]
+    else:
+        fq1, fq2 = shape(a), b""
+    return fq1, fq2, paired, r.choice([100_000, 100_000, 250_000])
+
+
+def check_block(codec, encode, seed):
+    """block_case(seed): encode == oracle (or the same refusal), decode(oracle image) == oracle decode."""
+    from repaq_amd import RfqError
+    fq1, fq2, paired, cb = block_case(seed)
+    try:
+        want = O.encode_file(fq1, fq2, paired, cb)
+    except O.OracleError as e:
+        try:
+            encode(codec, fq1, fq2, paired, cb)
+        except RfqError as g:
+            same_refusal = any(k in g.message and k in str(e) for k in ("1.5x scratch buffer", "quality line", "shorter than"))
+            assert same_refusal or g.message.strip() == str(e).strip(), (seed, g.message, str(e))
+            return "error"
+        raise AssertionError("block seed %d: the oracle refuses this input (%s), the engine encoded it" % (seed, e))
+    got = encode(codec, fq1, fq2, paired, cb)
+    assert got == want, "block seed %d: image differs (%d vs %d bytes, first difference at %d)" % (
+        seed, len(got), len(want), next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1))
+    if want:
+        split = paired != O.SE
+        assert codec.decode_bytes(want, split_pe=split) == O.decode_file(want, split), "block seed %d: decode differs" % seed
+    return "ok"

@@ -130,6 +130,29 @@ def build_cases():
     r2long = r2big + [rec(illumina(i, mate=2, tile=1101 + i // 4000), rseq(bigrng, 40), rqual(bigrng, 40)) for i in range(em_n, em_n + 400)]
     C["pe_truncated_r2_into_last_block"] = dict(fq1=fastq(bigrecs[:em_n]), fq2=truncated(r2long, MiB + 40), paired=PE2, k=100)
     C["pe_truncated_r1_exact_mib"] = dict(fq1=truncated(bigrecs, MiB), fq2=fastq(r2big), paired=PE2, k=100)
+    # exactly 1 MiB WITH its final line break: the flag still goes up - at the empty read behind the last full block the reader tests the byte
+    # in front of its buffer (src/fastqreader.cpp:41-45) - so the tail chunk carries the bit (and the reference's own decode drops the last line break)
+    def exact_mib_nl(recs):
+        m = len(recs)
+        while len(fastq(recs[:m])) > MiB:
+            m -= 1
+        need = MiB - len(fastq(recs[:m]))
+        out = fastq([rec(recs[0][0] + "P" * need, recs[0][1], recs[0][3])] + recs[1:m])
+        assert len(out) == MiB and out[-1:] == b"\n"
+        return out
+    C["se_exact_mib_with_final_newline"] = dict(fq1=exact_mib_nl(bigrecs), paired=SE, k=100)
+    # "\r\n" laid across R2's first block edge is an empty line: reading stops there (src/fastqreader.cpp:112-114,180-191) - but FastqReaderPair::read
+    # has already taken R1's record of that pair, and that record ends inside R1's final block: the tail chunk carries R1's bit
+    def crlf_on_edge(recs):
+        full = fastq(recs)
+        e = full.rfind(b"\n", 0, MiB - 200)                                               # a line end somewhere before the edge ...
+        k = full.index(b"\n")
+        out = full[:k] + b"P" * (MiB - 1 - e) + full[k:]                                   # ... moved onto the edge's last byte by padding the first name
+        assert out[MiB - 1:MiB] == b"\n"
+        return out[:MiB - 1] + b"\r\n" + out[MiB:]
+    r1edge = fastq(bigrecs[:em_n] + bigrecs[:30], final_eol=False)
+    assert MiB < len(r1edge) < MiB + 8000
+    C["pe_crlf_across_r2_block_edge_r1_tail_in_last_block"] = dict(fq1=r1edge, fq2=crlf_on_edge(r2long), paired=PE2, k=100)
     C["se_partial_last_record"] = dict(fq1=fastq(base) + b"@partial\nACGT\n", paired=SE)
     C["se_single_read"] = dict(fq1=fastq(base[:1]), paired=SE)
     r2 = [rec(illumina(i, mate=2), rseq(rng, 40), rqual(rng, 40)) for i in range(30)]

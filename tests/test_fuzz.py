@@ -25,6 +25,39 @@ def test_oracle_equals_reference_binary_on_fuzz_inputs(seed, tmp_path):
     assert O.encode_file(fq1, fq2, paired, cb) == O.ref_encode(fq1, fq2, paired, cb // 1000, tmpdir=str(tmp_path))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_block_fuzz_on_simt_emulation(seed):
+    """inputs of one to three reader blocks with varied ends and block edges (tests/_fuzz.py::block_case)"""
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    try:
+        F.check_block(c, E.encode, seed)
+    finally:
+        c.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref/repaq)")
+@pytest.mark.parametrize("seed", range(0, 60))
+def test_oracle_equals_reference_binary_on_block_fuzz_inputs(seed, tmp_path):
+    fq1, fq2, paired, cb = F.block_case(seed)
+    try:
+        want = O.encode_file(fq1, fq2, paired, cb)
+    except O.OracleError:
+        pytest.skip("an input both sides refuse (reference UB zone)")
+    assert want == O.ref_encode(fq1, fq2, paired, cb // 1000, tmpdir=str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_block_fuzz_on_gpu():
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.PRODUCT_LIB)
+    try:
+        outcomes = [F.check_block(c, E.encode, seed) for seed in range(120)]
+    finally:
+        c.close()
+    assert outcomes.count("ok") > 60
+
+
 @pytest.mark.gpu
 def test_fuzz_on_gpu():
     from repaq_amd import RfqCodec
