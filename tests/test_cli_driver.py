@@ -234,6 +234,51 @@ def test_cli_io_pipeline_on_gpu(tmp_path):
     assert os.path.exists(GPU_BIN), "repaq_hip is built by __graft_entry__.build()"
     _io_pipeline_suite(GPU_BIN, tmp_path, reads=120000)
 
+
+def _block_fuzz_through_cli(binary, tmp_path, seeds):
+    """tests/_fuzz.py::block_case inputs through the streaming driver in small batches (thresholds known late, carry-over, reading that
+    stops at an empty line mid-stream), the image against the oracle, then a streamed decode against the oracle's decode."""
+    import _fuzz as F
+    done = 0
+    for seed in seeds:
+        fq1, fq2, paired, cb = F.block_case(seed)
+        try:
+            want = O.encode_file(fq1, fq2, paired, cb)
+        except O.OracleError:
+            continue                                                     # an input both sides refuse
+        d = tmp_path / ("s%d" % seed); d.mkdir()
+        p1 = d / "a.fq"; p1.write_bytes(fq1); out = d / "o.rfq"
+        args = ["-c", "-i", str(p1), "-o", str(out), "-k", str(cb // 1000), "--batch_mb", str(1 + seed % 3), "--block_mb", "1", "--io_threads", str(1 + seed % 4)]
+        if paired == O.PE_TWO_FILES:
+            p2 = d / "b.fq"; p2.write_bytes(fq2); args += ["-I", str(p2)]
+        if paired == O.PE_INTERLEAVED:
+            args += ["--interleaved_in"]
+        r = _run(binary, args)
+        assert r.returncode == 0, (seed, r.stderr)
+        assert out.read_bytes() == want, "block seed %d through the driver" % seed
+        split = paired != O.SE
+        a1, a2 = d / "x1.fq", d / "x2.fq"
+        r = _run(binary, ["-d", "-i", str(out), "-o", str(a1)] + (["-O", str(a2)] if split else []) + ["--batch_mb", "8", "--block_mb", "1"])
+        assert r.returncode == 0, (seed, r.stderr)
+        exp = O.decode_file(want, split)
+        if split:
+            assert (a1.read_bytes(), a2.read_bytes()) == tuple(exp), seed
+        else:
+            assert a1.read_bytes() == (exp if isinstance(exp, bytes) else exp[0]), seed
+        done += 1
+    assert done >= len(seeds) // 2
+
+
+def test_cli_block_fuzz_on_simt_emulation(tmp_path):
+    E.build_emu()
+    _block_fuzz_through_cli(EMU_BIN, tmp_path, range(8))
+
+
+@pytest.mark.gpu
+def test_cli_block_fuzz_on_gpu(tmp_path):
+    assert os.path.exists(GPU_BIN), "repaq_hip is built by __graft_entry__.build()"
+    _block_fuzz_through_cli(GPU_BIN, tmp_path, range(40))
+
 def test_cli_on_simt_emulation(tmp_path):
     E.build_emu()
     subprocess.check_call(["make", "-s", "-C", E.EMU_DIR, "all"])
