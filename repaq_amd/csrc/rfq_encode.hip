@@ -514,6 +514,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, hipMemcpy(&v, (axis ? R.y : R.x) + f + (size_t)i * (ilv ? 2 : 1), 4, hipMemcpyDeviceToHost));
         return rfq_fail(ctx, RFQ_E_DATA, "The X/Y coordinate cannot be larger than 2M, but we get: %u", v);
     }
+    if ((hs.err & DE_TAIL_BLANK) && !nm) return RFQ_NEED_NORM;         // (rare: the tail chunk's line-break bits need the normaliser's verdict on a blank line behind the records)
     if (hs.err & DE_QUAL_OVERFLOW) return rfq_fail(ctx, RFQ_E_UNPINNED, "quality payload exceeds the reference's 1.5x scratch buffer (reference heap overflow, SURVEY.md App. C Q6)");
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_HIP, "internal: a stream exceeded its scratch capacity");
     if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %llu bytes", (unsigned long long)(hs.total_image + hdr_bytes));

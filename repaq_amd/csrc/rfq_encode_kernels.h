@@ -1679,6 +1679,9 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
             if (l0 + 2u >= nl) { next = nl; return n_; }                                       // fewer than three lines left: read to the end
             const uint32_t* lo_ = T.lo[st_]; bool e3 = false;
             for (uint32_t k = 0; k < 3; k++) if (lo_[l0 + k + 1] - 1u - lo_[l0 + k] == 0u) e3 = true;
+            // (on text that was not normalised - only the encoded records were looked at - an empty line here may be a blank line the reader
+            // swallows, src/fastqreader.cpp:112-114: the host repeats the call on the normalised text)
+            if (!T.ot[st_] && (e3 || (l0 + 3u < nl && lo_[l0 + 4u] - 1u - lo_[l0 + 3u] == 0u))) atomicOr(&st->err, (uint32_t)DE_TAIL_BLANK);
             if (!e3 && l0 + 3u >= nl) { next = nl; return n_; }                                // the quality line is asked for at the end of the file
             const uint32_t lastl = e3 ? l0 + 2u : l0 + 3u; next = lastl + 1u;
             return line_end(st_, lastl);

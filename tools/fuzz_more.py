@@ -12,3 +12,9 @@ for seed in range(300, 2300):
     except AssertionError as e: bad += 1; print("FAIL", seed, str(e)[:200])
     except Exception as e: bad += 1; print("EXC", seed, repr(e)[:200])
 print(res, "bad", bad)
+res = collections.Counter()
+for seed in range(120, 720):
+    try: res[F.check_block(c, E.encode, seed)] += 1
+    except AssertionError as e: bad += 1; print("BLOCK FAIL", seed, str(e)[:200])
+    except Exception as e: bad += 1; print("BLOCK EXC", seed, repr(e)[:200])
+print("block", res, "bad", bad)
