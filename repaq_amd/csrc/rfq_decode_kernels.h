@@ -506,6 +506,30 @@ __device__ __forceinline__ void pos_lane_adv_cnt(const PosFront& f, uint32_t sle
         if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
     }
 }
+__device__ __forceinline__ int sel4(const int (&v)[4], uint32_t t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
+// The same for ALL four entry states at once: the tokens that start at each of the lane's bytes are decoded once, a backward pass chains them
+// (a token that starts at byte k is followed by the one at k + its length), and entry state s - s bytes to skip - reads the chain at byte s.
+// (pos_lane_adv_cnt four times over was 60 % of the summary kernel's instructions.)
+__device__ __forceinline__ void pos_lane_adv_cnt4(const PosFront& f, uint32_t slen, uint32_t i0, int (&adv)[4], int (&cnt)[4]) {
+    const uint32_t nv = i0 >= slen ? 0u : (slen - i0 < 4u ? slen - i0 : 4u);   // the lane's valid bytes
+    int ca[4], cc[4]; uint32_t tl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b0 = f.bt[k];
+        const uint32_t b1 = (uint32_t)(f.v >> (8 * (k + 1))) & 0xFFu, b2 = (uint32_t)(f.v >> (8 * (k + 2))) & 0xFFu, b3 = (uint32_t)(f.v >> (8 * (k + 3))) & 0xFFu;
+        if ((b0 & 0x80u) == 0) { ca[k] = (int)b0 + 1; cc[k] = 1; tl[k] = 1; }
+        else if ((b0 & 0x40u) == 0) { ca[k] = (int)(((b0 & 0x3Fu) << 8) | b1) + 1; cc[k] = 1; tl[k] = 2; }
+        else if ((b0 & 0x20u) == 0) { ca[k] = (int)(b0 & 0x1Fu) + 1; cc[k] = ca[k]; tl[k] = 1; }
+        else { ca[k] = (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1; cc[k] = 1; tl[k] = 4; }
+    }
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {                                           // chain: byte k's token, then whatever starts behind it inside the lane
+        const uint32_t nx = (uint32_t)k + tl[k];
+        if (nx < nv) { const int a_ = nx == 1u ? ca[1] : (nx == 2u ? ca[2] : ca[3]), c_ = nx == 1u ? cc[1] : (nx == 2u ? cc[2] : cc[3]); ca[k] += a_; cc[k] += c_; }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) { const bool on = (uint32_t)s < nv; adv[s] = on ? ca[s] : 0; cnt[s] = on ? cc[s] : 0; }
+}
 // grid (ceil(maxseg / 4), streams, n_chunks) x 256 threads: one wave per segment; index arrays are [chunk][nstr][maxseg]; segA[8 * idx + s] =
 // positions advanced, segA[8 * idx + 4 + s] = positions emitted for entry state s
 __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
@@ -525,8 +549,9 @@ __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __
         const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
         uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
         const uint32_t G = fn_compose(Fcum, Fex);                          // segment entry state -> state in front of my bytes
+        int la[4], lc[4]; pos_lane_adv_cnt4(f, s.slen, i0, la, lc);         // the lane's tokens for each state in front of its bytes
 #pragma unroll
-        for (int e = 0; e < 4; e++) { int a_, n_; pos_lane_adv_cnt(f, s.slen, i0, (G >> (2 * e)) & 3u, a_, n_); a[e] += a_; n[e] += n_; }
+        for (int e = 0; e < 4; e++) { const uint32_t t_ = (G >> (2 * e)) & 3u; a[e] += sel4(la, t_); n[e] += sel4(lc, t_); }
         Fcum = fn_compose(Fcum, __shfl(f.Fin, 63));
     }
 #pragma unroll
@@ -538,7 +563,6 @@ __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __
 // one wave per (chunk, stream): entry state / position / list index of every segment by a scan over (transition table, advance and count
 // per entry state): x then y is (y.F o x.F, s -> x.a[s] + y.a[x.F[s]]); also the stream's number of list entries
 struct PosLink { uint32_t F; int a[4], n[4]; };
-__device__ __forceinline__ int sel4(const int (&v)[4], uint32_t t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ PosLink poslink_then(const PosLink& x, const PosLink& y) {   // x first, then y
     PosLink r; r.F = fn_compose(x.F, y.F);
 #pragma unroll
