@@ -199,3 +199,78 @@ def check_block(codec, encode, seed):
         split = paired != O.SE
         assert codec.decode_bytes(want, split_pe=split) == O.decode_file(want, split), "block seed %d: decode differs" % seed
     return "ok"
+
+
+def long_case(seed: int):
+    """-> (fq1, fq2, paired, chunk_bases): reads of 300 .. 30000 bases beside short ones - rows longer than the overlap search packs, records
+    longer than a gather / emit tile (the byte-wise paths), the decoder's materialising path (reads > 2000 bases)."""
+    r = random.Random(5000 + seed)
+    paired = r.choice([O.SE, O.PE_TWO_FILES, O.PE_INTERLEAVED])
+    n = r.randint(3, 60)
+    quals = bytes(r.sample(range(35, 75), r.choice([2, 4, 6])))
+    recs1, recs2 = [], []
+    for i in range(n):
+        L = r.choice([300, 700, 1999, 2000, 2001, 2500, 6000, 7000, 14000, 30000]) if r.random() < 0.5 else r.randint(1, 400)
+        seq = bytes(r.choice(b"ACGTN" if r.random() < 0.05 else b"ACGT") for _ in range(L)); q = bytes(r.choices(quals, k=L))
+        name = b"@M01:26:FCX:1:%d:%d:%d 1:N:0:AC" % (1101 + i // 7, 1000 + i * 3, 2000 + i)
+        recs1.append(name + b"\n" + seq + b"\n+\n" + q + b"\n")
+        if paired != O.SE:
+            L2 = r.choice([L, r.randint(1, max(1, L))])
+            if r.random() < 0.5 and min(L, L2) >= 12:
+                ov = r.randint(12, min(L, L2))
+                tail = seq[L - ov:] + bytes(r.choice(b"ACGT") for _ in range(max(0, L2 - ov)))
+                s2 = _rc(bytes(b if b in COMP else 65 for b in tail[:L2]))
+            else:
+                s2 = bytes(r.choice(b"ACGT") for _ in range(L2))
+            recs2.append(name.replace(b" 1:", b" 2:") + b"\n" + s2 + b"\n+\n" + bytes(r.choices(quals, k=len(s2))) + b"\n")
+    if paired == O.PE_INTERLEAVED:
+        return b"".join(a + b for a, b in zip(recs1, recs2)), b"", paired, 100_000
+    return b"".join(recs1), b"".join(recs2), paired, 100_000
+
+
+def qual_case(seed: int):
+    """-> (fq1, fq2, paired, chunk_bases): 1 .. 93 distinct quality values with flat to very skewed weights (the header's table rules,
+    src/rfqheader.cpp:130-237: up to 64 streams, raw qualities beyond), values that first appear after chunk 0 (exception records), N bases
+    whose quality is or is not the N quality."""
+    r = random.Random(9000 + seed)
+    paired = r.choice([O.SE, O.SE, O.PE_TWO_FILES, O.PE_INTERLEAVED])
+    n = r.choice([5, 40, 400, 1500])
+    nq = r.choice([1, 2, 3, 12, 40, 62, 63, 64, 65, 66, 80, 93])
+    quals = bytes(r.sample(range(33, 127), nq)); w = [r.random() ** r.choice([1, 3, 6]) + 1e-3 for _ in quals]
+    L = r.choice([36, 75, 100, 151])
+    late = r.random() < 0.4
+    recs1, recs2 = [], []
+    for i in range(n):
+        pool, pw = (quals[:max(1, nq // 3)], w[:max(1, nq // 3)]) if (late and i < n // 2) else (quals, w)
+        seq = bytes(r.choice(b"ACGT") for _ in range(L)); q = bytearray(r.choices(pool, pw, k=L))
+        if r.random() < 0.1:
+            k = r.randrange(L); seq = seq[:k] + b"N" + seq[k + 1:]
+            if r.random() < 0.5:
+                q[k] = r.choice(quals)
+        name = b"@M01:26:FCX:1:%d:%d:%d 1:N:0:AC" % (1101 + i // 70, 1000 + i * 3, 2000 + i)
+        recs1.append(name + b"\n" + seq + b"\n+\n" + bytes(q) + b"\n")
+        if paired != O.SE:
+            s2 = bytes(r.choice(b"ACGT") for _ in range(L))
+            recs2.append(name.replace(b" 1:", b" 2:") + b"\n" + s2 + b"\n+\n" + bytes(r.choices(pool, pw, k=L)) + b"\n")
+    if paired == O.PE_INTERLEAVED:
+        return b"".join(a + b for a, b in zip(recs1, recs2)), b"", paired, 100_000
+    return b"".join(recs1), b"".join(recs2), paired, 100_000
+
+
+def check_gen(codec, encode, gen, seed):
+    """gen(seed): encode == oracle (or both refuse), decode(oracle image) == oracle decode."""
+    from repaq_amd import RfqError
+    fq1, fq2, paired, cb = gen(seed)
+    try:
+        want = O.encode_file(fq1, fq2, paired, cb)
+    except O.OracleError as e:
+        try:
+            encode(codec, fq1, fq2, paired, cb)
+        except RfqError:
+            return "error"
+        raise AssertionError("%s seed %d: the oracle refuses this input (%s), the engine encoded it" % (gen.__name__, seed, e))
+    got = encode(codec, fq1, fq2, paired, cb)
+    assert got == want, "%s seed %d: image differs" % (gen.__name__, seed)
+    split = paired != O.SE
+    assert codec.decode_bytes(want, split_pe=split) == O.decode_file(want, split), "%s seed %d: decode differs" % (gen.__name__, seed)
+    return "ok"

@@ -47,6 +47,39 @@ def test_oracle_equals_reference_binary_on_block_fuzz_inputs(seed, tmp_path):
     assert want == O.ref_encode(fq1, fq2, paired, cb // 1000, tmpdir=str(tmp_path))
 
 
+@pytest.mark.parametrize("gen,seed", [(g, s) for g in ("long_case", "qual_case") for s in range(4)])
+def test_shape_fuzz_on_simt_emulation(gen, seed):
+    """long reads (byte-wise tile paths, materialising decoder) / quality tables of 1 .. 93 values with late exceptions (tests/_fuzz.py)"""
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    try:
+        F.check_gen(c, E.encode, getattr(F, gen), seed)
+    finally:
+        c.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref/repaq)")
+@pytest.mark.parametrize("gen,seed", [(g, s) for g in ("long_case", "qual_case") for s in range(12)])
+def test_oracle_equals_reference_binary_on_shape_fuzz_inputs(gen, seed, tmp_path):
+    fq1, fq2, paired, cb = getattr(F, gen)(seed)
+    try:
+        want = O.encode_file(fq1, fq2, paired, cb)
+    except O.OracleError:
+        pytest.skip("an input both sides refuse (reference UB zone)")
+    assert want == O.ref_encode(fq1, fq2, paired, cb // 1000, tmpdir=str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_shape_fuzz_on_gpu():
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.PRODUCT_LIB)
+    try:
+        outcomes = [F.check_gen(c, E.encode, g, seed) for g in (F.long_case, F.qual_case) for seed in range(80)]
+    finally:
+        c.close()
+    assert outcomes.count("ok") > 120
+
+
 @pytest.mark.gpu
 def test_block_fuzz_on_gpu():
     from repaq_amd import RfqCodec
