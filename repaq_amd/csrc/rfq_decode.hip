@@ -261,7 +261,11 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         // the verifying parse rides behind the speculative walk without a host round trip in between (its grid covers the first
         // PARSE_AHEAD chunks; the walk's own verdict is in the status words it reads)
         const uint32_t PARSE_AHEAD = use_table ? std::max(a->n_chunk_off, 1u) : 4096u;
-        if (speculate) { hipLaunchKernelGGL(k_dec_parse, dim3(std::min(cap, PARSE_AHEAD)), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, 0u); KCHK(ctx, "k_dec_parse"); }
+        if (speculate) {
+            hipLaunchKernelGGL(k_dec_parse, dim3(std::min(cap, PARSE_AHEAD)), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, 0u);
+            hipLaunchKernelGGL(k_dec_summary, dim3(1), dim3(256), 0, S, (const DChunk*)B[DB_CHUNKS].as<DChunk>(), dst, 0u, std::min(cap, PARSE_AHEAD));
+            KCHK(ctx, "k_dec_parse");
+        }
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
         if (use_table) {
@@ -274,6 +278,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
         if (hs.n_chunks > PARSE_AHEAD) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
+            hipLaunchKernelGGL(k_dec_summary, dim3(1), dim3(256), 0, S, (const DChunk*)B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD, hs.n_chunks - PARSE_AHEAD);
             KCHK(ctx, "k_dec_parse");
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));

@@ -19,7 +19,8 @@ struct DChunk {                  // one parsed chunk (offsets relative to the ch
     uint32_t rbase;              // reads in earlier chunks of the range being decoded
     uint32_t rbase_abs;          // reads in earlier chunks of the image (rbase is re-based per range by k_dec_rebase)
     uint64_t bases;              // sum of the chunk's read lengths (64-bit: a corrupt length table must not wrap the 32-bit prefix sums)
-    uint32_t max_len, pad_;      // longest read of the chunk
+    uint32_t max_len, nrec;      // longest read of the chunk; exception records behind its quality streams (0xFFFFFFFF: not looked at)
+    uint32_t max_one, pad_;      // its longest single quality stream
 };
 struct DecStatus {
     uint32_t err, n_chunks, max_reads, overflow;
@@ -58,7 +59,7 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
         uint32_t mx = 0;
         if (fl & C_READ_LEN_SAME) { mx = rl(0); sum = (unsigned long long)mx * s; }
         else { for (uint32_t r = (uint32_t)lane_id(); r < s; r += 64) { const uint32_t v = rl(r); sum += v; if (v > mx) mx = v; } sum = wave_sum<unsigned long long>(sum); mx = wave_max(mx); }
-        d.bases = sum; d.max_len = mx; d.pad_ = 0;
+        d.bases = sum; d.max_len = mx; d.nrec = 0; d.max_one = 0; d.pad_ = 0;
     }
 #define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
         const uint32_t m_ = (fl & (LENFLAG)) ? 1u : s; OFF = (uint32_t)q; if (q + m_ > left) return 2; \
@@ -176,12 +177,31 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
     DChunk d; const int rc = (rlb == 1 || rlb == 2 || rlb == 4) ? parse_chunk(img, n, k, hf, rlb, d) : 2;
     if (rc != 0 || d.total != want || d.reads != reads) { if (lane_id() == 0) atomicOr(&st->pad, 1u); return; }
     d.rbase = rbase; d.rbase_abs = rbase;
-    if (lane_id() == 0) { CH[c] = d; atomicMax(&st->max_stream, d.qual_size); atomicMax(&st->max_npos, d.npos_size); atomicAdd((unsigned long long*)&st->base_slots[c & 15u], (unsigned long long)d.bases);
-                          atomicMax(&st->max_len, d.max_len); atomicMax(&st->max_bases, d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases);
-                          if ((hf & H_QUAL_BY_COL) && !(hf & H_DONT_QUAL) && 4ull * D->n_normal <= d.qual_size) {
-                              const uint8_t* qp = img + d.off + d.o_qual; uint64_t off = 4ull * D->n_normal; uint32_t mo = 0;
-                              for (uint32_t i = 0; i < D->n_normal; i++) { const uint32_t sl = ld_u32(qp + 4 * i); off += sl; if (sl > mo) mo = sl; }
-                              if (off <= d.qual_size) { atomicMax(&st->max_nrec, (uint32_t)((d.qual_size - off) / 5)); atomicMax(&st->max_one, mo); } } }
+    // what the host sizes its passes from - longest stream, exception records - stays with the chunk; k_dec_summary reduces it (thousands of waves
+    // raising the same few maxima with atomics, all at once, were 130 of this kernel's 164 us)
+    if ((hf & H_QUAL_BY_COL) && !(hf & H_DONT_QUAL) && 4ull * D->n_normal <= d.qual_size) {
+        const uint8_t* qp = img + d.off + d.o_qual; uint64_t off = 4ull * D->n_normal; uint32_t mo = 0;
+        for (uint32_t i = 0; i < D->n_normal; i++) { const uint32_t sl = ld_u32(qp + 4 * i); off += sl; if (sl > mo) mo = sl; }
+        if (off <= d.qual_size) { d.nrec = (uint32_t)((d.qual_size - off) / 5); d.max_one = mo; }
+    }
+    if (lane_id() == 0) CH[c] = d;
+}
+// maxima / sums over the parsed chunks [first, first + count) -> the status words (one workgroup; the parse wrote every chunk's own values)
+__global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint32_t first, uint32_t count) {
+    if (st->overflow || st->pad) return;
+    const uint32_t end = first + count < st->n_chunks ? first + count : st->n_chunks;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0; unsigned long long sum = 0;
+    for (uint32_t c = first + threadIdx.x; c < end; c += blockDim.x) {
+        const DChunk& d = CH[c];
+        if (d.qual_size > m0) m0 = d.qual_size; if (d.npos_size > m1) m1 = d.npos_size; if (d.max_len > m2) m2 = d.max_len;
+        const uint32_t b32 = d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases; if (b32 > m3) m3 = b32;
+        if (d.nrec > m4) m4 = d.nrec;
+        sum += d.bases;
+    }
+    uint32_t m5 = 0; for (uint32_t c = first + threadIdx.x; c < end; c += blockDim.x) if (CH[c].max_one > m5) m5 = CH[c].max_one;
+    m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2); m3 = wave_max(m3); m4 = wave_max(m4); m5 = wave_max(m5); sum = wave_sum<unsigned long long>(sum);
+    if (lane_id() == 0) { atomicMax(&st->max_stream, m0); atomicMax(&st->max_npos, m1); atomicMax(&st->max_len, m2); atomicMax(&st->max_bases, m3); atomicMax(&st->max_nrec, m4); atomicMax(&st->max_one, m5);
+                          atomicAdd((unsigned long long*)&st->base_slots[0], sum); }
 }
 
 struct DReadTab {
