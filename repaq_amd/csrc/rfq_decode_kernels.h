@@ -139,25 +139,29 @@ __global__ void k_dec_spec_walk(const uint8_t* __restrict__ img, uint64_t n, uin
 // parallel (one workgroup, 256 chunks per round, running read base by a block scan) - no dependent load per chunk.  k_dec_parse
 // verifies every extent exactly as it does behind the speculative walk.
 __global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const uint64_t* __restrict__ off, uint32_t nch, DChunk* __restrict__ out, DecStatus* st) {
-    __shared__ uint64_t s_carry; __shared__ uint32_t s_bad, s_maxr;
-    if (threadIdx.x == 0) { s_carry = 0; s_bad = 0; s_maxr = 0; }
+    __shared__ uint32_t s_bad, s_maxr;
+    if (threadIdx.x == 0) { s_bad = 0; s_maxr = 0; }
     __syncthreads();
-    for (uint32_t b0 = 0; b0 < nch; b0 += blockDim.x) {
-        const uint32_t c = b0 + threadIdx.x; uint32_t reads = 0; uint64_t k = 0, e = 0; bool bad = false;
-        if (c < nch) {
-            k = off[c]; e = off[c + 1];
-            if (e > n || k + 18 > e || e - k > 0xFFFFFFFFull) bad = true; else { reads = ld_u32(img + k + 4); if (reads == 0) bad = true; }
-        }
-        uint32_t tot; const uint32_t ex = block_excl_sum<uint32_t>(bad ? 0u : reads, &tot);
-        const uint64_t carry = s_carry;
-        if (c < nch && !bad) { out[c].off = k; out[c].total = (uint32_t)(e - k); out[c].rbase = (uint32_t)(carry + ex); out[c].reads = reads; atomicMax(&s_maxr, reads); }
-        if (bad) atomicOr(&s_bad, 1u);
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
-        __syncthreads();
+    // every thread a run of consecutive chunks: their read counts summed, one block scan, the run re-walked with its base
+    const uint32_t K = (nch + blockDim.x - 1) / blockDim.x, c0 = threadIdx.x * K, c1 = c0 + K < nch ? c0 + K : nch;
+    auto reads_of = [&](uint32_t c, bool& bad) -> uint32_t {
+        const uint64_t k = off[c], e = off[c + 1];
+        if (e > n || k + 18 > e || e - k > 0xFFFFFFFFull) { bad = true; return 0u; }
+        const uint32_t r = ld_u32(img + k + 4); if (r == 0) bad = true;
+        return r;
+    };
+    unsigned long long acc = 0; bool anybad = false; uint32_t mx = 0;
+    for (uint32_t c = c0; c < c1; c++) { bool bad = false; const uint32_t r = reads_of(c, bad); if (bad) anybad = true; else { acc += r; if (r > mx) mx = r; } }
+    unsigned long long tot; unsigned long long run = block_excl_sum<unsigned long long>(acc, &tot);
+    for (uint32_t c = c0; c < c1; c++) {
+        bool bad = false; const uint32_t r = reads_of(c, bad);
+        if (!bad) { out[c].off = off[c]; out[c].total = (uint32_t)(off[c + 1] - off[c]); out[c].rbase = (uint32_t)run; out[c].reads = r; run += r; }
     }
+    if (mx) atomicMax(&s_maxr, mx);
+    if (anybad) atomicOr(&s_bad, 1u);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const uint64_t rb = s_carry; uint32_t bad = s_bad | (rb > 0xFFFFFFF0ull ? 1u : 0u);
+        const uint64_t rb = tot; uint32_t bad = s_bad | (rb > 0xFFFFFFF0ull ? 1u : 0u);
         st->n_chunks = nch; st->max_reads = s_maxr; st->total_reads = rb; st->consumed = off[nch]; st->overflow = 0; st->pad = bad;
         st->last_flags = (!bad && nch) ? ld_u16(img + off[nch - 1] + 8) : 0u;
     }
@@ -626,19 +630,13 @@ __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __r
 // exclusive prefix of the streams' entry counts (one workgroup; n_streams is some thousands) -> where each list starts in the arena; the total
 // goes to st->list_need (the host grows the arena and repeats k_dec_pos_list when it did not fit)
 __global__ void k_dec_pos_off(const uint32_t* __restrict__ nent, unsigned long long* __restrict__ loff, uint32_t n_streams, DecStatus* st) {
-    __shared__ unsigned long long s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < n_streams; b0 += blockDim.x) {
-        const uint32_t i = b0 + threadIdx.x; const unsigned long long v = i < n_streams ? nent[i] : 0ull;
-        unsigned long long tot; const unsigned long long ex = block_excl_sum<unsigned long long>(v, &tot);
-        const unsigned long long c = s_carry;
-        if (i < n_streams) loff[i] = c + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = c + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) st->list_need = s_carry;
+    // every thread a run of consecutive streams (summed, one block scan, re-walked): no barrier per 256 streams
+    const uint32_t K = (n_streams + blockDim.x - 1) / blockDim.x, i0 = threadIdx.x * K, i1 = i0 + K < n_streams ? i0 + K : n_streams;
+    unsigned long long acc = 0;
+    for (uint32_t i = i0; i < i1; i++) acc += nent[i];
+    unsigned long long tot; unsigned long long run = block_excl_sum<unsigned long long>(acc, &tot);
+    for (uint32_t i = i0; i < i1; i++) { loff[i] = run; run += nent[i]; }
+    if (threadIdx.x == 0) st->list_need = tot;
 }
 // decodeSingleQualByCol (src/rfqcodec.cpp:957-1007) for one segment from its entry (state, last covered position, list index): the positions
 // it codes go to plist[loff + k ...] in stream order; cellidx[cell] = index (within the stream's list) of the first entry >= cell * POS2_CELL

@@ -289,7 +289,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_FIRST].ensure(((size_t)cap_chunks + 2) * 4));
     ChunkTab C; memset(&C, 0, sizeof C);
     C.first = B[B_FIRST].as<uint32_t>();
-    hipLaunchKernelGGL(k_partition, dim3(1), dim3(64), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, fin ? 1 : 0,
+    hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, fin ? 1 : 0,
                        (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst);
     KCHK(ctx, "k_partition");
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));

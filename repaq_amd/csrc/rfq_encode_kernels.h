@@ -433,8 +433,15 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
 __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, int final_batch,
                             const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
     const int l = lane_id();
+    // shortest / longest unit: every thread of the workgroup (1024: a single wave walked 44 k block entries in 158 us), then wave 0 goes on alone
+    __shared__ uint32_t s_mn[16], s_mx[16];
     uint32_t len_minmax[2];
-    { uint32_t mn = 0xFFFFFFFFu, mx = 0; for (uint32_t i = (uint32_t)l; i < n_blk; i += 64) { const uint32_t a = blk_minmax[2 * i], b = blk_minmax[2 * i + 1]; if (a < mn) mn = a; if (b > mx) mx = b; }
+    { uint32_t mn = 0xFFFFFFFFu, mx = 0; for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk_minmax[2 * i], b = blk_minmax[2 * i + 1]; if (a < mn) mn = a; if (b > mx) mx = b; }
+      mn = wave_min(mn); mx = wave_max(mx);
+      if (l == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; }
+      __syncthreads();
+      if (wave_id() != 0) return;
+      const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u;
       len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); }
     uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0;
     if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
