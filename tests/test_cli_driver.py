@@ -304,3 +304,20 @@ def test_cli_compare_on_gpu(tmp_path):
     import __graft_entry__ as g
     g.build_host_tools()
     _compare_suite(GPU_BIN, tmp_path, batch_mb=1)
+
+
+@pytest.mark.gpu
+def test_cli_devices_on_two_physical_gpus(tmp_path):
+    """--devices 0,1: chunk ranges planned on GPU 0, pulled GPU-to-GPU (rfq_copy_peer = hipMemcpyPeerAsync) and encoded on both; the image is
+    the one-shot image.  Needs two GPUs: skipped on the one-GPU test box (the same path runs there as --devices 0,0 in test_cli_on_gpu)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    assert os.path.exists(GPU_BIN)
+    a, b = O.gen(O.NOVA_PE150, 60000, seed=45)
+    pa, pb = tmp_path / "r1.fq", tmp_path / "r2.fq"; pa.write_bytes(a); pb.write_bytes(b)
+    one, two = tmp_path / "one.rfq", tmp_path / "two.rfq"
+    assert _run(GPU_BIN, ["-c", "-i", str(pa), "-I", str(pb), "-o", str(one), "-k", "100"]).returncode == 0
+    r = _run(GPU_BIN, ["-c", "-i", str(pa), "-I", str(pb), "-o", str(two), "-k", "100", "--batch_mb", "8", "--devices", "0,1"])
+    assert r.returncode == 0, r.stderr
+    assert two.read_bytes() == one.read_bytes() == O.encode_file(a, b, O.PE_TWO_FILES, 100_000)
