@@ -36,7 +36,7 @@ STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "rea
                  "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder", "k_pos_sizes"],
                  "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
                  "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
-                 "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list",
+                 "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list", "k_dec_textlen",   # (fused path: the text lengths run beside the list chain)
                                  # (reads longer than 2000 bases, -k values whose chunks exceed 4096 records, and legacy RLE files take the materialising path)
                                  "k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_pos_index", "k_dec_except", "k_dec_rle"],
                  "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit2"]}

@@ -70,7 +70,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
     const bool rle_h = !(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL));          // legacy run-length quality coding: k_dec_rle on the materialising path
     const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u;
-    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false; const uint32_t f_nstr = HH.n_normal + 1;
+    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S; const uint32_t f_nstr = HH.n_normal + 1;
     if (fused) {
         ctx->timer.begin("streams", S);
         const bool hasn = (HH.flags & H_N_POS) != 0; const uint32_t nn = bycol_h ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u;
@@ -98,9 +98,10 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, A);
             f_lists = true; f_mq = mq; f_mn = mn; f_nn = nn; f_hasn = hasn;
         }
-        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
+        // (no join yet: the text lengths and their prefix - the main stream's next kernels - need the coordinates, not the lists; the two chains
+        // meet in front of the status read-back below, and the "streams" stage runs until then)
+        f_join = forked; f_aux = A;
         KCHK(ctx, "k_dec_streams");
-        ctx->timer.end(S);
     }
     uint64_t* qbase = nullptr; uint64_t* sbase = nullptr; uint8_t* qdec = nullptr; uint8_t* sdec = nullptr; size_t qbytes = 0, sbytes = 0;
     if (!fused) {
@@ -155,10 +156,11 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     }
 
     // ---- text
-    ctx->timer.begin("textlen", S);
+    if (!fused) ctx->timer.begin("textlen", S);                          // (fused path: still inside "streams", beside the list chain)
     const int split = a->split_pe ? 1 : 0;
     hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
     scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
+    if (f_join) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, f_aux)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     U4 tt;
     HIPCHK(ctx, ctx->fetch(&tt, R.tp + n_reads, 16, S));
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
