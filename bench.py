@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MI
 
 # stage (HIP-event pair inside librfq_hip) -> the kernels it brackets (names as rocprofv3 reports them)
 STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
-                 "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
+                 "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_overlap_apply", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
                  "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder", "k_pos_sizes"],
                  "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
                  "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],

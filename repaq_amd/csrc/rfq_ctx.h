@@ -55,6 +55,7 @@ struct rfq_ctx {
     // ev_fork recorded on `stream`, join with ev_join recorded on `aux`
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
     hipStream_t aux2 = nullptr; hipEvent_t ev_f = nullptr;                     // decode: the bandwidth-bound prefill beside the latency-bound chains
+    hipEvent_t ev_ovl = nullptr;                                               // encode: the overlap search (aux) has finished
     bool aux_ready() {
         if (aux) return true;
         if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; return false; }
@@ -62,6 +63,7 @@ struct rfq_ctx {
             hipEventCreateWithFlags(&ev_mid, hipEventDisableTiming) != hipSuccess) return false;
         if (hipStreamCreateWithFlags(&aux2, hipStreamNonBlocking) != hipSuccess) { aux2 = nullptr; return false; }
         if (hipEventCreateWithFlags(&ev_f, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&ev_ovl, hipEventDisableTiming) != hipSuccess) return false;
         return true;
     }
     std::string err;

@@ -11,7 +11,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_BITMAP0 = 0, B_BITMAP1, B_BLK0, B_BLK1, B_LO0, B_LO1, B_SCANTMP,
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
-    B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
+    B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
     B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_ENC_END
 };
 
@@ -262,6 +262,25 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (n_units == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
     const bool is_pe = a->paired != RFQ_SE;
 
+    // PE: the overlap search of every pair starts now, on the second stream (see k_overlap); it is joined where its results are applied
+    struct AuxGuard { rfq_ctx* c; bool armed; void sync() { if (armed) { (void)hipStreamSynchronize(c->aux); armed = false; } } ~AuxGuard() { sync(); } } ovl_guard = { ctx, false };   // (an early return must not leave it running over buffers that are about to be reused)
+    bool ovl_aside = false;
+    if (is_pe && !scan_only) {
+        const uint32_t np = n_units; const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
+        HIPCHK(ctx, B[B_OVRAW].ensure((size_t)np * 2 + 64));
+        ovl_aside = ctx->aux_ready(); hipStream_t OS = ovl_aside ? ctx->aux : S;
+        if (ovl_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(OS, ctx->ev_fork, 0)); }
+        if (tune & 64) {     // per-phase cycle counters (profiling aid)
+            HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats) + 8192));
+            unsigned long long* dbg = (unsigned long long*)B[B_HSTATS].p + 600; (void)hipMemsetAsync(dbg, 0, 64, OS);
+            hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, OS, T, B[B_OVRAW].as<int16_t>(), np, dbg, 0);
+            unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+            if (h[5]) fprintf(stderr, "[overlap dbg] waves=%llu avg cycles/wave: meta=%llu pack=%llu fwd=%llu bwd=%llu slow+write=%llu verifies/wave=%.1f\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5], (double)h[6]/h[5]);
+        } else hipLaunchKernelGGL(k_overlap<false>, dim3(ob), dim3(256), 0, OS, T, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, (tune >> 8) & 7);   // (tune bits 8-10: ablation switches, results invalid)
+        KCHK(ctx, "k_overlap");
+        if (ovl_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_ovl, OS)); ovl_guard.armed = true; }
+    }
+
     ctx->timer.begin("read_table+cut", S);
     const size_t nr = (size_t)n_reads + 2;
     HIPCHK(ctx, B[B_LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N1LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N2OFF].ensure(nr * 4));
@@ -299,6 +318,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // "\n\n" is a swallowed blank line, not an empty one: classify the text properly first.  On normalised text an empty line is
         // where FastqReader::read returns NULL (src/fastqreader.cpp:180-191): the record and everything after it are never read.
         if (!nm) return RFQ_NEED_NORM;
+        ovl_guard.sync();                                                   // (the repeat rebuilds nothing, but starts its own search over the same buffers)
         return encode_impl(ctx, a, res, nm, hs.first_empty / T.upr, true, scan_only, skip);
     }
     if (hs.err & DE_QUAL_SHORT) return rfq_fail(ctx, RFQ_E_UNPINNED, "a quality line is shorter than its sequence line (the reference reads past the string: undefined)");
@@ -382,13 +402,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, 1, (const uint32_t*)cbits, (const uint32_t*)cfail, (const uint32_t*)redo);
     }
     if (is_pe) {
-        const uint32_t np = reads_used / 2; const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
-        if (tune & 64) {     // per-phase cycle counters (profiling aid)
-            unsigned long long* dbg = (unsigned long long*)B[B_HSTATS].p + 600; (void)hipMemsetAsync(dbg, 0, 64, S);
-            hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np, dbg, 0);
-            unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
-            if (h[5]) fprintf(stderr, "[overlap dbg] waves=%llu avg cycles/wave: meta=%llu pack=%llu fwd=%llu bwd=%llu slow+write=%llu verifies/wave=%.1f\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5], (double)h[6]/h[5]);
-        } else hipLaunchKernelGGL(k_overlap<false>, dim3(ob), dim3(256), 0, S, T, R, C, (const DevHeader*)D, ovb, np, (unsigned long long*)nullptr, (tune >> 8) & 7);   // (tune bits 8-10: ablation switches, results invalid)
+        const uint32_t np = reads_used / 2;
+        if (ovl_aside) { HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_ovl, 0)); ovl_guard.armed = false; }
+        hipLaunchKernelGGL(k_overlap_apply, dim3((np + 255) / 256), dim3(256), 0, S, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb, np);
     }
     hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, B[B_PVIN].as<U4>(), n_reads);
     scan_exclusive<U4>(S, B[B_PVIN].as<U4>(), R.pv, n_reads, B[B_SCANTMP].as<U4>(), 1);

@@ -841,11 +841,13 @@ __device__ __forceinline__ bool ov2_verify(const uint8_t* ac, const uint8_t* an,
     return !__any(diff != 0);
 }
 // 256 pairs per block, 64 per wave.  Only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
-template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int8_t* __restrict__ ovb, uint32_t n_pairs, unsigned long long* dbg, int abl) {
+// The search needs nothing but the text and its line table, so it runs for EVERY pair as soon as the index exists - on the second stream, beside
+// the read table, the cut, the header and the chunk flags (those are latency-bound, this is VALU-bound) - and leaves the raw offset (0 = none)
+// in ovraw; k_overlap_apply takes them over for the chunks that turn out to be interleaved under a header with BIT_ENCODE_PE_BY_OVERLAP.
+template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int16_t* __restrict__ ovraw, uint32_t n_pairs, unsigned long long* dbg, int abl) {
     __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4)]; __shared__ uint32_t s_bad[4][2];
     long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a_meta = 0, a_pack = 0, a_fwd = 0, a_bwd = 0, a_slow = 0; uint32_t n_ver = 0;
-    if (!(D->flags & H_PE_OVERLAP)) return;                     // uniform
-    const int shift = D->overlap_shift; const int l = lane_id(), w = wave_id();
+    const int l = lane_id(), w = wave_id();
     uint8_t* const c1 = (uint8_t*)(s_rows + (size_t)w * (OV2_WAVE_BYTES / 4)); uint8_t* const c2 = c1 + 64u * OV2_CROW;
     uint8_t* const n1 = c2 + 64u * OV2_CROW; uint8_t* const n2 = n1 + 64u * OV2_NROW;
     for (uint32_t p0 = (blockIdx.x * 4u + (uint32_t)w) * 64u; p0 < n_pairs; p0 += gridDim.x * 256u) {       // wave-uniform
@@ -853,7 +855,8 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, Rea
         const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0;
         if (p < n_pairs) {
             const uint32_t g = 2u * p;
-            if (!(abl & 4) && C.il[R.chunk[g]]) { len1 = (int)R.len[g]; len2 = (int)R.len[g + 1]; uint32_t r; read_loc(T, g, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, g + 1, s2, r); q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }
+            if (!(abl & 4)) { uint32_t r; read_loc(T, g, s1, r); const uint32_t* pa = t_lo(T, s1) + 4 * (size_t)r; q1 = pa[1]; len1 = (int)(pa[2] - 1u - q1);
+                              read_loc(T, g + 1, s2, r); const uint32_t* pb = t_lo(T, s2) + 4 * (size_t)r; q2 = pb[1]; len2 = (int)(pb[2] - 1u - q2); }
         }
         const bool slow = len1 >= 0 && ((uint32_t)len1 > OV2_CAP || (uint32_t)len2 > OV2_CAP), fast = len1 >= 0 && !slow;
         const int mx = wave_max(fast ? (len1 > len2 ? len1 : len2) : 0);
@@ -971,14 +974,21 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, Rea
             const int r = wave_overlap(a, __shfl(len1, j), b, __shfl(len2, j));
             if (l == j) ov = r;
         }
-        if (len1 >= 0) {
-            if (ov + shift > 127) ov = 0;
-            if (ov + shift < -127) ov = 0;
-            ovb[p] = (int8_t)(ov + shift); R.stored[2 * (size_t)p + 1] = (uint32_t)(len2 - (ov < 0 ? -ov : ov));
-        }
+        if (len1 >= 0) ovraw[p] = (int16_t)(ov > 32767 ? 0 : (ov < -32767 ? 0 : ov));      // (beyond +-127 - shift the clamp of k_overlap_apply makes it 0 anyway)
         if (DBG) { k5 = clock64(); a_slow += k5 - k4; }
     }
     if (DBG && dbg && l == 0) { atomicAdd(&dbg[0], (unsigned long long)a_meta); atomicAdd(&dbg[1], (unsigned long long)a_pack); atomicAdd(&dbg[2], (unsigned long long)a_fwd); atomicAdd(&dbg[3], (unsigned long long)a_bwd); atomicAdd(&dbg[4], (unsigned long long)a_slow); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)n_ver); }
+}
+// the clamp of src/rfqcodec.cpp:376-383 and the stored length of the mate, for the pairs of interleaved chunks (k_overlap found the offsets)
+__global__ void k_overlap_apply(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const int16_t* __restrict__ ovraw, int8_t* __restrict__ ovb, uint32_t n_pairs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs || !(D->flags & H_PE_OVERLAP)) return;
+    const uint32_t g = 2u * p;
+    if (!C.il[R.chunk[g]]) return;
+    const int shift = D->overlap_shift; int ov = ovraw[p];
+    if (ov + shift > 127) ov = 0;
+    if (ov + shift < -127) ov = 0;
+    ovb[p] = (int8_t)(ov + shift); R.stored[g + 1] = R.len[g + 1] - (uint32_t)(ov < 0 ? -ov : ov);
 }
 __global__ void k_pv_in(Text T, ReadTab R, U4* __restrict__ v, uint32_t n_reads) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
