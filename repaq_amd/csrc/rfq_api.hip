@@ -22,6 +22,7 @@ extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     rfq_ctx* c = new (std::nothrow) rfq_ctx();
     if (!c) return RFQ_E_HIP;
     c->device = device_id;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) c->n_cu = (uint32_t)cu; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return RFQ_E_NO_DEVICE; }
     c->own_stream = true;
     memset(&c->h_hdr, 0, sizeof c->h_hdr);

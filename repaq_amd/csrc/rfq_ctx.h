@@ -48,8 +48,22 @@ struct StageTimer {
     void destroy() { for (auto& s : stages) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); } stages.clear(); }
 };
 
+// Workgroups per chunk for a tile kernel whose grid is (x, n_chunks): the GPU holds `slots` of its workgroups at a time, and a grid that is not
+// a whole number of such rounds leaves the last round part empty (3360 chunks x 2 = 6720 workgroups on 1280 slots are 5.25 rounds: measured
+// 12 % slower than x 3 = 7.9 rounds).  Among the grids of about 6 .. 12 rounds the one that fills its last round best; ties go to the smaller.
+static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, uint32_t slots) {
+    uint32_t best = 1; double best_eff = 0.0;
+    if (!n_chunks || !slots) return 1;
+    for (uint32_t k = 6; k <= 12; k++) {
+        uint32_t bx = (uint32_t)(((uint64_t)k * slots + n_chunks / 2) / n_chunks);
+        if (bx < 1) bx = 1; if (bx > tiles_per_chunk) bx = tiles_per_chunk; if (bx < 1) bx = 1;
+        const double rounds = (double)bx * n_chunks / slots, full = (double)(uint64_t)(rounds + 0.999999), eff = full > 0 ? rounds / full : 0.0;
+        if (eff > best_eff + 1e-3) { best = bx; best_eff = eff; }
+    }
+    return best;
+}
 struct rfq_ctx {
-    int device = 0;
+    int device = 0; uint32_t n_cu = 256;                                         // compute units of the device (rfq_create)
     hipStream_t stream = nullptr; bool own_stream = false;
     // second stream for small latency-bound kernels that are independent of the main chain (coordinate coder / decoder): fork with
     // ev_fork recorded on `stream`, join with ev_join recorded on `aux`

@@ -181,7 +181,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     ctx->timer.end(S);
     ctx->timer.begin("emit", S);                                       // k_dec_emit alone: the path's largest kernel (bench.py roofline)
     {
-        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + ET_READS - 1) / ET_READS, std::max(1u, 8192u / n_chunks)));
+        const uint32_t bx = grid_x_for(n_chunks, (max_reads + ET_READS - 1) / ET_READS, (fused ? 4u : 4u) * ctx->n_cu);   // (39 KB of LDS: four workgroups per CU)
         const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
 #define RFQ_EMIT2_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
                        (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr

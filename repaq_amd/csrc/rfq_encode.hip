@@ -422,7 +422,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
     {
         // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 64; enough workgroups to fill 256 CUs x 2
-        const uint32_t bx = std::max(1u, std::min<uint32_t>((max_reads + GT_READS - 1) / GT_READS, std::max(1u, 8192u / n_chunks)));
+        const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
 #define RFQ_GATHER_ARGS T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, \
                         tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune
         if (tune & 7) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
