@@ -497,7 +497,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // the line-break bit of the input's tail chunk looks at how far the readers got on their last, failed attempt (see k_assemble): when this
         // call ends the input - at its end or at an empty line - and not at a worker's chunk boundary
         const uint32_t tail_bases = ((a->final && !a->flush_all) || ended) ? a->chunk_bases : 0u;
-        const uint32_t bpc = std::max(1u, std::min(64u, 4096u / n_chunks));
+        const uint32_t bpc = grid_x_for(n_chunks, 64u, 8u * ctx->n_cu);       // (no LDS, 28 VGPRs: eight workgroups per CU)
         hipLaunchKernelGGL(k_assemble, dim3(bpc, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L,
                            (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(),
                            (const uint8_t*)B[B_XS].as<uint8_t>(), (const uint8_t*)B[B_YS].as<uint8_t>(), (const int8_t*)ovb, img, img_cap, hdr_bytes,
