@@ -13,7 +13,14 @@ PRODUCT_LIB = os.path.join(ROOT, "repaq_amd", "lib", "librfq_hip.so")
 
 
 def build_emu():
-    subprocess.check_call(["make", "-s", "-j4", "-C", EMU_DIR])
+    # (pytest-xdist workers call this at the same time: one make at a time, the others find everything up to date)
+    import fcntl
+    with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-s", "-j4", "-C", EMU_DIR])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return EMU_LIB
 
 
