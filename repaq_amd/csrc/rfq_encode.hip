@@ -268,7 +268,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (is_pe && !scan_only) {
         const uint32_t np = n_units; const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
         HIPCHK(ctx, B[B_OVRAW].ensure((size_t)np * 2 + 64));
-        ovl_aside = ctx->aux_ready(); hipStream_t OS = ovl_aside ? ctx->aux : S;
+        ovl_aside = ctx->aux_ready() && !(tune & 2048); hipStream_t OS = ovl_aside ? ctx->aux : S;
         if (ovl_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(OS, ctx->ev_fork, 0)); }
         if (tune & 64) {     // per-phase cycle counters (profiling aid)
             HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats) + 8192));

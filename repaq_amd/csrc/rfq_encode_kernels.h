@@ -798,15 +798,16 @@ __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int 
 // (G 0, A 1, T 2, C 3, anything else 0) plus one "is N" bit per base.  RfqCodec::overlap compares characters: R1's are compared as
 // they stand, RC2's are in {A,C,G,T,N} (Read::changeToReverseComplement maps everything else to N), so two bases are equal iff their
 // codes and their N bits are equal - except a base of R1 outside A/C/G/T/N, which equals nothing (such pairs, and reads longer than
-// the rows, take wave_overlap above).  Every lane then walks ITS pair's candidates o = 12, 13, ...: a candidate passes the filter
-// when the first 12 bases of the window (24 code bits: one byte-granular ds_read_b32 + bit-field extract) equal the 12-base head of the
-// other read; the few that pass are verified by the whole wave (4 bases per lane, codes and N bits).  Forward before backward,
-// smallest o first (src/rfqcodec.cpp:1391-1438).  The former wave-per-pair search cost ~600 wave-instructions per pair.
+// the rows, take wave_overlap above).  Every lane then filters ITS pair's candidates o = 12, 13, ...: a candidate passes when the
+// first 12 bases of its window equal the 12-base head of the other read - all window starts of the row at once, as bit-string
+// arithmetic on the row held in registers; the few that pass are verified by the whole wave (4 bases per lane, codes and N bits).
+// Forward before backward, smallest o first (src/rfqcodec.cpp:1391-1438).  The former wave-per-pair search cost ~600
+// wave-instructions per pair, the per-candidate filter (one 64-bit window per 16 candidates) ~35.
 #define OV2_CAP 256u              // bases per read held in a row (64 lanes x 4 bases verify one candidate in one step)
 #define OV2_CROW 68u              // code row: 64 bytes + 4 of slack for the last unaligned word; 17 dwords, so that lanes reading their own rows at one offset hit 64 different banks
 #define OV2_NROW 36u              // N-bit row: 32 bytes + 4; 9 dwords
 #define OV2_WAVE_BYTES (128u * (OV2_CROW + OV2_NROW))
-#define OV2_BATCH 16              // candidates filtered per round (one 64-bit window of the row)
+#define OV2_FILTER 8              // bases of the head the candidate filter compares (any number <= 12, the smallest o: what passes is verified in full)
 __device__ __forceinline__ uint32_t bfe_u32(uint32_t v, uint32_t off, uint32_t wid) { return (v >> off) & ((1u << wid) - 1u); }
 // 16 bytes at base + off (any alignment); bytes outside [0, n) read as 0
 static __device__ __noinline__ uint4 ld16_edge(const uint8_t* __restrict__ base, long long off, uint64_t n) {
@@ -866,63 +867,71 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int
         { uint4* z = (uint4*)c1; for (uint32_t i = (uint32_t)l; i < OV2_WAVE_BYTES / 16u; i += 64u) z[i] = make_uint4(0, 0, 0, 0); }
         wave_lds_sync();
         if (DBG) { k1 = clock64(); a_meta += k1 - k0; }
-        // ---- pack: task t = (row, ALIGNED 16-byte group of the text that holds part of the row's sequence line); rows 0..63 R1, 64..127 RC2.
-        // Consecutive lanes take consecutive groups of one line: every load is an aligned, coalesced dwordx4 (a dwordx4 at an odd address -
-        // one per 16 bases of the line itself - keeps the texture addresser busy for hundreds of cycles).  A group's 16 bases land at an
-        // arbitrary base position of the row: their codes (32 bits) and N bits (16 bits) are shifted into place and OR-ed into the row.
-        const uint32_t G = ((uint32_t)mx + 15u + 15u) >> 4, ntasks = 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 4096, G <= 17
-        for (uint32_t t0 = 0; t0 < ((abl & 2) ? 0u : ntasks); t0 += 256u) {
-            uint32_t v[4][4]; uint32_t row[4]; int L[4], pos0[4]; bool on[4], edge[4]; const uint8_t* src[4]; uint32_t at[4], lim[4];
+        // ---- pack: task t = (row, ALIGNED 32-byte group of the text that holds part of the row's sequence line); rows 0..63 R1, 64..127 RC2.
+        // Consecutive lanes take consecutive groups of one line: every load is an aligned dwordx4 (a dwordx4 at an odd address - one per
+        // 16 bases of the line itself - keeps the texture addresser busy for hundreds of cycles).  A group's 32 bases land at an arbitrary
+        // base position of the row: their codes (64 bits) and N bits (32 bits) are shifted into place and OR-ed into the row.  (16-byte
+        // tasks cost 150 instructions each, 90 of them per task and not per byte: row look-up, masks, atomics.)
+        const uint32_t G = ((uint32_t)mx + 31u + 31u) >> 5, ntasks = (abl & 2) ? 0u : 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 4096, G <= 17
+        const uint32_t meta1 = (uint32_t)(len1 < 0 ? 0 : (len1 > 0xFFFF ? 0xFFFF : len1)) | ((uint32_t)s1 << 16) | (fast ? 1u << 17 : 0u);
+        const uint32_t meta2 = (uint32_t)(len2 < 0 ? 0 : (len2 > 0xFFFF ? 0xFFFF : len2)) | ((uint32_t)s2 << 16);
+        for (uint32_t t0 = 0; t0 < ntasks; t0 += 256u) {
+            uint32_t v[4][8]; uint32_t row[4]; int L[4], pos0[4]; bool on[4], edge[4]; const uint8_t* src[4]; uint32_t at[4], lim[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)l; row[u] = t < ntasks ? (t * ginv) >> 16 : 0u; const uint32_t j = t - row[u] * G;
                 const int srcl = (int)(row[u] & 63u); const bool second = row[u] >= 64u;
-                const int a1 = __shfl(len1, srcl), a2 = __shfl(len2, srcl); const uint32_t o1 = __shfl(q1, srcl), o2 = __shfl(q2, srcl);
-                const int z1 = __shfl(s1, srcl), z2 = __shfl(s2, srcl); const bool f = __shfl(fast ? 1 : 0, srcl) != 0;
-                L[u] = second ? a2 : a1; const uint32_t q = second ? o2 : o1, m = q & 15u;
-                at[u] = (q & ~15u) + 16u * j;                              // the group's offset in its stream
+                const uint32_t ma = __shfl(meta1, srcl), mb = __shfl(meta2, srcl), o1 = __shfl(q1, srcl), o2 = __shfl(q2, srcl);
+                const uint32_t mm = second ? mb : ma; const bool f = (ma >> 17) & 1u;
+                L[u] = (int)(mm & 0xFFFFu); const uint32_t q = second ? o2 : o1, m = q & 31u;
+                at[u] = (q & ~31u) + 32u * j;                              // the group's offset in its stream
                 on[u] = t < ntasks && f && at[u] < q + (uint32_t)L[u];
-                const int z = second ? z2 : z1; src[u] = t_fq(T, z); lim[u] = t_n(T, z);
+                const int z = (int)((mm >> 16) & 1u); src[u] = t_fq(T, z); lim[u] = t_n(T, z);
                 // base position (in the row) of the group's first byte once the row's orientation is applied: R1 as it stands, R2 back to front
-                pos0[u] = second ? L[u] - 16 * (int)j + (int)m - 16 : 16 * (int)j - (int)m;
-                edge[u] = on[u] && (unsigned long long)at[u] + 16ull > (unsigned long long)lim[u];
+                pos0[u] = second ? L[u] - 32 * (int)j + (int)m - 32 : 32 * (int)j - (int)m;
+                edge[u] = on[u] && (unsigned long long)at[u] + 32ull > (unsigned long long)lim[u];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0;
-                if (on[u] && !edge[u]) { const uint4 x = *(const uint4*)(src[u] + at[u]); v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; }
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[u][i] = 0;
+                if (on[u] && !edge[u]) { const uint4 x = *(const uint4*)(src[u] + at[u]), y = *(const uint4*)(src[u] + at[u] + 16u);
+                                         v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z; v[u][7] = y.w; }
             }
             if (__any(edge[0] || edge[1] || edge[2] || edge[3])) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], (long long)at[u], (uint64_t)lim[u]); v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; }
+                for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], (long long)at[u], (uint64_t)lim[u]), y = ld16_edge(src[u], (long long)at[u] + 16, (uint64_t)lim[u]);
+                                                           v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z; v[u][7] = y.w; }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (!on[u]) continue;
                 const bool second = row[u] >= 64u; const uint32_t pr = row[u] & 63u;
-                uint32_t cw = 0, nw = 0, badb = 0;                          // 16 codes, 16 N bits, 16 "neither A/C/G/T nor N" bits - byte b of the (re-oriented) group at bit b
+                unsigned long long cw = 0; uint32_t nw = 0, badb = 0;       // 32 codes, 32 N bits, 32 "neither A/C/G/T nor N" bits - byte b of the (re-oriented) group at bit b
                 if (!second) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { uint32_t c, nb, bd; ov2_pack_r1(v[u][i], c, nb, bd); cw |= c << (8 * i); nw |= nb << (4 * i); if (bd) badb |= (((bd & 0x01010101u) * 0x01020408u) >> 24) << (4 * i); }
+                    for (int i = 0; i < 8; i++) { uint32_t c, nb, bd; ov2_pack_r1(v[u][i], c, nb, bd); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); if (bd) badb |= (((bd & 0x01010101u) * 0x01020408u) >> 24) << (4 * i); }
                 } else {
-                    const uint32_t x[4] = { bswap32(v[u][3]), bswap32(v[u][2]), bswap32(v[u][1]), bswap32(v[u][0]) };
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { uint32_t c, nb; ov2_pack_rc(x[i], c, nb); cw |= c << (8 * i); nw |= nb << (4 * i); }
+                    for (int i = 0; i < 8; i++) { uint32_t c, nb; ov2_pack_rc(bswap32(v[u][7 - i]), c, nb); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); }
                 }
-                // keep the bases whose position lies inside the read, drop the `lo` leading ones, shift into place
-                const int lo = pos0[u] < 0 ? -pos0[u] : 0, hi = L[u] - pos0[u] < 16 ? L[u] - pos0[u] : 16;
+                // keep the bases whose position lies inside the read: drop the `lo` leading ones and everything from `hi` on, shift into place
+                const int lo = pos0[u] < 0 ? -pos0[u] : 0, hi = L[u] - pos0[u] < 32 ? L[u] - pos0[u] : 32;
                 if (hi <= lo) continue;
-                const uint32_t vm = ((hi >= 16 ? 0xFFFFu : (1u << hi) - 1u) >> lo) << lo;
-                uint32_t sp = vm; sp = (sp | (sp << 8)) & 0x00FF00FFu; sp = (sp | (sp << 4)) & 0x0F0F0F0Fu; sp = (sp | (sp << 2)) & 0x33333333u; sp = (sp | (sp << 1)) & 0x55555555u;
-                cw = (cw & (sp * 3u)) >> (2 * lo); nw = (nw & vm) >> lo;
-                if (badb & vm) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
+                const uint32_t nk = (uint32_t)(hi - lo);                   // 1..32 bases kept
+                const uint32_t km = nk >= 32u ? 0xFFFFFFFFu : (1u << nk) - 1u;
+                cw = (cw >> (2 * lo)) & (nk >= 32u ? ~0ull : (1ull << (2u * nk)) - 1ull); nw = (nw >> lo) & km;
+                if ((badb >> lo) & km) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
                 const uint32_t p = (uint32_t)(pos0[u] + lo);
-                uint32_t* const crow = (uint32_t*)((second ? c2 : c1) + pr * OV2_CROW); uint32_t* const nrow = (uint32_t*)((second ? n2 : n1) + pr * OV2_NROW);
-                const unsigned long long cv = (unsigned long long)cw << ((2u * p) & 31u), nv = (unsigned long long)nw << (p & 31u);
-                if ((uint32_t)cv) atomicOr(&crow[(2u * p) >> 5], (uint32_t)cv);
-                if ((uint32_t)(cv >> 32)) atomicOr(&crow[((2u * p) >> 5) + 1u], (uint32_t)(cv >> 32));
-                if ((uint32_t)nv) atomicOr(&nrow[p >> 5], (uint32_t)nv);
-                if ((uint32_t)(nv >> 32)) atomicOr(&nrow[(p >> 5) + 1u], (uint32_t)(nv >> 32));
+                uint32_t* const crow = (uint32_t*)((second ? c2 : c1) + pr * OV2_CROW) + ((2u * p) >> 5); uint32_t* const nrow = (uint32_t*)((second ? n2 : n1) + pr * OV2_NROW) + (p >> 5);
+                const uint32_t cs = (2u * p) & 31u, ns = p & 31u;
+                const unsigned long long cv = cw << cs; const uint32_t ctop = cs ? (uint32_t)(cw >> (64u - cs)) : 0u;
+                const unsigned long long nv = (unsigned long long)nw << ns;
+                if ((uint32_t)cv) atomicOr(&crow[0], (uint32_t)cv);
+                if ((uint32_t)(cv >> 32)) atomicOr(&crow[1], (uint32_t)(cv >> 32));
+                if (ctop) atomicOr(&crow[2], ctop);
+                if ((uint32_t)nv) atomicOr(&nrow[0], (uint32_t)nv);
+                if ((uint32_t)(nv >> 32)) atomicOr(&nrow[1], (uint32_t)(nv >> 32));
             }
         }
         wave_lds_sync();
@@ -931,37 +940,54 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int
         const bool go = fast && !bad; const int minlen = len1 < len2 ? len1 : len2;
         const uint8_t* const r1c = c1 + (uint32_t)l * OV2_CROW; const uint8_t* const r2c = c2 + (uint32_t)l * OV2_CROW;
         int ov = 0; bool done = !go || minlen < 12 || (abl & 1);
-        const int omax = wave_max(done ? 0 : minlen);
         const uint32_t head1 = lds_get4(r1c, 0) & 0xFFFFFFu, head2 = lds_get4(r2c, 0) & 0xFFFFFFu;
+        const uint32_t nd = ((uint32_t)mx + 15u) >> 4;          // dwords of a code row in use (16 bases each), wave-uniform
 #pragma unroll 1
         for (int dir = 0; dir < 2; dir++) {                     // 0: R1 tail == RC2 head (+o), 1: RC2 tail == R1 head (-o)
             const uint8_t* const wc = dir ? r2c : r1c; const int wl = dir ? len2 : len1; const uint32_t head = dir ? head1 : head2;
             if (DBG) { k3 = clock64(); if (dir) a_fwd += k3 - k2; }
             if (!__any(!done)) break;
-            const int wlc = go ? wl : 0;
-            for (int o0 = 12; o0 <= omax; o0 += OV2_BATCH) {
-                // the filter of OV2_BATCH = 16 candidates from ONE 64-bit window of the row: candidate o0 + u tests the 24 code bits from base
-                // wl - o0 - u on; the lowest start (u = 15) and the highest (u = 0) are 30 bits apart, + 24 bits + the start's 6-bit phase < 64
-                const int pb = wlc - o0 - (OV2_BATCH - 1); const uint32_t byte = (uint32_t)(pb < 0 ? 0 : pb) >> 2;
-                const unsigned long long w64 = lds_get8(wc, byte);
-                const int sh0 = 2 * (wlc - o0) - 8 * (int)byte;             // bit offset of candidate u = 0 inside the window; u-th: sh0 - 2u
-                uint32_t hits = 0;
+            // the filter, ALL window starts of the row at once: base i of the row starts a candidate (o = wl - i) when the OV2_FILTER bases
+            // from i on equal the head of the other read.  With the row as a bit string (2 bits per base), X_k = (row >> 2k) ^ (head's base k
+            // in every 2-bit group) has a zero group at i iff base i + k matches; OR over k leaves a zero group exactly at the starts that
+            // pass.  3 instructions per 16 candidates and head base (funnel shift, xor, or) instead of 7 per candidate; 8 bases let a
+            // random start through once in 65536 - 0.3 extra verifications per 64 pairs.
+            uint32_t W[17], Dm[16];
 #pragma unroll
-                for (int u = 0; u < OV2_BATCH; u++) { const uint32_t c = (uint32_t)(w64 >> ((uint32_t)(sh0 - 2 * u) & 63u)); hits |= ((((c ^ head) & 0xFFFFFFu) == 0u) ? 1u : 0u) << u; }
-                const int nval = minlen - o0 + 1;                           // candidates of the batch that exist for this pair (o <= minlen)
-                hits &= nval >= OV2_BATCH ? 0xFFFFu : (nval > 0 ? (1u << nval) - 1u : 0u);
-                if (done) hits = 0;
-                // the few that pass are verified by the whole wave, a lane's candidates in ascending order
+            for (int d = 0; d < 17; d++) W[d] = (uint32_t)d <= nd ? ((const uint32_t*)wc)[d] : 0u;
+#pragma unroll
+            for (int d = 0; d < 16; d++) Dm[d] = 0u;
+#pragma unroll
+            for (int k = 0; k < OV2_FILTER; k++) {
+                const uint32_t rep = ((head >> (2 * k)) & 3u) * 0x55555555u;
+#pragma unroll
+                for (int d = 0; d < 16; d++) if ((uint32_t)d < nd) {
+                    const uint32_t sk = k ? (uint32_t)(((((unsigned long long)W[d + 1]) << 32) | W[d]) >> (2 * k)) : W[d];
+                    Dm[d] |= sk ^ rep;
+                }
+            }
+            // the few starts that pass are verified by the whole wave; a lane's candidates in ascending o = descending start
+            const int i_lo = wl - minlen, i_hi = wl - 12;       // starts that exist for this pair (12 <= o <= minlen)
+#pragma unroll
+            for (int d = 15; d >= 0; d--) {
+                if ((uint32_t)d >= nd) continue;
+                uint32_t hits = done ? 0u : (~(Dm[d] | (Dm[d] >> 1)) & 0x55555555u);
+                if (!__any(hits != 0)) continue;                // wave-uniform
+                { const int a0 = i_lo - 16 * d, a1 = i_hi - 16 * d + 1;          // valid starts of this dword: [a0, a1)
+                  const int c0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0), c1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
+                  const unsigned long long below1 = (1ull << (2 * c1)) - 1ull, below0 = (1ull << (2 * c0)) - 1ull;
+                  hits &= (uint32_t)(below1 & ~below0); }
                 for (;;) {
                     const unsigned long long m = __ballot(hits != 0);
                     if (!m) break;                                       // wave-uniform
                     const int j = __ffsll((long long)m) - 1;
-                    const int uj = __shfl(__ffs((int)hits) - 1, j); const uint32_t o = (uint32_t)(o0 + uj);
+                    const int bit = hits ? 31 - __clz((int)hits) : 0;
+                    const uint32_t o = (uint32_t)__shfl(wl - (16 * d + (bit >> 1)), j);
                     const int jl = dir ? __shfl(len2, j) : __shfl(len1, j);
                     const uint8_t* ac = (dir ? c2 : c1) + (uint32_t)j * OV2_CROW; const uint8_t* an = (dir ? n2 : n1) + (uint32_t)j * OV2_NROW;
                     const uint8_t* bc = (dir ? c1 : c2) + (uint32_t)j * OV2_CROW; const uint8_t* bn = (dir ? n1 : n2) + (uint32_t)j * OV2_NROW;
                     const bool ok = ov2_verify(ac, an, bc, bn, (uint32_t)jl - o, o, l); if (DBG) n_ver++;
-                    if (l == j) { if (ok) { done = true; ov = dir ? -(int)o : (int)o; hits = 0; } else hits &= hits - 1u; }
+                    if (l == j) { if (ok) { done = true; ov = dir ? -(int)o : (int)o; hits = 0; } else hits &= ~(1u << bit); }
                 }
             }
         }
