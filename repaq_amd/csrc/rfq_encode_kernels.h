@@ -800,10 +800,10 @@ __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int 
 // codes and their N bits are equal - except a base of R1 outside A/C/G/T/N, which equals nothing (such pairs, and reads longer than
 // the rows, take wave_overlap above).  Every lane then filters ITS pair's candidates o = 12, 13, ...: a candidate passes when the
 // first 12 bases of its window equal the 12-base head of the other read - all window starts of the row at once, as bit-string
-// arithmetic on the row held in registers; the few that pass are verified by the whole wave (4 bases per lane, codes and N bits).
+// arithmetic on the row held in registers; the few that pass are verified in full (codes and N bits) by the same lane.
 // Forward before backward, smallest o first (src/rfqcodec.cpp:1391-1438).  The former wave-per-pair search cost ~600
-// wave-instructions per pair, the per-candidate filter (one 64-bit window per 16 candidates) ~35.
-#define OV2_CAP 256u              // bases per read held in a row (64 lanes x 4 bases verify one candidate in one step)
+// wave-instructions per pair, the per-candidate filter (one 64-bit window per 16 candidates) with wave-wide verification ~35.
+#define OV2_CAP 256u              // bases per read held in a row
 #define OV2_CROW 68u              // code row: 64 bytes + 4 of slack for the last unaligned word; 17 dwords, so that lanes reading their own rows at one offset hit 64 different banks
 #define OV2_NROW 36u              // N-bit row: 32 bytes + 4; 9 dwords
 #define OV2_WAVE_BYTES (128u * (OV2_CROW + OV2_NROW))
@@ -830,23 +830,12 @@ __device__ __forceinline__ void ov2_pack_rc(uint32_t w, uint32_t& code, uint32_t
     code = ((__builtin_amdgcn_perm(0u, 0x03010002u, idx) & ok) * 0x01041040u) >> 24;      // [A,C,T,G] -> codes of T,G,A,C
     nbits = ((~ok & 0x01010101u) * 0x01020408u) >> 24;
 }
-// window[pa .. pa+o) of row (ac, an) == head[0 .. o) of row (bc, bn): the whole wave, 4 bases per lane
-__device__ __forceinline__ bool ov2_verify(const uint8_t* ac, const uint8_t* an, const uint8_t* bc, const uint8_t* bn, uint32_t pa, uint32_t o, int l) {
-    const uint32_t b0 = 4u * (uint32_t)l; uint32_t diff = 0;
-    if (b0 < o) {
-        const uint32_t nb = o - b0 < 4u ? o - b0 : 4u, q = pa + b0;
-        const uint32_t ca = bfe_u32(lds_get4(ac, (2u * q) >> 3), (2u * q) & 7u, 8u), cb = bc[l];
-        const uint32_t na = bfe_u32(lds_get4(an, q >> 3), q & 7u, 4u), nbm = ((uint32_t)bn[l >> 1] >> (4u * ((uint32_t)l & 1u))) & 0xFu;
-        diff = ((ca ^ cb) & ((1u << (2u * nb)) - 1u)) | ((na ^ nbm) & ((1u << nb) - 1u));
-    }
-    return !__any(diff != 0);
-}
 // 256 pairs per block, 64 per wave.  Only pairs of interleaved chunks are examined (src/rfqcodec.cpp:371-386)
 // The search needs nothing but the text and its line table, so it runs for EVERY pair as soon as the index exists - on the second stream, beside
 // the read table, the cut, the header and the chunk flags (those are latency-bound, this is VALU-bound) - and leaves the raw offset (0 = none)
 // in ovraw; k_overlap_apply takes them over for the chunks that turn out to be interleaved under a header with BIT_ENCODE_PE_BY_OVERLAP.
 template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int16_t* __restrict__ ovraw, uint32_t n_pairs, unsigned long long* dbg, int abl) {
-    __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4)]; __shared__ uint32_t s_bad[4][2];
+    __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4) + 4]; __shared__ uint32_t s_bad[4][2];      // (+4: a verification step reads 9 bytes from a byte offset inside the last row)
     long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a_meta = 0, a_pack = 0, a_fwd = 0, a_bwd = 0, a_slow = 0; uint32_t n_ver = 0;
     const int l = lane_id(), w = wave_id();
     uint8_t* const c1 = (uint8_t*)(s_rows + (size_t)w * (OV2_WAVE_BYTES / 4)); uint8_t* const c2 = c1 + 64u * OV2_CROW;
@@ -966,28 +955,51 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int
                     Dm[d] |= sk ^ rep;
                 }
             }
-            // the few starts that pass are verified by the whole wave; a lane's candidates in ascending o = descending start
+            // the starts that pass are verified by their own lane, in ascending o = descending start: the window row from base wl - o on
+            // against the head of the other row, 32 bases (64 code bits) or 64 N bits per step - byte-granular 8-byte LDS reads + a
+            // sub-byte funnel shift.  (The whole wave used to verify ONE candidate at a time: ~27 rounds of ~45 instructions for 64 pairs.)
             const int i_lo = wl - minlen, i_hi = wl - 12;       // starts that exist for this pair (12 <= o <= minlen)
 #pragma unroll
-            for (int d = 15; d >= 0; d--) {
-                if ((uint32_t)d >= nd) continue;
-                uint32_t hits = done ? 0u : (~(Dm[d] | (Dm[d] >> 1)) & 0x55555555u);
-                if (!__any(hits != 0)) continue;                // wave-uniform
-                { const int a0 = i_lo - 16 * d, a1 = i_hi - 16 * d + 1;          // valid starts of this dword: [a0, a1)
-                  const int c0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0), c1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
-                  const unsigned long long below1 = (1ull << (2 * c1)) - 1ull, below0 = (1ull << (2 * c0)) - 1ull;
-                  hits &= (uint32_t)(below1 & ~below0); }
-                for (;;) {
-                    const unsigned long long m = __ballot(hits != 0);
-                    if (!m) break;                                       // wave-uniform
-                    const int j = __ffsll((long long)m) - 1;
-                    const int bit = hits ? 31 - __clz((int)hits) : 0;
-                    const uint32_t o = (uint32_t)__shfl(wl - (16 * d + (bit >> 1)), j);
-                    const int jl = dir ? __shfl(len2, j) : __shfl(len1, j);
-                    const uint8_t* ac = (dir ? c2 : c1) + (uint32_t)j * OV2_CROW; const uint8_t* an = (dir ? n2 : n1) + (uint32_t)j * OV2_NROW;
-                    const uint8_t* bc = (dir ? c1 : c2) + (uint32_t)j * OV2_CROW; const uint8_t* bn = (dir ? n1 : n2) + (uint32_t)j * OV2_NROW;
-                    const bool ok = ov2_verify(ac, an, bc, bn, (uint32_t)jl - o, o, l); if (DBG) n_ver++;
-                    if (l == j) { if (ok) { done = true; ov = dir ? -(int)o : (int)o; hits = 0; } else hits &= ~(1u << bit); }
+            for (int d = 0; d < 16; d++) {
+                if ((uint32_t)d >= nd) { Dm[d] = 0u; continue; }
+                const int a0 = i_lo - 16 * d, a1 = i_hi - 16 * d + 1;            // valid starts of this dword: [a0, a1)
+                const int e0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0), e1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
+                const unsigned long long below1 = (1ull << (2 * e1)) - 1ull, below0 = (1ull << (2 * e0)) - 1ull;
+                Dm[d] = done ? 0u : (~(Dm[d] | (Dm[d] >> 1)) & 0x55555555u & (uint32_t)(below1 & ~below0));
+            }
+            const uint8_t* const wn = (dir ? n2 : n1) + (uint32_t)l * OV2_NROW;    // window row's N bits; the other row: codes oc, N bits on
+            const uint8_t* const oc = dir ? r1c : r2c; const uint8_t* const on_ = (dir ? n1 : n2) + (uint32_t)l * OV2_NROW;
+            const uint32_t nch = ((uint32_t)mx + 31u) >> 5, nch2 = ((uint32_t)mx + 63u) >> 6;          // wave-uniform step counts
+            for (;;) {
+                int cand = -1;
+#pragma unroll
+                for (int d = 15; d >= 0; d--) if ((uint32_t)d < nd && cand < 0 && Dm[d]) cand = 16 * d + ((31 - __clz((int)Dm[d])) >> 1);
+                if (!__any(cand >= 0)) break;                    // wave-uniform
+                if (DBG) n_ver++;
+                const uint32_t pa = cand >= 0 ? (uint32_t)cand : 0u, o = cand >= 0 ? (uint32_t)(wl - cand) : 0u;
+                unsigned long long diff = 0;
+                for (uint32_t c = 0; c < nch; c++) {
+                    if (32u * c >= o) continue;
+                    const uint32_t bit = 2u * (pa + 32u * c), off = bit >> 3, sh = bit & 7u;
+                    unsigned long long x = lds_get8(wc, off) >> sh; if (sh) x |= (unsigned long long)wc[off + 8u] << (64u - sh);
+                    const uint32_t nb = o - 32u * c;
+                    diff |= (x ^ lds_get8(oc, 8u * c)) & (nb >= 32u ? ~0ull : (1ull << (2u * nb)) - 1ull);
+                }
+                for (uint32_t c = 0; c < nch2; c++) {
+                    if (64u * c >= o) continue;
+                    const uint32_t bit = pa + 64u * c, off = bit >> 3, sh = bit & 7u;
+                    unsigned long long x = lds_get8(wn, off) >> sh; if (sh) x |= (unsigned long long)wn[off + 8u] << (64u - sh);
+                    const uint32_t nb = o - 64u * c;
+                    diff |= (x ^ lds_get8(on_, 8u * c)) & (nb >= 64u ? ~0ull : (1ull << nb) - 1ull);
+                }
+                if (cand >= 0) {
+                    if (diff == 0) { done = true; ov = dir ? -(int)o : (int)o;
+#pragma unroll
+                        for (int d = 0; d < 16; d++) Dm[d] = 0u; }
+                    else {
+#pragma unroll
+                        for (int d = 0; d < 16; d++) if (d == (cand >> 4)) Dm[d] &= ~(1u << (2 * (cand & 15)));
+                    }
                 }
             }
         }
