@@ -257,6 +257,69 @@ def qual_case(seed: int):
     return b"".join(recs1), b"".join(recs2), paired, 100_000
 
 
+def overlap_case(seed: int):
+    """-> (fq1, fq2, paired, chunk_bases): pairs made to stress the overlap search (src/rfqcodec.cpp:1391-1438): low-complexity reads (homopolymers,
+    di- / tri-nucleotide repeats, a short motif with a few point changes) whose 8-base heads recur all along the mate - many candidates pass the
+    filter and fail in full, or succeed at the SMALLEST o only -, planted overlaps of every length from 12 up with 0 .. 2 mismatches (one mismatch
+    kills a candidate), N inside or outside the overlap, lengths around the 32-base pack groups and the 256-base rows; one file in eight holds a
+    lower-case or other character (a pair that leaves the 2-bit rows; the reference then refuses the file: both sides must)."""
+    r = random.Random(13000 + seed)
+    paired = r.choice([O.PE_TWO_FILES, O.PE_INTERLEAVED])
+    n = r.randint(20, 160)
+    quals = bytes(r.sample(range(35, 75), 4))
+    lens = [12, 13, 20, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 150, 151, 200, 250, 255, 256, 257, 300]
+    odd = r.random() < 0.12; odd_at = r.randrange(n)
+
+    def lowc(L):
+        t = r.random()
+        if t < 0.25:
+            return bytes([r.choice(b"ACGT")]) * L
+        if t < 0.5:
+            m = bytes(r.choice(b"ACGT") for _ in range(r.choice([2, 3, 4, 5, 7])))
+            return (m * (L // len(m) + 1))[:L]
+        if t < 0.75:
+            m = bytes(r.choice(b"ACGT") for _ in range(r.choice([8, 9, 12, 16, 24])))
+            b = bytearray((m * (L // len(m) + 1))[:L])
+            for _ in range(r.randint(0, 3)):
+                b[r.randrange(L)] = r.choice(b"ACGT")
+            return bytes(b)
+        return bytes(r.choice(b"ACGT") for _ in range(L))
+
+    recs1, recs2 = [], []
+    for i in range(n):
+        L1 = r.choice(lens) if r.random() < 0.7 else r.randint(1, 300)
+        s1 = bytearray(lowc(L1))
+        L2 = L1 if r.random() < 0.5 else (r.choice(lens) if r.random() < 0.7 else r.randint(1, 300))
+        mode = r.random(); m = min(L1, L2)
+        if mode < 0.45 and m >= 12:                               # R1 tail == RC(R2) head
+            ov = r.choice([12, 13, m, m - 1 if m > 12 else 12, r.randint(12, m)])
+            rc2 = bytearray(bytes(s1[L1 - ov:]) + lowc(max(1, L2 - ov)))[:L2]
+        elif mode < 0.7 and m >= 12:                              # RC(R2) tail == R1 head
+            ov = r.choice([12, m, r.randint(12, m)])
+            rc2 = bytearray(lowc(max(1, L2 - ov)) + bytes(s1[:ov]))[-L2:]
+        elif mode < 0.85:
+            rc2 = bytearray(s1[:L2] if L2 <= L1 else bytes(s1) + lowc(L2 - L1))   # the same low-complexity text: candidates everywhere
+        else:
+            rc2 = bytearray(lowc(L2))
+        if len(rc2) < L2:
+            rc2 = rc2 + bytearray(lowc(L2 - len(rc2)))
+        for _ in range(r.choice([0, 0, 0, 1, 2])):                 # point changes after the overlap was planted
+            b = s1 if r.random() < 0.5 else rc2
+            b[r.randrange(len(b))] = r.choice(b"ACGT")
+        t = r.random()
+        if t < 0.15:
+            b = s1 if r.random() < 0.5 else rc2; b[r.randrange(len(b))] = 78                 # N
+        elif odd and i == odd_at:                                                              # (the reference refuses such a file as a whole - after the search has met the pair)
+            b = s1 if r.random() < 0.5 else rc2; b[r.randrange(len(b))] = r.choice(b"acgtnRYKM.")
+        s2 = bytes(COMP.get(c, c) if c in COMP else c for c in reversed(bytes(rc2)))
+        name = b"@M01:26:FCX:1:%d:%d:%d 1:N:0:AC" % (1101 + i // 50, 1000 + i * 3, 2000 + i)
+        recs1.append(name + b"\n" + bytes(s1) + b"\n+\n" + bytes(r.choices(quals, k=len(s1))) + b"\n")
+        recs2.append(name.replace(b" 1:", b" 2:") + b"\n" + s2 + b"\n+\n" + bytes(r.choices(quals, k=len(s2))) + b"\n")
+    if paired == O.PE_INTERLEAVED:
+        return b"".join(a + b for a, b in zip(recs1, recs2)), b"", paired, 100_000
+    return b"".join(recs1), b"".join(recs2), paired, 100_000
+
+
 def check_gen(codec, encode, gen, seed):
     """gen(seed): encode == oracle (or both refuse), decode(oracle image) == oracle decode."""
     from repaq_amd import RfqError

@@ -69,6 +69,39 @@ def test_oracle_equals_reference_binary_on_shape_fuzz_inputs(gen, seed, tmp_path
     assert want == O.ref_encode(fq1, fq2, paired, cb // 1000, tmpdir=str(tmp_path))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_overlap_fuzz_on_simt_emulation(seed):
+    """low-complexity pairs, planted overlaps with point changes, N and odd characters: many candidates pass the search's filter (tests/_fuzz.py)"""
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    try:
+        assert F.check_gen(c, E.encode, F.overlap_case, seed) in ("ok", "error")
+    finally:
+        c.close()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="needs the compiled reference (oracle/_ref/repaq)")
+@pytest.mark.parametrize("seed", range(24))
+def test_oracle_equals_reference_binary_on_overlap_fuzz_inputs(seed, tmp_path):
+    fq1, fq2, paired, cb = F.overlap_case(seed)
+    try:
+        want = O.encode_file(fq1, fq2, paired, cb)
+    except O.OracleError:
+        pytest.skip("a file the reference refuses (a base outside A/C/G/T/N)")
+    assert want == O.ref_encode(fq1, fq2, paired, cb // 1000, tmpdir=str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_overlap_fuzz_on_gpu():
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.PRODUCT_LIB)
+    try:
+        outcomes = [F.check_gen(c, E.encode, F.overlap_case, seed) for seed in range(300)]
+    finally:
+        c.close()
+    assert outcomes.count("ok") > 240 and outcomes.count("ok") + outcomes.count("error") == 300
+
+
 @pytest.mark.gpu
 def test_shape_fuzz_on_gpu():
     from repaq_amd import RfqCodec
