@@ -1338,7 +1338,7 @@ __device__ __forceinline__ Raw64 pc_load_raw(const uint8_t* __restrict__ B, uint
     else { r.v[0] = z; r.v[1] = z; r.v[2] = z; r.v[3] = z; }
     return r;
 }
-__device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uint32_t p0, int mode, uint32_t q, const DevHeader* __restrict__ D) {
+__device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uint32_t p0, int mode, uint32_t q, const DevHeader* __restrict__ D, const uint8_t* exc_tab = nullptr) {
     if (p0 >= len) return 0ull;
     uint64_t m = 0;
     const uint4* p = r.v;
@@ -1359,18 +1359,20 @@ __device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uin
                 for (int k = 0; k < 4; k++) known |= (uint64_t)eq_mask16(p[k], pj) << (16 * k); }
             m = ~known;
         } else {
-            uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            for (uint32_t v = 0; v < 256; v++) if (!D->is_exception[v]) { const uint64_t bit = 1ull << (v & 63u); if (v < 64) a0 |= bit; else if (v < 128) a1 |= bit; else if (v < 192) a2 |= bit; else a3 |= bit; }
+            // many values: exc_tab = the header's 256-entry "is an exception" table in LDS (its 64 words lie in 64 banks: any 64 byte reads are
+            // conflict-free); one read per position.  (Rebuilding a 256-bit set from the header in every call - a 256-step scalar loop - and
+            // testing it with 64-bit selects and shifts cost ~3600 instructions per step, eight times a value stream's.)
+            uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint4 w = p[k]; const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
 #pragma unroll
                 for (int t = 0; t < 16; t++) {
-                    const uint32_t b = (ww[t >> 2] >> (8 * (t & 3))) & 0xFFu; const uint32_t hi = b >> 6;
-                    const uint64_t set = hi == 0 ? a0 : (hi == 1 ? a1 : (hi == 2 ? a2 : a3));
-                    if (!((set >> (b & 63u)) & 1ull)) m |= 1ull << (16 * k + t);
+                    const uint32_t e = exc_tab[(ww[t >> 2] >> (8 * (t & 3))) & 0xFFu];
+                    if (k < 2) lo |= e << (16 * k + t); else hi |= e << (16 * (k - 2) + t);
                 }
             }
+            m = ((uint64_t)hi << 32) | lo;
         }
     }
     if (len - p0 < 64) m &= (1ull << (len - p0)) - 1ull;
@@ -1432,7 +1434,7 @@ struct PcStream {
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
 // with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  The bytes go to S[t].out[0..).
 template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
-                                                                           PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift) {
+                                                                           PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift, const uint8_t* exc_tab) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
     // software pipeline, two steps deep: raw bytes of step+2 are in flight while step is coded; a step's raw bytes become masks
@@ -1457,7 +1459,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
 #pragma unroll
             for (int t = 0; t < G; t++) {
                 if (!need[t]) continue;
-                const uint64_t z = ~pc_mask_of(rb, len, pb, MODE, S[t].q, D);
+                const uint64_t z = ~pc_mask_of(rb, len, pb, MODE, S[t].q, D, exc_tab);
                 const unsigned long long h0 = __ballot(z != 0);
                 if (h0) { const int v = z ? (int)pb + 63 - __clzll((long long)z) : -1; S[t].zero_carry = __shfl(v, 63 - __clzll((long long)h0)); need[t] = false; }
                 else any = true;
@@ -1465,7 +1467,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
         }
     }
 #pragma unroll
-    for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D); S[t].outpos = 0; }
+    for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D, exc_tab); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D, exc_tab); S[t].outpos = 0; }
     raw_n = loadc(step0 + 2, q0 + 8192u);
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
@@ -1512,7 +1514,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
             if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > s.zero_carry) s.zero_carry = zl; }
         }
 #pragma unroll
-        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D); }
+        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D, exc_tab); }
         raw_n = loadc(step + 3, p0 + 12288u);
     }
 }
@@ -1522,7 +1524,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
 // written here.  Streams whose value does not occur in the chunk (histogram) are skipped outright.
 template <int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg,
-                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st) {
+                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st, const uint8_t* exc_tab = nullptr) {
     const uint32_t nshift = nmap ? nmap_shift(len) : 0u;
     const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
     const uint32_t step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
@@ -1552,7 +1554,7 @@ template <int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab&
         S[t].out = scratch + cbase[c] + C.soff[k] + off; S[t].room = off + own <= cap ? own : 0u;
     }
     if (!any) return;                                                      // wave-uniform
-    wave_pos_encode_group<MODE, G>(B, len, D, S, step0, step1, nmap, nshift);
+    wave_pos_encode_group<MODE, G>(B, len, D, S, step0, step1, nmap, nshift, exc_tab);
 #pragma unroll
     for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) {
         segb[kk[t] * n_seg + seg] = S[t].outpos;
@@ -1578,7 +1580,12 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
     if (grp < n_qgroups) pc_run<PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
-    else if (grp == n_qgroups) pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st);
+    else if (grp == n_qgroups) {
+        __shared__ uint8_t s_exc[256];                                      // (a workgroup is one wave)
+        for (uint32_t v = (uint32_t)lane_id(); v < 256u; v += 64u) s_exc[v] = D->is_exception[v] ? 1 : 0;
+        wave_lds_sync();
+        pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st, s_exc);
+    }
     else pc_run<PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
