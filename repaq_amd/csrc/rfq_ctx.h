@@ -56,7 +56,7 @@ static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, u
     if (!n_chunks || !slots) return 1;
     for (uint32_t k = 6; k <= 12; k++) {
         uint32_t bx = (uint32_t)(((uint64_t)k * slots + n_chunks / 2) / n_chunks);
-        if (bx < 1) bx = 1; if (bx > tiles_per_chunk) bx = tiles_per_chunk; if (bx < 1) bx = 1;
+        bx = std::max<uint32_t>(1u, std::min<uint32_t>(std::max<uint32_t>(bx, 1u), tiles_per_chunk));
         const double rounds = (double)bx * n_chunks / slots, full = (double)(uint64_t)(rounds + 0.999999), eff = full > 0 ? rounds / full : 0.0;
         if (eff > best_eff + 1e-3) { best = bx; best_eff = eff; }
     }

@@ -64,7 +64,8 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
 #define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
         const uint32_t m_ = (fl & (LENFLAG)) ? 1u : s; OFF = (uint32_t)q; if (q + m_ > left) return 2; \
         uint32_t sum_ = (fl & (LENFLAG)) ? (uint32_t)p[q] : wave_sum_bytes(p + q, m_); \
-        if ((fl & (LENFLAG)) && !(fl & (SAMEFLAG))) sum_ *= s; SIZE = sum_; q += m_; }
+        if ((fl & (LENFLAG)) && !(fl & (SAMEFLAG))) { sum_ *= s; } \
+        SIZE = sum_; q += m_; }
     RFQ_LENARR(d.o_n1lens, d.n1_size, C_NAME1_LEN_SAME, C_NAME1_SAME)
     d.o_n2lens = (uint32_t)q; d.n2_size = 0;
     if (hf & H_NAME2) RFQ_LENARR(d.o_n2lens, d.n2_size, C_NAME2_LEN_SAME, C_NAME2_SAME)
@@ -99,9 +100,11 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
         d.rbase = (uint32_t)rb; d.rbase_abs = (uint32_t)rb;
         if (c < cap) { if (l == 0) out[c] = d; } else ovf = 1;
         if (d.reads > maxr) maxr = d.reads;
-        if (d.qual_size > maxs) maxs = d.qual_size; if (d.npos_size > maxn) maxn = d.npos_size;
+        if (d.qual_size > maxs) maxs = d.qual_size;
+        if (d.npos_size > maxn) maxn = d.npos_size;
         lastfl = d.flags; rb += d.reads; k += d.total; c++; tb += d.bases;
-        if (d.max_len > maxl) maxl = d.max_len; { const uint32_t b32 = d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases; if (b32 > maxb) maxb = b32; }
+        if (d.max_len > maxl) maxl = d.max_len;
+        { const uint32_t b32 = d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases; if (b32 > maxb) maxb = b32; }
         if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
     }
     if (l == 0) { st->max_len = maxl; st->max_bases = maxb; st->base_slots[0] = tb; st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
@@ -197,7 +200,9 @@ __global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint
     uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0; unsigned long long sum = 0;
     for (uint32_t c = first + threadIdx.x; c < end; c += blockDim.x) {
         const DChunk& d = CH[c];
-        if (d.qual_size > m0) m0 = d.qual_size; if (d.npos_size > m1) m1 = d.npos_size; if (d.max_len > m2) m2 = d.max_len;
+        if (d.qual_size > m0) m0 = d.qual_size;
+        if (d.npos_size > m1) m1 = d.npos_size;
+        if (d.max_len > m2) m2 = d.max_len;
         const uint32_t b32 = d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases; if (b32 > m3) m3 = b32;
         if (d.nrec > m4) m4 = d.nrec;
         sum += d.bases;
@@ -833,7 +838,8 @@ __global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __r
     if (threadIdx.x == 0) {
         unsigned long long a = 0, b = 0; for (uint32_t i = 0; i < (blockDim.x >> 6); i++) { a += s_t[0][i]; b += s_t[1][i]; }
         const uint32_t slot = (blockIdx.y * 7u + blockIdx.x) & 63u;
-        if (a) atomicAdd((unsigned long long*)&st->text_slots[0][slot], a); if (b) atomicAdd((unsigned long long*)&st->text_slots[1][slot], b);
+        if (a) atomicAdd((unsigned long long*)&st->text_slots[0][slot], a);
+        if (b) atomicAdd((unsigned long long*)&st->text_slots[1][slot], b);
     }
 }
 // ---- text emission (name re-assembly src/rfqcodec.cpp:1157-1231, overlap re-expansion :865-897, implied N :1093-1100, RC of odd
