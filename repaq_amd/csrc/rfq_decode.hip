@@ -27,7 +27,7 @@ static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk
 #undef RFQ_LIST_ARGS
 }
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
-struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one; };
+struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one; uint64_t bases; };   // bases: sum of the range's read lengths (the walk's 64-bit total)
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
 // out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
@@ -40,6 +40,44 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     const uint32_t n_chunks = g.n_chunks, n_reads = g.n_reads, max_reads = std::max(g.max_reads, 1u);
     const DChunk* CH = g.CH;
     HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
+    // ---- the position-list chain of the fused path (rfq_decode_kernels.h "fused path"): the emitter builds qualities and bases tile by tile in LDS
+    // from the packed bytes and lists of coded positions; the lists need nothing but the chunk table, so their chain (stream summaries, link,
+    // offsets, lists + cell index) starts NOW on the second stream, beside read table, prefixes, coordinates and text lengths, and is joined in
+    // front of the last status read-back before the emitter.  Taken for files with few quality streams whose reads and exception lists fit a
+    // tile; RFQ_TUNE bit 11 forces the materialising path.
+    const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
+    const bool rle_h = !(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL));          // legacy run-length quality coding: k_dec_rle on the materialising path
+    const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u;
+    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S; const uint32_t f_nstr = HH.n_normal + 1;
+    struct AuxJoin { rfq_ctx* c; bool armed; ~AuxJoin() { if (armed) (void)hipStreamSynchronize(c->aux); } } aux_guard = { ctx, false };   // (an early return must not leave the chain running over buffers the next call reuses)
+    if (fused) {
+        const bool hasn = (HH.flags & H_N_POS) != 0; const uint32_t nn = bycol_h ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u;
+        const bool forked = ctx->aux_ready(); hipStream_t A = forked ? ctx->aux : S;
+        if (nn || hasn) {
+            if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); aux_guard.armed = true; }
+            const uint32_t mq = nn ? g.max_one / POS2_SEG + 1 : 0u, mn = hasn ? g.max_npos / POS2_SEG + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
+            f_ncell = g.max_bases / POS2_CELL + 2;
+            const size_t nst = (size_t)n_chunks * f_nstr, nseg = nst * f_maxseg, ncl = nst * f_ncell;
+            HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 32 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure(nst * 4 + 16));
+            HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_SEGK].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_CELL].ensure(ncl * 4 + 16));
+            HIPCHK(ctx, B[DB_NENT].ensure(nst * 4 + 16)); HIPCHK(ctx, B[DB_LOFF].ensure(nst * 8 + 16));
+            // the arena of the position lists: a position belongs to at most one stream, the coded ones are a few percent of the bases; if a
+            // file needs more than the arena holds, k_dec_pos_list leaves it alone and the pass is repeated below with the right size
+            HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 2 + 1024) * 4));
+            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
+#define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
+            if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);
+            if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr);
+#undef RFQ_SUM2_ARGS
+            hipLaunchKernelGGL(k_dec_pos_link2, dim3((uint32_t)((nst + 3) / 4)), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
+                               (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_SEGK].as<uint32_t>(), B[DB_NENT].as<uint32_t>(), f_maxseg, (uint32_t)nst);
+            hipLaunchKernelGGL(k_dec_pos_off, dim3(1), dim3(256), 0, A, (const uint32_t*)B[DB_NENT].as<uint32_t>(), B[DB_LOFF].as<unsigned long long>(), (uint32_t)nst, dst);
+            launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, A);
+            f_lists = true; f_mq = mq; f_mn = mn; f_nn = nn; f_hasn = hasn;
+            f_join = forked; f_aux = A;
+            KCHK(ctx, "k_dec_pos_*");
+        }
+    }
     // ---- read table + prefixes
     ctx->timer.begin("read_table", S);
     const size_t nr = (size_t)n_reads + 2, nc = (size_t)n_chunks + 2;
@@ -63,45 +101,11 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");
     *nbases = total_bases;
 
-    // ---- streams
-    // Fused path (rfq_decode_kernels.h "fused path"): the emitter builds qualities and bases tile by tile in LDS from the packed bytes and the
-    // position tokens; what runs here is the coordinate decoder and, beside it, the one-step stream summaries + their link / cell index.
-    // Taken for files with few quality streams whose reads and exception lists fit a tile; RFQ_TUNE bit 11 forces the materialising path.
-    const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
-    const bool rle_h = !(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL));          // legacy run-length quality coding: k_dec_rle on the materialising path
-    const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u;
-    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S; const uint32_t f_nstr = HH.n_normal + 1;
+    // ---- streams (fused path: the coordinate decoder here, the list chain has been running since the top)
     if (fused) {
         ctx->timer.begin("streams", S);
-        const bool hasn = (HH.flags & H_N_POS) != 0; const uint32_t nn = bycol_h ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u;
-        const bool forked = ctx->aux_ready(); hipStream_t A = forked ? ctx->aux : S;
-        if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); }
         hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
-        if (nn || hasn) {
-            const uint32_t mq = nn ? g.max_one / POS2_SEG + 1 : 0u, mn = hasn ? g.max_npos / POS2_SEG + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
-            f_ncell = g.max_bases / POS2_CELL + 2;
-            const size_t nst = (size_t)n_chunks * f_nstr, nseg = nst * f_maxseg, ncl = nst * f_ncell;
-            HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 32 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure(nst * 4 + 16));
-            HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_SEGK].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_CELL].ensure(ncl * 4 + 16));
-            HIPCHK(ctx, B[DB_NENT].ensure(nst * 4 + 16)); HIPCHK(ctx, B[DB_LOFF].ensure(nst * 8 + 16));
-            // the arena of the position lists: a position belongs to at most one stream, the coded ones are a few percent of the bases; if a
-            // file needs more than the arena holds, k_dec_pos_list leaves it alone and the pass is repeated below with the right size
-            HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(((uint64_t)total_bases + pv_tot.d) / 4 + 1024) * 4));
-            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
-#define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
-            if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);
-            if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr);
-#undef RFQ_SUM2_ARGS
-            hipLaunchKernelGGL(k_dec_pos_link2, dim3((uint32_t)((nst + 3) / 4)), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
-                               (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_SEGK].as<uint32_t>(), B[DB_NENT].as<uint32_t>(), f_maxseg, (uint32_t)nst);
-            hipLaunchKernelGGL(k_dec_pos_off, dim3(1), dim3(256), 0, A, (const uint32_t*)B[DB_NENT].as<uint32_t>(), B[DB_LOFF].as<unsigned long long>(), (uint32_t)nst, dst);
-            launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, A);
-            f_lists = true; f_mq = mq; f_mn = mn; f_nn = nn; f_hasn = hasn;
-        }
-        // (no join yet: the text lengths and their prefix - the main stream's next kernels - need the coordinates, not the lists; the two chains
-        // meet in front of the status read-back below, and the "streams" stage runs until then)
-        f_join = forked; f_aux = A;
-        KCHK(ctx, "k_dec_streams");
+        KCHK(ctx, "k_dec_coords");
     }
     uint64_t* qbase = nullptr; uint64_t* sbase = nullptr; uint8_t* qdec = nullptr; uint8_t* sdec = nullptr; size_t qbytes = 0, sbytes = 0;
     if (!fused) {
@@ -161,6 +165,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
     scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
     if (f_join) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, f_aux)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
+    aux_guard.armed = false;       // (everything below is ordered behind the chain on the main stream)
     U4 tt;
     HIPCHK(ctx, ctx->fetch(&tt, R.tp + n_reads, 16, S));
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
@@ -306,7 +311,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
     if (tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
-        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one;
+        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.bases = tb;
         rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
         if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
     }
@@ -330,10 +335,10 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         for (size_t i = 0; i < ctx->timer.names.size() && i < 1; i++) acc_ms.emplace_back(ctx->timer.names[i], ctx->timer.ms[i]);
         while (!todo.empty()) {
             const auto r = todo.back(); todo.pop_back();
-            const uint32_t c0 = r.first, c1 = r.second; uint64_t reads = 0; for (uint32_t c = c0; c < c1; c++) reads += hc[c].reads;
+            const uint32_t c0 = r.first, c1 = r.second; uint64_t reads = 0, rbases = 0; for (uint32_t c = c0; c < c1; c++) { reads += hc[c].reads; rbases += hc[c].bases; }
             hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
             KCHK(ctx, "k_dec_rebase");
-            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one;
+            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.bases = rbases;
             uint8_t *q1 = nullptr, *q2 = nullptr; size_t m1 = 0, m2 = 0; uint64_t mb = 0;
             ctx->timer.reset();
             rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);
