@@ -4,11 +4,12 @@
 // compare JSON live here; every byte of codec work happens on the GPU (there is no CPU codec in this binary).
 //
 // I/O pipeline: readers fill page-locked staging blocks (16 MB) ahead of the codec - a regular file by several
-// threads with pread, block i always before block i+1 is handed out; stdin, .gz through zlib like src/fastqreader.cpp:31-37 and .xz
-// through an `xz -d -c` pipe like src/main.cpp:160-177 by one thread, two blocks ahead so that the end of the input is known in time.
+// threads with pread, block i always before block i+1 is handed out; stdin, .gz (src/fastqreader.cpp:31-37: blocked gzip is inflated on
+// many threads, a plain gzip stream by zlib) and .xz through an `xz -d -c` pipe like src/main.cpp:160-177 by one reader, two blocks ahead
+// so that the end of the input is known in time.
 // The main thread moves blocks into a device-resident batch (256 MB by default: the codec's fixed cost per call is paid per batch, not
 // per staging block), runs the codec and copies results out piece by piece into page-locked buffers; writers drain them - a regular
-// file by several threads with pwrite at each piece's offset, stdout / .gz (zlib like src/writer.cpp:39-51) / .rfq.xz (an `xz -z -c`
+// file by several threads with pwrite at each piece's offset, stdout / .gz (src/writer.cpp:39-51; written as blocked gzip, deflated on many threads) / .rfq.xz (an `xz -z -c`
 // pipe like src/main.cpp:134-159) by one thread in order.  Inputs and outputs of any size stream through: nothing is slurped.
 #include "rfq_hip.h"
 #include <zlib.h>
@@ -16,6 +17,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -58,17 +60,126 @@ static const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_cl
 static bool g_trace = false;
 static void trace_mark(const char* what) { if (g_trace) fprintf(stderr, "[trace] %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count(), what); }
 
+// ------------------------------------------------------------------------------------------------ blocked gzip (BGZF)
+// A .gz is one deflate stream in the reference (src/writer.cpp:39-51, src/fastqreader.cpp:31-37): one core, ~100 MB/s out, ~300 MB/s in - three
+// orders of magnitude under the codec.  gzip members may be concatenated, so the driver WRITES a .gz as independent members of <= 64 KiB, each
+// carrying its compressed size in a 'BC' extra field (the BGZF layout of the SAM specification, what bgzip writes): every reader of gzip (zlib's
+// gzread, gunzip, the reference) reads it as the same text, and the members deflate on all the I/O threads at once.  READING, a .gz whose
+// members carry that field is inflated block-parallel the same way; any other .gz goes through zlib's gzread as before (a plain gzip stream
+// cannot be entered in the middle).
+static const size_t BGZF_TEXT = 0xff00;                                      // text bytes per member (bgzip's block size)
+template <class F> static void parallel_for(size_t n, int threads, F fn) {
+    const size_t nt = std::min<size_t>((size_t)std::max(1, threads), n);
+    if (nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0}; std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back([&] { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) return; fn(i); } });
+    for (auto& t : th) t.join();
+}
+// threads for deflate / inflate of blocked gzip: the I/O threads, and up to 32 of half the host's cores (the codec leaves the host idle)
+static int gz_threads(const Options& o) { const int hw = (int)std::thread::hardware_concurrency(); return std::max(std::max(1, std::max(o.threads, o.ioThreads)), std::min(32, hw / 2)); }
+// one member: 18-byte header (extra field 'B','C',2,BSIZE = member size - 1), raw deflate, crc32, text size
+static void bgzf_member(const uint8_t* p, size_t n, int level, std::vector<uint8_t>& out) {
+    out.resize(18 + compressBound((uLong)n) + 16 + 8);
+    z_stream z; memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) error_exit("zlib: deflateInit2 failed");
+    z.next_in = (Bytef*)p; z.avail_in = (uInt)n; z.next_out = out.data() + 18; z.avail_out = (uInt)(out.size() - 18 - 8);
+    if (deflate(&z, Z_FINISH) != Z_STREAM_END) error_exit("zlib: deflate failed");
+    const size_t zn = z.total_out; deflateEnd(&z);
+    const size_t total = 18 + zn + 8;
+    if (total > 65536) error_exit("internal: a gzip block outgrew 64 KiB");      // (0xff00 bytes of text cannot: stored blocks add 5 bytes per 64 KiB)
+    const uint8_t h[18] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((total - 1) & 0xff), (uint8_t)((total - 1) >> 8) };
+    memcpy(out.data(), h, 18);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n), isz = (uint32_t)n;
+    uint8_t* t = out.data() + 18 + zn;
+    for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isz >> (8 * i)); }
+    out.resize(total);
+}
+// the member that starts at h (>= 18 bytes visible): its size if it is a BGZF member, else 0
+static size_t bgzf_member_size(const uint8_t* h) {
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+    const size_t xlen = h[10] | ((size_t)h[11] << 8);
+    if (xlen != 6 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0) return 0;   // (bgzip writes exactly this; a member with more subfields takes the serial path)
+    return (size_t)(h[16] | ((size_t)h[17] << 8)) + 1;
+}
+
 // ------------------------------------------------------------------------------------------------ byte sources / sinks
-struct ByteSource {                      // sequential bytes of a plain file, stdin, a .gz (zlib) or a .xz (xz -d -c pipe)
-    FILE* f = nullptr; gzFile gz = nullptr; bool piped = false; std::string path;
-    bool open(const std::string& p) {
-        path = p;
-        if (ends_with(p, ".gz")) { gz = gzopen(p.c_str(), "rb"); if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr; }
+struct ByteSource {                      // sequential bytes of a plain file, stdin, a .gz (block-parallel when blocked, else zlib) or a .xz (xz -d -c pipe)
+    FILE* f = nullptr; gzFile gz = nullptr; bool piped = false; std::string path; int zthreads = 1;
+    // blocked gzip: compressed bytes are read ahead into zbuf; `left` = text of a member that did not fit the caller's buffer
+    bool bgzf = false; int zfd = -1; std::vector<uint8_t> zbuf; size_t zpos = 0, zend = 0; uint64_t zoff = 0; bool zeof = false; std::vector<uint8_t> left; size_t left_pos = 0;
+    bool open(const std::string& p, int threads = 1) {
+        path = p; zthreads = std::max(1, threads);
+        if (ends_with(p, ".gz")) {
+            zfd = ::open(p.c_str(), O_RDONLY);
+            if (zfd >= 0) {
+                uint8_t h[18]; const ssize_t k = pread(zfd, h, 18, 0);
+                if (k == 18 && bgzf_member_size(h) >= 26) { bgzf = true; zbuf.resize((size_t)8 << 20); return true; }
+                ::close(zfd); zfd = -1;
+            }
+            gz = gzopen(p.c_str(), "rb"); if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr;
+        }
         if (ends_with(p, ".xz")) { f = popen(("xz -d -c '" + p + "'").c_str(), "r"); piped = true; return f != nullptr; }
         f = p == "/dev/stdin" ? stdin : fopen(p.c_str(), "rb");
         return f != nullptr;
     }
+    // more compressed bytes behind zbuf[zpos, zend) (moved to the front first); false at the end of the file
+    bool zfill() {
+        if (zeof) return false;
+        if (zpos) { memmove(zbuf.data(), zbuf.data() + zpos, zend - zpos); zend -= zpos; zpos = 0; }
+        if (zend == zbuf.size()) zbuf.resize(zbuf.size() * 2);
+        const ssize_t k = pread(zfd, zbuf.data() + zend, zbuf.size() - zend, (off_t)zoff);
+        if (k < 0) error_exit("Error to read gzip file");
+        if (k == 0) { zeof = true; return false; }
+        zend += (size_t)k; zoff += (uint64_t)k; return true;
+    }
+    size_t read_bgzf(uint8_t* dst, size_t cap) {
+        size_t got = 0;
+        while (got < cap) {
+            if (left_pos < left.size()) { const size_t k = std::min(cap - got, left.size() - left_pos); memcpy(dst + got, left.data() + left_pos, k); got += k; left_pos += k; continue; }
+            if (gz) { const int n = gzread(gz, dst + got, (unsigned)std::min<size_t>(cap - got, 1u << 30)); if (n < 0) error_exit("Error to read gzip file"); if (n == 0) break; got += (size_t)n; continue; }
+            // the members that fit what is left of dst: where each starts (relative to zpos: refills move the buffer's content), and where its text goes
+            struct Mem { size_t at, size, text, out; }; std::vector<Mem> ms; size_t out = got, rel = 0; bool spill = false, foreign = false;
+            auto need = [&](size_t bytes) -> bool { while (zend - zpos < rel + bytes) if (!zfill()) return false; return true; };   // bytes visible from the next member's start on
+            for (;;) {
+                if (!need(1)) break;                                           // nothing behind the last member: the end of the file
+                if (!need(18)) error_exit("Error to read gzip file");
+                const size_t sz = bgzf_member_size(zbuf.data() + zpos + rel);
+                if (sz < 26) { foreign = true; break; }                        // a member of another shape: zlib takes over from here (below)
+                if (!need(sz)) error_exit("Error to read gzip file");
+                const uint8_t* e = zbuf.data() + zpos + rel + sz - 4; const size_t text = (size_t)e[0] | ((size_t)e[1] << 8) | ((size_t)e[2] << 16) | ((size_t)e[3] << 24);
+                if (text > 65536) error_exit("Error to read gzip file");
+                if (out + text > cap) { if (ms.empty()) { ms.push_back(Mem{ rel, sz, text, 0 }); rel += sz; spill = true; } break; }
+                ms.push_back(Mem{ rel, sz, text, out }); out += text; rel += sz;
+                if (ms.size() >= 4096) break;
+            }
+            for (auto& m : ms) m.at += zpos;
+            if (ms.empty() && !foreign) break;                                 // end of the file
+            if (spill) { left.resize(ms[0].text); left_pos = 0; }
+            const uint8_t* zb = zbuf.data(); uint8_t* lp = left.data(); const bool sp = spill;
+            parallel_for(ms.size(), zthreads, [&](size_t i) {
+                const Mem& m = ms[i]; uint8_t* o = sp ? lp : dst + m.out;
+                z_stream z; memset(&z, 0, sizeof z);
+                if (inflateInit2(&z, -15) != Z_OK) error_exit("zlib: inflateInit2 failed");
+                z.next_in = (Bytef*)(zb + m.at + 18); z.avail_in = (uInt)(m.size - 26); z.next_out = o; z.avail_out = (uInt)m.text;
+                const int rc = m.text || m.size > 26 ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+                if (rc != Z_STREAM_END || z.total_out != m.text) error_exit("Error to read gzip file");
+                inflateEnd(&z);
+                const uint8_t* e = zb + m.at + m.size - 8; const uint32_t want = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24);
+                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), o, (uInt)m.text) != want) error_exit("Error to read gzip file");
+            });
+            zpos += rel;
+            if (!spill) got = out;
+            if (foreign) {                                                     // the rest of the file is some other gzip: one stream, zlib
+                const uint64_t file_at = zoff - (zend - zpos);
+                if (lseek(zfd, (off_t)file_at, SEEK_SET) < 0) error_exit("Error to read gzip file");
+                gz = gzdopen(zfd, "rb"); if (!gz) error_exit("Error to read gzip file");
+                gzbuffer(gz, 1 << 20); zfd = -1;
+            }
+        }
+        return got;
+    }
     size_t read(uint8_t* dst, size_t cap) {          // fills `cap` unless the stream ends
+        if (bgzf) return read_bgzf(dst, cap);
         size_t got = 0;
         while (got < cap) {
             long n;
@@ -83,16 +194,17 @@ struct ByteSource {                      // sequential bytes of a plain file, st
         if (gz) gzclose(gz);
         else if (piped) { if (f && pclose(f) != 0) error_exit("failed to call xz, please confirm that xz is installed in your system"); }
         else if (f && f != stdin) fclose(f);
-        gz = nullptr; f = nullptr;
+        if (zfd >= 0) ::close(zfd);
+        gz = nullptr; f = nullptr; zfd = -1;
     }
 };
 struct ByteSink {
-    FILE* f = nullptr; gzFile gz = nullptr; bool piped = false; std::string path;
+    FILE* f = nullptr; bool piped = false, bgzf = false; std::string path; int level = 3, zthreads = 1; std::vector<uint8_t> pend;   // pend: text short of a member
     void open(const std::string& p, const Options& o) {
         path = p;
-        if (ends_with(p, ".gz")) {                                          // src/writer.cpp:39-44
-            gz = gzopen(p.c_str(), "wb"); if (!gz) error_exit("Failed to open file for writing: " + p);
-            gzsetparams(gz, o.compression, Z_DEFAULT_STRATEGY); gzbuffer(gz, 1024 * 1024); return;
+        if (ends_with(p, ".gz")) {                                          // src/writer.cpp:39-44: the same text at the same level, as blocked gzip (above)
+            f = fopen(p.c_str(), "wb"); if (!f) error_exit("Failed to open file for writing: " + p);
+            bgzf = true; level = o.compression; zthreads = gz_threads(o); return;
         }
         if (ends_with(p, ".xz")) {                                          // src/main.cpp:134-159
             std::string cmd = "xz -z -c";
@@ -108,20 +220,41 @@ struct ByteSink {
         f = p == "/dev/stdout" ? stdout : fopen(p.c_str(), "wb");
         if (!f) error_exit("Failed to open file for writing: " + p);
     }
+    void put(const uint8_t* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) error_exit("Failed to write: " + path); }
+    // whole members of p[0, n) deflated on all threads, written in order; what is left (< one member) stays in pend
+    void write_bgzf(const uint8_t* p, size_t n) {
+        if (!pend.empty()) {                                                 // top the pending text up to one member first
+            const size_t k = std::min(n, BGZF_TEXT - pend.size()); pend.insert(pend.end(), p, p + k); p += k; n -= k;
+            if (pend.size() < BGZF_TEXT) return;
+            std::vector<uint8_t> z; bgzf_member(pend.data(), pend.size(), level, z); put(z.data(), z.size()); pend.clear();
+        }
+        const size_t nb = n / BGZF_TEXT;
+        for (size_t b0 = 0; b0 < nb; b0 += 1024) {                            // (64 MB of text per round)
+            const size_t cnt = std::min<size_t>(1024, nb - b0); std::vector<std::vector<uint8_t>> z(cnt);
+            const int lv = level;
+            parallel_for(cnt, zthreads, [&](size_t i) { bgzf_member(p + (b0 + i) * BGZF_TEXT, BGZF_TEXT, lv, z[i]); });
+            for (auto& m : z) put(m.data(), m.size());
+        }
+        pend.assign(p + nb * BGZF_TEXT, p + n);
+    }
     void write(const uint8_t* p, size_t n) {
+        if (bgzf) { write_bgzf(p, n); return; }
         while (n) {
             const size_t k = std::min<size_t>(n, 1u << 30);
-            if (gz) { if (gzwrite(gz, p, (unsigned)k) != (int)k) error_exit("Failed to write: " + path); }
-            else if (fwrite(p, 1, k, f) != k) error_exit("Failed to write: " + path);
+            if (fwrite(p, 1, k, f) != k) error_exit("Failed to write: " + path);
             p += k; n -= k;
         }
     }
     void close() {
-        if (gz) { gzflush(gz, Z_FINISH); gzclose(gz); }
+        if (bgzf) {
+            if (!pend.empty()) { std::vector<uint8_t> z; bgzf_member(pend.data(), pend.size(), level, z); put(z.data(), z.size()); pend.clear(); }
+            std::vector<uint8_t> z; bgzf_member(nullptr, 0, level, z); put(z.data(), z.size());      // the empty member bgzip ends a file with (an empty input is just this)
+            if (fclose(f) != 0) error_exit("Failed to write: " + path);
+        }
         else if (piped) { if (f && pclose(f) != 0) error_exit("failed to call xz, please confirm that xz is installed in your system"); }
         else if (f == stdout) fflush(stdout);
         else if (f) fclose(f);
-        gz = nullptr; f = nullptr;
+        f = nullptr; bgzf = false;
     }
 };
 
@@ -185,7 +318,7 @@ public:
             threads = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, threads), n_blocks));
             nbuf = (int)std::min<uint64_t>((uint64_t)threads + 3, std::max<uint64_t>(n_blocks, 1));
             if (n_blocks == 0) eof = true;
-        } else if (!src.open(path)) error_exit("Failed to open file: " + path);
+        } else if (!src.open(path, std::max(threads, std::min(32, (int)std::thread::hardware_concurrency() / 2)))) error_exit("Failed to open file: " + path);
         to_alloc = nbuf;
         if (regular) { running = n_blocks ? threads : 0; for (int i = 0; i < running; i++) th.emplace_back([this] { run_par(); }); }
         else th.emplace_back([this] { run_seq(); });

@@ -68,6 +68,29 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     bg = tmp_path / "back.fq.gz"
     assert _run(binary, ["-d", "-i", str(og), "-o", str(bg), "--batch_mb", str(batch_mb)]).returncode == 0
     assert gzip.decompress(bg.read_bytes()) == fq1
+    # the .gz the driver writes is blocked gzip (members of <= 64 KiB with their size in a 'BC' extra field, an empty member at the end: what bgzip
+    # writes), deflated and - read back - inflated on all I/O threads; any gzip reader sees the same text, the reference included; a plain .gz
+    # and a file that turns from blocked into plain gzip half way go through zlib's one-stream reader
+    z = bg.read_bytes(); off = 0; members = 0
+    while off < len(z):
+        assert z[off:off + 4] == b"\x1f\x8b\x08\x04" and z[off + 10:off + 16] == b"\x06\x00BC\x02\x00", "member %d at %d is not a BGZF member" % (members, off)
+        off += (z[off + 16] | (z[off + 17] << 8)) + 1; members += 1
+    assert off == len(z) and members >= 2 and z[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    og2 = tmp_path / "ag2.rfq"
+    assert _run(binary, ["-c", "-i", str(bg), "-o", str(og2), "-k", "100", "--batch_mb", str(batch_mb), "--block_mb", "1"]).returncode == 0
+    assert og2.read_bytes() == og.read_bytes()
+    mixed = tmp_path / "mixed.fq.gz"; cutz = 0
+    for _ in range(max(1, members // 2)):
+        cutz += (z[cutz + 16] | (z[cutz + 17] << 8)) + 1
+    mixed.write_bytes(z[:cutz] + gzip.compress(fq1[len(gzip.decompress(z[:cutz])):], 1))
+    assert _run(binary, ["-c", "-i", str(mixed), "-o", str(og2), "-k", "100", "--batch_mb", str(batch_mb)]).returncode == 0
+    assert og2.read_bytes() == og.read_bytes()
+    ez = tmp_path / "empty_back.fq.gz"; pe0 = tmp_path / "e0.rfq"; pe0.write_bytes(b"")
+    assert _run(binary, ["-d", "-i", str(pe0), "-o", str(ez)]).returncode == 0 and gzip.decompress(ez.read_bytes()) == b""
+    if O.have_ref():
+        rr = tmp_path / "ref_from_blocked.rfq"
+        assert subprocess.run([O.REF_BIN, "-c", "-i", str(bg), "-o", str(rr), "-k", "100"], capture_output=True).returncode == 0
+        assert rr.read_bytes() == og.read_bytes()
     if shutil.which("xz"):
         ox = tmp_path / "a.rfq.xz"
         r = _run(binary, ["-c", "-i", str(p), "-o", str(ox), "-k", "100", "-z", "1", "--batch_mb", str(batch_mb)])
