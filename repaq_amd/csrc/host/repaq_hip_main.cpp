@@ -113,7 +113,7 @@ struct ByteSource {                      // sequential bytes of a plain file, st
             zfd = ::open(p.c_str(), O_RDONLY);
             if (zfd >= 0) {
                 uint8_t h[18]; const ssize_t k = pread(zfd, h, 18, 0);
-                if (k == 18 && bgzf_member_size(h) >= 26) { bgzf = true; zbuf.resize((size_t)8 << 20); return true; }
+                if (k == 18 && bgzf_member_size(h) >= 26) { bgzf = true; const char* e = getenv("RFQ_GZ_BUF"); zbuf.resize(e ? (size_t)std::max(64, atoi(e)) : (size_t)8 << 20); return true; }   // (RFQ_GZ_BUF: test aid - a small read-ahead makes refills happen on small files)
                 ::close(zfd); zfd = -1;
             }
             gz = gzopen(p.c_str(), "rb"); if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr;
