@@ -274,6 +274,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats) + 8192));
             unsigned long long* dbg = (unsigned long long*)B[B_HSTATS].p + 600; (void)hipMemsetAsync(dbg, 0, 64, OS);
             hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, OS, T, B[B_OVRAW].as<int16_t>(), np, dbg, 0);
+            (void)hipStreamSynchronize(OS);                                   // (the second stream does not order against the copy below)
             unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
             if (h[5]) fprintf(stderr, "[overlap dbg] waves=%llu avg cycles/wave: meta=%llu pack=%llu fwd=%llu bwd=%llu slow+write=%llu verifies/wave=%.1f\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5], (double)h[6]/h[5]);
         } else hipLaunchKernelGGL(k_overlap<false>, dim3(ob), dim3(256), 0, OS, T, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, (tune >> 8) & 7);   // (tune bits 8-10: ablation switches, results invalid)
