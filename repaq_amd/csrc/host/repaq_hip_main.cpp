@@ -812,7 +812,8 @@ static void usage() {
           "usage: repaq_hip [-c|-d|-p] -i in1 [-I in2] -o out1 [-O out2] [-k chunk_kb] [--stdin] [--stdout] [--interleaved_in]\n"
           "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N | --devices a,b,...]\n"
           "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--trace]\n"
-          "       FASTQ may be .gz (zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
+          "       FASTQ may be .gz (written as blocked gzip - bgzip's layout, readable by every gzip tool - on many threads; a blocked .gz is\n"
+          "       also read on many threads, any other through zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
 }
 int main(int argc, char** argv) {
     if (argc == 1) { usage(); return 0; }
