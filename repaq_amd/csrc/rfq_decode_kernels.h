@@ -496,7 +496,7 @@ __global__ void k_dec_pos_emit(const uint8_t* __restrict__ img, const DChunk* __
 // u32 per coded position, in stream order, all streams of all chunks in one arena (a position belongs to at most one stream, so a list is a
 // few percent of the bases).  The emitter prefills a tile's qualities with the major value in LDS, scatters the list entries that fall into
 // the tile, unpacks the tile's bases LDS -> LDS from the packed bytes and scatters the N list: no qdec / sdec, no prefill, unpack or
-// one-line-per-token scatter kernels.  Three light passes build the lists, one wave per 256-byte segment of a stream:
+// one-line-per-token scatter kernels.  Three light passes build the lists, one wave per POS2_SEG-byte segment of a stream (256-byte steps):
 //   k_dec_pos_sum2   per segment and entry state of the token automaton: exit state, positions advanced, positions emitted
 //   k_dec_pos_link2  per stream, a wave scan over those summaries: entry state / entry position / entry list index of every segment
 //   k_dec_pos_list   decodes every segment from its now-known entry and writes its positions; records for every POS2_CELL positions the
