@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MI
 # stage (HIP-event pair inside librfq_hip) -> the kernels it brackets (names as rocprofv3 reports them)
 STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
                  "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_overlap_apply", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
-                 "gather": ["k_gather", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder", "k_pos_sizes"],
+                 "gather": ["k_gather2", "k_seqpack", "k_stream_plan", "k_chunk_layout"], "gather_bytes": ["k_gather", "k_packbytes", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder", "k_pos_sizes"],
                  "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
                  "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
                  "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list", "k_dec_textlen",   # (fused path: the text lengths run beside the list chain)
@@ -195,6 +195,19 @@ class Workload:
             self.step(True)
         sync(); barrier()
         return time.perf_counter() - t0
+
+    def decode_walk(self, steps, sync):
+        """Decode throughput WITHOUT the encoder's chunk index (a .rfq file has none, src/rfqchunk.cpp:161-228): the library finds the chunk
+        starts itself (k_dec_spec_walk + verifying parse).  Returns (MB/s, walk stage ms)."""
+        c = self.codec; r = self.r
+        kw = dict(split_pe=self.paired, d_out1=self.o1.data_ptr(), cap1=self.n1 + 64, d_out2=self.o2.data_ptr() if self.paired else None, cap2=(self.n2 + 64) if self.paired else 0)
+        c.decode(r.d_rfq, r.rfq_len, **kw); sync()
+        walk = 0.0; t0 = time.perf_counter()
+        for _ in range(steps):
+            c.decode(r.d_rfq, r.rfq_len, **kw)
+            walk += dict(c.timings()).get("walk", 0.0)
+        sync()
+        return round(self.n * steps / (time.perf_counter() - t0) / 1e6, 1), round(walk / steps, 3)
 
     def summary(self, steps):
         stage = {k: v / steps for k, v in self.stage.items()}
@@ -420,13 +433,18 @@ def main():
     parity = "unchecked" if args.no_verify else w.check()
     dt = w.run(args.steps, args.warmup, sync, lambda: None)
     head, stage, enc_ms, dec_ms = line_of(w, args.steps, dt, w.n, parity)
+    walk = w.decode_walk(args.steps, sync) if w.do_decode else None
     out = {
         "metric": "raw FASTQ MB/s encode+decode" if w.do_decode else "raw FASTQ MB/s encode",
         "value": head["value_MBps"], "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": w.label, "chunks_per_gpu": w.chunks, "rfq_over_fastq": head["rfq_over_fastq"],
-                   "encode_MBps_per_gpu": head["encode_MBps"], "decode_MBps_per_gpu": head["decode_MBps"], "parity": parity, "stage_ms": head["stage_ms"]},
+                   "encode_MBps_per_gpu": head["encode_MBps"], "decode_MBps_per_gpu": head["decode_MBps"],
+                   # the headline decode is handed the encoder's chunk offsets (a round trip holds them); the same decode finding the chunks itself:
+                   "decode_MBps_walk": walk[0] if walk else None, "walk_ms": walk[1] if walk else None,
+                   "value_MBps_walk": round(2 * w.n / (w.n / (head["encode_MBps"] * 1e6) + w.n / (walk[0] * 1e6)) / 1e6, 1) if walk and head["encode_MBps"] else None,
+                   "parity": parity, "stage_ms": head["stage_ms"]},
         "roofline": roofline_of(w, stage, enc_ms, dec_ms, args.workload),
     }
     if not args.no_cpu_baseline:

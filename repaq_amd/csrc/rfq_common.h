@@ -46,6 +46,7 @@
 #define DE_NO_QUAL_BINS    (1u << 7)  // "bad quality string"
 #define DE_CORRUPT         (1u << 8)  // decode: inconsistent chunk image
 #define DE_TAIL_BLANK      (1u << 9)  // an empty line in the \n-only text right behind the encoded records: blank or empty is for the normaliser to say
+#define DE_ODD_BASE        (1u << 10) // a reverse-complemented mate holds a byte outside A/C/G/T/N: the 2-bit fast path cannot code it (k_gather2)
 
 // Device-resident file header + derived tables (RfqHeader, src/rfqheader.h:44-108)
 struct DevHeader {
@@ -80,7 +81,7 @@ struct DevStatus {
     uint64_t total_image;       // bytes of all chunk images
     uint64_t total_bases;
     uint32_t first_empty;       // first read (interleaved order) with an empty line, ~0 if none
-    uint32_t pad_;
+    uint32_t max_rec;           // longest record (four lines with their terminators) in bytes
 };
 
 struct U4 { uint32_t a, b, c, d; };

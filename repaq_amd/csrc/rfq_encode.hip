@@ -12,7 +12,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 72, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -201,7 +201,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     DBuf* B = ctx->b;
     ctx->timer.reset();
     ctx->pend.clear(); ctx->pin_used = 0;                                   // (read-backs an earlier call left behind on an error path)
-    static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // kernel ablation switches for profiling runs (results are invalid when set)
+    const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // kernel ablation switches for profiling runs (results are invalid when set; read per call: tools/ab_encode.py flips them inside one process)
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
     // ---- status block
@@ -299,8 +299,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     uint16_t* adj = B[B_ADJ].as<uint16_t>(); uint32_t* pinfo = is_pe ? B[B_PINFO].as<uint32_t>() : nullptr;
     hipLaunchKernelGGL(k_read_table, dim3((n_reads + 4 * RT_NEW - 1) / (4 * RT_NEW)), dim3(256), 0, S, T, R, n_reads, adj, pinfo, dst);
     const uint32_t ublocks = (n_units + 255) / 256;
-    HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 8));
-    hipLaunchKernelGGL(k_unit_len, dim3(ublocks), dim3(256), 0, S, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
+    HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 12));
+    hipLaunchKernelGGL(k_unit_len, dim3(ublocks), dim3(256), 0, S, T, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
     KCHK(ctx, "k_read_table");
     scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1);
     scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1);
@@ -356,7 +356,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_IMGSIZE].ensure(nc * 8)); HIPCHK(ctx, B[B_IMGOFF].ensure(nc * 8)); HIPCHK(ctx, B[B_CTOTAL].ensure(nc * 8)); HIPCHK(ctx, B[B_CBASE].ensure(nc * 8));
     HIPCHK(ctx, B[B_LAYOUT].ensure(nc * sizeof(Layout))); HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats) + 8192)); HIPCHK(ctx, B[B_OVB].ensure(nr / 2 + 16));
     const size_t catbytes = (size_t)total_bases + 64 * nc + 256;
-    HIPCHK(ctx, B[B_QCAT].ensure(catbytes)); HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
+    HIPCHK(ctx, B[B_QCAT].ensure(catbytes));
     HIPCHK(ctx, ctx->d_hdr.ensure(sizeof(DevHeader)));
     C.flags = B[B_CFLAGS].as<uint32_t>(); C.il = B[B_IL].as<uint32_t>(); C.ncount = B[B_NCOUNT].as<uint32_t>();
     HIPCHK(ctx, B[B_NMAP].ensure(nc * NMAP_WORDS * 4)); C.nmap = B[B_NMAP].as<uint32_t>();
@@ -415,32 +415,66 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.end(S);
 
     ctx->timer.begin("gather", S);
-    HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
     // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
     const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
     const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
     HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
-    HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
-    {
-        // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 64; enough workgroups to fill 256 CUs x 2
-        const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
+    HIPCHK(ctx, B[B_SPK].ensure((catbytes >> 4) * 4 + 64)); HIPCHK(ctx, B[B_SNM].ensure((catbytes >> 4) * 2 + 64));
+    // Fast path (k_gather2 + k_seqpack): tiles of K reads - the largest power of two whose records always fit the staged-text buffer.  Reads too long
+    // for a two-read tile, and batches where a reverse-complemented mate holds a byte outside A/C/G/T/N (found by the fast path itself), take
+    // the byte-wise k_gather + k_packbytes.  RFQ_GATHER=old forces that path (tests run both).
+    uint32_t kshift = 6; if (getenv("RFQ_G2_KSHIFT")) kshift = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_G2_KSHIFT"))));   // (profiling aid: smaller tiles)
+    while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > G2_CAP) kshift--;
+    const char* genv = getenv("RFQ_GATHER");
+    bool fast = kshift >= 1 && !(genv && !strcmp(genv, "old"));
+    const uint32_t max_rec = hs.max_rec;
+    for (;;) {
+        HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
+        HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
+        if (fast) {
+            const size_t nld = (size_t)(total_bases >> 4) + reads_used + 16;
+            HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2));
+            const uint32_t K = 1u << kshift;
+            const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
+            hipLaunchKernelGGL(k_gather2, dim3(bx, n_chunks), dim3(256), 0, S, T, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint32_t*)C.il, (const uint64_t*)C.qbase, (const DevHeader*)D,
+                               B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, dst, (tune >> 16) & 15);   // (tune bits 16-19: ablation switches of k_gather2, results invalid)
+            const uint32_t sx = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
+            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, S, (const uint32_t*)R.pq, (const U4*)R.pv, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
+                               (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
+                               C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
+        } else {
+            HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
+            // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 32
+            const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
 #define RFQ_GATHER_ARGS T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, \
                         tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune
-        if (tune & 7) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
-        else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
+            if (tune & 7) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
+            else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
 #undef RFQ_GATHER_ARGS
-        if (tune & 7) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
-            if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
+            if (tune & 7) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
+                if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
+            const uint32_t px = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
+            hipLaunchKernelGGL(k_packbytes, dim3(px, n_chunks), dim3(256), 0, S, (const U4*)R.pv, (const uint32_t*)C.first, (const uint64_t*)C.sbase, (const uint8_t*)B[B_SCAT].as<uint8_t>(),
+                               B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>());
+        }
+        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg);
+        scan_exclusive<uint64_t>(S, B[B_CTOTAL].as<uint64_t>(), B[B_CBASE].as<uint64_t>(), n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+        hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
+        scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 0, dst);
+        KCHK(ctx, "k_gather");
+        HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+        if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
+        if (fast && (hs.err & DE_ODD_BASE)) {                                // the 2-bit path met a mate it cannot code: once more, byte-wise
+            fast = false; hs.err &= ~(uint32_t)DE_ODD_BASE;
+            HIPCHK(ctx, hipMemcpyAsync(&dst->err, &hs.err, 4, hipMemcpyHostToDevice, S));
+            continue;
+        }
+        break;
     }
-    hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg);
-    scan_exclusive<uint64_t>(S, B[B_CTOTAL].as<uint64_t>(), B[B_CBASE].as<uint64_t>(), n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-    hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
-    scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-    hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 0, dst);
-    KCHK(ctx, "k_gather");
-    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-    if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
-    HIPCHK(ctx, ctx->fetch_sync(S));
+    (void)max_rec;
+    ctx->timer.stages[ctx->timer.used].name = fast ? "gather" : "gather_bytes";   // (which formulation ran: tests and the bench look at it)
     ctx->timer.end(S);
     if (hs.err & (DE_BAD_QUAL | DE_BAD_BASE)) {
         // RfqHeader::makeQualityTable error_exit texts, src/rfqheader.cpp:140-166
@@ -478,7 +512,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         const uint32_t n_qgroups = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
         const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * (n_qgroups + 2) * n_seg;
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
-        hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, S, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(),
+        hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, S, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint16_t*)B[B_SNM].as<uint16_t>(),
                            B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(),
                            n_seg, n_chunks, n_qgroups, dst);
         hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const uint32_t*)B[B_SEGB].as<uint32_t>(), n_seg);
@@ -500,7 +534,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         const uint32_t tail_bases = ((a->final && !a->flush_all) || ended) ? a->chunk_bases : 0u;
         const uint32_t bpc = grid_x_for(n_chunks, 64u, 8u * ctx->n_cu);       // (no LDS, 28 VGPRs: eight workgroups per CU)
         hipLaunchKernelGGL(k_assemble, dim3(bpc, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L,
-                           (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint8_t*)B[B_SCAT].as<uint8_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(),
+                           (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint32_t*)B[B_SPK].as<uint32_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(),
                            (const uint8_t*)B[B_XS].as<uint8_t>(), (const uint8_t*)B[B_YS].as<uint8_t>(), (const int8_t*)ovb, img, img_cap, hdr_bytes,
                            a->file_off1, a->file_off2, a->nolb_from1, a->nolb_from2,
                            (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, dst,

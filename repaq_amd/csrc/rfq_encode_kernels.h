@@ -396,18 +396,22 @@ __global__ void k_chunk_ends(Text T, const uint32_t* __restrict__ first, uint32_
 }
 // bases per partition unit (a read, or a pair) + per-block min / max for the partitioner's uniform-length fast path
 // (no atomics: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
-__global__ void k_unit_len(const uint32_t* __restrict__ len, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax) {
-    __shared__ uint32_t s_mn[4], s_mx[4];
+__global__ void k_unit_len(Text T, const uint32_t* __restrict__ len, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax) {
+    __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4];
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t tot = 0;
-    if (u < n_units) { for (uint32_t j = 0; j < upr; j++) tot += len[(size_t)u * upr + j]; ulen[u] = tot; }
+    uint64_t tot = 0; uint32_t rec = 0;                                     // rec: bytes of the unit's longest record (k_gather2 sizes its tiles by it)
+    if (u < n_units) {
+        for (uint32_t j = 0; j < upr; j++) tot += len[(size_t)u * upr + j];
+        ulen[u] = tot;
+        for (uint32_t j = 0; j < upr; j++) { int s; uint32_t r; read_loc(T, u * upr + j, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r; const uint32_t b = p[4] - p[0]; if (b > rec) rec = b; }
+    }
     uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
-    mn = wave_min(mn); mx = wave_max(mx);
-    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; }
+    mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec);
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; }
-        blk_minmax[2 * blockIdx.x] = mn; blk_minmax[2 * blockIdx.x + 1] = mx;
+        for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; if (s_rc[i] > rec) rec = s_rc[i]; }
+        blk_minmax[3 * blockIdx.x] = mn; blk_minmax[3 * blockIdx.x + 1] = mx; blk_minmax[3 * blockIdx.x + 2] = rec;
     }
 }
 
@@ -434,15 +438,15 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
                             const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
     const int l = lane_id();
     // shortest / longest unit: every thread of the workgroup (1024: a single wave walked 44 k block entries in 158 us), then wave 0 goes on alone
-    __shared__ uint32_t s_mn[16], s_mx[16];
-    uint32_t len_minmax[2];
-    { uint32_t mn = 0xFFFFFFFFu, mx = 0; for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk_minmax[2 * i], b = blk_minmax[2 * i + 1]; if (a < mn) mn = a; if (b > mx) mx = b; }
-      mn = wave_min(mn); mx = wave_max(mx);
-      if (l == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; }
+    __shared__ uint32_t s_mn[16], s_mx[16], s_rc[16];
+    uint32_t len_minmax[2], max_rec;
+    { uint32_t mn = 0xFFFFFFFFu, mx = 0, rc = 0; for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk_minmax[3 * i], b = blk_minmax[3 * i + 1], r = blk_minmax[3 * i + 2]; if (a < mn) mn = a; if (b > mx) mx = b; if (r > rc) rc = r; }
+      mn = wave_min(mn); mx = wave_max(mx); rc = wave_max(rc);
+      if (l == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rc; }
       __syncthreads();
       if (wave_id() != 0) return;
-      const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u;
-      len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); }
+      const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u; rc = (uint32_t)l < nw ? s_rc[l] : 0u;
+      len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); max_rec = wave_max(rc); }
     uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0;
     if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
         // every unit has the same length L: a chunk is K = ceil(chunk_bases / L) units
@@ -475,7 +479,7 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
     if (l == 0) {
         st->n_chunks = c; st->n_units_used = start; st->max_chunk_reads = max_units * upr;
         st->max_chunk_bases = (uint32_t)(max_bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : max_bases);
-        st->total_bases = start ? P[start - 1] : 0;
+        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec;
     }
 }
 __global__ void k_chunk_ids(ChunkTab C, ReadTab R) {
@@ -1293,6 +1297,253 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
     if (DBG && tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a_fit); atomicAdd(&dbg[1], (unsigned long long)a_meta); atomicAdd(&dbg[2], (unsigned long long)a_stage); atomicAdd(&dbg[3], (unsigned long long)a_q); atomicAdd(&dbg[4], (unsigned long long)a_s); atomicAdd(&dbg[5], 1ull); }
 }
 
+// =============================================================== gather, second formulation (fast path) + sequence packer
+// What round 2's kernel timeline left: k_gather's tile loop spends half its instructions on per-tile bookkeeping (fit test, seven LDS tables, four
+// barriers) and needs two LDS output tiles, which caps the tile at 32 reads.  k_gather2 has NO output tile and no fit test:
+//   * a tile is a fixed number K of reads (K = 64, 32, ... chosen by the host so that K records always fit the staged-text buffer);
+//   * qualities go from the staged text straight to qcat with byte-granular 16-byte stores (the lanes of one read are neighbours, so a wave's
+//     stores still cover contiguous runs), counted from the registers they pass through;
+//   * bases are 2-bit packed (+ one "is N" bit each) where they stand, in FILE orientation and untrimmed, into a per-read slot of a LOOSE array:
+//     read g (batch order) owns the dwords Ld(g) = (pq[g] >> 4) + g ... of `lpk` (16 codes each; G 0, A 1, T 2, C 3, anything else 0,
+//     src/rfqcodec.cpp:590-604) and the same u16 slots of `lnb`.  No stored-base prefix, no overlap result, no orientation is needed here:
+//     k_seqpack applies them (reverse complement in 2-bit space, overlap trim, compaction to the chunk's tight 2-bit stream + N bit mask).
+// A reverse-complemented mate that holds a byte outside A/C/G/T/N (Read::changeToReverseComplement maps those to N, in file orientation they
+// code as 0 without an N position) cannot be told apart in 2-bit space: DE_ODD_BASE sends the batch through the byte-wise k_gather instead.
+#define G2_CAP 23552u             // staged text of a tile (64 x 357-byte records are 22.9 KB)
+#define G2_CNT 256u               // replicated quality counters (see QualCount)
+struct __attribute__((packed, aligned(1))) GU16g { uint32_t a, b, c, d; };
+// four bases -> four 2-bit codes (exact upper-case A/C/G/T, anything else 0), four "is N" bits, four "neither" bits
+__device__ __forceinline__ void pack4_codes(uint32_t w, uint32_t& code, uint32_t& nb, uint32_t& bad) {
+    const uint32_t idx = (w >> 1) & 0x03030303u;
+    const uint32_t ok = eq_bytes_full(__builtin_amdgcn_perm(0u, 0x47544341u, idx), w);
+    code = ((__builtin_amdgcn_perm(0u, 0x00020301u, idx) & ok) * 0x01041040u) >> 24;
+    nb = 0; bad = 0;
+    if (ok != 0xFFFFFFFFu) { const uint32_t isn = eq_bytes_full(w, 0x4E4E4E4Eu); nb = ((isn & 0x01010101u) * 0x01020408u) >> 24; bad = (((~ok & ~isn) & 0x01010101u) * 0x01020408u) >> 24; }
+}
+__global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const uint64_t* __restrict__ qbase,
+                                                 const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb,
+                                                 uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift, DevStatus* st, int abl) {
+    __shared__ uint4 s_text4[G2_CAP / 16 + 8];
+    __shared__ uint32_t sh[G2_CNT]; __shared__ int sh_last[G2_CNT]; __shared__ uint8_t s_slot[256];
+    uint8_t* const s_text = (uint8_t*)(s_text4 + 1);                      // 16 bytes of slack in front: reversed 16-byte fetches may start before a line
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < G2_CNT; i += blockDim.x) { sh[i] = 0; sh_last[i] = -1; }
+    const uint32_t nn_s = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, nslot = nn_s + 1u;
+    uint32_t nrep = 1; while (nrep < 16u && 4u * nrep * nslot <= G2_CNT) nrep *= 2u;
+    for (uint32_t i = tid; i < 256; i += blockDim.x) { const uint32_t j = D->stream_of[i]; s_slot[i] = (uint8_t)(j < nn_s ? j : nn_s); }
+    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1];
+    const bool il = ilv[c] != 0, two = T.paired == 1;
+    uint8_t* const qd = qcat + qbase[c]; const uint32_t pq0 = pq[f];
+    uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup
+    const uint32_t gs = f + blockIdx.x * per, ge = gs + per < e ? gs + per : e;
+    const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;              // K reads per tile, P threads per read
+    const uint32_t j = tid >> pshift, part = tid & (P - 1u);
+    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
+    bool odd = false;
+    __syncthreads();
+    for (uint32_t cur = gs; cur < ge; cur += K) {                          // block-uniform
+        const uint32_t cnt = ge - cur < K ? ge - cur : K;
+        // ---- the tile's text spans (one per stream), wave-uniform
+        uint32_t a0[2], sp_end[2] = { 0, 0 };
+        if (two) { const size_t r0 = 4 * (size_t)(cur >> 1), r1 = 4 * (size_t)((cur + cnt) >> 1);
+                   a0[0] = uni32(T.lo[0][r0]) & ~15u; sp_end[0] = uni32(T.lo[0][r1]); a0[1] = uni32(T.lo[1][r0]) & ~15u; sp_end[1] = uni32(T.lo[1][r1]); }
+        else { a0[0] = uni32(T.lo[0][4 * (size_t)cur]) & ~15u; sp_end[0] = uni32(T.lo[0][4 * (size_t)(cur + cnt)]); a0[1] = 0; }
+        const uint32_t base1 = two ? (((sp_end[0] - a0[0] + 15u) & ~15u) + 16u) : 0u;   // LDS offset of stream 1's span
+        for (int st_ = 0; st_ < (two ? 2 : 1); st_++) {
+            const uint32_t nb = sp_end[st_] - a0[st_], ng = (nb + 15u) / 16u, lb = st_ ? base1 : 0u;
+            const uint8_t* src = t_fq(T, st_) + a0[st_];
+            const uint32_t nfull = (uint64_t)a0[st_] + 16ull * ng <= (uint64_t)t_n(T, st_) ? ng : ng - 1u;      // (only a stream's very last group may reach past the buffer)
+            uint4* const l4 = s_text4 + 1 + lb / 16;
+            for (uint32_t i = tid; i < nfull; i += blockDim.x)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i), (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
+            if (nfull < ng && tid == 0) for (uint32_t k = 0; k < 16 && a0[st_] + 16 * nfull + k < t_n(T, st_); k++) s_text[lb + 16 * nfull + k] = src[16 * (size_t)nfull + k];
+        }
+        // ---- my read (P neighbouring threads share one): where its lines are, where its output goes
+        const uint32_t g = cur + j; const bool on = j < cnt;
+        uint32_t len = 0, qsrc = 0, ssrc = 0, qpos = 0, ld = 0; bool rc = false;
+        const uint32_t qbeg = uni32(pq[cur]) - pq0;                          // the tile's first quality position (chunk-relative)
+        if (on) {
+            int s_; uint32_t r_; read_loc(T, g, s_, r_);
+            const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);   // starts of the read's four lines
+            const uint32_t lb = s_ ? base1 : 0u, a = s_ ? a0[1] : a0[0];
+            len = lo4.z - 1u - lo4.y; ssrc = lb + (lo4.y - a); qsrc = lb + (lo4.w - a);
+            const uint32_t pg = pq[g]; qpos = pg - pq0; ld = (pg >> 4) + g;
+            rc = il && ((g - f) & 1u);
+        }
+        __syncthreads();                                                    // (drains the LDS-DMA)
+        qc.seg0 = qbeg / PC_SEG_POS;
+        if (on && !(abl & 1)) {
+            // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
+            const uint32_t n = len; uint8_t* const o = qd + qpos;
+            if (n >= 16u) {
+                const uint32_t ng = (n + 15u) >> 4;
+                for (uint32_t gi = part; gi < ng; gi += P) {
+                    uint32_t p0 = 16u * gi, dup = 0; if (p0 + 16u > n) { dup = p0 + 16u - n; p0 = n - 16u; }     // the last group ends exactly at n: its first `dup` bytes repeat the group before
+                    uint32_t w[4]; lds_get16(s_text, rc ? qsrc + n - p0 - 16u : qsrc + p0, w);
+                    if (rc) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
+                    if (!(abl & 4)) { GU16g v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16g*)(o + p0) = v; }
+                    if (abl & 8) continue;
+                    if (!dup) qc.group(qpos + p0, w[0], w[1], w[2], w[3]);
+                    else for (uint32_t k = dup; k < 16u; k++) qc(qpos + p0 + k, (uint8_t)(w[k >> 2] >> (8u * (k & 3u))));
+                }
+            } else for (uint32_t i = part; i < n; i += P) { const uint8_t q = s_text[rc ? qsrc + n - 1u - i : qsrc + i]; o[i] = q; qc(qpos + i, q); }
+        }
+        if (on && !(abl & 2)) {
+            // ---- bases: 16 per step -> one dword of codes + 16 N bits, file orientation, into the read's loose slot
+            const uint32_t ng = (len + 15u) >> 4;
+            for (uint32_t gi = part; gi < ng; gi += P) {
+                uint32_t w[4]; lds_get16(s_text, ssrc + 16u * gi, w);
+                uint32_t code = 0, nbits = 0, bad = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
+                const uint32_t nv = len - 16u * gi;                        // valid bases of this step (what lies behind the line's end is not the read's)
+                if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; const uint32_t m = (1u << nv) - 1u; nbits &= m; bad &= m; }
+                if (bad && rc) odd = true;
+                lpk[ld + gi] = code; lnb[ld + gi] = (uint16_t)nbits;
+            }
+        }
+        __syncthreads();                                                    // the text is free for the next tile; the tile's counts are complete
+        qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
+    }
+    if (__any(odd) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_ODD_BASE);
+}
+// 16 consecutive codes / N bits of a loose slot from base index b on (b + 16 may pass the slot's end: the caller masks)
+__device__ __forceinline__ uint32_t loose_codes(const uint32_t* __restrict__ lpk, uint32_t ld, uint32_t b) {
+    const uint32_t d = ld + (b >> 4), sh = 2u * (b & 15u); const uint32_t lo = lpk[d];
+    return sh ? (uint32_t)(((((unsigned long long)lpk[d + 1]) << 32) | lo) >> sh) : lo;
+}
+__device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb, uint32_t ld, uint32_t b) {
+    const uint32_t d = ld + (b >> 4), sh = b & 15u; const uint32_t lo = lnb[d];
+    return (sh ? ((((uint32_t)lnb[d + 1]) << 16) | lo) >> sh : lo) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t rev2x16(uint32_t v) {                   // the sixteen 2-bit fields of v in reverse order
+    v = bswap32(v); v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4); return ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+}
+__device__ __forceinline__ uint32_t rev1x16(uint32_t v) {                   // the low sixteen bits of v in reverse order
+    v = ((v >> 8) & 0xFFu) | ((v & 0xFFu) << 8); v = ((v >> 4) & 0x0F0Fu) | ((v & 0x0F0Fu) << 4);
+    v = ((v >> 2) & 0x3333u) | ((v & 0x3333u) << 2); return ((v >> 1) & 0x5555u) | ((v & 0x5555u) << 1);
+}
+__device__ __forceinline__ uint32_t spread16(uint32_t v) {                  // bit i of v -> bits 2i and 2i+1
+    v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v * 3u;
+}
+// `take` (1..16) stored bases of one read from stored index si on: codes in the low 2 * take bits, N bits in the low `take` bits.
+// Stored bases (src/rfqcodec.cpp:371-407): the read as it stands, or - an interleaved chunk's mate - its reverse complement without the
+// `skip` leading bases the overlap with R1 implies: stored[s] = comp(file[len - 1 - skip - s]).  The complement of a code is its bitwise NOT
+// (G 0 <-> C 3, A 1 <-> T 2); an N stays an N and codes as 0.
+__device__ __forceinline__ void stored_codes(const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb, uint32_t ld, uint32_t len, uint32_t skip, bool rc, uint32_t si, uint32_t take,
+                                             uint32_t& code, uint32_t& nbits) {
+    const uint32_t cm = take >= 16u ? 0xFFFFFFFFu : (1u << (2u * take)) - 1u, nm = (1u << take) - 1u;
+    if (!rc) { code = loose_codes(lpk, ld, si) & cm; nbits = loose_nbits(lnb, ld, si) & nm; return; }
+    const int hi = (int)(len - 1u - skip - si), lo = hi - 15;              // file indices hi, hi-1, ... become stored si, si+1, ...
+    uint32_t cw, nw;
+    if (lo >= 0) { cw = loose_codes(lpk, ld, (uint32_t)lo); nw = loose_nbits(lnb, ld, (uint32_t)lo); }
+    else { cw = loose_codes(lpk, ld, 0u) << (2u * (uint32_t)(-lo)); nw = (loose_nbits(lnb, ld, 0u) << (uint32_t)(-lo)) & 0xFFFFu; }   // (file indices < 0 land at stored indices >= take: masked)
+    nbits = rev1x16(nw) & nm;
+    code = ~rev2x16(cw) & ~spread16(nbits) & cm;
+}
+// Loose slots -> the chunk's tight streams: spk = 2-bit stored bases, 16 per dword, dword k of chunk c at (sbase[c] >> 4) + k - the bytes of the
+// image's sequence section (RfqChunk::write copies them) - and snm = one "is N" bit per stored base at the same u16 index (the N-position
+// coder's match mask).  One thread makes one dword: the reads that overlap a run of 256 dwords are found once per run (their stored prefixes
+// staged in LDS, the cursor moves on monotonically), then every thread bisects that window for its first base and walks on.  N counts per
+// coder segment, the chunk's N total and N map are left as k_gather leaves them.
+#define SP_WIN 256u
+__global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
+                                                 const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
+                                                 uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
+    __shared__ uint32_t s_sd[SP_WIN + 1], s_ld[SP_WIN], s_len[SP_WIN], s_sk[SP_WIN], s_next;
+    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1], tid = threadIdx.x;
+    const uint32_t ps0 = pv[f].d, S = pv[e].d - ps0, ndw = (S + 15u) >> 4;
+    uint32_t per = (ndw + gridDim.x - 1) / gridDim.x; per = (per + 255u) & ~255u;
+    const uint32_t k0 = blockIdx.x * per, k1 = k0 + per < ndw ? k0 + per : ndw;
+    if (k0 >= k1) return;
+    const bool il = ilv[c] != 0, enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
+    uint32_t* const ok = spk + (size_t)(sbase[c] >> 4); uint16_t* const on = snm + (size_t)(sbase[c] >> 4);
+    const uint32_t nshift = nmap_shift(S); uint32_t* const nm = nmap + (size_t)c * NMAP_WORDS;
+    const size_t nsi = ((size_t)c * MAX_STREAMS + NPOS_SLOT) * n_seg;
+    // the read that holds stored base 16 * k0: the last r in [f, e) whose stored prefix is <= it (wave-uniform bisection)
+    uint32_t rcur;
+    { uint32_t lo = f, hi = e; const uint32_t B = 16u * k0; while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (pv[mid].d - ps0 <= B) lo = mid; else hi = mid; } rcur = lo; }
+    uint32_t nsum = 0;
+    for (uint32_t kb = k0; kb < k1; ) {                                      // block-uniform
+        const uint32_t nr = e - rcur < SP_WIN ? e - rcur : SP_WIN;          // reads in the window
+        for (uint32_t t = tid; t <= nr; t += blockDim.x) {
+            const uint32_t g = rcur + t; s_sd[t] = pv[g].d - ps0;
+            if (t < nr) {
+                const uint32_t pg = pq[g], len = pq[g + 1] - pg; const bool rc = il && ((g - f) & 1u);
+                uint32_t skip = 0; if (rc && enc) { const int ov = (int)ovb[g >> 1] - shift; if (ov > 0) skip = (uint32_t)ov; }
+                s_ld[t] = (pg >> 4) + g; s_len[t] = len; s_sk[t] = skip | (rc ? 0x80000000u : 0u);
+            }
+        }
+        __syncthreads();
+        // dwords whose bases all lie inside the window
+        const uint32_t lim = s_sd[nr]; const uint32_t kmax = lim >= S ? ndw : lim >> 4;
+        uint32_t kend = kb + 256u < k1 ? kb + 256u : k1; if (kend > kmax) kend = kmax;
+        if (kend <= kb) kend = kb;                                          // (a window of SP_WIN reads holds fewer than 16 bases: the serial step below)
+        const uint32_t k = kb + tid;
+        if (k < kend) {
+            const uint32_t B = 16u * k, need = S - B < 16u ? S - B : 16u;
+            uint32_t lo = 0, hi = nr; while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_sd[mid] <= B) lo = mid; else hi = mid; }
+            unsigned long long acc = 0; uint32_t nacc = 0, filled = 0, r = lo;
+            while (filled < need) {
+                const uint32_t pos = B + filled, avail = s_sd[r + 1] - pos;
+                if (avail == 0) { r++; continue; }
+                const uint32_t take = avail < need - filled ? avail : need - filled;
+                uint32_t cw, nw; const uint32_t sk = s_sk[r];
+                stored_codes(lpk, lnb, s_ld[r], s_len[r], sk & 0x7FFFFFFFu, (sk >> 31) != 0, pos - s_sd[r], take, cw, nw);
+                acc |= (unsigned long long)cw << (2u * filled); nacc |= nw << filled; filled += take;
+            }
+            ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc;
+            if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
+        }
+        if (kend == kb) {
+            // serial step: one dword, its bases gathered read by read from global memory (thousands of near-empty reads in a row)
+            if (tid == 0) {
+                const uint32_t B = 16u * kb, need = S - B < 16u ? S - B : 16u; unsigned long long acc = 0; uint32_t nacc = 0, filled = 0, g = rcur;
+                while (filled < need) {
+                    const uint32_t sd0 = pv[g].d - ps0, sd1 = pv[g + 1].d - ps0, pos = B + filled;
+                    if (sd1 <= pos) { g++; continue; }
+                    const uint32_t avail = sd1 - pos, take = avail < need - filled ? avail : need - filled;
+                    const uint32_t pg = pq[g], len = pq[g + 1] - pg; const bool rc = il && ((g - f) & 1u);
+                    uint32_t skip = 0; if (rc && enc) { const int ov = (int)ovb[g >> 1] - shift; if (ov > 0) skip = (uint32_t)ov; }
+                    uint32_t cw, nw; stored_codes(lpk, lnb, (pg >> 4) + g, len, skip, rc, pos - sd0, take, cw, nw);
+                    acc |= (unsigned long long)cw << (2u * filled); nacc |= nw << filled; filled += take;
+                }
+                ok[kb] = (uint32_t)acc; on[kb] = (uint16_t)nacc;
+                if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
+                s_next = g;                                                  // the read that holds the dword's last base
+            }
+            kend = kb + 1u;
+            __syncthreads();
+            rcur = s_next;
+            // (fall through to the cursor search below with the window re-based: simplest is to continue the loop)
+            kb = kend; __syncthreads(); continue;
+        }
+        // the cursor for the next run: the read that holds stored base 16 * kend (inside this window by construction, or the chunk is done)
+        if (kend < k1) { const uint32_t B = 16u * kend; uint32_t lo = 0, hi = nr; while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_sd[mid] <= B) lo = mid; else hi = mid; } rcur += lo; }
+        kb = kend;
+        __syncthreads();
+    }
+    nsum = wave_sum(nsum);
+    if (lane_id() == 0 && nsum) atomicAdd(&ncount[c], nsum);
+}
+// general path: the byte-wise k_gather left the stored bases as bytes in scat (and counted their N); the same tight streams from those
+__global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint64_t* __restrict__ sbase, const uint8_t* __restrict__ scat,
+                                                   uint32_t* __restrict__ spk, uint16_t* __restrict__ snm) {
+    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1];
+    const uint32_t S = pv[e].d - pv[f].d, ndw = (S + 15u) >> 4;
+    const uint4* const src = (const uint4*)(scat + sbase[c]);               // (chunk bases are 64-byte aligned and padded)
+    uint32_t* const ok = spk + (size_t)(sbase[c] >> 4); uint16_t* const on = snm + (size_t)(sbase[c] >> 4);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < ndw; k += gridDim.x * blockDim.x) {
+        const uint4 v = src[k]; const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        uint32_t code = 0, nbits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
+        const uint32_t nv = S - 16u * k;
+        if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; nbits &= (1u << nv) - 1u; }
+        ok[k] = code; on[k] = (uint16_t)nbits;
+    }
+}
+
 // scratch capacity of every stream of a chunk: a value with k matches in len positions codes to at most
 // k + len/128 + 3*len/16384 bytes (one byte per token, +1 for each gap > 128, +3 for each gap > 16384).
 __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint64_t* __restrict__ ctotal, uint32_t n_chunks, const uint32_t* __restrict__ segm, uint32_t n_seg) {
@@ -1433,7 +1684,7 @@ struct PcStream {
 };
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
 // with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  The bytes go to S[t].out[0..).
-template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
+template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
                                                                            PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift, const uint8_t* exc_tab) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
@@ -1441,7 +1692,15 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
     // only one step after they were requested, so the wave never waits on the load it has just issued
     const uint32_t q0 = step0 * 4096u + 64u * (uint32_t)l;                 // positions fit int32: a stream of one batch is < 4 GiB of text, i.e. < 2^31 bases
     // (N positions: a step whose bit in the chunk's N map is clear holds no match - its 4096 bytes are not even loaded)
-    auto load = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (nmap && !nmap_test(nmap, nshift, step_)) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; } return pc_load_raw(B, len, p_); };
+    // BITS: B is not a byte per position but the match mask itself, one bit per position (the N-position stream reads k_seqpack's N mask):
+    // a lane's 64 positions are one u64 (kept in v[0].x / .y)
+    auto load = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (nmap && !nmap_test(nmap, nshift, step_)) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; }
+                                                           if (BITS) { Raw64 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = make_uint4(0, 0, 0, 0); if (p_ < len) { const uint2 w = ((const uint2*)B)[p_ >> 6]; r.v[0].x = w.x; r.v[0].y = w.y; } return r; }
+                                                           return pc_load_raw(B, len, p_); };
+    auto mask_of = [&](const Raw64& r_, uint32_t p_, uint32_t q_) -> uint64_t {
+        if (!BITS) return pc_mask_of(r_, len, p_, MODE, q_, D, exc_tab);
+        if (p_ >= len) return 0ull;
+        uint64_t m_ = ((uint64_t)r_.v[0].y << 32) | r_.v[0].x; if (len - p_ < 64) m_ &= (1ull << (len - p_)) - 1ull; return m_; };
     const uint32_t nst = (len + 4095u) / 4096u;
     auto loadc = [&](uint32_t step_, uint32_t p_) -> Raw64 { return load(step_ < nst ? step_ : nst - 1u, step_ < nst ? p_ : len); };
     Raw64 raw_n = loadc(step0 + 1, q0 + 4096u);
@@ -1459,7 +1718,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
 #pragma unroll
             for (int t = 0; t < G; t++) {
                 if (!need[t]) continue;
-                const uint64_t z = ~pc_mask_of(rb, len, pb, MODE, S[t].q, D, exc_tab);
+                const uint64_t z = ~mask_of(rb, pb, S[t].q);
                 const unsigned long long h0 = __ballot(z != 0);
                 if (h0) { const int v = z ? (int)pb + 63 - __clzll((long long)z) : -1; S[t].zero_carry = __shfl(v, 63 - __clzll((long long)h0)); need[t] = false; }
                 else any = true;
@@ -1467,7 +1726,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
         }
     }
 #pragma unroll
-    for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = pc_mask_of(r0, len, q0, MODE, S[t].q, D, exc_tab); S[t].m_next = pc_mask_of(raw_n, len, q0 + 4096u, MODE, S[t].q, D, exc_tab); S[t].outpos = 0; }
+    for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = mask_of(r0, q0, S[t].q); S[t].m_next = mask_of(raw_n, q0 + 4096u, S[t].q); S[t].outpos = 0; }
     raw_n = loadc(step0 + 2, q0 + 8192u);
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
@@ -1514,7 +1773,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
             if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > s.zero_carry) s.zero_carry = zl; }
         }
 #pragma unroll
-        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = pc_mask_of(raw_n, len, p0 + 8192u, MODE, S[t].q, D, exc_tab); }
+        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = mask_of(raw_n, p0 + 8192u, S[t].q); }
         raw_n = loadc(step + 3, p0 + 12288u);
     }
 }
@@ -1522,7 +1781,7 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_group
 // streams 4g .. 4g+3, group n_qgroups the exception stream, group n_qgroups + 1 the N-position stream (it reads the base buffer).
 // si = (c * MAX_STREAMS + j) * n_seg + seg; segm[si] = matches in the segment, segc[si] = its last match (k_gather), segb[si] = bytes
 // written here.  Streams whose value does not occur in the chunk (histogram) are skipped outright.
-template <int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
+template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg,
                             uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st, const uint8_t* exc_tab = nullptr) {
     const uint32_t nshift = nmap ? nmap_shift(len) : 0u;
@@ -1554,7 +1813,7 @@ template <int MODE, int G> __device__ __forceinline__ void pc_run(const ReadTab&
         S[t].out = scratch + cbase[c] + C.soff[k] + off; S[t].room = off + own <= cap ? own : 0u;
     }
     if (!any) return;                                                      // wave-uniform
-    wave_pos_encode_group<MODE, G>(B, len, D, S, step0, step1, nmap, nshift, exc_tab);
+    wave_pos_encode_group<MODE, G, BITS>(B, len, D, S, step0, step1, nmap, nshift, exc_tab);
 #pragma unroll
     for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) {
         segb[kk[t] * n_seg + seg] = S[t].outpos;
@@ -1570,7 +1829,7 @@ __global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint3
         C.ssize[k] = tot;
     }
 }
-__global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat,
+__global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint16_t* __restrict__ snm,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
                             uint32_t n_qgroups, DevStatus* st) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
@@ -1586,7 +1845,7 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
         wave_lds_sync();
         pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st, s_exc);
     }
-    else pc_run<PC_MATCH, 1>(R, C, D, scat + C.sbase[c], R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
+    else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
@@ -1712,7 +1971,7 @@ __device__ __forceinline__ void copy_to_image(uint8_t* __restrict__ dst, const u
 // grid (blocks_per_chunk, n_chunks): fixed fields, per-read arrays, coordinate streams, "same" names, packed bases,
 // quality payload, overlap bytes, N positions.
 __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L,
-                           const uint8_t* __restrict__ qcat, const uint8_t* __restrict__ scat, const uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
+                           const uint8_t* __restrict__ qcat, const uint32_t* __restrict__ spk, const uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
                            const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
                            uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2,
                            const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, DevStatus* st,
@@ -1788,44 +2047,8 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
     if (fl & C_NAME1_SAME) { const uint8_t* src = line_ptr(T, f, 0); for (uint32_t i = t; i < o.n1_size; i += NT) out[o.off_n1 + i] = src[i]; }
     if ((hf & H_NAME2) && (fl & C_NAME2_SAME)) { const uint8_t* src = line_ptr(T, f, 0) + R.name2_off[f]; for (uint32_t i = t; i < o.n2_size; i += NT) out[o.off_n2 + i] = src[i]; }
     if (fl & C_STRAND_SAME) { const uint8_t* src = line_ptr(T, f, 2); for (uint32_t i = t; i < o.st_size; i += NT) out[o.off_st + i] = src[i]; }
-    // 2-bit bases: G=0 A=1 T=2 C=3, anything else 0 (src/rfqcodec.cpp:590-604).  16 bases -> one ALIGNED dword of the image: the first
-    // (4 - address & 3) & 3 bytes go out as bytes, which shifts the 16-base groups by a multiple of 4 bases, i.e. dword-aligned in scat.
-    {
-        const uint8_t* sb = scat + C.sbase[c]; const uint32_t n = R.pv[f + s].d - R.pv[f].d;
-        uint8_t* od = out + o.off_seq; const uint32_t nbytes = o.seq_size;
-        uint32_t head = (uint32_t)((4u - ((uintptr_t)od & 3u)) & 3u); if (head > nbytes) head = nbytes;
-        auto pack4 = [&](uint32_t w, uint32_t p) -> uint32_t {            // 4 bases at positions p..p+3 -> one byte
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) { const uint32_t ch = (w >> (8 * b)) & 0xFFu; const uint32_t code = p + (uint32_t)b < n ? (ch == 'A' ? 1u : (ch == 'T' ? 2u : (ch == 'C' ? 3u : 0u))) : 0u; v |= code << (2 * b); }
-            return v;
-        };
-        // four bases -> one byte without per-base branches: bits 1-2 of a base are a perfect hash (A 0, C 1, T 2, G 3), v_perm_b32 looks
-        // the codes up, a second look-up in the identity table zeroes everything that is not exactly A/C/G/T, one multiply gathers the
-        // four 2-bit fields.  Only for words that lie wholly below n (the pad behind a chunk's bases may hold anything).
-        auto pack4_fast = [&](uint32_t w) -> uint32_t {
-            const uint32_t idx = (w >> 1) & 0x03030303u;
-            const uint32_t code = __builtin_amdgcn_perm(0u, 0x00020301u, idx) & eq_bytes_full(__builtin_amdgcn_perm(0u, 0x47544341u, idx), w);
-            return (code * 0x01041040u) >> 24;
-        };
-        const uint32_t* sw = (const uint32_t*)sb;                           // scat chunk bases are 64-byte aligned, padded to 64
-        if (t < head) od[t] = (uint8_t)pack4(sw[t], 4 * t);
-        const uint32_t body = (nbytes - head) / 4; uint32_t* dw = (uint32_t*)(od + head);
-        for (uint32_t k0 = t; k0 < body; k0 += 2 * NT) {                  // two dwords (32 bases) per thread in flight
-            uint32_t w[2][4];
-#pragma unroll
-            for (int u = 0; u < 2; u++) { const uint32_t k = k0 + (uint32_t)u * NT;
-#pragma unroll
-                for (int i = 0; i < 4; i++) w[u][i] = k < body ? sw[head + 4 * k + (uint32_t)i] : 0u; }
-#pragma unroll
-            for (int u = 0; u < 2; u++) { const uint32_t k = k0 + (uint32_t)u * NT; if (k >= body) continue;
-                const uint32_t p = 4 * (head + 4 * k);
-                if (p + 16u <= n) dw[k] = pack4_fast(w[u][0]) | (pack4_fast(w[u][1]) << 8) | (pack4_fast(w[u][2]) << 16) | (pack4_fast(w[u][3]) << 24);
-                else dw[k] = pack4(w[u][0], p) | (pack4(w[u][1], p + 4) << 8) | (pack4(w[u][2], p + 8) << 16) | (pack4(w[u][3], p + 12) << 24); }
-        }
-        const uint32_t done = head + 4 * body;
-        if (t < nbytes - done) od[done + t] = (uint8_t)pack4(sw[done + t], 4 * (done + t));
-    }
+    // 2-bit bases (src/rfqcodec.cpp:590-604): k_seqpack / k_packbytes left the section's bytes in spk
+    copy_to_image(out + o.off_seq, (const uint8_t*)(spk + (size_t)(C.sbase[c] >> 4)), o.seq_size, t, NT);
     // quality payload
     if (hf & H_DONT_QUAL) copy_to_image(out + o.off_qual, qcat + C.qbase[c], o.qual_size, t, NT);
     else if (hf & H_QUAL_BY_COL) {

@@ -47,6 +47,28 @@ def test_multichunk_matches_oracle(codec, label, prof, reads, seed, cb, paired, 
     assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
 
 
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:6], ids=[m[0] for m in MULTI[:6]])
+def test_multichunk_bytewise_gather_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+    """RFQ_GATHER=old: the byte-wise k_gather + k_packbytes (the path of reads too long for a tile and of mates with odd bases)."""
+    monkeypatch.setenv("RFQ_GATHER", "old")
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+    assert "gather_bytes" in dict(codec.timings())
+
+
+def test_gather_paths_are_the_ones_expected(codec):
+    """The tile gather (k_gather2 + k_seqpack) is what runs by default; a mate with a byte outside A/C/G/T/N in an interleaved chunk makes the
+    call fall back to the byte-wise gather (Read::changeToReverseComplement turns such a byte into N, which 2-bit codes cannot express)."""
+    fq1, fq2 = O.gen(O.NOVA_PE150, 200, seed=31)
+    assert E.encode(codec, fq1, fq2, O.PE_TWO_FILES, 20000) == O.encode_file(fq1, fq2, O.PE_TWO_FILES, 20000)
+    assert "gather" in dict(codec.timings())
+    lines = fq2.split(b"\n")
+    lines[4 * 150 + 1] = lines[4 * 150 + 1][:30] + b"r" + lines[4 * 150 + 1][31:]       # a mate of the second chunk or later (chunk 0 must be clean: the header is made from it)
+    odd = b"\n".join(lines)
+    assert E.encode(codec, fq1, odd, O.PE_TWO_FILES, 20000) == O.encode_file(fq1, odd, O.PE_TWO_FILES, 20000)
+    assert "gather_bytes" in dict(codec.timings())
+
+
 def test_batched_encode_with_carry_over_equals_one_shot(codec):
     """Repaq::compress reads a stream; the host driver feeds it in batches: non-final batches stop at the last full chunk and
     report consumed bytes, the remainder is carried into the next batch.  Concatenation must equal the one-shot image."""
