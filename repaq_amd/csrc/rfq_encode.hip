@@ -423,9 +423,12 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // Fast path (k_gather2 + k_seqpack): tiles of K reads - the largest power of two whose records always fit the staged-text buffer.  Reads too long
     // for a two-read tile, and batches where a reverse-complemented mate holds a byte outside A/C/G/T/N (found by the fast path itself), take
     // the byte-wise k_gather + k_packbytes.  RFQ_GATHER=old forces that path (tests run both).
-    uint32_t kshift = 6; if (getenv("RFQ_G2_KSHIFT")) kshift = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_G2_KSHIFT"))));   // (profiling aid: smaller tiles)
-    while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > G2_CAP) kshift--;
+    // (RFQ_GATHER=pipe: two half-size text buffers, the next tile's staging under this tile's compose; RFQ_G2_KSHIFT: smaller tiles - profiling aids)
     const char* genv = getenv("RFQ_GATHER");
+    const bool pipe = genv && !strcmp(genv, "pipe");
+    const uint32_t g2cap = pipe ? G2_CAP / 2 : G2_CAP;
+    uint32_t kshift = 6; if (getenv("RFQ_G2_KSHIFT")) kshift = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_G2_KSHIFT"))));
+    while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > g2cap) kshift--;
     bool fast = kshift >= 1 && !(genv && !strcmp(genv, "old"));
     const uint32_t max_rec = hs.max_rec;
     for (;;) {
@@ -436,8 +439,11 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2));
             const uint32_t K = 1u << kshift;
             const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
-            hipLaunchKernelGGL(k_gather2, dim3(bx, n_chunks), dim3(256), 0, S, T, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint32_t*)C.il, (const uint64_t*)C.qbase, (const DevHeader*)D,
-                               B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, dst, (tune >> 16) & 15);   // (tune bits 16-19: ablation switches of k_gather2, results invalid)
+#define RFQ_G2_ARGS T, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint32_t*)C.il, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), \
+                    B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, dst, (tune >> 16) & 15      /* (tune bits 16-19: ablation switches of k_gather2, results invalid) */
+            if (pipe) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
+            else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
+#undef RFQ_G2_ARGS
             const uint32_t sx = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
             hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, S, (const uint32_t*)R.pq, (const U4*)R.pv, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),

@@ -1320,14 +1320,87 @@ __device__ __forceinline__ void pack4_codes(uint32_t w, uint32_t& code, uint32_t
     nb = 0; bad = 0;
     if (ok != 0xFFFFFFFFu) { const uint32_t isn = eq_bytes_full(w, 0x4E4E4E4Eu); nb = ((isn & 0x01010101u) * 0x01020408u) >> 24; bad = (((~ok & ~isn) & 0x01010101u) * 0x01020408u) >> 24; }
 }
-__global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const uint64_t* __restrict__ qbase,
+struct G2Geo { uint32_t a00, a01, end0, end1, base1; };                         // a tile's text spans: 16-aligned begin and end per stream, LDS offset of stream 1's span
+struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld; };       // my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
+__device__ __forceinline__ G2Geo g2_geo(const Text& T, bool two, uint32_t cur, uint32_t cnt) {
+    G2Geo g;
+    if (two) { const size_t r0 = 4 * (size_t)(cur >> 1), r1 = 4 * (size_t)((cur + cnt) >> 1);
+               g.a00 = uni32(T.lo[0][r0]) & ~15u; g.end0 = uni32(T.lo[0][r1]); g.a01 = uni32(T.lo[1][r0]) & ~15u; g.end1 = uni32(T.lo[1][r1]); }
+    else { g.a00 = uni32(T.lo[0][4 * (size_t)cur]) & ~15u; g.end0 = uni32(T.lo[0][4 * (size_t)(cur + cnt)]); g.a01 = 0; g.end1 = 0; }
+    g.base1 = two ? (((g.end0 - g.a00 + 15u) & ~15u) + 16u) : 0u;
+    return g;
+}
+// LDS-DMA of a tile's spans to buf4 (global_load_lds_dwordx4: every lane names its own 16 global bytes, a wave's 64 groups land contiguously)
+__device__ __forceinline__ void g2_stage1(const uint8_t* __restrict__ fq, uint32_t n, uint32_t a0, uint32_t end, uint4* l4, uint32_t tid) {
+    const uint32_t nb = end - a0, ng = (nb + 15u) / 16u;
+    const uint8_t* src = fq + a0;
+    const uint32_t nfull = (uint64_t)a0 + 16ull * ng <= (uint64_t)n ? ng : ng - 1u;      // (only a stream's very last group may reach past the buffer)
+    for (uint32_t i = tid; i < nfull; i += blockDim.x)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i), (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
+    if (nfull < ng && tid == 0) { uint8_t* const bytes = (uint8_t*)l4; for (uint32_t k = 0; k < 16 && a0 + 16 * nfull + k < n; k++) bytes[16 * nfull + k] = src[16 * (size_t)nfull + k]; }
+}
+__device__ __forceinline__ void g2_stage(const Text& T, bool two, const G2Geo& g, uint4* buf4, uint32_t tid) {
+    g2_stage1(T.fq[0], T.n[0], g.a00, g.end0, buf4, tid);
+    if (two) g2_stage1(T.fq[1], T.n[1], g.a01, g.end1, buf4 + g.base1 / 16, tid);
+}
+__device__ __forceinline__ G2Read g2_read(const Text& T, const uint32_t* __restrict__ pq, const G2Geo& g, uint32_t f, uint32_t pq0, bool il, uint32_t cur, uint32_t j, uint32_t cnt) {
+    G2Read m; m.on = j < cnt; m.rc = false; m.len = m.qsrc = m.ssrc = m.qpos = m.ld = 0;
+    if (m.on) {
+        const uint32_t gi = cur + j; int s_; uint32_t r_; read_loc(T, gi, s_, r_);
+        const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);     // starts of the read's four lines
+        const uint32_t lb = s_ ? g.base1 : 0u, a = s_ ? g.a01 : g.a00;
+        m.len = lo4.z - 1u - lo4.y; m.ssrc = lb + (lo4.y - a); m.qsrc = lb + (lo4.w - a);
+        const uint32_t pg = pq[gi]; m.qpos = pg - pq0; m.ld = (pg >> 4) + gi;
+        m.rc = il && ((gi - f) & 1u);
+    }
+    return m;
+}
+// my share (groups part, part + P, ...) of my read's two lines: qualities -> qcat, bases -> the loose slot.  Returns "a reverse-complemented mate holds an odd byte".
+__device__ __forceinline__ bool g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, QualCount& qc, int abl) {
+    bool odd = false;
+    if (m.on && !(abl & 1)) {
+        // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
+        const uint32_t n = m.len; uint8_t* const o = qd + m.qpos; const bool rc = m.rc;
+        if (n >= 16u) {
+            const uint32_t ng = (n + 15u) >> 4;
+            for (uint32_t gi = part; gi < ng; gi += P) {
+                uint32_t p0 = 16u * gi, dup = 0; if (p0 + 16u > n) { dup = p0 + 16u - n; p0 = n - 16u; }     // the last group ends exactly at n: its first `dup` bytes repeat the group before
+                uint32_t w[4]; lds_get16(s_text, rc ? m.qsrc + n - p0 - 16u : m.qsrc + p0, w);
+                if (rc) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
+                if (!(abl & 4)) { GU16g v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16g*)(o + p0) = v; }
+                if (abl & 8) continue;
+                if (!dup) qc.group(m.qpos + p0, w[0], w[1], w[2], w[3]);
+                else for (uint32_t k = dup; k < 16u; k++) qc(m.qpos + p0 + k, (uint8_t)(w[k >> 2] >> (8u * (k & 3u))));
+            }
+        } else for (uint32_t i = part; i < n; i += P) { const uint8_t q = s_text[rc ? m.qsrc + n - 1u - i : m.qsrc + i]; o[i] = q; qc(m.qpos + i, q); }
+    }
+    if (m.on && !(abl & 2)) {
+        // ---- bases: 16 per step -> one dword of codes + 16 N bits, file orientation, into the read's loose slot
+        const uint32_t ng = (m.len + 15u) >> 4;
+        for (uint32_t gi = part; gi < ng; gi += P) {
+            uint32_t w[4]; lds_get16(s_text, m.ssrc + 16u * gi, w);
+            uint32_t code = 0, nbits = 0, bad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
+            const uint32_t nv = m.len - 16u * gi;                          // valid bases of this step (what lies behind the line's end is not the read's)
+            if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; const uint32_t mk = (1u << nv) - 1u; nbits &= mk; bad &= mk; }
+            if (bad && m.rc) odd = true;
+            lpk[m.ld + gi] = code; lnb[m.ld + gi] = (uint16_t)nbits;
+        }
+    }
+    return odd;
+}
+// PIPE: two text buffers of half the size; the next tile's LDS-DMA is issued right behind the barrier that hands over this tile's text and flies
+// under this tile's compose - one barrier per tile.  (Measured on configs[2], single buffer, K = 64: of the kernel's 3.4 ms, 1.8 ms are the bare
+// stage-and-wait loop - 8 GB at 4.4 TB/s with a third of the resident workgroups in their staging phase at any time.)
+template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb,
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift, DevStatus* st, int abl) {
-    __shared__ uint4 s_text4[G2_CAP / 16 + 8];
-    __shared__ uint32_t sh[G2_CNT]; __shared__ int sh_last[G2_CNT]; __shared__ uint8_t s_slot[256];
-    uint8_t* const s_text = (uint8_t*)(s_text4 + 1);                      // 16 bytes of slack in front: reversed 16-byte fetches may start before a line
+    __shared__ uint4 s_text4[G2_CAP / 16 + 16];
+    __shared__ uint32_t sh[PIPE ? 2 : 1][G2_CNT]; __shared__ int sh_last[PIPE ? 2 : 1][G2_CNT]; __shared__ uint8_t s_slot[256];   // (two counter sets when tiles overlap)
+    constexpr uint32_t HALF4 = G2_CAP / 32 + 8;                             // uint4 per buffer when there are two (each with its own slack)
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < G2_CNT; i += blockDim.x) { sh[i] = 0; sh_last[i] = -1; }
+    for (uint32_t i = tid; i < (PIPE ? 2u : 1u) * G2_CNT; i += blockDim.x) { (&sh[0][0])[i] = 0; (&sh_last[0][0])[i] = -1; }
     const uint32_t nn_s = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, nslot = nn_s + 1u;
     uint32_t nrep = 1; while (nrep < 16u && 4u * nrep * nslot <= G2_CNT) nrep *= 2u;
     for (uint32_t i = tid; i < 256; i += blockDim.x) { const uint32_t j = D->stream_of[i]; s_slot[i] = (uint8_t)(j < nn_s ? j : nn_s); }
@@ -1338,72 +1411,45 @@ __global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restr
     const uint32_t gs = f + blockIdx.x * per, ge = gs + per < e ? gs + per : e;
     const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;              // K reads per tile, P threads per read
     const uint32_t j = tid >> pshift, part = tid & (P - 1u);
-    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
+    QualCount qc; qc.cnt = sh[0]; qc.last = sh_last[0]; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
     bool odd = false;
-    __syncthreads();
-    for (uint32_t cur = gs; cur < ge; cur += K) {                          // block-uniform
-        const uint32_t cnt = ge - cur < K ? ge - cur : K;
-        // ---- the tile's text spans (one per stream), wave-uniform
-        uint32_t a0[2], sp_end[2] = { 0, 0 };
-        if (two) { const size_t r0 = 4 * (size_t)(cur >> 1), r1 = 4 * (size_t)((cur + cnt) >> 1);
-                   a0[0] = uni32(T.lo[0][r0]) & ~15u; sp_end[0] = uni32(T.lo[0][r1]); a0[1] = uni32(T.lo[1][r0]) & ~15u; sp_end[1] = uni32(T.lo[1][r1]); }
-        else { a0[0] = uni32(T.lo[0][4 * (size_t)cur]) & ~15u; sp_end[0] = uni32(T.lo[0][4 * (size_t)(cur + cnt)]); a0[1] = 0; }
-        const uint32_t base1 = two ? (((sp_end[0] - a0[0] + 15u) & ~15u) + 16u) : 0u;   // LDS offset of stream 1's span
-        for (int st_ = 0; st_ < (two ? 2 : 1); st_++) {
-            const uint32_t nb = sp_end[st_] - a0[st_], ng = (nb + 15u) / 16u, lb = st_ ? base1 : 0u;
-            const uint8_t* src = t_fq(T, st_) + a0[st_];
-            const uint32_t nfull = (uint64_t)a0[st_] + 16ull * ng <= (uint64_t)t_n(T, st_) ? ng : ng - 1u;      // (only a stream's very last group may reach past the buffer)
-            uint4* const l4 = s_text4 + 1 + lb / 16;
-            for (uint32_t i = tid; i < nfull; i += blockDim.x)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i), (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
-            if (nfull < ng && tid == 0) for (uint32_t k = 0; k < 16 && a0[st_] + 16 * nfull + k < t_n(T, st_); k++) s_text[lb + 16 * nfull + k] = src[16 * (size_t)nfull + k];
+    if (!PIPE) {
+        uint4* const buf4 = s_text4 + 1;
+        __syncthreads();
+        for (uint32_t cur = gs; cur < ge; cur += K) {                      // block-uniform
+            const uint32_t cnt = ge - cur < K ? ge - cur : K;
+            const G2Geo g = g2_geo(T, two, cur, cnt);
+            g2_stage(T, two, g, buf4, tid);
+            const G2Read m = g2_read(T, pq, g, f, pq0, il, cur, j, cnt);
+            const uint32_t qbeg = uni32(pq[cur]) - pq0;                      // the tile's first quality position (chunk-relative)
+            __syncthreads();                                                // (drains the LDS-DMA)
+            qc.seg0 = qbeg / PC_SEG_POS;
+            odd |= g2_compose((const uint8_t*)buf4, m, part, P, qd, lpk, lnb, qc, abl);
+            __syncthreads();                                                // the text is free for the next tile; the tile's counts are complete
+            qual_flush(sh[0], sh_last[0], nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
         }
-        // ---- my read (P neighbouring threads share one): where its lines are, where its output goes
-        const uint32_t g = cur + j; const bool on = j < cnt;
-        uint32_t len = 0, qsrc = 0, ssrc = 0, qpos = 0, ld = 0; bool rc = false;
-        const uint32_t qbeg = uni32(pq[cur]) - pq0;                          // the tile's first quality position (chunk-relative)
-        if (on) {
-            int s_; uint32_t r_; read_loc(T, g, s_, r_);
-            const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);   // starts of the read's four lines
-            const uint32_t lb = s_ ? base1 : 0u, a = s_ ? a0[1] : a0[0];
-            len = lo4.z - 1u - lo4.y; ssrc = lb + (lo4.y - a); qsrc = lb + (lo4.w - a);
-            const uint32_t pg = pq[g]; qpos = pg - pq0; ld = (pg >> 4) + g;
-            rc = il && ((g - f) & 1u);
-        }
-        __syncthreads();                                                    // (drains the LDS-DMA)
-        qc.seg0 = qbeg / PC_SEG_POS;
-        if (on && !(abl & 1)) {
-            // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
-            const uint32_t n = len; uint8_t* const o = qd + qpos;
-            if (n >= 16u) {
-                const uint32_t ng = (n + 15u) >> 4;
-                for (uint32_t gi = part; gi < ng; gi += P) {
-                    uint32_t p0 = 16u * gi, dup = 0; if (p0 + 16u > n) { dup = p0 + 16u - n; p0 = n - 16u; }     // the last group ends exactly at n: its first `dup` bytes repeat the group before
-                    uint32_t w[4]; lds_get16(s_text, rc ? qsrc + n - p0 - 16u : qsrc + p0, w);
-                    if (rc) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
-                    if (!(abl & 4)) { GU16g v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16g*)(o + p0) = v; }
-                    if (abl & 8) continue;
-                    if (!dup) qc.group(qpos + p0, w[0], w[1], w[2], w[3]);
-                    else for (uint32_t k = dup; k < 16u; k++) qc(qpos + p0 + k, (uint8_t)(w[k >> 2] >> (8u * (k & 3u))));
-                }
-            } else for (uint32_t i = part; i < n; i += P) { const uint8_t q = s_text[rc ? qsrc + n - 1u - i : qsrc + i]; o[i] = q; qc(qpos + i, q); }
-        }
-        if (on && !(abl & 2)) {
-            // ---- bases: 16 per step -> one dword of codes + 16 N bits, file orientation, into the read's loose slot
-            const uint32_t ng = (len + 15u) >> 4;
-            for (uint32_t gi = part; gi < ng; gi += P) {
-                uint32_t w[4]; lds_get16(s_text, ssrc + 16u * gi, w);
-                uint32_t code = 0, nbits = 0, bad = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
-                const uint32_t nv = len - 16u * gi;                        // valid bases of this step (what lies behind the line's end is not the read's)
-                if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; const uint32_t m = (1u << nv) - 1u; nbits &= m; bad &= m; }
-                if (bad && rc) odd = true;
-                lpk[ld + gi] = code; lnb[ld + gi] = (uint16_t)nbits;
+    } else if (gs < ge) {
+        uint32_t cnt = ge - gs < K ? ge - gs : K;
+        G2Geo g = g2_geo(T, two, gs, cnt);
+        g2_stage(T, two, g, s_text4 + 1, tid);
+        G2Read m = g2_read(T, pq, g, f, pq0, il, gs, j, cnt);
+        uint32_t qbeg = uni32(pq[gs]) - pq0, seg_prev = 0;
+        uint32_t pb = 0;
+        for (uint32_t cur = gs; cur < ge; cur += K, pb ^= 1u) {            // block-uniform
+            __syncthreads();                                                // this tile's text has landed; every wave is done with the tile before (its text buffer, its counters)
+            if (cur > gs) qual_flush(sh[PIPE ? pb ^ 1u : 0u], sh_last[PIPE ? pb ^ 1u : 0u], nrep, nslot, seg_prev, c, nn_s, segm, segc, n_seg);   // (that set is next counted into two barriers from here)
+            const uint32_t nxt = cur + K; G2Geo gn = g; G2Read mn = m; uint32_t qn = 0, cn = 0;
+            if (nxt < ge) {                                                 // the next tile's text and my read of it: in flight under this tile's compose
+                cn = ge - nxt < K ? ge - nxt : K; gn = g2_geo(T, two, nxt, cn);
+                g2_stage(T, two, gn, s_text4 + 1 + (pb ^ 1u) * HALF4, tid);
+                mn = g2_read(T, pq, gn, f, pq0, il, nxt, j, cn); qn = uni32(pq[nxt]) - pq0;
             }
+            qc.cnt = sh[PIPE ? pb : 0u]; qc.last = sh_last[PIPE ? pb : 0u]; qc.seg0 = qbeg / PC_SEG_POS; seg_prev = qc.seg0;
+            odd |= g2_compose((const uint8_t*)(s_text4 + 1 + pb * HALF4), m, part, P, qd, lpk, lnb, qc, abl);
+            g = gn; m = mn; qbeg = qn; cnt = cn;
         }
-        __syncthreads();                                                    // the text is free for the next tile; the tile's counts are complete
-        qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
+        __syncthreads();
+        qual_flush(sh[PIPE ? pb ^ 1u : 0u], sh_last[PIPE ? pb ^ 1u : 0u], nrep, nslot, seg_prev, c, nn_s, segm, segc, n_seg);
     }
     if (__any(odd) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_ODD_BASE);
 }
@@ -1443,88 +1489,96 @@ __device__ __forceinline__ void stored_codes(const uint32_t* __restrict__ lpk, c
 }
 // Loose slots -> the chunk's tight streams: spk = 2-bit stored bases, 16 per dword, dword k of chunk c at (sbase[c] >> 4) + k - the bytes of the
 // image's sequence section (RfqChunk::write copies them) - and snm = one "is N" bit per stored base at the same u16 index (the N-position
-// coder's match mask).  One thread makes one dword: the reads that overlap a run of 256 dwords are found once per run (their stored prefixes
-// staged in LDS, the cursor moves on monotonically), then every thread bisects that window for its first base and walks on.  N counts per
-// coder segment, the chunk's N total and N map are left as k_gather leaves them.
-#define SP_WIN 256u
+// coder's match mask).  One lane makes one dword.  Waves are independent (no LDS, no barrier: the first form - a workgroup staging a window of
+// reads in LDS, three barriers per 256 dwords - took 2.8 ms on configs[2], all of it exposed latency): a wave owns a run of dwords and walks it 256
+// at a time; the stored prefixes and slot data of the 64 reads from its cursor on sit in its lanes, a lane bisects them with shuffles for the read
+// that holds its first base and walks on from there.  N counts per coder segment, the chunk's N total and N map are left as k_gather leaves them.
+#define SP_U 4u                   // dwords per lane and step
 __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
                                                  const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
                                                  uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
-    __shared__ uint32_t s_sd[SP_WIN + 1], s_ld[SP_WIN], s_len[SP_WIN], s_sk[SP_WIN], s_next;
-    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1], tid = threadIdx.x;
+    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1]; const int l = lane_id();
     const uint32_t ps0 = pv[f].d, S = pv[e].d - ps0, ndw = (S + 15u) >> 4;
-    uint32_t per = (ndw + gridDim.x - 1) / gridDim.x; per = (per + 255u) & ~255u;
-    const uint32_t k0 = blockIdx.x * per, k1 = k0 + per < ndw ? k0 + per : ndw;
-    if (k0 >= k1) return;
+    const uint32_t nwv = gridDim.x * (blockDim.x >> 6), wv = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id();
+    uint32_t per = (ndw + nwv - 1) / nwv; per = (per + 64u * SP_U - 1u) / (64u * SP_U) * (64u * SP_U);
+    const uint32_t k0 = uni32(wv * per), k1 = uni32(k0 + per < ndw ? k0 + per : ndw);
+    if (k0 >= k1) return;                                                   // (wave-uniform; nothing below synchronises across waves)
     const bool il = ilv[c] != 0, enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
     uint32_t* const ok = spk + (size_t)(sbase[c] >> 4); uint16_t* const on = snm + (size_t)(sbase[c] >> 4);
     const uint32_t nshift = nmap_shift(S); uint32_t* const nm = nmap + (size_t)c * NMAP_WORDS;
     const size_t nsi = ((size_t)c * MAX_STREAMS + NPOS_SLOT) * n_seg;
     // the read that holds stored base 16 * k0: the last r in [f, e) whose stored prefix is <= it (wave-uniform bisection)
     uint32_t rcur;
-    { uint32_t lo = f, hi = e; const uint32_t B = 16u * k0; while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (pv[mid].d - ps0 <= B) lo = mid; else hi = mid; } rcur = lo; }
+    { uint32_t lo = f, hi = e; const uint32_t B = 16u * k0; while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (uni32(pv[mid].d) - ps0 <= B) lo = mid; else hi = mid; } rcur = lo; }
     uint32_t nsum = 0;
-    for (uint32_t kb = k0; kb < k1; ) {                                      // block-uniform
-        const uint32_t nr = e - rcur < SP_WIN ? e - rcur : SP_WIN;          // reads in the window
-        for (uint32_t t = tid; t <= nr; t += blockDim.x) {
-            const uint32_t g = rcur + t; s_sd[t] = pv[g].d - ps0;
-            if (t < nr) {
-                const uint32_t pg = pq[g], len = pq[g + 1] - pg; const bool rc = il && ((g - f) & 1u);
-                uint32_t skip = 0; if (rc && enc) { const int ov = (int)ovb[g >> 1] - shift; if (ov > 0) skip = (uint32_t)ov; }
-                s_ld[t] = (pg >> 4) + g; s_len[t] = len; s_sk[t] = skip | (rc ? 0x80000000u : 0u);
-            }
-        }
-        __syncthreads();
+    auto slot_of = [&](uint32_t g, uint32_t& ld, uint32_t& len, uint32_t& sk) {
+        const uint32_t pg = pq[g]; len = pq[g + 1] - pg; ld = (pg >> 4) + g; const bool rc = il && ((g - f) & 1u);
+        uint32_t skip = 0; if (rc && enc) { const int ov = (int)ovb[g >> 1] - shift; if (ov > 0) skip = (uint32_t)ov; }
+        sk = skip | (rc ? 0x80000000u : 0u);
+    };
+    auto n_stats = [&](uint32_t B, uint32_t nacc) {
+        const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B);
+        atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc)));
+    };
+    for (uint32_t kb = k0; kb < k1; ) {                                      // wave-uniform
+        const uint32_t nr = e - rcur < 64u ? e - rcur : 64u;                 // reads in the window: lane i holds read rcur + i
+        uint32_t sdA = 0xFFFFFFFFu, sdB = 0xFFFFFFFFu, w_ld = 0, w_len = 0, w_sk = 0;
+        if ((uint32_t)l < nr) { const uint32_t g = rcur + (uint32_t)l; sdA = pv[g].d - ps0; sdB = pv[g + 1].d - ps0; slot_of(g, w_ld, w_len, w_sk); }
         // dwords whose bases all lie inside the window
-        const uint32_t lim = s_sd[nr]; const uint32_t kmax = lim >= S ? ndw : lim >> 4;
-        uint32_t kend = kb + 256u < k1 ? kb + 256u : k1; if (kend > kmax) kend = kmax;
-        if (kend <= kb) kend = kb;                                          // (a window of SP_WIN reads holds fewer than 16 bases: the serial step below)
-        const uint32_t k = kb + tid;
-        if (k < kend) {
-            const uint32_t B = 16u * k, need = S - B < 16u ? S - B : 16u;
-            uint32_t lo = 0, hi = nr; while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_sd[mid] <= B) lo = mid; else hi = mid; }
-            unsigned long long acc = 0; uint32_t nacc = 0, filled = 0, r = lo;
-            while (filled < need) {
-                const uint32_t pos = B + filled, avail = s_sd[r + 1] - pos;
-                if (avail == 0) { r++; continue; }
-                const uint32_t take = avail < need - filled ? avail : need - filled;
-                uint32_t cw, nw; const uint32_t sk = s_sk[r];
-                stored_codes(lpk, lnb, s_ld[r], s_len[r], sk & 0x7FFFFFFFu, (sk >> 31) != 0, pos - s_sd[r], take, cw, nw);
-                acc |= (unsigned long long)cw << (2u * filled); nacc |= nw << filled; filled += take;
-            }
-            ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc;
-            if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
-        }
-        if (kend == kb) {
-            // serial step: one dword, its bases gathered read by read from global memory (thousands of near-empty reads in a row)
-            if (tid == 0) {
+        const uint32_t lim = uni32(__shfl(sdB, (int)nr - 1)); const uint32_t kmax = lim >= S ? ndw : lim >> 4;
+        uint32_t kend = kb + 64u * SP_U < k1 ? kb + 64u * SP_U : k1; if (kend > kmax) kend = kmax;
+        if (kend <= kb) {
+            // serial step: one dword, its bases gathered read by read (sixty-four reads in a row that hold fewer than 16 bases)
+            uint32_t gnext = rcur;
+            if (l == 0) {
                 const uint32_t B = 16u * kb, need = S - B < 16u ? S - B : 16u; unsigned long long acc = 0; uint32_t nacc = 0, filled = 0, g = rcur;
                 while (filled < need) {
                     const uint32_t sd0 = pv[g].d - ps0, sd1 = pv[g + 1].d - ps0, pos = B + filled;
                     if (sd1 <= pos) { g++; continue; }
                     const uint32_t avail = sd1 - pos, take = avail < need - filled ? avail : need - filled;
-                    const uint32_t pg = pq[g], len = pq[g + 1] - pg; const bool rc = il && ((g - f) & 1u);
-                    uint32_t skip = 0; if (rc && enc) { const int ov = (int)ovb[g >> 1] - shift; if (ov > 0) skip = (uint32_t)ov; }
-                    uint32_t cw, nw; stored_codes(lpk, lnb, (pg >> 4) + g, len, skip, rc, pos - sd0, take, cw, nw);
+                    uint32_t ld, len, sk; slot_of(g, ld, len, sk);
+                    uint32_t cw, nw; stored_codes(lpk, lnb, ld, len, sk & 0x7FFFFFFFu, (sk >> 31) != 0, pos - sd0, take, cw, nw);
                     acc |= (unsigned long long)cw << (2u * filled); nacc |= nw << filled; filled += take;
                 }
                 ok[kb] = (uint32_t)acc; on[kb] = (uint16_t)nacc;
-                if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
-                s_next = g;                                                  // the read that holds the dword's last base
+                if (nacc) n_stats(B, nacc);
+                gnext = g;                                                   // the read that holds the dword's last base
             }
-            kend = kb + 1u;
-            __syncthreads();
-            rcur = s_next;
-            // (fall through to the cursor search below with the window re-based: simplest is to continue the loop)
-            kb = kend; __syncthreads(); continue;
+            rcur = uni32(__shfl(gnext, 0)); kb = kb + 1u; continue;
         }
-        // the cursor for the next run: the read that holds stored base 16 * kend (inside this window by construction, or the chunk is done)
-        if (kend < k1) { const uint32_t B = 16u * kend; uint32_t lo = 0, hi = nr; while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_sd[mid] <= B) lo = mid; else hi = mid; } rcur += lo; }
+#pragma unroll 1
+        for (uint32_t u = 0; u < SP_U; u++) {
+            const uint32_t k = kb + 64u * u + (uint32_t)l; const bool act = k < kend;
+            if (!__any(act)) break;
+            const uint32_t B = act ? 16u * k : 16u * kb, need = act ? (S - B < 16u ? S - B : 16u) : 0u;
+            uint32_t lo = 0, hi = nr;
+#pragma unroll
+            for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(sdA, (int)mid); if (hi - lo > 1u) { if (v <= B) lo = mid; else hi = mid; } }   // (six steps whatever the lane's interval: the shuffles stay wave-wide)
+            unsigned long long acc = 0; uint32_t nacc = 0, filled = 0, r = lo;
+            while (__any(filled < need)) {                                   // (a dword spans two reads once in ~ten, more only when reads are tiny)
+                const int rr = (int)(r < nr ? r : nr - 1u);
+                const uint32_t a = __shfl(sdA, rr), b = __shfl(sdB, rr), ld = __shfl(w_ld, rr), len = __shfl(w_len, rr), sk = __shfl(w_sk, rr);
+                if (filled < need) {
+                    const uint32_t pos = B + filled, avail = b - pos;
+                    if (avail == 0) r++;
+                    else {
+                        const uint32_t take = avail < need - filled ? avail : need - filled;
+                        uint32_t cw, nw; stored_codes(lpk, lnb, ld, len, sk & 0x7FFFFFFFu, (sk >> 31) != 0, pos - a, take, cw, nw);
+                        acc |= (unsigned long long)cw << (2u * filled); nacc |= nw << filled; filled += take; if (take == avail) r++;
+                    }
+                }
+            }
+            if (act) { ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc; if (nacc) n_stats(B, nacc); }
+        }
+        // the cursor for the next step: the read that holds stored base 16 * kend (inside this window by construction, or the run is done)
+        if (kend < k1) { const uint32_t B = 16u * kend; uint32_t lo = 0, hi = nr;
+#pragma unroll
+            for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(sdA, (int)mid); if (hi - lo > 1u) { if (v <= B) lo = mid; else hi = mid; } }
+            rcur += uni32(lo); }
         kb = kend;
-        __syncthreads();
     }
     nsum = wave_sum(nsum);
-    if (lane_id() == 0 && nsum) atomicAdd(&ncount[c], nsum);
+    if (l == 0 && nsum) atomicAdd(&ncount[c], nsum);
 }
 // general path: the byte-wise k_gather left the stored bases as bytes in scat (and counted their N); the same tight streams from those
 __global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint64_t* __restrict__ sbase, const uint8_t* __restrict__ scat,
