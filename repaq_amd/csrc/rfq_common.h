@@ -46,7 +46,6 @@
 #define DE_NO_QUAL_BINS    (1u << 7)  // "bad quality string"
 #define DE_CORRUPT         (1u << 8)  // decode: inconsistent chunk image
 #define DE_TAIL_BLANK      (1u << 9)  // an empty line in the \n-only text right behind the encoded records: blank or empty is for the normaliser to say
-#define DE_ODD_BASE        (1u << 10) // a reverse-complemented mate holds a byte outside A/C/G/T/N: the 2-bit fast path cannot code it (k_gather2)
 
 // Device-resident file header + derived tables (RfqHeader, src/rfqheader.h:44-108)
 struct DevHeader {

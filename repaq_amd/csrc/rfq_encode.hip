@@ -421,8 +421,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
     HIPCHK(ctx, B[B_SPK].ensure((catbytes >> 4) * 4 + 64)); HIPCHK(ctx, B[B_SNM].ensure((catbytes >> 4) * 2 + 64));
     // Fast path (k_gather2 + k_seqpack): tiles of K reads - the largest power of two whose records always fit the staged-text buffer.  Reads too long
-    // for a two-read tile, and batches where a reverse-complemented mate holds a byte outside A/C/G/T/N (found by the fast path itself), take
-    // the byte-wise k_gather + k_packbytes.  RFQ_GATHER=old forces that path (tests run both).
+    // for a two-read tile take the byte-wise k_gather + k_packbytes.  RFQ_GATHER=old forces that path (tests run both).
     // (RFQ_GATHER=pipe: two half-size text buffers, the next tile's staging under this tile's compose; RFQ_G2_KSHIFT: smaller tiles - profiling aids)
     const char* genv = getenv("RFQ_GATHER");
     const bool pipe = genv && !strcmp(genv, "pipe");
@@ -444,10 +443,14 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             if (pipe) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
             else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
 #undef RFQ_G2_ARGS
-            const uint32_t sx = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
+            // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
+            const uint32_t max_len = max_rec / 2u;                             // (a record holds its sequence twice over: bases and qualities)
+            uint32_t rshift = 8; while (rshift && ((uint64_t)(max_len / 16u + 1u) << rshift) > SP_OWN) rshift--;
+            uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
+            if (getenv("RFQ_SP_X")) sx = std::max(1, atoi(getenv("RFQ_SP_X")));
             hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, S, (const uint32_t*)R.pq, (const U4*)R.pv, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
-                               C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
+                               C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift, (tune >> 20) & 15);   // (tune bits 20-23: ablation switches, results invalid)
         } else {
             HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
             // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 32
@@ -472,14 +475,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
         HIPCHK(ctx, ctx->fetch_sync(S));
-        if (fast && (hs.err & DE_ODD_BASE)) {                                // the 2-bit path met a mate it cannot code: once more, byte-wise
-            fast = false; hs.err &= ~(uint32_t)DE_ODD_BASE;
-            HIPCHK(ctx, hipMemcpyAsync(&dst->err, &hs.err, 4, hipMemcpyHostToDevice, S));
-            continue;
-        }
         break;
     }
-    (void)max_rec;
     ctx->timer.stages[ctx->timer.used].name = fast ? "gather" : "gather_bytes";   // (which formulation ran: tests and the bench look at it)
     ctx->timer.end(S);
     if (hs.err & (DE_BAD_QUAL | DE_BAD_BASE)) {

@@ -1303,12 +1303,10 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
 //   * a tile is a fixed number K of reads (K = 64, 32, ... chosen by the host so that K records always fit the staged-text buffer);
 //   * qualities go from the staged text straight to qcat with byte-granular 16-byte stores (the lanes of one read are neighbours, so a wave's
 //     stores still cover contiguous runs), counted from the registers they pass through;
-//   * bases are 2-bit packed (+ one "is N" bit each) where they stand, in FILE orientation and untrimmed, into a per-read slot of a LOOSE array:
+//   * bases are 2-bit packed (+ one "is N" bit each) where they stand - in stored orientation (a mate reverse-complemented) but untrimmed - into a per-read slot of a LOOSE array:
 //     read g (batch order) owns the dwords Ld(g) = (pq[g] >> 4) + g ... of `lpk` (16 codes each; G 0, A 1, T 2, C 3, anything else 0,
-//     src/rfqcodec.cpp:590-604) and the same u16 slots of `lnb`.  No stored-base prefix, no overlap result, no orientation is needed here:
-//     k_seqpack applies them (reverse complement in 2-bit space, overlap trim, compaction to the chunk's tight 2-bit stream + N bit mask).
-// A reverse-complemented mate that holds a byte outside A/C/G/T/N (Read::changeToReverseComplement maps those to N, in file orientation they
-// code as 0 without an N position) cannot be told apart in 2-bit space: DE_ODD_BASE sends the batch through the byte-wise k_gather instead.
+//     src/rfqcodec.cpp:590-604) and the same u16 slots of `lnb`.  No stored-base prefix and no overlap result is needed here:
+//     k_seqpack applies them (overlap trim, compaction to the chunk's tight 2-bit stream + N bit mask).
 #define G2_CAP 23552u             // staged text of a tile (64 x 357-byte records are 22.9 KB)
 #define G2_CNT 256u               // replicated quality counters (see QualCount)
 struct __attribute__((packed, aligned(1))) GU16g { uint32_t a, b, c, d; };
@@ -1319,6 +1317,14 @@ __device__ __forceinline__ void pack4_codes(uint32_t w, uint32_t& code, uint32_t
     code = ((__builtin_amdgcn_perm(0u, 0x00020301u, idx) & ok) * 0x01041040u) >> 24;
     nb = 0; bad = 0;
     if (ok != 0xFFFFFFFFu) { const uint32_t isn = eq_bytes_full(w, 0x4E4E4E4Eu); nb = ((isn & 0x01010101u) * 0x01020408u) >> 24; bad = (((~ok & ~isn) & 0x01010101u) * 0x01020408u) >> 24; }
+}
+// the same for a base of a reverse-complemented mate (the four bytes are already in reversed order): Read::changeToReverseComplement
+// (src/read.cpp:77-115) maps either case of A/C/G/T to the upper-case complement and everything else to N
+__device__ __forceinline__ void pack4_codes_rc(uint32_t w, uint32_t& code, uint32_t& nb) {
+    const uint32_t u = w & 0xDFDFDFDFu, idx = (u >> 1) & 0x03030303u;
+    const uint32_t ok = eq_bytes_full(__builtin_amdgcn_perm(0u, 0x47544341u, idx), u);
+    code = ((__builtin_amdgcn_perm(0u, 0x03010002u, idx) & ok) * 0x01041040u) >> 24;      // [A,C,T,G] -> codes of T,G,A,C
+    nb = ((~ok & 0x01010101u) * 0x01020408u) >> 24;
 }
 struct G2Geo { uint32_t a00, a01, end0, end1, base1; };                         // a tile's text spans: 16-aligned begin and end per stream, LDS offset of stream 1's span
 struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld; };       // my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
@@ -1355,9 +1361,8 @@ __device__ __forceinline__ G2Read g2_read(const Text& T, const uint32_t* __restr
     }
     return m;
 }
-// my share (groups part, part + P, ...) of my read's two lines: qualities -> qcat, bases -> the loose slot.  Returns "a reverse-complemented mate holds an odd byte".
-__device__ __forceinline__ bool g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, QualCount& qc, int abl) {
-    bool odd = false;
+// my share (groups part, part + P, ...) of my read's two lines: qualities -> qcat, bases -> the loose slot
+__device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, QualCount& qc, int abl) {
     if (m.on && !(abl & 1)) {
         // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
         const uint32_t n = m.len; uint8_t* const o = qd + m.qpos; const bool rc = m.rc;
@@ -1375,20 +1380,26 @@ __device__ __forceinline__ bool g2_compose(const uint8_t* s_text, const G2Read& 
         } else for (uint32_t i = part; i < n; i += P) { const uint8_t q = s_text[rc ? m.qsrc + n - 1u - i : m.qsrc + i]; o[i] = q; qc(m.qpos + i, q); }
     }
     if (m.on && !(abl & 2)) {
-        // ---- bases: 16 per step -> one dword of codes + 16 N bits, file orientation, into the read's loose slot
+        // ---- bases: 16 per step -> one dword of codes + 16 N bits into the read's loose slot, in STORED orientation (an interleaved chunk's mate
+        // reverse-complemented, src/rfqcodec.cpp:371-407) but untrimmed: k_seqpack skips what the overlap with R1 implies
         const uint32_t ng = (m.len + 15u) >> 4;
         for (uint32_t gi = part; gi < ng; gi += P) {
-            uint32_t w[4]; lds_get16(s_text, m.ssrc + 16u * gi, w);
-            uint32_t code = 0, nbits = 0, bad = 0;
+            uint32_t w[4], code = 0, nbits = 0;
+            if (!m.rc) {
+                lds_get16(s_text, m.ssrc + 16u * gi, w);
 #pragma unroll
-            for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
-            const uint32_t nv = m.len - 16u * gi;                          // valid bases of this step (what lies behind the line's end is not the read's)
-            if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; const uint32_t mk = (1u << nv) - 1u; nbits &= mk; bad &= mk; }
-            if (bad && m.rc) odd = true;
+                for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
+            } else {
+                lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);       // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line: masked below)
+                const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { uint32_t c4, n4; pack4_codes_rc(w[i], c4, n4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
+            }
+            const uint32_t nv = m.len - 16u * gi;                          // valid bases of this step (what lies outside the line is not the read's)
+            if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; nbits &= (1u << nv) - 1u; }
             lpk[m.ld + gi] = code; lnb[m.ld + gi] = (uint16_t)nbits;
         }
     }
-    return odd;
 }
 // PIPE: two text buffers of half the size; the next tile's LDS-DMA is issued right behind the barrier that hands over this tile's text and flies
 // under this tile's compose - one barrier per tile.  (Measured on configs[2], single buffer, K = 64: of the kernel's 3.4 ms, 1.8 ms are the bare
@@ -1412,7 +1423,6 @@ template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, co
     const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;              // K reads per tile, P threads per read
     const uint32_t j = tid >> pshift, part = tid & (P - 1u);
     QualCount qc; qc.cnt = sh[0]; qc.last = sh_last[0]; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
-    bool odd = false;
     if (!PIPE) {
         uint4* const buf4 = s_text4 + 1;
         __syncthreads();
@@ -1424,7 +1434,7 @@ template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, co
             const uint32_t qbeg = uni32(pq[cur]) - pq0;                      // the tile's first quality position (chunk-relative)
             __syncthreads();                                                // (drains the LDS-DMA)
             qc.seg0 = qbeg / PC_SEG_POS;
-            odd |= g2_compose((const uint8_t*)buf4, m, part, P, qd, lpk, lnb, qc, abl);
+            g2_compose((const uint8_t*)buf4, m, part, P, qd, lpk, lnb, qc, abl);
             __syncthreads();                                                // the text is free for the next tile; the tile's counts are complete
             qual_flush(sh[0], sh_last[0], nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
         }
@@ -1445,13 +1455,12 @@ template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, co
                 mn = g2_read(T, pq, gn, f, pq0, il, nxt, j, cn); qn = uni32(pq[nxt]) - pq0;
             }
             qc.cnt = sh[PIPE ? pb : 0u]; qc.last = sh_last[PIPE ? pb : 0u]; qc.seg0 = qbeg / PC_SEG_POS; seg_prev = qc.seg0;
-            odd |= g2_compose((const uint8_t*)(s_text4 + 1 + pb * HALF4), m, part, P, qd, lpk, lnb, qc, abl);
+            g2_compose((const uint8_t*)(s_text4 + 1 + pb * HALF4), m, part, P, qd, lpk, lnb, qc, abl);
             g = gn; m = mn; qbeg = qn; cnt = cn;
         }
         __syncthreads();
         qual_flush(sh[PIPE ? pb ^ 1u : 0u], sh_last[PIPE ? pb ^ 1u : 0u], nrep, nslot, seg_prev, c, nn_s, segm, segc, n_seg);
     }
-    if (__any(odd) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_ODD_BASE);
 }
 // 16 consecutive codes / N bits of a loose slot from base index b on (b + 16 may pass the slot's end: the caller masks)
 __device__ __forceinline__ uint32_t loose_codes(const uint32_t* __restrict__ lpk, uint32_t ld, uint32_t b) {
@@ -1462,123 +1471,77 @@ __device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb
     const uint32_t d = ld + (b >> 4), sh = b & 15u; const uint32_t lo = lnb[d];
     return (sh ? ((((uint32_t)lnb[d + 1]) << 16) | lo) >> sh : lo) & 0xFFFFu;
 }
-__device__ __forceinline__ uint32_t rev2x16(uint32_t v) {                   // the sixteen 2-bit fields of v in reverse order
-    v = bswap32(v); v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4); return ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
-}
-__device__ __forceinline__ uint32_t rev1x16(uint32_t v) {                   // the low sixteen bits of v in reverse order
-    v = ((v >> 8) & 0xFFu) | ((v & 0xFFu) << 8); v = ((v >> 4) & 0x0F0Fu) | ((v & 0x0F0Fu) << 4);
-    v = ((v >> 2) & 0x3333u) | ((v & 0x3333u) << 2); return ((v >> 1) & 0x5555u) | ((v & 0x5555u) << 1);
-}
-__device__ __forceinline__ uint32_t spread16(uint32_t v) {                  // bit i of v -> bits 2i and 2i+1
-    v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v * 3u;
-}
-// `take` (1..16) stored bases of one read from stored index si on: codes in the low 2 * take bits, N bits in the low `take` bits.
-// Stored bases (src/rfqcodec.cpp:371-407): the read as it stands, or - an interleaved chunk's mate - its reverse complement without the
-// `skip` leading bases the overlap with R1 implies: stored[s] = comp(file[len - 1 - skip - s]).  The complement of a code is its bitwise NOT
-// (G 0 <-> C 3, A 1 <-> T 2); an N stays an N and codes as 0.
-__device__ __forceinline__ void stored_codes(const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb, uint32_t ld, uint32_t len, uint32_t skip, bool rc, uint32_t si, uint32_t take,
-                                             uint32_t& code, uint32_t& nbits) {
-    const uint32_t cm = take >= 16u ? 0xFFFFFFFFu : (1u << (2u * take)) - 1u, nm = (1u << take) - 1u;
-    if (!rc) { code = loose_codes(lpk, ld, si) & cm; nbits = loose_nbits(lnb, ld, si) & nm; return; }
-    const int hi = (int)(len - 1u - skip - si), lo = hi - 15;              // file indices hi, hi-1, ... become stored si, si+1, ...
-    uint32_t cw, nw;
-    if (lo >= 0) { cw = loose_codes(lpk, ld, (uint32_t)lo); nw = loose_nbits(lnb, ld, (uint32_t)lo); }
-    else { cw = loose_codes(lpk, ld, 0u) << (2u * (uint32_t)(-lo)); nw = (loose_nbits(lnb, ld, 0u) << (uint32_t)(-lo)) & 0xFFFFu; }   // (file indices < 0 land at stored indices >= take: masked)
-    nbits = rev1x16(nw) & nm;
-    code = ~rev2x16(cw) & ~spread16(nbits) & cm;
-}
 // Loose slots -> the chunk's tight streams: spk = 2-bit stored bases, 16 per dword, dword k of chunk c at (sbase[c] >> 4) + k - the bytes of the
 // image's sequence section (RfqChunk::write copies them) - and snm = one "is N" bit per stored base at the same u16 index (the N-position
-// coder's match mask).  One lane makes one dword.  Waves are independent (no LDS, no barrier: the first form - a workgroup staging a window of
-// reads in LDS, three barriers per 256 dwords - took 2.8 ms on configs[2], all of it exposed latency): a wave owns a run of dwords and walks it 256
-// at a time; the stored prefixes and slot data of the 64 reads from its cursor on sit in its lanes, a lane bisects them with shuffles for the read
-// that holds its first base and walks on from there.  N counts per coder segment, the chunk's N total and N map are left as k_gather leaves them.
-#define SP_U 4u                   // dwords per lane and step
+// coder's match mask).  A read's stored bases are slot[skip, skip + keep) (skip: what the overlap with R1 implies for a mate,
+// src/rfqcodec.cpp:376-407) and go to tight positions sd .. sd + keep; the read OWNS the tight dwords whose first base is one of its own, and
+// what is left of its last one comes from the read(s) behind it.  A workgroup takes R consecutive reads at a time, in two phases:
+//   1  a lane per read: stored prefix, slot, skip -> LDS, and the read's index into s_own[] for every dword it owns (LDS stores, no search);
+//   2  a lane per tight dword, consecutive lanes = consecutive dwords: owner from s_own[], its data from LDS, 16 codes + 16 N bits fetched from
+//      the slot(s) with a funnel shift, stored.  Loads and stores are coalesced, two memory round trips per R reads, ~50 instructions per dword.
+// What the four earlier forms cost on configs[2] (210 M dwords), and why: a lane per dword with the reads found by bisecting stored prefixes (in LDS /
+// in the wave's lanes by shuffles) and a reverse complement in 2-bit space, 2.3 - 2.8 ms: ~600 instructions per dword; four lanes per read, one
+// dword per round trip, 1.9 ms: the waves' chains of dependent round trips; a lane per read with all its loads up front, 2.3 ms: 64 scattered
+// 4-byte (2-byte) stores per wave instruction - 420 M write requests at the L2's request rate (ablation: 1.0 of the 1.5 ms were the stores).
+// N counts per coder segment, the chunk's N total and N map are left as k_gather leaves them.
+#define SP_OWN 4096u              // tight dwords of one step (the host sizes R by the longest read: R * (max_len / 16 + 1) <= SP_OWN)
+#define SP_EXTRA 8u               // reads behind the step's last whose LDS entries the last dword's tail may need (beyond: global memory)
 __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
                                                  const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
-                                                 uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
-    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1]; const int l = lane_id();
-    const uint32_t ps0 = pv[f].d, S = pv[e].d - ps0, ndw = (S + 15u) >> 4;
-    const uint32_t nwv = gridDim.x * (blockDim.x >> 6), wv = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id();
-    uint32_t per = (ndw + nwv - 1) / nwv; per = (per + 64u * SP_U - 1u) / (64u * SP_U) * (64u * SP_U);
-    const uint32_t k0 = uni32(wv * per), k1 = uni32(k0 + per < ndw ? k0 + per : ndw);
-    if (k0 >= k1) return;                                                   // (wave-uniform; nothing below synchronises across waves)
+                                                 uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
+                                                 uint32_t rshift, int abl) {
+    __shared__ uint32_t s_sd[256 + SP_EXTRA + 1], s_ld[256 + SP_EXTRA], s_sk[256 + SP_EXTRA]; __shared__ uint8_t s_own[SP_OWN];
+    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1], tid = threadIdx.x;
+    const uint32_t ps0 = pv[f].d, S = pv[e].d - ps0;
     const bool il = ilv[c] != 0, enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
     uint32_t* const ok = spk + (size_t)(sbase[c] >> 4); uint16_t* const on = snm + (size_t)(sbase[c] >> 4);
     const uint32_t nshift = nmap_shift(S); uint32_t* const nm = nmap + (size_t)c * NMAP_WORDS;
     const size_t nsi = ((size_t)c * MAX_STREAMS + NPOS_SLOT) * n_seg;
-    // the read that holds stored base 16 * k0: the last r in [f, e) whose stored prefix is <= it (wave-uniform bisection)
-    uint32_t rcur;
-    { uint32_t lo = f, hi = e; const uint32_t B = 16u * k0; while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (uni32(pv[mid].d) - ps0 <= B) lo = mid; else hi = mid; } rcur = lo; }
     uint32_t nsum = 0;
-    auto slot_of = [&](uint32_t g, uint32_t& ld, uint32_t& len, uint32_t& sk) {
-        const uint32_t pg = pq[g]; len = pq[g + 1] - pg; ld = (pg >> 4) + g; const bool rc = il && ((g - f) & 1u);
-        uint32_t skip = 0; if (rc && enc) { const int ov = (int)ovb[g >> 1] - shift; if (ov > 0) skip = (uint32_t)ov; }
-        sk = skip | (rc ? 0x80000000u : 0u);
+    auto skip_of = [&](uint32_t g) -> uint32_t {                            // leading bases of read g's slot that are not stored
+        if (enc && ((g - f) & 1u)) { const int ov = (int)ovb[g >> 1] - shift; if (ov > 0) return (uint32_t)ov; }
+        return 0u;
     };
-    auto n_stats = [&](uint32_t B, uint32_t nacc) {
-        const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B);
-        atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc)));
-    };
-    for (uint32_t kb = k0; kb < k1; ) {                                      // wave-uniform
-        const uint32_t nr = e - rcur < 64u ? e - rcur : 64u;                 // reads in the window: lane i holds read rcur + i
-        uint32_t sdA = 0xFFFFFFFFu, sdB = 0xFFFFFFFFu, w_ld = 0, w_len = 0, w_sk = 0;
-        if ((uint32_t)l < nr) { const uint32_t g = rcur + (uint32_t)l; sdA = pv[g].d - ps0; sdB = pv[g + 1].d - ps0; slot_of(g, w_ld, w_len, w_sk); }
-        // dwords whose bases all lie inside the window
-        const uint32_t lim = uni32(__shfl(sdB, (int)nr - 1)); const uint32_t kmax = lim >= S ? ndw : lim >> 4;
-        uint32_t kend = kb + 64u * SP_U < k1 ? kb + 64u * SP_U : k1; if (kend > kmax) kend = kmax;
-        if (kend <= kb) {
-            // serial step: one dword, its bases gathered read by read (sixty-four reads in a row that hold fewer than 16 bases)
-            uint32_t gnext = rcur;
-            if (l == 0) {
-                const uint32_t B = 16u * kb, need = S - B < 16u ? S - B : 16u; unsigned long long acc = 0; uint32_t nacc = 0, filled = 0, g = rcur;
-                while (filled < need) {
-                    const uint32_t sd0 = pv[g].d - ps0, sd1 = pv[g + 1].d - ps0, pos = B + filled;
-                    if (sd1 <= pos) { g++; continue; }
-                    const uint32_t avail = sd1 - pos, take = avail < need - filled ? avail : need - filled;
-                    uint32_t ld, len, sk; slot_of(g, ld, len, sk);
-                    uint32_t cw, nw; stored_codes(lpk, lnb, ld, len, sk & 0x7FFFFFFFu, (sk >> 31) != 0, pos - sd0, take, cw, nw);
-                    acc |= (unsigned long long)cw << (2u * filled); nacc |= nw << filled; filled += take;
-                }
-                ok[kb] = (uint32_t)acc; on[kb] = (uint16_t)nacc;
-                if (nacc) n_stats(B, nacc);
-                gnext = g;                                                   // the read that holds the dword's last base
-            }
-            rcur = uni32(__shfl(gnext, 0)); kb = kb + 1u; continue;
+    const uint32_t R = 1u << rshift;
+    for (uint32_t r0 = f + blockIdx.x * R; r0 < e; r0 += gridDim.x * R) {   // block-uniform
+        const uint32_t nr = e - r0 < R ? e - r0 : R, nx = e - r0 < R + SP_EXTRA ? e - r0 : R + SP_EXTRA;    // my reads; reads with LDS entries
+        // ---- phase 1
+        for (uint32_t t = tid; t <= nx; t += blockDim.x) {
+            const uint32_t g = r0 + t; s_sd[t] = pv[g].d - ps0;
+            if (t < nx) { s_ld[t] = (pq[g] >> 4) + g; s_sk[t] = skip_of(g); }
         }
-#pragma unroll 1
-        for (uint32_t u = 0; u < SP_U; u++) {
-            const uint32_t k = kb + 64u * u + (uint32_t)l; const bool act = k < kend;
-            if (!__any(act)) break;
-            const uint32_t B = act ? 16u * k : 16u * kb, need = act ? (S - B < 16u ? S - B : 16u) : 0u;
-            uint32_t lo = 0, hi = nr;
-#pragma unroll
-            for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(sdA, (int)mid); if (hi - lo > 1u) { if (v <= B) lo = mid; else hi = mid; } }   // (six steps whatever the lane's interval: the shuffles stay wave-wide)
-            unsigned long long acc = 0; uint32_t nacc = 0, filled = 0, r = lo;
-            while (__any(filled < need)) {                                   // (a dword spans two reads once in ~ten, more only when reads are tiny)
-                const int rr = (int)(r < nr ? r : nr - 1u);
-                const uint32_t a = __shfl(sdA, rr), b = __shfl(sdB, rr), ld = __shfl(w_ld, rr), len = __shfl(w_len, rr), sk = __shfl(w_sk, rr);
-                if (filled < need) {
-                    const uint32_t pos = B + filled, avail = b - pos;
-                    if (avail == 0) r++;
-                    else {
-                        const uint32_t take = avail < need - filled ? avail : need - filled;
-                        uint32_t cw, nw; stored_codes(lpk, lnb, ld, len, sk & 0x7FFFFFFFu, (sk >> 31) != 0, pos - a, take, cw, nw);
-                        acc |= (unsigned long long)cw << (2u * filled); nacc |= nw << filled; filled += take; if (take == avail) r++;
-                    }
+        __syncthreads();
+        const uint32_t kbase = (s_sd[0] + 15u) >> 4, kend = (s_sd[nr] + 15u) >> 4;    // the step's dwords: those whose first base belongs to one of my reads
+        if (tid < nr) { const uint32_t ka = (s_sd[tid] + 15u) >> 4, kb = (s_sd[tid + 1] + 15u) >> 4; for (uint32_t k = ka; k < kb; k++) s_own[k - kbase] = (uint8_t)tid; }
+        __syncthreads();
+        // ---- phase 2
+        for (uint32_t i = tid; i < kend - kbase; i += blockDim.x) {
+            const uint32_t k = kbase + i, j = s_own[i];
+            const uint32_t B = 16u * k, sdg = s_sd[j], si = B - sdg, need = S - B < 16u ? S - B : 16u, av = s_sd[j + 1] - B, t1 = need < av ? need : av;
+            const uint32_t ld = s_ld[j], b0 = s_sk[j] + si;
+            unsigned long long acc = 0; uint32_t nacc = 0;
+            if (!(abl & 1)) acc = loose_codes(lpk, ld, b0) & (t1 >= 16u ? 0xFFFFFFFFu : (1u << (2u * t1)) - 1u);
+            if (!(abl & 2)) nacc = loose_nbits(lnb, ld, b0) & ((1u << t1) - 1u);
+            uint32_t filled = t1, jj = j + 1;
+            while (filled < need) {                                         // the read's last dword: the rest comes from the read(s) behind it
+                uint32_t a, b, l2, s2;
+                if (jj < nx) { a = s_sd[jj]; b = s_sd[jj + 1]; l2 = s_ld[jj]; s2 = s_sk[jj]; }
+                else { const uint32_t gg = r0 + jj; a = pv[gg].d - ps0; b = pv[gg + 1].d - ps0; l2 = (pq[gg] >> 4) + gg; s2 = skip_of(gg); }   // (more than SP_EXTRA reads of a few bases in a row)
+                const uint32_t avail = b - a;
+                if (avail) {
+                    const uint32_t take = avail < need - filled ? avail : need - filled;
+                    acc |= (unsigned long long)(loose_codes(lpk, l2, s2) & (take >= 16u ? 0xFFFFFFFFu : (1u << (2u * take)) - 1u)) << (2u * filled);
+                    nacc |= (loose_nbits(lnb, l2, s2) & ((1u << take) - 1u)) << filled; filled += take;
                 }
+                jj++;
             }
-            if (act) { ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc; if (nacc) n_stats(B, nacc); }
+            if (!(abl & 4)) ok[k] = (uint32_t)acc; if (!(abl & 8)) on[k] = (uint16_t)nacc;
+            if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
         }
-        // the cursor for the next step: the read that holds stored base 16 * kend (inside this window by construction, or the run is done)
-        if (kend < k1) { const uint32_t B = 16u * kend; uint32_t lo = 0, hi = nr;
-#pragma unroll
-            for (int it = 0; it < 6; it++) { const uint32_t mid = (lo + hi) >> 1; const uint32_t v = __shfl(sdA, (int)mid); if (hi - lo > 1u) { if (v <= B) lo = mid; else hi = mid; } }
-            rcur += uni32(lo); }
-        kb = kend;
+        __syncthreads();                                                    // (the LDS tables are rewritten by the next step)
     }
     nsum = wave_sum(nsum);
-    if (l == 0 && nsum) atomicAdd(&ncount[c], nsum);
+    if (lane_id() == 0 && nsum) atomicAdd(&ncount[c], nsum);
 }
 // general path: the byte-wise k_gather left the stored bases as bytes in scat (and counted their N); the same tight streams from those
 __global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint64_t* __restrict__ sbase, const uint8_t* __restrict__ scat,

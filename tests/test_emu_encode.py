@@ -57,15 +57,23 @@ def test_multichunk_bytewise_gather_matches_oracle(codec, monkeypatch, label, pr
 
 
 def test_gather_paths_are_the_ones_expected(codec):
-    """The tile gather (k_gather2 + k_seqpack) is what runs by default; a mate with a byte outside A/C/G/T/N in an interleaved chunk makes the
-    call fall back to the byte-wise gather (Read::changeToReverseComplement turns such a byte into N, which 2-bit codes cannot express)."""
+    """The tile gather (k_gather2 + k_seqpack) is what runs by default - also when a mate of an interleaved chunk holds bytes outside A/C/G/T/N
+    (Read::changeToReverseComplement turns them into N, lower case into the upper-case complement) - and reads too long for a tile of two
+    take the byte-wise gather."""
     fq1, fq2 = O.gen(O.NOVA_PE150, 200, seed=31)
     assert E.encode(codec, fq1, fq2, O.PE_TWO_FILES, 20000) == O.encode_file(fq1, fq2, O.PE_TWO_FILES, 20000)
     assert "gather" in dict(codec.timings())
     lines = fq2.split(b"\n")
-    lines[4 * 150 + 1] = lines[4 * 150 + 1][:30] + b"r" + lines[4 * 150 + 1][31:]       # a mate of the second chunk or later (chunk 0 must be clean: the header is made from it)
+    for k, ch in ((150, b"r"), (151, b"a"), (152, b"n"), (170, b"."), (171, b"g")):     # mates of the second chunk or later (chunk 0 must be clean: the header is made from it)
+        lines[4 * k + 1] = lines[4 * k + 1][:30] + ch + lines[4 * k + 1][31:]
     odd = b"\n".join(lines)
-    assert E.encode(codec, fq1, odd, O.PE_TWO_FILES, 20000) == O.encode_file(fq1, odd, O.PE_TWO_FILES, 20000)
+    l1 = fq1.split(b"\n"); l1[4 * 160 + 1] = l1[4 * 160 + 1][:7] + b"x" + l1[4 * 160 + 1][8:]; odd1 = b"\n".join(l1)
+    assert E.encode(codec, odd1, odd, O.PE_TWO_FILES, 20000) == O.encode_file(odd1, odd, O.PE_TWO_FILES, 20000)
+    assert "gather" in dict(codec.timings())
+    long1, _ = O.gen(O.SE_VAR, 40, seed=5)
+    big = b"@r\n" + b"ACGT" * 4000 + b"\n+\n" + b"F" * 16000 + b"\n"
+    fq = long1 + big + long1
+    assert E.encode(codec, fq, b"", O.SE, 20000) == O.encode_file(fq, b"", O.SE, 20000)
     assert "gather_bytes" in dict(codec.timings())
 
 
