@@ -32,14 +32,16 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MI
 
 # stage (HIP-event pair inside librfq_hip) -> the kernels it brackets (names as rocprofv3 reports them)
 STAGE_KERNELS = {"index": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
-                 "chunk_flags+overlap": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_overlap", "k_overlap_apply", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_chunk_bases"],
-                 "gather": ["k_gather2", "k_seqpack", "k_stream_plan", "k_chunk_layout"], "gather_bytes": ["k_gather", "k_packbytes", "k_stream_plan", "k_chunk_layout"], "pos_coder": ["k_pos_coder", "k_pos_sizes"],
-                 "coords+layout": ["k_coords"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
+                 "chunk_flags": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_chunk_bases"],
+                 "gather": ["k_gather2", "k_stream_plan"], "gather_bytes": ["k_overlap", "k_overlap_apply", "k_pv_in", "k_gather", "k_packbytes", "k_stream_plan", "k_chunk_layout"],
+                 # (tile gather: the overlap search on the loose slots, the stored prefix, the sequence packer and the N streams run on the second stream beside the coder)
+                 "pos_coder": ["k_pos_coder", "k_overlap", "k_overlap_apply", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_seqpack", "k_chunk_layout", "k_coords"],
+                 "coords+layout": ["k_pos_sizes", "k_chunk_layout"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
                  "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
                  "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list", "k_dec_textlen",   # (fused path: the text lengths run beside the list chain)
                                  # (reads longer than 2000 bases, -k values whose chunks exceed 4096 records, and legacy RLE files take the materialising path)
                                  "k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_pos_index", "k_dec_except", "k_dec_rle"],
-                 "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit2"]}
+                 "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit3"], "dec:emit2": ["k_dec_emit2", "k_dec_emit"]}
 
 WORKLOADS = {
     # key: (label, fqgen profile, units (reads or pairs), seed, extra gen kwargs, paired)

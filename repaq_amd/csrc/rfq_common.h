@@ -71,7 +71,8 @@ struct DevStatus {
     uint32_t err_read;          // read index (interleaved order) tied to the first data error, or value for coords
     uint64_t err_key;           // ordering key for "first error"
     uint64_t coord_key;         // (chunk << 34 | axis << 33 | index) of the first out-of-range X/Y, ~0 if none
-    uint64_t total_scratch;     // bytes of stream scratch needed
+    uint64_t total_scratch;     // bytes of stream scratch needed (quality value + exception streams)
+    uint64_t total_scratch_n;   // ... by the N-position streams (their own arena: planned later, behind the sequence packer)
     uint64_t image_bound;       // upper bound of all chunk images (from stream capacities)
     uint32_t n_chunks;
     uint32_t max_chunk_reads;

@@ -27,13 +27,13 @@ static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk
 #undef RFQ_LIST_ARGS
 }
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
-struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one; uint64_t bases; };   // bases: sum of the range's read lengths (the walk's 64-bit total)
+struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one, pieces; uint64_t bases; };   // bases: sum of the range's read lengths (the walk's 64-bit total)
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
 // out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
                         uint8_t** p1, uint8_t** p2, size_t* n1, size_t* n2, uint64_t* nbases) {
     hipStream_t S = ctx->stream; DBuf* B = ctx->b;
-    static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;
+    const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;
     const DevHeader& HH = ctx->h_hdr; const DevHeader* D = ctx->d_hdr.as<DevHeader>();
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs; memset(&hs, 0, sizeof hs);
     hs.max_stream = g.max_stream; hs.max_npos = g.max_npos;
@@ -184,13 +184,24 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     if (out1) { o1 = out1; cap1 = ocap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
     if (out2) { o2 = out2; cap2 = ocap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
     ctx->timer.end(S);
-    ctx->timer.begin("emit", S);                                       // k_dec_emit alone: the path's largest kernel (bench.py roofline)
+    ctx->timer.begin("emit", S);                                       // the emitter alone: the path's largest kernel (bench.py roofline); named "emit2" below when the tile-fitting kernels ran
     {
+        // k_dec_emit3 (no output tile, K reads per tile: the largest power of two whose qualities fit its tile) whenever the pieces of a name are shared
+        // by whole chunks; k_dec_emit2 (tiles fitted read by read) otherwise.  RFQ_EMIT=2 forces the latter (tests run both).
+        uint32_t e3k = 6; while (e3k >= 1 && ((uint64_t)g.max_len << e3k) > E3_QCAP) e3k--;
+        const char* eenv = getenv("RFQ_EMIT");
+        const bool emit3 = fused && !g.pieces && e3k >= 1 && !(eenv && !strcmp(eenv, "2")) && !(tune & 7);
+        if (!emit3) ctx->timer.stages[ctx->timer.used].name = "emit2";
+        if (emit3) {
+            const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
+            hipLaunchKernelGGL(k_dec_emit3, dim3(b3, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(),
+                               (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k, (tune >> 12) & 255);
+        }
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + ET_READS - 1) / ET_READS, (fused ? 4u : 4u) * ctx->n_cu);   // (39 KB of LDS: four workgroups per CU)
         const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
 #define RFQ_EMIT2_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
                        (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr
-        if (fused && (tune & 7)) {
+        if (emit3) {} else if (fused && (tune & 7)) {
             unsigned long long* dbg = (unsigned long long*)B[DB_SCAN].p; (void)hipMemsetAsync(dbg, 0, 128, S);      // (the scan scratch is idle here)
             hipLaunchKernelGGL(k_dec_emit2<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, dbg, 0);
             unsigned long long h[16]; (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
@@ -281,7 +292,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             break;
         }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
-        if (!speculate) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
+        if (!speculate) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
         if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
         if (hs.n_chunks > PARSE_AHEAD) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
@@ -290,7 +301,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
             if (h2.pad) { speculate = false; continue; }
-            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
+            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
         break;
@@ -311,7 +322,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
     if (tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
-        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.bases = tb;
+        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.bases = tb;
         rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
         if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
     }
@@ -338,7 +349,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             const uint32_t c0 = r.first, c1 = r.second; uint64_t reads = 0, rbases = 0; for (uint32_t c = c0; c < c1; c++) { reads += hc[c].reads; rbases += hc[c].bases; }
             hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
             KCHK(ctx, "k_dec_rebase");
-            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.bases = rbases;
+            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.bases = rbases;
             uint8_t *q1 = nullptr, *q2 = nullptr; size_t m1 = 0, m2 = 0; uint64_t mb = 0;
             ctx->timer.reset();
             rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);

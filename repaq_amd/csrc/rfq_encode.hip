@@ -12,10 +12,10 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_ENC_END
 };
 
-static_assert(B_ENC_END <= 72, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
+static_assert(B_ENC_END <= 80, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
 
 static int fetch_bytes(rfq_ctx* ctx, const uint8_t* d, size_t n, std::string& out) {
     out.resize(n);
@@ -262,26 +262,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (n_units == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
     const bool is_pe = a->paired != RFQ_SE;
 
-    // PE: the overlap search of every pair starts now, on the second stream (see k_overlap); it is joined where its results are applied
-    struct AuxGuard { rfq_ctx* c; bool armed; void sync() { if (armed) { (void)hipStreamSynchronize(c->aux); armed = false; } } ~AuxGuard() { sync(); } } ovl_guard = { ctx, false };   // (an early return must not leave it running over buffers that are about to be reused)
-    bool ovl_aside = false;
-    if (is_pe && !scan_only) {
-        const uint32_t np = n_units; const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
-        HIPCHK(ctx, B[B_OVRAW].ensure((size_t)np * 2 + 64));
-        ovl_aside = ctx->aux_ready() && !(tune & 2048); hipStream_t OS = ovl_aside ? ctx->aux : S;
-        if (ovl_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(OS, ctx->ev_fork, 0)); }
-        if (tune & 64) {     // per-phase cycle counters (profiling aid)
-            HIPCHK(ctx, B[B_HSTATS].ensure(sizeof(HdrStats) + 8192));
-            unsigned long long* dbg = (unsigned long long*)B[B_HSTATS].p + 600; (void)hipMemsetAsync(dbg, 0, 64, OS);
-            hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, OS, T, B[B_OVRAW].as<int16_t>(), np, dbg, 0);
-            (void)hipStreamSynchronize(OS);                                   // (the second stream does not order against the copy below)
-            unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
-            if (h[5]) fprintf(stderr, "[overlap dbg] waves=%llu avg cycles/wave: meta=%llu pack=%llu fwd=%llu bwd=%llu slow+write=%llu verifies/wave=%.1f\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5], (double)h[6]/h[5]);
-        } else hipLaunchKernelGGL(k_overlap<false>, dim3(ob), dim3(256), 0, OS, T, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, (tune >> 8) & 7);   // (tune bits 8-10: ablation switches, results invalid)
-        KCHK(ctx, "k_overlap");
-        if (ovl_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_ovl, OS)); ovl_guard.armed = true; }
-    }
-
+    // (an early return must not leave the second stream running over buffers that are about to be reused)
+    struct AuxGuard { rfq_ctx* c; bool armed; void sync() { if (armed) { (void)hipStreamSynchronize(c->aux); armed = false; } } ~AuxGuard() { sync(); } } ovl_guard = { ctx, false };
     ctx->timer.begin("read_table+cut", S);
     const size_t nr = (size_t)n_reads + 2;
     HIPCHK(ctx, B[B_LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N1LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N2OFF].ensure(nr * 4));
@@ -390,7 +372,23 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     ctx->timer.end(S);
 
-    ctx->timer.begin("chunk_flags+overlap", S);
+    // Which gather: the tile gather k_gather2 (+ k_seqpack) whenever two records fit its staged-text buffer - tiles of K reads, the largest power of two
+    // that always fits - else the byte-wise k_gather (+ k_packbytes).  RFQ_GATHER=old forces the latter (tests run both); RFQ_GATHER=pipe /
+    // RFQ_G2_KSHIFT are profiling aids (two half-size text buffers; smaller tiles).
+    const char* genv = getenv("RFQ_GATHER");
+    const bool pipe = genv && !strcmp(genv, "pipe");
+    const uint32_t g2cap = pipe ? G2_CAP / 2 : G2_CAP;
+    uint32_t kshift = 6; if (getenv("RFQ_G2_KSHIFT")) kshift = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_G2_KSHIFT"))));
+    while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > g2cap) kshift--;
+    const bool fast = kshift >= 1 && !(genv && !strcmp(genv, "old"));
+    const uint32_t max_rec = hs.max_rec;
+    const uint32_t np = reads_used / 2;
+    HIPCHK(ctx, B[B_OVRAW].ensure((size_t)(is_pe ? n_units : 0) * 2 + 64));
+    HIPCHK(ctx, B[B_SCANTMP2].ensure(std::max<size_t>(4096, (nr / SCAN_TILE + 2) * 16 + (nc / SCAN_TILE + 2) * 8)));
+    HIPCHK(ctx, B[B_CTOTALN].ensure(nc * 8)); HIPCHK(ctx, B[B_CBASEN].ensure(nc * 8));
+    const OvLoose noz = { nullptr, nullptr, nullptr, nullptr };
+
+    ctx->timer.begin("chunk_flags", S);
     if (!is_pe) hipLaunchKernelGGL(k_chunk_flags_se, dim3(n_chunks), dim3(64), 0, S, C, (const uint16_t*)adj);
     else {
         // PE: adjacency path first; chunks where the interleave test fails mid-chunk (rare) go through the read-0 kernels, which exit at
@@ -402,82 +400,111 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, 1, cbits, cfail, (const uint32_t*)redo);
         hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, 1, (const uint32_t*)cbits, (const uint32_t*)cfail, (const uint32_t*)redo);
     }
-    if (is_pe) {
-        const uint32_t np = reads_used / 2;
-        if (ovl_aside) { HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_ovl, 0)); ovl_guard.armed = false; }
-        hipLaunchKernelGGL(k_overlap_apply, dim3((np + 255) / 256), dim3(256), 0, S, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb, np);
+    hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks, 1);
+    // the stored-base prefix (it needs the mates' overlaps): k_overlap_apply, per-read prefix inputs, their scan, the chunks' bases in the tight streams
+    auto stored_prefix = [&](hipStream_t Q, U4* tmp) {
+        if (is_pe) hipLaunchKernelGGL(k_overlap_apply, dim3((np + 255) / 256), dim3(256), 0, Q, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb, np);
+        hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, Q, T, R, B[B_PVIN].as<U4>(), n_reads);
+        scan_exclusive<U4>(Q, B[B_PVIN].as<U4>(), R.pv, n_reads, tmp, 1);
+        hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, Q, R, C, n_chunks, 2);
+    };
+    if (!fast) {
+        // byte-wise gather: it writes the stored bases themselves, so the overlap search (on the text) and the stored prefix come first
+        if (is_pe) {
+            const uint32_t ob = std::min<uint32_t>((n_units + 255) / 256, 65535u * 16u);
+            if (tune & 64) {     // per-phase cycle counters (profiling aid)
+                unsigned long long* dbg = (unsigned long long*)B[B_HSTATS].p + 600; (void)hipMemsetAsync(dbg, 0, 64, S);
+                hipLaunchKernelGGL((k_overlap<true, false>), dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units, dbg, 0);
+                (void)hipStreamSynchronize(S);
+                unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+                if (h[5]) fprintf(stderr, "[overlap dbg] waves=%llu avg cycles/wave: meta=%llu pack=%llu fwd=%llu bwd=%llu slow+write=%llu verifies/wave=%.1f\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5], (double)h[6]/h[5]);
+            } else hipLaunchKernelGGL((k_overlap<false, false>), dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units, (unsigned long long*)nullptr, (tune >> 8) & 7);   // (tune bits 8-10: ablation switches, results invalid)
+        }
+        stored_prefix(S, B[B_SCANTMP].as<U4>());
     }
-    hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, B[B_PVIN].as<U4>(), n_reads);
-    scan_exclusive<U4>(S, B[B_PVIN].as<U4>(), R.pv, n_reads, B[B_SCANTMP].as<U4>(), 1);
-    hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks);
     KCHK(ctx, "k_chunk_flags");
     if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));      // the gather needs the header (major quality, flags)
     ctx->timer.end(S);
 
-    ctx->timer.begin("gather", S);
+    ctx->timer.begin(fast ? "gather" : "gather_bytes", S);                  // (which formulation ran: tests and the bench look at it)
     // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
     const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
     const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
     HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
     HIPCHK(ctx, B[B_SPK].ensure((catbytes >> 4) * 4 + 64)); HIPCHK(ctx, B[B_SNM].ensure((catbytes >> 4) * 2 + 64));
-    // Fast path (k_gather2 + k_seqpack): tiles of K reads - the largest power of two whose records always fit the staged-text buffer.  Reads too long
-    // for a two-read tile take the byte-wise k_gather + k_packbytes.  RFQ_GATHER=old forces that path (tests run both).
-    // (RFQ_GATHER=pipe: two half-size text buffers, the next tile's staging under this tile's compose; RFQ_G2_KSHIFT: smaller tiles - profiling aids)
-    const char* genv = getenv("RFQ_GATHER");
-    const bool pipe = genv && !strcmp(genv, "pipe");
-    const uint32_t g2cap = pipe ? G2_CAP / 2 : G2_CAP;
-    uint32_t kshift = 6; if (getenv("RFQ_G2_KSHIFT")) kshift = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_G2_KSHIFT"))));
-    while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > g2cap) kshift--;
-    bool fast = kshift >= 1 && !(genv && !strcmp(genv, "old"));
-    const uint32_t max_rec = hs.max_rec;
-    for (;;) {
-        HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
-        HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
-        if (fast) {
-            const size_t nld = (size_t)(total_bases >> 4) + reads_used + 16;
-            HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2));
-            const uint32_t K = 1u << kshift;
-            const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
+    HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
+    HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
+    uint64_t* const ctot = B[B_CTOTAL].as<uint64_t>(); uint64_t* const cbase = B[B_CBASE].as<uint64_t>(); uint64_t* const ctot_n = B[B_CTOTALN].as<uint64_t>(); uint64_t* const cbase_n = B[B_CBASEN].as<uint64_t>();
+    bool aux_chain = false;
+    if (fast) {
+        const size_t nld = (size_t)(total_bases >> 4) + reads_used + 16;
+        HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2)); HIPCHK(ctx, B[B_RFLAG].ensure(nr));
+        HIPCHK(ctx, hipMemsetAsync(B[B_RFLAG].p, 0, nr, S));
+        const uint32_t K = 1u << kshift;
+        const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, (pipe ? 5u : 6u) * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
 #define RFQ_G2_ARGS T, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint32_t*)C.il, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), \
-                    B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, dst, (tune >> 16) & 15      /* (tune bits 16-19: ablation switches of k_gather2, results invalid) */
-            if (pipe) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
-            else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
+                    B[B_RFLAG].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, dst, (tune >> 16) & 15      /* (tune bits 16-19: ablation switches of k_gather2, results invalid) */
+        if (pipe) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
+        else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
 #undef RFQ_G2_ARGS
-            // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
+        // the quality streams' scratch plan needs nothing else: the position coder can start as soon as the host has sized its arena
+        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 1);
+        scan_exclusive<uint64_t>(S, ctot, cbase, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst);
+        // Second chain (aux stream), beside the position coder: overlap search on the loose slots the gather has just left, stored prefix, sequence packer
+        // (tight 2-bit stream + N mask + N counts), the N streams' plan, the image's upper bound.  These are chains of small latency-bound kernels
+        // and a search that is VALU-bound; the coder hides them.
+        aux_chain = ctx->aux_ready() && !(tune & 2048); hipStream_t A = aux_chain ? ctx->aux : S;
+        if (aux_chain) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); ovl_guard.armed = true; }
+        if (is_pe) {
+            const OvLoose Z = { (const uint32_t*)R.pq, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), (const uint8_t*)B[B_RFLAG].as<uint8_t>() };
+            const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
+            hipLaunchKernelGGL((k_overlap<false, true>), dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, (tune >> 8) & 7);
+        }
+        stored_prefix(A, B[B_SCANTMP2].as<U4>());
+        {
             const uint32_t max_len = max_rec / 2u;                             // (a record holds its sequence twice over: bases and qualities)
+            // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
             uint32_t rshift = 8; while (rshift && ((uint64_t)(max_len / 16u + 1u) << rshift) > SP_OWN) rshift--;
             uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
             if (getenv("RFQ_SP_X")) sx = std::max(1, atoi(getenv("RFQ_SP_X")));
-            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, S, (const uint32_t*)R.pq, (const U4*)R.pv, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
+            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
                                C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift, (tune >> 20) & 15);   // (tune bits 20-23: ablation switches, results invalid)
-        } else {
-            HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
-            // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 32
-            const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
+        }
+        uint64_t* tmp2 = B[B_SCANTMP2].as<uint64_t>() + (nr / SCAN_TILE + 2) * 2;   // (behind the U4 scan's part of the buffer)
+        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, A, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 2);
+        scan_exclusive<uint64_t>(A, ctot_n, cbase_n, n_chunks, tmp2, 1);
+        hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, A, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
+        scan_exclusive<uint64_t>(A, C.img_size, C.img_off, n_chunks, tmp2, 1);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, A, C, (const uint64_t*)cbase_n, n_chunks, 2, dst);
+        KCHK(ctx, "k_gather2");
+    } else {
+        HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
+        // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 32
+        const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
 #define RFQ_GATHER_ARGS T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, \
                         tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune
-            if (tune & 7) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
-            else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
+        if (tune & 7) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
+        else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
 #undef RFQ_GATHER_ARGS
-            if (tune & 7) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
-                if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
-            const uint32_t px = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
-            hipLaunchKernelGGL(k_packbytes, dim3(px, n_chunks), dim3(256), 0, S, (const U4*)R.pv, (const uint32_t*)C.first, (const uint64_t*)C.sbase, (const uint8_t*)B[B_SCAT].as<uint8_t>(),
-                               B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>());
-        }
-        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_CTOTAL].as<uint64_t>(), n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg);
-        scan_exclusive<uint64_t>(S, B[B_CTOTAL].as<uint64_t>(), B[B_CBASE].as<uint64_t>(), n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+        if (tune & 7) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
+            if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
+        const uint32_t px = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
+        hipLaunchKernelGGL(k_packbytes, dim3(px, n_chunks), dim3(256), 0, S, (const U4*)R.pv, (const uint32_t*)C.first, (const uint64_t*)C.sbase, (const uint8_t*)B[B_SCAT].as<uint8_t>(),
+                           B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>());
+        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 3);
+        scan_exclusive<uint64_t>(S, ctot, cbase, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
+        scan_exclusive<uint64_t>(S, ctot_n, cbase_n, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
         hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
         scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 0, dst);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase_n, n_chunks, 2, dst);
         KCHK(ctx, "k_gather");
-        HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-        if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
-        HIPCHK(ctx, ctx->fetch_sync(S));
-        break;
     }
-    ctx->timer.stages[ctx->timer.used].name = fast ? "gather" : "gather_bytes";   // (which formulation ran: tests and the bench look at it)
+    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+    if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
+    HIPCHK(ctx, ctx->fetch_sync(S));
     ctx->timer.end(S);
     if (hs.err & (DE_BAD_QUAL | DE_BAD_BASE)) {
         // RfqHeader::makeQualityTable error_exit texts, src/rfqheader.cpp:140-166
@@ -495,6 +522,27 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // ---- phase 4: code streams, exact layout, assemble
     HIPCHK(ctx, B[B_SCRATCH].ensure((size_t)hs.total_scratch + 256));
     HIPCHK(ctx, B[B_XS].ensure(3 * nr + 64)); HIPCHK(ctx, B[B_YS].ensure(3 * nr + 64));
+    const uint32_t nqg = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
+    auto launch_coder = [&](hipStream_t Q, uint32_t g0, uint32_t gn) -> int {
+        const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * gn * n_seg;
+        if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
+        hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint16_t*)B[B_SNM].as<uint16_t>(),
+                           B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase, B[B_SCRATCHN].as<uint8_t>(), (const uint64_t*)cbase_n,
+                           B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, nqg, g0, gn, dst);
+        return RFQ_OK;
+    };
+    ctx->timer.begin("pos_coder", S);
+    const bool fork_coords = ctx->aux_ready();
+    if (!fast && fork_coords) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0)); }
+    if (fast) {
+        // the quality / exception streams now; the N streams when the second chain has planned them (its totals come back while the coder runs)
+        if (!aux_chain) HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));   // (one stream: the N plan is already in)
+        const bool pc_all = !aux_chain && getenv("RFQ_PC_ALL");            // (profiling aid: with everything on one stream, all groups in one launch)
+        { const int rc = launch_coder(S, 0, pc_all ? nqg + 2 : nqg + 1); if (rc) return rc; }
+        if (aux_chain) { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, ctx->aux)); HIPCHK(ctx, ctx->fetch_sync(ctx->aux)); ovl_guard.armed = false; }
+        else { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S)); HIPCHK(ctx, ctx->fetch_sync(S)); }
+    }
+    HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));
     const uint64_t hdr_bytes = a->emit_header ? HH.len : 0;
     uint8_t* img; uint64_t img_cap;
     if (a->d_out) { img = a->d_out; img_cap = a->out_cap; }
@@ -503,31 +551,22 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (img_cap < hdr_bytes) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small for the header");
         HIPCHK(ctx, hipMemcpyAsync(img, HH.bytes, hdr_bytes, hipMemcpyHostToDevice, S));
     }
-    // the coordinate coder (one dependent chain of ~100 steps per (axis, chunk)) runs beside the position coder on the aux stream
-    const bool fork_coords = ctx->aux_ready();
-    if (fork_coords) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-        hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, ctx->aux, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
-    }
-    ctx->timer.begin("pos_coder", S);
+    // the coordinate coder (one dependent chain of ~100 steps per (axis, chunk)) runs beside the quality streams on the aux stream - fast path: behind
+    // the second chain, and so do the N streams (that chain has planned them)
     {
-        const uint32_t n_qgroups = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
-        const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * (n_qgroups + 2) * n_seg;
-        if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
-        hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, S, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint16_t*)B[B_SNM].as<uint16_t>(),
-                           B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(), B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(),
-                           n_seg, n_chunks, n_qgroups, dst);
-        hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const uint32_t*)B[B_SEGB].as<uint32_t>(), n_seg);
+        hipStream_t A2 = (fast ? aux_chain : fork_coords) ? ctx->aux : S;
+        hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, A2, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
+        if (fast) { if (!(!aux_chain && getenv("RFQ_PC_ALL"))) { const int rc = launch_coder(A2, nqg + 1, 1); if (rc) return rc; } }
+        else { const int rc = launch_coder(S, 0, nqg + 2); if (rc) return rc; }
+        if (A2 != S) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A2)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     }
     KCHK(ctx, "k_pos_coder");
     ctx->timer.end(S);
     ctx->timer.begin("coords+layout", S);
-    if (fork_coords) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0));
-    else hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
+    hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const uint32_t*)B[B_SEGB].as<uint32_t>(), n_seg);
     hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-    hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)B[B_CBASE].as<uint64_t>(), n_chunks, 1, dst);
+    hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 1, dst);
     KCHK(ctx, "k_coords");
     ctx->timer.end(S);
     ctx->timer.begin("assemble", S);
@@ -537,7 +576,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         const uint32_t tail_bases = ((a->final && !a->flush_all) || ended) ? a->chunk_bases : 0u;
         const uint32_t bpc = grid_x_for(n_chunks, 64u, 8u * ctx->n_cu);       // (no LDS, 28 VGPRs: eight workgroups per CU)
         hipLaunchKernelGGL(k_assemble, dim3(bpc, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, (const Layout*)L,
-                           (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint32_t*)B[B_SPK].as<uint32_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)B[B_CBASE].as<uint64_t>(),
+                           (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint32_t*)B[B_SPK].as<uint32_t>(), (const uint8_t*)B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase,
+                           (const uint8_t*)B[B_SCRATCHN].as<uint8_t>(), (const uint64_t*)cbase_n,
                            (const uint8_t*)B[B_XS].as<uint8_t>(), (const uint8_t*)B[B_YS].as<uint8_t>(), (const int8_t*)ovb, img, img_cap, hdr_bytes,
                            a->file_off1, a->file_off2, a->nolb_from1, a->nolb_from2,
                            (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, dst,

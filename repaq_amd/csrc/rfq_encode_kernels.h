@@ -838,7 +838,11 @@ __device__ __forceinline__ void ov2_pack_rc(uint32_t w, uint32_t& code, uint32_t
 // The search needs nothing but the text and its line table, so it runs for EVERY pair as soon as the index exists - on the second stream, beside
 // the read table, the cut, the header and the chunk flags (those are latency-bound, this is VALU-bound) - and leaves the raw offset (0 = none)
 // in ovraw; k_overlap_apply takes them over for the chunks that turn out to be interleaved under a header with BIT_ENCODE_PE_BY_OVERLAP.
-template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int16_t* __restrict__ ovraw, uint32_t n_pairs, unsigned long long* dbg, int abl) {
+// LOOSE: the rows are not packed from the text but copied from the loose slots k_gather2 has left (the same codes, R2 already reverse-complemented,
+// valid for the pairs of interleaved chunks - the only ones whose result is used): lengths and slots come from the quality prefix pq, the
+// "R1 holds a byte outside A/C/G/T/N" verdict from rflag.  The search then runs behind the gather, beside the position coder.
+struct OvLoose { const uint32_t* pq; const uint32_t* lpk; const uint16_t* lnb; const uint8_t* rflag; };
+template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, OvLoose Z, int16_t* __restrict__ ovraw, uint32_t n_pairs, unsigned long long* dbg, int abl) {
     __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4) + 4]; __shared__ uint32_t s_bad[4][2];      // (+4: a verification step reads 9 bytes from a byte offset inside the last row)
     long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a_meta = 0, a_pack = 0, a_fwd = 0, a_bwd = 0, a_slow = 0; uint32_t n_ver = 0;
     const int l = lane_id(), w = wave_id();
@@ -846,10 +850,11 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int
     uint8_t* const n1 = c2 + 64u * OV2_CROW; uint8_t* const n2 = n1 + 64u * OV2_NROW;
     for (uint32_t p0 = (blockIdx.x * 4u + (uint32_t)w) * 64u; p0 < n_pairs; p0 += gridDim.x * 256u) {       // wave-uniform
         if (DBG) k0 = clock64();
-        const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0;
+        const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0; uint32_t ld1 = 0, ld2 = 0;
         if (p < n_pairs) {
             const uint32_t g = 2u * p;
-            if (!(abl & 4)) { uint32_t r; read_loc(T, g, s1, r); const uint32_t* pa = t_lo(T, s1) + 4 * (size_t)r; q1 = pa[1]; len1 = (int)(pa[2] - 1u - q1);
+            if (LOOSE) { const uint32_t a = Z.pq[g], b = Z.pq[g + 1], c_ = Z.pq[g + 2]; len1 = (int)(b - a); len2 = (int)(c_ - b); ld1 = (a >> 4) + g; ld2 = (b >> 4) + g + 1u; }
+            else if (!(abl & 4)) { uint32_t r; read_loc(T, g, s1, r); const uint32_t* pa = t_lo(T, s1) + 4 * (size_t)r; q1 = pa[1]; len1 = (int)(pa[2] - 1u - q1);
                               read_loc(T, g + 1, s2, r); const uint32_t* pb = t_lo(T, s2) + 4 * (size_t)r; q2 = pb[1]; len2 = (int)(pb[2] - 1u - q2); }
         }
         const bool slow = len1 >= 0 && ((uint32_t)len1 > OV2_CAP || (uint32_t)len2 > OV2_CAP), fast = len1 >= 0 && !slow;
@@ -865,71 +870,89 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int
         // 16 bases of the line itself - keeps the texture addresser busy for hundreds of cycles).  A group's 32 bases land at an arbitrary
         // base position of the row: their codes (64 bits) and N bits (32 bits) are shifted into place and OR-ed into the row.  (16-byte
         // tasks cost 150 instructions each, 90 of them per task and not per byte: row look-up, masks, atomics.)
-        const uint32_t G = ((uint32_t)mx + 31u + 31u) >> 5, ntasks = (abl & 2) ? 0u : 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 4096, G <= 17
-        const uint32_t meta1 = (uint32_t)(len1 < 0 ? 0 : (len1 > 0xFFFF ? 0xFFFF : len1)) | ((uint32_t)s1 << 16) | (fast ? 1u << 17 : 0u);
-        const uint32_t meta2 = (uint32_t)(len2 < 0 ? 0 : (len2 > 0xFFFF ? 0xFFFF : len2)) | ((uint32_t)s2 << 16);
-        for (uint32_t t0 = 0; t0 < ntasks; t0 += 256u) {
-            uint32_t v[4][8]; uint32_t row[4]; int L[4], pos0[4]; bool on[4], edge[4]; const uint8_t* src[4]; uint32_t at[4], lim[4];
+        if (LOOSE) {
+            // every lane copies its own pair's two slots into its two rows, four dwords of each per round: the loads of a round are all in flight
+            // together (a task list dealt out over the wave - a shuffled row look-up and one load per step - was a chain of twenty round trips)
+            const uint32_t nd_ = ((uint32_t)mx + 15u) >> 4;
+            uint32_t* const r1w = (uint32_t*)(c1 + (uint32_t)l * OV2_CROW); uint32_t* const r2w = (uint32_t*)(c2 + (uint32_t)l * OV2_CROW);
+            uint16_t* const m1w = (uint16_t*)(n1 + (uint32_t)l * OV2_NROW); uint16_t* const m2w = (uint16_t*)(n2 + (uint32_t)l * OV2_NROW);
+            for (uint32_t j0 = 0; j0 < nd_; j0 += 4u) {
+                uint32_t va[4], vb[4]; uint16_t ma[4], mb[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)l; row[u] = t < ntasks ? (t * ginv) >> 16 : 0u; const uint32_t j = t - row[u] * G;
-                const int srcl = (int)(row[u] & 63u); const bool second = row[u] >= 64u;
-                const uint32_t ma = __shfl(meta1, srcl), mb = __shfl(meta2, srcl), o1 = __shfl(q1, srcl), o2 = __shfl(q2, srcl);
-                const uint32_t mm = second ? mb : ma; const bool f = (ma >> 17) & 1u;
-                L[u] = (int)(mm & 0xFFFFu); const uint32_t q = second ? o2 : o1, m = q & 31u;
-                at[u] = (q & ~31u) + 32u * j;                              // the group's offset in its stream
-                on[u] = t < ntasks && f && at[u] < q + (uint32_t)L[u];
-                const int z = (int)((mm >> 16) & 1u); src[u] = t_fq(T, z); lim[u] = t_n(T, z);
-                // base position (in the row) of the group's first byte once the row's orientation is applied: R1 as it stands, R2 back to front
-                pos0[u] = second ? L[u] - 32 * (int)j + (int)m - 32 : 32 * (int)j - (int)m;
-                edge[u] = on[u] && (unsigned long long)at[u] + 32ull > (unsigned long long)lim[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[u][i] = 0;
-                if (on[u] && !edge[u]) { const uint4 x = *(const uint4*)(src[u] + at[u]), y = *(const uint4*)(src[u] + at[u] + 16u);
-                                         v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z; v[u][7] = y.w; }
-            }
-            if (__any(edge[0] || edge[1] || edge[2] || edge[3])) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], (long long)at[u], (uint64_t)lim[u]), y = ld16_edge(src[u], (long long)at[u] + 16, (uint64_t)lim[u]);
-                                                           v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z; v[u][7] = y.w; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (!on[u]) continue;
-                const bool second = row[u] >= 64u; const uint32_t pr = row[u] & 63u;
-                unsigned long long cw = 0; uint32_t nw = 0, badb = 0;       // 32 codes, 32 N bits, 32 "neither A/C/G/T nor N" bits - byte b of the (re-oriented) group at bit b
-                if (!second) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) { uint32_t c, nb, bd; ov2_pack_r1(v[u][i], c, nb, bd); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); if (bd) badb |= (((bd & 0x01010101u) * 0x01020408u) >> 24) << (4 * i); }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) { uint32_t c, nb; ov2_pack_rc(bswap32(v[u][7 - i]), c, nb); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); }
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t j = j0 + u; const bool o1 = fast && j < nd_ && 16u * j < (uint32_t)len1, o2 = fast && j < nd_ && 16u * j < (uint32_t)len2;
+                    va[u] = o1 ? Z.lpk[ld1 + j] : 0u; ma[u] = o1 ? Z.lnb[ld1 + j] : (uint16_t)0; vb[u] = o2 ? Z.lpk[ld2 + j] : 0u; mb[u] = o2 ? Z.lnb[ld2 + j] : (uint16_t)0;
                 }
-                // keep the bases whose position lies inside the read: drop the `lo` leading ones and everything from `hi` on, shift into place
-                const int lo = pos0[u] < 0 ? -pos0[u] : 0, hi = L[u] - pos0[u] < 32 ? L[u] - pos0[u] : 32;
-                if (hi <= lo) continue;
-                const uint32_t nk = (uint32_t)(hi - lo);                   // 1..32 bases kept
-                const uint32_t km = nk >= 32u ? 0xFFFFFFFFu : (1u << nk) - 1u;
-                cw = (cw >> (2 * lo)) & (nk >= 32u ? ~0ull : (1ull << (2u * nk)) - 1ull); nw = (nw >> lo) & km;
-                if ((badb >> lo) & km) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
-                const uint32_t p = (uint32_t)(pos0[u] + lo);
-                uint32_t* const crow = (uint32_t*)((second ? c2 : c1) + pr * OV2_CROW) + ((2u * p) >> 5); uint32_t* const nrow = (uint32_t*)((second ? n2 : n1) + pr * OV2_NROW) + (p >> 5);
-                const uint32_t cs = (2u * p) & 31u, ns = p & 31u;
-                const unsigned long long cv = cw << cs; const uint32_t ctop = cs ? (uint32_t)(cw >> (64u - cs)) : 0u;
-                const unsigned long long nv = (unsigned long long)nw << ns;
-                if ((uint32_t)cv) atomicOr(&crow[0], (uint32_t)cv);
-                if ((uint32_t)(cv >> 32)) atomicOr(&crow[1], (uint32_t)(cv >> 32));
-                if (ctop) atomicOr(&crow[2], ctop);
-                if ((uint32_t)nv) atomicOr(&nrow[0], (uint32_t)nv);
-                if ((uint32_t)(nv >> 32)) atomicOr(&nrow[1], (uint32_t)(nv >> 32));
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) { const uint32_t j = j0 + u; if (fast && j < nd_) { r1w[j] = va[u]; m1w[j] = ma[u]; r2w[j] = vb[u]; m2w[j] = mb[u]; } }
+            }
+        } else {
+        const uint32_t G = ((uint32_t)mx + 31u + 31u) >> 5, ntasks = (abl & 2) ? 0u : 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 4096, G <= 17
+            const uint32_t meta1 = (uint32_t)(len1 < 0 ? 0 : (len1 > 0xFFFF ? 0xFFFF : len1)) | ((uint32_t)s1 << 16) | (fast ? 1u << 17 : 0u);
+            const uint32_t meta2 = (uint32_t)(len2 < 0 ? 0 : (len2 > 0xFFFF ? 0xFFFF : len2)) | ((uint32_t)s2 << 16);
+            for (uint32_t t0 = 0; t0 < ntasks; t0 += 256u) {
+                uint32_t v[4][8]; uint32_t row[4]; int L[4], pos0[4]; bool on[4], edge[4]; const uint8_t* src[4]; uint32_t at[4], lim[4];
+    #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)l; row[u] = t < ntasks ? (t * ginv) >> 16 : 0u; const uint32_t j = t - row[u] * G;
+                    const int srcl = (int)(row[u] & 63u); const bool second = row[u] >= 64u;
+                    const uint32_t ma = __shfl(meta1, srcl), mb = __shfl(meta2, srcl), o1 = __shfl(q1, srcl), o2 = __shfl(q2, srcl);
+                    const uint32_t mm = second ? mb : ma; const bool f = (ma >> 17) & 1u;
+                    L[u] = (int)(mm & 0xFFFFu); const uint32_t q = second ? o2 : o1, m = q & 31u;
+                    at[u] = (q & ~31u) + 32u * j;                              // the group's offset in its stream
+                    on[u] = t < ntasks && f && at[u] < q + (uint32_t)L[u];
+                    const int z = (int)((mm >> 16) & 1u); src[u] = t_fq(T, z); lim[u] = t_n(T, z);
+                    // base position (in the row) of the group's first byte once the row's orientation is applied: R1 as it stands, R2 back to front
+                    pos0[u] = second ? L[u] - 32 * (int)j + (int)m - 32 : 32 * (int)j - (int)m;
+                    edge[u] = on[u] && (unsigned long long)at[u] + 32ull > (unsigned long long)lim[u];
+                }
+    #pragma unroll
+                for (int u = 0; u < 4; u++) {
+    #pragma unroll
+                    for (int i = 0; i < 8; i++) v[u][i] = 0;
+                    if (on[u] && !edge[u]) { const uint4 x = *(const uint4*)(src[u] + at[u]), y = *(const uint4*)(src[u] + at[u] + 16u);
+                                             v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z; v[u][7] = y.w; }
+                }
+                if (__any(edge[0] || edge[1] || edge[2] || edge[3])) {
+    #pragma unroll
+                    for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], (long long)at[u], (uint64_t)lim[u]), y = ld16_edge(src[u], (long long)at[u] + 16, (uint64_t)lim[u]);
+                                                               v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z; v[u][7] = y.w; }
+                }
+    #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!on[u]) continue;
+                    const bool second = row[u] >= 64u; const uint32_t pr = row[u] & 63u;
+                    unsigned long long cw = 0; uint32_t nw = 0, badb = 0;       // 32 codes, 32 N bits, 32 "neither A/C/G/T nor N" bits - byte b of the (re-oriented) group at bit b
+                    if (!second) {
+    #pragma unroll
+                        for (int i = 0; i < 8; i++) { uint32_t c, nb, bd; ov2_pack_r1(v[u][i], c, nb, bd); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); if (bd) badb |= (((bd & 0x01010101u) * 0x01020408u) >> 24) << (4 * i); }
+                    } else {
+    #pragma unroll
+                        for (int i = 0; i < 8; i++) { uint32_t c, nb; ov2_pack_rc(bswap32(v[u][7 - i]), c, nb); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); }
+                    }
+                    // keep the bases whose position lies inside the read: drop the `lo` leading ones and everything from `hi` on, shift into place
+                    const int lo = pos0[u] < 0 ? -pos0[u] : 0, hi = L[u] - pos0[u] < 32 ? L[u] - pos0[u] : 32;
+                    if (hi <= lo) continue;
+                    const uint32_t nk = (uint32_t)(hi - lo);                   // 1..32 bases kept
+                    const uint32_t km = nk >= 32u ? 0xFFFFFFFFu : (1u << nk) - 1u;
+                    cw = (cw >> (2 * lo)) & (nk >= 32u ? ~0ull : (1ull << (2u * nk)) - 1ull); nw = (nw >> lo) & km;
+                    if ((badb >> lo) & km) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
+                    const uint32_t p = (uint32_t)(pos0[u] + lo);
+                    uint32_t* const crow = (uint32_t*)((second ? c2 : c1) + pr * OV2_CROW) + ((2u * p) >> 5); uint32_t* const nrow = (uint32_t*)((second ? n2 : n1) + pr * OV2_NROW) + (p >> 5);
+                    const uint32_t cs = (2u * p) & 31u, ns = p & 31u;
+                    const unsigned long long cv = cw << cs; const uint32_t ctop = cs ? (uint32_t)(cw >> (64u - cs)) : 0u;
+                    const unsigned long long nv = (unsigned long long)nw << ns;
+                    if ((uint32_t)cv) atomicOr(&crow[0], (uint32_t)cv);
+                    if ((uint32_t)(cv >> 32)) atomicOr(&crow[1], (uint32_t)(cv >> 32));
+                    if (ctop) atomicOr(&crow[2], ctop);
+                    if ((uint32_t)nv) atomicOr(&nrow[0], (uint32_t)nv);
+                    if ((uint32_t)(nv >> 32)) atomicOr(&nrow[1], (uint32_t)(nv >> 32));
+                }
             }
         }
         wave_lds_sync();
         if (DBG) { k2 = clock64(); a_pack += k2 - k1; }
-        const bool bad = fast && ((s_bad[w][l >> 5] >> (l & 31)) & 1u);
+        const bool bad = fast && (LOOSE ? (p < n_pairs && Z.rflag[2u * p] != 0) : ((s_bad[w][l >> 5] >> (l & 31)) & 1u) != 0);
         const bool go = fast && !bad; const int minlen = len1 < len2 ? len1 : len2;
         const uint8_t* const r1c = c1 + (uint32_t)l * OV2_CROW; const uint8_t* const r2c = c2 + (uint32_t)l * OV2_CROW;
         int ov = 0; bool done = !go || minlen < 12 || (abl & 1);
@@ -1010,6 +1033,7 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_overlap(Text T, int
         if (DBG) { k4 = clock64(); a_bwd += k4 - k3; }
         // reads longer than a row, or an R1 holding a character outside A/C/G/T/N: the byte-wise search, one pair at a time
         unsigned long long sm = __ballot(slow || bad);
+        if (LOOSE && sm && len1 >= 0) { uint32_t r; read_loc(T, 2u * p, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, 2u * p + 1u, s2, r); q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }   // (the byte-wise search reads the text)
         while (sm) {
             const int j = __ffsll((long long)sm) - 1; sm &= sm - 1;
             const uint8_t* a = t_fq(T, __shfl(s1, j)) + __shfl(q1, j); const uint8_t* b = t_fq(T, __shfl(s2, j)) + __shfl(q2, j);
@@ -1036,9 +1060,10 @@ __global__ void k_pv_in(Text T, ReadTab R, U4* __restrict__ v, uint32_t n_reads)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n_reads) { U4 t; t.a = R.name1_len[g]; t.b = name2_len_of(T, R, g); t.c = line_len(T, g, 2); t.d = R.stored[g]; v[g] = t; }
 }
-__global__ void k_chunk_bases(ReadTab R, ChunkTab C, uint32_t n_chunks) {
+// which: bit 0 = qbase (needs the quality prefix only), bit 1 = sbase (needs the stored-base prefix, i.e. the overlaps)
+__global__ void k_chunk_bases(ReadTab R, ChunkTab C, uint32_t n_chunks, int which) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_chunks) { const uint32_t f = C.first[c]; C.qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c; C.sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
+    if (c < n_chunks) { const uint32_t f = C.first[c]; if (which & 1) C.qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c; if (which & 2) C.sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
 }
 
 // =============================================================== gather (RfqCodec::encodeChunk pass 2, src/rfqcodec.cpp:371-407)
@@ -1327,7 +1352,7 @@ __device__ __forceinline__ void pack4_codes_rc(uint32_t w, uint32_t& code, uint3
     nb = ((~ok & 0x01010101u) * 0x01020408u) >> 24;
 }
 struct G2Geo { uint32_t a00, a01, end0, end1, base1; };                         // a tile's text spans: 16-aligned begin and end per stream, LDS offset of stream 1's span
-struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld; };       // my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
+struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld, gi; };       // my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
 __device__ __forceinline__ G2Geo g2_geo(const Text& T, bool two, uint32_t cur, uint32_t cnt) {
     G2Geo g;
     if (two) { const size_t r0 = 4 * (size_t)(cur >> 1), r1 = 4 * (size_t)((cur + cnt) >> 1);
@@ -1350,7 +1375,7 @@ __device__ __forceinline__ void g2_stage(const Text& T, bool two, const G2Geo& g
     if (two) g2_stage1(T.fq[1], T.n[1], g.a01, g.end1, buf4 + g.base1 / 16, tid);
 }
 __device__ __forceinline__ G2Read g2_read(const Text& T, const uint32_t* __restrict__ pq, const G2Geo& g, uint32_t f, uint32_t pq0, bool il, uint32_t cur, uint32_t j, uint32_t cnt) {
-    G2Read m; m.on = j < cnt; m.rc = false; m.len = m.qsrc = m.ssrc = m.qpos = m.ld = 0;
+    G2Read m; m.on = j < cnt; m.rc = false; m.len = m.qsrc = m.ssrc = m.qpos = m.ld = 0; m.gi = cur + j;
     if (m.on) {
         const uint32_t gi = cur + j; int s_; uint32_t r_; read_loc(T, gi, s_, r_);
         const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);     // starts of the read's four lines
@@ -1362,7 +1387,7 @@ __device__ __forceinline__ G2Read g2_read(const Text& T, const uint32_t* __restr
     return m;
 }
 // my share (groups part, part + P, ...) of my read's two lines: qualities -> qcat, bases -> the loose slot
-__device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, QualCount& qc, int abl) {
+__device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag, QualCount& qc, int abl) {
     if (m.on && !(abl & 1)) {
         // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
         const uint32_t n = m.len; uint8_t* const o = qd + m.qpos; const bool rc = m.rc;
@@ -1387,8 +1412,10 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
             uint32_t w[4], code = 0, nbits = 0;
             if (!m.rc) {
                 lds_get16(s_text, m.ssrc + 16u * gi, w);
+                uint32_t bad = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
+                for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
+                if (bad) { const uint32_t nv_ = m.len - 16u * gi; if (nv_ >= 16u || (bad & ((1u << nv_) - 1u))) rflag[m.gi] = 1; }   // a byte outside A/C/G/T/N: it equals nothing in RfqCodec::overlap (k_overlap's byte-wise path)
             } else {
                 lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);       // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line: masked below)
                 const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3;
@@ -1405,7 +1432,7 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
 // under this tile's compose - one barrier per tile.  (Measured on configs[2], single buffer, K = 64: of the kernel's 3.4 ms, 1.8 ms are the bare
 // stage-and-wait loop - 8 GB at 4.4 TB/s with a third of the resident workgroups in their staging phase at any time.)
 template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const uint64_t* __restrict__ qbase,
-                                                 const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb,
+                                                 const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift, DevStatus* st, int abl) {
     __shared__ uint4 s_text4[G2_CAP / 16 + 16];
     __shared__ uint32_t sh[PIPE ? 2 : 1][G2_CNT]; __shared__ int sh_last[PIPE ? 2 : 1][G2_CNT]; __shared__ uint8_t s_slot[256];   // (two counter sets when tiles overlap)
@@ -1434,7 +1461,7 @@ template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, co
             const uint32_t qbeg = uni32(pq[cur]) - pq0;                      // the tile's first quality position (chunk-relative)
             __syncthreads();                                                // (drains the LDS-DMA)
             qc.seg0 = qbeg / PC_SEG_POS;
-            g2_compose((const uint8_t*)buf4, m, part, P, qd, lpk, lnb, qc, abl);
+            g2_compose((const uint8_t*)buf4, m, part, P, qd, lpk, lnb, rflag, qc, abl);
             __syncthreads();                                                // the text is free for the next tile; the tile's counts are complete
             qual_flush(sh[0], sh_last[0], nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
         }
@@ -1455,7 +1482,7 @@ template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, co
                 mn = g2_read(T, pq, gn, f, pq0, il, nxt, j, cn); qn = uni32(pq[nxt]) - pq0;
             }
             qc.cnt = sh[PIPE ? pb : 0u]; qc.last = sh_last[PIPE ? pb : 0u]; qc.seg0 = qbeg / PC_SEG_POS; seg_prev = qc.seg0;
-            g2_compose((const uint8_t*)(s_text4 + 1 + pb * HALF4), m, part, P, qd, lpk, lnb, qc, abl);
+            g2_compose((const uint8_t*)(s_text4 + 1 + pb * HALF4), m, part, P, qd, lpk, lnb, rflag, qc, abl);
             g = gn; m = mn; qbeg = qn; cnt = cn;
         }
         __syncthreads();
@@ -1563,29 +1590,34 @@ __global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, co
 
 // scratch capacity of every stream of a chunk: a value with k matches in len positions codes to at most
 // k + len/128 + 3*len/16384 bytes (one byte per token, +1 for each gap > 128, +3 for each gap > 16384).
-__global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint64_t* __restrict__ ctotal, uint32_t n_chunks, const uint32_t* __restrict__ segm, uint32_t n_seg) {
+// which: 1 = the quality-value and exception streams (arena `scratch`, chunk total -> ctotal), 2 = the N-position stream (its own arena: it is
+// planned later, when the sequence packer has counted the N; chunk total -> ctotal_n), 3 = both
+__global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint64_t* __restrict__ ctotal, uint64_t* __restrict__ ctotal_n, uint32_t n_chunks, const uint32_t* __restrict__ segm, uint32_t n_seg, int which) {
     // one wave per chunk: lane j plans slot j (slots 64 / 65 by lanes 0 / 1 afterwards); offsets by a wave scan
     const uint32_t c = blockIdx.x; const int l = lane_id();
     if (c >= n_chunks) return;
     const uint32_t f = C.first[c], e = C.first[c + 1];
-    const uint32_t len = R.pq[e] - R.pq[f], slen = R.pv[e].d - R.pv[f].d;
+    const uint32_t len = R.pq[e] - R.pq[f];
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT;
     const bool bycol = (D->flags & H_QUAL_BY_COL) && !(D->flags & H_DONT_QUAL);
-    // occurrences of a stream's value in the chunk = its per-segment match counts (k_gather), summed
-    auto occ = [&](uint32_t j) -> uint32_t { uint32_t t = 0; const uint32_t* p = segm + ((size_t)c * MAX_STREAMS + j) * n_seg; for (uint32_t s_ = 0; s_ < n_seg; s_++) t += p[s_]; return t; };
-    const uint32_t ex = bycol ? occ(EXC_SLOT) : 0u;
-    const uint32_t pad = PC_SEG_PAD * pc_n_seg(len), pads = PC_SEG_PAD * pc_n_seg(slen);
-    uint32_t cap = (bycol && (uint32_t)l < nn) ? occ((uint32_t)l) + len / 128 + 3 * (len / 16384) + 16 + pad : 0u;
-    const uint32_t al = (cap + 15u) & ~15u;
-    const uint32_t incl = wave_incl_sum(al);
     const size_t k = (size_t)c * MAX_STREAMS;
-    C.scap[k + l] = cap; C.soff[k + l] = incl - al; C.ssize[k + l] = 0;
-    const uint32_t run64 = __shfl(incl, 63);
-    if (l < 2) {
-        const uint32_t capn = (D->flags & H_N_POS) ? C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16 + pads : 0u, cape = bycol ? 5 * ex + 16 + pad : 0u;
-        const uint32_t aln = (capn + 15u) & ~15u, ale = (cape + 15u) & ~15u;
-        if (l == 0) { C.scap[k + NPOS_SLOT] = capn; C.soff[k + NPOS_SLOT] = run64; C.ssize[k + NPOS_SLOT] = 0; }
-        else { C.scap[k + EXC_SLOT] = cape; C.soff[k + EXC_SLOT] = run64 + aln; C.ssize[k + EXC_SLOT] = 0; ctotal[c] = (uint64_t)run64 + aln + ale; }
+    if (which & 1) {
+        // occurrences of a stream's value in the chunk = its per-segment match counts (k_gather), summed
+        auto occ = [&](uint32_t j) -> uint32_t { uint32_t t = 0; const uint32_t* p = segm + ((size_t)c * MAX_STREAMS + j) * n_seg; for (uint32_t s_ = 0; s_ < n_seg; s_++) t += p[s_]; return t; };
+        const uint32_t ex = bycol ? occ(EXC_SLOT) : 0u;
+        const uint32_t pad = PC_SEG_PAD * pc_n_seg(len);
+        uint32_t cap = (bycol && (uint32_t)l < nn) ? occ((uint32_t)l) + len / 128 + 3 * (len / 16384) + 16 + pad : 0u;
+        const uint32_t al = (cap + 15u) & ~15u;
+        const uint32_t incl = wave_incl_sum(al);
+        C.scap[k + l] = cap; C.soff[k + l] = incl - al; C.ssize[k + l] = 0;
+        const uint32_t run64 = __shfl(incl, 63);
+        if (l == 0) { const uint32_t cape = bycol ? 5 * ex + 16 + pad : 0u, ale = (cape + 15u) & ~15u;
+                      C.scap[k + EXC_SLOT] = cape; C.soff[k + EXC_SLOT] = run64; C.ssize[k + EXC_SLOT] = 0; ctotal[c] = (uint64_t)run64 + ale; }
+    }
+    if ((which & 2) && l == 0) {
+        const uint32_t slen = R.pv[e].d - R.pv[f].d, pads = PC_SEG_PAD * pc_n_seg(slen);
+        const uint32_t capn = (D->flags & H_N_POS) ? C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16 + pads : 0u;
+        C.scap[k + NPOS_SLOT] = capn; C.soff[k + NPOS_SLOT] = 0; C.ssize[k + NPOS_SLOT] = 0; ctotal_n[c] = (uint64_t)((capn + 15u) & ~15u);
     }
 }
 
@@ -1846,13 +1878,17 @@ __global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint3
         C.ssize[k] = tot;
     }
 }
+// g0, gn: the groups this launch codes (the quality / exception groups run behind the gather, the N group behind the sequence packer)
 __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint16_t* __restrict__ snm,
-                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
-                            uint32_t n_qgroups, DevStatus* st) {
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint8_t* __restrict__ scratch_n, const uint64_t* __restrict__ cbase_n,
+                            uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
+                            uint32_t n_qgroups, uint32_t g0, uint32_t gn, DevStatus* st) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
     // (group, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's data stays in ONE private L2.
-    const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = (n_qgroups + 2) * n_seg;
-    const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = rest % (n_qgroups + 2), seg = rest / (n_qgroups + 2);
+    const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = gn * n_seg;
+    // (a chunk's workgroups group by group, not segment by segment: with two groups - quality streams and the usually empty exception stream -
+    // alternating, every other workgroup returned at once and the coder ran at half speed: 4.7 instead of 2.6 ms, consecutive ids share a SIMD pattern)
+    const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = g0 + rest / n_seg, seg = rest % n_seg;
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
     if (grp < n_qgroups) pc_run<PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
@@ -1862,7 +1898,7 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
         wave_lds_sync();
         pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st, s_exc);
     }
-    else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), R.pv[e].d - R.pv[f].d, scratch, cbase, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
+    else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), R.pv[e].d - R.pv[f].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
@@ -1989,7 +2025,7 @@ __device__ __forceinline__ void copy_to_image(uint8_t* __restrict__ dst, const u
 // quality payload, overlap bytes, N positions.
 __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L,
                            const uint8_t* __restrict__ qcat, const uint32_t* __restrict__ spk, const uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
-                           const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
+                           const uint8_t* __restrict__ scratch_n, const uint64_t* __restrict__ cbase_n, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
                            uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2,
                            const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, DevStatus* st,
                            uint32_t tail_bases, uint32_t tail_units, uint32_t tail_nl1, uint32_t tail_nl2, uint64_t tail_n1, uint64_t tail_n2) {
@@ -2091,7 +2127,7 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
             const uint32_t sz = segb[si0 + seg]; if (!sz) continue;
             uint32_t dst = o.off_npos, so = 0;
             for (uint32_t s2 = 0; s2 < seg; s2++) { dst += segb[si0 + s2]; so += pc_seg_cap(false, segm[si0 + s2], PC_SEG_POS); }
-            copy_to_image(out + dst, scratch + cbase[c] + C.soff[k0 + NPOS_SLOT] + so, sz, l, 64u);
+            copy_to_image(out + dst, scratch_n + cbase_n[c] + C.soff[k0 + NPOS_SLOT] + so, sz, l, 64u);
         }
     }
 }
@@ -2123,6 +2159,7 @@ __global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader*
 }
 __global__ void k_enc_totals(ChunkTab C, const uint64_t* __restrict__ ctotal_prefix, uint32_t n_chunks, int which, DevStatus* st) {
     if (threadIdx.x || blockIdx.x) return;
-    if (which == 0) { st->total_scratch = ctotal_prefix[n_chunks]; st->image_bound = C.img_off[n_chunks]; }
+    if (which == 0) { st->total_scratch = ctotal_prefix[n_chunks]; }                     // ctotal_prefix: the quality arena's
+    else if (which == 2) { st->total_scratch_n = ctotal_prefix[n_chunks]; st->image_bound = C.img_off[n_chunks]; }   // ... the N arena's
     else st->total_image = C.img_off[n_chunks];
 }

@@ -51,6 +51,32 @@ def test_multichunk_round_trip(codec, label, prof, reads, seed, cb, paired, kw):
     assert d == ((fq1, fq2) if paired != O.SE else fq1)
 
 
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI, ids=[m[0] for m in MULTI])
+def test_multichunk_round_trip_tile_fitting_emitter(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+    """RFQ_EMIT=2: k_dec_emit2 (tiles fitted read by read; the emitter of files whose name pieces are stored per read)."""
+    monkeypatch.setenv("RFQ_EMIT", "2")
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    rfq = O.encode_file(fq1, fq2, paired, cb)
+    d = codec.decode_bytes(rfq, split_pe=(paired != O.SE))
+    assert d == ((fq1, fq2) if paired != O.SE else fq1)
+    assert "emit2" in dict(codec.timings())
+
+
+def test_emitters_are_the_ones_expected(codec):
+    """k_dec_emit3 (fixed tiles, no output tile) decodes files whose chunks share their name pieces - NovaSeq-style names do; a file with
+    per-read name pieces goes to k_dec_emit2."""
+    for prof, paired in ((O.NOVA_PE150, O.PE_TWO_FILES), (O.NOVA_SE150, O.SE)):
+        fq1, fq2 = O.gen(prof, 300, seed=41)
+        rfq = O.encode_file(fq1, fq2, paired, 20000)
+        d = codec.decode_bytes(rfq, split_pe=(paired != O.SE))
+        assert d == ((fq1, fq2) if paired != O.SE else fq1)
+        assert "emit" in dict(codec.timings()), dict(codec.timings())
+    fq1, _ = O.gen(O.SE_VAR, 300, seed=42)
+    lines = fq1.split(b"\n"); lines[4 * 7] = lines[4 * 7] + b"x"; fq = b"\n".join(lines)      # one name that differs from the others in the part before the coordinates
+    rfq = O.encode_file(fq, b"", O.SE, 20000)
+    assert codec.decode_bytes(rfq) == fq
+
+
 def test_encode_then_decode_on_device_round_trip(codec):
     fq1, fq2 = O.gen(O.NOVA_PE150, 250, seed=33)
     rfq = E.encode(codec, fq1, fq2, O.PE_TWO_FILES, 15000)
