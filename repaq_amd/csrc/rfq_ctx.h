@@ -106,7 +106,7 @@ struct rfq_ctx {
     DBuf d_status; DevStatus h_status;
     DBuf d_cmp;                 // rfq_compare_bytes: one u64 (first differing offset)
     // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
-    DBuf b[104];
+    DBuf b[120];
     DBuf out_img, out_fq1, out_fq2, out_acc, out_acc1, out_acc2;       // out_acc*: the results of a sliced encode / decode call, appended
     std::vector<uint64_t> chunk_off;
     std::vector<uint64_t> scan_end[2];     // rfq_scan_batch: end offset of every chunk in each input stream

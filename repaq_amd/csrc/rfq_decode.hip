@@ -11,9 +11,9 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 72, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_SEGK, DB_NENT, DB_LOFF, DB_PLIST, DB_END
+    DB_CHUNKS = 80, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_SEGK, DB_NENT, DB_LOFF, DB_PLIST, DB_GWCAND, DB_GWLIST, DB_GWCNT, DB_GWLAND, DB_END
 };
-static_assert(DB_END <= 104, "rfq_ctx::b too small");
+static_assert(DB_END <= 120, "rfq_ctx::b too small");
 
 // fused path: k_dec_pos_list for the quality streams and the N-position stream (the arena is whatever B[DB_PLIST] holds)
 static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk* CH, uint32_t n_chunks, uint32_t maxseg, uint32_t ncell, uint32_t nstr,
@@ -261,17 +261,32 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs;
     uint32_t cap = (uint32_t)std::max<size_t>(B[DB_CHUNKS].cap / sizeof(DChunk), 4096);
     bool speculate = true;
-    // 0: the caller's chunk index (verified below), 1: the speculative mSize chain (verified), 2: the exact serial walk
+    // the chunk starts: the caller's chunk index (verified below); else guess-and-verify (k_dec_gw_*: an index made on the device, verified the same
+    // way); else the speculative mSize chain (verified); else the exact serial walk
     bool use_table = a->h_chunk_off && a->n_chunk_off && a->h_chunk_off[0] == start && a->h_chunk_off[a->n_chunk_off] <= a->n;
+    const char* wenv = getenv("RFQ_WALK");
+    bool guess = !use_table && !(wenv && !strcmp(wenv, "chain"));            // (RFQ_WALK=chain: straight to the one-wave chain; tests run both)
     for (;;) {
         if (use_table && a->n_chunk_off + 1u > cap) cap = a->n_chunk_off + 1u;
         HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
         HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
+        const bool table = use_table || guess;
         if (use_table) {
             const size_t tb = ((size_t)a->n_chunk_off + 1) * 8;
             HIPCHK(ctx, B[DB_OFFT].ensure(tb));
             HIPCHK(ctx, hipMemcpyAsync(B[DB_OFFT].p, a->h_chunk_off, tb, hipMemcpyHostToDevice, S));
             hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), a->n_chunk_off, B[DB_CHUNKS].as<DChunk>(), dst);
+        } else if (guess) {
+            HIPCHK(ctx, B[DB_OFFT].ensure(((size_t)cap + 2) * 8));
+            HIPCHK(ctx, B[DB_GWCAND].ensure(GW_SEGS * 8 + 64)); HIPCHK(ctx, B[DB_GWLIST].ensure((size_t)GW_SEGS * GW_LCAP * 8)); HIPCHK(ctx, B[DB_GWCNT].ensure(GW_SEGS * 4 + 64)); HIPCHK(ctx, B[DB_GWLAND].ensure(GW_SEGS * 8 + 64));
+            unsigned long long* cand = B[DB_GWCAND].as<unsigned long long>(); uint32_t* gbad = B[DB_GWCNT].as<uint32_t>() + GW_SEGS;
+            HIPCHK(ctx, hipMemsetAsync(cand, 0xFF, GW_SEGS * 8, S)); HIPCHK(ctx, hipMemsetAsync(gbad, 0, 4, S));
+            const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> (getenv("RFQ_GW_SHIFT") ? atoi(getenv("RFQ_GW_SHIFT")) : 16)));   // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
+            if (mseg > 1) hipLaunchKernelGGL(k_dec_gw_find, dim3(16, mseg - 1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, cand, mseg);
+            hipLaunchKernelGGL(k_dec_gw_walk, dim3(mseg), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, B[DB_GWLIST].as<unsigned long long>(), B[DB_GWCNT].as<uint32_t>(), B[DB_GWLAND].as<unsigned long long>(), gbad, mseg);
+            hipLaunchKernelGGL(k_dec_gw_stitch, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, (const unsigned long long*)B[DB_GWLIST].as<unsigned long long>(),
+                               (const uint32_t*)B[DB_GWCNT].as<uint32_t>(), (const unsigned long long*)B[DB_GWLAND].as<unsigned long long>(), (const uint32_t*)gbad, B[DB_OFFT].as<uint64_t>(), cap, dst, mseg);
+            hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), 0xFFFFFFFFu, B[DB_CHUNKS].as<DChunk>(), dst);
         }
         else if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
         else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
@@ -292,20 +307,23 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             break;
         }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
+        if (guess && hs.pad) { guess = false; continue; }                  // the guessed index did not verify: the chain
         if (!speculate) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
-        if (hs.pad) { speculate = false; continue; }                       // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
+        if (hs.pad) { speculate = false; guess = false; continue; }        // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
         if (hs.n_chunks > PARSE_AHEAD) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
             hipLaunchKernelGGL(k_dec_summary, dim3(1), dim3(256), 0, S, (const DChunk*)B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD, hs.n_chunks - PARSE_AHEAD);
             KCHK(ctx, "k_dec_parse");
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
-            if (h2.pad) { speculate = false; continue; }
+            if (h2.pad) { if (guess) { guess = false; continue; } speculate = false; continue; }
             hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
-        if (hs.consumed != a->n && a->n - hs.consumed >= 18) { speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
+        if (hs.consumed != a->n && a->n - hs.consumed >= 18) { if (guess) { guess = false; continue; } speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
+        (void)table;
         break;
     }
+    if (getenv("RFQ_TRACE")) fprintf(stderr, "[rfq] chunk starts: %s, %u chunks\n", use_table ? "caller's index" : (guess ? "guess-and-verify" : (speculate ? "mSize chain" : "exact walk")), hs.n_chunks);
     ctx->timer.end(S);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "truncated or corrupt rfq chunk at byte %llu", (unsigned long long)hs.consumed);
     // 64-bit total of the read lengths: bases, qualities and text are placed by 32-bit prefix sums below (a corrupt length table

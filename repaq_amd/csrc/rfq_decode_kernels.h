@@ -142,7 +142,10 @@ __global__ void k_dec_spec_walk(const uint8_t* __restrict__ img, uint64_t n, uin
 // The chain from a chunk index the caller supplied (rfq_decode_args.h_chunk_off): the read counts of all chunks are fetched in
 // parallel (one workgroup, 256 chunks per round, running read base by a block scan) - no dependent load per chunk.  k_dec_parse
 // verifies every extent exactly as it does behind the speculative walk.
-__global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const uint64_t* __restrict__ off, uint32_t nch, DChunk* __restrict__ out, DecStatus* st) {
+__global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const uint64_t* __restrict__ off, uint32_t nch_, DChunk* __restrict__ out, DecStatus* st) {
+    // (nch_ == ~0: the table was made on the device - k_dec_gw_* below - and so was its length; a table that failed there leaves pad set)
+    const uint32_t nch = nch_ == 0xFFFFFFFFu ? st->n_chunks : nch_;
+    if (nch_ == 0xFFFFFFFFu && (st->pad || st->overflow)) return;
     __shared__ uint32_t s_bad, s_maxr;
     if (threadIdx.x == 0) { s_bad = 0; s_maxr = 0; }
     __syncthreads();
@@ -169,6 +172,111 @@ __global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const u
         st->n_chunks = nch; st->max_reads = s_maxr; st->total_reads = rb; st->consumed = off[nch]; st->overflow = 0; st->pad = bad;
         st->last_flags = (!bad && nch) ? ld_u16(img + off[nch - 1] + 8) : 0u;
     }
+}
+// ---- the chunk starts of an image that comes without an index (a .rfq file has none: RfqChunk::read walks it, src/rfqchunk.cpp:161-228).
+// The one-wave chain above is one dependent memory round trip per chunk - 2.0 ms for the 3360 chunks of configs[2].  Guess-and-verify instead:
+// the image is cut into up to GW_SEGS segments of ~16 chunks (sized from the first chunk); k_dec_gw_find tests every byte offset of a
+// window at each segment's start for "a chunk header whose mSize chain leads to another plausible header" and keeps the lowest; k_dec_gw_walk
+// walks each segment from its candidate to the next segment's (the same one-read-per-chunk chain, a wave per segment, ~16 hops); k_dec_gw_stitch
+// checks that every walk lands exactly on the next candidate and concatenates the lists into a chunk index, which k_dec_table / k_dec_parse
+// then treat like a caller's: every extent is parsed and verified in full.  Anything that does not add up (a foreign writer, chunk sizes that
+// differ wildly, a corrupt image) sets pad, and the host falls back to the chain.
+#define GW_SEGS 1024u
+#define GW_LCAP 256u              // chunk starts a segment's walk may record
+struct GwGeo { uint64_t first, seglen, win; uint32_t nseg; };
+__device__ __forceinline__ long long gw_total(uint32_t ms, uint32_t s, uint32_t fl, uint32_t hf) {      // true chunk size from mSize (see k_dec_spec_walk)
+    const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s; long long total = (long long)ms;
+    if (hf & H_LANE) total += (fl & C_LANE_SAME) ? 1 : (long long)h;
+    if (!(hf & H_TILE)) total -= (fl & C_TILE_SAME) ? 2 : 2ll * h;
+    if (!(hf & H_NAME2)) total -= (fl & C_NAME2_LEN_SAME) ? 1 : (long long)s;
+    return total;
+}
+// a plausible chunk header at byte o?  (lite: the fields alone; else also that its size leads to the image's end or another plausible header)
+__device__ __forceinline__ bool gw_plausible(const uint8_t* __restrict__ img, uint64_t n, uint64_t o, uint32_t hf, bool lite, uint64_t* next) {
+    if (n - o < 18) return false;
+    const LdsU16 hd = *(const LdsU16*)(img + o);
+    const uint32_t ms = hd.a, s = hd.b, fl = hd.c & 0xFFFFu, seqsz = (hd.c >> 16) | (hd.d << 16), qualsz = (hd.d >> 16) | ((uint32_t)ld_u16(img + o + 16) << 16);
+    if (s == 0 || s > 0x1000000u || fl >= 0x1000u) return false;
+    const long long total = gw_total(ms, s, fl, hf);
+    if (total < 18 || (unsigned long long)total > n - o || (unsigned long long)seqsz + qualsz + 18ull > (unsigned long long)total) return false;
+    if (next) *next = o + (uint64_t)total;
+    if (lite) return true;
+    const uint64_t o2 = o + (uint64_t)total;
+    if (n - o2 < 18) return true;                                           // the image ends here (or with a tail too short to be a chunk)
+    if (ld_u32(img + o2 + 4) == 0) return true;                             // mReads == 0: a clean end
+    return gw_plausible(img, n, o2, hf, true, nullptr);
+}
+__device__ __forceinline__ GwGeo gw_geo(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, uint32_t hf, uint32_t max_seg) {
+    GwGeo g; g.first = 0; g.seglen = n - start; g.win = 0; g.nseg = 1;
+    uint64_t nx = 0;
+    if (start < n && gw_plausible(img, n, start, hf, true, &nx)) {
+        g.first = nx - start;
+        const uint64_t want = 16ull * g.first; uint64_t ns = (n - start) / (want ? want : 1ull);
+        if (ns < 1) ns = 1; if (ns > GW_SEGS) ns = GW_SEGS; if (ns > max_seg) ns = max_seg;     // (max_seg: what the host sized its grids for)
+        g.nseg = (uint32_t)ns; g.seglen = (n - start + ns - 1) / ns; g.win = 2ull * g.first < g.seglen ? 2ull * g.first : g.seglen;
+    }
+    return g;
+}
+// cand[k] = the lowest plausible chunk start in the window at the head of segment k (k >= 1; cand[0] = start); ~0 when there is none
+__global__ void k_dec_gw_find(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, unsigned long long* __restrict__ cand, uint32_t max_seg) {
+    const uint32_t hf = D->flags; const GwGeo g = gw_geo(img, n, start, hf, max_seg);
+    const uint32_t k = blockIdx.y + 1u; if (k >= g.nseg) return;
+    const uint64_t g0 = start + (uint64_t)k * g.seglen;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.win; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t o = g0 + i;
+        if (o + 18 > n) continue;
+        // first the two bytes that are almost never right by chance - read count < 2^24, flags < 0x1000: one unaligned dword, 1 offset in 4096 passes
+        if (((const LdsU4*)(img + o + 6))->a & 0xF000FF00u) continue;
+        if (gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k], (unsigned long long)o);
+    }
+}
+// a wave per segment: the chain from its candidate up to the next segment that has one; list[k][..] = the chunk starts met, land[k] = where it stopped
+__global__ void k_dec_gw_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, const unsigned long long* __restrict__ cand,
+                              unsigned long long* __restrict__ list, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ land, uint32_t* __restrict__ bad, uint32_t max_seg) {
+    const uint32_t hf = D->flags; const GwGeo g = gw_geo(img, n, start, hf, max_seg);
+    const uint32_t k = blockIdx.x; if (k >= g.nseg) return;
+    uint64_t o = k == 0 ? start : cand[k];
+    if (o == ~0ull) { if (lane_id() == 0) { cnt[k] = 0; land[k] = ~0ull; } return; }
+    uint64_t stop = n; for (uint32_t m = k + 1; m < g.nseg; m++) if (cand[m] != ~0ull) { stop = cand[m]; break; }
+    uint32_t c = 0, b = 0, ended = 0;
+    while (o < stop) {
+        uint64_t nx = 0;
+        if (n - o < 18 || ld_u32(img + o + 4) == 0) { ended = 1; break; }   // end of the image
+        if (!gw_plausible(img, n, o, hf, true, &nx)) { b = 1; break; }
+        if (c < GW_LCAP) { if (lane_id() == 0) list[(size_t)k * GW_LCAP + c] = o; } else { b = 1; break; }
+        c++; o = nx;
+    }
+    if (o >= n || n - o < 18) ended = 1;
+    if (lane_id() == 0) { cnt[k] = c | (ended << 31); land[k] = o; if (b) atomicOr(bad, 1u); }     // (bit 31: the chain ended in this segment)
+}
+// every walk must land on the next candidate; the lists, concatenated, are the chunk index (off[0 .. n_chunks], the last entry = where the chain ended)
+__global__ void k_dec_gw_stitch(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, const unsigned long long* __restrict__ cand,
+                                const unsigned long long* __restrict__ list, const uint32_t* __restrict__ cnt, const unsigned long long* __restrict__ land, const uint32_t* __restrict__ bad,
+                                uint64_t* __restrict__ off, uint32_t cap, DecStatus* st, uint32_t max_seg) {
+    __shared__ uint32_t s_base[GW_SEGS + 1], s_cnt[GW_SEGS]; __shared__ unsigned long long s_cand[GW_SEGS], s_land[GW_SEGS]; __shared__ uint32_t s_fail; __shared__ unsigned long long s_end;
+    const uint32_t hf = D->flags; const GwGeo g = gw_geo(img, n, start, hf, max_seg);
+    for (uint32_t k = threadIdx.x; k < g.nseg; k += blockDim.x) { s_cand[k] = k == 0 ? (unsigned long long)start : cand[k]; s_cnt[k] = cnt[k]; s_land[k] = land[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t fail = *bad, tot = 0; unsigned long long expect = start; bool open = true;      // expect: where the next walk must begin
+        for (uint32_t k = 0; k < g.nseg; k++) {
+            s_base[k] = tot;
+            const unsigned long long ck = s_cand[k];
+            if (ck == ~0ull) continue;
+            if (!open) { fail = 1; break; }                                  // a candidate behind the end of the chain
+            if (ck != expect) { fail = 1; break; }
+            tot += s_cnt[k] & 0x7FFFFFFFu; expect = s_land[k];
+            if (s_cnt[k] >> 31) open = false;                                // the chain has ended
+        }
+        s_base[g.nseg] = tot; s_fail = fail; s_end = expect;
+        if (g.first == 0 && start < n && n - start >= 18 && ld_u32(img + start + 4) != 0) s_fail = 1;      // (the first header itself is not plausible: let the chain decide)
+    }
+    __syncthreads();
+    const uint32_t tot = s_base[g.nseg];
+    if (s_fail || tot > cap) { if (threadIdx.x == 0) { st->pad = s_fail ? 1u : 0u; st->overflow = (!s_fail && tot > cap) ? 1u : 0u; st->n_chunks = tot; } return; }
+    // (a wave per segment: its list is a handful of entries)
+    for (uint32_t k = threadIdx.x >> 6; k < g.nseg; k += blockDim.x >> 6) { const uint32_t c = s_cnt[k] & 0x7FFFFFFFu; if (s_cand[k] == ~0ull) continue; for (uint32_t i = threadIdx.x & 63u; i < c; i += 64u) off[s_base[k] + i] = list[(size_t)k * GW_LCAP + i]; }
+    if (threadIdx.x == 0) { off[tot] = s_end; st->n_chunks = tot; st->pad = 0; st->overflow = 0; }
 }
 // a range of chunks is decoded as a batch of its own: its reads count from 0
 __global__ void k_dec_rebase(DChunk* __restrict__ CH, uint32_t n, uint32_t base) {
@@ -1622,7 +1730,7 @@ __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ i
         else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, n2a, n2e, img_bytes, true), l);
                if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, sta, ste, img_bytes, true), l); }
         // qualities start as the major value (src/rfqcodec.cpp:1089), the N bits as none
-        if (bycol) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
+        if (bycol && !(abl & 1)) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         for (uint32_t i = tid; i < ((s1 - s0 + 31u) >> 5) + 1u; i += blockDim.x) t_nb[i] = 0;
         // ---- the tile's list entries, requested now and scattered after the barrier (k_dec_emit2's scheme: wave w takes the lists w, w + 4, ...)
         uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const uint32_t* ls_p = plist;
@@ -1709,8 +1817,9 @@ __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ i
                 auto group = [&](uint32_t k0) {                               // output positions [k0, k0 + 16) of both lines (k0 + 16 <= len)
                     uint32_t qw[4]; const uint32_t pa = rc ? len - k0 - 16u : k0;
                     lds_get16(q_t, qp_ + pa, qw);
-                    uint32_t cw, nw;
-                    if (pa + 16u <= xa) fetch(A + pa, cw, nw);
+                    uint32_t cw = 0, nw = 0;
+                    if (abl & 64) {}                                            // (ablation: no base fetch)
+                    else if (pa + 16u <= xa) fetch(A + pa, cw, nw);
                     else if (pa >= xa) fetch(Bs + (pa - xa), cw, nw);
                     else { uint32_t c2, n2_; const uint32_t t1 = xa - pa; fetch(A + pa, cw, nw); fetch(Bs, c2, n2_); cw = (cw & ((1u << (2u * t1)) - 1u)) | (c2 << (2u * t1)); nw = (nw & ((1u << t1) - 1u)) | ((n2_ << t1) & 0xFFFFu); }
                     if (rc) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3;
@@ -1724,6 +1833,7 @@ __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ i
                         if (implied_n) mk |= eq_bytes_full(qw[i], nq4);
                         sw[i] = (x & ~mk) | (0x4E4E4E4Eu & mk);
                     }
+                    if (abl & 32) { if (qw[0] == 0x12345678u && sw[1] == 0x9ABCDEFu) rec[0] = 0; return; }      // (ablation: no stores)
                     GU16d v; v.a = qw[0]; v.b = qw[1]; v.c = qw[2]; v.d = qw[3]; *(GU16d*)(rec + oq + k0) = v;
                     v.a = sw[0]; v.b = sw[1]; v.c = sw[2]; v.d = sw[3]; *(GU16d*)(rec + oseq + k0) = v;
                 };

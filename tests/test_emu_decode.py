@@ -77,6 +77,26 @@ def test_emitters_are_the_ones_expected(codec):
     assert codec.decode_bytes(rfq) == fq
 
 
+def test_chunk_starts_without_an_index(codec, monkeypatch):
+    """A .rfq has no chunk index: the decoder guesses segment starts, walks the segments in parallel and verifies every extent (k_dec_gw_*);
+    RFQ_WALK=chain is the one-wave chain it falls back to.  Small segments (RFQ_GW_SHIFT) so that a small image has several."""
+    fq1, fq2 = O.gen(O.NOVA_PE150, 3000, seed=51)
+    rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 9000)
+    assert len(O.chunk_table(rfq)) - 1 > 80
+    monkeypatch.setenv("RFQ_GW_SHIFT", "12")
+    assert codec.decode_bytes(rfq, split_pe=True) == (fq1, fq2)
+    monkeypatch.setenv("RFQ_WALK", "chain")
+    assert codec.decode_bytes(rfq, split_pe=True) == (fq1, fq2)
+    monkeypatch.delenv("RFQ_WALK")
+    # chunks of very different sizes (a guessed start that is not one, segments without any start): whatever happens, the text is right
+    big, _ = O.gen(O.SE_VAR, 4000, seed=52)
+    for cb in (3000, 150000):
+        assert codec.decode_bytes(O.encode_file(big, b"", O.SE, cb)) == big
+    trunc = rfq[: len(rfq) - 1000]
+    with pytest.raises(Exception):
+        codec.decode_bytes(trunc, split_pe=True)
+
+
 def test_encode_then_decode_on_device_round_trip(codec):
     fq1, fq2 = O.gen(O.NOVA_PE150, 250, seed=33)
     rfq = E.encode(codec, fq1, fq2, O.PE_TWO_FILES, 15000)
