@@ -194,8 +194,11 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         if (!emit3) ctx->timer.stages[ctx->timer.used].name = "emit2";
         if (emit3) {
             const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
-            hipLaunchKernelGGL(k_dec_emit3, dim3(b3, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(),
-                               (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k, (tune >> 12) & 255);
+#define RFQ_EMIT3_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
+                       (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k, (tune >> 12) & 255
+            if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_emit3<false>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+            else hipLaunchKernelGGL(k_dec_emit3<true>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+#undef RFQ_EMIT3_ARGS
         }
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + ET_READS - 1) / ET_READS, (fused ? 4u : 4u) * ctx->n_cu);   // (39 KB of LDS: four workgroups per CU)
         const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots

@@ -1653,7 +1653,7 @@ __device__ __forceinline__ uint32_t e3_rev1x16(uint32_t v) {
     v = ((v >> 8) & 0xFFu) | ((v & 0xFFu) << 8); v = ((v >> 4) & 0x0F0Fu) | ((v & 0x0F0Fu) << 4);
     v = ((v >> 2) & 0x3333u) | ((v & 0x3333u) << 2); return ((v >> 1) & 0x5555u) | ((v & 0x5555u) << 1);
 }
-__global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
                            uint32_t ncell, uint32_t nstr, uint32_t kshift, int abl) {
@@ -1665,7 +1665,8 @@ __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ i
     __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2];
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
     const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
-    const bool implied_n = !(hf & H_N_POS); const uint32_t nq4 = (D->n_base_qual & 0xFFu) * 0x01010101u, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
+    constexpr bool implied_n = IMPL;                                        // (the host instantiates by the header: N positions implied by the quality, or listed)
+    const uint32_t nq4 = (D->n_base_qual & 0xFFu) * 0x01010101u, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
     const int l = lane_id(), w = (int)uni32((uint32_t)wave_id()); const uint32_t tid = threadIdx.x;
     const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
     const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;
@@ -1730,7 +1731,7 @@ __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ i
         else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, n2a, n2e, img_bytes, true), l);
                if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, sta, ste, img_bytes, true), l); }
         // qualities start as the major value (src/rfqcodec.cpp:1089), the N bits as none
-        if (bycol && !(abl & 1)) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
+        if (bycol) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         for (uint32_t i = tid; i < ((s1 - s0 + 31u) >> 5) + 1u; i += blockDim.x) t_nb[i] = 0;
         // ---- the tile's list entries, requested now and scattered after the barrier (k_dec_emit2's scheme: wave w takes the lists w, w + 4, ...)
         uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const uint32_t* ls_p = plist;
@@ -1817,23 +1818,23 @@ __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ i
                 auto group = [&](uint32_t k0) {                               // output positions [k0, k0 + 16) of both lines (k0 + 16 <= len)
                     uint32_t qw[4]; const uint32_t pa = rc ? len - k0 - 16u : k0;
                     lds_get16(q_t, qp_ + pa, qw);
-                    uint32_t cw = 0, nw = 0;
-                    if (abl & 64) {}                                            // (ablation: no base fetch)
-                    else if (pa + 16u <= xa) fetch(A + pa, cw, nw);
+                    uint32_t cw, nw;
+                    if (pa + 16u <= xa) fetch(A + pa, cw, nw);
                     else if (pa >= xa) fetch(Bs + (pa - xa), cw, nw);
                     else { uint32_t c2, n2_; const uint32_t t1 = xa - pa; fetch(A + pa, cw, nw); fetch(Bs, c2, n2_); cw = (cw & ((1u << (2u * t1)) - 1u)) | (c2 << (2u * t1)); nw = (nw & ((1u << t1) - 1u)) | ((n2_ << t1) & 0xFFFFu); }
                     if (rc) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3;
-                              cw = ~e3_rev2x16(cw); nw = e3_rev1x16(nw); }
+                              cw = ~e3_rev2x16(cw); if (nw) nw = e3_rev1x16(nw); }
                     uint32_t sw[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t b = (cw >> (8 * i)) & 0xFFu, y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u;
-                        uint32_t x = __builtin_amdgcn_perm(0u, 0x43544147u, idx);
-                        uint32_t mk = ((((nw >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
-                        if (implied_n) mk |= eq_bytes_full(qw[i], nq4);
-                        sw[i] = (x & ~mk) | (0x4E4E4E4Eu & mk);
+                    for (int i = 0; i < 4; i++) { const uint32_t b = (cw >> (8 * i)) & 0xFFu, y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u; sw[i] = __builtin_amdgcn_perm(0u, 0x43544147u, idx); }
+                    if (nw) {                                                   // (rare: an N among the 16)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const uint32_t mk = ((((nw >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu; sw[i] = (sw[i] & ~mk) | (0x4E4E4E4Eu & mk); }
                     }
-                    if (abl & 32) { if (qw[0] == 0x12345678u && sw[1] == 0x9ABCDEFu) rec[0] = 0; return; }      // (ablation: no stores)
+                    if (implied_n) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const uint32_t mk = eq_bytes_full(qw[i], nq4); sw[i] = (sw[i] & ~mk) | (0x4E4E4E4Eu & mk); }
+                    }
                     GU16d v; v.a = qw[0]; v.b = qw[1]; v.c = qw[2]; v.d = qw[3]; *(GU16d*)(rec + oq + k0) = v;
                     v.a = sw[0]; v.b = sw[1]; v.c = sw[2]; v.d = sw[3]; *(GU16d*)(rec + oseq + k0) = v;
                 };

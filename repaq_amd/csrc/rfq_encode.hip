@@ -376,8 +376,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // that always fits - else the byte-wise k_gather (+ k_packbytes).  RFQ_GATHER=old forces the latter (tests run both); RFQ_GATHER=pipe /
     // RFQ_G2_KSHIFT are profiling aids (two half-size text buffers; smaller tiles).
     const char* genv = getenv("RFQ_GATHER");
-    const bool pipe = genv && !strcmp(genv, "pipe");
-    const uint32_t g2cap = pipe ? G2_CAP / 2 : G2_CAP;
+    const bool pipe2 = genv && !strcmp(genv, "pipe2"), pipe = pipe2 || (genv && !strcmp(genv, "pipe"));   // (pipe2: two full-size buffers)
+    const uint32_t g2cap = (pipe && !pipe2) ? G2_CAP / 2 : G2_CAP;
     uint32_t kshift = 6; if (getenv("RFQ_G2_KSHIFT")) kshift = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_G2_KSHIFT"))));
     while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > g2cap) kshift--;
     const bool fast = kshift >= 1 && !(genv && !strcmp(genv, "old"));
@@ -444,7 +444,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, (pipe ? 5u : 6u) * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
 #define RFQ_G2_ARGS T, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint32_t*)C.il, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), \
                     B[B_RFLAG].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, dst, (tune >> 16) & 15      /* (tune bits 16-19: ablation switches of k_gather2, results invalid) */
-        if (pipe) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
+        if (pipe2) hipLaunchKernelGGL((k_gather2<true, G2_CAP>), dim3(grid_x_for(n_chunks, (max_reads + K - 1) / K, 3u * ctx->n_cu), n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
+        else if (pipe) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
         else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
 #undef RFQ_G2_ARGS
         // the quality streams' scratch plan needs nothing else: the position coder can start as soon as the host has sized its arena

@@ -1431,12 +1431,12 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
 // PIPE: two text buffers of half the size; the next tile's LDS-DMA is issued right behind the barrier that hands over this tile's text and flies
 // under this tile's compose - one barrier per tile.  (Measured on configs[2], single buffer, K = 64: of the kernel's 3.4 ms, 1.8 ms are the bare
 // stage-and-wait loop - 8 GB at 4.4 TB/s with a third of the resident workgroups in their staging phase at any time.)
-template <bool PIPE> __global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const uint64_t* __restrict__ qbase,
+template <bool PIPE, uint32_t CAPB = (PIPE ? G2_CAP / 2 : G2_CAP)> __global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift, DevStatus* st, int abl) {
-    __shared__ uint4 s_text4[G2_CAP / 16 + 16];
+    __shared__ uint4 s_text4[(PIPE ? 2 : 1) * (CAPB / 16 + 8)];           // (CAPB: staged text per buffer)
     __shared__ uint32_t sh[PIPE ? 2 : 1][G2_CNT]; __shared__ int sh_last[PIPE ? 2 : 1][G2_CNT]; __shared__ uint8_t s_slot[256];   // (two counter sets when tiles overlap)
-    constexpr uint32_t HALF4 = G2_CAP / 32 + 8;                             // uint4 per buffer when there are two (each with its own slack)
+    constexpr uint32_t HALF4 = CAPB / 16 + 8;                               // uint4 per buffer (each with its own slack)
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < (PIPE ? 2u : 1u) * G2_CNT; i += blockDim.x) { (&sh[0][0])[i] = 0; (&sh_last[0][0])[i] = -1; }
     const uint32_t nn_s = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, nslot = nn_s + 1u;
