@@ -10,7 +10,9 @@
  *   - plain pointers + sizes, no C++/torch types; every d_* pointer is DEVICE memory (hipMalloc or a torch CUDA
  *     tensor's data_ptr()); h_* pointers are host memory.  Input pointers (FASTQ text, .rfq image) may have any alignment and
  *     any length: a stream of 4 GiB or more is worked through in slices inside the call, the result is the one image / the
- *     one text.  Caller-provided OUTPUT buffers must be 16-byte aligned.
+ *     one text.  A FASTQ pointer that is not 16-byte aligned is rounded down inside the call: the (up to 15) bytes in front of it are READ
+ *     (never interpreted), so they must belong to the same allocation - true of any pointer into a hipMalloc'ed buffer or a torch tensor.
+ *     Caller-provided OUTPUT buffers must be 16-byte aligned.
  *   - return 0 (RFQ_OK) or a negative RFQ_E_* code; rfq_last_error(ctx) then holds the reference's error_exit text
  *     (src/util.h:246-249) where the reference has one for the condition.
  *   - one rfq_ctx per (host thread, GPU); distinct contexts may be used concurrently.  A context owns its workspace

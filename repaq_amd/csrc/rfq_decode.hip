@@ -63,7 +63,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             HIPCHK(ctx, B[DB_NENT].ensure(nst * 4 + 16)); HIPCHK(ctx, B[DB_LOFF].ensure(nst * 8 + 16));
             // the arena of the position lists: a position belongs to at most one stream, the coded ones are a few percent of the bases; if a
             // file needs more than the arena holds, k_dec_pos_list leaves it alone and the pass is repeated below with the right size
-            HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 2 + 1024) * 4));
+            // (2 bytes per base is far more than most files need; when that much is not to be had, start small: the pass is repeated with the exact size)
+            if (B[DB_PLIST].ensure((size_t)(g.bases / 2 + 1024) * 4) != hipSuccess) { (void)hipGetLastError(); HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 32 + 1024) * 4)); }
             HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
 #define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
             if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);

@@ -129,7 +129,12 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
     uint32_t chunks = 0; uint64_t reads = 0, bases = 0; int ended = 0;
     for (;;) {
         const size_t r1 = a->n1 - pos1, r2 = two ? a->n2 - pos2 : 0;
-        const size_t t1 = std::min(r1, slice), t2 = std::min(r2, slice);
+        size_t t1 = std::min(r1, slice), t2 = std::min(r2, slice);
+        // Two files of different length: once one file's slice holds all that is left of it, no pair lies beyond it - the other file's slice grows
+        // to what is left of ITS file (as far as one call can address), and the call ends the input there like the reference does (it truncates
+        // to the shorter file).  (With the other slice left at its size the slice ran as a non-final one, the short file's last records - less
+        // than a chunk - were never flushed, and the call failed with "no whole chunk".)
+        if (two && (t1 == r1) != (t2 == r2)) { const size_t grow = slice_env ? 64 * slice_env : lim; if (t1 == r1) t2 = std::min(r2, grow); else t1 = std::min(r1, grow); }
         const bool last = t1 == r1 && t2 == r2;
         rfq_encode_args s = *a;
         s.d_fq1 = a->d_fq1 + pos1; s.n1 = t1; s.file_off1 = a->file_off1 + pos1;

@@ -35,6 +35,16 @@ def main(lib):
         if d2:
             c.dev_free(d2)
         n += 1
+    # mates of different length (the reference truncates to the shorter file): the short file ends inside a slice while the other goes on
+    fq1, fq2 = O.gen(O.NOVA_PE150, 3000, seed=9)
+    short = b"\n".join(fq2.split(b"\n")[: 4 * 300]) + b"\n"
+    for a, b in ((fq1, short), (short.replace(b"/2", b"/1") if b"/2" in short else fq1[: len(short)].rsplit(b"\n@", 1)[0] + b"\n", fq2)):
+        try:
+            want = O.encode_file(a, b, O.PE_TWO_FILES, 20000)
+        except Exception:
+            continue
+        assert E.encode(c, a, b, O.PE_TWO_FILES, 20000) == want, "sliced encode of mates of different length differs from the oracle"
+        n += 1
     c.close()
     print("SLICES_OK", n)
 

@@ -164,4 +164,4 @@ def test_sliced_calls_equal_one_shot():
     import sys
     env = dict(os.environ, RFQ_SLICE_BYTES="150000", RFQ_SLICE_BASES="60000", PYTHONPATH=os.pathsep.join([E.ROOT, os.path.join(E.ROOT, "tests"), os.path.join(E.ROOT, "tests", "golden")]))
     r = subprocess.run([sys.executable, os.path.join(E.ROOT, "tests", "_slice_probe.py"), E.build_emu()], env=env, capture_output=True, text=True)
-    assert r.returncode == 0 and "SLICES_OK 5" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "SLICES_OK 7" in r.stdout, r.stdout + r.stderr
