@@ -96,6 +96,38 @@ def cpu_baseline(a1, a2, paired, units, sample_units):
             "encode_MBps": round(mb / (t1 - t0), 1), "decode_MBps": round(mb / (t2 - t1), 1), "host_cpus": os.cpu_count()}
 
 
+def cpu_baseline_all_cores(a1, a2, paired, units, shard_units, max_procs=32):
+    """The same reference binary on min(32, host cores) processes at once, each on its own shard of the workload (`shard_units` reads / pairs,
+    consecutive shards from the start of the input): what the host's cores deliver together - chunks are independent, so a chunk-parallel CPU
+    run would look like this.  A stated baseline, never the target."""
+    import _oracle as O
+    if not O.have_ref():
+        return None
+    procs = max(1, min(max_procs, os.cpu_count() or 1, units // max(1, shard_units)))
+    cuts1 = [offset_of_record(a1, i * shard_units) for i in range(procs + 1)]
+    cuts2 = [offset_of_record(a2, i * shard_units) for i in range(procs + 1)] if paired else None
+    mb = (cuts1[-1] + (cuts2[-1] if paired else 0)) / 1e6
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        enc, dec = [], []
+        for i in range(procs):
+            p1, p2, o, q1, q2 = (os.path.join(d, "%s%d" % (n, i)) for n in ("r1_", "r2_", "o_", "b1_", "b2_"))
+            a1[cuts1[i]:cuts1[i + 1]].tofile(p1)
+            if paired:
+                a2[cuts2[i]:cuts2[i + 1]].tofile(p2)
+            enc.append([O.REF_BIN, "-c", "-i", p1, "-o", o] + (["-I", p2] if paired else []))
+            dec.append([O.REF_BIN, "-d", "-i", o, "-o", q1] + (["-O", q2] if paired else []))
+        t0 = time.perf_counter()
+        for p in [subprocess.Popen(c) for c in enc]:
+            assert p.wait() == 0
+        t1 = time.perf_counter()
+        for p in [subprocess.Popen(c) for c in dec]:
+            assert p.wait() == 0
+        t2 = time.perf_counter()
+    return {"value": round(mb * 2 / (t2 - t0), 1), "unit": "MB/s", "cores": procs, "kind": "reference",
+            "sample": "%d concurrent repaq processes, each -c then -d on its own %d %s of the workload (%.0f MB of FASTQ in all), files in /tmp" % (procs, shard_units, "pairs" if paired else "reads", mb),
+            "encode_MBps": round(mb / (t1 - t0), 1), "decode_MBps": round(mb / (t2 - t1), 1), "host_cpus": os.cpu_count()}
+
+
 def golden_md5(key, units, seed, k):
     """The reference's .rfq md5 for this exact input, if a golden was made for it (tests/golden/*.json), else None."""
     try:
@@ -225,8 +257,9 @@ def roofline_of(w, stage, enc_ms, dec_ms, traffic_key):
     dom = max(stage, key=stage.get)
     alg = float(w.n + w.rfq_len)
     traffic = None
-    pj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(pj):
+    pjs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+    pj = os.path.join(ROOT, "profiles", pjs[-1]) if pjs else ""
+    if pj and os.path.exists(pj):
         pmc = json.load(open(pj)).get(traffic_key)
         if pmc and pmc.get("units") == w.units:
             ks = [k for k in STAGE_KERNELS.get(dom, []) if k in pmc["kernels"]]
@@ -236,7 +269,7 @@ def roofline_of(w, stage, enc_ms, dec_ms, traffic_key):
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(stage[dom], 4),
             "note": "achieved = one direction's algorithmic bytes (B_fastq + B_rfq) / the dominant kernel's HIP-event time: an upper bound for that kernel; "
                     "whole_*_frac divide the same bytes by the whole direction's device time; traffic = that kernel's HBM bytes per launch from the committed "
-                    "rocprofv3 PMC passes of this workload (profiles/r02_pmc_traffic.json), null if none was collected at this size",
+                    "rocprofv3 PMC passes of this workload (profiles/*_pmc_traffic.json, the newest), null if none was collected at this size",
             "whole_encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if enc_ms else None,
             "whole_decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}
 
@@ -276,6 +309,9 @@ def run_multi(args, rank, world, local):
     dev = torch.device("cuda", local)
     codec = RfqCodec(device=local)
     seg_pairs, per = args.seg_pairs, args.segs_per_gpu
+    if args.strong:                                   # ONE fixed input (--segs-per-gpu segments in all) split over the ranks
+        assert per % world == 0, "--strong: --segs-per-gpu (%d: the segments of the whole input) must be a multiple of the number of GPUs" % per
+        per = per // world
     cb = max(100, args.chunk_kb) * 1000
     # ---- this rank's share (+ the head of the next one), generated straight into one buffer per stream
     parts1, parts2 = [], []
@@ -295,7 +331,10 @@ def run_multi(args, rank, world, local):
     dist.all_gather_object(lens, (share1, share2))
     off1, off2 = sum(x[0] for x in lens[:rank]), sum(x[1] for x in lens[:rank])
     # ---- plan chain, header
-    cut1, cut2, n1, n2 = D.plan_shares(codec, rank, world, t1.data_ptr(), share1, avail1, t2.data_ptr(), share2, avail2, PE_TWO_FILES, cb)
+    plan = {}
+    torch.cuda.synchronize(); D.barrier()
+    cut1, cut2, n1, n2 = D.plan_shares(codec, rank, world, t1.data_ptr(), share1, avail1, t2.data_ptr(), share2, avail2, PE_TWO_FILES, cb, stats=plan)
+    plan_ms = D.reduce_max_sum(plan.get("plan_ms", 0.0) / 1e3, 0)[0] * 1e3      # (untimed set-up, like opening the files: reported, max over ranks)
     last = rank == world - 1
     o1 = torch.empty(n1 + 64, dtype=torch.uint8, device=dev); o2 = torch.empty(n2 + 64, dtype=torch.uint8, device=dev)
     state = {"stage": {}, "enc_s": 0.0, "dec_s": 0.0}
@@ -379,11 +418,12 @@ def run_multi(args, rank, world, local):
         alg = float(n1 + n2 + r.rfq_len); dom = max(stage, key=stage.get) if stage else None
         out = {"metric": "raw FASTQ MB/s encode+decode" if passes == 2 else "raw FASTQ MB/s encode",
                "value": round(total * passes * K / dt / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-               "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": "configs[3] shape: ONE synthetic NovaSeq PE150 input of %d x (2 x %.2f GB) = 2 x %.1f GB FASTQ (%d segments: fqgen profile 1, %d pairs, seed %d + s), -k %d, "
-                                      "chunk-parallel over %d GPUs (each encodes + decodes the byte range resident in its HBM; plan chain + header over the host, no RCCL)"
+                                      "chunk-parallel over %d GPUs (each encodes + decodes the byte range resident in its HBM; plan + header over the host, no RCCL)"
                                       % (world, share1 / 1e9, total / 2e9, per * world, seg_pairs, SEG_SEED0, args.chunk_kb, world),
                           "rfq_over_fastq": round(rfq_total / total, 4), "parity": parity,
+                          "plan": plan.get("plan"), "plan_ms": round(plan_ms, 2), "strong": bool(args.strong),
                           "rank0": {"chunks": r.n_chunks, "encode_MBps": round((n1 + n2) * K / state["enc_s"] / 1e6, 1), "decode_MBps": round((n1 + n2) * K / state["dec_s"] / 1e6, 1) if state["dec_s"] else None,
                                     "stage_ms": {k: round(v, 3) for k, v in stage.items()}}},
                "roofline": None if not dom else {"bound": "hbm", "kernel": "+".join(STAGE_KERNELS.get(dom, [dom])), "stage": dom, "achieved": round(alg / (stage[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
@@ -411,6 +451,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (kernel ablation runs with RFQ_TUNE set)")
     ap.add_argument("--seg-pairs", type=int, default=SEG_PAIRS, help="N>1: pairs per segment of the logical input (test aid: smaller inputs)")
     ap.add_argument("--segs-per-gpu", type=int, default=SEGS_PER_GPU, help="N>1: segments per GPU share (configs[3]: 8 x 2.8 M pairs = 2 x 8 GB per GPU)")
+    ap.add_argument("--strong", action="store_true", help="N>1: strong scaling - the input is --segs-per-gpu segments IN ALL (default 8 = 2 x 8 GB), split over the N GPUs")
     args = ap.parse_args()
 
     import torch
@@ -451,6 +492,9 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w.a1, w.a2, w.paired, w.units, args.cpu_sample)
+        allc = cpu_baseline_all_cores(w.a1, w.a2, w.paired, w.units, max(1, args.cpu_sample // 8))
+        if allc:
+            out["cpu_baseline_all_cores"] = allc
     if not args.no_secondary and args.workload == "cfg2" and not args.units:
         sec = {}
         del w

@@ -83,7 +83,9 @@ typedef struct {
                                              every record of it (like final) without treating its end as the end of the
                                              input (an unterminated last line is not a line; the 1 MiB reader-block rule
                                              still sees the file continue).  For workers of a multi-GPU host queue.     */
-    int32_t  reserved2;
+    uint32_t carry_bases;                 /* plan pass of a share of a larger input (rfq_scan_batch): bases the chunk that is open at the start of
+                                             this text has already taken from the text in front of it (< chunk_bases); the first chunk
+                                             closes at chunk_bases - carry_bases.  0 for an encode (a range starts on a chunk boundary).   */
 } rfq_encode_args;
 
 typedef struct {
@@ -118,7 +120,8 @@ typedef struct {
     const uint64_t* h_end1;               /* host arrays [n_chunks], valid until the next call on the context           */
     const uint64_t* h_end2;
     int32_t  input_ended;                 /* as in rfq_encode_result                                                   */
-    int32_t  reserved;
+    uint32_t unit_bases;                  /* bases of every cut unit (a read, or a pair) when they are all the same, else 0: with equal units the
+                                             chunk cuts of a share follow from the number of units in front of it (repaq_amd/dist.py)      */
 } rfq_scan_result;
 int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_scan_result* res);
 

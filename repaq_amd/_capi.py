@@ -28,7 +28,7 @@ class EncodeArgs(C.Structure):
     _fields_ = [("d_fq1", C.c_void_p), ("n1", C.c_size_t), ("d_fq2", C.c_void_p), ("n2", C.c_size_t), ("paired", C.c_int32),
                 ("chunk_bases", C.c_uint32), ("final", C.c_int32), ("emit_header", C.c_int32), ("file_off1", C.c_uint64),
                 ("file_off2", C.c_uint64), ("nolb_from1", C.c_uint64), ("nolb_from2", C.c_uint64), ("d_out", C.c_void_p), ("out_cap", C.c_size_t),
-                ("flush_all", C.c_int32), ("reserved2", C.c_int32)]
+                ("flush_all", C.c_int32), ("carry_bases", C.c_uint32)]
 
 
 class EncodeResult(C.Structure):
@@ -39,7 +39,7 @@ class EncodeResult(C.Structure):
 
 class ScanResult(C.Structure):
     _fields_ = [("n_chunks", C.c_uint32), ("n_reads", C.c_uint64), ("consumed1", C.c_size_t), ("consumed2", C.c_size_t),
-                ("h_end1", C.POINTER(C.c_uint64)), ("h_end2", C.POINTER(C.c_uint64)), ("input_ended", C.c_int32), ("reserved", C.c_int32)]
+                ("h_end1", C.POINTER(C.c_uint64)), ("h_end2", C.POINTER(C.c_uint64)), ("input_ended", C.c_int32), ("unit_bases", C.c_uint32)]
 
 
 class DecodeArgs(C.Structure):

@@ -63,8 +63,9 @@ class RfqCodec:
         return r
 
     # --- the plan pass of a chunk-parallel encode: where every chunk ends in the input stream(s)
-    def scan(self, d_fq1, n1, d_fq2=None, n2=0, paired=SE, chunk_bases=1_000_000, final=True, file_off1=0, file_off2=0):
-        a = A.EncodeArgs(d_fq1, n1, d_fq2, n2, paired, chunk_bases, 1 if final else 0, 0, file_off1, file_off2, U64_MAX, U64_MAX, None, 0, 0, 0)
+    def scan(self, d_fq1, n1, d_fq2=None, n2=0, paired=SE, chunk_bases=1_000_000, final=True, file_off1=0, file_off2=0, carry_bases=0):
+        """rfq_scan_batch: the plan pass.  carry_bases: bases the chunk that is open at the start of this text took from the text in front of it."""
+        a = A.EncodeArgs(d_fq1, n1, d_fq2, n2, paired, chunk_bases, 1 if final else 0, 0, file_off1, file_off2, U64_MAX, U64_MAX, None, 0, 0, carry_bases)
         r = A.ScanResult()
         self._check(self._L.rfq_scan_batch(self._h, C.byref(a), C.byref(r)))
         ends1 = [r.h_end1[i] for i in range(r.n_chunks)]

@@ -82,6 +82,7 @@ struct DevStatus {
     uint64_t total_bases;
     uint32_t first_empty;       // first read (interleaved order) with an empty line, ~0 if none
     uint32_t max_rec;           // longest record (four lines with their terminators) in bytes
+    uint32_t unit_bases, pad2_; // bases of every cut unit when they are all the same, else 0
 };
 
 struct U4 { uint32_t a, b, c, d; };

@@ -126,7 +126,7 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
     HIPCHK(ctx, hipSetDevice(ctx->device));
     size_t pos1 = 0, pos2 = 0, written = 0; bool first = true;
     std::vector<uint64_t> offs(1, 0), e1, e2; std::vector<std::pair<const char*, float>> acc;
-    uint32_t chunks = 0; uint64_t reads = 0, bases = 0; int ended = 0;
+    uint32_t chunks = 0; uint64_t reads = 0, bases = 0; int ended = 0; int32_t ub = 0;
     for (;;) {
         const size_t r1 = a->n1 - pos1, r2 = two ? a->n2 - pos2 : 0;
         size_t t1 = std::min(r1, slice), t2 = std::min(r2, slice);
@@ -139,7 +139,7 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
         rfq_encode_args s = *a;
         s.d_fq1 = a->d_fq1 + pos1; s.n1 = t1; s.file_off1 = a->file_off1 + pos1;
         if (two) { s.d_fq2 = a->d_fq2 + pos2; s.n2 = t2; s.file_off2 = a->file_off2 + pos2; }
-        s.final = last ? a->final : 0; s.flush_all = last ? a->flush_all : 0; s.emit_header = first ? a->emit_header : 0;
+        s.final = last ? a->final : 0; s.flush_all = last ? a->flush_all : 0; s.emit_header = first ? a->emit_header : 0; s.carry_bases = first ? a->carry_bases : 0u;
         if (a->d_out) { s.d_out = a->d_out + written; s.out_cap = a->out_cap > written ? a->out_cap - written : 0; }
         rfq_encode_result r;
         const int rc = encode_one(ctx, &s, &r, scan_only);
@@ -161,6 +161,7 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
             if (first && r.n_chunks) offs[0] = r.h_chunk_off[0];
             written += r.rfq_len;
         }
+        if (first) ub = r.reserved; else if (r.reserved != ub) ub = 0;      // (scan: the units' common length, if the slices agree on one)
         chunks += r.n_chunks; reads += r.n_reads; bases += r.n_bases; pos1 += r.consumed1; pos2 += r.consumed2; first = false;
         if (r.input_ended) { ended = 1; break; }
         if (last) break;
@@ -168,7 +169,7 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
     }
     ctx->timer.names.clear(); ctx->timer.ms.clear();
     for (auto& q : acc) { ctx->timer.names.push_back(q.first); ctx->timer.ms.push_back(q.second); }
-    res->n_chunks = chunks; res->n_reads = reads; res->n_bases = bases; res->consumed1 = pos1; res->consumed2 = pos2; res->input_ended = ended;
+    res->n_chunks = chunks; res->n_reads = reads; res->n_bases = bases; res->consumed1 = pos1; res->consumed2 = pos2; res->input_ended = ended; res->reserved = scan_only ? ub : 0;
     if (scan_only) { ctx->scan_end[0] = e1; ctx->scan_end[1] = e2; return RFQ_OK; }
     ctx->chunk_off = offs; res->h_chunk_off = ctx->chunk_off.data();
     res->rfq_len = written; res->d_rfq = written ? (a->d_out ? a->d_out : ctx->out_acc.as<uint8_t>()) : nullptr;
@@ -181,7 +182,7 @@ extern "C" int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_scan_r
     rfq_encode_result r;
     const int rc = encode_or_scan(ctx, a, &r, true);
     if (rc != RFQ_OK) return rc;
-    out->n_chunks = r.n_chunks; out->n_reads = r.n_reads; out->consumed1 = r.consumed1; out->consumed2 = r.consumed2; out->input_ended = r.input_ended;
+    out->n_chunks = r.n_chunks; out->n_reads = r.n_reads; out->consumed1 = r.consumed1; out->consumed2 = r.consumed2; out->input_ended = r.input_ended; out->unit_bases = (uint32_t)r.reserved;
     out->h_end1 = r.n_chunks ? ctx->scan_end[0].data() : nullptr;
     out->h_end2 = (r.n_chunks && a->paired == RFQ_PE_TWO_FILES) ? ctx->scan_end[1].data() : nullptr;
     return RFQ_OK;
@@ -296,7 +297,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_FIRST].ensure(((size_t)cap_chunks + 2) * 4));
     ChunkTab C; memset(&C, 0, sizeof C);
     C.first = B[B_FIRST].as<uint32_t>();
-    hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, fin ? 1 : 0,
+    if (a->carry_bases && !scan_only) return rfq_fail(ctx, RFQ_E_ARG, "carry_bases is for the plan pass (rfq_scan_batch): an encode starts on a chunk boundary");
+    if (a->carry_bases >= a->chunk_bases) return rfq_fail(ctx, RFQ_E_ARG, "carry_bases must be < chunk_bases");
+    hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->carry_bases, fin ? 1 : 0,
                        (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst);
     KCHK(ctx, "k_partition");
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
@@ -329,7 +332,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         const size_t lim0 = nm ? nm->orig_n[0] : nbytes[0], lim1 = nm ? nm->orig_n[1] : nbytes[1];
         for (auto& v : ctx->scan_end[0]) { if (v > lim0) v = lim0; if (!nm) v -= skip[0]; }   // (a virtual terminator past an unterminated last line; offsets count from the stream's own first byte)
         for (auto& v : ctx->scan_end[1]) { if (v > lim1) v = lim1; if (!nm) v -= skip[1]; }
-        res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases;
+        res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases; res->reserved = (int32_t)hs.unit_bases;
         res->consumed1 = (size_t)ctx->scan_end[0].back(); res->consumed2 = nstreams == 2 ? (size_t)ctx->scan_end[1].back() : 0;
         ctx->timer.collect();
         return RFQ_OK;

@@ -434,7 +434,8 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
     if (!b) return hi;
     return lo + (uint32_t)(__ffsll((long long)b) - 1);
 }
-__global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, int final_batch,
+// carry: bases the chunk that is open at unit 0 has taken from the text in front of this batch (plan pass of a share, rfq_encode_args.carry_bases)
+__global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, uint32_t carry, int final_batch,
                             const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
     const int l = lane_id();
     // shortest / longest unit: every thread of the workgroup (1024: a single wave walked 44 k block entries in 158 us), then wave 0 goes on alone
@@ -451,15 +452,17 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
     if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
         // every unit has the same length L: a chunk is K = ceil(chunk_bases / L) units
         const uint32_t L = len_minmax[0]; const uint32_t K = (uint32_t)(((uint64_t)chunk_bases + L - 1) / L);
-        const uint32_t full = n_units / K, rem = n_units - full * K;
+        // (the chunk open at unit 0 already holds `carry` bases: it closes after K0 units, the others after K each)
+        const uint32_t K0 = carry ? (uint32_t)(((uint64_t)(chunk_bases - carry) + L - 1) / L) : K;
+        const uint32_t head = n_units >= K0 ? K0 : 0u, full = head ? 1u + (n_units - K0) / K : 0u, used = head ? K0 + (full - 1u) * K : 0u, rem = n_units - used;
         const uint32_t nch = full + ((rem && final_batch) ? 1u : 0u);
-        for (uint32_t i = (uint32_t)l; i <= nch && i < cap_chunks; i += 64) { uint64_t f = (uint64_t)i * K; if (f > n_units) f = n_units; first[i] = (uint32_t)f * upr; }
-        c = nch; start = (rem && !final_batch) ? full * K : n_units;
-        max_units = full ? K : rem; max_bases = (uint64_t)max_units * L;
+        for (uint32_t i = (uint32_t)l; i <= nch && i < cap_chunks; i += 64) { uint64_t f = i == 0 ? 0ull : (uint64_t)K0 + (uint64_t)(i - 1u) * K; if (f > n_units) f = n_units; first[i] = (uint32_t)f * upr; }
+        c = nch; start = (rem && !final_batch) ? used : n_units;
+        max_units = head ? K0 : 0u; if (full > 1u && K > max_units) max_units = K; if (rem && final_batch && rem > max_units) max_units = rem; max_bases = (uint64_t)max_units * L;
     } else {
         uint32_t guess = 0;
         while (start < n_units) {
-            const uint64_t target = prevP + chunk_bases;
+            const uint64_t target = prevP + chunk_bases - (c == 0 ? carry : 0u);
             uint32_t e = n_units; bool found = false;
             if (guess > 32 && start + guess - 32 < n_units) {            // probe a 64-wide window around the previous chunk's size
                 const uint32_t w0 = start + guess - 32; const uint32_t i = w0 + (uint32_t)l;
@@ -479,7 +482,7 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
     if (l == 0) {
         st->n_chunks = c; st->n_units_used = start; st->max_chunk_reads = max_units * upr;
         st->max_chunk_bases = (uint32_t)(max_bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : max_bases);
-        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec;
+        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec; st->unit_bases = (n_units > 0 && len_minmax[0] == len_minmax[1]) ? len_minmax[0] : 0u;
     }
 }
 __global__ void k_chunk_ids(ChunkTab C, ReadTab R) {
