@@ -165,6 +165,12 @@ int rfq_last_timings(const rfq_ctx* ctx, const char** names, float* ms, int cap)
 int rfq_dev_malloc(rfq_ctx* ctx, void** d_ptr, size_t n);
 int rfq_dev_free(rfq_ctx* ctx, void* d_ptr);
 int rfq_copy_h2d(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n);
+/* The same without waiting: the copy is queued on the context's copy stream (h_src page-locked: rfq_host_alloc) and runs beside whatever the
+ * context's own stream does.  *ticket (optional) identifies it: rfq_copy_done says whether it has finished (the host buffer may be reused),
+ * rfq_copy_sync waits for everything queued so far - call it before handing the destination to rfq_encode_batch / rfq_decode_batch. */
+int rfq_copy_h2d_async(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n, uint64_t* ticket);
+int rfq_copy_done(rfq_ctx* ctx, uint64_t ticket);      /* 1: finished, 0: still running, < 0: error */
+int rfq_copy_sync(rfq_ctx* ctx);
 int rfq_copy_d2h(rfq_ctx* ctx, void* h_dst, const void* d_src, size_t n);
 int rfq_copy_d2d(rfq_ctx* ctx, void* d_dst, const void* d_src, size_t n);
 /* d_dst on ctx's GPU <- d_src on src_ctx's GPU (hipMemcpyPeerAsync): how a worker of a multi-GPU host queue pulls its byte range */

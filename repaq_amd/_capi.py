@@ -86,6 +86,9 @@ def load(path=None):
     L.rfq_dev_malloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
     L.rfq_dev_free.argtypes = [C.c_void_p, C.c_void_p]
     L.rfq_copy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.rfq_copy_h2d_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.rfq_copy_done.argtypes = [C.c_void_p, C.c_uint64]
+    L.rfq_copy_sync.argtypes = [C.c_void_p]
     L.rfq_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.rfq_copy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.rfq_copy_peer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -98,4 +101,5 @@ def load(path=None):
 
 EXPORTS = ["rfq_version", "rfq_create", "rfq_destroy", "rfq_last_error", "rfq_set_stream", "rfq_set_header", "rfq_get_header", "rfq_clear_header",
            "rfq_encode_batch", "rfq_scan_batch", "rfq_decode_batch", "rfq_last_timings", "rfq_dev_malloc", "rfq_dev_free", "rfq_copy_h2d", "rfq_copy_d2h",
+           "rfq_copy_h2d_async", "rfq_copy_done", "rfq_copy_sync",
            "rfq_copy_d2d", "rfq_copy_peer", "rfq_host_alloc", "rfq_host_free", "rfq_compare_bytes"]

@@ -276,7 +276,7 @@ struct Block { uint8_t* p = nullptr; size_t n = 0; };
 class Prefetcher {
     ByteSource src; Gpu& g; size_t block; std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
     std::map<uint64_t, Block> ready; uint64_t next_out = 0, next_claim = 0, n_blocks = 0; std::vector<uint8_t*> freeb; int to_alloc = 0;   // to_alloc: page-locked blocks not allocated yet (a reader allocates its own: pinning runs beside the first reads)
-    bool eof = false, stop = false, regular = false; uint64_t total = 0; int last_byte = -1; int fd = -1; int running = 0;
+    bool eof = false, stop = false, regular = false; uint64_t total = 0; int last_byte = -1; int fd = -1; int running = 0; int nbuf_ = 4;
     void run_seq() {
         for (;;) {
             uint8_t* buf;
@@ -319,7 +319,7 @@ public:
             nbuf = (int)std::min<uint64_t>((uint64_t)threads + 3, std::max<uint64_t>(n_blocks, 1));
             if (n_blocks == 0) eof = true;
         } else if (!src.open(path, std::max(threads, std::min(32, (int)std::thread::hardware_concurrency() / 2)))) error_exit("Failed to open file: " + path);
-        to_alloc = nbuf;
+        to_alloc = nbuf; nbuf_ = nbuf;
         if (regular) { running = n_blocks ? threads : 0; for (int i = 0; i < running; i++) th.emplace_back([this] { run_par(); }); }
         else th.emplace_back([this] { run_seq(); });
     }
@@ -335,6 +335,9 @@ public:
         return true;
     }
     void release(const Block& b) { std::unique_lock<std::mutex> lk(mu); freeb.push_back(b.p); cv.notify_all(); }
+    // staging blocks the consumer may hold back (copies in flight) without starving the readers: half of a regular file's, none of a sequential source's
+    // (its reader must be able to run three blocks ahead with the four it has)
+    size_t flight_limit() const { return regular ? (size_t)std::max(1, std::min(6, nbuf_ / 2)) : 1u; }
     bool end_known() { std::unique_lock<std::mutex> lk(mu); return regular || eof; }
     bool drained() { std::unique_lock<std::mutex> lk(mu); return regular ? next_out >= n_blocks : (eof && ready.empty()); }
     uint64_t total_bytes() { std::unique_lock<std::mutex> lk(mu); return total; }
@@ -411,6 +414,23 @@ struct DevStream {
             d[cur] = nd; cap[cur] = nc;
         }
         g.check(rfq_copy_h2d(g.c, (uint8_t*)d[cur] + have, b.p, b.n)); have += b.n;
+    }
+    // the same, the copy only queued (rfq_copy_h2d_async): a run of blocks then crosses the link back to back while the caller waits for the next
+    // block to be read; `flight` keeps the staging blocks until their copies are done (the caller hands them back to their reader: drain)
+    std::deque<std::pair<Block, uint64_t>> flight;
+    void append_async(Gpu& g, const Block& b, size_t room = 0) {
+        if (cap[cur] < have + b.n) {                                          // grow: the copies queued into the old buffer must have landed before it is moved
+            g.check(rfq_copy_sync(g.c));
+            const size_t nc = std::max(have + b.n + (have + b.n) / 8, room); void* nd = g.dev(nc);
+            if (have) g.check(rfq_copy_d2d(g.c, nd, d[cur], have));
+            if (d[cur]) rfq_dev_free(g.c, d[cur]);
+            d[cur] = nd; cap[cur] = nc;
+        }
+        uint64_t t = 0; g.check(rfq_copy_h2d_async(g.c, (uint8_t*)d[cur] + have, b.p, b.n, &t)); have += b.n; flight.emplace_back(b, t);
+    }
+    template <class Release> void drain(Gpu& g, bool all, Release rel) {     // hand back the staging blocks whose copies are done (all: wait for every one)
+        if (all) g.check(rfq_copy_sync(g.c));
+        while (!flight.empty()) { if (!all) { const int d_ = rfq_copy_done(g.c, flight.front().second); if (d_ < 0) g.check(d_); if (!d_) break; } rel(flight.front().first); flight.pop_front(); }
     }
     void free_all(Gpu& g) { for (int i = 0; i < 2; i++) if (d[i]) rfq_dev_free(g.c, d[i]); }
 };
@@ -501,13 +521,20 @@ static void do_compress(const Options& o) {
     trace_mark("compress: pipeline up");
     Verifier* ver = (o.completeCheck || o.fastCheck) ? new Verifier(o, o.device) : nullptr;
     for (;;) {
-        for (int s = 0; s < ns; s++) {
-            while (!ds[s].ended && ds[s].have < want) {
-                Block b; if (!in[s]->next(b)) { ds[s].ended = true; break; }
-                ds[s].append(g, b, batch + block); in[s]->release(b);
+        // (the two files of a pair block by block in turn: filled one after the other, one file's readers sat idle - their buffers full - while
+        // the other's worked: 8 GB crossed at the rate of ONE set of readers, 22 - 25 GB/s)
+        for (bool more = true; more; ) {
+            more = false;
+            for (int s = 0; s < ns; s++) {
+                if (ds[s].ended || ds[s].have >= want) continue;
+                Block b; if (!in[s]->next(b)) { ds[s].ended = true; continue; }
+                // (at most flight_limit() staging blocks wait for their copies, so the readers never run dry while this thread waits for a block)
+                ds[s].append_async(g, b, batch + block); ds[s].drain(g, ds[s].flight.size() >= in[s]->flight_limit(), [&](const Block& x) { in[s]->release(x); });
                 if (in[s]->drained()) ds[s].ended = true;
+                more = true;
             }
         }
+        for (int s = 0; s < ns; s++) ds[s].drain(g, true, [&](const Block& x) { in[s]->release(x); });      // every queued copy has landed
         trace_mark("compress: batch resident");
         const bool final = ds[0].ended && (!two || ds[1].ended);
         rfq_encode_args a; memset(&a, 0, sizeof a);

@@ -37,6 +37,7 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     for (auto& b : c->b) b.release();
     c->d_hdr.release(); c->d_status.release(); c->d_cmp.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release(); c->out_acc.release(); c->out_acc1.release(); c->out_acc2.release();
     c->timer.destroy();
+    if (c->copy) { (void)hipStreamDestroy(c->copy); for (auto& e : c->copy_ev) if (e) (void)hipEventDestroy(e); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -95,6 +96,32 @@ extern "C" int rfq_copy_h2d(rfq_ctx* c, void* d, const void* h, size_t n) {
     if (!c) return RFQ_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (n) { HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    return RFQ_OK;
+}
+extern "C" int rfq_copy_h2d_async(rfq_ctx* c, void* d, const void* h, size_t n, uint64_t* ticket) {
+    if (!c) return RFQ_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->copy) HIPCHK(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    const uint64_t t = c->copy_next; hipEvent_t& ev = c->copy_ev[t & 63u];
+    if (t >= 64 && c->copy_done + 64 <= t) { HIPCHK(c, hipEventSynchronize(ev)); c->copy_done = t - 63; }   // the slot's previous copy (64 tickets back)
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (n) HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(c, hipEventRecord(ev, c->copy));
+    c->copy_next = t + 1;
+    if (ticket) *ticket = t;
+    return RFQ_OK;
+}
+extern "C" int rfq_copy_done(rfq_ctx* c, uint64_t ticket) {
+    if (!c || ticket >= c->copy_next) return RFQ_E_ARG;
+    if (ticket < c->copy_done || ticket + 64 < c->copy_next) return 1;      // (older than the ring: finished long ago)
+    const hipError_t e = hipEventQuery(c->copy_ev[ticket & 63u]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return rfq_fail(c, RFQ_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+}
+extern "C" int rfq_copy_sync(rfq_ctx* c) {
+    if (!c) return RFQ_E_ARG;
+    if (c->copy) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->copy)); c->copy_done = c->copy_next; }
     return RFQ_OK;
 }
 extern "C" int rfq_copy_d2d(rfq_ctx* c, void* dst, const void* src, size_t n) {

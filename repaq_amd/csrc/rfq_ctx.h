@@ -70,6 +70,8 @@ struct rfq_ctx {
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
     hipStream_t aux2 = nullptr; hipEvent_t ev_f = nullptr;                     // decode: the bandwidth-bound prefill beside the latency-bound chains
     hipEvent_t ev_ovl = nullptr;                                               // encode: the overlap search (aux) has finished
+    // rfq_copy_h2d_async: a stream of its own and a ring of events (ticket t lives in slot t % 64; a slot is reused only when its copy is done)
+    hipStream_t copy = nullptr; hipEvent_t copy_ev[64] = {}; uint64_t copy_next = 0, copy_done = 0;
     bool aux_ready() {
         if (aux) return true;
         if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; return false; }
