@@ -135,6 +135,10 @@ def golden_md5(key, units, seed, k):
             g = json.load(open(os.path.join(ROOT, "tests", "golden", "big.json"))).get("cfg2")
             if g and g["pairs"] == units and g["seed"] == seed and k == g["k"]:
                 return g["rfq_md5"]
+        if key == "cfg4":
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "big.json"))).get("cfg4")
+            if g and g["pairs"] == units and g["seed"] == seed and k == g["k"] and g["n_quals"] == 40:
+                return g["rfq_md5"]
         if key == "cfg1":
             for g in json.load(open(os.path.join(ROOT, "tests", "golden", "generated.json"))):
                 if g["profile"] == 0 and g["reads"] == units and g["seed"] == seed and g["nppm"] == 20 and g["k"] == k and not g["nonl"]:

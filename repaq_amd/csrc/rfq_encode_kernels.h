@@ -1354,6 +1354,22 @@ __device__ __forceinline__ void pack4_codes_rc(uint32_t w, uint32_t& code, uint3
     code = ((__builtin_amdgcn_perm(0u, 0x03010002u, idx) & ok) * 0x01041040u) >> 24;      // [A,C,T,G] -> codes of T,G,A,C
     nb = ((~ok & 0x01010101u) * 0x01020408u) >> 24;
 }
+// 16 bases that are all upper-case A/C/G/T (nearly every group of a sequencer's file) -> their 16 codes; false when a byte is anything else (the
+// exact per-byte forms above then decide).  The letters are looked up back from the 2-bit index and compared with one xor: ten VALU instructions
+// per four bases instead of seventeen (k_gather2 is VALU-bound: 1.85 G wave instructions on configs[2], 3.0 of its 3.5 ms).
+__device__ __forceinline__ bool pack16_fast(const uint32_t (&w)[4], uint32_t& code) {
+    uint32_t diff = 0; code = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t idx = (w[i] >> 1) & 0x03030303u;
+        diff |= __builtin_amdgcn_perm(0u, 0x47544341u, idx) ^ w[i];
+        code |= ((__builtin_amdgcn_perm(0u, 0x00020301u, idx) * 0x01041040u) >> 24) << (8 * i);
+    }
+    return diff == 0;
+}
+__device__ __forceinline__ uint32_t g2_rev2x16(uint32_t v) {                // the sixteen 2-bit fields of v in reverse order
+    v = bswap32(v); v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4); return ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+}
 struct G2Geo { uint32_t a00, a01, end0, end1, base1; };                         // a tile's text spans: 16-aligned begin and end per stream, LDS offset of stream 1's span
 struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld, gi; };       // my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
 __device__ __forceinline__ G2Geo g2_geo(const Text& T, bool two, uint32_t cur, uint32_t cnt) {
@@ -1413,17 +1429,28 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
         const uint32_t ng = (m.len + 15u) >> 4;
         for (uint32_t gi = part; gi < ng; gi += P) {
             uint32_t w[4], code = 0, nbits = 0;
+            const uint32_t nv0 = m.len - 16u * gi;                         // valid bases of this step
+            // (the bytes of a last, partial step that lie outside the line would fail the all-ACGT test in some lane of nearly every wave - and a wave
+            // runs the exact path if any of its lanes does: they are made 'A' first; their codes are masked off below)
+            auto blank = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) { uint32_t& x = w[k >> 2]; const uint32_t sh = 8u * (k & 3u); x = (x & ~(0xFFu << sh)) | (0x41u << sh); } };
             if (!m.rc) {
                 lds_get16(s_text, m.ssrc + 16u * gi, w);
-                uint32_t bad = 0;
+                if (nv0 < 16u) blank(nv0, 16u);
+                if (!pack16_fast(w, code)) {                                // (an N, a lower-case or any other byte among the 16)
+                    uint32_t bad = 0; code = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
-                if (bad) { const uint32_t nv_ = m.len - 16u * gi; if (nv_ >= 16u || (bad & ((1u << nv_) - 1u))) rflag[m.gi] = 1; }   // a byte outside A/C/G/T/N: it equals nothing in RfqCodec::overlap (k_overlap's byte-wise path)
+                    for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
+                    if (bad) rflag[m.gi] = 1;                                // a byte outside A/C/G/T/N: it equals nothing in RfqCodec::overlap (k_overlap's byte-wise path)
+                }
             } else {
-                lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);       // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line: masked below)
-                const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3;
+                lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);       // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line)
+                if (nv0 < 16u) blank(0u, 16u - nv0);
+                if (pack16_fast(w, code)) code = ~g2_rev2x16(code);         // reverse complement in 2-bit space: the fields back to front, G 0 <-> C 3, A 1 <-> T 2
+                else {
+                    const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; code = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) { uint32_t c4, n4; pack4_codes_rc(w[i], c4, n4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
+                    for (int i = 0; i < 4; i++) { uint32_t c4, n4; pack4_codes_rc(w[i], c4, n4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
+                }
             }
             const uint32_t nv = m.len - 16u * gi;                          // valid bases of this step (what lies outside the line is not the read's)
             if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; nbits &= (1u << nv) - 1u; }

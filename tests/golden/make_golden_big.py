@@ -6,6 +6,8 @@ oracle/Makefile, and ~20 GB of /tmp).  Writes tests/golden/big.json:
   cfg3_share  one GPU's share of configs[3] (2 x 64 GB over 8 GPUs = 2 x 8 GB: fqgen profile 1, 22.4 M pairs, seed 4) encoded by
         the reference as a file of its own: md5 / size of the image + crc32 and size of every chunk image (the table a
         chunk-parallel encode is checked against, chunk by chunk)
+  cfg4  the bench's configs[4]-shaped input (BGI-style PE100 with long names, 40 quality values, N runs: fqgen profile 3, 1.4 M pairs, seed 6,
+        --nppm 0 --nquals 40): md5 / size of the reference's .rfq and whether its own decode restored the inputs
 The committed JSON is data (hashes of inputs and of the reference's outputs); no reference source is stored."""
 import hashlib
 import json
@@ -32,11 +34,11 @@ def md5_file(p):
     return h.hexdigest()
 
 
-def run_case(label, pairs, seed, chunk_table):
-    out = {"label": label, "profile": O.NOVA_PE150, "pairs": pairs, "seed": seed, "nppm": 20, "k": 1000, "paired": O.PE_TWO_FILES}
+def run_case(label, pairs, seed, chunk_table, profile=1, extra=(), nppm=20, n_quals=0):
+    out = {"label": label, "profile": profile, "pairs": pairs, "seed": seed, "nppm": nppm, "n_quals": n_quals, "k": 1000, "paired": O.PE_TWO_FILES}
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         r1, r2, rfq = (os.path.join(d, n) for n in ("r1.fq", "r2.fq", "o.rfq"))
-        subprocess.check_call([FQGEN, "--profile", "1", "--reads", str(pairs), "--seed", str(seed), "-o", r1, "-O", r2])
+        subprocess.check_call([FQGEN, "--profile", str(profile), "--reads", str(pairs), "--seed", str(seed)] + list(extra) + ["-o", r1, "-O", r2])
         out["fq_bytes"] = [os.path.getsize(r1), os.path.getsize(r2)]
         out["fq_md5"] = [md5_file(r1), md5_file(r2)]
         t0 = time.time()
@@ -68,6 +70,9 @@ def main():
     res = json.load(open(p)) if os.path.exists(p) else {}
     if "cfg2" in which:
         res["cfg2"] = run_case("cfg2_pe150_2x4GB", 11_200_000, 3, False)
+        json.dump(res, open(p, "w"), indent=0, sort_keys=True)
+    if "cfg4" in which:
+        res["cfg4"] = run_case("cfg4_bgi_pe100_q40", 1_400_000, 6, False, profile=3, extra=("--nppm", "0", "--nquals", "40"), nppm=0, n_quals=40)
         json.dump(res, open(p, "w"), indent=0, sort_keys=True)
     if "cfg3_share" in which:
         res["cfg3_share"] = run_case("cfg3_share_pe150_2x8GB", 22_400_000, 4, True)

@@ -252,6 +252,13 @@ def test_xz_is_present_so_the_rfq_xz_legs_ran():
     assert subprocess.run(["xz", "--version"], capture_output=True).returncode == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__("shutil").which("xz") is None, reason="no external xz on the GPU box: the .rfq.xz legs inside the GPU CLI suites did NOT run")
+def test_xz_is_present_on_the_gpu_box_so_the_rfq_xz_legs_ran():
+    """the same check inside the -m gpu run: a GPU box without xz shows up as a reported skip there too"""
+    assert subprocess.run(["xz", "--version"], capture_output=True).returncode == 0
+
+
 def test_cli_io_pipeline_on_simt_emulation(tmp_path):
     E.build_emu()
     assert os.path.exists(EMU_BIN)

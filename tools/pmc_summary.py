@@ -11,8 +11,16 @@ import sys
 def per_kernel(path, counter):
     cur = sqlite3.connect(path).cursor()
     rows = cur.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name", (counter,)).fetchall()
-    # (kernels templated on a debug switch are reported under their plain name: k_dec_emit<false> -> k_dec_emit)
-    return {r[0].split("(")[0].replace("void ", "").replace("<false>", "").replace("<true>", ""): (r[1], r[2]) for r in rows}
+    # (kernels templated on switches are reported under their plain name - k_gather2<false, 23552u> -> k_gather2 -, launches of several
+    # instantiations of one kernel are added up; the scans keep their element type: k_scan_apply<U4>)
+    import re
+    out = {}
+    for name, n, v in rows:
+        k = name.split("(")[0].replace("void ", "")
+        if not k.startswith("k_scan_"):
+            k = re.sub(r"<.*>$", "", k)
+        a = out.get(k, (0, 0.0)); out[k] = (a[0] + n, a[1] + (v or 0.0))
+    return out
 
 
 def main():

@@ -15,7 +15,9 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 pairs = [("bench.json.log", "bench.json.log"), ("bench_under_rocprof.json.log", "bench_under_rocprof.json.log"),
          ("trace_kernel_stats.txt", "kernel_stats_cfg2.txt"), ("trace_cfg1_kernel_stats.txt", "kernel_stats_cfg1.txt"),
-         ("trace_cfg4_kernel_stats.txt", "kernel_stats_cfg4.txt"), ("pmc_traffic.txt", "pmc_traffic_cfg2.txt"), ("e2e_cli.txt", "e2e_cli.txt")]
+         ("trace_cfg4_kernel_stats.txt", "kernel_stats_cfg4.txt"), ("pmc_traffic.txt", "pmc_traffic_cfg2.txt"), ("pmc_traffic_cfg1.txt", "pmc_traffic_cfg1.txt"), ("pmc_traffic_cfg4.txt", "pmc_traffic_cfg4.txt"),
+         ("e2e_cli.txt", "e2e_cli.txt"), ("e2e_pe.txt", "e2e_pe.txt"), ("sq_counters.txt", "sq_counters.txt"),
+         ("multi/gpus2_single_device.json.log", "gpus2_single_device.json.log"), ("multi/gpus4_single_device.json.log", "gpus4_single_device.json.log"), ("multi/gpus2_strong_single_device.json.log", "gpus2_strong_single_device.json.log")]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p):
@@ -25,5 +27,9 @@ pj = os.path.join(src, "pmc_traffic.json")
 if os.path.exists(pj):
     out = {"cfg2": {"kernels": json.load(open(pj)), "units": units,
                     "source": "profiles/%s_%s_pmc_traffic_cfg2.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, KB units, FETCH_SIZE x2 on gfx950)" % (rnd, letter)}}
+    for wl, wunits in (("cfg1", 2800000), ("cfg4", 1400000)):            # (the secondary workloads' own PMC passes, at bench.py's sizes)
+        pw = os.path.join(src, "pmc_traffic_%s.json" % wl)
+        if os.path.exists(pw):
+            out[wl] = {"kernels": json.load(open(pw)), "units": wunits, "source": "profiles/%s_%s_pmc_traffic_%s.txt" % (rnd, letter, wl)}
     json.dump(out, open(os.path.join(dst, "%s_pmc_traffic.json" % rnd), "w"), indent=1, sort_keys=True)
     print("profiles/%s_pmc_traffic.json" % rnd)
