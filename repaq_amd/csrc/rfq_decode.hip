@@ -189,12 +189,13 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     {
         // k_dec_emit3 (no output tile, K reads per tile: the largest power of two whose qualities fit its tile) whenever the pieces of a name are shared
         // by whole chunks; k_dec_emit2 (tiles fitted read by read) otherwise.  RFQ_EMIT=2 forces the latter (tests run both).
-        uint32_t e3k = 6; while (e3k >= 1 && ((uint64_t)g.max_len << e3k) > E3_QCAP) e3k--;
+        uint32_t e3k = 6; if (getenv("RFQ_E3_K")) e3k = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_E3_K"))));   // (profiling aid: smaller tiles)
+        while (e3k >= 1 && ((uint64_t)g.max_len << e3k) > E3_QCAP) e3k--;
         const char* eenv = getenv("RFQ_EMIT");
         const bool emit3 = fused && !g.pieces && e3k >= 1 && !(eenv && !strcmp(eenv, "2")) && !(tune & 7);
         if (!emit3) ctx->timer.stages[ctx->timer.used].name = "emit2";
         if (emit3) {
-            const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
+            const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, (getenv("RFQ_E3_SLOTS") ? (uint32_t)atoi(getenv("RFQ_E3_SLOTS")) : 6u) * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
 #define RFQ_EMIT3_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
                        (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k, (tune >> 12) & 255
             if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_emit3<false>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);

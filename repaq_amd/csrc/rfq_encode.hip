@@ -216,31 +216,68 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     DevStatus* dst = ctx->d_status.as<DevStatus>();
     HIPCHK(ctx, hipMemcpyAsync(dst, &hs, sizeof hs, hipMemcpyHostToDevice, S));
 
-    // ---- phase 1: newline bitmap + counts
+    // ---- phase 1: the line index lo[] of every stream.  One pass (k_line_index) where the lines are long enough for a table sized in advance
+    // (RFQ_INDEX=2pass, or more than one line per 16 bytes: newline bitmap -> scan -> k_line_offsets, the table sized exactly)
     ctx->timer.begin("index", S);
     uint32_t nblk[2] = { 0, 0 }; uint64_t nwords[2] = { 0, 0 };
-    size_t scantmp = 1024;
-    for (int s = 0; s < nstreams; s++) {
-        nwords[s] = (nbytes[s] + 63) / 64; nblk[s] = (uint32_t)((nwords[s] + 255) / 256);
-        HIPCHK(ctx, B[B_BITMAP0 + s].ensure(nwords[s] * 8 + 64));
-        HIPCHK(ctx, B[B_BLK0 + s].ensure(((size_t)nblk[s] + 2) * 4));
-        scantmp = std::max(scantmp, ((size_t)nblk[s] / SCAN_TILE + 2) * 16);
-    }
-    HIPCHK(ctx, B[B_SCANTMP].ensure(scantmp));
-    for (int s = 0; s < nstreams; s++) {
-        if (!nblk[s]) continue;
-        hipLaunchKernelGGL(k_nl_bitmap, dim3(nblk[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], skip[s], B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), dst);
-        KCHK(ctx, "k_nl_bitmap");
-        scan_exclusive<uint32_t>(S, B[B_BLK0 + s].as<uint32_t>(), B[B_BLK0 + s].as<uint32_t>(), nblk[s], B[B_SCANTMP].as<uint32_t>(), 1);
-    }
+    for (int s = 0; s < nstreams; s++) { nwords[s] = (nbytes[s] + 63) / 64; nblk[s] = (uint32_t)((nwords[s] + 255) / 256); }
+    int idx_tiles = getenv("RFQ_IDX_TILES") ? atoi(getenv("RFQ_IDX_TILES")) : NLF_TILES;
+    if (idx_tiles != 4 && idx_tiles != 8 && idx_tiles != 16) idx_tiles = NLF_TILES;
+    uint32_t nidx[2] = { 0, 0 };                                                           // workgroups of the one-pass index
+    for (int s = 0; s < nstreams; s++) nidx[s] = (uint32_t)((nbytes[s] + idx_tiles * 16384u - 1) / (idx_tiles * 16384u));
     uint32_t n_newlines[2] = { 0, 0 }; uint8_t lastbyte[2] = { '\n', '\n' };
-    for (int s = 0; s < nstreams; s++) {
-        if (!nblk[s]) continue;
-        HIPCHK(ctx, ctx->fetch(&n_newlines[s], B[B_BLK0 + s].as<uint32_t>() + nblk[s], 4, S));
-        HIPCHK(ctx, ctx->fetch(&lastbyte[s], fq[s] + nbytes[s] - 1, 1, S));
+    const char* ienv = getenv("RFQ_INDEX");
+    bool one_pass = !(ienv && !strcmp(ienv, "2pass"));
+    if (one_pass) {
+        size_t cap[2] = { 0, 0 };
+        for (int s = 0; s < nstreams; s++) {
+            if (!nblk[s]) continue;
+            cap[s] = std::max(B[B_LO0 + s].cap / 4, nbytes[s] / 16 + 4096);
+            HIPCHK(ctx, B[B_LO0 + s].ensure(cap[s] * 4));
+            HIPCHK(ctx, B[B_BLK0 + s].ensure((size_t)nidx[s] * 8 + 64));                  // state words, then the ticket and the total
+            HIPCHK(ctx, hipMemsetAsync(B[B_BLK0 + s].p, 0, (size_t)nidx[s] * 8 + 64, S));
+            unsigned long long* state = B[B_BLK0 + s].as<unsigned long long>();
+            uint32_t* tt = (uint32_t*)(state + nidx[s]);
+            const uint32_t lo_cap = (uint32_t)std::min<size_t>(cap[s] - 4, 0xFFFFFFF0u);
+            auto kern = idx_tiles == 16 ? k_line_index<16> : (idx_tiles == 4 ? k_line_index<4> : k_line_index<8>);
+            hipLaunchKernelGGL(kern, dim3(nidx[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], skip[s], B[B_LO0 + s].as<uint32_t>(), lo_cap, state, tt, tt + 1, dst);
+            KCHK(ctx, "k_line_index");
+            HIPCHK(ctx, ctx->fetch(&n_newlines[s], tt + 1, 4, S));
+            HIPCHK(ctx, ctx->fetch(&lastbyte[s], fq[s] + nbytes[s] - 1, 1, S));
+        }
+        HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
+        if (hs.err & DE_INDEX_RETRY) {                                                    // start over with a clean status block
+            one_pass = false;
+            memset(&hs, 0, sizeof hs); hs.err_key = ~0ull; hs.coord_key = ~0ull; hs.first_empty = ~0u;
+            HIPCHK(ctx, hipMemcpyAsync(dst, &hs, sizeof hs, hipMemcpyHostToDevice, S));
+            HIPCHK(ctx, hipStreamSynchronize(S));                                         // (hs is a stack object the copy reads)
+            n_newlines[0] = n_newlines[1] = 0;
+        }
     }
-    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-    HIPCHK(ctx, ctx->fetch_sync(S));
+    if (!one_pass) {
+        ctx->timer.end(S); ctx->timer.begin("index_2pass", S);
+        size_t scantmp = 1024;
+        for (int s = 0; s < nstreams; s++) {
+            HIPCHK(ctx, B[B_BITMAP0 + s].ensure(nwords[s] * 8 + 64));
+            HIPCHK(ctx, B[B_BLK0 + s].ensure(((size_t)nblk[s] + 2) * 4));
+            scantmp = std::max(scantmp, ((size_t)nblk[s] / SCAN_TILE + 2) * 16);
+        }
+        HIPCHK(ctx, B[B_SCANTMP].ensure(scantmp));
+        for (int s = 0; s < nstreams; s++) {
+            if (!nblk[s]) continue;
+            hipLaunchKernelGGL(k_nl_bitmap, dim3(nblk[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], skip[s], B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), dst);
+            KCHK(ctx, "k_nl_bitmap");
+            scan_exclusive<uint32_t>(S, B[B_BLK0 + s].as<uint32_t>(), B[B_BLK0 + s].as<uint32_t>(), nblk[s], B[B_SCANTMP].as<uint32_t>(), 1);
+        }
+        for (int s = 0; s < nstreams; s++) {
+            if (!nblk[s]) continue;
+            HIPCHK(ctx, ctx->fetch(&n_newlines[s], B[B_BLK0 + s].as<uint32_t>() + nblk[s], 4, S));
+            HIPCHK(ctx, ctx->fetch(&lastbyte[s], fq[s] + nbytes[s] - 1, 1, S));
+        }
+        HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
+    }
     if (hs.err & DE_HAS_CR) return nm ? rfq_fail(ctx, RFQ_E_HIP, "internal: '\\r' in normalised text") : RFQ_NEED_NORM;
     uint32_t nlines[2] = { 0, 0 }, nrec[2] = { 0, 0 };
     for (int s = 0; s < nstreams; s++) {
@@ -248,9 +285,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // batch boundary and belongs to the next batch
         const int unterm = a->final && nbytes[s] > 0 && lastbyte[s] != '\n';
         nlines[s] = n_newlines[s] + (unterm ? 1u : 0u); nrec[s] = nlines[s] / 4;
-        HIPCHK(ctx, B[B_LO0 + s].ensure(((size_t)nlines[s] + 4) * 4));
+        if (!one_pass || !nblk[s]) HIPCHK(ctx, B[B_LO0 + s].ensure(((size_t)nlines[s] + 4) * 4));
         if (nblk[s]) {
-            hipLaunchKernelGGL(k_line_offsets, dim3(nblk[s]), dim3(256), 0, S, B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), (uint32_t)nbytes[s], skip[s], B[B_LO0 + s].as<uint32_t>());
+            if (!one_pass) hipLaunchKernelGGL(k_line_offsets, dim3(nblk[s]), dim3(256), 0, S, B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), (uint32_t)nbytes[s], skip[s], B[B_LO0 + s].as<uint32_t>());
             hipLaunchKernelGGL(k_line_tail, dim3(1), dim3(64), 0, S, B[B_LO0 + s].as<uint32_t>(), n_newlines[s], (uint32_t)nbytes[s], unterm);
             KCHK(ctx, "k_line_offsets");
         }
@@ -277,7 +314,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
     HIPCHK(ctx, B[B_PV].ensure(nr * 16)); HIPCHK(ctx, B[B_PVIN].ensure(nr * 16));
     HIPCHK(ctx, B[B_ULEN].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_P].ensure(((size_t)n_units + 2) * 8));
-    HIPCHK(ctx, B[B_SCANTMP].ensure(std::max(scantmp, (nr / SCAN_TILE + 2) * 16)));
+    HIPCHK(ctx, B[B_SCANTMP].ensure(std::max<size_t>(1024, (nr / SCAN_TILE + 2) * 16)));
     ReadTab R;
     R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>(); R.y = B[B_Y].as<uint32_t>();
     R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>(); R.stored = B[B_STORED].as<uint32_t>();

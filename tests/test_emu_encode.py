@@ -56,6 +56,39 @@ def test_multichunk_bytewise_gather_matches_oracle(codec, monkeypatch, label, pr
     assert "gather_bytes" in dict(codec.timings())
 
 
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[3:8], ids=[m[0] for m in MULTI[3:8]])
+def test_multichunk_two_pass_index_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+    """RFQ_INDEX=2pass: newline bitmap -> scan -> line offsets (what the one-pass k_line_index falls back to when the text holds more lines than its table)."""
+    monkeypatch.setenv("RFQ_INDEX", "2pass")
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+    assert "index_2pass" in dict(codec.timings())
+
+
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:4], ids=[m[0] for m in MULTI[:4]])
+def test_multichunk_index_over_several_workgroups_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+    """RFQ_IDX_TILES=4: 64 KiB of text per workgroup of k_line_index, so that these small inputs span several and the look-back runs."""
+    monkeypatch.setenv("RFQ_IDX_TILES", "4")
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    assert len(fq1) > 3 * 65536 or paired != O.SE
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+    assert "index_2pass" not in dict(codec.timings())
+
+
+def test_line_index_falls_back_when_lines_are_short():
+    """The one-pass index sizes its table for one line per 16 bytes (+ 4096; a table an earlier call left behind is used whole: a fresh codec here);
+    a text of two-byte lines overflows it and is indexed in two passes."""
+    from repaq_amd import RfqCodec
+    codec = RfqCodec(device=0, library=E.build_emu())
+    fq1, _ = O.gen(O.NOVA_SE150, 50, seed=12)
+    assert E.encode(codec, fq1, b"", O.SE, 20000) == O.encode_file(fq1, b"", O.SE, 20000)
+    assert "index_2pass" not in dict(codec.timings())
+    tiny = b"".join(b"@%d\n%s\n+\n%s\n" % (i % 10, b"ACGT"[i % 4:i % 4 + 1], b"F") for i in range(12000))
+    assert E.encode(codec, tiny, b"", O.SE, 5000) == O.encode_file(tiny, b"", O.SE, 5000)
+    assert "index_2pass" in dict(codec.timings())
+    codec.close()
+
+
 def test_gather_paths_are_the_ones_expected(codec):
     """The tile gather (k_gather2 + k_seqpack) is what runs by default - also when a mate of an interleaved chunk holds bytes outside A/C/G/T/N
     (Read::changeToReverseComplement turns them into N, lower case into the upper-case complement) - and reads too long for a tile of two

@@ -15,7 +15,7 @@ import bench as B  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="cfg2"); ap.add_argument("--units", type=int, default=0); ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--encode-only", action="store_true"); ap.add_argument("variants", nargs="*")
+    ap.add_argument("--encode-only", action="store_true"); ap.add_argument("--check", action="store_true", help="parity of every variant (rfq md5 against the golden, decode == input)"); ap.add_argument("variants", nargs="*")
     a = ap.parse_args()
     import torch
     from repaq_amd import RfqCodec
@@ -28,10 +28,11 @@ def main():
         for k in keys: os.environ.pop(k, None)
         for k, val in env.items(): os.environ[k] = val; keys.add(k)
         w.stage = {}; w.enc_s = w.dec_s = 0.0
+        par = w.check() if a.check else None
         dt = w.run(a.steps, 1, torch.cuda.synchronize, lambda: None)
         st = {k: round(val / a.steps, 3) for k, val in w.stage.items()}
         enc = sum(val for k, val in st.items() if not k.startswith("dec:")); dec = sum(val for k, val in st.items() if k.startswith("dec:"))
-        print(json.dumps({"variant": name, "env": env, "ms_per_step": round(dt / a.steps * 1e3, 3), "enc_ms": round(enc, 3), "dec_ms": round(dec, 3), "stage_ms": st}), flush=True)
+        print(json.dumps({"variant": name, "env": env, "ms_per_step": round(dt / a.steps * 1e3, 3), "enc_ms": round(enc, 3), "dec_ms": round(dec, 3), "stage_ms": st, "parity": par}), flush=True)
     codec.close()
 
 
