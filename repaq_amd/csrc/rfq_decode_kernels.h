@@ -1653,6 +1653,9 @@ __device__ __forceinline__ uint32_t e3_rev1x16(uint32_t v) {
     v = ((v >> 8) & 0xFFu) | ((v & 0xFFu) << 8); v = ((v >> 4) & 0x0F0Fu) | ((v & 0x0F0Fu) << 4);
     v = ((v >> 2) & 0x3333u) | ((v & 0x3333u) << 2); return ((v >> 1) & 0x5555u) | ((v & 0x5555u) << 1);
 }
+// dword i of the mask "bytes >= t of a 16-byte group" (t <= 0: all of them, t >= 16: none)
+__device__ __forceinline__ uint32_t e3_from(int t, int i) { const int k = t - 4 * i; return k <= 0 ? 0xFFFFFFFFu : (k >= 4 ? 0u : 0xFFFFFFFFu << (8 * k)); }
+__device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }   // v_alignbyte_b32
 template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
@@ -1660,7 +1663,8 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
     __shared__ uint4 t_q4[E3_QCAP / 16 + 6];                                // quality tile (16 bytes of slack in front, the rest behind)
     __shared__ uint4 t_pk4[E3_QCAP / 64 + 6];                               // the tile's packed bases
     __shared__ uint32_t t_nb[E3_QCAP / 32 + 8];                             // one bit per stored base of the tile: is N
-    __shared__ uint4 t_mid4[64 * 40 / 16 + 4], t_n14[ET_N1CAP / 16 + 4], t_n24[ET_N2CAP / 16 + 4], t_st4[ET_STCAP / 16 + 4];
+    __shared__ uint4 t_mid4_[64 * 40 / 16 + 5], t_n14_[ET_N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];
+    uint4* const t_mid4 = t_mid4_ + 1; uint4* const t_n14 = t_n14_ + 1; uint4* const t_n24 = t_n24_ + 1;   // (16 readable bytes in front of each: a 16-byte group of the name line may start before a piece)
     __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
     __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2];
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
@@ -1800,12 +1804,42 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
             const uint32_t e0 = n1 + md + n2, oseq = e0 + 1u, ost = oseq + len + 1u, oq = ost + sl + 1u, total = oq + len + 1u;
             if ((uint64_t)toff + total > capo) { if (part == 0) atomicOr(&st->err, 1u << 31); }
             else {
-                // names, strand, line ends: one lane each (short pieces)
-                if (part == 0) e3_copy(rec, (const uint8_t*)t_n14 + (uint32_t)(n1a & 15ull) + (same1 ? 0u : o7), n1, 0, 1, -1, 0);
-                else if (part == 1 % P) e3_copy(rec + n1, (const uint8_t*)t_mid4 + (uint32_t)(((uint64_t)g0 * 40) & 15ull) + 40u * j, md, 0, 1, -1, 0);
-                if (part == 2 % P) e3_copy(rec + n1 + md, (const uint8_t*)t_n24 + (uint32_t)(n2a & 15ull) + (same2 ? 0u : o8), n2, 0, 1, (same2 && rc && dch != 0 && dpos < n2) ? (int)dpos : -1, dch);
-                if (part == 3 % P) { e3_copy(rec + ost, (const uint8_t*)t_st4 + (uint32_t)(sta & 15ull) + (same3 ? 0u : o9), sl, 0, 1, -1, 0);
-                                     rec[e0] = '\n'; rec[ost - 1u] = '\n'; rec[oq - 1u] = '\n'; rec[total - 1u] = '\n'; }
+                // The name line = name1 + middle + name2 + '\n' (three LDS pieces at arbitrary byte offsets): a lane builds a whole 16-byte group of the line
+                // in registers - one unaligned 16-byte LDS read per piece the group touches, later pieces laid over the earlier ones from their first byte
+                // on - and stores it once.  (Piece by piece this was ~10 partial stores per read: 1.4 ms of the kernel's 5.1 on 2 x 4 GB.)
+                const uint32_t L = e0 + 1u; const bool nfast = L >= 16u, jfast = sl == 1u && len >= 16u;
+                const uint8_t* const src1 = (const uint8_t*)t_n14 + (uint32_t)(n1a & 15ull) + (same1 ? 0u : o7);
+                const uint8_t* const src2 = (const uint8_t*)t_mid4 + (uint32_t)(((uint64_t)g0 * 40) & 15ull) + 40u * j;
+                const uint8_t* const src3 = (const uint8_t*)t_n24 + (uint32_t)(n2a & 15ull) + (same2 ? 0u : o8);
+                const uint8_t* const src4 = (const uint8_t*)t_st4 + (uint32_t)(sta & 15ull) + (same3 ? 0u : o9);
+                const int pat2 = (same2 && rc && dch != 0 && dpos < n2) ? (int)dpos : -1;
+                if (abl & 128) {}
+                else if (nfast) {
+                    const uint32_t ngl = (L + 15u) >> 4;
+                    for (uint32_t gi = part; gi < ngl; gi += P) {
+                        uint32_t p0 = 16u * gi; if (p0 + 16u > L) p0 = L - 16u;
+                        const int t1 = (int)n1 - (int)p0, t2 = t1 + (int)md, t3 = t2 + (int)n2;          // where the middle, name2 and the '\n' start in this group
+                        uint32_t w[4] = { 0, 0, 0, 0 }, x[4];
+                        if (t1 > 0) lds_get16(src1 + p0, 0, w);
+                        if (t1 < 16 && t2 > 0 && md) { lds_get16(src2 - t1, 0, x);
+#pragma unroll
+                            for (int i = 0; i < 4; i++) { const uint32_t m = e3_from(t1, i); w[i] = (w[i] & ~m) | (x[i] & m); } }
+                        if (t2 < 16 && t3 > 0 && n2) { lds_get16(src3 - t2, 0, x);
+                            if (pat2 >= 0) { const int b = t2 + pat2; if (b >= 0 && b < 16) { const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& y = x[b >> 2]; y = (y & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); } }
+#pragma unroll
+                            for (int i = 0; i < 4; i++) { const uint32_t m = e3_from(t2, i); w[i] = (w[i] & ~m) | (x[i] & m); } }
+                        if (t3 == 15) w[3] = (w[3] & 0x00FFFFFFu) | 0x0A000000u;                           // (the line's last byte, in its last group only)
+                        GU16d v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16d*)(rec + p0) = v;
+                    }
+                } else {
+                    if (part == 0) e3_copy(rec, src1, n1, 0, 1, -1, 0);
+                    else if (part == 1 % P) e3_copy(rec + n1, src2, md, 0, 1, -1, 0);
+                    if (part == 2 % P) e3_copy(rec + n1 + md, src3, n2, 0, 1, pat2, dch);
+                    if (part == 3 % P) rec[e0] = '\n';
+                }
+                // "\n" + strand + "\n" behind the bases and the '\n' behind the qualities ride on the last 16-byte stores of those lines when the strand line is
+                // one character (below); otherwise they are written here
+                if (!jfast && !(abl & 128) && part == 3 % P) { e3_copy(rec + ost, src4, sl, 0, 1, -1, 0); rec[ost - 1u] = '\n'; rec[oq - 1u] = '\n'; rec[total - 1u] = '\n'; }
                 // bases and qualities, 16 positions per step.  I = the read in interleaved orientation: I[p] = stored[A + p] for p < xa, stored[Bs + p - xa] behind
                 // (the part of a mate that overlaps R1 is R1's: src/rfqcodec.cpp:865-897); the output is I, or its reverse complement for an interleaved chunk's mate
                 const uint32_t xa = ov < 0 ? len - (uint32_t)(-ov) : len; const uint32_t A = ov > 0 ? sp - (uint32_t)ov : sp, Bs = sp - prevlen;
@@ -1815,8 +1849,8 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
                     const uint32_t nb_ = lds_get4((const uint8_t*)t_nb, (si >> 3)) >> (si & 7u); nw = nb_ & 0xFFFFu;
                     if (byte + 5u > have) { uint32_t lim_ = 4u * have > sbit0 / 2u + si ? 4u * have - sbit0 / 2u - si : 0u; if (lim_ < 16u) nw |= (0xFFFFu << lim_) & 0xFFFFu; }   // bases past the packed buffer read as N (the reference's 'N' prefill)
                 };
-                auto group = [&](uint32_t k0) {                               // output positions [k0, k0 + 16) of both lines (k0 + 16 <= len)
-                    uint32_t qw[4]; const uint32_t pa = rc ? len - k0 - 16u : k0;
+                auto group = [&](uint32_t k0, uint32_t (&qw)[4], uint32_t (&sw)[4]) {   // output positions [k0, k0 + 16) of both lines (k0 + 16 <= len)
+                    const uint32_t pa = rc ? len - k0 - 16u : k0;
                     lds_get16(q_t, qp_ + pa, qw);
                     uint32_t cw, nw;
                     if (pa + 16u <= xa) fetch(A + pa, cw, nw);
@@ -1824,7 +1858,6 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
                     else { uint32_t c2, n2_; const uint32_t t1 = xa - pa; fetch(A + pa, cw, nw); fetch(Bs, c2, n2_); cw = (cw & ((1u << (2u * t1)) - 1u)) | (c2 << (2u * t1)); nw = (nw & ((1u << t1) - 1u)) | ((n2_ << t1) & 0xFFFFu); }
                     if (rc) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3;
                               cw = ~e3_rev2x16(cw); if (nw) nw = e3_rev1x16(nw); }
-                    uint32_t sw[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) { const uint32_t b = (cw >> (8 * i)) & 0xFFu, y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u; sw[i] = __builtin_amdgcn_perm(0u, 0x43544147u, idx); }
                     if (nw) {                                                   // (rare: an N among the 16)
@@ -1835,12 +1868,28 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const uint32_t mk = eq_bytes_full(qw[i], nq4); sw[i] = (sw[i] & ~mk) | (0x4E4E4E4Eu & mk); }
                     }
-                    GU16d v; v.a = qw[0]; v.b = qw[1]; v.c = qw[2]; v.d = qw[3]; *(GU16d*)(rec + oq + k0) = v;
-                    v.a = sw[0]; v.b = sw[1]; v.c = sw[2]; v.d = sw[3]; *(GU16d*)(rec + oseq + k0) = v;
+                };
+                auto put = [&](uint32_t at_q, uint32_t at_s, const uint32_t (&qw)[4], const uint32_t (&sw)[4], bool both) {
+                    if (abl & 64) { if ((qw[0] ^ sw[1] ^ qw[2] ^ sw[3] ^ sw[0] ^ qw[1] ^ sw[2] ^ qw[3]) == 0x12345678u) rec[0] = 1; return; }     // (ablation: everything but the stores)
+                    GU16d v;
+                    if (both) { v.a = qw[0]; v.b = qw[1]; v.c = qw[2]; v.d = qw[3]; *(GU16d*)(rec + at_q) = v; }
+                    v.a = sw[0]; v.b = sw[1]; v.c = sw[2]; v.d = sw[3]; *(GU16d*)(rec + at_s) = v;
                 };
                 if (len >= 16u) {
-                    const uint32_t ng = (len + 15u) >> 4;
-                    for (uint32_t gi = part; gi < ng; gi += P) { uint32_t k0 = 16u * gi; if (k0 + 16u > len) k0 = len - 16u; group(k0); }
+                    const uint32_t nfull = len >> 4, rem = len & 15u; uint32_t qw[4], sw[4];
+                    for (uint32_t gi = part; gi < nfull; gi += P) { group(16u * gi, qw, sw); put(oq + 16u * gi, oseq + 16u * gi, qw, sw, true); }
+                    if ((nfull & (P - 1u)) == part && (rem || jfast)) {       // the lines' tails: positions [len - 16, len)
+                        group(len - 16u, qw, sw);
+                        if (!jfast) put(oq + len - 16u, oseq + len - 16u, qw, sw, true);
+                        else {
+                            if (rem > 13u) put(0u, oseq + len - 16u, qw, sw, false);                       // (the shifted store below starts behind position 16 * nfull)
+                            const uint32_t jd = 0x000A000Au | ((uint32_t)src4[0] << 8);                    // '\n', the strand character, '\n'
+                            uint32_t qs[4], ss[4];
+                            ss[0] = e3_align(sw[1], sw[0], 3); ss[1] = e3_align(sw[2], sw[1], 3); ss[2] = e3_align(sw[3], sw[2], 3); ss[3] = e3_align(jd, sw[3], 3);
+                            qs[0] = e3_align(qw[1], qw[0], 1); qs[1] = e3_align(qw[2], qw[1], 1); qs[2] = e3_align(qw[3], qw[2], 1); qs[3] = e3_align(0x0Au, qw[3], 1);
+                            put(oq + len - 15u, oseq + len - 13u, qs, ss, true);
+                        }
+                    }
                 } else if (part == 0) {
                     for (uint32_t k = 0; k < len; k++) {                      // a read of < 16 bases: byte by byte
                         const uint32_t p = rc ? len - 1u - k : k, si = p < xa ? A + p : Bs + (p - xa);

@@ -77,6 +77,38 @@ def test_emitters_are_the_ones_expected(codec):
     assert codec.decode_bytes(rfq) == fq
 
 
+def _handmade(n, name_of, len_of, strand_of, seed):
+    import random
+    rnd = random.Random(seed); out = []
+    for i in range(n):
+        ln = len_of(i); seq = "".join(rnd.choice("ACGT") if rnd.random() > 0.01 else "N" for _ in range(ln))
+        qual = "".join("#" if c == "N" else rnd.choice("FFFFFF:,") for c in seq)
+        out.append("@%s\n%s\n%s\n%s\n" % (name_of(i), seq, strand_of(i), qual))
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("label,name_of,strand_of", [
+    ("novaseq_names", lambda i: "A00123:45:HXXYYDSXX:1:1101:%d:%d 1:N:0:ACGTACGT" % (1000 + 7 * i, 2000 + i), lambda i: "+"),
+    ("short_names", lambda i: "a:1:b:1:2:%d:%d x" % (1 + i % 120, 3 + i % 95), lambda i: "+"),         # name lines of 17 .. 21 bytes
+    ("tiny_names", lambda i: "a:1:b:1:2:%d:%d" % (i % 9, i % 7), lambda i: "+"),                       # name lines of < 16 bytes
+    ("strand_text", lambda i: "A00123:45:HXXYYDSXX:1:1101:%d:%d" % (1000 + i, 2000 + i), lambda i: "+strand"),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_fixed_tile_emitter_line_shapes(codec, label, name_of, strand_of):
+    """k_dec_emit3 writes the name line as whole 16-byte groups merged from its three pieces, and lets "\\n+\\n" and the last '\\n' ride on the last
+    stores of the base / quality lines: every read length 1 .. 70 (all residues mod 16, reads shorter than one group) under name lines shorter
+    than, around and well above 16 bytes, and strand lines that carry text (written piece by piece)."""
+    fq = _handmade(420, name_of, lambda i: 1 + (i * 11) % 70, strand_of, seed=len(label))
+    for cb in (900, 100000):
+        rfq = O.encode_file(fq, b"", O.SE, cb)
+        assert O.decode_file(rfq) == fq
+        assert codec.decode_bytes(rfq) == fq
+        assert label in ("tiny_names", "strand_text") or "emit" in dict(codec.timings()), dict(codec.timings())   # (those two hold per-read pieces: k_dec_emit2)
+    fq2 = _handmade(420, name_of, lambda i: 1 + (i * 11) % 70, strand_of, seed=99)
+    rfq = O.encode_file(fq, fq2, O.PE_TWO_FILES, 2000)
+    assert codec.decode_bytes(rfq, split_pe=True) == (fq, fq2)
+    assert codec.decode_bytes(rfq, split_pe=False) == O.decode_file(rfq, split_pe=False)          # (interleaved text: the mates in stored orientation)
+
+
 def test_chunk_starts_without_an_index(codec, monkeypatch):
     """A .rfq has no chunk index: the decoder guesses segment starts, walks the segments in parallel and verifies every extent (k_dec_gw_*);
     RFQ_WALK=chain is the one-wave chain it falls back to.  Small segments (RFQ_GW_SHIFT) so that a small image has several."""
