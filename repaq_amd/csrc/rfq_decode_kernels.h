@@ -393,19 +393,21 @@ __global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __re
 
 // ---- token-boundary automaton: state = bytes of the current token still to skip (0 = next byte starts a token).
 // A byte's transition is s>0 ? s-1 : len(byte)-1; composition of 4-entry tables is associative -> wave scan.
-__device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) {     // (then o first)[s] = then[first[s]]
-    uint32_t r = 0;
-#pragma unroll
-    for (int s = 0; s < 4; s++) r |= ((then >> (2 * ((first >> (2 * s)) & 3u))) & 3u) << (2 * s);
-    return r;
-}
+// A table is four bytes, byte s = the state that follows state s: composing two tables is ONE v_perm_b32 (the first table's bytes select bytes of
+// the second).  (Two bits per state in one byte - the form the segment summaries are stored in, fn_pack8 - made a composition ~28 instructions, and a
+// step's wave scan composes nine times: most of what the position-list passes executed.)
+__device__ __forceinline__ uint32_t fn_compose(uint32_t first, uint32_t then) { return __builtin_amdgcn_perm(0u, then, first); }    // (then o first)[s] = then[first[s]]
+__device__ __forceinline__ uint32_t fn_apply(uint32_t F, uint32_t s) { return (F >> (8u * s)) & 3u; }
+__device__ __forceinline__ uint32_t fn_of_len(uint32_t tok_len) { return 0x02010000u | (tok_len - 1u); }                            // s > 0 ? s - 1 : len - 1
+__device__ __forceinline__ uint32_t fn_pack8(uint32_t F) { return (F & 3u) | ((F >> 6) & 0xCu) | ((F >> 12) & 0x30u) | ((F >> 18) & 0xC0u); }
+__device__ __forceinline__ uint32_t fn_unpack8(uint32_t b) { return (b & 3u) | ((b & 0xCu) << 6) | ((b & 0x30u) << 12) | ((b & 0xC0u) << 18); }
 // returns the state BEFORE this lane's byte; carry = state after the wave's last byte
 __device__ __forceinline__ uint32_t wave_token_states(uint32_t tok_len, bool valid, uint32_t& carry) {
     const int l = lane_id();
-    uint32_t f = valid ? ((tok_len - 1u) | (0u << 2) | (1u << 4) | (2u << 6)) : (0u | (1u << 2) | (2u << 4) | (3u << 6));
+    uint32_t f = valid ? fn_of_len(tok_len) : 0x03020100u;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(f, (unsigned)d); if (l >= d) f = fn_compose(t, f); }
-    const uint32_t after = (f >> (2 * carry)) & 3u;
+    const uint32_t after = fn_apply(f, carry);
     uint32_t before = __shfl_up(after, 1u); if (l == 0) before = carry;
     carry = __shfl(after, 63);
     return before;
@@ -442,11 +444,11 @@ __device__ __forceinline__ unsigned long long pos_bytes8(const PosStep& r, const
 // One step = 256 stream bytes, 4 per lane.  pos_front: the lane's bytes, their transition tables and Fin = the composed table of all
 // bytes of the step up to and including the lane's (one wave scan).
 struct PosFront { unsigned long long v; uint32_t bt[4], fn[4], Fin; };
-#define POS_ID (0u | (1u << 2) | (2u << 4) | (3u << 6))
+#define POS_ID 0x03020100u
 __device__ __forceinline__ PosFront pos_front(const PosStep& w, const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0, int l) {
     PosFront f; f.v = pos_bytes8(w, sp, slen, i0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const bool valid = i0 + (uint32_t)k < slen; f.bt[k] = (uint32_t)(f.v >> (8 * k)) & 0xFFu; f.fn[k] = valid ? ((pos_tok_len(f.bt[k]) - 1u) | (0u << 2) | (1u << 4) | (2u << 6)) : POS_ID; }
+    for (int k = 0; k < 4; k++) { const bool valid = i0 + (uint32_t)k < slen; f.bt[k] = (uint32_t)(f.v >> (8 * k)) & 0xFFu; f.fn[k] = valid ? fn_of_len(pos_tok_len(f.bt[k])) : POS_ID; }
     uint32_t F = fn_compose(fn_compose(fn_compose(f.fn[0], f.fn[1]), f.fn[2]), f.fn[3]);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(F, (unsigned)d); if (l >= d) F = fn_compose(t, F); }
@@ -466,7 +468,7 @@ __device__ __forceinline__ int pos_lane_adv(const PosFront& f, uint32_t slen, ui
             else if ((b0 & 0x20u) == 0) a += (int)(b0 & 0x1Fu) + 1;
             else a += (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
         }
-        if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
+        if (valid) st = fn_apply(f.fn[k], st);
     }
     return a;
 }
@@ -485,7 +487,7 @@ __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, 
         const PosStep cur = nxt;
         if (base + 256 < b1_) nxt = pos_fetch(sp, slen, i0 + 256u, lim);    // the next step's words are in flight while this one is decoded
         const PosFront f = pos_front(cur, sp, slen, i0, l);
-        const uint32_t after = (f.Fin >> (2 * carry)) & 3u;                  // state after my 4 bytes
+        const uint32_t after = fn_apply(f.Fin, carry);                  // state after my 4 bytes
         uint32_t st = __shfl_up(after, 1u); if (l == 0) st = carry;         // state in front of my first byte
         carry = __shfl(after, 63);
         int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0;
@@ -501,7 +503,7 @@ __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, 
                 else adv[k] = (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1;
             }
             lane_adv += adv[k];
-            if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
+            if (valid) st = fn_apply(f.fn[k], st);
         }
         const int incl = wave_incl_sum(lane_adv);
         int end = last + incl - lane_adv;                                    // last covered position in front of my tokens
@@ -574,7 +576,7 @@ __global__ void k_dec_pos_sum(const uint8_t* __restrict__ img, const DChunk* __r
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
     if (l == 0) {
         const size_t idx = ((size_t)c * nstr + jj) * maxseg + g;
-        segF[idx] = (uint8_t)Fcum; segA[4 * idx + 0] = a0; segA[4 * idx + 1] = a1; segA[4 * idx + 2] = a2; segA[4 * idx + 3] = a3;
+        segF[idx] = (uint8_t)fn_pack8(Fcum); segA[4 * idx + 0] = a0; segA[4 * idx + 1] = a1; segA[4 * idx + 2] = a2; segA[4 * idx + 3] = a3;
     }
 }
 // one thread per (chunk, stream): entry state and entry position of every segment
@@ -585,7 +587,7 @@ __global__ void k_dec_pos_link(const uint8_t* __restrict__ segF, const int* __re
     for (uint32_t g = 0; g < n; g++) {
         const size_t idx = (size_t)t * maxseg + g;
         segS[idx] = (uint8_t)st; segP[idx] = last;
-        last += segA[4 * idx + st]; st = ((uint32_t)segF[idx] >> (2 * st)) & 3u;
+        last += segA[4 * idx + st]; st = fn_apply(fn_unpack8(segF[idx]), st);
     }
 }
 // grid (maxseg, nn + 1, n_chunks): normal quality streams -> qdec, N positions -> sdec
@@ -643,7 +645,7 @@ __device__ __forceinline__ void pos_lane_adv_cnt(const PosFront& f, uint32_t sle
             else if ((b0 & 0x20u) == 0) { adv += (int)(b0 & 0x1Fu) + 1; cnt += (int)(b0 & 0x1Fu) + 1; }
             else { adv += (int)(((b0 & 0x1Fu) << 24) | (b1 << 16) | (b2 << 8) | b3) + 1; cnt++; }
         }
-        if (valid) st = (f.fn[k] >> (2 * st)) & 3u;
+        if (valid) st = fn_apply(f.fn[k], st);
     }
 }
 __device__ __forceinline__ int sel4(const int (&v)[4], uint32_t t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
@@ -691,12 +693,12 @@ __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __
         const uint32_t G = fn_compose(Fcum, Fex);                          // segment entry state -> state in front of my bytes
         int la[4], lc[4]; pos_lane_adv_cnt4(f, s.slen, i0, la, lc);         // the lane's tokens for each state in front of its bytes
 #pragma unroll
-        for (int e = 0; e < 4; e++) { const uint32_t t_ = (G >> (2 * e)) & 3u; a[e] += sel4(la, t_); n[e] += sel4(lc, t_); }
+        for (int e = 0; e < 4; e++) { const uint32_t t_ = fn_apply(G, e); a[e] += sel4(la, t_); n[e] += sel4(lc, t_); }
         Fcum = fn_compose(Fcum, __shfl(f.Fin, 63));
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) { a[e] = wave_sum(a[e]); n[e] = wave_sum(n[e]); }
-    if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)Fcum;
+    if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)fn_pack8(Fcum);
 #pragma unroll
                   for (int e = 0; e < 4; e++) { segA[8 * idx + e] = a[e]; segA[8 * idx + 4 + e] = n[e]; } }
 }
@@ -706,7 +708,7 @@ struct PosLink { uint32_t F; int a[4], n[4]; };
 __device__ __forceinline__ PosLink poslink_then(const PosLink& x, const PosLink& y) {   // x first, then y
     PosLink r; r.F = fn_compose(x.F, y.F);
 #pragma unroll
-    for (int s = 0; s < 4; s++) { const uint32_t t = (x.F >> (2 * s)) & 3u; r.a[s] = x.a[s] + sel4(y.a, t); r.n[s] = x.n[s] + sel4(y.n, t); }
+    for (int s = 0; s < 4; s++) { const uint32_t t = fn_apply(x.F, s); r.a[s] = x.a[s] + sel4(y.a, t); r.n[s] = x.n[s] + sel4(y.n, t); }
     return r;
 }
 __device__ __forceinline__ PosLink poslink_shfl_up(const PosLink& v, unsigned dd) {
@@ -725,7 +727,7 @@ __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __r
         PosLink me; me.F = POS_ID;
 #pragma unroll
         for (int s = 0; s < 4; s++) { me.a[s] = 0; me.n[s] = 0; }
-        if (g < n) { me.F = segF[idx];
+        if (g < n) { me.F = fn_unpack8(segF[idx]);
 #pragma unroll
                      for (int s = 0; s < 4; s++) { me.a[s] = segA[8 * idx + s]; me.n[s] = segA[8 * idx + 4 + s]; } }
         PosLink inc = me;
@@ -735,11 +737,11 @@ __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __r
         if (l == 0) { ex.F = POS_ID;
 #pragma unroll
                       for (int s = 0; s < 4; s++) { ex.a[s] = 0; ex.n[s] = 0; } }
-        if (g < n) { segS[idx] = (uint8_t)((ex.F >> (2 * cs)) & 3u); segP[idx] = cp + sel4(ex.a, cs); segK[idx] = ck + (uint32_t)sel4(ex.n, cs); }
+        if (g < n) { segS[idx] = (uint8_t)(fn_apply(ex.F, cs)); segP[idx] = cp + sel4(ex.a, cs); segK[idx] = ck + (uint32_t)sel4(ex.n, cs); }
         const uint32_t Fl = __shfl(inc.F, 63); int al[4], nl[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) { al[s] = __shfl(inc.a[s], 63); nl[s] = __shfl(inc.n[s], 63); }
-        cp += sel4(al, cs); ck += (uint32_t)sel4(nl, cs); cs = (Fl >> (2 * cs)) & 3u;
+        cp += sel4(al, cs); ck += (uint32_t)sel4(nl, cs); cs = fn_apply(Fl, cs);
     }
     if (l == 0) nent[t] = ck;
 }
@@ -775,7 +777,7 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
         if (base + 256u < b1) nxt = pos_fetch(s.sp, s.slen, i0 + 256u, lim);
         const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
         uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
-        uint32_t st0 = (Fex >> (2 * carry)) & 3u;                          // state in front of my first byte
+        uint32_t st0 = fn_apply(Fex, carry);                          // state in front of my first byte
         int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0, lane_cnt = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -790,7 +792,7 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
                 lane_cnt += run[k] ? (int)run[k] : 1;
             }
             lane_adv += adv[k];
-            if (valid) st0 = (f.fn[k] >> (2 * st0)) & 3u;
+            if (valid) st0 = fn_apply(f.fn[k], st0);
         }
         const int ia = wave_incl_sum(lane_adv), ic = wave_incl_sum(lane_cnt);
         int end = last + ia - lane_adv; uint32_t k = k0 + (uint32_t)(ic - lane_cnt);   // last covered position / list index in front of my tokens
@@ -807,7 +809,7 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
                 pp = p;
             }
         }
-        last += __shfl(ia, 63); k0 += (uint32_t)__shfl(ic, 63); carry = (__shfl(f.Fin, 63) >> (2 * carry)) & 3u;
+        last += __shfl(ia, 63); k0 += (uint32_t)__shfl(ic, 63); carry = fn_apply((uint32_t)__shfl(f.Fin, 63), carry);
     }
 }
 
