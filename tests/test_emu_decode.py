@@ -77,12 +77,12 @@ def test_emitters_are_the_ones_expected(codec):
     assert codec.decode_bytes(rfq) == fq
 
 
-def _handmade(n, name_of, len_of, strand_of, seed):
+def _handmade(n, name_of, len_of, strand_of, seed, qual_of=None):
     import random
     rnd = random.Random(seed); out = []
     for i in range(n):
         ln = len_of(i); seq = "".join(rnd.choice("ACGT") if rnd.random() > 0.01 else "N" for _ in range(ln))
-        qual = "".join("#" if c == "N" else rnd.choice("FFFFFF:,") for c in seq)
+        qual = "".join("#" if c == "N" else (qual_of(i, j) if qual_of else rnd.choice("FFFFFF:,")) for j, c in enumerate(seq))
         out.append("@%s\n%s\n%s\n%s\n" % (name_of(i), seq, strand_of(i), qual))
     return "".join(out).encode()
 
@@ -107,6 +107,18 @@ def test_fixed_tile_emitter_line_shapes(codec, label, name_of, strand_of):
     rfq = O.encode_file(fq, fq2, O.PE_TWO_FILES, 2000)
     assert codec.decode_bytes(rfq, split_pe=True) == (fq, fq2)
     assert codec.decode_bytes(rfq, split_pe=False) == O.decode_file(rfq, split_pe=False)          # (interleaved text: the mates in stored orientation)
+
+
+def test_position_lists_of_long_runs(codec):
+    """Long runs of a minority quality value: a 256-byte step of its position stream codes thousands of list entries, more than the 1024 a wave
+    of k_dec_pos_list fills in at a time (run tokens whose entries straddle the windows), next to streams of single positions."""
+    nm = lambda i: "A00123:45:HXXYYDSXX:1:1101:%d:%d 1:N:0:ACGT" % (1000 + 3 * i, 2000 + i)
+    fq = _handmade(900, nm, lambda i: 150, lambda i: "+", seed=5, qual_of=lambda i, j: "F" if j < 78 + (i % 5) else ("," if (i + j) % 41 else ":"))
+    for cb in (30000, 1_000_000):
+        rfq = O.encode_file(fq, b"", O.SE, cb)
+        assert O.decode_file(rfq) == fq
+        assert codec.decode_bytes(rfq) == fq
+        assert "emit" in dict(codec.timings())
 
 
 def test_chunk_starts_without_an_index(codec, monkeypatch):
