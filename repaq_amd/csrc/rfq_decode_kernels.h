@@ -569,8 +569,8 @@ __global__ void k_dec_pos_sum(const uint8_t* __restrict__ img, const DChunk* __r
         const PosFront f = pos_front(cur, s.sp, s.slen, i0, l);
         uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
         const uint32_t G = fn_compose(Fcum, Fex);                            // segment entry state -> state in front of my bytes
-        a0 += pos_lane_adv(f, s.slen, i0, (G >> 0) & 3u); a1 += pos_lane_adv(f, s.slen, i0, (G >> 2) & 3u);
-        a2 += pos_lane_adv(f, s.slen, i0, (G >> 4) & 3u); a3 += pos_lane_adv(f, s.slen, i0, (G >> 6) & 3u);
+        a0 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 0u)); a1 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 1u));
+        a2 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 2u)); a3 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 3u));
         Fcum = fn_compose(Fcum, __shfl(f.Fin, 63));
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);

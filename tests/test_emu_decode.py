@@ -177,11 +177,17 @@ def test_decode_in_slices_equals_one_shot(codec, step):
 
 @pytest.mark.parametrize("prof,reads,kw", [(O.NOVA_SE150, 7500, {}), (O.BGI_PE100, 6000, dict(n_quals=40)), (O.NOVA_SE150, 7500, dict(nppm=5000))],
                          ids=["se150", "bgi_q40", "se150_manyN"])
-def test_full_size_chunk_position_streams_span_many_segments(codec, prof, reads, kw):
-    """-k 1000 chunks: position streams of 10-100 KB are decoded in 2 KB segments by independent waves (k_dec_pos_sum / link / emit)."""
+def test_full_size_chunk_position_streams_span_many_segments(codec, monkeypatch, prof, reads, kw):
+    """-k 1000 chunks: position streams of 10-100 KB are decoded in 1 KB / 2 KB segments by independent waves, which enter them in any of the token
+    automaton's states - by the list passes (k_dec_pos_sum2 / link2 / list) and, RFQ_TUNE=2048, by the materialising path a streaming caller's
+    non-final slices take (k_dec_pos_sum / link / emit)."""
     fq1, fq2 = O.gen(prof, reads, seed=9, **kw)
     rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES if fq2 else O.SE, 1_000_000)
     assert codec.decode_bytes(rfq, split_pe=bool(fq2)) == ((fq1, fq2) if fq2 else fq1)
+    assert "emit" in dict(codec.timings()) or "emit2" in dict(codec.timings())
+    monkeypatch.setenv("RFQ_TUNE", "2048")
+    assert codec.decode_bytes(rfq, split_pe=bool(fq2)) == ((fq1, fq2) if fq2 else fq1)
+    assert "textlen" in dict(codec.timings()), dict(codec.timings())           # (a stage of its own only on that path)
 
 
 def _first_diff_cases():
