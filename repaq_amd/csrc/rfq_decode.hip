@@ -289,7 +289,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> (getenv("RFQ_GW_SHIFT") ? atoi(getenv("RFQ_GW_SHIFT")) : 16)));   // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
             if (mseg > 1) hipLaunchKernelGGL(k_dec_gw_find, dim3(16, mseg - 1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, cand, mseg);
             hipLaunchKernelGGL(k_dec_gw_walk, dim3(mseg), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, B[DB_GWLIST].as<unsigned long long>(), B[DB_GWCNT].as<uint32_t>(), B[DB_GWLAND].as<unsigned long long>(), gbad, mseg);
-            hipLaunchKernelGGL(k_dec_gw_stitch, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, (const unsigned long long*)B[DB_GWLIST].as<unsigned long long>(),
+            hipLaunchKernelGGL(k_dec_gw_stitch, dim3(1), dim3(1024), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, (const unsigned long long*)B[DB_GWLIST].as<unsigned long long>(),
                                (const uint32_t*)B[DB_GWCNT].as<uint32_t>(), (const unsigned long long*)B[DB_GWLAND].as<unsigned long long>(), (const uint32_t*)gbad, B[DB_OFFT].as<uint64_t>(), cap, dst, mseg);
             hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), 0xFFFFFFFFu, B[DB_CHUNKS].as<DChunk>(), dst);
         }

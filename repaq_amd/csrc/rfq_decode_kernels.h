@@ -222,18 +222,32 @@ __global__ void k_dec_gw_find(const uint8_t* __restrict__ img, uint64_t n, uint6
     const uint32_t hf = D->flags; const GwGeo g = gw_geo(img, n, start, hf, max_seg);
     const uint32_t k = blockIdx.y + 1u; if (k >= g.nseg) return;
     const uint64_t g0 = start + (uint64_t)k * g.seglen;
-    // first the two bytes that are almost never right by chance - read count < 2^24, flags < 0x1000: one unaligned dword, 1 offset in 4096 passes.
-    // Eight offsets per round, their loads in flight together: a thread's offsets one after the other were ~160 dependent round trips (174 us for 135 MB).
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.win; i += 8ull * stride) {
-        uint32_t w[8];
+    // first the two bytes that are almost never right by chance - read count < 2^24, flags < 0x1000 (bytes 6 .. 9 of a header): 1 offset in 4096 passes.
+    // A thread tests 16 consecutive offsets from two 16-byte loads (the 19 bytes they look at); two such groups per round, their loads in flight
+    // together.  (One dword load per offset - a wave instruction for 67 useful bytes, a thread's offsets one dependent round trip after the other - was
+    // 171 us for the 135 MB of the bench image's windows.)
+    const uint64_t stride = 16ull * gridDim.x * blockDim.x;
+    for (uint64_t i = 16ull * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x); i < g.win; i += 2ull * stride) {
+        uint32_t d[2][8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const uint64_t ii = i + (uint64_t)j * stride, o = g0 + ii; w[j] = (ii < g.win && o + 18 <= n) ? ((const LdsU4*)(img + o + 6))->a : 0xFFFFFFFFu; }
+        for (int u = 0; u < 2; u++) {
+            const uint64_t ii = i + (uint64_t)u * stride; const bool in = ii < g.win && g0 + ii + 6 + 32 <= n;      // (loads without a branch around them)
+            const uint8_t* p = img + (in ? g0 + ii : g0) + 6;
+            const LdsU16 x = *(const LdsU16*)p, y = *(const LdsU16*)(p + 16);
+            d[u][0] = x.a; d[u][1] = x.b; d[u][2] = x.c; d[u][3] = x.d; d[u][4] = y.a; d[u][5] = y.b; d[u][6] = y.c; d[u][7] = y.d;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (w[j] & 0xF000FF00u) continue;
-            const uint64_t o = g0 + i + (uint64_t)j * stride;
-            if (gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k], (unsigned long long)o);
+        for (int u = 0; u < 2; u++) {
+            const uint64_t ii = i + (uint64_t)u * stride;
+            if (ii >= g.win) continue;
+            if (g0 + ii + 6 + 32 > n) {                                       // the image's last bytes: offset by offset
+                for (uint32_t j = 0; j < 16 && ii + j < g.win; j++) { const uint64_t o = g0 + ii + j; if (o + 18 <= n && !(((const LdsU4*)(img + o + 6))->a & 0xF000FF00u) && gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k], (unsigned long long)o); }
+                continue;
+            }
+            uint32_t hit = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const uint32_t w = (uint32_t)((((unsigned long long)d[u][(j >> 2) + 1] << 32) | d[u][j >> 2]) >> (8 * (j & 3))); if (!(w & 0xF000FF00u)) hit |= 1u << j; }
+            while (hit) { const int j = __ffs((int)hit) - 1; hit &= hit - 1; const uint64_t o = g0 + ii + (uint32_t)j; if (ii + (uint32_t)j < g.win && o + 18 <= n && gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k], (unsigned long long)o); }
         }
     }
 }
@@ -257,7 +271,7 @@ __global__ void k_dec_gw_walk(const uint8_t* __restrict__ img, uint64_t n, uint6
     if (lane_id() == 0) { cnt[k] = c | (ended << 31); land[k] = o; if (b) atomicOr(bad, 1u); }     // (bit 31: the chain ended in this segment)
 }
 // every walk must land on the next candidate; the lists, concatenated, are the chunk index (off[0 .. n_chunks], the last entry = where the chain ended)
-__global__ void k_dec_gw_stitch(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, const unsigned long long* __restrict__ cand,
+__global__ void __launch_bounds__(1024) k_dec_gw_stitch(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, const unsigned long long* __restrict__ cand,
                                 const unsigned long long* __restrict__ list, const uint32_t* __restrict__ cnt, const unsigned long long* __restrict__ land, const uint32_t* __restrict__ bad,
                                 uint64_t* __restrict__ off, uint32_t cap, DecStatus* st, uint32_t max_seg) {
     __shared__ uint32_t s_base[GW_SEGS + 1], s_cnt[GW_SEGS]; __shared__ unsigned long long s_cand[GW_SEGS], s_land[GW_SEGS]; __shared__ uint32_t s_fail; __shared__ unsigned long long s_end;
@@ -281,7 +295,7 @@ __global__ void k_dec_gw_stitch(const uint8_t* __restrict__ img, uint64_t n, uin
     __syncthreads();
     const uint32_t tot = s_base[g.nseg];
     if (s_fail || tot > cap) { if (threadIdx.x == 0) { st->pad = s_fail ? 1u : 0u; st->overflow = (!s_fail && tot > cap) ? 1u : 0u; st->n_chunks = tot; } return; }
-    // (a wave per segment: its list is a handful of entries)
+    // (a wave per segment: its list is a handful of entries; sixteen waves - with four, a wave copied 50 segments one dependent load -> store after the other: 50 of the kernel's 55 us)
     for (uint32_t k = threadIdx.x >> 6; k < g.nseg; k += blockDim.x >> 6) { const uint32_t c = s_cnt[k] & 0x7FFFFFFFu; if (s_cand[k] == ~0ull) continue; for (uint32_t i = threadIdx.x & 63u; i < c; i += 64u) off[s_base[k] + i] = list[(size_t)k * GW_LCAP + i]; }
     if (threadIdx.x == 0) { off[tot] = s_end; st->n_chunks = tot; st->pad = 0; st->overflow = 0; }
 }
