@@ -1787,7 +1787,7 @@ __device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uin
     if (mode == PC_MATCH) {
         const uint32_t pat = q * 0x01010101u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) m |= (uint64_t)eq_mask16(p[k], pat) << (16 * k);
+        for (int k = 0; k < 4; k++) m |= (uint64_t)eq_mask16c(p[k], pat) << (16 * k);
     } else {
         // exception = neither the major value nor any normal value.  Few values: union of byte-equality masks;
         // many values: 256-bit membership set held in four u64 (no table loads either way).
@@ -1795,10 +1795,10 @@ __device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uin
         if (nn <= 8) {
             uint64_t known = 0; const uint32_t pm = (D->major & 0xFFu) * 0x01010101u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) known |= (uint64_t)eq_mask16(p[k], pm) << (16 * k);
+            for (int k = 0; k < 4; k++) known |= (uint64_t)eq_mask16c(p[k], pm) << (16 * k);
             for (uint32_t j = 0; j < nn; j++) { const uint32_t pj = (uint32_t)D->normal[j] * 0x01010101u;
 #pragma unroll
-                for (int k = 0; k < 4; k++) known |= (uint64_t)eq_mask16(p[k], pj) << (16 * k); }
+                for (int k = 0; k < 4; k++) known |= (uint64_t)eq_mask16c(p[k], pj) << (16 * k); }
             m = ~known;
         } else {
             // many values: exc_tab = the header's 256-entry "is an exception" table in LDS (its 64 words lie in 64 banks: any 64 byte reads are
