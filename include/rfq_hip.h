@@ -132,7 +132,10 @@ typedef struct {
                                              0: decompress (everything to out1 in chunk order; Q14)                    */
     int32_t  final;                       /* 1: the image ends the file: apply the NO_LINE_BREAK bits of the last chunk
                                              (src/repaq.cpp:301-328,375-413)                                           */
-    int32_t  reserved;
+    int32_t  bug_compat;                  /* 1: Repaq::decompress / decompressPE as they stand (src/repaq.cpp:262-417): a chunk that carries a NO_LINE_BREAK
+                                             bit and is not the image's last makes the reference's loop lose the chunk behind it (and, decompressPE with
+                                             the R1 bit, the flagged chunk's R2 text).  0 (default): every read is kept.  With final = 0 a flagged chunk
+                                             at the very end of the range stays unconsumed (what follows it decides)                                   */
     uint8_t* d_out1; size_t cap1;         /* optional caller buffers; NULL = context-owned results                     */
     uint8_t* d_out2; size_t cap2;
     /* optional chunk index (the .rfq format has none: RfqChunk::read finds chunk c+1 only by parsing chunk c, src/rfqchunk.cpp:161-228,

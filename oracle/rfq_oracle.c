@@ -763,6 +763,48 @@ static int decode_chunk(const rfqo_header* h, const chunk_t* c, int split, bb_t*
  * The final '\n' of a stream is dropped when the LAST chunk carries its NO_LINE_BREAK bit.
  * Deliberate divergence: decompressPE's `continue` (src/repaq.cpp:389,400) loses data when a NON-last chunk carries
  * the bit (files < 1 MiB without trailing newline and > 1 chunk); this restatement keeps every read instead. */
+/* Repaq::decompress / decompressPE AS WRITTEN (src/repaq.cpp:262-417), data loss included: a chunk that carries a NO_LINE_BREAK bit makes the loop read
+ * the chunk BEHIND it to see whether it was the last one (:303-311, :376-387) - and when it was not, the loop goes on with `continue` (:322-325,
+ * :389-392, :400-403), i.e. with a fresh read: the chunk it peeked at is never decoded.  decompressPE additionally leaves the loop body before the R2
+ * text of the flagged chunk is written when it is the R1 bit that is set (:389-392).  rfqo_decode_file (below) keeps every read instead; this
+ * function is what `--bug_compat` must reproduce, pinned against the reference binary in tests/test_oracle_golden.py. */
+int rfqo_decode_file_compat(const uint8_t* rfq, size_t n, int split_pe, uint8_t** out1, size_t* n1, uint8_t** out2, size_t* n2, char* err) {
+    rfqo_header h; size_t used = 0; err[0] = 0;
+    *out1 = NULL; *n1 = 0; if (out2) { *out2 = NULL; *n2 = 0; }
+    if (n == 0) {
+        if (split_pe) { snprintf(err, 256, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>"); return -1; }
+        return 0;
+    }
+    if (rfqo_header_read(rfq, n, &h, &used, err)) return -1;
+    if (split_pe && !(h.flags & RFQO_H_PAIRED)) { snprintf(err, 256, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>"); return -1; }
+    bb_t outs[2] = { {0}, {0} }; size_t k = used;
+    for (;;) {
+        chunk_t c; int r = chunk_parse(&h, rfq + k, n - k, &c, err);
+        if (r < 0) { free(outs[0].p); free(outs[1].p); return -1; }
+        if (r == 1) break;
+        bb_t t[2] = { {0}, {0} };
+        if (decode_chunk(&h, &c, split_pe, t, err)) { free(t[0].p); free(t[1].p); free(outs[0].p); free(outs[1].p); return -1; }
+        k += c.total;
+        const int f1 = (c.flags & RFQO_C_NO_LB) != 0, f2 = split_pe && (c.flags & RFQO_C_NO_LB_R2) != 0;
+        int last = 0;
+        if (f1 || f2) {                                                     /* the peek: the next chunk is read - and, if there is one, lost */
+            chunk_t nx; char e2[256]; const int r2 = chunk_parse(&h, rfq + k, n - k, &nx, e2);
+            last = r2 != 0;
+            if (!last) k += nx.total;
+        }
+        int skip2 = 0;
+        if (f1) { if (last) bb_put(&outs[0], t[0].p, t[0].n ? t[0].n - 1 : 0); else { bb_put(&outs[0], t[0].p, t[0].n); skip2 = 1; } }
+        else bb_put(&outs[0], t[0].p, t[0].n);
+        if (split_pe && !skip2) {
+            if (f2 && last) bb_put(&outs[1], t[1].p, t[1].n ? t[1].n - 1 : 0); else bb_put(&outs[1], t[1].p, t[1].n);
+        }
+        free(t[0].p); free(t[1].p);
+        if (!split_pe && f1 && last) break;                                 /* (:319-321) */
+    }
+    *out1 = outs[0].p; *n1 = outs[0].n;
+    if (out2) { *out2 = outs[1].p; *n2 = outs[1].n; } else free(outs[1].p);
+    return 0;
+}
 int rfqo_decode_file(const uint8_t* rfq, size_t n, int split_pe, uint8_t** out1, size_t* n1, uint8_t** out2, size_t* n2, char* err) {
     rfqo_header h; size_t used = 0; err[0] = 0;
     *out1 = NULL; *n1 = 0; if (out2) { *out2 = NULL; *n2 = 0; }

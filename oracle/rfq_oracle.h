@@ -87,6 +87,9 @@ int      rfqo_header_read(const uint8_t* in, size_t n, rfqo_header* h, size_t* u
  * *out is malloc'd; caller frees with rfqo_free. */
 int  rfqo_encode_file(const uint8_t* fq1, size_t n1, const uint8_t* fq2, size_t n2, int paired,
                       uint32_t chunk_bases, uint8_t** out, size_t* out_len, char* err);
+/* the same as the reference's loops stand, chunks lost behind a NO_LINE_BREAK chunk included (what repaq_hip --bug_compat reproduces) */
+int  rfqo_decode_file_compat(const uint8_t* rfq, size_t n, int split_pe,
+                      uint8_t** out1, size_t* n1, uint8_t** out2, size_t* n2, char* err);
 int  rfqo_decode_file(const uint8_t* rfq, size_t n, int split_pe,
                       uint8_t** out1, size_t* n1, uint8_t** out2, size_t* n2, char* err);
 void rfqo_free(void* p);

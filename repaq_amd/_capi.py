@@ -43,7 +43,7 @@ class ScanResult(C.Structure):
 
 
 class DecodeArgs(C.Structure):
-    _fields_ = [("d_rfq", C.c_void_p), ("n", C.c_size_t), ("has_header", C.c_int32), ("split_pe", C.c_int32), ("final", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("d_rfq", C.c_void_p), ("n", C.c_size_t), ("has_header", C.c_int32), ("split_pe", C.c_int32), ("final", C.c_int32), ("bug_compat", C.c_int32),
                 ("d_out1", C.c_void_p), ("cap1", C.c_size_t), ("d_out2", C.c_void_p), ("cap2", C.c_size_t),
                 ("h_chunk_off", C.POINTER(C.c_uint64)), ("n_chunk_off", C.c_uint32), ("reserved3", C.c_uint32)]
 

@@ -73,12 +73,13 @@ class RfqCodec:
         return r, ends1, ends2
 
     # --- RfqCodec::decodeChunk for every chunk of an image
-    def decode(self, d_rfq, n, has_header=True, split_pe=False, final=True, d_out1=None, cap1=0, d_out2=None, cap2=0, chunk_off=None, n_chunks=0):
-        """chunk_off / n_chunks: optional chunk index (EncodeResult.h_chunk_off + n_chunks, or a sequence of n_chunks + 1 offsets)."""
+    def decode(self, d_rfq, n, has_header=True, split_pe=False, final=True, d_out1=None, cap1=0, d_out2=None, cap2=0, chunk_off=None, n_chunks=0, bug_compat=False):
+        """chunk_off / n_chunks: optional chunk index (EncodeResult.h_chunk_off + n_chunks, or a sequence of n_chunks + 1 offsets).
+        bug_compat: lose what Repaq::decompress / decompressPE lose behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:303-325,376-403)."""
         if chunk_off is not None and not isinstance(chunk_off, C.POINTER(C.c_uint64)):
             n_chunks = len(chunk_off) - 1
             chunk_off = C.cast((C.c_uint64 * len(chunk_off))(*chunk_off), C.POINTER(C.c_uint64))
-        a = A.DecodeArgs(d_rfq, n, 1 if has_header else 0, 1 if split_pe else 0, 1 if final else 0, 0, d_out1, cap1, d_out2, cap2,
+        a = A.DecodeArgs(d_rfq, n, 1 if has_header else 0, 1 if split_pe else 0, 1 if final else 0, 1 if bug_compat else 0, d_out1, cap1, d_out2, cap2,
                          chunk_off if (chunk_off is not None and n_chunks) else None, n_chunks if chunk_off is not None else 0, 0)
         r = A.DecodeResult()
         self._check(self._L.rfq_decode_batch(self._h, C.byref(a), C.byref(r)))

@@ -54,6 +54,7 @@ struct Options {
     int ioThreads = 8;                      // readers per regular input file (pread)
     int writeThreads = 1;                   // writers per regular output file (pwrite); tmpfs does not scale with more, parallel file systems do
     bool trace = false;                     // --trace: wall-clock marks of the pipeline on stderr
+    bool bugCompat = false;                 // --bug_compat (-d): lose what Repaq::decompress* lose behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:303-325, 376-403); default: keep every read
     size_t block() const { return std::max<size_t>(std::min(blockBytes, batchBytes), (size_t)1 << 20); }   // >= the reader's 1 MiB block (line-break thresholds)
 };
 static const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
@@ -688,7 +689,7 @@ static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& p
         }
         trace_mark("decode: batch resident");
         rfq_decode_args a; memset(&a, 0, sizeof a);
-        a.d_rfq = ds.base(); a.n = ds.have; a.has_header = first ? 1 : 0; a.split_pe = split ? 1 : 0; a.final = ds.ended ? 1 : 0;
+        a.d_rfq = ds.base(); a.n = ds.have; a.has_header = first ? 1 : 0; a.split_pe = split ? 1 : 0; a.final = ds.ended ? 1 : 0; a.bug_compat = (o.bugCompat && o.decompress) ? 1 : 0;
         rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
         first = false;
         trace_mark("decode: batch decoded");
@@ -838,7 +839,7 @@ static void usage() {
     fputs("repaq_hip: repack FASTQ to .rfq on an MI355X (repaq v0.5.1 compatible)\n"
           "usage: repaq_hip [-c|-d|-p] -i in1 [-I in2] -o out1 [-O out2] [-k chunk_kb] [--stdin] [--stdout] [--interleaved_in]\n"
           "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N | --devices a,b,...]\n"
-          "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--trace]\n"
+          "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--trace] [--bug_compat]\n"
           "       FASTQ may be .gz (written as blocked gzip - bgzip's layout, readable by every gzip tool - on many threads; a blocked .gz is\n"
           "       also read on many threads, any other through zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
 }
@@ -873,6 +874,7 @@ int main(int argc, char** argv) {
         else if (a == "-z" || a == "--compression" || a.rfind("--compression=", 0) == 0) o.compression = atoi(val(i, "compression").c_str());
         else if (a == "--device") o.device = atoi(val(i, "device").c_str());
         else if (a == "--devices" || a.rfind("--devices=", 0) == 0) { const std::string v = val(i, "devices"); size_t p0 = 0; while (p0 <= v.size()) { const size_t q = v.find(',', p0); const std::string t = v.substr(p0, q == std::string::npos ? std::string::npos : q - p0); if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (q == std::string::npos) break; p0 = q + 1; } }
+        else if (a == "--bug_compat") o.bugCompat = true;
         else if (a == "--batch_mb") o.batchBytes = (size_t)atol(val(i, "batch_mb").c_str()) << 20;
         else if (a == "--block_mb") o.blockBytes = (size_t)atol(val(i, "block_mb").c_str()) << 20;
         else if (a == "--io_threads") o.ioThreads = std::max(1, atoi(val(i, "io_threads").c_str()));

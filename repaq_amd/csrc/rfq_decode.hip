@@ -344,7 +344,33 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     const uint64_t slice_bases = slice_env ? slice_env : 1500000000ull, one_pass = slice_env ? slice_env : 0xFFFFFFF0ull;   // (a pass whose text turns out to be >= 4 GiB is redone in ranges)
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
-    if (tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
+    // bug_compat: Repaq::decompress / decompressPE as they stand (src/repaq.cpp:262-417).  A chunk with a NO_LINE_BREAK bit makes the loop read the
+    // chunk behind it to see whether it was the last (:303-311, :376-387); when it was not, `continue` (:322-325, :389-392, :400-403) goes on with a
+    // fresh read and the chunk it peeked at is never decoded - and decompressPE leaves the body before the flagged chunk's R2 text is written when
+    // it is the R1 bit that is set.  The text is decoded piece by piece: runs of chunks that survive, R1 only where the reference drops R2.
+    struct Rng { uint32_t c0, c1; bool r1_only; };
+    std::vector<Rng> pieces; std::vector<DChunk> hc; bool strip1 = (last_flags & C_NO_LB) != 0, strip2 = (last_flags & C_NO_LB_R2) != 0;
+    const bool compat = a->bug_compat != 0;
+    if (compat) {
+        hc.resize(n_chunks);
+        HIPCHK(ctx, hipMemcpy(hc.data(), CHm, (size_t)n_chunks * sizeof(DChunk), hipMemcpyDeviceToHost));
+        uint32_t run = 0, end = n_chunks; strip1 = strip2 = false;
+        for (uint32_t i = 0; i < n_chunks;) {
+            const bool f1 = (hc[i].flags & C_NO_LB) != 0, f2 = split && (hc[i].flags & C_NO_LB_R2) != 0;
+            if (!f1 && !f2) { i++; continue; }
+            if (i + 1 == n_chunks) {                                            // nothing behind it in this image
+                if (!a->final) { end = i; res->consumed = (size_t)hc[i].off; }  // the caller has to show what follows: the chunk stays unconsumed
+                else { strip1 = f1; strip2 = f2; }
+                break;
+            }
+            if (split && f1) { if (i > run) pieces.push_back({ run, i, false }); pieces.push_back({ i, i + 1, true }); }
+            else pieces.push_back({ run, i + 1, false });
+            run = i + 2; i += 2;                                                // (the chunk behind a flagged one that is not the last: lost)
+        }
+        if (run < end) pieces.push_back({ run, end, false });
+        res->n_chunks = 0; for (auto& q : pieces) res->n_chunks += q.c1 - q.c0;
+    }
+    if (!compat && tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
         DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.bases = tb;
         rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
         if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
@@ -353,23 +379,25 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         // Reads, bases and text of one pass are placed by 32-bit prefix sums: a larger image is decoded range by range (contiguous chunks of
         // about slice_bases bases; a range whose text still does not fit is halved), every range into the context's own buffers and from
         // there to its place in the result.
-        std::vector<DChunk> hc(n_chunks);
-        HIPCHK(ctx, hipMemcpy(hc.data(), CHm, (size_t)n_chunks * sizeof(DChunk), hipMemcpyDeviceToHost));
-        std::vector<std::pair<uint32_t, uint32_t>> todo;                    // stack of [c0, c1), first range on top
-        { std::vector<std::pair<uint32_t, uint32_t>> fw; uint32_t c0 = 0; uint64_t acc = 0, rd = 0;
-          for (uint32_t c = 0; c < n_chunks; c++) {
-              if (c > c0 && (acc + hc[c].bases > slice_bases || rd + hc[c].reads > 0x7FFFFFF0ull)) { fw.emplace_back(c0, c); c0 = c; acc = 0; rd = 0; }
-              acc += hc[c].bases; rd += hc[c].reads;
+        if (!compat) { hc.resize(n_chunks); HIPCHK(ctx, hipMemcpy(hc.data(), CHm, (size_t)n_chunks * sizeof(DChunk), hipMemcpyDeviceToHost)); pieces.push_back({ 0, n_chunks, false }); }
+        std::vector<Rng> todo;                                               // stack of [c0, c1), first range on top
+        { std::vector<Rng> fw;
+          for (auto& pc : pieces) {
+              uint32_t c0 = pc.c0; uint64_t acc = 0, rd = 0;
+              for (uint32_t c = pc.c0; c < pc.c1; c++) {
+                  if (c > c0 && (acc + hc[c].bases > slice_bases || rd + hc[c].reads > 0x7FFFFFF0ull)) { fw.push_back({ c0, c, pc.r1_only }); c0 = c; acc = 0; rd = 0; }
+                  acc += hc[c].bases; rd += hc[c].reads;
+              }
+              fw.push_back({ c0, pc.c1, pc.r1_only });
           }
-          fw.emplace_back(c0, n_chunks);
           for (size_t i = fw.size(); i-- > 0;) todo.push_back(fw[i]); }
         size_t w1 = 0, w2 = 0; n1 = n2 = 0; nb = 0;
         std::vector<std::pair<const char*, float>> acc_ms;
         ctx->timer.collect();                                                // (the walk, and whatever a failed one-pass attempt got through)
         for (size_t i = 0; i < ctx->timer.names.size() && i < 1; i++) acc_ms.emplace_back(ctx->timer.names[i], ctx->timer.ms[i]);
         while (!todo.empty()) {
-            const auto r = todo.back(); todo.pop_back();
-            const uint32_t c0 = r.first, c1 = r.second; uint64_t reads = 0, rbases = 0; for (uint32_t c = c0; c < c1; c++) { reads += hc[c].reads; rbases += hc[c].bases; }
+            const Rng r = todo.back(); todo.pop_back();
+            const uint32_t c0 = r.c0, c1 = r.c1; uint64_t reads = 0, rbases = 0; for (uint32_t c = c0; c < c1; c++) { reads += hc[c].reads; rbases += hc[c].bases; }
             hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
             KCHK(ctx, "k_dec_rebase");
             DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.bases = rbases;
@@ -378,7 +406,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);
             if (rc == RFQ_RANGE_TOO_BIG) {
                 if (c1 - c0 < 2) return rfq_fail(ctx, RFQ_E_ARG, "a single chunk decodes to 4 GiB of text or more");
-                const uint32_t mid = c0 + (c1 - c0) / 2; todo.emplace_back(mid, c1); todo.emplace_back(c0, mid); continue;
+                const uint32_t mid = c0 + (c1 - c0) / 2; todo.push_back({ mid, c1, r.r1_only }); todo.push_back({ c0, mid, r.r1_only }); continue;
             }
             if (rc != RFQ_OK) return rc;
             for (size_t i = 0; i < ctx->timer.names.size(); i++) {
@@ -388,7 +416,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             }
             for (int k = 0; k < (split ? 2 : 1); k++) {
                 uint8_t* src = k ? q2 : q1; const size_t m = k ? m2 : m1; size_t& w = k ? w2 : w1; uint8_t* dcall = k ? a->d_out2 : a->d_out1; const size_t dcap = k ? a->cap2 : a->cap1;
-                if (!m) continue;
+                if (!m || (k && r.r1_only)) continue;
                 uint8_t* to;
                 if (dcall) { if (w + m > dcap) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small"); to = dcall + w; }
                 else { DBuf& ab = k ? ctx->out_acc2 : ctx->out_acc1; HIPCHK(ctx, ab.ensure_keep(w + m + 64, w, S)); to = ab.as<uint8_t>() + w; }
@@ -405,8 +433,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     }
     res->n_bases = nb;
     if (a->final) {   // Repaq::decompress*: drop the final '\n' when the last chunk carries the NO_LINE_BREAK bit
-        if ((last_flags & C_NO_LB) && n1) n1--;
-        if (split && (last_flags & C_NO_LB_R2) && n2) n2--;
+        if (strip1 && n1) n1--;
+        if (split && strip2 && n2) n2--;
     }
     res->d_fq1 = o1; res->n1 = n1; res->d_fq2 = split ? o2 : nullptr; res->n2 = split ? n2 : 0;
     return RFQ_OK;

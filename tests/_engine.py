@@ -18,7 +18,7 @@ def build_emu():
     with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            subprocess.check_call(["make", "-s", "-j4", "-C", EMU_DIR])
+            subprocess.check_call(["make", "-s", "-j4", "-C", EMU_DIR, "all"])       # (all: the library AND the driver linked against it)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return EMU_LIB
@@ -60,7 +60,7 @@ def check_case(codec, name, case, golden):
     return got
 
 
-def decode_in_slices(codec, rfq: bytes, split_pe: bool, step: int):
+def decode_in_slices(codec, rfq: bytes, split_pe: bool, step: int, **kw):
     """Feed an image `step` bytes at a time (has_header on the first call, final on the last, unconsumed tail carried over): the
     streaming contract of rfq_decode_batch that the C++ driver relies on."""
     out1, out2 = bytearray(), bytearray()
@@ -70,7 +70,7 @@ def decode_in_slices(codec, rfq: bytes, split_pe: bool, step: int):
         buf = rfq[pos:end]
         d = codec.dev_put(buf)
         try:
-            r = codec.decode(d, len(buf), has_header=first, split_pe=split_pe, final=final)
+            r = codec.decode(d, len(buf), has_header=first, split_pe=split_pe, final=final, **kw)
             if r.n1:
                 out1 += codec.dev_get(r.d_fq1, r.n1)
             if split_pe and r.n2:

@@ -49,6 +49,8 @@ def lib():
         L.rfqo_decode_file.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p]
         L.rfqo_decode_file.restype = C.c_int
+        L.rfqo_decode_file_compat.argtypes = L.rfqo_decode_file.argtypes
+        L.rfqo_decode_file_compat.restype = C.c_int
         L.rfqo_free.argtypes = [C.c_void_p]
         L.rfqo_parse_name.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(_Meta)]
         L.rfqo_overlap.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
@@ -81,10 +83,11 @@ def encode_file(fq1: bytes, fq2: bytes = b"", paired: int = SE, chunk_bases: int
         L.rfqo_free(out)
 
 
-def decode_file(rfq: bytes, split_pe: bool = False):
+def decode_file(rfq: bytes, split_pe: bool = False, bug_compat: bool = False):
+    """bug_compat: the reference's decompress loops as they stand - a chunk behind a non-last NO_LINE_BREAK chunk is lost (src/repaq.cpp:303-325,376-403)."""
     L = lib()
     o1 = C.c_void_p(); n1 = C.c_size_t(); o2 = C.c_void_p(); n2 = C.c_size_t(); err = C.create_string_buffer(256)
-    rc = L.rfqo_decode_file(rfq, len(rfq), 1 if split_pe else 0, C.byref(o1), C.byref(n1), C.byref(o2), C.byref(n2), err)
+    rc = (L.rfqo_decode_file_compat if bug_compat else L.rfqo_decode_file)(rfq, len(rfq), 1 if split_pe else 0, C.byref(o1), C.byref(n1), C.byref(o2), C.byref(n2), err)
     if rc:
         raise OracleError(err.value.decode(errors="replace"))
     try:

@@ -246,6 +246,43 @@ def _io_pipeline_suite(binary, tmp_path, reads):
     assert r.returncode == 0 and json.loads(r.stdout)["result"] == "passed", r.stdout
 
 
+def _bug_compat_suite(binary, tmp_path, names, batch_mb):
+    """`-d --bug_compat` writes what the reference binary writes (tests/golden/compat.json: sizes and md5 of ITS decode output, made by make_golden_compat.py):
+    the chunk behind a non-last NO_LINE_BREAK chunk lost, the flagged chunk's R2 text too when it is the R1 bit; plain `-d` keeps every read."""
+    import hashlib
+    import json
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compat.json")))
+    for name in names:
+        g = G[name]
+        fq1, fq2 = O.gen(g["profile"], g["reads"], seed=g["seed"], **g["kw"])
+        rfq = O.encode_file(fq1, fq2, g["paired"], 100_000)
+        assert hashlib.md5(rfq).hexdigest() == g["rfq_md5"]
+        p = tmp_path / (name + ".rfq"); p.write_bytes(rfq)
+        split = g["paired"] != O.SE
+        o1 = tmp_path / (name + "_1.fq"); o2 = tmp_path / (name + "_2.fq")
+        outs = ["-o", str(o1)] + (["-O", str(o2)] if split else [])
+        r = _run(binary, ["-d", "-i", str(p)] + outs + ["--bug_compat", "--batch_mb", str(batch_mb)])
+        assert r.returncode == 0, r.stderr
+        texts = [o1.read_bytes()] + ([o2.read_bytes()] if split else [])
+        assert [len(t) for t in texts] == g["ref_decode_len"] and [hashlib.md5(t).hexdigest() for t in texts] == g["ref_decode_md5"], name
+        r = _run(binary, ["-d", "-i", str(p)] + outs + ["--batch_mb", str(batch_mb)])
+        assert r.returncode == 0, r.stderr
+        assert [o1.read_bytes()] + ([o2.read_bytes()] if split else []) == ([fq1, fq2] if split else [fq1]), name
+
+
+def test_cli_bug_compat_on_simt_emulation(tmp_path):
+    E.build_emu()
+    assert os.path.exists(EMU_BIN)
+    _bug_compat_suite(EMU_BIN, tmp_path, ["pe_nonl_r1_small"], batch_mb=1)
+
+
+@pytest.mark.gpu
+def test_cli_bug_compat_on_gpu(tmp_path):
+    assert os.path.exists(GPU_BIN), "repaq_hip is built by __graft_entry__.build()"
+    for mb in (256, 2):                                                         # one call per image; a streaming caller's slices
+        _bug_compat_suite(GPU_BIN, tmp_path, ["se_nonl", "pe_nonl_r2", "pe_nonl_r1", "pe_nonl_both", "pe_nonl_r1_small", "bgi_nonl_both"], batch_mb=mb)
+
+
 @pytest.mark.skipif(__import__("shutil").which("xz") is None, reason="no external xz here: the .rfq.xz legs inside the CLI suites (src/main.cpp:134-177) did NOT run")
 def test_xz_is_present_so_the_rfq_xz_legs_ran():
     """the CLI suites skip their .rfq.xz leg quietly when xz is missing; this test makes that visible as a reported skip"""

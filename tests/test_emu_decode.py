@@ -121,6 +121,32 @@ def test_position_lists_of_long_runs(codec):
         assert "emit" in dict(codec.timings())
 
 
+COMPAT = [("se_nonl", O.NOVA_SE150, 1500, 1, O.SE, dict(nonl=1)), ("pe_nonl_r2", O.NOVA_PE150, 1200, 4, O.PE_TWO_FILES, dict(nonl=2)),
+          ("pe_nonl_r1", O.NOVA_PE150, 1200, 5, O.PE_TWO_FILES, dict(nonl=1)), ("pe_nonl_both", O.NOVA_PE150, 1200, 6, O.PE_TWO_FILES, dict(nonl=3)),
+          ("pe_one_chunk", O.NOVA_PE150, 100, 7, O.PE_TWO_FILES, dict(nonl=3)), ("pe_with_newlines", O.NOVA_PE150, 700, 8, O.PE_TWO_FILES, {})]
+
+
+@pytest.mark.parametrize("label,prof,reads,seed,paired,kw", COMPAT, ids=[c[0] for c in COMPAT])
+def test_bug_compat_decode_loses_what_the_reference_loses(codec, label, prof, reads, seed, paired, kw):
+    """rfq_decode_args.bug_compat: Repaq::decompress / decompressPE as they stand - the chunk behind a non-last NO_LINE_BREAK chunk is lost, and the
+    flagged chunk's R2 text when it is the R1 bit (src/repaq.cpp:303-325, 376-403; oracle: rfqo_decode_file_compat, pinned against the reference
+    binary in test_oracle_golden.py).  One call, and a streaming caller's slices (a flagged chunk at the end of a non-final slice waits for what follows)."""
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    rfq = O.encode_file(fq1, fq2, paired, 100_000)
+    split = paired != O.SE
+    want = O.decode_file(rfq, split_pe=split, bug_compat=True)
+    keep = O.decode_file(rfq, split_pe=split)
+    assert keep == ((fq1, fq2) if split else fq1)
+    if label in ("pe_nonl_r2", "pe_nonl_r1", "pe_nonl_both"):
+        assert want != keep                                                   # (these inputs do lose text in the reference)
+    assert codec.decode_bytes(rfq, split_pe=split, bug_compat=True) == want
+    assert codec.decode_bytes(rfq, split_pe=split) == keep
+    for step in (9000, 70000):
+        assert E.decode_in_slices(codec, rfq, split, step, bug_compat=True) == want, step
+    if split:
+        assert codec.decode_bytes(rfq, split_pe=False, bug_compat=True) == O.decode_file(rfq, split_pe=False, bug_compat=True)
+
+
 def test_chunk_starts_without_an_index(codec, monkeypatch):
     """A .rfq has no chunk index: the decoder guesses segment starts, walks the segments in parallel and verifies every extent (k_dec_gw_*);
     RFQ_WALK=chain is the one-wave chain it falls back to.  Small segments (RFQ_GW_SHIFT) so that a small image has several."""

@@ -113,3 +113,25 @@ def test_oracle_decodes_legacy_run_length_images_like_the_reference():
         got = O.decode_file(img, split)
         assert [hashlib.md5(x).hexdigest() for x in (got if split else (got,))] == g["decode_md5"], name
         assert g["roundtrip"]
+
+
+COMPAT_J = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compat.json")))
+
+
+@pytest.mark.parametrize("name", sorted(COMPAT_J))
+def test_bug_compat_decode_equals_the_reference_binarys_output(name):
+    """rfqo_decode_file_compat - the reference's decompress loops as they stand, data loss included - against what the reference BINARY wrote for the
+    same image (tests/golden/compat.json, made by make_golden_compat.py); and against the binary itself where it exists."""
+    g = COMPAT_J[name]
+    fq1, fq2 = O.gen(g["profile"], g["reads"], seed=g["seed"], **g["kw"])
+    rfq = O.encode_file(fq1, fq2, g["paired"], 100_000)
+    assert hashlib.md5(rfq).hexdigest() == g["rfq_md5"]
+    split = g["paired"] != O.SE
+    got = O.decode_file(rfq, split_pe=split, bug_compat=True)
+    texts = got if split else (got,)
+    assert [len(t) for t in texts] == g["ref_decode_len"] and [hashlib.md5(t).hexdigest() for t in texts] == g["ref_decode_md5"]
+    keep = O.decode_file(rfq, split_pe=split)
+    assert (list(keep) if split else [keep]) == ([fq1, fq2] if split else [fq1])          # the default keeps every read
+    assert g["ref_roundtrip"] == (list(texts) == ([fq1, fq2] if split else [fq1]))
+    if O.have_ref():
+        assert O.ref_decode(rfq, split_pe=split) == got
