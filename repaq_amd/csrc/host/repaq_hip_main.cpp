@@ -650,12 +650,15 @@ static void do_compress_multi(const Options& o) {
                 const uint32_t c0 = (uint32_t)((uint64_t)sr.n_chunks * p / parts), c1 = (uint32_t)((uint64_t)sr.n_chunks * (p + 1) / parts);
                 const bool tail = p + 1 == parts;
                 const uint64_t s1 = c0 ? sr.h_end1[c0 - 1] : 0, s2 = (two && c0) ? sr.h_end2[c0 - 1] : 0;
-                // the last range of the last batch runs to the end of the data (final semantics see every byte, like the one-shot encode)
-                const uint64_t e1 = (tail && last_batch && !sr.input_ended) ? ds[0].have : (c1 ? sr.h_end1[c1 - 1] : 0);
-                const uint64_t e2 = two ? ((tail && last_batch && !sr.input_ended) ? ds[1].have : (c1 ? sr.h_end2[c1 - 1] : 0)) : 0;
+                // the last range of the last batch runs to the end of the data: the worker sees every byte the one-shot encode would - also when the
+                // reader stops at an empty line inside it (cut at the last chunk's end, the worker never met that line and the tail chunk's
+                // line-break rule - how far the readers' last, failed attempt got - was not applied)
+                const bool to_end = tail && last_batch;
+                const uint64_t e1 = to_end ? ds[0].have : (c1 ? sr.h_end1[c1 - 1] : 0);
+                const uint64_t e2 = two ? (to_end ? ds[1].have : (c1 ? sr.h_end2[c1 - 1] : 0)) : 0;
                 WorkItem it; it.seq = seq++; it.d1 = ds[0].base() + s1; it.n1 = (size_t)(e1 - s1); it.d2 = two ? ds[1].base() + s2 : nullptr; it.n2 = (size_t)(e2 - s2);
                 it.off1 = ds[0].file_off + s1; it.off2 = ds[1].file_off + s2; it.th1 = th[0]; it.th2 = two ? th[1] : th[0];
-                it.final = tail && last_batch && !sr.input_ended;
+                it.final = to_end && final;                                 // (a range that ends at an empty line before the data does flushes by flush_all; its encode reports input_ended itself)
                 queue.push_back(it);
             }
             cv.notify_all();

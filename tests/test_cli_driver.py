@@ -133,6 +133,23 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
         r = _run(binary, ["-c", "-i", str(pm), "-o", str(om), "-k", "100", "--batch_mb", str(batch_mb)] + extra)
         assert r.returncode == 0, r.stderr
         assert om.read_bytes() == O.encode_file(em, b"", O.SE, 100_000)
+    # the input stops at an empty line (two blank lines behind the last record, which ends shortly before the reader's last 1 MiB block; no final line
+    # break): the tail chunk's line-break bit follows from how far the readers' last attempt got - one-shot and under --devices
+    lines = fq1.split(b"\n"); recs = [lines[4 * i: 4 * i + 4] for i in range(len(lines) // 4)]
+    cut = (1 << 20) - 37; acc = bytearray(); i = 0
+    while len(acc) + 2 * 360 <= cut:                                             # (a record of this profile is < 360 bytes)
+        acc += b"\n".join(recs[i % len(recs)]) + b"\n"; i += 1
+    pad = cut - len(acc) - sum(len(x) + 1 for x in recs[i % len(recs)])          # the next record, lengthened to end exactly at `cut`
+    nm, sq, st_, ql = recs[i % len(recs)]
+    acc += nm + b"p" * (pad & 1) + b"\n" + sq + b"A" * (pad >> 1) + b"\n" + st_ + b"\n" + ql + b"F" * (pad >> 1) + b"\n"
+    assert len(acc) == cut
+    tail_case = bytes(acc) + b"\n\n" + b"\n".join(recs[0])                      # two blank lines, then an unterminated record in the last block
+    pt = tmp_path / "stops.fq"; pt.write_bytes(tail_case)
+    want_t = O.encode_file(tail_case, b"", O.SE, 100_000)
+    for extra in ([], ["--devices", "0,0,0"]):
+        r = _run(binary, ["-c", "-i", str(pt), "-o", str(om), "-k", "100", "--batch_mb", str(batch_mb)] + extra)
+        assert r.returncode == 0, r.stderr
+        assert om.read_bytes() == want_t, extra
     # an empty input leaves an empty .rfq, which decodes to an empty FASTQ (RfqHeader defaults, src/rfqheader.cpp:7-17)
     pz = tmp_path / "empty.fq"; pz.write_bytes(b""); oz = tmp_path / "empty.rfq"; bz = tmp_path / "empty_back.fq"
     assert _run(binary, ["-c", "-i", str(pz), "-o", str(oz)]).returncode == 0 and oz.read_bytes() == b""
