@@ -63,6 +63,7 @@ static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, u
     return best;
 }
 struct rfq_ctx {
+    bool e3_pieces_failed = false;       // decode: a tile of k_dec_emit3 did not hold its reads' name pieces - files like this one go to k_dec_emit2
     int device = 0; uint32_t n_cu = 256;                                         // compute units of the device (rfq_create)
     hipStream_t stream = nullptr; bool own_stream = false;
     // second stream for small latency-bound kernels that are independent of the main chain (coordinate coder / decoder): fork with

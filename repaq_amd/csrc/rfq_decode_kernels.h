@@ -22,6 +22,9 @@ struct DChunk {                  // one parsed chunk (offsets relative to the ch
     uint32_t max_len, nrec;      // longest read of the chunk; exception records behind its quality streams (0xFFFFFFFF: not looked at)
     uint32_t max_one, pad_;      // its longest single quality stream
 };
+#define ET_N1CAP 3072u            // staged name1 / name2 / strand pieces of an emitter's tile (k_dec_emit2 falls back to global memory when larger, k_dec_emit3 hands the range over)
+#define ET_N2CAP 1024u
+#define ET_STCAP 1024u
 struct DecStatus {
     uint32_t err, n_chunks, max_reads, overflow;
     uint64_t total_reads, consumed, total_bases, total_stored, text1, text2;
@@ -32,7 +35,8 @@ struct DecStatus {
     uint32_t max_len, max_bases;     // longest read / largest chunk (bases, clamped to 2^32 - 1) of the image
     uint32_t max_nrec, max_one;      // most exception records of any chunk / longest single quality stream (by-column quality payloads)
     unsigned long long list_need;    // fused path: entries of all position lists (k_dec_pos_off)
-    uint32_t per_read_pieces, pad3;  // some chunk stores name1 / name2 / strand per read (k_dec_emit3 stages only pieces a whole chunk shares)
+    uint32_t per_read_pieces, piece_avg;  // some chunk stores name1 / name2 / strand per read; the largest average size of such a piece over the chunks, as a
+                                     // fraction of its tile capacity in 1/256 (k_dec_emit3: the host sizes its tiles by it, a tile that still does not fit asks for k_dec_emit2)
 };
 
 // sum of n bytes by one wave (wave-uniform result)
@@ -327,10 +331,15 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
 __global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint32_t first, uint32_t count) {
     if (st->overflow || st->pad) return;
     const uint32_t end = first + count < st->n_chunks ? first + count : st->n_chunks;
-    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, pr = 0; unsigned long long sum = 0;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, pr = 0, pa = 0; unsigned long long sum = 0;
     for (uint32_t c = first + threadIdx.x; c < end; c += blockDim.x) {
         const DChunk& d = CH[c];
         if ((d.flags & (C_NAME1_SAME | C_NAME2_SAME | C_STRAND_SAME)) != (C_NAME1_SAME | C_NAME2_SAME | C_STRAND_SAME)) pr = 1;
+        if (d.reads) {                                                     // per-read pieces: bytes per read against the emitter's tile capacity for that piece
+            if (!(d.flags & C_NAME1_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.n1_size * 256ull / d.reads + ET_N1CAP - 1) / ET_N1CAP); if (v > pa) pa = v; }
+            if (!(d.flags & C_NAME2_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.n2_size * 256ull / d.reads + ET_N2CAP - 1) / ET_N2CAP); if (v > pa) pa = v; }
+            if (!(d.flags & C_STRAND_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.st_size * 256ull / d.reads + ET_STCAP - 1) / ET_STCAP); if (v > pa) pa = v; }
+        }
         if (d.qual_size > m0) m0 = d.qual_size;
         if (d.npos_size > m1) m1 = d.npos_size;
         if (d.max_len > m2) m2 = d.max_len;
@@ -341,6 +350,7 @@ __global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint
     uint32_t m5 = 0; for (uint32_t c = first + threadIdx.x; c < end; c += blockDim.x) if (CH[c].max_one > m5) m5 = CH[c].max_one;
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2); m3 = wave_max(m3); m4 = wave_max(m4); m5 = wave_max(m5); sum = wave_sum<unsigned long long>(sum);
     if (__any(pr != 0) && lane_id() == 0) atomicOr(&st->per_read_pieces, 1u);
+    pa = wave_max(pa); if (pa && lane_id() == 0) atomicMax(&st->piece_avg, pa);
     if (lane_id() == 0) { atomicMax(&st->max_stream, m0); atomicMax(&st->max_npos, m1); atomicMax(&st->max_len, m2); atomicMax(&st->max_bases, m3); atomicMax(&st->max_nrec, m4); atomicMax(&st->max_one, m5);
                           atomicAdd((unsigned long long*)&st->base_slots[0], sum); }
 }
@@ -1138,9 +1148,6 @@ __device__ __forceinline__ void emit_copy(uint8_t* o, const uint8_t* pool, uint3
 #define EM_ROW 17                 // words per read in s_meta: 16 used + 1 pad, so that lanes reading the same field of consecutive reads hit 32 different banks
 #define ET_OCAP 12288u            // output tile bytes (split: half per stream): 32 records of 357 bytes are 11.4 KB
 #define ET_SCAP 5632u             // staged qualities / stored bases
-#define ET_N1CAP 3072u            // staged name1 / name2 / strand pieces of the tile (fall back to global memory when larger)
-#define ET_N2CAP 1024u
-#define ET_STCAP 1024u
 template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
                            const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, uint64_t img_bytes, int split,
@@ -1743,7 +1750,7 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
         const uint32_t cnt = re - cur < K ? re - cur : K, g0 = f + cur, g1 = g0 + cnt;
         const TileP tp = tp_cur; const uint32_t q0 = tp.q0, q1 = tp.q1, s0 = tp.s0, s1 = tp.s1;
         const bool fits = q1 - q0 <= E3_QCAP && (same1 || tp.e7 - tp.a7 + 32u <= ET_N1CAP) && (same2 || tp.e8 - tp.a8 + 32u <= ET_N2CAP) && (same3 || tp.e9 - tp.a9 + 32u <= ET_STCAP);
-        if (!fits) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); break; }   // (the host sizes K by the longest read and keeps files with long per-read name pieces off this kernel)
+        if (!fits) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_E3_RETRY); break; }   // (the host sizes K by the longest read and by the chunks' average piece sizes; a tile whose pieces are longer than that allowed for: the host repeats the range with k_dec_emit2)
         // ---- stage: packed bases, middles, per-read name pieces (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
         const uint64_t ib = d.off;
         const uint64_t n1a = ib + d.o_n1 + (same1 ? 0u : tp.a7), n1e = same1 ? n1a + d.n1_size : ib + d.o_n1 + tp.e7;

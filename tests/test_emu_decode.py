@@ -109,6 +109,33 @@ def test_fixed_tile_emitter_line_shapes(codec, label, name_of, strand_of):
     assert codec.decode_bytes(rfq, split_pe=False) == O.decode_file(rfq, split_pe=False)          # (interleaved text: the mates in stored orientation)
 
 
+def test_fixed_tile_emitter_with_per_read_name_pieces():
+    """Names FastqMeta::parse does not take apart are stored whole, per read: k_dec_emit3 stages a tile's name pieces when the chunks' AVERAGE piece
+    leaves room (the host sizes the tile by it); a tile whose reads carry much longer names than that raises DE_E3_RETRY and the range is emitted
+    again by k_dec_emit2 - as are, from then on, the following ranges on that context; long names throughout go to k_dec_emit2 at once."""
+    from repaq_amd import RfqCodec
+    codec = RfqCodec(device=0, library=E.build_emu())                            # (a context that has not given up on such files yet)
+    short = _handmade(900, lambda i: "SRR0123456.%d %d length=150" % (i + 1, i + 1), lambda i: 150 - (i % 3), lambda i: "+", seed=3)
+    rfq = O.encode_file(short, b"", O.SE, 50_000)
+    assert codec.decode_bytes(rfq) == short
+    assert "emit" in dict(codec.timings()), dict(codec.timings())
+    mixed = _handmade(900, lambda i: ("SRR0123456.%d" % i) if not 400 <= i < 480 else ("L" * 110 + "%d" % i), lambda i: 100, lambda i: "+", seed=4)
+    rfq = O.encode_file(mixed, b"", O.SE, 1_000_000)
+    assert codec.decode_bytes(rfq) == mixed
+    assert "emit2" in dict(codec.timings()), dict(codec.timings())               # (the retry)
+    assert codec.decode_bytes(O.encode_file(short, b"", O.SE, 50_000)) == short
+    assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
+    codec.close()
+    codec = RfqCodec(device=0, library=E.build_emu())
+    longn = _handmade(300, lambda i: "N" * 240 + "%d" % i, lambda i: 100, lambda i: "+", seed=5)          # (sixteen of them do not fit a tile)
+    assert codec.decode_bytes(O.encode_file(longn, b"", O.SE, 1_000_000)) == longn
+    assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
+    mid = _handmade(300, lambda i: "N" * 120 + "%d" % i, lambda i: 100, lambda i: "+", seed=6)           # (sixteen would fit: only full tiles of 64 pay)
+    assert codec.decode_bytes(O.encode_file(mid, b"", O.SE, 1_000_000)) == mid
+    assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
+    codec.close()
+
+
 def test_position_lists_of_long_runs(codec):
     """Long runs of a minority quality value: a 256-byte step of its position stream codes thousands of list entries, more than the 1024 a wave
     of k_dec_pos_list fills in at a time (run tokens whose entries straddle the windows), next to streams of single positions."""
