@@ -89,6 +89,32 @@ def test_line_index_falls_back_when_lines_are_short():
     codec.close()
 
 
+@pytest.mark.parametrize("gather", ["tile", "bytes"])
+def test_strand_lines_of_equal_length_and_different_bytes(codec, monkeypatch, gather):
+    """Strand lines that differ in a byte but not in length - anywhere in the chunk, first or last read of a gather tile, one character or behind the
+    sixteenth - clear STRAND_SAME exactly like the reference's pass 1 (src/rfqcodec.cpp:220-250); k_read_table compares every read's with its
+    predecessor's.  (Leaving the bytes to k_gather2, which has the line staged anyway, was built and measured: 2.9 GB less traffic in k_read_table but
+    only 0.08 ms, against 0.2 ms more in the VALU-bound k_gather2 - not kept.)"""
+    if gather == "bytes":
+        monkeypatch.setenv("RFQ_GATHER", "old")
+    fq1, fq2 = O.gen(O.NOVA_PE150, 400, seed=77)
+    def with_strands(fq, edits):
+        lines = fq.split(b"\n")
+        for k, st in edits.items():
+            lines[4 * k + 2] = st
+        return b"\n".join(lines)
+    cases = [({}, {}),                                                            # all "+": the flag stays
+             ({70: b"-"}, {}), ({}, {131: b"-"}), ({63: b"x"}, {64: b"y"}), ({0: b"-"}, {}),          # one character, different places (read 0 itself: every other read differs)
+             ({k: b"+strand_line_with_text_%02d" % (k % 7) for k in range(400)}, {k: b"+strand_line_with_text_%02d" % (k % 7) for k in range(400)}),   # same length, bytes differ behind the 16th
+             ({k: b"+same_text_everywhere" for k in range(400)}, {k: b"+same_text_everywhere" for k in range(400)})]
+    for e1, e2 in cases:
+        a, b = with_strands(fq1, e1), with_strands(fq2, e2)
+        for cb in (20000, 1_000_000):
+            assert E.encode(codec, a, b, O.PE_TWO_FILES, cb) == O.encode_file(a, b, O.PE_TWO_FILES, cb), (sorted(e1)[:3], sorted(e2)[:3], cb)
+        assert E.encode(codec, a, b"", O.SE, 30000) == O.encode_file(a, b"", O.SE, 30000)
+    assert ("gather_bytes" if gather == "bytes" else "gather") in dict(codec.timings())
+
+
 def test_gather_paths_are_the_ones_expected(codec):
     """The tile gather (k_gather2 + k_seqpack) is what runs by default - also when a mate of an interleaved chunk holds bytes outside A/C/G/T/N
     (Read::changeToReverseComplement turns them into N, lower case into the upper-case complement) - and reads too long for a tile of two
