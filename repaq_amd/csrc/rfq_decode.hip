@@ -27,7 +27,7 @@ static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk
 #undef RFQ_LIST_ARGS
 }
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
-struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one, pieces, piece_avg; uint64_t bases; };   // bases: sum of the range's read lengths (the walk's 64-bit total)
+struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one, pieces, piece_avg, piece_n1; uint64_t bases; };   // bases: sum of the range's read lengths (the walk's 64-bit total)
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
 // out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
@@ -196,7 +196,13 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         // fifth of the tile left for reads above the average; a tile that still does not fit raises DE_E3_RETRY and the range is emitted again by
         // k_dec_emit2 (remembered on the context: the next ranges of such a file go there at once).  Only with full tiles of 64 reads: with 16 - names of
         // ~125 bytes, the configs[4] shape - most of a read's sixteen lanes idle and k_dec_emit2 is faster (2.2 against 2.5 ms there)
-        if (g.pieces) { while (e3k >= 1 && ((uint64_t)g.piece_avg << e3k) > 204u) e3k--; }
+        // name1 has a second instantiation with a 13 KB tile (names of up to ~165 bytes on average, e.g. the configs[4] shape; four workgroups per CU)
+        bool n1big = false;
+        if (g.pieces) {
+            while (e3k >= 1 && ((uint64_t)g.piece_avg << e3k) > 204u) e3k--;
+            const uint64_t need1 = ((uint64_t)g.piece_n1 << e3k) * 5u / 4u + 32u;          // a fifth of the tile for reads above the average
+            if (need1 > ET_N1CAP) { if (e3k == 6 && need1 <= E3_N1BIG) n1big = true; else e3k = 0; }
+        }
         bool emit3 = fused && e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed) && !(eenv && !strcmp(eenv, "2")) && !(tune & 7);
     emit_again:
         if (!emit3) ctx->timer.stages[ctx->timer.used].name = "emit2";
@@ -204,7 +210,12 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, (getenv("RFQ_E3_SLOTS") ? (uint32_t)atoi(getenv("RFQ_E3_SLOTS")) : 6u) * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
 #define RFQ_EMIT3_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
                        (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k, (tune >> 12) & 255
-            if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_emit3<false>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+            if (n1big) {
+                const uint32_t b4 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 4u * ctx->n_cu);
+                if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+                else hipLaunchKernelGGL((k_dec_emit3<true, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+            }
+            else if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_emit3<false>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             else hipLaunchKernelGGL(k_dec_emit3<true>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
 #undef RFQ_EMIT3_ARGS
         }
@@ -326,7 +337,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
         if (guess && hs.pad) { guess = false; continue; }                  // the guessed index did not verify: the chain
-        if (!speculate) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; hs.piece_avg = 0xFFFFu; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
+        if (!speculate) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; hs.piece_avg = 0xFFFFu; hs.piece_n1 = 0xFFFFu; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
         if (hs.pad) { speculate = false; guess = false; continue; }        // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
         if (hs.n_chunks > PARSE_AHEAD) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
@@ -335,7 +346,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
             if (h2.pad) { if (guess) { guess = false; continue; } speculate = false; continue; }
-            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; hs.piece_avg = h2.piece_avg; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
+            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; hs.piece_avg = h2.piece_avg; hs.piece_n1 = h2.piece_n1; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
         if (hs.consumed != a->n && a->n - hs.consumed >= 18) { if (guess) { guess = false; continue; } speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
         (void)table;
@@ -384,7 +395,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         res->n_chunks = 0; for (auto& q : pieces) res->n_chunks += q.c1 - q.c0;
     }
     if (!compat && tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
-        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.bases = tb;
+        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.piece_n1 = hs.piece_n1; g.bases = tb;
         rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
         if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
     }
@@ -413,7 +424,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             const uint32_t c0 = r.c0, c1 = r.c1; uint64_t reads = 0, rbases = 0; for (uint32_t c = c0; c < c1; c++) { reads += hc[c].reads; rbases += hc[c].bases; }
             hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
             KCHK(ctx, "k_dec_rebase");
-            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.bases = rbases;
+            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.piece_n1 = hs.piece_n1; g.bases = rbases;
             uint8_t *q1 = nullptr, *q2 = nullptr; size_t m1 = 0, m2 = 0; uint64_t mb = 0;
             ctx->timer.reset();
             rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);

@@ -35,8 +35,9 @@ struct DecStatus {
     uint32_t max_len, max_bases;     // longest read / largest chunk (bases, clamped to 2^32 - 1) of the image
     uint32_t max_nrec, max_one;      // most exception records of any chunk / longest single quality stream (by-column quality payloads)
     unsigned long long list_need;    // fused path: entries of all position lists (k_dec_pos_off)
-    uint32_t per_read_pieces, piece_avg;  // some chunk stores name1 / name2 / strand per read; the largest average size of such a piece over the chunks, as a
-                                     // fraction of its tile capacity in 1/256 (k_dec_emit3: the host sizes its tiles by it, a tile that still does not fit asks for k_dec_emit2)
+    uint32_t per_read_pieces, piece_avg;  // some chunk stores name1 / name2 / strand per read; the largest average size of a per-read name2 / strand piece over the
+                                     // chunks, as a fraction of its tile capacity in 1/256 (k_dec_emit3: the host sizes its tiles by it, a tile that still does not fit asks for k_dec_emit2)
+    uint32_t piece_n1, pad4;              // the same for name1, in bytes per read (rounded up): k_dec_emit3 has a second instantiation with a large name1 tile
 };
 
 // sum of n bytes by one wave (wave-uniform result)
@@ -331,12 +332,12 @@ __global__ void k_dec_parse(const uint8_t* __restrict__ img, uint64_t n, const D
 __global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint32_t first, uint32_t count) {
     if (st->overflow || st->pad) return;
     const uint32_t end = first + count < st->n_chunks ? first + count : st->n_chunks;
-    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, pr = 0, pa = 0; unsigned long long sum = 0;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, pr = 0, pa = 0, p1 = 0; unsigned long long sum = 0;
     for (uint32_t c = first + threadIdx.x; c < end; c += blockDim.x) {
         const DChunk& d = CH[c];
         if ((d.flags & (C_NAME1_SAME | C_NAME2_SAME | C_STRAND_SAME)) != (C_NAME1_SAME | C_NAME2_SAME | C_STRAND_SAME)) pr = 1;
         if (d.reads) {                                                     // per-read pieces: bytes per read against the emitter's tile capacity for that piece
-            if (!(d.flags & C_NAME1_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.n1_size * 256ull / d.reads + ET_N1CAP - 1) / ET_N1CAP); if (v > pa) pa = v; }
+            if (!(d.flags & C_NAME1_SAME)) { const uint32_t v = (d.n1_size + d.reads - 1) / d.reads; if (v > p1) p1 = v; }
             if (!(d.flags & C_NAME2_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.n2_size * 256ull / d.reads + ET_N2CAP - 1) / ET_N2CAP); if (v > pa) pa = v; }
             if (!(d.flags & C_STRAND_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.st_size * 256ull / d.reads + ET_STCAP - 1) / ET_STCAP); if (v > pa) pa = v; }
         }
@@ -351,6 +352,7 @@ __global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint
     m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2); m3 = wave_max(m3); m4 = wave_max(m4); m5 = wave_max(m5); sum = wave_sum<unsigned long long>(sum);
     if (__any(pr != 0) && lane_id() == 0) atomicOr(&st->per_read_pieces, 1u);
     pa = wave_max(pa); if (pa && lane_id() == 0) atomicMax(&st->piece_avg, pa);
+    p1 = wave_max(p1); if (p1 && lane_id() == 0) atomicMax(&st->piece_n1, p1);
     if (lane_id() == 0) { atomicMax(&st->max_stream, m0); atomicMax(&st->max_npos, m1); atomicMax(&st->max_len, m2); atomicMax(&st->max_bases, m3); atomicMax(&st->max_nrec, m4); atomicMax(&st->max_one, m5);
                           atomicAdd((unsigned long long*)&st->base_slots[0], sum); }
 }
@@ -1654,6 +1656,7 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
 //   * the quality group of the same 16 positions is in registers at that moment (same lane), which is all the implied-N rule needs.
 // Everything else - the lists' exact entry ranges from the cell index, wave-per-list rounds, the next tile's metadata requested a tile ahead - is k_dec_emit2's.
 #define E3_QCAP 10240u            // quality tile: K reads' qualities (64 x 160)
+#define E3_N1BIG 13312u           // name1 tile of the second instantiation: 64 per-read names of 200 bytes (34 KB of LDS, four workgroups per CU)
 struct __attribute__((packed, aligned(1))) GU16d { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) GU8d { uint32_t a, b; };
 struct __attribute__((packed, aligned(1))) GU4d { uint32_t a; };
@@ -1686,14 +1689,14 @@ __device__ __forceinline__ uint32_t e3_rev1x16(uint32_t v) {
 // dword i of the mask "bytes >= t of a 16-byte group" (t <= 0: all of them, t >= 16: none)
 __device__ __forceinline__ uint32_t e3_from(int t, int i) { const int k = t - 4 * i; return k <= 0 ? 0xFFFFFFFFu : (k >= 4 ? 0u : 0xFFFFFFFFu << (8 * k)); }
 __device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }   // v_alignbyte_b32
-template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
                            uint32_t ncell, uint32_t nstr, uint32_t kshift, int abl) {
     __shared__ uint4 t_q4[E3_QCAP / 16 + 6];                                // quality tile (16 bytes of slack in front, the rest behind)
     __shared__ uint4 t_pk4[E3_QCAP / 64 + 6];                               // the tile's packed bases
     __shared__ uint32_t t_nb[E3_QCAP / 32 + 8];                             // one bit per stored base of the tile: is N
-    __shared__ uint4 t_mid4_[64 * 40 / 16 + 5], t_n14_[ET_N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];
+    __shared__ uint4 t_mid4_[64 * 40 / 16 + 5], t_n14_[N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];      // (N1CAP: E3_N1BIG for files with long per-read names)
     uint4* const t_mid4 = t_mid4_ + 1; uint4* const t_n14 = t_n14_ + 1; uint4* const t_n24 = t_n24_ + 1;   // (16 readable bytes in front of each: a 16-byte group of the name line may start before a piece)
     __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
     __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2];
@@ -1749,7 +1752,7 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
     while (cur < re) {                                                       // block-uniform
         const uint32_t cnt = re - cur < K ? re - cur : K, g0 = f + cur, g1 = g0 + cnt;
         const TileP tp = tp_cur; const uint32_t q0 = tp.q0, q1 = tp.q1, s0 = tp.s0, s1 = tp.s1;
-        const bool fits = q1 - q0 <= E3_QCAP && (same1 || tp.e7 - tp.a7 + 32u <= ET_N1CAP) && (same2 || tp.e8 - tp.a8 + 32u <= ET_N2CAP) && (same3 || tp.e9 - tp.a9 + 32u <= ET_STCAP);
+        const bool fits = q1 - q0 <= E3_QCAP && (same1 || tp.e7 - tp.a7 + 32u <= N1CAP) && (same2 || tp.e8 - tp.a8 + 32u <= ET_N2CAP) && (same3 || tp.e9 - tp.a9 + 32u <= ET_STCAP);
         if (!fits) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_E3_RETRY); break; }   // (the host sizes K by the longest read and by the chunks' average piece sizes; a tile whose pieces are longer than that allowed for: the host repeats the range with k_dec_emit2)
         // ---- stage: packed bases, middles, per-read name pieces (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
         const uint64_t ib = d.off;
@@ -1761,7 +1764,7 @@ template <bool IMPL> __global__ void __launch_bounds__(256) k_dec_emit3(const ui
         if (raw) span_dma<(int)((E3_QCAP / 16 + 4 + 255) / 256)>(make_span(t_q4 + 1, img, rqa, rqe, img_bytes, true));
         if (w == 0) span_dma_wave<(int)((E3_QCAP / 64 + 4 + 63) / 64)>(make_span(t_pk4, img, pka, pke, img_bytes, true), l);
         else if (w == 1) span_dma_wave<(int)((64 * 40 / 16 + 4 + 63) / 64)>(make_span(t_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
-        else if (w == 2) { if (!same1) span_dma_wave<(int)((ET_N1CAP / 16 + 4 + 63) / 64)>(make_span(t_n14, img, n1a, n1e, img_bytes, true), l); }
+        else if (w == 2) { if (!same1) span_dma_wave<(int)((N1CAP / 16 + 4 + 63) / 64)>(make_span(t_n14, img, n1a, n1e, img_bytes, true), l); }
         else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, n2a, n2e, img_bytes, true), l);
                if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, sta, ste, img_bytes, true), l); }
         // qualities start as the major value (src/rfqcodec.cpp:1089), the N bits as none

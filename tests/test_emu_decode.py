@@ -127,12 +127,12 @@ def test_fixed_tile_emitter_with_per_read_name_pieces():
     assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
     codec.close()
     codec = RfqCodec(device=0, library=E.build_emu())
-    longn = _handmade(300, lambda i: "N" * 240 + "%d" % i, lambda i: 100, lambda i: "+", seed=5)          # (sixteen of them do not fit a tile)
+    longn = _handmade(300, lambda i: "N" * 240 + "%d" % i, lambda i: 100, lambda i: "+", seed=5)          # (64 of them do not fit the large tile either)
     assert codec.decode_bytes(O.encode_file(longn, b"", O.SE, 1_000_000)) == longn
     assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
-    mid = _handmade(300, lambda i: "N" * 120 + "%d" % i, lambda i: 100, lambda i: "+", seed=6)           # (sixteen would fit: only full tiles of 64 pay)
+    mid = _handmade(300, lambda i: "N" * 120 + "%d" % i, lambda i: 100, lambda i: "+", seed=6)           # (the instantiation with the 13 KB name tile)
     assert codec.decode_bytes(O.encode_file(mid, b"", O.SE, 1_000_000)) == mid
-    assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
+    assert "emit" in dict(codec.timings()), dict(codec.timings())
     codec.close()
 
 
