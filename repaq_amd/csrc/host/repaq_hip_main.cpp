@@ -675,6 +675,53 @@ static void do_compress_multi(const Options& o) {
     for (int s = 0; s < ns; s++) { ds[s].free_all(gs); delete in[s]; }
 }
 
+// RfqChunk::read's chain (src/rfqchunk.cpp:161-228) on the host, as the blocks of the image go by on their way to the GPU: the format has no chunk
+// index, chunk c + 1 is found from chunk c's 12-byte header (mSize, mReads, mFlags; mSize is short of the true size by what the writer's size bug
+// leaves out, SURVEY.md App. C Q1: a function of the header's and the chunk's flags).  The offsets go to rfq_decode_batch as its optional chunk
+// index, which takes the dependent walk off the device; every extent is verified there all the same, a table that does not verify is ignored.
+struct ChunkWalker {
+    std::vector<uint64_t> off;             // absolute offsets of the chunk starts found so far
+    uint64_t fed = 0, next = 0;            // bytes seen; where the next chunk header starts
+    uint8_t head[17]; int nhead = 0; uint8_t carry[12]; int ncarry = 0;
+    uint32_t hf = 0; bool have_hdr = false, dead = false, ended = false;
+    static uint32_t u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+    void feed(const uint8_t* p, size_t n) {
+        const uint64_t base = fed; fed += n;
+        if (dead || ended) return;
+        size_t i = 0;
+        if (!have_hdr) {                                                     // RfqHeader::read (src/rfqheader.cpp:19-43): 17 bytes + the quality table
+            while (nhead < 17 && i < n) head[nhead++] = p[i++];
+            if (nhead < 17) return;
+            hf = (uint32_t)head[10] | ((uint32_t)head[11] << 8); next = 17u + head[16]; have_hdr = true;
+        }
+        for (;;) {
+            if (next + 12 > fed) {                                            // the header is not (all) here yet: keep what there is of it
+                if (next < fed) { const uint64_t from = std::max(next, base); const size_t k = (size_t)(fed - from); if (ncarry + k <= 12) { memcpy(carry + ncarry, p + (from - base), k); ncarry += (int)k; } else dead = true; }
+                return;
+            }
+            uint8_t h[12];
+            if (ncarry) { const size_t k = 12 - ncarry; memcpy(h, carry, ncarry); memcpy(h + ncarry, p + (next + ncarry - base), k); ncarry = 0; }
+            else memcpy(h, p + (next - base), 12);
+            const uint32_t ms = u32(h), reads = u32(h + 4), fl = (uint32_t)h[8] | ((uint32_t)h[9] << 8);
+            if (reads == 0) { ended = true; return; }                        // a clean end (RfqChunk::read leaves mReads 0)
+            const uint32_t half = (fl & (1u << 9)) ? reads / 2 : reads;      // C_PE_INTERLEAVED: lane / tile per pair (constants: rfq_common.h)
+            long long total = (long long)ms;
+            if (hf & 1u) total += (fl & (1u << 4)) ? 1 : (long long)half;                  // H_LANE, C_LANE_SAME
+            if (!(hf & 2u)) total -= (fl & (1u << 5)) ? 2 : 2ll * half;                    // H_TILE, C_TILE_SAME
+            if (!(hf & 16u)) total -= (fl & (1u << 2)) ? 1 : (long long)reads;             // H_NAME2, C_NAME2_LEN_SAME
+            if (total < 18 || reads > 0x1000000u || fl >= 0x1000u) { dead = true; return; }
+            off.push_back(next); next += (uint64_t)total;
+        }
+    }
+    // chunk index of the batch [b0, b0 + n): offsets relative to b0 of every chunk that lies wholly inside, then the end of the last one
+    bool table(uint64_t b0, size_t n, std::vector<uint64_t>& t) const {
+        t.clear(); if (dead) return false;
+        auto it = std::lower_bound(off.begin(), off.end(), b0);
+        for (; it != off.end(); ++it) { const uint64_t end = (it + 1 != off.end()) ? *(it + 1) : next; if (end > b0 + n || (it + 1 == off.end() && next > fed)) break; if (t.empty()) t.push_back(*it - b0); t.push_back(end - b0); }
+        return t.size() >= 2;
+    }
+};
+
 // Streaming decoder: .rfq blocks -> rfq_decode_batch over whole chunks -> device text handed to `emit_dev(out1, n1, out2, n2)`
 struct DecodeTotals { uint64_t reads = 0, bases = 0; };
 static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& path, bool split,
@@ -683,15 +730,18 @@ static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& p
     // image bytes per call ~ 1/8 of the text batch: .rfq is 7-25 % of its FASTQ, so the text of one call is about one batch
     const size_t batch = std::max<size_t>(o.batchBytes / 8, (size_t)1 << 16), block = std::min(batch, o.block());
     Prefetcher in(g, path, block, o.ioThreads);
-    DevStream ds; bool first = true; size_t want = batch; DecodeTotals tot;
+    DevStream ds; bool first = true; size_t want = batch; DecodeTotals tot; ChunkWalker walker;
     for (;;) {
         while (!ds.ended && ds.have < want) {
             Block b; if (!in.next(b)) { ds.ended = true; break; }
+            walker.feed(b.p, b.n);                                            // (the chunk headers, while the block is on its way)
             ds.append(g, b, batch + block); in.release(b);
             if (in.drained()) ds.ended = true;
         }
         trace_mark("decode: batch resident");
         rfq_decode_args a; memset(&a, 0, sizeof a);
+        std::vector<uint64_t> tab;
+        if (walker.table(ds.file_off, ds.have, tab)) { a.h_chunk_off = tab.data(); a.n_chunk_off = (uint32_t)(tab.size() - 1); }
         a.d_rfq = ds.base(); a.n = ds.have; a.has_header = first ? 1 : 0; a.split_pe = split ? 1 : 0; a.final = ds.ended ? 1 : 0; a.bug_compat = (o.bugCompat && o.decompress) ? 1 : 0;
         rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
         first = false;
@@ -718,6 +768,98 @@ static void do_decompress(const Options& o) {
     });
     w1.finish(); if (w2) { w2->finish(); delete w2; }
     trace_mark("decompress: outputs closed");
+}
+
+// Chunk-parallel decompress of one image over several GPUs (--devices a,b,... with -d).  The main thread streams the image, walks the chunk
+// headers as the blocks go by (ChunkWalker) and deals RANGES of whole chunks - about one batch of text each - into a queue; one worker per device
+// PULLS the next range, uploads it through its OWN device's link (per-device ingestion: nothing crosses between the GPUs), decodes it with the
+// range's chunk index and hands the text to an ordered writer.  Only the <= 272-byte header is shared.
+struct DecItem { uint64_t seq = 0; std::vector<uint8_t> bytes; std::vector<uint64_t> tab; bool final = false; };
+static void do_decompress_multi(const Options& o) {
+    if (o.bugCompat) error_exit("--bug_compat follows the reference's loop from chunk to chunk: use a single device");
+    const bool split = !o.out2.empty();
+    Gpu gs(o.devices[0]);                                                    // (page-locked staging blocks of the reader)
+    const size_t target = std::max<size_t>(o.batchBytes / 8, (size_t)1 << 16), block = std::min(target, o.block());
+    Prefetcher in(gs, o.in1, block, o.ioThreads);
+    std::mutex mu; std::condition_variable cv;
+    std::deque<DecItem> queue; bool no_more = false; std::vector<uint8_t> header; bool header_ready = false;
+    std::map<uint64_t, std::pair<std::vector<uint8_t>, std::vector<uint8_t>>> done; uint64_t next_write = 0, total_items = 0; bool all_queued = false;
+    ByteSink s1; s1.open(o.out1, o); ByteSink s2; if (split) s2.open(o.out2, o);
+    std::thread writer([&] {
+        for (;;) {
+            std::pair<std::vector<uint8_t>, std::vector<uint8_t>> t;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.count(next_write) || (all_queued && next_write == total_items); });
+              if (all_queued && next_write == total_items) return;
+              t = std::move(done[next_write]); done.erase(next_write); next_write++; cv.notify_all(); }
+            if (!t.first.empty()) s1.write(t.first.data(), t.first.size());
+            if (split && !t.second.empty()) s2.write(t.second.data(), t.second.size());
+        }
+    });
+    std::vector<std::thread> workers;
+    for (size_t w = 0; w < o.devices.size(); w++) workers.emplace_back([&, w] {
+        Gpu g(o.devices[w]); void* d = nullptr; size_t cap = 0; bool have_hdr = false;
+        for (;;) {
+            DecItem it;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = std::move(queue.front()); queue.pop_front(); cv.notify_all(); }
+            if (!have_hdr) { { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return header_ready; }); } g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
+            if (cap < it.bytes.size() + 64) { if (d) rfq_dev_free(g.c, d); cap = it.bytes.size() + it.bytes.size() / 4 + 64; d = g.dev(cap); }
+            g.check(rfq_copy_h2d(g.c, d, it.bytes.data(), it.bytes.size()));
+            rfq_decode_args a; memset(&a, 0, sizeof a);
+            a.d_rfq = (const uint8_t*)d; a.n = it.bytes.size(); a.has_header = 0; a.split_pe = split ? 1 : 0; a.final = it.final ? 1 : 0;
+            a.h_chunk_off = it.tab.data(); a.n_chunk_off = (uint32_t)(it.tab.size() - 1);
+            rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
+            if (r.consumed != it.bytes.size()) error_exit("internal: a dealt range does not decode as whole chunks");
+            std::pair<std::vector<uint8_t>, std::vector<uint8_t>> t; t.first.resize(r.n1); t.second.resize(split ? r.n2 : 0);
+            if (r.n1) g.check(rfq_copy_d2h(g.c, t.first.data(), r.d_fq1, r.n1));
+            if (split && r.n2) g.check(rfq_copy_d2h(g.c, t.second.data(), r.d_fq2, r.n2));
+            std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.size() < 2 * o.devices.size() || it.seq == next_write; });
+            done[it.seq] = std::move(t); cv.notify_all();
+        }
+        if (d) rfq_dev_free(g.c, d);
+    });
+    // the dealer: bytes not dealt yet start at a chunk boundary (pend_off) - or, at first, at the file header
+    ChunkWalker walker; std::vector<uint8_t> pend; uint64_t pend_off = 0, seq = 0; bool hdr_done = false, ended = false;
+    auto deal = [&](bool last) {
+        if (!hdr_done) {
+            if (!walker.have_hdr || walker.fed < 17u + walker.head[16]) { if (last && walker.fed) error_exit("Not a valid repaq file!"); return; }
+            const size_t hl = 17u + walker.head[16];
+            { std::unique_lock<std::mutex> lk(mu); header.assign(pend.begin(), pend.begin() + hl); header_ready = true; cv.notify_all(); }
+            { Gpu& g = gs; g.check(rfq_set_header(g.c, header.data(), header.size())); }                   // (validates it: the reference's messages for a foreign / newer file)
+            pend.erase(pend.begin(), pend.begin() + hl); pend_off = hl; hdr_done = true;
+        }
+        if (walker.dead) error_exit("cannot index the image's chunks on the host: decompress it on a single device");
+        for (;;) {
+            // the chunk ends known so far that lie inside pend: cut behind the last one within `target` bytes (at least one chunk; everything at the end)
+            auto lo = std::lower_bound(walker.off.begin(), walker.off.end(), pend_off);
+            if (lo == walker.off.end()) break;
+            std::vector<uint64_t> tab; uint64_t e = pend_off;
+            for (auto it = lo; it != walker.off.end(); ++it) {
+                const uint64_t end = (it + 1 != walker.off.end()) ? *(it + 1) : walker.next;
+                if (end > pend_off + pend.size()) break;
+                if (tab.empty()) tab.push_back(*it - pend_off);
+                tab.push_back(end - pend_off); e = end;
+                if (!last && e - pend_off >= target) break;
+            }
+            if (tab.size() < 2) break;
+            const bool all = last && e >= walker.next;                         // (behind it: nothing, or a tail too short to be a chunk)
+            if (!last && e - pend_off < target) break;                         // (wait for more: ranges of about a batch of text)
+            DecItem it; it.seq = seq++; it.bytes.assign(pend.begin(), pend.begin() + (e - pend_off)); it.tab = std::move(tab); it.final = all;
+            pend.erase(pend.begin(), pend.begin() + (e - pend_off)); pend_off = e;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return queue.size() < 2 * o.devices.size(); }); queue.push_back(std::move(it)); cv.notify_all(); }
+            if (all) break;
+        }
+        if (last && !pend.empty() && pend.size() >= 18) error_exit("the image ends inside a chunk");
+    };
+    while (!ended) {
+        Block b; if (!in.next(b)) { ended = true; break; }
+        walker.feed(b.p, b.n); pend.insert(pend.end(), b.p, b.p + b.n); in.release(b);
+        if (in.drained()) ended = true;
+        deal(ended);
+    }
+    deal(true);
+    { std::unique_lock<std::mutex> lk(mu); no_more = true; total_items = seq; all_queued = true; header_ready = true; cv.notify_all(); }
+    for (auto& t : workers) t.join();
+    writer.join(); s1.close(); if (split) s2.close();
 }
 
 // ---- compare mode (src/repaq.cpp:36-259): decode on the GPU, compare read by read with the FASTQ text, same JSON
@@ -918,7 +1060,7 @@ int main(int argc, char** argv) {
         if (!o.in2.empty()) error_exit("In decompress mode, only one RFQ input file is allowed, but you specified <in2>");
         if (ends_with(o.in1, ".fq") || ends_with(o.in1, ".fastq")) error_exit("In decompress mode, the input should not be a FASTQ file. Expect a .rfq or .rfq.xz file, but got " + o.in1);
         if (ends_with(o.out1, ".rfq")) error_exit("In decompress mode, the output should not be a RFQ file. Expect a .fq or .fq.gz file, but got " + o.out1);
-        do_decompress(o);
+        if (o.devices.size() > 1) do_decompress_multi(o); else { if (o.devices.size() == 1) o.device = o.devices[0]; do_decompress(o); }
     } else {
         if (o.useStdin) o.rfqCompare = "/dev/stdin";
         if (o.rfqCompare.empty()) error_exit("In compare mode, you should specify the RFQ file to compare by <rfq_to_compare>");

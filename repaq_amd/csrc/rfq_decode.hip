@@ -312,7 +312,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             HIPCHK(ctx, hipMemsetAsync(cand, 0xFF, GW_SEGS * 8, S)); HIPCHK(ctx, hipMemsetAsync(gbad, 0, 4, S));
             const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> (getenv("RFQ_GW_SHIFT") ? atoi(getenv("RFQ_GW_SHIFT")) : 16)));   // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
             if (mseg > 1) hipLaunchKernelGGL(k_dec_gw_find, dim3(16, mseg - 1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, cand, mseg);
-            hipLaunchKernelGGL(k_dec_gw_walk, dim3(mseg), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, B[DB_GWLIST].as<unsigned long long>(), B[DB_GWCNT].as<uint32_t>(), B[DB_GWLAND].as<unsigned long long>(), gbad, mseg);
+            hipLaunchKernelGGL(k_dec_gw_walk, dim3(mseg), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, B[DB_GWLIST].as<unsigned long long>(), B[DB_GWCNT].as<uint32_t>(), B[DB_GWLAND].as<unsigned long long>(), gbad, mseg, a->final ? 1 : 0);
             hipLaunchKernelGGL(k_dec_gw_stitch, dim3(1), dim3(1024), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, (const unsigned long long*)B[DB_GWLIST].as<unsigned long long>(),
                                (const uint32_t*)B[DB_GWCNT].as<uint32_t>(), (const unsigned long long*)B[DB_GWLAND].as<unsigned long long>(), (const uint32_t*)gbad, B[DB_OFFT].as<uint64_t>(), cap, dst, mseg);
             hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), 0xFFFFFFFFu, B[DB_CHUNKS].as<DChunk>(), dst);
@@ -332,7 +332,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         HIPCHK(ctx, ctx->fetch_sync(S));
         if (use_table) {
             // the table must cover whole chunks up to the end of the image (or up to a tail too short to be a chunk): anything else walks
-            if (hs.pad || (hs.consumed != a->n && a->n - hs.consumed >= 18)) { use_table = false; continue; }
+            // (a range that does not end the image may end inside a chunk: whole chunks in front of it are all a table has to cover there)
+            if (hs.pad || (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0))) { use_table = false; continue; }
             break;
         }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
@@ -348,7 +349,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             if (h2.pad) { if (guess) { guess = false; continue; } speculate = false; continue; }
             hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; hs.piece_avg = h2.piece_avg; hs.piece_n1 = h2.piece_n1; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
-        if (hs.consumed != a->n && a->n - hs.consumed >= 18) { if (guess) { guess = false; continue; } speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk
+        if (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0)) { if (guess) { guess = false; continue; } speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk (a range that does not end the image may end inside one)
         (void)table;
         break;
     }

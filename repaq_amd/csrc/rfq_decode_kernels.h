@@ -211,6 +211,15 @@ __device__ __forceinline__ bool gw_plausible(const uint8_t* __restrict__ img, ui
     if (ld_u32(img + o2 + 4) == 0) return true;                             // mReads == 0: a clean end
     return gw_plausible(img, n, o2, hf, true, nullptr);
 }
+// the header at o is plausible in its fields but the chunk runs past the end of the image (the tail of a range that does not end the image)
+__device__ __forceinline__ bool gw_cut_by_end(const uint8_t* __restrict__ img, uint64_t n, uint64_t o, uint32_t hf) {
+    if (n - o < 18) return true;
+    const LdsU16 hd = *(const LdsU16*)(img + o);
+    const uint32_t ms = hd.a, s = hd.b, fl = hd.c & 0xFFFFu;
+    if (s == 0 || s > 0x1000000u || fl >= 0x1000u) return false;
+    const long long total = gw_total(ms, s, fl, hf);
+    return total >= 18 && (unsigned long long)total > n - o;
+}
 __device__ __forceinline__ GwGeo gw_geo(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, uint32_t hf, uint32_t max_seg) {
     GwGeo g; g.first = 0; g.seglen = n - start; g.win = 0; g.nseg = 1;
     uint64_t nx = 0;
@@ -258,7 +267,7 @@ __global__ void k_dec_gw_find(const uint8_t* __restrict__ img, uint64_t n, uint6
 }
 // a wave per segment: the chain from its candidate up to the next segment that has one; list[k][..] = the chunk starts met, land[k] = where it stopped
 __global__ void k_dec_gw_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, const unsigned long long* __restrict__ cand,
-                              unsigned long long* __restrict__ list, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ land, uint32_t* __restrict__ bad, uint32_t max_seg) {
+                              unsigned long long* __restrict__ list, uint32_t* __restrict__ cnt, unsigned long long* __restrict__ land, uint32_t* __restrict__ bad, uint32_t max_seg, int final) {
     const uint32_t hf = D->flags; const GwGeo g = gw_geo(img, n, start, hf, max_seg);
     const uint32_t k = blockIdx.x; if (k >= g.nseg) return;
     uint64_t o = k == 0 ? start : cand[k];
@@ -268,7 +277,11 @@ __global__ void k_dec_gw_walk(const uint8_t* __restrict__ img, uint64_t n, uint6
     while (o < stop) {
         uint64_t nx = 0;
         if (n - o < 18 || ld_u32(img + o + 4) == 0) { ended = 1; break; }   // end of the image
-        if (!gw_plausible(img, n, o, hf, true, &nx)) { b = 1; break; }
+        if (!gw_plausible(img, n, o, hf, true, &nx)) {
+            // a range that does not end the image may end inside a chunk: a header whose fields hold but whose size leads past the end stops the chain cleanly
+            if (!final && gw_cut_by_end(img, n, o, hf)) { ended = 1; break; }
+            b = 1; break;
+        }
         if (c < GW_LCAP) { if (lane_id() == 0) list[(size_t)k * GW_LCAP + c] = o; } else { b = 1; break; }
         c++; o = nx;
     }

@@ -125,6 +125,16 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
     assert om.read_bytes() == pe.read_bytes()
     r = _run(binary, ["-c", "--stdin", "--stdout", "-k", "100", "--batch_mb", str(4 * batch_mb), "--devices=0,0,0,0"], input=fq1)
     assert r.returncode == 0 and r.stdout == og.read_bytes(), r.stderr
+    # -d --devices a,b,c: the image's chunk headers walked on the host as the blocks go by, ranges of whole chunks pulled by one worker per device
+    # (each uploads its own range), ordered writer - the text must be the one-device text; an image without a final line break too
+    for src, split, ref in ((og, False, fq1), (pe, True, None)):
+        o1 = tmp_path / "multi_back_1.fq"; o2 = tmp_path / "multi_back_2.fq"
+        r = _run(binary, ["-d", "-i", str(src), "-o", str(o1)] + (["-O", str(o2)] if split else []) + ["--batch_mb", str(batch_mb), "--devices", "0,0,0"])
+        assert r.returncode == 0, r.stderr
+        if split:
+            assert o1.read_bytes() == pa.read_bytes() and o2.read_bytes() == pb.read_bytes()
+        else:
+            assert o1.read_bytes() == ref
     # a file of exactly 1 MiB without a final line break: only the chunk that holds the last record carries the line-break bit (ADVICE r1;
     # the driver computes the threshold itself, one-shot and under --devices)
     from cases import CASES
