@@ -2043,6 +2043,160 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
     else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), R.pv[e].d - R.pv[f].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
+// =============================================================== position coder for MANY value streams, list form (RFQ_CODER=ms; measured, not the default)
+// k_pos_coder tests every position against every value: ~650 instructions per ACTIVE stream and 4096-position step - three streams on a NovaSeq-binned
+// file, forty on an old-Illumina / BGI one (the configs[4] shape), where it is most of the encode.  Here one wave codes ALL value streams of a (chunk,
+// segment): per step every quality byte is looked up ONCE in the header's value -> stream table, the coded positions are bucketed by stream in LDS
+// (a count pass, one prefix over the lanes per stream, a scatter pass: the list holds each stream's positions in ascending order), and the tokens are
+// made from the LIST, 64 entries per round whatever streams they belong to - the closed form of k_pos_coder's header comment read per entry:
+//   entry p is a streak START when the previous match of its stream is not p - 1:  gap token, d = p - previous match (1 / 2 / 4 bytes);
+//   p == 1 in a streak that starts at 0:  token 0x00 (the `cur > 1` rule);
+//   p == a + b + 32 k (a = start of its streak, b = 2 if a == 0 else 1):  run token 0xC0 | (min(32, matches from p on) - 1);  nothing otherwise.
+// A stream's previous match and the start of its open streak carry over in LDS from step to step; a segment takes them from segc (k_gather*) and, when
+// it begins inside a streak, from a walk back over the bytes.  Slots, capacities and byte counts are k_pos_coder's (pc_seg_cap, segb): k_assemble is unchanged.
+// STATUS: bit-exact (the interpreter's whole encode suite and the fuzzes with it forced on; the configs[2] / configs[4] goldens on the GPU) and SLOWER than
+// k_pos_coder - 4.4 against 3.2 ms at forty streams, 15.6 against 5.5 ms at three: a round of 64 list entries costs ~400 instructions.
+#define MS_LIST 4096u
+struct MsLds {
+    uint16_t list[MS_LIST];                  // positions inside the step, stream after stream
+    uint8_t sid[MS_LIST];                    // the stream of every list entry
+    uint16_t base[NPOS_SLOT][64];            // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part
+    uint16_t off[NPOS_SLOT + 2];             // where a stream's part of the list starts
+    int prev[NPOS_SLOT], sa[NPOS_SLOT];      // last match so far (-1: none), start of the streak it belongs to
+    uint32_t outpos[NPOS_SLOT], room[NPOS_SLOT]; unsigned long long out[NPOS_SLOT];
+    uint8_t tab[256], q[NPOS_SLOT], on[NPOS_SLOT], after[NPOS_SLOT];
+};
+__global__ void __launch_bounds__(64) k_pos_coder_ms(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
+                                                     uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks, DevStatus* st, int abl) {
+    __shared__ MsLds S;
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3;       // (a chunk's workgroups on one XCD, as in k_pos_coder)
+    const uint32_t c = (idx / n_seg) * 8u + xcd, seg = idx % n_seg;
+    if (c >= n_chunks) return;
+    const int l = lane_id();
+    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];
+    const uint8_t* __restrict__ B = qcat + C.qbase[c]; const uint32_t len = R.pq[e] - R.pq[f];
+    const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS, step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
+    if (step0 >= nsteps) return;
+    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = D->stream_of[v]; S.tab[v] = (uint8_t)(j < nn ? j : 0xFFu); }
+    {   // a lane per stream: is it there, where it stands, where its bytes go (pc_run's entry state)
+        const uint32_t j = (uint32_t)l; bool on = false;
+        if (j < nn) {
+            const size_t k = (size_t)c * MAX_STREAMS + j, s0i = k * n_seg; const uint32_t cap = C.scap[k], qv = D->normal[j];
+            on = cap != 0 && segm[s0i + seg] != 0;
+            int prev = -1; for (int s_ = (int)seg - 1; s_ >= 0 && prev < 0; s_--) prev = segc[s0i + (uint32_t)s_];
+            uint32_t off = 0; for (uint32_t s_ = 0; s_ < seg; s_++) off += pc_seg_cap(false, segm[s0i + s_], PC_SEG_POS);
+            const uint32_t own = pc_seg_cap(false, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
+            int sa = -1;
+            if (on && prev >= 0 && (uint32_t)prev + 1u == step0 * 4096u) { int p = prev; while (p > 0 && B[p - 1] == (uint8_t)qv) p--; sa = p; }   // the segment begins inside a streak
+            S.q[j] = (uint8_t)qv; S.prev[j] = prev; S.sa[j] = sa; S.outpos[j] = 0; S.room[j] = off + own <= cap ? own : 0u;
+            S.out[j] = (unsigned long long)(uintptr_t)(scratch + cbase[c] + C.soff[k] + off);
+        }
+        S.on[l] = on ? 1 : 0;
+        if (!__any(on)) return;
+    }
+    wave_lds_sync();
+    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = S.tab[v]; if (j != 0xFFu && !S.on[j]) S.tab[v] = 0xFFu; }   // (values whose stream has nothing in this segment: not looked at again)
+    wave_lds_sync();
+    const uint32_t inc = (l & 1) ? 0x10000u : 1u;
+    for (uint32_t step = step0; step < step1; step++) {
+        const uint32_t sb = step * 4096u, p0 = sb + 64u * (uint32_t)l;
+        const uint32_t nv = p0 >= len ? 0u : (len - p0 < 64u ? len - p0 : 64u);
+        const Raw64 r = pc_load_raw(B, len, p0);
+        const uint32_t w[16] = { r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w, r.v[1].x, r.v[1].y, r.v[1].z, r.v[1].w, r.v[2].x, r.v[2].y, r.v[2].z, r.v[2].w, r.v[3].x, r.v[3].y, r.v[3].z, r.v[3].w };
+        // ---- the stream of each of my 64 positions: 64 independent table reads, kept packed in registers (0xFF: none)
+        uint32_t sw[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t x = w[i];
+            const uint32_t s0_ = S.tab[x & 0xFFu], s1_ = S.tab[(x >> 8) & 0xFFu], s2_ = S.tab[(x >> 16) & 0xFFu], s3_ = S.tab[x >> 24];
+            uint32_t v = s0_ | (s1_ << 8) | (s2_ << 16) | (s3_ << 24);
+            const int left = (int)nv - 4 * i;                                // positions behind the chunk's end: none
+            if (left < 4) v |= left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * left));
+            sw[i] = v;
+        }
+        // ---- count: my positions per stream (fire-and-forget 32-bit atomics on the u16 pairs of neighbouring lanes)
+        for (uint32_t j = 0; j < nn; j++) S.base[j][l] = 0;
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 64; k++) { const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu; if (j != 0xFFu) atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); }
+        wave_lds_sync();
+        // ---- a prefix over the lanes per stream: where my entries of the stream go
+        uint32_t tot = 0;
+        for (uint32_t j = 0; j < nn; j++) {                                // (wave-uniform)
+            if (l == 0) S.off[j] = (uint16_t)tot;
+            if (!uni32(S.on[j])) continue;
+            const uint32_t cnt = S.base[j][l], incl = wave_incl_sum<uint32_t>(cnt);
+            S.base[j][l] = (uint16_t)(incl - cnt);
+            tot += (uint32_t)__shfl((int)incl, 63);
+        }
+        if (l == 0) { S.off[nn] = (uint16_t)tot; S.off[nn + 1] = (uint16_t)tot; }
+        const uint32_t E = tot;
+        wave_lds_sync();
+        // ---- scatter the positions into the list (returning atomics, independent of one another)
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            if (j != 0xFFu) { const uint32_t old_ = atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); const uint32_t at = S.off[j] + ((l & 1) ? old_ >> 16 : old_ & 0xFFFFu);
+                              S.list[at] = (uint16_t)(64u * (uint32_t)l + (uint32_t)k); S.sid[at] = (uint8_t)j; }
+        }
+        // ---- matches that open the next step (a run token looks up to 31 positions ahead)
+        if ((uint32_t)l < nn && S.on[l]) { const uint32_t nb_ = sb + 4096u; uint32_t k = 0; const uint8_t qv = S.q[l]; while (k < 31u && nb_ + k < len && B[nb_ + k] == qv) k++; S.after[l] = (uint8_t)k; }
+        wave_lds_sync();
+        // ---- tokens, 64 list entries per round
+        for (uint32_t r0 = 0; r0 < ((abl & 1) ? 0u : E); r0 += 64u) {          // (wave-uniform; abl: profiling switches, results invalid)
+            const uint32_t i = r0 + (uint32_t)l; const bool valid = i < E;
+            const uint32_t j = S.sid[valid ? i : 0u];                          // the stream whose part holds entry i
+            const uint32_t pos = valid ? S.list[i] : 0u; const int p = (int)(sb + pos);
+            const uint32_t jbeg = S.off[j], jend = S.off[j + 1];
+            const int prevp = (i == jbeg) ? S.prev[j] : (int)(sb + S.list[valid ? i - 1u : 0u]);
+            const bool start = !(prevp >= 0 && prevp == p - 1);
+            const uint32_t key = valid ? ((j << 13) | (start ? pos + 1u : 0u)) : 0u, mx = wave_incl_max<uint32_t>(key);
+            const int a = ((mx >> 13) == j && (mx & 0x1FFFu)) ? (int)(sb + (mx & 0x1FFFu) - 1u) : S.sa[j];     // start of my streak
+            uint32_t nb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (valid) {
+                if (start) {
+                    const uint32_t d = (uint32_t)(p - prevp), v = d - 1u;
+                    if (d <= 128u) { nb = 1; t0 = v; } else if (d <= 16384u) { nb = 2; t0 = (v >> 8) | 0x80u; t1 = v & 0xFFu; } else { nb = 4; t0 = (v >> 24) | 0xE0u; t1 = (v >> 16) & 0xFFu; t2 = (v >> 8) & 0xFFu; t3 = v & 0xFFu; }
+                } else if (a == 0 && p == 1) { nb = 1; t0 = 0; }
+                else {
+                    const int t = p - a - (a == 0 ? 2 : 1);
+                    if (t >= 0 && (t & 31) == 0) {
+                        uint32_t L = 1;                                      // matches from p on: entries i, i + 1, ... at consecutive positions
+#pragma unroll
+                        for (uint32_t stp = 16; stp >= 1; stp >>= 1) { const uint32_t k = L - 1u + stp; if (i + k < jend && S.list[i + k] == pos + k) L += stp; }
+                        if (L < 32u && i + L == jend && pos + L == 4096u) L += S.after[j];
+                        if (L > 32u) L = 32u;
+                        nb = 1; t0 = 0xC0u | (L - 1u);
+                    }
+                }
+            }
+            // byte offsets: a sum over the round, cut at the stream boundaries
+            const uint32_t incl = wave_incl_sum<uint32_t>(nb);
+            const uint32_t jprev = (uint32_t)__shfl_up((int)j, 1u);
+            const unsigned long long bm = __ballot(valid && (l == 0 || j != jprev));
+            const unsigned long long upto = l == 63 ? ~0ull : ((2ull << l) - 1ull);
+            const int segl = 63 - __clzll((long long)((bm & upto) | 1ull));
+            const uint32_t excl = incl - nb - (uint32_t)__shfl((int)(incl - nb), segl);
+            const uint32_t o = S.outpos[j] + excl;
+            if (valid && nb && o + nb <= S.room[j] && !(abl & 2)) {
+                uint8_t* op = (uint8_t*)(uintptr_t)S.out[j] + o;
+                op[0] = (uint8_t)t0; if (nb >= 2u) op[1] = (uint8_t)t1; if (nb == 4u) { op[2] = (uint8_t)t2; op[3] = (uint8_t)t3; }
+            }
+            const uint32_t jnext = (uint32_t)__shfl_down((int)j, 1u);
+            const bool lastl = valid && (l == 63 || i + 1u >= E || jnext != j);
+            wave_lds_sync();                                                // (every lane has read its stream's state)
+            if (lastl) { S.outpos[j] = o + nb; S.sa[j] = a; }
+            wave_lds_sync();
+        }
+        if ((uint32_t)l < nn && S.on[l] && S.off[l + 1] > S.off[l]) S.prev[l] = (int)(sb + S.list[S.off[l + 1] - 1u]);
+        wave_lds_sync();
+    }
+    if ((uint32_t)l < nn && S.on[l]) {
+        segb[((size_t)c * MAX_STREAMS + (uint32_t)l) * n_seg + seg] = S.outpos[l];
+        if (S.outpos[l] > S.room[l]) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
+    }
+}
+
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
 // One wave per (axis, chunk).  `last` always equals the previous element, so every token is local: a repeat element
 // closes a 0xC0|k token when it is the 32nd of its group or the next element is not a repeat.

@@ -115,6 +115,14 @@ def test_strand_lines_of_equal_length_and_different_bytes(codec, monkeypatch, ga
     assert ("gather_bytes" if gather == "bytes" else "gather") in dict(codec.timings())
 
 
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:7], ids=[m[0] for m in MULTI[:7]])
+def test_multichunk_list_coder_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+    """RFQ_CODER=ms: k_pos_coder_ms, the value streams coded from a per-step list of the coded positions (bit-exact; not the default: it is slower so far)."""
+    monkeypatch.setenv("RFQ_CODER", "ms")
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+
+
 def test_gather_paths_are_the_ones_expected(codec):
     """The tile gather (k_gather2 + k_seqpack) is what runs by default - also when a mate of an interleaved chunk holds bytes outside A/C/G/T/N
     (Read::changeToReverseComplement turns them into N, lower case into the upper-case complement) - and reads too long for a tile of two
