@@ -783,21 +783,25 @@ static void do_decompress_multi(const Options& o) {
     Prefetcher in(gs, o.in1, block, o.ioThreads);
     std::mutex mu; std::condition_variable cv;
     std::deque<DecItem> queue; bool no_more = false; std::vector<uint8_t> header; bool header_ready = false;
-    std::map<uint64_t, std::pair<std::vector<uint8_t>, std::vector<uint8_t>>> done; uint64_t next_write = 0, total_items = 0; bool all_queued = false;
+    // a range's text leaves its device into PAGE-LOCKED buffers (two per worker, handed to the writer and back): pageable vectors - 8 GB of fresh pages and a
+    // staged copy - were most of the first version's 2.5 s on the 2 x 4 GB input
+    struct OutBuf { uint8_t* p1 = nullptr; size_t c1 = 0; uint8_t* p2 = nullptr; size_t c2 = 0; size_t n1 = 0, n2 = 0; bool busy = false; };
+    std::map<uint64_t, OutBuf*> done; uint64_t next_write = 0, total_items = 0; bool all_queued = false;
     ByteSink s1; s1.open(o.out1, o); ByteSink s2; if (split) s2.open(o.out2, o);
     std::thread writer([&] {
         for (;;) {
-            std::pair<std::vector<uint8_t>, std::vector<uint8_t>> t;
+            OutBuf* t = nullptr;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.count(next_write) || (all_queued && next_write == total_items); });
               if (all_queued && next_write == total_items) return;
-              t = std::move(done[next_write]); done.erase(next_write); next_write++; cv.notify_all(); }
-            if (!t.first.empty()) s1.write(t.first.data(), t.first.size());
-            if (split && !t.second.empty()) s2.write(t.second.data(), t.second.size());
+              t = done[next_write]; done.erase(next_write); next_write++; cv.notify_all(); }
+            if (t->n1) s1.write(t->p1, t->n1);
+            if (split && t->n2) s2.write(t->p2, t->n2);
+            { std::unique_lock<std::mutex> lk(mu); t->busy = false; cv.notify_all(); }
         }
     });
     std::vector<std::thread> workers;
     for (size_t w = 0; w < o.devices.size(); w++) workers.emplace_back([&, w] {
-        Gpu g(o.devices[w]); void* d = nullptr; size_t cap = 0; bool have_hdr = false;
+        Gpu g(o.devices[w]); void* d = nullptr; size_t cap = 0; bool have_hdr = false; OutBuf ob[2]; int turn = 0;
         for (;;) {
             DecItem it;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = std::move(queue.front()); queue.pop_front(); cv.notify_all(); }
@@ -809,12 +813,17 @@ static void do_decompress_multi(const Options& o) {
             a.h_chunk_off = it.tab.data(); a.n_chunk_off = (uint32_t)(it.tab.size() - 1);
             rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
             if (r.consumed != it.bytes.size()) error_exit("internal: a dealt range does not decode as whole chunks");
-            std::pair<std::vector<uint8_t>, std::vector<uint8_t>> t; t.first.resize(r.n1); t.second.resize(split ? r.n2 : 0);
-            if (r.n1) g.check(rfq_copy_d2h(g.c, t.first.data(), r.d_fq1, r.n1));
-            if (split && r.n2) g.check(rfq_copy_d2h(g.c, t.second.data(), r.d_fq2, r.n2));
-            std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.size() < 2 * o.devices.size() || it.seq == next_write; });
-            done[it.seq] = std::move(t); cv.notify_all();
+            OutBuf& t = ob[turn]; turn ^= 1;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !t.busy; }); }               // (the writer is done with what this buffer held two ranges ago)
+            if (t.c1 < r.n1) { if (t.p1) rfq_host_free(g.c, t.p1); t.c1 = r.n1 + r.n1 / 4 + 4096; t.p1 = g.pinned(t.c1); }
+            if (split && t.c2 < r.n2) { if (t.p2) rfq_host_free(g.c, t.p2); t.c2 = r.n2 + r.n2 / 4 + 4096; t.p2 = g.pinned(t.c2); }
+            t.n1 = r.n1; t.n2 = split ? r.n2 : 0;
+            if (r.n1) g.check(rfq_copy_d2h(g.c, t.p1, r.d_fq1, r.n1));
+            if (split && r.n2) g.check(rfq_copy_d2h(g.c, t.p2, r.d_fq2, r.n2));
+            std::unique_lock<std::mutex> lk(mu); t.busy = true; done[it.seq] = &t; cv.notify_all();
         }
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !ob[0].busy && !ob[1].busy; }); }   // (the writer still reads them)
+        for (auto& t : ob) { if (t.p1) rfq_host_free(g.c, t.p1); if (t.p2) rfq_host_free(g.c, t.p2); }
         if (d) rfq_dev_free(g.c, d);
     });
     // the dealer: bytes not dealt yet start at a chunk boundary (pend_off) - or, at first, at the file header
