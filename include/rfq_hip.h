@@ -132,10 +132,11 @@ typedef struct {
                                              0: decompress (everything to out1 in chunk order; Q14)                    */
     int32_t  final;                       /* 1: the image ends the file: apply the NO_LINE_BREAK bits of the last chunk
                                              (src/repaq.cpp:301-328,375-413)                                           */
-    int32_t  bug_compat;                  /* 1: Repaq::decompress / decompressPE as they stand (src/repaq.cpp:262-417): a chunk that carries a NO_LINE_BREAK
-                                             bit and is not the image's last makes the reference's loop lose the chunk behind it (and, decompressPE with
+    int32_t  bug_compat;                  /* 1: Repaq::decompressPE as it stands (src/repaq.cpp:330-417): with split_pe = 1, a chunk that carries a
+                                             NO_LINE_BREAK bit and is not the image's last makes the reference's loop lose the chunk behind it (and, with
                                              the R1 bit, the flagged chunk's R2 text).  0 (default): every read is kept.  With final = 0 a flagged chunk
-                                             at the very end of the range stays unconsumed (what follows it decides)                                   */
+                                             at the very end of the range stays unconsumed (what follows it decides).  Repaq::decompress (split_pe = 0,
+                                             :262-328) keeps the chunk it peeks at and loses nothing: the flag changes nothing there.               */
     uint8_t* d_out1; size_t cap1;         /* optional caller buffers; NULL = context-owned results                     */
     uint8_t* d_out2; size_t cap2;
     /* optional chunk index (the .rfq format has none: RfqChunk::read finds chunk c+1 only by parsing chunk c, src/rfqchunk.cpp:161-228,
@@ -187,6 +188,10 @@ int rfq_host_free(rfq_ctx* ctx, void* h_ptr);
  * reference's four per-read tests (name, sequence, strand, quality; :85-108) for every read in it; the host cuts records only in
  * a batch that differs, to word the reference's message. */
 int rfq_compare_bytes(rfq_ctx* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first_diff);
+
+/* self test of the wave-level scans / reductions every kernel is built on (DPP row shifts and broadcasts on gfx950): h_in holds 64 * n_waves lane
+ * values, h_out receives 12 u64 per lane (see k_selftest_wave in rfq_api.hip); tests/test_gpu_wave.py checks them against a serial reference. */
+int rfq_selftest_wave(rfq_ctx* ctx, const uint64_t* h_in, uint32_t n_waves, uint64_t* h_out);
 
 /* library / build info: "rfq_hip <version> gfx950" (or "... simt-emulation" for the test build) */
 const char* rfq_version(void);

@@ -765,9 +765,11 @@ static int decode_chunk(const rfqo_header* h, const chunk_t* c, int split, bb_t*
  * the bit (files < 1 MiB without trailing newline and > 1 chunk); this restatement keeps every read instead. */
 /* Repaq::decompress / decompressPE AS WRITTEN (src/repaq.cpp:262-417), data loss included: a chunk that carries a NO_LINE_BREAK bit makes the loop read
  * the chunk BEHIND it to see whether it was the last one (:303-311, :376-387) - and when it was not, the loop goes on with `continue` (:322-325,
- * :389-392, :400-403), i.e. with a fresh read: the chunk it peeked at is never decoded.  decompressPE additionally leaves the loop body before the R2
- * text of the flagged chunk is written when it is the R1 bit that is set (:389-392).  rfqo_decode_file (below) keeps every read instead; this
- * function is what `--bug_compat` must reproduce, pinned against the reference binary in tests/test_oracle_golden.py. */
+ * :389-392, :400-403).  decompressPE declares its chunk inside the loop (:347-349), so that is a fresh read: the chunk it peeked at is never decoded,
+ * and it leaves the loop body before the R2 text of the flagged chunk is written when it is the R1 bit that is set (:389-392).  decompress (one
+ * output) keeps the peeked chunk in a variable declared outside the loop (:281-286) and decodes it in the next iteration: nothing is lost there.
+ * rfqo_decode_file (below) keeps every read instead; this function is what `--bug_compat` must reproduce, pinned against the reference binary in
+ * tests/test_oracle_golden.py. */
 int rfqo_decode_file_compat(const uint8_t* rfq, size_t n, int split_pe, uint8_t** out1, size_t* n1, uint8_t** out2, size_t* n2, char* err) {
     rfqo_header h; size_t used = 0; err[0] = 0;
     *out1 = NULL; *n1 = 0; if (out2) { *out2 = NULL; *n2 = 0; }
@@ -790,10 +792,10 @@ int rfqo_decode_file_compat(const uint8_t* rfq, size_t n, int split_pe, uint8_t*
         if (f1 || f2) {                                                     /* the peek: the next chunk is read - and, if there is one, lost */
             chunk_t nx; char e2[256]; const int r2 = chunk_parse(&h, rfq + k, n - k, &nx, e2);
             last = r2 != 0;
-            if (!last) k += nx.total;
+            if (!last && split_pe) k += nx.total;                           /* decompressPE reads afresh (:347-349); decompress keeps the peeked chunk and decodes it next (:282-286) */
         }
         int skip2 = 0;
-        if (f1) { if (last) bb_put(&outs[0], t[0].p, t[0].n ? t[0].n - 1 : 0); else { bb_put(&outs[0], t[0].p, t[0].n); skip2 = 1; } }
+        if (f1) { if (last) bb_put(&outs[0], t[0].p, t[0].n ? t[0].n - 1 : 0); else { bb_put(&outs[0], t[0].p, t[0].n); skip2 = split_pe; } }
         else bb_put(&outs[0], t[0].p, t[0].n);
         if (split_pe && !skip2) {
             if (f2 && last) bb_put(&outs[1], t[1].p, t[1].n ? t[1].n - 1 : 0); else bb_put(&outs[1], t[1].p, t[1].n);

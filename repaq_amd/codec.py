@@ -41,6 +41,13 @@ class RfqCodec:
     def set_stream(self, stream_ptr):
         self._check(self._L.rfq_set_stream(self._h, stream_ptr))
 
+    def selftest_wave(self, lanes):
+        """rfq_selftest_wave: the wave scans / reductions of rfq_common.h on `lanes` (64 * k u64 values) -> 12 u64 per lane."""
+        n = len(lanes); assert n and n % 64 == 0
+        a = (C.c_uint64 * n)(*lanes); o = (C.c_uint64 * (12 * n))()
+        self._check(self._L.rfq_selftest_wave(self._h, a, n // 64, o))
+        return [list(o[12 * i: 12 * i + 12]) for i in range(n)]
+
     # --- RfqCodec::setHeader / header accessors
     def setHeader(self, header_bytes: bytes):
         self._check(self._L.rfq_set_header(self._h, header_bytes, len(header_bytes)))
@@ -75,7 +82,7 @@ class RfqCodec:
     # --- RfqCodec::decodeChunk for every chunk of an image
     def decode(self, d_rfq, n, has_header=True, split_pe=False, final=True, d_out1=None, cap1=0, d_out2=None, cap2=0, chunk_off=None, n_chunks=0, bug_compat=False):
         """chunk_off / n_chunks: optional chunk index (EncodeResult.h_chunk_off + n_chunks, or a sequence of n_chunks + 1 offsets).
-        bug_compat: lose what Repaq::decompress / decompressPE lose behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:303-325,376-403)."""
+        bug_compat: with split_pe, lose what Repaq::decompressPE loses behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:376-403); Repaq::decompress (one output) loses nothing."""
         if chunk_off is not None and not isinstance(chunk_off, C.POINTER(C.c_uint64)):
             n_chunks = len(chunk_off) - 1
             chunk_off = C.cast((C.c_uint64 * len(chunk_off))(*chunk_off), C.POINTER(C.c_uint64))

@@ -54,7 +54,7 @@ struct Options {
     int ioThreads = 8;                      // readers per regular input file (pread)
     int writeThreads = 1;                   // writers per regular output file (pwrite); tmpfs does not scale with more, parallel file systems do
     bool trace = false;                     // --trace: wall-clock marks of the pipeline on stderr
-    bool bugCompat = false;                 // --bug_compat (-d): lose what Repaq::decompress* lose behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:303-325, 376-403); default: keep every read
+    bool bugCompat = false;                 // --bug_compat (-d with two outputs): lose what Repaq::decompressPE loses behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:376-403); Repaq::decompress loses nothing; default: keep every read
     size_t block() const { return std::max<size_t>(std::min(blockBytes, batchBytes), (size_t)1 << 20); }   // >= the reader's 1 MiB block (line-break thresholds)
 };
 static const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();

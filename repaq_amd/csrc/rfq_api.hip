@@ -196,3 +196,39 @@ extern "C" int rfq_copy_d2h(rfq_ctx* c, void* h, const void* d, size_t n) {
     if (n) { HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return RFQ_OK;
 }
+
+// ---------------------------------------------------------------- self test of the wave primitives (rfq_common.h)
+// Every kernel's scans and reductions go through wave_incl_sum / wave_incl_max / wave_sum / ... - DPP row shifts and row broadcasts on the GPU,
+// shuffles under the SIMT interpreter, which therefore cannot vouch for the DPP forms.  This entry point runs them on caller-chosen lane values so
+// that a GPU test can sweep patterns across all 64 lanes against a serial reference (tests/test_gpu_wave.py).  out: 12 u64 per lane.
+__global__ void k_selftest_wave(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x; const unsigned long long v = in[i];
+    const uint32_t a = (uint32_t)v; const int sa = (int)a;
+    unsigned long long* o = out + 12ull * i;
+    o[0] = wave_incl_sum<uint32_t>(a);
+    o[1] = wave_incl_sum<unsigned long long>(v);
+    o[2] = (unsigned long long)(long long)wave_incl_max<int>(sa);
+    o[3] = (unsigned long long)wave_incl_max<long long>((long long)v);
+    o[4] = wave_sum<uint32_t>(a);
+    o[5] = wave_min<uint32_t>(a);
+    o[6] = wave_max<uint32_t>(a);
+    o[7] = ((unsigned long long)wave_and(a) << 32) | wave_or(a);
+    o[8] = wave_shr1<uint32_t>(a, 0xABCD1234u);
+    o[9] = wave_last<uint32_t>(a);
+    o[10] = wave_min<unsigned long long>(v);
+    { U4 u; u.a = a; u.b = a >> 3; u.c = a ^ 0x5A5Au; u.d = (uint32_t)(v >> 32); const U4 r = wave_incl_sum(u); o[11] = ((unsigned long long)(r.a + r.b + r.c) << 32) | r.d; }
+}
+extern "C" int rfq_selftest_wave(rfq_ctx* c, const uint64_t* h_in, uint32_t n_waves, uint64_t* h_out) {
+    if (!c || !h_in || !h_out || !n_waves) return RFQ_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_waves * 64u;
+    void *din = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc(&din, n * 8)); if (hipMalloc(&dout, n * 96) != hipSuccess) { (void)hipFree(din); return rfq_fail(c, RFQ_E_HIP, "hipMalloc failed"); }
+    hipError_t e = hipMemcpy(din, h_in, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_wave, dim3(n_waves), dim3(64), 0, c->stream, (const unsigned long long*)din, (unsigned long long*)dout); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h_out, dout, n * 96, hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    if (e != hipSuccess) return rfq_fail(c, RFQ_E_HIP, "rfq_selftest_wave: %s", hipGetErrorString(e));
+    return RFQ_OK;
+}

@@ -95,14 +95,15 @@ __device__ __host__ __forceinline__ U4 operator-(const U4& x, const U4& y) { U4 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
+// Wave scans and reductions run on DPP (row_shr:1/2/4/8 inside the rows of 16 lanes, row_bcast:15 / row_bcast:31 across them): six VALU
+// instructions with a DPP source operand per 32-bit scan.  The __shfl forms they replace went through ds_bpermute_b32 - address VALU + LDS crossbar
+// + s_waitcnt per step - in kernels that are VALU-issue-bound (1,505 bpermute sites, no DPP).  The SIMT interpreter of the test build
+// (RFQ_SIMT_EMULATION) has no DPP and keeps the shuffle forms; tests/test_gpu_wave.py sweeps both against a serial reference on the GPU.
+#ifdef RFQ_SIMT_EMULATION
 template <class T> __device__ __forceinline__ T wave_incl_sum(T v) {
     const int l = lane_id();
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) { T t = __shfl_up(v, (unsigned)d); if (l >= d) v = t + v; }
-    return v;
-}
-__device__ __forceinline__ U4 wave_incl_sum(U4 v) {
-    v.a = wave_incl_sum(v.a); v.b = wave_incl_sum(v.b); v.c = wave_incl_sum(v.c); v.d = wave_incl_sum(v.d);
     return v;
 }
 template <class T> __device__ __forceinline__ T wave_incl_max(T v) {
@@ -134,6 +135,53 @@ __device__ __forceinline__ uint32_t wave_and(uint32_t v) {
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d);
+    return v;
+}
+// lane l <- lane l-1 (lane 0 <- fill); the value of lane 63 in every lane
+template <class T> __device__ __forceinline__ T wave_shr1(T v, T fill) { const T t = __shfl_up(v, 1u); return lane_id() ? t : fill; }
+template <class T> __device__ __forceinline__ T wave_last(T v) { return __shfl(v, 63); }
+#else
+// v of the lane the DPP control names; lanes it names none for (or that row_mask leaves out) get `old`
+template <int CTRL, int ROWS, class T> __device__ __forceinline__ T dpp_take(T old, T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dpp_take: 32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        const int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false);
+        return __builtin_bit_cast(T, r);
+    } else {
+        const unsigned long long o = __builtin_bit_cast(unsigned long long, old), x = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)x, CTRL, ROWS, 0xF, false);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(x >> 32), CTRL, ROWS, 0xF, false);
+        return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+    }
+}
+template <class T> __device__ __forceinline__ T wave_read63(T v) {
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    else { const unsigned long long x = __builtin_bit_cast(unsigned long long, v);
+           const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+           return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo); }
+}
+// inclusive scan with an associative op whose identity is `id` (for an idempotent op - min, max, and, or - pass the value itself: op(v, v) = v)
+#define RFQ_DPP_SCAN(v, OP, ID)                                                                          \
+    { v = OP(v, (dpp_take<0x111, 0xF>(ID, v))); v = OP(v, (dpp_take<0x112, 0xF>(ID, v))); v = OP(v, (dpp_take<0x114, 0xF>(ID, v))); v = OP(v, (dpp_take<0x118, 0xF>(ID, v))); \
+      v = OP(v, (dpp_take<0x142, 0xA>(ID, v))); v = OP(v, (dpp_take<0x143, 0xC>(ID, v))); }
+#define RFQ_OP_ADD(a, b) ((a) + (b))
+#define RFQ_OP_MAX(a, b) ((b) > (a) ? (b) : (a))
+#define RFQ_OP_MIN(a, b) ((b) < (a) ? (b) : (a))
+#define RFQ_OP_AND(a, b) ((a) & (b))
+#define RFQ_OP_OR(a, b) ((a) | (b))
+template <class T> __device__ __forceinline__ T wave_incl_sum(T v) { RFQ_DPP_SCAN(v, RFQ_OP_ADD, T()) return v; }
+template <class T> __device__ __forceinline__ T wave_incl_max(T v) { RFQ_DPP_SCAN(v, RFQ_OP_MAX, v) return v; }
+template <class T> __device__ __forceinline__ T wave_sum(T v) { RFQ_DPP_SCAN(v, RFQ_OP_ADD, T()) return wave_read63(v); }
+template <class T> __device__ __forceinline__ T wave_max(T v) { RFQ_DPP_SCAN(v, RFQ_OP_MAX, v) return wave_read63(v); }
+template <class T> __device__ __forceinline__ T wave_min(T v) { RFQ_DPP_SCAN(v, RFQ_OP_MIN, v) return wave_read63(v); }
+__device__ __forceinline__ uint32_t wave_and(uint32_t v) { RFQ_DPP_SCAN(v, RFQ_OP_AND, v) return wave_read63(v); }
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) { RFQ_DPP_SCAN(v, RFQ_OP_OR, v) return wave_read63(v); }
+// lane l <- lane l-1 (lane 0 <- fill): wave_shr:1; the value of lane 63 in every lane (an SGPR)
+template <class T> __device__ __forceinline__ T wave_shr1(T v, T fill) { return dpp_take<0x138, 0xF>(fill, v); }
+template <class T> __device__ __forceinline__ T wave_last(T v) { return wave_read63(v); }
+#endif
+__device__ __forceinline__ U4 wave_incl_sum(U4 v) {
+    v.a = wave_incl_sum(v.a); v.b = wave_incl_sum(v.b); v.c = wave_incl_sum(v.c); v.d = wave_incl_sum(v.d);
     return v;
 }
 

@@ -369,13 +369,15 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     const uint64_t slice_bases = slice_env ? slice_env : 1500000000ull, one_pass = slice_env ? slice_env : 0xFFFFFFF0ull;   // (a pass whose text turns out to be >= 4 GiB is redone in ranges)
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
-    // bug_compat: Repaq::decompress / decompressPE as they stand (src/repaq.cpp:262-417).  A chunk with a NO_LINE_BREAK bit makes the loop read the
-    // chunk behind it to see whether it was the last (:303-311, :376-387); when it was not, `continue` (:322-325, :389-392, :400-403) goes on with a
-    // fresh read and the chunk it peeked at is never decoded - and decompressPE leaves the body before the flagged chunk's R2 text is written when
-    // it is the R1 bit that is set.  The text is decoded piece by piece: runs of chunks that survive, R1 only where the reference drops R2.
+    // bug_compat: Repaq::decompressPE as it stands (src/repaq.cpp:330-417).  A chunk with a NO_LINE_BREAK bit makes the loop read the chunk behind it
+    // to see whether it was the last (:376-387); when it was not, `continue` (:389-392, :400-403) goes on with a fresh read - decompressPE declares
+    // its chunk inside the loop - and the chunk it peeked at is never decoded; it also leaves the body before the flagged chunk's R2 text is written
+    // when it is the R1 bit that is set.  The text is decoded piece by piece: runs of chunks that survive, R1 only where the reference drops R2.
+    // Repaq::decompress (one output, :262-328) peeks the same way but keeps the peeked chunk in a variable that outlives the iteration and decodes it
+    // next: nothing is lost there, and the only effect of the bit - the last chunk's final '\n' dropped - is the default behaviour.
     struct Rng { uint32_t c0, c1; bool r1_only; };
     std::vector<Rng> pieces; std::vector<DChunk> hc; bool strip1 = (last_flags & C_NO_LB) != 0, strip2 = (last_flags & C_NO_LB_R2) != 0;
-    const bool compat = a->bug_compat != 0;
+    const bool compat = a->bug_compat != 0 && split;
     if (compat) {
         hc.resize(n_chunks);
         HIPCHK(ctx, hipMemcpy(hc.data(), CHm, (size_t)n_chunks * sizeof(DChunk), hipMemcpyDeviceToHost));

@@ -447,15 +447,27 @@ __device__ __forceinline__ uint32_t fn_apply(uint32_t F, uint32_t s) { return (F
 __device__ __forceinline__ uint32_t fn_of_len(uint32_t tok_len) { return 0x02010000u | (tok_len - 1u); }                            // s > 0 ? s - 1 : len - 1
 __device__ __forceinline__ uint32_t fn_pack8(uint32_t F) { return (F & 3u) | ((F >> 6) & 0xCu) | ((F >> 12) & 0x30u) | ((F >> 18) & 0xC0u); }
 __device__ __forceinline__ uint32_t fn_unpack8(uint32_t b) { return (b & 3u) | ((b & 0xCu) << 6) | ((b & 0x30u) << 12) | ((b & 0xC0u) << 18); }
+// inclusive wave scan of transition tables: lane l ends with (table of lane 0) o ... o (its own).  Composition is associative, not commutative:
+// the earlier lanes' table always goes first.  DPP row shifts + row broadcasts on the GPU (rfq_common.h), shuffles under the SIMT interpreter.
+__device__ __forceinline__ uint32_t wave_scan_compose(uint32_t F) {
+#ifdef RFQ_SIMT_EMULATION
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(F, (unsigned)d); if (l >= d) F = fn_compose(t, F); }
+#else
+#define RFQ_OP_COMPOSE(a, b) fn_compose((b), (a))
+    RFQ_DPP_SCAN(F, RFQ_OP_COMPOSE, 0x03020100u)
+#undef RFQ_OP_COMPOSE
+#endif
+    return F;
+}
 // returns the state BEFORE this lane's byte; carry = state after the wave's last byte
 __device__ __forceinline__ uint32_t wave_token_states(uint32_t tok_len, bool valid, uint32_t& carry) {
-    const int l = lane_id();
     uint32_t f = valid ? fn_of_len(tok_len) : 0x03020100u;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(f, (unsigned)d); if (l >= d) f = fn_compose(t, f); }
+    f = wave_scan_compose(f);
     const uint32_t after = fn_apply(f, carry);
-    uint32_t before = __shfl_up(after, 1u); if (l == 0) before = carry;
-    carry = __shfl(after, 63);
+    const uint32_t before = wave_shr1(after, carry);
+    carry = wave_last(after);
     return before;
 }
 // decodeSingleQualByCol (src/rfqcodec.cpp:957-1007): one wave per (stream, chunk); writes q at every coded position.
@@ -496,9 +508,8 @@ __device__ __forceinline__ PosFront pos_front(const PosStep& w, const uint8_t* _
 #pragma unroll
     for (int k = 0; k < 4; k++) { const bool valid = i0 + (uint32_t)k < slen; f.bt[k] = (uint32_t)(f.v >> (8 * k)) & 0xFFu; f.fn[k] = valid ? fn_of_len(pos_tok_len(f.bt[k])) : POS_ID; }
     uint32_t F = fn_compose(fn_compose(fn_compose(f.fn[0], f.fn[1]), f.fn[2]), f.fn[3]);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(F, (unsigned)d); if (l >= d) F = fn_compose(t, F); }
-    f.Fin = F;
+    (void)l;
+    f.Fin = wave_scan_compose(F);
     return f;
 }
 // positions covered by the tokens that START in the lane's 4 bytes when the automaton enters them in state st
@@ -534,8 +545,8 @@ __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, 
         if (base + 256 < b1_) nxt = pos_fetch(sp, slen, i0 + 256u, lim);    // the next step's words are in flight while this one is decoded
         const PosFront f = pos_front(cur, sp, slen, i0, l);
         const uint32_t after = fn_apply(f.Fin, carry);                  // state after my 4 bytes
-        uint32_t st = __shfl_up(after, 1u); if (l == 0) st = carry;         // state in front of my first byte
-        carry = __shfl(after, 63);
+        uint32_t st = wave_shr1(after, carry);         // state in front of my first byte
+        carry = wave_last(after);
         int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -556,7 +567,7 @@ __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, 
         uint32_t singles = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) if (start[k] && !run[k]) singles++;
-        const uint32_t sincl = wave_incl_sum(singles); uint32_t so = sincl - singles; const uint32_t stot = __shfl(sincl, 63);
+        const uint32_t sincl = wave_incl_sum(singles); uint32_t so = sincl - singles; const uint32_t stot = wave_last(sincl);
         wave_lds_sync();                                                     // the previous step's tp is no longer read
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -567,7 +578,7 @@ __device__ __forceinline__ void wave_pos_decode(const uint8_t* __restrict__ sp, 
         }
         wave_lds_sync();
         for (uint32_t j = (uint32_t)l; j < stot; j += 64) { const int p = tp[j]; if (p >= 0 && (uint32_t)p < out_len) out[p] = q; }
-        last += __shfl(incl, 63);
+        last += wave_last(incl);
     }
 }
 // A position stream is decoded in SEGMENTS of POS_SEG bytes by independent waves (a serial walk of a 50 KB stream is ~200 dependent
@@ -613,11 +624,11 @@ __global__ void k_dec_pos_sum(const uint8_t* __restrict__ img, const DChunk* __r
         const PosStep cur = nxt;
         if (base + 256 < b1) nxt = pos_fetch(s.sp, s.slen, i0 + 256u, lim);
         const PosFront f = pos_front(cur, s.sp, s.slen, i0, l);
-        uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
+        const uint32_t Fex = wave_shr1(f.Fin, POS_ID);
         const uint32_t G = fn_compose(Fcum, Fex);                            // segment entry state -> state in front of my bytes
         a0 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 0u)); a1 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 1u));
         a2 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 2u)); a3 += pos_lane_adv(f, s.slen, i0, fn_apply(G, 3u));
-        Fcum = fn_compose(Fcum, __shfl(f.Fin, 63));
+        Fcum = fn_compose(Fcum, wave_last(f.Fin));
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
     if (l == 0) {
@@ -735,12 +746,12 @@ __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __
         const PosStep w = nxt;
         if (base + 256u < b1) nxt = pos_fetch(s.sp, s.slen, i0 + 256u, lim);
         const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
-        uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
+        const uint32_t Fex = wave_shr1(f.Fin, POS_ID);
         const uint32_t G = fn_compose(Fcum, Fex);                          // segment entry state -> state in front of my bytes
         int la[4], lc[4]; pos_lane_adv_cnt4(f, s.slen, i0, la, lc);         // the lane's tokens for each state in front of its bytes
 #pragma unroll
         for (int e = 0; e < 4; e++) { const uint32_t t_ = fn_apply(G, e); a[e] += sel4(la, t_); n[e] += sel4(lc, t_); }
-        Fcum = fn_compose(Fcum, __shfl(f.Fin, 63));
+        Fcum = fn_compose(Fcum, wave_last(f.Fin));
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) { a[e] = wave_sum(a[e]); n[e] = wave_sum(n[e]); }
@@ -784,9 +795,9 @@ __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __r
 #pragma unroll
                       for (int s = 0; s < 4; s++) { ex.a[s] = 0; ex.n[s] = 0; } }
         if (g < n) { segS[idx] = (uint8_t)(fn_apply(ex.F, cs)); segP[idx] = cp + sel4(ex.a, cs); segK[idx] = ck + (uint32_t)sel4(ex.n, cs); }
-        const uint32_t Fl = __shfl(inc.F, 63); int al[4], nl[4];
+        const uint32_t Fl = wave_last(inc.F); int al[4], nl[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) { al[s] = __shfl(inc.a[s], 63); nl[s] = __shfl(inc.n[s], 63); }
+        for (int s = 0; s < 4; s++) { al[s] = wave_last(inc.a[s]); nl[s] = wave_last(inc.n[s]); }
         cp += sel4(al, cs); ck += (uint32_t)sel4(nl, cs); cs = fn_apply(Fl, cs);
     }
     if (l == 0) nent[t] = ck;
@@ -822,7 +833,7 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
         const PosStep w = nxt;
         if (base + 256u < b1) nxt = pos_fetch(s.sp, s.slen, i0 + 256u, lim);
         const PosFront f = pos_front(w, s.sp, s.slen, i0, l);
-        uint32_t Fex = __shfl_up(f.Fin, 1u); if (l == 0) Fex = POS_ID;
+        const uint32_t Fex = wave_shr1(f.Fin, POS_ID);
         uint32_t st0 = fn_apply(Fex, carry);                          // state in front of my first byte
         int adv[4]; uint32_t run[4]; bool start[4]; int lane_adv = 0, lane_cnt = 0;
 #pragma unroll
@@ -855,7 +866,7 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
                 pp = p;
             }
         }
-        last += __shfl(ia, 63); k0 += (uint32_t)__shfl(ic, 63); carry = fn_apply((uint32_t)__shfl(f.Fin, 63), carry);
+        last += wave_last(ia); k0 += (uint32_t)wave_last(ic); carry = fn_apply((uint32_t)wave_last(f.Fin), carry);
     }
 }
 
@@ -943,7 +954,7 @@ __global__ void k_dec_coords(const uint8_t* __restrict__ img, const DChunk* __re
         const uint32_t value = a ? v : cur + v;
         const uint32_t incl = wave_incl_sum(cnt); const uint32_t o = produced + incl - cnt;
         if (start) for (uint32_t k = 0; k < cnt; k++) if (o + k < num) out[o + k] = value;
-        produced += __shfl(incl, 63); cur = __shfl(value, 63);
+        produced += wave_last(incl); cur = wave_last(value);
     }
 }
 

@@ -167,7 +167,7 @@ template <int NLF_T> __global__ void __launch_bounds__(256) k_line_index(const u
     if (__any(cr) && lane == 0) atomicOr(&st->err, (uint32_t)DE_HAS_CR);
     uint32_t wtot = 0;
 #pragma unroll
-    for (int k = 0; k < NLF_T; k++) { incl[k] = wave_incl_sum<uint32_t>((uint32_t)__popcll(m[k])); tsum[k] = (uint32_t)__shfl((int)incl[k], 63); wtot += tsum[k]; }
+    for (int k = 0; k < NLF_T; k++) { incl[k] = wave_incl_sum<uint32_t>((uint32_t)__popcll(m[k])); tsum[k] = wave_last(incl[k]); wtot += tsum[k]; }
     if (lane == 0) s_wave[wv] = wtot;
     __syncthreads();
     const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -1752,7 +1752,7 @@ __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict
         const uint32_t al = (cap + 15u) & ~15u;
         const uint32_t incl = wave_incl_sum(al);
         C.scap[k + l] = cap; C.soff[k + l] = incl - al; C.ssize[k + l] = 0;
-        const uint32_t run64 = __shfl(incl, 63);
+        const uint32_t run64 = wave_last(incl);
         if (l == 0) { const uint32_t cape = bycol ? 5 * ex + 16 + pad : 0u, ale = (cape + 15u) & ~15u;
                       C.scap[k + EXC_SLOT] = cape; C.soff[k + EXC_SLOT] = run64; C.ssize[k + EXC_SLOT] = 0; ctotal[c] = (uint64_t)run64 + ale; }
     }
@@ -1947,7 +1947,7 @@ template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wa
             else { PackSink ps; pc_gen_tokens(m, p0, prev_in, zero_in, after, ps); bytes = ps.n; pk = ps.pk; }
             const uint32_t incl = wave_incl_sum(bytes);
             uint32_t o = s.outpos + incl - bytes;
-            const uint32_t tot = __shfl(incl, 63);
+            const uint32_t tot = wave_last(incl);
             if (s.outpos + tot <= s.room) {
                 uint8_t* out = s.out;
                 if (MODE == PC_EXCEPT) {
@@ -2127,7 +2127,7 @@ __global__ void __launch_bounds__(64) k_pos_coder_ms(ReadTab R, ChunkTab C, cons
             if (!uni32(S.on[j])) continue;
             const uint32_t cnt = S.base[j][l], incl = wave_incl_sum<uint32_t>(cnt);
             S.base[j][l] = (uint16_t)(incl - cnt);
-            tot += (uint32_t)__shfl((int)incl, 63);
+            tot += wave_last(incl);
         }
         if (l == 0) { S.off[nn] = (uint16_t)tot; S.off[nn + 1] = (uint16_t)tot; }
         const uint32_t E = tot;
@@ -2212,10 +2212,10 @@ __global__ void k_coords(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D,
     for (uint32_t base = 0; base < num; base += 64) {
         const uint32_t i = base + (uint32_t)l; const bool valid = i < num;
         const uint32_t v = valid ? V[(size_t)i * stride] : 0u;
-        uint32_t p = __shfl_up(v, 1u); if (l == 0) p = carry_prev;
+        const uint32_t p = wave_shr1(v, carry_prev);
         const uint32_t rep = (valid && v == p) ? 1u : 0u;
         const bool rep_next = (i + 1 < num) && V[(size_t)(i + 1) * stride] == v;
-        uint32_t rep_prev = __shfl_up(rep, 1u); if (l == 0) rep_prev = carry_rep;
+        const uint32_t rep_prev = wave_shr1(rep, carry_rep);
         long long sidx = (rep && !rep_prev) ? (long long)i : -1;
         sidx = wave_incl_max(sidx); if (carry_start > sidx) sidx = carry_start;
         uint32_t bytes = 0, kind = 0;                                       // kind 1: repeat close, 2: +diff, 3: 15-bit, 4: 21-bit
@@ -2234,8 +2234,8 @@ __global__ void k_coords(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D,
         else if (kind == 2) out[o] = (uint8_t)(0x80u | (uint32_t)((int)(v - p) - 1));
         else if (kind == 3) { out[o] = (uint8_t)(v >> 8); out[o + 1] = (uint8_t)v; }
         else if (kind == 4) { out[o] = (uint8_t)((v >> 16) | 0xE0u); out[o + 1] = (uint8_t)(v >> 8); out[o + 2] = (uint8_t)v; }
-        outpos += __shfl(incl, 63);
-        carry_prev = __shfl(v, 63); carry_rep = __shfl(rep, 63); carry_start = __shfl(sidx, 63);
+        outpos += wave_last(incl);
+        carry_prev = wave_last(v); carry_rep = wave_last(rep); carry_start = wave_last(sidx);
     }
     if (l == 0) { if (axis) C.ysize[c] = outpos; else C.xsize[c] = outpos; }
 }

@@ -285,7 +285,7 @@ def _bug_compat_suite(binary, tmp_path, names, batch_mb):
         rfq = O.encode_file(fq1, fq2, g["paired"], 100_000)
         assert hashlib.md5(rfq).hexdigest() == g["rfq_md5"]
         p = tmp_path / (name + ".rfq"); p.write_bytes(rfq)
-        split = g["paired"] != O.SE
+        split = g.get("split", g["paired"] != O.SE)
         o1 = tmp_path / (name + "_1.fq"); o2 = tmp_path / (name + "_2.fq")
         outs = ["-o", str(o1)] + (["-O", str(o2)] if split else [])
         r = _run(binary, ["-d", "-i", str(p)] + outs + ["--bug_compat", "--batch_mb", str(batch_mb)])
@@ -294,20 +294,23 @@ def _bug_compat_suite(binary, tmp_path, names, batch_mb):
         assert [len(t) for t in texts] == g["ref_decode_len"] and [hashlib.md5(t).hexdigest() for t in texts] == g["ref_decode_md5"], name
         r = _run(binary, ["-d", "-i", str(p)] + outs + ["--batch_mb", str(batch_mb)])
         assert r.returncode == 0, r.stderr
-        assert [o1.read_bytes()] + ([o2.read_bytes()] if split else []) == ([fq1, fq2] if split else [fq1]), name
+        if split or g["paired"] == O.SE:
+            assert [o1.read_bytes()] + ([o2.read_bytes()] if split else []) == ([fq1, fq2] if split else [fq1]), name
+        else:
+            assert hashlib.md5(o1.read_bytes()).hexdigest() == g["ref_decode_md5"][0], name   # (one output: the reference loses nothing there)
 
 
 def test_cli_bug_compat_on_simt_emulation(tmp_path):
     E.build_emu()
     assert os.path.exists(EMU_BIN)
-    _bug_compat_suite(EMU_BIN, tmp_path, ["pe_nonl_r1_small"], batch_mb=1)
+    _bug_compat_suite(EMU_BIN, tmp_path, ["pe_nonl_r1_small", "se_nonl_small", "pe_nonl_r1_one_output"], batch_mb=1)
 
 
 @pytest.mark.gpu
 def test_cli_bug_compat_on_gpu(tmp_path):
     assert os.path.exists(GPU_BIN), "repaq_hip is built by __graft_entry__.build()"
     for mb in (256, 2):                                                         # one call per image; a streaming caller's slices
-        _bug_compat_suite(GPU_BIN, tmp_path, ["se_nonl", "pe_nonl_r2", "pe_nonl_r1", "pe_nonl_both", "pe_nonl_r1_small", "bgi_nonl_both"], batch_mb=mb)
+        _bug_compat_suite(GPU_BIN, tmp_path, ["se_nonl", "se_nonl_small", "pe_nonl_r1_one_output", "pe_nonl_both_one_output", "pe_nonl_r2", "pe_nonl_r1", "pe_nonl_both", "pe_nonl_r1_small", "bgi_nonl_both"], batch_mb=mb)
 
 
 @pytest.mark.skipif(__import__("shutil").which("xz") is None, reason="no external xz here: the .rfq.xz legs inside the CLI suites (src/main.cpp:134-177) did NOT run")

@@ -155,9 +155,10 @@ COMPAT = [("se_nonl", O.NOVA_SE150, 1500, 1, O.SE, dict(nonl=1)), ("pe_nonl_r2",
 
 @pytest.mark.parametrize("label,prof,reads,seed,paired,kw", COMPAT, ids=[c[0] for c in COMPAT])
 def test_bug_compat_decode_loses_what_the_reference_loses(codec, label, prof, reads, seed, paired, kw):
-    """rfq_decode_args.bug_compat: Repaq::decompress / decompressPE as they stand - the chunk behind a non-last NO_LINE_BREAK chunk is lost, and the
-    flagged chunk's R2 text when it is the R1 bit (src/repaq.cpp:303-325, 376-403; oracle: rfqo_decode_file_compat, pinned against the reference
-    binary in test_oracle_golden.py).  One call, and a streaming caller's slices (a flagged chunk at the end of a non-final slice waits for what follows)."""
+    """rfq_decode_args.bug_compat: Repaq::decompressPE as it stands - the chunk behind a non-last NO_LINE_BREAK chunk is lost, and the
+    flagged chunk's R2 text when it is the R1 bit (src/repaq.cpp:376-403; oracle: rfqo_decode_file_compat, pinned against the reference
+    binary in test_oracle_golden.py); Repaq::decompress (one output) loses nothing (the SE case: three chunks, two of them flagged and not the last).
+    One call, and a streaming caller's slices (a flagged chunk at the end of a non-final slice waits for what follows)."""
     fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
     rfq = O.encode_file(fq1, fq2, paired, 100_000)
     split = paired != O.SE
@@ -166,6 +167,8 @@ def test_bug_compat_decode_loses_what_the_reference_loses(codec, label, prof, re
     assert keep == ((fq1, fq2) if split else fq1)
     if label in ("pe_nonl_r2", "pe_nonl_r1", "pe_nonl_both"):
         assert want != keep                                                   # (these inputs do lose text in the reference)
+    if not split:
+        assert want == keep and len(O.chunk_table(rfq)) - 1 >= 3             # (one output: nothing is lost, flagged chunks or not)
     assert codec.decode_bytes(rfq, split_pe=split, bug_compat=True) == want
     assert codec.decode_bytes(rfq, split_pe=split) == keep
     for step in (9000, 70000):
