@@ -41,6 +41,23 @@ class RfqCodec:
     def set_stream(self, stream_ptr):
         self._check(self._L.rfq_set_stream(self._h, stream_ptr))
 
+    def set_option(self, name, value=None):
+        """rfq_set_option: a test / diagnostic switch of this context (names = the RFQ_* environment variables; None = default)."""
+        self._check(self._L.rfq_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
+
+    def option(self, name, value):
+        """with codec.option("RFQ_GATHER", "old"): ... - the switch set for the block, back to its default afterwards"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.set_option(name, value)
+            try:
+                yield self
+            finally:
+                self.set_option(name, None)
+        return scope()
+
     def selftest_wave(self, lanes):
         """rfq_selftest_wave: the wave scans / reductions of rfq_common.h on `lanes` (64 * k u64 values) -> 12 u64 per lane."""
         n = len(lanes); assert n and n % 64 == 0

@@ -3,6 +3,8 @@
 #include <cstring>
 #include <algorithm>
 #include <new>
+#include <cstdlib>
+#include <string>
 
 extern "C" const char* rfq_version(void) {
 #ifdef RFQ_SIMT_EMULATION
@@ -11,6 +13,27 @@ extern "C" const char* rfq_version(void) {
     return "rfq_hip 0.1.0 gfx950";
 #endif
 }
+
+// name = the environment variable's name; value NULL or "" = back to the default.  Unknown names are an error (a typo must not pass for a default).
+extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
+    if (!c || !name) return RFQ_E_ARG;
+    const std::string n = name, v = value ? value : ""; const bool set = !v.empty(); const RfqOpts d;
+    const long long num = set ? atoll(v.c_str()) : 0;
+    if (n == "RFQ_GATHER") { if (set && v != "old" && v != "tile") return rfq_fail(c, RFQ_E_ARG, "RFQ_GATHER is old or tile"); c->opt.gather_old = v == "old"; }
+    else if (n == "RFQ_INDEX") { if (set && v != "2pass" && v != "1pass") return rfq_fail(c, RFQ_E_ARG, "RFQ_INDEX is 2pass or 1pass"); c->opt.index_2pass = v == "2pass"; }
+    else if (n == "RFQ_IDX_TILES") { if (set && num != 4 && num != 8 && num != 16) return rfq_fail(c, RFQ_E_ARG, "RFQ_IDX_TILES is 4, 8 or 16"); c->opt.idx_tiles = set ? (int)num : d.idx_tiles; }
+    else if (n == "RFQ_STREAMS") c->opt.one_stream = set && num == 1;
+    else if (n == "RFQ_SLICE_BYTES") c->opt.slice_bytes = set ? (size_t)num : 0;
+    else if (n == "RFQ_SLICE_BASES") c->opt.slice_bases = set ? (uint64_t)num : 0;
+    else if (n == "RFQ_EMIT") { if (set && num != 2 && num != 3) return rfq_fail(c, RFQ_E_ARG, "RFQ_EMIT is 2 or 3"); c->opt.emit = set && num == 2 ? 2 : 0; }
+    else if (n == "RFQ_WALK") { if (set && v != "chain" && v != "exact" && v != "guess") return rfq_fail(c, RFQ_E_ARG, "RFQ_WALK is guess, chain or exact"); c->opt.walk = v == "chain" ? 1 : (v == "exact" ? 2 : 0); }
+    else if (n == "RFQ_GW_SHIFT") c->opt.gw_shift = set ? (int)std::min<long long>(30, std::max<long long>(4, num)) : d.gw_shift;
+    else if (n == "RFQ_MATERIALISE") c->opt.materialise = set && num != 0;
+    else if (n == "RFQ_TRACE") c->opt.trace = set && v != "0";
+    else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
+    return RFQ_OK;
+}
+static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE" };
 
 extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (!out) return RFQ_E_ARG;
@@ -26,6 +49,8 @@ extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return RFQ_E_NO_DEVICE; }
     c->own_stream = true;
     memset(&c->h_hdr, 0, sizeof c->h_hdr);
+    for (const char* nm : RFQ_OPTION_NAMES) { const char* v = getenv(nm); if (v && *v && rfq_set_option(c, nm, v) != RFQ_OK) fprintf(stderr, "rfq_hip: ignoring %s=%s (%s)\n", nm, v, c->err.c_str()); }
+    c->err.clear();
     *out = c;
     return RFQ_OK;
 }

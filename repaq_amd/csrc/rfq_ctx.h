@@ -62,7 +62,23 @@ static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, u
     }
     return best;
 }
+// Test / diagnostic switches of a context (rfq_set_option).  The RFQ_* environment variables of the same names are read ONCE, when the context is created
+// (no getenv on the batch paths - the switches changed chunk walking and emission silently per call, and getenv races a concurrent setenv).
+struct RfqOpts {
+    bool gather_old = false;          // RFQ_GATHER=old     encode: the byte-wise gather (k_gather + k_packbytes) also for reads that fit a tile
+    bool index_2pass = false;         // RFQ_INDEX=2pass    encode: newline bitmap -> scan -> line offsets instead of the one-pass index
+    int  idx_tiles = 0;               // RFQ_IDX_TILES=4|8|16   text per workgroup of the one-pass index (x 16 KiB); 0 = default
+    bool one_stream = false;          // RFQ_STREAMS=1      no second stream: every kernel of a batch on the context's stream
+    size_t slice_bytes = 0;           // RFQ_SLICE_BYTES    encode: slices of that many bytes per stream (so that the slicing logic runs on small inputs)
+    uint64_t slice_bases = 0;         // RFQ_SLICE_BASES    decode: ranges of that many bases
+    int  emit = 0;                    // RFQ_EMIT=2         decode: the tile emitter k_dec_emit2 instead of k_dec_emit3
+    int  walk = 0;                    // RFQ_WALK=chain|exact   decode without a chunk index: 1 = the mSize chain by one wave, 2 = the exact serial walk; 0 = guess and verify
+    int  gw_shift = 16;               // RFQ_GW_SHIFT       log2 of the smallest guess-and-verify segment
+    bool materialise = false;         // RFQ_MATERIALISE=1  decode: qualities / bases expanded in HBM (the path of a streaming caller's non-final slices) on every call
+    bool trace = false;               // RFQ_TRACE          a line on stderr about how chunk starts were found
+};
 struct rfq_ctx {
+    RfqOpts opt;
     bool e3_pieces_failed = false;       // decode: a tile of k_dec_emit3 did not hold its reads' name pieces - files like this one go to k_dec_emit2
     int device = 0; uint32_t n_cu = 256;                                         // compute units of the device (rfq_create)
     hipStream_t stream = nullptr; bool own_stream = false;

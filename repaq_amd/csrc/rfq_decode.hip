@@ -33,7 +33,7 @@ struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_s
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
                         uint8_t** p1, uint8_t** p2, size_t* n1, size_t* n2, uint64_t* nbases) {
     hipStream_t S = ctx->stream; DBuf* B = ctx->b;
-    const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;
+    const int tune = ctx->opt.materialise ? 2048 : 0;                       // (RFQ_MATERIALISE: the expanding decode of a streaming caller's non-final slices, on every call)
     const DevHeader& HH = ctx->h_hdr; const DevHeader* D = ctx->d_hdr.as<DevHeader>();
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs; memset(&hs, 0, sizeof hs);
     hs.max_stream = g.max_stream; hs.max_npos = g.max_npos;
@@ -189,9 +189,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     {
         // k_dec_emit3 (no output tile, K reads per tile: the largest power of two whose qualities fit its tile) whenever the pieces of a name are shared
         // by whole chunks; k_dec_emit2 (tiles fitted read by read) otherwise.  RFQ_EMIT=2 forces the latter (tests run both).
-        uint32_t e3k = 6; if (getenv("RFQ_E3_K")) e3k = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_E3_K"))));   // (profiling aid: smaller tiles)
+        uint32_t e3k = 6;
         while (e3k >= 1 && ((uint64_t)g.max_len << e3k) > E3_QCAP) e3k--;
-        const char* eenv = getenv("RFQ_EMIT");
         // per-read name pieces (names FastqMeta::parse does not take apart, strand lines with text): K also by the chunks' average piece size, with a
         // fifth of the tile left for reads above the average; a tile that still does not fit raises DE_E3_RETRY and the range is emitted again by
         // k_dec_emit2 (remembered on the context: the next ranges of such a file go there at once).  Only with full tiles of 64 reads: with 16 - names of
@@ -203,11 +202,11 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             const uint64_t need1 = ((uint64_t)g.piece_n1 << e3k) * 5u / 4u + 32u;          // a fifth of the tile for reads above the average
             if (need1 > ET_N1CAP) { if (e3k == 6 && need1 <= E3_N1BIG) n1big = true; else e3k = 0; }
         }
-        bool emit3 = fused && e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed) && !(eenv && !strcmp(eenv, "2")) && !(tune & 7);
+        bool emit3 = fused && e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed) && ctx->opt.emit != 2 && !(tune & 7);
     emit_again:
         if (!emit3) ctx->timer.stages[ctx->timer.used].name = "emit2";
         if (emit3) {
-            const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, (getenv("RFQ_E3_SLOTS") ? (uint32_t)atoi(getenv("RFQ_E3_SLOTS")) : 6u) * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
+            const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
 #define RFQ_EMIT3_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
                        (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k, (tune >> 12) & 255
             if (n1big) {
@@ -267,7 +266,6 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         return RFQ_OK;
     }
     hipStream_t S = ctx->stream; DBuf* B = ctx->b;
-    static const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // profiling aid: phase cycle counters (dbg words alias the head of the mid buffer: text is invalid when set)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->timer.reset();
     ctx->pend.clear(); ctx->pin_used = 0;                                   // (read-backs an earlier call left behind on an error path)
@@ -289,12 +287,11 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     HIPCHK(ctx, B[DB_STATUS].ensure(sizeof(DecStatus)));
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs;
     uint32_t cap = (uint32_t)std::max<size_t>(B[DB_CHUNKS].cap / sizeof(DChunk), 4096);
-    bool speculate = true;
+    bool speculate = ctx->opt.walk != 2;                                     // (RFQ_WALK=exact: straight to the serial walk)
     // the chunk starts: the caller's chunk index (verified below); else guess-and-verify (k_dec_gw_*: an index made on the device, verified the same
     // way); else the speculative mSize chain (verified); else the exact serial walk
     bool use_table = a->h_chunk_off && a->n_chunk_off && a->h_chunk_off[0] == start && a->h_chunk_off[a->n_chunk_off] <= a->n;
-    const char* wenv = getenv("RFQ_WALK");
-    bool guess = !use_table && !(wenv && !strcmp(wenv, "chain"));            // (RFQ_WALK=chain: straight to the one-wave chain; tests run both)
+    bool guess = !use_table && ctx->opt.walk == 0;                           // (RFQ_WALK=chain: straight to the one-wave chain; tests run both)
     for (;;) {
         if (use_table && a->n_chunk_off + 1u > cap) cap = a->n_chunk_off + 1u;
         HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
@@ -310,7 +307,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             HIPCHK(ctx, B[DB_GWCAND].ensure(GW_SEGS * 8 + 64)); HIPCHK(ctx, B[DB_GWLIST].ensure((size_t)GW_SEGS * GW_LCAP * 8)); HIPCHK(ctx, B[DB_GWCNT].ensure(GW_SEGS * 4 + 64)); HIPCHK(ctx, B[DB_GWLAND].ensure(GW_SEGS * 8 + 64));
             unsigned long long* cand = B[DB_GWCAND].as<unsigned long long>(); uint32_t* gbad = B[DB_GWCNT].as<uint32_t>() + GW_SEGS;
             HIPCHK(ctx, hipMemsetAsync(cand, 0xFF, GW_SEGS * 8, S)); HIPCHK(ctx, hipMemsetAsync(gbad, 0, 4, S));
-            const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> (getenv("RFQ_GW_SHIFT") ? atoi(getenv("RFQ_GW_SHIFT")) : 16)));   // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
+            const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> ctx->opt.gw_shift));   // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
             if (mseg > 1) hipLaunchKernelGGL(k_dec_gw_find, dim3(16, mseg - 1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, cand, mseg);
             hipLaunchKernelGGL(k_dec_gw_walk, dim3(mseg), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, B[DB_GWLIST].as<unsigned long long>(), B[DB_GWCNT].as<uint32_t>(), B[DB_GWLAND].as<unsigned long long>(), gbad, mseg, a->final ? 1 : 0);
             hipLaunchKernelGGL(k_dec_gw_stitch, dim3(1), dim3(1024), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, (const unsigned long long*)B[DB_GWLIST].as<unsigned long long>(),
@@ -353,7 +350,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         (void)table;
         break;
     }
-    if (getenv("RFQ_TRACE")) fprintf(stderr, "[rfq] chunk starts: %s, %u chunks\n", use_table ? "caller's index" : (guess ? "guess-and-verify" : (speculate ? "mSize chain" : "exact walk")), hs.n_chunks);
+    if (ctx->opt.trace) fprintf(stderr, "[rfq] chunk starts: %s, %u chunks\n", use_table ? "caller's index" : (guess ? "guess-and-verify" : (speculate ? "mSize chain" : "exact walk")), hs.n_chunks);
     ctx->timer.end(S);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "truncated or corrupt rfq chunk at byte %llu", (unsigned long long)hs.consumed);
     // 64-bit total of the read lengths: bases, qualities and text are placed by 32-bit prefix sums below (a corrupt length table
@@ -365,7 +362,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     const uint32_t last_flags = hs.last_flags; const int split = a->split_pe ? 1 : 0;
     DChunk* CHm = B[DB_CHUNKS].as<DChunk>();
     // (RFQ_SLICE_BASES: test aid - ranges of that many bases, so that the slicing logic runs on small images)
-    static const uint64_t slice_env = getenv("RFQ_SLICE_BASES") ? (uint64_t)atoll(getenv("RFQ_SLICE_BASES")) : 0;
+    const uint64_t slice_env = ctx->opt.slice_bases;
     const uint64_t slice_bases = slice_env ? slice_env : 1500000000ull, one_pass = slice_env ? slice_env : 0xFFFFFFF0ull;   // (a pass whose text turns out to be >= 4 GiB is redone in ranges)
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;

@@ -120,7 +120,7 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
     if (a->paired < 0 || a->paired > 2) return rfq_fail(ctx, RFQ_E_ARG, "paired must be RFQ_SE, RFQ_PE_TWO_FILES or RFQ_PE_INTERLEAVED");
     const bool two = a->paired == RFQ_PE_TWO_FILES;
     // (RFQ_SLICE_BYTES: test aid - slices of that many bytes, so that the slicing logic runs on small inputs)
-    static const size_t slice_env = getenv("RFQ_SLICE_BYTES") ? (size_t)atoll(getenv("RFQ_SLICE_BYTES")) : 0;
+    const size_t slice_env = ctx->opt.slice_bytes;
     const size_t slice = slice_env ? slice_env : RFQ_SLICE, lim = slice_env ? slice_env : 0xFFFFFFF0ull - 16;
     if (a->n1 < lim && (!two || a->n2 < lim)) return encode_one(ctx, a, res, scan_only);
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -207,7 +207,6 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     DBuf* B = ctx->b;
     ctx->timer.reset();
     ctx->pend.clear(); ctx->pin_used = 0;                                   // (read-backs an earlier call left behind on an error path)
-    const int tune = getenv("RFQ_TUNE") ? atoi(getenv("RFQ_TUNE")) : 0;   // kernel ablation switches for profiling runs (results are invalid when set; read per call: tools/ab_encode.py flips them inside one process)
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
     // ---- status block
@@ -221,13 +220,12 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.begin("index", S);
     uint32_t nblk[2] = { 0, 0 }; uint64_t nwords[2] = { 0, 0 };
     for (int s = 0; s < nstreams; s++) { nwords[s] = (nbytes[s] + 63) / 64; nblk[s] = (uint32_t)((nwords[s] + 255) / 256); }
-    int idx_tiles = getenv("RFQ_IDX_TILES") ? atoi(getenv("RFQ_IDX_TILES")) : NLF_TILES;
+    int idx_tiles = ctx->opt.idx_tiles ? ctx->opt.idx_tiles : NLF_TILES;
     if (idx_tiles != 4 && idx_tiles != 8 && idx_tiles != 16) idx_tiles = NLF_TILES;
     uint32_t nidx[2] = { 0, 0 };                                                           // workgroups of the one-pass index
     for (int s = 0; s < nstreams; s++) nidx[s] = (uint32_t)((nbytes[s] + idx_tiles * 16384u - 1) / (idx_tiles * 16384u));
     uint32_t n_newlines[2] = { 0, 0 }; uint8_t lastbyte[2] = { '\n', '\n' };
-    const char* ienv = getenv("RFQ_INDEX");
-    bool one_pass = !(ienv && !strcmp(ienv, "2pass"));
+    bool one_pass = !ctx->opt.index_2pass;
     if (one_pass) {
         size_t cap[2] = { 0, 0 };
         for (int s = 0; s < nstreams; s++) {
@@ -307,7 +305,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
 
     // (an early return must not leave the second stream running over buffers that are about to be reused)
     struct AuxGuard { rfq_ctx* c; bool armed; void sync() { if (armed) { (void)hipStreamSynchronize(c->aux); armed = false; } } ~AuxGuard() { sync(); } } ovl_guard = { ctx, false };
-    ctx->timer.begin("read_table+cut", S);
+    ctx->timer.begin("lens+cut", S);
     const size_t nr = (size_t)n_reads + 2;
     HIPCHK(ctx, B[B_LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N1LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N2OFF].ensure(nr * 4));
     HIPCHK(ctx, B[B_X].ensure(nr * 4)); HIPCHK(ctx, B[B_Y].ensure(nr * 4)); HIPCHK(ctx, B[B_TILE].ensure(nr * 2)); HIPCHK(ctx, B[B_LANE].ensure(nr)); HIPCHK(ctx, B[B_OK].ensure(nr));
@@ -319,14 +317,12 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>(); R.y = B[B_Y].as<uint32_t>();
     R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>(); R.stored = B[B_STORED].as<uint32_t>();
     R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
-    // the chunk flags come from per-read adjacency bits (and, PE, per-pair mate summaries) written here
-    HIPCHK(ctx, B[B_ADJ].ensure(2 * nr)); HIPCHK(ctx, B[B_PINFO].ensure(2 * nr + 16));
-    uint16_t* adj = B[B_ADJ].as<uint16_t>(); uint32_t* pinfo = is_pe ? B[B_PINFO].as<uint32_t>() : nullptr;
-    hipLaunchKernelGGL(k_read_table, dim3((n_reads + 4 * RT_NEW - 1) / (4 * RT_NEW)), dim3(256), 0, S, T, R, n_reads, adj, pinfo, dst);
+    // sequence lengths come from the line table alone; the names are parsed where the text is staged anyway (k_gather2), or by k_read_table for
+    // the reads that need them earlier (chunk 0 of a first batch: the file header) / on the byte-wise gather path (all of them)
     const uint32_t ublocks = (n_units + 255) / 256;
     HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 12));
-    hipLaunchKernelGGL(k_unit_len, dim3(ublocks), dim3(256), 0, S, T, (const uint32_t*)R.len, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>());
-    KCHK(ctx, "k_read_table");
+    hipLaunchKernelGGL(k_read_lens, dim3(ublocks), dim3(256), 0, S, T, R.len, R.stored, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>(), dst);
+    KCHK(ctx, "k_read_lens");
     scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1);
     scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1);
     const uint64_t cap64 = (uint64_t)(nbytes[0] + nbytes[1]) / (2ull * a->chunk_bases) + 3;
@@ -400,11 +396,22 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     const bool hdr_aside = make_header && !is_pe && ctx->aux_ready();
     hipStream_t HS = hdr_aside ? ctx->aux : S;
     if (hdr_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(HS, ctx->ev_fork, 0)); }
+    // Which gather: the tile gather k_gather2 (+ k_seqpack) whenever two records fit its staged-text buffer - tiles of K reads, the largest power of two
+    // that always fits - else the byte-wise k_gather (+ k_packbytes).  RFQ_GATHER=old forces the latter (tests run both).
+    uint32_t kshift = 6;
+    while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > G2_CAP) kshift--;
+    const bool fast = kshift >= 1 && !ctx->opt.gather_old;
+    const uint32_t max_rec = hs.max_rec;
+    const uint32_t np = reads_used / 2;
     ctx->timer.begin("header", S);
     hipLaunchKernelGGL(k_chunk_ids, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, C, R);
+    // parsed names ahead of the gather: chunk 0's for the file header of a first batch; every read's on the byte-wise path
+    const uint32_t c0_reads = std::max(1u, std::min(max_reads, reads_used));
+    if (!fast) hipLaunchKernelGGL(k_read_table, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, n_reads);
+    else if (make_header) hipLaunchKernelGGL(k_read_table, dim3((c0_reads + 255) / 256), dim3(256), 0, S, T, R, c0_reads);
+    if (hdr_aside) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(HS, ctx->ev_fork, 0)); }
     if (make_header) {
         HdrStats* H = B[B_HSTATS].as<HdrStats>();
-        const uint32_t c0_reads = std::max(1u, std::min(max_reads, reads_used));
         const uint32_t hb = std::min<uint32_t>(1024, (c0_reads + 3) / 4);
         hipLaunchKernelGGL(k_hdr_init, dim3(1), dim3(128), 0, HS, H);
         hipLaunchKernelGGL(k_hdr_stats, dim3(hb), dim3(256), 0, HS, T, R, (const uint32_t*)C.first, H);
@@ -417,34 +424,17 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     ctx->timer.end(S);
 
-    // Which gather: the tile gather k_gather2 (+ k_seqpack) whenever two records fit its staged-text buffer - tiles of K reads, the largest power of two
-    // that always fits - else the byte-wise k_gather (+ k_packbytes).  RFQ_GATHER=old forces the latter (tests run both); RFQ_GATHER=pipe /
-    // RFQ_G2_KSHIFT are profiling aids (two half-size text buffers; smaller tiles).
-    const char* genv = getenv("RFQ_GATHER");
-    const bool pipe2 = genv && !strcmp(genv, "pipe2"), pipe = pipe2 || (genv && !strcmp(genv, "pipe"));   // (pipe2: two full-size buffers)
-    const uint32_t g2cap = (pipe && !pipe2) ? G2_CAP / 2 : G2_CAP;
-    uint32_t kshift = 6; if (getenv("RFQ_G2_KSHIFT")) kshift = std::min(6u, std::max(1u, (uint32_t)atoi(getenv("RFQ_G2_KSHIFT"))));
-    while (kshift >= 1 && ((uint64_t)hs.max_rec << kshift) + 64u > g2cap) kshift--;
-    const bool fast = kshift >= 1 && !(genv && !strcmp(genv, "old"));
-    const uint32_t max_rec = hs.max_rec;
-    const uint32_t np = reads_used / 2;
     HIPCHK(ctx, B[B_OVRAW].ensure((size_t)(is_pe ? n_units : 0) * 2 + 64));
     HIPCHK(ctx, B[B_SCANTMP2].ensure(std::max<size_t>(4096, (nr / SCAN_TILE + 2) * 16 + (nc / SCAN_TILE + 2) * 8)));
     HIPCHK(ctx, B[B_CTOTALN].ensure(nc * 8)); HIPCHK(ctx, B[B_CBASEN].ensure(nc * 8));
     const OvLoose noz = { nullptr, nullptr, nullptr, nullptr };
 
+    // per-chunk accumulators of the read-0 / mate comparisons (CF_ALL): all ones; k_chunk_flags_b makes the flag words from them.  The tile gather
+    // fills them itself (and the flags follow it); the byte-wise path needs the flags first (overlap search on the text, stored prefix).
+    HIPCHK(ctx, B[B_ADJ].ensure(3 * nc * 4));
+    uint32_t* cbits = B[B_ADJ].as<uint32_t>(); uint32_t* cfail = cbits + nc; uint32_t* redo = cfail + nc;
+    HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
     ctx->timer.begin("chunk_flags", S);
-    if (!is_pe) hipLaunchKernelGGL(k_chunk_flags_se, dim3(n_chunks), dim3(64), 0, S, C, (const uint16_t*)adj);
-    else {
-        // PE: adjacency path first; chunks where the interleave test fails mid-chunk (rare) go through the read-0 kernels, which exit at
-        // once for every other chunk.  Their per-chunk AND / MIN accumulators start at all-ones.
-        uint32_t* cbits = B[B_SCAP].as<uint32_t>(); uint32_t* cfail = cbits + nc; uint32_t* redo = cfail + nc;   // borrowed: B_SCAP is written later by k_stream_plan
-        HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
-        hipLaunchKernelGGL(k_chunk_flags_pe, dim3(n_chunks), dim3(64), 0, S, T, R, C, (const DevHeader*)D, (const uint16_t*)adj, (const uint32_t*)pinfo, redo);
-        const uint32_t fbx = std::max(1u, std::min<uint32_t>((max_reads + 255) / 256, std::max(1u, 4096u / n_chunks)));
-        hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, 1, cbits, cfail, (const uint32_t*)redo);
-        hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, 1, (const uint32_t*)cbits, (const uint32_t*)cfail, (const uint32_t*)redo);
-    }
     hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks, 1);
     // the stored-base prefix (it needs the mates' overlaps): k_overlap_apply, per-read prefix inputs, their scan, the chunks' bases in the tight streams
     auto stored_prefix = [&](hipStream_t Q, U4* tmp) {
@@ -453,22 +443,19 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         scan_exclusive<U4>(Q, B[B_PVIN].as<U4>(), R.pv, n_reads, tmp, 1);
         hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, Q, R, C, n_chunks, 2);
     };
+    if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));      // from here on everything needs the header (major quality, flags, the mates' name2 rule)
     if (!fast) {
-        // byte-wise gather: it writes the stored bases themselves, so the overlap search (on the text) and the stored prefix come first
+        // byte-wise gather: it writes the stored bases themselves, so chunk flags, the overlap search (on the text) and the stored prefix come first
+        const uint32_t fbx = std::max(1u, std::min<uint32_t>((max_reads + 255) / 256, std::max(1u, 4096u / n_chunks)));
+        hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, is_pe ? 1 : 0, cbits, cfail);
+        hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail, (uint32_t*)nullptr);
         if (is_pe) {
             const uint32_t ob = std::min<uint32_t>((n_units + 255) / 256, 65535u * 16u);
-            if (tune & 64) {     // per-phase cycle counters (profiling aid)
-                unsigned long long* dbg = (unsigned long long*)B[B_HSTATS].p + 600; (void)hipMemsetAsync(dbg, 0, 64, S);
-                hipLaunchKernelGGL((k_overlap<true, false>), dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units, dbg, 0);
-                (void)hipStreamSynchronize(S);
-                unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
-                if (h[5]) fprintf(stderr, "[overlap dbg] waves=%llu avg cycles/wave: meta=%llu pack=%llu fwd=%llu bwd=%llu slow+write=%llu verifies/wave=%.1f\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5], (double)h[6]/h[5]);
-            } else hipLaunchKernelGGL((k_overlap<false, false>), dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units, (unsigned long long*)nullptr, (tune >> 8) & 7);   // (tune bits 8-10: ablation switches, results invalid)
+            hipLaunchKernelGGL((k_overlap<false, false>), dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units, (unsigned long long*)nullptr, 0);
         }
         stored_prefix(S, B[B_SCANTMP].as<U4>());
+        KCHK(ctx, "k_chunk_flags");
     }
-    KCHK(ctx, "k_chunk_flags");
-    if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));      // the gather needs the header (major quality, flags)
     ctx->timer.end(S);
 
     ctx->timer.begin(fast ? "gather" : "gather_bytes", S);                  // (which formulation ran: tests and the bench look at it)
@@ -486,13 +473,16 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2)); HIPCHK(ctx, B[B_RFLAG].ensure(nr));
         HIPCHK(ctx, hipMemsetAsync(B[B_RFLAG].p, 0, nr, S));
         const uint32_t K = 1u << kshift;
-        const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, (pipe ? 5u : 6u) * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
-#define RFQ_G2_ARGS T, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint32_t*)C.il, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), \
-                    B[B_RFLAG].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, dst, (tune >> 16) & 15      /* (tune bits 16-19: ablation switches of k_gather2, results invalid) */
-        if (pipe2) hipLaunchKernelGGL((k_gather2<true, G2_CAP>), dim3(grid_x_for(n_chunks, (max_reads + K - 1) / K, 3u * ctx->n_cu), n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
-        else if (pipe) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
-        else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_G2_ARGS);
-#undef RFQ_G2_ARGS
+        const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
+        // phase 1: every chunk, names parsed on the way, mates taken for interleaved wherever the header allows; then the flag words; then phase 2 for the
+        // (rare) chunks whose interleave test failed somewhere: their workgroups are the only ones of that launch that do not return at once
+        for (int phase = 1; phase <= (is_pe ? 2 : 1); phase++) {
+            if (phase == 2) hipLaunchKernelGGL(k_gather_redo_reset, dim3(n_chunks), dim3(64), 0, S, (const uint32_t*)redo, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
+            hipLaunchKernelGGL(k_gather2, dim3(bx, n_chunks), dim3(256), 0, S, T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(),
+                               B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_RFLAG].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift,
+                               cbits, cfail, phase == 2 ? (const uint32_t*)redo : (const uint32_t*)nullptr, dst);
+            if (phase == 1) hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail, redo);
+        }
         // the quality streams' scratch plan needs nothing else: the position coder can start as soon as the host has sized its arena
         hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 1);
         scan_exclusive<uint64_t>(S, ctot, cbase, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
@@ -500,12 +490,12 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // Second chain (aux stream), beside the position coder: overlap search on the loose slots the gather has just left, stored prefix, sequence packer
         // (tight 2-bit stream + N mask + N counts), the N streams' plan, the image's upper bound.  These are chains of small latency-bound kernels
         // and a search that is VALU-bound; the coder hides them.
-        aux_chain = ctx->aux_ready() && !(tune & 2048); hipStream_t A = aux_chain ? ctx->aux : S;
+        aux_chain = ctx->aux_ready() && !ctx->opt.one_stream; hipStream_t A = aux_chain ? ctx->aux : S;
         if (aux_chain) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); ovl_guard.armed = true; }
         if (is_pe) {
             const OvLoose Z = { (const uint32_t*)R.pq, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), (const uint8_t*)B[B_RFLAG].as<uint8_t>() };
             const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
-            hipLaunchKernelGGL((k_overlap<false, true>), dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, (tune >> 8) & 7);
+            hipLaunchKernelGGL((k_overlap<false, true>), dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, 0);
         }
         stored_prefix(A, B[B_SCANTMP2].as<U4>());
         {
@@ -513,10 +503,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
             uint32_t rshift = 8; while (rshift && ((uint64_t)(max_len / 16u + 1u) << rshift) > SP_OWN) rshift--;
             uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
-            if (getenv("RFQ_SP_X")) sx = std::max(1, atoi(getenv("RFQ_SP_X")));
             hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
-                               C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift, (tune >> 20) & 15);   // (tune bits 20-23: ablation switches, results invalid)
+                               C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift);
         }
         uint64_t* tmp2 = B[B_SCANTMP2].as<uint64_t>() + (nr / SCAN_TILE + 2) * 2;   // (behind the U4 scan's part of the buffer)
         hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, A, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 2);
@@ -529,13 +518,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
         // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 32
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
-#define RFQ_GATHER_ARGS T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, \
-                        tune ? (unsigned long long*)B[B_HSTATS + 0].p + 512 : nullptr, tune
-        if (tune & 7) hipLaunchKernelGGL(k_gather<true>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
-        else hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, RFQ_GATHER_ARGS);
-#undef RFQ_GATHER_ARGS
-        if (tune & 7) { unsigned long long h[8]; (void)hipMemcpy(h, (unsigned long long*)B[B_HSTATS].p + 512, 64, hipMemcpyDeviceToHost); (void)hipMemset((unsigned long long*)B[B_HSTATS].p + 512, 0, 64);
-            if (h[5]) fprintf(stderr, "[gather dbg] blocks=%llu avg cycles/block: fit=%llu meta=%llu stage=%llu emit_q=%llu emit_s=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[4]/h[5]); }
+        hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg,
+                           (unsigned long long*)nullptr, 0);
         const uint32_t px = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
         hipLaunchKernelGGL(k_packbytes, dim3(px, n_chunks), dim3(256), 0, S, (const U4*)R.pv, (const uint32_t*)C.first, (const uint64_t*)C.sbase, (const uint8_t*)B[B_SCAT].as<uint8_t>(),
                            B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>());
@@ -569,19 +553,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_SCRATCH].ensure((size_t)hs.total_scratch + 256));
     HIPCHK(ctx, B[B_XS].ensure(3 * nr + 64)); HIPCHK(ctx, B[B_YS].ensure(3 * nr + 64));
     const uint32_t nqg = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
-    // RFQ_CODER=ms: the value streams by k_pos_coder_ms (one wave per segment for all of them, tokens from a per-step list of the coded positions) instead of a
-    // wave per four streams testing every position.  Bit-exact, and slower at any number of streams so far: kept for tests and the next attempt
-    const char* cenv = getenv("RFQ_CODER");
-    const bool coder_ms = cenv && !strcmp(cenv, "ms") && !(HH.flags & H_DONT_QUAL) && (HH.flags & H_QUAL_BY_COL) && HH.n_normal >= 1;
     auto launch_coder = [&](hipStream_t Q, uint32_t g0, uint32_t gn) -> int {
-        if (coder_ms && g0 == 0 && gn >= nqg) {                            // the value streams: the list coder; what is left of the request (exception group, N group) below
-            const uint64_t mb = (uint64_t)((n_chunks + 7) / 8) * 8ull * n_seg;
-            if (mb > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
-            hipLaunchKernelGGL(k_pos_coder_ms, dim3((uint32_t)mb), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase,
-                               B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, dst, (tune >> 27) & 3);
-            g0 = nqg; gn -= nqg;
-            if (gn == 0) return RFQ_OK;
-        }
         const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * gn * n_seg;
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
         hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint16_t*)B[B_SNM].as<uint16_t>(),
@@ -595,8 +567,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (fast) {
         // the quality / exception streams now; the N streams when the second chain has planned them (its totals come back while the coder runs)
         if (!aux_chain) HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));   // (one stream: the N plan is already in)
-        const bool pc_all = !aux_chain && getenv("RFQ_PC_ALL");            // (profiling aid: with everything on one stream, all groups in one launch)
-        { const int rc = launch_coder(S, 0, pc_all ? nqg + 2 : nqg + 1); if (rc) return rc; }
+        { const int rc = launch_coder(S, 0, nqg + 1); if (rc) return rc; }
         if (aux_chain) { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, ctx->aux)); HIPCHK(ctx, ctx->fetch_sync(ctx->aux)); ovl_guard.armed = false; }
         else { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S)); HIPCHK(ctx, ctx->fetch_sync(S)); }
     }
@@ -614,7 +585,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     {
         hipStream_t A2 = (fast ? aux_chain : fork_coords) ? ctx->aux : S;
         hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, A2, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
-        if (fast) { if (!(!aux_chain && getenv("RFQ_PC_ALL"))) { const int rc = launch_coder(A2, nqg + 1, 1); if (rc) return rc; } }
+        if (fast) { const int rc = launch_coder(A2, nqg + 1, 1); if (rc) return rc; }
         else { const int rc = launch_coder(S, 0, nqg + 2); if (rc) return rc; }
         if (A2 != S) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A2)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     }

@@ -385,115 +385,25 @@ __device__ __forceinline__ bool lds_bytes_eq(const uint8_t* rows, uint32_t a, ui
     }
     return true;
 }
-// A wave takes 64 consecutive reads, its first two being the previous wave's last two (62 new reads per wave, so that mates stay in
-// the same wave and lane parity = read parity): every read but the batch's first then has its predecessor in the same wave, and the "equal to the chunk's read 0" tests of RfqCodec::encodeChunk's
-// pass 1 (src/rfqcodec.cpp:220-250) - equality is transitive - become per-read ADJACENCY bits (adj[g]: read g vs read g-1, bit
-// layout of k_chunk_flags_a plus bit 8 = name2 equal to read g-1's, bit 9 = name2 equal to read g-2's) that a chunk later AND-reduces
-// over its reads but the first.  PE: pinfo[g >> 1] summarises the mate tests of pair (g-1, g) that do not need the file header yet:
-//   bit 0 name2 lengths equal, bits 1-2 number of differing name2 bytes (0, 1, 2 = more), bit 3 lane / tile / x / y differ,
-//   bits 8-15 position of the first difference, bits 16-23 the R2 byte there.  adj / pinfo may be null.
-#define RT_NEW 62u
-__global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads, uint16_t* __restrict__ adj, uint32_t* __restrict__ pinfo, DevStatus* st) {
+// FastqMeta::parse for reads [0, n_reads) by themselves - a lane per read, names staged in LDS rows - for the two callers that need the parsed
+// names BEFORE the gather: the file header of a first batch (RfqCodec::makeHeader looks at chunk 0 only, src/rfqcodec.cpp:20-145: the host passes
+// chunk 0's reads) and the byte-wise gather path (every read).  The tile gather k_gather2 parses the names of the tile it has staged anyway
+// (g2_parse) - the text is not read a third time for them.
+__global__ void k_read_table(Text T, ReadTab R, uint32_t n_reads) {
     __shared__ __attribute__((aligned(16))) uint8_t s_names[4 * 64 * RT_ROW + 16];
     const int l = lane_id(), w = wave_id();
-    const uint32_t g = (blockIdx.x * (blockDim.x >> 6) + (uint32_t)w) * RT_NEW + (uint32_t)l;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = g < n_reads;
-    uint32_t nb = 0, nl = 0, sl = 0, tl = 0, ql = 0, tb = 0; int s = 0;
-    if (valid) {
-        uint32_t r; read_loc(T, g, s, r);
-        const uint32_t* p = t_lo(T, s) + 4 * (size_t)r;
-        const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
-        nb = p0; nl = p1 - 1 - p0; sl = p2 - 1 - p1; tl = p3 - 1 - p2; ql = p4 - 1 - p3; tb = p2;
-    }
+    uint32_t nb = 0, nl = 0; int s = 0;
+    if (valid) { uint32_t r; read_loc(T, g, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r; nb = p[0]; nl = p[1] - 1 - nb; }
     uint8_t* rows = s_names + (size_t)w * 64 * RT_ROW + 16;              // (+16: a row's name begins 16 bytes into the row)
-    // the strand line's first four bytes (almost always just "+"), fetched beside the names
-    uint32_t st4 = 0;
-    if (adj && valid) { const uint8_t* sp = t_fq(T, s) + tb; for (uint32_t i = 0; i < 4 && i < tl; i++) st4 |= (uint32_t)sp[i] << (8 * i); }
     stage_name_rows_wide(T, rows - 16, nb, nl, s, l);
     __syncthreads();
-    uint32_t err = 0; Meta m; m.ok = 0; m.name1_len = 0; m.name2_off = 0; m.x = 0; m.y = 0; m.tile = 0; m.lane = 0;
     if (valid) {
-        if (nl == 0 || sl == 0 || tl == 0 || ql == 0) err |= DE_EMPTY_LINE;
-        if (ql < sl) err |= DE_QUAL_SHORT;
         bool settled = true;
-        m = dev_parse_name(rows + l * RT_ROW, nl, RT_NAME_CAP, &settled);
+        Meta m = dev_parse_name(rows + l * RT_ROW, nl, RT_NAME_CAP, &settled);
         if (!settled) m = dev_parse_name(t_fq(T, s) + nb, nl);
-        R.len[g] = sl; R.stored[g] = sl;
         R.name1_len[g] = m.name1_len; R.name2_off[g] = m.name2_off; R.x[g] = m.x; R.y[g] = m.y; R.tile[g] = m.tile; R.lane[g] = m.lane; R.ok[g] = (uint8_t)m.ok;
-    }
-    if (adj) {                                                            // wave-uniform
-        const uint32_t n1 = m.name1_len, n2o = m.name2_off, n2 = nl - n2o;
-        const uint32_t psl = __shfl_up(sl, 1u), pnl = __shfl_up(nl, 1u), pn1 = __shfl_up(n1, 1u), pn2o = __shfl_up(n2o, 1u), ptl = __shfl_up(tl, 1u), pst4 = __shfl_up(st4, 1u);
-        const uint32_t plane = __shfl_up((uint32_t)m.lane, 1u), ptile = __shfl_up((uint32_t)m.tile, 1u), pnb = __shfl_up(nb, 1u), ptb = __shfl_up(tb, 1u); const int ps = __shfl_up(s, 1u);
-        const uint32_t px = __shfl_up(m.x, 1u), py = __shfl_up(m.y, 1u);
-        const uint32_t qnl = __shfl_up(nl, 2u), qn2o = __shfl_up(n2o, 2u), qnb = __shfl_up(nb, 2u); const int qs = __shfl_up(s, 2u);   // same-parity predecessor
-        if (valid && l > 0) {
-            const uint32_t pn2 = pnl - pn2o; uint32_t b = 0;
-            if (sl == psl) b |= 1u << 0;
-            if (n1 == pn1) b |= 1u << 1;
-            if (n2 == pn2) b |= 1u << 2;
-            if (tl == ptl) b |= 1u << 3;
-            if (tl == ptl) {                                               // strand bytes
-                bool eq = st4 == pst4;
-                if (eq && tl > 4) { const uint8_t* a = t_fq(T, s) + tb; const uint8_t* c = t_fq(T, ps) + ptb; for (uint32_t i = 4; i < tl && eq; i++) eq = a[i] == c[i]; }
-                if (eq) b |= 1u << 4;
-            }
-            if ((uint32_t)m.lane == plane) b |= 1u << 5;
-            if ((uint32_t)m.tile == ptile) b |= 1u << 6;
-            // n bytes at offset oa / ob of two names: what both rows hold is compared in LDS, the rest (names longer than RT_NAME_CAP) in global memory
-            const uint32_t ra = (uint32_t)l * RT_ROW, rb = (uint32_t)(l - 1) * RT_ROW;
-            const uint8_t* ga = t_fq(T, s) + nb; const uint8_t* gb = t_fq(T, ps) + pnb;
-            auto names_eq = [&](uint32_t rowa, uint32_t oa, uint32_t la, const uint8_t* pa, uint32_t rowb, uint32_t ob, uint32_t lb_, const uint8_t* pb_, uint32_t n) -> bool {
-                const uint32_t sa = la < RT_NAME_CAP ? la : RT_NAME_CAP, sb = lb_ < RT_NAME_CAP ? lb_ : RT_NAME_CAP;
-                const uint32_t va = sa > oa ? sa - oa : 0u, vb = sb > ob ? sb - ob : 0u; uint32_t k = va < vb ? va : vb; if (k > n) k = n;
-                if (k && !lds_bytes_eq(rows, rowa + oa, rowb + ob, k)) return false;
-                return k == n || bytes_eq(pa + oa + k, n - k, pb_ + ob + k, n - k);
-            };
-            const bool inl = nl <= RT_NAME_CAP && pnl <= RT_NAME_CAP;        // both names wholly staged in LDS
-            if (n1 == pn1 && names_eq(ra, 0u, nl, ga, rb, 0u, pnl, gb, n1)) b |= 1u << 7;
-            if (n2 == pn2 && names_eq(ra, n2o, nl, ga, rb, pn2o, pnl, gb, n2)) b |= 1u << 8;
-            if (l > 1 && pinfo) {                                              // PE: the previous pair's mate of the same side
-                const uint32_t qn2 = qnl - qn2o;
-                if (n2 == qn2 && names_eq(ra, n2o, nl, ga, (uint32_t)(l - 2) * RT_ROW, qn2o, qnl, t_fq(T, qs) + qnb, n2)) b |= 1u << 9;
-            }
-            adj[g] = (uint16_t)b;
-            if (pinfo && (g & 1u)) {                                           // (g-1, g) is a pair: a = R1's name2, b = R2's name2
-                uint32_t info = 0, nd = 0, pd = 0, bch = 0;
-                if (n2 == pn2) {
-                    info |= 1u;
-                    for (uint32_t i = 0; i < n2 && nd < 2; i++) {
-                        const uint8_t ca = (inl || pn2o + i < RT_NAME_CAP) ? rows[rb + pn2o + i] : gb[pn2o + i], cb = (inl || n2o + i < RT_NAME_CAP) ? rows[ra + n2o + i] : ga[n2o + i];
-                        if (ca != cb) { if (nd == 0) { pd = i; bch = cb; } nd++; }
-                    }
-                }
-                if ((uint32_t)m.lane != plane || (uint32_t)m.tile != ptile || m.x != px || m.y != py) info |= 1u << 3;
-                info |= (nd > 2 ? 2u : nd) << 1; info |= (pd & 0xFFu) << 8; info |= (bch & 0xFFu) << 16;
-                pinfo[g >> 1] = info;
-            }
-        }
-    }
-    const uint32_t fe = wave_min((valid && (err & DE_EMPTY_LINE)) ? g : 0xFFFFFFFFu);
-    err = wave_or(err);
-    if (l == 0 && err) { atomicOr(&st->err, err); if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); }
-}
-// SE chunks (no mates, no interleave rule): the flag word from the adjacency bits, one wave per chunk
-__global__ void k_chunk_flags_se(ChunkTab C, const uint16_t* __restrict__ adj) {
-    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
-    uint32_t bits = 0x1FFu;
-    for (uint32_t g = f + 1 + (uint32_t)l; g < e; g += 64) bits &= adj[g];
-    bits = wave_and(bits);
-    if (l == 0) {
-        uint32_t fl = 0;
-        if (bits & (1u << 0)) fl |= C_READ_LEN_SAME;
-        if (bits & (1u << 1)) fl |= C_NAME1_LEN_SAME;
-        if (bits & (1u << 2)) fl |= C_NAME2_LEN_SAME;
-        if (bits & (1u << 3)) fl |= C_STRAND_LEN_SAME;
-        if (bits & (1u << 4)) fl |= C_STRAND_SAME;
-        if (bits & (1u << 5)) fl |= C_LANE_SAME;
-        if (bits & (1u << 6)) fl |= C_TILE_SAME;
-        if (bits & (1u << 7)) fl |= C_NAME1_SAME;
-        if (bits & (1u << 8)) fl |= C_NAME2_SAME;
-        C.flags[c] = fl; C.il[c] = 0u;
     }
 }
 // rfq_scan_batch: offset just past the last record of every chunk, per input stream, in the caller's coordinates (onx: normalised text)
@@ -506,20 +416,28 @@ __global__ void k_chunk_ends(Text T, const uint32_t* __restrict__ first, uint32_
     end1[c] = onx0 ? (rec ? (uint64_t)onx0[li - 1] : 0ull) : (uint64_t)T.lo[0][li];
     if (T.paired == 1) end2[c] = onx1 ? (rec ? (uint64_t)onx1[li - 1] : 0ull) : (uint64_t)T.lo[1][li];
 }
-// bases per partition unit (a read, or a pair) + per-block min / max for the partitioner's uniform-length fast path
-// (no atomics: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
-__global__ void k_unit_len(Text T, const uint32_t* __restrict__ len, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax) {
+// Sequence lengths from the line table alone (no text is read): len / stored per read, the line checks of FastqReader::read (an empty line ends
+// the input there, src/fastqreader.cpp:180-191; a quality line shorter than its sequence is refused), bases per partition unit (a read, or a
+// pair) + per-block min / max for the partitioner's uniform-length fast path and the longest record (k_gather2 sizes its tiles by it).
+// (no atomics for the min / max: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
+__global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __restrict__ stored, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax, DevStatus* st) {
     __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4];
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t tot = 0; uint32_t rec = 0;                                     // rec: bytes of the unit's longest record (k_gather2 sizes its tiles by it)
+    uint64_t tot = 0; uint32_t rec = 0, err = 0, fe = 0xFFFFFFFFu;        // rec: bytes of the unit's longest record
     if (u < n_units) {
-        for (uint32_t j = 0; j < upr; j++) tot += len[(size_t)u * upr + j];
+        for (uint32_t j = 0; j < upr; j++) {
+            const uint32_t g = u * upr + j; int s; uint32_t r; read_loc(T, g, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r;
+            const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
+            const uint32_t nl = p1 - 1 - p0, sl = p2 - 1 - p1, tl = p3 - 1 - p2, ql = p4 - 1 - p3;
+            if (nl == 0 || sl == 0 || tl == 0 || ql == 0) { err |= DE_EMPTY_LINE; if (g < fe) fe = g; }
+            if (ql < sl) err |= DE_QUAL_SHORT;
+            len[g] = sl; stored[g] = sl; tot += sl; if (p4 - p0 > rec) rec = p4 - p0;
+        }
         ulen[u] = tot;
-        for (uint32_t j = 0; j < upr; j++) { int s; uint32_t r; read_loc(T, u * upr + j, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r; const uint32_t b = p[4] - p[0]; if (b > rec) rec = b; }
     }
     uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
-    mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec);
-    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; }
+    mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec); fe = wave_min(fe); err = wave_or(err);
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; if (err) { atomicOr(&st->err, err); if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); } }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; if (s_rc[i] > rec) rec = s_rc[i]; }
@@ -770,11 +688,18 @@ struct Layout {                  // byte offsets of every section inside one chu
 };
 __device__ __forceinline__ uint32_t name2_len_of(const Text& T, const ReadTab& R, uint32_t g) { return line_len(T, g, 0) - R.name2_off[g]; }
 
-// Pass A — grid (blocks, n_chunks): a wave takes 64 consecutive reads of the chunk, stages their names row by row in LDS with
-// coalesced loads (as k_read_table does), and every lane compares its read with the chunk's read 0 (row 64) and, for odd reads of a
-// PE chunk, with its mate (the previous row).  Results are AND / MIN-combined per chunk with one atomic per wave.
-__global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only) {
-    if (only && !only[blockIdx.y]) return;                                // only the chunks the adjacency path could not settle
+// Every read of a chunk is compared with the chunk's read 0 (src/rfqcodec.cpp:220-250) and, in a PE chunk under a header that supports interleaving, every
+// odd read with its mate (:233-263).  The per-read verdicts are AND / MIN-combined per chunk:
+//   cbits[c]  bits 0-7  readLen / name1Len / name2Len / strandLen / strand / lane / tile / name1 equal to read 0's      (starts as all ones)
+//             bit 8     name2 equal to read 0's, every read;  bit 9  the same over the even reads only (what counts while the chunk stays interleaved)
+//   cfail[c]  (first odd read whose mate test fails) << 1 | (0: the name2 rule failed, 1: only lane / tile / x / y differ)  (starts as all ones)
+//   eq2[g]    name2 of read g equal to read 0's - only looked at for chunks whose mate test fails somewhere (the order-dependent rule of Q12)
+// Two producers: g2_parse inside k_gather2 (the tile gather has the names staged) and k_chunk_flags_a (byte-wise gather path); k_chunk_flags_b turns them
+// into the flag word.
+#define CF_ALL 0x3FFu
+// Pass A (byte-wise gather path) — grid (blocks, n_chunks): a wave takes 64 consecutive reads of the chunk, stages their names row by row in LDS with
+// coalesced loads, and every lane compares its read with the chunk's read 0 (row 64) and, for odd reads of a PE chunk, with its mate (the previous row).
+__global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail) {
     __shared__ uint8_t s_names[4 * 65 * NAME_STRIDE];
     const uint32_t c = blockIdx.y, f = C.first[c], e = C.first[c + 1];
     const int l = lane_id(), w = wave_id(); const uint32_t wpb = blockDim.x >> 6;
@@ -786,7 +711,7 @@ __global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* 
     const uint8_t* st0 = line_ptr(T, f, 2); const uint8_t lane0 = R.lane[f]; const uint16_t tile0 = R.tile[f];
     { const uint32_t take = nl0 < NAME_CAP ? nl0 : NAME_CAP; for (uint32_t i = (uint32_t)l; i < take; i += 64) rows[64 * NAME_STRIDE + i] = nm0g[i]; }
     const uint8_t* nm0 = nl0 <= NAME_CAP ? rows + 64 * NAME_STRIDE : nm0g;
-    uint32_t bits = 0xFF, fail = 0xFFFFFFFFu;
+    uint32_t bits = CF_ALL, fail = 0xFFFFFFFFu;
     for (uint32_t gb = f + (blockIdx.x * wpb + (uint32_t)w) * 64u; gb < e; gb += gridDim.x * wpb * 64u) {      // wave-uniform
         const uint32_t g = gb + (uint32_t)l; const bool v = g < e;
         uint32_t nb = 0, nl = 0, stb = 0, stl = 0; int s = 0;
@@ -797,6 +722,7 @@ __global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* 
         if (v) {
             const uint8_t* nm = nl <= NAME_CAP ? rows + l * NAME_STRIDE : t_fq(T, s) + nb;
             const uint32_t n1l = R.name1_len[g], n2o = R.name2_off[g], n2l = nl - n2o;
+            const uint32_t rel = g - f;
             uint32_t b = 0;
             if (R.len[g] == len0) b |= 1u << 0;
             if (n1l == n1l0) b |= 1u << 1;
@@ -806,9 +732,11 @@ __global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* 
             if (R.lane[g] == lane0) b |= 1u << 5;
             if (R.tile[g] == tile0) b |= 1u << 6;
             if (bytes_eq(nm0, n1l0, nm, n1l)) b |= 1u << 7;
+            const bool e2 = bytes_eq(nm0 + n2o0, n2l0, nm + n2o, n2l);
+            if (e2) b |= 1u << 8;
+            if (e2 || (rel & 1u)) b |= 1u << 9;
             bits &= b;
-            R.eq2[g] = bytes_eq(nm0 + n2o0, n2l0, nm + n2o, n2l) ? 1 : 0;
-            const uint32_t rel = g - f;
+            R.eq2[g] = e2 ? 1 : 0;
             if (can0 && (rel & 1u)) {                                        // mate = previous row (groups start at even reads)
                 const uint32_t m = g - 1; const uint32_t mnl = line_len(T, m, 0), mo = R.name2_off[m];
                 const uint8_t* mn = (mnl <= NAME_CAP ? rows + (l - 1) * NAME_STRIDE : line_ptr(T, m, 0)) + mo;
@@ -819,24 +747,26 @@ __global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* 
         }
     }
     bits = wave_and(bits); fail = wave_min(fail);
-    if (l == 0) { if (bits != 0xFF) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
+    if (l == 0) { if (bits != CF_ALL) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
 }
-// Pass B — one wave per chunk: name2Same with the order-dependent rule of src/rfqcodec.cpp:233-250 (Q12), then the flag word
-__global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, const uint32_t* __restrict__ cbits, const uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only) {
-    if (only && !only[blockIdx.x]) return;
+// Pass B — one wave per chunk: the flag word; name2Same with the order-dependent rule of src/rfqcodec.cpp:233-250 (Q12) - odd reads do not count while
+// the chunk is still interleaved - from the accumulated bits, read by read only for a chunk whose mate test fails somewhere.
+// assumed (may be null): the orientation the gather has already used for chunk c's mates; redo[c] = 1 where it turns out wrong (k_gather2 runs again there)
+__global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, const uint32_t* __restrict__ cbits, const uint32_t* __restrict__ cfail, uint32_t* __restrict__ redo) {
     const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
     const bool can0 = is_pe && D->support_interleaved;
-    const uint32_t bits = cbits[c] & 0xFFu, fail = cfail[c];
+    const uint32_t acc = cbits[c], bits = acc & 0xFFu, fail = cfail[c];
     const bool failed = can0 && fail != 0xFFFFFFFFu; const uint32_t frel = fail >> 1; const bool kind_a = !(fail & 1u);
-    uint32_t n2same = 1;
-    for (uint32_t g = f + (uint32_t)l; g < e; g += 64) {
-        const uint32_t rel = g - f; bool counts;
-        if (!can0) counts = true;
-        else if (!failed) counts = !(rel & 1u);
-        else counts = (rel < frel) ? !(rel & 1u) : (rel == frel ? kind_a : true);
-        if (counts && !R.eq2[g]) n2same = 0;
+    uint32_t n2same = can0 ? (acc >> 9) & 1u : (acc >> 8) & 1u;
+    if (failed) {                                                            // wave-uniform
+        n2same = 1;
+        for (uint32_t g = f + (uint32_t)l; g < e; g += 64) {
+            const uint32_t rel = g - f;
+            const bool counts = (rel < frel) ? !(rel & 1u) : (rel == frel ? kind_a : true);
+            if (counts && !R.eq2[g]) n2same = 0;
+        }
+        n2same = wave_and(n2same);
     }
-    n2same = wave_and(n2same);
     if (l == 0) {
         const bool il = can0 && !failed;
         uint32_t fl = 0;
@@ -851,46 +781,7 @@ __global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restri
         if (bits & (1u << 7)) fl |= C_NAME1_SAME;
         if (n2same) fl |= C_NAME2_SAME;
         C.flags[c] = fl; C.il[c] = il ? 1u : 0u;
-    }
-}
-
-// PE chunks from the adjacency bits and the pair summaries of k_read_table, one wave per chunk.  A chunk whose interleave test
-// fails somewhere (mates that do not match: the order-dependent name2 rule of src/rfqcodec.cpp:233-250, Q12) is left to
-// k_chunk_flags_a / _b (redo[c] = 1); everywhere else: all reads agree with read 0 <=> every read agrees with its predecessor,
-// and "every R1 name2 equals read 0's" <=> every R1 name2 equals the previous pair's.
-__global__ void k_chunk_flags_pe(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint16_t* __restrict__ adj, const uint32_t* __restrict__ pinfo, uint32_t* __restrict__ redo) {
-    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
-    const bool can0 = D->support_interleaved != 0; const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
-    uint32_t bits = 0xFFu, eq_all = 1, eq_even = 1, failed = 0;
-    for (uint32_t g = f + (uint32_t)l; g < e; g += 64) {
-        const uint32_t rel = g - f;
-        if (rel) { const uint32_t a = adj[g]; bits &= a & 0xFFu; eq_all &= (a >> 8) & 1u; if (rel >= 2 && !(rel & 1u)) eq_even &= (a >> 9) & 1u; }
-        if (can0 && (rel & 1u)) {
-            const uint32_t info = pinfo[g >> 1], nd = (info >> 1) & 3u;
-            bool ok = false;                                                 // (R1's name2 with [dpos] = dch) == R2's name2
-            if (info & 1u) {
-                if (nd == 1) ok = dch != 0 && ((info >> 8) & 0xFFu) == dpos && ((info >> 16) & 0xFFu) == dch;
-                else if (nd == 0) { ok = true; if (dch != 0 && dpos < name2_len_of(T, R, g)) ok = line_ptr(T, g, 0)[R.name2_off[g] + dpos] == (uint8_t)dch; }
-            }
-            if (!ok || (info & 8u)) failed = 1;
-        }
-    }
-    bits = wave_and(bits); eq_all = wave_and(eq_all); eq_even = wave_and(eq_even); failed = wave_or(failed);
-    if (l == 0) {
-        if (can0 && failed) { redo[c] = 1; return; }
-        redo[c] = 0;
-        uint32_t fl = 0;
-        if (can0) fl |= C_PE_INTERLEAVED;
-        if (bits & (1u << 0)) fl |= C_READ_LEN_SAME;
-        if (bits & (1u << 1)) fl |= C_NAME1_LEN_SAME;
-        if (bits & (1u << 2)) fl |= C_NAME2_LEN_SAME;
-        if (bits & (1u << 3)) fl |= C_STRAND_LEN_SAME;
-        if (bits & (1u << 4)) fl |= C_STRAND_SAME;
-        if (bits & (1u << 5)) fl |= C_LANE_SAME;
-        if (bits & (1u << 6)) fl |= C_TILE_SAME;
-        if (bits & (1u << 7)) fl |= C_NAME1_SAME;
-        if (can0 ? eq_even : eq_all) fl |= C_NAME2_SAME;
-        C.flags[c] = fl; C.il[c] = can0 ? 1u : 0u;
+        if (redo) redo[c] = (can0 && failed) ? 1u : 0u;                      // the gather took the mates of every chunk for interleaved
     }
 }
 
@@ -1517,9 +1408,43 @@ __device__ __forceinline__ G2Read g2_read(const Text& T, const uint32_t* __restr
     }
     return m;
 }
+// my share (groups part, part + P, ...) of my read's sequence line: 16 bases per step -> one dword of codes + 16 N bits into the read's loose slot, in STORED
+// orientation (an interleaved chunk's mate reverse-complemented, src/rfqcodec.cpp:371-407) but untrimmed: k_seqpack skips what the overlap with R1 implies
+__device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag) {
+    const uint32_t ng = (m.len + 15u) >> 4;
+    for (uint32_t gi = part; gi < ng; gi += P) {
+        uint32_t w[4], code = 0, nbits = 0;
+        const uint32_t nv0 = m.len - 16u * gi;                             // valid bases of this step
+        // (the bytes of a last, partial step that lie outside the line would fail the all-ACGT test in some lane of nearly every wave - and a wave
+        // runs the exact path if any of its lanes does: they are made 'A' first; their codes are masked off below)
+        auto blank = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) { uint32_t& x = w[k >> 2]; const uint32_t sh = 8u * (k & 3u); x = (x & ~(0xFFu << sh)) | (0x41u << sh); } };
+        if (!m.rc) {
+            lds_get16(s_text, m.ssrc + 16u * gi, w);
+            if (nv0 < 16u) blank(nv0, 16u);
+            if (!pack16_fast(w, code)) {                                    // (an N, a lower-case or any other byte among the 16)
+                uint32_t bad = 0; code = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
+                if (bad) rflag[m.gi] = 1;                                    // a byte outside A/C/G/T/N: it equals nothing in RfqCodec::overlap (k_overlap's byte-wise path)
+            }
+        } else {
+            lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);           // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line)
+            if (nv0 < 16u) blank(0u, 16u - nv0);
+            if (pack16_fast(w, code)) code = ~g2_rev2x16(code);             // reverse complement in 2-bit space: the fields back to front, G 0 <-> C 3, A 1 <-> T 2
+            else {
+                const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; code = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { uint32_t c4, n4; pack4_codes_rc(w[i], c4, n4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
+            }
+        }
+        if (nv0 < 16u) { code &= (1u << (2u * nv0)) - 1u; nbits &= (1u << nv0) - 1u; }   // (what lies outside the line is not the read's)
+        lpk[m.ld + gi] = code; lnb[m.ld + gi] = (uint16_t)nbits;
+    }
+}
 // my share (groups part, part + P, ...) of my read's two lines: qualities -> qcat, bases -> the loose slot
-__device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag, QualCount& qc, int abl) {
-    if (m.on && !(abl & 1)) {
+__device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag, QualCount& qc) {
+    if (!m.on) return;
+    {
         // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
         const uint32_t n = m.len; uint8_t* const o = qd + m.qpos; const bool rc = m.rc;
         if (n >= 16u) {
@@ -1528,108 +1453,137 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
                 uint32_t p0 = 16u * gi, dup = 0; if (p0 + 16u > n) { dup = p0 + 16u - n; p0 = n - 16u; }     // the last group ends exactly at n: its first `dup` bytes repeat the group before
                 uint32_t w[4]; lds_get16(s_text, rc ? m.qsrc + n - p0 - 16u : m.qsrc + p0, w);
                 if (rc) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
-                if (!(abl & 4)) { GU16g v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16g*)(o + p0) = v; }
-                if (abl & 8) continue;
+                { GU16g v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16g*)(o + p0) = v; }
                 if (!dup) qc.group(m.qpos + p0, w[0], w[1], w[2], w[3]);
                 else for (uint32_t k = dup; k < 16u; k++) qc(m.qpos + p0 + k, (uint8_t)(w[k >> 2] >> (8u * (k & 3u))));
             }
         } else for (uint32_t i = part; i < n; i += P) { const uint8_t q = s_text[rc ? m.qsrc + n - 1u - i : m.qsrc + i]; o[i] = q; qc(m.qpos + i, q); }
     }
-    if (m.on && !(abl & 2)) {
-        // ---- bases: 16 per step -> one dword of codes + 16 N bits into the read's loose slot, in STORED orientation (an interleaved chunk's mate
-        // reverse-complemented, src/rfqcodec.cpp:371-407) but untrimmed: k_seqpack skips what the overlap with R1 implies
-        const uint32_t ng = (m.len + 15u) >> 4;
-        for (uint32_t gi = part; gi < ng; gi += P) {
-            uint32_t w[4], code = 0, nbits = 0;
-            const uint32_t nv0 = m.len - 16u * gi;                         // valid bases of this step
-            // (the bytes of a last, partial step that lie outside the line would fail the all-ACGT test in some lane of nearly every wave - and a wave
-            // runs the exact path if any of its lanes does: they are made 'A' first; their codes are masked off below)
-            auto blank = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) { uint32_t& x = w[k >> 2]; const uint32_t sh = 8u * (k & 3u); x = (x & ~(0xFFu << sh)) | (0x41u << sh); } };
-            if (!m.rc) {
-                lds_get16(s_text, m.ssrc + 16u * gi, w);
-                if (nv0 < 16u) blank(nv0, 16u);
-                if (!pack16_fast(w, code)) {                                // (an N, a lower-case or any other byte among the 16)
-                    uint32_t bad = 0; code = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
-                    if (bad) rflag[m.gi] = 1;                                // a byte outside A/C/G/T/N: it equals nothing in RfqCodec::overlap (k_overlap's byte-wise path)
-                }
-            } else {
-                lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);       // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line)
-                if (nv0 < 16u) blank(0u, 16u - nv0);
-                if (pack16_fast(w, code)) code = ~g2_rev2x16(code);         // reverse complement in 2-bit space: the fields back to front, G 0 <-> C 3, A 1 <-> T 2
-                else {
-                    const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; code = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { uint32_t c4, n4; pack4_codes_rc(w[i], c4, n4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
-                }
-            }
-            const uint32_t nv = m.len - 16u * gi;                          // valid bases of this step (what lies outside the line is not the read's)
-            if (nv < 16u) { code &= (1u << (2u * nv)) - 1u; nbits &= (1u << nv) - 1u; }
-            lpk[m.ld + gi] = code; lnb[m.ld + gi] = (uint16_t)nbits;
+    g2_bases(s_text, m, part, P, lpk, lnb, rflag);
+}
+// FastqMeta::parse + RfqCodec::encodeChunk's pass 1 (src/fastqmeta.cpp:22-80, src/rfqcodec.cpp:220-263) for the reads of the tile k_gather2 has staged -
+// a lane per read, the tile's first wave: the name line is in LDS already, so the text is not fetched a third time for the names (the separate
+// read-table pass cost 8.1 GB / 1.9 ms on configs[2]).  The parsed fields go to the read table; the comparisons with the chunk's read 0 (staged once per
+// workgroup: G2Ref) and with the mate are accumulated in acc (see CF_ALL) and leave the workgroup as one atomicAnd / atomicMin per chunk.
+#define G2_REFCAP 128u            // bytes of read 0's name / strand line kept in LDS (longer ones are compared from global memory)
+#define G2_REFROW 144u
+struct G2Ref { uint32_t nl, n1l, n2o, len, stl, lane, tile, nb, tb; int s; };   // read 0 of the chunk: lengths, parsed fields, where its name / strand line start in the text
+struct G2Acc { uint32_t bits, fail; };
+// n bytes at LDS offset a of tx against read 0's: its first G2_REFCAP bytes are in LDS (offset ro + off0), the rest in global memory
+__device__ __forceinline__ bool g2_eq_ref(const uint8_t* tx, uint32_t a, uint32_t ro, const uint8_t* g0, uint32_t off0, uint32_t len0, uint32_t n) {
+    if (len0 <= G2_REFCAP) return lds_bytes_eq(tx, a, ro + off0, n);
+    for (uint32_t i = 0; i < n; i++) if (tx[a + i] != g0[off0 + i]) return false;
+    return true;
+}
+__device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const uint8_t* tx, uint32_t refn, uint32_t refs, const G2Geo& g, const G2Ref& r0, uint32_t f, uint32_t cur, uint32_t cnt,
+                                         bool can0, uint32_t dpos, uint32_t dch, G2Acc& acc) {
+    const uint32_t t = threadIdx.x; const bool on = t < cnt; const uint32_t gi = cur + t;
+    uint32_t nsrc = 0, nl = 0, sl = 0, tsrc = 0, tl = 0; Meta m; m.ok = 0; m.name1_len = 0; m.name2_off = 0; m.x = 0; m.y = 0; m.tile = 0; m.lane = 0;
+    if (on) {
+        int s_; uint32_t r_; read_loc(T, gi, s_, r_);
+        const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);
+        const uint32_t lb = s_ ? g.base1 : 0u, a = s_ ? g.a01 : g.a00;
+        nsrc = lb + (lo4.x - a); nl = lo4.y - 1u - lo4.x; sl = lo4.z - 1u - lo4.y; tsrc = lb + (lo4.z - a); tl = lo4.w - 1u - lo4.z;
+        m = dev_parse_name(tx + nsrc, nl);
+        R.name1_len[gi] = m.name1_len; R.name2_off[gi] = m.name2_off; R.x[gi] = m.x; R.y[gi] = m.y; R.tile[gi] = m.tile; R.lane[gi] = m.lane; R.ok[gi] = (uint8_t)m.ok;
+    }
+    // the mate's fields (the lane in front: tiles start at even reads and hold whole pairs)
+    const uint32_t pn = wave_shr1(nsrc, 0u), pnl = wave_shr1(nl, 0u), pn2o = wave_shr1(m.name2_off, 0u), plane = wave_shr1((uint32_t)m.lane, 0u), ptile = wave_shr1((uint32_t)m.tile, 0u),
+                   px = wave_shr1(m.x, 0u), py = wave_shr1(m.y, 0u);
+    if (on) {
+        const uint32_t rel = gi - f, n1l = m.name1_len, n2o = m.name2_off, n2l = nl - n2o, n2l0 = r0.nl - r0.n2o;
+        const uint8_t* g0n = t_fq(T, r0.s) + r0.nb; const uint8_t* g0s = t_fq(T, r0.s) + r0.tb;
+        uint32_t b = 0;
+        if (sl == r0.len) b |= 1u << 0;
+        if (n1l == r0.n1l) b |= 1u << 1;
+        if (n2l == n2l0) b |= 1u << 2;
+        if (tl == r0.stl) b |= 1u << 3;
+        if (tl == r0.stl && g2_eq_ref(tx, tsrc, refs, g0s, 0u, r0.stl, tl)) b |= 1u << 4;
+        if ((uint32_t)m.lane == r0.lane) b |= 1u << 5;
+        if ((uint32_t)m.tile == r0.tile) b |= 1u << 6;
+        if (n1l == r0.n1l && g2_eq_ref(tx, nsrc, refn, g0n, 0u, r0.nl, n1l)) b |= 1u << 7;
+        const bool e2 = n2l == n2l0 && g2_eq_ref(tx, nsrc + n2o, refn, g0n, r0.n2o, r0.nl, n2l);
+        if (e2) b |= 1u << 8;
+        if (e2 || (rel & 1u)) b |= 1u << 9;
+        acc.bits &= b;
+        R.eq2[gi] = e2 ? 1 : 0;
+        if (can0 && (rel & 1u)) {
+            const bool fa = !name2_eq_replaced(tx + pn + pn2o, pnl - pn2o, tx + nsrc + n2o, n2l, dpos, dch);
+            const bool fb = plane != (uint32_t)m.lane || ptile != (uint32_t)m.tile || px != m.x || py != m.y;
+            if (fa || fb) { const uint32_t key = (rel << 1) | (fa ? 0u : 1u); if (key < acc.fail) acc.fail = key; }
         }
     }
 }
-// PIPE: two text buffers of half the size; the next tile's LDS-DMA is issued right behind the barrier that hands over this tile's text and flies
-// under this tile's compose - one barrier per tile.  (Measured on configs[2], single buffer, K = 64: of the kernel's 3.4 ms, 1.8 ms are the bare
-// stage-and-wait loop - 8 GB at 4.4 TB/s with a third of the resident workgroups in their staging phase at any time.)
-template <bool PIPE, uint32_t CAPB = (PIPE ? G2_CAP / 2 : G2_CAP)> __global__ void __launch_bounds__(256) k_gather2(Text T, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const uint64_t* __restrict__ qbase,
+// phase 1: every chunk, mates taken for interleaved wherever the header allows it (the names that decide are parsed in this very pass), names parsed and
+// compared; phase 2: only the chunks k_chunk_flags_b marked in `only` - their interleave test failed somewhere - once more with the mates as they stand.
+__global__ void __launch_bounds__(256) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
-                                                 uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift, DevStatus* st, int abl) {
-    __shared__ uint4 s_text4[(PIPE ? 2 : 1) * (CAPB / 16 + 8)];           // (CAPB: staged text per buffer)
-    __shared__ uint32_t sh[PIPE ? 2 : 1][G2_CNT]; __shared__ int sh_last[PIPE ? 2 : 1][G2_CNT]; __shared__ uint8_t s_slot[256];   // (two counter sets when tiles overlap)
-    constexpr uint32_t HALF4 = CAPB / 16 + 8;                               // uint4 per buffer (each with its own slack)
+                                                 uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
+                                                 uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, DevStatus* st) {
+    constexpr uint32_t TILE4 = G2_CAP / 16 + 8, REFN = (TILE4 - 1) * 16, REFS = REFN + G2_REFROW;     // (byte offsets from the tile's first byte)
+    __shared__ uint4 s_text4[TILE4 + 2 * G2_REFROW / 16];                  // staged text | read 0's name | read 0's strand line
+    __shared__ uint32_t sh[G2_CNT]; __shared__ int sh_last[G2_CNT]; __shared__ uint8_t s_slot[256]; __shared__ uint32_t s_r0[8];
+    const uint32_t c = blockIdx.y;
+    const bool redo = only != nullptr;
+    if (redo && !only[c]) return;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < (PIPE ? 2u : 1u) * G2_CNT; i += blockDim.x) { (&sh[0][0])[i] = 0; (&sh_last[0][0])[i] = -1; }
+    const uint32_t* __restrict__ pq = R.pq;
+    for (uint32_t i = tid; i < G2_CNT; i += blockDim.x) { sh[i] = 0; sh_last[i] = -1; }
     const uint32_t nn_s = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, nslot = nn_s + 1u;
     uint32_t nrep = 1; while (nrep < 16u && 4u * nrep * nslot <= G2_CNT) nrep *= 2u;
     for (uint32_t i = tid; i < 256; i += blockDim.x) { const uint32_t j = D->stream_of[i]; s_slot[i] = (uint8_t)(j < nn_s ? j : nn_s); }
-    const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1];
-    const bool il = ilv[c] != 0, two = T.paired == 1;
+    const uint32_t f = first[c], e = first[c + 1];
+    const bool two = T.paired == 1, can0 = T.paired != 0 && D->support_interleaved != 0, il = can0 && !redo;
+    const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
     uint8_t* const qd = qcat + qbase[c]; const uint32_t pq0 = pq[f];
     uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup
     const uint32_t gs = f + blockIdx.x * per, ge = gs + per < e ? gs + per : e;
     const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;              // K reads per tile, P threads per read
     const uint32_t j = tid >> pshift, part = tid & (P - 1u);
-    QualCount qc; qc.cnt = sh[0]; qc.last = sh_last[0]; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
-    if (!PIPE) {
-        uint4* const buf4 = s_text4 + 1;
+    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
+    uint4* const buf4 = s_text4 + 1; const uint8_t* const tx = (const uint8_t*)buf4;
+    G2Ref r0; G2Acc acc; acc.bits = CF_ALL; acc.fail = 0xFFFFFFFFu;
+    const bool parse = !redo && gs < ge;                                    // block-uniform
+    if (parse) {
+        // read 0 of the chunk: the first bytes of its name and strand lines into LDS, its name parsed by one lane
+        uint32_t r_; read_loc(T, f, r0.s, r_); const uint32_t* p = t_lo(T, r0.s) + 4 * (size_t)r_;
+        const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+        r0.nb = p0; r0.nl = p1 - 1u - p0; r0.len = p2 - 1u - p1; r0.tb = p2; r0.stl = p3 - 1u - p2;
+        uint8_t* const wr = (uint8_t*)buf4;
+        if (tid < 128u) { if (tid < r0.nl) wr[REFN + tid] = t_fq(T, r0.s)[r0.nb + tid]; }
+        else if (tid - 128u < r0.stl) wr[REFS + tid - 128u] = t_fq(T, r0.s)[r0.tb + tid - 128u];
         __syncthreads();
-        for (uint32_t cur = gs; cur < ge; cur += K) {                      // block-uniform
-            const uint32_t cnt = ge - cur < K ? ge - cur : K;
-            const G2Geo g = g2_geo(T, two, cur, cnt);
-            g2_stage(T, two, g, buf4, tid);
-            const G2Read m = g2_read(T, pq, g, f, pq0, il, cur, j, cnt);
-            const uint32_t qbeg = uni32(pq[cur]) - pq0;                      // the tile's first quality position (chunk-relative)
-            __syncthreads();                                                // (drains the LDS-DMA)
-            qc.seg0 = qbeg / PC_SEG_POS;
-            g2_compose((const uint8_t*)buf4, m, part, P, qd, lpk, lnb, rflag, qc, abl);
-            __syncthreads();                                                // the text is free for the next tile; the tile's counts are complete
-            qual_flush(sh[0], sh_last[0], nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
+        if (tid == 0) {
+            const Meta m0 = r0.nl <= G2_REFCAP ? dev_parse_name(tx + REFN, r0.nl) : dev_parse_name(t_fq(T, r0.s) + r0.nb, r0.nl);
+            s_r0[0] = m0.name1_len; s_r0[1] = m0.name2_off; s_r0[2] = m0.lane; s_r0[3] = m0.tile;
         }
-    } else if (gs < ge) {
-        uint32_t cnt = ge - gs < K ? ge - gs : K;
-        G2Geo g = g2_geo(T, two, gs, cnt);
-        g2_stage(T, two, g, s_text4 + 1, tid);
-        G2Read m = g2_read(T, pq, g, f, pq0, il, gs, j, cnt);
-        uint32_t qbeg = uni32(pq[gs]) - pq0, seg_prev = 0;
-        uint32_t pb = 0;
-        for (uint32_t cur = gs; cur < ge; cur += K, pb ^= 1u) {            // block-uniform
-            __syncthreads();                                                // this tile's text has landed; every wave is done with the tile before (its text buffer, its counters)
-            if (cur > gs) qual_flush(sh[PIPE ? pb ^ 1u : 0u], sh_last[PIPE ? pb ^ 1u : 0u], nrep, nslot, seg_prev, c, nn_s, segm, segc, n_seg);   // (that set is next counted into two barriers from here)
-            const uint32_t nxt = cur + K; G2Geo gn = g; G2Read mn = m; uint32_t qn = 0, cn = 0;
-            if (nxt < ge) {                                                 // the next tile's text and my read of it: in flight under this tile's compose
-                cn = ge - nxt < K ? ge - nxt : K; gn = g2_geo(T, two, nxt, cn);
-                g2_stage(T, two, gn, s_text4 + 1 + (pb ^ 1u) * HALF4, tid);
-                mn = g2_read(T, pq, gn, f, pq0, il, nxt, j, cn); qn = uni32(pq[nxt]) - pq0;
-            }
-            qc.cnt = sh[PIPE ? pb : 0u]; qc.last = sh_last[PIPE ? pb : 0u]; qc.seg0 = qbeg / PC_SEG_POS; seg_prev = qc.seg0;
-            g2_compose((const uint8_t*)(s_text4 + 1 + pb * HALF4), m, part, P, qd, lpk, lnb, rflag, qc, abl);
-            g = gn; m = mn; qbeg = qn; cnt = cn;
-        }
-        __syncthreads();
-        qual_flush(sh[PIPE ? pb ^ 1u : 0u], sh_last[PIPE ? pb ^ 1u : 0u], nrep, nslot, seg_prev, c, nn_s, segm, segc, n_seg);
     }
+    __syncthreads();
+    if (parse) { r0.n1l = s_r0[0]; r0.n2o = s_r0[1]; r0.lane = s_r0[2]; r0.tile = s_r0[3]; }
+    for (uint32_t cur = gs; cur < ge; cur += K) {                          // block-uniform
+        const uint32_t cnt = ge - cur < K ? ge - cur : K;
+        const G2Geo g = g2_geo(T, two, cur, cnt);
+        g2_stage(T, two, g, buf4, tid);
+        const G2Read m = g2_read(T, pq, g, f, pq0, il, cur, j, cnt);
+        const uint32_t qbeg = uni32(pq[cur]) - pq0;                          // the tile's first quality position (chunk-relative)
+        __syncthreads();                                                    // (drains the LDS-DMA)
+        qc.seg0 = qbeg / PC_SEG_POS;
+        if (parse && tid < 64u) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (wave-uniform: the tile's first wave, a lane per read)
+        g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
+        __syncthreads();                                                    // the text is free for the next tile; the tile's counts are complete
+        qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
+    }
+    if (parse && tid < 64u) {
+        const uint32_t bits = wave_and(acc.bits), fail = wave_min(acc.fail);
+        if (tid == 0) { if (bits != CF_ALL) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
+    }
+    (void)st;
+}
+// phase 2 of the gather re-counts the qualities of the chunks it repeats: their per-(stream, segment) entries back to "nothing seen"
+__global__ void k_gather_redo_reset(const uint32_t* __restrict__ only, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
+    const uint32_t c = blockIdx.x; if (!only[c]) return;
+    const size_t k = (size_t)c * MAX_STREAMS * n_seg;
+    for (uint32_t i = threadIdx.x; i < MAX_STREAMS * n_seg; i += blockDim.x) { segm[k + i] = 0u; segc[k + i] = -1; }
 }
 // 16 consecutive codes / N bits of a loose slot from base index b on (b + 16 may pass the slot's end: the caller masks)
 __device__ __forceinline__ uint32_t loose_codes(const uint32_t* __restrict__ lpk, uint32_t ld, uint32_t b) {
@@ -1658,7 +1612,7 @@ __device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb
 __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
                                                  const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
                                                  uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
-                                                 uint32_t rshift, int abl) {
+                                                 uint32_t rshift) {
     __shared__ uint32_t s_sd[256 + SP_EXTRA + 1], s_ld[256 + SP_EXTRA], s_sk[256 + SP_EXTRA]; __shared__ uint8_t s_own[SP_OWN];
     const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1], tid = threadIdx.x;
     const uint32_t ps0 = pv[f].d, S = pv[e].d - ps0;
@@ -1689,8 +1643,8 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
             const uint32_t B = 16u * k, sdg = s_sd[j], si = B - sdg, need = S - B < 16u ? S - B : 16u, av = s_sd[j + 1] - B, t1 = need < av ? need : av;
             const uint32_t ld = s_ld[j], b0 = s_sk[j] + si;
             unsigned long long acc = 0; uint32_t nacc = 0;
-            if (!(abl & 1)) acc = loose_codes(lpk, ld, b0) & (t1 >= 16u ? 0xFFFFFFFFu : (1u << (2u * t1)) - 1u);
-            if (!(abl & 2)) nacc = loose_nbits(lnb, ld, b0) & ((1u << t1) - 1u);
+            acc = loose_codes(lpk, ld, b0) & (t1 >= 16u ? 0xFFFFFFFFu : (1u << (2u * t1)) - 1u);
+            nacc = loose_nbits(lnb, ld, b0) & ((1u << t1) - 1u);
             uint32_t filled = t1, jj = j + 1;
             while (filled < need) {                                         // the read's last dword: the rest comes from the read(s) behind it
                 uint32_t a, b, l2, s2;
@@ -1704,7 +1658,7 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
                 }
                 jj++;
             }
-            if (!(abl & 4)) ok[k] = (uint32_t)acc; if (!(abl & 8)) on[k] = (uint16_t)nacc;
+            ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc;
             if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
         }
         __syncthreads();                                                    // (the LDS tables are rewritten by the next step)
@@ -2041,160 +1995,6 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
         pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st, s_exc);
     }
     else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), R.pv[e].d - R.pv[f].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
-}
-
-// =============================================================== position coder for MANY value streams, list form (RFQ_CODER=ms; measured, not the default)
-// k_pos_coder tests every position against every value: ~650 instructions per ACTIVE stream and 4096-position step - three streams on a NovaSeq-binned
-// file, forty on an old-Illumina / BGI one (the configs[4] shape), where it is most of the encode.  Here one wave codes ALL value streams of a (chunk,
-// segment): per step every quality byte is looked up ONCE in the header's value -> stream table, the coded positions are bucketed by stream in LDS
-// (a count pass, one prefix over the lanes per stream, a scatter pass: the list holds each stream's positions in ascending order), and the tokens are
-// made from the LIST, 64 entries per round whatever streams they belong to - the closed form of k_pos_coder's header comment read per entry:
-//   entry p is a streak START when the previous match of its stream is not p - 1:  gap token, d = p - previous match (1 / 2 / 4 bytes);
-//   p == 1 in a streak that starts at 0:  token 0x00 (the `cur > 1` rule);
-//   p == a + b + 32 k (a = start of its streak, b = 2 if a == 0 else 1):  run token 0xC0 | (min(32, matches from p on) - 1);  nothing otherwise.
-// A stream's previous match and the start of its open streak carry over in LDS from step to step; a segment takes them from segc (k_gather*) and, when
-// it begins inside a streak, from a walk back over the bytes.  Slots, capacities and byte counts are k_pos_coder's (pc_seg_cap, segb): k_assemble is unchanged.
-// STATUS: bit-exact (the interpreter's whole encode suite and the fuzzes with it forced on; the configs[2] / configs[4] goldens on the GPU) and SLOWER than
-// k_pos_coder - 4.4 against 3.2 ms at forty streams, 15.6 against 5.5 ms at three: a round of 64 list entries costs ~400 instructions.
-#define MS_LIST 4096u
-struct MsLds {
-    uint16_t list[MS_LIST];                  // positions inside the step, stream after stream
-    uint8_t sid[MS_LIST];                    // the stream of every list entry
-    uint16_t base[NPOS_SLOT][64];            // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part
-    uint16_t off[NPOS_SLOT + 2];             // where a stream's part of the list starts
-    int prev[NPOS_SLOT], sa[NPOS_SLOT];      // last match so far (-1: none), start of the streak it belongs to
-    uint32_t outpos[NPOS_SLOT], room[NPOS_SLOT]; unsigned long long out[NPOS_SLOT];
-    uint8_t tab[256], q[NPOS_SLOT], on[NPOS_SLOT], after[NPOS_SLOT];
-};
-__global__ void __launch_bounds__(64) k_pos_coder_ms(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
-                                                     uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks, DevStatus* st, int abl) {
-    __shared__ MsLds S;
-    const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3;       // (a chunk's workgroups on one XCD, as in k_pos_coder)
-    const uint32_t c = (idx / n_seg) * 8u + xcd, seg = idx % n_seg;
-    if (c >= n_chunks) return;
-    const int l = lane_id();
-    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];
-    const uint8_t* __restrict__ B = qcat + C.qbase[c]; const uint32_t len = R.pq[e] - R.pq[f];
-    const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS, step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
-    if (step0 >= nsteps) return;
-    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = D->stream_of[v]; S.tab[v] = (uint8_t)(j < nn ? j : 0xFFu); }
-    {   // a lane per stream: is it there, where it stands, where its bytes go (pc_run's entry state)
-        const uint32_t j = (uint32_t)l; bool on = false;
-        if (j < nn) {
-            const size_t k = (size_t)c * MAX_STREAMS + j, s0i = k * n_seg; const uint32_t cap = C.scap[k], qv = D->normal[j];
-            on = cap != 0 && segm[s0i + seg] != 0;
-            int prev = -1; for (int s_ = (int)seg - 1; s_ >= 0 && prev < 0; s_--) prev = segc[s0i + (uint32_t)s_];
-            uint32_t off = 0; for (uint32_t s_ = 0; s_ < seg; s_++) off += pc_seg_cap(false, segm[s0i + s_], PC_SEG_POS);
-            const uint32_t own = pc_seg_cap(false, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
-            int sa = -1;
-            if (on && prev >= 0 && (uint32_t)prev + 1u == step0 * 4096u) { int p = prev; while (p > 0 && B[p - 1] == (uint8_t)qv) p--; sa = p; }   // the segment begins inside a streak
-            S.q[j] = (uint8_t)qv; S.prev[j] = prev; S.sa[j] = sa; S.outpos[j] = 0; S.room[j] = off + own <= cap ? own : 0u;
-            S.out[j] = (unsigned long long)(uintptr_t)(scratch + cbase[c] + C.soff[k] + off);
-        }
-        S.on[l] = on ? 1 : 0;
-        if (!__any(on)) return;
-    }
-    wave_lds_sync();
-    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = S.tab[v]; if (j != 0xFFu && !S.on[j]) S.tab[v] = 0xFFu; }   // (values whose stream has nothing in this segment: not looked at again)
-    wave_lds_sync();
-    const uint32_t inc = (l & 1) ? 0x10000u : 1u;
-    for (uint32_t step = step0; step < step1; step++) {
-        const uint32_t sb = step * 4096u, p0 = sb + 64u * (uint32_t)l;
-        const uint32_t nv = p0 >= len ? 0u : (len - p0 < 64u ? len - p0 : 64u);
-        const Raw64 r = pc_load_raw(B, len, p0);
-        const uint32_t w[16] = { r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w, r.v[1].x, r.v[1].y, r.v[1].z, r.v[1].w, r.v[2].x, r.v[2].y, r.v[2].z, r.v[2].w, r.v[3].x, r.v[3].y, r.v[3].z, r.v[3].w };
-        // ---- the stream of each of my 64 positions: 64 independent table reads, kept packed in registers (0xFF: none)
-        uint32_t sw[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t x = w[i];
-            const uint32_t s0_ = S.tab[x & 0xFFu], s1_ = S.tab[(x >> 8) & 0xFFu], s2_ = S.tab[(x >> 16) & 0xFFu], s3_ = S.tab[x >> 24];
-            uint32_t v = s0_ | (s1_ << 8) | (s2_ << 16) | (s3_ << 24);
-            const int left = (int)nv - 4 * i;                                // positions behind the chunk's end: none
-            if (left < 4) v |= left <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * left));
-            sw[i] = v;
-        }
-        // ---- count: my positions per stream (fire-and-forget 32-bit atomics on the u16 pairs of neighbouring lanes)
-        for (uint32_t j = 0; j < nn; j++) S.base[j][l] = 0;
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < 64; k++) { const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu; if (j != 0xFFu) atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); }
-        wave_lds_sync();
-        // ---- a prefix over the lanes per stream: where my entries of the stream go
-        uint32_t tot = 0;
-        for (uint32_t j = 0; j < nn; j++) {                                // (wave-uniform)
-            if (l == 0) S.off[j] = (uint16_t)tot;
-            if (!uni32(S.on[j])) continue;
-            const uint32_t cnt = S.base[j][l], incl = wave_incl_sum<uint32_t>(cnt);
-            S.base[j][l] = (uint16_t)(incl - cnt);
-            tot += wave_last(incl);
-        }
-        if (l == 0) { S.off[nn] = (uint16_t)tot; S.off[nn + 1] = (uint16_t)tot; }
-        const uint32_t E = tot;
-        wave_lds_sync();
-        // ---- scatter the positions into the list (returning atomics, independent of one another)
-#pragma unroll
-        for (int k = 0; k < 64; k++) {
-            const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            if (j != 0xFFu) { const uint32_t old_ = atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); const uint32_t at = S.off[j] + ((l & 1) ? old_ >> 16 : old_ & 0xFFFFu);
-                              S.list[at] = (uint16_t)(64u * (uint32_t)l + (uint32_t)k); S.sid[at] = (uint8_t)j; }
-        }
-        // ---- matches that open the next step (a run token looks up to 31 positions ahead)
-        if ((uint32_t)l < nn && S.on[l]) { const uint32_t nb_ = sb + 4096u; uint32_t k = 0; const uint8_t qv = S.q[l]; while (k < 31u && nb_ + k < len && B[nb_ + k] == qv) k++; S.after[l] = (uint8_t)k; }
-        wave_lds_sync();
-        // ---- tokens, 64 list entries per round
-        for (uint32_t r0 = 0; r0 < ((abl & 1) ? 0u : E); r0 += 64u) {          // (wave-uniform; abl: profiling switches, results invalid)
-            const uint32_t i = r0 + (uint32_t)l; const bool valid = i < E;
-            const uint32_t j = S.sid[valid ? i : 0u];                          // the stream whose part holds entry i
-            const uint32_t pos = valid ? S.list[i] : 0u; const int p = (int)(sb + pos);
-            const uint32_t jbeg = S.off[j], jend = S.off[j + 1];
-            const int prevp = (i == jbeg) ? S.prev[j] : (int)(sb + S.list[valid ? i - 1u : 0u]);
-            const bool start = !(prevp >= 0 && prevp == p - 1);
-            const uint32_t key = valid ? ((j << 13) | (start ? pos + 1u : 0u)) : 0u, mx = wave_incl_max<uint32_t>(key);
-            const int a = ((mx >> 13) == j && (mx & 0x1FFFu)) ? (int)(sb + (mx & 0x1FFFu) - 1u) : S.sa[j];     // start of my streak
-            uint32_t nb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            if (valid) {
-                if (start) {
-                    const uint32_t d = (uint32_t)(p - prevp), v = d - 1u;
-                    if (d <= 128u) { nb = 1; t0 = v; } else if (d <= 16384u) { nb = 2; t0 = (v >> 8) | 0x80u; t1 = v & 0xFFu; } else { nb = 4; t0 = (v >> 24) | 0xE0u; t1 = (v >> 16) & 0xFFu; t2 = (v >> 8) & 0xFFu; t3 = v & 0xFFu; }
-                } else if (a == 0 && p == 1) { nb = 1; t0 = 0; }
-                else {
-                    const int t = p - a - (a == 0 ? 2 : 1);
-                    if (t >= 0 && (t & 31) == 0) {
-                        uint32_t L = 1;                                      // matches from p on: entries i, i + 1, ... at consecutive positions
-#pragma unroll
-                        for (uint32_t stp = 16; stp >= 1; stp >>= 1) { const uint32_t k = L - 1u + stp; if (i + k < jend && S.list[i + k] == pos + k) L += stp; }
-                        if (L < 32u && i + L == jend && pos + L == 4096u) L += S.after[j];
-                        if (L > 32u) L = 32u;
-                        nb = 1; t0 = 0xC0u | (L - 1u);
-                    }
-                }
-            }
-            // byte offsets: a sum over the round, cut at the stream boundaries
-            const uint32_t incl = wave_incl_sum<uint32_t>(nb);
-            const uint32_t jprev = (uint32_t)__shfl_up((int)j, 1u);
-            const unsigned long long bm = __ballot(valid && (l == 0 || j != jprev));
-            const unsigned long long upto = l == 63 ? ~0ull : ((2ull << l) - 1ull);
-            const int segl = 63 - __clzll((long long)((bm & upto) | 1ull));
-            const uint32_t excl = incl - nb - (uint32_t)__shfl((int)(incl - nb), segl);
-            const uint32_t o = S.outpos[j] + excl;
-            if (valid && nb && o + nb <= S.room[j] && !(abl & 2)) {
-                uint8_t* op = (uint8_t*)(uintptr_t)S.out[j] + o;
-                op[0] = (uint8_t)t0; if (nb >= 2u) op[1] = (uint8_t)t1; if (nb == 4u) { op[2] = (uint8_t)t2; op[3] = (uint8_t)t3; }
-            }
-            const uint32_t jnext = (uint32_t)__shfl_down((int)j, 1u);
-            const bool lastl = valid && (l == 63 || i + 1u >= E || jnext != j);
-            wave_lds_sync();                                                // (every lane has read its stream's state)
-            if (lastl) { S.outpos[j] = o + nb; S.sa[j] = a; }
-            wave_lds_sync();
-        }
-        if ((uint32_t)l < nn && S.on[l] && S.off[l + 1] > S.off[l]) S.prev[l] = (int)(sb + S.list[S.off[l + 1] - 1u]);
-        wave_lds_sync();
-    }
-    if ((uint32_t)l < nn && S.on[l]) {
-        segb[((size_t)c * MAX_STREAMS + (uint32_t)l) * n_seg + seg] = S.outpos[l];
-        if (S.outpos[l] > S.room[l]) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
-    }
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)

@@ -12,6 +12,9 @@ EMU_LIB = os.path.join(EMU_DIR, "librfq_emu.so")
 PRODUCT_LIB = os.path.join(ROOT, "repaq_amd", "lib", "librfq_hip.so")
 
 
+OPTION_NAMES = ("RFQ_GATHER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE")
+
+
 def build_emu():
     # (pytest-xdist workers call this at the same time: one make at a time, the others find everything up to date)
     import fcntl

@@ -14,6 +14,14 @@ def codec():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _options_back_to_default(codec):
+    """rfq_set_option switches a test sets on the shared codec do not outlive it"""
+    yield
+    for name in E.OPTION_NAMES:
+        codec.set_option(name, None)
+
+
 def _oracle_rfq(case):
     try:
         return O.encode_file(case["fq1"], case.get("fq2", b""), case["paired"], case.get("k", 1000) * 1000)
@@ -52,9 +60,9 @@ def test_multichunk_round_trip(codec, label, prof, reads, seed, cb, paired, kw):
 
 
 @pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI, ids=[m[0] for m in MULTI])
-def test_multichunk_round_trip_tile_fitting_emitter(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+def test_multichunk_round_trip_tile_fitting_emitter(codec, label, prof, reads, seed, cb, paired, kw):
     """RFQ_EMIT=2: k_dec_emit2 (tiles fitted read by read; the emitter of files whose name pieces are stored per read)."""
-    monkeypatch.setenv("RFQ_EMIT", "2")
+    codec.set_option("RFQ_EMIT", "2")
     fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
     rfq = O.encode_file(fq1, fq2, paired, cb)
     d = codec.decode_bytes(rfq, split_pe=(paired != O.SE))
@@ -177,17 +185,17 @@ def test_bug_compat_decode_loses_what_the_reference_loses(codec, label, prof, re
         assert codec.decode_bytes(rfq, split_pe=False, bug_compat=True) == O.decode_file(rfq, split_pe=False, bug_compat=True)
 
 
-def test_chunk_starts_without_an_index(codec, monkeypatch):
+def test_chunk_starts_without_an_index(codec):
     """A .rfq has no chunk index: the decoder guesses segment starts, walks the segments in parallel and verifies every extent (k_dec_gw_*);
     RFQ_WALK=chain is the one-wave chain it falls back to.  Small segments (RFQ_GW_SHIFT) so that a small image has several."""
     fq1, fq2 = O.gen(O.NOVA_PE150, 3000, seed=51)
     rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 9000)
     assert len(O.chunk_table(rfq)) - 1 > 80
-    monkeypatch.setenv("RFQ_GW_SHIFT", "12")
+    codec.set_option("RFQ_GW_SHIFT", "12")
     assert codec.decode_bytes(rfq, split_pe=True) == (fq1, fq2)
-    monkeypatch.setenv("RFQ_WALK", "chain")
+    codec.set_option("RFQ_WALK", "chain")
     assert codec.decode_bytes(rfq, split_pe=True) == (fq1, fq2)
-    monkeypatch.delenv("RFQ_WALK")
+    codec.set_option("RFQ_WALK", None)
     # chunks of very different sizes (a guessed start that is not one, segments without any start): whatever happens, the text is right
     big, _ = O.gen(O.SE_VAR, 4000, seed=52)
     for cb in (3000, 150000):
@@ -233,7 +241,7 @@ def test_decode_in_slices_equals_one_shot(codec, step):
 
 @pytest.mark.parametrize("prof,reads,kw", [(O.NOVA_SE150, 7500, {}), (O.BGI_PE100, 6000, dict(n_quals=40)), (O.NOVA_SE150, 7500, dict(nppm=5000))],
                          ids=["se150", "bgi_q40", "se150_manyN"])
-def test_full_size_chunk_position_streams_span_many_segments(codec, monkeypatch, prof, reads, kw):
+def test_full_size_chunk_position_streams_span_many_segments(codec, prof, reads, kw):
     """-k 1000 chunks: position streams of 10-100 KB are decoded in 1 KB / 2 KB segments by independent waves, which enter them in any of the token
     automaton's states - by the list passes (k_dec_pos_sum2 / link2 / list) and, RFQ_TUNE=2048, by the materialising path a streaming caller's
     non-final slices take (k_dec_pos_sum / link / emit)."""
@@ -241,7 +249,7 @@ def test_full_size_chunk_position_streams_span_many_segments(codec, monkeypatch,
     rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES if fq2 else O.SE, 1_000_000)
     assert codec.decode_bytes(rfq, split_pe=bool(fq2)) == ((fq1, fq2) if fq2 else fq1)
     assert "emit" in dict(codec.timings()) or "emit2" in dict(codec.timings())
-    monkeypatch.setenv("RFQ_TUNE", "2048")
+    codec.set_option("RFQ_MATERIALISE", "1")
     assert codec.decode_bytes(rfq, split_pe=bool(fq2)) == ((fq1, fq2) if fq2 else fq1)
     assert "textlen" in dict(codec.timings()), dict(codec.timings())           # (a stage of its own only on that path)
 

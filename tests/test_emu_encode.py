@@ -23,6 +23,14 @@ def codec():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _options_back_to_default(codec):
+    """rfq_set_option switches a test sets on the shared codec do not outlive it"""
+    yield
+    for name in E.OPTION_NAMES:
+        codec.set_option(name, None)
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_case_matches_reference_golden(codec, name):
     E.check_case(codec, name, CASES[name], CASES_J[name])
@@ -48,27 +56,27 @@ def test_multichunk_matches_oracle(codec, label, prof, reads, seed, cb, paired, 
 
 
 @pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:6], ids=[m[0] for m in MULTI[:6]])
-def test_multichunk_bytewise_gather_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+def test_multichunk_bytewise_gather_matches_oracle(codec, label, prof, reads, seed, cb, paired, kw):
     """RFQ_GATHER=old: the byte-wise k_gather + k_packbytes (the path of reads too long for a tile and of mates with odd bases)."""
-    monkeypatch.setenv("RFQ_GATHER", "old")
+    codec.set_option("RFQ_GATHER", "old")
     fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
     assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
     assert "gather_bytes" in dict(codec.timings())
 
 
 @pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[3:8], ids=[m[0] for m in MULTI[3:8]])
-def test_multichunk_two_pass_index_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+def test_multichunk_two_pass_index_matches_oracle(codec, label, prof, reads, seed, cb, paired, kw):
     """RFQ_INDEX=2pass: newline bitmap -> scan -> line offsets (what the one-pass k_line_index falls back to when the text holds more lines than its table)."""
-    monkeypatch.setenv("RFQ_INDEX", "2pass")
+    codec.set_option("RFQ_INDEX", "2pass")
     fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
     assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
     assert "index_2pass" in dict(codec.timings())
 
 
 @pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:4], ids=[m[0] for m in MULTI[:4]])
-def test_multichunk_index_over_several_workgroups_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
+def test_multichunk_index_over_several_workgroups_matches_oracle(codec, label, prof, reads, seed, cb, paired, kw):
     """RFQ_IDX_TILES=4: 64 KiB of text per workgroup of k_line_index, so that these small inputs span several and the look-back runs."""
-    monkeypatch.setenv("RFQ_IDX_TILES", "4")
+    codec.set_option("RFQ_IDX_TILES", "4")
     fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
     assert len(fq1) > 3 * 65536 or paired != O.SE
     assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
@@ -90,13 +98,13 @@ def test_line_index_falls_back_when_lines_are_short():
 
 
 @pytest.mark.parametrize("gather", ["tile", "bytes"])
-def test_strand_lines_of_equal_length_and_different_bytes(codec, monkeypatch, gather):
+def test_strand_lines_of_equal_length_and_different_bytes(codec, gather):
     """Strand lines that differ in a byte but not in length - anywhere in the chunk, first or last read of a gather tile, one character or behind the
     sixteenth - clear STRAND_SAME exactly like the reference's pass 1 (src/rfqcodec.cpp:220-250); k_read_table compares every read's with its
     predecessor's.  (Leaving the bytes to k_gather2, which has the line staged anyway, was built and measured: 2.9 GB less traffic in k_read_table but
     only 0.08 ms, against 0.2 ms more in the VALU-bound k_gather2 - not kept.)"""
     if gather == "bytes":
-        monkeypatch.setenv("RFQ_GATHER", "old")
+        codec.set_option("RFQ_GATHER", "old")
     fq1, fq2 = O.gen(O.NOVA_PE150, 400, seed=77)
     def with_strands(fq, edits):
         lines = fq.split(b"\n")
@@ -113,14 +121,6 @@ def test_strand_lines_of_equal_length_and_different_bytes(codec, monkeypatch, ga
             assert E.encode(codec, a, b, O.PE_TWO_FILES, cb) == O.encode_file(a, b, O.PE_TWO_FILES, cb), (sorted(e1)[:3], sorted(e2)[:3], cb)
         assert E.encode(codec, a, b"", O.SE, 30000) == O.encode_file(a, b"", O.SE, 30000)
     assert ("gather_bytes" if gather == "bytes" else "gather") in dict(codec.timings())
-
-
-@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:7], ids=[m[0] for m in MULTI[:7]])
-def test_multichunk_list_coder_matches_oracle(codec, monkeypatch, label, prof, reads, seed, cb, paired, kw):
-    """RFQ_CODER=ms: k_pos_coder_ms, the value streams coded from a per-step list of the coded positions (bit-exact; not the default: it is slower so far)."""
-    monkeypatch.setenv("RFQ_CODER", "ms")
-    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
-    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
 
 
 def test_gather_paths_are_the_ones_expected(codec):
