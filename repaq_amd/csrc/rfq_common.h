@@ -140,6 +140,9 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // lane l <- lane l-1 (lane 0 <- fill); the value of lane 63 in every lane
 template <class T> __device__ __forceinline__ T wave_shr1(T v, T fill) { const T t = __shfl_up(v, 1u); return lane_id() ? t : fill; }
 template <class T> __device__ __forceinline__ T wave_last(T v) { return __shfl(v, 63); }
+// lane K of my quad (four consecutive lanes); the lane four in front of mine (callers only use it where that lane lies in the same row of 16)
+template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__shfl((int)v, (lane_id() & ~3) | K); }
+__device__ __forceinline__ uint32_t lane_shr4(uint32_t v) { return (uint32_t)__shfl_up((int)v, 4u); }
 #else
 // v of the lane the DPP control names; lanes it names none for (or that row_mask leaves out) get `old`
 template <int CTRL, int ROWS, class T> __device__ __forceinline__ T dpp_take(T old, T v) {
@@ -161,9 +164,12 @@ template <class T> __device__ __forceinline__ T wave_read63(T v) {
            return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo); }
 }
 // inclusive scan with an associative op whose identity is `id` (for an idempotent op - min, max, and, or - pass the value itself: op(v, v) = v)
+// (the DPP move is taken into a temporary first: an OP that names its operand twice would otherwise repeat the move - and the compiler may put the
+// second copy inside a divergent select, where the lanes it reads from are switched off)
+#define RFQ_DPP_STEP(v, OP, ID, CTRL, ROWS) { const auto t_ = dpp_take<CTRL, ROWS>(ID, v); v = OP(v, t_); }
 #define RFQ_DPP_SCAN(v, OP, ID)                                                                          \
-    { v = OP(v, (dpp_take<0x111, 0xF>(ID, v))); v = OP(v, (dpp_take<0x112, 0xF>(ID, v))); v = OP(v, (dpp_take<0x114, 0xF>(ID, v))); v = OP(v, (dpp_take<0x118, 0xF>(ID, v))); \
-      v = OP(v, (dpp_take<0x142, 0xA>(ID, v))); v = OP(v, (dpp_take<0x143, 0xC>(ID, v))); }
+    { RFQ_DPP_STEP(v, OP, ID, 0x111, 0xF) RFQ_DPP_STEP(v, OP, ID, 0x112, 0xF) RFQ_DPP_STEP(v, OP, ID, 0x114, 0xF) RFQ_DPP_STEP(v, OP, ID, 0x118, 0xF) \
+      RFQ_DPP_STEP(v, OP, ID, 0x142, 0xA) RFQ_DPP_STEP(v, OP, ID, 0x143, 0xC) }
 #define RFQ_OP_ADD(a, b) ((a) + (b))
 #define RFQ_OP_MAX(a, b) ((b) > (a) ? (b) : (a))
 #define RFQ_OP_MIN(a, b) ((b) < (a) ? (b) : (a))
@@ -179,6 +185,8 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) { RFQ_DPP_SCAN(v, RFQ_OP
 // lane l <- lane l-1 (lane 0 <- fill): wave_shr:1; the value of lane 63 in every lane (an SGPR)
 template <class T> __device__ __forceinline__ T wave_shr1(T v, T fill) { return dpp_take<0x138, 0xF>(fill, v); }
 template <class T> __device__ __forceinline__ T wave_last(T v) { return wave_read63(v); }
+template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true); }   // quad_perm:[K,K,K,K]
+__device__ __forceinline__ uint32_t lane_shr4(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); }             // row_shr:4
 #endif
 __device__ __forceinline__ U4 wave_incl_sum(U4 v) {
     v.a = wave_incl_sum(v.a); v.b = wave_incl_sum(v.b); v.c = wave_incl_sum(v.c); v.d = wave_incl_sum(v.d);

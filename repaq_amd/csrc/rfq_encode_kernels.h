@@ -1461,67 +1461,172 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
     }
     g2_bases(s_text, m, part, P, lpk, lnb, rflag);
 }
-// FastqMeta::parse + RfqCodec::encodeChunk's pass 1 (src/fastqmeta.cpp:22-80, src/rfqcodec.cpp:220-263) for the reads of the tile k_gather2 has staged -
-// a lane per read, the tile's first wave: the name line is in LDS already, so the text is not fetched a third time for the names (the separate
-// read-table pass cost 8.1 GB / 1.9 ms on configs[2]).  The parsed fields go to the read table; the comparisons with the chunk's read 0 (staged once per
-// workgroup: G2Ref) and with the mate are accumulated in acc (see CF_ALL) and leave the workgroup as one atomicAnd / atomicMin per chunk.
-#define G2_REFCAP 128u            // bytes of read 0's name / strand line kept in LDS (longer ones are compared from global memory)
-#define G2_REFROW 144u
+// FastqMeta::parse + RfqCodec::encodeChunk's pass 1 (src/fastqmeta.cpp:22-80, src/rfqcodec.cpp:220-263) for the reads of the tile k_gather2 has staged:
+// the name line is in LDS already, so the text is not fetched a third time for the names (the separate read-table pass cost 8.1 GB / 1.9 ms
+// on configs[2]).  FOUR LANES PER READ (a quad; thread t parses read t >> 2 of the tile, whatever the compose mapping is), nothing serial:
+//   * each lane turns 16 bytes of the name's first 64 into a colon mask and a space mask; quad broadcasts (DPP quad_perm) give every lane the 64-bit masks;
+//   * the parse is a function of those masks: it stops at the first space or the seventh colon, whichever comes first; the fields are the digits between
+//     colons 3|4, 4|5, 5|6, 6|7 (a space that ends the name part early takes over the field it closes - the reference's loop, restated below);
+//   * lane k of the quad converts field k (lane, tile, x, y) - up to eight digits from one 8-byte LDS read - and stores it;
+//   * the comparisons with the chunk's read 0 (staged once per workgroup: G2Ref) are made 16 bytes per lane and OR-ed over the quad; an odd read meets
+//     its mate's fields through a row shift by four lanes.  The verdicts are accumulated per lane (G2Acc, see CF_ALL) and leave the workgroup as
+//     atomicAnd / atomicMin per wave.
+// A name whose first 64 bytes hold neither a space nor seven colons, a field with a sign / white space / more than eight characters: the byte-wise
+// dev_parse_name / dev_atoi decide (first lane of the quad).  (A lane per read walking its name byte by byte - the first version - ran the kernel at
+// 7.1 instead of 3.5 ms on configs[2]: one wave of the workgroup in a chain of dependent LDS reads, three waiting at the barrier.)
+#define G2_REFN 256u              // bytes of read 0's name kept in LDS (a longer one is compared from global memory)
+#define G2_REFS 128u              // ... of its strand line
 struct G2Ref { uint32_t nl, n1l, n2o, len, stl, lane, tile, nb, tb; int s; };   // read 0 of the chunk: lengths, parsed fields, where its name / strand line start in the text
 struct G2Acc { uint32_t bits, fail; };
-// n bytes at LDS offset a of tx against read 0's: its first G2_REFCAP bytes are in LDS (offset ro + off0), the rest in global memory
-__device__ __forceinline__ bool g2_eq_ref(const uint8_t* tx, uint32_t a, uint32_t ro, const uint8_t* g0, uint32_t off0, uint32_t len0, uint32_t n) {
-    if (len0 <= G2_REFCAP) return lds_bytes_eq(tx, a, ro + off0, n);
-    for (uint32_t i = 0; i < n; i++) if (tx[a + i] != g0[off0 + i]) return false;
-    return true;
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) { return quad_bcast<0>(v) | quad_bcast<1>(v) | quad_bcast<2>(v) | quad_bcast<3>(v); }
+// n bytes at LDS offsets a and b of tx: are they equal?  The quad's lanes take 16-byte groups part, part + 4, ...; the answer is the same in all four.
+// Every lane of the WAVE must call it (the loop runs while any quad still has bytes to compare); `on` = my quad takes part.
+__device__ __forceinline__ bool quad_bytes_eq(const uint8_t* tx, uint32_t a, uint32_t b, uint32_t n, uint32_t part, bool on) {
+    bool eq = true;
+    for (uint32_t o = 0; __any(on && eq && o < n); o += 64u) {
+        const uint32_t p0 = o + 16u * part; uint32_t d = 0;
+        if (on && eq && p0 < n) {
+            uint32_t x[4], y[4]; lds_get16(tx, a + p0, x); lds_get16(tx, b + p0, y);
+            const uint32_t v = n - p0;                                      // bytes of this group that count (>= 1)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { uint32_t e = x[k] ^ y[k]; const uint32_t lim = 4u * (uint32_t)k; if (v < lim + 4u) e = v > lim ? e & ((1u << (8u * (v - lim))) - 1u) : 0u; d |= e; }
+        }
+        if (quad_or(d)) eq = false;
+    }
+    return eq;
 }
+// the same against read 0's bytes [off0, off0 + n): LDS (offset ro of tx) when read 0's line fits the part of it kept there, else global memory
+__device__ __forceinline__ bool g2_eq_ref(const uint8_t* tx, uint32_t a, uint32_t ro, uint32_t cap, const uint8_t* g0, uint32_t off0, uint32_t len0, uint32_t n, uint32_t part, bool on) {
+    bool slow = on && len0 > cap, eq = quad_bytes_eq(tx, a, ro + off0, n, part, on && !slow);
+    if (slow) for (uint32_t i = 0; i < n && eq; i++) if (tx[a + i] != g0[off0 + i]) eq = false;        // (all four lanes walk the same bytes)
+    return eq;
+}
+// digits of tx[a, a + n) as glibc's atoi reads them: the common form - at most eight characters, the first neither white space nor a sign - from one
+// 8-byte LDS read; anything else byte by byte
+__device__ __forceinline__ uint32_t g2_atoi(const uint8_t* tx, uint32_t a, uint32_t n) {
+    if (n == 0) return 0u;
+    const unsigned long long w = lds_get8(tx, a); const uint32_t c0 = (uint32_t)w & 0xFFu;
+    if (n > 8u || c0 == ' ' || (c0 >= 9u && c0 <= 13u) || c0 == '+' || c0 == '-') return (uint32_t)dev_atoi(tx + a, n);
+    uint32_t val = 0; bool go = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t dgt = ((uint32_t)(w >> (8 * k)) & 0xFFu) - (uint32_t)'0'; go = go && (uint32_t)k < n && dgt <= 9u; if (go) val = val * 10u + dgt; }
+    return val;
+}
+__device__ __forceinline__ uint32_t ctz64_or64(unsigned long long m) { return m ? (uint32_t)(__ffsll((long long)m) - 1) : 64u; }
 __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const uint8_t* tx, uint32_t refn, uint32_t refs, const G2Geo& g, const G2Ref& r0, uint32_t f, uint32_t cur, uint32_t cnt,
                                          bool can0, uint32_t dpos, uint32_t dch, G2Acc& acc) {
-    const uint32_t t = threadIdx.x; const bool on = t < cnt; const uint32_t gi = cur + t;
-    uint32_t nsrc = 0, nl = 0, sl = 0, tsrc = 0, tl = 0; Meta m; m.ok = 0; m.name1_len = 0; m.name2_off = 0; m.x = 0; m.y = 0; m.tile = 0; m.lane = 0;
+    const uint32_t t = threadIdx.x, jp = t >> 2, part = t & 3u; const bool on = jp < cnt; const uint32_t gi = cur + jp;
+    uint32_t nsrc = 0, nl = 0, sl = 0, tsrc = 0, tl = 0;
     if (on) {
         int s_; uint32_t r_; read_loc(T, gi, s_, r_);
         const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);
         const uint32_t lb = s_ ? g.base1 : 0u, a = s_ ? g.a01 : g.a00;
         nsrc = lb + (lo4.x - a); nl = lo4.y - 1u - lo4.x; sl = lo4.z - 1u - lo4.y; tsrc = lb + (lo4.z - a); tl = lo4.w - 1u - lo4.z;
-        m = dev_parse_name(tx + nsrc, nl);
-        R.name1_len[gi] = m.name1_len; R.name2_off[gi] = m.name2_off; R.x[gi] = m.x; R.y[gi] = m.y; R.tile[gi] = m.tile; R.lane[gi] = m.lane; R.ok[gi] = (uint8_t)m.ok;
     }
-    // the mate's fields (the lane in front: tiles start at even reads and hold whole pairs)
-    const uint32_t pn = wave_shr1(nsrc, 0u), pnl = wave_shr1(nl, 0u), pn2o = wave_shr1(m.name2_off, 0u), plane = wave_shr1((uint32_t)m.lane, 0u), ptile = wave_shr1((uint32_t)m.tile, 0u),
-                   px = wave_shr1(m.x, 0u), py = wave_shr1(m.y, 0u);
+    // ---- colon / space masks of the name's first 64 bytes
+    uint32_t pk = 0;
+    if (on && 16u * part < nl) {
+        uint32_t w[4]; lds_get16(tx, nsrc + 16u * part, w); const uint4 q = make_uint4(w[0], w[1], w[2], w[3]);
+        const uint32_t v = nl - 16u * part, keep = v >= 16u ? 0xFFFFu : (1u << v) - 1u;
+        pk = (eq_mask16c(q, 0x3A3A3A3Au) & keep) | ((eq_mask16c(q, 0x20202020u) & keep) << 16);
+    }
+    const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
+    const unsigned long long Cm = ((unsigned long long)((v2 & 0xFFFFu) | (v3 << 16)) << 32) | ((v0 & 0xFFFFu) | (v1 << 16));
+    const unsigned long long Sm = ((unsigned long long)((v2 >> 16) | (v3 & 0xFFFF0000u)) << 32) | ((v0 >> 16) | (v1 & 0xFFFF0000u));
+    // ---- the parse as a function of the masks (src/fastqmeta.cpp:22-80: the loop stops at the first space or at the seventh colon; at a colon
+    // numbered 4 .. 7 and at a space behind colon 4 .. 6 the digits since the previous colon become lane / tile / x / y)
+    const uint32_t sp = ctz64_or64(Sm);
+    unsigned long long cb = sp < 64u ? Cm & ((1ull << sp) - 1ull) : Cm;                // colons in front of the first space
+    const uint32_t k = (uint32_t)__popcll(cb);
+    uint32_t cpos[8];
+#pragma unroll
+    for (int i = 1; i <= 7; i++) { cpos[i] = ctz64_or64(cb); cb &= cb - 1ull; }
+    const bool at7 = cpos[7] < 64u, at_sp = !at7 && sp < 64u;                         // where the loop stops (inside these 64 bytes)
+    const bool undecided = on && !at7 && !at_sp && nl > 64u;                           // the stop, if any, lies further on
+    uint32_t ok = 0, n1l = nl, n2o = nl, fs = 0, fe = 0;                               // my field: tx[nsrc + fs, nsrc + fe)
+    if (on && (at7 || (at_sp && k >= 4u))) {
+        ok = 1; n2o = at7 ? cpos[7] : sp;
+        n1l = (at_sp && k == 4u) ? cpos[4] : cpos[3];                                  // cstart - 1: the colon in front of the lane field
+        if (part == 0u) { if (at_sp && k == 4u) { fs = cpos[4] + 1u; fe = sp; } else { fs = cpos[3] + 1u; fe = cpos[4]; } }
+        else if (part == 1u) { if (at_sp && k == 5u) { fs = cpos[5] + 1u; fe = sp; } else if (k >= 5u) { fs = cpos[4] + 1u; fe = cpos[5]; } }
+        else if (part == 2u) { if (k >= 6u) { fs = cpos[5] + 1u; fe = cpos[6]; } }
+        else { if (at7) { fs = cpos[6] + 1u; fe = cpos[7]; } else if (k == 6u) { fs = cpos[6] + 1u; fe = sp; } }
+    }
+    uint32_t val = (on && ok) ? g2_atoi(tx, nsrc + fs, fe - fs) : 0u;
+    if (__any(undecided)) {                                                            // (rare: wave-uniform)
+        Meta m; m.ok = 0; m.name1_len = nl; m.name2_off = nl; m.x = m.y = 0; m.tile = 0; m.lane = 0;
+        if (undecided) m = dev_parse_name(tx + nsrc, nl);                              // all four lanes walk the same name
+        if (undecided) { ok = m.ok; n1l = m.name1_len; n2o = m.name2_off; val = part == 0u ? (uint32_t)m.lane : (part == 1u ? (uint32_t)m.tile : (part == 2u ? m.x : m.y)); }
+    }
+    if (part == 0u) val &= 0xFFu; else if (part == 1u) val &= 0xFFFFu;                 // (uint8_t) lane, (uint16_t) tile
     if (on) {
-        const uint32_t rel = gi - f, n1l = m.name1_len, n2o = m.name2_off, n2l = nl - n2o, n2l0 = r0.nl - r0.n2o;
-        const uint8_t* g0n = t_fq(T, r0.s) + r0.nb; const uint8_t* g0s = t_fq(T, r0.s) + r0.tb;
+        if (part == 0u) { R.lane[gi] = (uint8_t)val; R.name1_len[gi] = n1l; R.name2_off[gi] = n2o; R.ok[gi] = (uint8_t)ok; }
+        else if (part == 1u) R.tile[gi] = (uint16_t)val;
+        else if (part == 2u) R.x[gi] = val;
+        else R.y[gi] = val;
+    }
+    const uint32_t lane_v = quad_bcast<0>(val), tile_v = quad_bcast<1>(val), x_v = quad_bcast<2>(val), y_v = quad_bcast<3>(val);
+    // ---- against read 0 of the chunk
+    const uint32_t n2l = nl - n2o, n2l0 = r0.nl - r0.n2o;
+    const uint8_t* g0n = t_fq(T, r0.s) + r0.nb; const uint8_t* g0s = t_fq(T, r0.s) + r0.tb;
+    const bool st_eq = g2_eq_ref(tx, tsrc, refs, G2_REFS, g0s, 0u, r0.stl, tl, part, on && tl == r0.stl);
+    const bool n1_eq = g2_eq_ref(tx, nsrc, refn, G2_REFN, g0n, 0u, r0.nl, n1l, part, on && n1l == r0.n1l);
+    const bool n2_eq = g2_eq_ref(tx, nsrc + n2o, refn, G2_REFN, g0n, r0.n2o, r0.nl, n2l, part, on && n2l == n2l0);
+    // ---- an odd read and its mate (the quad in front: tiles start at even reads and hold whole pairs; a pair's eight lanes share a row of 16)
+    const uint32_t pn = lane_shr4(nsrc), pnl = lane_shr4(nl), pn2o = lane_shr4(n2o), plane = lane_shr4(lane_v), ptile = lane_shr4(tile_v), px = lane_shr4(x_v), py = lane_shr4(y_v);
+    const uint32_t rel = gi - f; const bool odd = on && can0 && (rel & 1u);
+    bool fa = false;                                                                   // (R1's name2 with [dpos] = dch) != R2's name2   (src/rfqcodec.cpp:237-245)
+    if (__any(odd)) {
+        const uint32_t pn2l = pnl - pn2o; const bool same_len = odd && pn2l == n2l;
+        if (odd && !same_len) fa = true;
+        // byte dpos apart, the names must be equal; at dpos the mate's byte - or dch in its place - must be mine
+        bool eq = true;
+        for (uint32_t o = 0; __any(same_len && eq && o < n2l); o += 64u) {
+            const uint32_t p0 = o + 16u * part; uint32_t d = 0;
+            if (same_len && eq && p0 < n2l) {
+                uint32_t x[4], y[4]; lds_get16(tx, pn + pn2o + p0, x); lds_get16(tx, nsrc + n2o + p0, y);
+                if (dch != 0u && dpos >= p0 && dpos < p0 + 16u) {
+                    const uint32_t kk = dpos - p0, sh = 8u * (kk & 3u);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if ((kk >> 2) == (uint32_t)q) x[q] = (x[q] & ~(0xFFu << sh)) | (dch << sh);      // (static indices: no scratch)
+                }
+                const uint32_t v = n2l - p0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { uint32_t e = x[q] ^ y[q]; const uint32_t lim = 4u * (uint32_t)q; if (v < lim + 4u) e = v > lim ? e & ((1u << (8u * (v - lim))) - 1u) : 0u; d |= e; }
+            }
+            if (quad_or(d)) eq = false;
+        }
+        if (same_len && !eq) fa = true;
+    }
+    if (on && part == 0u) {
         uint32_t b = 0;
         if (sl == r0.len) b |= 1u << 0;
         if (n1l == r0.n1l) b |= 1u << 1;
         if (n2l == n2l0) b |= 1u << 2;
         if (tl == r0.stl) b |= 1u << 3;
-        if (tl == r0.stl && g2_eq_ref(tx, tsrc, refs, g0s, 0u, r0.stl, tl)) b |= 1u << 4;
-        if ((uint32_t)m.lane == r0.lane) b |= 1u << 5;
-        if ((uint32_t)m.tile == r0.tile) b |= 1u << 6;
-        if (n1l == r0.n1l && g2_eq_ref(tx, nsrc, refn, g0n, 0u, r0.nl, n1l)) b |= 1u << 7;
-        const bool e2 = n2l == n2l0 && g2_eq_ref(tx, nsrc + n2o, refn, g0n, r0.n2o, r0.nl, n2l);
+        if (tl == r0.stl && st_eq) b |= 1u << 4;
+        if (lane_v == r0.lane) b |= 1u << 5;
+        if (tile_v == r0.tile) b |= 1u << 6;
+        if (n1l == r0.n1l && n1_eq) b |= 1u << 7;
+        const bool e2 = n2l == n2l0 && n2_eq;
         if (e2) b |= 1u << 8;
         if (e2 || (rel & 1u)) b |= 1u << 9;
         acc.bits &= b;
         R.eq2[gi] = e2 ? 1 : 0;
-        if (can0 && (rel & 1u)) {
-            const bool fa = !name2_eq_replaced(tx + pn + pn2o, pnl - pn2o, tx + nsrc + n2o, n2l, dpos, dch);
-            const bool fb = plane != (uint32_t)m.lane || ptile != (uint32_t)m.tile || px != m.x || py != m.y;
+        if (odd) {
+            const bool fb = plane != lane_v || ptile != tile_v || px != x_v || py != y_v;
             if (fa || fb) { const uint32_t key = (rel << 1) | (fa ? 0u : 1u); if (key < acc.fail) acc.fail = key; }
         }
     }
 }
 // phase 1: every chunk, mates taken for interleaved wherever the header allows it (the names that decide are parsed in this very pass), names parsed and
 // compared; phase 2: only the chunks k_chunk_flags_b marked in `only` - their interleave test failed somewhere - once more with the mates as they stand.
-__global__ void __launch_bounds__(256) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
+__global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
                                                  uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, DevStatus* st) {
-    constexpr uint32_t TILE4 = G2_CAP / 16 + 8, REFN = (TILE4 - 1) * 16, REFS = REFN + G2_REFROW;     // (byte offsets from the tile's first byte)
-    __shared__ uint4 s_text4[TILE4 + 2 * G2_REFROW / 16];                  // staged text | read 0's name | read 0's strand line
+    constexpr uint32_t TILE4 = G2_CAP / 16 + 8, REFN = (TILE4 - 1) * 16, REFS = REFN + G2_REFN + 16;   // (byte offsets from the tile's first byte)
+    __shared__ uint4 s_text4[TILE4 + (G2_REFN + G2_REFS + 32) / 16];       // staged text | read 0's name | read 0's strand line
     __shared__ uint32_t sh[G2_CNT]; __shared__ int sh_last[G2_CNT]; __shared__ uint8_t s_slot[256]; __shared__ uint32_t s_r0[8];
     const uint32_t c = blockIdx.y;
     const bool redo = only != nullptr;
@@ -1550,11 +1655,11 @@ __global__ void __launch_bounds__(256) k_gather2(Text T, ReadTab R, const uint32
         const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
         r0.nb = p0; r0.nl = p1 - 1u - p0; r0.len = p2 - 1u - p1; r0.tb = p2; r0.stl = p3 - 1u - p2;
         uint8_t* const wr = (uint8_t*)buf4;
-        if (tid < 128u) { if (tid < r0.nl) wr[REFN + tid] = t_fq(T, r0.s)[r0.nb + tid]; }
-        else if (tid - 128u < r0.stl) wr[REFS + tid - 128u] = t_fq(T, r0.s)[r0.tb + tid - 128u];
+        if (tid < r0.nl) wr[REFN + tid] = t_fq(T, r0.s)[r0.nb + tid];      // (G2_REFN = the workgroup's 256 threads)
+        if (tid < G2_REFS && tid < r0.stl) wr[REFS + tid] = t_fq(T, r0.s)[r0.tb + tid];
         __syncthreads();
         if (tid == 0) {
-            const Meta m0 = r0.nl <= G2_REFCAP ? dev_parse_name(tx + REFN, r0.nl) : dev_parse_name(t_fq(T, r0.s) + r0.nb, r0.nl);
+            const Meta m0 = r0.nl <= G2_REFN ? dev_parse_name(tx + REFN, r0.nl) : dev_parse_name(t_fq(T, r0.s) + r0.nb, r0.nl);
             s_r0[0] = m0.name1_len; s_r0[1] = m0.name2_off; s_r0[2] = m0.lane; s_r0[3] = m0.tile;
         }
     }
@@ -1568,14 +1673,14 @@ __global__ void __launch_bounds__(256) k_gather2(Text T, ReadTab R, const uint32
         const uint32_t qbeg = uni32(pq[cur]) - pq0;                          // the tile's first quality position (chunk-relative)
         __syncthreads();                                                    // (drains the LDS-DMA)
         qc.seg0 = qbeg / PC_SEG_POS;
-        if (parse && tid < 64u) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (wave-uniform: the tile's first wave, a lane per read)
+        if (parse) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (block-uniform; four lanes per read)
         g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
         __syncthreads();                                                    // the text is free for the next tile; the tile's counts are complete
         qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
     }
-    if (parse && tid < 64u) {
+    if (parse) {
         const uint32_t bits = wave_and(acc.bits), fail = wave_min(acc.fail);
-        if (tid == 0) { if (bits != CF_ALL) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
+        if ((tid & 63u) == 0) { if (bits != CF_ALL) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
     }
     (void)st;
 }
