@@ -237,6 +237,11 @@ __device__ __forceinline__ unsigned long long lds_get8(const uint8_t* base, uint
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
 template <class P> __device__ __forceinline__ P* uniptr(P* p) { return (P*)(uintptr_t)uni64((uint64_t)(uintptr_t)p); }
+#ifdef RFQ_SIMT_EMULATION
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+#else
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }      // both factors < 2^24
+#endif
 __device__ __forceinline__ uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 // byte-wise full mask (0xFF per byte of w equal to the pattern byte)
 __device__ __forceinline__ uint32_t eq_bytes_full(uint32_t w, uint32_t pat) {

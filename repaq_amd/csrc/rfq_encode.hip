@@ -12,7 +12,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 80, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -383,6 +383,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, ctx->d_hdr.ensure(sizeof(DevHeader)));
     C.flags = B[B_CFLAGS].as<uint32_t>(); C.il = B[B_IL].as<uint32_t>(); C.ncount = B[B_NCOUNT].as<uint32_t>();
     HIPCHK(ctx, B[B_NMAP].ensure(nc * NMAP_WORDS * 4)); C.nmap = B[B_NMAP].as<uint32_t>();
+    HIPCHK(ctx, B[B_PTOT].ensure(nc * sizeof(U4))); C.ptot = B[B_PTOT].as<U4>();
     C.scap = B[B_SCAP].as<uint32_t>(); C.soff = B[B_SOFF].as<uint64_t>(); C.ssize = B[B_SSIZE].as<uint32_t>(); C.xsize = B[B_XSIZE].as<uint32_t>(); C.ysize = B[B_YSIZE].as<uint32_t>();
     C.qbase = B[B_QBASE].as<uint64_t>(); C.sbase = B[B_SBASE].as<uint64_t>(); C.img_size = B[B_IMGSIZE].as<uint64_t>(); C.img_off = B[B_IMGOFF].as<uint64_t>();
     DevHeader* D = ctx->d_hdr.as<DevHeader>();
@@ -442,6 +443,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, Q, T, R, B[B_PVIN].as<U4>(), n_reads);
         scan_exclusive<U4>(Q, B[B_PVIN].as<U4>(), R.pv, n_reads, tmp, 1);
         hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, Q, R, C, n_chunks, 2);
+        hipLaunchKernelGGL(k_chunk_ptot, dim3((n_chunks + 255) / 256), dim3(256), 0, Q, R, C, n_chunks);
     };
     if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));      // from here on everything needs the header (major quality, flags, the mates' name2 rule)
     if (!fast) {
@@ -497,20 +499,20 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
             hipLaunchKernelGGL((k_overlap<false, true>), dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, 0);
         }
-        stored_prefix(A, B[B_SCANTMP2].as<U4>());
+        hipLaunchKernelGGL(k_chunk_prefix, dim3(n_chunks), dim3(256), 0, A, T, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb);
         {
             const uint32_t max_len = max_rec / 2u;                             // (a record holds its sequence twice over: bases and qualities)
             // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
             uint32_t rshift = 8; while (rshift && ((uint64_t)(max_len / 16u + 1u) << rshift) > SP_OWN) rshift--;
             uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
-            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
+            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const U4*)C.ptot, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
                                C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift);
         }
         uint64_t* tmp2 = B[B_SCANTMP2].as<uint64_t>() + (nr / SCAN_TILE + 2) * 2;   // (behind the U4 scan's part of the buffer)
         hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, A, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 2);
         scan_exclusive<uint64_t>(A, ctot_n, cbase_n, n_chunks, tmp2, 1);
-        hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, A, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
+        hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, A, T, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
         scan_exclusive<uint64_t>(A, C.img_size, C.img_off, n_chunks, tmp2, 1);
         hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, A, C, (const uint64_t*)cbase_n, n_chunks, 2, dst);
         KCHK(ctx, "k_gather2");
@@ -526,7 +528,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 3);
         scan_exclusive<uint64_t>(S, ctot, cbase, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
         scan_exclusive<uint64_t>(S, ctot_n, cbase_n, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-        hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
+        hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, T, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
         scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
         hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst);
         hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase_n, n_chunks, 2, dst);
@@ -593,7 +595,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.end(S);
     ctx->timer.begin("coords+layout", S);
     hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const uint32_t*)B[B_SEGB].as<uint32_t>(), n_seg);
-    hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
+    hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, T, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
     hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 1, dst);
     KCHK(ctx, "k_coords");

@@ -43,7 +43,8 @@ struct ReadTab {                 // per-read arrays, indexed by g (interleaved o
     uint32_t* stored;            // bases kept in the sequence stream (after overlap trimming)
     uint8_t*  eq2;               // name2 == name2 of the chunk's read 0
     uint32_t* pq;                // exclusive prefix of len          (n_reads + 1 entries)
-    U4*       pv;                // exclusive prefix of (name1_len, name2_len, strand_len, stored) (n_reads + 1)
+    U4*       pv;                // exclusive prefix of (name1_len, name2_len, strand_len, stored): only differences inside one chunk are ever used (pv[g] - pv[first[c]];
+                                 // the chunk's totals: ChunkTab::ptot) - the tile path restarts it at 0 in every chunk (k_chunk_prefix), the byte-wise path scans the whole batch
 };
 
 struct ChunkTab {                // per-chunk arrays
@@ -59,6 +60,7 @@ struct ChunkTab {                // per-chunk arrays
     uint64_t* qbase; uint64_t* sbase;   // 64-byte aligned bases of the chunk in qcat / scat
     uint64_t* img_size;          // bytes of the chunk image
     uint64_t* img_off;           // exclusive prefix (n_chunks + 1)
+    U4*       ptot;              // the chunk's totals of (name1_len, name2_len, strand_len, stored): ReadTab::pv[g] - pv[first] is read g's offset inside the chunk
 };
 
 // =============================================================== index
@@ -1072,6 +1074,44 @@ __global__ void k_chunk_bases(ReadTab R, ChunkTab C, uint32_t n_chunks, int whic
     if (c < n_chunks) { const uint32_t f = C.first[c]; if (which & 1) C.qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c; if (which & 2) C.sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
 }
 
+// Tile path: overlap clamp (src/rfqcodec.cpp:376-383), stored lengths and the per-read prefix of (name1, name2, strand, stored) in ONE launch, a workgroup
+// per chunk - the prefix restarts in every chunk, so nothing crosses workgroups.  (It was k_overlap_apply -> k_pv_in -> a three-launch U4 scan over the
+// batch -> k_chunk_bases: six launches in a row on the second stream, 2.7 GB of traffic, 0.5 ms of latency in front of the sequence packer.)
+__global__ void __launch_bounds__(256) k_chunk_prefix(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const int16_t* __restrict__ ovraw, int8_t* __restrict__ ovb) {
+    const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1], tid = threadIdx.x;
+    const bool enc = C.il[c] != 0 && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
+    U4 carry; carry.a = carry.b = carry.c = carry.d = 0;
+    for (uint32_t base = f; base < e; base += 1024u) {                     // block-uniform
+        U4 v[4]; U4 acc; acc.a = acc.b = acc.c = acc.d = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t g = base + 4u * tid + (uint32_t)i; v[i].a = v[i].b = v[i].c = v[i].d = 0;
+            if (g < e) {
+                int s_; uint32_t r_; read_loc(T, g, s_, r_); const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);
+                uint32_t st = R.len[g];
+                if (enc && ((g - f) & 1u)) {
+                    int ov = ovraw[g >> 1];
+                    if (ov + shift > 127) ov = 0;
+                    if (ov + shift < -127) ov = 0;
+                    ovb[g >> 1] = (int8_t)(ov + shift); st -= (uint32_t)(ov < 0 ? -ov : ov); R.stored[g] = st;
+                }
+                v[i].a = R.name1_len[g]; v[i].b = (lo4.y - 1u - lo4.x) - R.name2_off[g]; v[i].c = lo4.w - 1u - lo4.z; v[i].d = st;
+                acc = acc + v[i];
+            }
+        }
+        U4 tot; U4 run = carry + block_excl_sum<U4>(acc, &tot);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const uint32_t g = base + 4u * tid + (uint32_t)i; if (g < e) { R.pv[g] = run; run = run + v[i]; } }
+        carry = carry + tot;
+    }
+    if (tid == 0) { C.ptot[c] = carry; C.sbase[c] = C.qbase[c]; }          // (the tight streams are laid out like the qualities: stored <= len)
+}
+// byte-wise path: the totals from the batch-wide prefix
+__global__ void k_chunk_ptot(ReadTab R, ChunkTab C, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_chunks) C.ptot[c] = R.pv[C.first[c + 1]] - R.pv[C.first[c]];
+}
+
 // =============================================================== gather (RfqCodec::encodeChunk pass 2, src/rfqcodec.cpp:371-407)
 // qcat = full-length qualities in chunk order (R2 reversed when interleaved); scat = stored bases (R2 reverse-complemented and
 // overlap-trimmed when interleaved).  Also builds the chunk's quality histogram and N count.
@@ -1463,42 +1503,51 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
 }
 // FastqMeta::parse + RfqCodec::encodeChunk's pass 1 (src/fastqmeta.cpp:22-80, src/rfqcodec.cpp:220-263) for the reads of the tile k_gather2 has staged:
 // the name line is in LDS already, so the text is not fetched a third time for the names (the separate read-table pass cost 8.1 GB / 1.9 ms
-// on configs[2]).  FOUR LANES PER READ (a quad; thread t parses read t >> 2 of the tile, whatever the compose mapping is), nothing serial:
-//   * each lane turns 16 bytes of the name's first 64 into a colon mask and a space mask; quad broadcasts (DPP quad_perm) give every lane the 64-bit masks;
-//   * the parse is a function of those masks: it stops at the first space or the seventh colon, whichever comes first; the fields are the digits between
-//     colons 3|4, 4|5, 5|6, 6|7 (a space that ends the name part early takes over the field it closes - the reference's loop, restated below);
-//   * lane k of the quad converts field k (lane, tile, x, y) - up to eight digits from one 8-byte LDS read - and stores it;
-//   * the comparisons with the chunk's read 0 (staged once per workgroup: G2Ref) are made 16 bytes per lane and OR-ed over the quad; an odd read meets
-//     its mate's fields through a row shift by four lanes.  The verdicts are accumulated per lane (G2Acc, see CF_ALL) and leave the workgroup as
-//     atomicAnd / atomicMin per wave.
+// on configs[2]).  ONE WAVE of the workgroup per tile - a different one every tile, so that the extra work spreads over the SIMDs - A LANE PER READ,
+// and no loop over the name's bytes:
+//   * the name's first 64 bytes become a 64-bit colon mask and a 64-bit space mask (four 16-byte LDS reads, SWAR byte equality);
+//   * the parse is a function of those masks: the reference's loop stops at the first space or the seventh colon, whichever comes first; the fields are
+//     the digits between colons 3|4, 4|5, 5|6, 6|7, and a space that ends the name part early takes over the field it closes (restated below);
+//   * a field of up to eight digits is converted from one 8-byte LDS read (SWAR: pairs, then fours);
+//   * the comparisons with the chunk's read 0 (staged once per workgroup: G2Ref) run 16 bytes per step; an odd read meets its mate's fields through
+//     a shift by one lane.  The verdicts are accumulated per lane (G2Acc, see CF_ALL) and leave the workgroup as one atomicAnd / atomicMin per wave.
 // A name whose first 64 bytes hold neither a space nor seven colons, a field with a sign / white space / more than eight characters: the byte-wise
-// dev_parse_name / dev_atoi decide (first lane of the quad).  (A lane per read walking its name byte by byte - the first version - ran the kernel at
-// 7.1 instead of 3.5 ms on configs[2]: one wave of the workgroup in a chain of dependent LDS reads, three waiting at the barrier.)
+// dev_parse_name / dev_atoi decide.  What this replaced, on configs[2] (k_gather2 alone: 3.5 ms): a lane per read walking its name byte by byte,
+// 7.1 ms - one wave in a chain of dependent LDS reads, three waiting at the barrier; four lanes per read on 16 bytes each, every wave, 4.9 ms - ~600
+// instructions per wave and tile, most of them the same work four times over.
 #define G2_REFN 256u              // bytes of read 0's name kept in LDS (a longer one is compared from global memory)
 #define G2_REFS 128u              // ... of its strand line
 struct G2Ref { uint32_t nl, n1l, n2o, len, stl, lane, tile, nb, tb; int s; };   // read 0 of the chunk: lengths, parsed fields, where its name / strand line start in the text
 struct G2Acc { uint32_t bits, fail; };
-__device__ __forceinline__ uint32_t quad_or(uint32_t v) { return quad_bcast<0>(v) | quad_bcast<1>(v) | quad_bcast<2>(v) | quad_bcast<3>(v); }
-// n bytes at LDS offsets a and b of tx: are they equal?  The quad's lanes take 16-byte groups part, part + 4, ...; the answer is the same in all four.
-// Every lane of the WAVE must call it (the loop runs while any quad still has bytes to compare); `on` = my quad takes part.
-__device__ __forceinline__ bool quad_bytes_eq(const uint8_t* tx, uint32_t a, uint32_t b, uint32_t n, uint32_t part, bool on) {
+// n bytes at LDS offsets a and b of tx: are they equal?  16 bytes per step; a length that is not a multiple of 16 ends with a group moved back to end at
+// n (>= 16 bytes) or with one masked group (< 16).  Every lane of the wave must call it (the loop runs while any lane has bytes left); `on` = mine count.
+__device__ __forceinline__ bool lane_bytes_eq(const uint8_t* tx, uint32_t a, uint32_t b, uint32_t n, bool on) {
     bool eq = true;
-    for (uint32_t o = 0; __any(on && eq && o < n); o += 64u) {
-        const uint32_t p0 = o + 16u * part; uint32_t d = 0;
-        if (on && eq && p0 < n) {
+    for (uint32_t o = 0; __any(on && eq && o < n); o += 16u) {
+        if (on && eq && o < n) {
+            uint32_t p0 = o, v = n - o; if (v < 16u && n >= 16u) { p0 = n - 16u; v = 16u; }
             uint32_t x[4], y[4]; lds_get16(tx, a + p0, x); lds_get16(tx, b + p0, y);
-            const uint32_t v = n - p0;                                      // bytes of this group that count (>= 1)
-#pragma unroll
-            for (int k = 0; k < 4; k++) { uint32_t e = x[k] ^ y[k]; const uint32_t lim = 4u * (uint32_t)k; if (v < lim + 4u) e = v > lim ? e & ((1u << (8u * (v - lim))) - 1u) : 0u; d |= e; }
+            unsigned long long dl = (((unsigned long long)(x[1] ^ y[1])) << 32) | (x[0] ^ y[0]), dh = (((unsigned long long)(x[3] ^ y[3])) << 32) | (x[2] ^ y[2]);
+            if (v < 16u) { dl &= v >= 8u ? ~0ull : (1ull << (8u * v)) - 1ull; dh &= v > 8u ? (1ull << (8u * (v - 8u))) - 1ull : 0ull; }
+            if (dl | dh) eq = false;
         }
-        if (quad_or(d)) eq = false;
     }
     return eq;
 }
+// the common sizes without a loop: n <= 32 bytes as one or two 16-byte groups (the second moved back to end at n; one masked group below 16)
+__device__ __forceinline__ bool lane_bytes_eq32(const uint8_t* tx, uint32_t a, uint32_t b, uint32_t n) {
+    uint32_t x[4], y[4]; lds_get16(tx, a, x); lds_get16(tx, b, y);
+    unsigned long long dl = (((unsigned long long)(x[1] ^ y[1])) << 32) | (x[0] ^ y[0]), dh = (((unsigned long long)(x[3] ^ y[3])) << 32) | (x[2] ^ y[2]);
+    if (n < 16u) { dl &= n >= 8u ? ~0ull : (1ull << (8u * n)) - 1ull; dh &= n > 8u ? (1ull << (8u * (n - 8u))) - 1ull : 0ull; }
+    else { const uint32_t t = n - 16u; lds_get16(tx, a + t, x); lds_get16(tx, b + t, y); dl |= (((unsigned long long)(x[1] ^ y[1])) << 32) | (x[0] ^ y[0]); dh |= (((unsigned long long)(x[3] ^ y[3])) << 32) | (x[2] ^ y[2]); }
+    return (dl | dh) == 0ull;
+}
 // the same against read 0's bytes [off0, off0 + n): LDS (offset ro of tx) when read 0's line fits the part of it kept there, else global memory
-__device__ __forceinline__ bool g2_eq_ref(const uint8_t* tx, uint32_t a, uint32_t ro, uint32_t cap, const uint8_t* g0, uint32_t off0, uint32_t len0, uint32_t n, uint32_t part, bool on) {
-    bool slow = on && len0 > cap, eq = quad_bytes_eq(tx, a, ro + off0, n, part, on && !slow);
-    if (slow) for (uint32_t i = 0; i < n && eq; i++) if (tx[a + i] != g0[off0 + i]) eq = false;        // (all four lanes walk the same bytes)
+__device__ __forceinline__ bool g2_eq_ref(const uint8_t* tx, uint32_t a, uint32_t ro, uint32_t cap, const uint8_t* g0, uint32_t off0, uint32_t len0, uint32_t n, bool on) {
+    const bool slow = on && len0 > cap, big = on && !slow && n > 32u; bool eq = true;
+    if (on && !slow && !big && n) eq = lane_bytes_eq32(tx, a, ro + off0, n);
+    if (__any(big)) { if (!lane_bytes_eq(tx, a, ro + off0, n, big)) eq = false; }   // (rare: wave-uniform)
+    if (slow) for (uint32_t i = 0; i < n && eq; i++) if (tx[a + i] != g0[off0 + i]) eq = false;
     return eq;
 }
 // digits of tx[a, a + n) as glibc's atoi reads them: the common form - at most eight characters, the first neither white space nor a sign - from one
@@ -1507,15 +1556,20 @@ __device__ __forceinline__ uint32_t g2_atoi(const uint8_t* tx, uint32_t a, uint3
     if (n == 0) return 0u;
     const unsigned long long w = lds_get8(tx, a); const uint32_t c0 = (uint32_t)w & 0xFFu;
     if (n > 8u || c0 == ' ' || (c0 >= 9u && c0 <= 13u) || c0 == '+' || c0 == '-') return (uint32_t)dev_atoi(tx + a, n);
-    uint32_t val = 0; bool go = true;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const uint32_t dgt = ((uint32_t)(w >> (8 * k)) & 0xFFu) - (uint32_t)'0'; go = go && (uint32_t)k < n && dgt <= 9u; if (go) val = val * 10u + dgt; }
-    return val;
+    const unsigned long long x = w ^ 0x3030303030303030ull;                             // a digit's byte is now its value 0 .. 9
+    const unsigned long long nd = (((x & 0x7F7F7F7F7F7F7F7Full) + 0x7676767676767676ull) | x) & 0x8080808080808080ull;   // 0x80 in every byte that is not a digit
+    uint32_t m = nd ? (uint32_t)(__ffsll((long long)nd) - 1) >> 3 : 8u; if (m > n) m = n;      // leading digits: atoi stops at the first other byte
+    if (m == 0) return 0u;
+    const unsigned long long X = x << (8u * (8u - m));                                  // last digit in byte 7, zeros (leading zero digits) in front
+    const uint32_t hi4 = (uint32_t)X, lo4 = (uint32_t)(X >> 32);                        // four digits each, the most significant one in the lowest byte
+    const uint32_t uh = ((hi4 << 3) + (hi4 << 1) + (hi4 >> 8)) & 0x00FF00FFu, ul = ((lo4 << 3) + (lo4 << 1) + (lo4 >> 8)) & 0x00FF00FFu;   // pairs: d0 d1 -> 10 d0 + d1 (no carry between bytes: <= 99)
+    const uint32_t vh = mul24(uh & 0xFFu, 100u) + (uh >> 16), vl = mul24(ul & 0xFFu, 100u) + (ul >> 16);
+    return mul24(vh, 10000u) + vl;                                                      // (24-bit multiplies run at full rate, v_mul_lo_u32 at a quarter)
 }
 __device__ __forceinline__ uint32_t ctz64_or64(unsigned long long m) { return m ? (uint32_t)(__ffsll((long long)m) - 1) : 64u; }
 __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const uint8_t* tx, uint32_t refn, uint32_t refs, const G2Geo& g, const G2Ref& r0, uint32_t f, uint32_t cur, uint32_t cnt,
                                          bool can0, uint32_t dpos, uint32_t dch, G2Acc& acc) {
-    const uint32_t t = threadIdx.x, jp = t >> 2, part = t & 3u; const bool on = jp < cnt; const uint32_t gi = cur + jp;
+    const uint32_t l = (uint32_t)lane_id(); const bool on = l < cnt; const uint32_t gi = cur + l;
     uint32_t nsrc = 0, nl = 0, sl = 0, tsrc = 0, tl = 0;
     if (on) {
         int s_; uint32_t r_; read_loc(T, gi, s_, r_);
@@ -1523,16 +1577,16 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
         const uint32_t lb = s_ ? g.base1 : 0u, a = s_ ? g.a01 : g.a00;
         nsrc = lb + (lo4.x - a); nl = lo4.y - 1u - lo4.x; sl = lo4.z - 1u - lo4.y; tsrc = lb + (lo4.z - a); tl = lo4.w - 1u - lo4.z;
     }
-    // ---- colon / space masks of the name's first 64 bytes
-    uint32_t pk = 0;
-    if (on && 16u * part < nl) {
-        uint32_t w[4]; lds_get16(tx, nsrc + 16u * part, w); const uint4 q = make_uint4(w[0], w[1], w[2], w[3]);
-        const uint32_t v = nl - 16u * part, keep = v >= 16u ? 0xFFFFu : (1u << v) - 1u;
-        pk = (eq_mask16c(q, 0x3A3A3A3Au) & keep) | ((eq_mask16c(q, 0x20202020u) & keep) << 16);
+    // ---- colon / space masks of the name's first 64 bytes (what lies behind the name is read too - it is inside the tile or its slack - and masked off)
+    unsigned long long Cm = 0, Sm = 0;
+    {
+        uint32_t c[4], sp_[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) { uint32_t w[4]; lds_get16(tx, nsrc + 16u * (uint32_t)p, w); const uint4 q = make_uint4(w[0], w[1], w[2], w[3]); c[p] = eq_mask16c(q, 0x3A3A3A3Au); sp_[p] = eq_mask16c(q, 0x20202020u); }
+        const unsigned long long keep = !on ? 0ull : (nl >= 64u ? ~0ull : (1ull << nl) - 1ull);
+        Cm = ((((unsigned long long)(c[2] | (c[3] << 16))) << 32) | (c[0] | (c[1] << 16))) & keep;
+        Sm = ((((unsigned long long)(sp_[2] | (sp_[3] << 16))) << 32) | (sp_[0] | (sp_[1] << 16))) & keep;
     }
-    const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
-    const unsigned long long Cm = ((unsigned long long)((v2 & 0xFFFFu) | (v3 << 16)) << 32) | ((v0 & 0xFFFFu) | (v1 << 16));
-    const unsigned long long Sm = ((unsigned long long)((v2 >> 16) | (v3 & 0xFFFF0000u)) << 32) | ((v0 >> 16) | (v1 & 0xFFFF0000u));
     // ---- the parse as a function of the masks (src/fastqmeta.cpp:22-80: the loop stops at the first space or at the seventh colon; at a colon
     // numbered 4 .. 7 and at a space behind colon 4 .. 6 the digits since the previous colon become lane / tile / x / y)
     const uint32_t sp = ctz64_or64(Sm);
@@ -1543,62 +1597,55 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
     for (int i = 1; i <= 7; i++) { cpos[i] = ctz64_or64(cb); cb &= cb - 1ull; }
     const bool at7 = cpos[7] < 64u, at_sp = !at7 && sp < 64u;                         // where the loop stops (inside these 64 bytes)
     const bool undecided = on && !at7 && !at_sp && nl > 64u;                           // the stop, if any, lies further on
-    uint32_t ok = 0, n1l = nl, n2o = nl, fs = 0, fe = 0;                               // my field: tx[nsrc + fs, nsrc + fe)
+    uint32_t ok = 0, n1l = nl, n2o = nl, lane_v = 0, tile_v = 0, x_v = 0, y_v = 0;
     if (on && (at7 || (at_sp && k >= 4u))) {
         ok = 1; n2o = at7 ? cpos[7] : sp;
-        n1l = (at_sp && k == 4u) ? cpos[4] : cpos[3];                                  // cstart - 1: the colon in front of the lane field
-        if (part == 0u) { if (at_sp && k == 4u) { fs = cpos[4] + 1u; fe = sp; } else { fs = cpos[3] + 1u; fe = cpos[4]; } }
-        else if (part == 1u) { if (at_sp && k == 5u) { fs = cpos[5] + 1u; fe = sp; } else if (k >= 5u) { fs = cpos[4] + 1u; fe = cpos[5]; } }
-        else if (part == 2u) { if (k >= 6u) { fs = cpos[5] + 1u; fe = cpos[6]; } }
-        else { if (at7) { fs = cpos[6] + 1u; fe = cpos[7]; } else if (k == 6u) { fs = cpos[6] + 1u; fe = sp; } }
+        const bool k4 = at_sp && k == 4u, k5 = at_sp && k == 5u;
+        n1l = k4 ? cpos[4] : cpos[3];                                                  // cstart - 1: the colon in front of the lane field
+        const uint32_t ls = (k4 ? cpos[4] : cpos[3]) + 1u, le = k4 ? sp : cpos[4];
+        lane_v = g2_atoi(tx, nsrc + ls, le - ls) & 0xFFu;                              // (uint8_t)
+        if (k >= 5u) { const uint32_t ts = (k5 ? cpos[5] : cpos[4]) + 1u, te = k5 ? sp : cpos[5]; tile_v = g2_atoi(tx, nsrc + ts, te - ts) & 0xFFFFu; }   // (uint16_t)
+        if (k >= 6u) x_v = g2_atoi(tx, nsrc + cpos[5] + 1u, cpos[6] - cpos[5] - 1u);
+        if (at7) y_v = g2_atoi(tx, nsrc + cpos[6] + 1u, cpos[7] - cpos[6] - 1u);
+        else if (k == 6u) y_v = g2_atoi(tx, nsrc + cpos[6] + 1u, sp - cpos[6] - 1u);
     }
-    uint32_t val = (on && ok) ? g2_atoi(tx, nsrc + fs, fe - fs) : 0u;
     if (__any(undecided)) {                                                            // (rare: wave-uniform)
-        Meta m; m.ok = 0; m.name1_len = nl; m.name2_off = nl; m.x = m.y = 0; m.tile = 0; m.lane = 0;
-        if (undecided) m = dev_parse_name(tx + nsrc, nl);                              // all four lanes walk the same name
-        if (undecided) { ok = m.ok; n1l = m.name1_len; n2o = m.name2_off; val = part == 0u ? (uint32_t)m.lane : (part == 1u ? (uint32_t)m.tile : (part == 2u ? m.x : m.y)); }
+        if (undecided) { const Meta m = dev_parse_name(tx + nsrc, nl); ok = m.ok; n1l = m.name1_len; n2o = m.name2_off; lane_v = m.lane; tile_v = m.tile; x_v = m.x; y_v = m.y; }
     }
-    if (part == 0u) val &= 0xFFu; else if (part == 1u) val &= 0xFFFFu;                 // (uint8_t) lane, (uint16_t) tile
-    if (on) {
-        if (part == 0u) { R.lane[gi] = (uint8_t)val; R.name1_len[gi] = n1l; R.name2_off[gi] = n2o; R.ok[gi] = (uint8_t)ok; }
-        else if (part == 1u) R.tile[gi] = (uint16_t)val;
-        else if (part == 2u) R.x[gi] = val;
-        else R.y[gi] = val;
-    }
-    const uint32_t lane_v = quad_bcast<0>(val), tile_v = quad_bcast<1>(val), x_v = quad_bcast<2>(val), y_v = quad_bcast<3>(val);
+    if (on) { R.name1_len[gi] = n1l; R.name2_off[gi] = n2o; R.x[gi] = x_v; R.y[gi] = y_v; R.tile[gi] = (uint16_t)tile_v; R.lane[gi] = (uint8_t)lane_v; R.ok[gi] = (uint8_t)ok; }
     // ---- against read 0 of the chunk
     const uint32_t n2l = nl - n2o, n2l0 = r0.nl - r0.n2o;
     const uint8_t* g0n = t_fq(T, r0.s) + r0.nb; const uint8_t* g0s = t_fq(T, r0.s) + r0.tb;
-    const bool st_eq = g2_eq_ref(tx, tsrc, refs, G2_REFS, g0s, 0u, r0.stl, tl, part, on && tl == r0.stl);
-    const bool n1_eq = g2_eq_ref(tx, nsrc, refn, G2_REFN, g0n, 0u, r0.nl, n1l, part, on && n1l == r0.n1l);
-    const bool n2_eq = g2_eq_ref(tx, nsrc + n2o, refn, G2_REFN, g0n, r0.n2o, r0.nl, n2l, part, on && n2l == n2l0);
-    // ---- an odd read and its mate (the quad in front: tiles start at even reads and hold whole pairs; a pair's eight lanes share a row of 16)
-    const uint32_t pn = lane_shr4(nsrc), pnl = lane_shr4(nl), pn2o = lane_shr4(n2o), plane = lane_shr4(lane_v), ptile = lane_shr4(tile_v), px = lane_shr4(x_v), py = lane_shr4(y_v);
+    const bool st_eq = g2_eq_ref(tx, tsrc, refs, G2_REFS, g0s, 0u, r0.stl, tl, on && tl == r0.stl);
+    const bool n1_eq = g2_eq_ref(tx, nsrc, refn, G2_REFN, g0n, 0u, r0.nl, n1l, on && n1l == r0.n1l);
+    const bool n2_eq = g2_eq_ref(tx, nsrc + n2o, refn, G2_REFN, g0n, r0.n2o, r0.nl, n2l, on && n2l == n2l0);
+    // ---- an odd read and its mate (the lane in front: tiles start at even reads and hold whole pairs)
+    const uint32_t pn = wave_shr1(nsrc, 0u), pnl = wave_shr1(nl, 0u), pn2o = wave_shr1(n2o, 0u), plane = wave_shr1(lane_v, 0u), ptile = wave_shr1(tile_v, 0u), px = wave_shr1(x_v, 0u), py = wave_shr1(y_v, 0u);
     const uint32_t rel = gi - f; const bool odd = on && can0 && (rel & 1u);
     bool fa = false;                                                                   // (R1's name2 with [dpos] = dch) != R2's name2   (src/rfqcodec.cpp:237-245)
     if (__any(odd)) {
+        // byte dpos apart, the names must be equal; at dpos the mate's byte - or dch in its place - must be mine
         const uint32_t pn2l = pnl - pn2o; const bool same_len = odd && pn2l == n2l;
         if (odd && !same_len) fa = true;
-        // byte dpos apart, the names must be equal; at dpos the mate's byte - or dch in its place - must be mine
-        bool eq = true;
-        for (uint32_t o = 0; __any(same_len && eq && o < n2l); o += 64u) {
-            const uint32_t p0 = o + 16u * part; uint32_t d = 0;
-            if (same_len && eq && p0 < n2l) {
-                uint32_t x[4], y[4]; lds_get16(tx, pn + pn2o + p0, x); lds_get16(tx, nsrc + n2o + p0, y);
-                if (dch != 0u && dpos >= p0 && dpos < p0 + 16u) {
-                    const uint32_t kk = dpos - p0, sh = 8u * (kk & 3u);
+        const uint32_t ma = pn + pn2o, mb = nsrc + n2o; const bool small = same_len && n2l <= 16u, big = same_len && !small;
+        if (small && n2l) {                                                            // one group: the mate's bytes with [dpos] patched, against mine
+            uint32_t x[4], y[4]; lds_get16(tx, ma, x); lds_get16(tx, mb, y);
+            if (dch != 0u && dpos < n2l) {
+                const uint32_t sh = 8u * (dpos & 3u);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) if ((kk >> 2) == (uint32_t)q) x[q] = (x[q] & ~(0xFFu << sh)) | (dch << sh);      // (static indices: no scratch)
-                }
-                const uint32_t v = n2l - p0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { uint32_t e = x[q] ^ y[q]; const uint32_t lim = 4u * (uint32_t)q; if (v < lim + 4u) e = v > lim ? e & ((1u << (8u * (v - lim))) - 1u) : 0u; d |= e; }
+                for (int q = 0; q < 4; q++) if ((dpos >> 2) == (uint32_t)q) x[q] = (x[q] & ~(0xFFu << sh)) | (dch << sh);      // (static indices: no scratch)
             }
-            if (quad_or(d)) eq = false;
+            unsigned long long dl = (((unsigned long long)(x[1] ^ y[1])) << 32) | (x[0] ^ y[0]), dh = (((unsigned long long)(x[3] ^ y[3])) << 32) | (x[2] ^ y[2]);
+            if (n2l < 16u) { dl &= n2l >= 8u ? ~0ull : (1ull << (8u * n2l)) - 1ull; dh &= n2l > 8u ? (1ull << (8u * (n2l - 8u))) - 1ull : 0ull; }
+            if (dl | dh) fa = true;
         }
-        if (same_len && !eq) fa = true;
+        if (__any(big)) {                                                              // (rare: wave-uniform) in front of dpos, at dpos, behind it
+            if (!lane_bytes_eq(tx, ma, mb, dpos < n2l ? dpos : n2l, big)) fa = true;
+            if (big && dpos < n2l) { if ((dch != 0u ? dch : (uint32_t)tx[ma + dpos]) != (uint32_t)tx[mb + dpos]) fa = true; }
+            if (!lane_bytes_eq(tx, ma + dpos + 1u, mb + dpos + 1u, n2l > dpos + 1u ? n2l - dpos - 1u : 0u, big && dpos + 1u < n2l)) fa = true;
+        }
     }
-    if (on && part == 0u) {
+    if (on) {
         uint32_t b = 0;
         if (sl == r0.len) b |= 1u << 0;
         if (n1l == r0.n1l) b |= 1u << 1;
@@ -1665,7 +1712,8 @@ __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uin
     }
     __syncthreads();
     if (parse) { r0.n1l = s_r0[0]; r0.n2o = s_r0[1]; r0.lane = s_r0[2]; r0.tile = s_r0[3]; }
-    for (uint32_t cur = gs; cur < ge; cur += K) {                          // block-uniform
+    uint32_t tix = blockIdx.x + blockIdx.y;                                 // (which wave parses: another one every tile, and not the same one in every workgroup)
+    for (uint32_t cur = gs; cur < ge; cur += K, tix++) {                   // block-uniform
         const uint32_t cnt = ge - cur < K ? ge - cur : K;
         const G2Geo g = g2_geo(T, two, cur, cnt);
         g2_stage(T, two, g, buf4, tid);
@@ -1673,7 +1721,7 @@ __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uin
         const uint32_t qbeg = uni32(pq[cur]) - pq0;                          // the tile's first quality position (chunk-relative)
         __syncthreads();                                                    // (drains the LDS-DMA)
         qc.seg0 = qbeg / PC_SEG_POS;
-        if (parse) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (block-uniform; four lanes per read)
+        if (parse && (uint32_t)wave_id() == (tix & 3u)) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (wave-uniform: this tile's parsing wave)
         g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
         __syncthreads();                                                    // the text is free for the next tile; the tile's counts are complete
         qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
@@ -1714,13 +1762,13 @@ __device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb
 // N counts per coder segment, the chunk's N total and N map are left as k_gather leaves them.
 #define SP_OWN 4096u              // tight dwords of one step (the host sizes R by the longest read: R * (max_len / 16 + 1) <= SP_OWN)
 #define SP_EXTRA 8u               // reads behind the step's last whose LDS entries the last dword's tail may need (beyond: global memory)
-__global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
+__global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const U4* __restrict__ ptot, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
                                                  const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
                                                  uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
                                                  uint32_t rshift) {
     __shared__ uint32_t s_sd[256 + SP_EXTRA + 1], s_ld[256 + SP_EXTRA], s_sk[256 + SP_EXTRA]; __shared__ uint8_t s_own[SP_OWN];
     const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1], tid = threadIdx.x;
-    const uint32_t ps0 = pv[f].d, S = pv[e].d - ps0;
+    const uint32_t ps0 = pv[f].d, S = ptot[c].d;
     const bool il = ilv[c] != 0, enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
     uint32_t* const ok = spk + (size_t)(sbase[c] >> 4); uint16_t* const on = snm + (size_t)(sbase[c] >> 4);
     const uint32_t nshift = nmap_shift(S); uint32_t* const nm = nmap + (size_t)c * NMAP_WORDS;
@@ -1735,7 +1783,7 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
         const uint32_t nr = e - r0 < R ? e - r0 : R, nx = e - r0 < R + SP_EXTRA ? e - r0 : R + SP_EXTRA;    // my reads; reads with LDS entries
         // ---- phase 1
         for (uint32_t t = tid; t <= nx; t += blockDim.x) {
-            const uint32_t g = r0 + t; s_sd[t] = pv[g].d - ps0;
+            const uint32_t g = r0 + t; s_sd[t] = g < e ? pv[g].d - ps0 : S;  // (pv[e] belongs to the next chunk)
             if (t < nx) { s_ld[t] = (pq[g] >> 4) + g; s_sk[t] = skip_of(g); }
         }
         __syncthreads();
@@ -1754,7 +1802,7 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
             while (filled < need) {                                         // the read's last dword: the rest comes from the read(s) behind it
                 uint32_t a, b, l2, s2;
                 if (jj < nx) { a = s_sd[jj]; b = s_sd[jj + 1]; l2 = s_ld[jj]; s2 = s_sk[jj]; }
-                else { const uint32_t gg = r0 + jj; a = pv[gg].d - ps0; b = pv[gg + 1].d - ps0; l2 = (pq[gg] >> 4) + gg; s2 = skip_of(gg); }   // (more than SP_EXTRA reads of a few bases in a row)
+                else { const uint32_t gg = r0 + jj; a = pv[gg].d - ps0; b = gg + 1u < e ? pv[gg + 1].d - ps0 : S; l2 = (pq[gg] >> 4) + gg; s2 = skip_of(gg); }   // (more than SP_EXTRA reads of a few bases in a row)
                 const uint32_t avail = b - a;
                 if (avail) {
                     const uint32_t take = avail < need - filled ? avail : need - filled;
@@ -1775,7 +1823,7 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
 __global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint64_t* __restrict__ sbase, const uint8_t* __restrict__ scat,
                                                    uint32_t* __restrict__ spk, uint16_t* __restrict__ snm) {
     const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1];
-    const uint32_t S = pv[e].d - pv[f].d, ndw = (S + 15u) >> 4;
+    const uint32_t S = pv[e].d - pv[f].d, ndw = (S + 15u) >> 4;              // (byte-wise path: the prefix runs over the whole batch)
     const uint4* const src = (const uint4*)(scat + sbase[c]);               // (chunk bases are 64-byte aligned and padded)
     uint32_t* const ok = spk + (size_t)(sbase[c] >> 4); uint16_t* const on = snm + (size_t)(sbase[c] >> 4);
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < ndw; k += gridDim.x * blockDim.x) {
@@ -1816,7 +1864,7 @@ __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict
                       C.scap[k + EXC_SLOT] = cape; C.soff[k + EXC_SLOT] = run64; C.ssize[k + EXC_SLOT] = 0; ctotal[c] = (uint64_t)run64 + ale; }
     }
     if ((which & 2) && l == 0) {
-        const uint32_t slen = R.pv[e].d - R.pv[f].d, pads = PC_SEG_PAD * pc_n_seg(slen);
+        const uint32_t slen = C.ptot[c].d, pads = PC_SEG_PAD * pc_n_seg(slen);
         const uint32_t capn = (D->flags & H_N_POS) ? C.ncount[c] + slen / 128 + 3 * (slen / 16384) + 16 + pads : 0u;
         C.scap[k + NPOS_SLOT] = capn; C.soff[k + NPOS_SLOT] = 0; C.ssize[k + NPOS_SLOT] = 0; ctotal_n[c] = (uint64_t)((capn + 15u) & ~15u);
     }
@@ -2099,7 +2147,7 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
         wave_lds_sync();
         pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st, s_exc);
     }
-    else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), R.pv[e].d - R.pv[f].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
+    else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), C.ptot[c].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
@@ -2147,20 +2195,20 @@ __global__ void k_coords(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D,
 
 // =============================================================== chunk image (RfqChunk::calcTotalBufSize + write, src/rfqchunk.cpp:141-159,230-311)
 // mode 0: upper bound of the image size from stream capacities (before coding); mode 1: exact layout (after coding).
-__global__ void k_chunk_layout(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, Layout* __restrict__ L, uint32_t n_chunks, int exact, DevStatus* st) {
+__global__ void k_chunk_layout(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, Layout* __restrict__ L, uint32_t n_chunks, int exact, DevStatus* st) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const uint32_t f = C.first[c], e = C.first[c + 1], s = e - f, fl = C.flags[c], hf = D->flags, rlb = D->read_len_bytes, nn = D->n_normal;
     const bool il = (fl & C_PE_INTERLEAVED) != 0; const uint32_t h = il ? s / 2 : s;
-    const U4 a = R.pv[f], b = R.pv[e];
-    const uint32_t len = R.pq[e] - R.pq[f], seqCopied = b.d - a.d;
+    const U4 b = C.ptot[c];
+    const uint32_t len = R.pq[e] - R.pq[f], seqCopied = b.d;
     Layout o;
     o.n_reads = s; o.flags = fl;
     const uint32_t readLenBuf = (fl & C_READ_LEN_SAME) ? rlb : rlb * s;
     const uint32_t n1Len = (fl & C_NAME1_LEN_SAME) ? 1 : s, n2Len = (fl & C_NAME2_LEN_SAME) ? 1 : s, stLen = (fl & C_STRAND_LEN_SAME) ? 1 : s;
-    o.n1_size = (fl & C_NAME1_SAME) ? R.name1_len[f] : b.a - a.a;
-    o.n2_size = (fl & C_NAME2_SAME) ? (R.pv[f + 1].b - a.b) : b.b - a.b;
-    o.st_size = (fl & C_STRAND_SAME) ? (R.pv[f + 1].c - a.c) : b.c - a.c;
+    o.n1_size = (fl & C_NAME1_SAME) ? R.name1_len[f] : b.a;
+    o.n2_size = (fl & C_NAME2_SAME) ? name2_len_of(T, R, f) : b.b;
+    o.st_size = (fl & C_STRAND_SAME) ? line_len(T, f, 2) : b.c;
     o.seq_size = (seqCopied + 3) / 4;
     const size_t k0 = (size_t)c * MAX_STREAMS;
     uint32_t qsz = 0;
