@@ -30,10 +30,11 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     else if (n == "RFQ_GW_SHIFT") c->opt.gw_shift = set ? (int)std::min<long long>(30, std::max<long long>(4, num)) : d.gw_shift;
     else if (n == "RFQ_MATERIALISE") c->opt.materialise = set && num != 0;
     else if (n == "RFQ_TRACE") c->opt.trace = set && v != "0";
+    else if (n == "RFQ_G2_PAD") c->opt.g2_pad = set ? (uint32_t)num : 0u;
     else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
     return RFQ_OK;
 }
-static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE" };
+static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD" };
 
 extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (!out) return RFQ_E_ARG;

@@ -76,6 +76,7 @@ struct RfqOpts {
     int  gw_shift = 16;               // RFQ_GW_SHIFT       log2 of the smallest guess-and-verify segment
     bool materialise = false;         // RFQ_MATERIALISE=1  decode: qualities / bases expanded in HBM (the path of a streaming caller's non-final slices) on every call
     bool trace = false;               // RFQ_TRACE          a line on stderr about how chunk starts were found
+    uint32_t g2_pad = 0;              // RFQ_G2_PAD         profiling aid: bytes of unused dynamic LDS added to k_gather2 (fewer resident workgroups)
 };
 struct rfq_ctx {
     RfqOpts opt;

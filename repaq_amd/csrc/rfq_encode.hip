@@ -480,7 +480,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // (rare) chunks whose interleave test failed somewhere: their workgroups are the only ones of that launch that do not return at once
         for (int phase = 1; phase <= (is_pe ? 2 : 1); phase++) {
             if (phase == 2) hipLaunchKernelGGL(k_gather_redo_reset, dim3(n_chunks), dim3(64), 0, S, (const uint32_t*)redo, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
-            hipLaunchKernelGGL(k_gather2, dim3(bx, n_chunks), dim3(256), 0, S, T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(),
+            hipLaunchKernelGGL(k_gather2, dim3(bx, n_chunks), dim3(256), ctx->opt.g2_pad, S, T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(),
                                B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_RFLAG].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift,
                                cbits, cfail, phase == 2 ? (const uint32_t*)redo : (const uint32_t*)nullptr, dst);
             if (phase == 1) hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail, redo);
