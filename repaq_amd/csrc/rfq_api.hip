@@ -20,6 +20,7 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     const std::string n = name, v = value ? value : ""; const bool set = !v.empty(); const RfqOpts d;
     const long long num = set ? atoll(v.c_str()) : 0;
     if (n == "RFQ_GATHER") { if (set && v != "old" && v != "tile") return rfq_fail(c, RFQ_E_ARG, "RFQ_GATHER is old or tile"); c->opt.gather_old = v == "old"; }
+    else if (n == "RFQ_QUAL") { if (set && v != "bytes" && v != "masks") return rfq_fail(c, RFQ_E_ARG, "RFQ_QUAL is bytes or masks"); c->opt.qual_bytes = v == "bytes"; }
     else if (n == "RFQ_INDEX") { if (set && v != "2pass" && v != "1pass") return rfq_fail(c, RFQ_E_ARG, "RFQ_INDEX is 2pass or 1pass"); c->opt.index_2pass = v == "2pass"; }
     else if (n == "RFQ_IDX_TILES") { if (set && num != 4 && num != 8 && num != 16) return rfq_fail(c, RFQ_E_ARG, "RFQ_IDX_TILES is 4, 8 or 16"); c->opt.idx_tiles = set ? (int)num : d.idx_tiles; }
     else if (n == "RFQ_STREAMS") c->opt.one_stream = set && num == 1;
@@ -34,7 +35,7 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
     return RFQ_OK;
 }
-static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD" };
+static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD" };
 
 extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (!out) return RFQ_E_ARG;
@@ -102,7 +103,7 @@ extern "C" int rfq_get_header(rfq_ctx* c, uint8_t* out, size_t* len) {
     memcpy(out, c->h_hdr.bytes, c->h_hdr.len); *len = c->h_hdr.len;
     return RFQ_OK;
 }
-extern "C" void rfq_clear_header(rfq_ctx* c) { if (c) { c->have_hdr = false; memset(&c->h_hdr, 0, sizeof c->h_hdr); } }
+extern "C" void rfq_clear_header(rfq_ctx* c) { if (c) { c->have_hdr = false; c->dense_ok = false; memset(&c->h_hdr, 0, sizeof c->h_hdr); } }
 
 extern "C" int rfq_last_timings(const rfq_ctx* c, const char** names, float* ms, int cap) {
     if (!c) return 0;

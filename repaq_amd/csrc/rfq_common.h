@@ -64,6 +64,8 @@ struct DevHeader {
     uint8_t  normal[256];       // normalQualBuf()
     uint8_t  stream_of[256];    // quality byte -> index into normal[] (0xFF = none)
     uint8_t  is_exception[256]; // 1: neither major nor a normal value -> 5-byte exception record
+    uint8_t  dense[4];          // encode, match-mask mode: the coded values' streams by falling frequency in chunk 0 (k_dense_order): the first ones get planes built in LDS
+    uint32_t dense_valid;
     uint32_t valid;
 };
 
@@ -84,12 +86,20 @@ struct DevStatus {
     uint64_t total_bases;
     uint32_t first_empty;       // first read (interleaved order) with an empty line, ~0 if none
     uint32_t max_rec;           // longest record (four lines with their terminators) in bytes
-    uint32_t unit_bases, pad2_; // bases of every cut unit when they are all the same, else 0
+    uint32_t unit_bases;        // bases of every cut unit when they are all the same, else 0
+    uint32_t max_len;           // longest read (bases)
 };
 
 struct U4 { uint32_t a, b, c, d; };
 __device__ __host__ __forceinline__ U4 operator+(const U4& x, const U4& y) { U4 r; r.a = x.a + y.a; r.b = x.b + y.b; r.c = x.c + y.c; r.d = x.d + y.d; return r; }
 __device__ __host__ __forceinline__ U4 operator-(const U4& x, const U4& y) { U4 r; r.a = x.a - y.a; r.b = x.b - y.b; r.c = x.c - y.c; r.d = x.d - y.d; return r; }
+
+// the launch's dynamic LDS as an array `name` of `type` (the SIMT interpreter of the test build hands out a fixed 64 KB buffer)
+#ifdef RFQ_SIMT_EMULATION
+#define RFQ_DYN_SHARED(type, name) type* const name = (type*)emu::dyn_shared()
+#else
+#define RFQ_DYN_SHARED(type, name) extern __shared__ type name[]
+#endif
 
 // ---------------------------------------------------------------- wave64 primitives
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }

@@ -65,6 +65,7 @@ static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, u
 // Test / diagnostic switches of a context (rfq_set_option).  The RFQ_* environment variables of the same names are read ONCE, when the context is created
 // (no getenv on the batch paths - the switches changed chunk walking and emission silently per call, and getenv races a concurrent setenv).
 struct RfqOpts {
+    bool qual_bytes = false;          // RFQ_QUAL=bytes     encode: k_gather2 writes the quality bytes (qcat) also for files with <= 3 coded values (default there: match masks)
     bool gather_old = false;          // RFQ_GATHER=old     encode: the byte-wise gather (k_gather + k_packbytes) also for reads that fit a tile
     bool index_2pass = false;         // RFQ_INDEX=2pass    encode: newline bitmap -> scan -> line offsets instead of the one-pass index
     int  idx_tiles = 0;               // RFQ_IDX_TILES=4|8|16   text per workgroup of the one-pass index (x 16 KiB); 0 = default
@@ -128,6 +129,10 @@ struct rfq_ctx {
     // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
     DBuf b[120];
     DBuf out_img, out_fq1, out_fq2, out_acc, out_acc1, out_acc2;       // out_acc*: the results of a sliced encode / decode call, appended
+    bool dense_ok = false;                 // encode, match-mask mode: DevHeader::dense of the device header is set (k_dense_order; reset with the header)
+    bool qplane_dirty = true;              // encode, match-mask mode: the rare planes of b[B_QPLANE] may hold bits (fresh buffer, or a call that left early): zero them whole
+    uint32_t qplane_nd = 0, qplane_mask = 0; // ... dense planes the last batch used: how many, which (the others must be all-zero)
+    size_t qplane_stride = 0;              // ... words per plane the buffer is laid out with (fixed while the buffer is)
     std::vector<uint64_t> chunk_off;
     std::vector<uint64_t> scan_end[2];     // rfq_scan_batch: end offset of every chunk in each input stream
     StageTimer timer;

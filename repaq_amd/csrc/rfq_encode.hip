@@ -6,13 +6,14 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <cstddef>
 
 enum EncBuf {   // indices into rfq_ctx::b
     B_BITMAP0 = 0, B_BITMAP1, B_BLK0, B_BLK1, B_LO0, B_LO1, B_SCANTMP,
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_QPLANE, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 80, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -45,7 +46,7 @@ int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n) {
     KCHK(c, "k_hdr_from_bytes");
     HIPCHK(c, c->fetch(&c->h_hdr, c->d_hdr.p, sizeof(DevHeader), c->stream));
     HIPCHK(c, c->fetch_sync(c->stream));
-    c->have_hdr = true;
+    c->have_hdr = true; c->dense_ok = false;
     return RFQ_OK;
 }
 
@@ -320,7 +321,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // sequence lengths come from the line table alone; the names are parsed where the text is staged anyway (k_gather2), or by k_read_table for
     // the reads that need them earlier (chunk 0 of a first batch: the file header) / on the byte-wise gather path (all of them)
     const uint32_t ublocks = (n_units + 255) / 256;
-    HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 12));
+    HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 16));
     hipLaunchKernelGGL(k_read_lens, dim3(ublocks), dim3(256), 0, S, T, R.len, R.stored, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>(), dst);
     KCHK(ctx, "k_read_lens");
     scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1);
@@ -420,10 +421,30 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_hdr_pass2, dim3(hb), dim3(256), 0, HS, T, R, (const uint32_t*)C.first, H);
         if (is_pe) hipLaunchKernelGGL(k_hdr_pe, dim3((c0_reads / 2 + 255) / 256), dim3(256), 0, HS, T, R, (const uint32_t*)C.first, H);
         hipLaunchKernelGGL(k_hdr_finalize, dim3(1), dim3(64), 0, HS, T, H, D, is_pe ? 1 : 0, dst);
+        if (fast) { hipLaunchKernelGGL(k_dense_order, dim3(1), dim3(64), 0, HS, (const HdrStats*)H, D); ctx->dense_ok = true; }
         KCHK(ctx, "k_hdr_*");
         if (hdr_aside) HIPCHK(ctx, hipEventRecord(ctx->ev_mid, HS));
+    } else if (fast && !ctx->dense_ok) {
+        // a header that was set, not made (rfq_set_header: a worker of a multi-GPU queue, a later file): which coded values are frequent is taken from this batch's chunk 0
+        HdrStats* H = B[B_HSTATS].as<HdrStats>();
+        const uint32_t hb = std::min<uint32_t>(1024, (c0_reads + 3) / 4);
+        hipLaunchKernelGGL(k_hdr_init, dim3(1), dim3(128), 0, S, H);
+        hipLaunchKernelGGL(k_hdr_stats, dim3(hb), dim3(256), 0, S, T, R, (const uint32_t*)C.first, H);
+        hipLaunchKernelGGL(k_dense_order, dim3(1), dim3(64), 0, S, (const HdrStats*)H, D);
+        ctx->dense_ok = true;
+        HIPCHK(ctx, ctx->fetch(ctx->h_hdr.dense, (const uint8_t*)D + offsetof(DevHeader, dense), 4, S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
+    }
+    if (make_header && fast) {
+        // the tile gather is instantiated by the header (match masks for <= 3 coded quality values, bytes otherwise): a first batch waits for it here
+        if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));
+        HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
     }
     ctx->timer.end(S);
+    // match masks for files with at most four coded quality values (a NovaSeq-binned file: ':' ',' '#' and the 0xFF entry the reference's table gets when the
+    // N bases have no quality of their own); the most frequent two or three get planes built in LDS, the others are set bit by bit
+    const bool masks = fast && !ctx->opt.qual_bytes && ctx->h_hdr.valid && (ctx->h_hdr.flags & H_QUAL_BY_COL) && !(ctx->h_hdr.flags & H_DONT_QUAL) && ctx->h_hdr.n_normal >= 1u && ctx->h_hdr.n_normal <= 4u;
 
     HIPCHK(ctx, B[B_OVRAW].ensure((size_t)(is_pe ? n_units : 0) * 2 + 64));
     HIPCHK(ctx, B[B_SCANTMP2].ensure(std::max<size_t>(4096, (nr / SCAN_TILE + 2) * 16 + (nc / SCAN_TILE + 2) * 8)));
@@ -460,6 +481,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     ctx->timer.end(S);
 
+    if (masks) { ctx->timer.begin("quality_masks", S); ctx->timer.end(S); }   // (a marker, not a phase: k_gather2 leaves match masks instead of quality bytes - tests and the bench look for it)
     ctx->timer.begin(fast ? "gather" : "gather_bytes", S);                  // (which formulation ran: tests and the bench look at it)
     // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
     const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
@@ -476,13 +498,41 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, hipMemsetAsync(B[B_RFLAG].p, 0, nr, S));
         const uint32_t K = 1u << kshift;
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
+        // dynamic LDS of k_gather2: the staged text of K of the batch's longest records (+ slack), read 0's name / strand line, and - match-mask mode - three
+        // bit planes of K of the longest reads.  Six workgroups per CU need <= 26.8 KB each (measured: with five the kernel is 10 % slower).
+        const uint32_t text4 = (uint32_t)((((uint64_t)max_rec << kshift) + 64u + 15u) / 16u) + 8u;
+        G2Planes M; M.planes = nullptr; M.rare = nullptr; M.pstride = 0; M.nd = 0; M.pw = (uint32_t)((((uint64_t)hs.max_len << kshift) + 31u) / 32u) + 2u;
+        auto dyn_of = [&](uint32_t nd_) -> uint32_t { return text4 * 16u + (G2_REFN + G2_REFS + 32u) + 4u * nd_ * M.pw; };
+        if (masks) {
+            // dense planes: three if the workgroup still fits six to a CU (26.8 KB of LDS each: with five the kernel is 10 % slower), else two
+            M.nd = std::min<uint32_t>(ctx->h_hdr.n_normal, 3u);
+            if (M.nd == 3u && dyn_of(3u) + 64u > 26880u) M.nd = 2u;
+            // five planes laid out by the buffer's capacity (so that the planes' places are fixed while the buffer is), + rare[n_chunks] behind them
+            const size_t need_w = (catbytes >> 5) + 16, extra_w = nc / G2_PLANES + 16;
+            if (B[B_QPLANE].cap / 4 / G2_PLANES < need_w + extra_w || ctx->qplane_stride < need_w) {
+                HIPCHK(ctx, B[B_QPLANE].ensure((need_w + extra_w) * G2_PLANES * 4)); ctx->qplane_stride = B[B_QPLANE].cap / 4 / G2_PLANES - extra_w; ctx->qplane_dirty = true;
+            }
+            if ((ctx->qplane_stride + extra_w) * G2_PLANES * 4 > B[B_QPLANE].cap) { ctx->qplane_stride = B[B_QPLANE].cap / 4 / G2_PLANES - extra_w; ctx->qplane_dirty = true; }
+            uint32_t dmask = 0; for (uint32_t d = 0; d < M.nd; d++) dmask |= 1u << (ctx->h_hdr.dense[d] & 7u);
+            if (ctx->qplane_mask & ~dmask) ctx->qplane_dirty = true;        // (a plane that was stored whole is now set bit by bit: it has to start all-zero)
+            ctx->qplane_mask = dmask;
+            M.planes = B[B_QPLANE].as<uint32_t>(); M.pstride = ctx->qplane_stride; M.rare = M.planes + G2_PLANES * M.pstride;
+            if (ctx->qplane_dirty) HIPCHK(ctx, hipMemsetAsync(M.planes, 0, ((size_t)M.pstride * G2_PLANES + nc) * 4, S));
+            ctx->qplane_dirty = true; ctx->qplane_nd = M.nd;                // (dirty until this call's cleanup is queued)
+        }
+        const uint32_t dyn = dyn_of(M.nd) + ctx->opt.g2_pad;
         // phase 1: every chunk, names parsed on the way, mates taken for interleaved wherever the header allows; then the flag words; then phase 2 for the
         // (rare) chunks whose interleave test failed somewhere: their workgroups are the only ones of that launch that do not return at once
         for (int phase = 1; phase <= (is_pe ? 2 : 1); phase++) {
-            if (phase == 2) hipLaunchKernelGGL(k_gather_redo_reset, dim3(n_chunks), dim3(64), 0, S, (const uint32_t*)redo, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
-            hipLaunchKernelGGL(k_gather2, dim3(bx, n_chunks), dim3(256), ctx->opt.g2_pad, S, T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(),
-                               B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_RFLAG].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift,
-                               cbits, cfail, phase == 2 ? (const uint32_t*)redo : (const uint32_t*)nullptr, dst);
+            const uint32_t* only = phase == 2 ? (const uint32_t*)redo : (const uint32_t*)nullptr;
+            if (phase == 2) hipLaunchKernelGGL(k_gather_redo_reset, dim3(n_chunks), dim3(64), 0, S, only, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg,
+                                               masks ? M.planes : (uint32_t*)nullptr, M.pstride, (const DevHeader*)D, M.nd, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase);
+            if (masks) hipLaunchKernelGGL(k_mask_bounds, dim3(n_chunks), dim3(64), 0, S, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase, M.planes, M.pstride, (const DevHeader*)D, M.nd, bx, only);
+#define RFQ_G2_ARGS T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_RFLAG].as<uint8_t>(), \
+                    B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, cbits, cfail, only, text4, M
+            if (masks) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
+            else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
+#undef RFQ_G2_ARGS
             if (phase == 1) hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail, redo);
         }
         // the quality streams' scratch plan needs nothing else: the position coder can start as soon as the host has sized its arena
@@ -560,7 +610,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
         hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint16_t*)B[B_SNM].as<uint16_t>(),
                            B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase, B[B_SCRATCHN].as<uint8_t>(), (const uint64_t*)cbase_n,
-                           B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, nqg, g0, gn, dst);
+                           B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, nqg, g0, gn, dst,
+                           masks ? (const uint32_t*)B[B_QPLANE].as<uint32_t>() : (const uint32_t*)nullptr, (uint64_t)ctx->qplane_stride);
         return RFQ_OK;
     };
     ctx->timer.begin("pos_coder", S);
@@ -592,6 +643,11 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (A2 != S) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A2)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     }
     KCHK(ctx, "k_pos_coder");
+    if (masks) {                                                            // the rare planes back to all-zero (stream-ordered behind the coder that read them)
+        hipLaunchKernelGGL(k_rare_cleanup, dim3(n_chunks), dim3(256), 0, S, B[B_QPLANE].as<uint32_t>() + G2_PLANES * ctx->qplane_stride, B[B_QPLANE].as<uint32_t>(), (uint64_t)ctx->qplane_stride,
+                           (const DevHeader*)D, ctx->qplane_nd, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase);
+        ctx->qplane_dirty = false;
+    }
     ctx->timer.end(S);
     ctx->timer.begin("coords+layout", S);
     hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const uint32_t*)B[B_SEGB].as<uint32_t>(), n_seg);

@@ -423,9 +423,9 @@ __global__ void k_chunk_ends(Text T, const uint32_t* __restrict__ first, uint32_
 // pair) + per-block min / max for the partitioner's uniform-length fast path and the longest record (k_gather2 sizes its tiles by it).
 // (no atomics for the min / max: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
 __global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __restrict__ stored, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax, DevStatus* st) {
-    __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4];
+    __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4], s_ml[4];
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t tot = 0; uint32_t rec = 0, err = 0, fe = 0xFFFFFFFFu;        // rec: bytes of the unit's longest record
+    uint64_t tot = 0; uint32_t rec = 0, ml = 0, err = 0, fe = 0xFFFFFFFFu;   // rec: bytes of the unit's longest record, ml: bases of its longest read
     if (u < n_units) {
         for (uint32_t j = 0; j < upr; j++) {
             const uint32_t g = u * upr + j; int s; uint32_t r; read_loc(T, g, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r;
@@ -433,17 +433,17 @@ __global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __rest
             const uint32_t nl = p1 - 1 - p0, sl = p2 - 1 - p1, tl = p3 - 1 - p2, ql = p4 - 1 - p3;
             if (nl == 0 || sl == 0 || tl == 0 || ql == 0) { err |= DE_EMPTY_LINE; if (g < fe) fe = g; }
             if (ql < sl) err |= DE_QUAL_SHORT;
-            len[g] = sl; stored[g] = sl; tot += sl; if (p4 - p0 > rec) rec = p4 - p0;
+            len[g] = sl; stored[g] = sl; tot += sl; if (p4 - p0 > rec) rec = p4 - p0; if (sl > ml) ml = sl;
         }
         ulen[u] = tot;
     }
     uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
-    mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec); fe = wave_min(fe); err = wave_or(err);
-    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; if (err) { atomicOr(&st->err, err); if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); } }
+    mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec); ml = wave_max(ml); fe = wave_min(fe); err = wave_or(err);
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; s_ml[wave_id()] = ml; if (err) { atomicOr(&st->err, err); if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); } }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; if (s_rc[i] > rec) rec = s_rc[i]; }
-        blk_minmax[3 * blockIdx.x] = mn; blk_minmax[3 * blockIdx.x + 1] = mx; blk_minmax[3 * blockIdx.x + 2] = rec;
+        for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; if (s_rc[i] > rec) rec = s_rc[i]; if (s_ml[i] > ml) ml = s_ml[i]; }
+        blk_minmax[4 * blockIdx.x] = mn; blk_minmax[4 * blockIdx.x + 1] = mx; blk_minmax[4 * blockIdx.x + 2] = rec; blk_minmax[4 * blockIdx.x + 3] = ml;
     }
 }
 
@@ -471,15 +471,16 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
                             const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
     const int l = lane_id();
     // shortest / longest unit: every thread of the workgroup (1024: a single wave walked 44 k block entries in 158 us), then wave 0 goes on alone
-    __shared__ uint32_t s_mn[16], s_mx[16], s_rc[16];
-    uint32_t len_minmax[2], max_rec;
-    { uint32_t mn = 0xFFFFFFFFu, mx = 0, rc = 0; for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk_minmax[3 * i], b = blk_minmax[3 * i + 1], r = blk_minmax[3 * i + 2]; if (a < mn) mn = a; if (b > mx) mx = b; if (r > rc) rc = r; }
-      mn = wave_min(mn); mx = wave_max(mx); rc = wave_max(rc);
-      if (l == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rc; }
+    __shared__ uint32_t s_mn[16], s_mx[16], s_rc[16], s_ml[16];
+    uint32_t len_minmax[2], max_rec, max_len;
+    { uint32_t mn = 0xFFFFFFFFu, mx = 0, rc = 0, ml = 0;
+      for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk_minmax[4 * i], b = blk_minmax[4 * i + 1], r = blk_minmax[4 * i + 2], m = blk_minmax[4 * i + 3]; if (a < mn) mn = a; if (b > mx) mx = b; if (r > rc) rc = r; if (m > ml) ml = m; }
+      mn = wave_min(mn); mx = wave_max(mx); rc = wave_max(rc); ml = wave_max(ml);
+      if (l == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rc; s_ml[wave_id()] = ml; }
       __syncthreads();
       if (wave_id() != 0) return;
-      const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u; rc = (uint32_t)l < nw ? s_rc[l] : 0u;
-      len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); max_rec = wave_max(rc); }
+      const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u; rc = (uint32_t)l < nw ? s_rc[l] : 0u; ml = (uint32_t)l < nw ? s_ml[l] : 0u;
+      len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); max_rec = wave_max(rc); max_len = wave_max(ml); }
     uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0;
     if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
         // every unit has the same length L: a chunk is K = ceil(chunk_bases / L) units
@@ -514,7 +515,7 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
     if (l == 0) {
         st->n_chunks = c; st->n_units_used = start; st->max_chunk_reads = max_units * upr;
         st->max_chunk_bases = (uint32_t)(max_bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : max_bases);
-        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec; st->unit_bases = (n_units > 0 && len_minmax[0] == len_minmax[1]) ? len_minmax[0] : 0u;
+        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec; st->max_len = max_len; st->unit_bases = (n_units > 0 && len_minmax[0] == len_minmax[1]) ? len_minmax[0] : 0u;
     }
 }
 __global__ void k_chunk_ids(ChunkTab C, ReadTab R) {
@@ -681,6 +682,17 @@ __global__ void k_hdr_finalize(Text T, HdrStats* H, DevHeader* D, int is_pe, Dev
     b[9] = H->max_len > 255 ? 2 : 1;                       // never 4: src/rfqcodec.cpp:48-53 (second `if` is not `else if`)
     b[10] = (uint8_t)flags; b[11] = (uint8_t)(flags >> 8); b[12] = (uint8_t)dpos; b[13] = (uint8_t)dch; b[14] = (uint8_t)nbq; b[15] = (uint8_t)(-24); b[16] = (uint8_t)bins;
     hdr_derive(D);
+}
+
+// match-mask mode of k_gather2: which coded values get a plane built in LDS - the most frequent ones of chunk 0 (a NovaSeq-binned file codes ':' and ','
+// a few percent of the time each, '#' only under N bases, and the table's 0xFF entry never)
+__global__ void k_dense_order(const HdrStats* __restrict__ H, DevHeader* D) {
+    if (threadIdx.x || blockIdx.x) return;
+    const uint32_t nn = D->n_normal < 4u ? D->n_normal : 4u; uint32_t fr[4], ix[4];
+    for (uint32_t j = 0; j < 4; j++) { ix[j] = j; const uint32_t v = D->normal[j]; fr[j] = (j < nn && v < 128u) ? H->hist[v] : 0u; }
+    for (uint32_t a = 1; a < 4; a++) for (uint32_t b = a; b > 0 && fr[ix[b]] > fr[ix[b - 1]]; b--) { const uint32_t t = ix[b]; ix[b] = ix[b - 1]; ix[b - 1] = t; }   // (stable: ties keep the table's order)
+    for (uint32_t j = 0; j < 4; j++) D->dense[j] = (uint8_t)ix[j];
+    D->dense_valid = 1;
 }
 
 // =============================================================== per-chunk analysis (RfqCodec::encodeChunk pass 1, src/rfqcodec.cpp:181-287)
@@ -1666,24 +1678,119 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
         }
     }
 }
+// ---- MASKS mode (files with at most three coded quality values - a NovaSeq-binned file has three): no quality bytes leave the kernel.  A lane turns its 16
+// bytes into one 16-bit match mask per value and ORs them, shifted to their chunk position, into bit planes of the tile in LDS (ds_or, no return); after the
+// barrier the planes leave as whole 32-bit words - coalesced, plain stores - and are counted on the way (popcount per segment, last match: what QualCount
+// did with two LDS atomics per coded byte).  A word that straddles two tiles of a workgroup is carried to the next tile; one that straddles two workgroups is
+// OR-ed into global memory by both (k_mask_bounds has zeroed those words).  A byte that is neither the major value nor a coded one (rare: the header's table
+// comes from chunk 0) goes to qcat at its position, its bit into the exception plane (global atomicOr on a plane zeroed per batch).
+// The planes of a batch: the plane of coded value j (its index in the header's table, j < 4) at planes + j * pstride (u32 words; chunk c's words start at
+// qbase[c] >> 5), the exception plane at index 4.  The `nd` most frequent values (DevHeader::dense) are DENSE: built in LDS and stored whole.  The others -
+// on a NovaSeq-binned file '#', which only N bases carry, and the 0xFF entry the reference appends to the table of a file whose N bases have no quality of
+// their own (src/rfqheader.cpp:214-230) - and the exceptions are RARE: their planes stay all-zero between batches, bits are OR-ed in where there is one, rare[c]
+// remembers the chunks that have any, and k_rare_cleanup zeroes those again behind the coder.  (Three LDS planes of a 64-read tile would cost the kernel its
+// sixth resident workgroup - 10 % - on 150-base reads; two fit.)
+#define G2_PLANES 5u
+#define G2_PLANE_EXC 4u
+struct G2Planes { uint32_t* planes; uint64_t pstride; uint32_t pw, nd; uint32_t* rare; };      // pw: words per LDS plane; nd: dense planes; rare: [n_chunks]
+__device__ __forceinline__ void g2_quals_masks(const uint8_t* tx, const G2Read& m, uint32_t part, uint32_t P, uint32_t* pl, uint32_t pw, uint32_t wbase, uint32_t nd,
+                                               uint32_t pat0, uint32_t pat1, uint32_t pat2, uint32_t patm, const DevHeader* __restrict__ D, uint8_t* qd, uint32_t* __restrict__ gpl, uint64_t pstride,
+                                               uint32_t* __restrict__ segm_c, int* __restrict__ segc_c, uint32_t n_seg, uint32_t* __restrict__ rare_c) {
+    if (!m.on) return;
+    const uint32_t n = m.len, ng = (n + 15u) >> 4; const bool rc = m.rc;
+    for (uint32_t gi = part; gi < ng; gi += P) {
+        const uint32_t p0 = 16u * gi, nv = n - p0;                         // (a last, partial group reads past the line - in front of it, for a reversed mate - and masks those bits off)
+        uint32_t w[4]; lds_get16(tx, rc ? m.qsrc + n - p0 - 16u : m.qsrc + p0, w);
+        if (rc) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
+        const uint32_t valid = nv >= 16u ? 0xFFFFu : (1u << nv) - 1u;
+        const uint4 q = make_uint4(w[0], w[1], w[2], w[3]);
+        const uint32_t bit = m.qpos + p0 - wbase, wi = bit >> 5, sh = bit & 31u;
+        uint32_t known = eq_mask16c(q, patm);
+        auto plane = [&](uint32_t d, uint32_t pat) {
+            const uint32_t mv = eq_mask16c(q, pat); known |= mv;
+            const unsigned long long x = (unsigned long long)(mv & valid) << sh;
+            if ((uint32_t)x) atomicOr(&pl[d * pw + wi], (uint32_t)x);
+            if ((uint32_t)(x >> 32)) atomicOr(&pl[d * pw + wi + 1u], (uint32_t)(x >> 32));
+        };
+        if (nd > 0u) plane(0u, pat0);                                       // (nd is the same for every lane)
+        if (nd > 1u) plane(1u, pat1);
+        if (nd > 2u) plane(2u, pat2);
+        uint32_t rest = ~known & valid;
+        while (rest) {                                                      // (rare) neither the major value nor a dense one: a rare coded value, or one the header's table does not know
+            const uint32_t k = (uint32_t)__ffs((int)rest) - 1u; rest &= rest - 1u;
+            const uint32_t ww = k < 8u ? (k < 4u ? w[0] : w[1]) : (k < 12u ? w[2] : w[3]), pos = m.qpos + p0 + k, b = (ww >> (8u * (k & 3u))) & 0xFFu;
+            const uint32_t j = D->stream_of[b];
+            if (j < 4u && j < D->n_normal) { const size_t si = (size_t)j * n_seg + pos / PC_SEG_POS; atomicOr(&gpl[(size_t)j * pstride + (pos >> 5)], 1u << (pos & 31u)); atomicAdd(&segm_c[si], 1u); atomicMax(&segc_c[si], (int)pos); }
+            else { qd[pos] = (uint8_t)b; atomicOr(&gpl[(size_t)G2_PLANE_EXC * pstride + (pos >> 5)], 1u << (pos & 31u)); atomicAdd(&segm_c[(size_t)EXC_SLOT * n_seg + pos / PC_SEG_POS], 1u); }
+            *rare_c = 1u;
+        }
+    }
+}
+// the tile's planes -> global words [gw0, gw0 + nw) of each plane, counted per coder segment; the LDS planes are left zeroed, a word that the next tile of
+// this workgroup continues (carry) stays behind in s_carry.  or_first / or_last: that word is shared with another workgroup.
+__device__ __forceinline__ void g2_flush_masks(uint32_t* pl, uint32_t pw, uint32_t nd, uint32_t dense3 /* the dense planes' streams, a byte each */, uint32_t* s_carry, uint32_t* __restrict__ gpl, uint64_t pstride,
+                                               uint32_t gw0, uint32_t nw, bool carry, bool or_first, bool or_last,
+                                               size_t seg_index0 /* (c * MAX_STREAMS) * n_seg */, uint32_t n_seg, uint32_t* __restrict__ segm, int* __restrict__ segc) {
+    const uint32_t tid = threadIdx.x, seg0 = (gw0 << 5) / PC_SEG_POS;
+    for (uint32_t d = 0; d < nd; d++) {                                     // (uniform)
+        const uint32_t v = (dense3 >> (8u * d)) & 0xFFu;                   // LDS plane d holds coded value v
+        uint32_t c01 = 0; int l0 = -1, l1 = -1;
+        for (uint32_t i = tid; i < nw; i += blockDim.x) {
+            const uint32_t x = pl[d * pw + i]; pl[d * pw + i] = 0u;
+            const bool last = i + 1u == nw;
+            if (last && carry) { s_carry[d] = x; continue; }
+            const uint32_t gw = gw0 + i; uint32_t* const dst = gpl + (size_t)v * pstride + gw;
+            if ((i == 0u && or_first) || (last && or_last)) { if (x) atomicOr(dst, x); } else *dst = x;
+            if (x) { const uint32_t sg = ((gw << 5) / PC_SEG_POS) - seg0; const int lp = (int)((gw << 5) + 31u - (uint32_t)__clz((int)x));
+                     c01 += (uint32_t)__popc(x) << (16u * sg); if (sg) { if (lp > l1) l1 = lp; } else if (lp > l0) l0 = lp; }
+        }
+        if (!carry && tid == 0) s_carry[d] = 0u;
+        c01 = wave_sum(c01); l0 = wave_max(l0); l1 = wave_max(l1);
+        if ((tid & 63u) == 0 && c01) {
+            const size_t si = seg_index0 + (size_t)v * n_seg + seg0;
+            if (c01 & 0xFFFFu) { atomicAdd(&segm[si], c01 & 0xFFFFu); atomicMax(&segc[si], l0); }
+            if ((c01 >> 16) && seg0 + 1u < n_seg) { atomicAdd(&segm[si + 1u], c01 >> 16); atomicMax(&segc[si + 1u], l1); }
+        }
+    }
+}
+// the words of the batch's planes that two workgroups of k_gather2<true> OR into: zeroed (per = reads per workgroup, as the gather computes it)
+__global__ void k_mask_bounds(const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase, uint32_t* __restrict__ planes, uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd, uint32_t bx,
+                              const uint32_t* __restrict__ only) {
+    const uint32_t c = blockIdx.x; if (only && !only[c]) return;
+    const uint32_t f = first[c], e = first[c + 1], pq0 = pq[f];
+    uint32_t per = ((e - f) + bx - 1) / bx; per = (per + 1u) & ~1u;
+    for (uint32_t b = 1u + threadIdx.x; b < bx; b += blockDim.x) {
+        const uint32_t gs = f + b * per; if (gs >= e) break;
+        const uint32_t w = (uint32_t)(qbase[c] >> 5) + ((pq[gs] - pq0) >> 5);
+        for (uint32_t d = 0; d < nd; d++) planes[(size_t)D->dense[d] * pstride + w] = 0u;
+    }
+}
 // phase 1: every chunk, mates taken for interleaved wherever the header allows it (the names that decide are parsed in this very pass), names parsed and
 // compared; phase 2: only the chunks k_chunk_flags_b marked in `only` - their interleave test failed somewhere - once more with the mates as they stand.
-__global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
+// Dynamic LDS: [text4 x 16 bytes of staged text, slack included][read 0's name and strand line][MASKS: three planes of M.pw words].
+template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
-                                                 uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, DevStatus* st) {
-    constexpr uint32_t TILE4 = G2_CAP / 16 + 8, REFN = (TILE4 - 1) * 16, REFS = REFN + G2_REFN + 16;   // (byte offsets from the tile's first byte)
-    __shared__ uint4 s_text4[TILE4 + (G2_REFN + G2_REFS + 32) / 16];       // staged text | read 0's name | read 0's strand line
-    __shared__ uint32_t sh[G2_CNT]; __shared__ int sh_last[G2_CNT]; __shared__ uint8_t s_slot[256]; __shared__ uint32_t s_r0[8];
+                                                 uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, uint32_t text4, G2Planes M) {
+    RFQ_DYN_SHARED(uint4, g2_lds);
+    __shared__ uint32_t sh[MASKS ? 1 : G2_CNT]; __shared__ int sh_last[MASKS ? 1 : G2_CNT]; __shared__ uint8_t s_slot[MASKS ? 16 : 256]; __shared__ uint32_t s_r0[8], s_carry[4];
+    const uint32_t REFN = (text4 - 1u) * 16u, REFS = REFN + G2_REFN + 16u;      // (byte offsets from the tile's first byte)
+    uint32_t* const pl = (uint32_t*)(g2_lds + text4 + (G2_REFN + G2_REFS + 32u) / 16u);
     const uint32_t c = blockIdx.y;
     const bool redo = only != nullptr;
     if (redo && !only[c]) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t* __restrict__ pq = R.pq;
-    for (uint32_t i = tid; i < G2_CNT; i += blockDim.x) { sh[i] = 0; sh_last[i] = -1; }
     const uint32_t nn_s = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, nslot = nn_s + 1u;
-    uint32_t nrep = 1; while (nrep < 16u && 4u * nrep * nslot <= G2_CNT) nrep *= 2u;
-    for (uint32_t i = tid; i < 256; i += blockDim.x) { const uint32_t j = D->stream_of[i]; s_slot[i] = (uint8_t)(j < nn_s ? j : nn_s); }
+    uint32_t nrep = 1;
+    if (!MASKS) {
+        for (uint32_t i = tid; i < G2_CNT; i += blockDim.x) { sh[i] = 0; sh_last[i] = -1; }
+        while (nrep < 16u && 4u * nrep * nslot <= G2_CNT) nrep *= 2u;
+        for (uint32_t i = tid; i < 256; i += blockDim.x) { const uint32_t j = D->stream_of[i]; s_slot[i] = (uint8_t)(j < nn_s ? j : nn_s); }
+    } else {
+        for (uint32_t i = tid; i < M.nd * M.pw; i += blockDim.x) pl[i] = 0u;
+        if (tid < 4u) s_carry[tid] = 0u;
+    }
     const uint32_t f = first[c], e = first[c + 1];
     const bool two = T.paired == 1, can0 = T.paired != 0 && D->support_interleaved != 0, il = can0 && !redo;
     const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
@@ -1693,7 +1800,10 @@ __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uin
     const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;              // K reads per tile, P threads per read
     const uint32_t j = tid >> pshift, part = tid & (P - 1u);
     QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
-    uint4* const buf4 = s_text4 + 1; const uint8_t* const tx = (const uint8_t*)buf4;
+    const uint32_t nd = MASKS ? M.nd : 0u, dense3 = (uint32_t)D->dense[0] | ((uint32_t)D->dense[1] << 8) | ((uint32_t)D->dense[2] << 16);     // planes built in LDS, and whose they are
+    const uint32_t pat0 = (uint32_t)D->normal[dense3 & 0xFFu] * 0x01010101u, pat1 = (uint32_t)D->normal[(dense3 >> 8) & 0xFFu] * 0x01010101u, pat2 = (uint32_t)D->normal[(dense3 >> 16) & 0xFFu] * 0x01010101u, patm = (D->major & 0xFFu) * 0x01010101u;
+    uint32_t* const gpl = M.planes + (MASKS ? (size_t)(qbase[c] >> 5) : (size_t)0);        // the chunk's words of plane 0
+    uint4* const buf4 = g2_lds + 1; const uint8_t* const tx = (const uint8_t*)buf4;
     G2Ref r0; G2Acc acc; acc.bits = CF_ALL; acc.fail = 0xFFFFFFFFu;
     const bool parse = !redo && gs < ge;                                    // block-uniform
     if (parse) {
@@ -1718,25 +1828,47 @@ __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uin
         const G2Geo g = g2_geo(T, two, cur, cnt);
         g2_stage(T, two, g, buf4, tid);
         const G2Read m = g2_read(T, pq, g, f, pq0, il, cur, j, cnt);
-        const uint32_t qbeg = uni32(pq[cur]) - pq0;                          // the tile's first quality position (chunk-relative)
+        const uint32_t qbeg = uni32(pq[cur]) - pq0, qend = uni32(pq[cur + cnt]) - pq0;   // the tile's quality positions (chunk-relative)
         __syncthreads();                                                    // (drains the LDS-DMA)
         qc.seg0 = qbeg / PC_SEG_POS;
         if (parse && (uint32_t)wave_id() == (tix & 3u)) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (wave-uniform: this tile's parsing wave)
-        g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
-        __syncthreads();                                                    // the text is free for the next tile; the tile's counts are complete
-        qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
+        if (MASKS) {
+            if (tid < nd && s_carry[tid]) atomicOr(&pl[tid * M.pw], s_carry[tid]);       // the word the tile in front left unfinished
+            g2_quals_masks(tx, m, part, P, pl, M.pw, qbeg & ~31u, nd, pat0, pat1, pat2, patm, D, qd, gpl, M.pstride, segm + (size_t)c * MAX_STREAMS * n_seg, segc + (size_t)c * MAX_STREAMS * n_seg, n_seg, M.rare + c);
+            g2_bases(tx, m, part, P, lpk, lnb, rflag);
+        } else g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
+        __syncthreads();                                                    // the text is free for the next tile; the tile's counts / planes are complete
+        if (MASKS) {
+            const uint32_t gw0 = qbeg >> 5, nw = ((qend + 31u) >> 5) - gw0; const bool last_tile = cur + cnt >= ge;
+            g2_flush_masks(pl, M.pw, nd, dense3, s_carry, gpl, M.pstride, gw0, nw, !last_tile && (qend & 31u) != 0u, cur == gs && gs > f && (qbeg & 31u) != 0u, last_tile && ge < e && (qend & 31u) != 0u,
+                           (size_t)c * MAX_STREAMS * n_seg, n_seg, segm, segc);
+        } else qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
     }
     if (parse) {
         const uint32_t bits = wave_and(acc.bits), fail = wave_min(acc.fail);
         if ((tid & 63u) == 0) { if (bits != CF_ALL) atomicAnd(&cbits[c], bits); if (fail != 0xFFFFFFFFu) atomicMin(&cfail[c], fail); }
     }
-    (void)st;
 }
 // phase 2 of the gather re-counts the qualities of the chunks it repeats: their per-(stream, segment) entries back to "nothing seen"
-__global__ void k_gather_redo_reset(const uint32_t* __restrict__ only, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
+__device__ __forceinline__ uint32_t dense_mask_of(const DevHeader* __restrict__ D, uint32_t nd) { uint32_t m = 0; for (uint32_t d = 0; d < nd; d++) m |= 1u << D->dense[d]; return m; }
+__device__ __forceinline__ void k_rare_zero_chunk(uint32_t* __restrict__ planes, uint64_t pstride, uint32_t dense_mask, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase, uint32_t c) {
+    const uint32_t nw = (pq[first[c + 1]] - pq[first[c]] + 31u) >> 5; const size_t w0 = (size_t)(qbase[c] >> 5);
+    for (uint32_t v = 0; v < G2_PLANES; v++) if (!((dense_mask >> v) & 1u)) for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) planes[(size_t)v * pstride + w0 + i] = 0u;
+}
+// (xplane: the planes of MASKS mode, or null - the chunk's words of the rare planes are zeroed: the repeat sets them afresh)
+__global__ void k_gather_redo_reset(const uint32_t* __restrict__ only, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
+                                    uint32_t* __restrict__ xplane, uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase) {
     const uint32_t c = blockIdx.x; if (!only[c]) return;
     const size_t k = (size_t)c * MAX_STREAMS * n_seg;
     for (uint32_t i = threadIdx.x; i < MAX_STREAMS * n_seg; i += blockDim.x) { segm[k + i] = 0u; segc[k + i] = -1; }
+    if (xplane) k_rare_zero_chunk(xplane, pstride, dense_mask_of(D, nd), pq, first, qbase, c);
+}
+// behind the coder: the rare planes all-zero again (chunks that set bits in them are marked in rare[])
+__global__ void k_rare_cleanup(uint32_t* __restrict__ rare, uint32_t* __restrict__ planes, uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase) {
+    const uint32_t c = blockIdx.x; if (!rare[c]) return;
+    k_rare_zero_chunk(planes, pstride, dense_mask_of(D, nd), pq, first, qbase, c);
+    __syncthreads();
+    if (threadIdx.x == 0) rare[c] = 0u;
 }
 // 16 consecutive codes / N bits of a loose slot from base index b on (b + 16 may pass the slot's end: the caller masks)
 __device__ __forceinline__ uint32_t loose_codes(const uint32_t* __restrict__ lpk, uint32_t ld, uint32_t b) {
@@ -1980,6 +2112,46 @@ struct PcStream {
     int prev_carry, zero_carry;             // last match / last non-match before the current step
     uint32_t outpos; uint8_t* out; uint32_t room;
 };
+// one stream, one step of 4096 positions: the tokens of the lanes' words to the stream's slot, carries updated.  B: the bytes an exception record quotes (MODE PC_EXCEPT)
+template <int MODE> __device__ __forceinline__ void pc_stream_step(PcStream& s, const uint8_t* __restrict__ B, uint32_t step, uint32_t p0, int l, unsigned long long below) {
+    const uint64_t m = s.m_cur;
+    const unsigned long long has1 = __ballot(m != 0);
+    if (!has1) { s.zero_carry = (int)(step * 4096u + 4095u); return; }   // nothing to code in these 4096 positions
+    const unsigned long long has0 = __ballot(~m != 0);
+    // last match / last non-match before my word: the nearest earlier lane that has one (ballot + one permute), else the carry
+    const int mylast = m ? (int)p0 + 63 - __clzll((long long)m) : -1;
+    const int myzero = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1;
+    const unsigned long long b1 = has1 & below, b0m = has0 & below;
+    const int src1 = b1 ? 63 - __clzll((long long)b1) : 0, src0 = b0m ? 63 - __clzll((long long)b0m) : 0;
+    const int got1 = __shfl(mylast, src1), got0 = __shfl(myzero, src0);
+    const int prev_in = b1 ? got1 : s.prev_carry, zero_in = b0m ? got0 : s.zero_carry;
+    // matches continuing right after my word (for run lengths): leading ones of the next lane's word (the next step's first word
+    // for lane 63 - also when that step belongs to the next segment)
+    const uint32_t lead = (m == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);
+    const uint32_t lead_n = (s.m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~s.m_next) - 1);
+    uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
+    if (l == 63) after = after63;
+    uint32_t bytes; uint64_t pk = 0;
+    if (MODE == PC_EXCEPT) bytes = 5u * (uint32_t)__popcll(m);
+    else { PackSink ps; pc_gen_tokens(m, p0, prev_in, zero_in, after, ps); bytes = ps.n; pk = ps.pk; }
+    const uint32_t incl = wave_incl_sum(bytes);
+    uint32_t o = s.outpos + incl - bytes;
+    const uint32_t tot = wave_last(incl);
+    if (s.outpos + tot <= s.room) {
+        uint8_t* out = s.out;
+        if (MODE == PC_EXCEPT) {
+            uint64_t mm = m;
+            while (mm) { const int b = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)b]; st_u32(out + o + 1, p0 + (uint32_t)b); o += 5; }
+        } else if (bytes <= 8) {
+            for (uint32_t k = 0; k < bytes; k++) out[o + k] = (uint8_t)(pk >> (8 * k));
+        } else { StoreSink ss; ss.p = out + o; pc_gen_tokens(m, p0, prev_in, zero_in, after, ss); }   // dense word: regenerate straight to memory
+    }
+    s.outpos += tot;
+    // carries: the last lane that has a match / a non-match in this step
+    const int pl = __shfl(mylast, 63 - __clzll((long long)has1));
+    if (pl > s.prev_carry) s.prev_carry = pl;
+    if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > s.zero_carry) s.zero_carry = zl; }
+}
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
 // with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  The bytes go to S[t].out[0..).
 template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
@@ -2029,47 +2201,7 @@ template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wa
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
 #pragma unroll
-        for (int t = 0; t < G; t++) {
-            if (!S[t].on) continue;                                           // wave-uniform
-            PcStream& s = S[t];
-            const uint64_t m = s.m_cur;
-            const unsigned long long has1 = __ballot(m != 0);
-            if (!has1) { s.zero_carry = (int)(step * 4096u + 4095u); continue; }   // nothing to code in these 4096 positions
-            const unsigned long long has0 = __ballot(~m != 0);
-            // last match / last non-match before my word: the nearest earlier lane that has one (ballot + one permute), else the carry
-            const int mylast = m ? (int)p0 + 63 - __clzll((long long)m) : -1;
-            const int myzero = (~m) ? (int)p0 + 63 - __clzll((long long)~m) : -1;
-            const unsigned long long b1 = has1 & below, b0m = has0 & below;
-            const int src1 = b1 ? 63 - __clzll((long long)b1) : 0, src0 = b0m ? 63 - __clzll((long long)b0m) : 0;
-            const int got1 = __shfl(mylast, src1), got0 = __shfl(myzero, src0);
-            const int prev_in = b1 ? got1 : s.prev_carry, zero_in = b0m ? got0 : s.zero_carry;
-            // matches continuing right after my word (for run lengths): leading ones of the next lane's word (the next step's first word
-            // for lane 63 - also when that step belongs to the next segment)
-            const uint32_t lead = (m == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~m) - 1);
-            const uint32_t lead_n = (s.m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~s.m_next) - 1);
-            uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
-            if (l == 63) after = after63;
-            uint32_t bytes; uint64_t pk = 0;
-            if (MODE == PC_EXCEPT) bytes = 5u * (uint32_t)__popcll(m);
-            else { PackSink ps; pc_gen_tokens(m, p0, prev_in, zero_in, after, ps); bytes = ps.n; pk = ps.pk; }
-            const uint32_t incl = wave_incl_sum(bytes);
-            uint32_t o = s.outpos + incl - bytes;
-            const uint32_t tot = wave_last(incl);
-            if (s.outpos + tot <= s.room) {
-                uint8_t* out = s.out;
-                if (MODE == PC_EXCEPT) {
-                    uint64_t mm = m;
-                    while (mm) { const int b = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)b]; st_u32(out + o + 1, p0 + (uint32_t)b); o += 5; }
-                } else if (bytes <= 8) {
-                    for (uint32_t k = 0; k < bytes; k++) out[o + k] = (uint8_t)(pk >> (8 * k));
-                } else { StoreSink ss; ss.p = out + o; pc_gen_tokens(m, p0, prev_in, zero_in, after, ss); }   // dense word: regenerate straight to memory
-            }
-            s.outpos += tot;
-            // carries: the last lane that has a match / a non-match in this step
-            const int pl = __shfl(mylast, 63 - __clzll((long long)has1));
-            if (pl > s.prev_carry) s.prev_carry = pl;
-            if (has0) { const int zl = __shfl(myzero, 63 - __clzll((long long)has0)); if (zl > s.zero_carry) s.zero_carry = zl; }
-        }
+        for (int t = 0; t < G; t++) if (S[t].on) pc_stream_step<MODE>(S[t], B, step, p0, l, below);      // (wave-uniform)
 #pragma unroll
         for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = mask_of(raw_n, p0 + 8192u, S[t].q); }
         raw_n = loadc(step + 3, p0 + 12288u);
@@ -2118,6 +2250,86 @@ template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void pc
         if (S[t].outpos > S[t].room) atomicOr(&st->err, (uint32_t)DE_CORRUPT);   // (would mean pc_seg_cap is wrong: nothing was written past the slot)
     }
 }
+// ---- the same over MATCH MASKS: k_gather2<true> leaves, for files with few coded quality values, one bit per position and value instead of the quality
+// bytes (planes: value v's u64 of the chunk's positions [64 k, 64 k + 64) at bits[v][k]; the exception plane behind them).  A lane's 64 positions are one
+// 8-byte load per stream and step - the byte form loads 64 bytes and compares them with every value (~120 instructions per stream and step) - and the
+// gather writes 0.375 - 0.5 B per base instead of 1.
+template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_planes(const uint8_t* __restrict__ qbytes, uint32_t len, PcStream (&S)[G], const unsigned long long* const (&bits)[G], uint32_t step0, uint32_t step1) {
+    const int l = lane_id();
+    const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;
+    const uint32_t nst = (len + 4095u) / 4096u, q0 = step0 * 4096u + 64u * (uint32_t)l;
+    auto load = [&](int t, uint32_t step_, uint32_t p_) -> uint64_t {
+        if (step_ >= nst || p_ >= len) return 0ull;
+        uint64_t m_ = bits[t][p_ >> 6]; if (len - p_ < 64u) m_ &= (1ull << (len - p_)) - 1ull; return m_; };
+    uint64_t ahead[G];                                                      // the masks of step + 2: requested two steps before they are coded
+#pragma unroll
+    for (int t = 0; t < G; t++) { ahead[t] = 0; if (S[t].on) { S[t].m_cur = load(t, step0, q0); S[t].m_next = load(t, step0 + 1u, q0 + 4096u); ahead[t] = load(t, step0 + 2u, q0 + 8192u); S[t].outpos = 0; } }
+    if (MODE == PC_MATCH && step0 > 0) {
+        // the last non-match in front of the segment: back step by step until every stream has met one
+        bool need[G]; bool any = false;
+#pragma unroll
+        for (int t = 0; t < G; t++) { need[t] = S[t].on; any = any || need[t]; }
+        for (uint32_t sb = step0; any && sb > 0; ) {                        // wave-uniform
+            sb--; const uint32_t pb = sb * 4096u + 64u * (uint32_t)l;
+            any = false;
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                if (!need[t]) continue;
+                const uint64_t z = ~load(t, sb, pb);
+                const unsigned long long h0 = __ballot(z != 0);
+                if (h0) { const int v = z ? (int)pb + 63 - __clzll((long long)z) : -1; S[t].zero_carry = __shfl(v, 63 - __clzll((long long)h0)); need[t] = false; }
+                else any = true;
+            }
+        }
+    }
+    for (uint32_t step = step0; step < step1; step++) {
+        const uint32_t p0 = step * 4096u + 64u * (uint32_t)l;
+#pragma unroll
+        for (int t = 0; t < G; t++) if (S[t].on) pc_stream_step<MODE>(S[t], qbytes, step, p0, l, below);      // (wave-uniform)
+#pragma unroll
+        for (int t = 0; t < G; t++) if (S[t].on) { S[t].m_cur = S[t].m_next; S[t].m_next = ahead[t]; ahead[t] = load(t, step + 3u, p0 + 12288u); }
+    }
+}
+// planes: plane v of the batch at planes + v * pstride (u32 words); the chunk's words start at qbase >> 5.  Streams j0 .. jend - 1 of the quality values,
+// or (MODE PC_EXCEPT, j0 = EXC_SLOT) the exception records from plane 3 and the bytes k_gather2 kept at the exceptions' positions in qcat.
+template <int MODE, int G> __device__ __forceinline__ void pc_run_planes(const ChunkTab& C, const DevHeader* __restrict__ D, const uint32_t* __restrict__ planes, uint64_t pstride, const uint8_t* __restrict__ qbytes, uint32_t len,
+                            uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg,
+                            uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, DevStatus* st) {
+    const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
+    const uint32_t step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
+    if (step0 >= nsteps) return;
+    PcStream S[G]; size_t kk[G]; const unsigned long long* bits[G]; bool any = false;
+    const size_t w0 = (size_t)(C.qbase[c] >> 5);
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        const uint32_t j = j0 + (uint32_t)t;
+        S[t].on = false; kk[t] = 0; bits[t] = nullptr;
+        if (j >= jend) continue;
+        const size_t k = (size_t)c * MAX_STREAMS + j; kk[t] = k;
+        const uint32_t cap = C.scap[k];
+        if (cap == 0) continue;                                            // stream not present
+        const size_t s0i = k * n_seg;
+        if (segm[s0i + seg] == 0) continue;                                // nothing to code in this segment: its byte count stays 0
+        S[t].on = true; any = true;
+        S[t].mode = MODE; S[t].q = 0; S[t].outpos = 0;
+        bits[t] = (const unsigned long long*)(planes + (size_t)(MODE == PC_EXCEPT ? G2_PLANE_EXC : j) * pstride + w0);
+        int prev = -1;
+        for (int s = (int)seg - 1; s >= 0 && prev < 0; s--) prev = segc[s0i + (uint32_t)s];
+        S[t].prev_carry = prev; S[t].zero_carry = -1;
+        uint32_t off = 0;
+        for (uint32_t s = 0; s < seg; s++) off += pc_seg_cap(MODE == PC_EXCEPT, segm[s0i + s], PC_SEG_POS);
+        const uint32_t own = pc_seg_cap(MODE == PC_EXCEPT, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
+        S[t].out = scratch + cbase[c] + C.soff[k] + off; S[t].room = off + own <= cap ? own : 0u;
+    }
+    if (!any) return;                                                      // wave-uniform
+    wave_pos_encode_planes<MODE, G>(qbytes, len, S, bits, step0, step1);
+#pragma unroll
+    for (int t = 0; t < G; t++) if (S[t].on && lane_id() == 0) {
+        segb[kk[t] * n_seg + seg] = S[t].outpos;
+        if (S[t].outpos > S[t].room) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
+    }
+    (void)D;
+}
 // bytes of every stream of a chunk = sum of its segments' byte counts; one wave per chunk
 __global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint32_t n_seg) {
     const uint32_t c = blockIdx.x; const int l = lane_id();
@@ -2131,7 +2343,7 @@ __global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint3
 __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint16_t* __restrict__ snm,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint8_t* __restrict__ scratch_n, const uint64_t* __restrict__ cbase_n,
                             uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
-                            uint32_t n_qgroups, uint32_t g0, uint32_t gn, DevStatus* st) {
+                            uint32_t n_qgroups, uint32_t g0, uint32_t gn, DevStatus* st, const uint32_t* __restrict__ planes, uint64_t pstride) {
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; a different placement only costs speed).  All
     // (group, segment) workgroups of chunk c are given ids congruent to c mod 8, so a chunk's data stays in ONE private L2.
     const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, per_chunk = gn * n_seg;
@@ -2140,7 +2352,11 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
     const uint32_t c = (idx / per_chunk) * 8u + xcd, rest = idx % per_chunk, grp = g0 + rest / n_seg, seg = rest % n_seg;
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
-    if (grp < n_qgroups) pc_run<PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
+    if (planes && grp <= n_qgroups) {                                      // (k_gather2<true> ran: match masks, not bytes)
+        if (grp < n_qgroups) pc_run_planes<PC_MATCH, PC_G>(C, D, planes, pstride, nullptr, R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, st);
+        else pc_run_planes<PC_EXCEPT, 1>(C, D, planes, pstride, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, st);
+    }
+    else if (grp < n_qgroups) pc_run<PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
     else if (grp == n_qgroups) {
         __shared__ uint8_t s_exc[256];                                      // (a workgroup is one wave)
         for (uint32_t v = (uint32_t)lane_id(); v < 256u; v += 64u) s_exc[v] = D->is_exception[v] ? 1 : 0;

@@ -26,6 +26,8 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __shared__ static thread_local
+// dynamic shared memory (the launch's shmem argument): one 64 KB buffer per interpreter thread - a worker runs one block at a time
+namespace emu { inline void* dyn_shared() { alignas(16) static thread_local unsigned char buf[65536]; return buf; } }
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 

@@ -123,13 +123,51 @@ def test_strand_lines_of_equal_length_and_different_bytes(codec, gather):
     assert ("gather_bytes" if gather == "bytes" else "gather") in dict(codec.timings())
 
 
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:6], ids=[m[0] for m in MULTI[:6]])
+def test_multichunk_quality_bytes_instead_of_masks_matches_oracle(codec, label, prof, reads, seed, cb, paired, kw):
+    """RFQ_QUAL=bytes: k_gather2 writes the quality bytes and counts them (the path of files with more than three coded values) where the default is match masks."""
+    codec.set_option("RFQ_QUAL", "bytes")
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+    assert "quality_masks" not in dict(codec.timings())
+
+
+def test_match_masks_with_values_chunk_0_does_not_have(codec):
+    """Match-mask mode (<= 3 coded quality values in the header, which comes from chunk 0): values that first appear in later chunks are exception records -
+    their bytes go to qcat at their positions, their bits to the exception plane; runs of them, at word / tile / segment borders, in reversed mates."""
+    import random
+    rng = random.Random(5)
+    for paired, prof in ((O.SE, O.NOVA_SE150), (O.PE_TWO_FILES, O.NOVA_PE150)):
+        fq1, fq2 = O.gen(prof, 900, seed=41)
+        def spoil(fq, first_read):
+            lines = fq.split(b"\n")
+            for k in range(first_read, len(lines) // 4):
+                q = bytearray(lines[4 * k + 3])
+                r = rng.random()
+                if r < 0.3:
+                    for _ in range(rng.randrange(1, 4)): q[rng.randrange(len(q))] = rng.choice(b"!5?A")
+                elif r < 0.4:
+                    a = rng.randrange(len(q)); b = min(len(q), a + rng.randrange(1, 80)); q[a:b] = bytes([rng.choice(b"5?")]) * (b - a)
+                elif r < 0.45:
+                    q[:] = bytes([rng.choice(b"!A")]) * len(q)
+                lines[4 * k + 3] = bytes(q)
+            return b"\n".join(lines)
+        a = spoil(fq1, 300); b = spoil(fq2, 300) if fq2 else b""       # (behind chunk 0 for both chunk sizes: the header keeps its three values)
+        for cb in (20000, 33000):
+            want = O.encode_file(a, b, paired, cb)
+            assert E.encode(codec, a, b, paired, cb) == want
+            assert "quality_masks" in dict(codec.timings())
+            with codec.option("RFQ_QUAL", "bytes"):
+                assert E.encode(codec, a, b, paired, cb) == want
+
+
 def test_gather_paths_are_the_ones_expected(codec):
     """The tile gather (k_gather2 + k_seqpack) is what runs by default - also when a mate of an interleaved chunk holds bytes outside A/C/G/T/N
     (Read::changeToReverseComplement turns them into N, lower case into the upper-case complement) - and reads too long for a tile of two
     take the byte-wise gather."""
     fq1, fq2 = O.gen(O.NOVA_PE150, 200, seed=31)
     assert E.encode(codec, fq1, fq2, O.PE_TWO_FILES, 20000) == O.encode_file(fq1, fq2, O.PE_TWO_FILES, 20000)
-    assert "gather" in dict(codec.timings())
+    assert "gather" in dict(codec.timings()) and "quality_masks" in dict(codec.timings())     # (a NovaSeq-binned file: three coded quality values)
     lines = fq2.split(b"\n")
     for k, ch in ((150, b"r"), (151, b"a"), (152, b"n"), (170, b"."), (171, b"g")):     # mates of the second chunk or later (chunk 0 must be clean: the header is made from it)
         lines[4 * k + 1] = lines[4 * k + 1][:30] + ch + lines[4 * k + 1][31:]
