@@ -508,7 +508,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             M.nd = std::min<uint32_t>(ctx->h_hdr.n_normal, 3u);
             if (M.nd == 3u && dyn_of(3u) + 64u > 26880u) M.nd = 2u;
             // five planes laid out by the buffer's capacity (so that the planes' places are fixed while the buffer is), + rare[n_chunks] behind them
-            const size_t need_w = (catbytes >> 5) + 16, extra_w = nc / G2_PLANES + 16;
+            const size_t need_w = (catbytes >> 5) + 16, extra_w = nc * (1u + G2_RARE_LIST) / G2_PLANES + 16;
             if (B[B_QPLANE].cap / 4 / G2_PLANES < need_w + extra_w || ctx->qplane_stride < need_w) {
                 HIPCHK(ctx, B[B_QPLANE].ensure((need_w + extra_w) * G2_PLANES * 4)); ctx->qplane_stride = B[B_QPLANE].cap / 4 / G2_PLANES - extra_w; ctx->qplane_dirty = true;
             }
@@ -517,7 +517,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             if (ctx->qplane_mask & ~dmask) ctx->qplane_dirty = true;        // (a plane that was stored whole is now set bit by bit: it has to start all-zero)
             ctx->qplane_mask = dmask;
             M.planes = B[B_QPLANE].as<uint32_t>(); M.pstride = ctx->qplane_stride; M.rare = M.planes + G2_PLANES * M.pstride;
-            if (ctx->qplane_dirty) HIPCHK(ctx, hipMemsetAsync(M.planes, 0, ((size_t)M.pstride * G2_PLANES + nc) * 4, S));
+            if (ctx->qplane_dirty) HIPCHK(ctx, hipMemsetAsync(M.planes, 0, ((size_t)M.pstride * G2_PLANES + nc * (1u + G2_RARE_LIST)) * 4, S));
             ctx->qplane_dirty = true; ctx->qplane_nd = M.nd;                // (dirty until this call's cleanup is queued)
         }
         const uint32_t dyn = dyn_of(M.nd) + ctx->opt.g2_pad;

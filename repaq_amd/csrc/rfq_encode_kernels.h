@@ -1692,7 +1692,12 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
 // sixth resident workgroup - 10 % - on 150-base reads; two fit.)
 #define G2_PLANES 5u
 #define G2_PLANE_EXC 4u
-struct G2Planes { uint32_t* planes; uint64_t pstride; uint32_t pw, nd; uint32_t* rare; };      // pw: words per LDS plane; nd: dense planes; rare: [n_chunks]
+#define G2_RARE_LIST 255u          // words of rare planes a chunk may touch before the cleanup zeroes its whole extent instead
+struct G2Planes { uint32_t* planes; uint64_t pstride; uint32_t pw, nd; uint32_t* rare; };      // pw: words per LDS plane; nd: dense planes; rare: [n_chunks][1 + G2_RARE_LIST]: count, then (plane << 28 | word of the chunk)
+__device__ __forceinline__ void g2_rare_or(uint32_t* __restrict__ gpl, uint64_t pstride, uint32_t* __restrict__ rare_c, uint32_t plane, uint32_t pos) {
+    const uint32_t old = atomicOr(&gpl[(size_t)plane * pstride + (pos >> 5)], 1u << (pos & 31u));
+    if (old == 0u) { const uint32_t k = atomicAdd(rare_c, 1u); if (k < G2_RARE_LIST) rare_c[1u + k] = (plane << 28) | (pos >> 5); }      // the word's first bit: remember the word
+}
 __device__ __forceinline__ void g2_quals_masks(const uint8_t* tx, const G2Read& m, uint32_t part, uint32_t P, uint32_t* pl, uint32_t pw, uint32_t wbase, uint32_t nd,
                                                uint32_t pat0, uint32_t pat1, uint32_t pat2, uint32_t patm, const DevHeader* __restrict__ D, uint8_t* qd, uint32_t* __restrict__ gpl, uint64_t pstride,
                                                uint32_t* __restrict__ segm_c, int* __restrict__ segc_c, uint32_t n_seg, uint32_t* __restrict__ rare_c) {
@@ -1720,9 +1725,8 @@ __device__ __forceinline__ void g2_quals_masks(const uint8_t* tx, const G2Read& 
             const uint32_t k = (uint32_t)__ffs((int)rest) - 1u; rest &= rest - 1u;
             const uint32_t ww = k < 8u ? (k < 4u ? w[0] : w[1]) : (k < 12u ? w[2] : w[3]), pos = m.qpos + p0 + k, b = (ww >> (8u * (k & 3u))) & 0xFFu;
             const uint32_t j = D->stream_of[b];
-            if (j < 4u && j < D->n_normal) { const size_t si = (size_t)j * n_seg + pos / PC_SEG_POS; atomicOr(&gpl[(size_t)j * pstride + (pos >> 5)], 1u << (pos & 31u)); atomicAdd(&segm_c[si], 1u); atomicMax(&segc_c[si], (int)pos); }
-            else { qd[pos] = (uint8_t)b; atomicOr(&gpl[(size_t)G2_PLANE_EXC * pstride + (pos >> 5)], 1u << (pos & 31u)); atomicAdd(&segm_c[(size_t)EXC_SLOT * n_seg + pos / PC_SEG_POS], 1u); }
-            *rare_c = 1u;
+            if (j < 4u && j < D->n_normal) { const size_t si = (size_t)j * n_seg + pos / PC_SEG_POS; g2_rare_or(gpl, pstride, rare_c, j, pos); atomicAdd(&segm_c[si], 1u); atomicMax(&segc_c[si], (int)pos); }
+            else { qd[pos] = (uint8_t)b; g2_rare_or(gpl, pstride, rare_c, G2_PLANE_EXC, pos); atomicAdd(&segm_c[(size_t)EXC_SLOT * n_seg + pos / PC_SEG_POS], 1u); }
         }
     }
 }
@@ -1834,7 +1838,7 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
         if (parse && (uint32_t)wave_id() == (tix & 3u)) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (wave-uniform: this tile's parsing wave)
         if (MASKS) {
             if (tid < nd && s_carry[tid]) atomicOr(&pl[tid * M.pw], s_carry[tid]);       // the word the tile in front left unfinished
-            g2_quals_masks(tx, m, part, P, pl, M.pw, qbeg & ~31u, nd, pat0, pat1, pat2, patm, D, qd, gpl, M.pstride, segm + (size_t)c * MAX_STREAMS * n_seg, segc + (size_t)c * MAX_STREAMS * n_seg, n_seg, M.rare + c);
+            g2_quals_masks(tx, m, part, P, pl, M.pw, qbeg & ~31u, nd, pat0, pat1, pat2, patm, D, qd, gpl, M.pstride, segm + (size_t)c * MAX_STREAMS * n_seg, segc + (size_t)c * MAX_STREAMS * n_seg, n_seg, M.rare + (size_t)c * (1u + G2_RARE_LIST));
             g2_bases(tx, m, part, P, lpk, lnb, rflag);
         } else g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
         __syncthreads();                                                    // the text is free for the next tile; the tile's counts / planes are complete
@@ -1861,14 +1865,15 @@ __global__ void k_gather_redo_reset(const uint32_t* __restrict__ only, uint32_t*
     const uint32_t c = blockIdx.x; if (!only[c]) return;
     const size_t k = (size_t)c * MAX_STREAMS * n_seg;
     for (uint32_t i = threadIdx.x; i < MAX_STREAMS * n_seg; i += blockDim.x) { segm[k + i] = 0u; segc[k + i] = -1; }
-    if (xplane) k_rare_zero_chunk(xplane, pstride, dense_mask_of(D, nd), pq, first, qbase, c);
+    if (xplane) { k_rare_zero_chunk(xplane, pstride, dense_mask_of(D, nd), pq, first, qbase, c); if (threadIdx.x == 0) xplane[(size_t)G2_PLANES * pstride + (size_t)c * (1u + G2_RARE_LIST)] = 0u; }   // (rare[] lies behind the planes)
 }
 // behind the coder: the rare planes all-zero again (chunks that set bits in them are marked in rare[])
 __global__ void k_rare_cleanup(uint32_t* __restrict__ rare, uint32_t* __restrict__ planes, uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase) {
-    const uint32_t c = blockIdx.x; if (!rare[c]) return;
-    k_rare_zero_chunk(planes, pstride, dense_mask_of(D, nd), pq, first, qbase, c);
+    const uint32_t c = blockIdx.x; uint32_t* const rc = rare + (size_t)c * (1u + G2_RARE_LIST); const uint32_t n = rc[0]; if (!n) return;
+    if (n <= G2_RARE_LIST) { const size_t w0 = (size_t)(qbase[c] >> 5); for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t e = rc[1u + i]; planes[(size_t)(e >> 28) * pstride + w0 + (e & 0x0FFFFFFFu)] = 0u; } }
+    else k_rare_zero_chunk(planes, pstride, dense_mask_of(D, nd), pq, first, qbase, c);
     __syncthreads();
-    if (threadIdx.x == 0) rare[c] = 0u;
+    if (threadIdx.x == 0) rc[0] = 0u;
 }
 // 16 consecutive codes / N bits of a loose slot from base index b on (b + 16 may pass the slot's end: the caller masks)
 __device__ __forceinline__ uint32_t loose_codes(const uint32_t* __restrict__ lpk, uint32_t ld, uint32_t b) {
