@@ -21,6 +21,7 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     const long long num = set ? atoll(v.c_str()) : 0;
     if (n == "RFQ_GATHER") { if (set && v != "old" && v != "tile") return rfq_fail(c, RFQ_E_ARG, "RFQ_GATHER is old or tile"); c->opt.gather_old = v == "old"; }
     else if (n == "RFQ_QUAL") { if (set && v != "bytes" && v != "masks") return rfq_fail(c, RFQ_E_ARG, "RFQ_QUAL is bytes or masks"); c->opt.qual_bytes = v == "bytes"; }
+    else if (n == "RFQ_CODER") { if (set && v != "list" && v != "mask") return rfq_fail(c, RFQ_E_ARG, "RFQ_CODER is list or mask"); c->opt.coder = v == "list" ? 1 : (v == "mask" ? 2 : 0); }
     else if (n == "RFQ_INDEX") { if (set && v != "2pass" && v != "1pass") return rfq_fail(c, RFQ_E_ARG, "RFQ_INDEX is 2pass or 1pass"); c->opt.index_2pass = v == "2pass"; }
     else if (n == "RFQ_IDX_TILES") { if (set && num != 4 && num != 8 && num != 16) return rfq_fail(c, RFQ_E_ARG, "RFQ_IDX_TILES is 4, 8 or 16"); c->opt.idx_tiles = set ? (int)num : d.idx_tiles; }
     else if (n == "RFQ_STREAMS") c->opt.one_stream = set && num == 1;
@@ -31,11 +32,13 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     else if (n == "RFQ_GW_SHIFT") c->opt.gw_shift = set ? (int)std::min<long long>(30, std::max<long long>(4, num)) : d.gw_shift;
     else if (n == "RFQ_MATERIALISE") c->opt.materialise = set && num != 0;
     else if (n == "RFQ_TRACE") c->opt.trace = set && v != "0";
+    else if (n == "RFQ_AUX_PRIO") c->opt.aux_priority = set && num != 0;
+    else if (n == "RFQ_E3_OCC") c->opt.e3_occ = set && num == 6 ? 6 : 5;
     else if (n == "RFQ_G2_PAD") c->opt.g2_pad = set ? (uint32_t)num : 0u;
     else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
     return RFQ_OK;
 }
-static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD" };
+static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD", "RFQ_AUX_PRIO", "RFQ_E3_OCC" };
 
 extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (!out) return RFQ_E_ARG;

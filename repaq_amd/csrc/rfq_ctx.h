@@ -65,6 +65,7 @@ static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, u
 // Test / diagnostic switches of a context (rfq_set_option).  The RFQ_* environment variables of the same names are read ONCE, when the context is created
 // (no getenv on the batch paths - the switches changed chunk walking and emission silently per call, and getenv races a concurrent setenv).
 struct RfqOpts {
+    int  coder = 0;                   // RFQ_CODER=list|mask   encode, quality bytes: the list coder / the mask coder whatever the number of coded values (default: list from five on)
     bool qual_bytes = false;          // RFQ_QUAL=bytes     encode: k_gather2 writes the quality bytes (qcat) also for files with <= 3 coded values (default there: match masks)
     bool gather_old = false;          // RFQ_GATHER=old     encode: the byte-wise gather (k_gather + k_packbytes) also for reads that fit a tile
     bool index_2pass = false;         // RFQ_INDEX=2pass    encode: newline bitmap -> scan -> line offsets instead of the one-pass index
@@ -77,6 +78,8 @@ struct RfqOpts {
     int  gw_shift = 16;               // RFQ_GW_SHIFT       log2 of the smallest guess-and-verify segment
     bool materialise = false;         // RFQ_MATERIALISE=1  decode: qualities / bases expanded in HBM (the path of a streaming caller's non-final slices) on every call
     bool trace = false;               // RFQ_TRACE          a line on stderr about how chunk starts were found
+    bool aux_priority = false;        // RFQ_AUX_PRIO=1     the second stream with a higher priority (measured: nothing on encode, 0.3 ms worse on decode)
+    int  e3_occ = 5;                  // RFQ_E3_OCC=6       decode: k_dec_emit3 compiled for six waves per SIMD (80 VGPRs)
     uint32_t g2_pad = 0;              // RFQ_G2_PAD         profiling aid: bytes of unused dynamic LDS added to k_gather2 (fewer resident workgroups)
 };
 struct rfq_ctx {
@@ -93,7 +96,11 @@ struct rfq_ctx {
     hipStream_t copy = nullptr; hipEvent_t copy_ev[64] = {}; uint64_t copy_next = 0, copy_done = 0;
     bool aux_ready() {
         if (aux) return true;
-        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; return false; }
+        // (the second stream carries the chains of small, latency-bound kernels - stored prefix, sequence packer, N coder, coordinates; decode: the list
+        // chain - beside one large VALU-bound kernel on the main stream: with a higher priority their workgroups get the slots they need when they are ready)
+        { int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+          const bool prio = opt.aux_priority && hi_p != lo_p;
+          if ((prio ? hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi_p) : hipStreamCreateWithFlags(&aux, hipStreamNonBlocking)) != hipSuccess) { aux = nullptr; return false; } }
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_mid, hipEventDisableTiming) != hipSuccess) return false;
         if (hipStreamCreateWithFlags(&aux2, hipStreamNonBlocking) != hipSuccess) { aux2 = nullptr; return false; }

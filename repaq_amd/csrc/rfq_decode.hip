@@ -214,6 +214,10 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
                 if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
                 else hipLaunchKernelGGL((k_dec_emit3<true, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             }
+            else if (ctx->opt.e3_occ == 6) {                                  // (RFQ_E3_OCC=6: 80 VGPRs, six workgroups per CU instead of five)
+                if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, ET_N1CAP, 6>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+                else hipLaunchKernelGGL((k_dec_emit3<true, ET_N1CAP, 6>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+            }
             else if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_emit3<false>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             else hipLaunchKernelGGL(k_dec_emit3<true>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
 #undef RFQ_EMIT3_ARGS

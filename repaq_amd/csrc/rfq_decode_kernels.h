@@ -1713,7 +1713,7 @@ __device__ __forceinline__ uint32_t e3_rev1x16(uint32_t v) {
 // dword i of the mask "bytes >= t of a 16-byte group" (t <= 0: all of them, t >= 16: none)
 __device__ __forceinline__ uint32_t e3_from(int t, int i) { const int k = t - 4 * i; return k <= 0 ? 0xFFFFFFFFu : (k >= 4 ? 0u : 0xFFFFFFFFu << (8 * k)); }
 __device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }   // v_alignbyte_b32
-template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds__(256) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __launch_bounds__(256, OCC) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
                            uint32_t ncell, uint32_t nstr, uint32_t kshift, int abl) {

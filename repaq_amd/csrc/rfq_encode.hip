@@ -605,7 +605,18 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_SCRATCH].ensure((size_t)hs.total_scratch + 256));
     HIPCHK(ctx, B[B_XS].ensure(3 * nr + 64)); HIPCHK(ctx, B[B_YS].ensure(3 * nr + 64));
     const uint32_t nqg = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
+    // the value streams of a file with many coded quality values (no match masks): the list coder - one wave per (chunk, segment) for all of them, work
+    // proportional to the coded positions - instead of a wave per four streams testing every position (RFQ_CODER=list / mask force one or the other)
+    const bool coder_list = !masks && !(HH.flags & H_DONT_QUAL) && (HH.flags & H_QUAL_BY_COL) && HH.n_normal >= 1 && (ctx->opt.coder == 1 || (ctx->opt.coder == 0 && HH.n_normal >= 5));
     auto launch_coder = [&](hipStream_t Q, uint32_t g0, uint32_t gn) -> int {
+        if (coder_list && g0 == 0 && gn >= nqg) {                          // the value streams; what is left of the request (exception group, N group) below
+            const uint64_t mb = (uint64_t)((n_chunks + 7) / 8) * 8ull * n_seg;
+            if (mb > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
+            hipLaunchKernelGGL(k_pos_coder_list, dim3((uint32_t)mb), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase,
+                               B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, dst);
+            g0 = nqg; gn -= nqg;
+            if (gn == 0) return RFQ_OK;
+        }
         const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * gn * n_seg;
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
         hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint16_t*)B[B_SNM].as<uint16_t>(),

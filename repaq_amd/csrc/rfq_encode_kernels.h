@@ -2371,6 +2371,204 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
     else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), C.ptot[c].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
+// =============================================================== position coder for MANY value streams (list form)
+// k_pos_coder tests every position against every value: ~650 instructions per ACTIVE stream and 4096-position step - fine for the three or four streams of
+// a NovaSeq-binned file, most of the encode at forty (old Illumina / BGI files: the configs[4] shape).  Here ONE wave codes ALL value streams of a (chunk,
+// segment) and the work is proportional to the coded POSITIONS:
+//   * per step every quality byte is looked up once in the header's value -> stream table;
+//   * what kind of token a position gets is a property of the BYTE sequence, not of the stream: a stream holds one value, so "the previous match of my
+//     stream is the position in front of me" is "my byte equals the byte in front of me".  One SWAR pass gives a lane the mask E of its 64 positions
+//     that equal their predecessor; streak starts are the zeros of E, a position's distance from its streak start and the matches that follow it are
+//     bit scans of E (chained through the lanes for runs that cross them);
+//   * the coded positions are bucketed by stream in LDS (count, one prefix over the lanes per stream, scatter), every entry already carrying its kind -
+//     gap token / the 0x00 of a streak that starts at position 0 (the `cur > 1` rule) / run token with its length / nothing;
+//   * the tokens are written from the list, 64 entries per round whatever streams they belong to: the only thing an entry still needs is its stream's
+//     previous match - the entry in front of it.
+// Round 3's version of this idea found streak starts by a keyed max-scan over the list and run lengths by a 5-probe search in it: ~400 instructions per
+// round of 64 entries, slower than k_pos_coder even at forty streams (4.4 against 3.2 ms).  Slots, capacities and byte counts are k_pos_coder's
+// (pc_seg_cap, segb): k_assemble does not know which coder ran.  The exception records stay with k_pos_coder's exception group.
+#define PL_LIST 4096u
+struct PlLds {
+    uint32_t list[PL_LIST];                  // entries, stream after stream: position in the step (12 bits) | kind << 12 | (run token value) << 14 | stream << 19
+    uint16_t base[NPOS_SLOT][64];            // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part
+    uint16_t off[NPOS_SLOT + 2];             // where a stream's part of the list starts
+    int prev[NPOS_SLOT];                     // the stream's last match so far (-1: none)
+    uint32_t outpos[NPOS_SLOT], room[NPOS_SLOT]; unsigned long long out[NPOS_SLOT];
+    uint8_t tab[256], on[NPOS_SLOT];
+};
+// bit k of the result: byte k of (w, 64 bytes) equals byte k - 1 (byte 0: pb)
+__device__ __forceinline__ unsigned long long pl_eq_prev(const uint32_t (&w)[16], uint32_t pb) {
+    uint32_t lo = 0, hi = 0, carry = pb << 24;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const uint32_t a = w[i], b = w[i + 1];
+        const uint32_t sa = (a << 8) | (carry >> 24), sb_ = (b << 8) | (a >> 24); carry = b;      // the bytes in front
+        const uint32_t m = eq_mask8(a ^ sa, b ^ sb_, 0u);                                        // zero bytes of the xors
+        if (i < 8) lo |= m << (4 * i); else hi |= m << (4 * (i - 8));
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+__global__ void __launch_bounds__(64) k_pos_coder_list(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
+                                                       uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks, DevStatus* st) {
+    __shared__ PlLds S;
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3;       // (a chunk's workgroups on one XCD, as in k_pos_coder)
+    const uint32_t c = (idx / n_seg) * 8u + xcd, seg = idx % n_seg;
+    if (c >= n_chunks) return;
+    const int l = lane_id();
+    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];
+    const uint8_t* __restrict__ B = qcat + C.qbase[c]; const uint32_t len = R.pq[e] - R.pq[f];
+    const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS, step1 = step0 + PC_SEG_STEPS < nsteps ? step0 + PC_SEG_STEPS : nsteps;
+    if (step0 >= nsteps) return;
+    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = D->stream_of[v]; S.tab[v] = (uint8_t)(j < nn ? j : 0xFFu); }
+    {   // a lane per stream: is it there, where it stands, where its bytes go (pc_run's entry state)
+        const uint32_t j = (uint32_t)l; bool on = false;
+        if (j < nn) {
+            const size_t k = (size_t)c * MAX_STREAMS + j, s0i = k * n_seg; const uint32_t cap = C.scap[k];
+            on = cap != 0 && segm[s0i + seg] != 0;
+            int prev = -1; for (int s_ = (int)seg - 1; s_ >= 0 && prev < 0; s_--) prev = segc[s0i + (uint32_t)s_];
+            uint32_t off = 0; for (uint32_t s_ = 0; s_ < seg; s_++) off += pc_seg_cap(false, segm[s0i + s_], PC_SEG_POS);
+            const uint32_t own = pc_seg_cap(false, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
+            S.prev[j] = prev; S.outpos[j] = 0; S.room[j] = off + own <= cap ? own : 0u;
+            S.out[j] = (unsigned long long)(uintptr_t)(scratch + cbase[c] + C.soff[k] + off);
+        }
+        S.on[l] = on ? 1 : 0;
+        if (!__any(on)) return;
+    }
+    wave_lds_sync();
+    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = S.tab[v]; if (j != 0xFFu && !S.on[j]) S.tab[v] = 0xFFu; }   // (values whose stream has nothing in this segment: not looked at again)
+    wave_lds_sync();
+    // the byte in front of the segment and how far it is from the start of its streak (the segment may begin inside one)
+    uint32_t carry_byte = 0x100u; uint32_t carry_R = 0;                     // (0x100: no byte in front - it equals nothing)
+    if (step0 > 0) {
+        const uint32_t sb0 = step0 * 4096u; carry_byte = B[sb0 - 1u];
+        uint32_t p = sb0 - 1u; while (p > 0 && B[p - 1u] == (uint8_t)carry_byte) p--;          // (every lane walks the same bytes)
+        carry_R = sb0 - 1u - p;
+    }
+    const uint32_t inc = (l & 1) ? 0x10000u : 1u;
+    for (uint32_t step = step0; step < step1; step++) {
+        const uint32_t sb = step * 4096u, p0 = sb + 64u * (uint32_t)l;
+        const uint32_t nv = p0 >= len ? 0u : (len - p0 < 64u ? len - p0 : 64u);
+        const Raw64 r = pc_load_raw(B, len, p0);
+        const uint32_t w[16] = { r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w, r.v[1].x, r.v[1].y, r.v[1].z, r.v[1].w, r.v[2].x, r.v[2].y, r.v[2].z, r.v[2].w, r.v[3].x, r.v[3].y, r.v[3].z, r.v[3].w };
+        const unsigned long long vmask = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
+        // ---- the stream of each of my 64 positions: 64 independent table reads, kept packed in registers (0xFF: none); Cm: my coded positions
+        uint32_t sw[16]; unsigned long long Cm = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t x = w[i];
+            const uint32_t s0_ = S.tab[x & 0xFFu], s1_ = S.tab[(x >> 8) & 0xFFu], s2_ = S.tab[(x >> 16) & 0xFFu], s3_ = S.tab[x >> 24];
+            sw[i] = s0_ | (s1_ << 8) | (s2_ << 16) | (s3_ << 24);
+            Cm |= (unsigned long long)(((s0_ != 0xFFu) ? 1u : 0u) | ((s1_ != 0xFFu) ? 2u : 0u) | ((s2_ != 0xFFu) ? 4u : 0u) | ((s3_ != 0xFFu) ? 8u : 0u)) << (4 * i);
+        }
+        Cm &= vmask;
+        // ---- E: my positions that equal the position in front; Rin: how far the position in front of my first is from the start of its streak
+        const uint32_t lastb = nv ? (w[15] >> 24) : 0x100u;
+        const uint32_t pb = wave_shr1(nv == 64u ? lastb : 0x100u, carry_byte);
+        unsigned long long E = (pb > 0xFFu) ? (pl_eq_prev(w, 0u) & ~1ull) : pl_eq_prev(w, pb);
+        E &= vmask; if (p0 == 0u) E &= ~1ull;
+        const bool hz = (~E & vmask) != 0ull || nv < 64u;                   // my positions do not all continue one streak
+        const uint32_t ztop = (~E & vmask) ? (uint32_t)(63 - __clzll((long long)(~E & vmask))) : 0u;
+        uint32_t tailR = hz ? (nv ? nv - 1u - ztop : 0u) : 0u, Rin = 0;
+        for (;;) {                                                          // (one pass unless a streak covers whole lanes)
+            Rin = wave_shr1(tailR, carry_R);
+            const uint32_t t2 = hz ? tailR : Rin + 64u;
+            const bool ch = t2 != tailR; tailR = t2;
+            if (!__any(ch)) break;
+        }
+        // matches that follow my last position (a run token counts up to 31 of them): the head of the next lane's E, for lane 63 the next step's first bytes
+        uint32_t ext;
+        {
+            const uint32_t hd = (E & 1ull) ? ((~E & vmask) ? (uint32_t)(__ffsll((long long)(~E & vmask)) - 1) : nv) : 0u;     // my leading positions that continue the streak in front
+            ext = (uint32_t)__shfl_down((int)hd, 1u);
+            if (l == 63) { ext = 0; const uint32_t nb_ = sb + 4096u; if (nv == 64u) { while (ext < 31u && nb_ + ext < len && B[nb_ + ext] == (uint8_t)lastb) ext++; } }
+            if (nv < 64u) ext = 0;
+        }
+        // ---- count: my positions per stream (fire-and-forget 32-bit atomics on the u16 pairs of neighbouring lanes)
+        for (uint32_t j = 0; j < nn; j++) S.base[j][l] = 0;
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 64; k++) { const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu; if ((Cm >> k) & 1ull) atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); }
+        wave_lds_sync();
+        // ---- a prefix over the lanes per stream: where my entries of the stream go
+        uint32_t tot = 0;
+        for (uint32_t j = 0; j < nn; j++) {                                // (wave-uniform)
+            if (l == 0) S.off[j] = (uint16_t)tot;
+            if (!uni32(S.on[j])) continue;
+            const uint32_t cnt = S.base[j][l], incl = wave_incl_sum<uint32_t>(cnt);
+            S.base[j][l] = (uint16_t)(incl - cnt);
+            tot += wave_last(incl);
+        }
+        if (l == 0) { S.off[nn] = (uint16_t)tot; S.off[nn + 1] = (uint16_t)tot; }
+        const uint32_t NE = tot;
+        wave_lds_sync();
+        // ---- scatter the entries into the list (returning atomics, independent of one another), each with its kind
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            if (!((Cm >> k) & 1ull)) continue;
+            const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            uint32_t kind = 1u, val = 0u;                                   // 1: the streak starts here - gap token
+            if ((E >> k) & 1ull) {
+                const unsigned long long zb = ~E & (k ? ((2ull << k) - 1ull) : 1ull);            // zeros of E at or below k
+                const uint32_t Rk = zb ? (uint32_t)k - (uint32_t)(63 - __clzll((long long)zb)) : Rin + (uint32_t)k + 1u;     // my distance from the start of my streak
+                const uint32_t p = p0 + (uint32_t)k; kind = 0u;
+                int t;
+                if (p == Rk) { if (Rk == 1u) { kind = 2u; t = -1; } else t = (int)Rk - 2; } else t = (int)Rk - 1;    // (p == Rk: the streak starts at position 0 of the chunk)
+                if (kind == 0u && t >= 0 && (t & 31) == 0) {
+                    const unsigned long long up = (k < 63) ? (E >> (k + 1)) : 0ull;               // the positions behind me that continue
+                    const uint32_t on_ = (k < 63) ? ((~up) ? (uint32_t)(__ffsll((long long)~up) - 1) : 64u) : 0u;
+                    uint32_t L = 1u + (on_ > 63u - (uint32_t)k ? 63u - (uint32_t)k : on_);
+                    if ((uint32_t)k + L == 64u) L += ext;
+                    if (L > 32u) L = 32u;
+                    kind = 3u; val = L - 1u;
+                }
+            }
+            const uint32_t old_ = atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); const uint32_t at = S.off[j] + ((l & 1) ? old_ >> 16 : old_ & 0xFFFFu);
+            S.list[at] = (64u * (uint32_t)l + (uint32_t)k) | (kind << 12) | (val << 14) | (j << 19);
+        }
+        wave_lds_sync();
+        // ---- tokens, 64 list entries per round
+        uint32_t carry_e = 0xFFFFFFFFu;                                     // the entry in front of the round (none: a stream of its own)
+        for (uint32_t r0 = 0; r0 < NE; r0 += 64u) {                         // (wave-uniform)
+            const uint32_t i = r0 + (uint32_t)l; const bool valid = i < NE;
+            const uint32_t en = valid ? S.list[i] : 0xFFFFFFFFu;
+            const uint32_t ep = wave_shr1(en, carry_e); carry_e = wave_last(en);
+            const uint32_t j = (en >> 19) & 63u, pos = en & 0xFFFu, kind = (en >> 12) & 3u, jp = ep == 0xFFFFFFFFu ? 0xFFu : ((ep >> 19) & 63u);
+            const bool first = valid && j != jp;                            // my stream's first entry of the step
+            const int p = (int)(sb + pos);
+            uint32_t nb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (valid && kind == 1u) {
+                const int prevp = first ? S.prev[j] : (int)(sb + (ep & 0xFFFu));
+                const uint32_t d = (uint32_t)(p - prevp), v = d - 1u;
+                if (d <= 128u) { nb = 1; t0 = v; } else if (d <= 16384u) { nb = 2; t0 = (v >> 8) | 0x80u; t1 = v & 0xFFu; } else { nb = 4; t0 = (v >> 24) | 0xE0u; t1 = (v >> 16) & 0xFFu; t2 = (v >> 8) & 0xFFu; t3 = v & 0xFFu; }
+            } else if (valid && kind == 2u) { nb = 1; t0 = 0; }
+            else if (valid && kind == 3u) { nb = 1; t0 = 0xC0u | ((en >> 14) & 31u); }
+            // byte offsets: a sum over the round, cut at the stream boundaries
+            const uint32_t incl = wave_incl_sum<uint32_t>(nb);
+            const unsigned long long bm = __ballot(first || (valid && l == 0));
+            const unsigned long long upto = l == 63 ? ~0ull : ((2ull << l) - 1ull);
+            const int segl = 63 - __clzll((long long)((bm & upto) | 1ull));
+            const uint32_t excl = incl - nb - (uint32_t)__shfl((int)(incl - nb), segl);
+            const uint32_t o = valid ? S.outpos[j] + excl : 0u;
+            if (valid && nb && o + nb <= S.room[j]) {
+                uint8_t* op = (uint8_t*)(uintptr_t)S.out[j] + o;
+                op[0] = (uint8_t)t0; if (nb >= 2u) op[1] = (uint8_t)t1; if (nb == 4u) { op[2] = (uint8_t)t2; op[3] = (uint8_t)t3; }
+            }
+            const uint32_t jn = (uint32_t)__shfl_down((int)j, 1u);
+            const bool lastl = valid && (l == 63 || i + 1u >= NE || jn != j);
+            wave_lds_sync();                                                // (every lane has read its stream's state)
+            if (lastl) S.outpos[j] = o + nb;
+            wave_lds_sync();
+        }
+        if ((uint32_t)l < nn && S.on[l] && S.off[l + 1] > S.off[l]) S.prev[l] = (int)(sb + (S.list[S.off[l + 1] - 1u] & 0xFFFu));
+        carry_byte = wave_last(nv == 64u ? lastb : 0x100u); carry_R = wave_last(tailR);
+        wave_lds_sync();
+    }
+    if ((uint32_t)l < nn && S.on[l]) {
+        segb[((size_t)c * MAX_STREAMS + (uint32_t)l) * n_seg + seg] = S.outpos[l];
+        if (S.outpos[l] > S.room[l]) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
+    }
+}
+
 // =============================================================== coordinate coder (encodeCoords, src/rfqcodec.cpp:1262-1330)
 // One wave per (axis, chunk).  `last` always equals the previous element, so every token is local: a repeat element
 // closes a 0xC0|k token when it is the 32nd of its group or the next element is not a repeat.

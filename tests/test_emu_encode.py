@@ -161,6 +161,47 @@ def test_match_masks_with_values_chunk_0_does_not_have(codec):
                 assert E.encode(codec, a, b, paired, cb) == want
 
 
+@pytest.mark.parametrize("coder", ["list", "mask"])
+@pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:7], ids=[m[0] for m in MULTI[:7]])
+def test_multichunk_both_position_coders_match_oracle(codec, coder, label, prof, reads, seed, cb, paired, kw):
+    """RFQ_CODER=list / mask on the quality bytes (RFQ_QUAL=bytes: also for files that would get match masks): k_pos_coder_list - all value streams of a segment
+    by one wave, from a per-step list of the coded positions - and k_pos_coder - a wave per four streams - write the same bytes."""
+    codec.set_option("RFQ_QUAL", "bytes"); codec.set_option("RFQ_CODER", coder)
+    fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+
+
+def test_list_coder_on_runs_that_cross_lanes_steps_and_segments(codec):
+    """The list coder takes streak starts, distances and run lengths from the byte sequence: runs of one value that cross 64-position lanes, 4096-position steps
+    and 32768-position segments, start at position 0 / 1 of the chunk, are 32 / 33 / 34 / 65 long, in files with many quality values."""
+    import random
+    rng = random.Random(11)
+    vals = bytes(range(40, 40 + 24))
+    def quals(n):
+        out = bytearray(vals * 8)                                            # (chunk 0 sees every value: the header's table knows them all - no exception records)
+        while len(out) < n:
+            r = rng.random()
+            run = rng.choice((1, 1, 1, 2, 3, 31, 32, 33, 34, 35, 63, 64, 65, 66, 130, 700) + ((4096, 5000, 33000) if len(out) > 110000 else ())) if r < 0.25 else 1
+            out += bytes([rng.choice(vals)]) * run
+        return bytes(out[:n])
+    for L, nreads, cb in ((150, 1600, 40000), (100, 2500, 70000), (251, 1000, 100000)):
+        q = quals(L * nreads)
+        recs = []
+        for i in range(nreads):
+            recs.append(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(L)), q[i * L:(i + 1) * L]))
+        fq = b"".join(recs)
+        want = O.encode_file(fq, b"", O.SE, cb)
+        for coder in ("list", "mask"):
+            with codec.option("RFQ_CODER", coder):
+                assert E.encode(codec, fq, b"", O.SE, cb) == want, (L, coder)
+    # a streak from position 0 of the chunk (the `cur > 1` rule) in a many-valued file
+    head = bytes([vals[3]]) * 70 + quals(150 * 300 - 70)[:150 * 300 - 70]
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"A" * 150, head[i * 150:(i + 1) * 150]) for i in range(300))
+    for coder in ("list", "mask"):
+        with codec.option("RFQ_CODER", coder):
+            assert E.encode(codec, fq, b"", O.SE, 30000) == O.encode_file(fq, b"", O.SE, 30000), coder
+
+
 def test_gather_paths_are_the_ones_expected(codec):
     """The tile gather (k_gather2 + k_seqpack) is what runs by default - also when a mate of an interleaved chunk holds bytes outside A/C/G/T/N
     (Read::changeToReverseComplement turns them into N, lower case into the upper-case complement) - and reads too long for a tile of two
