@@ -151,6 +151,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 template <class T> __device__ __forceinline__ T wave_shr1(T v, T fill) { const T t = __shfl_up(v, 1u); return lane_id() ? t : fill; }
 template <class T> __device__ __forceinline__ T wave_last(T v) { return __shfl(v, 63); }
 // lane K of my quad (four consecutive lanes); the lane four in front of mine (callers only use it where that lane lies in the same row of 16)
+template <class T> __device__ __forceinline__ T wave_read(T v, uint32_t lane) { return __shfl(v, (int)lane); }      // lane: the same in every lane of the wave
 template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__shfl((int)v, (lane_id() & ~3) | K); }
 __device__ __forceinline__ uint32_t lane_shr4(uint32_t v) { return (uint32_t)__shfl_up((int)v, 4u); }
 #else
@@ -195,6 +196,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) { RFQ_DPP_SCAN(v, RFQ_OP
 // lane l <- lane l-1 (lane 0 <- fill): wave_shr:1; the value of lane 63 in every lane (an SGPR)
 template <class T> __device__ __forceinline__ T wave_shr1(T v, T fill) { return dpp_take<0x138, 0xF>(fill, v); }
 template <class T> __device__ __forceinline__ T wave_last(T v) { return wave_read63(v); }
+template <class T> __device__ __forceinline__ T wave_read(T v, uint32_t lane) { static_assert(sizeof(T) == 4, "wave_read: 32-bit values"); return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane((int)lane))); }
 template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true); }   // quad_perm:[K,K,K,K]
 __device__ __forceinline__ uint32_t lane_shr4(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); }             // row_shr:4
 #endif

@@ -13,7 +13,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_QPLANE, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_QPLANE, B_SEGD, B_SEGS, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 80, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -612,7 +612,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (coder_list && g0 == 0 && gn >= nqg) {                          // the value streams; what is left of the request (exception group, N group) below
             const uint64_t mb = (uint64_t)((n_chunks + 7) / 8) * 8ull * n_seg;
             if (mb > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
-            hipLaunchKernelGGL(k_pos_coder_list, dim3((uint32_t)mb), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase,
+            hipLaunchKernelGGL(k_pos_coder_list, dim3((uint32_t)mb), dim3(64), std::min<uint32_t>(HH.n_normal, NPOS_SLOT) * 128u, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase,
                                B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, dst);
             g0 = nqg; gn -= nqg;
             if (gn == 0) return RFQ_OK;
@@ -661,7 +661,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     ctx->timer.end(S);
     ctx->timer.begin("coords+layout", S);
-    hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const uint32_t*)B[B_SEGB].as<uint32_t>(), n_seg);
+    HIPCHK(ctx, B[B_SEGD].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGS].ensure(nsb * 4));
+    hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const DevHeader*)D, (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, B[B_SEGD].as<uint32_t>(), B[B_SEGS].as<uint32_t>());
     hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, T, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
     hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 1, dst);
@@ -678,7 +679,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
                            (const uint8_t*)B[B_SCRATCHN].as<uint8_t>(), (const uint64_t*)cbase_n,
                            (const uint8_t*)B[B_XS].as<uint8_t>(), (const uint8_t*)B[B_YS].as<uint8_t>(), (const int8_t*)ovb, img, img_cap, hdr_bytes,
                            a->file_off1, a->file_off2, a->nolb_from1, a->nolb_from2,
-                           (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, dst,
+                           (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGD].as<uint32_t>(), (const uint32_t*)B[B_SEGS].as<uint32_t>(), n_seg, dst,
                            tail_bases, units_used, nlines[0], nlines[1], (uint64_t)(nm ? nm->orig_n[0] : nbytes[0]), (uint64_t)(nm ? nm->orig_n[1] : nbytes[1]));
         // (a wave per eight reads, three dependent loads each: as many waves as there are groups of eight, not a serial walk per wave)
         // (most files share their names' fixed parts: the workgroups of such chunks leave at once, so the grid stays small - a workgroup loops over its share)

@@ -2335,14 +2335,23 @@ template <int MODE, int G> __device__ __forceinline__ void pc_run_planes(const C
     }
     (void)D;
 }
-// bytes of every stream of a chunk = sum of its segments' byte counts; one wave per chunk
-__global__ void k_pos_sizes(ChunkTab C, const uint32_t* __restrict__ segb, uint32_t n_seg) {
+// bytes of every stream of a chunk = sum of its segments' byte counts; one wave per chunk.  Also, for k_assemble's copy of every (stream, segment) piece into
+// the image: segd[si] = where the piece goes inside the quality payload (behind the length words: the streams in header order, the exception records last;
+// N-position stream: inside its own section) and segs[si] = where it lies in the stream's scratch area (the slots of the segments in front of it) - the
+// pieces used to find both by walking over the streams and segments in front of them, ~70 loads for each of a chunk's (streams + 1) x segments pieces.
+__global__ void k_pos_sizes(ChunkTab C, const DevHeader* __restrict__ D, const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t* __restrict__ segd, uint32_t* __restrict__ segs) {
     const uint32_t c = blockIdx.x; const int l = lane_id();
+    const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT;
+    uint32_t mine = 0;                                                      // lane j < 64: bytes of value stream j
     for (uint32_t j = (uint32_t)l; j < MAX_STREAMS; j += 64) {
-        const size_t k = (size_t)c * MAX_STREAMS + j; uint32_t tot = 0;
-        if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) tot += segb[k * n_seg + s];
-        C.ssize[k] = tot;
+        const size_t k = (size_t)c * MAX_STREAMS + j; uint32_t tot = 0, so = 0;
+        if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) { const size_t si = k * n_seg + s; segd[si] = tot; segs[si] = so; tot += segb[si]; so += pc_seg_cap(j == EXC_SLOT, segm[si], PC_SEG_POS); }
+        C.ssize[k] = tot; if (j < 64u) mine = j < nn ? tot : 0u;
     }
+    // the streams' places in the payload: value streams in header order, then the exception records
+    const uint32_t incl = wave_incl_sum(mine), base = incl - mine, total = wave_last(incl);
+    if ((uint32_t)l < nn) { const size_t k = (size_t)c * MAX_STREAMS + (uint32_t)l; if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) segd[k * n_seg + s] += base; }
+    if (l == (int)(EXC_SLOT - 64u)) { const size_t k = (size_t)c * MAX_STREAMS + EXC_SLOT; if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) segd[k * n_seg + s] += total; }   // (the lane that wrote them)
 }
 // g0, gn: the groups this launch codes (the quality / exception groups run behind the gather, the N group behind the sequence packer)
 __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint16_t* __restrict__ snm,
@@ -2388,13 +2397,16 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
 // round of 64 entries, slower than k_pos_coder even at forty streams (4.4 against 3.2 ms).  Slots, capacities and byte counts are k_pos_coder's
 // (pc_seg_cap, segb): k_assemble does not know which coder ran.  The exception records stay with k_pos_coder's exception group.
 #define PL_LIST 4096u
+// (LDS per wave decides how many of these one-wave workgroups a CU holds - the rounds are chains of LDS round trips, other waves are what hides them: the
+// list is 16 bits per entry + a byte for its stream, a stream's state one 16-byte record)
+struct PlStream { uint32_t outpos, room; unsigned long long out; };          // bytes written so far, the slot's size, where the slot is
 struct PlLds {
-    uint32_t list[PL_LIST];                  // entries, stream after stream: position in the step (12 bits) | kind << 12 | (run token value) << 14 | stream << 19
-    uint16_t base[NPOS_SLOT][64];            // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part
+    uint16_t list[PL_LIST];                  // entries, stream after stream: position in the step (12 bits) | code << 12 - 0 no token, 1 gap token (a streak starts), 2 the 0x00
+                                             // of a streak that starts at position 0, 3 + v: run token 0xC0 | v for v <= 11, 15: run token, length to be counted from the list
     uint16_t off[NPOS_SLOT + 2];             // where a stream's part of the list starts
     int prev[NPOS_SLOT];                     // the stream's last match so far (-1: none)
-    uint32_t outpos[NPOS_SLOT], room[NPOS_SLOT]; unsigned long long out[NPOS_SLOT];
-    uint8_t tab[256], on[NPOS_SLOT];
+    PlStream str[NPOS_SLOT];
+    uint8_t tab[256], on[NPOS_SLOT], after;  // after: matches that follow the step's last position (for a run token there)
 };
 // bit k of the result: byte k of (w, 64 bytes) equals byte k - 1 (byte 0: pb)
 __device__ __forceinline__ unsigned long long pl_eq_prev(const uint32_t (&w)[16], uint32_t pb) {
@@ -2408,9 +2420,10 @@ __device__ __forceinline__ unsigned long long pl_eq_prev(const uint32_t (&w)[16]
     }
     return ((unsigned long long)hi << 32) | lo;
 }
-__global__ void __launch_bounds__(64) k_pos_coder_list(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
+__global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
                                                        uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks, DevStatus* st) {
     __shared__ PlLds S;
+    RFQ_DYN_SHARED(uint16_t, pl_base);                                      // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part (n_normal x 64 u16: dynamic)
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3;       // (a chunk's workgroups on one XCD, as in k_pos_coder)
     const uint32_t c = (idx / n_seg) * 8u + xcd, seg = idx % n_seg;
     if (c >= n_chunks) return;
@@ -2428,8 +2441,8 @@ __global__ void __launch_bounds__(64) k_pos_coder_list(ReadTab R, ChunkTab C, co
             int prev = -1; for (int s_ = (int)seg - 1; s_ >= 0 && prev < 0; s_--) prev = segc[s0i + (uint32_t)s_];
             uint32_t off = 0; for (uint32_t s_ = 0; s_ < seg; s_++) off += pc_seg_cap(false, segm[s0i + s_], PC_SEG_POS);
             const uint32_t own = pc_seg_cap(false, segm[s0i + seg], len - seg * PC_SEG_POS < PC_SEG_POS ? len - seg * PC_SEG_POS : PC_SEG_POS);
-            S.prev[j] = prev; S.outpos[j] = 0; S.room[j] = off + own <= cap ? own : 0u;
-            S.out[j] = (unsigned long long)(uintptr_t)(scratch + cbase[c] + C.soff[k] + off);
+            S.prev[j] = prev; PlStream ps; ps.outpos = 0; ps.room = off + own <= cap ? own : 0u;
+            ps.out = (unsigned long long)(uintptr_t)(scratch + cbase[c] + C.soff[k] + off); S.str[j] = ps;
         }
         S.on[l] = on ? 1 : 0;
         if (!__any(on)) return;
@@ -2445,10 +2458,12 @@ __global__ void __launch_bounds__(64) k_pos_coder_list(ReadTab R, ChunkTab C, co
         carry_R = sb0 - 1u - p;
     }
     const uint32_t inc = (l & 1) ? 0x10000u : 1u;
+    Raw64 ahead = pc_load_raw(B, len, step0 * 4096u + 64u * (uint32_t)l);   // (a step's bytes are requested one step before they are looked at)
     for (uint32_t step = step0; step < step1; step++) {
         const uint32_t sb = step * 4096u, p0 = sb + 64u * (uint32_t)l;
         const uint32_t nv = p0 >= len ? 0u : (len - p0 < 64u ? len - p0 : 64u);
-        const Raw64 r = pc_load_raw(B, len, p0);
+        const Raw64 r = ahead;
+        if (step + 1u < step1) ahead = pc_load_raw(B, len, p0 + 4096u);
         const uint32_t w[16] = { r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w, r.v[1].x, r.v[1].y, r.v[1].z, r.v[1].w, r.v[2].x, r.v[2].y, r.v[2].z, r.v[2].w, r.v[3].x, r.v[3].y, r.v[3].z, r.v[3].w };
         const unsigned long long vmask = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
         // ---- the stream of each of my 64 positions: 64 independent table reads, kept packed in registers (0xFF: none); Cm: my coded positions
@@ -2480,92 +2495,123 @@ __global__ void __launch_bounds__(64) k_pos_coder_list(ReadTab R, ChunkTab C, co
         {
             const uint32_t hd = (E & 1ull) ? ((~E & vmask) ? (uint32_t)(__ffsll((long long)(~E & vmask)) - 1) : nv) : 0u;     // my leading positions that continue the streak in front
             ext = (uint32_t)__shfl_down((int)hd, 1u);
-            if (l == 63) { ext = 0; const uint32_t nb_ = sb + 4096u; if (nv == 64u) { while (ext < 31u && nb_ + ext < len && B[nb_ + ext] == (uint8_t)lastb) ext++; } }
+            if (l == 63) { ext = 0; const uint32_t nb_ = sb + 4096u; if (nv == 64u) { while (ext < 31u && nb_ + ext < len && B[nb_ + ext] == (uint8_t)lastb) ext++; } S.after = (uint8_t)ext; }
             if (nv < 64u) ext = 0;
         }
         // ---- count: my positions per stream (fire-and-forget 32-bit atomics on the u16 pairs of neighbouring lanes)
-        for (uint32_t j = 0; j < nn; j++) S.base[j][l] = 0;
+        for (uint32_t j = 0; j < nn; j++) pl_base[j * 64u + l] = 0;
         wave_lds_sync();
 #pragma unroll
-        for (int k = 0; k < 64; k++) { const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu; if ((Cm >> k) & 1ull) atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); }
+        for (int k = 0; k < 64; k++) { const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu; if ((Cm >> k) & 1ull) atomicAdd((uint32_t*)&pl_base[j * 64u + (l & ~1)], inc); }
         wave_lds_sync();
         // ---- a prefix over the lanes per stream: where my entries of the stream go
         uint32_t tot = 0;
-        for (uint32_t j = 0; j < nn; j++) {                                // (wave-uniform)
-            if (l == 0) S.off[j] = (uint16_t)tot;
-            if (!uni32(S.on[j])) continue;
-            const uint32_t cnt = S.base[j][l], incl = wave_incl_sum<uint32_t>(cnt);
-            S.base[j][l] = (uint16_t)(incl - cnt);
-            tot += wave_last(incl);
+        for (uint32_t j0 = 0; j0 < nn; j0 += 4u) {                         // (wave-uniform; four streams at a time: their LDS reads are in flight together)
+            uint32_t cnt[4], incl[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) cnt[u] = j0 + u < nn ? pl_base[(j0 + u) * 64u + l] : 0u;     // (a stream that is not `on` has no entries: its counts are zero)
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) incl[u] = wave_incl_sum<uint32_t>(cnt[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) if (j0 + u < nn) { if (l == 0) S.off[j0 + u] = (uint16_t)tot; pl_base[(j0 + u) * 64u + l] = (uint16_t)(incl[u] - cnt[u]); tot += wave_last(incl[u]); }
         }
         if (l == 0) { S.off[nn] = (uint16_t)tot; S.off[nn + 1] = (uint16_t)tot; }
         const uint32_t NE = tot;
         wave_lds_sync();
-        // ---- scatter the entries into the list (returning atomics, independent of one another), each with its kind
-#pragma unroll
-        for (int k = 0; k < 64; k++) {
-            if (!((Cm >> k) & 1ull)) continue;
-            const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            uint32_t kind = 1u, val = 0u;                                   // 1: the streak starts here - gap token
-            if ((E >> k) & 1ull) {
-                const unsigned long long zb = ~E & (k ? ((2ull << k) - 1ull) : 1ull);            // zeros of E at or below k
-                const uint32_t Rk = zb ? (uint32_t)k - (uint32_t)(63 - __clzll((long long)zb)) : Rin + (uint32_t)k + 1u;     // my distance from the start of my streak
-                const uint32_t p = p0 + (uint32_t)k; kind = 0u;
-                int t;
-                if (p == Rk) { if (Rk == 1u) { kind = 2u; t = -1; } else t = (int)Rk - 2; } else t = (int)Rk - 1;    // (p == Rk: the streak starts at position 0 of the chunk)
-                if (kind == 0u && t >= 0 && (t & 31) == 0) {
-                    const unsigned long long up = (k < 63) ? (E >> (k + 1)) : 0ull;               // the positions behind me that continue
-                    const uint32_t on_ = (k < 63) ? ((~up) ? (uint32_t)(__ffsll((long long)~up) - 1) : 64u) : 0u;
-                    uint32_t L = 1u + (on_ > 63u - (uint32_t)k ? 63u - (uint32_t)k : on_);
-                    if ((uint32_t)k + L == 64u) L += ext;
-                    if (L > 32u) L = 32u;
-                    kind = 3u; val = L - 1u;
+        // ---- scatter the entries into the list (returning atomics, independent of one another), each with its code.
+        // The codes of a lane's 64 positions as four bit masks - no work per position: a streak starts at the zeros of E (code 1); a run token stands at the
+        // first continuing position of a run (R == 1: E set, the bit below clear; the lane's head continues the streak in front: where Rin + k is a multiple
+        // of 32) - code 3 when the run ends there, 15 (counted from the list, rare) when it goes on.  Lanes with a run of 33 or more in them, and the step that
+        // holds position 0 of the chunk (the `cur > 1` rule), take the exact per-position form.
+        bool slow = sb == 0u;
+        { unsigned long long x = E & (E >> 1); x &= x >> 2; x &= x >> 4; x &= x >> 8; x &= x >> 16; if (x) slow = true; }      // 32 consecutive ones in E
+        const uint32_t hd_ = (E & 1ull) ? ((~E & vmask) ? (uint32_t)(__ffsll((long long)(~E & vmask)) - 1) : nv) : 0u;           // my leading positions that continue the streak in front
+        if (hd_ && Rin + hd_ >= 32u) slow = true;
+        unsigned long long M3 = 0, M15 = 0;
+        {
+            unsigned long long T3 = E & ~(E << 1) & ~1ull;                  // R == 1 inside the lane
+            if ((E & 1ull) && (Rin & 31u) == 0u) T3 |= 1ull;                // my first position: R = Rin + 1
+            const unsigned long long En = (E >> 1) | ((ext ? 1ull : 0ull) << 63);      // the position behind continues
+            M3 = T3 & ~En; M15 = T3 & En;
+        }
+        if (__any(slow)) {                                                  // (rare: wave-uniform) every position by the book
+#pragma unroll 1
+            for (uint32_t k = 0; k < 64u; k++) {
+                if (!((Cm >> k) & 1ull)) continue;
+                const uint32_t j = (uint32_t)S.tab[B[p0 + k]];
+                uint32_t kind = 1u, val = 0u;                               // 1: the streak starts here - gap token
+                if ((E >> k) & 1ull) {
+                    const unsigned long long zb = ~E & (k ? ((2ull << k) - 1ull) : 1ull);            // zeros of E at or below k
+                    const uint32_t Rk = zb ? k - (uint32_t)(63 - __clzll((long long)zb)) : Rin + k + 1u;     // my distance from the start of my streak
+                    const uint32_t p = p0 + k; kind = 0u;
+                    int t;
+                    if (p == Rk) { if (Rk == 1u) { kind = 2u; t = -1; } else t = (int)Rk - 2; } else t = (int)Rk - 1;    // (p == Rk: the streak starts at position 0 of the chunk)
+                    if (kind == 0u && t >= 0 && (t & 31) == 0) {
+                        const unsigned long long up = (k < 63u) ? (E >> (k + 1u)) : 0ull;             // the positions behind me that continue
+                        const uint32_t on_ = (k < 63u) ? ((~up) ? (uint32_t)(__ffsll((long long)~up) - 1) : 64u) : 0u;
+                        uint32_t L = 1u + (on_ > 63u - k ? 63u - k : on_);
+                        if (k + L == 64u) L += ext;
+                        if (L > 32u) L = 32u;
+                        kind = 3u; val = L - 1u;
+                    }
                 }
+                const uint32_t code = kind < 3u ? kind : (val <= 11u ? 3u + val : 15u);
+                const uint32_t old_ = atomicAdd((uint32_t*)&pl_base[j * 64u + (l & ~1)], inc); const uint32_t at = S.off[j] + ((l & 1) ? old_ >> 16 : old_ & 0xFFFFu);
+                S.list[at] = (uint16_t)((64u * (uint32_t)l + k) | (code << 12));
             }
-            const uint32_t old_ = atomicAdd((uint32_t*)&S.base[j][l & ~1], inc); const uint32_t at = S.off[j] + ((l & 1) ? old_ >> 16 : old_ & 0xFFFFu);
-            S.list[at] = (64u * (uint32_t)l + (uint32_t)k) | (kind << 12) | (val << 14) | (j << 19);
+        } else {
+            const uint32_t m1lo = (uint32_t)~E, m1hi = (uint32_t)(~E >> 32), m3lo = (uint32_t)M3, m3hi = (uint32_t)(M3 >> 32), m15lo = (uint32_t)M15, m15hi = (uint32_t)(M15 >> 32), clo = (uint32_t)Cm, chi = (uint32_t)(Cm >> 32);
+#pragma unroll
+            for (int k = 0; k < 64; k++) {
+                const uint32_t sh = (uint32_t)k & 31u;
+                if (!(((k < 32 ? clo : chi) >> sh) & 1u)) continue;
+                const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const uint32_t code = (((k < 32 ? m1lo : m1hi) >> sh) & 1u) + 3u * (((k < 32 ? m3lo : m3hi) >> sh) & 1u) + 15u * (((k < 32 ? m15lo : m15hi) >> sh) & 1u);
+                const uint32_t old_ = atomicAdd((uint32_t*)&pl_base[j * 64u + (l & ~1)], inc); const uint32_t at = S.off[j] + ((l & 1) ? old_ >> 16 : old_ & 0xFFFFu);
+                S.list[at] = (uint16_t)((64u * (uint32_t)l + (uint32_t)k) | (code << 12));
+            }
         }
         wave_lds_sync();
-        // ---- tokens, 64 list entries per round
-        uint32_t carry_e = 0xFFFFFFFFu;                                     // the entry in front of the round (none: a stream of its own)
-        for (uint32_t r0 = 0; r0 < NE; r0 += 64u) {                         // (wave-uniform)
-            const uint32_t i = r0 + (uint32_t)l; const bool valid = i < NE;
-            const uint32_t en = valid ? S.list[i] : 0xFFFFFFFFu;
-            const uint32_t ep = wave_shr1(en, carry_e); carry_e = wave_last(en);
-            const uint32_t j = (en >> 19) & 63u, pos = en & 0xFFFu, kind = (en >> 12) & 3u, jp = ep == 0xFFFFFFFFu ? 0xFFu : ((ep >> 19) & 63u);
-            const bool first = valid && j != jp;                            // my stream's first entry of the step
-            const int p = (int)(sb + pos);
-            uint32_t nb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            if (valid && kind == 1u) {
-                const int prevp = first ? S.prev[j] : (int)(sb + (ep & 0xFFFu));
-                const uint32_t d = (uint32_t)(p - prevp), v = d - 1u;
-                if (d <= 128u) { nb = 1; t0 = v; } else if (d <= 16384u) { nb = 2; t0 = (v >> 8) | 0x80u; t1 = v & 0xFFu; } else { nb = 4; t0 = (v >> 24) | 0xE0u; t1 = (v >> 16) & 0xFFu; t2 = (v >> 8) & 0xFFu; t3 = v & 0xFFu; }
-            } else if (valid && kind == 2u) { nb = 1; t0 = 0; }
-            else if (valid && kind == 3u) { nb = 1; t0 = 0xC0u | ((en >> 14) & 31u); }
-            // byte offsets: a sum over the round, cut at the stream boundaries
-            const uint32_t incl = wave_incl_sum<uint32_t>(nb);
-            const unsigned long long bm = __ballot(first || (valid && l == 0));
-            const unsigned long long upto = l == 63 ? ~0ull : ((2ull << l) - 1ull);
-            const int segl = 63 - __clzll((long long)((bm & upto) | 1ull));
-            const uint32_t excl = incl - nb - (uint32_t)__shfl((int)(incl - nb), segl);
-            const uint32_t o = valid ? S.outpos[j] + excl : 0u;
-            if (valid && nb && o + nb <= S.room[j]) {
-                uint8_t* op = (uint8_t*)(uintptr_t)S.out[j] + o;
-                op[0] = (uint8_t)t0; if (nb >= 2u) op[1] = (uint8_t)t1; if (nb == 4u) { op[2] = (uint8_t)t2; op[3] = (uint8_t)t3; }
+        // ---- tokens: stream after stream, 64 entries of its part of the list per round.  The stream's state - previous match, bytes written - is the same
+        // for every lane (scalar registers); an entry's previous match is the entry in front of it (a shift by one lane, the round in front by its last lane).
+        for (uint32_t j = 0; j < nn; j++) {                                // (wave-uniform)
+            const uint32_t b0 = uni32(S.off[j]), b1 = uni32(S.off[j + 1]);
+            if (b0 == b1) continue;
+            int prevp = (int)uni32((uint32_t)S.prev[j]);
+            const PlStream ps = S.str[j]; uint32_t outpos = uni32(ps.outpos); const uint32_t room = uni32(ps.room); uint8_t* const outp = (uint8_t*)(uintptr_t)uni64(ps.out);
+            for (uint32_t r0 = b0; r0 < b1; r0 += 64u) {                    // (wave-uniform)
+                const uint32_t i = r0 + (uint32_t)l; const bool valid = i < b1;
+                const uint32_t en = valid ? (uint32_t)S.list[i] : 0u, pos = en & 0xFFFu, code = en >> 12;
+                const int p = (int)(sb + pos), pp = wave_shr1(p, prevp);
+                uint32_t nb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                if (valid && code == 1u) {
+                    const uint32_t d = (uint32_t)(p - pp), v = d - 1u;
+                    if (d <= 128u) { nb = 1; t0 = v; } else if (d <= 16384u) { nb = 2; t0 = (v >> 8) | 0x80u; t1 = v & 0xFFu; } else { nb = 4; t0 = (v >> 24) | 0xE0u; t1 = (v >> 16) & 0xFFu; t2 = (v >> 8) & 0xFFu; t3 = v & 0xFFu; }
+                } else if (valid && code >= 2u && code < 15u) { nb = 1; t0 = code == 2u ? 0u : (0xC0u | (code - 3u)); }
+                if (__any(valid && code == 15u)) {                          // (rare) a run token that covers 13 .. 32 matches: they are the entries behind me at consecutive positions
+                    if (valid && code == 15u) {
+                        uint32_t L = 1;
+#pragma unroll
+                        for (uint32_t stp = 16; stp >= 1; stp >>= 1) { const uint32_t k = L - 1u + stp; if (i + k < b1 && ((uint32_t)S.list[i + k] & 0xFFFu) == pos + k) L += stp; }
+                        if (L < 32u && i + L == b1 && pos + L == 4096u) L += S.after;
+                        if (L > 32u) L = 32u;
+                        nb = 1; t0 = 0xC0u | (L - 1u);
+                    }
+                }
+                const uint32_t incl = wave_incl_sum<uint32_t>(nb), o = outpos + incl - nb;
+                if (nb && o + nb <= room) { uint8_t* op = outp + o; op[0] = (uint8_t)t0; if (nb >= 2u) op[1] = (uint8_t)t1; if (nb == 4u) { op[2] = (uint8_t)t2; op[3] = (uint8_t)t3; } }
+                outpos += wave_last(incl);
+                const uint32_t nlast = b1 - r0 < 64u ? b1 - r0 - 1u : 63u;   // the round's last entry
+                prevp = wave_read(p, nlast);
             }
-            const uint32_t jn = (uint32_t)__shfl_down((int)j, 1u);
-            const bool lastl = valid && (l == 63 || i + 1u >= NE || jn != j);
-            wave_lds_sync();                                                // (every lane has read its stream's state)
-            if (lastl) S.outpos[j] = o + nb;
-            wave_lds_sync();
+            if (l == 0) { S.str[j].outpos = outpos; S.prev[j] = prevp; }
         }
-        if ((uint32_t)l < nn && S.on[l] && S.off[l + 1] > S.off[l]) S.prev[l] = (int)(sb + (S.list[S.off[l + 1] - 1u] & 0xFFFu));
         carry_byte = wave_last(nv == 64u ? lastb : 0x100u); carry_R = wave_last(tailR);
         wave_lds_sync();
     }
     if ((uint32_t)l < nn && S.on[l]) {
-        segb[((size_t)c * MAX_STREAMS + (uint32_t)l) * n_seg + seg] = S.outpos[l];
-        if (S.outpos[l] > S.room[l]) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
+        segb[((size_t)c * MAX_STREAMS + (uint32_t)l) * n_seg + seg] = S.str[l].outpos;
+        if (S.str[l].outpos > S.str[l].room) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
     }
 }
 
@@ -2695,7 +2741,7 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
                            const uint8_t* __restrict__ qcat, const uint32_t* __restrict__ spk, const uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
                            const uint8_t* __restrict__ scratch_n, const uint64_t* __restrict__ cbase_n, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ ys, const int8_t* __restrict__ ovb,
                            uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2,
-                           const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, DevStatus* st,
+                           const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segd, const uint32_t* __restrict__ segs, uint32_t n_seg, DevStatus* st,
                            uint32_t tail_bases, uint32_t tail_units, uint32_t tail_nl1, uint32_t tail_nl2, uint64_t tail_n1, uint64_t tail_n2) {
     const uint32_t c = blockIdx.y; const Layout o = L[c];
     const uint64_t at = img_base + C.img_off[c];
@@ -2781,11 +2827,8 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
             const uint32_t jj = pc / n_seg, seg = pc - jj * n_seg, js = jj < nn ? jj : (uint32_t)EXC_SLOT; const size_t si0 = (k0 + js) * n_seg;
             const uint32_t sz = C.scap[k0 + js] ? segb[si0 + seg] : 0u;
             if (!sz) continue;                                               // wave-uniform
-            uint32_t dst = o.off_qual + 4 * nn, so = 0;
-            for (uint32_t j2 = 0; j2 < jj; j2++) dst += C.ssize[k0 + j2];
-            for (uint32_t s2 = 0; s2 < seg; s2++) { dst += segb[si0 + s2]; so += pc_seg_cap(js == EXC_SLOT, segm[si0 + s2], PC_SEG_POS); }
             (void)qlen;
-            copy_to_image(out + dst, sc + C.soff[k0 + js] + so, sz, l, 64u);
+            copy_to_image(out + o.off_qual + 4 * nn + segd[si0 + seg], sc + C.soff[k0 + js] + segs[si0 + seg], sz, l, 64u);
         }
     }
     if (il && (hf & H_PE_OVERLAP)) for (uint32_t i = t; i < s / 2; i += NT) out[o.off_ov + i] = (uint8_t)ovb[(f >> 1) + i];
@@ -2793,9 +2836,7 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
         const size_t si0 = (k0 + NPOS_SLOT) * n_seg; const uint32_t nw = NT >> 6, wv = t >> 6; const uint32_t l = t & 63u;
         for (uint32_t seg = wv; seg < n_seg; seg += nw) {
             const uint32_t sz = segb[si0 + seg]; if (!sz) continue;
-            uint32_t dst = o.off_npos, so = 0;
-            for (uint32_t s2 = 0; s2 < seg; s2++) { dst += segb[si0 + s2]; so += pc_seg_cap(false, segm[si0 + s2], PC_SEG_POS); }
-            copy_to_image(out + dst, scratch_n + cbase_n[c] + C.soff[k0 + NPOS_SLOT] + so, sz, l, 64u);
+            copy_to_image(out + o.off_npos + segd[si0 + seg], scratch_n + cbase_n[c] + C.soff[k0 + NPOS_SLOT] + segs[si0 + seg], sz, l, 64u);
         }
     }
 }
