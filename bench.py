@@ -31,12 +31,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 # stage (HIP-event pair inside librfq_hip) -> the kernels it brackets (names as rocprofv3 reports them)
-STAGE_KERNELS = {"index": ["k_line_index", "k_line_tail"], "index_2pass": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "read_table+cut": ["k_read_table", "k_unit_len", "k_partition"],
-                 "chunk_flags": ["k_chunk_flags_se", "k_chunk_flags_pe", "k_chunk_flags_a", "k_chunk_flags_b", "k_chunk_bases"],
-                 "gather": ["k_gather2", "k_stream_plan"], "gather_bytes": ["k_overlap", "k_overlap_apply", "k_pv_in", "k_gather", "k_packbytes", "k_stream_plan", "k_chunk_layout"],
+STAGE_KERNELS = {"index": ["k_line_index", "k_line_tail"], "index_2pass": ["k_nl_bitmap", "k_line_offsets", "k_line_tail"], "lens+cut": ["k_read_lens", "k_partition"],
+                 "chunk_flags": ["k_chunk_flags_a", "k_chunk_flags_b", "k_chunk_bases"],
+                 "gather": ["k_gather2", "k_mask_bounds", "k_chunk_flags_b", "k_stream_plan"], "gather_bytes": ["k_overlap", "k_overlap_apply", "k_pv_in", "k_gather", "k_packbytes", "k_stream_plan", "k_chunk_layout"],
                  # (tile gather: the overlap search on the loose slots, the stored prefix, the sequence packer and the N streams run on the second stream beside the coder)
-                 "pos_coder": ["k_pos_coder", "k_overlap", "k_overlap_apply", "k_pv_in", "k_scan_reduce<U4>", "k_scan_apply<U4>", "k_seqpack", "k_chunk_layout", "k_coords"],
-                 "coords+layout": ["k_pos_sizes", "k_chunk_layout"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_hdr_stats", "k_hdr_pass2"],
+                 "pos_coder": ["k_pos_coder", "k_pos_coder_list", "k_overlap", "k_chunk_prefix", "k_seqpack", "k_chunk_layout", "k_coords", "k_rare_cleanup"],
+                 "coords+layout": ["k_pos_sizes", "k_chunk_layout"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_read_table", "k_hdr_stats", "k_hdr_pass2", "k_dense_order"],
                  "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
                  "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list", "k_dec_textlen",   # (fused path: the text lengths run beside the list chain)
                                  # (reads longer than 2000 bases, -k values whose chunks exceed 4096 records, and legacy RLE files take the materialising path)
@@ -263,31 +263,109 @@ class Workload:
         return stage, enc_ms, dec_ms
 
 
-def roofline_of(w, stage, enc_ms, dec_ms, traffic_key):
+def roofline_of(w, stage, enc_ms, dec_ms, traffic_key, live=None, live_note=None):
     """The dominant kernel (longest HIP-event stage of either direction) against the HBM roofline, on ALGORITHMIC bytes (SURVEY.md
     §8(d): B_fastq + B_rfq per direction of a batch)."""
     if not stage:
         return None
     dom = dominant_kernel_stage(stage); longest = max(stage, key=stage.get)
     alg = float(w.n + w.rfq_len)
-    traffic = None
-    pjs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-    pj = os.path.join(ROOT, "profiles", pjs[-1]) if pjs else ""
-    if pj and os.path.exists(pj):
-        pmc = json.load(open(pj)).get(traffic_key)
-        if pmc and pmc.get("units") == w.units:
-            ks = [k for k in STAGE_KERNELS.get(dom, []) if k in pmc["kernels"]]
-            traffic = int(sum(pmc["kernels"][k]["fetch_bytes"] + pmc["kernels"][k]["write_bytes"] for k in ks)) if ks else None
+    traffic = None; kernels = None; source = None
+    if live:
+        kernels, source = live, live_note
+    else:
+        pjs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        pj = os.path.join(ROOT, "profiles", pjs[-1]) if pjs else ""
+        if pj and os.path.exists(pj):
+            pmc = json.load(open(pj)).get(traffic_key)
+            if pmc and pmc.get("units") == w.units:
+                kernels = pmc["kernels"]
+                source = "NOT measured in this run (%s): the committed PMC passes of this workload, profiles/%s" % (live_note or "not asked for", pjs[-1])
+    def kernel_traffic(names):
+        ks = [k for k in names if kernels and k in kernels]
+        return int(sum(kernels[k]["fetch_bytes"] + kernels[k]["write_bytes"] for k in ks)) if ks else None
+    traffic = kernel_traffic(STAGE_KERNELS.get(dom, []))
+    per_step = None
+    if kernels and live:
+        tot = {"encode": 0.0, "decode": 0.0}
+        for k, v in kernels.items():
+            for side, share in side_of(k).items():
+                tot[side] += share * (v["fetch_bytes"] + v["write_bytes"])
+        top = sorted(((k, v["fetch_bytes"], v["write_bytes"]) for k, v in kernels.items() if k.startswith("k_")), key=lambda t: -(t[1] + t[2]))[:12]
+        per_step = {"encode_bytes": int(tot["encode"]), "decode_bytes": int(tot["decode"]), "encode_per_fastq_byte": round(tot["encode"] / w.n, 3), "decode_per_fastq_byte": round(tot["decode"] / w.n, 3),
+                    "algorithmic_per_fastq_byte": round(alg / w.n, 3), "top_kernels_MB": {k: [round(f / 1e6, 1), round(wr / 1e6, 1)] for k, f, wr in top}}
+    # the longest single kernel of the ENCODE side next to the dominant one (which has been the emitter of the decode side)
+    enc_dom = max((k for k in stage if k in KERNEL_STAGES and not k.startswith("dec:")), key=stage.get, default=None)
+    enc_kernel = None
+    if enc_dom:
+        a = alg / (stage[enc_dom] * 1e-3) / 1e9
+        enc_kernel = {"kernel": STAGE_KERNELS.get(enc_dom, [enc_dom])[0], "stage": enc_dom, "avg_launch_ms": round(stage[enc_dom], 4), "achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBS, 4),
+                      "traffic": kernel_traffic(STAGE_KERNELS.get(enc_dom, [])[:1])}
     ach = alg / (stage[dom] * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": STAGE_KERNELS.get(dom, [dom])[0], "stage": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "longest_stage": {"stage": longest, "ms": round(stage[longest], 4), "kernels": STAGE_KERNELS.get(longest, [longest])},
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(stage[dom], 4),
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source, "hbm_traffic_per_step": per_step, "encode_kernel": enc_kernel,
+            "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(stage[dom], 4),
             "note": "achieved = one direction's algorithmic bytes (B_fastq + B_rfq) / the HIP-event time of the longest single kernel (its stage holds nothing else of weight): an upper bound for that kernel; "
                     "longest_stage = the longest timed phase, which may be several kernels on two streams; "
-                    "whole_*_frac divide the same bytes by the whole direction's device time; traffic = that kernel's HBM bytes per launch from the committed "
-                    "rocprofv3 PMC passes of this workload (profiles/*_pmc_traffic.json, the newest), null if none was collected at this size",
+                    "whole_*_frac divide the same bytes by the whole direction's device time; traffic = that kernel's HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, KB), "
+                    "see traffic_source; hbm_traffic_per_step = the same counters summed over all kernels of a direction; encode_kernel = the encode side's longest single kernel",
             "whole_encode_frac": round(alg / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if enc_ms else None,
             "whole_decode_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}
+
+
+def pmc_traffic_live(workload, chunk_kb, units, seed, timeout_s=300):
+    """HBM traffic per kernel of ONE step of `workload`, measured now: this script re-executes itself twice under rocprofv3 - `--pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE`, each in its own run with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE x 2 on
+    gfx950: tools/pmc_summary.py) - on one warm-up and one timed step, and sums every kernel's counters over a step.  None when rocprofv3 is not there or a
+    pass fails (the caller then falls back to the committed profiles/*_pmc_traffic.json and says so)."""
+    import glob
+    import shutil
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary as P
+    except Exception as e:                               # noqa: BLE001
+        return None, "tools/pmc_summary.py: %s" % e
+    got = {}
+    work = tempfile.mkdtemp(prefix="rfq_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload,
+                   "--steps", "1", "--warmup", "1", "--chunk-kb", str(chunk_kb), "--no-cpu-baseline", "--no-secondary", "--no-verify", "--no-pmc"]
+            if units:
+                cmd += ["--units", str(units)]
+            if seed is not None:
+                cmd += ["--seed", str(seed)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            got[counter] = P.per_kernel(dbs[0], counter)
+    except Exception as e:                               # noqa: BLE001
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    passes = 2.0                                         # the child runs the step twice (one warm-up, one timed); counters are summed over both
+    ker = {}
+    for k in set(got["FETCH_SIZE"]) | set(got["WRITE_SIZE"]):
+        nf, vf = got["FETCH_SIZE"].get(k, (0, 0.0)); nw, vw = got["WRITE_SIZE"].get(k, (0, 0.0))
+        ker[k] = {"fetch_bytes": 2.0 * vf * 1024 / passes, "write_bytes": vw * 1024 / passes, "launches_per_step": max(nf, nw) / passes}
+    return ker, "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of this script, --kernel-trace only, one step each; KB units, FETCH_SIZE x 2 on gfx950)"
+
+
+def side_of(kernel):
+    """which direction a kernel belongs to, for the per-step traffic totals (scans: the tile path's encode uses the u64 / u32 ones, decode the U4 ones and one u32)"""
+    if kernel.startswith("k_dec_"):
+        return {"decode": 1.0}
+    if kernel.startswith("k_scan_"):
+        return {"decode": 1.0} if "U4" in kernel else ({"encode": 0.5, "decode": 0.5} if "unsigned int" in kernel else {"encode": 1.0})
+    if kernel.startswith("k_") :
+        return {"encode": 1.0}
+    return {}
 
 
 def line_of(w, steps, dt, total_bytes, parity):
@@ -300,6 +378,29 @@ def line_of(w, steps, dt, total_bytes, parity):
 
 
 SEG_PAIRS, SEG_SEED0, SEGS_PER_GPU, HEAD_PAIRS = 2_800_000, 4000, 8, 4000
+
+
+def pin_to_gpu_numa(local):
+    """Bind this process to the CPUs of the NUMA node its GPU hangs off (set-up work - generating the rank's text, the host side of hipMemcpy - then stays off
+    the other sockets' memory).  Returns the node, or None when the topology cannot be read (nothing is changed then)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:                                    # noqa: BLE001
+        pass
+    return None
 
 
 def run_multi(args, rank, world, local):
@@ -330,14 +431,21 @@ def run_multi(args, rank, world, local):
         per = per // world
     cb = max(100, args.chunk_kb) * 1000
     # ---- this rank's share (+ the head of the next one), generated straight into one buffer per stream
-    parts1, parts2 = [], []
-    for s_ in range(per * rank, per * rank + per):
-        a, b = O.gen_np(O.NOVA_PE150, seg_pairs, seed=SEG_SEED0 + s_)
-        parts1.append(a); parts2.append(b)
+    # (set-up, untimed: the generator is a C loop that drops the GIL - the rank's segments are made on several threads, on the cores next to its GPU)
+    numa = pin_to_gpu_numa(local)
+    t_gen = time.perf_counter()
+    from concurrent.futures import ThreadPoolExecutor
+    gen_threads = max(1, min(per, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)) // max(1, world if numa is None else 1), 8))
+    with ThreadPoolExecutor(gen_threads) as ex:
+        segs = list(ex.map(lambda s_: O.gen_np(O.NOVA_PE150, seg_pairs, seed=SEG_SEED0 + s_), range(per * rank, per * rank + per)))
+    parts1, parts2 = [a for a, _ in segs], [b for _, b in segs]
+    a = b = None
+    del segs
     share1, share2 = sum(int(x.size) for x in parts1), sum(int(x.size) for x in parts2)
     if rank < world - 1:
         a, b = O.gen_np(O.NOVA_PE150, min(HEAD_PAIRS, seg_pairs), seed=SEG_SEED0 + per * (rank + 1))
         parts1.append(a); parts2.append(b)
+    gen_s = time.perf_counter() - t_gen
     h1 = torch.from_numpy(np.concatenate(parts1)); h2 = torch.from_numpy(np.concatenate(parts2))
     del parts1, parts2, a, b
     avail1, avail2 = int(h1.numel()), int(h2.numel())
@@ -425,8 +533,16 @@ def run_multi(args, rank, world, local):
         step(True)
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
+    my_dt = dt
     dt, total = D.reduce_max_sum(dt, n1 + n2)
     rfq_total = D.reduce_max_sum(0.0, r.rfq_len)[1]
+    # every rank's own line (a straggler must be visible in the one JSON object rank 0 prints)
+    K_ = args.steps
+    mine_line = {"rank": rank, "gpu": local, "numa_node": numa, "fastq_bytes": n1 + n2, "chunks": r.n_chunks, "s_per_step": round(my_dt / K_, 5),
+                 "encode_MBps": round((n1 + n2) * K_ / state["enc_s"] / 1e6, 1) if state["enc_s"] else None, "decode_MBps": round((n1 + n2) * K_ / state["dec_s"] / 1e6, 1) if state["dec_s"] else None,
+                 "setup_generate_s": round(gen_s, 1), "gen_threads": gen_threads, "stage_ms": {k: round(v / K_, 3) for k, v in state["stage"].items()}}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, mine_line)
     if rank == 0:
         K = args.steps; passes = 1 if args.encode_only else 2
         stage = {k: v / K for k, v in state["stage"].items()}
@@ -439,7 +555,7 @@ def run_multi(args, rank, world, local):
                                       "chunk-parallel over %d GPUs (each encodes + decodes the byte range resident in its HBM; plan + header over the host, no RCCL)"
                                       % (world, share1 / 1e9, total / 2e9, per * world, seg_pairs, SEG_SEED0, args.chunk_kb, world),
                           "rfq_over_fastq": round(rfq_total / total, 4), "parity": parity,
-                          "plan": plan.get("plan"), "plan_ms": round(plan_ms, 2), "strong": bool(args.strong),
+                          "plan": plan.get("plan"), "plan_ms": round(plan_ms, 2), "strong": bool(args.strong), "ranks": ranks,
                           "rank0": {"chunks": r.n_chunks, "encode_MBps": round((n1 + n2) * K / state["enc_s"] / 1e6, 1), "decode_MBps": round((n1 + n2) * K / state["dec_s"] / 1e6, 1) if state["dec_s"] else None,
                                     "stage_ms": {k: round(v, 3) for k, v in stage.items()}}},
                "roofline": None if not dom else {"bound": "hbm", "kernel": STAGE_KERNELS.get(dom, [dom])[0], "stage": dom, "achieved": round(alg / (stage[dom] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
@@ -467,6 +583,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (kernel ablation runs with RFQ_TUNE set)")
     ap.add_argument("--seg-pairs", type=int, default=SEG_PAIRS, help="N>1: pairs per segment of the logical input (test aid: smaller inputs)")
     ap.add_argument("--segs-per-gpu", type=int, default=SEGS_PER_GPU, help="N>1: segments per GPU share (configs[3]: 8 x 2.8 M pairs = 2 x 8 GB per GPU)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two extra passes of one step under rocprofv3 --pmc): take the committed profiles/*_pmc_traffic.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the counter passes: one warm-up + one step, nothing else
     ap.add_argument("--strong", action="store_true", help="N>1: strong scaling - the input is --segs-per-gpu segments IN ALL (default 8 = 2 x 8 GB), split over the N GPUs")
     args = ap.parse_args()
 
@@ -492,7 +610,10 @@ def main():
     parity = "unchecked" if args.no_verify else w.check()
     dt = w.run(args.steps, args.warmup, sync, lambda: None)
     head, stage, enc_ms, dec_ms = line_of(w, args.steps, dt, w.n, parity)
+    if args.pmc_child:
+        print(json.dumps({"pmc_child": True, "value": head["value_MBps"]})); codec.close(); return
     walk = w.decode_walk(args.steps, sync) if w.do_decode else None
+    live, live_note = (None, "--no-pmc") if args.no_pmc else pmc_traffic_live(args.workload, args.chunk_kb, args.units, args.seed)
     out = {
         "metric": "raw FASTQ MB/s encode+decode" if w.do_decode else "raw FASTQ MB/s encode",
         "value": head["value_MBps"], "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -504,7 +625,7 @@ def main():
                    "decode_MBps_walk": walk[0] if walk else None, "walk_ms": walk[1] if walk else None,
                    "value_MBps_walk": round(2 * w.n / (w.n / (head["encode_MBps"] * 1e6) + w.n / (walk[0] * 1e6)) / 1e6, 1) if walk and head["encode_MBps"] else None,
                    "parity": parity, "stage_ms": head["stage_ms"]},
-        "roofline": roofline_of(w, stage, enc_ms, dec_ms, args.workload),
+        "roofline": roofline_of(w, stage, enc_ms, dec_ms, args.workload, live, live_note),
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w.a1, w.a2, w.paired, w.units, args.cpu_sample)

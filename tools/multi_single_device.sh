@@ -1,7 +1,7 @@
 #!/bin/bash
 # N > 1 control flow on ONE GPU (RFQ_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0): the plan (parallel scans), every rank's encode + decode of its own byte
 # range, the chunk tables of all ranks against the reference's golden for the configs[3] input.  The rates say nothing (the ranks share one GPU);
-# the parity strings and plan_ms do.  usage (on the box): bash tools/r03_multi.sh <tag>
+# the parity strings and plan_ms do.  usage (on the box): bash tools/multi_single_device.sh <tag>
 set -u
 TAG=${1:-r03multi}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd $ROOT
