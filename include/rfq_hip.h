@@ -182,6 +182,9 @@ int rfq_copy_peer(rfq_ctx* ctx, void* d_dst, const rfq_ctx* src_ctx, const void*
 /* page-locked host buffers (hipHostMalloc): H2D / D2H copies from them run at full PCIe rate */
 int rfq_host_alloc(rfq_ctx* ctx, void** h_ptr, size_t n);
 int rfq_host_free(rfq_ctx* ctx, void* h_ptr);
+/* the same for memory the caller owns (hipHostRegister / hipHostUnregister): buffers a host filled before the context existed */
+int rfq_host_register(rfq_ctx* ctx, void* h_ptr, size_t n);
+int rfq_host_unregister(rfq_ctx* ctx, void* h_ptr);
 
 /* --compare on the device (Repaq::compare / comparePE, src/repaq.cpp:36-233): the first offset at which two device texts differ,
  * *first_diff = n when they are identical.  A decoded batch equal byte for byte to the same span of the FASTQ text passes the

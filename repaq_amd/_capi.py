@@ -104,4 +104,4 @@ def load(path=None):
 EXPORTS = ["rfq_version", "rfq_create", "rfq_destroy", "rfq_last_error", "rfq_set_stream", "rfq_set_header", "rfq_get_header", "rfq_clear_header",
            "rfq_encode_batch", "rfq_scan_batch", "rfq_decode_batch", "rfq_last_timings", "rfq_dev_malloc", "rfq_dev_free", "rfq_copy_h2d", "rfq_copy_d2h",
            "rfq_copy_h2d_async", "rfq_copy_done", "rfq_copy_sync",
-           "rfq_copy_d2d", "rfq_copy_peer", "rfq_host_alloc", "rfq_host_free", "rfq_compare_bytes", "rfq_selftest_wave", "rfq_set_option"]
+           "rfq_copy_d2d", "rfq_copy_peer", "rfq_host_alloc", "rfq_host_free", "rfq_compare_bytes", "rfq_selftest_wave", "rfq_set_option", "rfq_host_register", "rfq_host_unregister"]

@@ -220,6 +220,18 @@ extern "C" int rfq_host_alloc(rfq_ctx* c, void** p, size_t n) {
     return RFQ_OK;
 }
 extern "C" int rfq_host_free(rfq_ctx* c, void* p) { if (!c) return RFQ_E_ARG; if (p) HIPCHK(c, hipHostFree(p)); return RFQ_OK; }
+// page-lock memory the caller already owns (hipHostRegister): a driver that starts reading its input before the HIP runtime is up locks those buffers afterwards
+extern "C" int rfq_host_register(rfq_ctx* c, void* h_ptr, size_t n) {
+    if (!c || !h_ptr || !n) return RFQ_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostRegister(h_ptr, n, hipHostRegisterDefault));
+    return RFQ_OK;
+}
+extern "C" int rfq_host_unregister(rfq_ctx* c, void* h_ptr) {
+    if (!c || !h_ptr) return RFQ_E_ARG;
+    HIPCHK(c, hipHostUnregister(h_ptr));
+    return RFQ_OK;
+}
 extern "C" int rfq_copy_d2h(rfq_ctx* c, void* h, const void* d, size_t n) {
     if (!c) return RFQ_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));

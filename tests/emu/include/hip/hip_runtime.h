@@ -191,6 +191,9 @@ static inline hipError_t hipMalloc(void** p, size_t n) { *p = nullptr; if (posix
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+#define hipHostRegisterDefault 0u
+static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }

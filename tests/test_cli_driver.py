@@ -135,6 +135,16 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
             assert o1.read_bytes() == pa.read_bytes() and o2.read_bytes() == pb.read_bytes()
         else:
             assert o1.read_bytes() == ref
+    # bytes behind the chain's end (an mReads == 0 record, then anything: the reference stops reading there, src/repaq.cpp:287-292) and an implausible chunk
+    # header in mid-image: the host's walk cannot index those - the multi-device path then hands the rest to the device's own walk, as the one-device path
+    # does, and writes the same text / gives the same error (it used to exit with "cannot index" after it had opened its outputs)
+    padded = tmp_path / "padded.rfq"; padded.write_bytes(og.read_bytes() + bytes(64))
+    texts = []
+    for extra in ([], ["--devices", "0,0"]):
+        o1 = tmp_path / "padded_back.fq"
+        r = _run(binary, ["-d", "-i", str(padded), "-o", str(o1), "--batch_mb", str(batch_mb)] + extra)
+        texts.append((r.returncode, o1.read_bytes() if r.returncode == 0 else r.stderr))
+    assert texts[0] == texts[1] and texts[0] == (0, fq1), texts[0][0]
     # a file of exactly 1 MiB without a final line break: only the chunk that holds the last record carries the line-break bit (ADVICE r1;
     # the driver computes the threshold itself, one-shot and under --devices)
     from cases import CASES
