@@ -41,11 +41,11 @@ STAGE_KERNELS = {"index": ["k_line_index", "k_line_tail"], "index_2pass": ["k_nl
                  "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list", "k_dec_textlen",   # (fused path: the text lengths run beside the list chain)
                                  # (reads longer than 2000 bases, -k values whose chunks exceed 4096 records, and legacy RLE files take the materialising path)
                                  "k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_pos_index", "k_dec_except", "k_dec_rle"],
-                 "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit3"], "dec:emit2": ["k_dec_emit2", "k_dec_emit"]}
+                 "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit3"], "dec:emit_expanded": ["k_dec_emit"]}
 
 # stages that are ONE kernel (the roofline object is about a kernel: the longest of these; "pos_coder" is a phase of two streams - the coder beside the
 # overlap / prefix / sequence-packer chain - and is reported as `longest_stage`)
-KERNEL_STAGES = ("dec:emit", "dec:emit2", "gather")
+KERNEL_STAGES = ("dec:emit", "dec:emit_expanded", "gather")
 
 
 def dominant_kernel_stage(stage):

@@ -27,18 +27,15 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     else if (n == "RFQ_STREAMS") c->opt.one_stream = set && num == 1;
     else if (n == "RFQ_SLICE_BYTES") c->opt.slice_bytes = set ? (size_t)num : 0;
     else if (n == "RFQ_SLICE_BASES") c->opt.slice_bases = set ? (uint64_t)num : 0;
-    else if (n == "RFQ_EMIT") { if (set && num != 2 && num != 3) return rfq_fail(c, RFQ_E_ARG, "RFQ_EMIT is 2 or 3"); c->opt.emit = set && num == 2 ? 2 : 0; }
-    else if (n == "RFQ_WALK") { if (set && v != "chain" && v != "exact" && v != "guess") return rfq_fail(c, RFQ_E_ARG, "RFQ_WALK is guess, chain or exact"); c->opt.walk = v == "chain" ? 1 : (v == "exact" ? 2 : 0); }
+    else if (n == "RFQ_WALK") { if (set && v != "exact" && v != "guess") return rfq_fail(c, RFQ_E_ARG, "RFQ_WALK is guess or exact"); c->opt.walk_exact = v == "exact"; }
     else if (n == "RFQ_GW_SHIFT") c->opt.gw_shift = set ? (int)std::min<long long>(30, std::max<long long>(4, num)) : d.gw_shift;
     else if (n == "RFQ_MATERIALISE") c->opt.materialise = set && num != 0;
     else if (n == "RFQ_TRACE") c->opt.trace = set && v != "0";
-    else if (n == "RFQ_AUX_PRIO") c->opt.aux_priority = set && num != 0;
-    else if (n == "RFQ_E3_OCC") c->opt.e3_occ = set && num == 6 ? 6 : 5;
     else if (n == "RFQ_G2_PAD") c->opt.g2_pad = set ? (uint32_t)num : 0u;
     else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
     return RFQ_OK;
 }
-static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD", "RFQ_AUX_PRIO", "RFQ_E3_OCC" };
+static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD" };
 
 extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (!out) return RFQ_E_ARG;

@@ -45,7 +45,7 @@
 #define DE_QUAL_OVERFLOW   (1u << 6)  // quality payload > 1.5 x bases: overflows the reference's scratch (UB)
 #define DE_NO_QUAL_BINS    (1u << 7)  // "bad quality string"
 #define DE_CORRUPT         (1u << 8)  // decode: inconsistent chunk image
-#define DE_E3_RETRY        (1u << 29) // decode, k_dec_emit3: a tile's per-read name pieces do not fit its LDS tiles: emit the range with k_dec_emit2
+#define DE_E3_RETRY        (1u << 29) // decode, k_dec_emit3: a tile's per-read name pieces do not fit its LDS tiles: the range is emitted again by the expanded path (k_dec_emit)
 #define DE_INDEX_RETRY     (1u << 30) // encode, one-pass line index: more lines than the table sized in advance holds (or a wait that did not end): index in two passes
 #define DE_TAIL_BLANK      (1u << 9)  // an empty line in the \n-only text right behind the encoded records: blank or empty is for the normaliser to say
 

@@ -73,18 +73,15 @@ struct RfqOpts {
     bool one_stream = false;          // RFQ_STREAMS=1      no second stream: every kernel of a batch on the context's stream
     size_t slice_bytes = 0;           // RFQ_SLICE_BYTES    encode: slices of that many bytes per stream (so that the slicing logic runs on small inputs)
     uint64_t slice_bases = 0;         // RFQ_SLICE_BASES    decode: ranges of that many bases
-    int  emit = 0;                    // RFQ_EMIT=2         decode: the tile emitter k_dec_emit2 instead of k_dec_emit3
-    int  walk = 0;                    // RFQ_WALK=chain|exact   decode without a chunk index: 1 = the mSize chain by one wave, 2 = the exact serial walk; 0 = guess and verify
+    bool walk_exact = false;          // RFQ_WALK=exact     decode without a chunk index: straight to the exact serial walk (default: guess and verify, that walk behind it)
     int  gw_shift = 16;               // RFQ_GW_SHIFT       log2 of the smallest guess-and-verify segment
     bool materialise = false;         // RFQ_MATERIALISE=1  decode: qualities / bases expanded in HBM (the path of a streaming caller's non-final slices) on every call
     bool trace = false;               // RFQ_TRACE          a line on stderr about how chunk starts were found
-    bool aux_priority = false;        // RFQ_AUX_PRIO=1     the second stream with a higher priority (measured: nothing on encode, 0.3 ms worse on decode)
-    int  e3_occ = 5;                  // RFQ_E3_OCC=6       decode: k_dec_emit3 compiled for six waves per SIMD (80 VGPRs)
     uint32_t g2_pad = 0;              // RFQ_G2_PAD         profiling aid: bytes of unused dynamic LDS added to k_gather2 (fewer resident workgroups)
 };
 struct rfq_ctx {
     RfqOpts opt;
-    bool e3_pieces_failed = false;       // decode: a tile of k_dec_emit3 did not hold its reads' name pieces - files like this one go to k_dec_emit2
+    bool e3_pieces_failed = false;       // decode: a tile of k_dec_emit3 did not hold its reads' name pieces - files like this one go to the expanded path
     int device = 0; uint32_t n_cu = 256;                                         // compute units of the device (rfq_create)
     hipStream_t stream = nullptr; bool own_stream = false;
     // second stream for small latency-bound kernels that are independent of the main chain (coordinate coder / decoder): fork with
@@ -97,10 +94,9 @@ struct rfq_ctx {
     bool aux_ready() {
         if (aux) return true;
         // (the second stream carries the chains of small, latency-bound kernels - stored prefix, sequence packer, N coder, coordinates; decode: the list
-        // chain - beside one large VALU-bound kernel on the main stream: with a higher priority their workgroups get the slots they need when they are ready)
-        { int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-          const bool prio = opt.aux_priority && hi_p != lo_p;
-          if ((prio ? hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi_p) : hipStreamCreateWithFlags(&aux, hipStreamNonBlocking)) != hipSuccess) { aux = nullptr; return false; } }
+        // chain - beside one large VALU-bound kernel on the main stream.  A higher stream priority for it was measured in round 4: nothing on
+        // encode, 0.3 ms worse on decode - plain streams)
+        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; return false; }
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_mid, hipEventDisableTiming) != hipSuccess) return false;
         if (hipStreamCreateWithFlags(&aux2, hipStreamNonBlocking) != hipSuccess) { aux2 = nullptr; return false; }

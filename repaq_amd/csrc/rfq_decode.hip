@@ -47,7 +47,21 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // tile; RFQ_TUNE bit 11 forces the materialising path.
     const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
     const bool rle_h = !(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL));          // legacy run-length quality coding: k_dec_rle on the materialising path
-    const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u;
+    // The fused path ends in k_dec_emit3 (no output tile, K reads per tile: the largest power of two whose qualities fit its tile).  Names FastqMeta::parse does not
+    // take apart and strand lines with text are stored per read: K then also goes by the chunks' average piece size, a fifth of the tile left for reads above the
+    // average, full tiles of 64 reads only (name1 has a second instantiation with a 13 KB tile: names of up to ~165 bytes on average, e.g. the configs[4] shape).
+    // What does not fit - longer names, reads of more than 2000 bases, chunks of more than 4096 exception records, legacy run-length images - takes the ONE
+    // fallback: qualities and bases expanded in HBM, k_dec_emit.  A tile whose pieces turn out longer than the averages allowed for raises DE_E3_RETRY: the range
+    // is decoded again on the fallback, and the context remembers it for the ranges that follow.
+    uint32_t e3k = 6; bool n1big = false;
+    while (e3k >= 1 && ((uint64_t)g.max_len << e3k) > E3_QCAP) e3k--;
+    if (g.pieces) {
+        while (e3k >= 1 && ((uint64_t)g.piece_avg << e3k) > 204u) e3k--;
+        const uint64_t need1 = ((uint64_t)g.piece_n1 << e3k) * 5u / 4u + 32u;
+        if (need1 > ET_N1CAP) { if (e3k == 6 && need1 <= E3_N1BIG) n1big = true; else e3k = 0; }
+    }
+    const bool e3_ok = e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed);
+    const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u && e3_ok;
     uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S; const uint32_t f_nstr = HH.n_normal + 1;
     struct AuxJoin { rfq_ctx* c; bool armed; ~AuxJoin() { if (armed) (void)hipStreamSynchronize(c->aux); } } aux_guard = { ctx, false };   // (an early return must not leave the chain running over buffers the next call reuses)
     if (fused) {
@@ -185,71 +199,32 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     if (out1) { o1 = out1; cap1 = ocap1; } else { HIPCHK(ctx, ctx->out_fq1.ensure((size_t)tt.a + 64)); o1 = ctx->out_fq1.as<uint8_t>(); cap1 = ctx->out_fq1.cap; }
     if (out2) { o2 = out2; cap2 = ocap2; } else { HIPCHK(ctx, ctx->out_fq2.ensure((size_t)tt.b + 64)); o2 = ctx->out_fq2.as<uint8_t>(); cap2 = ctx->out_fq2.cap; }
     ctx->timer.end(S);
-    ctx->timer.begin("emit", S);                                       // the emitter alone: the path's largest kernel (bench.py roofline); named "emit2" below when the tile-fitting kernels ran
+    ctx->timer.begin(fused ? "emit" : "emit_expanded", S);             // the emitter alone: the path's largest kernel (bench.py roofline)
     {
-        // k_dec_emit3 (no output tile, K reads per tile: the largest power of two whose qualities fit its tile) whenever the pieces of a name are shared
-        // by whole chunks; k_dec_emit2 (tiles fitted read by read) otherwise.  RFQ_EMIT=2 forces the latter (tests run both).
-        uint32_t e3k = 6;
-        while (e3k >= 1 && ((uint64_t)g.max_len << e3k) > E3_QCAP) e3k--;
-        // per-read name pieces (names FastqMeta::parse does not take apart, strand lines with text): K also by the chunks' average piece size, with a
-        // fifth of the tile left for reads above the average; a tile that still does not fit raises DE_E3_RETRY and the range is emitted again by
-        // k_dec_emit2 (remembered on the context: the next ranges of such a file go there at once).  Only with full tiles of 64 reads: with 16 - names of
-        // ~125 bytes, the configs[4] shape - most of a read's sixteen lanes idle and k_dec_emit2 is faster (2.2 against 2.5 ms there)
-        // name1 has a second instantiation with a 13 KB tile (names of up to ~165 bytes on average, e.g. the configs[4] shape; four workgroups per CU)
-        bool n1big = false;
-        if (g.pieces) {
-            while (e3k >= 1 && ((uint64_t)g.piece_avg << e3k) > 204u) e3k--;
-            const uint64_t need1 = ((uint64_t)g.piece_n1 << e3k) * 5u / 4u + 32u;          // a fifth of the tile for reads above the average
-            if (need1 > ET_N1CAP) { if (e3k == 6 && need1 <= E3_N1BIG) n1big = true; else e3k = 0; }
-        }
-        bool emit3 = fused && e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed) && ctx->opt.emit != 2 && !(tune & 7);
-    emit_again:
-        if (!emit3) ctx->timer.stages[ctx->timer.used].name = "emit2";
-        if (emit3) {
+        if (fused) {
             const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
 #define RFQ_EMIT3_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
-                       (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k, (tune >> 12) & 255
+                       (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k
             if (n1big) {
                 const uint32_t b4 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 4u * ctx->n_cu);
                 if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
                 else hipLaunchKernelGGL((k_dec_emit3<true, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             }
-            else if (ctx->opt.e3_occ == 6) {                                  // (RFQ_E3_OCC=6: 80 VGPRs, six workgroups per CU instead of five)
-                if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, ET_N1CAP, 6>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
-                else hipLaunchKernelGGL((k_dec_emit3<true, ET_N1CAP, 6>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
-            }
             else if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_emit3<false>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             else hipLaunchKernelGGL(k_dec_emit3<true>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
 #undef RFQ_EMIT3_ARGS
+        } else {
+            const uint32_t bx = grid_x_for(n_chunks, (max_reads + ET_READS - 1) / ET_READS, 4u * ctx->n_cu);   // (39 KB of LDS: four workgroups per CU)
+            hipLaunchKernelGGL(k_dec_emit, dim3(bx, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
+                               (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst);
         }
-        const uint32_t bx = grid_x_for(n_chunks, (max_reads + ET_READS - 1) / ET_READS, (fused ? 4u : 4u) * ctx->n_cu);   // (39 KB of LDS: four workgroups per CU)
-        const uint32_t etpb = 256u;                                     // k_dec_emit: __launch_bounds__(256), 8 x ET_READS piece slots
-#define RFQ_EMIT2_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
-                       (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr
-        if (emit3) {} else if (fused && (tune & 7)) {
-            unsigned long long* dbg = (unsigned long long*)B[DB_SCAN].p; (void)hipMemsetAsync(dbg, 0, 128, S);      // (the scan scratch is idle here)
-            hipLaunchKernelGGL(k_dec_emit2<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, dbg, 0);
-            unsigned long long h[16]; (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
-            if (h[6]) fprintf(stderr, "[emit2 dbg] waves=%llu avg cycles/wave: stage=%llu (fit+spans %llu, dma issue %llu, list requests %llu, next tile's metadata + cells %llu, barrier %llu) unpack=%llu tokens=%llu nstream=%llu compose=%llu flush=%llu\n", h[6], h[0]/h[6], h[8]/h[6], h[9]/h[6], h[10]/h[6], h[11]/h[6], h[12]/h[6], h[1]/h[6], h[2]/h[6], h[3]/h[6], h[4]/h[6], h[5]/h[6]);
-        } else if (fused) hipLaunchKernelGGL(k_dec_emit2<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, RFQ_EMIT2_ARGS, (unsigned long long*)nullptr, (tune >> 12) & 255);   // (tune bits 12-19: ablation switches, text invalid)
-#undef RFQ_EMIT2_ARGS
-        else
-        if (tune & 7) (void)hipMemsetAsync(B[DB_MID].p, 0, 64, S);
-        if (fused) {} else if (tune & 7) hipLaunchKernelGGL(k_dec_emit<true>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
-                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
-        else hipLaunchKernelGGL(k_dec_emit<false>, dim3(bx, n_chunks), dim3(etpb), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase,
-                           (const uint8_t*)qdec, (const uint8_t*)sdec, (uint64_t)qbytes, (uint64_t)sbytes, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, tune ? (unsigned long long*)B[DB_MID].p : nullptr);
-        if (!fused && (tune & 7)) { unsigned long long h[8]; (void)hipMemcpy(h, B[DB_MID].p, 64, hipMemcpyDeviceToHost); if (h[5]) fprintf(stderr, "[emit dbg] blocks=%llu avg cycles/block: meta=%llu fit=%llu stage=%llu compose=%llu (wave0 own %llu, setup %llu) flush=%llu\n", h[5], h[0]/h[5], h[1]/h[5], h[2]/h[5], h[3]/h[5], h[6]/h[5], h[7]/h[5], h[4]/h[5]); }
         KCHK(ctx, "k_dec_emit");
         ctx->timer.end(S);
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
-        if (emit3 && (hs.err & DE_E3_RETRY)) {
-            ctx->e3_pieces_failed = true; emit3 = false;
-            const uint32_t cleared = hs.err & ~(uint32_t)DE_E3_RETRY;
-            HIPCHK(ctx, hipMemcpyAsync(&dst->err, &cleared, 4, hipMemcpyHostToDevice, S)); HIPCHK(ctx, hipStreamSynchronize(S));
-            ctx->timer.begin("emit2", S);
-            goto emit_again;
+        if (fused && (hs.err & DE_E3_RETRY)) {                             // per-read name pieces that did not fit a tile: once more, expanded
+            ctx->e3_pieces_failed = true;
+            return decode_range(ctx, a, g, out1, ocap1, out2, ocap2, p1, p2, n1, n2, nbases);
         }
     }
     ctx->timer.collect();
@@ -291,16 +266,15 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     HIPCHK(ctx, B[DB_STATUS].ensure(sizeof(DecStatus)));
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs;
     uint32_t cap = (uint32_t)std::max<size_t>(B[DB_CHUNKS].cap / sizeof(DChunk), 4096);
-    bool speculate = ctx->opt.walk != 2;                                     // (RFQ_WALK=exact: straight to the serial walk)
     // the chunk starts: the caller's chunk index (verified below); else guess-and-verify (k_dec_gw_*: an index made on the device, verified the same
-    // way); else the speculative mSize chain (verified); else the exact serial walk
+    // way); else the exact serial walk (one wave, a full parse per chunk: foreign writers, corrupt images)
     bool use_table = a->h_chunk_off && a->n_chunk_off && a->h_chunk_off[0] == start && a->h_chunk_off[a->n_chunk_off] <= a->n;
-    bool guess = !use_table && ctx->opt.walk == 0;                           // (RFQ_WALK=chain: straight to the one-wave chain; tests run both)
+    bool guess = !use_table && !ctx->opt.walk_exact;                         // (RFQ_WALK=exact: straight to the serial walk; tests run both)
     for (;;) {
         if (use_table && a->n_chunk_off + 1u > cap) cap = a->n_chunk_off + 1u;
         HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
         HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
-        const bool table = use_table || guess;
+        const bool indexed = use_table || guess;                             // chunk starts that have to verify
         if (use_table) {
             const size_t tb = ((size_t)a->n_chunk_off + 1) * 8;
             HIPCHK(ctx, B[DB_OFFT].ensure(tb));
@@ -318,13 +292,12 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
                                (const uint32_t*)B[DB_GWCNT].as<uint32_t>(), (const unsigned long long*)B[DB_GWLAND].as<unsigned long long>(), (const uint32_t*)gbad, B[DB_OFFT].as<uint64_t>(), cap, dst, mseg);
             hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), 0xFFFFFFFFu, B[DB_CHUNKS].as<DChunk>(), dst);
         }
-        else if (speculate) hipLaunchKernelGGL(k_dec_spec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst);
         else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
         KCHK(ctx, "k_dec_walk");
-        // the verifying parse rides behind the speculative walk without a host round trip in between (its grid covers the first
+        // the verifying parse rides behind the index without a host round trip in between (its grid covers the first
         // PARSE_AHEAD chunks; the walk's own verdict is in the status words it reads)
         const uint32_t PARSE_AHEAD = use_table ? std::max(a->n_chunk_off, 1u) : 4096u;
-        if (speculate) {
+        if (indexed) {
             hipLaunchKernelGGL(k_dec_parse, dim3(std::min(cap, PARSE_AHEAD)), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, 0u);
             hipLaunchKernelGGL(k_dec_summary, dim3(1), dim3(256), 0, S, (const DChunk*)B[DB_CHUNKS].as<DChunk>(), dst, 0u, std::min(cap, PARSE_AHEAD));
             KCHK(ctx, "k_dec_parse");
@@ -334,27 +307,25 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         if (use_table) {
             // the table must cover whole chunks up to the end of the image (or up to a tail too short to be a chunk): anything else walks
             // (a range that does not end the image may end inside a chunk: whole chunks in front of it are all a table has to cover there)
-            if (hs.pad || (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0))) { use_table = false; continue; }
+            if (hs.pad || (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0))) { use_table = false; guess = !ctx->opt.walk_exact; continue; }
             break;
         }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
-        if (guess && hs.pad) { guess = false; continue; }                  // the guessed index did not verify: the chain
-        if (!speculate) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; hs.piece_avg = 0xFFFFu; hs.piece_n1 = 0xFFFFu; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
-        if (hs.pad) { speculate = false; guess = false; continue; }        // the mSize chain left the image (or an extent did not verify: foreign writer / corrupt image): walk it properly
+        if (!indexed) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; hs.piece_avg = 0xFFFFu; hs.piece_n1 = 0xFFFFu; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
+        if (hs.pad) { guess = false; continue; }                           // the guessed index did not verify (foreign writer / corrupt image): walk it properly
         if (hs.n_chunks > PARSE_AHEAD) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
             hipLaunchKernelGGL(k_dec_summary, dim3(1), dim3(256), 0, S, (const DChunk*)B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD, hs.n_chunks - PARSE_AHEAD);
             KCHK(ctx, "k_dec_parse");
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
-            if (h2.pad) { if (guess) { guess = false; continue; } speculate = false; continue; }
+            if (h2.pad) { guess = false; continue; }
             hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; hs.piece_avg = h2.piece_avg; hs.piece_n1 = h2.piece_n1; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
-        if (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0)) { if (guess) { guess = false; continue; } speculate = false; continue; }   // let the exact walk decide about a trailing partial chunk (a range that does not end the image may end inside one)
-        (void)table;
+        if (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0)) { guess = false; continue; }   // let the exact walk decide about a trailing partial chunk (a range that does not end the image may end inside one)
         break;
     }
-    if (ctx->opt.trace) fprintf(stderr, "[rfq] chunk starts: %s, %u chunks\n", use_table ? "caller's index" : (guess ? "guess-and-verify" : (speculate ? "mSize chain" : "exact walk")), hs.n_chunks);
+    if (ctx->opt.trace) fprintf(stderr, "[rfq] chunk starts: %s, %u chunks\n", use_table ? "caller's index" : (guess ? "guess-and-verify" : "exact walk"), hs.n_chunks);
     ctx->timer.end(S);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "truncated or corrupt rfq chunk at byte %llu", (unsigned long long)hs.consumed);
     // 64-bit total of the read lengths: bases, qualities and text are placed by 32-bit prefix sums below (a corrupt length table

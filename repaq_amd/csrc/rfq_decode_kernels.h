@@ -22,7 +22,7 @@ struct DChunk {                  // one parsed chunk (offsets relative to the ch
     uint32_t max_len, nrec;      // longest read of the chunk; exception records behind its quality streams (0xFFFFFFFF: not looked at)
     uint32_t max_one, pad_;      // its longest single quality stream
 };
-#define ET_N1CAP 3072u            // staged name1 / name2 / strand pieces of an emitter's tile (k_dec_emit2 falls back to global memory when larger, k_dec_emit3 hands the range over)
+#define ET_N1CAP 3072u            // staged name1 / name2 / strand pieces of an emitter's tile (k_dec_emit3 hands a range whose pieces are larger over to the expanded path)
 #define ET_N2CAP 1024u
 #define ET_STCAP 1024u
 struct DecStatus {
@@ -36,7 +36,7 @@ struct DecStatus {
     uint32_t max_nrec, max_one;      // most exception records of any chunk / longest single quality stream (by-column quality payloads)
     unsigned long long list_need;    // fused path: entries of all position lists (k_dec_pos_off)
     uint32_t per_read_pieces, piece_avg;  // some chunk stores name1 / name2 / strand per read; the largest average size of a per-read name2 / strand piece over the
-                                     // chunks, as a fraction of its tile capacity in 1/256 (k_dec_emit3: the host sizes its tiles by it, a tile that still does not fit asks for k_dec_emit2)
+                                     // chunks, as a fraction of its tile capacity in 1/256 (k_dec_emit3: the host sizes its tiles by it, a tile that still does not fit asks for the expanded path)
     uint32_t piece_n1, pad4;              // the same for name1, in bytes per read (rounded up): k_dec_emit3 has a second instantiation with a large name1 tile
 };
 
@@ -115,35 +115,6 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
     }
     if (l == 0) { st->max_len = maxl; st->max_bases = maxb; st->base_slots[0] = tb; st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
 }
-// Speculative walk: images written by repaq (or this engine) carry mSize = true size - Delta(flags) (the accounting bug Q1 is a
-// pure function of the header and chunk flags), so the chain needs ONE dependent 10-byte read per chunk instead of a full parse.
-// k_dec_parse then parses every candidate in parallel and verifies that its true extent equals the speculated one; any mismatch
-// (a foreign writer, a corrupt image) makes the host fall back to k_dec_walk.
-__global__ void k_dec_spec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st) {
-    const uint32_t hf = D->flags; const int l = lane_id();
-    uint64_t k = start; uint32_t c = 0, maxr = 0, lastfl = 0, ovf = 0, bad = 0; uint64_t rb = 0;
-    for (;;) {
-        if (n - k < 18) break;
-        const uint8_t* p = img + k;
-        // mSize, read count and flags come from ONE byte-granular 16-byte load (>= 18 bytes are left) and ONE test decides whether
-        // the walk goes on: the chain is one memory latency per chunk (as three loads with the read count tested first, the
-        // compiler paid a second round trip for the other two)
-        const LdsU16 hd = *(const LdsU16*)p;
-        const uint32_t ms = hd.a, s = hd.b, fl = hd.c & 0xFFFFu;
-        const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s;
-        long long total = (long long)ms;
-        if (hf & H_LANE) total += (fl & C_LANE_SAME) ? 1 : (long long)h;                         // lane bytes are never counted in mSize
-        if (!(hf & H_TILE)) total -= (fl & C_TILE_SAME) ? 2 : 2ll * h;                           // "tile" bytes are counted even when absent
-        if (!(hf & H_NAME2)) total -= (fl & C_NAME2_LEN_SAME) ? 1 : (long long)s;                // so are the name2 lengths (name2 bytes assumed empty)
-        const bool wrong = (total < 18) | ((unsigned long long)total > n - k);
-        if ((s == 0) | wrong) { if (s != 0) bad = 1; break; }
-        if (c < cap) { if (l == 0) { out[c].off = k; out[c].total = (uint32_t)total; out[c].rbase = (uint32_t)rb; out[c].reads = s; } } else ovf = 1;
-        if (s > maxr) maxr = s;
-        lastfl = fl; rb += s; k += (unsigned long long)total; c++;
-        if (rb > 0xFFFFFFF0ull) { bad = 1; break; }
-    }
-    if (l == 0) { st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->pad = bad; }
-}
 // The chain from a chunk index the caller supplied (rfq_decode_args.h_chunk_off): the read counts of all chunks are fetched in
 // parallel (one workgroup, 256 chunks per round, running read base by a block scan) - no dependent load per chunk.  k_dec_parse
 // verifies every extent exactly as it does behind the speculative walk.
@@ -189,7 +160,7 @@ __global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const u
 #define GW_SEGS 1024u
 #define GW_LCAP 256u              // chunk starts a segment's walk may record
 struct GwGeo { uint64_t first, seglen, win; uint32_t nseg; };
-__device__ __forceinline__ long long gw_total(uint32_t ms, uint32_t s, uint32_t fl, uint32_t hf) {      // true chunk size from mSize (see k_dec_spec_walk)
+__device__ __forceinline__ long long gw_total(uint32_t ms, uint32_t s, uint32_t fl, uint32_t hf) {      // true chunk size from mSize: repaq's writers store mSize = true size - Delta(flags) (accounting bug Q1, a pure function of header and chunk flags)
     const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s; long long total = (long long)ms;
     if (hf & H_LANE) total += (fl & C_LANE_SAME) ? 1 : (long long)h;
     if (!(hf & H_TILE)) total -= (fl & C_TILE_SAME) ? 2 : 2ll * h;
@@ -1174,11 +1145,10 @@ __device__ __forceinline__ void emit_copy(uint8_t* o, const uint8_t* pool, uint3
 #define EM_ROW 17                 // words per read in s_meta: 16 used + 1 pad, so that lanes reading the same field of consecutive reads hit 32 different banks
 #define ET_OCAP 12288u            // output tile bytes (split: half per stream): 32 records of 357 bytes are 11.4 KB
 #define ET_SCAP 5632u             // staged qualities / stored bases
-template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+__global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            const uint64_t* __restrict__ qbase, const uint64_t* __restrict__ sbase,
                            const uint8_t* __restrict__ qdec, const uint8_t* __restrict__ sdec, uint64_t qdec_bytes, uint64_t sdec_bytes, uint64_t img_bytes, int split,
-                           uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st, unsigned long long* dbg) {
-    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, aS = 0;
+                           uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st) {
     __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
     // staged sources in ONE pool (a piece is addressed by a byte offset into it): qualities | stored bases | name middles | name1 | name2 |
     // strand pieces (region starts in uint4 units)
@@ -1228,13 +1198,10 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
           if (r_ < re) { m[0] = (split && odd_) ? tp_.b : tp_.a; m[1] = len_; m[2] = ov_; m[3] = pl_; m[4] = n1_; m[5] = n2_; m[6] = sl_;   \
                          m[11] = md_; m[10] = n1_ + md_ + n2_ + 1; } }                     /* ":lane:tile:x:y" bytes; offset of the sequence line */
     uint32_t cur = rs; uint32_t pb = 0;
-    if (DBG) k0 = clock64();
     { EMIT_META_VARS if (cur < re && tid <= ET_READS && cur + tid <= re) { EMIT_META_LOAD(cur) EMIT_META_STORE(s_meta2[0]) } }
     __syncthreads();
-    if (DBG) { k1 = clock64(); a1 += k1 - k0; }
     while (cur < re) {                                                       // block-uniform
         uint32_t* const s_meta = s_meta2[pb]; uint32_t* const s_next = s_meta2[pb ^ 1u];
-        if (DBG) k1 = clock64();
         const uint32_t g0 = f + cur;
         // ---- phase 2: how many reads fit (from LDS)
         const uint32_t* mb = s_meta;                                          // entry 0 = first read of the tile
@@ -1264,7 +1231,6 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
         U4 tp0, tp1; tp0.a = mb[12]; tp0.b = mb[13]; tp1.a = me[12]; tp1.b = me[13];
         const uint32_t q0 = mb[15], s0 = mb[14];
         const uint64_t qa = qg0 + q0, qe = qg0 + me[15], sa = sg0 + s0, se = sg0 + me[14];
-        if (DBG) { k2 = clock64(); a2 += k2 - k1; }
         // ---- phase 3: stage the tile's sources with aligned 16-byte loads.  name1 / name2 / strand: one copy when the chunk stores
         // them once, else the contiguous run of the tile's reads
         const uint64_t ib = d.off;                                         // global byte offsets inside the image
@@ -1284,7 +1250,6 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
             if (nextm) EMIT_META_STORE(s_next)
         }
         __syncthreads();
-        if (DBG) { k3 = clock64(); a3 += k3 - k2; }
         // ---- phase 4: compose the tile's text in LDS
         const uint8_t* q_l = (const uint8_t*)(s_q4 + 1) + (qa & 15ull); const uint8_t* s_l = (const uint8_t*)(s_s4 + 1) + (sa & 15ull);
         const uint8_t* m_l = (const uint8_t*)s_mid4 + (((uint64_t)g0 * 40) & 15ull);
@@ -1331,7 +1296,6 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
                     uint32_t gb = 0, ge = (n + 15u) >> 4;                       // the piece's 16-byte groups; a half takes the first / the second part
                     if (half == 0) ge = (ge + 1u) >> 1; else if (half == 1) gb = (ge + 1u) >> 1;
                     uint8_t* const o = out + dst;
-                    if (DBG) { const long long kA = clock64(); if (tid == 0) aS += kA - k3; }
                     // the copy loop, specialised for what the piece can need (a wave holds two kinds: the tests below are nearly wave-uniform)
                     if (kind <= 1) emit_copy<false, true, false>(o, pool, src, n, gb, ge, rev, 0u, false, nq, -1, dch);
                     else if (kind <= 4) emit_copy<true, true, false>(o, pool, src, n, gb, ge, rev, qsrc, implied_n, nq, -1, dch);
@@ -1365,308 +1329,17 @@ template <bool DBG> __global__ void k_dec_emit(const uint8_t* __restrict__ img, 
                 emit_one((to2 ? out2 : out1) + at, e, sdec + sg0, qdec + qg0, implied_n, nq, dpos, dch, l);
             }
         }
-        if (DBG) { const long long k35 = clock64(); a6 += k35 - k3; }
         __syncthreads();
-        if (DBG) { k4 = clock64(); a4 += k4 - k3; }
         // ---- phase 5: aligned 16-byte stores of the finished tile (no barrier after it: three barriers precede the next compose)
         if (tiled) {
             if (tp1.a <= cap1) flush_span(s_out4, out1, tp0.a, tp1.a);
             if (split && tp1.b <= cap2) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
         }
-        if (DBG) { k5 = clock64(); a5 += k5 - k4; }
         cur += cnt; pb ^= 1u;
     }
 #undef EMIT_META_VARS
 #undef EMIT_META_LOAD
 #undef EMIT_META_STORE
-    if (DBG && tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a1); atomicAdd(&dbg[1], (unsigned long long)a2); atomicAdd(&dbg[2], (unsigned long long)a3); atomicAdd(&dbg[3], (unsigned long long)a4); atomicAdd(&dbg[4], (unsigned long long)a5); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)a6); atomicAdd(&dbg[7], (unsigned long long)aS); }
-}
-
-// ================================================================== fused emitter (see "fused path" above)
-// k_dec_emit's tile with its two largest sources BUILT in LDS instead of staged from HBM:
-//   qualities   prefilled with the major value, then every quality stream's tokens (one wave per stream, starting at the segment the cell
-//               index names, two steps prefetched beside the staging) and the exception records are scattered into the tile;
-//               DONT_ENCODE_QUAL files stage their raw qualities straight from the image
-//   bases       the tile's packed bytes (1/4 of the bases) staged by LDS-DMA, unpacked LDS -> LDS, N positions scattered from their stream
-// Everything after that - one thread = one piece, byte-granular ds_read_b128 / ds_write_b128, aligned flush - is k_dec_emit's compose phase.
-#define EG2_PK EG_END
-#define EG2_END (EG2_PK + ET_SCAP / 64 + 4)
-#define EL2_LP 2                  // N-list entries per thread requested up front
-#define EL2_FL 4                  // quality-list items per thread requested up front (1024 per tile)
-template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
-                           uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
-                           const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
-                           uint32_t ncell, uint32_t nstr, unsigned long long* dbg, int abl) {
-    __shared__ uint4 s_out4[ET_OCAP / 16 + 4];
-    __shared__ uint4 s_src4[EG2_END];
-    __shared__ uint32_t s_cnt; __shared__ __attribute__((aligned(16))) uint32_t s_meta2[2][(ET_READS + 1) * EM_ROW];
-    // per stream of the chunk (t < nn: quality value t, t == nn: the N positions): list start in the arena, entries, value; per tile (two
-    // buffers): first entry at the tile's cell (s_g), first entry beyond the tile (s_kb)
-    __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
-    __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2], s_nl0;
-    long long c0 = 0, c1 = 0, cs = 0, a_s1 = 0, a_s2 = 0, a_s3 = 0, a_s4 = 0, a_s5 = 0, a_stage = 0, a_unpack = 0, a_tok = 0, a_n = 0, a_comp = 0, a_flush = 0, a_steps = 0;
-    const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint8_t* lim = img + img_bytes;
-    const uint32_t fl = d.flags, hf = D->flags, f = d.rbase; const bool il = (fl & C_PE_INTERLEAVED) != 0;
-    const bool implied_n = !(hf & H_N_POS); const uint32_t nq = D->n_base_qual, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
-    const int l = lane_id(), w = (int)uni32((uint32_t)wave_id()); const uint32_t tid = threadIdx.x;
-    const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
-    uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;
-    const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
-    const uint32_t ocap = split ? ET_OCAP / 2 : ET_OCAP;
-    const bool raw = (hf & H_DONT_QUAL) != 0, bycol = !raw && (hf & H_QUAL_BY_COL);
-    const uint32_t nn = bycol ? (D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT) : 0u; const bool hasn = (hf & H_N_POS) != 0;
-    const uint32_t T = nn + (hasn ? 1u : 0u);                                // streams of the tile: t < nn quality value t, t == nn the N positions
-    const uint32_t major4 = (D->major & 0xFFu) * 0x01010101u;
-    const uint32_t qlen_c = R.pq[f + d.reads] - pq0, slen_c = R.pv[f + d.reads].d - pv0.d;      // qualities / stored bases of the chunk
-    // the chunk's position lists: where they start in the arena, how long they are, what they write
-    if (tid < T) { const uint32_t jj = tid < nn ? tid : D->n_normal; const size_t t_ = (size_t)c * nstr + jj; s_loff[tid] = loff[t_]; s_nent[tid] = nent[t_]; s_val[tid] = tid < nn ? (uint32_t)D->normal[tid] : (uint32_t)'N'; }
-    // exception records behind the streams (src/rfqcodec.cpp:1034-1043)
-    uint32_t nrec = 0; const uint8_t* xrec = nullptr;
-    if (bycol && 4ull * D->n_normal <= d.qual_size) {
-        const uint8_t* qp = cp + d.o_qual; uint64_t off = 4ull * D->n_normal;
-        for (uint32_t i = 0; i < D->n_normal; i++) off += ld_u32(qp + 4 * i);
-        off = uni64(off);
-        if (off <= d.qual_size) { nrec = (uint32_t)((d.qual_size - off) / 5); xrec = qp + off; }
-    }
-    // cell of a tile start -> index of the first entry of list t at or beyond the cell (the lookup for the NEXT tile rides beside this tile's staging)
-    // ... and, `bound`: of the first entry beyond anything a tile that starts there can hold (a tile spans < ET_SCAP positions): the entries a
-    // tile needs are known exactly before it asks for them
-    auto cell_lookup = [&](uint32_t t, uint32_t qpos, uint32_t spos, bool bound) -> uint32_t {
-        const uint32_t jj = t < nn ? t : D->n_normal; uint32_t cell = ((t < nn ? qpos : spos) + (bound ? ET_SCAP : 0u)) / POS2_CELL + (bound ? 1u : 0u);
-        if (cell >= ncell) return bound ? 0xFFFFFFFFu : cellidx[((size_t)c * nstr + jj) * ncell + ncell - 1u];
-        return cellidx[((size_t)c * nstr + jj) * ncell + cell];
-    };
-#define EMIT_META_VARS U4 tp_, pv_; uint32_t pq_ = 0, len_ = 0, ov_ = 0, pl_ = 0, n1_ = 0, n2_ = 0, sl_ = 0, md_ = 0, r_ = 0; bool odd_ = false; tp_.a = tp_.b = 0; pv_.a = pv_.b = pv_.c = pv_.d = 0;
-#define EMIT_META_LOAD(from)                                                                                                          \
-        { r_ = (from) + tid; const uint32_t g_ = f + r_; odd_ = (r_ & 1u) != 0;                                                       \
-          tp_ = R.tp[g_]; pv_ = R.pv[g_]; pq_ = R.pq[g_];                                                                             \
-          if (r_ < re) {                                                                                                              \
-              len_ = R.len[g_]; ov_ = (uint32_t)R.ov[g_]; pl_ = odd_ ? R.len[g_ - 1] : 0u;                                            \
-              n1_ = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r_)];                                                             \
-              n2_ = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r_)] : 0u;                                       \
-              sl_ = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r_)]; md_ = R.mid[(size_t)g_ * 40 + 39];                         \
-          } }
-#define EMIT_META_STORE(mrow)                                                                                                         \
-        { uint32_t* m = (mrow) + EM_ROW * tid;                                                                                        \
-          m[12] = tp_.a; m[13] = tp_.b; m[14] = pv_.d - pv0.d; m[15] = pq_ - pq0;                                                     \
-          m[7] = pv_.a - pv0.a; m[8] = pv_.b - pv0.b; m[9] = pv_.c - pv0.c;                                                           \
-          if (r_ < re) { m[0] = (split && odd_) ? tp_.b : tp_.a; m[1] = len_; m[2] = ov_; m[3] = pl_; m[4] = n1_; m[5] = n2_; m[6] = sl_;   \
-                         m[11] = md_; m[10] = n1_ + md_ + n2_ + 1; } }
-    uint32_t cur = rs; uint32_t pb = 0;
-    { EMIT_META_VARS if (cur < re && tid <= ET_READS && cur + tid <= re) { EMIT_META_LOAD(cur) EMIT_META_STORE(s_meta2[0]) }
-      if (cur < re && tid < 128) {                                          // (waves 0 and 1: T <= 65)
-          uint32_t g_ = 0xFFFFFFFFu, b_ = 0xFFFFFFFFu;
-          if (tid < T) { const uint32_t qp_ = R.pq[f + cur] - pq0, sp_ = R.pv[f + cur].d - pv0.d; g_ = cell_lookup(tid, qp_, sp_, false); b_ = cell_lookup(tid, qp_, sp_, true); s_g[0][tid] = g_; s_kb[0][tid] = b_; }
-      } }
-    if (cur < re) {                                                          // pieces every read of the chunk shares: staged once
-        const uint64_t ib = d.off;
-        if (fl & C_NAME1_SAME) span_dma<1>(make_span(s_src4 + EG_N1, img, ib + d.o_n1, ib + d.o_n1 + d.n1_size, img_bytes, true));
-        if (fl & C_NAME2_SAME) span_dma<1>(make_span(s_src4 + EG_N2, img, ib + d.o_n2, ib + d.o_n2 + d.n2_size, img_bytes, true));
-        if (fl & C_STRAND_SAME) span_dma<1>(make_span(s_src4 + EG_ST, img, ib + d.o_st, ib + d.o_st + d.st_size, img_bytes, true));
-    }
-    __syncthreads();
-    while (cur < re) {                                                       // block-uniform
-        uint32_t* const s_meta = s_meta2[pb]; uint32_t* const s_next = s_meta2[pb ^ 1u];
-        if (DBG) c0 = clock64();
-        const uint32_t g0 = f + cur;
-        const uint32_t* mb = s_meta;
-#define EMIT_FITS(me) ((me[12] - mb[12]) + 16u <= ocap && (me[13] - mb[13]) + 16u <= ocap && (me[15] - mb[15]) + 48u <= ET_SCAP && (me[14] - mb[14]) + 48u <= ET_SCAP \
-                && ((fl & C_NAME1_SAME) || (me[7] - mb[7]) + 32u <= ET_N1CAP) && ((fl & C_NAME2_SAME) || (me[8] - mb[8]) + 32u <= ET_N2CAP)                          \
-                && ((fl & C_STRAND_SAME) || (me[9] - mb[9]) + 32u <= ET_STCAP))
-        const uint32_t all = re - cur < ET_READS ? re - cur : ET_READS;
-        uint32_t cnt;
-        { const uint32_t* ma = s_meta + EM_ROW * all; cnt = EMIT_FITS(ma) ? all : 0xFFFFFFFFu; }
-        if (cnt == 0xFFFFFFFFu) {                                          // block-uniform
-            bool fits = false;
-            if (tid < ET_READS && cur + tid < re) {
-                uint32_t mm = (tid + 2u) & ~1u; if (cur + mm > re) mm = re - cur;
-                const uint32_t* me = s_meta + EM_ROW * mm;
-                fits = EMIT_FITS(me);
-            }
-            if (tid < 64) { const unsigned long long fb = __ballot(fits); if (l == 0) s_cnt = (uint32_t)__popcll(fb); }
-            __syncthreads();
-            cnt = s_cnt; if (cur + cnt > re) cnt = re - cur;
-        }
-#undef EMIT_FITS
-        cnt = uni32(cnt);
-        if (cnt == 0) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT); break; }   // (a pair beyond the tile: the host keeps such images off this kernel)
-        const uint32_t g1 = g0 + cnt; const uint32_t* me = s_meta + EM_ROW * cnt;
-        U4 tp0, tp1; tp0.a = uni32(mb[12]); tp0.b = uni32(mb[13]); tp1.a = uni32(me[12]); tp1.b = uni32(me[13]);
-        const uint32_t q0 = uni32(mb[15]), s0 = uni32(mb[14]), q1 = uni32(me[15]), s1 = uni32(me[14]);
-        // the NEXT tile's metadata and cells are asked for first: wave 0 needs them back before it can reach the barrier, and everything
-        // below (spans, LDS-DMA, list requests) is issue work that fits inside that latency
-        const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
-        EMIT_META_VARS
-        if (nextm) EMIT_META_LOAD(cur + cnt)
-        uint32_t gnext = 0xFFFFFFFFu, bnext = 0xFFFFFFFFu; if (cur + cnt < re && tid < T) { gnext = cell_lookup(tid, q1, s1, false); bnext = cell_lookup(tid, q1, s1, true); }
-        // ---- stage: packed bases, name pieces, middles (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
-        const uint64_t ib = d.off;
-        const uint32_t a7 = (fl & C_NAME1_SAME) ? 0u : uni32(mb[7]), a8 = (fl & C_NAME2_SAME) ? 0u : uni32(mb[8]), a9 = (fl & C_STRAND_SAME) ? 0u : uni32(mb[9]);
-        const uint32_t e7 = uni32(me[7]), e8 = uni32(me[8]), e9 = uni32(me[9]);
-        const uint64_t n1a = ib + d.o_n1 + a7, n1e = (fl & C_NAME1_SAME) ? n1a + d.n1_size : ib + d.o_n1 + e7;
-        const uint64_t n2a = ib + d.o_n2 + a8, n2e = (fl & C_NAME2_SAME) ? n2a + d.n2_size : ib + d.o_n2 + e8;
-        const uint64_t sta = ib + d.o_st + a9, ste = (fl & C_STRAND_SAME) ? sta + d.st_size : ib + d.o_st + e9;
-        uint64_t pka = ib + d.o_seq + (s0 >> 2), pke = ib + d.o_seq + ((s1 + 3u) >> 2); { const uint64_t pend = ib + d.o_seq + d.seq_size; if (pke > pend) pke = pend; if (pka > pke) pka = pke; }
-        uint64_t rqa = ib + d.o_qual + q0, rqe = ib + d.o_qual + q1; { const uint64_t qend = ib + d.o_qual + d.qual_size; if (rqe > qend) rqe = qend; if (rqa > rqe) rqa = rqe; }
-        // the LDS-DMA of the tile's sources goes out FIRST (it returns nothing into registers, so nothing the compiler does to the loads
-        // below - it makes some of them wait for each other - can hold it back), then the prefill, then the register loads
-        {
-            // (a name1 / name2 / strand piece shared by the whole chunk was staged once, in front of the loop); one span per wave
-            if (raw) span_dma<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(make_span(s_src4 + EG_Q + 1, img, rqa, rqe, img_bytes, true));
-            if (abl & 64) {} else if (w == 0) span_dma_wave<(int)((ET_SCAP / 64 + 4 + 63) / 64)>(make_span(s_src4 + EG2_PK, img, pka, pke, img_bytes, true), l);
-            else if (w == 1) span_dma_wave<(int)((ET_READS * 40 / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_MID, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
-            else if (w == 2) { if (!(fl & C_NAME1_SAME)) span_dma_wave<(int)((ET_N1CAP / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_N1, img, n1a, n1e, img_bytes, true), l); }
-            else {
-                if (!(fl & C_NAME2_SAME)) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_N2, img, n2a, n2e, img_bytes, true), l);
-                if (!(fl & C_STRAND_SAME)) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(s_src4 + EG_ST, img, sta, ste, img_bytes, true), l);
-            }
-            if (DBG) { const long long t_ = clock64(); a_s2 += t_ - cs; cs = t_; }
-            // qualities start as the major value (src/rfqcodec.cpp:1089): no source to wait for
-            if (bycol && !(abl & 1)) { uint4* qt = s_src4 + EG_Q + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
-        }
-        // the tile's list entries, requested now and scattered after the barrier.  Quality lists: wave w takes the lists t = w, w + 4, ...;
-        // a round = 64 consecutive entries of one list, one per lane (the entries [k0, ke) a tile needs are known exactly); EL2_FL rounds
-        // are requested up front, the rest on demand.  Everything that steers this - list, round, bounds - is wave-uniform.
-        uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const uint32_t* ls_p = plist;
-        auto ls_open = [&](uint32_t t_) {                                   // the tile's entries of list t_
-            const uint32_t g_ = uni32(s_g[pb][t_]), b_ = uni32(s_kb[pb][t_]), n_ = uni32(s_nent[t_]);
-            ls_k0 = g_ == 0xFFFFFFFFu ? 0u : g_; ls_ke = g_ == 0xFFFFFFFFu ? 0u : (b_ < n_ ? b_ : n_); ls_base = 0;
-            ls_val = uni32(s_val[t_]); ls_p = plist + uni64(s_loff[t_]);
-        };
-        auto ls_round = [&](uint32_t& e_, uint32_t& v_) {                   // the next round of this wave's lists (e_ stays ~0 when there is none)
-            while (ls_t < nn && ls_k0 + ls_base >= ls_ke) { ls_t += 4u; if (ls_t < nn) ls_open(ls_t); }
-            if (ls_t < nn) { const uint32_t kk = ls_k0 + ls_base + (uint32_t)l; if (kk < ls_ke) e_ = ls_p[kk]; v_ = ls_val; ls_base += 64u; }
-        };
-        if (ls_t < nn && !(abl & 8)) ls_open(ls_t); else ls_t = nn;
-        uint32_t fe[EL2_FL], fv[EL2_FL];
-#pragma unroll
-        for (int i = 0; i < EL2_FL; i++) { fe[i] = 0xFFFFFFFFu; fv[i] = 0; ls_round(fe[i], fv[i]); }
-        if (DBG) { const long long t_ = clock64(); a_s3 += t_ - cs; cs = t_; }
-        // the N list (most tiles hold no N: its first entry tells, and the phase is skipped)
-        uint32_t pn[EL2_LP];
-#pragma unroll
-        for (int i = 0; i < EL2_LP; i++) pn[i] = 0xFFFFFFFFu;
-        if (hasn) {
-            const uint32_t k0 = s_g[pb][nn]; uint32_t ke = s_kb[pb][nn]; if (ke > s_nent[nn]) ke = s_nent[nn];
-            const uint32_t* lp = plist + s_loff[nn];
-#pragma unroll
-            for (int i = 0; i < EL2_LP; i++) { const uint32_t kk = k0 + tid + 256u * (uint32_t)i; if (k0 != 0xFFFFFFFFu && kk < ke) pn[i] = lp[kk]; }
-        }
-        // what came back for the next tile -> LDS (requested at the top of this phase)
-        if (nextm) EMIT_META_STORE(s_next)
-        if (tid < T) { s_g[pb ^ 1u][tid] = gnext; s_kb[pb ^ 1u][tid] = bnext; }
-        if (tid == 0) s_nl0 = pn[0];                                        // the tile's first N position
-        if (DBG) { const long long t_ = clock64(); a_s4 += t_ - cs; cs = t_; }
-        __syncthreads();
-        if (DBG) { c1 = clock64(); a_s5 += c1 - cs; a_stage += c1 - c0; c0 = c1; }
-        uint8_t* const q_t = (uint8_t*)(s_src4 + EG_Q + 1) + (raw ? (uint32_t)(rqa & 15ull) : 0u);        // quality of chunk position q0 + i at q_t[i]
-        uint8_t* const s_t = (uint8_t*)(s_src4 + EG_S + 1);                                              // stored base s0 + i at s_t[i]
-        // ---- bases: 16 per thread, packed bytes -> G A T C (src/rfqcodec.cpp:833-853); beyond mSeqBuf the 'N' prefill of allSeq stays
-        {
-            const uint8_t* pk = (const uint8_t*)(s_src4 + EG2_PK) + (uint32_t)(pka & 15ull); const uint32_t r2 = 2u * (s0 & 3u), ng = (s1 - s0 + 15u) >> 4;
-            const uint32_t have = (uint32_t)(pke - pka);                     // staged packed bytes
-            auto unpack4v = [](uint32_t b) -> uint32_t { const uint32_t y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u; return __builtin_amdgcn_perm(0u, 0x43544147u, idx); };
-            for (uint32_t k = tid; k < ((abl & 2) ? 0u : ng); k += blockDim.x) {
-                const unsigned long long v = lds_get8(pk, 4u * k); const uint32_t pk32 = (uint32_t)(v >> r2);
-                uint32_t o[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) o[i] = unpack4v((pk32 >> (8 * i)) & 0xFFu);
-                if (4u * k + 5u > have) {                                    // the tile's last bytes: bases past the packed buffer read as 'N'
-#pragma unroll
-                    for (int i = 0; i < 4; i++) for (int b = 0; b < 4; b++) { const uint32_t bi = ((s0 & 3u) + 16u * k + 4u * (uint32_t)i + (uint32_t)b) >> 2; if (bi >= have) o[i] = (o[i] & ~(0xFFu << (8 * b))) | (0x4Eu << (8 * b)); }
-                }
-                *(uint4*)(s_t + 16u * k) = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-        }
-        if (DBG) { c1 = clock64(); a_unpack += c1 - c0; c0 = c1; }
-        // ---- quality lists and exception records into the quality tile (the prefill was done before the barrier)
-        if (!(abl & 4)) {
-#pragma unroll
-            for (int i = 0; i < EL2_FL; i++) { const uint32_t p = fe[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
-            // (files with tens of quality values: the rest of the wave's rounds, four requests in flight)
-            while (ls_t < nn) {
-                uint32_t e_[4], v_[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { e_[i] = 0xFFFFFFFFu; v_[i] = 0; ls_round(e_[i], v_[i]); }
-#pragma unroll
-                for (int i = 0; i < 4; i++) { const uint32_t p = e_[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
-            }
-        }
-        if (nrec) {
-            // (every tile looks at all of the chunk's records: the host keeps images with many of them off this kernel)
-            for (uint32_t i = tid; i < nrec; i += blockDim.x) { const uint8_t* r = xrec + 5ull * i; const uint32_t pos = ld_u32(r + 1); if (pos >= q0 && pos < q1 && pos < qlen_c) q_t[pos - q0] = r[0]; }
-        }
-        if (DBG) { c1 = clock64(); a_tok += c1 - c0; c0 = c1; }
-        const uint32_t send = s1 < slen_c ? s1 : slen_c;
-        if (hasn && s_nl0 < send) {                                        // (block-uniform; s_nl0 was written before the first barrier)
-            __syncthreads();                                               // the bases are in place
-            const uint32_t t = nn;
-#pragma unroll
-            for (int i = 0; i < EL2_LP; i++) { const uint32_t p = pn[i]; if (p >= s0 && p < send) s_t[p - s0] = (uint8_t)'N'; }
-            const uint32_t k0 = s_g[pb][t]; uint32_t ke = s_kb[pb][t]; if (ke > s_nent[t]) ke = s_nent[t];
-            if (k0 != 0xFFFFFFFFu && k0 + 256u * EL2_LP < ke) {
-                const uint32_t* lp = plist + s_loff[t];
-                for (uint32_t kk = k0 + 256u * EL2_LP + tid; kk < ke; kk += 256u) { const uint32_t p = lp[kk]; if (p >= s0 && p < send) s_t[p - s0] = (uint8_t)'N'; }
-            }
-        }
-        __syncthreads();
-        if (DBG) { c1 = clock64(); a_n += c1 - c0; c0 = c1; }
-        // ---- compose the tile's text in LDS: one thread = one piece (k_dec_emit)
-        {
-            uint8_t* const out = (uint8_t*)s_out4;
-            const uint32_t qoff = 16u + (raw ? (uint32_t)(rqa & 15ull) : 0u), soff = 16u, moff = (uint32_t)(((uint64_t)g0 * 40) & 15ull);
-            const uint32_t n1off = (uint32_t)(n1a & 15ull), n2off = (uint32_t)(n2a & 15ull), stoff = (uint32_t)(sta & 15ull);
-            const uint32_t recA = (tp0.a & 15u) - tp0.a, recB = ET_OCAP / 2 + (tp0.b & 15u) - tp0.b;
-            const uint8_t* const pool = (const uint8_t*)s_src4;
-            for (uint32_t slot = tid; slot < ((abl & 16) ? 0u : 8u * ET_READS); slot += blockDim.x) {
-                const uint32_t j = slot % ET_READS, kind = slot / ET_READS;
-                if (j >= cnt) continue;
-                const uint32_t* m = s_meta + EM_ROW * j; const bool odd = ((cur + j) & 1u) != 0, to2 = split && odd, rc = il && odd;
-                const uint32_t rec = (to2 ? recB : recA) + m[0], len = m[1], mid = m[11];
-                if (kind == 6) {
-                    const uint32_t e0 = m[10] - 1, e1 = e0 + 1 + len, e2 = e1 + 1 + m[6], e3 = e2 + 1 + len;
-                    out[rec + e0] = '\n'; out[rec + e1] = '\n'; out[rec + e2] = '\n'; out[rec + e3] = '\n';
-                    if ((uint64_t)m[0] + e3 + 1 > (to2 ? cap2 : cap1)) atomicOr(&st->err, 1u << 31);
-                }
-                for (int sub = 0; sub < (kind == 7 ? 2 : 1); sub++) {
-                    uint32_t n, dst, src, qsrc = 0; bool rev = false; int pat = -1, half = -1;
-                    const uint32_t qs = 16u * EG_Q + qoff + (m[15] - q0);
-                    if (kind <= 1) { n = len; dst = rec + m[10] + len + 1 + m[6] + 1; src = qs; rev = rc; half = (int)kind; }
-                    else if (kind <= 4) {
-                        const int ov = (int)m[2]; const uint32_t xa = ov < 0 ? len - (uint32_t)(-ov) : len; const uint32_t sp = m[14] - s0;
-                        const bool partb = kind == 4; const uint32_t p0 = partb ? xa : 0u;
-                        n = partb ? len - xa : xa;
-                        src = 16u * EG_S + soff + (partb ? sp - m[3] : (ov > 0 ? sp - (uint32_t)ov : sp));
-                        dst = rec + m[10] + (rc ? len - p0 - n : p0); rev = rc; qsrc = qs + p0; half = partb ? -1 : (int)kind - 2;
-                    }
-                    else if (kind == 5) { n = m[4]; dst = rec; src = 16u * EG_N1 + n1off + ((fl & C_NAME1_SAME) ? 0u : m[7] - a7); }
-                    else if (kind == 6) { n = mid; dst = rec + m[4]; src = 16u * EG_MID + moff + 40u * j; }
-                    else if (sub == 0) { n = m[5]; dst = rec + m[4] + mid; src = 16u * EG_N2 + n2off + ((fl & C_NAME2_SAME) ? 0u : m[8] - a8);
-                                         if ((fl & C_NAME2_SAME) && rc && dch != 0 && dpos < n) pat = (int)dpos; }
-                    else { n = m[6]; dst = rec + m[10] + len + 1; src = 16u * EG_ST + stoff + ((fl & C_STRAND_SAME) ? 0u : m[9] - a9); }
-                    uint32_t gb = 0, ge = (n + 15u) >> 4;
-                    if (half == 0) ge = (ge + 1u) >> 1; else if (half == 1) gb = (ge + 1u) >> 1;
-                    uint8_t* const o = out + dst;
-                    if (kind <= 1) emit_copy<false, true, false>(o, pool, src, n, gb, ge, rev, 0u, false, nq, -1, dch);
-                    else if (kind <= 4) emit_copy<true, true, false>(o, pool, src, n, gb, ge, rev, qsrc, implied_n, nq, -1, dch);
-                    else if (pat < 0) emit_copy<false, false, false>(o, pool, src, n, gb, ge, false, 0u, false, nq, -1, dch);
-                    else emit_copy<false, false, true>(o, pool, src, n, gb, ge, false, 0u, false, nq, pat, dch);
-                }
-            }
-        }
-        __syncthreads();
-        if (DBG) { c1 = clock64(); a_comp += c1 - c0; c0 = c1; }
-        if (tp1.a <= cap1 && !(abl & 32)) flush_span(s_out4, out1, tp0.a, tp1.a);
-        if (split && tp1.b <= cap2 && !(abl & 32)) flush_span(s_out4 + ET_OCAP / 32, out2, tp0.b, tp1.b);
-        if (DBG) { c1 = clock64(); a_flush += c1 - c0; }
-        cur += cnt; pb ^= 1u;
-    }
-#undef EMIT_META_VARS
-#undef EMIT_META_LOAD
-#undef EMIT_META_STORE
-    if (DBG && dbg && l == 0) { atomicAdd(&dbg[0], (unsigned long long)a_stage); atomicAdd(&dbg[1], (unsigned long long)a_unpack); atomicAdd(&dbg[2], (unsigned long long)a_tok); atomicAdd(&dbg[3], (unsigned long long)a_n);
-                                atomicAdd(&dbg[4], (unsigned long long)a_comp); atomicAdd(&dbg[5], (unsigned long long)a_flush); atomicAdd(&dbg[6], 1ull); atomicAdd(&dbg[7], (unsigned long long)a_steps);
-                                atomicAdd(&dbg[8], (unsigned long long)a_s1); atomicAdd(&dbg[9], (unsigned long long)a_s2); atomicAdd(&dbg[10], (unsigned long long)a_s3); atomicAdd(&dbg[11], (unsigned long long)a_s4); atomicAdd(&dbg[12], (unsigned long long)a_s5); }
 }
 
 // =============================================================== text emission, third formulation (no output tile)
@@ -1678,7 +1351,7 @@ template <bool DBG> __global__ void __launch_bounds__(256) k_dec_emit2(const uin
 //   * the bases are never expanded to a byte tile: a lane takes 16 codes from the staged 2-bit stream at any bit offset (8-byte LDS read + shift),
 //     reverses / complements them in 2-bit space, looks the letters up with v_perm_b32 and patches N from a bit tile the N list was scattered into;
 //   * the quality group of the same 16 positions is in registers at that moment (same lane), which is all the implied-N rule needs.
-// Everything else - the lists' exact entry ranges from the cell index, wave-per-list rounds, the next tile's metadata requested a tile ahead - is k_dec_emit2's.
+// Everything else - the lists' exact entry ranges from the cell index, wave-per-list rounds, the next tile's metadata requested a tile ahead - carries over from the tile emitter this kernel replaced.
 #define E3_QCAP 10240u            // quality tile: K reads' qualities (64 x 160)
 #define E3_N1BIG 13312u           // name1 tile of the second instantiation: 64 per-read names of 200 bytes (34 KB of LDS, four workgroups per CU)
 struct __attribute__((packed, aligned(1))) GU16d { uint32_t a, b, c, d; };
@@ -1713,10 +1386,10 @@ __device__ __forceinline__ uint32_t e3_rev1x16(uint32_t v) {
 // dword i of the mask "bytes >= t of a 16-byte group" (t <= 0: all of them, t >= 16: none)
 __device__ __forceinline__ uint32_t e3_from(int t, int i) { const int k = t - 4 * i; return k <= 0 ? 0xFFFFFFFFu : (k >= 4 ? 0u : 0xFFFFFFFFu << (8 * k)); }
 __device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }   // v_alignbyte_b32
-template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __launch_bounds__(256, OCC) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds__(256, N1CAP == ET_N1CAP ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
-                           uint32_t ncell, uint32_t nstr, uint32_t kshift, int abl) {
+                           uint32_t ncell, uint32_t nstr, uint32_t kshift) {
     __shared__ uint4 t_q4[E3_QCAP / 16 + 6];                                // quality tile (16 bytes of slack in front, the rest behind)
     __shared__ uint4 t_pk4[E3_QCAP / 64 + 6];                               // the tile's packed bases
     __shared__ uint32_t t_nb[E3_QCAP / 32 + 8];                             // one bit per stored base of the tile: is N
@@ -1794,7 +1467,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __l
         // qualities start as the major value (src/rfqcodec.cpp:1089), the N bits as none
         if (bycol) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         for (uint32_t i = tid; i < ((s1 - s0 + 31u) >> 5) + 1u; i += blockDim.x) t_nb[i] = 0;
-        // ---- the tile's list entries, requested now and scattered after the barrier (k_dec_emit2's scheme: wave w takes the lists w, w + 4, ...)
+        // ---- the tile's list entries, requested now and scattered after the barrier (wave w takes the lists w, w + 4, ...)
         uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const uint32_t* ls_p = plist;
         auto ls_open = [&](uint32_t t_) {
             const uint32_t g_ = uni32(s_g[pb][t_]), b_ = uni32(s_kb[pb][t_]), n_ = uni32(s_nent[t_]);
@@ -1834,7 +1507,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __l
         const uint8_t* const pk = (const uint8_t*)t_pk4 + (uint32_t)(pka & 15ull);                     // packed byte (s0 >> 2) + i at pk[i]
         const uint32_t have = (uint32_t)(pke - pka), sbit0 = 2u * (s0 & 3u);                              // staged packed bytes; bit offset of stored base s0 in pk
         // ---- quality lists, exception records, N list into the tiles
-        if (!(abl & 4)) {
+        {
 #pragma unroll
             for (int i = 0; i < 8; i++) { const uint32_t p = fe[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
             while (ls_t < nn) {
@@ -1856,7 +1529,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __l
         if (nxt < re && tid < T) { s_g[pb ^ 1u][tid] = cell_lookup(tid, tp_n.q0, tp_n.s0, false); s_kb[pb ^ 1u][tid] = cell_lookup(tid, tp_n.q0, tp_n.s0, true); }
         __syncthreads();
         // ---- compose: my share of my read's four lines, straight to the output (src/rfqcodec.cpp:1141-1254, Read::toString src/read.cpp:170)
-        if (on && !(abl & 16)) {
+        if (on) {
             uint8_t* const rec = (to2 ? out2 : out1) + toff; const uint64_t capo = to2 ? cap2 : cap1;
             const uint32_t e0 = n1 + md + n2, oseq = e0 + 1u, ost = oseq + len + 1u, oq = ost + sl + 1u, total = oq + len + 1u;
             if ((uint64_t)toff + total > capo) { if (part == 0) atomicOr(&st->err, 1u << 31); }
@@ -1870,8 +1543,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __l
                 const uint8_t* const src3 = (const uint8_t*)t_n24 + (uint32_t)(n2a & 15ull) + (same2 ? 0u : o8);
                 const uint8_t* const src4 = (const uint8_t*)t_st4 + (uint32_t)(sta & 15ull) + (same3 ? 0u : o9);
                 const int pat2 = (same2 && rc && dch != 0 && dpos < n2) ? (int)dpos : -1;
-                if (abl & 128) {}
-                else if (nfast) {
+                if (nfast) {
                     const uint32_t ngl = (L + 15u) >> 4;
                     for (uint32_t gi = part; gi < ngl; gi += P) {
                         uint32_t p0 = 16u * gi; if (p0 + 16u > L) p0 = L - 16u;
@@ -1896,7 +1568,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __l
                 }
                 // "\n" + strand + "\n" behind the bases and the '\n' behind the qualities ride on the last 16-byte stores of those lines when the strand line is
                 // one character (below); otherwise they are written here
-                if (!jfast && !(abl & 128) && part == 3 % P) { e3_copy(rec + ost, src4, sl, 0, 1, -1, 0); rec[ost - 1u] = '\n'; rec[oq - 1u] = '\n'; rec[total - 1u] = '\n'; }
+                if (!jfast && part == 3 % P) { e3_copy(rec + ost, src4, sl, 0, 1, -1, 0); rec[ost - 1u] = '\n'; rec[oq - 1u] = '\n'; rec[total - 1u] = '\n'; }
                 // bases and qualities, 16 positions per step.  I = the read in interleaved orientation: I[p] = stored[A + p] for p < xa, stored[Bs + p - xa] behind
                 // (the part of a mate that overlaps R1 is R1's: src/rfqcodec.cpp:865-897); the output is I, or its reverse complement for an interleaved chunk's mate
                 const uint32_t xa = ov < 0 ? len - (uint32_t)(-ov) : len; const uint32_t A = ov > 0 ? sp - (uint32_t)ov : sp, Bs = sp - prevlen;
@@ -1927,7 +1599,6 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, int OCC = 5> __global__ void __l
                     }
                 };
                 auto put = [&](uint32_t at_q, uint32_t at_s, const uint32_t (&qw)[4], const uint32_t (&sw)[4], bool both) {
-                    if (abl & 64) { if ((qw[0] ^ sw[1] ^ qw[2] ^ sw[3] ^ sw[0] ^ qw[1] ^ sw[2] ^ qw[3]) == 0x12345678u) rec[0] = 1; return; }     // (ablation: everything but the stores)
                     GU16d v;
                     if (both) { v.a = qw[0]; v.b = qw[1]; v.c = qw[2]; v.d = qw[3]; *(GU16d*)(rec + at_q) = v; }
                     v.a = sw[0]; v.b = sw[1]; v.c = sw[2]; v.d = sw[3]; *(GU16d*)(rec + at_s) = v;

@@ -474,7 +474,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail, (uint32_t*)nullptr);
         if (is_pe) {
             const uint32_t ob = std::min<uint32_t>((n_units + 255) / 256, 65535u * 16u);
-            hipLaunchKernelGGL((k_overlap<false, false>), dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units, (unsigned long long*)nullptr, 0);
+            hipLaunchKernelGGL(k_overlap<false>, dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units);
         }
         stored_prefix(S, B[B_SCANTMP].as<U4>());
         KCHK(ctx, "k_chunk_flags");
@@ -520,7 +520,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             if (ctx->qplane_dirty) HIPCHK(ctx, hipMemsetAsync(M.planes, 0, ((size_t)M.pstride * G2_PLANES + nc * (1u + G2_RARE_LIST)) * 4, S));
             ctx->qplane_dirty = true; ctx->qplane_nd = M.nd;                // (dirty until this call's cleanup is queued)
         }
-        const uint32_t dyn = dyn_of(M.nd) + ctx->opt.g2_pad;
+        const uint32_t dyn = dyn_of(M.nd) + ctx->opt.g2_pad; (void)dyn;   // (the interpreter's launch macro takes its dynamic LDS from a buffer of its own)
         // phase 1: every chunk, names parsed on the way, mates taken for interleaved wherever the header allows; then the flag words; then phase 2 for the
         // (rare) chunks whose interleave test failed somewhere: their workgroups are the only ones of that launch that do not return at once
         for (int phase = 1; phase <= (is_pe ? 2 : 1); phase++) {
@@ -547,7 +547,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (is_pe) {
             const OvLoose Z = { (const uint32_t*)R.pq, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), (const uint8_t*)B[B_RFLAG].as<uint8_t>() };
             const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
-            hipLaunchKernelGGL((k_overlap<false, true>), dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np, (unsigned long long*)nullptr, 0);
+            hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np);
         }
         hipLaunchKernelGGL(k_chunk_prefix, dim3(n_chunks), dim3(256), 0, A, T, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb);
         {
@@ -570,8 +570,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
         // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 32
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
-        hipLaunchKernelGGL(k_gather<false>, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg,
-                           (unsigned long long*)nullptr, 0);
+        hipLaunchKernelGGL(k_gather, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
         const uint32_t px = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
         hipLaunchKernelGGL(k_packbytes, dim3(px, n_chunks), dim3(256), 0, S, (const U4*)R.pv, (const uint32_t*)C.first, (const uint64_t*)C.sbase, (const uint8_t*)B[B_SCAT].as<uint8_t>(),
                            B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>());

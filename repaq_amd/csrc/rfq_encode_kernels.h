@@ -862,19 +862,17 @@ __device__ __forceinline__ void ov2_pack_rc(uint32_t w, uint32_t& code, uint32_t
 // valid for the pairs of interleaved chunks - the only ones whose result is used): lengths and slots come from the quality prefix pq, the
 // "R1 holds a byte outside A/C/G/T/N" verdict from rflag.  The search then runs behind the gather, beside the position coder.
 struct OvLoose { const uint32_t* pq; const uint32_t* lpk; const uint16_t* lnb; const uint8_t* rflag; };
-template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, OvLoose Z, int16_t* __restrict__ ovraw, uint32_t n_pairs, unsigned long long* dbg, int abl) {
+template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, OvLoose Z, int16_t* __restrict__ ovraw, uint32_t n_pairs) {
     __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4) + 4]; __shared__ uint32_t s_bad[4][2];      // (+4: a verification step reads 9 bytes from a byte offset inside the last row)
-    long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, k5 = 0, a_meta = 0, a_pack = 0, a_fwd = 0, a_bwd = 0, a_slow = 0; uint32_t n_ver = 0;
     const int l = lane_id(), w = wave_id();
     uint8_t* const c1 = (uint8_t*)(s_rows + (size_t)w * (OV2_WAVE_BYTES / 4)); uint8_t* const c2 = c1 + 64u * OV2_CROW;
     uint8_t* const n1 = c2 + 64u * OV2_CROW; uint8_t* const n2 = n1 + 64u * OV2_NROW;
     for (uint32_t p0 = (blockIdx.x * 4u + (uint32_t)w) * 64u; p0 < n_pairs; p0 += gridDim.x * 256u) {       // wave-uniform
-        if (DBG) k0 = clock64();
         const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0; uint32_t ld1 = 0, ld2 = 0;
         if (p < n_pairs) {
             const uint32_t g = 2u * p;
             if (LOOSE) { const uint32_t a = Z.pq[g], b = Z.pq[g + 1], c_ = Z.pq[g + 2]; len1 = (int)(b - a); len2 = (int)(c_ - b); ld1 = (a >> 4) + g; ld2 = (b >> 4) + g + 1u; }
-            else if (!(abl & 4)) { uint32_t r; read_loc(T, g, s1, r); const uint32_t* pa = t_lo(T, s1) + 4 * (size_t)r; q1 = pa[1]; len1 = (int)(pa[2] - 1u - q1);
+            else { uint32_t r; read_loc(T, g, s1, r); const uint32_t* pa = t_lo(T, s1) + 4 * (size_t)r; q1 = pa[1]; len1 = (int)(pa[2] - 1u - q1);
                               read_loc(T, g + 1, s2, r); const uint32_t* pb = t_lo(T, s2) + 4 * (size_t)r; q2 = pb[1]; len2 = (int)(pb[2] - 1u - q2); }
         }
         const bool slow = len1 >= 0 && ((uint32_t)len1 > OV2_CAP || (uint32_t)len2 > OV2_CAP), fast = len1 >= 0 && !slow;
@@ -884,7 +882,6 @@ template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap
         wave_lds_sync();
         { uint4* z = (uint4*)c1; for (uint32_t i = (uint32_t)l; i < OV2_WAVE_BYTES / 16u; i += 64u) z[i] = make_uint4(0, 0, 0, 0); }
         wave_lds_sync();
-        if (DBG) { k1 = clock64(); a_meta += k1 - k0; }
         // ---- pack: task t = (row, ALIGNED 32-byte group of the text that holds part of the row's sequence line); rows 0..63 R1, 64..127 RC2.
         // Consecutive lanes take consecutive groups of one line: every load is an aligned dwordx4 (a dwordx4 at an odd address - one per
         // 16 bases of the line itself - keeps the texture addresser busy for hundreds of cycles).  A group's 32 bases land at an arbitrary
@@ -907,7 +904,7 @@ template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap
                 for (uint32_t u = 0; u < 4u; u++) { const uint32_t j = j0 + u; if (fast && j < nd_) { r1w[j] = va[u]; m1w[j] = ma[u]; r2w[j] = vb[u]; m2w[j] = mb[u]; } }
             }
         } else {
-        const uint32_t G = ((uint32_t)mx + 31u + 31u) >> 5, ntasks = (abl & 2) ? 0u : 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 4096, G <= 17
+        const uint32_t G = ((uint32_t)mx + 31u + 31u) >> 5, ntasks = 128u * G, ginv = G ? (65536u + G - 1u) / G : 0u;   // t / G == (t * ginv) >> 16 for t < 4096, G <= 17
             const uint32_t meta1 = (uint32_t)(len1 < 0 ? 0 : (len1 > 0xFFFF ? 0xFFFF : len1)) | ((uint32_t)s1 << 16) | (fast ? 1u << 17 : 0u);
             const uint32_t meta2 = (uint32_t)(len2 < 0 ? 0 : (len2 > 0xFFFF ? 0xFFFF : len2)) | ((uint32_t)s2 << 16);
             for (uint32_t t0 = 0; t0 < ntasks; t0 += 256u) {
@@ -971,17 +968,15 @@ template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap
             }
         }
         wave_lds_sync();
-        if (DBG) { k2 = clock64(); a_pack += k2 - k1; }
         const bool bad = fast && (LOOSE ? (p < n_pairs && Z.rflag[2u * p] != 0) : ((s_bad[w][l >> 5] >> (l & 31)) & 1u) != 0);
         const bool go = fast && !bad; const int minlen = len1 < len2 ? len1 : len2;
         const uint8_t* const r1c = c1 + (uint32_t)l * OV2_CROW; const uint8_t* const r2c = c2 + (uint32_t)l * OV2_CROW;
-        int ov = 0; bool done = !go || minlen < 12 || (abl & 1);
+        int ov = 0; bool done = !go || minlen < 12;
         const uint32_t head1 = lds_get4(r1c, 0) & 0xFFFFFFu, head2 = lds_get4(r2c, 0) & 0xFFFFFFu;
         const uint32_t nd = ((uint32_t)mx + 15u) >> 4;          // dwords of a code row in use (16 bases each), wave-uniform
 #pragma unroll 1
         for (int dir = 0; dir < 2; dir++) {                     // 0: R1 tail == RC2 head (+o), 1: RC2 tail == R1 head (-o)
             const uint8_t* const wc = dir ? r2c : r1c; const int wl = dir ? len2 : len1; const uint32_t head = dir ? head1 : head2;
-            if (DBG) { k3 = clock64(); if (dir) a_fwd += k3 - k2; }
             if (!__any(!done)) break;
             // the filter, ALL window starts of the row at once: base i of the row starts a candidate (o = wl - i) when the OV2_FILTER bases
             // from i on equal the head of the other read.  With the row as a bit string (2 bits per base), X_k = (row >> 2k) ^ (head's base k
@@ -1022,7 +1017,6 @@ template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap
 #pragma unroll
                 for (int d = 15; d >= 0; d--) if ((uint32_t)d < nd && cand < 0 && Dm[d]) cand = 16 * d + ((31 - __clz((int)Dm[d])) >> 1);
                 if (!__any(cand >= 0)) break;                    // wave-uniform
-                if (DBG) n_ver++;
                 const uint32_t pa = cand >= 0 ? (uint32_t)cand : 0u, o = cand >= 0 ? (uint32_t)(wl - cand) : 0u;
                 unsigned long long diff = 0;
                 for (uint32_t c = 0; c < nch; c++) {
@@ -1050,7 +1044,6 @@ template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap
                 }
             }
         }
-        if (DBG) { k4 = clock64(); a_bwd += k4 - k3; }
         // reads longer than a row, or an R1 holding a character outside A/C/G/T/N: the byte-wise search, one pair at a time
         unsigned long long sm = __ballot(slow || bad);
         if (LOOSE && sm && len1 >= 0) { uint32_t r; read_loc(T, 2u * p, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, 2u * p + 1u, s2, r); q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }   // (the byte-wise search reads the text)
@@ -1061,9 +1054,7 @@ template <bool DBG, bool LOOSE> __global__ void __launch_bounds__(256) k_overlap
             if (l == j) ov = r;
         }
         if (len1 >= 0) ovraw[p] = (int16_t)(ov > 32767 ? 0 : (ov < -32767 ? 0 : ov));      // (beyond +-127 - shift the clamp of k_overlap_apply makes it 0 anyway)
-        if (DBG) { k5 = clock64(); a_slow += k5 - k4; }
     }
-    if (DBG && dbg && l == 0) { atomicAdd(&dbg[0], (unsigned long long)a_meta); atomicAdd(&dbg[1], (unsigned long long)a_pack); atomicAdd(&dbg[2], (unsigned long long)a_fwd); atomicAdd(&dbg[3], (unsigned long long)a_bwd); atomicAdd(&dbg[4], (unsigned long long)a_slow); atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)n_ver); }
 }
 // the clamp of src/rfqcodec.cpp:376-383 and the stored length of the mate, for the pairs of interleaved chunks (k_overlap found the offsets)
 __global__ void k_overlap_apply(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const int16_t* __restrict__ ovraw, int8_t* __restrict__ ovb, uint32_t n_pairs) {
@@ -1231,19 +1222,18 @@ template <bool SEQ> __device__ __forceinline__ void gather_copy(uint8_t* o, cons
 }
 // LDS tile -> global [gbeg, gend) (positions relative to gbase, which is 64-byte aligned; the tile sits at LDS offset gbeg & 15): aligned
 // 16-byte stores; every byte goes through the counter - count.group for an aligned group, count(pos, byte) for the edge bytes
-template <class Count> __device__ __forceinline__ void flush_count(const uint4* lds4, uint8_t* gbase, uint32_t gbeg, uint32_t gend, Count& count, int abl = 0) {
+template <class Count> __device__ __forceinline__ void flush_count(const uint4* lds4, uint8_t* gbase, uint32_t gbeg, uint32_t gend, Count& count) {
     if (gend <= gbeg) return;
     const uint8_t* lds = (const uint8_t*)lds4; const uint32_t a0 = gbeg & ~15u;
     const uint32_t first_full = (gbeg + 15u) & ~15u, last_full = gend & ~15u;
     if (first_full < last_full) { const uint32_t ng = (last_full - first_full) / 16u, g0 = (first_full - a0) / 16u;
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint4 v = lds4[g0 + i]; if (!(abl & 32)) *(uint4*)(gbase + first_full + 16u * i) = v; if (!(abl & 16)) count.group(first_full + 16u * i, v.x, v.y, v.z, v.w); } }
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint4 v = lds4[g0 + i]; *(uint4*)(gbase + first_full + 16u * i) = v; count.group(first_full + 16u * i, v.x, v.y, v.z, v.w); } }
     const uint32_t he = first_full < gend ? first_full : gend;
     for (uint32_t x = gbeg + threadIdx.x; x < he; x += blockDim.x) { const uint8_t b = lds[x - a0]; gbase[x] = b; count(x, b); }
     if (last_full >= first_full) for (uint32_t x = last_full + threadIdx.x; x < gend; x += blockDim.x) { const uint8_t b = lds[x - a0]; gbase[x] = b; count(x, b); }
 }
-template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict__ ovb, const DevHeader* __restrict__ D,
-                         uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, unsigned long long* dbg, int tune) {
-    long long tk0 = DBG ? clock64() : 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0; long long a_fit = 0, a_meta = 0, a_stage = 0, a_q = 0, a_s = 0;
+__global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict__ ovb, const DevHeader* __restrict__ D,
+                         uint8_t* __restrict__ qcat, uint8_t* __restrict__ scat, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
     __shared__ uint4 s_text4[GT_CAP / 16 + 6]; __shared__ uint4 s_qo4[GT_OCAP / 16 + 2], s_so4[GT_OCAP / 16 + 2];
     __shared__ uint32_t s_qsrc[GT_READS], s_ssrc[GT_READS], s_len[GT_READS], s_skip[GT_READS], s_keep[GT_READS], s_qdst[GT_READS + 1], s_sdst[GT_READS + 1];
     __shared__ uint8_t s_rc[GT_READS]; __shared__ uint32_t s_nx[GT_READS];
@@ -1294,7 +1284,6 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
               nfits = need + 16u <= GT_CAP && (qend - (R.pq[(from)] - pq0)) + 16u <= GT_OCAP;                                         \
           } } }
     while (cur < ge) {                                                   // block-uniform
-        if (DBG) tk0 = clock64();
         if (!have) GATHER_META_LOAD(cur)
         a0[0] = na0[0]; a0[1] = na0[1]; fits = nfits; m_st = nm_st; m_p1 = nm_p1; m_p3 = nm_p3; m_nx = nm_nx; m_len = nm_len; m_qdst = nm_qdst; m_sdst = nm_sdst; m_ov = nm_ov; m_rc = nm_rc; have = false;
         if (tid < GT_READS) s_nx[tid] = m_nx;
@@ -1320,7 +1309,6 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
             }
             cur += upr; __syncthreads(); continue;
         }
-        if (DBG) { tk1 = clock64(); a_fit += tk1 - tk0; }
         // ---- per-read metadata -> LDS (from the registers loaded above)
         uint32_t span_end[2] = { 0, 0 };
         if (two) { span_end[0] = s_nx[cnt - 2]; span_end[1] = s_nx[cnt - 1]; }   // cnt is even for two files: the last pair's records end the spans
@@ -1332,7 +1320,6 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
             s_skip[tid] = m_ov > 0 ? (uint32_t)m_ov : 0u; s_keep[tid] = m_len - (uint32_t)(m_ov < 0 ? -m_ov : m_ov);
         }
         if (tid <= cnt) { s_qdst[tid] = m_qdst; s_sdst[tid] = m_sdst; }
-        if (DBG) { tk2 = clock64(); a_meta += tk2 - tk1; }
         // ---- stage the spans: aligned 16-byte loads (the very last group of a stream may not be fully inside the buffer)
         for (int st = 0; st < (two ? 2 : 1); st++) {
             const uint32_t nb = span_end[st] - a0[st]; const uint32_t ng = (nb + 15) / 16; const uint32_t lb = st ? base1 : 0u;
@@ -1348,7 +1335,6 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
         }
         if (cur + cnt < ge) { GATHER_META_LOAD(cur + cnt) have = true; }      // the next tile's round of loads, in flight beside the staging
         __syncthreads();
-        if (DBG) { tk3 = clock64(); a_stage += tk3 - tk2; }
         // ---- compose: one thread = a quarter of one piece (32 reads x {qualities, stored bases} x 4), text tile -> output tiles, LDS to LDS
         const uint32_t q_beg = s_qdst[0], q_end = s_qdst[cnt], s_beg = s_sdst[0], s_end = s_sdst[cnt];
         {
@@ -1359,25 +1345,22 @@ template <bool DBG> __global__ void k_gather(Text T, ReadTab R, ChunkTab C, cons
                 if (!seq) { n = len; src = s_qsrc[j]; o = (uint8_t*)s_qo4 + (q_beg & 15u) + (s_qdst[j] - q_beg); }
                 else { n = s_keep[j]; src = s_ssrc[j] + (rc ? len - s_skip[j] - n : 0u); o = (uint8_t*)s_so4 + (s_beg & 15u) + (s_sdst[j] - s_beg); }   // stored bases of a mate: RC(R2)[skip, skip + keep) = R2[len - skip - keep, len - skip) back to front
                 const uint32_t ng = (n + 15u) >> 4, per4 = (ng + 3u) >> 2, gb = quarter * per4, ge_ = gb + per4 < ng ? gb + per4 : ng;
-                if (gb < ge_ && !(tune & 128)) { if (seq) gather_copy<true>(o, s_text, src, n, gb, ge_, rc); else gather_copy<false>(o, s_text, src, n, gb, ge_, rc); }
+                if (gb < ge_) { if (seq) gather_copy<true>(o, s_text, src, n, gb, ge_, rc); else gather_copy<false>(o, s_text, src, n, gb, ge_, rc); }
             }
         }
         __syncthreads();
-        if (DBG) { tk4 = clock64(); a_q += tk4 - tk3; }
         // ---- flush the two tiles with aligned 16-byte stores; the same pass counts (histogram, per-segment tables, N map)
         qc.seg0 = q_beg / PC_SEG_POS;
-        flush_count(s_qo4, qd, q_beg, q_end, qc, tune);
-        flush_count(s_so4, sd, s_beg, s_end, nc, tune);
+        flush_count(s_qo4, qd, q_beg, q_end, qc);
+        flush_count(s_so4, sd, s_beg, s_end, nc);
         __syncthreads();
         qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);       // (the next tile's counting starts three barriers from here)
-        if (DBG) { tk5 = clock64(); a_s += tk5 - tk4; }
         cur += cnt;
     }
     const uint32_t nn = wave_sum(nc.n);
     if (lane_id() == 0 && nn) atomicAdd(&s_n, nn);
     __syncthreads();
     if (tid == 0 && s_n) atomicAdd(&C.ncount[c], s_n);
-    if (DBG && tid == 0 && dbg) { atomicAdd(&dbg[0], (unsigned long long)a_fit); atomicAdd(&dbg[1], (unsigned long long)a_meta); atomicAdd(&dbg[2], (unsigned long long)a_stage); atomicAdd(&dbg[3], (unsigned long long)a_q); atomicAdd(&dbg[4], (unsigned long long)a_s); atomicAdd(&dbg[5], 1ull); }
 }
 
 // =============================================================== gather, second formulation (fast path) + sequence packer
@@ -1808,7 +1791,7 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
     const uint32_t pat0 = (uint32_t)D->normal[dense3 & 0xFFu] * 0x01010101u, pat1 = (uint32_t)D->normal[(dense3 >> 8) & 0xFFu] * 0x01010101u, pat2 = (uint32_t)D->normal[(dense3 >> 16) & 0xFFu] * 0x01010101u, patm = (D->major & 0xFFu) * 0x01010101u;
     uint32_t* const gpl = M.planes + (MASKS ? (size_t)(qbase[c] >> 5) : (size_t)0);        // the chunk's words of plane 0
     uint4* const buf4 = g2_lds + 1; const uint8_t* const tx = (const uint8_t*)buf4;
-    G2Ref r0; G2Acc acc; acc.bits = CF_ALL; acc.fail = 0xFFFFFFFFu;
+    G2Ref r0 = {}; G2Acc acc; acc.bits = CF_ALL; acc.fail = 0xFFFFFFFFu;
     const bool parse = !redo && gs < ge;                                    // block-uniform
     if (parse) {
         // read 0 of the chunk: the first bytes of its name and strand lines into LDS, its name parsed by one lane
@@ -2516,7 +2499,6 @@ __global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C,
             for (uint32_t u = 0; u < 4u; u++) if (j0 + u < nn) { if (l == 0) S.off[j0 + u] = (uint16_t)tot; pl_base[(j0 + u) * 64u + l] = (uint16_t)(incl[u] - cnt[u]); tot += wave_last(incl[u]); }
         }
         if (l == 0) { S.off[nn] = (uint16_t)tot; S.off[nn + 1] = (uint16_t)tot; }
-        const uint32_t NE = tot;
         wave_lds_sync();
         // ---- scatter the entries into the list (returning atomics, independent of one another), each with its code.
         // The codes of a lane's 64 positions as four bit masks - no work per position: a streak starts at the zeros of E (code 1); a run token stands at the

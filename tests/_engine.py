@@ -12,7 +12,7 @@ EMU_LIB = os.path.join(EMU_DIR, "librfq_emu.so")
 PRODUCT_LIB = os.path.join(ROOT, "repaq_amd", "lib", "librfq_hip.so")
 
 
-OPTION_NAMES = ("RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_EMIT", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE")
+OPTION_NAMES = ("RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE")
 
 
 def build_emu():

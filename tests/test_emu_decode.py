@@ -61,18 +61,19 @@ def test_multichunk_round_trip(codec, label, prof, reads, seed, cb, paired, kw):
 
 @pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI, ids=[m[0] for m in MULTI])
 def test_multichunk_round_trip_tile_fitting_emitter(codec, label, prof, reads, seed, cb, paired, kw):
-    """RFQ_EMIT=2: k_dec_emit2 (tiles fitted read by read; the emitter of files whose name pieces are stored per read)."""
-    codec.set_option("RFQ_EMIT", "2")
+    """RFQ_MATERIALISE=1: the expanded path (qualities and bases expanded in HBM, k_dec_emit's tiles fitted read by read) - the path of a streaming
+    caller's non-final slices and of files whose name pieces are stored per read."""
+    codec.set_option("RFQ_MATERIALISE", "1")
     fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
     rfq = O.encode_file(fq1, fq2, paired, cb)
     d = codec.decode_bytes(rfq, split_pe=(paired != O.SE))
     assert d == ((fq1, fq2) if paired != O.SE else fq1)
-    assert "emit2" in dict(codec.timings())
+    assert "emit_expanded" in dict(codec.timings())
 
 
 def test_emitters_are_the_ones_expected(codec):
     """k_dec_emit3 (fixed tiles, no output tile) decodes files whose chunks share their name pieces - NovaSeq-style names do; a file with
-    per-read name pieces goes to k_dec_emit2."""
+    per-read name pieces goes to the expanded path (k_dec_emit)."""
     for prof, paired in ((O.NOVA_PE150, O.PE_TWO_FILES), (O.NOVA_SE150, O.SE)):
         fq1, fq2 = O.gen(prof, 300, seed=41)
         rfq = O.encode_file(fq1, fq2, paired, 20000)
@@ -110,7 +111,7 @@ def test_fixed_tile_emitter_line_shapes(codec, label, name_of, strand_of):
         rfq = O.encode_file(fq, b"", O.SE, cb)
         assert O.decode_file(rfq) == fq
         assert codec.decode_bytes(rfq) == fq
-        assert label in ("tiny_names", "strand_text") or "emit" in dict(codec.timings()), dict(codec.timings())   # (those two hold per-read pieces: k_dec_emit2)
+        assert label in ("tiny_names", "strand_text") or "emit" in dict(codec.timings()), dict(codec.timings())   # (those two hold per-read pieces: the expanded path)
     fq2 = _handmade(420, name_of, lambda i: 1 + (i * 11) % 70, strand_of, seed=99)
     rfq = O.encode_file(fq, fq2, O.PE_TWO_FILES, 2000)
     assert codec.decode_bytes(rfq, split_pe=True) == (fq, fq2)
@@ -120,7 +121,7 @@ def test_fixed_tile_emitter_line_shapes(codec, label, name_of, strand_of):
 def test_fixed_tile_emitter_with_per_read_name_pieces():
     """Names FastqMeta::parse does not take apart are stored whole, per read: k_dec_emit3 stages a tile's name pieces when the chunks' AVERAGE piece
     leaves room (the host sizes the tile by it); a tile whose reads carry much longer names than that raises DE_E3_RETRY and the range is emitted
-    again by k_dec_emit2 - as are, from then on, the following ranges on that context; long names throughout go to k_dec_emit2 at once."""
+    again by the expanded path - as are, from then on, the following ranges on that context; long names throughout go there at once."""
     from repaq_amd import RfqCodec
     codec = RfqCodec(device=0, library=E.build_emu())                            # (a context that has not given up on such files yet)
     short = _handmade(900, lambda i: "SRR0123456.%d %d length=150" % (i + 1, i + 1), lambda i: 150 - (i % 3), lambda i: "+", seed=3)
@@ -130,14 +131,14 @@ def test_fixed_tile_emitter_with_per_read_name_pieces():
     mixed = _handmade(900, lambda i: ("SRR0123456.%d" % i) if not 400 <= i < 480 else ("L" * 110 + "%d" % i), lambda i: 100, lambda i: "+", seed=4)
     rfq = O.encode_file(mixed, b"", O.SE, 1_000_000)
     assert codec.decode_bytes(rfq) == mixed
-    assert "emit2" in dict(codec.timings()), dict(codec.timings())               # (the retry)
+    assert "emit_expanded" in dict(codec.timings()), dict(codec.timings())               # (the retry)
     assert codec.decode_bytes(O.encode_file(short, b"", O.SE, 50_000)) == short
-    assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
+    assert "emit_expanded" in dict(codec.timings()) and "emit" not in dict(codec.timings())
     codec.close()
     codec = RfqCodec(device=0, library=E.build_emu())
     longn = _handmade(300, lambda i: "N" * 240 + "%d" % i, lambda i: 100, lambda i: "+", seed=5)          # (64 of them do not fit the large tile either)
     assert codec.decode_bytes(O.encode_file(longn, b"", O.SE, 1_000_000)) == longn
-    assert "emit2" in dict(codec.timings()) and "emit" not in dict(codec.timings())
+    assert "emit_expanded" in dict(codec.timings()) and "emit" not in dict(codec.timings())
     mid = _handmade(300, lambda i: "N" * 120 + "%d" % i, lambda i: 100, lambda i: "+", seed=6)           # (the instantiation with the 13 KB name tile)
     assert codec.decode_bytes(O.encode_file(mid, b"", O.SE, 1_000_000)) == mid
     assert "emit" in dict(codec.timings()), dict(codec.timings())
@@ -187,13 +188,13 @@ def test_bug_compat_decode_loses_what_the_reference_loses(codec, label, prof, re
 
 def test_chunk_starts_without_an_index(codec):
     """A .rfq has no chunk index: the decoder guesses segment starts, walks the segments in parallel and verifies every extent (k_dec_gw_*);
-    RFQ_WALK=chain is the one-wave chain it falls back to.  Small segments (RFQ_GW_SHIFT) so that a small image has several."""
+    RFQ_WALK=exact is the one-wave serial walk it falls back to.  Small segments (RFQ_GW_SHIFT) so that a small image has several."""
     fq1, fq2 = O.gen(O.NOVA_PE150, 3000, seed=51)
     rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 9000)
     assert len(O.chunk_table(rfq)) - 1 > 80
     codec.set_option("RFQ_GW_SHIFT", "12")
     assert codec.decode_bytes(rfq, split_pe=True) == (fq1, fq2)
-    codec.set_option("RFQ_WALK", "chain")
+    codec.set_option("RFQ_WALK", "exact")
     assert codec.decode_bytes(rfq, split_pe=True) == (fq1, fq2)
     codec.set_option("RFQ_WALK", None)
     # chunks of very different sizes (a guessed start that is not one, segments without any start): whatever happens, the text is right
@@ -248,7 +249,7 @@ def test_full_size_chunk_position_streams_span_many_segments(codec, prof, reads,
     fq1, fq2 = O.gen(prof, reads, seed=9, **kw)
     rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES if fq2 else O.SE, 1_000_000)
     assert codec.decode_bytes(rfq, split_pe=bool(fq2)) == ((fq1, fq2) if fq2 else fq1)
-    assert "emit" in dict(codec.timings()) or "emit2" in dict(codec.timings())
+    assert "emit" in dict(codec.timings()) or "emit_expanded" in dict(codec.timings())
     codec.set_option("RFQ_MATERIALISE", "1")
     assert codec.decode_bytes(rfq, split_pe=bool(fq2)) == ((fq1, fq2) if fq2 else fq1)
     assert "textlen" in dict(codec.timings()), dict(codec.timings())           # (a stage of its own only on that path)
