@@ -1444,7 +1444,9 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         if (same2) span_dma<1>(make_span(t_n24, img, ib + d.o_n2, ib + d.o_n2 + d.n2_size, img_bytes, true));
         if (same3) span_dma<1>(make_span(t_st4, img, ib + d.o_st, ib + d.o_st + d.st_size, img_bytes, true));
     }
-    const uint32_t j = tid >> pshift, part = tid & (P - 1u);
+    // thread -> (read of the tile, part of it): the even reads first, then the odd ones - an interleaved chunk's mates are written back to front and
+    // complemented, their R1 as stored, and a wave that holds both runs both paths
+    const uint32_t jj = tid >> pshift, j = ((jj << 1) & (K - 1u)) | (jj >> (kshift - 1u)), part = tid & (P - 1u);
     __syncthreads();
     while (cur < re) {                                                       // block-uniform
         const uint32_t cnt = re - cur < K ? re - cur : K, g0 = f + cur, g1 = g0 + cnt;

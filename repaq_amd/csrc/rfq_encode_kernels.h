@@ -1410,14 +1410,33 @@ __device__ __forceinline__ uint32_t g2_rev2x16(uint32_t v) {                // t
 }
 struct G2Geo { uint32_t a00, a01, end0, end1, base1; };                         // a tile's text spans: 16-aligned begin and end per stream, LDS offset of stream 1's span
 struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld, gi; };       // my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
-__device__ __forceinline__ G2Geo g2_geo(const Text& T, bool two, uint32_t cur, uint32_t cnt) {
-    G2Geo g;
-    if (two) { const size_t r0 = 4 * (size_t)(cur >> 1), r1 = 4 * (size_t)((cur + cnt) >> 1);
-               g.a00 = uni32(T.lo[0][r0]) & ~15u; g.end0 = uni32(T.lo[0][r1]); g.a01 = uni32(T.lo[1][r0]) & ~15u; g.end1 = uni32(T.lo[1][r1]); }
-    else { g.a00 = uni32(T.lo[0][4 * (size_t)cur]) & ~15u; g.end0 = uni32(T.lo[0][4 * (size_t)(cur + cnt)]); g.a01 = 0; g.end1 = 0; }
+// ---- what a tile needs before its text can be requested.  A tile BOUNDARY (where the text of tile k starts in each stream, its first quality position)
+// is a scalar load issued three tiles ahead, the lines of my read in the next tile are requested a tile ahead: the tile's only round trip at its start
+// is the text's own (they used to be two: boundaries, then text + lines).  (The text itself cannot be requested a tile ahead: into registers it costs 24
+// VGPRs the kernel does not have at six waves per SIMD - it spills at 80 as it is -, into a second LDS buffer it costs resident workgroups.)
+struct G2Bound { uint32_t l0, l1, q; };                                       // tile boundary: line-table entry of its first read in each stream, quality prefix of that read
+struct G2MRaw { uint4 lo4; uint32_t pg; };
+#ifdef RFQ_SIMT_EMULATION
+__device__ __forceinline__ uint32_t ld_uniform(const uint32_t* p) { return *p; }
+#else
+// a load whose address is the same in every lane, from memory no kernel in flight writes: constant address space -> s_load_dword, the value in an SGPR
+__device__ __forceinline__ uint32_t ld_uniform(const uint32_t* p) { return *(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p; }
+#endif
+__device__ __forceinline__ G2Bound g2_bound(const Text& T, bool two, const uint32_t* __restrict__ pq, uint32_t r) {   // r: uniform; even when `two`
+    G2Bound b;
+    if (two) { const size_t k = 4 * (size_t)(r >> 1); b.l0 = ld_uniform(T.lo[0] + k); b.l1 = ld_uniform(T.lo[1] + k); }
+    else { b.l0 = ld_uniform(T.lo[0] + 4 * (size_t)r); b.l1 = 0u; }
+    b.q = ld_uniform(pq + r);
+    return b;
+}
+__device__ __forceinline__ G2Geo g2_geo(const G2Bound& b, const G2Bound& e, bool two) {
+    G2Geo g; g.a00 = b.l0 & ~15u; g.end0 = e.l0; g.a01 = two ? b.l1 & ~15u : 0u; g.end1 = two ? e.l1 : 0u;
     g.base1 = two ? (((g.end0 - g.a00 + 15u) & ~15u) + 16u) : 0u;
     return g;
 }
+// thread tid's groups of a tile: group i = tid + 256 k of the spans laid end to end (stream 0's n0 groups, then stream 1's); its place in LDS: i, or one
+// group further on for stream 1 (base1).  Only a stream's very last group may reach past the caller's buffer: it is not requested here but copied byte by
+// byte when the tile is put down.
 // LDS-DMA of a tile's spans to buf4 (global_load_lds_dwordx4: every lane names its own 16 global bytes, a wave's 64 groups land contiguously)
 __device__ __forceinline__ void g2_stage1(const uint8_t* __restrict__ fq, uint32_t n, uint32_t a0, uint32_t end, uint4* l4, uint32_t tid) {
     const uint32_t nb = end - a0, ng = (nb + 15u) / 16u;
@@ -1431,14 +1450,18 @@ __device__ __forceinline__ void g2_stage(const Text& T, bool two, const G2Geo& g
     g2_stage1(T.fq[0], T.n[0], g.a00, g.end0, buf4, tid);
     if (two) g2_stage1(T.fq[1], T.n[1], g.a01, g.end1, buf4 + g.base1 / 16, tid);
 }
-__device__ __forceinline__ G2Read g2_read(const Text& T, const uint32_t* __restrict__ pq, const G2Geo& g, uint32_t f, uint32_t pq0, bool il, uint32_t cur, uint32_t j, uint32_t cnt) {
+__device__ __forceinline__ G2MRaw g2_mraw(const Text& T, const uint32_t* __restrict__ pq, uint32_t cur, uint32_t j, uint32_t cnt) {
+    G2MRaw r; r.lo4 = make_uint4(0, 0, 0, 0); r.pg = 0;
+    if (j < cnt) { const uint32_t gi = cur + j; int s_; uint32_t r_; read_loc(T, gi, s_, r_); r.lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_); r.pg = pq[gi]; }   // starts of the read's four lines
+    return r;
+}
+__device__ __forceinline__ G2Read g2_read(const Text& T, const G2MRaw& r, const G2Geo& g, uint32_t f, uint32_t pq0, bool il, uint32_t cur, uint32_t j, uint32_t cnt) {
     G2Read m; m.on = j < cnt; m.rc = false; m.len = m.qsrc = m.ssrc = m.qpos = m.ld = 0; m.gi = cur + j;
     if (m.on) {
         const uint32_t gi = cur + j; int s_; uint32_t r_; read_loc(T, gi, s_, r_);
-        const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);     // starts of the read's four lines
         const uint32_t lb = s_ ? g.base1 : 0u, a = s_ ? g.a01 : g.a00;
-        m.len = lo4.z - 1u - lo4.y; m.ssrc = lb + (lo4.y - a); m.qsrc = lb + (lo4.w - a);
-        const uint32_t pg = pq[gi]; m.qpos = pg - pq0; m.ld = (pg >> 4) + gi;
+        m.len = r.lo4.z - 1u - r.lo4.y; m.ssrc = lb + (r.lo4.y - a); m.qsrc = lb + (r.lo4.w - a);
+        m.qpos = r.pg - pq0; m.ld = (r.pg >> 4) + gi;
         m.rc = il && ((gi - f) & 1u);
     }
     return m;
@@ -1785,7 +1808,9 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
     uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup
     const uint32_t gs = f + blockIdx.x * per, ge = gs + per < e ? gs + per : e;
     const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;              // K reads per tile, P threads per read
-    const uint32_t j = tid >> pshift, part = tid & (P - 1u);
+    // thread -> (read of the tile, part of it): the even reads first, then the odd ones - an interleaved chunk's mates (odd, reverse-complemented) and
+    // their R1 take different paths through the base packer, and a wave that holds both runs both
+    const uint32_t jj = tid >> pshift, j = ((jj << 1) & (K - 1u)) | (jj >> (kshift - 1u)), part = tid & (P - 1u);
     QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
     const uint32_t nd = MASKS ? M.nd : 0u, dense3 = (uint32_t)D->dense[0] | ((uint32_t)D->dense[1] << 8) | ((uint32_t)D->dense[2] << 16);     // planes built in LDS, and whose they are
     const uint32_t pat0 = (uint32_t)D->normal[dense3 & 0xFFu] * 0x01010101u, pat1 = (uint32_t)D->normal[(dense3 >> 8) & 0xFFu] * 0x01010101u, pat2 = (uint32_t)D->normal[(dense3 >> 16) & 0xFFu] * 0x01010101u, patm = (D->major & 0xFFu) * 0x01010101u;
@@ -1810,12 +1835,19 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
     __syncthreads();
     if (parse) { r0.n1l = s_r0[0]; r0.n2o = s_r0[1]; r0.lane = s_r0[2]; r0.tile = s_r0[3]; }
     uint32_t tix = blockIdx.x + blockIdx.y;                                 // (which wave parses: another one every tile, and not the same one in every workgroup)
-    for (uint32_t cur = gs; cur < ge; cur += K, tix++) {                   // block-uniform
-        const uint32_t cnt = ge - cur < K ? ge - cur : K;
-        const G2Geo g = g2_geo(T, two, cur, cnt);
+    // boundaries b0 .. b2 of tiles t, t + 1, t + 2 are here, b3 is requested; my read's lines in tile t are in `mr` (requested a tile ago)
+    const uint32_t ntile = gs < ge ? (ge - gs + K - 1u) >> kshift : 0u;
+    auto tile_at = [&](uint32_t t_) -> uint32_t { const uint32_t x = gs + (t_ << kshift); return x < ge ? x : ge; };
+    G2Bound b0 = g2_bound(T, two, pq, tile_at(0)), b1 = g2_bound(T, two, pq, tile_at(1)), b2 = g2_bound(T, two, pq, tile_at(2));
+    G2MRaw mr = g2_mraw(T, pq, gs, j, ntile ? tile_at(1) - gs : 0u);
+    for (uint32_t t = 0; t < ntile; t++, tix++) {                          // block-uniform
+        const uint32_t cur = tile_at(t), cnt = tile_at(t + 1u) - cur;
+        const G2Geo g = g2_geo(b0, b1, two);
         g2_stage(T, two, g, buf4, tid);
-        const G2Read m = g2_read(T, pq, g, f, pq0, il, cur, j, cnt);
-        const uint32_t qbeg = uni32(pq[cur]) - pq0, qend = uni32(pq[cur + cnt]) - pq0;   // the tile's quality positions (chunk-relative)
+        const G2Read m = g2_read(T, mr, g, f, pq0, il, cur, j, cnt);
+        const uint32_t qbeg = b0.q - pq0, qend = b1.q - pq0;               // the tile's quality positions (chunk-relative)
+        { const uint32_t ncur = tile_at(t + 1u); mr = g2_mraw(T, pq, ncur, j, tile_at(t + 2u) - ncur); }
+        const G2Bound b3 = g2_bound(T, two, pq, tile_at(t + 3u));
         __syncthreads();                                                    // (drains the LDS-DMA)
         qc.seg0 = qbeg / PC_SEG_POS;
         if (parse && (uint32_t)wave_id() == (tix & 3u)) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (wave-uniform: this tile's parsing wave)
@@ -1830,6 +1862,7 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
             g2_flush_masks(pl, M.pw, nd, dense3, s_carry, gpl, M.pstride, gw0, nw, !last_tile && (qend & 31u) != 0u, cur == gs && gs > f && (qbeg & 31u) != 0u, last_tile && ge < e && (qend & 31u) != 0u,
                            (size_t)c * MAX_STREAMS * n_seg, n_seg, segm, segc);
         } else qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
+        b0 = b1; b1 = b2; b2 = b3;
     }
     if (parse) {
         const uint32_t bits = wave_and(acc.bits), fail = wave_min(acc.fail);

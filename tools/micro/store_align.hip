@@ -1,0 +1,63 @@
+// How fast are 16-byte global stores at byte granularity?  (k_dec_emit3 writes every line of the text with them.)
+// Each lane stores 16 bytes; patterns:
+//   0  contiguous, 16-aligned (the reference: a plain copy's store side)
+//   1  contiguous, every address + 1        (whole wave shifted by a byte)
+//   2  contiguous, every address + 4
+//   3  records: 4 lanes write 64 consecutive bytes of a record, records 357 bytes apart, 6 rounds cover the record (emit3's shape)
+//   4  as 3, but every 16-byte group moved DOWN to a 4-aligned address (what a dword-aligned variant would issue)
+//   5  as 3 with 16-aligned groups
+//   6 / 7 / 8  as 3 with 8 / 16 / 32 lanes per record (runs of 128 / 256 / 357 contiguous bytes per instruction)
+// usage: store_align [MB]   build: hipcc --offload-arch=gfx950 -O3 -o /tmp/store_align tools/micro/store_align.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+struct __attribute__((packed, aligned(1))) U16 { uint32_t a, b, c, d; };
+template <int MODE> __global__ void __launch_bounds__(256) k(uint8_t* out, size_t n_groups, uint32_t seed) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
+    U16 v; v.a = seed + (uint32_t)tid; v.b = v.a * 3u; v.c = v.a * 5u; v.d = v.a * 7u;
+    if (MODE <= 2) {
+        const size_t off = MODE == 1 ? 1 : (MODE == 2 ? 4 : 0);
+        for (size_t g = tid; g < n_groups; g += nthr) *(U16*)(out + off + 16 * g) = v;
+    } else {
+        // record r = thread / 4 (+ rounds), part = thread & 3; a record is 357 bytes = 22 groups + 5 bytes: groups part, part + 4, ...
+        const size_t n_rec = (n_groups * 16) / 357 - 2;
+        const int LS = MODE == 6 ? 3 : (MODE == 7 ? 4 : (MODE == 8 ? 5 : 2)); const uint32_t L = 1u << LS;
+        for (size_t r = tid >> LS; r < n_rec; r += nthr >> LS) {
+            const size_t base = r * 357;
+            for (uint32_t gi = (uint32_t)(tid & (L - 1)); gi < 22; gi += L) {
+                size_t a = base + 16 * gi;
+                if (MODE == 4) a &= ~(size_t)3;
+                if (MODE == 5) a &= ~(size_t)15;
+                *(U16*)(out + a) = v;
+            }
+        }
+    }
+}
+int main(int argc, char** argv) {
+    const size_t mb = argc > 1 ? atoi(argv[1]) : 4096, bytes = mb << 20, n_groups = bytes / 16 - 64;
+    uint8_t* d; hipMalloc(&d, bytes + 4096); hipMemset(d, 0, bytes + 4096);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const char* names[] = { "contiguous aligned", "contiguous + 1 byte", "contiguous + 4 bytes", "records, byte-granular", "records, 4-aligned groups", "records, 16-aligned groups", "records, 8 lanes", "records, 16 lanes", "records, 32 lanes" };
+    for (int mode = 0; mode < 9; mode++) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; rep++) {
+            hipEventRecord(e0);
+            const int grid = 256 * 24;
+            switch (mode) {
+                case 0: hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 1: hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 3: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 4: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 5: hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 6: hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 7: hipLaunchKernelGGL(k<7>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+                case 8: hipLaunchKernelGGL(k<8>, dim3(grid), dim3(256), 0, 0, d, n_groups, rep); break;
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        }
+        printf("%-30s %8.3f ms  %7.1f GB/s\n", names[mode], best, bytes / best / 1e6);
+    }
+    return 0;
+}
