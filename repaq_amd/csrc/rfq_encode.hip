@@ -491,7 +491,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
     HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
     uint64_t* const ctot = B[B_CTOTAL].as<uint64_t>(); uint64_t* const cbase = B[B_CBASE].as<uint64_t>(); uint64_t* const ctot_n = B[B_CTOTALN].as<uint64_t>(); uint64_t* const cbase_n = B[B_CBASEN].as<uint64_t>();
-    bool aux_chain = false;
+    bool aux_chain = false, coder_waits = false;
     if (fast) {
         const size_t nld = (size_t)(total_bases >> 4) + reads_used + 16;
         HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2)); HIPCHK(ctx, B[B_RFLAG].ensure(nr));
@@ -548,6 +548,12 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             const OvLoose Z = { (const uint32_t*)R.pq, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), (const uint8_t*)B[B_RFLAG].as<uint8_t>() };
             const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
             hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np);
+            // The search and the position coder are both VALU-bound: side by side they only share the issue slots, and the latency-bound chain behind the search
+            // (stored prefix -> sequence packer -> N plan -> N coder) then runs alone, with nothing to hide its round trips (round 4's timeline: coder 1.6 ms and
+            // search 2.5 ms together, then 1.9 ms of that chain on an empty device).  The coder waits for the search instead and runs beside the chain
+            // (4.4 -> 4.1 ms for the stage.  The packer beside the coder still takes twice its time alone - the coder's single-wave workgroups take the slots
+            // that free up - and on a stream of the highest priority it is the other way round, 3.1 ms for the coder: the two kernels take turns, in either order).
+            if (aux_chain) { HIPCHK(ctx, hipEventRecord(ctx->ev_ovl, A)); coder_waits = true; }
         }
         hipLaunchKernelGGL(k_chunk_prefix, dim3(n_chunks), dim3(256), 0, A, T, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb);
         {
@@ -630,7 +636,10 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (fast) {
         // the quality / exception streams now; the N streams when the second chain has planned them (its totals come back while the coder runs)
         if (!aux_chain) HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));   // (one stream: the N plan is already in)
+        if (coder_waits) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_ovl, 0));
         { const int rc = launch_coder(S, 0, nqg + 1); if (rc) return rc; }
+        // the coordinate coder (one dependent chain of ~100 steps per (axis, chunk)) needs nothing of either chain: behind the coder on the main stream
+        hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
         if (aux_chain) { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, ctx->aux)); HIPCHK(ctx, ctx->fetch_sync(ctx->aux)); ovl_guard.armed = false; }
         else { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S)); HIPCHK(ctx, ctx->fetch_sync(S)); }
     }
@@ -643,11 +652,11 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (img_cap < hdr_bytes) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small for the header");
         HIPCHK(ctx, hipMemcpyAsync(img, HH.bytes, hdr_bytes, hipMemcpyHostToDevice, S));
     }
-    // the coordinate coder (one dependent chain of ~100 steps per (axis, chunk)) runs beside the quality streams on the aux stream - fast path: behind
-    // the second chain, and so do the N streams (that chain has planned them)
+    // byte-wise path: the coordinate coder runs beside the quality streams on the aux stream; tile path: the N streams behind the second chain (which has
+    // planned them)
     {
         hipStream_t A2 = (fast ? aux_chain : fork_coords) ? ctx->aux : S;
-        hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, A2, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
+        if (!fast) hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, A2, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
         if (fast) { const int rc = launch_coder(A2, nqg + 1, 1); if (rc) return rc; }
         else { const int rc = launch_coder(S, 0, nqg + 2); if (rc) return rc; }
         if (A2 != S) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A2)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }

@@ -2117,6 +2117,64 @@ template <class Sink> __device__ __forceinline__ void pc_gen_tokens(uint64_t m, 
         mm = (run >= 64u - (uint32_t)s) ? 0ull : (mm & ~(((1ull << run) - 1ull) << s));
     }
 }
+// The first 16 token bytes of a word in four registers (a word of a stream that takes up to a quarter of the positions codes to that): bytes are shifted
+// in from the top, finish() moves them down to byte 0.  (PackSink kept 8: on a NovaSeq-binned file one lane in thirty overflowed it, so nearly every wave
+// generated its tokens a second time, straight to memory.)
+__device__ __forceinline__ uint32_t pc_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh); }   // sh < 32
+struct PackSink16 {
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, n = 0;
+    __device__ __forceinline__ void put(uint32_t b) { w0 = pc_alignbit(w1, w0, 8); w1 = pc_alignbit(w2, w1, 8); w2 = pc_alignbit(w3, w2, 8); w3 = (w3 >> 8) | (b << 24); n++; }
+    __device__ __forceinline__ void finish() {                              // (n <= 16)
+        const uint32_t k = 16u - n;
+        if (k & 8u) { w0 = w2; w1 = w3; w2 = 0; w3 = 0; }
+        if (k & 4u) { w0 = w1; w1 = w2; w2 = w3; w3 = 0; }
+        const uint32_t sh = 8u * (k & 3u);
+        if (k >= 16u) { w0 = w1 = w2 = w3 = 0; }
+        else { w0 = pc_alignbit(w1, w0, sh); w1 = pc_alignbit(w2, w1, sh); w2 = pc_alignbit(w3, w2, sh); w3 >>= sh; }
+    }
+};
+struct __attribute__((packed, aligned(1))) GPc8 { uint32_t a, b; };
+struct __attribute__((packed, aligned(1))) GPc4 { uint32_t a; };
+struct __attribute__((packed, aligned(1))) GPc2 { uint16_t a; };
+// n <= 16 finished bytes to p: at most five stores of 8, 8, 4, 2, 1 bytes (a byte loop ran as long as the wave's longest lane)
+__device__ __forceinline__ void pc_store16(uint8_t* p, const PackSink16& k) {
+    uint32_t a0 = k.w0, a1 = k.w1, a2 = k.w2, a3 = k.w3; const uint32_t n = k.n;
+    if (n & 16u) { GPc8 v; v.a = a0; v.b = a1; *(GPc8*)p = v; v.a = a2; v.b = a3; *(GPc8*)(p + 8) = v; return; }
+    if (n & 8u) { GPc8 v; v.a = a0; v.b = a1; *(GPc8*)p = v; p += 8; a0 = a2; a1 = a3; }
+    if (n & 4u) { GPc4 v; v.a = a0; *(GPc4*)p = v; p += 4; a0 = a1; }
+    if (n & 2u) { GPc2 v; v.a = (uint16_t)a0; *(GPc2*)p = v; p += 2; a0 >>= 16; }
+    if (n & 1u) *p = (uint8_t)a0;
+}
+// May pc_gen_fast code this word?  Not when it holds position 0 of the stream or continues a streak that started there (the `cur > 1` rule), or holds a run
+// of 32 or more.
+__device__ __forceinline__ bool pc_word_is_plain(uint64_t m, uint32_t p0, int zero_in) {
+    if (p0 == 0u && (m & 1ull)) return false;
+    uint64_t x = m & (m >> 1); x &= x >> 2; x &= x >> 4; x &= x >> 8; x &= x >> 16;
+    if (x) return false;
+    if ((m & 1ull) && zero_in < 0) return false;                             // (the continuation of a streak that starts at position 0)
+    return true;
+}
+// pc_gen_tokens for such a word: a streak is a gap token and, from two positions on, ONE run token
+template <class Sink> __device__ __forceinline__ void pc_gen_fast(uint64_t m, uint32_t p0, int prev_in, int zero_in, uint32_t after, Sink& sink) {
+    uint64_t mm = m; int prev = prev_in;
+    if ((m & 1ull) && zero_in + 1 != (int)p0) {
+        // the word starts inside a streak (begun at zero_in + 1): it owes the run token that starts in its part, if one does (they start every 32 positions
+        // behind the streak's second position; lead < 32: at most one)
+        const uint32_t lead = (uint32_t)(__ffsll((long long)~m) - 1), b0 = (uint32_t)zero_in + 2u, i = b0 + (((p0 - b0) + 31u) & ~31u);
+        if (i < p0 + lead) sink.put(0xC0u | (p0 + lead - i - 1u));
+        prev = (int)(p0 + lead) - 1; mm = (m >> lead) << lead;
+    }
+    while (mm) {
+        const uint32_t s = (uint32_t)(__ffsll((long long)mm) - 1); const uint64_t t = mm >> s; const uint32_t run = (uint32_t)(__ffsll((long long)~t) - 1);      // (run < 32)
+        const int abs_s = (int)(p0 + s); const int d = abs_s - prev; const uint32_t v = (uint32_t)(d - 1);
+        if (d <= 128) sink.put(v);
+        else if (d <= 16384) { sink.put((v >> 8) | 0x80u); sink.put(v & 0xFFu); }
+        else { sink.put((v >> 24) | 0xE0u); sink.put((v >> 16) & 0xFFu); sink.put((v >> 8) & 0xFFu); sink.put(v & 0xFFu); }
+        if (run >= 2u) { uint32_t rem = run - 1u + (s + run == 64u ? after : 0u); if (rem > 32u) rem = 32u; sink.put(0xC0u | (rem - 1u)); }
+        prev = abs_s + (int)run - 1;
+        mm = s + run >= 64u ? 0ull : (t >> run) << (s + run);
+    }
+}
 // A (chunk, stream) is cut into segments of PC_SEG_STEPS steps (32768 positions) coded by independent waves: a wave's steps are
 // a dependent chain at memory latency, so the kernel's run time is that of its longest chain (256 steps with one wave per stream;
 // 32-step segments measured 1.15 ms, 8-step segments 0.93 ms, 4-step segments 0.96 ms).  What a segment needs to start:
@@ -2152,9 +2210,12 @@ template <int MODE> __device__ __forceinline__ void pc_stream_step(PcStream& s, 
     const uint32_t lead_n = (s.m_next == ~0ull) ? 64u : (uint32_t)(__ffsll((long long)~s.m_next) - 1);
     uint32_t after = __shfl_down(lead, 1u); const uint32_t after63 = __shfl(lead_n, 0);
     if (l == 63) after = after63;
-    uint32_t bytes; uint64_t pk = 0;
+    uint32_t bytes; PackSink16 ps;
     if (MODE == PC_EXCEPT) bytes = 5u * (uint32_t)__popcll(m);
-    else { PackSink ps; pc_gen_tokens(m, p0, prev_in, zero_in, after, ps); bytes = ps.n; pk = ps.pk; }
+    else {
+        if (pc_word_is_plain(m, p0, zero_in)) pc_gen_fast(m, p0, prev_in, zero_in, after, ps); else pc_gen_tokens(m, p0, prev_in, zero_in, after, ps);
+        bytes = ps.n; if (bytes <= 16u) ps.finish();
+    }
     const uint32_t incl = wave_incl_sum(bytes);
     uint32_t o = s.outpos + incl - bytes;
     const uint32_t tot = wave_last(incl);
@@ -2163,9 +2224,8 @@ template <int MODE> __device__ __forceinline__ void pc_stream_step(PcStream& s, 
         if (MODE == PC_EXCEPT) {
             uint64_t mm = m;
             while (mm) { const int b = __ffsll((long long)mm) - 1; mm &= mm - 1; out[o] = B[p0 + (uint32_t)b]; st_u32(out + o + 1, p0 + (uint32_t)b); o += 5; }
-        } else if (bytes <= 8) {
-            for (uint32_t k = 0; k < bytes; k++) out[o + k] = (uint8_t)(pk >> (8 * k));
-        } else { StoreSink ss; ss.p = out + o; pc_gen_tokens(m, p0, prev_in, zero_in, after, ss); }   // dense word: regenerate straight to memory
+        } else if (bytes <= 16u) pc_store16(out + o, ps);
+        else { StoreSink ss; ss.p = out + o; pc_gen_tokens(m, p0, prev_in, zero_in, after, ss); }   // dense word: regenerate straight to memory
     }
     s.outpos += tot;
     // carries: the last lane that has a match / a non-match in this step
