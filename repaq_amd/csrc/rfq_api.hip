@@ -32,10 +32,11 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     else if (n == "RFQ_MATERIALISE") c->opt.materialise = set && num != 0;
     else if (n == "RFQ_TRACE") c->opt.trace = set && v != "0";
     else if (n == "RFQ_G2_PAD") c->opt.g2_pad = set ? (uint32_t)num : 0u;
+    else if (n == "RFQ_SP_PAD") c->opt.sp_pad = set ? (uint32_t)std::min<long long>(150000, std::max<long long>(0, num)) : d.sp_pad;
     else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
     return RFQ_OK;
 }
-static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD" };
+static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD", "RFQ_SP_PAD" };
 
 extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (!out) return RFQ_E_ARG;

@@ -78,6 +78,7 @@ struct RfqOpts {
     bool materialise = false;         // RFQ_MATERIALISE=1  decode: qualities / bases expanded in HBM (the path of a streaming caller's non-final slices) on every call
     bool trace = false;               // RFQ_TRACE          a line on stderr about how chunk starts were found
     uint32_t g2_pad = 0;              // RFQ_G2_PAD         profiling aid: bytes of unused dynamic LDS added to k_gather2 (fewer resident workgroups)
+    uint32_t sp_pad = 0;              // RFQ_SP_PAD         bytes of unused dynamic LDS added to k_seqpack: caps its resident workgroups so that the position coder beside it keeps its share
 };
 struct rfq_ctx {
     RfqOpts opt;

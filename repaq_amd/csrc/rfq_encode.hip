@@ -553,15 +553,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             // search 2.5 ms together, then 1.9 ms of that chain on an empty device).  The coder waits for the search instead and runs beside the chain
             // (4.4 -> 4.1 ms for the stage.  The packer beside the coder still takes twice its time alone - the coder's single-wave workgroups take the slots
             // that free up - and on a stream of the highest priority it is the other way round, 3.1 ms for the coder: the two kernels take turns, in either order).
-            if (aux_chain) { HIPCHK(ctx, hipEventRecord(ctx->ev_ovl, A)); coder_waits = true; }
         }
         hipLaunchKernelGGL(k_chunk_prefix, dim3(n_chunks), dim3(256), 0, A, T, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb);
+        if (aux_chain) { HIPCHK(ctx, hipEventRecord(ctx->ev_ovl, A)); coder_waits = true; }
         {
             const uint32_t max_len = max_rec / 2u;                             // (a record holds its sequence twice over: bases and qualities)
             // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
             uint32_t rshift = 8; while (rshift && ((uint64_t)(max_len / 16u + 1u) << rshift) > SP_OWN) rshift--;
             uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
-            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), 0, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const U4*)C.ptot, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
+            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), aux_chain ? ctx->opt.sp_pad : 0u, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const U4*)C.ptot, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
                                C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift);
         }

@@ -1915,6 +1915,9 @@ __device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb
 // N counts per coder segment, the chunk's N total and N map are left as k_gather leaves them.
 #define SP_OWN 4096u              // tight dwords of one step (the host sizes R by the longest read: R * (max_len / 16 + 1) <= SP_OWN)
 #define SP_EXTRA 8u               // reads behind the step's last whose LDS entries the last dword's tail may need (beyond: global memory)
+#define SP_U 5                    // tight dwords per thread whose loads are in flight together
+struct __attribute__((packed, aligned(4))) SpU8 { uint32_t a, b; };
+struct __attribute__((packed, aligned(2))) SpU4 { uint32_t a; };
 __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const U4* __restrict__ ptot, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
                                                  const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
                                                  uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
@@ -1943,29 +1946,58 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
         const uint32_t kbase = (s_sd[0] + 15u) >> 4, kend = (s_sd[nr] + 15u) >> 4;    // the step's dwords: those whose first base belongs to one of my reads
         if (tid < nr) { const uint32_t ka = (s_sd[tid] + 15u) >> 4, kb = (s_sd[tid + 1] + 15u) >> 4; for (uint32_t k = ka; k < kb; k++) s_own[k - kbase] = (uint8_t)tid; }
         __syncthreads();
-        // ---- phase 2
-        for (uint32_t i = tid; i < kend - kbase; i += blockDim.x) {
-            const uint32_t k = kbase + i, j = s_own[i];
-            const uint32_t B = 16u * k, sdg = s_sd[j], si = B - sdg, need = S - B < 16u ? S - B : 16u, av = s_sd[j + 1] - B, t1 = need < av ? need : av;
-            const uint32_t ld = s_ld[j], b0 = s_sk[j] + si;
-            unsigned long long acc = 0; uint32_t nacc = 0;
-            acc = loose_codes(lpk, ld, b0) & (t1 >= 16u ? 0xFFFFFFFFu : (1u << (2u * t1)) - 1u);
-            nacc = loose_nbits(lnb, ld, b0) & ((1u << t1) - 1u);
-            uint32_t filled = t1, jj = j + 1;
-            while (filled < need) {                                         // the read's last dword: the rest comes from the read(s) behind it
-                uint32_t a, b, l2, s2;
-                if (jj < nx) { a = s_sd[jj]; b = s_sd[jj + 1]; l2 = s_ld[jj]; s2 = s_sk[jj]; }
-                else { const uint32_t gg = r0 + jj; a = pv[gg].d - ps0; b = gg + 1u < e ? pv[gg + 1].d - ps0 : S; l2 = (pq[gg] >> 4) + gg; s2 = skip_of(gg); }   // (more than SP_EXTRA reads of a few bases in a row)
-                const uint32_t avail = b - a;
-                if (avail) {
-                    const uint32_t take = avail < need - filled ? avail : need - filled;
-                    acc |= (unsigned long long)(loose_codes(lpk, l2, s2) & (take >= 16u ? 0xFFFFFFFFu : (1u << (2u * take)) - 1u)) << (2u * filled);
-                    nacc |= (loose_nbits(lnb, l2, s2) & ((1u << take) - 1u)) << filled; filled += take;
+        // ---- phase 2, SP_U dwords per thread at a time: every load a dword needs - sixteen codes and N bits from its owner's slot and from the slot of the
+        // read behind it, which finishes a read's last dword - is requested before the first one is used (a dword at a time, the step was a chain of a dozen
+        // round trips: 1.29 ms for a kernel with 0.47 ms of instructions)
+        const uint32_t ndw = kend - kbase;
+        for (uint32_t i0 = 0; i0 < ndw; i0 += blockDim.x * SP_U) {
+            struct Dw { uint32_t k, need, t1, jj, sh, sh2, take2, n, n2; unsigned long long c, c2; } q[SP_U];
+#pragma unroll
+            for (int u = 0; u < SP_U; u++) {
+                Dw& x = q[u]; x.need = 0; x.take2 = 0; x.k = x.t1 = x.jj = x.sh = x.sh2 = x.n = x.n2 = 0; x.c = x.c2 = 0;
+                const uint32_t i = i0 + (uint32_t)u * blockDim.x + tid;
+                if (i < ndw) {
+                    const uint32_t k = kbase + i, j = s_own[i];
+                    const uint32_t B = 16u * k, si = B - s_sd[j], need = S - B < 16u ? S - B : 16u, av = s_sd[j + 1] - B, t1 = need < av ? need : av;
+                    const uint32_t b0 = s_sk[j] + si, d = s_ld[j] + (b0 >> 4);
+                    x.k = k; x.need = need; x.t1 = t1; x.sh = b0 & 15u; x.jj = j + 1u;
+                    { const SpU8 v = *(const SpU8*)(lpk + d); x.c = (((unsigned long long)v.b) << 32) | v.a; x.n = ((const SpU4*)(lnb + d))->a; }
+                    if (t1 < need && j + 1u < nx) {                          // the read behind: its LDS entries are there
+                        const uint32_t avail = s_sd[j + 2] - s_sd[j + 1]; x.jj = j + 2u;
+                        if (avail) {
+                            const uint32_t s2 = s_sk[j + 1], d2 = s_ld[j + 1] + (s2 >> 4); x.sh2 = s2 & 15u; x.take2 = avail < need - t1 ? avail : need - t1;
+                            const SpU8 v = *(const SpU8*)(lpk + d2); x.c2 = (((unsigned long long)v.b) << 32) | v.a; x.n2 = ((const SpU4*)(lnb + d2))->a;
+                        }
+                    }
                 }
-                jj++;
             }
-            ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc;
-            if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
+#pragma unroll
+            for (int u = 0; u < SP_U; u++) {
+                const Dw& x = q[u];
+                if (!x.need) continue;
+                const uint32_t k = x.k, B = 16u * k, need = x.need;
+                unsigned long long acc = (uint32_t)(x.c >> (2u * x.sh)) & (x.t1 >= 16u ? 0xFFFFFFFFu : (1u << (2u * x.t1)) - 1u);
+                uint32_t nacc = ((x.n >> x.sh) & 0xFFFFu) & ((1u << x.t1) - 1u);
+                uint32_t filled = x.t1, jj = x.jj;
+                if (x.take2) {
+                    acc |= (unsigned long long)((uint32_t)(x.c2 >> (2u * x.sh2)) & (x.take2 >= 16u ? 0xFFFFFFFFu : (1u << (2u * x.take2)) - 1u)) << (2u * filled);
+                    nacc |= (((x.n2 >> x.sh2) & 0xFFFFu) & ((1u << x.take2) - 1u)) << filled; filled += x.take2;
+                }
+                while (filled < need) {                                         // (rare) reads of a few bases in a row, or reads beyond the step's LDS entries
+                    uint32_t a, b, l2, s2;
+                    if (jj < nx) { a = s_sd[jj]; b = s_sd[jj + 1]; l2 = s_ld[jj]; s2 = s_sk[jj]; }
+                    else { const uint32_t gg = r0 + jj; a = pv[gg].d - ps0; b = gg + 1u < e ? pv[gg + 1].d - ps0 : S; l2 = (pq[gg] >> 4) + gg; s2 = skip_of(gg); }
+                    const uint32_t avail = b - a;
+                    if (avail) {
+                        const uint32_t take = avail < need - filled ? avail : need - filled;
+                        acc |= (unsigned long long)(loose_codes(lpk, l2, s2) & (take >= 16u ? 0xFFFFFFFFu : (1u << (2u * take)) - 1u)) << (2u * filled);
+                        nacc |= (loose_nbits(lnb, l2, s2) & ((1u << take) - 1u)) << filled; filled += take;
+                    }
+                    jj++;
+                }
+                ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc;
+                if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
+            }
         }
         __syncthreads();                                                    // (the LDS tables are rewritten by the next step)
     }
