@@ -1840,10 +1840,10 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
     auto tile_at = [&](uint32_t t_) -> uint32_t { const uint32_t x = gs + (t_ << kshift); return x < ge ? x : ge; };
     G2Bound b0 = g2_bound(T, two, pq, tile_at(0)), b1 = g2_bound(T, two, pq, tile_at(1)), b2 = g2_bound(T, two, pq, tile_at(2));
     G2MRaw mr = g2_mraw(T, pq, gs, j, ntile ? tile_at(1) - gs : 0u);
+    if (ntile) g2_stage(T, two, g2_geo(b0, b1, two), buf4, tid);
     for (uint32_t t = 0; t < ntile; t++, tix++) {                          // block-uniform
         const uint32_t cur = tile_at(t), cnt = tile_at(t + 1u) - cur;
-        const G2Geo g = g2_geo(b0, b1, two);
-        g2_stage(T, two, g, buf4, tid);
+        const G2Geo g = g2_geo(b0, b1, two);                                // (its text was requested before the previous tile's flush)
         const G2Read m = g2_read(T, mr, g, f, pq0, il, cur, j, cnt);
         const uint32_t qbeg = b0.q - pq0, qend = b1.q - pq0;               // the tile's quality positions (chunk-relative)
         { const uint32_t ncur = tile_at(t + 1u); mr = g2_mraw(T, pq, ncur, j, tile_at(t + 2u) - ncur); }
@@ -1857,6 +1857,7 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
             g2_bases(tx, m, part, P, lpk, lnb, rflag);
         } else g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
         __syncthreads();                                                    // the text is free for the next tile; the tile's counts / planes are complete
+        if (t + 1u < ntile) g2_stage(T, two, g2_geo(b1, b2, two), buf4, tid);  // the next tile's text is on its way while the planes / counters of this one leave
         if (MASKS) {
             const uint32_t gw0 = qbeg >> 5, nw = ((qend + 31u) >> 5) - gw0; const bool last_tile = cur + cnt >= ge;
             g2_flush_masks(pl, M.pw, nd, dense3, s_carry, gpl, M.pstride, gw0, nw, !last_tile && (qend & 31u) != 0u, cur == gs && gs > f && (qbeg & 31u) != 0u, last_tile && ge < e && (qend & 31u) != 0u,
