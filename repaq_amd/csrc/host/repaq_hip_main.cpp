@@ -571,114 +571,153 @@ static void do_compress(const Options& o) {
     for (int s = 0; s < ns; s++) { ds[s].free_all(g); delete in[s]; }
 }
 
-// Chunk-parallel compress of one input over several GPUs (a host work queue, no collective).  The main thread streams
-// the text to the first device and PLANS every batch there (rfq_scan_batch: where each chunk ends); the batch's chunks are dealt out
-// in contiguous ranges to one worker thread per device, which pulls its byte range device-to-device, encodes it with flush_all and
-// hands the image to an ordered writer.  Only the <= 272-byte header (made by the very first range) crosses between workers.
-struct WorkItem { uint64_t seq; const uint8_t* d1; size_t n1; const uint8_t* d2; size_t n2; uint64_t off1, off2, th1, th2; bool final; };
+// Chunk-parallel compress of one input over several GPUs (a host work queue, no collective), PER-DEVICE INGESTION (the first
+// version sent all text over the first device's link and planned it there).  The input is dealt out batch by batch, round robin: batch k of every stream
+// is uploaded straight to device k mod D, over that device's own link, and never visits another one.  Chunks are cut greedily from the start of the file
+// (Repaq::compress, src/repaq.cpp:546-553), so a batch ends inside a chunk: its worker plans its own text (rfq_scan_batch: where every chunk ends), encodes
+// the whole chunks and PUBLISHES the rest - the carry, a chunk's worth of text at most - which the worker of batch k + 1 pulls in front of its own bytes
+// (rfq_copy_peer: the only text that crosses between devices).  The plan is a chain of scans (~1 ms per GB each) with the encodes running beside it; only
+// the <= 272-byte header (made by the first batch that holds a whole chunk) and the carries cross between workers.
+struct MBatch {
+    uint64_t seq = 0; int w = 0;
+    void* buf[2] = { nullptr, nullptr }; size_t cap[2] = { 0, 0 }, room = 0, n[2] = { 0, 0 };   // device buffers: [room for the carry][the batch's own bytes]
+    uint64_t file_off[2] = { 0, 0 }, th[2] = { UINT64_MAX, UINT64_MAX }; bool last = false;
+    // what this batch leaves to the next one (set by its worker, before it encodes)
+    bool carry_ready = false, carry_taken = false, ended = false, hdr_promised = false;
+    rfq_ctx* owner = nullptr; const uint8_t* carry_ptr[2] = { nullptr, nullptr }; size_t carry_n[2] = { 0, 0 }; uint64_t carry_off[2] = { 0, 0 };
+};
 static void do_compress_multi(const Options& o) {
-    const bool two = !o.in2.empty();
+    const bool two = !o.in2.empty(); const int ns = two ? 2 : 1, D = (int)o.devices.size();
     const int paired = two ? RFQ_PE_TWO_FILES : (o.interleaved ? RFQ_PE_INTERLEAVED : RFQ_SE);
     const uint32_t chunk_bases = (uint32_t)(std::max(100L, o.chunkKb) * 1000);
-    Gpu gs(o.devices[0]);                                                    // scanner context
     const size_t block = o.block(), batch = std::max(o.batchBytes, block);
-    Prefetcher* in[2] = { new Prefetcher(gs, o.in1, block, o.ioThreads), two ? new Prefetcher(gs, o.in2, block, o.ioThreads) : nullptr };
-    const int ns = two ? 2 : 1; DevStream ds[2];
-    // shared state
+    const size_t room = std::max<size_t>((size_t)4 << 20, 4 * (size_t)chunk_bases);          // (a chunk of b bases is ~2.4 b bytes of text per stream)
+    Prefetcher* in[2] = { new Prefetcher((Gpu*)nullptr, o.in1, block, o.ioThreads), two ? new Prefetcher((Gpu*)nullptr, o.in2, block, o.ioThreads) : nullptr };
+    std::vector<std::unique_ptr<Gpu>> gin((size_t)D);                          // ingestion contexts, one per device (the workers' own contexts are busy encoding)
+    gin[0].reset(new Gpu(o.devices[0]));
+    for (int s = 0; s < ns; s++) in[s]->attach(*gin[0]);                       // (the staging blocks are page-locked once; every device copies out of them)
     std::mutex mu; std::condition_variable cv;
-    std::deque<WorkItem> queue; bool no_more = false; uint64_t copied = 0;   // items whose input the workers have pulled off the scanner's buffers
+    std::map<uint64_t, std::shared_ptr<MBatch>> batches; uint64_t n_batches = 0; bool all_ingested = false;
     std::vector<uint8_t> header; bool header_ready = false;
-    std::map<uint64_t, std::vector<uint8_t>> done; uint64_t next_write = 0, total_items = 0; bool all_queued = false;
+    std::map<uint64_t, std::vector<uint8_t>> done; uint64_t next_write = 0;
     ByteSink sink; sink.open(o.out1, o);
     std::thread writer([&] {
         for (;;) {
             std::vector<uint8_t> buf;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.count(next_write) || (all_queued && next_write == total_items); });
-              if (all_queued && next_write == total_items) return;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.count(next_write) || (all_ingested && next_write == n_batches); });
+              if (!done.count(next_write)) return;
               buf = std::move(done[next_write]); done.erase(next_write); next_write++; cv.notify_all(); }
             if (!buf.empty()) sink.write(buf.data(), buf.size());
         }
     });
     std::vector<std::thread> workers;
-    for (size_t w = 0; w < o.devices.size(); w++) workers.emplace_back([&, w] {
-        Gpu g(o.devices[w]); void* b1 = nullptr; void* b2 = nullptr; size_t c1 = 0, c2 = 0; bool have_hdr = false;
-        std::unique_ptr<Verifier> ver; if (o.completeCheck || o.fastCheck) ver.reset(new Verifier(o, o.devices[w]));
-        for (;;) {
-            WorkItem it;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = queue.front(); queue.pop_front(); }
-            if (c1 < it.n1 + 64) { if (b1) rfq_dev_free(g.c, b1); c1 = it.n1 + it.n1 / 4 + 64; b1 = g.dev(c1); }
-            if (two && c2 < it.n2 + 64) { if (b2) rfq_dev_free(g.c, b2); c2 = it.n2 + it.n2 / 4 + 64; b2 = g.dev(c2); }
-            g.check(rfq_copy_peer(g.c, b1, gs.c, it.d1, it.n1)); if (two) g.check(rfq_copy_peer(g.c, b2, gs.c, it.d2, it.n2));   // the scanner's GPU -> mine
-            { std::unique_lock<std::mutex> lk(mu); copied++; cv.notify_all();
-              if (it.seq != 0 && !have_hdr) { cv.wait(lk, [&] { return header_ready; }); } }
-            if (it.seq != 0 && !have_hdr) { g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
+    for (int w = 0; w < D; w++) workers.emplace_back([&, w] {
+        Gpu g(o.devices[(size_t)w]); bool have_hdr = false;
+        std::unique_ptr<Verifier> ver; if (o.completeCheck || o.fastCheck) ver.reset(new Verifier(o, o.devices[(size_t)w]));
+        for (uint64_t k = (uint64_t)w; ; k += (uint64_t)D) {
+            std::shared_ptr<MBatch> b, prev;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return batches.count(k) || (all_ingested && k >= n_batches); });
+              if (!batches.count(k)) break;
+              b = batches[k];
+              if (k) { cv.wait(lk, [&] { return batches.count(k - 1) && batches[k - 1]->carry_ready; }); prev = batches[k - 1]; } }
+            auto publish = [&](bool ended, bool hdr, const uint8_t* p1, size_t n1, uint64_t o1, const uint8_t* p2, size_t n2, uint64_t o2) {
+                std::unique_lock<std::mutex> lk(mu);
+                b->ended = ended; b->hdr_promised = hdr; b->owner = g.c; b->carry_ptr[0] = p1; b->carry_n[0] = n1; b->carry_off[0] = o1; b->carry_ptr[1] = p2; b->carry_n[1] = n2; b->carry_off[1] = o2;
+                b->carry_ready = true; cv.notify_all();
+            };
+            auto finish = [&](std::vector<uint8_t>&& img) {                   // the image to the writer (in order), then the buffers go once the next batch has taken its carry
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return done.size() < 4 * (size_t)D || b->seq == next_write; });
+                done[b->seq] = std::move(img); cv.notify_all();
+                if (!b->last) cv.wait(lk, [&] { return b->carry_taken; });
+                lk.unlock();
+                for (int s = 0; s < ns; s++) if (b->buf[s]) rfq_dev_free(g.c, b->buf[s]);
+                lk.lock(); batches.erase(b->seq >= 2 ? b->seq - 2 : UINT64_MAX); cv.notify_all();
+            };
+            if (prev && prev->ended) {                                         // the reader stopped at an empty line in an earlier batch: nothing of this one is read
+                { std::unique_lock<std::mutex> lk(mu); prev->carry_taken = true; cv.notify_all(); }
+                publish(true, prev->hdr_promised, nullptr, 0, 0, nullptr, 0, 0);
+                finish(std::vector<uint8_t>());
+                continue;
+            }
+            // the carry of the batch in front, pulled in front of my own bytes
+            size_t cn[2] = { prev ? prev->carry_n[0] : 0, (prev && two) ? prev->carry_n[1] : 0 };
+            const uint8_t* tx[2] = { nullptr, nullptr }; size_t tn[2] = { 0, 0 }; uint64_t toff[2] = { 0, 0 };
+            for (int s = 0; s < ns; s++) {
+                size_t lead = b->room;                                         // my own bytes start `lead` bytes into the buffer
+                if (cn[s] > lead) {                                            // (a carry larger than the room left for it - a chunk of > 4 x chunk_bases bytes, or several batches without a whole chunk: a larger buffer)
+                    const size_t nc = cn[s] + b->n[s] + 64; void* nb = g.dev(nc); trace_mark("compress: carry larger than its room, buffer grown");
+                    if (b->n[s]) g.check(rfq_copy_d2d(g.c, (uint8_t*)nb + cn[s], (uint8_t*)b->buf[s] + lead, b->n[s]));
+                    g.check(rfq_dev_free(g.c, b->buf[s])); b->buf[s] = nb; b->cap[s] = nc; lead = cn[s];
+                }
+                if (cn[s]) g.check(rfq_copy_peer(g.c, (uint8_t*)b->buf[s] + lead - cn[s], prev->owner, prev->carry_ptr[s], cn[s]));
+                tx[s] = (const uint8_t*)b->buf[s] + lead - cn[s]; tn[s] = cn[s] + b->n[s]; toff[s] = prev ? prev->carry_off[s] : 0;
+            }
+            if (prev) { std::unique_lock<std::mutex> lk(mu); prev->carry_taken = true; cv.notify_all(); }
+            const bool hdr_before = prev && prev->hdr_promised;
             rfq_encode_args a; memset(&a, 0, sizeof a);
-            a.d_fq1 = (const uint8_t*)b1; a.n1 = it.n1; a.d_fq2 = two ? (const uint8_t*)b2 : nullptr; a.n2 = two ? it.n2 : 0; a.paired = paired; a.chunk_bases = chunk_bases;
-            a.final = it.final ? 1 : 0; a.flush_all = it.final ? 0 : 1; a.emit_header = it.seq == 0 ? 1 : 0;
-            a.file_off1 = it.off1; a.file_off2 = it.off2; a.nolb_from1 = it.th1; a.nolb_from2 = it.th2;
-            rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
-            if (ver && r.n_chunks && ver->wanted()) ver->check(g, r, it.seq == 0, it.final, two, (const uint8_t*)b1, it.n1, (const uint8_t*)b2, two ? it.n2 : 0, it.off1, it.off2);
-            std::vector<uint8_t> img(r.rfq_len); if (r.rfq_len) g.check(rfq_copy_d2h(g.c, img.data(), r.d_rfq, r.rfq_len));
-            if (it.seq == 0) {                                               // the header every other range is coded under
-                uint8_t hb[RFQ_HEADER_MAX]; size_t hn = 0; have_hdr = true;
-                if (r.n_chunks) g.check(rfq_get_header(g.c, hb, &hn));
-                std::unique_lock<std::mutex> lk(mu); header.assign(hb, hb + hn); header_ready = true; cv.notify_all();
+            a.d_fq1 = tx[0]; a.n1 = tn[0]; a.d_fq2 = two ? tx[1] : nullptr; a.n2 = two ? tn[1] : 0; a.paired = paired; a.chunk_bases = chunk_bases;
+            a.file_off1 = toff[0]; a.file_off2 = toff[1]; a.nolb_from1 = b->th[0]; a.nolb_from2 = two ? b->th[1] : b->th[0];
+            size_t en[2] = { tn[0], tn[1] }; bool encode_final = b->last, nothing = false, ended = false;
+            if (!b->last) {                                                    // plan: where my last whole chunk ends; the rest is the next batch's
+                rfq_scan_result sr; a.final = 0; g.check(rfq_scan_batch(g.c, &a, &sr));
+                if (sr.input_ended) ended = true;                              // (an empty line ends the input inside my text: all of it goes through the encode, which stops there)
+                else if (sr.n_chunks == 0) nothing = true;
+                else { en[0] = (size_t)sr.h_end1[sr.n_chunks - 1]; en[1] = two ? (size_t)sr.h_end2[sr.n_chunks - 1] : 0; }
+                if (ended) publish(true, true, nullptr, 0, 0, nullptr, 0, 0);
+                else if (nothing) publish(false, hdr_before, tx[0], tn[0], toff[0], tx[1], tn[1], toff[1]);
+                else publish(false, true, tx[0] + en[0], tn[0] - en[0], toff[0] + en[0], two ? tx[1] + en[1] : nullptr, two ? tn[1] - en[1] : 0, toff[1] + en[1]);
             }
-            std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done.size() < 4 * o.devices.size() || it.seq == next_write; });
-            done[it.seq] = std::move(img); cv.notify_all();
+            std::vector<uint8_t> img;
+            if (!nothing) {
+                if (hdr_before && !have_hdr) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return header_ready; }); lk.unlock(); g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
+                a.n1 = en[0]; a.n2 = two ? en[1] : 0; a.final = encode_final ? 1 : 0; a.flush_all = encode_final ? 0 : 1; a.emit_header = hdr_before ? 0 : 1;
+                rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
+                if (ver && r.n_chunks && ver->wanted()) ver->check(g, r, !hdr_before, encode_final || ended, two, tx[0], en[0], tx[1], two ? en[1] : 0, toff[0], toff[1]);
+                img.resize(r.rfq_len); if (r.rfq_len) g.check(rfq_copy_d2h(g.c, img.data(), r.d_rfq, r.rfq_len));
+                if (!hdr_before) {                                             // the header every later batch is coded under
+                    uint8_t hb[RFQ_HEADER_MAX]; size_t hn = 0; have_hdr = true;
+                    if (r.n_chunks) g.check(rfq_get_header(g.c, hb, &hn));
+                    std::unique_lock<std::mutex> lk(mu); header.assign(hb, hb + hn); header_ready = true; cv.notify_all();
+                }
+            }
+            finish(std::move(img));
         }
-        if (b1) rfq_dev_free(g.c, b1); if (b2) rfq_dev_free(g.c, b2);
     });
-    uint64_t seq = 0; size_t want = batch;
-    for (;;) {
-        for (int s = 0; s < ns; s++) {
-            while (!ds[s].ended && ds[s].have < want) {
-                Block b; if (!in[s]->next(b)) { ds[s].ended = true; break; }
-                ds[s].append(gs, b, batch + block); in[s]->release(b);
-                if (in[s]->drained()) ds[s].ended = true;
+    // ingestion: batch k of every stream to device k mod D
+    for (uint64_t k = 0; ; k++) {
+        const int w = (int)(k % (uint64_t)D);
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return k < next_write + 2 * (uint64_t)D + 1; }); }   // (at most two batches per device wait for their encode)
+        if (!gin[(size_t)w]) gin[(size_t)w].reset(new Gpu(o.devices[(size_t)w]));
+        Gpu& g = *gin[(size_t)w];
+        auto b = std::make_shared<MBatch>(); b->seq = k; b->w = w; b->room = room;
+        bool ended[2] = { false, !two };
+        for (int s = 0; s < ns; s++) { b->cap[s] = room + batch + block + 64; b->buf[s] = g.dev(b->cap[s]); b->file_off[s] = 0; }
+        std::deque<std::pair<Block, int>> flight; size_t held[2] = { 0, 0 };  // staging blocks whose copies are queued (a reader must never run out of blocks: flight_limit)
+        auto land = [&] { g.check(rfq_copy_sync(g.c)); for (auto& f : flight) in[f.second]->release(f.first); flight.clear(); held[0] = held[1] = 0; };
+        for (bool more = true; more; ) {
+            more = false;
+            for (int s = 0; s < ns; s++) {
+                if (ended[s] || b->n[s] >= batch) continue;
+                if (in[s]->drained()) { ended[s] = true; continue; }
+                Block blk; if (!in[s]->next(blk)) { ended[s] = true; continue; }
+                uint64_t t = 0; g.check(rfq_copy_h2d_async(g.c, (uint8_t*)b->buf[s] + room + b->n[s], blk.p, blk.n, &t)); b->n[s] += blk.n; flight.emplace_back(blk, s);
+                if (++held[s] >= in[s]->flight_limit()) land();
+                if (in[s]->drained()) ended[s] = true;
+                more = true;
             }
         }
-        const bool final = ds[0].ended && (!two || ds[1].ended);
-        rfq_encode_args a; memset(&a, 0, sizeof a);
-        a.d_fq1 = ds[0].base(); a.n1 = ds[0].have; a.d_fq2 = two ? ds[1].base() : nullptr; a.n2 = two ? ds[1].have : 0; a.paired = paired;
-        a.chunk_bases = chunk_bases; a.final = final ? 1 : 0; a.file_off1 = ds[0].file_off; a.file_off2 = ds[1].file_off;
-        rfq_scan_result sr; gs.check(rfq_scan_batch(gs.c, &a, &sr));
-        uint64_t th[2] = { UINT64_MAX, UINT64_MAX };
-        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t) th[s] = nolb_threshold(t, in[s]->final_byte()); }
-        const bool last_batch = final || sr.input_ended;
-        if (sr.n_chunks == 0 && !last_batch) { want = std::max(ds[0].have, ds[1].have) + batch; continue; }
-        // deal the chunks out in contiguous ranges, one per device (fewer when the batch holds fewer chunks)
-        const uint32_t parts = sr.n_chunks ? (uint32_t)std::min<size_t>(o.devices.size(), sr.n_chunks) : 1u;
-        uint64_t first_seq = seq;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            for (uint32_t p = 0; p < parts; p++) {
-                const uint32_t c0 = (uint32_t)((uint64_t)sr.n_chunks * p / parts), c1 = (uint32_t)((uint64_t)sr.n_chunks * (p + 1) / parts);
-                const bool tail = p + 1 == parts;
-                const uint64_t s1 = c0 ? sr.h_end1[c0 - 1] : 0, s2 = (two && c0) ? sr.h_end2[c0 - 1] : 0;
-                // the last range of the last batch runs to the end of the data: the worker sees every byte the one-shot encode would - also when the
-                // reader stops at an empty line inside it (cut at the last chunk's end, the worker never met that line and the tail chunk's
-                // line-break rule - how far the readers' last, failed attempt got - was not applied)
-                const bool to_end = tail && last_batch;
-                const uint64_t e1 = to_end ? ds[0].have : (c1 ? sr.h_end1[c1 - 1] : 0);
-                const uint64_t e2 = two ? (to_end ? ds[1].have : (c1 ? sr.h_end2[c1 - 1] : 0)) : 0;
-                WorkItem it; it.seq = seq++; it.d1 = ds[0].base() + s1; it.n1 = (size_t)(e1 - s1); it.d2 = two ? ds[1].base() + s2 : nullptr; it.n2 = (size_t)(e2 - s2);
-                it.off1 = ds[0].file_off + s1; it.off2 = ds[1].file_off + s2; it.th1 = th[0]; it.th2 = two ? th[1] : th[0];
-                it.final = to_end && final;                                 // (a range that ends at an empty line before the data does flushes by flush_all; its encode reports input_ended itself)
-                queue.push_back(it);
-            }
-            cv.notify_all();
-            cv.wait(lk, [&] { return copied == seq; });                      // the ranges are off the scanner's buffers: they may be recycled
-        }
-        (void)first_seq;
-        if (last_batch) break;
-        ds[0].advance(gs, sr.consumed1, batch + block); if (two) ds[1].advance(gs, sr.consumed2, batch + block);
-        want = batch;
+        land();
+        b->last = ended[0] && ended[1];
+        for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t) b->th[s] = nolb_threshold(t, in[s]->final_byte()); }
+        trace_mark("compress: batch resident");
+        { std::unique_lock<std::mutex> lk(mu); batches[k] = b; n_batches = k + 1; if (b->last) all_ingested = true; cv.notify_all(); }
+        if (b->last) break;
     }
-    { std::unique_lock<std::mutex> lk(mu); no_more = true; total_items = seq; all_queued = true; cv.notify_all(); }
     for (auto& t : workers) t.join();
+    { std::unique_lock<std::mutex> lk(mu); cv.notify_all(); }
     writer.join(); sink.close();
-    for (int s = 0; s < ns; s++) { ds[s].free_all(gs); delete in[s]; }
+    for (int s = 0; s < ns; s++) delete in[s];
 }
 
 // RfqChunk::read's chain (src/rfqchunk.cpp:161-228) on the host, as the blocks of the image go by on their way to the GPU: the format has no chunk

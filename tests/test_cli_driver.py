@@ -113,8 +113,8 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
         r = _run(binary, ["-c", flag, "-i", str(src), "-o", str(ov), "-k", "100", "--batch_mb", str(batch_mb)] + extra)
         assert r.returncode == 0 and r.stderr == b"", r.stderr
         assert ov.read_bytes() == ref
-    # --devices a,b,c: one input planned on the first device (rfq_scan_batch), its chunk ranges encoded on one context per listed device
-    # (flush_all) and written in order — the image must be the one-shot image whatever the split
+    # --devices a,b,c: the input's batches dealt round robin to one context per listed device (each uploads its own batches), every worker plans its own
+    # text (rfq_scan_batch), encodes its whole chunks (flush_all) and hands the rest to the next; written in order — the image must be the one-shot image whatever the split
     om = tmp_path / "multi.rfq"
     for src, ref in ((p, og.read_bytes()), (pc, O.encode_file(crlf, b"", O.SE, 100_000)), (ps, want), (p, og.read_bytes())):
         r = _run(binary, ["-c", "-i", str(src), "-o", str(om), "-k", "100", "--batch_mb", str(batch_mb), "--devices", "0,0,0"])
@@ -170,6 +170,17 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
         r = _run(binary, ["-c", "-i", str(pt), "-o", str(om), "-k", "100", "--batch_mb", str(batch_mb)] + extra)
         assert r.returncode == 0, r.stderr
         assert om.read_bytes() == want_t, extra
+    # --devices with batches smaller than a chunk and a carry larger than the room a batch leaves for it: names of ~210 bytes on reads of 3 bases make a
+    # chunk of 100 k bases ~7.4 MB of text - several batches without a whole chunk hand their text on, the buffer of the one that meets the chunk's end grows
+    import random
+    rnd = random.Random(77)
+    longn = b"".join(b"@" + (b"N%05d_" % i) + b"x" * 200 + b"\n" + bytes(rnd.choice(b"ACGT") for _ in range(3)) + b"\n+\n" + b"F:," + b"\n" for i in range(80000))
+    pl = tmp_path / "longnames.fq"; pl.write_bytes(longn)
+    want_l = O.encode_file(longn, b"", O.SE, 100_000)
+    for extra in (["--devices", "0,0,0"], ["--devices", "0,0"]):
+        r = _run(binary, ["-c", "-i", str(pl), "-o", str(om), "-k", "100", "--batch_mb", "1"] + extra)
+        assert r.returncode == 0, r.stderr
+        assert om.read_bytes() == want_l, extra
     # an empty input leaves an empty .rfq, which decodes to an empty FASTQ (RfqHeader defaults, src/rfqheader.cpp:7-17)
     pz = tmp_path / "empty.fq"; pz.write_bytes(b""); oz = tmp_path / "empty.rfq"; bz = tmp_path / "empty_back.fq"
     assert _run(binary, ["-c", "-i", str(pz), "-o", str(oz)]).returncode == 0 and oz.read_bytes() == b""
