@@ -946,17 +946,20 @@ __device__ __forceinline__ DName dec_name_parts(const uint8_t* cp, const DChunk&
 }
 // text bytes of every read; tin[g] = (bytes into out1, bytes into out2, 0, 0)
 __device__ __forceinline__ uint32_t dec_textlen_one(const uint8_t* __restrict__ img, const DChunk& d, const DevHeader* __restrict__ D, const DReadTab& R,
-                                                    const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, int split, uint32_t r, bool& second) {
+                                                    const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, int split, uint32_t r, bool& second, uint8_t* buf /* 40 bytes of LDS, 8-aligned: mine */) {
     const uint8_t* cp = img + d.off; const uint32_t g = d.rbase + r, hf = D->flags;
     const DName m = dec_name_parts(cp, d, D, xv, yv, r);
-    uint8_t buf[36]; uint32_t k = 0;                                 // ":255:65535:4294967295:4294967295" is 32 bytes
+    // the digits go to an LDS row and leave as five 8-byte stores (a local array indexed by a running count lives in scratch: 48 bytes of it, and the
+    // row went out byte by byte - VERDICT r3)
+    uint32_t k = 0;                                                  // ":255:65535:4294967295:4294967295" is 32 bytes
+    { unsigned long long* z = (unsigned long long*)buf; z[0] = z[1] = z[2] = z[3] = z[4] = 0ull; }
     if (hf & H_LANE) { buf[k++] = ':'; k += dec_put(buf + k, m.lane); }
     if (hf & H_TILE) { buf[k++] = ':'; k += dec_put(buf + k, m.tile); }
     if (hf & H_X) { buf[k++] = ':'; k += dec_put(buf + k, m.x); }
     if (hf & H_Y) { buf[k++] = ':'; k += dec_put(buf + k, m.y); }
-    uint8_t* mp = R.mid + (size_t)g * 40;
-    for (uint32_t i = 0; i < k; i++) mp[i] = buf[i];
-    mp[39] = (uint8_t)k;
+    buf[39] = (uint8_t)k;
+    { const unsigned long long* z = (const unsigned long long*)buf; unsigned long long* mp = (unsigned long long*)(R.mid + (size_t)g * 40);
+      const unsigned long long a0 = z[0], a1 = z[1], a2 = z[2], a3 = z[3], a4 = z[4]; mp[0] = a0; mp[1] = a1; mp[2] = a2; mp[3] = a3; mp[4] = a4; }
     const uint32_t nl = m.n1 + m.n2 + k;
     const uint32_t len = R.len[g]; const uint32_t text = nl + 1 + len + 1 + m.st + 1 + len + 1;
     second = split && (r & 1u);
@@ -969,7 +972,8 @@ __global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __r
     const DChunk d = CH[blockIdx.y]; const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= d.reads) return;                  // block-uniform
     uint32_t text = 0; bool second = false;
-    if (r < d.reads) text = dec_textlen_one(img, d, D, R, xv, yv, split, r, second);
+    __shared__ unsigned long long s_mid[256 * 5];                     // a 40-byte row per thread (blockDim.x <= 256)
+    if (r < d.reads) text = dec_textlen_one(img, d, D, R, xv, yv, split, r, second, (uint8_t*)(s_mid + 5u * threadIdx.x));
     // 64-bit totals: the per-read prefix sums that place the text are 32-bit, the host refuses a batch that would wrap them
     // (one atomic per block, spread over 64 slots: same-address atomics from every wave would serialise at ~11 ns each)
     __shared__ unsigned long long s_t[2][4];
