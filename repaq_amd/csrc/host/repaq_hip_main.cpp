@@ -9,7 +9,8 @@
 // so that the end of the input is known in time.
 // The main thread moves blocks into a device-resident batch (256 MB by default: the codec's fixed cost per call is paid per batch, not
 // per staging block), runs the codec and copies results out piece by piece into page-locked buffers; writers drain them - a regular
-// file by several threads with pwrite at each piece's offset, stdout / .gz (src/writer.cpp:39-51; written as blocked gzip, deflated on many threads) / .rfq.xz (an `xz -z -c`
+// file by several threads with pwrite at each piece's offset, stdout / .gz (src/writer.cpp:39-51; written as blocked gzip, deflated on many threads) / .rfq.xz (an `xz -z
+// -c`
 // pipe like src/main.cpp:134-159) by one thread in order.  Inputs and outputs of any size stream through: nothing is slurped.
 #include "rfq_hip.h"
 #include <zlib.h>
@@ -51,15 +52,19 @@ struct Options {
     int device = 0; int threads = 1, compression = 3;
     size_t batchBytes = (size_t)256 << 20;  // device-resident text per codec call (per stream)
     size_t blockBytes = (size_t)16 << 20;   // page-locked staging block (never larger than a batch)
-    int ioThreads = 16;                     // readers per regular input file (pread; tmpfs -> page-locked blocks -> HBM: 21.6 GB/s with 8, 29.2 with 16, tools/micro/mmap_h2d.cpp)
+    // readers per regular input file (pread; tmpfs -> page-locked blocks -> HBM: 21.6 GB/s with 8, 29.2 with 16, tools/micro/mmap_h2d.cpp)
+    int ioThreads = 16;
     int writeThreads = 1;                   // writers per regular output file (pwrite); tmpfs does not scale with more, parallel file systems do
     bool trace = false;                     // --trace: wall-clock marks of the pipeline on stderr
-    bool bugCompat = false;                 // --bug_compat (-d with two outputs): lose what Repaq::decompressPE loses behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:376-403); Repaq::decompress loses nothing; default: keep every read
+    // --bug_compat (-d with two outputs): lose what Repaq::decompressPE loses behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:376-403); Repaq::decompress loses
+    // nothing; default: keep every read
+    bool bugCompat = false;
     size_t block() const { return std::max<size_t>(std::min(blockBytes, batchBytes), (size_t)1 << 20); }   // >= the reader's 1 MiB block (line-break thresholds)
 };
 static const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
 static bool g_trace = false;
-static void trace_mark(const char* what) { if (g_trace) fprintf(stderr, "[trace] %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count(), what); }
+static void trace_mark(const char* what) { if (g_trace) fprintf(stderr, "[trace] %8.1f ms  %s\n", std::chrono::duration<double,
+        std::milli>(std::chrono::steady_clock::now() - g_t0).count(), what); }
 
 // ------------------------------------------------------------------------------------------------ blocked gzip (BGZF)
 // A .gz is one deflate stream in the reference (src/writer.cpp:39-51, src/fastqreader.cpp:31-37): one core, ~100 MB/s out, ~300 MB/s in - three
@@ -77,7 +82,8 @@ template <class F> static void parallel_for(size_t n, int threads, F fn) {
     for (auto& t : th) t.join();
 }
 // threads for deflate / inflate of blocked gzip: the I/O threads, and up to 32 of half the host's cores (the codec leaves the host idle)
-static int gz_threads(const Options& o) { const int hw = (int)std::thread::hardware_concurrency(); return std::max(std::max(1, std::max(o.threads, o.ioThreads)), std::min(32, hw / 2)); }
+static int gz_threads(const Options& o) { const int hw = (int)std::thread::hardware_concurrency();
+        return std::max(std::max(1, std::max(o.threads, o.ioThreads)), std::min(32, hw / 2)); }
 // one member: 18-byte header (extra field 'B','C',2,BSIZE = member size - 1), raw deflate, crc32, text size
 static void bgzf_member(const uint8_t* p, size_t n, int level, std::vector<uint8_t>& out) {
     out.resize(18 + compressBound((uLong)n) + 16 + 8);
@@ -99,7 +105,8 @@ static void bgzf_member(const uint8_t* p, size_t n, int level, std::vector<uint8
 static size_t bgzf_member_size(const uint8_t* h) {
     if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
     const size_t xlen = h[10] | ((size_t)h[11] << 8);
-    if (xlen != 6 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0) return 0;   // (bgzip writes exactly this; a member with more subfields takes the serial path)
+    // (bgzip writes exactly this; a member with more subfields takes the serial path)
+    if (xlen != 6 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0) return 0;
     return (size_t)(h[16] | ((size_t)h[17] << 8)) + 1;
 }
 
@@ -107,14 +114,17 @@ static size_t bgzf_member_size(const uint8_t* h) {
 struct ByteSource {                      // sequential bytes of a plain file, stdin, a .gz (block-parallel when blocked, else zlib) or a .xz (xz -d -c pipe)
     FILE* f = nullptr; gzFile gz = nullptr; bool piped = false; std::string path; int zthreads = 1;
     // blocked gzip: compressed bytes are read ahead into zbuf; `left` = text of a member that did not fit the caller's buffer
-    bool bgzf = false; int zfd = -1; std::vector<uint8_t> zbuf; size_t zpos = 0, zend = 0; uint64_t zoff = 0; bool zeof = false; std::vector<uint8_t> left; size_t left_pos = 0;
+    bool bgzf = false; int zfd = -1; std::vector<uint8_t> zbuf; size_t zpos = 0, zend = 0; uint64_t zoff = 0; bool zeof = false; std::vector<uint8_t> left;
+            size_t left_pos = 0;
     bool open(const std::string& p, int threads = 1) {
         path = p; zthreads = std::max(1, threads);
         if (ends_with(p, ".gz")) {
             zfd = ::open(p.c_str(), O_RDONLY);
             if (zfd >= 0) {
                 uint8_t h[18]; const ssize_t k = pread(zfd, h, 18, 0);
-                if (k == 18 && bgzf_member_size(h) >= 26) { bgzf = true; const char* e = getenv("RFQ_GZ_BUF"); zbuf.resize(e ? (size_t)std::max(64, atoi(e)) : (size_t)8 << 20); return true; }   // (RFQ_GZ_BUF: test aid - a small read-ahead makes refills happen on small files)
+                // (RFQ_GZ_BUF: test aid - a small read-ahead makes refills happen on small files)
+                if (k == 18 && bgzf_member_size(h) >= 26) { bgzf = true; const char* e = getenv("RFQ_GZ_BUF");
+                        zbuf.resize(e ? (size_t)std::max(64, atoi(e)) : (size_t)8 << 20); return true; }
                 ::close(zfd); zfd = -1;
             }
             gz = gzopen(p.c_str(), "rb"); if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr;
@@ -136,18 +146,22 @@ struct ByteSource {                      // sequential bytes of a plain file, st
     size_t read_bgzf(uint8_t* dst, size_t cap) {
         size_t got = 0;
         while (got < cap) {
-            if (left_pos < left.size()) { const size_t k = std::min(cap - got, left.size() - left_pos); memcpy(dst + got, left.data() + left_pos, k); got += k; left_pos += k; continue; }
-            if (gz) { const int n = gzread(gz, dst + got, (unsigned)std::min<size_t>(cap - got, 1u << 30)); if (n < 0) error_exit("Error to read gzip file"); if (n == 0) break; got += (size_t)n; continue; }
+            if (left_pos < left.size()) { const size_t k = std::min(cap - got, left.size() - left_pos); memcpy(dst + got, left.data() + left_pos, k); got += k;
+                    left_pos += k; continue; }
+            if (gz) { const int n = gzread(gz, dst + got, (unsigned)std::min<size_t>(cap - got, 1u << 30)); if (n < 0) error_exit("Error to read gzip file");
+                    if (n == 0) break; got += (size_t)n; continue; }
             // the members that fit what is left of dst: where each starts (relative to zpos: refills move the buffer's content), and where its text goes
             struct Mem { size_t at, size, text, out; }; std::vector<Mem> ms; size_t out = got, rel = 0; bool spill = false, foreign = false;
-            auto need = [&](size_t bytes) -> bool { while (zend - zpos < rel + bytes) if (!zfill()) return false; return true; };   // bytes visible from the next member's start on
+            // bytes visible from the next member's start on
+            auto need = [&](size_t bytes) -> bool { while (zend - zpos < rel + bytes) if (!zfill()) return false; return true; };
             for (;;) {
                 if (!need(1)) break;                                           // nothing behind the last member: the end of the file
                 if (!need(18)) error_exit("Error to read gzip file");
                 const size_t sz = bgzf_member_size(zbuf.data() + zpos + rel);
                 if (sz < 26) { foreign = true; break; }                        // a member of another shape: zlib takes over from here (below)
                 if (!need(sz)) error_exit("Error to read gzip file");
-                const uint8_t* e = zbuf.data() + zpos + rel + sz - 4; const size_t text = (size_t)e[0] | ((size_t)e[1] << 8) | ((size_t)e[2] << 16) | ((size_t)e[3] << 24);
+                const uint8_t* e = zbuf.data() + zpos + rel + sz - 4;
+                        const size_t text = (size_t)e[0] | ((size_t)e[1] << 8) | ((size_t)e[2] << 16) | ((size_t)e[3] << 24);
                 if (text > 65536) error_exit("Error to read gzip file");
                 if (out + text > cap) { if (ms.empty()) { ms.push_back(Mem{ rel, sz, text, 0 }); rel += sz; spill = true; } break; }
                 ms.push_back(Mem{ rel, sz, text, out }); out += text; rel += sz;
@@ -211,7 +225,8 @@ struct ByteSink {
             std::string cmd = "xz -z -c";
             if (o.threads > 1) cmd += " -T" + std::to_string(o.threads);
             if (o.compression <= 4) cmd += " -" + std::to_string(o.compression + 5);
-            else { unsigned long dict = (64ul * 1024 * 1024) << (o.compression - 4); if (o.compression == 9) dict = 1536ul * 1024 * 1024; cmd += " --lzma2=\"dict=" + std::to_string(dict) + "\""; }
+            else { unsigned long dict = (64ul * 1024 * 1024) << (o.compression - 4); if (o.compression == 9) dict = 1536ul * 1024 * 1024;
+                    cmd += " --lzma2=\"dict=" + std::to_string(dict) + "\""; }
             if (o.compression >= 4 && o.threads > 1) fprintf(stderr, "WARNING: when repaq compression level is >= 4, only single thread will be used for xz. Your options: compression = %d, thread = %d\n", o.compression, o.threads);
             cmd += " > '" + p + "'";
             f = popen(cmd.c_str(), "w"); piped = true;
@@ -249,7 +264,8 @@ struct ByteSink {
     void close() {
         if (bgzf) {
             if (!pend.empty()) { std::vector<uint8_t> z; bgzf_member(pend.data(), pend.size(), level, z); put(z.data(), z.size()); pend.clear(); }
-            std::vector<uint8_t> z; bgzf_member(nullptr, 0, level, z); put(z.data(), z.size());      // the empty member bgzip ends a file with (an empty input is just this)
+            // the empty member bgzip ends a file with (an empty input is just this)
+            std::vector<uint8_t> z; bgzf_member(nullptr, 0, level, z); put(z.data(), z.size());
             if (fclose(f) != 0) error_exit("Failed to write: " + path);
         }
         else if (piped) { if (f && pclose(f) != 0) error_exit("failed to call xz, please confirm that xz is installed in your system"); }
@@ -275,9 +291,13 @@ struct Gpu {
 //    before the last two is handed out (the line-break thresholds and `final` need it).
 struct Block { uint8_t* p = nullptr; size_t n = 0; };
 class Prefetcher {
-    ByteSource src; Gpu* g; std::vector<uint8_t*> plain; size_t block;    // g: null until attach() - the readers then fill ordinary page-aligned buffers (plain), which attach() page-locks
-    uint8_t* new_block() { if (g) return g->pinned(block); void* p = nullptr; if (posix_memalign(&p, 4096, block + 64) != 0) error_exit("out of memory"); std::unique_lock<std::mutex> lk(mu); if (g) { lk.unlock(); g->check(rfq_host_register(g->c, p, block + 64)); } else plain.push_back((uint8_t*)p); return (uint8_t*)p; } std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
-    std::map<uint64_t, Block> ready; uint64_t next_out = 0, next_claim = 0, n_blocks = 0; std::vector<uint8_t*> freeb; int to_alloc = 0;   // to_alloc: page-locked blocks not allocated yet (a reader allocates its own: pinning runs beside the first reads)
+    // g: null until attach() - the readers then fill ordinary page-aligned buffers (plain), which attach() page-locks
+    ByteSource src; Gpu* g; std::vector<uint8_t*> plain; size_t block;
+    uint8_t* new_block() { if (g) return g->pinned(block); void* p = nullptr; if (posix_memalign(&p, 4096, block + 64) != 0) error_exit("out of memory");
+            std::unique_lock<std::mutex> lk(mu); if (g) { lk.unlock(); g->check(rfq_host_register(g->c, p, block + 64)); } else plain.push_back((uint8_t*)p);
+            return (uint8_t*)p; } std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
+    // to_alloc: page-locked blocks not allocated yet (a reader allocates its own: pinning runs beside the first reads)
+    std::map<uint64_t, Block> ready; uint64_t next_out = 0, next_claim = 0, n_blocks = 0; std::vector<uint8_t*> freeb; int to_alloc = 0;
     bool eof = false, stop = false, regular = false; uint64_t total = 0; int last_byte = -1; int fd = -1; int running = 0; int nbuf_ = 4;
     void run_seq() {
         for (;;) {
@@ -308,7 +328,8 @@ class Prefetcher {
     }
 public:
     // (the context may come later: a compress starts its readers first and creates the context - 0.2 s of HIP start-up - while they fill their first blocks)
-    void attach(Gpu& gpu) { std::vector<uint8_t*> todo; { std::unique_lock<std::mutex> lk(mu); g = &gpu; todo.swap(plain); } for (uint8_t* p : todo) gpu.check(rfq_host_register(gpu.c, p, block + 64)); }
+    void attach(Gpu& gpu) { std::vector<uint8_t*> todo; { std::unique_lock<std::mutex> lk(mu); g = &gpu; todo.swap(plain);
+            } for (uint8_t* p : todo) gpu.check(rfq_host_register(gpu.c, p, block + 64)); }
     Prefetcher(Gpu& gpu, const std::string& path, size_t block_bytes, int threads = 1) : Prefetcher(&gpu, path, block_bytes, threads) {}
     Prefetcher(Gpu* gpu, const std::string& path, size_t block_bytes, int threads = 1) : g(gpu), block(block_bytes) {
         struct stat st;
@@ -329,7 +350,8 @@ public:
         else th.emplace_back([this] { run_seq(); });
     }
     // (a caller that stops early — an empty line ends the input, a failed compare — leaves blocks unread: wake the readers up)
-    ~Prefetcher() { { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); } for (auto& t : th) if (t.joinable()) t.join(); if (fd >= 0) ::close(fd); else src.close(); }
+    ~Prefetcher() { { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); } for (auto& t : th) if (t.joinable()) t.join(); if (fd >= 0) ::close(fd);
+            else src.close(); }
     // next block; false when the input is exhausted.  After it returns, end_known() tells whether the end of the input is known;
     // if not, at least two more full blocks follow the one just returned.
     bool next(Block& b) {
@@ -380,7 +402,8 @@ public:
     AsyncWriter(Gpu& gpu, const std::string& p, const Options& o) : g(gpu), piece(o.block()), path(p) {
         struct stat st; int threads = 1;
         regular = !ends_with(p, ".gz") && !ends_with(p, ".xz") && p != "/dev/stdout" && (stat(p.c_str(), &st) != 0 || S_ISREG(st.st_mode));
-        if (regular) { fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) error_exit("Failed to open file for writing: " + p); threads = std::max(1, o.writeThreads); max_flight = threads + 2; }
+        if (regular) { fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) error_exit("Failed to open file for writing: " + p);
+                threads = std::max(1, o.writeThreads); max_flight = threads + 2; }
         else sink.open(p, o);
         for (int i = 0; i < threads; i++) th.emplace_back([this] { run(); });
     }
@@ -435,7 +458,8 @@ struct DevStream {
     }
     template <class Release> void drain(Gpu& g, bool all, Release rel) {     // hand back the staging blocks whose copies are done (all: wait for every one)
         if (all) g.check(rfq_copy_sync(g.c));
-        while (!flight.empty()) { if (!all) { const int d_ = rfq_copy_done(g.c, flight.front().second); if (d_ < 0) g.check(d_); if (!d_) break; } rel(flight.front().first); flight.pop_front(); }
+        while (!flight.empty()) { if (!all) { const int d_ = rfq_copy_done(g.c, flight.front().second); if (d_ < 0) g.check(d_); if (!d_) break;
+                } rel(flight.front().first); flight.pop_front(); }
     }
     void free_all(Gpu& g) { for (int i = 0; i < 2; i++) if (d[i]) rfq_dev_free(g.c, d[i]); }
 };
@@ -556,7 +580,8 @@ static void do_compress(const Options& o) {
         a.nolb_from1 = th[0]; a.nolb_from2 = two ? th[1] : th[0];
         rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
         if (ver && r.n_chunks && ver->wanted())
-            ver->check(g, r, first, final || r.input_ended, two, ds[0].base(), final ? ds[0].have : r.consumed1, two ? ds[1].base() : nullptr, two ? (final ? ds[1].have : r.consumed2) : 0, ds[0].file_off, ds[1].file_off);
+            ver->check(g, r, first, final || r.input_ended, two, ds[0].base(), final ? ds[0].have : r.consumed1, two ? ds[1].base() : nullptr,
+                    two ? (final ? ds[1].have : r.consumed2) : 0, ds[0].file_off, ds[1].file_off);
         trace_mark("compress: batch encoded");
         if (r.rfq_len) { out.write_dev(r.d_rfq, r.rfq_len); if (r.n_chunks) first = false; }
         if (final || r.input_ended) break;            // input_ended: the reader stopped at an empty line (src/fastqreader.cpp:180-191)
@@ -622,10 +647,12 @@ static void do_compress_multi(const Options& o) {
               if (k) { cv.wait(lk, [&] { return batches.count(k - 1) && batches[k - 1]->carry_ready; }); prev = batches[k - 1]; } }
             auto publish = [&](bool ended, bool hdr, const uint8_t* p1, size_t n1, uint64_t o1, const uint8_t* p2, size_t n2, uint64_t o2) {
                 std::unique_lock<std::mutex> lk(mu);
-                b->ended = ended; b->hdr_promised = hdr; b->owner = g.c; b->carry_ptr[0] = p1; b->carry_n[0] = n1; b->carry_off[0] = o1; b->carry_ptr[1] = p2; b->carry_n[1] = n2; b->carry_off[1] = o2;
+                b->ended = ended; b->hdr_promised = hdr; b->owner = g.c; b->carry_ptr[0] = p1; b->carry_n[0] = n1; b->carry_off[0] = o1; b->carry_ptr[1] = p2;
+                        b->carry_n[1] = n2; b->carry_off[1] = o2;
                 b->carry_ready = true; cv.notify_all();
             };
-            auto finish = [&](std::vector<uint8_t>&& img) {                   // the image to the writer (in order), then the buffers go once the next batch has taken its carry
+            // the image to the writer (in order), then the buffers go once the next batch has taken its carry
+            auto finish = [&](std::vector<uint8_t>&& img) {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return done.size() < 4 * (size_t)D || b->seq == next_write; });
                 done[b->seq] = std::move(img); cv.notify_all();
@@ -645,7 +672,8 @@ static void do_compress_multi(const Options& o) {
             const uint8_t* tx[2] = { nullptr, nullptr }; size_t tn[2] = { 0, 0 }; uint64_t toff[2] = { 0, 0 };
             for (int s = 0; s < ns; s++) {
                 size_t lead = b->room;                                         // my own bytes start `lead` bytes into the buffer
-                if (cn[s] > lead) {                                            // (a carry larger than the room left for it - a chunk of > 4 x chunk_bases bytes, or several batches without a whole chunk: a larger buffer)
+                // (a carry larger than the room left for it - a chunk of > 4 x chunk_bases bytes, or several batches without a whole chunk: a larger buffer)
+                if (cn[s] > lead) {
                     const size_t nc = cn[s] + b->n[s] + 64; void* nb = g.dev(nc); trace_mark("compress: carry larger than its room, buffer grown");
                     if (b->n[s]) g.check(rfq_copy_d2d(g.c, (uint8_t*)nb + cn[s], (uint8_t*)b->buf[s] + lead, b->n[s]));
                     g.check(rfq_dev_free(g.c, b->buf[s])); b->buf[s] = nb; b->cap[s] = nc; lead = cn[s];
@@ -661,7 +689,8 @@ static void do_compress_multi(const Options& o) {
             size_t en[2] = { tn[0], tn[1] }; bool encode_final = b->last, nothing = false, ended = false;
             if (!b->last) {                                                    // plan: where my last whole chunk ends; the rest is the next batch's
                 rfq_scan_result sr; a.final = 0; g.check(rfq_scan_batch(g.c, &a, &sr));
-                if (sr.input_ended) ended = true;                              // (an empty line ends the input inside my text: all of it goes through the encode, which stops there)
+                // (an empty line ends the input inside my text: all of it goes through the encode, which stops there)
+                if (sr.input_ended) ended = true;
                 else if (sr.n_chunks == 0) nothing = true;
                 else { en[0] = (size_t)sr.h_end1[sr.n_chunks - 1]; en[1] = two ? (size_t)sr.h_end2[sr.n_chunks - 1] : 0; }
                 if (ended) publish(true, true, nullptr, 0, 0, nullptr, 0, 0);
@@ -670,7 +699,8 @@ static void do_compress_multi(const Options& o) {
             }
             std::vector<uint8_t> img;
             if (!nothing) {
-                if (hdr_before && !have_hdr) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return header_ready; }); lk.unlock(); g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
+                if (hdr_before && !have_hdr) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return header_ready; }); lk.unlock();
+                        g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
                 a.n1 = en[0]; a.n2 = two ? en[1] : 0; a.final = encode_final ? 1 : 0; a.flush_all = encode_final ? 0 : 1; a.emit_header = hdr_before ? 0 : 1;
                 rfq_encode_result r; g.check(rfq_encode_batch(g.c, &a, &r));
                 if (ver && r.n_chunks && ver->wanted()) ver->check(g, r, !hdr_before, encode_final || ended, two, tx[0], en[0], tx[1], two ? en[1] : 0, toff[0], toff[1]);
@@ -687,13 +717,15 @@ static void do_compress_multi(const Options& o) {
     // ingestion: batch k of every stream to device k mod D
     for (uint64_t k = 0; ; k++) {
         const int w = (int)(k % (uint64_t)D);
-        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return k < next_write + 2 * (uint64_t)D + 1; }); }   // (at most two batches per device wait for their encode)
+        // (at most two batches per device wait for their encode)
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return k < next_write + 2 * (uint64_t)D + 1; }); }
         if (!gin[(size_t)w]) gin[(size_t)w].reset(new Gpu(o.devices[(size_t)w]));
         Gpu& g = *gin[(size_t)w];
         auto b = std::make_shared<MBatch>(); b->seq = k; b->w = w; b->room = room;
         bool ended[2] = { false, !two };
         for (int s = 0; s < ns; s++) { b->cap[s] = room + batch + block + 64; b->buf[s] = g.dev(b->cap[s]); b->file_off[s] = 0; }
-        std::deque<std::pair<Block, int>> flight; size_t held[2] = { 0, 0 };  // staging blocks whose copies are queued (a reader must never run out of blocks: flight_limit)
+        // staging blocks whose copies are queued (a reader must never run out of blocks: flight_limit)
+        std::deque<std::pair<Block, int>> flight; size_t held[2] = { 0, 0 };
         auto land = [&] { g.check(rfq_copy_sync(g.c)); for (auto& f : flight) in[f.second]->release(f.first); flight.clear(); held[0] = held[1] = 0; };
         for (bool more = true; more; ) {
             more = false;
@@ -741,7 +773,8 @@ struct ChunkWalker {
         }
         for (;;) {
             if (next + 12 > fed) {                                            // the header is not (all) here yet: keep what there is of it
-                if (next < fed) { const uint64_t from = std::max(next, base); const size_t k = (size_t)(fed - from); if (ncarry + k <= 12) { memcpy(carry + ncarry, p + (from - base), k); ncarry += (int)k; } else dead = true; }
+                if (next < fed) { const uint64_t from = std::max(next, base); const size_t k = (size_t)(fed - from);
+                        if (ncarry + k <= 12) { memcpy(carry + ncarry, p + (from - base), k); ncarry += (int)k; } else dead = true; }
                 return;
             }
             uint8_t h[12];
@@ -762,7 +795,8 @@ struct ChunkWalker {
     bool table(uint64_t b0, size_t n, std::vector<uint64_t>& t) const {
         t.clear(); if (dead) return false;
         auto it = std::lower_bound(off.begin(), off.end(), b0);
-        for (; it != off.end(); ++it) { const uint64_t end = (it + 1 != off.end()) ? *(it + 1) : next; if (end > b0 + n || (it + 1 == off.end() && next > fed)) break; if (t.empty()) t.push_back(*it - b0); t.push_back(end - b0); }
+        for (; it != off.end(); ++it) { const uint64_t end = (it + 1 != off.end()) ? *(it + 1) : next; if (end > b0 + n || (it + 1 == off.end() && next > fed)) break;
+                if (t.empty()) t.push_back(*it - b0); t.push_back(end - b0); }
         return t.size() >= 2;
     }
 };
@@ -787,7 +821,8 @@ static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& p
         rfq_decode_args a; memset(&a, 0, sizeof a);
         std::vector<uint64_t> tab;
         if (walker.table(ds.file_off, ds.have, tab)) { a.h_chunk_off = tab.data(); a.n_chunk_off = (uint32_t)(tab.size() - 1); }
-        a.d_rfq = ds.base(); a.n = ds.have; a.has_header = first ? 1 : 0; a.split_pe = split ? 1 : 0; a.final = ds.ended ? 1 : 0; a.bug_compat = (o.bugCompat && o.decompress) ? 1 : 0;
+        a.d_rfq = ds.base(); a.n = ds.have; a.has_header = first ? 1 : 0; a.split_pe = split ? 1 : 0; a.final = ds.ended ? 1 : 0;
+                a.bug_compat = (o.bugCompat && o.decompress) ? 1 : 0;
         rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
         first = false;
         trace_mark("decode: batch decoded");
@@ -849,13 +884,16 @@ static void do_decompress_multi(const Options& o) {
         Gpu g(o.devices[w]); void* d = nullptr; size_t cap = 0; bool have_hdr = false; OutBuf ob[2]; int turn = 0;
         for (;;) {
             DecItem it;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = std::move(queue.front()); queue.pop_front(); cv.notify_all(); }
-            if (!have_hdr) { { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return header_ready; }); } g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty() || no_more; }); if (queue.empty()) break; it = std::move(queue.front());
+                    queue.pop_front(); cv.notify_all(); }
+            if (!have_hdr) { { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return header_ready; });
+                    } g.check(rfq_set_header(g.c, header.data(), header.size())); have_hdr = true; }
             if (cap < it.bytes.size() + 64) { if (d) rfq_dev_free(g.c, d); cap = it.bytes.size() + it.bytes.size() / 4 + 64; d = g.dev(cap); }
             g.check(rfq_copy_h2d(g.c, d, it.bytes.data(), it.bytes.size()));
             rfq_decode_args a; memset(&a, 0, sizeof a);
             a.d_rfq = (const uint8_t*)d; a.n = it.bytes.size(); a.has_header = 0; a.split_pe = split ? 1 : 0; a.final = it.final ? 1 : 0;
-            a.h_chunk_off = it.tab.size() >= 2 ? it.tab.data() : nullptr; a.n_chunk_off = it.tab.size() >= 2 ? (uint32_t)(it.tab.size() - 1) : 0u;   // (no table: what the host's walk could not index - the library finds the chunks itself, like the one-device path)
+            // (no table: what the host's walk could not index - the library finds the chunks itself, like the one-device path)
+            a.h_chunk_off = it.tab.size() >= 2 ? it.tab.data() : nullptr; a.n_chunk_off = it.tab.size() >= 2 ? (uint32_t)(it.tab.size() - 1) : 0u;
             rfq_decode_result r; g.check(rfq_decode_batch(g.c, &a, &r));
             if (it.tab.size() >= 2 && r.consumed != it.bytes.size()) error_exit("internal: a dealt range does not decode as whole chunks");
             OutBuf& t = ob[turn]; turn ^= 1;
@@ -878,7 +916,8 @@ static void do_decompress_multi(const Options& o) {
             if (!walker.have_hdr || walker.fed < 17u + walker.head[16]) { if (last && walker.fed) error_exit("Not a valid repaq file!"); return; }
             const size_t hl = 17u + walker.head[16];
             { std::unique_lock<std::mutex> lk(mu); header.assign(pend.begin(), pend.begin() + hl); header_ready = true; cv.notify_all(); }
-            { Gpu& g = gs; g.check(rfq_set_header(g.c, header.data(), header.size())); }                   // (validates it: the reference's messages for a foreign / newer file)
+            // (validates it: the reference's messages for a foreign / newer file)
+            { Gpu& g = gs; g.check(rfq_set_header(g.c, header.data(), header.size())); }
             pend.erase(pend.begin(), pend.begin() + hl); pend_off = hl; hdr_done = true;
         }
         // what the host's walk cannot index (an implausible chunk header, bytes behind the chain's end): not an error here - the one-device path copes with such
@@ -911,7 +950,8 @@ static void do_decompress_multi(const Options& o) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return queue.size() < 2 * o.devices.size(); }); queue.push_back(std::move(it)); cv.notify_all(); }
             if (all) break;
         }
-        if (last && !pend.empty() && pend.size() >= 18) deal_rest();        // (a tail the chain does not cover: the device's walk says whether it is a chunk, a cut one, or padding)
+        // (a tail the chain does not cover: the device's walk says whether it is a chunk, a cut one, or padding)
+        if (last && !pend.empty() && pend.size() >= 18) deal_rest();
     };
     while (!ended) {
         Block b; if (!in.next(b)) { ended = true; break; }
@@ -932,7 +972,8 @@ static void report(const Options& o, bool passed, const std::string& msg, long f
     j += "\t\"msg\":\"" + msg + "\",\n";
     j += "\t\"fastq_reads\":" + std::to_string(fqReads) + ",\n\t\"rfq_reads\":" + std::to_string(rfqReads) + ",\n";
     j += "\t\"fastq_bases\":" + std::to_string(fqBases) + ",\n\t\"rfq_bases\":" + std::to_string(rfqBases) + "\n}\n";
-    if (!o.json.empty()) { FILE* f = fopen(o.json.c_str(), "wb"); if (!f) error_exit("Failed to open file for writing: " + o.json); fwrite(j.data(), 1, j.size(), f); fclose(f); }
+    if (!o.json.empty()) { FILE* f = fopen(o.json.c_str(), "wb"); if (!f) error_exit("Failed to open file for writing: " + o.json); fwrite(j.data(), 1, j.size(), f);
+            fclose(f); }
     fputs(j.c_str(), stdout); fflush(stdout);
 }
 static void do_compare(const Options& o) {
@@ -1025,7 +1066,8 @@ static void do_compare(const Options& o) {
         const Rec& q = pair[second ? 1 : 0];
         fqReads++; fqBases += (long)q.f[1].size();
         for (int k = 0; k < 4 && !reported; k++) if (r.f[k] != q.f[k]) {
-            report(o, false, std::string("The RFQ file and FASTQ file have different ") + what[k] + " in the " + cnt(rfqReads) + unit + r.f[k] + " | " + q.f[k], fqReads, fqBases, rfqReads, rfqBases);
+            report(o, false, std::string("The RFQ file and FASTQ file have different ") + what[k] + " in the " + cnt(rfqReads) + unit + r.f[k] + " | " + q.f[k], fqReads,
+                    fqBases, rfqReads, rfqBases);
             reported = true;
         }
         if (reported) break;
@@ -1081,7 +1123,9 @@ int main(int argc, char** argv) {
         else if (a == "-t" || a == "--thread" || a.rfind("--thread=", 0) == 0) o.threads = atoi(val(i, "thread").c_str());
         else if (a == "-z" || a == "--compression" || a.rfind("--compression=", 0) == 0) o.compression = atoi(val(i, "compression").c_str());
         else if (a == "--device") o.device = atoi(val(i, "device").c_str());
-        else if (a == "--devices" || a.rfind("--devices=", 0) == 0) { const std::string v = val(i, "devices"); size_t p0 = 0; while (p0 <= v.size()) { const size_t q = v.find(',', p0); const std::string t = v.substr(p0, q == std::string::npos ? std::string::npos : q - p0); if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (q == std::string::npos) break; p0 = q + 1; } }
+        else if (a == "--devices" || a.rfind("--devices=", 0) == 0) { const std::string v = val(i, "devices"); size_t p0 = 0;
+                while (p0 <= v.size()) { const size_t q = v.find(',', p0); const std::string t = v.substr(p0, q == std::string::npos ? std::string::npos : q - p0);
+                if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (q == std::string::npos) break; p0 = q + 1; } }
         else if (a == "--bug_compat") o.bugCompat = true;
         else if (a == "--batch_mb") o.batchBytes = (size_t)atol(val(i, "batch_mb").c_str()) << 20;
         else if (a == "--block_mb") o.blockBytes = (size_t)atol(val(i, "block_mb").c_str()) << 20;
@@ -1106,7 +1150,8 @@ int main(int argc, char** argv) {
         if (o.useStdout) o.out1 = "/dev/stdout"; else if (!cmp) error_exit("Please specify output file by <out1>, or enable --stdout if you want to read STDIN");
     }
     if (o.compression < 1 || o.compression > 9) error_exit("compression level (-z) should be 1 ~ 9");
-    if ((ends_with(o.in1, ".xz") || ends_with(o.rfqCompare, ".xz")) && o.useStdin) error_exit("STDIN cannot be read when the input is a .xz file");   // src/main.cpp:123-131
+    // src/main.cpp:123-131
+    if ((ends_with(o.in1, ".xz") || ends_with(o.rfqCompare, ".xz")) && o.useStdin) error_exit("STDIN cannot be read when the input is a .xz file");
     if (ends_with(o.out1, ".xz") && o.useStdout) error_exit("STDOUT cannot be written when the output is a .xz file");
     const long cb = std::max(100L, o.chunkKb) * 1000;
     if (cb < 10000) error_exit("chunk size cannot be less than 10 kb");

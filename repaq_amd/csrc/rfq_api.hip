@@ -21,9 +21,12 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     const long long num = set ? atoll(v.c_str()) : 0;
     if (n == "RFQ_GATHER") { if (set && v != "old" && v != "tile") return rfq_fail(c, RFQ_E_ARG, "RFQ_GATHER is old or tile"); c->opt.gather_old = v == "old"; }
     else if (n == "RFQ_QUAL") { if (set && v != "bytes" && v != "masks") return rfq_fail(c, RFQ_E_ARG, "RFQ_QUAL is bytes or masks"); c->opt.qual_bytes = v == "bytes"; }
-    else if (n == "RFQ_CODER") { if (set && v != "list" && v != "mask") return rfq_fail(c, RFQ_E_ARG, "RFQ_CODER is list or mask"); c->opt.coder = v == "list" ? 1 : (v == "mask" ? 2 : 0); }
-    else if (n == "RFQ_INDEX") { if (set && v != "2pass" && v != "1pass") return rfq_fail(c, RFQ_E_ARG, "RFQ_INDEX is 2pass or 1pass"); c->opt.index_2pass = v == "2pass"; }
-    else if (n == "RFQ_IDX_TILES") { if (set && num != 4 && num != 8 && num != 16) return rfq_fail(c, RFQ_E_ARG, "RFQ_IDX_TILES is 4, 8 or 16"); c->opt.idx_tiles = set ? (int)num : d.idx_tiles; }
+    else if (n == "RFQ_CODER") { if (set && v != "list" && v != "mask") return rfq_fail(c, RFQ_E_ARG, "RFQ_CODER is list or mask");
+            c->opt.coder = v == "list" ? 1 : (v == "mask" ? 2 : 0); }
+    else if (n == "RFQ_INDEX") { if (set && v != "2pass" && v != "1pass") return rfq_fail(c, RFQ_E_ARG, "RFQ_INDEX is 2pass or 1pass"); c->opt.index_2pass = v == "2pass";
+            }
+    else if (n == "RFQ_IDX_TILES") { if (set && num != 4 && num != 8 && num != 16) return rfq_fail(c, RFQ_E_ARG, "RFQ_IDX_TILES is 4, 8 or 16");
+            c->opt.idx_tiles = set ? (int)num : d.idx_tiles; }
     else if (n == "RFQ_STREAMS") c->opt.one_stream = set && num == 1;
     else if (n == "RFQ_SLICE_BYTES") c->opt.slice_bytes = set ? (size_t)num : 0;
     else if (n == "RFQ_SLICE_BASES") c->opt.slice_bases = set ? (uint64_t)num : 0;
@@ -63,7 +66,8 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& b : c->b) b.release();
-    c->d_hdr.release(); c->d_status.release(); c->d_cmp.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release(); c->out_acc.release(); c->out_acc1.release(); c->out_acc2.release();
+    c->d_hdr.release(); c->d_status.release(); c->d_cmp.release(); c->out_img.release(); c->out_fq1.release(); c->out_fq2.release(); c->out_acc.release();
+            c->out_acc1.release(); c->out_acc2.release();
     c->timer.destroy();
     if (c->copy) { (void)hipStreamDestroy(c->copy); for (auto& e : c->copy_ev) if (e) (void)hipEventDestroy(e); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -256,7 +260,8 @@ __global__ void k_selftest_wave(const unsigned long long* __restrict__ in, unsig
     o[8] = wave_shr1<uint32_t>(a, 0xABCD1234u);
     o[9] = wave_last<uint32_t>(a);
     o[10] = wave_min<unsigned long long>(v);
-    { U4 u; u.a = a; u.b = a >> 3; u.c = a ^ 0x5A5Au; u.d = (uint32_t)(v >> 32); const U4 r = wave_incl_sum(u); o[11] = ((unsigned long long)(r.a + r.b + r.c) << 32) | r.d; }
+    { U4 u; u.a = a; u.b = a >> 3; u.c = a ^ 0x5A5Au; u.d = (uint32_t)(v >> 32); const U4 r = wave_incl_sum(u);
+            o[11] = ((unsigned long long)(r.a + r.b + r.c) << 32) | r.d; }
 }
 extern "C" int rfq_selftest_wave(rfq_ctx* c, const uint64_t* h_in, uint32_t n_waves, uint64_t* h_out) {
     if (!c || !h_in || !h_out || !n_waves) return RFQ_E_ARG;
@@ -265,7 +270,8 @@ extern "C" int rfq_selftest_wave(rfq_ctx* c, const uint64_t* h_in, uint32_t n_wa
     void *din = nullptr, *dout = nullptr;
     HIPCHK(c, hipMalloc(&din, n * 8)); if (hipMalloc(&dout, n * 96) != hipSuccess) { (void)hipFree(din); return rfq_fail(c, RFQ_E_HIP, "hipMalloc failed"); }
     hipError_t e = hipMemcpy(din, h_in, n * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_wave, dim3(n_waves), dim3(64), 0, c->stream, (const unsigned long long*)din, (unsigned long long*)dout); e = hipGetLastError(); }
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_wave, dim3(n_waves), dim3(64), 0, c->stream, (const unsigned long long*)din, (unsigned long long*)dout);
+            e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(h_out, dout, n * 96, hipMemcpyDeviceToHost);
     (void)hipFree(din); (void)hipFree(dout);

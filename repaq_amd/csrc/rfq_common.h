@@ -64,7 +64,8 @@ struct DevHeader {
     uint8_t  normal[256];       // normalQualBuf()
     uint8_t  stream_of[256];    // quality byte -> index into normal[] (0xFF = none)
     uint8_t  is_exception[256]; // 1: neither major nor a normal value -> 5-byte exception record
-    uint8_t  dense[4];          // encode, match-mask mode: the coded values' streams by falling frequency in chunk 0 (k_dense_order): the first ones get planes built in LDS
+    // encode, match-mask mode: the coded values' streams by falling frequency in chunk 0 (k_dense_order): the first ones get planes built in LDS
+    uint8_t  dense[4];
     uint32_t dense_valid;
     uint32_t valid;
 };
@@ -196,8 +197,11 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) { RFQ_DPP_SCAN(v, RFQ_OP
 // lane l <- lane l-1 (lane 0 <- fill): wave_shr:1; the value of lane 63 in every lane (an SGPR)
 template <class T> __device__ __forceinline__ T wave_shr1(T v, T fill) { return dpp_take<0x138, 0xF>(fill, v); }
 template <class T> __device__ __forceinline__ T wave_last(T v) { return wave_read63(v); }
-template <class T> __device__ __forceinline__ T wave_read(T v, uint32_t lane) { static_assert(sizeof(T) == 4, "wave_read: 32-bit values"); return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane((int)lane))); }
-template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true); }   // quad_perm:[K,K,K,K]
+template <class T> __device__ __forceinline__ T wave_read(T v, uint32_t lane) { static_assert(sizeof(T) == 4, "wave_read: 32-bit values");
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane((int)lane))); }
+// quad_perm:[K,K,K,K]
+template <int K> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6),
+        0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t lane_shr4(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); }             // row_shr:4
 #endif
 __device__ __forceinline__ U4 wave_incl_sum(U4 v) {

@@ -24,7 +24,8 @@ struct DBuf {
         void* q = nullptr; const size_t want = n + n / 2 + 4096;
         hipError_t e = hipMalloc(&q, want);
         if (e != hipSuccess) return e;
-        if (p && keep) { e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) { (void)hipFree(q); return e; } }
+        if (p && keep) { e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s);
+                if (e != hipSuccess) { (void)hipFree(q); return e; } }
         if (p) (void)hipFree(p);
         p = q; cap = want; return hipSuccess;
     }
@@ -65,20 +66,24 @@ static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, u
 // Test / diagnostic switches of a context (rfq_set_option).  The RFQ_* environment variables of the same names are read ONCE, when the context is created
 // (no getenv on the batch paths - the switches changed chunk walking and emission silently per call, and getenv races a concurrent setenv).
 struct RfqOpts {
-    int  coder = 0;                   // RFQ_CODER=list|mask   encode, quality bytes: the list coder / the mask coder whatever the number of coded values (default: list from five on)
-    bool qual_bytes = false;          // RFQ_QUAL=bytes     encode: k_gather2 writes the quality bytes (qcat) also for files with <= 3 coded values (default there: match masks)
+    // RFQ_CODER=list|mask   encode, quality bytes: the list coder / the mask coder whatever the number of coded values (default: list from five on)
+    int  coder = 0;
+    // RFQ_QUAL=bytes     encode: k_gather2 writes the quality bytes (qcat) also for files with <= 3 coded values (default there: match masks)
+    bool qual_bytes = false;
     bool gather_old = false;          // RFQ_GATHER=old     encode: the byte-wise gather (k_gather + k_packbytes) also for reads that fit a tile
     bool index_2pass = false;         // RFQ_INDEX=2pass    encode: newline bitmap -> scan -> line offsets instead of the one-pass index
     int  idx_tiles = 0;               // RFQ_IDX_TILES=4|8|16   text per workgroup of the one-pass index (x 16 KiB); 0 = default
     bool one_stream = false;          // RFQ_STREAMS=1      no second stream: every kernel of a batch on the context's stream
     size_t slice_bytes = 0;           // RFQ_SLICE_BYTES    encode: slices of that many bytes per stream (so that the slicing logic runs on small inputs)
     uint64_t slice_bases = 0;         // RFQ_SLICE_BASES    decode: ranges of that many bases
-    bool walk_exact = false;          // RFQ_WALK=exact     decode without a chunk index: straight to the exact serial walk (default: guess and verify, that walk behind it)
+    // RFQ_WALK=exact     decode without a chunk index: straight to the exact serial walk (default: guess and verify, that walk behind it)
+    bool walk_exact = false;
     int  gw_shift = 16;               // RFQ_GW_SHIFT       log2 of the smallest guess-and-verify segment
     bool materialise = false;         // RFQ_MATERIALISE=1  decode: qualities / bases expanded in HBM (the path of a streaming caller's non-final slices) on every call
     bool trace = false;               // RFQ_TRACE          a line on stderr about how chunk starts were found
     uint32_t g2_pad = 0;              // RFQ_G2_PAD         profiling aid: bytes of unused dynamic LDS added to k_gather2 (fewer resident workgroups)
-    uint32_t sp_pad = 0;              // RFQ_SP_PAD         bytes of unused dynamic LDS added to k_seqpack: caps its resident workgroups so that the position coder beside it keeps its share
+    // RFQ_SP_PAD         bytes of unused dynamic LDS added to k_seqpack: caps its resident workgroups so that the position coder beside it keeps its share
+    uint32_t sp_pad = 0;
 };
 struct rfq_ctx {
     RfqOpts opt;
@@ -134,7 +139,8 @@ struct rfq_ctx {
     DBuf b[120];
     DBuf out_img, out_fq1, out_fq2, out_acc, out_acc1, out_acc2;       // out_acc*: the results of a sliced encode / decode call, appended
     bool dense_ok = false;                 // encode, match-mask mode: DevHeader::dense of the device header is set (k_dense_order; reset with the header)
-    bool qplane_dirty = true;              // encode, match-mask mode: the rare planes of b[B_QPLANE] may hold bits (fresh buffer, or a call that left early): zero them whole
+    // encode, match-mask mode: the rare planes of b[B_QPLANE] may hold bits (fresh buffer, or a call that left early): zero them whole
+    bool qplane_dirty = true;
     uint32_t qplane_nd = 0, qplane_mask = 0; // ... dense planes the last batch used: how many, which (the others must be all-zero)
     size_t qplane_stride = 0;              // ... words per plane the buffer is laid out with (fixed while the buffer is)
     std::vector<uint64_t> chunk_off;

@@ -27,13 +27,16 @@ static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk
 #undef RFQ_LIST_ARGS
 }
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
-struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one, pieces, piece_avg, piece_n1; uint64_t bases; };   // bases: sum of the range's read lengths (the walk's 64-bit total)
+// bases: sum of the range's read lengths (the walk's 64-bit total)
+struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_stream, max_npos, max_len, max_bases, max_nrec, max_one, pieces, piece_avg, piece_n1;
+        uint64_t bases; };
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
 // out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
                         uint8_t** p1, uint8_t** p2, size_t* n1, size_t* n2, uint64_t* nbases) {
     hipStream_t S = ctx->stream; DBuf* B = ctx->b;
-    const int tune = ctx->opt.materialise ? 2048 : 0;                       // (RFQ_MATERIALISE: the expanding decode of a streaming caller's non-final slices, on every call)
+    // (RFQ_MATERIALISE: the expanding decode of a streaming caller's non-final slices, on every call)
+    const int tune = ctx->opt.materialise ? 2048 : 0;
     const DevHeader& HH = ctx->h_hdr; const DevHeader* D = ctx->d_hdr.as<DevHeader>();
     DecStatus* dst = B[DB_STATUS].as<DecStatus>(); DecStatus hs; memset(&hs, 0, sizeof hs);
     hs.max_stream = g.max_stream; hs.max_npos = g.max_npos;
@@ -62,8 +65,10 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     }
     const bool e3_ok = e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed);
     const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u && e3_ok;
-    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S; const uint32_t f_nstr = HH.n_normal + 1;
-    struct AuxJoin { rfq_ctx* c; bool armed; ~AuxJoin() { if (armed) (void)hipStreamSynchronize(c->aux); } } aux_guard = { ctx, false };   // (an early return must not leave the chain running over buffers the next call reuses)
+    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S;
+            const uint32_t f_nstr = HH.n_normal + 1;
+    // (an early return must not leave the chain running over buffers the next call reuses)
+    struct AuxJoin { rfq_ctx* c; bool armed; ~AuxJoin() { if (armed) (void)hipStreamSynchronize(c->aux); } } aux_guard = { ctx, false };
     if (fused) {
         const bool hasn = (HH.flags & H_N_POS) != 0; const uint32_t nn = bycol_h ? std::min<uint32_t>(HH.n_normal, NPOS_SLOT) : 0u;
         const bool forked = ctx->aux_ready(); hipStream_t A = forked ? ctx->aux : S;
@@ -73,20 +78,27 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             f_ncell = g.max_bases / POS2_CELL + 2;
             const size_t nst = (size_t)n_chunks * f_nstr, nseg = nst * f_maxseg, ncl = nst * f_ncell;
             HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 32 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure(nst * 4 + 16));
-            HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_SEGK].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_CELL].ensure(ncl * 4 + 16));
+            HIPCHK(ctx, B[DB_SEGS].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGP].ensure(nseg * 4 + 16)); HIPCHK(ctx, B[DB_SEGK].ensure(nseg * 4 + 16));
+                    HIPCHK(ctx, B[DB_CELL].ensure(ncl * 4 + 16));
             HIPCHK(ctx, B[DB_NENT].ensure(nst * 4 + 16)); HIPCHK(ctx, B[DB_LOFF].ensure(nst * 8 + 16));
             // the arena of the position lists: a position belongs to at most one stream, the coded ones are a few percent of the bases; if a
             // file needs more than the arena holds, k_dec_pos_list leaves it alone and the pass is repeated below with the right size
-            // (2 bytes per base is far more than most files need; when that much is not to be had, start small: the pass is repeated with the exact size)
-            if (B[DB_PLIST].ensure((size_t)(g.bases / 2 + 1024) * 4) != hipSuccess) { (void)hipGetLastError(); HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 32 + 1024) * 4)); }
-            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
+            // (an entry per eight bases to begin with - half a byte per base; a NovaSeq-binned file codes one position in twelve.  A file that codes more
+            // - forty quality values code most positions - runs the list pass a second time, once per context: the arena keeps its size.  Round 3 asked for
+            // 2 bytes per base up front: 6.7 GB on 2 x 4 GB of text)
+            if (B[DB_PLIST].ensure((size_t)(g.bases / 8 + 1024) * 4) != hipSuccess) { (void)hipGetLastError();
+                    HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 32 + 1024) * 4)); }
+            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A));
+                    HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
 #define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
             if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);
             if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr);
 #undef RFQ_SUM2_ARGS
-            hipLaunchKernelGGL(k_dec_pos_link2, dim3((uint32_t)((nst + 3) / 4)), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
+            hipLaunchKernelGGL(k_dec_pos_link2, dim3((uint32_t)((nst + 3) / 4)), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(),
+                    (const int*)B[DB_SEGA].as<int>(),
                                (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_SEGK].as<uint32_t>(), B[DB_NENT].as<uint32_t>(), f_maxseg, (uint32_t)nst);
-            hipLaunchKernelGGL(k_dec_pos_off, dim3(1), dim3(256), 0, A, (const uint32_t*)B[DB_NENT].as<uint32_t>(), B[DB_LOFF].as<unsigned long long>(), (uint32_t)nst, dst);
+            hipLaunchKernelGGL(k_dec_pos_off, dim3(1), dim3(256), 0, A, (const uint32_t*)B[DB_NENT].as<uint32_t>(), B[DB_LOFF].as<unsigned long long>(), (uint32_t)nst,
+                    dst);
             launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, A);
             f_lists = true; f_mq = mq; f_mn = mn; f_nn = nn; f_hasn = hasn;
             f_join = forked; f_aux = A;
@@ -103,7 +115,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     HIPCHK(ctx, B[DB_XV].ensure(nr * 4)); HIPCHK(ctx, B[DB_YV].ensure(nr * 4)); HIPCHK(ctx, B[DB_MID].ensure(nr * 40));
     HIPCHK(ctx, B[DB_SCAN].ensure((nr / SCAN_TILE + 2) * 16 + 1024));
     DReadTab R; R.len = B[DB_LEN].as<uint32_t>(); R.chunk = B[DB_CHUNKID].as<uint32_t>(); R.ov = B[DB_OV].as<int32_t>();
-    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>(); R.mid = B[DB_MID].as<uint8_t>();
+    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>();
+            R.mid = B[DB_MID].as<uint8_t>();
     hipLaunchKernelGGL(k_dec_readtab, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, dst);
     KCHK(ctx, "k_dec_readtab");
     scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
@@ -140,7 +153,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // the prefill is pure bandwidth, the coordinate decoder and the stream summaries are pure latency: third chain
     hipStream_t F = forked ? ctx->aux2 : S;
     if (forked) HIPCHK(ctx, hipStreamWaitEvent(F, ctx->ev_fork, 0));
-    hipLaunchKernelGGL(k_dec_fill, dim3((uint32_t)std::min<size_t>(8192, (qbytes / 16 + 255) / 256 + 1)), dim3(256), 0, F, qdec, (uint64_t)qbytes, D);   // (many short blocks: slots keep turning over for the two other chains)
+    // (many short blocks: slots keep turning over for the two other chains)
+    hipLaunchKernelGGL(k_dec_fill, dim3((uint32_t)std::min<size_t>(8192, (qbytes / 16 + 255) / 256 + 1)), dim3(256), 0, F, qdec, (uint64_t)qbytes, D);
     if (forked) HIPCHK(ctx, hipEventRecord(ctx->ev_f, F));
     hipLaunchKernelGGL(k_dec_coords, dim3(2, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, B[DB_XV].as<uint32_t>(), B[DB_YV].as<uint32_t>());
     if ((HH.flags & H_N_POS) || ((HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL))) {
@@ -157,13 +171,15 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         if (nn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mq, nn, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, 0u, nstr);
         if (hasn) hipLaunchKernelGGL(k_dec_pos_sum, dim3(mn, 1, n_chunks), dim3(64), 0, A, RFQ_SUM_ARGS, HH.n_normal, nstr);
 #undef RFQ_SUM_ARGS
-        hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(), (const int*)B[DB_SEGA].as<int>(),
+        hipLaunchKernelGGL(k_dec_pos_link, dim3((n_chunks * nstr + 255) / 256), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(),
+                (const int*)B[DB_SEGA].as<int>(),
                            (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), maxseg, n_chunks * nstr);
         if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_mid, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
         hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
         if (nn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mq, nn, n_chunks), dim3(64), 0, S, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
                                    (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, 0u, nstr);
-        if (hasn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mn, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec, sdec,
+        if (hasn) hipLaunchKernelGGL(k_dec_pos_emit, dim3(mn, 1, n_chunks), dim3(64), 0, A, a->d_rfq, CH, D, R, (const uint64_t*)qbase, (const uint64_t*)sbase, qdec,
+                sdec,
                                      (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), maxseg, (uint64_t)a->n, HH.n_normal, nstr);
     } else hipLaunchKernelGGL(k_dec_unpack, dim3(bpc, n_chunks), dim3(256), 0, A, a->d_rfq, CH, R, (const uint64_t*)sbase, sdec, (uint64_t)a->n);
     if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, A)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_f, 0)); }
@@ -177,7 +193,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // ---- text
     if (!fused) ctx->timer.begin("textlen", S);                          // (fused path: still inside "streams", beside the list chain)
     const int split = a->split_pe ? 1 : 0;
-    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(), (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
+    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(),
+            (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
     scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
     if (f_join) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, f_aux)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     aux_guard.armed = false;       // (everything below is ordered behind the chain on the main stream)
@@ -258,7 +275,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     } else if (!ctx->have_hdr) return rfq_fail(ctx, RFQ_E_STATE, "decode without a header: pass has_header=1 or call rfq_set_header first");
     const DevHeader& HH = ctx->h_hdr;
     if (a->split_pe && !(HH.flags & H_PAIRED)) return rfq_fail(ctx, RFQ_E_DATA, "The input RFQ file was encoded by single-end FASTQ, you should not specify <out2>");
-    if (HH.read_len_bytes != 1 && HH.read_len_bytes != 2 && HH.read_len_bytes != 4) return rfq_fail(ctx, RFQ_E_DATA, "header incorrect: read length bytes should be 1/2/4");
+    if (HH.read_len_bytes != 1 && HH.read_len_bytes != 2 && HH.read_len_bytes != 4) return rfq_fail(ctx, RFQ_E_DATA,
+            "header incorrect: read length bytes should be 1/2/4");
     const DevHeader* D = ctx->d_hdr.as<DevHeader>();
 
     // ---- walk the chunk chain
@@ -279,18 +297,24 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             const size_t tb = ((size_t)a->n_chunk_off + 1) * 8;
             HIPCHK(ctx, B[DB_OFFT].ensure(tb));
             HIPCHK(ctx, hipMemcpyAsync(B[DB_OFFT].p, a->h_chunk_off, tb, hipMemcpyHostToDevice, S));
-            hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), a->n_chunk_off, B[DB_CHUNKS].as<DChunk>(), dst);
+            hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), a->n_chunk_off,
+                    B[DB_CHUNKS].as<DChunk>(), dst);
         } else if (guess) {
             HIPCHK(ctx, B[DB_OFFT].ensure(((size_t)cap + 2) * 8));
-            HIPCHK(ctx, B[DB_GWCAND].ensure(GW_SEGS * 8 + 64)); HIPCHK(ctx, B[DB_GWLIST].ensure((size_t)GW_SEGS * GW_LCAP * 8)); HIPCHK(ctx, B[DB_GWCNT].ensure(GW_SEGS * 4 + 64)); HIPCHK(ctx, B[DB_GWLAND].ensure(GW_SEGS * 8 + 64));
+            HIPCHK(ctx, B[DB_GWCAND].ensure(GW_SEGS * 8 + 64)); HIPCHK(ctx, B[DB_GWLIST].ensure((size_t)GW_SEGS * GW_LCAP * 8));
+                    HIPCHK(ctx, B[DB_GWCNT].ensure(GW_SEGS * 4 + 64)); HIPCHK(ctx, B[DB_GWLAND].ensure(GW_SEGS * 8 + 64));
             unsigned long long* cand = B[DB_GWCAND].as<unsigned long long>(); uint32_t* gbad = B[DB_GWCNT].as<uint32_t>() + GW_SEGS;
             HIPCHK(ctx, hipMemsetAsync(cand, 0xFF, GW_SEGS * 8, S)); HIPCHK(ctx, hipMemsetAsync(gbad, 0, 4, S));
-            const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> ctx->opt.gw_shift));   // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
+            // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
+            const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> ctx->opt.gw_shift));
             if (mseg > 1) hipLaunchKernelGGL(k_dec_gw_find, dim3(16, mseg - 1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, cand, mseg);
-            hipLaunchKernelGGL(k_dec_gw_walk, dim3(mseg), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, B[DB_GWLIST].as<unsigned long long>(), B[DB_GWCNT].as<uint32_t>(), B[DB_GWLAND].as<unsigned long long>(), gbad, mseg, a->final ? 1 : 0);
-            hipLaunchKernelGGL(k_dec_gw_stitch, dim3(1), dim3(1024), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand, (const unsigned long long*)B[DB_GWLIST].as<unsigned long long>(),
+            hipLaunchKernelGGL(k_dec_gw_walk, dim3(mseg), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand,
+                    B[DB_GWLIST].as<unsigned long long>(), B[DB_GWCNT].as<uint32_t>(), B[DB_GWLAND].as<unsigned long long>(), gbad, mseg, a->final ? 1 : 0);
+            hipLaunchKernelGGL(k_dec_gw_stitch, dim3(1), dim3(1024), 0, S, a->d_rfq, (uint64_t)a->n, start, D, (const unsigned long long*)cand,
+                    (const unsigned long long*)B[DB_GWLIST].as<unsigned long long>(),
                                (const uint32_t*)B[DB_GWCNT].as<uint32_t>(), (const unsigned long long*)B[DB_GWLAND].as<unsigned long long>(), (const uint32_t*)gbad, B[DB_OFFT].as<uint64_t>(), cap, dst, mseg);
-            hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), 0xFFFFFFFFu, B[DB_CHUNKS].as<DChunk>(), dst);
+            hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), 0xFFFFFFFFu,
+                    B[DB_CHUNKS].as<DChunk>(), dst);
         }
         else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
         KCHK(ctx, "k_dec_walk");
@@ -307,11 +331,13 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         if (use_table) {
             // the table must cover whole chunks up to the end of the image (or up to a tail too short to be a chunk): anything else walks
             // (a range that does not end the image may end inside a chunk: whole chunks in front of it are all a table has to cover there)
-            if (hs.pad || (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0))) { use_table = false; guess = !ctx->opt.walk_exact; continue; }
+            if (hs.pad || (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0))) { use_table = false; guess = !ctx->opt.walk_exact;
+                    continue; }
             break;
         }
         if (hs.overflow) { cap = hs.n_chunks + 1024; continue; }
-        if (!indexed) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; hs.piece_avg = 0xFFFFu; hs.piece_n1 = 0xFFFFu; break; }   // (the exact walk does not look into the quality payloads: such images take the materialising path)
+        // (the exact walk does not look into the quality payloads: such images take the materialising path)
+        if (!indexed) { hs.max_nrec = 0xFFFFFFFFu; hs.max_one = hs.max_stream; hs.per_read_pieces = 1; hs.piece_avg = 0xFFFFu; hs.piece_n1 = 0xFFFFu; break; }
         if (hs.pad) { guess = false; continue; }                           // the guessed index did not verify (foreign writer / corrupt image): walk it properly
         if (hs.n_chunks > PARSE_AHEAD) {
             hipLaunchKernelGGL(k_dec_parse, dim3(hs.n_chunks - PARSE_AHEAD), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, D, B[DB_CHUNKS].as<DChunk>(), dst, PARSE_AHEAD);
@@ -320,9 +346,12 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S));
             HIPCHK(ctx, ctx->fetch_sync(S));
             if (h2.pad) { guess = false; continue; }
-            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec; hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; hs.piece_avg = h2.piece_avg; hs.piece_n1 = h2.piece_n1; memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
+            hs.max_stream = h2.max_stream; hs.max_npos = h2.max_npos; hs.max_len = h2.max_len; hs.max_bases = h2.max_bases; hs.max_nrec = h2.max_nrec;
+                    hs.max_one = h2.max_one; hs.per_read_pieces = h2.per_read_pieces; hs.piece_avg = h2.piece_avg; hs.piece_n1 = h2.piece_n1;
+                    memcpy(hs.base_slots, h2.base_slots, sizeof hs.base_slots);
         }
-        if (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0)) { guess = false; continue; }   // let the exact walk decide about a trailing partial chunk (a range that does not end the image may end inside one)
+        // let the exact walk decide about a trailing partial chunk (a range that does not end the image may end inside one)
+        if (hs.consumed != a->n && a->n - hs.consumed >= 18 && (a->final || hs.n_chunks == 0)) { guess = false; continue; }
         break;
     }
     if (ctx->opt.trace) fprintf(stderr, "[rfq] chunk starts: %s, %u chunks\n", use_table ? "caller's index" : (guess ? "guess-and-verify" : "exact walk"), hs.n_chunks);
@@ -338,7 +367,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     DChunk* CHm = B[DB_CHUNKS].as<DChunk>();
     // (RFQ_SLICE_BASES: test aid - ranges of that many bases, so that the slicing logic runs on small images)
     const uint64_t slice_env = ctx->opt.slice_bases;
-    const uint64_t slice_bases = slice_env ? slice_env : 1500000000ull, one_pass = slice_env ? slice_env : 0xFFFFFFF0ull;   // (a pass whose text turns out to be >= 4 GiB is redone in ranges)
+    // (a pass whose text turns out to be >= 4 GiB is redone in ranges)
+    const uint64_t slice_bases = slice_env ? slice_env : 1500000000ull, one_pass = slice_env ? slice_env : 0xFFFFFFF0ull;
     size_t n1 = 0, n2 = 0; uint64_t nb = 0; uint8_t *o1 = nullptr, *o2 = nullptr;
     int rc = RFQ_RANGE_TOO_BIG;
     // bug_compat: Repaq::decompressPE as it stands (src/repaq.cpp:330-417).  A chunk with a NO_LINE_BREAK bit makes the loop read the chunk behind it
@@ -370,7 +400,9 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         res->n_chunks = 0; for (auto& q : pieces) res->n_chunks += q.c1 - q.c0;
     }
     if (!compat && tb < one_pass && n_reads64 < 0x7FFFFFF0ull) {
-        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.piece_n1 = hs.piece_n1; g.bases = tb;
+        DecRange g; g.CH = CHm; g.n_chunks = n_chunks; g.n_reads = (uint32_t)n_reads64; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream;
+                g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one;
+                g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.piece_n1 = hs.piece_n1; g.bases = tb;
         rc = decode_range(ctx, a, g, a->d_out1, a->cap1, a->d_out2, a->cap2, &o1, &o2, &n1, &n2, &nb);
         if (rc != RFQ_OK && rc != RFQ_RANGE_TOO_BIG) return rc;
     }
@@ -378,7 +410,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
         // Reads, bases and text of one pass are placed by 32-bit prefix sums: a larger image is decoded range by range (contiguous chunks of
         // about slice_bases bases; a range whose text still does not fit is halved), every range into the context's own buffers and from
         // there to its place in the result.
-        if (!compat) { hc.resize(n_chunks); HIPCHK(ctx, hipMemcpy(hc.data(), CHm, (size_t)n_chunks * sizeof(DChunk), hipMemcpyDeviceToHost)); pieces.push_back({ 0, n_chunks, false }); }
+        if (!compat) { hc.resize(n_chunks); HIPCHK(ctx, hipMemcpy(hc.data(), CHm, (size_t)n_chunks * sizeof(DChunk), hipMemcpyDeviceToHost));
+                pieces.push_back({ 0, n_chunks, false }); }
         std::vector<Rng> todo;                                               // stack of [c0, c1), first range on top
         { std::vector<Rng> fw;
           for (auto& pc : pieces) {
@@ -399,7 +432,9 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             const uint32_t c0 = r.c0, c1 = r.c1; uint64_t reads = 0, rbases = 0; for (uint32_t c = c0; c < c1; c++) { reads += hc[c].reads; rbases += hc[c].bases; }
             hipLaunchKernelGGL(k_dec_rebase, dim3((c1 - c0 + 255) / 256), dim3(256), 0, S, CHm + c0, c1 - c0, hc[c0].rbase_abs);
             KCHK(ctx, "k_dec_rebase");
-            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream; g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one; g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.piece_n1 = hs.piece_n1; g.bases = rbases;
+            DecRange g; g.CH = CHm + c0; g.n_chunks = c1 - c0; g.n_reads = (uint32_t)reads; g.max_reads = hs.max_reads; g.max_stream = hs.max_stream;
+                    g.max_npos = hs.max_npos; g.max_len = hs.max_len; g.max_bases = hs.max_bases; g.max_nrec = hs.max_nrec; g.max_one = hs.max_one;
+                    g.pieces = hs.per_read_pieces; g.piece_avg = hs.piece_avg; g.piece_n1 = hs.piece_n1; g.bases = rbases;
             uint8_t *q1 = nullptr, *q2 = nullptr; size_t m1 = 0, m2 = 0; uint64_t mb = 0;
             ctx->timer.reset();
             rc = reads > 0x7FFFFFF0ull ? RFQ_RANGE_TOO_BIG : decode_range(ctx, a, g, nullptr, 0, nullptr, 0, &q1, &q2, &m1, &m2, &mb);
@@ -414,7 +449,8 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
                 if (!hit) acc_ms.emplace_back(ctx->timer.names[i], ctx->timer.ms[i]);
             }
             for (int k = 0; k < (split ? 2 : 1); k++) {
-                uint8_t* src = k ? q2 : q1; const size_t m = k ? m2 : m1; size_t& w = k ? w2 : w1; uint8_t* dcall = k ? a->d_out2 : a->d_out1; const size_t dcap = k ? a->cap2 : a->cap1;
+                uint8_t* src = k ? q2 : q1; const size_t m = k ? m2 : m1; size_t& w = k ? w2 : w1; uint8_t* dcall = k ? a->d_out2 : a->d_out1;
+                        const size_t dcap = k ? a->cap2 : a->cap1;
                 if (!m || (k && r.r1_only)) continue;
                 uint8_t* to;
                 if (dcall) { if (w + m > dcap) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small"); to = dcall + w; }

@@ -36,7 +36,8 @@ struct DecStatus {
     uint32_t max_nrec, max_one;      // most exception records of any chunk / longest single quality stream (by-column quality payloads)
     unsigned long long list_need;    // fused path: entries of all position lists (k_dec_pos_off)
     uint32_t per_read_pieces, piece_avg;  // some chunk stores name1 / name2 / strand per read; the largest average size of a per-read name2 / strand piece over the
-                                     // chunks, as a fraction of its tile capacity in 1/256 (k_dec_emit3: the host sizes its tiles by it, a tile that still does not fit asks for the expanded path)
+                                     // chunks, as a fraction of its tile capacity in 1/256 (k_dec_emit3: the host sizes its tiles by it, a tile that still does not fit
+                                     // asks for the expanded path)
     uint32_t piece_n1, pad4;              // the same for name1, in bytes per read (rounded up): k_dec_emit3 has a second instantiation with a large name1 tile
 };
 
@@ -64,7 +65,8 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
         auto rl = [&](uint32_t r) -> uint32_t { const uint8_t* x = lp + (size_t)r * rlb; return rlb == 1 ? x[0] : (rlb == 2 ? ld_u16(x) : ld_u32(x)); };
         uint32_t mx = 0;
         if (fl & C_READ_LEN_SAME) { mx = rl(0); sum = (unsigned long long)mx * s; }
-        else { for (uint32_t r = (uint32_t)lane_id(); r < s; r += 64) { const uint32_t v = rl(r); sum += v; if (v > mx) mx = v; } sum = wave_sum<unsigned long long>(sum); mx = wave_max(mx); }
+        else { for (uint32_t r = (uint32_t)lane_id(); r < s; r += 64) { const uint32_t v = rl(r); sum += v; if (v > mx) mx = v; } sum = wave_sum<unsigned long long>(sum);
+                mx = wave_max(mx); }
         d.bases = sum; d.max_len = mx; d.nrec = 0; d.max_one = 0; d.pad_ = 0;
     }
 #define RFQ_LENARR(OFF, SIZE, LENFLAG, SAMEFLAG) { \
@@ -95,7 +97,8 @@ __device__ __forceinline__ int parse_chunk(const uint8_t* __restrict__ img, uint
     return 0;
 }
 // One wave walks the image chunk by chunk (each chunk's extent depends on its own length arrays; the reader ignores mSize).
-__global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap, DecStatus* st, int final) {
+__global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, DChunk* __restrict__ out, uint32_t cap,
+        DecStatus* st, int final) {
     const uint32_t hf = D->flags, rlb = D->read_len_bytes; const int l = lane_id();
     uint64_t k = start; uint32_t c = 0, maxr = 0, maxs = 0, maxn = 0, lastfl = 0, maxl = 0, maxb = 0; uint64_t rb = 0, tb = 0; uint32_t err = 0, ovf = 0;
     if (rlb != 1 && rlb != 2 && rlb != 4) err = DE_CORRUPT;
@@ -113,7 +116,8 @@ __global__ void k_dec_walk(const uint8_t* __restrict__ img, uint64_t n, uint64_t
         { const uint32_t b32 = d.bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.bases; if (b32 > maxb) maxb = b32; }
         if (rb > 0xFFFFFFF0ull) { err = DE_CORRUPT; break; }
     }
-    if (l == 0) { st->max_len = maxl; st->max_bases = maxb; st->base_slots[0] = tb; st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb; st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
+    if (l == 0) { st->max_len = maxl; st->max_bases = maxb; st->base_slots[0] = tb; st->err |= err; st->n_chunks = c; st->max_reads = maxr; st->total_reads = rb;
+            st->consumed = k; st->last_flags = lastfl; st->overflow = ovf; st->max_stream = maxs; st->max_npos = maxn; }
 }
 // The chain from a chunk index the caller supplied (rfq_decode_args.h_chunk_off): the read counts of all chunks are fetched in
 // parallel (one workgroup, 256 chunks per round, running read base by a block scan) - no dependent load per chunk.  k_dec_parse
@@ -160,7 +164,8 @@ __global__ void k_dec_table(const uint8_t* __restrict__ img, uint64_t n, const u
 #define GW_SEGS 1024u
 #define GW_LCAP 256u              // chunk starts a segment's walk may record
 struct GwGeo { uint64_t first, seglen, win; uint32_t nseg; };
-__device__ __forceinline__ long long gw_total(uint32_t ms, uint32_t s, uint32_t fl, uint32_t hf) {      // true chunk size from mSize: repaq's writers store mSize = true size - Delta(flags) (accounting bug Q1, a pure function of header and chunk flags)
+// true chunk size from mSize: repaq's writers store mSize = true size - Delta(flags) (accounting bug Q1, a pure function of header and chunk flags)
+__device__ __forceinline__ long long gw_total(uint32_t ms, uint32_t s, uint32_t fl, uint32_t hf) {
     const uint32_t h = (fl & C_PE_INTERLEAVED) ? s / 2 : s; long long total = (long long)ms;
     if (hf & H_LANE) total += (fl & C_LANE_SAME) ? 1 : (long long)h;
     if (!(hf & H_TILE)) total -= (fl & C_TILE_SAME) ? 2 : 2ll * h;
@@ -203,7 +208,8 @@ __device__ __forceinline__ GwGeo gw_geo(const uint8_t* __restrict__ img, uint64_
     return g;
 }
 // cand[k] = the lowest plausible chunk start in the window at the head of segment k (k >= 1; cand[0] = start); ~0 when there is none
-__global__ void k_dec_gw_find(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, unsigned long long* __restrict__ cand, uint32_t max_seg) {
+__global__ void k_dec_gw_find(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, unsigned long long* __restrict__ cand,
+        uint32_t max_seg) {
     const uint32_t hf = D->flags; const GwGeo g = gw_geo(img, n, start, hf, max_seg);
     const uint32_t k = blockIdx.y + 1u; if (k >= g.nseg) return;
     const uint64_t g0 = start + (uint64_t)k * g.seglen;
@@ -226,13 +232,17 @@ __global__ void k_dec_gw_find(const uint8_t* __restrict__ img, uint64_t n, uint6
             const uint64_t ii = i + (uint64_t)u * stride;
             if (ii >= g.win) continue;
             if (g0 + ii + 6 + 32 > n) {                                       // the image's last bytes: offset by offset
-                for (uint32_t j = 0; j < 16 && ii + j < g.win; j++) { const uint64_t o = g0 + ii + j; if (o + 18 <= n && !(((const LdsU4*)(img + o + 6))->a & 0xF000FF00u) && gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k], (unsigned long long)o); }
+                for (uint32_t j = 0; j < 16 && ii + j < g.win; j++) { const uint64_t o = g0 + ii + j;
+                        if (o + 18 <= n && !(((const LdsU4*)(img + o + 6))->a & 0xF000FF00u) && gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k],
+                        (unsigned long long)o); }
                 continue;
             }
             uint32_t hit = 0;
 #pragma unroll
-            for (int j = 0; j < 16; j++) { const uint32_t w = (uint32_t)((((unsigned long long)d[u][(j >> 2) + 1] << 32) | d[u][j >> 2]) >> (8 * (j & 3))); if (!(w & 0xF000FF00u)) hit |= 1u << j; }
-            while (hit) { const int j = __ffs((int)hit) - 1; hit &= hit - 1; const uint64_t o = g0 + ii + (uint32_t)j; if (ii + (uint32_t)j < g.win && o + 18 <= n && gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k], (unsigned long long)o); }
+            for (int j = 0; j < 16; j++) { const uint32_t w = (uint32_t)((((unsigned long long)d[u][(j >> 2) + 1] << 32) | d[u][j >> 2]) >> (8 * (j & 3)));
+                    if (!(w & 0xF000FF00u)) hit |= 1u << j; }
+            while (hit) { const int j = __ffs((int)hit) - 1; hit &= hit - 1; const uint64_t o = g0 + ii + (uint32_t)j;
+                    if (ii + (uint32_t)j < g.win && o + 18 <= n && gw_plausible(img, n, o, hf, false, nullptr)) atomicMin(&cand[k], (unsigned long long)o); }
         }
     }
 }
@@ -260,10 +270,12 @@ __global__ void k_dec_gw_walk(const uint8_t* __restrict__ img, uint64_t n, uint6
     if (lane_id() == 0) { cnt[k] = c | (ended << 31); land[k] = o; if (b) atomicOr(bad, 1u); }     // (bit 31: the chain ended in this segment)
 }
 // every walk must land on the next candidate; the lists, concatenated, are the chunk index (off[0 .. n_chunks], the last entry = where the chain ended)
-__global__ void __launch_bounds__(1024) k_dec_gw_stitch(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D, const unsigned long long* __restrict__ cand,
+__global__ void __launch_bounds__(1024) k_dec_gw_stitch(const uint8_t* __restrict__ img, uint64_t n, uint64_t start, const DevHeader* __restrict__ D,
+        const unsigned long long* __restrict__ cand,
                                 const unsigned long long* __restrict__ list, const uint32_t* __restrict__ cnt, const unsigned long long* __restrict__ land, const uint32_t* __restrict__ bad,
                                 uint64_t* __restrict__ off, uint32_t cap, DecStatus* st, uint32_t max_seg) {
-    __shared__ uint32_t s_base[GW_SEGS + 1], s_cnt[GW_SEGS]; __shared__ unsigned long long s_cand[GW_SEGS], s_land[GW_SEGS]; __shared__ uint32_t s_fail; __shared__ unsigned long long s_end;
+    __shared__ uint32_t s_base[GW_SEGS + 1], s_cnt[GW_SEGS]; __shared__ unsigned long long s_cand[GW_SEGS], s_land[GW_SEGS]; __shared__ uint32_t s_fail;
+            __shared__ unsigned long long s_end;
     const uint32_t hf = D->flags; const GwGeo g = gw_geo(img, n, start, hf, max_seg);
     for (uint32_t k = threadIdx.x; k < g.nseg; k += blockDim.x) { s_cand[k] = k == 0 ? (unsigned long long)start : cand[k]; s_cnt[k] = cnt[k]; s_land[k] = land[k]; }
     __syncthreads();
@@ -279,13 +291,16 @@ __global__ void __launch_bounds__(1024) k_dec_gw_stitch(const uint8_t* __restric
             if (s_cnt[k] >> 31) open = false;                                // the chain has ended
         }
         s_base[g.nseg] = tot; s_fail = fail; s_end = expect;
-        if (g.first == 0 && start < n && n - start >= 18 && ld_u32(img + start + 4) != 0) s_fail = 1;      // (the first header itself is not plausible: let the chain decide)
+        // (the first header itself is not plausible: let the chain decide)
+        if (g.first == 0 && start < n && n - start >= 18 && ld_u32(img + start + 4) != 0) s_fail = 1;
     }
     __syncthreads();
     const uint32_t tot = s_base[g.nseg];
     if (s_fail || tot > cap) { if (threadIdx.x == 0) { st->pad = s_fail ? 1u : 0u; st->overflow = (!s_fail && tot > cap) ? 1u : 0u; st->n_chunks = tot; } return; }
-    // (a wave per segment: its list is a handful of entries; sixteen waves - with four, a wave copied 50 segments one dependent load -> store after the other: 50 of the kernel's 55 us)
-    for (uint32_t k = threadIdx.x >> 6; k < g.nseg; k += blockDim.x >> 6) { const uint32_t c = s_cnt[k] & 0x7FFFFFFFu; if (s_cand[k] == ~0ull) continue; for (uint32_t i = threadIdx.x & 63u; i < c; i += 64u) off[s_base[k] + i] = list[(size_t)k * GW_LCAP + i]; }
+    // (a wave per segment: its list is a handful of entries; sixteen waves - with four, a wave copied 50 segments one dependent load -> store after the other: 50 of the
+    // kernel's 55 us)
+    for (uint32_t k = threadIdx.x >> 6; k < g.nseg; k += blockDim.x >> 6) { const uint32_t c = s_cnt[k] & 0x7FFFFFFFu; if (s_cand[k] == ~0ull) continue;
+            for (uint32_t i = threadIdx.x & 63u; i < c; i += 64u) off[s_base[k] + i] = list[(size_t)k * GW_LCAP + i]; }
     if (threadIdx.x == 0) { off[tot] = s_end; st->n_chunks = tot; st->pad = 0; st->overflow = 0; }
 }
 // a range of chunks is decoded as a batch of its own: its reads count from 0
@@ -322,8 +337,10 @@ __global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint
         if ((d.flags & (C_NAME1_SAME | C_NAME2_SAME | C_STRAND_SAME)) != (C_NAME1_SAME | C_NAME2_SAME | C_STRAND_SAME)) pr = 1;
         if (d.reads) {                                                     // per-read pieces: bytes per read against the emitter's tile capacity for that piece
             if (!(d.flags & C_NAME1_SAME)) { const uint32_t v = (d.n1_size + d.reads - 1) / d.reads; if (v > p1) p1 = v; }
-            if (!(d.flags & C_NAME2_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.n2_size * 256ull / d.reads + ET_N2CAP - 1) / ET_N2CAP); if (v > pa) pa = v; }
-            if (!(d.flags & C_STRAND_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.st_size * 256ull / d.reads + ET_STCAP - 1) / ET_STCAP); if (v > pa) pa = v; }
+            if (!(d.flags & C_NAME2_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.n2_size * 256ull / d.reads + ET_N2CAP - 1) / ET_N2CAP);
+                    if (v > pa) pa = v; }
+            if (!(d.flags & C_STRAND_SAME)) { const uint32_t v = (uint32_t)(((unsigned long long)d.st_size * 256ull / d.reads + ET_STCAP - 1) / ET_STCAP);
+                    if (v > pa) pa = v; }
         }
         if (d.qual_size > m0) m0 = d.qual_size;
         if (d.npos_size > m1) m1 = d.npos_size;
@@ -337,7 +354,8 @@ __global__ void k_dec_summary(const DChunk* __restrict__ CH, DecStatus* st, uint
     if (__any(pr != 0) && lane_id() == 0) atomicOr(&st->per_read_pieces, 1u);
     pa = wave_max(pa); if (pa && lane_id() == 0) atomicMax(&st->piece_avg, pa);
     p1 = wave_max(p1); if (p1 && lane_id() == 0) atomicMax(&st->piece_n1, p1);
-    if (lane_id() == 0) { atomicMax(&st->max_stream, m0); atomicMax(&st->max_npos, m1); atomicMax(&st->max_len, m2); atomicMax(&st->max_bases, m3); atomicMax(&st->max_nrec, m4); atomicMax(&st->max_one, m5);
+    if (lane_id() == 0) { atomicMax(&st->max_stream, m0); atomicMax(&st->max_npos, m1); atomicMax(&st->max_len, m2); atomicMax(&st->max_bases, m3);
+            atomicMax(&st->max_nrec, m4); atomicMax(&st->max_one, m5);
                           atomicAdd((unsigned long long*)&st->base_slots[0], sum); }
 }
 
@@ -378,7 +396,8 @@ __global__ void k_dec_bases(const DChunk* __restrict__ CH, DReadTab R, uint64_t*
 // 2-bit unpack (src/rfqcodec.cpp:833-853): grid (blocks, n_chunks).  One thread turns 4 packed bytes into 16 bases and stores them
 // as one aligned uint4 (the chunk's base in sdec is 64-byte aligned); byte stores cost ~30 cycles per wave instruction.
 __device__ __forceinline__ uint32_t ld_word_lim(const uint8_t* p, const uint8_t* lim);
-__global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec, uint64_t img_bytes) {
+__global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, DReadTab R, const uint64_t* __restrict__ sbase, uint8_t* __restrict__ sdec,
+        uint64_t img_bytes) {
     // packed byte -> its four bases without a table: two shift-and-mask steps spread the four 2-bit codes over four bytes, v_perm_b32
     // looks them up in the 4-entry G A T C table (an LDS table cost a bank-conflicted read per byte and a fill per block)
     auto unpack4v = [](uint32_t b) -> uint32_t {
@@ -394,14 +413,16 @@ __global__ void k_dec_unpack(const uint8_t* __restrict__ img, const DChunk* __re
     for (uint32_t g0 = blockIdx.x * blockDim.x + threadIdx.x; g0 < ngroups; g0 += 4 * NT) {
         uint32_t lo[4], hi[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t gi = g0 + (uint32_t)u * NT; lo[u] = hi[u] = 0; if (gi < ngroups) { lo[u] = ld_word_lim(sa + 4 * (size_t)gi, lim); if (ph) hi[u] = ld_word_lim(sa + 4 * (size_t)gi + 4, lim); } }
+        for (int u = 0; u < 4; u++) { const uint32_t gi = g0 + (uint32_t)u * NT; lo[u] = hi[u] = 0; if (gi < ngroups) { lo[u] = ld_word_lim(sa + 4 * (size_t)gi, lim);
+                if (ph) hi[u] = ld_word_lim(sa + 4 * (size_t)gi + 4, lim); } }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t gi = g0 + (uint32_t)u * NT; if (gi >= ngroups) continue;
             const uint32_t pk = ph ? (uint32_t)((((uint64_t)hi[u] << 32) | lo[u]) >> sh) : lo[u];
             uint32_t w[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t i = 4 * gi + (uint32_t)k; w[k] = i < d.seq_size ? unpack4v((pk >> (8 * k)) & 0xFFu) : 0x4E4E4E4Eu; }   // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
+            // beyond mSeqBuf the 'N' prefill of allSeq stays (src/rfqcodec.cpp:1088)
+            for (int k = 0; k < 4; k++) { const uint32_t i = 4 * gi + (uint32_t)k; w[k] = i < d.seq_size ? unpack4v((pk >> (8 * k)) & 0xFFu) : 0x4E4E4E4Eu; }
             if (16 * gi + 16 <= n) *(uint4*)(dst + 16 * (size_t)gi) = make_uint4(w[0], w[1], w[2], w[3]);
             else for (uint32_t p = 16 * gi; p < n; p++) dst[p] = (uint8_t)(w[(p >> 2) & 3u] >> (8 * (p & 3u)));
         }
@@ -477,7 +498,8 @@ struct PosFront { unsigned long long v; uint32_t bt[4], fn[4], Fin; };
 __device__ __forceinline__ PosFront pos_front(const PosStep& w, const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0, int l) {
     PosFront f; f.v = pos_bytes8(w, sp, slen, i0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const bool valid = i0 + (uint32_t)k < slen; f.bt[k] = (uint32_t)(f.v >> (8 * k)) & 0xFFu; f.fn[k] = valid ? fn_of_len(pos_tok_len(f.bt[k])) : POS_ID; }
+    for (int k = 0; k < 4; k++) { const bool valid = i0 + (uint32_t)k < slen; f.bt[k] = (uint32_t)(f.v >> (8 * k)) & 0xFFu;
+            f.fn[k] = valid ? fn_of_len(pos_tok_len(f.bt[k])) : POS_ID; }
     uint32_t F = fn_compose(fn_compose(fn_compose(f.fn[0], f.fn[1]), f.fn[2]), f.fn[3]);
     (void)l;
     f.Fin = wave_scan_compose(F);
@@ -704,7 +726,8 @@ __device__ __forceinline__ void pos_lane_adv_cnt4(const PosFront& f, uint32_t sl
 // positions advanced, segA[8 * idx + 4 + s] = positions emitted for entry state s
 __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
                                uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes, uint32_t jj0, uint32_t nstr) {
-    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id();
+            const uint8_t* lim = img + img_bytes;
     const DChunk d = CH[c];
     const PosSrc s = pos_src_of(img, d, D, jj, g == 0 ? st : nullptr);
     if (g == 0 && l == 0) segN[(size_t)c * nstr + jj] = (s.slen + POS2_SEG - 1) / POS2_SEG;
@@ -745,7 +768,8 @@ __device__ __forceinline__ PosLink poslink_shfl_up(const PosLink& v, unsigned dd
     for (int s = 0; s < 4; s++) { u.a[s] = __shfl_up(v.a[s], dd); u.n[s] = __shfl_up(v.n[s], dd); }
     return u;
 }
-__global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __restrict__ segA, const uint32_t* __restrict__ segN, uint8_t* __restrict__ segS, int* __restrict__ segP,
+__global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __restrict__ segA, const uint32_t* __restrict__ segN, uint8_t* __restrict__ segS,
+        int* __restrict__ segP,
                                 uint32_t* __restrict__ segK, uint32_t* __restrict__ nent, uint32_t maxseg, uint32_t n_streams) {
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(); if (t >= n_streams) return;
     const int l = lane_id(); const uint32_t n = segN[t];
@@ -790,7 +814,8 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
                                const uint8_t* __restrict__ segS, const int* __restrict__ segP, const uint32_t* __restrict__ segK, const unsigned long long* __restrict__ loff,
                                uint32_t* __restrict__ plist, unsigned long long cap, uint32_t* __restrict__ cellidx, uint32_t maxseg, uint32_t ncell, uint64_t img_bytes, uint32_t jj0, uint32_t nstr, const DecStatus* st) {
     if (st->list_need > cap) return;                                      // (uniform) the arena is too small: the host repeats the pass
-    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id(); const uint8_t* lim = img + img_bytes;
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id();
+            const uint8_t* lim = img + img_bytes;
     const DChunk d = CH[c];
     const PosSrc s = pos_src_of(img, d, D, jj, nullptr);
     const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
@@ -898,7 +923,8 @@ __global__ void k_dec_fill(uint8_t* __restrict__ p, uint64_t n, const DevHeader*
 }
 
 // decodeCoords (src/rfqcodec.cpp:1332-1389): one wave per (axis, chunk)
-__global__ void k_dec_coords(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, uint32_t* __restrict__ xv, uint32_t* __restrict__ yv) {
+__global__ void k_dec_coords(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, uint32_t* __restrict__ xv,
+        uint32_t* __restrict__ yv) {
     const uint32_t axis = blockIdx.x, c = blockIdx.y;
     if (!(D->flags & (axis ? H_Y : H_X))) return;
     const DChunk d = CH[c]; const uint8_t* sp = img + d.off + (axis ? d.o_y : d.o_x) + 4; const uint32_t slen = axis ? d.y_size : d.x_size;
@@ -1038,7 +1064,8 @@ __device__ __forceinline__ StageSpan make_span(uint4* lds4, const uint8_t* gbase
 // destination, ~300 per wave and tile in a VALU-bound kernel).  UMAX = groups per thread the caller's capacities allow for the
 // span (a slower loop covers anything beyond).  A span that ends >= 16 bytes before its buffer's limit loads without per-group
 // limit tests.
-static __device__ __noinline__ void stage_span_slow(const uint8_t* g, uint64_t a0, uint32_t ng, uint4* l, uint64_t lim, uint32_t from) {   // byte-wise near the buffer's limit
+// byte-wise near the buffer's limit
+static __device__ __noinline__ void stage_span_slow(const uint8_t* g, uint64_t a0, uint32_t ng, uint4* l, uint64_t lim, uint32_t from) {
     for (uint32_t i = threadIdx.x + from; i < ng; i += blockDim.x) {
         const uint64_t ga = a0 + 16ull * i; uint32_t w[4] = { 0, 0, 0, 0 };
         for (uint32_t b = 0; b < 16 && ga + b < lim; b++) w[b >> 2] |= (uint32_t)g[ga + b] << (8 * (b & 3));
@@ -1129,12 +1156,14 @@ __device__ __forceinline__ void emit_copy(uint8_t* o, const uint8_t* pool, uint3
             if (rev) { w[0] = comp4_acgtn(w[0]); w[1] = comp4_acgtn(w[1]); w[2] = comp4_acgtn(w[2]); w[3] = comp4_acgtn(w[3]); }
             if (implied_n) {
                 uint32_t qw[4]; lds_get16(pool, rev ? qsrc + n - p0 - 16u : qsrc + p0, qw);
-                if (rev) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3; }
+                if (rev) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2;
+                        qw[3] = x3; }
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const uint32_t mk = eq_bytes_full(qw[i], (nq & 0xFFu) * 0x01010101u); w[i] = (w[i] & ~mk) | (0x4E4E4E4Eu & mk); }
             }
         }
-        if (PAT && pat >= (int)p0 && pat < (int)p0 + 16) { const int b = pat - (int)p0; const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& x = w[b >> 2]; x = (x & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
+        if (PAT && pat >= (int)p0 && pat < (int)p0 + 16) { const int b = pat - (int)p0; const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& x = w[b >> 2];
+                x = (x & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
         uint8_t* q = o + p0;
         if (!small) { LdsU16 v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(LdsU16*)q = v; }
         else {
@@ -1247,9 +1276,11 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
             const bool nextm = cur + cnt < re && tid <= ET_READS && cur + cnt + tid <= re;
             EMIT_META_VARS
             if (nextm) EMIT_META_LOAD(cur + cnt)
-            const StageSpan sp[6] = { make_span(s_q4 + 1, qdec, qa, qe, qdec_bytes, tiled), make_span(s_s4 + 1, sdec, sa, se, sdec_bytes, tiled),   // +1: 16 readable bytes in front
+            // +1: 16 readable bytes in front
+            const StageSpan sp[6] = { make_span(s_q4 + 1, qdec, qa, qe, qdec_bytes, tiled), make_span(s_s4 + 1, sdec, sa, se, sdec_bytes, tiled),
                                       make_span(s_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, tiled),
-                                      make_span(s_n14, img, n1a, n1e, img_bytes, n1l), make_span(s_n24, img, n2a, n2e, img_bytes, n2l), make_span(s_st4, img, sta, ste, img_bytes, stl_) };
+                                      make_span(s_n14, img, n1a, n1e, img_bytes, n1l), make_span(s_n24, img, n2a, n2e, img_bytes, n2l), make_span(s_st4, img, sta, ste,
+                                              img_bytes, stl_) };
             stage_spans6<(int)((ET_SCAP / 16 + 4 + 255) / 256)>(sp);                 // groups per thread at 256 threads
             if (nextm) EMIT_META_STORE(s_next)
         }
@@ -1270,7 +1301,8 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
             const uint8_t* const pool = (const uint8_t*)s_src4;
             for (uint32_t slot = tid; slot < 8u * ET_READS; slot += blockDim.x) {
                 const uint32_t rs_ = slot;
-                const uint32_t j = rs_ % ET_READS, kind = rs_ / ET_READS;         // 0,1 quality halves; 2,3 sequence halves; 4 borrowed part; 5 name1; 6 middle + newlines; 7 name2 + strand
+                // 0,1 quality halves; 2,3 sequence halves; 4 borrowed part; 5 name1; 6 middle + newlines; 7 name2 + strand
+                const uint32_t j = rs_ % ET_READS, kind = rs_ / ET_READS;
                 if (j >= cnt) continue;
                 const uint32_t* m = s_meta + EM_ROW * j; const bool odd = ((cur + j) & 1u) != 0, to2 = split && odd, rc = il && odd;
                 const uint32_t rec = (to2 ? recB : recA) + m[0], len = m[1], mid = m[11];
@@ -1282,7 +1314,8 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
                 for (int sub = 0; sub < (kind == 7 ? 2 : 1); sub++) {         // (slot 7 copies two short pieces)
                     uint32_t n, dst, src, qsrc = 0; bool rev = false; int pat = -1, half = -1;   // pat: piece offset of the byte to patch (name2)
                     const uint32_t qs = 16u * EG_Q + qoff + (m[15] - q0);
-                    if (kind <= 1) { n = len; dst = rec + m[10] + len + 1 + m[6] + 1; src = qs; rev = rc; half = (int)kind; }     // quality (back to front for an RC mate)
+                    // quality (back to front for an RC mate)
+                    if (kind <= 1) { n = len; dst = rec + m[10] + len + 1 + m[6] + 1; src = qs; rev = rc; half = (int)kind; }
                     else if (kind <= 4) {
                         // sequence: interleaved-orientation positions p in [0, xa) come from sA + p, p in [xa, len) from sB + (p - xa) (the
                         // part a negative overlap borrowed from the mate); an RC mate emits complemented, back to front
@@ -1355,7 +1388,8 @@ __global__ void k_dec_emit(const uint8_t* __restrict__ img, const DChunk* __rest
 //   * the bases are never expanded to a byte tile: a lane takes 16 codes from the staged 2-bit stream at any bit offset (8-byte LDS read + shift),
 //     reverses / complements them in 2-bit space, looks the letters up with v_perm_b32 and patches N from a bit tile the N list was scattered into;
 //   * the quality group of the same 16 positions is in registers at that moment (same lane), which is all the implied-N rule needs.
-// Everything else - the lists' exact entry ranges from the cell index, wave-per-list rounds, the next tile's metadata requested a tile ahead - carries over from the tile emitter this kernel replaced.
+// Everything else - the lists' exact entry ranges from the cell index, wave-per-list rounds, the next tile's metadata requested a tile ahead - carries over from the tile
+// emitter this kernel replaced.
 #define E3_QCAP 10240u            // quality tile: K reads' qualities (64 x 160)
 #define E3_N1BIG 13312u           // name1 tile of the second instantiation: 64 per-read names of 200 bytes (34 KB of LDS, four workgroups per CU)
 struct __attribute__((packed, aligned(1))) GU16d { uint32_t a, b, c, d; };
@@ -1369,7 +1403,8 @@ __device__ __forceinline__ void e3_copy(uint8_t* __restrict__ dst, const uint8_t
         for (uint32_t g = g0; g < ng; g += gs) {
             uint32_t p0 = 16u * g; if (p0 + 16u > n) p0 = n - 16u;
             uint32_t w[4]; lds_get16(src, p0, w);
-            if (pat >= (int)p0 && pat < (int)p0 + 16) { const int b = pat - (int)p0; const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& x = w[b >> 2]; x = (x & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
+            if (pat >= (int)p0 && pat < (int)p0 + 16) { const int b = pat - (int)p0; const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& x = w[b >> 2];
+                    x = (x & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); }
             GU16d v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16d*)(dst + p0) = v;
         }
     } else if (g0 == 0 && n) {
@@ -1382,23 +1417,28 @@ __device__ __forceinline__ void e3_copy(uint8_t* __restrict__ dst, const uint8_t
         if (n & 1u) *q = (uint8_t)w[0];
     }
 }
-__device__ __forceinline__ uint32_t e3_rev2x16(uint32_t v) { v = bswap32(v); v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4); return ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2); }
+__device__ __forceinline__ uint32_t e3_rev2x16(uint32_t v) { v = bswap32(v); v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+        return ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2); }
 __device__ __forceinline__ uint32_t e3_rev1x16(uint32_t v) {
     v = ((v >> 8) & 0xFFu) | ((v & 0xFFu) << 8); v = ((v >> 4) & 0x0F0Fu) | ((v & 0x0F0Fu) << 4);
     v = ((v >> 2) & 0x3333u) | ((v & 0x3333u) << 2); return ((v >> 1) & 0x5555u) | ((v & 0x5555u) << 1);
 }
 // dword i of the mask "bytes >= t of a 16-byte group" (t <= 0: all of them, t >= 16: none)
 __device__ __forceinline__ uint32_t e3_from(int t, int i) { const int k = t - 4 * i; return k <= 0 ? 0xFFFFFFFFu : (k >= 4 ? 0u : 0xFFFFFFFFu << (8 * k)); }
-__device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }   // v_alignbyte_b32
-template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds__(256, N1CAP == ET_N1CAP ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+// v_alignbyte_b32
+__device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }
+template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds__(256, N1CAP == ET_N1CAP ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img,
+        const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
                            uint32_t ncell, uint32_t nstr, uint32_t kshift) {
     __shared__ uint4 t_q4[E3_QCAP / 16 + 6];                                // quality tile (16 bytes of slack in front, the rest behind)
     __shared__ uint4 t_pk4[E3_QCAP / 64 + 6];                               // the tile's packed bases
     __shared__ uint32_t t_nb[E3_QCAP / 32 + 8];                             // one bit per stored base of the tile: is N
-    __shared__ uint4 t_mid4_[64 * 40 / 16 + 5], t_n14_[N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];      // (N1CAP: E3_N1BIG for files with long per-read names)
-    uint4* const t_mid4 = t_mid4_ + 1; uint4* const t_n14 = t_n14_ + 1; uint4* const t_n24 = t_n24_ + 1;   // (16 readable bytes in front of each: a 16-byte group of the name line may start before a piece)
+    // (N1CAP: E3_N1BIG for files with long per-read names)
+    __shared__ uint4 t_mid4_[64 * 40 / 16 + 5], t_n14_[N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];
+    // (16 readable bytes in front of each: a 16-byte group of the name line may start before a piece)
+    uint4* const t_mid4 = t_mid4_ + 1; uint4* const t_n14 = t_n14_ + 1; uint4* const t_n24 = t_n24_ + 1;
     __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
     __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2];
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
@@ -1417,7 +1457,8 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
     const uint32_t major4 = (D->major & 0xFFu) * 0x01010101u;
     const uint32_t qlen_c = R.pq[f + d.reads] - pq0, slen_c = R.pv[f + d.reads].d - pv0.d;      // qualities / stored bases of the chunk
     const bool same1 = (fl & C_NAME1_SAME) != 0, same2 = (fl & C_NAME2_SAME) != 0, same3 = (fl & C_STRAND_SAME) != 0;
-    if (tid < T) { const uint32_t jj = tid < nn ? tid : D->n_normal; const size_t t_ = (size_t)c * nstr + jj; s_loff[tid] = loff[t_]; s_nent[tid] = nent[t_]; s_val[tid] = tid < nn ? (uint32_t)D->normal[tid] : (uint32_t)'N'; }
+    if (tid < T) { const uint32_t jj = tid < nn ? tid : D->n_normal; const size_t t_ = (size_t)c * nstr + jj; s_loff[tid] = loff[t_]; s_nent[tid] = nent[t_];
+            s_val[tid] = tid < nn ? (uint32_t)D->normal[tid] : (uint32_t)'N'; }
     // exception records behind the streams (src/rfqcodec.cpp:1034-1043)
     uint32_t nrec = 0; const uint8_t* xrec = nullptr;
     if (bycol && 4ull * D->n_normal <= d.qual_size) {
@@ -1456,14 +1497,18 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         const uint32_t cnt = re - cur < K ? re - cur : K, g0 = f + cur, g1 = g0 + cnt;
         const TileP tp = tp_cur; const uint32_t q0 = tp.q0, q1 = tp.q1, s0 = tp.s0, s1 = tp.s1;
         const bool fits = q1 - q0 <= E3_QCAP && (same1 || tp.e7 - tp.a7 + 32u <= N1CAP) && (same2 || tp.e8 - tp.a8 + 32u <= ET_N2CAP) && (same3 || tp.e9 - tp.a9 + 32u <= ET_STCAP);
-        if (!fits) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_E3_RETRY); break; }   // (the host sizes K by the longest read and by the chunks' average piece sizes; a tile whose pieces are longer than that allowed for: the host repeats the range with k_dec_emit2)
+        // (the host sizes K by the longest read and by the chunks' average piece sizes; a tile whose pieces are longer than that allowed for: the host repeats the range
+        // with k_dec_emit2)
+        if (!fits) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_E3_RETRY); break; }
         // ---- stage: packed bases, middles, per-read name pieces (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
         const uint64_t ib = d.off;
         const uint64_t n1a = ib + d.o_n1 + (same1 ? 0u : tp.a7), n1e = same1 ? n1a + d.n1_size : ib + d.o_n1 + tp.e7;
         const uint64_t n2a = ib + d.o_n2 + (same2 ? 0u : tp.a8), n2e = same2 ? n2a + d.n2_size : ib + d.o_n2 + tp.e8;
         const uint64_t sta = ib + d.o_st + (same3 ? 0u : tp.a9), ste = same3 ? sta + d.st_size : ib + d.o_st + tp.e9;
-        uint64_t pka = ib + d.o_seq + (s0 >> 2), pke = ib + d.o_seq + ((s1 + 3u) >> 2); { const uint64_t pend = ib + d.o_seq + d.seq_size; if (pke > pend) pke = pend; if (pka > pke) pka = pke; }
-        uint64_t rqa = ib + d.o_qual + q0, rqe = ib + d.o_qual + q1; { const uint64_t qend = ib + d.o_qual + d.qual_size; if (rqe > qend) rqe = qend; if (rqa > rqe) rqa = rqe; }
+        uint64_t pka = ib + d.o_seq + (s0 >> 2), pke = ib + d.o_seq + ((s1 + 3u) >> 2); { const uint64_t pend = ib + d.o_seq + d.seq_size; if (pke > pend) pke = pend;
+                if (pka > pke) pka = pke; }
+        uint64_t rqa = ib + d.o_qual + q0, rqe = ib + d.o_qual + q1; { const uint64_t qend = ib + d.o_qual + d.qual_size; if (rqe > qend) rqe = qend;
+                if (rqa > rqe) rqa = rqe; }
         if (raw) span_dma<(int)((E3_QCAP / 16 + 4 + 255) / 256)>(make_span(t_q4 + 1, img, rqa, rqe, img_bytes, true));
         if (w == 0) span_dma_wave<(int)((E3_QCAP / 64 + 4 + 63) / 64)>(make_span(t_pk4, img, pka, pke, img_bytes, true), l);
         else if (w == 1) span_dma_wave<(int)((64 * 40 / 16 + 4 + 63) / 64)>(make_span(t_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
@@ -1471,7 +1516,8 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, n2a, n2e, img_bytes, true), l);
                if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, sta, ste, img_bytes, true), l); }
         // qualities start as the major value (src/rfqcodec.cpp:1089), the N bits as none
-        if (bycol) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4; for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
+        if (bycol) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4;
+                for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         for (uint32_t i = tid; i < ((s1 - s0 + 31u) >> 5) + 1u; i += blockDim.x) t_nb[i] = 0;
         // ---- the tile's list entries, requested now and scattered after the barrier (wave w takes the lists w, w + 4, ...)
         uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const uint32_t* ls_p = plist;
@@ -1523,12 +1569,15 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const uint32_t p = e_[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
             }
-            if (nrec) for (uint32_t i = tid; i < nrec; i += blockDim.x) { const uint8_t* rr = xrec + 5ull * i; const uint32_t pos = ld_u32(rr + 1); if (pos >= q0 && pos < q1 && pos < qlen_c) q_t[pos - q0] = rr[0]; }
+            if (nrec) for (uint32_t i = tid; i < nrec; i += blockDim.x) { const uint8_t* rr = xrec + 5ull * i; const uint32_t pos = ld_u32(rr + 1);
+                    if (pos >= q0 && pos < q1 && pos < qlen_c) q_t[pos - q0] = rr[0]; }
             if (hasn) {
                 const uint32_t send = s1 < slen_c ? s1 : slen_c;
 #pragma unroll
                 for (int i = 0; i < 2; i++) { const uint32_t p = pn[i]; if (p >= s0 && p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); }
-                if (nk0 != 0xFFFFFFFFu && nk0 + 512u < nke) { const uint32_t* lp = plist + s_loff[nn]; for (uint32_t kk = nk0 + 512u + tid; kk < nke; kk += 256u) { const uint32_t p = lp[kk]; if (p >= s0 && p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); } }
+                if (nk0 != 0xFFFFFFFFu && nk0 + 512u < nke) { const uint32_t* lp = plist + s_loff[nn];
+                        for (uint32_t kk = nk0 + 512u + tid; kk < nke; kk += 256u) { const uint32_t p = lp[kk];
+                        if (p >= s0 && p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); } }
             }
         }
         // the next tile's list cells (its parameters have come back by now)
@@ -1560,7 +1609,8 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
 #pragma unroll
                             for (int i = 0; i < 4; i++) { const uint32_t m = e3_from(t1, i); w[i] = (w[i] & ~m) | (x[i] & m); } }
                         if (t2 < 16 && t3 > 0 && n2) { lds_get16(src3 - t2, 0, x);
-                            if (pat2 >= 0) { const int b = t2 + pat2; if (b >= 0 && b < 16) { const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& y = x[b >> 2]; y = (y & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); } }
+                            if (pat2 >= 0) { const int b = t2 + pat2; if (b >= 0 && b < 16) { const uint32_t sh = 8u * (uint32_t)(b & 3); uint32_t& y = x[b >> 2];
+                                    y = (y & ~(0xFFu << sh)) | ((dch & 0xFFu) << sh); } }
 #pragma unroll
                             for (int i = 0; i < 4; i++) { const uint32_t m = e3_from(t2, i); w[i] = (w[i] & ~m) | (x[i] & m); } }
                         if (t3 == 15) w[3] = (w[3] & 0x00FFFFFFu) | 0x0A000000u;                           // (the line's last byte, in its last group only)
@@ -1582,7 +1632,9 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
                     const uint32_t bit = sbit0 + 2u * si, byte = bit >> 3; const unsigned long long v = lds_get8(pk, byte);
                     cw = (uint32_t)(v >> (bit & 7u));
                     const uint32_t nb_ = lds_get4((const uint8_t*)t_nb, (si >> 3)) >> (si & 7u); nw = nb_ & 0xFFFFu;
-                    if (byte + 5u > have) { uint32_t lim_ = 4u * have > sbit0 / 2u + si ? 4u * have - sbit0 / 2u - si : 0u; if (lim_ < 16u) nw |= (0xFFFFu << lim_) & 0xFFFFu; }   // bases past the packed buffer read as N (the reference's 'N' prefill)
+                    // bases past the packed buffer read as N (the reference's 'N' prefill)
+                    if (byte + 5u > have) { uint32_t lim_ = 4u * have > sbit0 / 2u + si ? 4u * have - sbit0 / 2u - si : 0u;
+                            if (lim_ < 16u) nw |= (0xFFFFu << lim_) & 0xFFFFu; }
                 };
                 auto group = [&](uint32_t k0, uint32_t (&qw)[4], uint32_t (&sw)[4]) {   // output positions [k0, k0 + 16) of both lines (k0 + 16 <= len)
                     const uint32_t pa = rc ? len - k0 - 16u : k0;
@@ -1590,14 +1642,18 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
                     uint32_t cw, nw;
                     if (pa + 16u <= xa) fetch(A + pa, cw, nw);
                     else if (pa >= xa) fetch(Bs + (pa - xa), cw, nw);
-                    else { uint32_t c2, n2_; const uint32_t t1 = xa - pa; fetch(A + pa, cw, nw); fetch(Bs, c2, n2_); cw = (cw & ((1u << (2u * t1)) - 1u)) | (c2 << (2u * t1)); nw = (nw & ((1u << t1) - 1u)) | ((n2_ << t1) & 0xFFFFu); }
-                    if (rc) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3;
+                    else { uint32_t c2, n2_; const uint32_t t1 = xa - pa; fetch(A + pa, cw, nw); fetch(Bs, c2, n2_);
+                            cw = (cw & ((1u << (2u * t1)) - 1u)) | (c2 << (2u * t1)); nw = (nw & ((1u << t1) - 1u)) | ((n2_ << t1) & 0xFFFFu); }
+                    if (rc) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2;
+                            qw[3] = x3;
                               cw = ~e3_rev2x16(cw); if (nw) nw = e3_rev1x16(nw); }
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { const uint32_t b = (cw >> (8 * i)) & 0xFFu, y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u; sw[i] = __builtin_amdgcn_perm(0u, 0x43544147u, idx); }
+                    for (int i = 0; i < 4; i++) { const uint32_t b = (cw >> (8 * i)) & 0xFFu, y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u;
+                            sw[i] = __builtin_amdgcn_perm(0u, 0x43544147u, idx); }
                     if (nw) {                                                   // (rare: an N among the 16)
 #pragma unroll
-                        for (int i = 0; i < 4; i++) { const uint32_t mk = ((((nw >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu; sw[i] = (sw[i] & ~mk) | (0x4E4E4E4Eu & mk); }
+                        for (int i = 0; i < 4; i++) { const uint32_t mk = ((((nw >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+                                sw[i] = (sw[i] & ~mk) | (0x4E4E4E4Eu & mk); }
                     }
                     if (implied_n) {
 #pragma unroll

@@ -65,7 +65,8 @@ static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t 
     HIPCHK(ctx, B[B_NKEEP].ensure(((size_t)nblk + 2) * 4)); HIPCHK(ctx, B[B_NTERM].ensure(((size_t)nblk + 2) * 4));
     HIPCHK(ctx, B[B_SCANTMP].ensure(std::max<size_t>(1024, ((size_t)nblk / SCAN_TILE + 2) * 16)));
     NormIn in; in.fq = fq; in.n = (uint32_t)n; in.file_off = file_off; in.file_end = final ? file_off + n : ~0ull;
-    hipLaunchKernelGGL(k_norm_classify, dim3(nblk), dim3(256), 0, S, in, B[B_TBITS].as<uint64_t>(), B[B_SBITS].as<uint64_t>(), B[B_NKEEP].as<uint32_t>(), B[B_NTERM].as<uint32_t>());
+    hipLaunchKernelGGL(k_norm_classify, dim3(nblk), dim3(256), 0, S, in, B[B_TBITS].as<uint64_t>(), B[B_SBITS].as<uint64_t>(), B[B_NKEEP].as<uint32_t>(),
+            B[B_NTERM].as<uint32_t>());
     KCHK(ctx, "k_norm_classify");
     scan_exclusive<uint32_t>(S, B[B_NKEEP].as<uint32_t>(), B[B_NKEEP].as<uint32_t>(), nblk, B[B_SCANTMP].as<uint32_t>(), 1);
     scan_exclusive<uint32_t>(S, B[B_NTERM].as<uint32_t>(), B[B_NTERM].as<uint32_t>(), nblk, B[B_SCANTMP].as<uint32_t>(), 1);
@@ -73,7 +74,8 @@ static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t 
     HIPCHK(ctx, ctx->fetch(&keep, B[B_NKEEP].as<uint32_t>() + nblk, 4, S));
     HIPCHK(ctx, ctx->fetch(&terms, B[B_NTERM].as<uint32_t>() + nblk, 4, S));
     HIPCHK(ctx, ctx->fetch_sync(S));
-    HIPCHK(ctx, B[B_NORM0 + s].ensure((size_t)keep + 64)); HIPCHK(ctx, B[B_OT0 + s].ensure(((size_t)terms + 4) * 4)); HIPCHK(ctx, B[B_ONX0 + s].ensure(((size_t)terms + 4) * 4));
+    HIPCHK(ctx, B[B_NORM0 + s].ensure((size_t)keep + 64)); HIPCHK(ctx, B[B_OT0 + s].ensure(((size_t)terms + 4) * 4));
+            HIPCHK(ctx, B[B_ONX0 + s].ensure(((size_t)terms + 4) * 4));
     hipLaunchKernelGGL(k_norm_emit, dim3(nblk), dim3(256), 0, S, in, (const uint64_t*)B[B_TBITS].as<uint64_t>(), (const uint64_t*)B[B_SBITS].as<uint64_t>(),
                        (const uint32_t*)B[B_NKEEP].as<uint32_t>(), (const uint32_t*)B[B_NTERM].as<uint32_t>(), B[B_NORM0 + s].as<uint8_t>(), B[B_OT0 + s].as<uint32_t>(), B[B_ONX0 + s].as<uint32_t>());
     hipLaunchKernelGGL(k_norm_tail, dim3(1), dim3(64), 0, S, B[B_OT0 + s].as<uint32_t>(), B[B_ONX0 + s].as<uint32_t>(), terms, (uint32_t)n);
@@ -83,15 +85,18 @@ static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t 
     return RFQ_OK;
 }
 
-static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only, const uint32_t* skip);
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only,
+        const uint32_t* skip);
 
 // One call's worth of text (< 4 GiB per stream; the stream pointers may sit at any byte address: they are rounded down to 16 bytes and the
 // bytes in front are skipped by the indexer)
 static int encode_one(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, bool scan_only) {
     memset(res, 0, sizeof *res);
     rfq_encode_args al = *a; uint32_t skip[2] = { 0, 0 };
-    if (a->n1 && a->d_fq1) { skip[0] = (uint32_t)((uintptr_t)a->d_fq1 & 15u); al.d_fq1 = a->d_fq1 - skip[0]; al.n1 = a->n1 + skip[0]; al.file_off1 = a->file_off1 - skip[0]; }
-    if (a->paired == RFQ_PE_TWO_FILES && a->n2 && a->d_fq2) { skip[1] = (uint32_t)((uintptr_t)a->d_fq2 & 15u); al.d_fq2 = a->d_fq2 - skip[1]; al.n2 = a->n2 + skip[1]; al.file_off2 = a->file_off2 - skip[1]; }
+    if (a->n1 && a->d_fq1) { skip[0] = (uint32_t)((uintptr_t)a->d_fq1 & 15u); al.d_fq1 = a->d_fq1 - skip[0]; al.n1 = a->n1 + skip[0];
+            al.file_off1 = a->file_off1 - skip[0]; }
+    if (a->paired == RFQ_PE_TWO_FILES && a->n2 && a->d_fq2) { skip[1] = (uint32_t)((uintptr_t)a->d_fq2 & 15u); al.d_fq2 = a->d_fq2 - skip[1]; al.n2 = a->n2 + skip[1];
+            al.file_off2 = a->file_off2 - skip[1]; }
     int rc = encode_impl(ctx, &al, res, nullptr, ~0u, false, scan_only, skip);
     if (rc != RFQ_NEED_NORM) return rc;
     // slow path: '\r' line ends or blank lines (src/fastqreader.cpp:94-196)
@@ -135,7 +140,8 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
         // to what is left of ITS file (as far as one call can address), and the call ends the input there like the reference does (it truncates
         // to the shorter file).  (With the other slice left at its size the slice ran as a non-final one, the short file's last records - less
         // than a chunk - were never flushed, and the call failed with "no whole chunk".)
-        if (two && (t1 == r1) != (t2 == r2)) { const size_t grow = slice_env ? 64 * slice_env : lim; if (t1 == r1) t2 = std::min(r2, grow); else t1 = std::min(r1, grow); }
+        if (two && (t1 == r1) != (t2 == r2)) { const size_t grow = slice_env ? 64 * slice_env : lim; if (t1 == r1) t2 = std::min(r2, grow); else t1 = std::min(r1, grow);
+                }
         const bool last = t1 == r1 && t2 == r2;
         rfq_encode_args s = *a;
         s.d_fq1 = a->d_fq1 + pos1; s.n1 = t1; s.file_off1 = a->file_off1 + pos1;
@@ -170,7 +176,8 @@ static int encode_or_scan(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_res
     }
     ctx->timer.names.clear(); ctx->timer.ms.clear();
     for (auto& q : acc) { ctx->timer.names.push_back(q.first); ctx->timer.ms.push_back(q.second); }
-    res->n_chunks = chunks; res->n_reads = reads; res->n_bases = bases; res->consumed1 = pos1; res->consumed2 = pos2; res->input_ended = ended; res->reserved = scan_only ? ub : 0;
+    res->n_chunks = chunks; res->n_reads = reads; res->n_bases = bases; res->consumed1 = pos1; res->consumed2 = pos2; res->input_ended = ended;
+            res->reserved = scan_only ? ub : 0;
     if (scan_only) { ctx->scan_end[0] = e1; ctx->scan_end[1] = e2; return RFQ_OK; }
     ctx->chunk_off = offs; res->h_chunk_off = ctx->chunk_off.data();
     res->rfq_len = written; res->d_rfq = written ? (a->d_out ? a->d_out : ctx->out_acc.as<uint8_t>()) : nullptr;
@@ -183,13 +190,15 @@ extern "C" int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* a, rfq_scan_r
     rfq_encode_result r;
     const int rc = encode_or_scan(ctx, a, &r, true);
     if (rc != RFQ_OK) return rc;
-    out->n_chunks = r.n_chunks; out->n_reads = r.n_reads; out->consumed1 = r.consumed1; out->consumed2 = r.consumed2; out->input_ended = r.input_ended; out->unit_bases = (uint32_t)r.reserved;
+    out->n_chunks = r.n_chunks; out->n_reads = r.n_reads; out->consumed1 = r.consumed1; out->consumed2 = r.consumed2; out->input_ended = r.input_ended;
+            out->unit_bases = (uint32_t)r.reserved;
     out->h_end1 = r.n_chunks ? ctx->scan_end[0].data() : nullptr;
     out->h_end2 = (r.n_chunks && a->paired == RFQ_PE_TWO_FILES) ? ctx->scan_end[1].data() : nullptr;
     return RFQ_OK;
 }
 
-static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only, const uint32_t* skip) {
+static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result* res, const NormMap* nm, uint32_t unit_cap, bool ended, bool scan_only,
+        const uint32_t* skip) {
     memset(res, 0, sizeof *res);
     res->input_ended = ended ? 1 : 0;
     const bool fin = a->final || ended || a->flush_all;
@@ -200,7 +209,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // skip[s] (< 16): leading bytes of stream s that are not part of it (see k_nl_bitmap); a stream that holds nothing else is empty
     const size_t nbytes[2] = { a->n1 > skip[0] ? a->n1 : 0, nstreams == 2 ? (a->n2 > skip[1] ? a->n2 : 0) : 0 };
     for (int s = 0; s < nstreams; s++) {
-        if (nbytes[s] >= 0xFFFFFFF0ull) return rfq_fail(ctx, RFQ_E_ARG, "a FASTQ stream of one batch must be < 4 GiB (got %zu bytes); split at record boundaries", nbytes[s]);
+        if (nbytes[s] >= 0xFFFFFFF0ull) return rfq_fail(ctx, RFQ_E_ARG, "a FASTQ stream of one batch must be < 4 GiB (got %zu bytes); split at record boundaries",
+                nbytes[s]);
         if (nbytes[s] && !fq[s]) return rfq_fail(ctx, RFQ_E_ARG, "null FASTQ pointer");
         if (((uintptr_t)fq[s]) & 15u) return rfq_fail(ctx, RFQ_E_ARG, "FASTQ device pointers must be 16-byte aligned");
     }
@@ -265,7 +275,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, B[B_SCANTMP].ensure(scantmp));
         for (int s = 0; s < nstreams; s++) {
             if (!nblk[s]) continue;
-            hipLaunchKernelGGL(k_nl_bitmap, dim3(nblk[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], skip[s], B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), dst);
+            hipLaunchKernelGGL(k_nl_bitmap, dim3(nblk[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], skip[s], B[B_BITMAP0 + s].as<uint64_t>(),
+                    B[B_BLK0 + s].as<uint32_t>(), dst);
             KCHK(ctx, "k_nl_bitmap");
             scan_exclusive<uint32_t>(S, B[B_BLK0 + s].as<uint32_t>(), B[B_BLK0 + s].as<uint32_t>(), nblk[s], B[B_SCANTMP].as<uint32_t>(), 1);
         }
@@ -286,7 +297,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         nlines[s] = n_newlines[s] + (unterm ? 1u : 0u); nrec[s] = nlines[s] / 4;
         if (!one_pass || !nblk[s]) HIPCHK(ctx, B[B_LO0 + s].ensure(((size_t)nlines[s] + 4) * 4));
         if (nblk[s]) {
-            if (!one_pass) hipLaunchKernelGGL(k_line_offsets, dim3(nblk[s]), dim3(256), 0, S, B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(), (uint32_t)nbytes[s], skip[s], B[B_LO0 + s].as<uint32_t>());
+            if (!one_pass) hipLaunchKernelGGL(k_line_offsets, dim3(nblk[s]), dim3(256), 0, S, B[B_BITMAP0 + s].as<uint64_t>(), B[B_BLK0 + s].as<uint32_t>(),
+                    (uint32_t)nbytes[s], skip[s], B[B_LO0 + s].as<uint32_t>());
             hipLaunchKernelGGL(k_line_tail, dim3(1), dim3(64), 0, S, B[B_LO0 + s].as<uint32_t>(), n_newlines[s], (uint32_t)nbytes[s], unterm);
             KCHK(ctx, "k_line_offsets");
         }
@@ -295,7 +307,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
 
     // ---- phase 2: read table, chunk cuts
     Text T; memset(&T, 0, sizeof T);
-    for (int s = 0; s < 2; s++) { T.fq[s] = fq[s]; T.n[s] = (uint32_t)nbytes[s]; T.lo[s] = s < nstreams ? B[B_LO0 + s].as<uint32_t>() : nullptr; T.ot[s] = nm && s < nstreams ? nm->ot[s] : nullptr; }
+    for (int s = 0; s < 2; s++) { T.fq[s] = fq[s]; T.n[s] = (uint32_t)nbytes[s]; T.lo[s] = s < nstreams ? B[B_LO0 + s].as<uint32_t>() : nullptr;
+            T.ot[s] = nm && s < nstreams ? nm->ot[s] : nullptr; }
     T.paired = a->paired; T.upr = a->paired == RFQ_SE ? 1u : 2u;
     uint32_t n_units = a->paired == RFQ_SE ? nrec[0] : (a->paired == RFQ_PE_TWO_FILES ? std::min(nrec[0], nrec[1]) : nrec[0] / 2);
     if (n_units > unit_cap) n_units = unit_cap;                       // the reader stopped at an empty line (src/fastqreader.cpp:180-191)
@@ -305,18 +318,22 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     const bool is_pe = a->paired != RFQ_SE;
 
     // (an early return must not leave the second stream running over buffers that are about to be reused)
-    struct AuxGuard { rfq_ctx* c; bool armed; void sync() { if (armed) { (void)hipStreamSynchronize(c->aux); armed = false; } } ~AuxGuard() { sync(); } } ovl_guard = { ctx, false };
+    struct AuxGuard { rfq_ctx* c; bool armed; void sync() { if (armed) { (void)hipStreamSynchronize(c->aux); armed = false; } } ~AuxGuard() { sync();
+            } } ovl_guard = { ctx, false };
     ctx->timer.begin("lens+cut", S);
     const size_t nr = (size_t)n_reads + 2;
     HIPCHK(ctx, B[B_LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N1LEN].ensure(nr * 4)); HIPCHK(ctx, B[B_N2OFF].ensure(nr * 4));
-    HIPCHK(ctx, B[B_X].ensure(nr * 4)); HIPCHK(ctx, B[B_Y].ensure(nr * 4)); HIPCHK(ctx, B[B_TILE].ensure(nr * 2)); HIPCHK(ctx, B[B_LANE].ensure(nr)); HIPCHK(ctx, B[B_OK].ensure(nr));
+    HIPCHK(ctx, B[B_X].ensure(nr * 4)); HIPCHK(ctx, B[B_Y].ensure(nr * 4)); HIPCHK(ctx, B[B_TILE].ensure(nr * 2)); HIPCHK(ctx, B[B_LANE].ensure(nr));
+            HIPCHK(ctx, B[B_OK].ensure(nr));
     HIPCHK(ctx, B[B_CHUNK].ensure(nr * 4)); HIPCHK(ctx, B[B_STORED].ensure(nr * 4)); HIPCHK(ctx, B[B_EQ2].ensure(nr)); HIPCHK(ctx, B[B_PQ].ensure(nr * 4));
     HIPCHK(ctx, B[B_PV].ensure(nr * 16)); HIPCHK(ctx, B[B_PVIN].ensure(nr * 16));
     HIPCHK(ctx, B[B_ULEN].ensure(((size_t)n_units + 2) * 8)); HIPCHK(ctx, B[B_P].ensure(((size_t)n_units + 2) * 8));
     HIPCHK(ctx, B[B_SCANTMP].ensure(std::max<size_t>(1024, (nr / SCAN_TILE + 2) * 16)));
     ReadTab R;
-    R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>(); R.y = B[B_Y].as<uint32_t>();
-    R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>(); R.stored = B[B_STORED].as<uint32_t>();
+    R.len = B[B_LEN].as<uint32_t>(); R.name1_len = B[B_N1LEN].as<uint32_t>(); R.name2_off = B[B_N2OFF].as<uint32_t>(); R.x = B[B_X].as<uint32_t>();
+            R.y = B[B_Y].as<uint32_t>();
+    R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>();
+            R.stored = B[B_STORED].as<uint32_t>();
     R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
     // sequence lengths come from the line table alone; the names are parsed where the text is staged anyway (k_gather2), or by k_read_table for
     // the reads that need them earlier (chunk 0 of a first batch: the file header) / on the byte-wise gather path (all of them)
@@ -364,7 +381,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (nstreams == 2) HIPCHK(ctx, ctx->fetch(ctx->scan_end[1].data(), e2, (size_t)n_chunks * 8, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
         const size_t lim0 = nm ? nm->orig_n[0] : nbytes[0], lim1 = nm ? nm->orig_n[1] : nbytes[1];
-        for (auto& v : ctx->scan_end[0]) { if (v > lim0) v = lim0; if (!nm) v -= skip[0]; }   // (a virtual terminator past an unterminated last line; offsets count from the stream's own first byte)
+        // (a virtual terminator past an unterminated last line; offsets count from the stream's own first byte)
+        for (auto& v : ctx->scan_end[0]) { if (v > lim0) v = lim0; if (!nm) v -= skip[0]; }
         for (auto& v : ctx->scan_end[1]) { if (v > lim1) v = lim1; if (!nm) v -= skip[1]; }
         res->n_chunks = n_chunks; res->n_reads = reads_used; res->n_bases = total_bases; res->reserved = (int32_t)hs.unit_bases;
         res->consumed1 = (size_t)ctx->scan_end[0].back(); res->consumed2 = nstreams == 2 ? (size_t)ctx->scan_end[1].back() : 0;
@@ -385,7 +403,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     C.flags = B[B_CFLAGS].as<uint32_t>(); C.il = B[B_IL].as<uint32_t>(); C.ncount = B[B_NCOUNT].as<uint32_t>();
     HIPCHK(ctx, B[B_NMAP].ensure(nc * NMAP_WORDS * 4)); C.nmap = B[B_NMAP].as<uint32_t>();
     HIPCHK(ctx, B[B_PTOT].ensure(nc * sizeof(U4))); C.ptot = B[B_PTOT].as<U4>();
-    C.scap = B[B_SCAP].as<uint32_t>(); C.soff = B[B_SOFF].as<uint64_t>(); C.ssize = B[B_SSIZE].as<uint32_t>(); C.xsize = B[B_XSIZE].as<uint32_t>(); C.ysize = B[B_YSIZE].as<uint32_t>();
+    C.scap = B[B_SCAP].as<uint32_t>(); C.soff = B[B_SOFF].as<uint64_t>(); C.ssize = B[B_SSIZE].as<uint32_t>(); C.xsize = B[B_XSIZE].as<uint32_t>();
+            C.ysize = B[B_YSIZE].as<uint32_t>();
     C.qbase = B[B_QBASE].as<uint64_t>(); C.sbase = B[B_SBASE].as<uint64_t>(); C.img_size = B[B_IMGSIZE].as<uint64_t>(); C.img_off = B[B_IMGOFF].as<uint64_t>();
     DevHeader* D = ctx->d_hdr.as<DevHeader>();
     Layout* L = B[B_LAYOUT].as<Layout>();
@@ -425,7 +444,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         KCHK(ctx, "k_hdr_*");
         if (hdr_aside) HIPCHK(ctx, hipEventRecord(ctx->ev_mid, HS));
     } else if (fast && !ctx->dense_ok) {
-        // a header that was set, not made (rfq_set_header: a worker of a multi-GPU queue, a later file): which coded values are frequent is taken from this batch's chunk 0
+        // a header that was set, not made (rfq_set_header: a worker of a multi-GPU queue, a later file): which coded values are frequent is taken from this batch's chunk
+        // 0
         HdrStats* H = B[B_HSTATS].as<HdrStats>();
         const uint32_t hb = std::min<uint32_t>(1024, (c0_reads + 3) / 4);
         hipLaunchKernelGGL(k_hdr_init, dim3(1), dim3(128), 0, S, H);
@@ -460,7 +480,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks, 1);
     // the stored-base prefix (it needs the mates' overlaps): k_overlap_apply, per-read prefix inputs, their scan, the chunks' bases in the tight streams
     auto stored_prefix = [&](hipStream_t Q, U4* tmp) {
-        if (is_pe) hipLaunchKernelGGL(k_overlap_apply, dim3((np + 255) / 256), dim3(256), 0, Q, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb, np);
+        if (is_pe) hipLaunchKernelGGL(k_overlap_apply, dim3((np + 255) / 256), dim3(256), 0, Q, R, C, (const DevHeader*)D, (const int16_t*)B[B_OVRAW].as<int16_t>(), ovb,
+                np);
         hipLaunchKernelGGL(k_pv_in, dim3((n_reads + 255) / 256), dim3(256), 0, Q, T, R, B[B_PVIN].as<U4>(), n_reads);
         scan_exclusive<U4>(Q, B[B_PVIN].as<U4>(), R.pv, n_reads, tmp, 1);
         hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, Q, R, C, n_chunks, 2);
@@ -471,7 +492,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // byte-wise gather: it writes the stored bases themselves, so chunk flags, the overlap search (on the text) and the stored prefix come first
         const uint32_t fbx = std::max(1u, std::min<uint32_t>((max_reads + 255) / 256, std::max(1u, 4096u / n_chunks)));
         hipLaunchKernelGGL(k_chunk_flags_a, dim3(fbx, n_chunks), dim3(256), 0, S, T, R, C, (const DevHeader*)D, is_pe ? 1 : 0, cbits, cfail);
-        hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail,
+                (uint32_t*)nullptr);
         if (is_pe) {
             const uint32_t ob = std::min<uint32_t>((n_units + 255) / 256, 65535u * 16u);
             hipLaunchKernelGGL(k_overlap<false>, dim3(ob), dim3(256), 0, S, T, noz, B[B_OVRAW].as<int16_t>(), n_units);
@@ -481,7 +503,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     ctx->timer.end(S);
 
-    if (masks) { ctx->timer.begin("quality_masks", S); ctx->timer.end(S); }   // (a marker, not a phase: k_gather2 leaves match masks instead of quality bytes - tests and the bench look for it)
+    // (a marker, not a phase: k_gather2 leaves match masks instead of quality bytes - tests and the bench look for it)
+    if (masks) { ctx->timer.begin("quality_masks", S); ctx->timer.end(S); }
     ctx->timer.begin(fast ? "gather" : "gather_bytes", S);                  // (which formulation ran: tests and the bench look at it)
     // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
     const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
@@ -489,8 +512,10 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
     HIPCHK(ctx, B[B_SPK].ensure((catbytes >> 4) * 4 + 64)); HIPCHK(ctx, B[B_SNM].ensure((catbytes >> 4) * 2 + 64));
     HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
-    HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
-    uint64_t* const ctot = B[B_CTOTAL].as<uint64_t>(); uint64_t* const cbase = B[B_CBASE].as<uint64_t>(); uint64_t* const ctot_n = B[B_CTOTALN].as<uint64_t>(); uint64_t* const cbase_n = B[B_CBASEN].as<uint64_t>();
+    HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S));
+            HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
+    uint64_t* const ctot = B[B_CTOTAL].as<uint64_t>(); uint64_t* const cbase = B[B_CBASE].as<uint64_t>(); uint64_t* const ctot_n = B[B_CTOTALN].as<uint64_t>();
+            uint64_t* const cbase_n = B[B_CBASEN].as<uint64_t>();
     bool aux_chain = false, coder_waits = false;
     if (fast) {
         const size_t nld = (size_t)(total_bases >> 4) + reads_used + 16;
@@ -510,9 +535,11 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             // five planes laid out by the buffer's capacity (so that the planes' places are fixed while the buffer is), + rare[n_chunks] behind them
             const size_t need_w = (catbytes >> 5) + 16, extra_w = nc * (1u + G2_RARE_LIST) / G2_PLANES + 16;
             if (B[B_QPLANE].cap / 4 / G2_PLANES < need_w + extra_w || ctx->qplane_stride < need_w) {
-                HIPCHK(ctx, B[B_QPLANE].ensure((need_w + extra_w) * G2_PLANES * 4)); ctx->qplane_stride = B[B_QPLANE].cap / 4 / G2_PLANES - extra_w; ctx->qplane_dirty = true;
+                HIPCHK(ctx, B[B_QPLANE].ensure((need_w + extra_w) * G2_PLANES * 4)); ctx->qplane_stride = B[B_QPLANE].cap / 4 / G2_PLANES - extra_w;
+                        ctx->qplane_dirty = true;
             }
-            if ((ctx->qplane_stride + extra_w) * G2_PLANES * 4 > B[B_QPLANE].cap) { ctx->qplane_stride = B[B_QPLANE].cap / 4 / G2_PLANES - extra_w; ctx->qplane_dirty = true; }
+            if ((ctx->qplane_stride + extra_w) * G2_PLANES * 4 > B[B_QPLANE].cap) { ctx->qplane_stride = B[B_QPLANE].cap / 4 / G2_PLANES - extra_w;
+                    ctx->qplane_dirty = true; }
             uint32_t dmask = 0; for (uint32_t d = 0; d < M.nd; d++) dmask |= 1u << (ctx->h_hdr.dense[d] & 7u);
             if (ctx->qplane_mask & ~dmask) ctx->qplane_dirty = true;        // (a plane that was stored whole is now set bit by bit: it has to start all-zero)
             ctx->qplane_mask = dmask;
@@ -527,16 +554,19 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             const uint32_t* only = phase == 2 ? (const uint32_t*)redo : (const uint32_t*)nullptr;
             if (phase == 2) hipLaunchKernelGGL(k_gather_redo_reset, dim3(n_chunks), dim3(64), 0, S, only, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg,
                                                masks ? M.planes : (uint32_t*)nullptr, M.pstride, (const DevHeader*)D, M.nd, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase);
-            if (masks) hipLaunchKernelGGL(k_mask_bounds, dim3(n_chunks), dim3(64), 0, S, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase, M.planes, M.pstride, (const DevHeader*)D, M.nd, bx, only);
+            if (masks) hipLaunchKernelGGL(k_mask_bounds, dim3(n_chunks), dim3(64), 0, S, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase,
+                    M.planes, M.pstride, (const DevHeader*)D, M.nd, bx, only);
 #define RFQ_G2_ARGS T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_RFLAG].as<uint8_t>(), \
                     B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, cbits, cfail, only, text4, M
             if (masks) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
             else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
 #undef RFQ_G2_ARGS
-            if (phase == 1) hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits, (const uint32_t*)cfail, redo);
+            if (phase == 1) hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits,
+                    (const uint32_t*)cfail, redo);
         }
         // the quality streams' scratch plan needs nothing else: the position coder can start as soon as the host has sized its arena
-        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 1);
+        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(),
+                n_seg, 1);
         scan_exclusive<uint64_t>(S, ctot, cbase, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
         hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst);
         // Second chain (aux stream), beside the position coder: overlap search on the loose slots the gather has just left, stored prefix, sequence packer
@@ -561,12 +591,14 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
             uint32_t rshift = 8; while (rshift && ((uint64_t)(max_len / 16u + 1u) << rshift) > SP_OWN) rshift--;
             uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
-            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), aux_chain ? ctx->opt.sp_pad : 0u, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const U4*)C.ptot, (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
+            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), aux_chain ? ctx->opt.sp_pad : 0u, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const U4*)C.ptot,
+                    (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
                                C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift);
         }
         uint64_t* tmp2 = B[B_SCANTMP2].as<uint64_t>() + (nr / SCAN_TILE + 2) * 2;   // (behind the U4 scan's part of the buffer)
-        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, A, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 2);
+        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, A, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(),
+                n_seg, 2);
         scan_exclusive<uint64_t>(A, ctot_n, cbase_n, n_chunks, tmp2, 1);
         hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, A, T, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
         scan_exclusive<uint64_t>(A, C.img_size, C.img_off, n_chunks, tmp2, 1);
@@ -576,11 +608,14 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
         // workgroups per chunk: each takes a contiguous run of reads in tiles of <= 32
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + GT_READS - 1) / GT_READS, 5u * ctx->n_cu);   // (30 KB of LDS: five workgroups per CU)
-        hipLaunchKernelGGL(k_gather, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
+        hipLaunchKernelGGL(k_gather, dim3(bx, n_chunks), dim3(256), 0, S, T, R, C, (const int8_t*)ovb, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(),
+                B[B_SCAT].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg);
         const uint32_t px = grid_x_for(n_chunks, (hs.max_chunk_bases / 16u + 255u) / 256u + 1u, 8u * ctx->n_cu);
-        hipLaunchKernelGGL(k_packbytes, dim3(px, n_chunks), dim3(256), 0, S, (const U4*)R.pv, (const uint32_t*)C.first, (const uint64_t*)C.sbase, (const uint8_t*)B[B_SCAT].as<uint8_t>(),
+        hipLaunchKernelGGL(k_packbytes, dim3(px, n_chunks), dim3(256), 0, S, (const U4*)R.pv, (const uint32_t*)C.first, (const uint64_t*)C.sbase,
+                (const uint8_t*)B[B_SCAT].as<uint8_t>(),
                            B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>());
-        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, 3);
+        hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(),
+                n_seg, 3);
         scan_exclusive<uint64_t>(S, ctot, cbase, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
         scan_exclusive<uint64_t>(S, ctot_n, cbase_n, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
         hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, T, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
@@ -617,14 +652,16 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (coder_list && g0 == 0 && gn >= nqg) {                          // the value streams; what is left of the request (exception group, N group) below
             const uint64_t mb = (uint64_t)((n_chunks + 7) / 8) * 8ull * n_seg;
             if (mb > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
-            hipLaunchKernelGGL(k_pos_coder_list, dim3((uint32_t)mb), dim3(64), std::min<uint32_t>(HH.n_normal, NPOS_SLOT) * 128u, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase,
+            hipLaunchKernelGGL(k_pos_coder_list, dim3((uint32_t)mb), dim3(64), std::min<uint32_t>(HH.n_normal, NPOS_SLOT) * 128u, Q, R, C, (const DevHeader*)D,
+                    (const uint8_t*)B[B_QCAT].as<uint8_t>(), B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase,
                                B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, dst);
             g0 = nqg; gn -= nqg;
             if (gn == 0) return RFQ_OK;
         }
         const uint64_t pc_blocks = (uint64_t)((n_chunks + 7) / 8) * 8ull * gn * n_seg;
         if (pc_blocks > 0x7FFFFFFFull) return rfq_fail(ctx, RFQ_E_ARG, "batch too large for the position-coder grid");
-        hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(), (const uint16_t*)B[B_SNM].as<uint16_t>(),
+        hipLaunchKernelGGL(k_pos_coder, dim3((uint32_t)pc_blocks), dim3(64), 0, Q, R, C, (const DevHeader*)D, (const uint8_t*)B[B_QCAT].as<uint8_t>(),
+                (const uint16_t*)B[B_SNM].as<uint16_t>(),
                            B[B_SCRATCH].as<uint8_t>(), (const uint64_t*)cbase, B[B_SCRATCHN].as<uint8_t>(), (const uint64_t*)cbase_n,
                            B[B_SEGB].as<uint32_t>(), (const int*)B[B_SEGC].as<int>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, n_chunks, nqg, g0, gn, dst,
                            masks ? (const uint32_t*)B[B_QPLANE].as<uint32_t>() : (const uint32_t*)nullptr, (uint64_t)ctx->qplane_stride);
@@ -663,14 +700,16 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     KCHK(ctx, "k_pos_coder");
     if (masks) {                                                            // the rare planes back to all-zero (stream-ordered behind the coder that read them)
-        hipLaunchKernelGGL(k_rare_cleanup, dim3(n_chunks), dim3(256), 0, S, B[B_QPLANE].as<uint32_t>() + G2_PLANES * ctx->qplane_stride, B[B_QPLANE].as<uint32_t>(), (uint64_t)ctx->qplane_stride,
+        hipLaunchKernelGGL(k_rare_cleanup, dim3(n_chunks), dim3(256), 0, S, B[B_QPLANE].as<uint32_t>() + G2_PLANES * ctx->qplane_stride, B[B_QPLANE].as<uint32_t>(),
+                (uint64_t)ctx->qplane_stride,
                            (const DevHeader*)D, ctx->qplane_nd, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase);
         ctx->qplane_dirty = false;
     }
     ctx->timer.end(S);
     ctx->timer.begin("coords+layout", S);
     HIPCHK(ctx, B[B_SEGD].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGS].ensure(nsb * 4));
-    hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const DevHeader*)D, (const uint32_t*)B[B_SEGB].as<uint32_t>(), (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, B[B_SEGD].as<uint32_t>(), B[B_SEGS].as<uint32_t>());
+    hipLaunchKernelGGL(k_pos_sizes, dim3(n_chunks), dim3(64), 0, S, C, (const DevHeader*)D, (const uint32_t*)B[B_SEGB].as<uint32_t>(),
+            (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, B[B_SEGD].as<uint32_t>(), B[B_SEGS].as<uint32_t>());
     hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, T, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
     hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 1, dst);
@@ -715,7 +754,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, hipMemcpy(&v, (axis ? R.y : R.x) + f + (size_t)i * (ilv ? 2 : 1), 4, hipMemcpyDeviceToHost));
         return rfq_fail(ctx, RFQ_E_DATA, "The X/Y coordinate cannot be larger than 2M, but we get: %u", v);
     }
-    if ((hs.err & DE_TAIL_BLANK) && !nm) return RFQ_NEED_NORM;         // (rare: the tail chunk's line-break bits need the normaliser's verdict on a blank line behind the records)
+    // (rare: the tail chunk's line-break bits need the normaliser's verdict on a blank line behind the records)
+    if ((hs.err & DE_TAIL_BLANK) && !nm) return RFQ_NEED_NORM;
     if (hs.err & DE_QUAL_OVERFLOW) return rfq_fail(ctx, RFQ_E_UNPINNED, "quality payload exceeds the reference's 1.5x scratch buffer (reference heap overflow, SURVEY.md App. C Q6)");
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_HIP, "internal: a stream exceeded its scratch capacity");
     if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %llu bytes", (unsigned long long)(hs.total_image + hdr_bytes));

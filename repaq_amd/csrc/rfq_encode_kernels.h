@@ -30,8 +30,10 @@ __device__ __forceinline__ void read_loc(const Text& T, uint32_t g, int& s, uint
     if (T.paired == 1) { s = (int)(g & 1u); r = g >> 1; } else { s = 0; r = g; }
 }
 __device__ __forceinline__ uint32_t line_beg(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return t_lo(T, s)[4 * (size_t)r + k]; }
-__device__ __forceinline__ uint32_t line_len(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r + k; return p[1] - 1 - p[0]; }
-__device__ __forceinline__ const uint8_t* line_ptr(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r); return t_fq(T, s) + t_lo(T, s)[4 * (size_t)r + k]; }
+__device__ __forceinline__ uint32_t line_len(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r);
+        const uint32_t* p = t_lo(T, s) + 4 * (size_t)r + k; return p[1] - 1 - p[0]; }
+__device__ __forceinline__ const uint8_t* line_ptr(const Text& T, uint32_t g, int k) { int s; uint32_t r; read_loc(T, g, s, r);
+        return t_fq(T, s) + t_lo(T, s)[4 * (size_t)r + k]; }
 
 struct ReadTab {                 // per-read arrays, indexed by g (interleaved order)
     uint32_t* len;               // sequence length
@@ -44,7 +46,8 @@ struct ReadTab {                 // per-read arrays, indexed by g (interleaved o
     uint8_t*  eq2;               // name2 == name2 of the chunk's read 0
     uint32_t* pq;                // exclusive prefix of len          (n_reads + 1 entries)
     U4*       pv;                // exclusive prefix of (name1_len, name2_len, strand_len, stored): only differences inside one chunk are ever used (pv[g] - pv[first[c]];
-                                 // the chunk's totals: ChunkTab::ptot) - the tile path restarts it at 0 in every chunk (k_chunk_prefix), the byte-wise path scans the whole batch
+                                 // the chunk's totals: ChunkTab::ptot) - the tile path restarts it at 0 in every chunk (k_chunk_prefix), the byte-wise path scans the
+                                 // whole batch
 };
 
 struct ChunkTab {                // per-chunk arrays
@@ -134,14 +137,17 @@ __device__ __forceinline__ unsigned long long nlf_load(const unsigned long long*
 __device__ __forceinline__ void nlf_pause() {}
 #else
 typedef __attribute__((address_space(1))) unsigned long long nlf_gu64;
-__device__ __forceinline__ void nlf_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store((nlf_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long nlf_load(const unsigned long long* p) { return __hip_atomic_load((nlf_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void nlf_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store((nlf_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+__device__ __forceinline__ unsigned long long nlf_load(const unsigned long long* p) { return __hip_atomic_load((nlf_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 __device__ __forceinline__ void nlf_pause() { __builtin_amdgcn_s_sleep(2); }
 #endif
 // Why NLF_TILES x 16 KiB and not 16 KiB per workgroup: a look-back is a few dependent round trips to memory (the state words bypass the L2s); with
 // 16 KiB of text per workgroup that is as long as the work itself, nobody's prefix is ever ready when its successors look, and every look-back walks
 // far (measured 5.9 ms against the two passes' 2.1 ms on 2 x 4 GB).  With 256 KiB the wait is a small part of a workgroup's life.
-template <int NLF_T> __global__ void __launch_bounds__(256) k_line_index(const uint8_t* __restrict__ fq, uint32_t n, uint32_t skip, uint32_t* __restrict__ lo, uint32_t lo_cap, unsigned long long* state,
+template <int NLF_T> __global__ void __launch_bounds__(256) k_line_index(const uint8_t* __restrict__ fq, uint32_t n, uint32_t skip, uint32_t* __restrict__ lo,
+        uint32_t lo_cap, unsigned long long* state,
                                                     uint32_t* ticket, uint32_t* total, DevStatus* st) {
     constexpr uint32_t NLF_BYTES = NLF_T * 16384u;
     __shared__ uint32_t s_blk, s_base, s_wave[4];
@@ -159,7 +165,8 @@ template <int NLF_T> __global__ void __launch_bounds__(256) k_line_index(const u
             const uint4* p = (const uint4*)(fq + base);
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) { uint4 q = p[q4]; mk |= (uint64_t)eq_mask16c(q, 0x0A0A0A0Au) << (16 * q4); crm |= has_byte16(q, 0x0D0D0D0Du); }
-            if (base == 0 && skip && crm) { crm = 0; for (uint32_t i = skip; i < 64; i++) if (fq[i] == '\r') crm = 1ull << 63; }              // (bytes in front of the stream do not count)
+            // (bytes in front of the stream do not count)
+            if (base == 0 && skip && crm) { crm = 0; for (uint32_t i = skip; i < 64; i++) if (fq[i] == '\r') crm = 1ull << 63; }
         } else if (base < n) {
             for (uint32_t i = 0; i < 64 && base + i < n; i++) { uint8_t c = fq[base + i]; if (c == '\n') mk |= 1ull << i; if (c == '\r') crm |= 1ull << i; }
         }
@@ -260,7 +267,8 @@ __global__ void k_norm_classify(NormIn c, uint64_t* __restrict__ tbits, uint64_t
     uint32_t tk, tt; (void)block_excl_sum<uint32_t>(valid - (uint32_t)__popcll(sm), &tk); (void)block_excl_sum<uint32_t>((uint32_t)__popcll(tm), &tt);
     if (threadIdx.x == 0) { blk_keep[blockIdx.x] = tk; blk_term[blockIdx.x] = tt; }
 }
-__global__ void k_norm_emit(NormIn c, const uint64_t* __restrict__ tbits, const uint64_t* __restrict__ sbits, const uint32_t* __restrict__ keep_base, const uint32_t* __restrict__ term_base,
+__global__ void k_norm_emit(NormIn c, const uint64_t* __restrict__ tbits, const uint64_t* __restrict__ sbits, const uint32_t* __restrict__ keep_base,
+        const uint32_t* __restrict__ term_base,
                             uint8_t* __restrict__ out, uint32_t* __restrict__ ot, uint32_t* __restrict__ onx) {
     const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; const uint64_t base = w * 64;
     uint64_t tm = 0, sm = 0; uint32_t valid = 0;
@@ -366,13 +374,16 @@ __device__ __forceinline__ void stage_name_rows_wide(const Text& T, uint8_t* row
         const int j = it * 8 + (l >> 3);
         const uint32_t jb = __shfl(nb, j), jl = __shfl(nl, j); const int js = __shfl(s, j);
         const uint32_t a = (jb & ~15u) + 16u * part;                         // the group's offset in its stream
-        ok[it] = jl != 0 && a < jb + (jl < RT_NAME_CAP ? jl : RT_NAME_CAP);  // it holds bytes of the name (of its first RT_NAME_CAP bytes: a longer name is parsed and compared from that prefix, and from global memory only where the prefix does not settle it)
+        // it holds bytes of the name (of its first RT_NAME_CAP bytes: a longer name is parsed and compared from that prefix, and from global memory only where the prefix
+        // does not settle it)
+        ok[it] = jl != 0 && a < jb + (jl < RT_NAME_CAP ? jl : RT_NAME_CAP);
         da[it] = (uint32_t)j * RT_ROW + 16u + 16u * part - (jb & 15u);
         v[it] = make_uint4(0, 0, 0, 0);
         if (ok[it]) {
             const uint8_t* g = t_fq(T, js) + a;
             if ((uint64_t)a + 16ull <= (uint64_t)t_n(T, js)) { const LdsU16 t = *(const LdsU16*)g; v[it] = make_uint4(t.a, t.b, t.c, t.d); }
-            else { uint32_t w[4] = { 0, 0, 0, 0 }; for (uint32_t b = 0; b < 16 && a + b < t_n(T, js); b++) w[b >> 2] |= (uint32_t)g[b] << (8 * (b & 3)); v[it] = make_uint4(w[0], w[1], w[2], w[3]); }
+            else { uint32_t w[4] = { 0, 0, 0, 0 }; for (uint32_t b = 0; b < 16 && a + b < t_n(T, js); b++) w[b >> 2] |= (uint32_t)g[b] << (8 * (b & 3));
+                    v[it] = make_uint4(w[0], w[1], w[2], w[3]); }
         }
     }
 #pragma unroll
@@ -422,7 +433,8 @@ __global__ void k_chunk_ends(Text T, const uint32_t* __restrict__ first, uint32_
 // the input there, src/fastqreader.cpp:180-191; a quality line shorter than its sequence is refused), bases per partition unit (a read, or a
 // pair) + per-block min / max for the partitioner's uniform-length fast path and the longest record (k_gather2 sizes its tiles by it).
 // (no atomics for the min / max: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
-__global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __restrict__ stored, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr, uint32_t* __restrict__ blk_minmax, DevStatus* st) {
+__global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __restrict__ stored, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr,
+        uint32_t* __restrict__ blk_minmax, DevStatus* st) {
     __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4], s_ml[4];
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t tot = 0; uint32_t rec = 0, ml = 0, err = 0, fe = 0xFFFFFFFFu;   // rec: bytes of the unit's longest record, ml: bases of its longest read
@@ -439,10 +451,12 @@ __global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __rest
     }
     uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
     mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec); ml = wave_max(ml); fe = wave_min(fe); err = wave_or(err);
-    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; s_ml[wave_id()] = ml; if (err) { atomicOr(&st->err, err); if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); } }
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; s_ml[wave_id()] = ml; if (err) { atomicOr(&st->err, err);
+            if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); } }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; if (s_rc[i] > rec) rec = s_rc[i]; if (s_ml[i] > ml) ml = s_ml[i]; }
+        for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; if (s_rc[i] > rec) rec = s_rc[i];
+                if (s_ml[i] > ml) ml = s_ml[i]; }
         blk_minmax[4 * blockIdx.x] = mn; blk_minmax[4 * blockIdx.x + 1] = mx; blk_minmax[4 * blockIdx.x + 2] = rec; blk_minmax[4 * blockIdx.x + 3] = ml;
     }
 }
@@ -479,7 +493,8 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
       if (l == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rc; s_ml[wave_id()] = ml; }
       __syncthreads();
       if (wave_id() != 0) return;
-      const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u; rc = (uint32_t)l < nw ? s_rc[l] : 0u; ml = (uint32_t)l < nw ? s_ml[l] : 0u;
+      const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u; rc = (uint32_t)l < nw ? s_rc[l] : 0u;
+              ml = (uint32_t)l < nw ? s_ml[l] : 0u;
       len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); max_rec = wave_max(rc); max_len = wave_max(ml); }
     uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0;
     if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
@@ -489,9 +504,11 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
         const uint32_t K0 = carry ? (uint32_t)(((uint64_t)(chunk_bases - carry) + L - 1) / L) : K;
         const uint32_t head = n_units >= K0 ? K0 : 0u, full = head ? 1u + (n_units - K0) / K : 0u, used = head ? K0 + (full - 1u) * K : 0u, rem = n_units - used;
         const uint32_t nch = full + ((rem && final_batch) ? 1u : 0u);
-        for (uint32_t i = (uint32_t)l; i <= nch && i < cap_chunks; i += 64) { uint64_t f = i == 0 ? 0ull : (uint64_t)K0 + (uint64_t)(i - 1u) * K; if (f > n_units) f = n_units; first[i] = (uint32_t)f * upr; }
+        for (uint32_t i = (uint32_t)l; i <= nch && i < cap_chunks; i += 64) { uint64_t f = i == 0 ? 0ull : (uint64_t)K0 + (uint64_t)(i - 1u) * K;
+                if (f > n_units) f = n_units; first[i] = (uint32_t)f * upr; }
         c = nch; start = (rem && !final_batch) ? used : n_units;
-        max_units = head ? K0 : 0u; if (full > 1u && K > max_units) max_units = K; if (rem && final_batch && rem > max_units) max_units = rem; max_bases = (uint64_t)max_units * L;
+        max_units = head ? K0 : 0u; if (full > 1u && K > max_units) max_units = K; if (rem && final_batch && rem > max_units) max_units = rem;
+                max_bases = (uint64_t)max_units * L;
     } else {
         uint32_t guess = 0;
         while (start < n_units) {
@@ -515,7 +532,8 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
     if (l == 0) {
         st->n_chunks = c; st->n_units_used = start; st->max_chunk_reads = max_units * upr;
         st->max_chunk_bases = (uint32_t)(max_bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : max_bases);
-        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec; st->max_len = max_len; st->unit_bases = (n_units > 0 && len_minmax[0] == len_minmax[1]) ? len_minmax[0] : 0u;
+        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec; st->max_len = max_len;
+                st->unit_bases = (n_units > 0 && len_minmax[0] == len_minmax[1]) ? len_minmax[0] : 0u;
     }
 }
 __global__ void k_chunk_ids(ChunkTab C, ReadTab R) {
@@ -541,7 +559,8 @@ struct HdrStats {
 };
 __global__ void k_hdr_init(HdrStats* H) {
     for (int i = threadIdx.x; i < 128; i += blockDim.x) H->hist[i] = 0;
-    if (threadIdx.x == 0) { H->n_count = 0; H->all_ok = 1; H->any_not_ok = 0; H->max_len = 0; H->first_n_key = ~0ull; H->first_err_key = ~0ull; H->q0 = 0; H->need_npos = 0; H->pe_support = 1; H->dpos = 0; H->dch = 0; }
+    if (threadIdx.x == 0) { H->n_count = 0; H->all_ok = 1; H->any_not_ok = 0; H->max_len = 0; H->first_n_key = ~0ull; H->first_err_key = ~0ull; H->q0 = 0;
+            H->need_npos = 0; H->pe_support = 1; H->dpos = 0; H->dch = 0; }
 }
 // pass 1: one wave per read of chunk 0 (grid-stride)
 __global__ void k_hdr_stats(Text T, ReadTab R, const uint32_t* __restrict__ first, HdrStats* H) {
@@ -680,7 +699,8 @@ __global__ void k_hdr_finalize(Text T, HdrStats* H, DevHeader* D, int is_pe, Dev
     if (!has_n) b[17 + bins - 1] = (uint8_t)nbq;
     if (bins <= 64) flags |= H_QUAL_BY_COL;
     b[9] = H->max_len > 255 ? 2 : 1;                       // never 4: src/rfqcodec.cpp:48-53 (second `if` is not `else if`)
-    b[10] = (uint8_t)flags; b[11] = (uint8_t)(flags >> 8); b[12] = (uint8_t)dpos; b[13] = (uint8_t)dch; b[14] = (uint8_t)nbq; b[15] = (uint8_t)(-24); b[16] = (uint8_t)bins;
+    b[10] = (uint8_t)flags; b[11] = (uint8_t)(flags >> 8); b[12] = (uint8_t)dpos; b[13] = (uint8_t)dch; b[14] = (uint8_t)nbq; b[15] = (uint8_t)(-24);
+            b[16] = (uint8_t)bins;
     hdr_derive(D);
 }
 
@@ -690,7 +710,8 @@ __global__ void k_dense_order(const HdrStats* __restrict__ H, DevHeader* D) {
     if (threadIdx.x || blockIdx.x) return;
     const uint32_t nn = D->n_normal < 4u ? D->n_normal : 4u; uint32_t fr[4], ix[4];
     for (uint32_t j = 0; j < 4; j++) { ix[j] = j; const uint32_t v = D->normal[j]; fr[j] = (j < nn && v < 128u) ? H->hist[v] : 0u; }
-    for (uint32_t a = 1; a < 4; a++) for (uint32_t b = a; b > 0 && fr[ix[b]] > fr[ix[b - 1]]; b--) { const uint32_t t = ix[b]; ix[b] = ix[b - 1]; ix[b - 1] = t; }   // (stable: ties keep the table's order)
+    // (stable: ties keep the table's order)
+    for (uint32_t a = 1; a < 4; a++) for (uint32_t b = a; b > 0 && fr[ix[b]] > fr[ix[b - 1]]; b--) { const uint32_t t = ix[b]; ix[b] = ix[b - 1]; ix[b - 1] = t; }
     for (uint32_t j = 0; j < 4; j++) D->dense[j] = (uint8_t)ix[j];
     D->dense_valid = 1;
 }
@@ -766,7 +787,8 @@ __global__ void k_chunk_flags_a(Text T, ReadTab R, ChunkTab C, const DevHeader* 
 // Pass B — one wave per chunk: the flag word; name2Same with the order-dependent rule of src/rfqcodec.cpp:233-250 (Q12) - odd reads do not count while
 // the chunk is still interleaved - from the accumulated bits, read by read only for a chunk whose mate test fails somewhere.
 // assumed (may be null): the orientation the gather has already used for chunk c's mates; redo[c] = 1 where it turns out wrong (k_gather2 runs again there)
-__global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, const uint32_t* __restrict__ cbits, const uint32_t* __restrict__ cfail, uint32_t* __restrict__ redo) {
+__global__ void k_chunk_flags_b(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, int is_pe, const uint32_t* __restrict__ cbits, const uint32_t* __restrict__ cfail,
+        uint32_t* __restrict__ redo) {
     const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1]; const int l = lane_id();
     const bool can0 = is_pe && D->support_interleaved;
     const uint32_t acc = cbits[c], bits = acc & 0xFFu, fail = cfail[c];
@@ -863,7 +885,8 @@ __device__ __forceinline__ void ov2_pack_rc(uint32_t w, uint32_t& code, uint32_t
 // "R1 holds a byte outside A/C/G/T/N" verdict from rflag.  The search then runs behind the gather, beside the position coder.
 struct OvLoose { const uint32_t* pq; const uint32_t* lpk; const uint16_t* lnb; const uint8_t* rflag; };
 template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, OvLoose Z, int16_t* __restrict__ ovraw, uint32_t n_pairs) {
-    __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4) + 4]; __shared__ uint32_t s_bad[4][2];      // (+4: a verification step reads 9 bytes from a byte offset inside the last row)
+    // (+4: a verification step reads 9 bytes from a byte offset inside the last row)
+    __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4) + 4]; __shared__ uint32_t s_bad[4][2];
     const int l = lane_id(), w = wave_id();
     uint8_t* const c1 = (uint8_t*)(s_rows + (size_t)w * (OV2_WAVE_BYTES / 4)); uint8_t* const c2 = c1 + 64u * OV2_CROW;
     uint8_t* const n1 = c2 + 64u * OV2_CROW; uint8_t* const n2 = n1 + 64u * OV2_NROW;
@@ -871,7 +894,8 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
         const uint32_t p = p0 + (uint32_t)l; int len1 = -1, len2 = 0; uint32_t q1 = 0, q2 = 0; int s1 = 0, s2 = 0; uint32_t ld1 = 0, ld2 = 0;
         if (p < n_pairs) {
             const uint32_t g = 2u * p;
-            if (LOOSE) { const uint32_t a = Z.pq[g], b = Z.pq[g + 1], c_ = Z.pq[g + 2]; len1 = (int)(b - a); len2 = (int)(c_ - b); ld1 = (a >> 4) + g; ld2 = (b >> 4) + g + 1u; }
+            if (LOOSE) { const uint32_t a = Z.pq[g], b = Z.pq[g + 1], c_ = Z.pq[g + 2]; len1 = (int)(b - a); len2 = (int)(c_ - b); ld1 = (a >> 4) + g;
+                    ld2 = (b >> 4) + g + 1u; }
             else { uint32_t r; read_loc(T, g, s1, r); const uint32_t* pa = t_lo(T, s1) + 4 * (size_t)r; q1 = pa[1]; len1 = (int)(pa[2] - 1u - q1);
                               read_loc(T, g + 1, s2, r); const uint32_t* pb = t_lo(T, s2) + 4 * (size_t)r; q2 = pb[1]; len2 = (int)(pb[2] - 1u - q2); }
         }
@@ -898,7 +922,8 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; u++) {
                     const uint32_t j = j0 + u; const bool o1 = fast && j < nd_ && 16u * j < (uint32_t)len1, o2 = fast && j < nd_ && 16u * j < (uint32_t)len2;
-                    va[u] = o1 ? Z.lpk[ld1 + j] : 0u; ma[u] = o1 ? Z.lnb[ld1 + j] : (uint16_t)0; vb[u] = o2 ? Z.lpk[ld2 + j] : 0u; mb[u] = o2 ? Z.lnb[ld2 + j] : (uint16_t)0;
+                    va[u] = o1 ? Z.lpk[ld1 + j] : 0u; ma[u] = o1 ? Z.lnb[ld1 + j] : (uint16_t)0; vb[u] = o2 ? Z.lpk[ld2 + j] : 0u;
+                            mb[u] = o2 ? Z.lnb[ld2 + j] : (uint16_t)0;
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; u++) { const uint32_t j = j0 + u; if (fast && j < nd_) { r1w[j] = va[u]; m1w[j] = ma[u]; r2w[j] = vb[u]; m2w[j] = mb[u]; } }
@@ -932,20 +957,25 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
                 }
                 if (__any(edge[0] || edge[1] || edge[2] || edge[3])) {
     #pragma unroll
-                    for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], (long long)at[u], (uint64_t)lim[u]), y = ld16_edge(src[u], (long long)at[u] + 16, (uint64_t)lim[u]);
-                                                               v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z; v[u][7] = y.w; }
+                    for (int u = 0; u < 4; u++) if (edge[u]) { const uint4 x = ld16_edge(src[u], (long long)at[u], (uint64_t)lim[u]), y = ld16_edge(src[u],
+                            (long long)at[u] + 16, (uint64_t)lim[u]);
+                                                               v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w; v[u][4] = y.x; v[u][5] = y.y; v[u][6] = y.z;
+                                                                       v[u][7] = y.w; }
                 }
     #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (!on[u]) continue;
                     const bool second = row[u] >= 64u; const uint32_t pr = row[u] & 63u;
-                    unsigned long long cw = 0; uint32_t nw = 0, badb = 0;       // 32 codes, 32 N bits, 32 "neither A/C/G/T nor N" bits - byte b of the (re-oriented) group at bit b
+                    // 32 codes, 32 N bits, 32 "neither A/C/G/T nor N" bits - byte b of the (re-oriented) group at bit b
+                    unsigned long long cw = 0; uint32_t nw = 0, badb = 0;
                     if (!second) {
     #pragma unroll
-                        for (int i = 0; i < 8; i++) { uint32_t c, nb, bd; ov2_pack_r1(v[u][i], c, nb, bd); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); if (bd) badb |= (((bd & 0x01010101u) * 0x01020408u) >> 24) << (4 * i); }
+                        for (int i = 0; i < 8; i++) { uint32_t c, nb, bd; ov2_pack_r1(v[u][i], c, nb, bd); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i);
+                                if (bd) badb |= (((bd & 0x01010101u) * 0x01020408u) >> 24) << (4 * i); }
                     } else {
     #pragma unroll
-                        for (int i = 0; i < 8; i++) { uint32_t c, nb; ov2_pack_rc(bswap32(v[u][7 - i]), c, nb); cw |= (unsigned long long)c << (8 * i); nw |= nb << (4 * i); }
+                        for (int i = 0; i < 8; i++) { uint32_t c, nb; ov2_pack_rc(bswap32(v[u][7 - i]), c, nb); cw |= (unsigned long long)c << (8 * i);
+                                nw |= nb << (4 * i); }
                     }
                     // keep the bases whose position lies inside the read: drop the `lo` leading ones and everything from `hi` on, shift into place
                     const int lo = pos0[u] < 0 ? -pos0[u] : 0, hi = L[u] - pos0[u] < 32 ? L[u] - pos0[u] : 32;
@@ -955,7 +985,8 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
                     cw = (cw >> (2 * lo)) & (nk >= 32u ? ~0ull : (1ull << (2u * nk)) - 1ull); nw = (nw >> lo) & km;
                     if ((badb >> lo) & km) atomicOr(&s_bad[w][pr >> 5], 1u << (pr & 31u));
                     const uint32_t p = (uint32_t)(pos0[u] + lo);
-                    uint32_t* const crow = (uint32_t*)((second ? c2 : c1) + pr * OV2_CROW) + ((2u * p) >> 5); uint32_t* const nrow = (uint32_t*)((second ? n2 : n1) + pr * OV2_NROW) + (p >> 5);
+                    uint32_t* const crow = (uint32_t*)((second ? c2 : c1) + pr * OV2_CROW) + ((2u * p) >> 5);
+                            uint32_t* const nrow = (uint32_t*)((second ? n2 : n1) + pr * OV2_NROW) + (p >> 5);
                     const uint32_t cs = (2u * p) & 31u, ns = p & 31u;
                     const unsigned long long cv = cw << cs; const uint32_t ctop = cs ? (uint32_t)(cw >> (64u - cs)) : 0u;
                     const unsigned long long nv = (unsigned long long)nw << ns;
@@ -1046,7 +1077,9 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
         }
         // reads longer than a row, or an R1 holding a character outside A/C/G/T/N: the byte-wise search, one pair at a time
         unsigned long long sm = __ballot(slow || bad);
-        if (LOOSE && sm && len1 >= 0) { uint32_t r; read_loc(T, 2u * p, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, 2u * p + 1u, s2, r); q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }   // (the byte-wise search reads the text)
+        // (the byte-wise search reads the text)
+        if (LOOSE && sm && len1 >= 0) { uint32_t r; read_loc(T, 2u * p, s1, r); q1 = t_lo(T, s1)[4 * (size_t)r + 1]; read_loc(T, 2u * p + 1u, s2, r);
+                q2 = t_lo(T, s2)[4 * (size_t)r + 1]; }
         while (sm) {
             const int j = __ffsll((long long)sm) - 1; sm &= sm - 1;
             const uint8_t* a = t_fq(T, __shfl(s1, j)) + __shfl(q1, j); const uint8_t* b = t_fq(T, __shfl(s2, j)) + __shfl(q2, j);
@@ -1074,13 +1107,15 @@ __global__ void k_pv_in(Text T, ReadTab R, U4* __restrict__ v, uint32_t n_reads)
 // which: bit 0 = qbase (needs the quality prefix only), bit 1 = sbase (needs the stored-base prefix, i.e. the overlaps)
 __global__ void k_chunk_bases(ReadTab R, ChunkTab C, uint32_t n_chunks, int which) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_chunks) { const uint32_t f = C.first[c]; if (which & 1) C.qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c; if (which & 2) C.sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
+    if (c < n_chunks) { const uint32_t f = C.first[c]; if (which & 1) C.qbase[c] = ((uint64_t)R.pq[f] & ~63ull) + 64ull * c;
+            if (which & 2) C.sbase[c] = ((uint64_t)R.pv[f].d & ~63ull) + 64ull * c; }
 }
 
 // Tile path: overlap clamp (src/rfqcodec.cpp:376-383), stored lengths and the per-read prefix of (name1, name2, strand, stored) in ONE launch, a workgroup
 // per chunk - the prefix restarts in every chunk, so nothing crosses workgroups.  (It was k_overlap_apply -> k_pv_in -> a three-launch U4 scan over the
 // batch -> k_chunk_bases: six launches in a row on the second stream, 2.7 GB of traffic, 0.5 ms of latency in front of the sequence packer.)
-__global__ void __launch_bounds__(256) k_chunk_prefix(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const int16_t* __restrict__ ovraw, int8_t* __restrict__ ovb) {
+__global__ void __launch_bounds__(256) k_chunk_prefix(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const int16_t* __restrict__ ovraw,
+        int8_t* __restrict__ ovb) {
     const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1], tid = threadIdx.x;
     const bool enc = C.il[c] != 0 && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
     U4 carry; carry.a = carry.b = carry.c = carry.d = 0;
@@ -1141,7 +1176,8 @@ __device__ __forceinline__ uint32_t pc_seg_cap(bool except, uint32_t cnt, uint32
 }
 __device__ __forceinline__ uint32_t pc_n_seg(uint32_t len) { return ((len + 4095u) / 4096u + PC_SEG_STEPS - 1u) / PC_SEG_STEPS; }
 #define NMAP_WORDS 8u
-__device__ __forceinline__ uint32_t nmap_shift(uint32_t n_bases) { const uint32_t steps = (n_bases + 4095u) / 4096u; uint32_t sh = 0; while ((steps >> sh) > 32u * NMAP_WORDS) sh++; return sh; }
+__device__ __forceinline__ uint32_t nmap_shift(uint32_t n_bases) { const uint32_t steps = (n_bases + 4095u) / 4096u; uint32_t sh = 0;
+        while ((steps >> sh) > 32u * NMAP_WORDS) sh++; return sh; }
 __device__ __forceinline__ void nmap_mark(uint32_t* m, uint32_t shift, uint32_t pos) { const uint32_t b = (pos >> 12) >> shift; atomicOr(&m[b >> 5], 1u << (b & 31u)); }
 __device__ __forceinline__ bool nmap_test(const uint32_t* m, uint32_t shift, uint32_t step) { const uint32_t b = step >> shift; return (m[b >> 5] >> (b & 31u)) & 1u; }
 // Quality / N counters of the gather's flush: group() takes 16 packed bytes, operator() one byte.  They keep what the position coder
@@ -1154,7 +1190,8 @@ struct QualCount {
     uint32_t* cnt; int* last;            // LDS [nrep][2][nslot]
     const uint8_t* slot;                 // LDS [256]: value -> slot
     uint32_t major; uint32_t seg0, nslot, rep; bool hot_ok;   // hot_ok: the major value has no stream of its own (it has one when it is also the N quality)
-    __device__ __forceinline__ void one(uint32_t p, uint32_t q) { const uint32_t i = (rep * 2u + (((p / PC_SEG_POS) - seg0) & 1u)) * nslot + slot[q]; atomicAdd(&cnt[i], 1u); atomicMax(&last[i], (int)p); }
+    __device__ __forceinline__ void one(uint32_t p, uint32_t q) { const uint32_t i = (rep * 2u + (((p / PC_SEG_POS) - seg0) & 1u)) * nslot + slot[q];
+            atomicAdd(&cnt[i], 1u); atomicMax(&last[i], (int)p); }
     __device__ __forceinline__ void operator()(uint32_t p, uint8_t q) { if (!(hot_ok && q == major)) one(p, q); }
     __device__ __forceinline__ void word(uint32_t p, uint32_t w, uint32_t pat) {
         if (hot_ok && w == pat) return;                                     // four major values (72 % of the words of a NovaSeq-binned file)
@@ -1168,19 +1205,22 @@ struct QualCount {
 };
 struct NCount {                          // p = chunk-relative position of the byte / of the group's first byte (a group never crosses a 4096 boundary)
     uint32_t n; uint32_t* nmap; uint32_t shift; uint32_t* segm; int* segc;   // segm / segc: the N-position stream's per-segment entries of the chunk
-    __device__ __forceinline__ void operator()(uint32_t p, uint8_t b) { if (b == 'N') { n++; nmap_mark(nmap, shift, p); atomicAdd(&segm[p / PC_SEG_POS], 1u); atomicMax(&segc[p / PC_SEG_POS], (int)p); } }
+    __device__ __forceinline__ void operator()(uint32_t p, uint8_t b) { if (b == 'N') { n++; nmap_mark(nmap, shift, p); atomicAdd(&segm[p / PC_SEG_POS], 1u);
+            atomicMax(&segc[p / PC_SEG_POS], (int)p); } }
     __device__ __forceinline__ void group(uint32_t p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
         // bit 3 is set in 'N' and in none of A / C / G / T: a group without it holds no N (anything else with the bit takes the exact test)
         if (!((w0 | w1 | w2 | w3) & 0x08080808u)) return;
         const uint32_t pat = (uint32_t)'N' * 0x01010101u;
         const uint32_t mk = eq_mask4(w0, pat) | (eq_mask4(w1, pat) << 4) | (eq_mask4(w2, pat) << 8) | (eq_mask4(w3, pat) << 12);
-        if (mk) { const uint32_t k = (uint32_t)__popc(mk); n += k; nmap_mark(nmap, shift, p); atomicAdd(&segm[p / PC_SEG_POS], k); atomicMax(&segc[p / PC_SEG_POS], (int)(p + 31u - (uint32_t)__clz((int)mk))); }
+        if (mk) { const uint32_t k = (uint32_t)__popc(mk); n += k; nmap_mark(nmap, shift, p); atomicAdd(&segm[p / PC_SEG_POS], k);
+                atomicMax(&segc[p / PC_SEG_POS], (int)(p + 31u - (uint32_t)__clz((int)mk))); }
     }
 };
 // the tile's counters (summed over the replicas) -> the coder's per-(stream, segment) tables; the counters are left zeroed.  One thread per
 // (counter, replica) - nrep * 2 * nslot <= 256 of them, a counter's replicas in neighbouring lanes - and a butterfly over the replicas: the
 // serial walk over 16 replicas by eight threads was a chain of 32 dependent LDS round trips at the end of every tile
-__device__ __forceinline__ void qual_flush(uint32_t* cnt, int* last, uint32_t nrep, uint32_t nslot, uint32_t seg0, uint32_t c, uint32_t nn, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg) {
+__device__ __forceinline__ void qual_flush(uint32_t* cnt, int* last, uint32_t nrep, uint32_t nslot, uint32_t seg0, uint32_t c, uint32_t nn, uint32_t* __restrict__ segm,
+        int* __restrict__ segc, uint32_t n_seg) {
     const uint32_t nitem = 2u * nslot;
     for (uint32_t t = threadIdx.x; (t & ~63u) < nrep * nitem; t += blockDim.x) {   // (wave-uniform bound: a wave none of whose lanes has a counter is done)
         const uint32_t r = t & (nrep - 1u), i = t / nrep;                 // nrep is a power of two <= 16
@@ -1227,7 +1267,8 @@ template <class Count> __device__ __forceinline__ void flush_count(const uint4* 
     const uint8_t* lds = (const uint8_t*)lds4; const uint32_t a0 = gbeg & ~15u;
     const uint32_t first_full = (gbeg + 15u) & ~15u, last_full = gend & ~15u;
     if (first_full < last_full) { const uint32_t ng = (last_full - first_full) / 16u, g0 = (first_full - a0) / 16u;
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint4 v = lds4[g0 + i]; *(uint4*)(gbase + first_full + 16u * i) = v; count.group(first_full + 16u * i, v.x, v.y, v.z, v.w); } }
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint4 v = lds4[g0 + i]; *(uint4*)(gbase + first_full + 16u * i) = v;
+                count.group(first_full + 16u * i, v.x, v.y, v.z, v.w); } }
     const uint32_t he = first_full < gend ? first_full : gend;
     for (uint32_t x = gbeg + threadIdx.x; x < he; x += blockDim.x) { const uint8_t b = lds[x - a0]; gbase[x] = b; count(x, b); }
     if (last_full >= first_full) for (uint32_t x = last_full + threadIdx.x; x < gend; x += blockDim.x) { const uint8_t b = lds[x - a0]; gbase[x] = b; count(x, b); }
@@ -1252,7 +1293,8 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     const bool two = T.paired == 1; const uint32_t upr = T.upr;
     uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup
     const uint32_t gs = f + blockIdx.x * per; const uint32_t ge = gs + per < e ? gs + per : e;
-    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
+    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u);
+            qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
     NCount nc; nc.n = 0; nc.nmap = C.nmap + (size_t)c * NMAP_WORDS; nc.shift = nmap_shift(R.pv[e].d - ps0);
     nc.segm = segm + ((size_t)c * MAX_STREAMS + NPOS_SLOT) * n_seg; nc.segc = segc + ((size_t)c * MAX_STREAMS + NPOS_SLOT) * n_seg;
     uint32_t cur = gs;
@@ -1260,7 +1302,8 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
     // round for the NEXT tile is issued while this tile's text is being staged (its start is known as soon as this tile's read count
     // is), so that a tile's chain holds one memory latency - the staging - not two.
     uint32_t a0[2] = { 0, 0 }, na0[2] = { 0, 0 };                          // 16-aligned global begin of each stream's span
-    bool fits = false, nfits = false; int m_st = 0, nm_st = 0; uint32_t m_p1 = 0, m_p3 = 0, m_nx = 0, m_len = 0, m_qdst = 0, m_sdst = 0, nm_p1 = 0, nm_p3 = 0, nm_nx = 0, nm_len = 0, nm_qdst = 0, nm_sdst = 0;
+    bool fits = false, nfits = false; int m_st = 0, nm_st = 0;
+            uint32_t m_p1 = 0, m_p3 = 0, m_nx = 0, m_len = 0, m_qdst = 0, m_sdst = 0, nm_p1 = 0, nm_p3 = 0, nm_nx = 0, nm_len = 0, nm_qdst = 0, nm_sdst = 0;
     int m_ov = 0, nm_ov = 0; bool m_rc = false, nm_rc = false, have = false;
 #define GATHER_META_LOAD(from)                                                                                                         \
     { nfits = false; nm_st = 0; nm_p1 = nm_p3 = nm_nx = nm_len = nm_qdst = nm_sdst = 0; nm_ov = 0; nm_rc = false;                      \
@@ -1285,9 +1328,11 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
           } } }
     while (cur < ge) {                                                   // block-uniform
         if (!have) GATHER_META_LOAD(cur)
-        a0[0] = na0[0]; a0[1] = na0[1]; fits = nfits; m_st = nm_st; m_p1 = nm_p1; m_p3 = nm_p3; m_nx = nm_nx; m_len = nm_len; m_qdst = nm_qdst; m_sdst = nm_sdst; m_ov = nm_ov; m_rc = nm_rc; have = false;
+        a0[0] = na0[0]; a0[1] = na0[1]; fits = nfits; m_st = nm_st; m_p1 = nm_p1; m_p3 = nm_p3; m_nx = nm_nx; m_len = nm_len; m_qdst = nm_qdst; m_sdst = nm_sdst;
+                m_ov = nm_ov; m_rc = nm_rc; have = false;
         if (tid < GT_READS) s_nx[tid] = m_nx;
-        if (tid < 64) {   // the candidates are the first GT_READS threads: wave 0 counts them (no barrier is needed in front: every wave read the previous tile's count four barriers ago)
+        // the candidates are the first GT_READS threads: wave 0 counts them (no barrier is needed in front: every wave read the previous tile's count four barriers ago)
+        if (tid < 64) {
             const unsigned long long fb = __ballot(fits);
             if (tid == 0) s_cnt = (uint32_t)__popcll(fb);
         }
@@ -1304,8 +1349,10 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
                 for (uint32_t i = tid; i < len; i += blockDim.x) { const uint8_t q = rc ? ql[len - 1 - i] : ql[i]; qo[i] = q;
                     if (!(qc.hot_ok && q == qc.major)) { const uint32_t pp = R.pq[g] - pq0 + i, sg = pp / PC_SEG_POS;
                            const uint32_t j = D->is_exception[q] ? (uint32_t)EXC_SLOT : (uint32_t)D->stream_of[q];
-                           if ((j < NPOS_SLOT || j == EXC_SLOT) && sg < n_seg) { const size_t si = ((size_t)c * MAX_STREAMS + j) * n_seg + sg; atomicAdd(&segm[si], 1u); if (j != EXC_SLOT) atomicMax(&segc[si], (int)pp); } } }
-                for (uint32_t i = tid; i < keep; i += blockDim.x) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b; nc(R.pv[g].d - ps0 + i, b); }
+                           if ((j < NPOS_SLOT || j == EXC_SLOT) && sg < n_seg) { const size_t si = ((size_t)c * MAX_STREAMS + j) * n_seg + sg; atomicAdd(&segm[si], 1u);
+                                   if (j != EXC_SLOT) atomicMax(&segc[si], (int)pp); } } }
+                for (uint32_t i = tid; i < keep; i += blockDim.x) { const uint32_t j = i + skip; const uint8_t b = rc ? comp_base(sq[len - 1 - j]) : sq[j]; so[i] = b;
+                        nc(R.pv[g].d - ps0 + i, b); }
             }
             cur += upr; __syncthreads(); continue;
         }
@@ -1330,8 +1377,10 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
             const uint32_t nfull = (uint64_t)a0[st] + 16ull * ng <= (uint64_t)t_n(T, st) ? ng : ng - 1u;
             uint4* const l4 = s_text4 + 1 + lb / 16;
             for (uint32_t i = tid; i < nfull; i += blockDim.x)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i), (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
-            if (nfull < ng && tid == 0) for (uint32_t k = 0; k < 16 && a0[st] + 16 * nfull + k < t_n(T, st); k++) s_text[lb + 16 * nfull + k] = src[16 * (size_t)nfull + k];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i),
+                        (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
+            if (nfull < ng && tid == 0) for (uint32_t k = 0; k < 16 && a0[st] + 16 * nfull + k < t_n(T,
+                    st); k++) s_text[lb + 16 * nfull + k] = src[16 * (size_t)nfull + k];
         }
         if (cur + cnt < ge) { GATHER_META_LOAD(cur + cnt) have = true; }      // the next tile's round of loads, in flight beside the staging
         __syncthreads();
@@ -1343,7 +1392,8 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
                 const uint32_t len = s_len[j]; const bool rc = s_rc[j] != 0;
                 uint32_t n, src; uint8_t* o;
                 if (!seq) { n = len; src = s_qsrc[j]; o = (uint8_t*)s_qo4 + (q_beg & 15u) + (s_qdst[j] - q_beg); }
-                else { n = s_keep[j]; src = s_ssrc[j] + (rc ? len - s_skip[j] - n : 0u); o = (uint8_t*)s_so4 + (s_beg & 15u) + (s_sdst[j] - s_beg); }   // stored bases of a mate: RC(R2)[skip, skip + keep) = R2[len - skip - keep, len - skip) back to front
+                // stored bases of a mate: RC(R2)[skip, skip + keep) = R2[len - skip - keep, len - skip) back to front
+                else { n = s_keep[j]; src = s_ssrc[j] + (rc ? len - s_skip[j] - n : 0u); o = (uint8_t*)s_so4 + (s_beg & 15u) + (s_sdst[j] - s_beg); }
                 const uint32_t ng = (n + 15u) >> 4, per4 = (ng + 3u) >> 2, gb = quarter * per4, ge_ = gb + per4 < ng ? gb + per4 : ng;
                 if (gb < ge_) { if (seq) gather_copy<true>(o, s_text, src, n, gb, ge_, rc); else gather_copy<false>(o, s_text, src, n, gb, ge_, rc); }
             }
@@ -1369,7 +1419,8 @@ __global__ void k_gather(Text T, ReadTab R, ChunkTab C, const int8_t* __restrict
 //   * a tile is a fixed number K of reads (K = 64, 32, ... chosen by the host so that K records always fit the staged-text buffer);
 //   * qualities go from the staged text straight to qcat with byte-granular 16-byte stores (the lanes of one read are neighbours, so a wave's
 //     stores still cover contiguous runs), counted from the registers they pass through;
-//   * bases are 2-bit packed (+ one "is N" bit each) where they stand - in stored orientation (a mate reverse-complemented) but untrimmed - into a per-read slot of a LOOSE array:
+//   * bases are 2-bit packed (+ one "is N" bit each) where they stand - in stored orientation (a mate reverse-complemented) but untrimmed - into a per-read slot of a
+//   LOOSE array:
 //     read g (batch order) owns the dwords Ld(g) = (pq[g] >> 4) + g ... of `lpk` (16 codes each; G 0, A 1, T 2, C 3, anything else 0,
 //     src/rfqcodec.cpp:590-604) and the same u16 slots of `lnb`.  No stored-base prefix and no overlap result is needed here:
 //     k_seqpack applies them (overlap trim, compaction to the chunk's tight 2-bit stream + N bit mask).
@@ -1382,7 +1433,8 @@ __device__ __forceinline__ void pack4_codes(uint32_t w, uint32_t& code, uint32_t
     const uint32_t ok = eq_bytes_full(__builtin_amdgcn_perm(0u, 0x47544341u, idx), w);
     code = ((__builtin_amdgcn_perm(0u, 0x00020301u, idx) & ok) * 0x01041040u) >> 24;
     nb = 0; bad = 0;
-    if (ok != 0xFFFFFFFFu) { const uint32_t isn = eq_bytes_full(w, 0x4E4E4E4Eu); nb = ((isn & 0x01010101u) * 0x01020408u) >> 24; bad = (((~ok & ~isn) & 0x01010101u) * 0x01020408u) >> 24; }
+    if (ok != 0xFFFFFFFFu) { const uint32_t isn = eq_bytes_full(w, 0x4E4E4E4Eu); nb = ((isn & 0x01010101u) * 0x01020408u) >> 24;
+            bad = (((~ok & ~isn) & 0x01010101u) * 0x01020408u) >> 24; }
 }
 // the same for a base of a reverse-complemented mate (the four bytes are already in reversed order): Read::changeToReverseComplement
 // (src/read.cpp:77-115) maps either case of A/C/G/T to the upper-case complement and everything else to N
@@ -1409,12 +1461,14 @@ __device__ __forceinline__ uint32_t g2_rev2x16(uint32_t v) {                // t
     v = bswap32(v); v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4); return ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
 }
 struct G2Geo { uint32_t a00, a01, end0, end1, base1; };                         // a tile's text spans: 16-aligned begin and end per stream, LDS offset of stream 1's span
-struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld, gi; };       // my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
+// my read: lengths, LDS offsets of its quality / sequence line, chunk-relative quality position, loose slot
+struct G2Read { bool on, rc; uint32_t len, qsrc, ssrc, qpos, ld, gi; };
 // ---- what a tile needs before its text can be requested.  A tile BOUNDARY (where the text of tile k starts in each stream, its first quality position)
 // is a scalar load issued three tiles ahead, the lines of my read in the next tile are requested a tile ahead: the tile's only round trip at its start
 // is the text's own (they used to be two: boundaries, then text + lines).  (The text itself cannot be requested a tile ahead: into registers it costs 24
 // VGPRs the kernel does not have at six waves per SIMD - it spills at 80 as it is -, into a second LDS buffer it costs resident workgroups.)
-struct G2Bound { uint32_t l0, l1, q; };                                       // tile boundary: line-table entry of its first read in each stream, quality prefix of that read
+// tile boundary: line-table entry of its first read in each stream, quality prefix of that read
+struct G2Bound { uint32_t l0, l1, q; };
 struct G2MRaw { uint4 lo4; uint32_t pg; };
 #ifdef RFQ_SIMT_EMULATION
 __device__ __forceinline__ uint32_t ld_uniform(const uint32_t* p) { return *p; }
@@ -1443,8 +1497,10 @@ __device__ __forceinline__ void g2_stage1(const uint8_t* __restrict__ fq, uint32
     const uint8_t* src = fq + a0;
     const uint32_t nfull = (uint64_t)a0 + 16ull * ng <= (uint64_t)n ? ng : ng - 1u;      // (only a stream's very last group may reach past the buffer)
     for (uint32_t i = tid; i < nfull; i += blockDim.x)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i), (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
-    if (nfull < ng && tid == 0) { uint8_t* const bytes = (uint8_t*)l4; for (uint32_t k = 0; k < 16 && a0 + 16 * nfull + k < n; k++) bytes[16 * nfull + k] = src[16 * (size_t)nfull + k]; }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * (size_t)i),
+                (__attribute__((address_space(3))) void*)(l4 + (i - (tid & 63u))), 16, 0, 0);
+    if (nfull < ng && tid == 0) { uint8_t* const bytes = (uint8_t*)l4;
+            for (uint32_t k = 0; k < 16 && a0 + 16 * nfull + k < n; k++) bytes[16 * nfull + k] = src[16 * (size_t)nfull + k]; }
 }
 __device__ __forceinline__ void g2_stage(const Text& T, bool two, const G2Geo& g, uint4* buf4, uint32_t tid) {
     g2_stage1(T.fq[0], T.n[0], g.a00, g.end0, buf4, tid);
@@ -1452,7 +1508,8 @@ __device__ __forceinline__ void g2_stage(const Text& T, bool two, const G2Geo& g
 }
 __device__ __forceinline__ G2MRaw g2_mraw(const Text& T, const uint32_t* __restrict__ pq, uint32_t cur, uint32_t j, uint32_t cnt) {
     G2MRaw r; r.lo4 = make_uint4(0, 0, 0, 0); r.pg = 0;
-    if (j < cnt) { const uint32_t gi = cur + j; int s_; uint32_t r_; read_loc(T, gi, s_, r_); r.lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_); r.pg = pq[gi]; }   // starts of the read's four lines
+    // starts of the read's four lines
+    if (j < cnt) { const uint32_t gi = cur + j; int s_; uint32_t r_; read_loc(T, gi, s_, r_); r.lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_); r.pg = pq[gi]; }
     return r;
 }
 __device__ __forceinline__ G2Read g2_read(const Text& T, const G2MRaw& r, const G2Geo& g, uint32_t f, uint32_t pq0, bool il, uint32_t cur, uint32_t j, uint32_t cnt) {
@@ -1468,14 +1525,16 @@ __device__ __forceinline__ G2Read g2_read(const Text& T, const G2MRaw& r, const 
 }
 // my share (groups part, part + P, ...) of my read's sequence line: 16 bases per step -> one dword of codes + 16 N bits into the read's loose slot, in STORED
 // orientation (an interleaved chunk's mate reverse-complemented, src/rfqcodec.cpp:371-407) but untrimmed: k_seqpack skips what the overlap with R1 implies
-__device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag) {
+__device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb,
+        uint8_t* __restrict__ rflag) {
     const uint32_t ng = (m.len + 15u) >> 4;
     for (uint32_t gi = part; gi < ng; gi += P) {
         uint32_t w[4], code = 0, nbits = 0;
         const uint32_t nv0 = m.len - 16u * gi;                             // valid bases of this step
         // (the bytes of a last, partial step that lie outside the line would fail the all-ACGT test in some lane of nearly every wave - and a wave
         // runs the exact path if any of its lanes does: they are made 'A' first; their codes are masked off below)
-        auto blank = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) { uint32_t& x = w[k >> 2]; const uint32_t sh = 8u * (k & 3u); x = (x & ~(0xFFu << sh)) | (0x41u << sh); } };
+        auto blank = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) { uint32_t& x = w[k >> 2]; const uint32_t sh = 8u * (k & 3u);
+                x = (x & ~(0xFFu << sh)) | (0x41u << sh); } };
         if (!m.rc) {
             lds_get16(s_text, m.ssrc + 16u * gi, w);
             if (nv0 < 16u) blank(nv0, 16u);
@@ -1483,7 +1542,8 @@ __device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m,
                 uint32_t bad = 0; code = 0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { uint32_t c4, n4, b4; pack4_codes(w[i], c4, n4, b4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); bad |= b4 << (4 * i); }
-                if (bad) rflag[m.gi] = 1;                                    // a byte outside A/C/G/T/N: it equals nothing in RfqCodec::overlap (k_overlap's byte-wise path)
+                // a byte outside A/C/G/T/N: it equals nothing in RfqCodec::overlap (k_overlap's byte-wise path)
+                if (bad) rflag[m.gi] = 1;
             }
         } else {
             lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);           // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line)
@@ -1500,7 +1560,8 @@ __device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m,
     }
 }
 // my share (groups part, part + P, ...) of my read's two lines: qualities -> qcat, bases -> the loose slot
-__device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag, QualCount& qc) {
+__device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk,
+        uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag, QualCount& qc) {
     if (!m.on) return;
     {
         // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
@@ -1508,7 +1569,8 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
         if (n >= 16u) {
             const uint32_t ng = (n + 15u) >> 4;
             for (uint32_t gi = part; gi < ng; gi += P) {
-                uint32_t p0 = 16u * gi, dup = 0; if (p0 + 16u > n) { dup = p0 + 16u - n; p0 = n - 16u; }     // the last group ends exactly at n: its first `dup` bytes repeat the group before
+                // the last group ends exactly at n: its first `dup` bytes repeat the group before
+                uint32_t p0 = 16u * gi, dup = 0; if (p0 + 16u > n) { dup = p0 + 16u - n; p0 = n - 16u; }
                 uint32_t w[4]; lds_get16(s_text, rc ? m.qsrc + n - p0 - 16u : m.qsrc + p0, w);
                 if (rc) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
                 { GU16g v; v.a = w[0]; v.b = w[1]; v.c = w[2]; v.d = w[3]; *(GU16g*)(o + p0) = v; }
@@ -1535,7 +1597,8 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
 // instructions per wave and tile, most of them the same work four times over.
 #define G2_REFN 256u              // bytes of read 0's name kept in LDS (a longer one is compared from global memory)
 #define G2_REFS 128u              // ... of its strand line
-struct G2Ref { uint32_t nl, n1l, n2o, len, stl, lane, tile, nb, tb; int s; };   // read 0 of the chunk: lengths, parsed fields, where its name / strand line start in the text
+// read 0 of the chunk: lengths, parsed fields, where its name / strand line start in the text
+struct G2Ref { uint32_t nl, n1l, n2o, len, stl, lane, tile, nb, tb; int s; };
 struct G2Acc { uint32_t bits, fail; };
 // n bytes at LDS offsets a and b of tx: are they equal?  16 bytes per step; a length that is not a multiple of 16 ends with a group moved back to end at
 // n (>= 16 bytes) or with one masked group (< 16).  Every lane of the wave must call it (the loop runs while any lane has bytes left); `on` = mine count.
@@ -1557,11 +1620,13 @@ __device__ __forceinline__ bool lane_bytes_eq32(const uint8_t* tx, uint32_t a, u
     uint32_t x[4], y[4]; lds_get16(tx, a, x); lds_get16(tx, b, y);
     unsigned long long dl = (((unsigned long long)(x[1] ^ y[1])) << 32) | (x[0] ^ y[0]), dh = (((unsigned long long)(x[3] ^ y[3])) << 32) | (x[2] ^ y[2]);
     if (n < 16u) { dl &= n >= 8u ? ~0ull : (1ull << (8u * n)) - 1ull; dh &= n > 8u ? (1ull << (8u * (n - 8u))) - 1ull : 0ull; }
-    else { const uint32_t t = n - 16u; lds_get16(tx, a + t, x); lds_get16(tx, b + t, y); dl |= (((unsigned long long)(x[1] ^ y[1])) << 32) | (x[0] ^ y[0]); dh |= (((unsigned long long)(x[3] ^ y[3])) << 32) | (x[2] ^ y[2]); }
+    else { const uint32_t t = n - 16u; lds_get16(tx, a + t, x); lds_get16(tx, b + t, y); dl |= (((unsigned long long)(x[1] ^ y[1])) << 32) | (x[0] ^ y[0]);
+            dh |= (((unsigned long long)(x[3] ^ y[3])) << 32) | (x[2] ^ y[2]); }
     return (dl | dh) == 0ull;
 }
 // the same against read 0's bytes [off0, off0 + n): LDS (offset ro of tx) when read 0's line fits the part of it kept there, else global memory
-__device__ __forceinline__ bool g2_eq_ref(const uint8_t* tx, uint32_t a, uint32_t ro, uint32_t cap, const uint8_t* g0, uint32_t off0, uint32_t len0, uint32_t n, bool on) {
+__device__ __forceinline__ bool g2_eq_ref(const uint8_t* tx, uint32_t a, uint32_t ro, uint32_t cap, const uint8_t* g0, uint32_t off0, uint32_t len0, uint32_t n,
+        bool on) {
     const bool slow = on && len0 > cap, big = on && !slow && n > 32u; bool eq = true;
     if (on && !slow && !big && n) eq = lane_bytes_eq32(tx, a, ro + off0, n);
     if (__any(big)) { if (!lane_bytes_eq(tx, a, ro + off0, n, big)) eq = false; }   // (rare: wave-uniform)
@@ -1580,12 +1645,14 @@ __device__ __forceinline__ uint32_t g2_atoi(const uint8_t* tx, uint32_t a, uint3
     if (m == 0) return 0u;
     const unsigned long long X = x << (8u * (8u - m));                                  // last digit in byte 7, zeros (leading zero digits) in front
     const uint32_t hi4 = (uint32_t)X, lo4 = (uint32_t)(X >> 32);                        // four digits each, the most significant one in the lowest byte
-    const uint32_t uh = ((hi4 << 3) + (hi4 << 1) + (hi4 >> 8)) & 0x00FF00FFu, ul = ((lo4 << 3) + (lo4 << 1) + (lo4 >> 8)) & 0x00FF00FFu;   // pairs: d0 d1 -> 10 d0 + d1 (no carry between bytes: <= 99)
+    // pairs: d0 d1 -> 10 d0 + d1 (no carry between bytes: <= 99)
+    const uint32_t uh = ((hi4 << 3) + (hi4 << 1) + (hi4 >> 8)) & 0x00FF00FFu, ul = ((lo4 << 3) + (lo4 << 1) + (lo4 >> 8)) & 0x00FF00FFu;
     const uint32_t vh = mul24(uh & 0xFFu, 100u) + (uh >> 16), vl = mul24(ul & 0xFFu, 100u) + (ul >> 16);
     return mul24(vh, 10000u) + vl;                                                      // (24-bit multiplies run at full rate, v_mul_lo_u32 at a quarter)
 }
 __device__ __forceinline__ uint32_t ctz64_or64(unsigned long long m) { return m ? (uint32_t)(__ffsll((long long)m) - 1) : 64u; }
-__device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const uint8_t* tx, uint32_t refn, uint32_t refs, const G2Geo& g, const G2Ref& r0, uint32_t f, uint32_t cur, uint32_t cnt,
+__device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const uint8_t* tx, uint32_t refn, uint32_t refs, const G2Geo& g, const G2Ref& r0, uint32_t f,
+        uint32_t cur, uint32_t cnt,
                                          bool can0, uint32_t dpos, uint32_t dch, G2Acc& acc) {
     const uint32_t l = (uint32_t)lane_id(); const bool on = l < cnt; const uint32_t gi = cur + l;
     uint32_t nsrc = 0, nl = 0, sl = 0, tsrc = 0, tl = 0;
@@ -1600,7 +1667,8 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
     {
         uint32_t c[4], sp_[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) { uint32_t w[4]; lds_get16(tx, nsrc + 16u * (uint32_t)p, w); const uint4 q = make_uint4(w[0], w[1], w[2], w[3]); c[p] = eq_mask16c(q, 0x3A3A3A3Au); sp_[p] = eq_mask16c(q, 0x20202020u); }
+        for (int p = 0; p < 4; p++) { uint32_t w[4]; lds_get16(tx, nsrc + 16u * (uint32_t)p, w); const uint4 q = make_uint4(w[0], w[1], w[2], w[3]);
+                c[p] = eq_mask16c(q, 0x3A3A3A3Au); sp_[p] = eq_mask16c(q, 0x20202020u); }
         const unsigned long long keep = !on ? 0ull : (nl >= 64u ? ~0ull : (1ull << nl) - 1ull);
         Cm = ((((unsigned long long)(c[2] | (c[3] << 16))) << 32) | (c[0] | (c[1] << 16))) & keep;
         Sm = ((((unsigned long long)(sp_[2] | (sp_[3] << 16))) << 32) | (sp_[0] | (sp_[1] << 16))) & keep;
@@ -1628,9 +1696,11 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
         else if (k == 6u) y_v = g2_atoi(tx, nsrc + cpos[6] + 1u, sp - cpos[6] - 1u);
     }
     if (__any(undecided)) {                                                            // (rare: wave-uniform)
-        if (undecided) { const Meta m = dev_parse_name(tx + nsrc, nl); ok = m.ok; n1l = m.name1_len; n2o = m.name2_off; lane_v = m.lane; tile_v = m.tile; x_v = m.x; y_v = m.y; }
+        if (undecided) { const Meta m = dev_parse_name(tx + nsrc, nl); ok = m.ok; n1l = m.name1_len; n2o = m.name2_off; lane_v = m.lane; tile_v = m.tile; x_v = m.x;
+                y_v = m.y; }
     }
-    if (on) { R.name1_len[gi] = n1l; R.name2_off[gi] = n2o; R.x[gi] = x_v; R.y[gi] = y_v; R.tile[gi] = (uint16_t)tile_v; R.lane[gi] = (uint8_t)lane_v; R.ok[gi] = (uint8_t)ok; }
+    if (on) { R.name1_len[gi] = n1l; R.name2_off[gi] = n2o; R.x[gi] = x_v; R.y[gi] = y_v; R.tile[gi] = (uint16_t)tile_v; R.lane[gi] = (uint8_t)lane_v;
+            R.ok[gi] = (uint8_t)ok; }
     // ---- against read 0 of the chunk
     const uint32_t n2l = nl - n2o, n2l0 = r0.nl - r0.n2o;
     const uint8_t* g0n = t_fq(T, r0.s) + r0.nb; const uint8_t* g0s = t_fq(T, r0.s) + r0.tb;
@@ -1638,7 +1708,8 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
     const bool n1_eq = g2_eq_ref(tx, nsrc, refn, G2_REFN, g0n, 0u, r0.nl, n1l, on && n1l == r0.n1l);
     const bool n2_eq = g2_eq_ref(tx, nsrc + n2o, refn, G2_REFN, g0n, r0.n2o, r0.nl, n2l, on && n2l == n2l0);
     // ---- an odd read and its mate (the lane in front: tiles start at even reads and hold whole pairs)
-    const uint32_t pn = wave_shr1(nsrc, 0u), pnl = wave_shr1(nl, 0u), pn2o = wave_shr1(n2o, 0u), plane = wave_shr1(lane_v, 0u), ptile = wave_shr1(tile_v, 0u), px = wave_shr1(x_v, 0u), py = wave_shr1(y_v, 0u);
+    const uint32_t pn = wave_shr1(nsrc, 0u), pnl = wave_shr1(nl, 0u), pn2o = wave_shr1(n2o, 0u), plane = wave_shr1(lane_v, 0u), ptile = wave_shr1(tile_v,
+            0u), px = wave_shr1(x_v, 0u), py = wave_shr1(y_v, 0u);
     const uint32_t rel = gi - f; const bool odd = on && can0 && (rel & 1u);
     bool fa = false;                                                                   // (R1's name2 with [dpos] = dch) != R2's name2   (src/rfqcodec.cpp:237-245)
     if (__any(odd)) {
@@ -1699,10 +1770,12 @@ __device__ __forceinline__ void g2_parse(const Text& T, const ReadTab& R, const 
 #define G2_PLANES 5u
 #define G2_PLANE_EXC 4u
 #define G2_RARE_LIST 255u          // words of rare planes a chunk may touch before the cleanup zeroes its whole extent instead
-struct G2Planes { uint32_t* planes; uint64_t pstride; uint32_t pw, nd; uint32_t* rare; };      // pw: words per LDS plane; nd: dense planes; rare: [n_chunks][1 + G2_RARE_LIST]: count, then (plane << 28 | word of the chunk)
+// pw: words per LDS plane; nd: dense planes; rare: [n_chunks][1 + G2_RARE_LIST]: count, then (plane << 28 | word of the chunk)
+struct G2Planes { uint32_t* planes; uint64_t pstride; uint32_t pw, nd; uint32_t* rare; };
 __device__ __forceinline__ void g2_rare_or(uint32_t* __restrict__ gpl, uint64_t pstride, uint32_t* __restrict__ rare_c, uint32_t plane, uint32_t pos) {
     const uint32_t old = atomicOr(&gpl[(size_t)plane * pstride + (pos >> 5)], 1u << (pos & 31u));
-    if (old == 0u) { const uint32_t k = atomicAdd(rare_c, 1u); if (k < G2_RARE_LIST) rare_c[1u + k] = (plane << 28) | (pos >> 5); }      // the word's first bit: remember the word
+    // the word's first bit: remember the word
+    if (old == 0u) { const uint32_t k = atomicAdd(rare_c, 1u); if (k < G2_RARE_LIST) rare_c[1u + k] = (plane << 28) | (pos >> 5); }
 }
 __device__ __forceinline__ void g2_quals_masks(const uint8_t* tx, const G2Read& m, uint32_t part, uint32_t P, uint32_t* pl, uint32_t pw, uint32_t wbase, uint32_t nd,
                                                uint32_t pat0, uint32_t pat1, uint32_t pat2, uint32_t patm, const DevHeader* __restrict__ D, uint8_t* qd, uint32_t* __restrict__ gpl, uint64_t pstride,
@@ -1710,7 +1783,8 @@ __device__ __forceinline__ void g2_quals_masks(const uint8_t* tx, const G2Read& 
     if (!m.on) return;
     const uint32_t n = m.len, ng = (n + 15u) >> 4; const bool rc = m.rc;
     for (uint32_t gi = part; gi < ng; gi += P) {
-        const uint32_t p0 = 16u * gi, nv = n - p0;                         // (a last, partial group reads past the line - in front of it, for a reversed mate - and masks those bits off)
+        // (a last, partial group reads past the line - in front of it, for a reversed mate - and masks those bits off)
+        const uint32_t p0 = 16u * gi, nv = n - p0;
         uint32_t w[4]; lds_get16(tx, rc ? m.qsrc + n - p0 - 16u : m.qsrc + p0, w);
         if (rc) { const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; }
         const uint32_t valid = nv >= 16u ? 0xFFFFu : (1u << nv) - 1u;
@@ -1727,11 +1801,13 @@ __device__ __forceinline__ void g2_quals_masks(const uint8_t* tx, const G2Read& 
         if (nd > 1u) plane(1u, pat1);
         if (nd > 2u) plane(2u, pat2);
         uint32_t rest = ~known & valid;
-        while (rest) {                                                      // (rare) neither the major value nor a dense one: a rare coded value, or one the header's table does not know
+        // (rare) neither the major value nor a dense one: a rare coded value, or one the header's table does not know
+        while (rest) {
             const uint32_t k = (uint32_t)__ffs((int)rest) - 1u; rest &= rest - 1u;
             const uint32_t ww = k < 8u ? (k < 4u ? w[0] : w[1]) : (k < 12u ? w[2] : w[3]), pos = m.qpos + p0 + k, b = (ww >> (8u * (k & 3u))) & 0xFFu;
             const uint32_t j = D->stream_of[b];
-            if (j < 4u && j < D->n_normal) { const size_t si = (size_t)j * n_seg + pos / PC_SEG_POS; g2_rare_or(gpl, pstride, rare_c, j, pos); atomicAdd(&segm_c[si], 1u); atomicMax(&segc_c[si], (int)pos); }
+            if (j < 4u && j < D->n_normal) { const size_t si = (size_t)j * n_seg + pos / PC_SEG_POS; g2_rare_or(gpl, pstride, rare_c, j, pos); atomicAdd(&segm_c[si], 1u);
+                    atomicMax(&segc_c[si], (int)pos); }
             else { qd[pos] = (uint8_t)b; g2_rare_or(gpl, pstride, rare_c, G2_PLANE_EXC, pos); atomicAdd(&segm_c[(size_t)EXC_SLOT * n_seg + pos / PC_SEG_POS], 1u); }
         }
     }
@@ -1764,7 +1840,8 @@ __device__ __forceinline__ void g2_flush_masks(uint32_t* pl, uint32_t pw, uint32
     }
 }
 // the words of the batch's planes that two workgroups of k_gather2<true> OR into: zeroed (per = reads per workgroup, as the gather computes it)
-__global__ void k_mask_bounds(const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase, uint32_t* __restrict__ planes, uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd, uint32_t bx,
+__global__ void k_mask_bounds(const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase, uint32_t* __restrict__ planes,
+        uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd, uint32_t bx,
                               const uint32_t* __restrict__ only) {
     const uint32_t c = blockIdx.x; if (only && !only[c]) return;
     const uint32_t f = first[c], e = first[c + 1], pq0 = pq[f];
@@ -1783,7 +1860,8 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
                                                  uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, uint32_t text4, G2Planes M) {
     RFQ_DYN_SHARED(uint4, g2_lds);
-    __shared__ uint32_t sh[MASKS ? 1 : G2_CNT]; __shared__ int sh_last[MASKS ? 1 : G2_CNT]; __shared__ uint8_t s_slot[MASKS ? 16 : 256]; __shared__ uint32_t s_r0[8], s_carry[4];
+    __shared__ uint32_t sh[MASKS ? 1 : G2_CNT]; __shared__ int sh_last[MASKS ? 1 : G2_CNT]; __shared__ uint8_t s_slot[MASKS ? 16 : 256];
+            __shared__ uint32_t s_r0[8], s_carry[4];
     const uint32_t REFN = (text4 - 1u) * 16u, REFS = REFN + G2_REFN + 16u;      // (byte offsets from the tile's first byte)
     uint32_t* const pl = (uint32_t*)(g2_lds + text4 + (G2_REFN + G2_REFS + 32u) / 16u);
     const uint32_t c = blockIdx.y;
@@ -1811,8 +1889,10 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
     // thread -> (read of the tile, part of it): the even reads first, then the odd ones - an interleaved chunk's mates (odd, reverse-complemented) and
     // their R1 take different paths through the base packer, and a wave that holds both runs both
     const uint32_t jj = tid >> pshift, j = ((jj << 1) & (K - 1u)) | (jj >> (kshift - 1u)), part = tid & (P - 1u);
-    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u); qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
-    const uint32_t nd = MASKS ? M.nd : 0u, dense3 = (uint32_t)D->dense[0] | ((uint32_t)D->dense[1] << 8) | ((uint32_t)D->dense[2] << 16);     // planes built in LDS, and whose they are
+    QualCount qc; qc.cnt = sh; qc.last = sh_last; qc.slot = s_slot; qc.major = D->major & 0xFFu; qc.seg0 = 0; qc.nslot = nslot; qc.rep = tid & (nrep - 1u);
+            qc.hot_ok = D->stream_of[D->major & 0xFFu] == 0xFF;
+    // planes built in LDS, and whose they are
+    const uint32_t nd = MASKS ? M.nd : 0u, dense3 = (uint32_t)D->dense[0] | ((uint32_t)D->dense[1] << 8) | ((uint32_t)D->dense[2] << 16);
     const uint32_t pat0 = (uint32_t)D->normal[dense3 & 0xFFu] * 0x01010101u, pat1 = (uint32_t)D->normal[(dense3 >> 8) & 0xFFu] * 0x01010101u, pat2 = (uint32_t)D->normal[(dense3 >> 16) & 0xFFu] * 0x01010101u, patm = (D->major & 0xFFu) * 0x01010101u;
     uint32_t* const gpl = M.planes + (MASKS ? (size_t)(qbase[c] >> 5) : (size_t)0);        // the chunk's words of plane 0
     uint4* const buf4 = g2_lds + 1; const uint8_t* const tx = (const uint8_t*)buf4;
@@ -1850,17 +1930,20 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
         const G2Bound b3 = g2_bound(T, two, pq, tile_at(t + 3u));
         __syncthreads();                                                    // (drains the LDS-DMA)
         qc.seg0 = qbeg / PC_SEG_POS;
-        if (parse && (uint32_t)wave_id() == (tix & 3u)) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);   // (wave-uniform: this tile's parsing wave)
+        // (wave-uniform: this tile's parsing wave)
+        if (parse && (uint32_t)wave_id() == (tix & 3u)) g2_parse(T, R, tx, REFN, REFS, g, r0, f, cur, cnt, can0, dpos, dch, acc);
         if (MASKS) {
             if (tid < nd && s_carry[tid]) atomicOr(&pl[tid * M.pw], s_carry[tid]);       // the word the tile in front left unfinished
-            g2_quals_masks(tx, m, part, P, pl, M.pw, qbeg & ~31u, nd, pat0, pat1, pat2, patm, D, qd, gpl, M.pstride, segm + (size_t)c * MAX_STREAMS * n_seg, segc + (size_t)c * MAX_STREAMS * n_seg, n_seg, M.rare + (size_t)c * (1u + G2_RARE_LIST));
+            g2_quals_masks(tx, m, part, P, pl, M.pw, qbeg & ~31u, nd, pat0, pat1, pat2, patm, D, qd, gpl, M.pstride, segm + (size_t)c * MAX_STREAMS * n_seg,
+                    segc + (size_t)c * MAX_STREAMS * n_seg, n_seg, M.rare + (size_t)c * (1u + G2_RARE_LIST));
             g2_bases(tx, m, part, P, lpk, lnb, rflag);
         } else g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
         __syncthreads();                                                    // the text is free for the next tile; the tile's counts / planes are complete
         if (t + 1u < ntile) g2_stage(T, two, g2_geo(b1, b2, two), buf4, tid);  // the next tile's text is on its way while the planes / counters of this one leave
         if (MASKS) {
             const uint32_t gw0 = qbeg >> 5, nw = ((qend + 31u) >> 5) - gw0; const bool last_tile = cur + cnt >= ge;
-            g2_flush_masks(pl, M.pw, nd, dense3, s_carry, gpl, M.pstride, gw0, nw, !last_tile && (qend & 31u) != 0u, cur == gs && gs > f && (qbeg & 31u) != 0u, last_tile && ge < e && (qend & 31u) != 0u,
+            g2_flush_masks(pl, M.pw, nd, dense3, s_carry, gpl, M.pstride, gw0, nw, !last_tile && (qend & 31u) != 0u, cur == gs && gs > f && (qbeg & 31u) != 0u,
+                    last_tile && ge < e && (qend & 31u) != 0u,
                            (size_t)c * MAX_STREAMS * n_seg, n_seg, segm, segc);
         } else qual_flush(sh, sh_last, nrep, nslot, qc.seg0, c, nn_s, segm, segc, n_seg);
         b0 = b1; b1 = b2; b2 = b3;
@@ -1871,8 +1954,10 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
     }
 }
 // phase 2 of the gather re-counts the qualities of the chunks it repeats: their per-(stream, segment) entries back to "nothing seen"
-__device__ __forceinline__ uint32_t dense_mask_of(const DevHeader* __restrict__ D, uint32_t nd) { uint32_t m = 0; for (uint32_t d = 0; d < nd; d++) m |= 1u << D->dense[d]; return m; }
-__device__ __forceinline__ void k_rare_zero_chunk(uint32_t* __restrict__ planes, uint64_t pstride, uint32_t dense_mask, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase, uint32_t c) {
+__device__ __forceinline__ uint32_t dense_mask_of(const DevHeader* __restrict__ D, uint32_t nd) { uint32_t m = 0;
+        for (uint32_t d = 0; d < nd; d++) m |= 1u << D->dense[d]; return m; }
+__device__ __forceinline__ void k_rare_zero_chunk(uint32_t* __restrict__ planes, uint64_t pstride, uint32_t dense_mask, const uint32_t* __restrict__ pq,
+        const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase, uint32_t c) {
     const uint32_t nw = (pq[first[c + 1]] - pq[first[c]] + 31u) >> 5; const size_t w0 = (size_t)(qbase[c] >> 5);
     for (uint32_t v = 0; v < G2_PLANES; v++) if (!((dense_mask >> v) & 1u)) for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) planes[(size_t)v * pstride + w0 + i] = 0u;
 }
@@ -1882,12 +1967,16 @@ __global__ void k_gather_redo_reset(const uint32_t* __restrict__ only, uint32_t*
     const uint32_t c = blockIdx.x; if (!only[c]) return;
     const size_t k = (size_t)c * MAX_STREAMS * n_seg;
     for (uint32_t i = threadIdx.x; i < MAX_STREAMS * n_seg; i += blockDim.x) { segm[k + i] = 0u; segc[k + i] = -1; }
-    if (xplane) { k_rare_zero_chunk(xplane, pstride, dense_mask_of(D, nd), pq, first, qbase, c); if (threadIdx.x == 0) xplane[(size_t)G2_PLANES * pstride + (size_t)c * (1u + G2_RARE_LIST)] = 0u; }   // (rare[] lies behind the planes)
+    // (rare[] lies behind the planes)
+    if (xplane) { k_rare_zero_chunk(xplane, pstride, dense_mask_of(D, nd), pq, first, qbase, c);
+            if (threadIdx.x == 0) xplane[(size_t)G2_PLANES * pstride + (size_t)c * (1u + G2_RARE_LIST)] = 0u; }
 }
 // behind the coder: the rare planes all-zero again (chunks that set bits in them are marked in rare[])
-__global__ void k_rare_cleanup(uint32_t* __restrict__ rare, uint32_t* __restrict__ planes, uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd, const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase) {
+__global__ void k_rare_cleanup(uint32_t* __restrict__ rare, uint32_t* __restrict__ planes, uint64_t pstride, const DevHeader* __restrict__ D, uint32_t nd,
+        const uint32_t* __restrict__ pq, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase) {
     const uint32_t c = blockIdx.x; uint32_t* const rc = rare + (size_t)c * (1u + G2_RARE_LIST); const uint32_t n = rc[0]; if (!n) return;
-    if (n <= G2_RARE_LIST) { const size_t w0 = (size_t)(qbase[c] >> 5); for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t e = rc[1u + i]; planes[(size_t)(e >> 28) * pstride + w0 + (e & 0x0FFFFFFFu)] = 0u; } }
+    if (n <= G2_RARE_LIST) { const size_t w0 = (size_t)(qbase[c] >> 5); for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t e = rc[1u + i];
+            planes[(size_t)(e >> 28) * pstride + w0 + (e & 0x0FFFFFFFu)] = 0u; } }
     else k_rare_zero_chunk(planes, pstride, dense_mask_of(D, nd), pq, first, qbase, c);
     __syncthreads();
     if (threadIdx.x == 0) rc[0] = 0u;
@@ -1919,7 +2008,8 @@ __device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb
 #define SP_U 5                    // tight dwords per thread whose loads are in flight together
 struct __attribute__((packed, aligned(4))) SpU8 { uint32_t a, b; };
 struct __attribute__((packed, aligned(2))) SpU4 { uint32_t a; };
-__global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const U4* __restrict__ ptot, const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
+__global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const U4* __restrict__ ptot,
+        const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
                                                  const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
                                                  uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
                                                  uint32_t rshift) {
@@ -1997,7 +2087,8 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
                     jj++;
                 }
                 ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc;
-                if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n); atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
+                if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n);
+                        atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
             }
         }
         __syncthreads();                                                    // (the LDS tables are rewritten by the next step)
@@ -2006,7 +2097,8 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
     if (lane_id() == 0 && nsum) atomicAdd(&ncount[c], nsum);
 }
 // general path: the byte-wise k_gather left the stored bases as bytes in scat (and counted their N); the same tight streams from those
-__global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint64_t* __restrict__ sbase, const uint8_t* __restrict__ scat,
+__global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, const uint32_t* __restrict__ first, const uint64_t* __restrict__ sbase,
+        const uint8_t* __restrict__ scat,
                                                    uint32_t* __restrict__ spk, uint16_t* __restrict__ snm) {
     const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1];
     const uint32_t S = pv[e].d - pv[f].d, ndw = (S + 15u) >> 4;              // (byte-wise path: the prefix runs over the whole batch)
@@ -2027,7 +2119,8 @@ __global__ void __launch_bounds__(256) k_packbytes(const U4* __restrict__ pv, co
 // k + len/128 + 3*len/16384 bytes (one byte per token, +1 for each gap > 128, +3 for each gap > 16384).
 // which: 1 = the quality-value and exception streams (arena `scratch`, chunk total -> ctotal), 2 = the N-position stream (its own arena: it is
 // planned later, when the sequence packer has counted the N; chunk total -> ctotal_n), 3 = both
-__global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint64_t* __restrict__ ctotal, uint64_t* __restrict__ ctotal_n, uint32_t n_chunks, const uint32_t* __restrict__ segm, uint32_t n_seg, int which) {
+__global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, uint64_t* __restrict__ ctotal, uint64_t* __restrict__ ctotal_n, uint32_t n_chunks,
+        const uint32_t* __restrict__ segm, uint32_t n_seg, int which) {
     // one wave per chunk: lane j plans slot j (slots 64 / 65 by lanes 0 / 1 afterwards); offsets by a wave scan
     const uint32_t c = blockIdx.x; const int l = lane_id();
     if (c >= n_chunks) return;
@@ -2038,7 +2131,8 @@ __global__ void k_stream_plan(ReadTab R, ChunkTab C, const DevHeader* __restrict
     const size_t k = (size_t)c * MAX_STREAMS;
     if (which & 1) {
         // occurrences of a stream's value in the chunk = its per-segment match counts (k_gather), summed
-        auto occ = [&](uint32_t j) -> uint32_t { uint32_t t = 0; const uint32_t* p = segm + ((size_t)c * MAX_STREAMS + j) * n_seg; for (uint32_t s_ = 0; s_ < n_seg; s_++) t += p[s_]; return t; };
+        auto occ = [&](uint32_t j) -> uint32_t { uint32_t t = 0; const uint32_t* p = segm + ((size_t)c * MAX_STREAMS + j) * n_seg;
+                for (uint32_t s_ = 0; s_ < n_seg; s_++) t += p[s_]; return t; };
         const uint32_t ex = bycol ? occ(EXC_SLOT) : 0u;
         const uint32_t pad = PC_SEG_PAD * pc_n_seg(len);
         uint32_t cap = (bycol && (uint32_t)l < nn) ? occ((uint32_t)l) + len / 128 + 3 * (len / 16384) + 16 + pad : 0u;
@@ -2073,7 +2167,8 @@ __device__ __forceinline__ Raw64 pc_load_raw(const uint8_t* __restrict__ B, uint
     else { r.v[0] = z; r.v[1] = z; r.v[2] = z; r.v[3] = z; }
     return r;
 }
-__device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uint32_t p0, int mode, uint32_t q, const DevHeader* __restrict__ D, const uint8_t* exc_tab = nullptr) {
+__device__ __forceinline__ uint64_t pc_mask_of(const Raw64& r, uint32_t len, uint32_t p0, int mode, uint32_t q, const DevHeader* __restrict__ D,
+        const uint8_t* exc_tab = nullptr) {
     if (p0 >= len) return 0ull;
     uint64_t m = 0;
     const uint4* p = r.v;
@@ -2156,7 +2251,8 @@ template <class Sink> __device__ __forceinline__ void pc_gen_tokens(uint64_t m, 
 __device__ __forceinline__ uint32_t pc_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh); }   // sh < 32
 struct PackSink16 {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, n = 0;
-    __device__ __forceinline__ void put(uint32_t b) { w0 = pc_alignbit(w1, w0, 8); w1 = pc_alignbit(w2, w1, 8); w2 = pc_alignbit(w3, w2, 8); w3 = (w3 >> 8) | (b << 24); n++; }
+    __device__ __forceinline__ void put(uint32_t b) { w0 = pc_alignbit(w1, w0, 8); w1 = pc_alignbit(w2, w1, 8); w2 = pc_alignbit(w3, w2, 8); w3 = (w3 >> 8) | (b << 24);
+            n++; }
     __device__ __forceinline__ void finish() {                              // (n <= 16)
         const uint32_t k = 16u - n;
         if (k & 8u) { w0 = w2; w1 = w3; w2 = 0; w3 = 0; }
@@ -2198,7 +2294,8 @@ template <class Sink> __device__ __forceinline__ void pc_gen_fast(uint64_t m, ui
         prev = (int)(p0 + lead) - 1; mm = (m >> lead) << lead;
     }
     while (mm) {
-        const uint32_t s = (uint32_t)(__ffsll((long long)mm) - 1); const uint64_t t = mm >> s; const uint32_t run = (uint32_t)(__ffsll((long long)~t) - 1);      // (run < 32)
+        // (run < 32)
+        const uint32_t s = (uint32_t)(__ffsll((long long)mm) - 1); const uint64_t t = mm >> s; const uint32_t run = (uint32_t)(__ffsll((long long)~t) - 1);
         const int abs_s = (int)(p0 + s); const int d = abs_s - prev; const uint32_t v = (uint32_t)(d - 1);
         if (d <= 128) sink.put(v);
         else if (d <= 16384) { sink.put((v >> 8) | 0x80u); sink.put(v & 0xFFu); }
@@ -2225,7 +2322,8 @@ struct PcStream {
     uint32_t outpos; uint8_t* out; uint32_t room;
 };
 // one stream, one step of 4096 positions: the tokens of the lanes' words to the stream's slot, carries updated.  B: the bytes an exception record quotes (MODE PC_EXCEPT)
-template <int MODE> __device__ __forceinline__ void pc_stream_step(PcStream& s, const uint8_t* __restrict__ B, uint32_t step, uint32_t p0, int l, unsigned long long below) {
+template <int MODE> __device__ __forceinline__ void pc_stream_step(PcStream& s, const uint8_t* __restrict__ B, uint32_t step, uint32_t p0, int l,
+        unsigned long long below) {
     const uint64_t m = s.m_cur;
     const unsigned long long has1 = __ballot(m != 0);
     if (!has1) { s.zero_carry = (int)(step * 4096u + 4095u); return; }   // nothing to code in these 4096 positions
@@ -2268,7 +2366,8 @@ template <int MODE> __device__ __forceinline__ void pc_stream_step(PcStream& s, 
 }
 // B must be 64-byte aligned and readable up to the next multiple of 64 past len.  Codes steps [step0, step1) of every active stream
 // with its entry state; S[t].outpos ends as the segment's byte count (wave-uniform).  The bytes go to S[t].out[0..).
-template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len, const DevHeader* __restrict__ D,
+template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wave_pos_encode_group(const uint8_t* __restrict__ B, uint32_t len,
+        const DevHeader* __restrict__ D,
                                                                            PcStream (&S)[G], uint32_t step0, uint32_t step1, const uint32_t* __restrict__ nmap, uint32_t nshift, const uint8_t* exc_tab) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;       // lanes before mine
@@ -2278,8 +2377,11 @@ template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wa
     // (N positions: a step whose bit in the chunk's N map is clear holds no match - its 4096 bytes are not even loaded)
     // BITS: B is not a byte per position but the match mask itself, one bit per position (the N-position stream reads k_seqpack's N mask):
     // a lane's 64 positions are one u64 (kept in v[0].x / .y)
-    auto load = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (nmap && !nmap_test(nmap, nshift, step_)) { Raw64 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; }
-                                                           if (BITS) { Raw64 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = make_uint4(0, 0, 0, 0); if (p_ < len) { const uint2 w = ((const uint2*)B)[p_ >> 6]; r.v[0].x = w.x; r.v[0].y = w.y; } return r; }
+    auto load = [&](uint32_t step_, uint32_t p_) -> Raw64 { if (nmap && !nmap_test(nmap, nshift, step_)) { Raw64 z;
+            z.v[0] = z.v[1] = z.v[2] = z.v[3] = make_uint4(0, 0, 0, 0); return z; }
+                                                           if (BITS) { Raw64 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = make_uint4(0, 0, 0, 0);
+                                                                   if (p_ < len) { const uint2 w = ((const uint2*)B)[p_ >> 6]; r.v[0].x = w.x; r.v[0].y = w.y; } return r;
+                                                                   }
                                                            return pc_load_raw(B, len, p_); };
     auto mask_of = [&](const Raw64& r_, uint32_t p_, uint32_t q_) -> uint64_t {
         if (!BITS) return pc_mask_of(r_, len, p_, MODE, q_, D, exc_tab);
@@ -2325,7 +2427,8 @@ template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void wa
 // streams 4g .. 4g+3, group n_qgroups the exception stream, group n_qgroups + 1 the N-position stream (it reads the base buffer).
 // si = (c * MAX_STREAMS + j) * n_seg + seg; segm[si] = matches in the segment, segc[si] = its last match (k_gather), segb[si] = bytes
 // written here.  Streams whose value does not occur in the chunk (histogram) are skipped outright.
-template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ B, uint32_t len,
+template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void pc_run(const ReadTab& R, const ChunkTab& C, const DevHeader* __restrict__ D,
+        const uint8_t* __restrict__ B, uint32_t len,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg,
                             uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, const uint32_t* __restrict__ nmap, DevStatus* st, const uint8_t* exc_tab = nullptr) {
     const uint32_t nshift = nmap ? nmap_shift(len) : 0u;
@@ -2368,7 +2471,8 @@ template <int MODE, int G, bool BITS = false> __device__ __forceinline__ void pc
 // bytes (planes: value v's u64 of the chunk's positions [64 k, 64 k + 64) at bits[v][k]; the exception plane behind them).  A lane's 64 positions are one
 // 8-byte load per stream and step - the byte form loads 64 bytes and compares them with every value (~120 instructions per stream and step) - and the
 // gather writes 0.375 - 0.5 B per base instead of 1.
-template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_planes(const uint8_t* __restrict__ qbytes, uint32_t len, PcStream (&S)[G], const unsigned long long* const (&bits)[G], uint32_t step0, uint32_t step1) {
+template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_planes(const uint8_t* __restrict__ qbytes, uint32_t len, PcStream (&S)[G],
+        const unsigned long long* const (&bits)[G], uint32_t step0, uint32_t step1) {
     const int l = lane_id();
     const unsigned long long below = l ? (~0ull >> (64 - l)) : 0ull;
     const uint32_t nst = (len + 4095u) / 4096u, q0 = step0 * 4096u + 64u * (uint32_t)l;
@@ -2377,7 +2481,8 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_plane
         uint64_t m_ = bits[t][p_ >> 6]; if (len - p_ < 64u) m_ &= (1ull << (len - p_)) - 1ull; return m_; };
     uint64_t ahead[G];                                                      // the masks of step + 2: requested two steps before they are coded
 #pragma unroll
-    for (int t = 0; t < G; t++) { ahead[t] = 0; if (S[t].on) { S[t].m_cur = load(t, step0, q0); S[t].m_next = load(t, step0 + 1u, q0 + 4096u); ahead[t] = load(t, step0 + 2u, q0 + 8192u); S[t].outpos = 0; } }
+    for (int t = 0; t < G; t++) { ahead[t] = 0; if (S[t].on) { S[t].m_cur = load(t, step0, q0); S[t].m_next = load(t, step0 + 1u, q0 + 4096u);
+            ahead[t] = load(t, step0 + 2u, q0 + 8192u); S[t].outpos = 0; } }
     if (MODE == PC_MATCH && step0 > 0) {
         // the last non-match in front of the segment: back step by step until every stream has met one
         bool need[G]; bool any = false;
@@ -2406,7 +2511,8 @@ template <int MODE, int G> __device__ __forceinline__ void wave_pos_encode_plane
 }
 // planes: plane v of the batch at planes + v * pstride (u32 words); the chunk's words start at qbase >> 5.  Streams j0 .. jend - 1 of the quality values,
 // or (MODE PC_EXCEPT, j0 = EXC_SLOT) the exception records from plane 3 and the bytes k_gather2 kept at the exceptions' positions in qcat.
-template <int MODE, int G> __device__ __forceinline__ void pc_run_planes(const ChunkTab& C, const DevHeader* __restrict__ D, const uint32_t* __restrict__ planes, uint64_t pstride, const uint8_t* __restrict__ qbytes, uint32_t len,
+template <int MODE, int G> __device__ __forceinline__ void pc_run_planes(const ChunkTab& C, const DevHeader* __restrict__ D, const uint32_t* __restrict__ planes,
+        uint64_t pstride, const uint8_t* __restrict__ qbytes, uint32_t len,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg,
                             uint32_t c, uint32_t seg, uint32_t j0, uint32_t jend, DevStatus* st) {
     const uint32_t nsteps = (len + 4095u) / 4096u, step0 = seg * PC_SEG_STEPS;
@@ -2448,19 +2554,23 @@ template <int MODE, int G> __device__ __forceinline__ void pc_run_planes(const C
 // the image: segd[si] = where the piece goes inside the quality payload (behind the length words: the streams in header order, the exception records last;
 // N-position stream: inside its own section) and segs[si] = where it lies in the stream's scratch area (the slots of the segments in front of it) - the
 // pieces used to find both by walking over the streams and segments in front of them, ~70 loads for each of a chunk's (streams + 1) x segments pieces.
-__global__ void k_pos_sizes(ChunkTab C, const DevHeader* __restrict__ D, const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t* __restrict__ segd, uint32_t* __restrict__ segs) {
+__global__ void k_pos_sizes(ChunkTab C, const DevHeader* __restrict__ D, const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segm, uint32_t n_seg,
+        uint32_t* __restrict__ segd, uint32_t* __restrict__ segs) {
     const uint32_t c = blockIdx.x; const int l = lane_id();
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT;
     uint32_t mine = 0;                                                      // lane j < 64: bytes of value stream j
     for (uint32_t j = (uint32_t)l; j < MAX_STREAMS; j += 64) {
         const size_t k = (size_t)c * MAX_STREAMS + j; uint32_t tot = 0, so = 0;
-        if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) { const size_t si = k * n_seg + s; segd[si] = tot; segs[si] = so; tot += segb[si]; so += pc_seg_cap(j == EXC_SLOT, segm[si], PC_SEG_POS); }
+        if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) { const size_t si = k * n_seg + s; segd[si] = tot; segs[si] = so; tot += segb[si];
+                so += pc_seg_cap(j == EXC_SLOT, segm[si], PC_SEG_POS); }
         C.ssize[k] = tot; if (j < 64u) mine = j < nn ? tot : 0u;
     }
     // the streams' places in the payload: value streams in header order, then the exception records
     const uint32_t incl = wave_incl_sum(mine), base = incl - mine, total = wave_last(incl);
     if ((uint32_t)l < nn) { const size_t k = (size_t)c * MAX_STREAMS + (uint32_t)l; if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) segd[k * n_seg + s] += base; }
-    if (l == (int)(EXC_SLOT - 64u)) { const size_t k = (size_t)c * MAX_STREAMS + EXC_SLOT; if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) segd[k * n_seg + s] += total; }   // (the lane that wrote them)
+    // (the lane that wrote them)
+    if (l == (int)(EXC_SLOT - 64u)) { const size_t k = (size_t)c * MAX_STREAMS + EXC_SLOT;
+            if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) segd[k * n_seg + s] += total; }
 }
 // g0, gn: the groups this launch codes (the quality / exception groups run behind the gather, the N group behind the sequence packer)
 __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint16_t* __restrict__ snm,
@@ -2476,17 +2586,21 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
     if (c >= n_chunks) return;
     const uint32_t nn = D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT, f = C.first[c], e = C.first[c + 1];   // (> 64 values: raw qualities, no streams)
     if (planes && grp <= n_qgroups) {                                      // (k_gather2<true> ran: match masks, not bytes)
-        if (grp < n_qgroups) pc_run_planes<PC_MATCH, PC_G>(C, D, planes, pstride, nullptr, R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, st);
-        else pc_run_planes<PC_EXCEPT, 1>(C, D, planes, pstride, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, st);
+        if (grp < n_qgroups) pc_run_planes<PC_MATCH, PC_G>(C, D, planes, pstride, nullptr, R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G,
+                nn, st);
+        else pc_run_planes<PC_EXCEPT, 1>(C, D, planes, pstride, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT,
+                EXC_SLOT + 1, st);
     }
-    else if (grp < n_qgroups) pc_run<PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn, nullptr, st);
+    else if (grp < n_qgroups) pc_run<PC_MATCH, PC_G>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, grp * PC_G, nn,
+            nullptr, st);
     else if (grp == n_qgroups) {
         __shared__ uint8_t s_exc[256];                                      // (a workgroup is one wave)
         for (uint32_t v = (uint32_t)lane_id(); v < 256u; v += 64u) s_exc[v] = D->is_exception[v] ? 1 : 0;
         wave_lds_sync();
         pc_run<PC_EXCEPT, 1>(R, C, D, qcat + C.qbase[c], R.pq[e] - R.pq[f], scratch, cbase, segb, segc, segm, n_seg, c, seg, EXC_SLOT, EXC_SLOT + 1, nullptr, st, s_exc);
     }
-    else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), C.ptot[c].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg, NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
+    else pc_run<PC_MATCH, 1, true>(R, C, D, (const uint8_t*)(snm + (size_t)(C.sbase[c] >> 4)), C.ptot[c].d, scratch_n, cbase_n, segb, segc, segm, n_seg, c, seg,
+            NPOS_SLOT, NPOS_SLOT + 1, C.nmap + (size_t)c * NMAP_WORDS, st);
 }
 
 // =============================================================== position coder for MANY value streams (list form)
@@ -2510,8 +2624,10 @@ __global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__
 // list is 16 bits per entry + a byte for its stream, a stream's state one 16-byte record)
 struct PlStream { uint32_t outpos, room; unsigned long long out; };          // bytes written so far, the slot's size, where the slot is
 struct PlLds {
-    uint16_t list[PL_LIST];                  // entries, stream after stream: position in the step (12 bits) | code << 12 - 0 no token, 1 gap token (a streak starts), 2 the 0x00
-                                             // of a streak that starts at position 0, 3 + v: run token 0xC0 | v for v <= 11, 15: run token, length to be counted from the list
+    // entries, stream after stream: position in the step (12 bits) | code << 12 - 0 no token, 1 gap token (a streak starts), 2 the 0x00
+    uint16_t list[PL_LIST];
+                                             // of a streak that starts at position 0, 3 + v: run token 0xC0 | v for v <= 11, 15: run token, length to be counted from the
+                                             // list
     uint16_t off[NPOS_SLOT + 2];             // where a stream's part of the list starts
     int prev[NPOS_SLOT];                     // the stream's last match so far (-1: none)
     PlStream str[NPOS_SLOT];
@@ -2529,10 +2645,12 @@ __device__ __forceinline__ unsigned long long pl_eq_prev(const uint32_t (&w)[16]
     }
     return ((unsigned long long)hi << 32) | lo;
 }
-__global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
+__global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat,
+        uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
                                                        uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks, DevStatus* st) {
     __shared__ PlLds S;
-    RFQ_DYN_SHARED(uint16_t, pl_base);                                      // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part (n_normal x 64 u16: dynamic)
+    // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part (n_normal x 64 u16: dynamic)
+    RFQ_DYN_SHARED(uint16_t, pl_base);
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3;       // (a chunk's workgroups on one XCD, as in k_pos_coder)
     const uint32_t c = (idx / n_seg) * 8u + xcd, seg = idx % n_seg;
     if (c >= n_chunks) return;
@@ -2557,7 +2675,8 @@ __global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C,
         if (!__any(on)) return;
     }
     wave_lds_sync();
-    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = S.tab[v]; if (j != 0xFFu && !S.on[j]) S.tab[v] = 0xFFu; }   // (values whose stream has nothing in this segment: not looked at again)
+    // (values whose stream has nothing in this segment: not looked at again)
+    for (uint32_t v = (uint32_t)l; v < 256u; v += 64u) { const uint32_t j = S.tab[v]; if (j != 0xFFu && !S.on[j]) S.tab[v] = 0xFFu; }
     wave_lds_sync();
     // the byte in front of the segment and how far it is from the start of its streak (the segment may begin inside one)
     uint32_t carry_byte = 0x100u; uint32_t carry_R = 0;                     // (0x100: no byte in front - it equals nothing)
@@ -2602,27 +2721,32 @@ __global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C,
         // matches that follow my last position (a run token counts up to 31 of them): the head of the next lane's E, for lane 63 the next step's first bytes
         uint32_t ext;
         {
-            const uint32_t hd = (E & 1ull) ? ((~E & vmask) ? (uint32_t)(__ffsll((long long)(~E & vmask)) - 1) : nv) : 0u;     // my leading positions that continue the streak in front
+            // my leading positions that continue the streak in front
+            const uint32_t hd = (E & 1ull) ? ((~E & vmask) ? (uint32_t)(__ffsll((long long)(~E & vmask)) - 1) : nv) : 0u;
             ext = (uint32_t)__shfl_down((int)hd, 1u);
-            if (l == 63) { ext = 0; const uint32_t nb_ = sb + 4096u; if (nv == 64u) { while (ext < 31u && nb_ + ext < len && B[nb_ + ext] == (uint8_t)lastb) ext++; } S.after = (uint8_t)ext; }
+            if (l == 63) { ext = 0; const uint32_t nb_ = sb + 4096u; if (nv == 64u) { while (ext < 31u && nb_ + ext < len && B[nb_ + ext] == (uint8_t)lastb) ext++;
+                    } S.after = (uint8_t)ext; }
             if (nv < 64u) ext = 0;
         }
         // ---- count: my positions per stream (fire-and-forget 32-bit atomics on the u16 pairs of neighbouring lanes)
         for (uint32_t j = 0; j < nn; j++) pl_base[j * 64u + l] = 0;
         wave_lds_sync();
 #pragma unroll
-        for (int k = 0; k < 64; k++) { const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu; if ((Cm >> k) & 1ull) atomicAdd((uint32_t*)&pl_base[j * 64u + (l & ~1)], inc); }
+        for (int k = 0; k < 64; k++) { const uint32_t j = (sw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                if ((Cm >> k) & 1ull) atomicAdd((uint32_t*)&pl_base[j * 64u + (l & ~1)], inc); }
         wave_lds_sync();
         // ---- a prefix over the lanes per stream: where my entries of the stream go
         uint32_t tot = 0;
         for (uint32_t j0 = 0; j0 < nn; j0 += 4u) {                         // (wave-uniform; four streams at a time: their LDS reads are in flight together)
             uint32_t cnt[4], incl[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) cnt[u] = j0 + u < nn ? pl_base[(j0 + u) * 64u + l] : 0u;     // (a stream that is not `on` has no entries: its counts are zero)
+            // (a stream that is not `on` has no entries: its counts are zero)
+            for (uint32_t u = 0; u < 4u; u++) cnt[u] = j0 + u < nn ? pl_base[(j0 + u) * 64u + l] : 0u;
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++) incl[u] = wave_incl_sum<uint32_t>(cnt[u]);
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) if (j0 + u < nn) { if (l == 0) S.off[j0 + u] = (uint16_t)tot; pl_base[(j0 + u) * 64u + l] = (uint16_t)(incl[u] - cnt[u]); tot += wave_last(incl[u]); }
+            for (uint32_t u = 0; u < 4u; u++) if (j0 + u < nn) { if (l == 0) S.off[j0 + u] = (uint16_t)tot; pl_base[(j0 + u) * 64u + l] = (uint16_t)(incl[u] - cnt[u]);
+                    tot += wave_last(incl[u]); }
         }
         if (l == 0) { S.off[nn] = (uint16_t)tot; S.off[nn + 1] = (uint16_t)tot; }
         wave_lds_sync();
@@ -2633,7 +2757,8 @@ __global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C,
         // holds position 0 of the chunk (the `cur > 1` rule), take the exact per-position form.
         bool slow = sb == 0u;
         { unsigned long long x = E & (E >> 1); x &= x >> 2; x &= x >> 4; x &= x >> 8; x &= x >> 16; if (x) slow = true; }      // 32 consecutive ones in E
-        const uint32_t hd_ = (E & 1ull) ? ((~E & vmask) ? (uint32_t)(__ffsll((long long)(~E & vmask)) - 1) : nv) : 0u;           // my leading positions that continue the streak in front
+        // my leading positions that continue the streak in front
+        const uint32_t hd_ = (E & 1ull) ? ((~E & vmask) ? (uint32_t)(__ffsll((long long)(~E & vmask)) - 1) : nv) : 0u;
         if (hd_ && Rin + hd_ >= 32u) slow = true;
         unsigned long long M3 = 0, M15 = 0;
         {
@@ -2653,7 +2778,8 @@ __global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C,
                     const uint32_t Rk = zb ? k - (uint32_t)(63 - __clzll((long long)zb)) : Rin + k + 1u;     // my distance from the start of my streak
                     const uint32_t p = p0 + k; kind = 0u;
                     int t;
-                    if (p == Rk) { if (Rk == 1u) { kind = 2u; t = -1; } else t = (int)Rk - 2; } else t = (int)Rk - 1;    // (p == Rk: the streak starts at position 0 of the chunk)
+                    // (p == Rk: the streak starts at position 0 of the chunk)
+                    if (p == Rk) { if (Rk == 1u) { kind = 2u; t = -1; } else t = (int)Rk - 2; } else t = (int)Rk - 1;
                     if (kind == 0u && t >= 0 && (t & 31) == 0) {
                         const unsigned long long up = (k < 63u) ? (E >> (k + 1u)) : 0ull;             // the positions behind me that continue
                         const uint32_t on_ = (k < 63u) ? ((~up) ? (uint32_t)(__ffsll((long long)~up) - 1) : 64u) : 0u;
@@ -2686,7 +2812,8 @@ __global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C,
             const uint32_t b0 = uni32(S.off[j]), b1 = uni32(S.off[j + 1]);
             if (b0 == b1) continue;
             int prevp = (int)uni32((uint32_t)S.prev[j]);
-            const PlStream ps = S.str[j]; uint32_t outpos = uni32(ps.outpos); const uint32_t room = uni32(ps.room); uint8_t* const outp = (uint8_t*)(uintptr_t)uni64(ps.out);
+            const PlStream ps = S.str[j]; uint32_t outpos = uni32(ps.outpos); const uint32_t room = uni32(ps.room);
+                    uint8_t* const outp = (uint8_t*)(uintptr_t)uni64(ps.out);
             for (uint32_t r0 = b0; r0 < b1; r0 += 64u) {                    // (wave-uniform)
                 const uint32_t i = r0 + (uint32_t)l; const bool valid = i < b1;
                 const uint32_t en = valid ? (uint32_t)S.list[i] : 0u, pos = en & 0xFFFu, code = en >> 12;
@@ -2694,20 +2821,24 @@ __global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C,
                 uint32_t nb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
                 if (valid && code == 1u) {
                     const uint32_t d = (uint32_t)(p - pp), v = d - 1u;
-                    if (d <= 128u) { nb = 1; t0 = v; } else if (d <= 16384u) { nb = 2; t0 = (v >> 8) | 0x80u; t1 = v & 0xFFu; } else { nb = 4; t0 = (v >> 24) | 0xE0u; t1 = (v >> 16) & 0xFFu; t2 = (v >> 8) & 0xFFu; t3 = v & 0xFFu; }
+                    if (d <= 128u) { nb = 1; t0 = v; } else if (d <= 16384u) { nb = 2; t0 = (v >> 8) | 0x80u; t1 = v & 0xFFu; } else { nb = 4; t0 = (v >> 24) | 0xE0u;
+                            t1 = (v >> 16) & 0xFFu; t2 = (v >> 8) & 0xFFu; t3 = v & 0xFFu; }
                 } else if (valid && code >= 2u && code < 15u) { nb = 1; t0 = code == 2u ? 0u : (0xC0u | (code - 3u)); }
-                if (__any(valid && code == 15u)) {                          // (rare) a run token that covers 13 .. 32 matches: they are the entries behind me at consecutive positions
+                // (rare) a run token that covers 13 .. 32 matches: they are the entries behind me at consecutive positions
+                if (__any(valid && code == 15u)) {
                     if (valid && code == 15u) {
                         uint32_t L = 1;
 #pragma unroll
-                        for (uint32_t stp = 16; stp >= 1; stp >>= 1) { const uint32_t k = L - 1u + stp; if (i + k < b1 && ((uint32_t)S.list[i + k] & 0xFFFu) == pos + k) L += stp; }
+                        for (uint32_t stp = 16; stp >= 1; stp >>= 1) { const uint32_t k = L - 1u + stp;
+                                if (i + k < b1 && ((uint32_t)S.list[i + k] & 0xFFFu) == pos + k) L += stp; }
                         if (L < 32u && i + L == b1 && pos + L == 4096u) L += S.after;
                         if (L > 32u) L = 32u;
                         nb = 1; t0 = 0xC0u | (L - 1u);
                     }
                 }
                 const uint32_t incl = wave_incl_sum<uint32_t>(nb), o = outpos + incl - nb;
-                if (nb && o + nb <= room) { uint8_t* op = outp + o; op[0] = (uint8_t)t0; if (nb >= 2u) op[1] = (uint8_t)t1; if (nb == 4u) { op[2] = (uint8_t)t2; op[3] = (uint8_t)t3; } }
+                if (nb && o + nb <= room) { uint8_t* op = outp + o; op[0] = (uint8_t)t0; if (nb >= 2u) op[1] = (uint8_t)t1; if (nb == 4u) { op[2] = (uint8_t)t2;
+                        op[3] = (uint8_t)t3; } }
                 outpos += wave_last(incl);
                 const uint32_t nlast = b1 - r0 < 64u ? b1 - r0 - 1u : 63u;   // the round's last entry
                 prevp = wave_read(p, nlast);
@@ -2752,7 +2883,8 @@ __global__ void k_coords(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D,
                 if (diff > 0 && diff <= 64) { bytes = 1; kind = 2; }
                 else if (v <= 32767u) { bytes = 2; kind = 3; }
                 else if (v < (1u << 21)) { bytes = 3; kind = 4; }
-                else { atomicOr(&st->err, (uint32_t)DE_COORD_RANGE); atomicMin((unsigned long long*)&st->coord_key, ((unsigned long long)c << 34) | ((unsigned long long)axis << 33) | (unsigned long long)i); }
+                else { atomicOr(&st->err, (uint32_t)DE_COORD_RANGE);
+                        atomicMin((unsigned long long*)&st->coord_key, ((unsigned long long)c << 34) | ((unsigned long long)axis << 33) | (unsigned long long)i); }
             }
         }
         const uint32_t incl = wave_incl_sum(bytes); uint32_t o = outpos + incl - bytes;
@@ -2786,7 +2918,8 @@ __global__ void k_chunk_layout(Text T, ReadTab R, ChunkTab C, const DevHeader* _
     const size_t k0 = (size_t)c * MAX_STREAMS;
     uint32_t qsz = 0;
     if (hf & H_DONT_QUAL) qsz = len;
-    else if (hf & H_QUAL_BY_COL) { qsz = 4 * nn; for (uint32_t j = 0; j < nn && j < NPOS_SLOT; j++) qsz += exact ? C.ssize[k0 + j] : C.scap[k0 + j]; qsz += exact ? C.ssize[k0 + EXC_SLOT] : C.scap[k0 + EXC_SLOT]; }
+    else if (hf & H_QUAL_BY_COL) { qsz = 4 * nn; for (uint32_t j = 0; j < nn && j < NPOS_SLOT; j++) qsz += exact ? C.ssize[k0 + j] : C.scap[k0 + j];
+            qsz += exact ? C.ssize[k0 + EXC_SLOT] : C.scap[k0 + EXC_SLOT]; }
     o.qual_size = qsz;
     o.npos_size = (hf & H_N_POS) ? (exact ? C.ssize[k0 + NPOS_SLOT] : C.scap[k0 + NPOS_SLOT]) : 0;
     o.x_size = (hf & H_X) ? (exact ? C.xsize[c] : 3 * h) : 0; o.y_size = (hf & H_Y) ? (exact ? C.ysize[c] : 3 * h) : 0;
@@ -2871,7 +3004,8 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
         const uint32_t last = f + s - 1;
         const bool tail = tail_bases && c + 1 == gridDim.y && R.pq[f + s] - R.pq[f] < tail_bases;
         auto line_end = [&](int st_, size_t q) -> uint64_t { return T.ot[st_] ? (uint64_t)T.ot[st_][q] : (uint64_t)T.lo[st_][q + 1] - 1; };
-        auto attempt = [&](int st_, uint32_t l0, uint32_t nl, uint64_t n_, uint32_t& next) -> uint64_t {   // one read() from line l0 on: where it stops (relative to the stream)
+        // one read() from line l0 on: where it stops (relative to the stream)
+        auto attempt = [&](int st_, uint32_t l0, uint32_t nl, uint64_t n_, uint32_t& next) -> uint64_t {
             if (l0 + 2u >= nl) { next = nl; return n_; }                                       // fewer than three lines left: read to the end
             const uint32_t* lo_ = T.lo[st_]; bool e3 = false;
             for (uint32_t k = 0; k < 3; k++) if (lo_[l0 + k + 1] - 1u - lo_[l0 + k] == 0u) e3 = true;
@@ -2910,7 +3044,8 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
         if ((hf & H_QUAL_BY_COL) && !(hf & H_DONT_QUAL)) for (uint32_t j = 0; j < nn; j++) st_u32(out + o.off_qual + 4 * j, C.ssize[k0 + j]);
     }
     // per-read arrays
-    if (!(fl & C_READ_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) { const uint32_t v = R.len[f + i]; uint8_t* p = out + o.off_readlens + (size_t)i * rlb; for (uint32_t b = 0; b < rlb; b++) p[b] = (uint8_t)(v >> (8 * b)); }
+    if (!(fl & C_READ_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) { const uint32_t v = R.len[f + i]; uint8_t* p = out + o.off_readlens + (size_t)i * rlb;
+            for (uint32_t b = 0; b < rlb; b++) p[b] = (uint8_t)(v >> (8 * b)); }
     if (!(fl & C_NAME1_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) out[o.off_n1lens + i] = (uint8_t)R.name1_len[f + i];
     if ((hf & H_NAME2) && !(fl & C_NAME2_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) out[o.off_n2lens + i] = (uint8_t)name2_len_of(T, R, f + i);
     if (!(fl & C_STRAND_LEN_SAME)) for (uint32_t i = t; i < s; i += NT) out[o.off_stlens + i] = (uint8_t)line_len(T, f + i, 2);
@@ -2920,7 +3055,8 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
     if (hf & H_Y) copy_to_image(out + o.off_y + 4, ys + 3ull * f, o.y_size, t, NT);
     // names / strand that are stored once
     if (fl & C_NAME1_SAME) { const uint8_t* src = line_ptr(T, f, 0); for (uint32_t i = t; i < o.n1_size; i += NT) out[o.off_n1 + i] = src[i]; }
-    if ((hf & H_NAME2) && (fl & C_NAME2_SAME)) { const uint8_t* src = line_ptr(T, f, 0) + R.name2_off[f]; for (uint32_t i = t; i < o.n2_size; i += NT) out[o.off_n2 + i] = src[i]; }
+    if ((hf & H_NAME2) && (fl & C_NAME2_SAME)) { const uint8_t* src = line_ptr(T, f, 0) + R.name2_off[f];
+            for (uint32_t i = t; i < o.n2_size; i += NT) out[o.off_n2 + i] = src[i]; }
     if (fl & C_STRAND_SAME) { const uint8_t* src = line_ptr(T, f, 2); for (uint32_t i = t; i < o.st_size; i += NT) out[o.off_st + i] = src[i]; }
     // 2-bit bases (src/rfqcodec.cpp:590-604): k_seqpack / k_packbytes left the section's bytes in spk
     copy_to_image(out + o.off_seq, (const uint8_t*)(spk + (size_t)(C.sbase[c] >> 4)), o.seq_size, t, NT);
@@ -2957,7 +3093,8 @@ __device__ __forceinline__ void copy_piece8(uint8_t* __restrict__ d, const uint8
     const uint32_t ng = (n + 15u) >> 4;
     for (uint32_t g = part; g < ng; g += 8u) { uint32_t p0 = 16u * g; if (p0 + 16u > n) p0 = n - 16u; *(GU16*)(d + p0) = *(const GU16*)(src + p0); }
 }
-__global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L, uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base) {
+__global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const Layout* __restrict__ L, uint8_t* __restrict__ img,
+        uint64_t img_cap, uint64_t img_base) {
     const uint32_t c = blockIdx.y; const uint32_t fl = C.flags[c];
     const bool need1 = !(fl & C_NAME1_SAME), need2 = (D->flags & H_NAME2) && !(fl & C_NAME2_SAME), need3 = !(fl & C_STRAND_SAME);
     if (!need1 && !need2 && !need3) return;
