@@ -193,9 +193,21 @@ template <class T> __global__ void k_scan_apply(const T* __restrict__ in, T* __r
     for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run = run + v[i]; }
     if (write_total && base < n && base + SCAN_ITEMS >= n) out[n] = run;
 }
+// a short array (per-chunk quantities: a few thousand elements) by ONE workgroup in ONE launch: every thread sums its run of consecutive elements, one block
+// scan, the runs re-walked with their offsets (three launches took 30 us each way for 3,360 elements, and an encode step has five of these)
+#define SCAN_SMALL 16384u
+template <class T> __global__ void k_scan_small(const T* in, T* out, uint32_t n, int write_total) {
+    const uint32_t K = (n + SCAN_TPB - 1) / SCAN_TPB, i0 = threadIdx.x * K, i1 = i0 + K < n ? i0 + K : n;
+    T acc = T();
+    for (uint32_t i = i0; i < i1; i++) acc = acc + in[i];
+    T tot; T run = block_excl_sum<T>(acc, &tot);
+    for (uint32_t i = i0; i < i1; i++) { const T v = in[i]; out[i] = run; run = run + v; }     // (out may alias in: a thread reads an element before it writes it)
+    if (write_total && threadIdx.x == 0) out[n] = tot;
+}
 // tmp must hold ceil(n / SCAN_TILE) + 1 elements of T
 template <class T> static inline void scan_exclusive(hipStream_t s, const T* in, T* out, uint64_t n, T* tmp, int write_total) {
     if (n == 0) { if (write_total) (void)hipMemsetAsync(out, 0, sizeof(T), s); return; }
+    if (n <= SCAN_SMALL) { hipLaunchKernelGGL((k_scan_small<T>), dim3(1), dim3(SCAN_TPB), 0, s, in, out, (uint32_t)n, write_total); return; }
     const uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, tmp, n);
     hipLaunchKernelGGL((k_scan_partials<T>), dim3(1), dim3(SCAN_TPB), 0, s, tmp, nb, (T*)nullptr);
