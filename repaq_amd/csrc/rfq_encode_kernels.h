@@ -2005,7 +2005,7 @@ __device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb
 // N counts per coder segment, the chunk's N total and N map are left as k_gather leaves them.
 #define SP_OWN 4096u              // tight dwords of one step (the host sizes R by the longest read: R * (max_len / 16 + 1) <= SP_OWN)
 #define SP_EXTRA 8u               // reads behind the step's last whose LDS entries the last dword's tail may need (beyond: global memory)
-#define SP_U 5                    // tight dwords per thread whose loads are in flight together
+#define SP_U 3                    // tight dwords per thread whose loads are in flight together (1 .. 3 measure the same beside the coder, 4 and more cost the stage 0.15 ms: registers)
 struct __attribute__((packed, aligned(4))) SpU8 { uint32_t a, b; };
 struct __attribute__((packed, aligned(2))) SpU4 { uint32_t a; };
 __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const U4* __restrict__ ptot,
