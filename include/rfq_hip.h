@@ -192,8 +192,8 @@ int rfq_host_unregister(rfq_ctx* ctx, void* h_ptr);
  * a batch that differs, to word the reference's message. */
 int rfq_compare_bytes(rfq_ctx* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first_diff);
 
-/* Test / diagnostic switches of one context: name = the RFQ_* environment variable of the same meaning (RFQ_GATHER=old, RFQ_INDEX=2pass, RFQ_IDX_TILES,
- * RFQ_STREAMS=1, RFQ_SLICE_BYTES, RFQ_SLICE_BASES, RFQ_EMIT=2, RFQ_WALK=chain|exact, RFQ_GW_SHIFT, RFQ_MATERIALISE=1, RFQ_TRACE; see RfqOpts in
+/* Test / diagnostic switches of one context: name = the RFQ_* environment variable of the same meaning (RFQ_GATHER=old, RFQ_QUAL=bytes|masks, RFQ_CODER=list|mask, RFQ_INDEX=2pass,
+ * RFQ_IDX_TILES, RFQ_STREAMS=1, RFQ_SLICE_BYTES, RFQ_SLICE_BASES, RFQ_WALK=exact, RFQ_GW_SHIFT, RFQ_MATERIALISE=1, RFQ_TRACE, RFQ_G2_PAD, RFQ_SP_PAD; see RfqOpts in
  * repaq_amd/csrc/rfq_ctx.h), value NULL or "" = default.  Every switch selects another formulation of the same, bit-identical result - they exist so that
  * the tests can pin each one.  The environment is read once, by rfq_create; the batch calls never call getenv. */
 int rfq_set_option(rfq_ctx* ctx, const char* name, const char* value);
