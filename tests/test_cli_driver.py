@@ -181,6 +181,23 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
         r = _run(binary, ["-c", "-i", str(pl), "-o", str(om), "-k", "100", "--batch_mb", "1"] + extra)
         assert r.returncode == 0, r.stderr
         assert om.read_bytes() == want_l, extra
+    # --devices, the reader stops at an empty line early in the input (src/fastqreader.cpp:180-191): the batch that meets it ends the image, the batches
+    # behind it - already uploaded to their devices - contribute nothing; and two files of different length (the pair reader stops with the shorter one)
+    early = fq1[: len(fq1) // 5]; early = early[: early.rfind(b"\n@") + 1] + b"\n\n" + fq1[len(fq1) // 5:]
+    pe_ = tmp_path / "early_stop.fq"; pe_.write_bytes(early)
+    want_e = O.encode_file(early, b"", O.SE, 100_000)
+    assert 0 < len(want_e) < len(og.read_bytes()) // 2
+    for extra in ([], ["--devices", "0,0,0"]):
+        r = _run(binary, ["-c", "-i", str(pe_), "-o", str(om), "-k", "100", "--batch_mb", "1"] + extra)
+        assert r.returncode == 0, r.stderr
+        assert om.read_bytes() == want_e, extra
+    fa, fb = pa.read_bytes(), pb.read_bytes(); cut_b = fb[: fb.rfind(b"\n@", 0, (2 * len(fb)) // 3) + 1]
+    pbs = tmp_path / "r2_short.fq"; pbs.write_bytes(cut_b)
+    want_s = O.encode_file(fa, cut_b, O.PE_TWO_FILES, 100_000)
+    for extra in ([], ["--devices", "0,0,0"]):
+        r = _run(binary, ["-c", "-i", str(pa), "-I", str(pbs), "-o", str(om), "-k", "100", "--batch_mb", "1"] + extra)
+        assert r.returncode == 0, r.stderr
+        assert om.read_bytes() == want_s, extra
     # an empty input leaves an empty .rfq, which decodes to an empty FASTQ (RfqHeader defaults, src/rfqheader.cpp:7-17)
     pz = tmp_path / "empty.fq"; pz.write_bytes(b""); oz = tmp_path / "empty.rfq"; bz = tmp_path / "empty_back.fq"
     assert _run(binary, ["-c", "-i", str(pz), "-o", str(oz)]).returncode == 0 and oz.read_bytes() == b""
