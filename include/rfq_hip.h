@@ -195,11 +195,16 @@ int rfq_compare_bytes(rfq_ctx* ctx, const void* d_a, const void* d_b, size_t n, 
 /* Test / diagnostic switches of one context: name = the RFQ_* environment variable of the same meaning (RFQ_GATHER=old, RFQ_QUAL=bytes|masks, RFQ_CODER=list|mask, RFQ_INDEX=2pass,
  * RFQ_IDX_TILES, RFQ_STREAMS=1, RFQ_SLICE_BYTES, RFQ_SLICE_BASES, RFQ_WALK=exact, RFQ_GW_SHIFT, RFQ_MATERIALISE=1, RFQ_TRACE, RFQ_G2_PAD, RFQ_SP_PAD; see RfqOpts in
  * repaq_amd/csrc/rfq_ctx.h), value NULL or "" = default.  Every switch selects another formulation of the same, bit-identical result - they exist so that
- * the tests can pin each one.  The environment is read once, by rfq_create; the batch calls never call getenv. */
+ * the tests can pin each one (tests/test_gpu_formulations.py forces every one of them on the GPU).  Unknown names and values that are not of the switch's
+ * form or range are RFQ_E_ARG.  The environment is read once, by rfq_create; the batch calls never call getenv. */
 int rfq_set_option(rfq_ctx* ctx, const char* name, const char* value);
+/* the switch's current value in the form rfq_set_option takes ("" = default), so that a caller can put back what it found */
+int rfq_get_option(const rfq_ctx* ctx, const char* name, char* out, size_t cap);
+/* the switches' names: i = 0, 1, ... until NULL */
+const char* rfq_option_name(int i);
 
 /* self test of the wave-level scans / reductions every kernel is built on (DPP row shifts and broadcasts on gfx950): h_in holds 64 * n_waves lane
- * values, h_out receives 12 u64 per lane (see k_selftest_wave in rfq_api.hip); tests/test_gpu_wave.py checks them against a serial reference. */
+ * values, h_out receives 12 u64 per lane (see k_selftest_wave in rfq_api.hip); tests/test_wave_primitives.py checks them against a serial reference. */
 int rfq_selftest_wave(rfq_ctx* ctx, const uint64_t* h_in, uint32_t n_waves, uint64_t* h_out);
 
 /* library / build info: "rfq_hip <version> gfx950" (or "... simt-emulation" for the test build) */

@@ -96,6 +96,8 @@ def load(path=None):
     L.rfq_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.rfq_compare_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.rfq_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.rfq_get_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.rfq_option_name.argtypes = [C.c_int]; L.rfq_option_name.restype = C.c_char_p
     L.rfq_selftest_wave.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64)]
     _libs[path] = L
     return L
@@ -104,4 +106,4 @@ def load(path=None):
 EXPORTS = ["rfq_version", "rfq_create", "rfq_destroy", "rfq_last_error", "rfq_set_stream", "rfq_set_header", "rfq_get_header", "rfq_clear_header",
            "rfq_encode_batch", "rfq_scan_batch", "rfq_decode_batch", "rfq_last_timings", "rfq_dev_malloc", "rfq_dev_free", "rfq_copy_h2d", "rfq_copy_d2h",
            "rfq_copy_h2d_async", "rfq_copy_done", "rfq_copy_sync",
-           "rfq_copy_d2d", "rfq_copy_peer", "rfq_host_alloc", "rfq_host_free", "rfq_compare_bytes", "rfq_selftest_wave", "rfq_set_option", "rfq_host_register", "rfq_host_unregister"]
+           "rfq_copy_d2d", "rfq_copy_peer", "rfq_host_alloc", "rfq_host_free", "rfq_compare_bytes", "rfq_selftest_wave", "rfq_set_option", "rfq_get_option", "rfq_option_name", "rfq_host_register", "rfq_host_unregister"]

@@ -45,17 +45,34 @@ class RfqCodec:
         """rfq_set_option: a test / diagnostic switch of this context (names = the RFQ_* environment variables; None = default)."""
         self._check(self._L.rfq_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
 
+    def get_option(self, name) -> str:
+        """rfq_get_option: the switch's current value ("" = default)"""
+        buf = C.create_string_buffer(64)
+        self._check(self._L.rfq_get_option(self._h, name.encode(), buf, 64))
+        return buf.value.decode()
+
+    def option_names(self):
+        """rfq_option_name: every switch the library knows"""
+        out, i = [], 0
+        while True:
+            n = self._L.rfq_option_name(i)
+            if not n:
+                return out
+            out.append(n.decode()); i += 1
+
     def option(self, name, value):
-        """with codec.option("RFQ_GATHER", "old"): ... - the switch set for the block, back to its default afterwards"""
+        """with codec.option("RFQ_GATHER", "old"): ... - the switch set for the block, back to what it WAS afterwards (an environment-provided
+        or earlier value, not necessarily the built-in default)"""
         import contextlib
 
         @contextlib.contextmanager
         def scope():
+            before = self.get_option(name)
             self.set_option(name, value)
             try:
                 yield self
             finally:
-                self.set_option(name, None)
+                self.set_option(name, before or None)
         return scope()
 
     def selftest_wave(self, lanes):

@@ -5,6 +5,7 @@
 #include <new>
 #include <cstdlib>
 #include <string>
+#include <cerrno>
 
 extern "C" const char* rfq_version(void) {
 #ifdef RFQ_SIMT_EMULATION
@@ -14,32 +15,63 @@ extern "C" const char* rfq_version(void) {
 #endif
 }
 
-// name = the environment variable's name; value NULL or "" = back to the default.  Unknown names are an error (a typo must not pass for a default).
+// name = the environment variable's name; value NULL or "" = back to the default.  Unknown names AND unknown values are errors (a typo must not pass for a
+// default - ADVICE r4: atoll took "foo" for 0 and a negative size for 2^64 - x): numbers are parsed with an end-pointer check and a range per switch.
+static bool opt_num(const std::string& v, long long lo, long long hi, long long* out) {
+    if (v.empty()) return false;
+    errno = 0; char* end = nullptr; const long long x = strtoll(v.c_str(), &end, 10);
+    if (errno || !end || *end || end == v.c_str() || x < lo || x > hi) return false;
+    *out = x; return true;
+}
 extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     if (!c || !name) return RFQ_E_ARG;
-    const std::string n = name, v = value ? value : ""; const bool set = !v.empty(); const RfqOpts d;
-    const long long num = set ? atoll(v.c_str()) : 0;
+    const std::string n = name, v = value ? value : ""; const bool set = !v.empty(); const RfqOpts d; long long num = 0;
+#define RFQ_OPT_NUM(LO, HI, WHAT) if (set && !opt_num(v, LO, HI, &num)) return rfq_fail(c, RFQ_E_ARG, "%s is " WHAT " (got \"%s\")", name, v.c_str());
     if (n == "RFQ_GATHER") { if (set && v != "old" && v != "tile") return rfq_fail(c, RFQ_E_ARG, "RFQ_GATHER is old or tile"); c->opt.gather_old = v == "old"; }
     else if (n == "RFQ_QUAL") { if (set && v != "bytes" && v != "masks") return rfq_fail(c, RFQ_E_ARG, "RFQ_QUAL is bytes or masks"); c->opt.qual_bytes = v == "bytes"; }
     else if (n == "RFQ_CODER") { if (set && v != "list" && v != "mask") return rfq_fail(c, RFQ_E_ARG, "RFQ_CODER is list or mask");
             c->opt.coder = v == "list" ? 1 : (v == "mask" ? 2 : 0); }
-    else if (n == "RFQ_INDEX") { if (set && v != "2pass" && v != "1pass") return rfq_fail(c, RFQ_E_ARG, "RFQ_INDEX is 2pass or 1pass"); c->opt.index_2pass = v == "2pass";
-            }
-    else if (n == "RFQ_IDX_TILES") { if (set && num != 4 && num != 8 && num != 16) return rfq_fail(c, RFQ_E_ARG, "RFQ_IDX_TILES is 4, 8 or 16");
-            c->opt.idx_tiles = set ? (int)num : d.idx_tiles; }
-    else if (n == "RFQ_STREAMS") c->opt.one_stream = set && num == 1;
-    else if (n == "RFQ_SLICE_BYTES") c->opt.slice_bytes = set ? (size_t)num : 0;
-    else if (n == "RFQ_SLICE_BASES") c->opt.slice_bases = set ? (uint64_t)num : 0;
+    else if (n == "RFQ_INDEX") { if (set && v != "2pass" && v != "1pass") return rfq_fail(c, RFQ_E_ARG, "RFQ_INDEX is 2pass or 1pass"); c->opt.index_2pass = v == "2pass"; }
+    else if (n == "RFQ_IDX_TILES") { if (set && v != "4" && v != "8" && v != "16") return rfq_fail(c, RFQ_E_ARG, "RFQ_IDX_TILES is 4, 8 or 16");
+            c->opt.idx_tiles = set ? atoi(v.c_str()) : d.idx_tiles; }
+    else if (n == "RFQ_STREAMS") { if (set && v != "1" && v != "2") return rfq_fail(c, RFQ_E_ARG, "RFQ_STREAMS is 1 or 2"); c->opt.one_stream = v == "1"; }
+    else if (n == "RFQ_SLICE_BYTES") { RFQ_OPT_NUM(1024, 0xFFFFFFF0ll - 16, "a number of bytes in 1024 .. 2^32 - 32") c->opt.slice_bytes = set ? (size_t)num : 0; }
+    else if (n == "RFQ_SLICE_BASES") { RFQ_OPT_NUM(1, 0xFFFFFFF0ll, "a number of bases in 1 .. 2^32 - 16") c->opt.slice_bases = set ? (uint64_t)num : 0; }
     else if (n == "RFQ_WALK") { if (set && v != "exact" && v != "guess") return rfq_fail(c, RFQ_E_ARG, "RFQ_WALK is guess or exact"); c->opt.walk_exact = v == "exact"; }
-    else if (n == "RFQ_GW_SHIFT") c->opt.gw_shift = set ? (int)std::min<long long>(30, std::max<long long>(4, num)) : d.gw_shift;
-    else if (n == "RFQ_MATERIALISE") c->opt.materialise = set && num != 0;
-    else if (n == "RFQ_TRACE") c->opt.trace = set && v != "0";
-    else if (n == "RFQ_G2_PAD") c->opt.g2_pad = set ? (uint32_t)num : 0u;
-    else if (n == "RFQ_SP_PAD") c->opt.sp_pad = set ? (uint32_t)std::min<long long>(150000, std::max<long long>(0, num)) : d.sp_pad;
+    else if (n == "RFQ_GW_SHIFT") { RFQ_OPT_NUM(4, 30, "4 .. 30") c->opt.gw_shift = set ? (int)num : d.gw_shift; }
+    else if (n == "RFQ_MATERIALISE") { if (set && v != "0" && v != "1") return rfq_fail(c, RFQ_E_ARG, "RFQ_MATERIALISE is 0 or 1"); c->opt.materialise = v == "1"; }
+    else if (n == "RFQ_TRACE") { if (set && v != "0" && v != "1") return rfq_fail(c, RFQ_E_ARG, "RFQ_TRACE is 0 or 1"); c->opt.trace = v == "1"; }
+    else if (n == "RFQ_G2_PAD") { RFQ_OPT_NUM(0, 150000, "0 .. 150000 bytes of LDS") c->opt.g2_pad = set ? (uint32_t)num : 0u; }
+    else if (n == "RFQ_SP_PAD") { RFQ_OPT_NUM(0, 150000, "0 .. 150000 bytes of LDS") c->opt.sp_pad = set ? (uint32_t)num : d.sp_pad; }
     else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
+#undef RFQ_OPT_NUM
     return RFQ_OK;
 }
 static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD", "RFQ_SP_PAD" };
+extern "C" const char* rfq_option_name(int i) { return (i >= 0 && i < (int)(sizeof RFQ_OPTION_NAMES / sizeof RFQ_OPTION_NAMES[0])) ? RFQ_OPTION_NAMES[i] : nullptr; }
+// the switch's current value in the form rfq_set_option takes ("" = its default): what a caller saves before it changes a switch for a while
+extern "C" int rfq_get_option(const rfq_ctx* c, const char* name, char* out, size_t cap) {
+    if (!c || !name || !out || !cap) return RFQ_E_ARG;
+    const std::string n = name; const RfqOpts& o = c->opt; const RfqOpts d; std::string v;
+    if (n == "RFQ_GATHER") v = o.gather_old ? "old" : "";
+    else if (n == "RFQ_QUAL") v = o.qual_bytes ? "bytes" : "";
+    else if (n == "RFQ_CODER") v = o.coder == 1 ? "list" : (o.coder == 2 ? "mask" : "");
+    else if (n == "RFQ_INDEX") v = o.index_2pass ? "2pass" : "";
+    else if (n == "RFQ_IDX_TILES") v = o.idx_tiles != d.idx_tiles ? std::to_string(o.idx_tiles) : "";
+    else if (n == "RFQ_STREAMS") v = o.one_stream ? "1" : "";
+    else if (n == "RFQ_SLICE_BYTES") v = o.slice_bytes ? std::to_string(o.slice_bytes) : "";
+    else if (n == "RFQ_SLICE_BASES") v = o.slice_bases ? std::to_string(o.slice_bases) : "";
+    else if (n == "RFQ_WALK") v = o.walk_exact ? "exact" : "";
+    else if (n == "RFQ_GW_SHIFT") v = o.gw_shift != d.gw_shift ? std::to_string(o.gw_shift) : "";
+    else if (n == "RFQ_MATERIALISE") v = o.materialise ? "1" : "";
+    else if (n == "RFQ_TRACE") v = o.trace ? "1" : "";
+    else if (n == "RFQ_G2_PAD") v = o.g2_pad ? std::to_string(o.g2_pad) : "";
+    else if (n == "RFQ_SP_PAD") v = o.sp_pad != d.sp_pad ? std::to_string(o.sp_pad) : "";
+    else return RFQ_E_ARG;
+    if (v.size() + 1 > cap) return RFQ_E_NOSPACE;
+    memcpy(out, v.c_str(), v.size() + 1);
+    return RFQ_OK;
+}
 
 extern "C" int rfq_create(rfq_ctx** out, int device_id) {
     if (!out) return RFQ_E_ARG;
@@ -108,7 +140,7 @@ extern "C" int rfq_get_header(rfq_ctx* c, uint8_t* out, size_t* len) {
     memcpy(out, c->h_hdr.bytes, c->h_hdr.len); *len = c->h_hdr.len;
     return RFQ_OK;
 }
-extern "C" void rfq_clear_header(rfq_ctx* c) { if (c) { c->have_hdr = false; c->dense_ok = false; memset(&c->h_hdr, 0, sizeof c->h_hdr); } }
+extern "C" void rfq_clear_header(rfq_ctx* c) { if (c) { c->have_hdr = false; c->dense_ok = false; c->e3_pieces_failed = false; memset(&c->h_hdr, 0, sizeof c->h_hdr); } }
 
 extern "C" int rfq_last_timings(const rfq_ctx* c, const char** names, float* ms, int cap) {
     if (!c) return 0;
@@ -244,7 +276,7 @@ extern "C" int rfq_copy_d2h(rfq_ctx* c, void* h, const void* d, size_t n) {
 // ---------------------------------------------------------------- self test of the wave primitives (rfq_common.h)
 // Every kernel's scans and reductions go through wave_incl_sum / wave_incl_max / wave_sum / ... - DPP row shifts and row broadcasts on the GPU,
 // shuffles under the SIMT interpreter, which therefore cannot vouch for the DPP forms.  This entry point runs them on caller-chosen lane values so
-// that a GPU test can sweep patterns across all 64 lanes against a serial reference (tests/test_gpu_wave.py).  out: 12 u64 per lane.
+// that a GPU test can sweep patterns across all 64 lanes against a serial reference (tests/test_wave_primitives.py).  out: 12 u64 per lane.
 __global__ void k_selftest_wave(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x; const unsigned long long v = in[i];
     const uint32_t a = (uint32_t)v; const int sa = (int)a;

@@ -109,7 +109,7 @@ __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 // Wave scans and reductions run on DPP (row_shr:1/2/4/8 inside the rows of 16 lanes, row_bcast:15 / row_bcast:31 across them): six VALU
 // instructions with a DPP source operand per 32-bit scan.  The __shfl forms they replace went through ds_bpermute_b32 - address VALU + LDS crossbar
 // + s_waitcnt per step - in kernels that are VALU-issue-bound (1,505 bpermute sites, no DPP).  The SIMT interpreter of the test build
-// (RFQ_SIMT_EMULATION) has no DPP and keeps the shuffle forms; tests/test_gpu_wave.py sweeps both against a serial reference on the GPU.
+// (RFQ_SIMT_EMULATION) has no DPP and keeps the shuffle forms; tests/test_wave_primitives.py sweeps both against a serial reference on the GPU.
 #ifdef RFQ_SIMT_EMULATION
 template <class T> __device__ __forceinline__ T wave_incl_sum(T v) {
     const int l = lane_id();

@@ -32,8 +32,10 @@ struct DecRange { const DChunk* CH; uint32_t n_chunks, n_reads, max_reads, max_s
         uint64_t bases; };
 // RfqCodec::decodeChunk + Read::toString for the chunks of one range (reads, bases and text of a range are placed by 32-bit prefix sums).
 // out1 / out2: caller buffers (16-byte aligned) or null = the context's own result buffers; *p1 / *p2 = where the text went.
+// force_expanded: the retry of a range whose fused emit raised DE_E3_RETRY - straight to the expanded path, whatever made the tile test fail (the retry
+// must terminate by construction, not because a flag happens to be honoured: ADVICE r4)
 static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& g, uint8_t* out1, uint64_t ocap1, uint8_t* out2, uint64_t ocap2,
-                        uint8_t** p1, uint8_t** p2, size_t* n1, size_t* n2, uint64_t* nbases) {
+                        uint8_t** p1, uint8_t** p2, size_t* n1, size_t* n2, uint64_t* nbases, bool force_expanded = false) {
     hipStream_t S = ctx->stream; DBuf* B = ctx->b;
     // (RFQ_MATERIALISE: the expanding decode of a streaming caller's non-final slices, on every call)
     const int tune = ctx->opt.materialise ? 2048 : 0;
@@ -55,7 +57,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // average, full tiles of 64 reads only (name1 has a second instantiation with a 13 KB tile: names of up to ~165 bytes on average, e.g. the configs[4] shape).
     // What does not fit - longer names, reads of more than 2000 bases, chunks of more than 4096 exception records, legacy run-length images - takes the ONE
     // fallback: qualities and bases expanded in HBM, k_dec_emit.  A tile whose pieces turn out longer than the averages allowed for raises DE_E3_RETRY: the range
-    // is decoded again on the fallback, and the context remembers it for the ranges that follow.
+    // is decoded again on the fallback (force_expanded: the retry cannot come back here), and the context remembers it for the ranges that follow until
+    // the next header is set or cleared.
     uint32_t e3k = 6; bool n1big = false;
     while (e3k >= 1 && ((uint64_t)g.max_len << e3k) > E3_QCAP) e3k--;
     if (g.pieces) {
@@ -64,7 +67,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         if (need1 > ET_N1CAP) { if (e3k == 6 && need1 <= E3_N1BIG) n1big = true; else e3k = 0; }
     }
     const bool e3_ok = e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed);
-    const bool fused = !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u && e3_ok;
+    const bool fused = !force_expanded && !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u && e3_ok;
     uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S;
             const uint32_t f_nstr = HH.n_normal + 1;
     // (an early return must not leave the chain running over buffers the next call reuses)
@@ -240,8 +243,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
         if (fused && (hs.err & DE_E3_RETRY)) {                             // per-read name pieces that did not fit a tile: once more, expanded
-            ctx->e3_pieces_failed = true;
-            return decode_range(ctx, a, g, out1, ocap1, out2, ocap2, p1, p2, n1, n2, nbases);
+            if (g.pieces) ctx->e3_pieces_failed = true;                    // (files like this one: the ranges that follow go straight to the expanded path)
+            return decode_range(ctx, a, g, out1, ocap1, out2, ocap2, p1, p2, n1, n2, nbases, true);
         }
     }
     ctx->timer.collect();

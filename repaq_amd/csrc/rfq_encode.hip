@@ -46,7 +46,7 @@ int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n) {
     KCHK(c, "k_hdr_from_bytes");
     HIPCHK(c, c->fetch(&c->h_hdr, c->d_hdr.p, sizeof(DevHeader), c->stream));
     HIPCHK(c, c->fetch_sync(c->stream));
-    c->have_hdr = true; c->dense_ok = false;
+    c->have_hdr = true; c->dense_ok = false; c->e3_pieces_failed = false;   // (another file: what its name pieces fit is not known yet)
     return RFQ_OK;
 }
 

@@ -12,7 +12,10 @@ EMU_LIB = os.path.join(EMU_DIR, "librfq_emu.so")
 PRODUCT_LIB = os.path.join(ROOT, "repaq_amd", "lib", "librfq_hip.so")
 
 
-OPTION_NAMES = ("RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE")
+def reset_options(codec):
+    """every switch the library knows (rfq_option_name) back to its default: what a test that sets switches on a shared codec does afterwards"""
+    for name in codec.option_names():
+        codec.set_option(name, None)
 
 
 def build_emu():
@@ -210,3 +213,81 @@ def check_rle_decode(codec, name, g):
     assert [hashlib.md5(x).hexdigest() for x in (got if split else (got,))] == g["decode_md5"], name
     if split:
         assert codec.decode_bytes(img, split_pe=False) == O.decode_file(img, False), name
+
+
+# ---------------------------------------------------------------- every alternative formulation, forced
+# rfq_set_option switches select another formulation of the same bit-identical result.  On the GPU the fallbacks otherwise run only when the data happens to
+# need them, and the SIMT interpreter cannot see a missing stream dependency, a wrong entry state or a DPP problem: tests/test_gpu_formulations.py forces
+# every one of them on the hardware against the reference's goldens.  marker: a stage name rfq_last_timings must (with "!": must not) show when the switch took effect.
+ENC_FORMS = {
+    "default": ({}, None),
+    "gather_old": ({"RFQ_GATHER": "old"}, "gather_bytes"),                                   # k_gather + k_chunk_flags_a + k_packbytes, k_read_table on every read, k_overlap<false>
+    "qual_bytes": ({"RFQ_QUAL": "bytes"}, "!quality_masks"),                                 # k_gather2<false>: quality bytes + per-byte counters
+    "coder_list": ({"RFQ_QUAL": "bytes", "RFQ_CODER": "list"}, "!quality_masks"),            # k_pos_coder_list on any file
+    "coder_mask": ({"RFQ_QUAL": "bytes", "RFQ_CODER": "mask"}, "!quality_masks"),            # k_pos_coder on byte streams, also with forty values
+    "index_2pass": ({"RFQ_INDEX": "2pass"}, "index_2pass"),                                  # k_nl_bitmap -> scan -> k_line_offsets
+    "idx_tiles4": ({"RFQ_IDX_TILES": "4"}, "!index_2pass"),                                  # k_line_index<4>: four times the workgroups, longer look-backs
+    "one_stream": ({"RFQ_STREAMS": "1"}, None),                                              # both chains on one stream
+    "slices": ({"RFQ_SLICE_BYTES": None}, None),                                             # (value per input: about three chunks per slice)
+    "old_2pass_one_stream": ({"RFQ_GATHER": "old", "RFQ_INDEX": "2pass", "RFQ_STREAMS": "1"}, "gather_bytes"),
+}
+DEC_FORMS = {
+    "default": ({}, None),
+    "walk_exact": ({"RFQ_WALK": "exact"}, "emit_expanded"),                                  # k_dec_walk; it does not look into the payloads: the expanded path behind it
+    "materialise": ({"RFQ_MATERIALISE": "1"}, "emit_expanded"),                              # k_dec_fill / unpack / pos_sum / pos_link / pos_emit / except + k_dec_emit
+    "one_stream": ({"RFQ_STREAMS": "1"}, None),
+    "slice_bases": ({"RFQ_SLICE_BASES": None}, None),                                        # ranges of two or three chunks
+    "gw_small": ({"RFQ_GW_SHIFT": "12"}, None),                                              # many guess-and-verify segments
+    "exact_materialise_slices": ({"RFQ_WALK": "exact", "RFQ_MATERIALISE": "1", "RFQ_SLICE_BASES": None}, None),
+}
+
+
+class _Options:
+    """the switches of a formulation set on a codec; what was there before is put back afterwards"""
+    def __init__(self, codec, opts):
+        self.codec, self.opts, self.before = codec, opts, {}
+
+    def __enter__(self):
+        for k, v in self.opts.items():
+            self.before[k] = self.codec.get_option(k)
+            self.codec.set_option(k, v)
+        return self.codec
+
+    def __exit__(self, *exc):
+        for k, v in self.before.items():
+            self.codec.set_option(k, v or None)
+
+
+def _marker_ok(codec, marker):
+    if marker:
+        names = dict(codec.timings())
+        assert (marker[1:] not in names) if marker.startswith("!") else (marker in names), (marker, sorted(names))
+
+
+def check_encode_formulation(codec, form, fq1, fq2, paired, chunk_bases, want_md5=None, want_len=None, want=None):
+    """one input through rfq_encode_batch with the switches of ENC_FORMS[form]: the image equals the golden (md5 + size) or the expected bytes"""
+    opts, marker = ENC_FORMS[form]
+    opts = dict(opts)
+    if "RFQ_SLICE_BYTES" in opts:
+        opts["RFQ_SLICE_BYTES"] = str(max(4096, int(3 * 2.6 * chunk_bases)))      # about three chunks of text per slice (2.6 bytes of a record per base)
+    with _Options(codec, opts):
+        got = encode(codec, fq1, fq2, paired, chunk_bases)
+        if "RFQ_SLICE_BYTES" not in opts:                                       # (a sliced call reports the stages of its slices summed: the names are there, but not worth a rule)
+            _marker_ok(codec, marker)
+    if want is not None:
+        assert got == want, (form, len(got), len(want))
+    else:
+        assert len(got) == want_len and hashlib.md5(got).hexdigest() == want_md5, (form, len(got), want_len)
+    return got
+
+
+def check_decode_formulation(codec, form, rfq, split, want, chunk_bases=1_000_000):
+    """one image through rfq_decode_batch with the switches of DEC_FORMS[form]: the text equals `want` (bytes; a pair with split)"""
+    opts, marker = DEC_FORMS[form]
+    opts = dict(opts)
+    if "RFQ_SLICE_BASES" in opts:
+        opts["RFQ_SLICE_BASES"] = str(int(2.5 * chunk_bases))
+    with _Options(codec, opts):
+        got = codec.decode_bytes(rfq, split_pe=split)
+        _marker_ok(codec, marker)
+    assert got == want, (form, [len(x) for x in (got if split else (got,))])

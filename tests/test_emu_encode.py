@@ -27,8 +27,7 @@ def codec():
 def _options_back_to_default(codec):
     """rfq_set_option switches a test sets on the shared codec do not outlive it"""
     yield
-    for name in E.OPTION_NAMES:
-        codec.set_option(name, None)
+    E.reset_options(codec)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
