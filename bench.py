@@ -37,10 +37,10 @@ STAGE_KERNELS = {"index": ["k_line_index", "k_line_tail"], "index_2pass": ["k_nl
                  # (tile gather: the overlap search on the loose slots, the stored prefix, the sequence packer and the N streams run on the second stream beside the coder)
                  "pos_coder": ["k_pos_coder", "k_pos_coder_list", "k_overlap", "k_chunk_prefix", "k_seqpack", "k_chunk_layout", "k_coords", "k_rare_cleanup"],
                  "coords+layout": ["k_pos_sizes", "k_chunk_layout"], "assemble": ["k_assemble", "k_assemble_names"], "header": ["k_read_table", "k_hdr_stats", "k_hdr_pass2", "k_dense_order"],
-                 "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_spec_walk", "k_dec_parse"], "dec:read_table": ["k_dec_readtab"],
+                 "dec:walk": ["k_dec_table", "k_dec_rebase", "k_dec_gw_find", "k_dec_gw_walk", "k_dec_gw_stitch", "k_dec_parse", "k_dec_summary"], "dec:read_table": ["k_dec_readtab"],
                  "dec:streams": ["k_dec_coords", "k_dec_pos_sum2", "k_dec_pos_link2", "k_dec_pos_off", "k_dec_pos_list", "k_dec_textlen",   # (fused path: the text lengths run beside the list chain)
                                  # (reads longer than 2000 bases, -k values whose chunks exceed 4096 records, and legacy RLE files take the materialising path)
-                                 "k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_pos_index", "k_dec_except", "k_dec_rle"],
+                                 "k_dec_bases", "k_dec_fill", "k_dec_unpack", "k_dec_pos_sum", "k_dec_pos_link", "k_dec_pos_emit", "k_dec_except", "k_dec_rle"],
                  "dec:textlen": ["k_dec_textlen"], "dec:emit": ["k_dec_emit3"], "dec:emit_expanded": ["k_dec_emit"]}
 
 # stages that are ONE kernel (the roofline object is about a kernel: the longest of these; "pos_coder" is a phase of two streams - the coder beside the
@@ -246,7 +246,7 @@ class Workload:
 
     def decode_walk(self, steps, sync):
         """Decode throughput WITHOUT the encoder's chunk index (a .rfq file has none, src/rfqchunk.cpp:161-228): the library finds the chunk
-        starts itself (k_dec_spec_walk + verifying parse).  Returns (MB/s, walk stage ms)."""
+        starts itself (guess and verify: k_dec_gw_find / walk / stitch + the verifying parse).  Returns (MB/s, walk stage ms)."""
         c = self.codec; r = self.r
         kw = dict(split_pe=self.paired, d_out1=self.o1.data_ptr(), cap1=self.n1 + 64, d_out2=self.o2.data_ptr() if self.paired else None, cap2=(self.n2 + 64) if self.paired else 0)
         c.decode(r.d_rfq, r.rfq_len, **kw); sync()
@@ -580,7 +580,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads / pairs of the workload the CPU baseline is timed on")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] secondary lines")
     ap.add_argument("--encode-only", action="store_true")
-    ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (kernel ablation runs with RFQ_TUNE set)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (A/B runs of a switch or a macro that changes nothing but time)")
     ap.add_argument("--seg-pairs", type=int, default=SEG_PAIRS, help="N>1: pairs per segment of the logical input (test aid: smaller inputs)")
     ap.add_argument("--segs-per-gpu", type=int, default=SEGS_PER_GPU, help="N>1: segments per GPU share (configs[3]: 8 x 2.8 M pairs = 2 x 8 GB per GPU)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two extra passes of one step under rocprofv3 --pmc): take the committed profiles/*_pmc_traffic.json")

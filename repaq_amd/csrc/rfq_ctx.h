@@ -68,7 +68,7 @@ static inline uint32_t grid_x_for(uint32_t n_chunks, uint32_t tiles_per_chunk, u
 struct RfqOpts {
     // RFQ_CODER=list|mask   encode, quality bytes: the list coder / the mask coder whatever the number of coded values (default: list from five on)
     int  coder = 0;
-    // RFQ_QUAL=bytes     encode: k_gather2 writes the quality bytes (qcat) also for files with <= 3 coded values (default there: match masks)
+    // RFQ_QUAL=bytes     encode: k_gather2 writes the quality bytes (qcat) also for files with <= 4 coded values (default there: match masks)
     bool qual_bytes = false;
     bool gather_old = false;          // RFQ_GATHER=old     encode: the byte-wise gather (k_gather + k_packbytes) also for reads that fit a tile
     bool index_2pass = false;         // RFQ_INDEX=2pass    encode: newline bitmap -> scan -> line offsets instead of the one-pass index

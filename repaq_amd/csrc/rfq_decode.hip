@@ -49,7 +49,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // from the packed bytes and lists of coded positions; the lists need nothing but the chunk table, so their chain (stream summaries, link,
     // offsets, lists + cell index) starts NOW on the second stream, beside read table, prefixes, coordinates and text lengths, and is joined in
     // front of the last status read-back before the emitter.  Taken for files with few quality streams whose reads and exception lists fit a
-    // tile; RFQ_TUNE bit 11 forces the materialising path.
+    // tile; RFQ_MATERIALISE=1 forces the materialising path.
     const bool bycol_h = (HH.flags & H_QUAL_BY_COL) && !(HH.flags & H_DONT_QUAL);
     const bool rle_h = !(HH.flags & (H_DONT_QUAL | H_QUAL_BY_COL));          // legacy run-length quality coding: k_dec_rle on the materialising path
     // The fused path ends in k_dec_emit3 (no output tile, K reads per tile: the largest power of two whose qualities fit its tile).  Names FastqMeta::parse does not

@@ -456,7 +456,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, ctx->fetch_sync(S));
     }
     if (make_header && fast) {
-        // the tile gather is instantiated by the header (match masks for <= 3 coded quality values, bytes otherwise): a first batch waits for it here
+        // the tile gather is instantiated by the header (match masks for <= 4 coded quality values, bytes otherwise): a first batch waits for it here
         if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));
         HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
         HIPCHK(ctx, ctx->fetch_sync(S));

@@ -243,7 +243,7 @@ def test_decode_in_slices_equals_one_shot(codec, step):
                          ids=["se150", "bgi_q40", "se150_manyN"])
 def test_full_size_chunk_position_streams_span_many_segments(codec, prof, reads, kw):
     """-k 1000 chunks: position streams of 10-100 KB are decoded in 1 KB / 2 KB segments by independent waves, which enter them in any of the token
-    automaton's states - by the list passes (k_dec_pos_sum2 / link2 / list) and, RFQ_TUNE=2048, by the materialising path a streaming caller's
+    automaton's states - by the list passes (k_dec_pos_sum2 / link2 / list) and, RFQ_MATERIALISE=1, by the materialising path a streaming caller's
     non-final slices take (k_dec_pos_sum / link / emit)."""
     fq1, fq2 = O.gen(prof, reads, seed=9, **kw)
     rfq = O.encode_file(fq1, fq2, O.PE_TWO_FILES if fq2 else O.SE, 1_000_000)

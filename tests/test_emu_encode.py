@@ -124,7 +124,7 @@ def test_strand_lines_of_equal_length_and_different_bytes(codec, gather):
 
 @pytest.mark.parametrize("label,prof,reads,seed,cb,paired,kw", MULTI[:6], ids=[m[0] for m in MULTI[:6]])
 def test_multichunk_quality_bytes_instead_of_masks_matches_oracle(codec, label, prof, reads, seed, cb, paired, kw):
-    """RFQ_QUAL=bytes: k_gather2 writes the quality bytes and counts them (the path of files with more than three coded values) where the default is match masks."""
+    """RFQ_QUAL=bytes: k_gather2 writes the quality bytes and counts them (the path of files with more than four coded values) where the default is match masks."""
     codec.set_option("RFQ_QUAL", "bytes")
     fq1, fq2 = O.gen(prof, reads, seed=seed, **kw)
     assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
@@ -132,7 +132,7 @@ def test_multichunk_quality_bytes_instead_of_masks_matches_oracle(codec, label, 
 
 
 def test_match_masks_with_values_chunk_0_does_not_have(codec):
-    """Match-mask mode (<= 3 coded quality values in the header, which comes from chunk 0): values that first appear in later chunks are exception records -
+    """Match-mask mode (<= 4 coded quality values in the header, which comes from chunk 0): values that first appear in later chunks are exception records -
     their bytes go to qcat at their positions, their bits to the exception plane; runs of them, at word / tile / segment borders, in reversed mates."""
     import random
     rng = random.Random(5)
