@@ -10,7 +10,8 @@ made by tests/golden/make_golden_big.py with the compiled reference), the decode
 Secondary lines (same JSON object, "secondary"): configs[1] (SE150 1 GB, md5 vs the reference golden) and the configs[4] shape
 (BGI-style PE100, 40 quality values).
 
-N > 1: ONE configs[3]-shaped PE150 input of N x (2 x 8 GB) encoded chunk-parallel by the N GPUs: see run_multi().
+N > 1: ONE configs[3]-shaped PE150 input of N x (2 x 8 GB) encoded chunk-parallel by the N GPUs: see run_multi() (static resident shares + a plan step);
+--queue: the same input through a host work queue - rank-agnostic batches pulled from a shared counter - see run_queue() (also with --gpus 1: the whole input on one GPU).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -380,6 +381,44 @@ def line_of(w, steps, dt, total_bytes, parity):
 SEG_PAIRS, SEG_SEED0, SEGS_PER_GPU, HEAD_PAIRS = 2_800_000, 4000, 8, 4000
 
 
+def peak_rss_gb():
+    import resource
+    return round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 2)          # (ru_maxrss is in KB on Linux)
+
+
+def segments_to_device(dev, seg_ids, seg_pairs, head_seed=None, head_pairs=0, threads=8):
+    """Segments `seg_ids` of the logical input (segment s = fqgen profile 1, `seg_pairs` pairs, seed SEG_SEED0 + s), then the first `head_pairs` pairs of segment
+    `head_seed`, laid end to end in ONE device buffer per stream.  The generator's threads hand each finished segment to the main thread, which copies it to its
+    place on the device and drops it: at most `threads` + 1 segments (2 x 1 GB each at full size) are alive on the host at any time - round 4 concatenated all of
+    a rank's segments on the host first (np.concatenate: twice the share, 32 GB per rank at configs[3] size).  Returns (t1, t2, [(n1, n2) per segment],
+    bytes of the head in each stream)."""
+    import collections
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    import _oracle as O
+    cap = (len(seg_ids) * seg_pairs + head_pairs) * 360 + 4096                          # (a NovaSeq-profile record is at most 359 bytes: see _oracle.gen_np)
+    t1 = torch.empty(cap, dtype=torch.uint8, device=dev); t2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    sizes, o1, o2 = [], 0, 0
+    jobs = [(SEG_SEED0 + s_, seg_pairs) for s_ in seg_ids] + ([(SEG_SEED0 + head_seed, head_pairs)] if head_pairs else [])
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        pend = collections.deque(); it = iter(jobs)
+        def feed():
+            while len(pend) < max(1, threads):
+                j = next(it, None)
+                if j is None:
+                    return
+                pend.append(ex.submit(lambda sd, n_: O.gen_np(O.NOVA_PE150, n_, seed=sd), j[0], j[1]))
+        feed()
+        while pend:
+            a, b = pend.popleft().result()
+            feed()
+            t1[o1:o1 + a.size].copy_(torch.from_numpy(a)); t2[o2:o2 + b.size].copy_(torch.from_numpy(b))
+            sizes.append((int(a.size), int(b.size))); o1 += int(a.size); o2 += int(b.size)
+            del a, b
+    head = sizes.pop() if head_pairs else (0, 0)
+    return t1, t2, sizes, head
+
+
 def pin_to_gpu_numa(local):
     """Bind this process to the CPUs of the NUMA node its GPU hangs off (set-up work - generating the rank's text, the host side of hipMemcpy - then stays off
     the other sockets' memory).  Returns the node, or None when the topology cannot be read (nothing is changed then)."""
@@ -434,23 +473,12 @@ def run_multi(args, rank, world, local):
     # (set-up, untimed: the generator is a C loop that drops the GIL - the rank's segments are made on several threads, on the cores next to its GPU)
     numa = pin_to_gpu_numa(local)
     t_gen = time.perf_counter()
-    from concurrent.futures import ThreadPoolExecutor
     gen_threads = max(1, min(per, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)) // max(1, world if numa is None else 1), 8))
-    with ThreadPoolExecutor(gen_threads) as ex:
-        segs = list(ex.map(lambda s_: O.gen_np(O.NOVA_PE150, seg_pairs, seed=SEG_SEED0 + s_), range(per * rank, per * rank + per)))
-    parts1, parts2 = [a for a, _ in segs], [b for _, b in segs]
-    a = b = None
-    del segs
-    share1, share2 = sum(int(x.size) for x in parts1), sum(int(x.size) for x in parts2)
-    if rank < world - 1:
-        a, b = O.gen_np(O.NOVA_PE150, min(HEAD_PAIRS, seg_pairs), seed=SEG_SEED0 + per * (rank + 1))
-        parts1.append(a); parts2.append(b)
+    t1, t2, sizes, head = segments_to_device(dev, range(per * rank, per * rank + per), seg_pairs, head_seed=per * (rank + 1), head_pairs=(min(HEAD_PAIRS, seg_pairs) if rank < world - 1 else 0),
+                                             threads=gen_threads)
+    share1, share2 = sum(x[0] for x in sizes), sum(x[1] for x in sizes)
+    avail1, avail2 = share1 + head[0], share2 + head[1]
     gen_s = time.perf_counter() - t_gen
-    h1 = torch.from_numpy(np.concatenate(parts1)); h2 = torch.from_numpy(np.concatenate(parts2))
-    del parts1, parts2, a, b
-    avail1, avail2 = int(h1.numel()), int(h2.numel())
-    t1 = h1.to(dev); t2 = h2.to(dev)
-    del h1, h2
     lens = [None] * world
     dist.all_gather_object(lens, (share1, share2))
     off1, off2 = sum(x[0] for x in lens[:rank]), sum(x[1] for x in lens[:rank])
@@ -540,7 +568,7 @@ def run_multi(args, rank, world, local):
     K_ = args.steps
     mine_line = {"rank": rank, "gpu": local, "numa_node": numa, "fastq_bytes": n1 + n2, "chunks": r.n_chunks, "s_per_step": round(my_dt / K_, 5),
                  "encode_MBps": round((n1 + n2) * K_ / state["enc_s"] / 1e6, 1) if state["enc_s"] else None, "decode_MBps": round((n1 + n2) * K_ / state["dec_s"] / 1e6, 1) if state["dec_s"] else None,
-                 "setup_generate_s": round(gen_s, 1), "gen_threads": gen_threads, "stage_ms": {k: round(v / K_, 3) for k, v in state["stage"].items()}}
+                 "setup_generate_s": round(gen_s, 1), "gen_threads": gen_threads, "peak_host_rss_gb": peak_rss_gb(), "stage_ms": {k: round(v / K_, 3) for k, v in state["stage"].items()}}
     ranks = [None] * world
     dist.all_gather_object(ranks, mine_line)
     if rank == 0:
@@ -567,6 +595,166 @@ def run_multi(args, rank, world, local):
     dist.destroy_process_group()
 
 
+def run_queue(args, rank, world, local):
+    """--queue: the host work queue north_star names, in bench form.  ONE configs[3]-shaped logical input (--segs-per-gpu x N segments; N = 8: 2 x 64 GB) is resident in
+    the HBM of EVERY GPU (128 GB of text at N = 8: it fits 288 GB), planned once (rfq_scan_batch: where every chunk ends), and cut into batches of --queue-chunks whole
+    chunks.  A step: every rank pulls batch numbers from ONE shared counter (the rendezvous store's atomic add; a local counter for N = 1) until none are left, and
+    encodes (+ decodes) each batch it got - rank-agnostic, no static shares, no data-path collective; the next ticket is fetched while the GPU works on the current
+    batch.  Parity (untimed pass): the (crc32, size) of every chunk image, gathered by batch number, against the reference's table for the whole input
+    (tests/golden/cfg3.json) - with N = 1 this is the whole configs[3] input through ONE GPU - and every decoded batch against its text.
+    Counterpart in the product: repaq_hip --devices (do_compress_multi / do_decompress_multi), which also moves the text over PCIe."""
+    import struct
+    import threading
+    import zlib
+    import torch
+    import torch.distributed as dist
+    from repaq_amd import RfqCodec, PE_TWO_FILES, dist as D
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    codec = RfqCodec(device=local)
+    seg_pairs, nseg = args.seg_pairs, args.segs_per_gpu * (1 if args.strong else world)
+    cb = max(100, args.chunk_kb) * 1000
+    numa = pin_to_gpu_numa(local)
+    t_gen = time.perf_counter()
+    gen_threads = max(1, min(nseg, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)) // max(1, world if numa is None else 1), 8))
+    t1, t2, sizes, _ = segments_to_device(dev, range(nseg), seg_pairs, threads=gen_threads)
+    n1, n2 = sum(x[0] for x in sizes), sum(x[1] for x in sizes)
+    gen_s = time.perf_counter() - t_gen
+    # ---- the plan: every chunk's end in both streams (every rank scans the same text: set-up, untimed)
+    torch.cuda.synchronize(); D.barrier()
+    t_plan = time.perf_counter()
+    sr, e1, e2 = codec.scan(t1.data_ptr(), n1, t2.data_ptr(), n2, PE_TWO_FILES, cb, final=True)
+    plan_ms = (time.perf_counter() - t_plan) * 1e3
+    nc = sr.n_chunks; B = max(1, args.queue_chunks); nb = (nc + B - 1) // B
+    cut1 = [0] + [e1[min(nc, (b + 1) * B) - 1] for b in range(nb)]; cut2 = [0] + [e2[min(nc, (b + 1) * B) - 1] for b in range(nb)]
+    cut1[-1], cut2[-1] = n1, n2                                                   # (the last batch runs to the end of the input: final)
+    big1 = max(cut1[b + 1] - cut1[b] for b in range(nb)); big2 = max(cut2[b + 1] - cut2[b] for b in range(nb))
+    o1 = torch.empty(big1 + 64, dtype=torch.uint8, device=dev); o2 = torch.empty(big2 + 64, dtype=torch.uint8, device=dev)
+    store = dist.distributed_c10d._get_default_store() if world > 1 else None
+    local_ctr = {}
+
+    def take(key):                                                                # the shared counter: the next batch nobody has taken yet
+        if store is not None:
+            return int(store.add(key, 1)) - 1
+        local_ctr[key] = local_ctr.get(key, -1) + 1
+        return local_ctr[key]
+
+    state = {"stage": {}, "enc_s": 0.0, "dec_s": 0.0, "batches": 0, "bytes": 0}
+
+    def one(b, collect, check=None):
+        last = b == nb - 1
+        a1, a2 = cut1[b], cut2[b]; m1, m2 = cut1[b + 1] - a1, cut2[b + 1] - a2
+        t_a = time.perf_counter()
+        r = codec.encode(t1.data_ptr() + a1, m1, t2.data_ptr() + a2, m2, PE_TWO_FILES, cb, final=last, emit_header=(b == 0), file_off1=a1, file_off2=a2, flush_all=not last)
+        t_b = time.perf_counter()
+        if collect:
+            for name, ms in codec.timings():
+                state["stage"][name] = state["stage"].get(name, 0.0) + ms
+        d = None
+        if not args.encode_only:
+            d = codec.decode(r.d_rfq, r.rfq_len, has_header=(b == 0), split_pe=True, final=last, d_out1=o1.data_ptr(), cap1=big1 + 64, d_out2=o2.data_ptr(), cap2=big2 + 64,
+                             chunk_off=r.h_chunk_off, n_chunks=r.n_chunks)
+            if collect:
+                for name, ms in codec.timings():
+                    state["stage"]["dec:" + name] = state["stage"].get("dec:" + name, 0.0) + ms
+        if collect:
+            t_c = time.perf_counter()
+            state["enc_s"] += t_b - t_a; state["dec_s"] += t_c - t_b; state["batches"] += 1; state["bytes"] += m1 + m2
+        if check is not None:
+            assert r.consumed1 == m1 and r.consumed2 == m2, "batch %d was not encoded whole" % b
+            img = codec.dev_get(r.d_rfq, r.rfq_len); offs = [r.h_chunk_off[i] for i in range(r.n_chunks + 1)]
+            check[b] = [(zlib.crc32(img[offs[i]:offs[i + 1]]) & 0xFFFFFFFF, offs[i + 1] - offs[i]) for i in range(r.n_chunks)]
+            if d is not None:
+                assert d.n1 == m1 and d.n2 == m2 and torch.equal(o1[:m1], t1[a1:a1 + m1]) and torch.equal(o2[:m2], t2[a2:a2 + m2]), "batch %d: decoded text differs from the input" % b
+        return r
+
+    def drain(key, collect, check=None):
+        """pull batches until the counter runs past the last one; the next ticket is on its way while this one is worked on"""
+        nxt = {"b": take(key)}
+        while nxt["b"] < nb:
+            b = nxt["b"]
+            th = threading.Thread(target=lambda: nxt.__setitem__("b", take(key)))
+            th.start()
+            one(b, collect, check)
+            th.join()
+
+    # ---- header: batch 0 on rank 0 makes it (RfqCodec::makeHeader), every rank sets it
+    if rank == 0:
+        codec.clearHeader(); one(0, False)
+    hdr = D.share_header(codec)
+    # ---- parity of what is being measured: one untimed pass over the queue
+    parity = "unchecked"
+    if not args.no_verify:
+        mine = {}
+        drain("verify", False, mine)
+        allc = [None] * world
+        if world > 1:
+            dist.all_gather_object(allc, mine)
+        else:
+            allc = [mine]
+        if rank == 0:
+            got = {}
+            for part in allc:
+                got.update(part)
+            assert sorted(got) == list(range(nb)), "the queue did not hand out every batch exactly once"
+            chunks = [c for b in range(nb) for c in got[b]]
+            parity = "%d chunks in %d batches over %d rank(s)" % (len(chunks), nb, world)
+            try:
+                g = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3.json")))
+            except OSError:
+                g = None
+            if g and g["seg_pairs"] == seg_pairs and g["seed0"] == SEG_SEED0 and g["segments"] >= nseg and cb == 1_000_000:
+                assert hdr.hex() == g["header_hex"], "header differs from the reference's"
+                G = g["group"]; whole = len(chunks) if g["segments"] == nseg else len(chunks) - 1
+                if g["segments"] == nseg:
+                    assert len(chunks) == g["n_chunks"], "chunk count differs from the reference's"
+                ok = 0
+                for gi in range(whole // G):
+                    hh = hashlib.md5()
+                    for c in chunks[gi * G:(gi + 1) * G]:
+                        hh.update(struct.pack("<II", c[0], c[1]))
+                    assert hh.hexdigest()[:16] == g["group_md5"][gi], "chunks %d..%d differ from the reference's" % (gi * G, gi * G + G - 1)
+                    ok += G
+                parity += ": header and %d chunk images (crc32 + size, groups of %d) == reference golden" % (ok, G)
+            else:
+                parity += " (no reference golden for this shape)"
+            parity += "; every batch: decode == its input text" if not args.encode_only else ""
+    # ---- timed: K passes over the queue
+    for w_ in range(args.warmup):
+        drain("warm%d" % w_, False)
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k_ in range(args.steps):
+        drain("step%d" % k_, True)
+        D.barrier()                                                               # (a pass ends when the queue is empty AND every rank is done with what it took)
+    torch.cuda.synchronize(); D.barrier()
+    dt = time.perf_counter() - t0
+    dt = D.reduce_max_sum(dt, 0)[0]
+    K = args.steps; passes = 1 if args.encode_only else 2
+    mine_line = {"rank": rank, "gpu": local, "numa_node": numa, "batches_per_step": round(state["batches"] / K, 1), "fastq_bytes_per_step": state["bytes"] // K,
+                 "encode_MBps": round(state["bytes"] / state["enc_s"] / 1e6, 1) if state["enc_s"] else None, "decode_MBps": round(state["bytes"] / state["dec_s"] / 1e6, 1) if state["dec_s"] else None,
+                 "setup_generate_s": round(gen_s, 1), "gen_threads": gen_threads, "peak_host_rss_gb": peak_rss_gb(), "stage_ms": {k: round(v / K, 3) for k, v in state["stage"].items()}}
+    ranks = [None] * world
+    if world > 1:
+        dist.all_gather_object(ranks, mine_line)
+    else:
+        ranks = [mine_line]
+    if rank == 0:
+        total = n1 + n2
+        out = {"metric": "raw FASTQ MB/s encode+decode" if passes == 2 else "raw FASTQ MB/s encode", "value": round(total * passes * K / dt / 1e6, 1), "unit": "MB/s", "n_gpus": world,
+               "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+               "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "configs[3] shape through the host work QUEUE: ONE synthetic NovaSeq PE150 input of 2 x %.1f GB FASTQ (%d segments: fqgen profile 1, %d pairs, seed %d + s), -k %d, "
+                                      "resident in every GPU's HBM; batches of %d chunks pulled from one shared counter by %d rank(s) (encode%s per batch; plan + header over the host, no RCCL)"
+                                      % (total / 2e9, nseg, seg_pairs, SEG_SEED0, args.chunk_kb, B, world, "" if args.encode_only else " + decode"),
+                          "queue": True, "batches": nb, "chunks": nc, "parity": parity, "plan": "scan of the whole input on every rank", "plan_ms": round(plan_ms, 2), "strong": bool(args.strong), "ranks": ranks},
+               "roofline": None}
+        print(json.dumps(out))
+    codec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -585,6 +773,8 @@ def main():
     ap.add_argument("--segs-per-gpu", type=int, default=SEGS_PER_GPU, help="N>1: segments per GPU share (configs[3]: 8 x 2.8 M pairs = 2 x 8 GB per GPU)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two extra passes of one step under rocprofv3 --pmc): take the committed profiles/*_pmc_traffic.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the counter passes: one warm-up + one step, nothing else
+    ap.add_argument("--queue", action="store_true", help="the host work queue: the whole logical input resident on every GPU, batches of --queue-chunks chunks pulled from one shared counter (see run_queue); works with --gpus 1 too")
+    ap.add_argument("--queue-chunks", type=int, default=256, help="--queue: chunks per batch")
     ap.add_argument("--strong", action="store_true", help="N>1: strong scaling - the input is --segs-per-gpu segments IN ALL (default 8 = 2 x 8 GB), split over the N GPUs")
     args = ap.parse_args()
 
@@ -598,6 +788,9 @@ def main():
         local = 0
     if world > 1:
         D.init("gloo")          # host-side rendezvous only (barriers, max-over-ranks time, the <= 272-byte header, chunk hashes): no RCCL on this path
+    if args.queue:
+        return run_queue(args, rank, world, local)
+    if world > 1:
         return run_multi(args, rank, world, local)
 
     torch.cuda.set_device(local)
