@@ -732,7 +732,7 @@ def run_queue(args, rank, world, local):
     dt = D.reduce_max_sum(dt, 0)[0]
     K = args.steps; passes = 1 if args.encode_only else 2
     mine_line = {"rank": rank, "gpu": local, "numa_node": numa, "batches_per_step": round(state["batches"] / K, 1), "fastq_bytes_per_step": state["bytes"] // K,
-                 "encode_MBps": round(state["bytes"] / state["enc_s"] / 1e6, 1) if state["enc_s"] else None, "decode_MBps": round(state["bytes"] / state["dec_s"] / 1e6, 1) if state["dec_s"] else None,
+                 "encode_MBps": round(state["bytes"] / state["enc_s"] / 1e6, 1) if state["enc_s"] else None, "decode_MBps": round(state["bytes"] / state["dec_s"] / 1e6, 1) if (state["dec_s"] and not args.encode_only) else None,
                  "setup_generate_s": round(gen_s, 1), "gen_threads": gen_threads, "peak_host_rss_gb": peak_rss_gb(), "stage_ms": {k: round(v / K, 3) for k, v in state["stage"].items()}}
     ranks = [None] * world
     if world > 1:

@@ -292,10 +292,16 @@ struct Gpu {
 struct Block { uint8_t* p = nullptr; size_t n = 0; };
 class Prefetcher {
     // g: null until attach() - the readers then fill ordinary page-aligned buffers (plain), which attach() page-locks
-    ByteSource src; Gpu* g; std::vector<uint8_t*> plain; size_t block;
-    uint8_t* new_block() { if (g) return g->pinned(block); void* p = nullptr; if (posix_memalign(&p, 4096, block + 64) != 0) error_exit("out of memory");
-            std::unique_lock<std::mutex> lk(mu); if (g) { lk.unlock(); g->check(rfq_host_register(g->c, p, block + 64)); } else plain.push_back((uint8_t*)p);
-            return (uint8_t*)p; } std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
+    // (g is written by attach() on the main thread while the readers run: atomic.  plain: buffers not page-locked yet; owned: every buffer this object made with
+    // posix_memalign - page-locked by rfq_host_register at some point - to be unregistered and freed at the end; pinned_: those that came from rfq_host_alloc)
+    ByteSource src; std::atomic<Gpu*> g; std::vector<uint8_t*> plain, owned, pinned_; size_t block;
+    uint8_t* new_block() {
+        if (Gpu* gp = g.load()) { uint8_t* p = gp->pinned(block); std::unique_lock<std::mutex> lk(mu); pinned_.push_back(p); return p; }
+        void* p = nullptr; if (posix_memalign(&p, 4096, block + 64) != 0) error_exit("out of memory");
+        std::unique_lock<std::mutex> lk(mu); owned.push_back((uint8_t*)p);
+        if (Gpu* gp = g.load()) { lk.unlock(); gp->check(rfq_host_register(gp->c, p, block + 64)); } else plain.push_back((uint8_t*)p);
+        return (uint8_t*)p; }
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
     // to_alloc: page-locked blocks not allocated yet (a reader allocates its own: pinning runs beside the first reads)
     std::map<uint64_t, Block> ready; uint64_t next_out = 0, next_claim = 0, n_blocks = 0; std::vector<uint8_t*> freeb; int to_alloc = 0;
     bool eof = false, stop = false, regular = false; uint64_t total = 0; int last_byte = -1; int fd = -1; int running = 0; int nbuf_ = 4;
@@ -328,7 +334,7 @@ class Prefetcher {
     }
 public:
     // (the context may come later: a compress starts its readers first and creates the context - 0.2 s of HIP start-up - while they fill their first blocks)
-    void attach(Gpu& gpu) { std::vector<uint8_t*> todo; { std::unique_lock<std::mutex> lk(mu); g = &gpu; todo.swap(plain);
+    void attach(Gpu& gpu) { std::vector<uint8_t*> todo; { std::unique_lock<std::mutex> lk(mu); g.store(&gpu); todo.swap(plain);
             } for (uint8_t* p : todo) gpu.check(rfq_host_register(gpu.c, p, block + 64)); }
     Prefetcher(Gpu& gpu, const std::string& path, size_t block_bytes, int threads = 1) : Prefetcher(&gpu, path, block_bytes, threads) {}
     Prefetcher(Gpu* gpu, const std::string& path, size_t block_bytes, int threads = 1) : g(gpu), block(block_bytes) {
@@ -351,7 +357,11 @@ public:
     }
     // (a caller that stops early — an empty line ends the input, a failed compare — leaves blocks unread: wake the readers up)
     ~Prefetcher() { { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); } for (auto& t : th) if (t.joinable()) t.join(); if (fd >= 0) ::close(fd);
-            else src.close(); }
+            else src.close();
+            // the staging buffers go back (registered blocks were never unregistered or freed; harmless in a process that _exits, not in one that serves many jobs)
+            Gpu* gp = g.load();
+            for (uint8_t* p : owned) { if (gp && std::find(plain.begin(), plain.end(), p) == plain.end()) (void)rfq_host_unregister(gp->c, p); free(p); }
+            if (gp) for (uint8_t* p : pinned_) (void)rfq_host_free(gp->c, p); }
     // next block; false when the input is exhausted.  After it returns, end_known() tells whether the end of the input is known;
     // if not, at least two more full blocks follow the one just returned.
     bool next(Block& b) {
@@ -567,11 +577,19 @@ static void do_compress(const Options& o) {
         }
         for (int s = 0; s < ns; s++) ds[s].drain(g, true, [&](const Block& x) { in[s]->release(x); });      // every queued copy has landed
         trace_mark("compress: batch resident");
-        const bool final = ds[0].ended && (!two || ds[1].ended);
+        bool final = ds[0].ended && (!two || ds[1].ended);
         rfq_encode_args a; memset(&a, 0, sizeof a);
         a.d_fq1 = ds[0].base(); a.n1 = ds[0].have; a.d_fq2 = two ? ds[1].base() : nullptr; a.n2 = two ? ds[1].have : 0; a.paired = paired;
-        a.chunk_bases = (uint32_t)(std::max(100L, o.chunkKb) * 1000); a.final = final ? 1 : 0; a.emit_header = first ? 1 : 0;
+        a.chunk_bases = (uint32_t)(std::max(100L, o.chunkKb) * 1000); a.emit_header = first ? 1 : 0;
         a.file_off1 = ds[0].file_off; a.file_off2 = ds[1].file_off;
+        // one file of a pair is used up, the other goes on: FastqReaderPair::read stops with the shorter file (src/fastqreader.cpp:287-299), so when a final plan of
+        // what is resident uses the short stream up, this batch ends the input - the rest of the longer file is never read (it used to be read, uploaded and, holding no
+        // whole chunk, re-planned batch after batch)
+        if (!final && two && ds[0].ended != ds[1].ended) {
+            const int s0 = ds[0].ended ? 0 : 1; rfq_scan_result sf; a.final = 1; g.check(rfq_scan_batch(g.c, &a, &sf));
+            if (!sf.input_ended && (s0 == 0 ? sf.consumed1 : sf.consumed2) == ds[s0].have) final = true;
+        }
+        a.final = final ? 1 : 0;
         // FastqReader::hasNoLineBreakAtEnd (src/fastqreader.cpp:31-46): known once the reader thread has seen
         // the end of the input; until then at least two full blocks (>= 2 MiB) follow this batch, so no chunk of it can reach the
         // reader's final 1 MiB block
@@ -607,6 +625,7 @@ struct MBatch {
     uint64_t seq = 0; int w = 0;
     void* buf[2] = { nullptr, nullptr }; size_t cap[2] = { 0, 0 }, room = 0, n[2] = { 0, 0 };   // device buffers: [room for the carry][the batch's own bytes]
     uint64_t file_off[2] = { 0, 0 }, th[2] = { UINT64_MAX, UINT64_MAX }; bool last = false;
+    bool eof[2] = { false, false };      // the stream's file ended in this batch or before it: its text here (carry included) is all that is left of it
     // what this batch leaves to the next one (set by its worker, before it encodes)
     bool carry_ready = false, carry_taken = false, ended = false, hdr_promised = false;
     rfq_ctx* owner = nullptr; const uint8_t* carry_ptr[2] = { nullptr, nullptr }; size_t carry_n[2] = { 0, 0 }; uint64_t carry_off[2] = { 0, 0 };
@@ -623,6 +642,9 @@ static void do_compress_multi(const Options& o) {
     for (int s = 0; s < ns; s++) in[s]->attach(*gin[0]);                       // (the staging blocks are page-locked once; every device copies out of them)
     std::mutex mu; std::condition_variable cv;
     std::map<uint64_t, std::shared_ptr<MBatch>> batches; uint64_t n_batches = 0; bool all_ingested = false;
+    // a worker has seen the end of the input in front of the files' ends - an empty line (src/fastqreader.cpp:180-191), or the shorter file of a pair used up
+    // (FastqReaderPair::read stops there, :287-299): nothing behind it is ever read, so the ingestion stops uploading (it read and uploaded the whole rest)
+    bool stop_ingest = false;
     std::vector<uint8_t> header; bool header_ready = false;
     std::map<uint64_t, std::vector<uint8_t>> done; uint64_t next_write = 0;
     ByteSink sink; sink.open(o.out1, o);
@@ -656,7 +678,7 @@ static void do_compress_multi(const Options& o) {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return done.size() < 4 * (size_t)D || b->seq == next_write; });
                 done[b->seq] = std::move(img); cv.notify_all();
-                if (!b->last) cv.wait(lk, [&] { return b->carry_taken; });
+                if (!b->last) cv.wait(lk, [&] { return b->carry_taken || (all_ingested && b->seq + 1 >= n_batches); });   // (no batch behind me: nobody will take a carry)
                 lk.unlock();
                 for (int s = 0; s < ns; s++) if (b->buf[s]) rfq_dev_free(g.c, b->buf[s]);
                 lk.lock(); batches.erase(b->seq >= 2 ? b->seq - 2 : UINT64_MAX); cv.notify_all();
@@ -687,10 +709,22 @@ static void do_compress_multi(const Options& o) {
             a.d_fq1 = tx[0]; a.n1 = tn[0]; a.d_fq2 = two ? tx[1] : nullptr; a.n2 = two ? tn[1] : 0; a.paired = paired; a.chunk_bases = chunk_bases;
             a.file_off1 = toff[0]; a.file_off2 = toff[1]; a.nolb_from1 = b->th[0]; a.nolb_from2 = two ? b->th[1] : b->th[0];
             size_t en[2] = { tn[0], tn[1] }; bool encode_final = b->last, nothing = false, ended = false;
-            if (!b->last) {                                                    // plan: where my last whole chunk ends; the rest is the next batch's
+            // One file of a pair is used up (all that is left of it is in front of me) and the other one goes on: the pair reader stops with the shorter file, so once
+            // every record of the short one finds its mate in MY text this batch ends the input - and the batches behind it, text of the longer file only, would
+            // each hold no whole chunk and hand their whole text on as carry (quadratic, unbounded).  A final plan tells: it must use the short stream up.
+            if (!b->last && two && (b->eof[0] != b->eof[1])) {
+                const int s0 = b->eof[0] ? 0 : 1;
+                rfq_scan_result sf; a.final = 1; g.check(rfq_scan_batch(g.c, &a, &sf));
+                if (!sf.input_ended && (s0 == 0 ? sf.consumed1 : sf.consumed2) == tn[s0]) {
+                    encode_final = true; ended = true;
+                    publish(true, true, nullptr, 0, 0, nullptr, 0, 0);
+                    std::unique_lock<std::mutex> lk(mu); stop_ingest = true; cv.notify_all();
+                }
+            }
+            if (!encode_final) {                                               // plan: where my last whole chunk ends; the rest is the next batch's
                 rfq_scan_result sr; a.final = 0; g.check(rfq_scan_batch(g.c, &a, &sr));
                 // (an empty line ends the input inside my text: all of it goes through the encode, which stops there)
-                if (sr.input_ended) ended = true;
+                if (sr.input_ended) { ended = true; std::unique_lock<std::mutex> lk(mu); stop_ingest = true; cv.notify_all(); }
                 else if (sr.n_chunks == 0) nothing = true;
                 else { en[0] = (size_t)sr.h_end1[sr.n_chunks - 1]; en[1] = two ? (size_t)sr.h_end2[sr.n_chunks - 1] : 0; }
                 if (ended) publish(true, true, nullptr, 0, 0, nullptr, 0, 0);
@@ -718,7 +752,8 @@ static void do_compress_multi(const Options& o) {
     for (uint64_t k = 0; ; k++) {
         const int w = (int)(k % (uint64_t)D);
         // (at most two batches per device wait for their encode)
-        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return k < next_write + 2 * (uint64_t)D + 1; }); }
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop_ingest || k < next_write + 2 * (uint64_t)D + 1; });
+          if (stop_ingest) { all_ingested = true; cv.notify_all(); break; } }
         if (!gin[(size_t)w]) gin[(size_t)w].reset(new Gpu(o.devices[(size_t)w]));
         Gpu& g = *gin[(size_t)w];
         auto b = std::make_shared<MBatch>(); b->seq = k; b->w = w; b->room = room;
@@ -740,7 +775,7 @@ static void do_compress_multi(const Options& o) {
             }
         }
         land();
-        b->last = ended[0] && ended[1];
+        b->last = ended[0] && ended[1]; b->eof[0] = ended[0]; b->eof[1] = two && ended[1];
         for (int s = 0; s < ns; s++) if (in[s]->end_known()) { const uint64_t t = in[s]->total_bytes(); if (t) b->th[s] = nolb_threshold(t, in[s]->final_byte()); }
         trace_mark("compress: batch resident");
         { std::unique_lock<std::mutex> lk(mu); batches[k] = b; n_batches = k + 1; if (b->last) all_ingested = true; cv.notify_all(); }

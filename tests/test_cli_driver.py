@@ -198,6 +198,17 @@ def _suite(binary, tmp_path, reads_se, pairs, batch_mb):
         r = _run(binary, ["-c", "-i", str(pa), "-I", str(pbs), "-o", str(om), "-k", "100", "--batch_mb", "1"] + extra)
         assert r.returncode == 0, r.stderr
         assert om.read_bytes() == want_s, extra
+    # the other way round and by a lot: R1 a tenth of R2.  The input ends with R1 (FastqReaderPair::read, src/fastqreader.cpp:287-299); the batch that holds the last of
+    # R1 finds that out by a final plan and ends the image there - the batches behind it (R2 text only, no whole chunk in any of them) used to be read, uploaded and
+    # carried from batch to batch in full: the trace shows how many batches became resident
+    cut_a = fa[: fa.rfind(b"\n@", 0, len(fa) // 10) + 1]
+    pas = tmp_path / "r1_short.fq"; pas.write_bytes(cut_a)
+    want_a = O.encode_file(cut_a, fb, O.PE_TWO_FILES, 100_000)
+    for extra in ([], ["--devices", "0,0,0"]):
+        r = _run(binary, ["-c", "-i", str(pas), "-I", str(pb), "-o", str(om), "-k", "100", "--batch_mb", "1"] + extra + ["--trace"])
+        assert r.returncode == 0, r.stderr
+        assert om.read_bytes() == want_a, extra
+        assert r.stderr.count(b"compress: batch resident") <= 2 + (len(cut_a) >> 20) + (3 if extra else 0), (extra, r.stderr.count(b"compress: batch resident"), len(fb) >> 20)
     # an empty input leaves an empty .rfq, which decodes to an empty FASTQ (RfqHeader defaults, src/rfqheader.cpp:7-17)
     pz = tmp_path / "empty.fq"; pz.write_bytes(b""); oz = tmp_path / "empty.rfq"; bz = tmp_path / "empty_back.fq"
     assert _run(binary, ["-c", "-i", str(pz), "-o", str(oz)]).returncode == 0 and oz.read_bytes() == b""
