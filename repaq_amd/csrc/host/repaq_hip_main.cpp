@@ -16,6 +16,7 @@
 #include <zlib.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
@@ -54,7 +55,9 @@ struct Options {
     size_t blockBytes = (size_t)16 << 20;   // page-locked staging block (never larger than a batch)
     // readers per regular input file (pread; tmpfs -> page-locked blocks -> HBM: 21.6 GB/s with 8, 29.2 with 16, tools/micro/mmap_h2d.cpp)
     int ioThreads = 16;
-    int writeThreads = 1;                   // writers per regular output file (pwrite); tmpfs does not scale with more, parallel file systems do
+    int writeThreads = 0;                   // writers per regular output file; 0 = 16 through a mapping (the default), 1 with --write_pwrite
+    bool writePwrite = false;               // --write_pwrite: pwrite instead of the mapping (one file's pwrites serialise on its inode lock: tmpfs does not scale with more writers)
+    bool serve = false;                     // --serve: jobs (one command line each) from stdin, the HIP runtime and the contexts stay up between them
     bool trace = false;                     // --trace: wall-clock marks of the pipeline on stderr
     // --bug_compat (-d with two outputs): lose what Repaq::decompressPE loses behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:376-403); Repaq::decompress loses
     // nothing; default: keep every read
@@ -275,10 +278,19 @@ struct ByteSink {
     }
 };
 
+static bool g_serve = false;
 struct Gpu {
-    rfq_ctx* c = nullptr;
-    explicit Gpu(int dev) { if (rfq_create(&c, dev) != RFQ_OK) error_exit("no usable MI355X / HIP device (repaq_hip has no CPU fallback)"); }
-    ~Gpu() { rfq_destroy(c); }
+    rfq_ctx* c = nullptr; bool leased = false;
+    // --serve: the main context of a device is made once and lent to every job (its workspace - several hundred MB of device buffers sized by the batches - stays);
+    // one job runs at a time, and a job's other contexts (verifier, per-device workers and ingestion of --devices) are still its own
+    explicit Gpu(int dev, bool main_ctx = false) {
+        static std::map<int, rfq_ctx*> kept; static std::mutex km;
+        if (g_serve && main_ctx) { std::unique_lock<std::mutex> lk(km); auto it = kept.find(dev);
+                if (it == kept.end()) { if (rfq_create(&c, dev) != RFQ_OK) error_exit("no usable MI355X / HIP device (repaq_hip has no CPU fallback)"); kept[dev] = c; } else c = it->second;
+                leased = true; rfq_clear_header(c); return; }
+        if (rfq_create(&c, dev) != RFQ_OK) error_exit("no usable MI355X / HIP device (repaq_hip has no CPU fallback)");
+    }
+    ~Gpu() { if (!leased) rfq_destroy(c); }
     void check(int rc) { if (rc != RFQ_OK) error_exit(rfq_last_error(c)); }
     void* dev(size_t n) { void* d = nullptr; check(rfq_dev_malloc(c, &d, n + 64)); return d; }
     uint8_t* pinned(size_t n) { void* h = nullptr; check(rfq_host_alloc(c, &h, n + 64)); return (uint8_t*)h; }
@@ -387,12 +399,25 @@ class AsyncWriter {
     ByteSink sink; Gpu& g; std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
     struct Item { uint8_t* p; size_t n, cap; uint64_t off; }; std::deque<Item> q; std::vector<Item> pool; bool done = false; int in_flight = 0, max_flight = 3;
     size_t piece; bool regular = false; int fd = -1; uint64_t off = 0; std::string path;
+    // A regular output file is written THROUGH A MAPPING: pwrite on one file serialises on the inode lock (tmpfs: 3 - 5 GB/s with 4, 8 or 16 writers), page faults on a
+    // shared mapping do not (16 writers copying the same pieces into an mmap of the pre-sized file: 14 GB/s; tools/micro/d2h_out.cpp, profiles/r05_io_micro.txt).  The
+    // file is grown ahead of the writers in steps (ftruncate; its final size is only known at the end, where it is cut to what was written); a piece's pages are mapped,
+    // filled and unmapped by the writer that has it.  A file system that refuses the mapping gets pwrite, as before.
+    bool mapped = false; uint64_t fsize = 0;
+    static constexpr uint64_t GROW = 1ull << 30;
+    void put(const Item& it) {
+        if (mapped) {
+            const uint64_t a0 = it.off & ~4095ull; const size_t len = (size_t)(it.off - a0) + it.n;
+            void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
+            if (m != MAP_FAILED) { memcpy((uint8_t*)m + (it.off - a0), it.p, it.n); munmap(m, len); return; }
+        }
+        size_t w = 0; while (w < it.n) { const ssize_t k = pwrite(fd, it.p + w, it.n - w, (off_t)(it.off + w)); if (k <= 0) error_exit("Failed to write: " + path); w += (size_t)k; }
+    }
     void run() {
         for (;;) {
             Item it;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !q.empty() || done; }); if (q.empty()) return; it = q.front(); q.pop_front(); }
-            if (regular) { size_t w = 0; while (w < it.n) { const ssize_t k = pwrite(fd, it.p + w, it.n - w, (off_t)(it.off + w)); if (k <= 0) error_exit("Failed to write: " + path); w += (size_t)k; } }
-            else sink.write(it.p, it.n);
+            if (regular) put(it); else sink.write(it.p, it.n);
             std::unique_lock<std::mutex> lk(mu); pool.push_back(it); in_flight--; cv.notify_all();
         }
     }
@@ -407,13 +432,20 @@ class AsyncWriter {
         if (stale) rfq_host_free(g.c, stale);
         cap = std::min(piece, std::max<size_t>(n + n / 4 + 4096, (size_t)1 << 20)); if (cap < n) cap = n; return g.pinned(cap);
     }
-    void submit(uint8_t* p, size_t n, size_t cap) { std::unique_lock<std::mutex> lk(mu); q.push_back(Item{ p, n, cap, off }); off += n; cv.notify_all(); }
+    void submit(uint8_t* p, size_t n, size_t cap) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (mapped && off + n > fsize) {                                       // (the writers map what lies inside the file: it grows ahead of them)
+            fsize = std::max<uint64_t>(off + n, fsize + GROW);
+            if (ftruncate(fd, (off_t)fsize) != 0) { mapped = false; }         // (a file that cannot be sized: pwrite from here on; what is mapped already stays valid)
+        }
+        q.push_back(Item{ p, n, cap, off }); off += n; cv.notify_all();
+    }
 public:
     AsyncWriter(Gpu& gpu, const std::string& p, const Options& o) : g(gpu), piece(o.block()), path(p) {
         struct stat st; int threads = 1;
         regular = !ends_with(p, ".gz") && !ends_with(p, ".xz") && p != "/dev/stdout" && (stat(p.c_str(), &st) != 0 || S_ISREG(st.st_mode));
-        if (regular) { fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) error_exit("Failed to open file for writing: " + p);
-                threads = std::max(1, o.writeThreads); max_flight = threads + 2; }
+        if (regular) { fd = ::open(p.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644); if (fd < 0) error_exit("Failed to open file for writing: " + p);
+                mapped = !o.writePwrite; threads = std::max(1, o.writeThreads ? o.writeThreads : (mapped ? 16 : 1)); max_flight = threads + 2; }
         else sink.open(p, o);
         for (int i = 0; i < threads; i++) th.emplace_back([this] { run(); });
     }
@@ -428,7 +460,10 @@ public:
         { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_all(); }
         for (auto& t : th) if (t.joinable()) t.join();
         th.clear();
-        if (regular) { if (fd >= 0 && ::close(fd) != 0) error_exit("Failed to write: " + path); fd = -1; } else sink.close();
+        for (auto& it : pool) (void)rfq_host_free(g.c, it.p);                  // (a serving process runs many jobs: the staging buffers go back)
+        pool.clear();
+        if (regular) { if (fd >= 0 && fsize != off && fsize && ftruncate(fd, (off_t)off) != 0) error_exit("Failed to write: " + path);
+                if (fd >= 0 && ::close(fd) != 0) error_exit("Failed to write: " + path); fd = -1; } else sink.close();
     }
     ~AsyncWriter() { if (!th.empty()) finish(); }
 };
@@ -554,7 +589,7 @@ static void do_compress(const Options& o) {
     const size_t block = o.block(), batch = std::max(o.batchBytes, block);      // staging block (>= the reader's 1 MiB block: see nolb below) / device batch
     // the readers first: they fill their first blocks while the HIP runtime comes up (context, code objects: 0.2 - 0.3 s of an 0.7 s run on 2 x 4 GB)
     Prefetcher* in[2] = { new Prefetcher((Gpu*)nullptr, o.in1, block, o.ioThreads), two ? new Prefetcher((Gpu*)nullptr, o.in2, block, o.ioThreads) : nullptr };
-    Gpu g(o.device);
+    Gpu g(o.device, true);
     for (int s = 0; s < 2; s++) if (in[s]) in[s]->attach(g);
     AsyncWriter out(g, o.out1, o);
     DevStream ds[2]; const int ns = two ? 2 : 1;
@@ -874,7 +909,7 @@ static DecodeTotals decode_stream(Gpu& g, const Options& o, const std::string& p
 }
 // Repaq::decompress / decompressPE (src/repaq.cpp:262-417)
 static void do_decompress(const Options& o) {
-    Gpu g(o.device);
+    Gpu g(o.device, true);
     const bool split = !o.out2.empty();
     AsyncWriter w1(g, o.out1, o); AsyncWriter* w2 = split ? new AsyncWriter(g, o.out2, o) : nullptr;
     decode_stream(g, o, o.in1, split, [&](const uint8_t* d1, size_t n1, const uint8_t* d2, size_t n2) {
@@ -1012,7 +1047,7 @@ static void report(const Options& o, bool passed, const std::string& msg, long f
     fputs(j.c_str(), stdout); fflush(stdout);
 }
 static void do_compare(const Options& o) {
-    Gpu g(o.device);
+    Gpu g(o.device, true);
     const bool pe = !o.in2.empty(); const int ns = pe ? 2 : 1;
     // Fast path, on the device: every decoded batch is compared byte for byte with the same span of the FASTQ
     // text uploaded beside it (rfq_compare_bytes); identical bytes mean identical reads, so only counters move.  The first batch
@@ -1124,13 +1159,13 @@ static void usage() {
     fputs("repaq_hip: repack FASTQ to .rfq on an MI355X (repaq v0.5.1 compatible)\n"
           "usage: repaq_hip [-c|-d|-p] -i in1 [-I in2] -o out1 [-O out2] [-k chunk_kb] [--stdin] [--stdout] [--interleaved_in]\n"
           "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N | --devices a,b,...]\n"
-          "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--trace] [--bug_compat]\n"
+          "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--write_pwrite] [--trace] [--bug_compat]\n"
+          "       repaq_hip --serve : a resident process, one job (the arguments of a command line) per line of stdin\n"
           "       FASTQ may be .gz (written as blocked gzip - bgzip's layout, readable by every gzip tool - on many threads; a blocked .gz is\n"
           "       also read on many threads, any other through zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
 }
-int main(int argc, char** argv) {
-    if (argc == 1) { usage(); return 0; }
-    if (argc == 2 && !strcmp(argv[1], "--version")) { printf("repaq_hip 0.5.1-compatible (%s)\n", rfq_version()); return 0; }
+// one job: a command line as the reference's main() takes it (src/main.cpp:15-184)
+static void run_job(int argc, char** argv) {
     Options o;
     auto val = [&](int& i, const char* name) -> std::string {
         std::string a = argv[i]; const std::string lo = std::string("--") + name + "=";
@@ -1166,6 +1201,7 @@ int main(int argc, char** argv) {
         else if (a == "--block_mb") o.blockBytes = (size_t)atol(val(i, "block_mb").c_str()) << 20;
         else if (a == "--io_threads") o.ioThreads = std::max(1, atoi(val(i, "io_threads").c_str()));
         else if (a == "--write_threads") o.writeThreads = std::max(1, atoi(val(i, "write_threads").c_str()));
+        else if (a == "--write_pwrite") o.writePwrite = true;
         else if (a == "--trace") { o.trace = true; g_trace = true; }
         else { usage(); error_exit("unknown option: " + a); }
     }
@@ -1211,6 +1247,37 @@ int main(int argc, char** argv) {
         if (o.in1.empty()) error_exit("Please specify input file by <in1>, or enable --stdin if you want to read STDIN");
         do_compare(o);
     }
+}
+// --serve: a resident process.  Every line of stdin is one job - the arguments of a repaq_hip command line, blank-separated, "double quotes" around an argument
+// that holds blanks - run one after the other in this process: the HIP runtime (0.2 - 0.33 s of every one-shot run: context, code objects) is paid once, and the main
+// context of a device keeps its workspace from job to job.  A line on stderr per job: "[serve] job N: S s".  A job that fails ends the process with the reference's
+// error text and status, like a one-shot run.  (--stdin jobs are refused: stdin is the job list.)
+static int serve() {
+    g_serve = true;
+    char* line = nullptr; size_t cap = 0; long n; int job = 0;
+    while ((n = getline(&line, &cap, stdin)) >= 0) {
+        std::vector<std::string> tok; std::string cur; bool inq = false, any = false;
+        for (long i = 0; i < n; i++) { const char ch = line[i];
+            if (ch == '"') { inq = !inq; any = true; }
+            else if (!inq && (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r')) { if (any || !cur.empty()) tok.push_back(cur); cur.clear(); any = false; }
+            else cur.push_back(ch); }
+        if (any || !cur.empty()) tok.push_back(cur);
+        if (tok.empty() || tok[0][0] == '#') continue;
+        if (tok[0] == "repaq_hip" || ends_with(tok[0], "/repaq_hip")) tok.erase(tok.begin());
+        for (auto& t : tok) if (t == "--stdin" || t == "--serve") error_exit("--serve: a job cannot read STDIN (it is the job list) or serve itself");
+        std::vector<char*> av; std::string a0 = "repaq_hip"; av.push_back(&a0[0]); for (auto& t : tok) av.push_back(&t[0]);
+        const auto t0 = std::chrono::steady_clock::now();
+        run_job((int)av.size(), av.data());
+        fflush(stdout);
+        fprintf(stderr, "[serve] job %d: %.3f s\n", ++job, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); fflush(stderr);
+    }
+    free(line);
+    return 0;
+}
+int main(int argc, char** argv) {
+    if (argc == 1) { usage(); return 0; }
+    if (argc == 2 && !strcmp(argv[1], "--version")) { printf("repaq_hip 0.5.1-compatible (%s)\n", rfq_version()); return 0; }
+    if (argc == 2 && !strcmp(argv[1], "--serve")) serve(); else run_job(argc, argv);
     trace_mark("done");
     // every output is closed and flushed: leave without the HIP runtime's static teardown (~80 ms of unmapping at exit)
     fflush(stdout); fflush(stderr); _exit(0);

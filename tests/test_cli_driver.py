@@ -473,3 +473,39 @@ def test_cli_devices_on_two_physical_gpus(tmp_path):
     r = _run(GPU_BIN, ["-c", "-i", str(pa), "-I", str(pb), "-o", str(two), "-k", "100", "--batch_mb", "8", "--devices", "0,1"])
     assert r.returncode == 0, r.stderr
     assert two.read_bytes() == one.read_bytes() == O.encode_file(a, b, O.PE_TWO_FILES, 100_000)
+
+
+def _serve_suite(binary, tmp_path, pairs):
+    """repaq_hip --serve: several jobs in ONE process (the HIP runtime and the device's main context stay up), one command line per line of stdin - compress, decompress,
+    compress another input under the same context (another header), a job with --write_pwrite; every output equals the one-shot run's / the oracle's."""
+    fq1, fq2 = O.gen(O.NOVA_PE150, pairs, seed=51, nonl=2)
+    se, _ = O.gen(O.SE_VAR, pairs, seed=52)
+    pa, pb, ps = tmp_path / "s_1.fq", tmp_path / "s_2.fq", tmp_path / "s_se.fq"
+    pa.write_bytes(fq1); pb.write_bytes(fq2); ps.write_bytes(se)
+    o1, o2, b1, b2, bs = tmp_path / "s_pe.rfq", tmp_path / "s_se.rfq", tmp_path / "s_b1.fq", tmp_path / "s_b2.fq", tmp_path / "s_bse.fq"
+    jobs = ["-c -i %s -I %s -o %s -k 100 --batch_mb 1" % (pa, pb, o1),
+            "# a comment line, and a blank one:", "",
+            "repaq_hip -d -i %s -o %s -O %s --batch_mb 1" % (o1, b1, b2),
+            '-c -i "%s" -o %s -k 100 --batch_mb 2 --write_pwrite' % (ps, o2),
+            "-d -i %s -o %s --write_threads 3" % (o2, bs)]
+    r = subprocess.run([binary, "--serve"], input=("\n".join(jobs) + "\n").encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count(b"[serve] job ") == 4, r.stderr
+    assert o1.read_bytes() == O.encode_file(fq1, fq2, O.PE_TWO_FILES, 100_000)
+    assert (b1.read_bytes(), b2.read_bytes()) == (fq1, fq2)
+    assert o2.read_bytes() == O.encode_file(se, b"", O.SE, 100_000) and bs.read_bytes() == se
+    # a job that cannot run ends the server with the reference's text and status
+    r = subprocess.run([binary, "--serve"], input=b"-c -i /nonexistent/x.fq -o /tmp/x.rfq\n", capture_output=True)
+    assert r.returncode == 255 and b"ERROR:" in r.stderr
+    r = subprocess.run([binary, "--serve"], input=b"-d --stdin -o /tmp/x.fq\n", capture_output=True)
+    assert r.returncode == 255 and b"--serve" in r.stderr
+
+
+def test_cli_serve_on_simt_emulation(tmp_path):
+    E.build_emu()
+    _serve_suite(EMU_BIN, tmp_path, 260)
+
+
+@pytest.mark.gpu
+def test_cli_serve_on_gpu(tmp_path):
+    _serve_suite(GPU_BIN, tmp_path, 40000)
