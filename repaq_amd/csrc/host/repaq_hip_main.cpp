@@ -16,7 +16,6 @@
 #include <zlib.h>
 #include <fcntl.h>
 #include <sys/stat.h>
-#include <sys/mman.h>
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
@@ -55,8 +54,7 @@ struct Options {
     size_t blockBytes = (size_t)16 << 20;   // page-locked staging block (never larger than a batch)
     // readers per regular input file (pread; tmpfs -> page-locked blocks -> HBM: 21.6 GB/s with 8, 29.2 with 16, tools/micro/mmap_h2d.cpp)
     int ioThreads = 16;
-    int writeThreads = 0;                   // writers per regular output file; 0 = 16 through a mapping (the default), 1 with --write_pwrite
-    bool writePwrite = false;               // --write_pwrite: pwrite instead of the mapping (one file's pwrites serialise on its inode lock: tmpfs does not scale with more writers)
+    int writeThreads = 1;                   // writers per regular output file (pwrite); tmpfs does not scale with more (nor with a mapping: see AsyncWriter), parallel file systems do
     bool serve = false;                     // --serve: jobs (one command line each) from stdin, the HIP runtime and the contexts stay up between them
     bool trace = false;                     // --trace: wall-clock marks of the pipeline on stderr
     // --bug_compat (-d with two outputs): lose what Repaq::decompressPE loses behind a non-last NO_LINE_BREAK chunk (src/repaq.cpp:376-403); Repaq::decompress loses
@@ -66,6 +64,7 @@ struct Options {
 };
 static const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
 static bool g_trace = false;
+static bool g_serve = false;               // --serve: many jobs in this process - what a one-shot run leaves to _exit (page-locked staging buffers) is handed back
 static void trace_mark(const char* what) { if (g_trace) fprintf(stderr, "[trace] %8.1f ms  %s\n", std::chrono::duration<double,
         std::milli>(std::chrono::steady_clock::now() - g_t0).count(), what); }
 
@@ -278,7 +277,6 @@ struct ByteSink {
     }
 };
 
-static bool g_serve = false;
 struct Gpu {
     rfq_ctx* c = nullptr; bool leased = false;
     // --serve: the main context of a device is made once and lent to every job (its workspace - several hundred MB of device buffers sized by the batches - stays);
@@ -371,9 +369,10 @@ public:
     ~Prefetcher() { { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); } for (auto& t : th) if (t.joinable()) t.join(); if (fd >= 0) ::close(fd);
             else src.close();
             // the staging buffers go back (registered blocks were never unregistered or freed; harmless in a process that _exits, not in one that serves many jobs)
+            // (a one-shot run leaves them to _exit: unlocking 38 blocks of 16 MB costs it 0.1 s for nothing)
             Gpu* gp = g.load();
-            for (uint8_t* p : owned) { if (gp && std::find(plain.begin(), plain.end(), p) == plain.end()) (void)rfq_host_unregister(gp->c, p); free(p); }
-            if (gp) for (uint8_t* p : pinned_) (void)rfq_host_free(gp->c, p); }
+            if (g_serve) { for (uint8_t* p : owned) { if (gp && std::find(plain.begin(), plain.end(), p) == plain.end()) (void)rfq_host_unregister(gp->c, p); free(p); }
+                    if (gp) for (uint8_t* p : pinned_) (void)rfq_host_free(gp->c, p); } }
     // next block; false when the input is exhausted.  After it returns, end_known() tells whether the end of the input is known;
     // if not, at least two more full blocks follow the one just returned.
     bool next(Block& b) {
@@ -399,25 +398,16 @@ class AsyncWriter {
     ByteSink sink; Gpu& g; std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
     struct Item { uint8_t* p; size_t n, cap; uint64_t off; }; std::deque<Item> q; std::vector<Item> pool; bool done = false; int in_flight = 0, max_flight = 3;
     size_t piece; bool regular = false; int fd = -1; uint64_t off = 0; std::string path;
-    // A regular output file is written THROUGH A MAPPING: pwrite on one file serialises on the inode lock (tmpfs: 3 - 5 GB/s with 4, 8 or 16 writers), page faults on a
-    // shared mapping do not (16 writers copying the same pieces into an mmap of the pre-sized file: 14 GB/s; tools/micro/d2h_out.cpp, profiles/r05_io_micro.txt).  The
-    // file is grown ahead of the writers in steps (ftruncate; its final size is only known at the end, where it is cut to what was written); a piece's pages are mapped,
-    // filled and unmapped by the writer that has it.  A file system that refuses the mapping gets pwrite, as before.
-    bool mapped = false; uint64_t fsize = 0;
-    static constexpr uint64_t GROW = 1ull << 30;
-    void put(const Item& it) {
-        if (mapped) {
-            const uint64_t a0 = it.off & ~4095ull; const size_t len = (size_t)(it.off - a0) + it.n;
-            void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
-            if (m != MAP_FAILED) { memcpy((uint8_t*)m + (it.off - a0), it.p, it.n); munmap(m, len); return; }
-        }
-        size_t w = 0; while (w < it.n) { const ssize_t k = pwrite(fd, it.p + w, it.n - w, (off_t)(it.off + w)); if (k <= 0) error_exit("Failed to write: " + path); w += (size_t)k; }
-    }
+    // (Round 5 tried the other way in: the output pre-sized and mapped - per piece, then in 1 GiB windows kept to the end - and the pieces copied into the mapping by 16
+    // writers, since pwrite on one tmpfs file serialises on its inode lock.  A micro-benchmark promised 14 GB/s against pwrite's 3 - 5; in the driver it was SLOWER than
+    // pwrite, 1.6 - 1.8 s against 1.4 s for 8 GB: what bounds either is the kernel's allocation of 2 M fresh tmpfs pages, and the benchmark's fast run had re-used
+    // the pages of the file it had just unlinked.  profiles/r05_io_micro.txt, tools/micro/d2h_out.cpp.)
     void run() {
         for (;;) {
             Item it;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !q.empty() || done; }); if (q.empty()) return; it = q.front(); q.pop_front(); }
-            if (regular) put(it); else sink.write(it.p, it.n);
+            if (regular) { size_t w = 0; while (w < it.n) { const ssize_t k = pwrite(fd, it.p + w, it.n - w, (off_t)(it.off + w)); if (k <= 0) error_exit("Failed to write: " + path); w += (size_t)k; } }
+            else sink.write(it.p, it.n);
             std::unique_lock<std::mutex> lk(mu); pool.push_back(it); in_flight--; cv.notify_all();
         }
     }
@@ -432,20 +422,13 @@ class AsyncWriter {
         if (stale) rfq_host_free(g.c, stale);
         cap = std::min(piece, std::max<size_t>(n + n / 4 + 4096, (size_t)1 << 20)); if (cap < n) cap = n; return g.pinned(cap);
     }
-    void submit(uint8_t* p, size_t n, size_t cap) {
-        std::unique_lock<std::mutex> lk(mu);
-        if (mapped && off + n > fsize) {                                       // (the writers map what lies inside the file: it grows ahead of them)
-            fsize = std::max<uint64_t>(off + n, fsize + GROW);
-            if (ftruncate(fd, (off_t)fsize) != 0) { mapped = false; }         // (a file that cannot be sized: pwrite from here on; what is mapped already stays valid)
-        }
-        q.push_back(Item{ p, n, cap, off }); off += n; cv.notify_all();
-    }
+    void submit(uint8_t* p, size_t n, size_t cap) { std::unique_lock<std::mutex> lk(mu); q.push_back(Item{ p, n, cap, off }); off += n; cv.notify_all(); }
 public:
     AsyncWriter(Gpu& gpu, const std::string& p, const Options& o) : g(gpu), piece(o.block()), path(p) {
         struct stat st; int threads = 1;
         regular = !ends_with(p, ".gz") && !ends_with(p, ".xz") && p != "/dev/stdout" && (stat(p.c_str(), &st) != 0 || S_ISREG(st.st_mode));
-        if (regular) { fd = ::open(p.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644); if (fd < 0) error_exit("Failed to open file for writing: " + p);
-                mapped = !o.writePwrite; threads = std::max(1, o.writeThreads ? o.writeThreads : (mapped ? 16 : 1)); max_flight = threads + 2; }
+        if (regular) { fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd < 0) error_exit("Failed to open file for writing: " + p);
+                threads = std::max(1, o.writeThreads); max_flight = threads + 2; }
         else sink.open(p, o);
         for (int i = 0; i < threads; i++) th.emplace_back([this] { run(); });
     }
@@ -460,10 +443,8 @@ public:
         { std::unique_lock<std::mutex> lk(mu); done = true; cv.notify_all(); }
         for (auto& t : th) if (t.joinable()) t.join();
         th.clear();
-        for (auto& it : pool) (void)rfq_host_free(g.c, it.p);                  // (a serving process runs many jobs: the staging buffers go back)
-        pool.clear();
-        if (regular) { if (fd >= 0 && fsize != off && fsize && ftruncate(fd, (off_t)off) != 0) error_exit("Failed to write: " + path);
-                if (fd >= 0 && ::close(fd) != 0) error_exit("Failed to write: " + path); fd = -1; } else sink.close();
+        if (g_serve) { for (auto& it : pool) (void)rfq_host_free(g.c, it.p); pool.clear(); }   // (a serving process runs many jobs: the staging buffers go back)
+        if (regular) { if (fd >= 0 && ::close(fd) != 0) error_exit("Failed to write: " + path); fd = -1; } else sink.close();
     }
     ~AsyncWriter() { if (!th.empty()) finish(); }
 };
@@ -1159,7 +1140,7 @@ static void usage() {
     fputs("repaq_hip: repack FASTQ to .rfq on an MI355X (repaq v0.5.1 compatible)\n"
           "usage: repaq_hip [-c|-d|-p] -i in1 [-I in2] -o out1 [-O out2] [-k chunk_kb] [--stdin] [--stdout] [--interleaved_in]\n"
           "                 [-r rfq_to_compare] [-j json] [-t xz_threads] [-z level] [--device N | --devices a,b,...]\n"
-          "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--write_pwrite] [--trace] [--bug_compat]\n"
+          "                 [--batch_mb M] [--block_mb M] [--io_threads N] [--write_threads N] [--trace] [--bug_compat]\n"
           "       repaq_hip --serve : a resident process, one job (the arguments of a command line) per line of stdin\n"
           "       FASTQ may be .gz (written as blocked gzip - bgzip's layout, readable by every gzip tool - on many threads; a blocked .gz is\n"
           "       also read on many threads, any other through zlib); .rfq may be .rfq.xz (external xz)\n", stderr);
@@ -1201,7 +1182,6 @@ static void run_job(int argc, char** argv) {
         else if (a == "--block_mb") o.blockBytes = (size_t)atol(val(i, "block_mb").c_str()) << 20;
         else if (a == "--io_threads") o.ioThreads = std::max(1, atoi(val(i, "io_threads").c_str()));
         else if (a == "--write_threads") o.writeThreads = std::max(1, atoi(val(i, "write_threads").c_str()));
-        else if (a == "--write_pwrite") o.writePwrite = true;
         else if (a == "--trace") { o.trace = true; g_trace = true; }
         else { usage(); error_exit("unknown option: " + a); }
     }

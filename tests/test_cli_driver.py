@@ -477,7 +477,7 @@ def test_cli_devices_on_two_physical_gpus(tmp_path):
 
 def _serve_suite(binary, tmp_path, pairs):
     """repaq_hip --serve: several jobs in ONE process (the HIP runtime and the device's main context stay up), one command line per line of stdin - compress, decompress,
-    compress another input under the same context (another header), a job with --write_pwrite; every output equals the one-shot run's / the oracle's."""
+    compress another input under the same context (another header), jobs with several writers; every output equals the one-shot run's / the oracle's."""
     fq1, fq2 = O.gen(O.NOVA_PE150, pairs, seed=51, nonl=2)
     se, _ = O.gen(O.SE_VAR, pairs, seed=52)
     pa, pb, ps = tmp_path / "s_1.fq", tmp_path / "s_2.fq", tmp_path / "s_se.fq"
@@ -486,7 +486,7 @@ def _serve_suite(binary, tmp_path, pairs):
     jobs = ["-c -i %s -I %s -o %s -k 100 --batch_mb 1" % (pa, pb, o1),
             "# a comment line, and a blank one:", "",
             "repaq_hip -d -i %s -o %s -O %s --batch_mb 1" % (o1, b1, b2),
-            '-c -i "%s" -o %s -k 100 --batch_mb 2 --write_pwrite' % (ps, o2),
+            '-c -i "%s" -o %s -k 100 --batch_mb 2 --write_threads 4' % (ps, o2),
             "-d -i %s -o %s --write_threads 3" % (o2, bs)]
     r = subprocess.run([binary, "--serve"], input=("\n".join(jobs) + "\n").encode(), capture_output=True)
     assert r.returncode == 0, r.stderr

@@ -9,8 +9,7 @@ for i in 1 2 3; do TIMEFORMAT="PE compress wall %R s (one-shot process)"; time $
 $B -c -i $D/r1.fq -I $D/r2.fq -o $D/pe.rfq --trace ${E2E_FLAGS:-} 2>&1 | grep -v "batch resident\|batch encoded" | head -20
 md5sum $D/pe.rfq
 for i in 1 2; do TIMEFORMAT="PE decompress to /dev/null wall %R s (one-shot process)"; time $B -d -i $D/pe.rfq -o /dev/null -O /dev/null; done
-for i in 1 2; do rm -f $D/o1.fq $D/o2.fq; TIMEFORMAT="PE decompress to two tmpfs files wall %R s (one-shot process; 16 writers through a mapping)"; time $B -d -i $D/pe.rfq -o $D/o1.fq -O $D/o2.fq; done
-rm -f $D/o1.fq $D/o2.fq; TIMEFORMAT="PE decompress to two tmpfs files wall %R s (one-shot process; --write_pwrite: round 4's writer)"; time $B -d -i $D/pe.rfq -o $D/o1.fq -O $D/o2.fq --write_pwrite
+for i in 1 2; do rm -f $D/o1.fq $D/o2.fq; TIMEFORMAT="PE decompress to two tmpfs files wall %R s (one-shot process)"; time $B -d -i $D/pe.rfq -o $D/o1.fq -O $D/o2.fq; done
 $B -d -i $D/pe.rfq -o $D/o1.fq -O $D/o2.fq --trace 2>&1 | grep -v "batch resident\|batch decoded" | head
 cmp $D/r1.fq $D/o1.fq && cmp $D/r2.fq $D/o2.fq && echo PE_ROUNDTRIP_OK
 # the resident process: job 1 pays the start-up, the others are warm
