@@ -43,7 +43,8 @@ __device__ __forceinline__ unsigned long long pl_eq_prev(const uint32_t (&w)[16]
     }
     return ((unsigned long long)hi << 32) | lo;
 }
-__global__ void __launch_bounds__(64, 3) k_pos_coder_list(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat,
+#define PL_WAVES 3                 // waves per SIMD the list coder is compiled for (A/B on the box: tools/ab_macro.sh)
+__global__ void __launch_bounds__(64, PL_WAVES) k_pos_coder_list(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat,
         uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase,
                                                        uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks, DevStatus* st) {
     __shared__ PlLds S;
