@@ -50,9 +50,9 @@ __device__ __forceinline__ uint32_t e3_from(int t, int i) { const int k = t - 4 
 // v_alignbyte_b32
 __device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }
 template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds__(256, N1CAP == ET_N1CAP ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img,
-        const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DReadTab R,
+        const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DFused F,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
-                           const uint32_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
+                           const plist_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
                            uint32_t ncell, uint32_t nstr, uint32_t kshift) {
     __shared__ uint4 t_q4[E3_QCAP / 16 + 6];                                // quality tile (16 bytes of slack in front, the rest behind)
     __shared__ uint4 t_pk4[E3_QCAP / 64 + 6];                               // the tile's packed bases
@@ -68,7 +68,8 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
     constexpr bool implied_n = IMPL;                                        // (the host instantiates by the header: N positions implied by the quality, or listed)
     const uint32_t nq4 = (D->n_base_qual & 0xFFu) * 0x01010101u, dpos = D->name2_diff_pos, dch = D->name2_diff_char;
     const int l = lane_id(), w = (int)uni32((uint32_t)wave_id()); const uint32_t tid = threadIdx.x;
-    const U4 pv0 = R.pv[f]; const uint32_t pq0 = R.pq[f];
+    const size_t fp = (size_t)f + c;                                       // the chunk's entries of the chunk-local prefixes (one more than it has reads: see DFused)
+    const U4 tb = F.tbase[c];
     const uint32_t K = 1u << kshift, pshift = 8u - kshift, P = 1u << pshift;
     uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + K - 1u) & ~(K - 1u);                 // whole tiles per workgroup (K is even: pairs stay together)
     const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
@@ -77,7 +78,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
     const uint32_t nn = bycol ? (D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT) : 0u; const bool hasn = (hf & H_N_POS) != 0;
     const uint32_t T = nn + (hasn ? 1u : 0u);                                // streams of the tile: t < nn quality value t, t == nn the N positions
     const uint32_t major4 = (D->major & 0xFFu) * 0x01010101u;
-    const uint32_t qlen_c = R.pq[f + d.reads] - pq0, slen_c = R.pv[f + d.reads].d - pv0.d;      // qualities / stored bases of the chunk
+    const uint32_t qlen_c = F.pql[fp + d.reads], slen_c = F.pvl[fp + d.reads].d;                // qualities / stored bases of the chunk
     const bool same1 = (fl & C_NAME1_SAME) != 0, same2 = (fl & C_NAME2_SAME) != 0, same3 = (fl & C_STRAND_SAME) != 0;
     if (tid < T) { const uint32_t jj = tid < nn ? tid : D->n_normal; const size_t t_ = (size_t)c * nstr + jj; s_loff[tid] = loff[t_]; s_nent[tid] = nent[t_];
             s_val[tid] = tid < nn ? (uint32_t)D->normal[tid] : (uint32_t)'N'; }
@@ -97,9 +98,9 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
     // a tile's uniform parameters: quality / stored-base / name-piece prefixes at its first read and behind its last
     struct TileP { uint32_t q0, q1, s0, s1, a7, a8, a9, e7, e8, e9; };
     auto tile_params = [&](uint32_t r0, uint32_t r1) -> TileP {
-        TileP t; const U4 a = R.pv[f + r0], b = R.pv[f + r1];
-        t.q0 = uni32(R.pq[f + r0]) - pq0; t.q1 = uni32(R.pq[f + r1]) - pq0; t.s0 = uni32(a.d) - pv0.d; t.s1 = uni32(b.d) - pv0.d;
-        t.a7 = uni32(a.a) - pv0.a; t.a8 = uni32(a.b) - pv0.b; t.a9 = uni32(a.c) - pv0.c; t.e7 = uni32(b.a) - pv0.a; t.e8 = uni32(b.b) - pv0.b; t.e9 = uni32(b.c) - pv0.c;
+        TileP t; const U4 a = F.pvl[fp + r0], b = F.pvl[fp + r1];
+        t.q0 = uni32(F.pql[fp + r0]); t.q1 = uni32(F.pql[fp + r1]); t.s0 = uni32(a.d); t.s1 = uni32(b.d);
+        t.a7 = uni32(a.a); t.a8 = uni32(a.b); t.a9 = uni32(a.c); t.e7 = uni32(b.a); t.e8 = uni32(b.b); t.e9 = uni32(b.c);
         return t;
     };
     uint32_t cur = rs, pb = 0;
@@ -133,7 +134,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
                 if (rqa > rqe) rqa = rqe; }
         if (raw) span_dma<(int)((E3_QCAP / 16 + 4 + 255) / 256)>(make_span(t_q4 + 1, img, rqa, rqe, img_bytes, true));
         if (w == 0) span_dma_wave<(int)((E3_QCAP / 64 + 4 + 63) / 64)>(make_span(t_pk4, img, pka, pke, img_bytes, true), l);
-        else if (w == 1) span_dma_wave<(int)((64 * 40 / 16 + 4 + 63) / 64)>(make_span(t_mid4, R.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
+        else if (w == 1) span_dma_wave<(int)((64 * 40 / 16 + 4 + 63) / 64)>(make_span(t_mid4, F.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
         else if (w == 2) { if (!same1) span_dma_wave<(int)((N1CAP / 16 + 4 + 63) / 64)>(make_span(t_n14, img, n1a, n1e, img_bytes, true), l); }
         else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, n2a, n2e, img_bytes, true), l);
                if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, sta, ste, img_bytes, true), l); }
@@ -142,7 +143,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
                 for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         for (uint32_t i = tid; i < ((s1 - s0 + 31u) >> 5) + 1u; i += blockDim.x) t_nb[i] = 0;
         // ---- the tile's list entries, requested now and scattered after the barrier (wave w takes the lists w, w + 4, ...)
-        uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const uint32_t* ls_p = plist;
+        uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const plist_t* ls_p = plist;
         auto ls_open = [&](uint32_t t_) {
             const uint32_t g_ = uni32(s_g[pb][t_]), b_ = uni32(s_kb[pb][t_]), n_ = uni32(s_nent[t_]);
             ls_k0 = g_ == 0xFFFFFFFFu ? 0u : g_; ls_ke = g_ == 0xFFFFFFFFu ? 0u : (b_ < n_ ? b_ : n_); ls_base = 0;
@@ -159,7 +160,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         uint32_t pn[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }; uint32_t nk0 = 0xFFFFFFFFu, nke = 0;
         if (hasn) {
             nk0 = s_g[pb][nn]; nke = s_kb[pb][nn]; if (nke > s_nent[nn]) nke = s_nent[nn];
-            const uint32_t* lp = plist + s_loff[nn];
+            const plist_t* lp = plist + s_loff[nn];
 #pragma unroll
             for (int i = 0; i < 2; i++) { const uint32_t kk = nk0 + tid + 256u * (uint32_t)i; if (nk0 != 0xFFFFFFFFu && kk < nke) pn[i] = lp[kk]; }
         }
@@ -167,11 +168,11 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         const uint32_t r = cur + j; const bool on = j < cnt; const bool odd = (r & 1u) != 0, rc = il && odd, to2 = split && odd;
         uint32_t len = 0, n1 = 0, n2 = 0, sl = 0, md = 0, prevlen = 0, sp = 0, qp_ = 0, o7 = 0, o8 = 0, o9 = 0; int ov = 0; uint32_t toff = 0;
         if (on) {
-            const uint32_t g_ = f + r; const U4 t4 = R.tp[g_], p4 = R.pv[g_];
-            toff = to2 ? t4.b : t4.a; sp = p4.d - pv0.d - s0; qp_ = R.pq[g_] - pq0 - q0; o7 = p4.a - pv0.a - tp.a7; o8 = p4.b - pv0.b - tp.a8; o9 = p4.c - pv0.c - tp.a9;
-            len = R.len[g_]; ov = R.ov[g_]; prevlen = odd ? R.len[g_ - 1] : 0u;
+            const uint32_t g_ = f + r; const uint2 t2 = F.tpl[g_]; const U4 p4 = F.pvl[fp + r];
+            toff = to2 ? tb.b + t2.y : tb.a + t2.x; sp = p4.d - s0; qp_ = F.pql[fp + r] - q0; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9;
+            len = F.len[g_]; ov = F.ov[g_]; prevlen = odd ? F.len[g_ - 1] : 0u;
             n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)]; n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
-            sl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)]; md = R.mid[(size_t)g_ * 40 + 39];
+            sl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)]; md = F.mid[(size_t)g_ * 40 + 39];
         }
         // ---- the next tile's parameters (consumed a tile from now)
         const uint32_t nxt = cur + cnt; TileP tp_n = tp;
@@ -183,23 +184,24 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         // ---- quality lists, exception records, N list into the tiles
         {
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const uint32_t p = fe[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
+            // (an entry holds the low 16 bits of its position: see plist_t; 0xFFFFFFFF = no entry)
+            for (int i = 0; i < 8; i++) { const uint32_t p = q0 + ((fe[i] - q0) & 0xFFFFu); if (fe[i] != 0xFFFFFFFFu && p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
             while (ls_t < nn) {
                 uint32_t e_[4], v_[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) { e_[i] = 0xFFFFFFFFu; v_[i] = 0; ls_round(e_[i], v_[i]); }
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const uint32_t p = e_[i]; if (p >= q0 && p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
+                for (int i = 0; i < 4; i++) { const uint32_t p = q0 + ((e_[i] - q0) & 0xFFFFu); if (e_[i] != 0xFFFFFFFFu && p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
             }
             if (nrec) for (uint32_t i = tid; i < nrec; i += blockDim.x) { const uint8_t* rr = xrec + 5ull * i; const uint32_t pos = ld_u32(rr + 1);
                     if (pos >= q0 && pos < q1 && pos < qlen_c) q_t[pos - q0] = rr[0]; }
             if (hasn) {
                 const uint32_t send = s1 < slen_c ? s1 : slen_c;
 #pragma unroll
-                for (int i = 0; i < 2; i++) { const uint32_t p = pn[i]; if (p >= s0 && p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); }
-                if (nk0 != 0xFFFFFFFFu && nk0 + 512u < nke) { const uint32_t* lp = plist + s_loff[nn];
-                        for (uint32_t kk = nk0 + 512u + tid; kk < nke; kk += 256u) { const uint32_t p = lp[kk];
-                        if (p >= s0 && p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); } }
+                for (int i = 0; i < 2; i++) { const uint32_t p = s0 + ((pn[i] - s0) & 0xFFFFu); if (pn[i] != 0xFFFFFFFFu && p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); }
+                if (nk0 != 0xFFFFFFFFu && nk0 + 512u < nke) { const plist_t* lp = plist + s_loff[nn];
+                        for (uint32_t kk = nk0 + 512u + tid; kk < nke; kk += 256u) { const uint32_t p = s0 + (((uint32_t)lp[kk] - s0) & 0xFFFFu);
+                        if (p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); } }
             }
         }
         // the next tile's list cells (its parameters have come back by now)

@@ -13,6 +13,9 @@
 //                    index of the first list entry at or beyond the cell (the emitter starts there)
 #define POS2_SEG 1024u            // bytes of a stream per wave: POS2_SEG / 256 steps of 4 bytes per lane
 #define POS2_CELL 1024u
+// A list entry is the LOW 16 BITS of a coded position (round 5; u32 before: 1.17 GB written and read back per 8 GB of text).  The emitter asks the cell index for the
+// entries of [tile start, tile start + tile + a cell) - a window far below 65536 positions - so an entry e is position q0 + ((e - q0) & 0xFFFF), q0 = the tile's first position.
+typedef uint16_t plist_t;
 struct PosSrc { const uint8_t* sp; uint32_t slen; uint8_t q; };
 // stream jj of a chunk: jj < nn = quality value stream, jj == nn = N positions.  slen = 0 when absent; corrupt length tables are flagged.
 __device__ __forceinline__ PosSrc pos_src_of(const uint8_t* __restrict__ img, const DChunk& d, const DevHeader* __restrict__ D, uint32_t jj, DecStatus* st) {
@@ -117,7 +120,8 @@ __device__ __forceinline__ PosLink poslink_shfl_up(const PosLink& v, unsigned dd
 }
 __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __restrict__ segA, const uint32_t* __restrict__ segN, uint8_t* __restrict__ segS,
         int* __restrict__ segP,
-                                uint32_t* __restrict__ segK, uint32_t* __restrict__ nent, uint32_t maxseg, uint32_t n_streams) {
+                                uint32_t* __restrict__ segK, uint32_t* __restrict__ nent, uint32_t maxseg, uint32_t n_streams,
+                                const DChunk* __restrict__ CH, uint32_t nstr, DecStatus* st) {
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(); if (t >= n_streams) return;
     const int l = lane_id(); const uint32_t n = segN[t];
     uint32_t cs = 0; int cp = -1; uint32_t ck = 0;                          // state / last covered position / list entries in front of the block of 64 segments
@@ -142,7 +146,13 @@ __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __r
         for (int s = 0; s < 4; s++) { al[s] = wave_last(inc.a[s]); nl[s] = wave_last(inc.n[s]); }
         cp += sel4(al, cs); ck += (uint32_t)sel4(nl, cs); cs = fn_apply(Fl, cs);
     }
-    if (l == 0) nent[t] = ck;
+    if (l == 0) {
+        nent[t] = ck;
+        // 16-bit list entries (plist_t) are unambiguous while a stream's positions stay within 32 K of the chunk's own extent - they do, unless the image codes positions its
+        // length table does not cover (the reference's two-byte lengths of reads > 65535 bases, App. C; corrupt images): such ranges take the expanded path
+        const unsigned long long ext = CH[t / nstr].bases;
+        if (cp >= 0 && (unsigned long long)cp >= ext + 32768ull) atomicOr(&st->err, (uint32_t)DE_E3_RETRY);
+    }
 }
 // exclusive prefix of the streams' entry counts (one workgroup; n_streams is some thousands) -> where each list starts in the arena; the total
 // goes to st->list_need (the host grows the arena and repeats k_dec_pos_list when it did not fit)
@@ -159,7 +169,7 @@ __global__ void k_dec_pos_off(const uint32_t* __restrict__ nent, unsigned long l
 // it codes go to plist[loff + k ...] in stream order; cellidx[cell] = index (within the stream's list) of the first entry >= cell * POS2_CELL
 __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
                                const uint8_t* __restrict__ segS, const int* __restrict__ segP, const uint32_t* __restrict__ segK, const unsigned long long* __restrict__ loff,
-                               uint32_t* __restrict__ plist, unsigned long long cap, uint32_t* __restrict__ cellidx, uint32_t maxseg, uint32_t ncell, uint64_t img_bytes, uint32_t jj0, uint32_t nstr, const DecStatus* st) {
+                               plist_t* __restrict__ plist, unsigned long long cap, uint32_t* __restrict__ cellidx, uint32_t maxseg, uint32_t ncell, uint64_t img_bytes, uint32_t jj0, uint32_t nstr, const DecStatus* st) {
     if (st->list_need > cap) return;                                      // (uniform) the arena is too small: the host repeats the pass
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id();
             const uint8_t* lim = img + img_bytes;
@@ -168,7 +178,7 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
     const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
     const size_t t = (size_t)c * nstr + jj, idx = t * maxseg + g;
     uint32_t carry = segS[idx]; int last = segP[idx]; uint32_t k0 = segK[idx];
-    uint32_t* const out = plist + loff[t]; uint32_t* const cells = cellidx + t * ncell;
+    plist_t* const out = plist + loff[t]; uint32_t* const cells = cellidx + t * ncell;
     const uint32_t b1 = b0 + POS2_SEG < s.slen ? b0 + POS2_SEG : s.slen;
     PosStep nxt = pos_fetch(s.sp, s.slen, b0 + 4u * (uint32_t)l, lim);
     for (uint32_t base = b0; base < b1; base += 256u) {                    // (wave-uniform) a step = 256 bytes; state, position and list index carry over
@@ -203,7 +213,7 @@ __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __
             const int lo = run[q] ? end - (int)run[q] + 1 : end;
             int pp = prev;                                                   // the position of list entry k - 1 (-1: none)
             for (int p = lo; p <= end; p++, k++) {
-                out[k] = (uint32_t)p;
+                out[k] = (plist_t)p;
                 uint32_t c0 = pp < 0 ? 0u : (uint32_t)pp / POS2_CELL + 1u; const uint32_t c1 = (uint32_t)p / POS2_CELL;
                 for (; c0 <= c1 && c0 < ncell; c0++) cells[c0] = k;
                 pp = p;

@@ -29,6 +29,58 @@ __global__ void k_dec_readtab(const uint8_t* __restrict__ img, const DChunk* __r
     v.d = stored;
     R.len[g] = len; R.chunk[g] = blockIdx.y; R.ov[g] = ov; R.pvin[g] = v;
 }
+// ---- fused path (k_dec_emit3): CHUNK-LOCAL prefixes, made where the per-read values are made.
+// Round 4 wrote the per-read inputs (pvin, len) to HBM and ran two batch-wide scans over them (3 launches each: reduce, partials, apply) - 1.0 ms of kernels and
+// 2.0 GB of traffic per 8 GB of text for prefixes of which the emitter only ever uses differences INSIDE one chunk.  Here a workgroup owns a chunk
+// and walks its reads 1024 at a time (four consecutive reads per thread, one block scan per step, the step's total carried): the prefixes restart at 0 in every
+// chunk and every chunk gets one entry more than it has reads - its totals - so chunk c's entries sit at [rbase + c, rbase + c + reads].
+struct DFused {
+    const uint32_t* len; const int32_t* ov;
+    const uint32_t* pql;        // [rbase + c + r]: qualities (= bases) of the chunk in front of read r; entry `reads` = the chunk's total
+    const U4* pvl;              // ... (name1, name2, strand piece bytes; stored bases) in front of read r
+    const uint2* tpl;           // [rbase + r]: text bytes of the chunk in front of read r, per output (x: out1, y: out2)
+    const U4* tbase;            // [c]: text bytes in front of chunk c (a: out1, b: out2); entry n_chunks = the range's totals
+    const uint8_t* mid;
+};
+__global__ void __launch_bounds__(256) k_dec_readtab2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
+                                                      uint32_t* __restrict__ len_o, int32_t* __restrict__ ov_o, uint32_t* __restrict__ pql, U4* __restrict__ pvl, DecStatus* st) {
+    const uint32_t c = blockIdx.x; const DChunk d = CH[c];
+    const uint8_t* cp = img + d.off; const uint32_t fl = d.flags, hf = D->flags, rlb = D->read_len_bytes, shift = (uint32_t)D->overlap_shift;
+    const bool ovl = (fl & C_PE_INTERLEAVED) && (hf & H_PE_OVERLAP);
+    const size_t fp = (size_t)d.rbase + c;
+    U4 carry; carry.a = carry.b = carry.c = carry.d = 0; uint32_t qcarry = 0, bad = 0;
+    for (uint32_t r0 = 0; r0 < d.reads; r0 += 4u * blockDim.x) {             // block-uniform
+        const uint32_t rb = r0 + 4u * threadIdx.x;
+        U4 v[4]; uint32_t ln[4]; U4 sum; sum.a = sum.b = sum.c = sum.d = 0; uint32_t qsum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t r = rb + (uint32_t)i; v[i].a = v[i].b = v[i].c = v[i].d = 0; ln[i] = 0;
+            if (r < d.reads) {
+                const uint32_t len = dec_read_len(cp, d, rlb, r);
+                v[i].a = (fl & C_NAME1_SAME) ? 0u : cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)];
+                v[i].b = ((hf & H_NAME2) && !(fl & C_NAME2_SAME)) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
+                v[i].c = (fl & C_STRAND_SAME) ? 0u : cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)];
+                int ov = 0; uint32_t stored = len;
+                if (ovl && (r & 1u)) {
+                    ov = (int)(int8_t)cp[d.o_ov + r / 2] - (int)shift;
+                    const uint32_t a = (uint32_t)(ov < 0 ? -ov : ov);
+                    const uint32_t prevlen = dec_read_len(cp, d, rlb, r - 1);
+                    if (a > len || a > prevlen) { bad = 1; ov = 0; } else stored = len - a;
+                }
+                v[i].d = stored; ln[i] = len;
+                len_o[(size_t)d.rbase + r] = len; ov_o[(size_t)d.rbase + r] = ov;
+            }
+            sum = sum + v[i]; qsum += ln[i];
+        }
+        U4 tot; uint32_t qtot;
+        U4 run = carry + block_excl_sum<U4>(sum, &tot); uint32_t qrun = qcarry + block_excl_sum<uint32_t>(qsum, &qtot);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const uint32_t r = rb + (uint32_t)i; if (r < d.reads) { pvl[fp + r] = run; pql[fp + r] = qrun; } run = run + v[i]; qrun += ln[i]; }
+        carry = carry + tot; qcarry += qtot;
+    }
+    if (threadIdx.x == 0) { pvl[fp + d.reads] = carry; pql[fp + d.reads] = qcarry; }
+    if (__any(bad != 0) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
+}
 // aligned bases of each chunk inside the concatenated quality / stored-sequence buffers
 __global__ void k_dec_bases(const DChunk* __restrict__ CH, DReadTab R, uint64_t* __restrict__ qbase, uint64_t* __restrict__ sbase, uint32_t n_chunks) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;

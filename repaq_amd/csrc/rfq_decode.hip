@@ -11,7 +11,7 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 80, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_SEGK, DB_NENT, DB_LOFF, DB_PLIST, DB_GWCAND, DB_GWLIST, DB_GWCNT, DB_GWLAND, DB_END
+    DB_CHUNKS = 80, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_SEGK, DB_NENT, DB_LOFF, DB_PLIST, DB_GWCAND, DB_GWLIST, DB_GWCNT, DB_GWLAND, DB_PQL, DB_PVL, DB_TPL, DB_CTEXT, DB_TBASE, DB_END
 };
 static_assert(DB_END <= 120, "rfq_ctx::b too small");
 
@@ -19,9 +19,9 @@ static_assert(DB_END <= 120, "rfq_ctx::b too small");
 static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk* CH, uint32_t n_chunks, uint32_t maxseg, uint32_t ncell, uint32_t nstr,
                             uint32_t mq, uint32_t mn, uint32_t nn, bool hasn, hipStream_t LS) {
     DBuf* B = ctx->b; const DevHeader* D = ctx->d_hdr.as<DevHeader>(); const DecStatus* dst = B[DB_STATUS].as<DecStatus>();
-    const unsigned long long cap = B[DB_PLIST].cap / 4;
+    const unsigned long long cap = B[DB_PLIST].cap / sizeof(plist_t);
 #define RFQ_LIST_ARGS a->d_rfq, CH, D, (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), (const uint32_t*)B[DB_SEGK].as<uint32_t>(), \
-                      (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), B[DB_PLIST].as<uint32_t>(), cap, B[DB_CELL].as<uint32_t>(), maxseg, ncell, (uint64_t)a->n
+                      (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), B[DB_PLIST].as<plist_t>(), cap, B[DB_CELL].as<uint32_t>(), maxseg, ncell, (uint64_t)a->n
     if (nn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, 0u, nstr, dst);
     if (hasn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, ctx->h_hdr.n_normal, nstr, dst);
 #undef RFQ_LIST_ARGS
@@ -89,8 +89,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             // (an entry per eight bases to begin with - half a byte per base; a NovaSeq-binned file codes one position in twelve.  A file that codes more
             // - forty quality values code most positions - runs the list pass a second time, once per context: the arena keeps its size.  Round 3 asked for
             // 2 bytes per base up front: 6.7 GB on 2 x 4 GB of text)
-            if (B[DB_PLIST].ensure((size_t)(g.bases / 8 + 1024) * 4) != hipSuccess) { (void)hipGetLastError();
-                    HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 32 + 1024) * 4)); }
+            if (B[DB_PLIST].ensure((size_t)(g.bases / 8 + 1024) * sizeof(plist_t)) != hipSuccess) { (void)hipGetLastError();
+                    HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 32 + 1024) * sizeof(plist_t))); }
             HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A));
                     HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
 #define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
@@ -99,7 +99,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
 #undef RFQ_SUM2_ARGS
             hipLaunchKernelGGL(k_dec_pos_link2, dim3((uint32_t)((nst + 3) / 4)), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(),
                     (const int*)B[DB_SEGA].as<int>(),
-                               (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_SEGK].as<uint32_t>(), B[DB_NENT].as<uint32_t>(), f_maxseg, (uint32_t)nst);
+                               (const uint32_t*)B[DB_SEGN].as<uint32_t>(), B[DB_SEGS].as<uint8_t>(), B[DB_SEGP].as<int>(), B[DB_SEGK].as<uint32_t>(), B[DB_NENT].as<uint32_t>(), f_maxseg, (uint32_t)nst,
+                               CH, f_nstr, dst);
             hipLaunchKernelGGL(k_dec_pos_off, dim3(1), dim3(256), 0, A, (const uint32_t*)B[DB_NENT].as<uint32_t>(), B[DB_LOFF].as<unsigned long long>(), (uint32_t)nst,
                     dst);
             launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, A);
@@ -111,26 +112,40 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // ---- read table + prefixes
     ctx->timer.begin("read_table", S);
     const size_t nr = (size_t)n_reads + 2, nc = (size_t)n_chunks + 2;
-    HIPCHK(ctx, B[DB_LEN].ensure(nr * 4)); HIPCHK(ctx, B[DB_CHUNKID].ensure(nr * 4)); HIPCHK(ctx, B[DB_OV].ensure(nr * 4));
-    HIPCHK(ctx, B[DB_PVIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_PV].ensure(nr * 16)); HIPCHK(ctx, B[DB_PQ].ensure(nr * 4));
-    HIPCHK(ctx, B[DB_TIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_TP].ensure(nr * 16));
-    HIPCHK(ctx, B[DB_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[DB_SBASE].ensure(nc * 8));
+    HIPCHK(ctx, B[DB_LEN].ensure(nr * 4)); HIPCHK(ctx, B[DB_OV].ensure(nr * 4));
     HIPCHK(ctx, B[DB_XV].ensure(nr * 4)); HIPCHK(ctx, B[DB_YV].ensure(nr * 4)); HIPCHK(ctx, B[DB_MID].ensure(nr * 40));
-    HIPCHK(ctx, B[DB_SCAN].ensure((nr / SCAN_TILE + 2) * 16 + 1024));
-    DReadTab R; R.len = B[DB_LEN].as<uint32_t>(); R.chunk = B[DB_CHUNKID].as<uint32_t>(); R.ov = B[DB_OV].as<int32_t>();
-    R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>();
-            R.mid = B[DB_MID].as<uint8_t>();
-    hipLaunchKernelGGL(k_dec_readtab, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, dst);
-    KCHK(ctx, "k_dec_readtab");
-    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
-    scan_exclusive<U4>(S, R.pvin, R.pv, n_reads, B[DB_SCAN].as<U4>(), 1);
-    uint32_t total_bases = 0; U4 pv_tot;
-    HIPCHK(ctx, ctx->fetch(&total_bases, R.pq + n_reads, 4, S));
-    HIPCHK(ctx, ctx->fetch(&pv_tot, R.pv + n_reads, 16, S));
-    { DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S)); HIPCHK(ctx, ctx->fetch_sync(S)); hs.err = h2.err; }
-    ctx->timer.end(S);
-    if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");
-    *nbases = total_bases;
+    DReadTab R; memset(&R, 0, sizeof R); DFused F; memset(&F, 0, sizeof F);
+    R.len = B[DB_LEN].as<uint32_t>(); R.ov = B[DB_OV].as<int32_t>(); R.mid = B[DB_MID].as<uint8_t>();
+    uint32_t total_bases = 0; U4 pv_tot; memset(&pv_tot, 0, sizeof pv_tot);
+    if (fused) {
+        // chunk-local prefixes made where the per-read values are made (k_dec_readtab2): no per-read scan inputs, no batch-wide scans, no read-back here - the
+        // status word is looked at with the next one, the range's bases are the walk's 64-bit total
+        HIPCHK(ctx, B[DB_PQL].ensure((nr + nc) * 4)); HIPCHK(ctx, B[DB_PVL].ensure((nr + nc) * 16)); HIPCHK(ctx, B[DB_TPL].ensure(nr * 8));
+        HIPCHK(ctx, B[DB_CTEXT].ensure(nc * 16)); HIPCHK(ctx, B[DB_TBASE].ensure(nc * 16)); HIPCHK(ctx, B[DB_SCAN].ensure((nc / SCAN_TILE + 2) * 16 + 1024));
+        F.len = R.len; F.ov = R.ov; F.pql = B[DB_PQL].as<uint32_t>(); F.pvl = B[DB_PVL].as<U4>(); F.tpl = B[DB_TPL].as<uint2>(); F.tbase = B[DB_TBASE].as<U4>(); F.mid = R.mid;
+        hipLaunchKernelGGL(k_dec_readtab2, dim3(n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R.len, R.ov, B[DB_PQL].as<uint32_t>(), B[DB_PVL].as<U4>(), dst);
+        KCHK(ctx, "k_dec_readtab2");
+        ctx->timer.end(S);
+        *nbases = g.bases;
+    } else {
+        HIPCHK(ctx, B[DB_CHUNKID].ensure(nr * 4));
+        HIPCHK(ctx, B[DB_PVIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_PV].ensure(nr * 16)); HIPCHK(ctx, B[DB_PQ].ensure(nr * 4));
+        HIPCHK(ctx, B[DB_TIN].ensure(nr * 16)); HIPCHK(ctx, B[DB_TP].ensure(nr * 16));
+        HIPCHK(ctx, B[DB_QBASE].ensure(nc * 8)); HIPCHK(ctx, B[DB_SBASE].ensure(nc * 8));
+        HIPCHK(ctx, B[DB_SCAN].ensure((nr / SCAN_TILE + 2) * 16 + 1024));
+        R.chunk = B[DB_CHUNKID].as<uint32_t>();
+        R.pvin = B[DB_PVIN].as<U4>(); R.pv = B[DB_PV].as<U4>(); R.pq = B[DB_PQ].as<uint32_t>(); R.tin = B[DB_TIN].as<U4>(); R.tp = B[DB_TP].as<U4>();
+        hipLaunchKernelGGL(k_dec_readtab, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, dst);
+        KCHK(ctx, "k_dec_readtab");
+        scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[DB_SCAN].as<uint32_t>(), 1);
+        scan_exclusive<U4>(S, R.pvin, R.pv, n_reads, B[DB_SCAN].as<U4>(), 1);
+        HIPCHK(ctx, ctx->fetch(&total_bases, R.pq + n_reads, 4, S));
+        HIPCHK(ctx, ctx->fetch(&pv_tot, R.pv + n_reads, 16, S));
+        { DecStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S)); HIPCHK(ctx, ctx->fetch_sync(S)); hs.err = h2.err; }
+        ctx->timer.end(S);
+        if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");
+        *nbases = total_bases;
+    }
 
     // ---- streams (fused path: the coordinate decoder here, the list chain has been running since the top)
     if (fused) {
@@ -196,19 +211,29 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // ---- text
     if (!fused) ctx->timer.begin("textlen", S);                          // (fused path: still inside "streams", beside the list chain)
     const int split = a->split_pe ? 1 : 0;
-    hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(),
-            (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
-    scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
+    U4 tt;
+    if (fused) {
+        hipLaunchKernelGGL(k_dec_textlen2, dim3(n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, (const uint32_t*)R.len, R.mid, (const uint32_t*)B[DB_XV].as<uint32_t>(),
+                (const uint32_t*)B[DB_YV].as<uint32_t>(), split, B[DB_TPL].as<uint2>(), B[DB_CTEXT].as<U4>(), dst);
+        KCHK(ctx, "k_dec_textlen2");
+        scan_exclusive<U4>(S, B[DB_CTEXT].as<U4>(), B[DB_TBASE].as<U4>(), n_chunks, B[DB_SCAN].as<U4>(), 1);      // where every chunk's text starts; entry n_chunks: the totals
+    } else {
+        hipLaunchKernelGGL(k_dec_textlen, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R, (const uint32_t*)B[DB_XV].as<uint32_t>(),
+                (const uint32_t*)B[DB_YV].as<uint32_t>(), split, dst);
+        scan_exclusive<U4>(S, R.tin, R.tp, n_reads, B[DB_SCAN].as<U4>(), 1);
+    }
     if (f_join) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, f_aux)); HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_join, 0)); }
     aux_guard.armed = false;       // (everything below is ordered behind the chain on the main stream)
-    U4 tt;
-    HIPCHK(ctx, ctx->fetch(&tt, R.tp + n_reads, 16, S));
+    HIPCHK(ctx, ctx->fetch(&tt, fused ? B[DB_TBASE].as<U4>() + n_chunks : R.tp + n_reads, 16, S));
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
     HIPCHK(ctx, ctx->fetch_sync(S));
+    if (fused && (hs.err & DE_CORRUPT)) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");   // (k_dec_readtab2's verdict: nothing reads the status in between)
+    // a stream codes positions far beyond its chunk's length table (k_dec_pos_link2): 16-bit list entries would alias - the range goes to the expanded path
+    if (fused && (hs.err & DE_E3_RETRY)) return decode_range(ctx, a, g, out1, ocap1, out2, ocap2, p1, p2, n1, n2, nbases, true);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");
     // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
-    if (fused && f_lists && hs.list_need > B[DB_PLIST].cap / 4) {            // the lists did not fit the arena: now that their size is known, build them
-        HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(hs.list_need + 1024) * 4));
+    if (fused && f_lists && hs.list_need > B[DB_PLIST].cap / sizeof(plist_t)) {            // the lists did not fit the arena: now that their size is known, build them
+        HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(hs.list_need + 1024) * sizeof(plist_t)));
         launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, f_mq, f_mn, f_nn, f_hasn, S);
         KCHK(ctx, "k_dec_pos_list");
     }
@@ -223,7 +248,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     {
         if (fused) {
             const uint32_t K = 1u << e3k, b3 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);       // (25 KB of LDS: six workgroups per CU)
-#define RFQ_EMIT3_ARGS a->d_rfq, CH, D, R, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const uint32_t*)B[DB_PLIST].as<uint32_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
+#define RFQ_EMIT3_ARGS a->d_rfq, CH, D, F, (uint64_t)a->n, split, o1, cap1, o2, cap2, dst, (const plist_t*)B[DB_PLIST].as<plist_t>(), (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), \
                        (const uint32_t*)B[DB_NENT].as<uint32_t>(), (const uint32_t*)B[DB_CELL].as<uint32_t>(), f_ncell, f_nstr, e3k
             if (n1big) {
                 const uint32_t b4 = grid_x_for(n_chunks, (max_reads + K - 1) / K, 4u * ctx->n_cu);
