@@ -185,22 +185,22 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         {
 #pragma unroll
             // (an entry holds the low 16 bits of its position: see plist_t; 0xFFFFFFFF = no entry)
-            for (int i = 0; i < 8; i++) { const uint32_t p = q0 + ((fe[i] - q0) & 0xFFFFu); if (fe[i] != 0xFFFFFFFFu && p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
+            for (int i = 0; i < 8; i++) { const uint32_t p = plist_pos(fe[i], q0); if (p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
             while (ls_t < nn) {
                 uint32_t e_[4], v_[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) { e_[i] = 0xFFFFFFFFu; v_[i] = 0; ls_round(e_[i], v_[i]); }
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const uint32_t p = q0 + ((e_[i] - q0) & 0xFFFFu); if (e_[i] != 0xFFFFFFFFu && p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
+                for (int i = 0; i < 4; i++) { const uint32_t p = plist_pos(e_[i], q0); if (p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
             }
             if (nrec) for (uint32_t i = tid; i < nrec; i += blockDim.x) { const uint8_t* rr = xrec + 5ull * i; const uint32_t pos = ld_u32(rr + 1);
                     if (pos >= q0 && pos < q1 && pos < qlen_c) q_t[pos - q0] = rr[0]; }
             if (hasn) {
                 const uint32_t send = s1 < slen_c ? s1 : slen_c;
 #pragma unroll
-                for (int i = 0; i < 2; i++) { const uint32_t p = s0 + ((pn[i] - s0) & 0xFFFFu); if (pn[i] != 0xFFFFFFFFu && p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); }
+                for (int i = 0; i < 2; i++) { const uint32_t p = plist_pos(pn[i], s0); if (p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); }
                 if (nk0 != 0xFFFFFFFFu && nk0 + 512u < nke) { const plist_t* lp = plist + s_loff[nn];
-                        for (uint32_t kk = nk0 + 512u + tid; kk < nke; kk += 256u) { const uint32_t p = s0 + (((uint32_t)lp[kk] - s0) & 0xFFFFu);
+                        for (uint32_t kk = nk0 + 512u + tid; kk < nke; kk += 256u) { const uint32_t p = plist_pos((uint32_t)lp[kk], s0);
                         if (p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); } }
             }
         }
