@@ -143,11 +143,30 @@ __global__ void k_chunk_ends(Text T, const uint32_t* __restrict__ first, uint32_
 // the input there, src/fastqreader.cpp:180-191; a quality line shorter than its sequence is refused), bases per partition unit (a read, or a
 // pair) + per-block min / max for the partitioner's uniform-length fast path and the longest record (k_gather2 sizes its tiles by it).
 // (no atomics for the min / max: 44k waves hitting two words serialise at ~11 ns each, and a "skip if no change" test reads stale L1 lines)
+#define LENS_BLK 8u               // words per block of k_read_lens' summary: shortest / longest unit (bases), longest record (bytes), longest / shortest read (bases)
+// Every read of the batch has the same number of bases L - sequencer output, as a rule - : the base prefix of read g is g x L, no scan needed.  One workgroup reduces
+// k_read_lens' block summaries to uni[0] = 1 / 0, uni[1] = L; the two prefix scans behind it (units, reads: six launches over 11 M / 22 M elements on the headline
+// workload, 0.25 ms) look at uni[0] and leave at once, k_fill_pq writes the closed form instead, and k_partition's uniform branch never needs the unit prefix.
+__global__ void k_lens_uniform(const uint32_t* __restrict__ blk, uint32_t n_blk, uint32_t n_units, uint32_t* __restrict__ uni) {
+    __shared__ uint32_t s_a[16], s_b[16];
+    uint32_t ml = 0, msl = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk[LENS_BLK * i + 3], b = blk[LENS_BLK * i + 4]; if (a > ml) ml = a; if (b < msl) msl = b; }
+    ml = wave_max(ml); msl = wave_min(msl);
+    if (lane_id() == 0) { s_a[wave_id()] = ml; s_b[wave_id()] = msl; }
+    __syncthreads();
+    if (threadIdx.x == 0) { for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_a[i] > ml) ml = s_a[i]; if (s_b[i] < msl) msl = s_b[i]; }
+            uni[0] = (n_units > 0 && ml == msl && ml > 0) ? 1u : 0u; uni[1] = ml; }
+}
+__global__ void k_fill_pq(uint32_t* __restrict__ pq, uint32_t n_reads, const uint32_t* __restrict__ uni) {
+    if (!uni[0]) return;                                                     // (uniform: mixed lengths took the scan)
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, L = uni[1];
+    if (g <= n_reads) pq[g] = g * L;                                         // (entry n_reads: the total; < 2^32: a call's stream is < 4 GiB of text)
+}
 __global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __restrict__ stored, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr,
         uint32_t* __restrict__ blk_minmax, DevStatus* st) {
-    __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4], s_ml[4];
+    __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4], s_ml[4], s_sl[4];
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t tot = 0; uint32_t rec = 0, ml = 0, err = 0, fe = 0xFFFFFFFFu;   // rec: bytes of the unit's longest record, ml: bases of its longest read
+    uint64_t tot = 0; uint32_t rec = 0, ml = 0, msl = 0xFFFFFFFFu, err = 0, fe = 0xFFFFFFFFu;   // rec: bytes of the unit's longest record, ml: bases of its longest read
     if (u < n_units) {
         for (uint32_t j = 0; j < upr; j++) {
             const uint32_t g = u * upr + j; int s; uint32_t r; read_loc(T, g, s, r); const uint32_t* p = t_lo(T, s) + 4 * (size_t)r;
@@ -155,19 +174,19 @@ __global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __rest
             const uint32_t nl = p1 - 1 - p0, sl = p2 - 1 - p1, tl = p3 - 1 - p2, ql = p4 - 1 - p3;
             if (nl == 0 || sl == 0 || tl == 0 || ql == 0) { err |= DE_EMPTY_LINE; if (g < fe) fe = g; }
             if (ql < sl) err |= DE_QUAL_SHORT;
-            len[g] = sl; stored[g] = sl; tot += sl; if (p4 - p0 > rec) rec = p4 - p0; if (sl > ml) ml = sl;
+            len[g] = sl; stored[g] = sl; tot += sl; if (p4 - p0 > rec) rec = p4 - p0; if (sl > ml) ml = sl; if (sl < msl) msl = sl;
         }
         ulen[u] = tot;
     }
     uint32_t mn = u < n_units ? (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : tot) : 0xFFFFFFFFu, mx = u < n_units ? mn : 0u;
-    mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec); ml = wave_max(ml); fe = wave_min(fe); err = wave_or(err);
-    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; s_ml[wave_id()] = ml; if (err) { atomicOr(&st->err, err);
+    mn = wave_min(mn); mx = wave_max(mx); rec = wave_max(rec); ml = wave_max(ml); msl = wave_min(msl); fe = wave_min(fe); err = wave_or(err);
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rec; s_ml[wave_id()] = ml; s_sl[wave_id()] = msl; if (err) { atomicOr(&st->err, err);
             if (fe != 0xFFFFFFFFu) atomicMin(&st->first_empty, fe); } }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_mn[i] < mn) mn = s_mn[i]; if (s_mx[i] > mx) mx = s_mx[i]; if (s_rc[i] > rec) rec = s_rc[i];
-                if (s_ml[i] > ml) ml = s_ml[i]; }
-        blk_minmax[4 * blockIdx.x] = mn; blk_minmax[4 * blockIdx.x + 1] = mx; blk_minmax[4 * blockIdx.x + 2] = rec; blk_minmax[4 * blockIdx.x + 3] = ml;
+                if (s_ml[i] > ml) ml = s_ml[i]; if (s_sl[i] < msl) msl = s_sl[i]; }
+        uint32_t* const o = blk_minmax + LENS_BLK * blockIdx.x; o[0] = mn; o[1] = mx; o[2] = rec; o[3] = ml; o[4] = msl;
     }
 }
 
@@ -198,7 +217,7 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
     __shared__ uint32_t s_mn[16], s_mx[16], s_rc[16], s_ml[16];
     uint32_t len_minmax[2], max_rec, max_len;
     { uint32_t mn = 0xFFFFFFFFu, mx = 0, rc = 0, ml = 0;
-      for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk_minmax[4 * i], b = blk_minmax[4 * i + 1], r = blk_minmax[4 * i + 2], m = blk_minmax[4 * i + 3]; if (a < mn) mn = a; if (b > mx) mx = b; if (r > rc) rc = r; if (m > ml) ml = m; }
+      for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk_minmax[LENS_BLK * i], b = blk_minmax[LENS_BLK * i + 1], r = blk_minmax[LENS_BLK * i + 2], m = blk_minmax[LENS_BLK * i + 3]; if (a < mn) mn = a; if (b > mx) mx = b; if (r > rc) rc = r; if (m > ml) ml = m; }
       mn = wave_min(mn); mx = wave_max(mx); rc = wave_max(rc); ml = wave_max(ml);
       if (l == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_rc[wave_id()] = rc; s_ml[wave_id()] = ml; }
       __syncthreads();
@@ -206,8 +225,9 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
       const uint32_t nw = blockDim.x >> 6; mn = (uint32_t)l < nw ? s_mn[l] : 0xFFFFFFFFu; mx = (uint32_t)l < nw ? s_mx[l] : 0u; rc = (uint32_t)l < nw ? s_rc[l] : 0u;
               ml = (uint32_t)l < nw ? s_ml[l] : 0u;
       len_minmax[0] = wave_min(mn); len_minmax[1] = wave_max(mx); max_rec = wave_max(rc); max_len = wave_max(ml); }
-    uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0;
+    uint32_t c = 0, start = 0, max_units = 0; uint64_t prevP = 0, max_bases = 0; bool closed = false;
     if (n_units > 0 && len_minmax[0] == len_minmax[1] && len_minmax[0] > 0) {
+        closed = true;                                                     // (the unit prefix P may not exist: k_lens_uniform lets its scan return at once when every READ is L bases)
         // every unit has the same length L: a chunk is K = ceil(chunk_bases / L) units
         const uint32_t L = len_minmax[0]; const uint32_t K = (uint32_t)(((uint64_t)chunk_bases + L - 1) / L);
         // (the chunk open at unit 0 already holds `carry` bases: it closes after K0 units, the others after K each)
@@ -242,7 +262,7 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
     if (l == 0) {
         st->n_chunks = c; st->n_units_used = start; st->max_chunk_reads = max_units * upr;
         st->max_chunk_bases = (uint32_t)(max_bases > 0xFFFFFFFFull ? 0xFFFFFFFFu : max_bases);
-        st->total_bases = start ? P[start - 1] : 0; st->max_rec = max_rec; st->max_len = max_len;
+        st->total_bases = start ? (closed ? (uint64_t)start * len_minmax[0] : P[start - 1]) : 0; st->max_rec = max_rec; st->max_len = max_len;
                 st->unit_bases = (n_units > 0 && len_minmax[0] == len_minmax[1]) ? len_minmax[0] : 0u;
     }
 }

@@ -161,7 +161,9 @@ static inline int rfq_fail(rfq_ctx* c, int code, const char* fmt, ...) {
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_TPB * SCAN_ITEMS)
 
-template <class T> __global__ void k_scan_reduce(const T* __restrict__ in, T* __restrict__ partial, uint64_t n) {
+// skip (optional): a device word - non-zero means "the caller has a closed form for this prefix": the launch returns at once (k_lens_uniform, rfq_encode.hip)
+template <class T> __global__ void k_scan_reduce(const T* __restrict__ in, T* __restrict__ partial, uint64_t n, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     // (a sum does not care about order: item i of thread t is element i * SCAN_TPB + t of the tile, so every load is coalesced)
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x;
     T v[SCAN_ITEMS];
@@ -175,7 +177,8 @@ template <class T> __global__ void k_scan_reduce(const T* __restrict__ in, T* __
 }
 // the tiles' sums -> their exclusive prefixes, by ONE workgroup: every thread takes a run of consecutive partials (summed, then re-walked with
 // its offset), one block scan in between (the earlier form - a block scan and two barriers per 256 partials - took 48 us for 11 k tiles)
-template <class T> __global__ void k_scan_partials(T* __restrict__ partial, uint32_t nb, T* __restrict__ grand) {
+template <class T> __global__ void k_scan_partials(T* __restrict__ partial, uint32_t nb, T* __restrict__ grand, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     const uint32_t K = (nb + SCAN_TPB - 1) / SCAN_TPB, i0 = threadIdx.x * K, i1 = i0 + K < nb ? i0 + K : nb;
     T acc = T();
     for (uint32_t i = i0; i < i1; i++) acc = acc + partial[i];
@@ -184,7 +187,8 @@ template <class T> __global__ void k_scan_partials(T* __restrict__ partial, uint
     if (threadIdx.x == 0 && grand) *grand = tot;
 }
 // out[i] = exclusive prefix; out may alias in.  When out has n+1 entries pass write_total=1 to store the total at out[n].
-template <class T> __global__ void k_scan_apply(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ partial, uint64_t n, int write_total) {
+template <class T> __global__ void k_scan_apply(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ partial, uint64_t n, int write_total, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
     T v[SCAN_ITEMS]; T acc = T();
     for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = base + i < n ? in[base + i] : T(); acc = acc + v[i]; }
@@ -196,7 +200,8 @@ template <class T> __global__ void k_scan_apply(const T* __restrict__ in, T* __r
 // a short array (per-chunk quantities: a few thousand elements) by ONE workgroup in ONE launch: every thread sums its run of consecutive elements, one block
 // scan, the runs re-walked with their offsets (three launches took 30 us each way for 3,360 elements, and an encode step has five of these)
 #define SCAN_SMALL 16384u
-template <class T> __global__ void k_scan_small(const T* in, T* out, uint32_t n, int write_total) {
+template <class T> __global__ void k_scan_small(const T* in, T* out, uint32_t n, int write_total, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     const uint32_t K = (n + SCAN_TPB - 1) / SCAN_TPB, i0 = threadIdx.x * K, i1 = i0 + K < n ? i0 + K : n;
     T acc = T();
     for (uint32_t i = i0; i < i1; i++) acc = acc + in[i];
@@ -205,11 +210,11 @@ template <class T> __global__ void k_scan_small(const T* in, T* out, uint32_t n,
     if (write_total && threadIdx.x == 0) out[n] = tot;
 }
 // tmp must hold ceil(n / SCAN_TILE) + 1 elements of T
-template <class T> static inline void scan_exclusive(hipStream_t s, const T* in, T* out, uint64_t n, T* tmp, int write_total) {
+template <class T> static inline void scan_exclusive(hipStream_t s, const T* in, T* out, uint64_t n, T* tmp, int write_total, const uint32_t* skip = nullptr) {
     if (n == 0) { if (write_total) (void)hipMemsetAsync(out, 0, sizeof(T), s); return; }
-    if (n <= SCAN_SMALL) { hipLaunchKernelGGL((k_scan_small<T>), dim3(1), dim3(SCAN_TPB), 0, s, in, out, (uint32_t)n, write_total); return; }
+    if (n <= SCAN_SMALL) { hipLaunchKernelGGL((k_scan_small<T>), dim3(1), dim3(SCAN_TPB), 0, s, in, out, (uint32_t)n, write_total, skip); return; }
     const uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, tmp, n);
-    hipLaunchKernelGGL((k_scan_partials<T>), dim3(1), dim3(SCAN_TPB), 0, s, tmp, nb, (T*)nullptr);
-    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, out, (const T*)tmp, n, write_total);
+    hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, tmp, n, skip);
+    hipLaunchKernelGGL((k_scan_partials<T>), dim3(1), dim3(SCAN_TPB), 0, s, tmp, nb, (T*)nullptr, skip);
+    hipLaunchKernelGGL((k_scan_apply<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, out, (const T*)tmp, n, write_total, skip);
 }

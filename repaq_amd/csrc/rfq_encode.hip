@@ -338,11 +338,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // sequence lengths come from the line table alone; the names are parsed where the text is staged anyway (k_gather2), or by k_read_table for
     // the reads that need them earlier (chunk 0 of a first batch: the file header) / on the byte-wise gather path (all of them)
     const uint32_t ublocks = (n_units + 255) / 256;
-    HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 1) * 16));
+    HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 2) * LENS_BLK * 4));
     hipLaunchKernelGGL(k_read_lens, dim3(ublocks), dim3(256), 0, S, T, R.len, R.stored, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>(), dst);
     KCHK(ctx, "k_read_lens");
-    scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1);
-    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1);
+    // every read the same length (sequencer output): both prefixes have a closed form - the scans see the flag and return, k_fill_pq writes g x L (no host round trip)
+    uint32_t* const uni = B[B_MINMAX].as<uint32_t>() + (size_t)ublocks * LENS_BLK;
+    hipLaunchKernelGGL(k_lens_uniform, dim3(1), dim3(1024), 0, S, (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, n_units, uni);
+    scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1, uni);
+    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1, uni);
+    hipLaunchKernelGGL(k_fill_pq, dim3(n_reads / 256 + 1), dim3(256), 0, S, R.pq, n_reads, (const uint32_t*)uni);
     const uint64_t cap64 = (uint64_t)(nbytes[0] + nbytes[1]) / (2ull * a->chunk_bases) + 3;
     const uint32_t cap_chunks = (uint32_t)std::min<uint64_t>(cap64, (uint64_t)n_units + 1);
     HIPCHK(ctx, B[B_FIRST].ensure(((size_t)cap_chunks + 2) * 4));
