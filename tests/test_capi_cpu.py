@@ -61,3 +61,15 @@ def test_product_sources_do_not_reference_the_oracle():
                 if "liboracle" in t or "rfq_oracle" in t or "rfqo_" in t:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_bench_names_only_kernels_that_exist():
+    """bench.py maps stage timers to kernel names (roofline.kernel, the traffic tables): every name must be a kernel of the sources (two deleted kernels were still listed)"""
+    src = ""
+    for base, _, files in os.walk(os.path.join(ROOT, "repaq_amd", "csrc")):
+        for f in files:
+            if f.endswith((".h", ".hip")):
+                src += open(os.path.join(base, f), errors="replace").read()
+    names = set(re.findall(r'"(k_[a-z0-9_]+[a-z0-9])"', open(os.path.join(ROOT, "bench.py")).read()))
+    missing = sorted(n for n in names if not re.search(r"\b%s\b" % n, src))
+    assert names and not missing, missing

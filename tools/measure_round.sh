@@ -26,6 +26,9 @@ for W in cfg1 cfg4; do ff=$(find $OUT/pmc_fetch_$W -name "*.db" 2>/dev/null | he
 [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_summary.py $ff $fw $OUT/pmc_traffic_$W.json > $OUT/pmc_traffic_$W.txt 2>&1; done
 # the N > 1 control flow on this one GPU (parity strings, plan_ms), the SQ counters, the driver end to end
 bash tools/multi_single_device.sh $TAG/multi > $OUT/multi.log 2>&1
+# the host work queue in bench form: small (1 and 2 ranks on this GPU) and the WHOLE configs[3] input through one GPU
+bash tools/queue_check.sh $TAG/queue small > $OUT/queue_small.log 2>&1
+bash tools/queue_check.sh $TAG/queue cfg3 > $OUT/queue_cfg3.log 2>&1
 bash tools/pmc_sq.sh $TAG/sq > /dev/null 2>&1; cp $OUT/sq/sq.txt $OUT/sq_counters.txt 2>/dev/null
 bash tools/e2e_pe.sh > $OUT/e2e_pe.txt 2>&1
 # the raw databases are large: keep the summaries, drop the traces

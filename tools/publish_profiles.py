@@ -17,7 +17,9 @@ pairs = [("bench.json.log", "bench.json.log"), ("bench_under_rocprof.json.log", 
          ("trace_kernel_stats.txt", "kernel_stats_cfg2.txt"), ("trace_cfg1_kernel_stats.txt", "kernel_stats_cfg1.txt"),
          ("trace_cfg4_kernel_stats.txt", "kernel_stats_cfg4.txt"), ("pmc_traffic.txt", "pmc_traffic_cfg2.txt"), ("pmc_traffic_cfg1.txt", "pmc_traffic_cfg1.txt"), ("pmc_traffic_cfg4.txt", "pmc_traffic_cfg4.txt"),
          ("e2e_cli.txt", "e2e_cli.txt"), ("e2e_pe.txt", "e2e_pe.txt"), ("sq_counters.txt", "sq_counters.txt"),
-         ("multi/gpus2_single_device.json.log", "gpus2_single_device.json.log"), ("multi/gpus4_single_device.json.log", "gpus4_single_device.json.log"), ("multi/gpus2_strong_single_device.json.log", "gpus2_strong_single_device.json.log")]
+         ("multi/gpus2_single_device.json.log", "gpus2_single_device.json.log"), ("multi/gpus4_single_device.json.log", "gpus4_single_device.json.log"), ("multi/gpus2_strong_single_device.json.log", "gpus2_strong_single_device.json.log"),
+         ("queue/queue_gpus1_2seg.json.log", "queue_gpus1_2seg.json.log"), ("queue/queue_gpus2_single_device.json.log", "queue_gpus2_single_device.json.log"),
+         ("queue/queue_cfg3_whole_one_gpu.json.log", "queue_cfg3_whole_one_gpu.json.log")]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p):
