@@ -58,7 +58,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
     __shared__ uint4 t_pk4[E3_QCAP / 64 + 6];                               // the tile's packed bases
     __shared__ uint32_t t_nb[E3_QCAP / 32 + 8];                             // one bit per stored base of the tile: is N
     // (N1CAP: E3_N1BIG for files with long per-read names)
-    __shared__ uint4 t_mid4_[64 * 40 / 16 + 5], t_n14_[N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];
+    __shared__ uint4 t_mid4_[64 * E3_MIDROW / 16 + 5], t_n14_[N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];
     // (16 readable bytes in front of each: a 16-byte group of the name line may start before a piece)
     uint4* const t_mid4 = t_mid4_ + 1; uint4* const t_n14 = t_n14_ + 1; uint4* const t_n24 = t_n24_ + 1;
     __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
@@ -134,7 +134,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
                 if (rqa > rqe) rqa = rqe; }
         if (raw) span_dma<(int)((E3_QCAP / 16 + 4 + 255) / 256)>(make_span(t_q4 + 1, img, rqa, rqe, img_bytes, true));
         if (w == 0) span_dma_wave<(int)((E3_QCAP / 64 + 4 + 63) / 64)>(make_span(t_pk4, img, pka, pke, img_bytes, true), l);
-        else if (w == 1) span_dma_wave<(int)((64 * 40 / 16 + 4 + 63) / 64)>(make_span(t_mid4, F.mid, (uint64_t)g0 * 40, (uint64_t)g1 * 40, ~0ull >> 1, true), l);
+        else if (w == 1) span_dma_wave<(int)((64 * E3_MIDROW / 16 + 4 + 63) / 64)>(make_span(t_mid4, F.mid, (uint64_t)g0 * E3_MIDROW, (uint64_t)g1 * E3_MIDROW, ~0ull >> 1, true), l);
         else if (w == 2) { if (!same1) span_dma_wave<(int)((N1CAP / 16 + 4 + 63) / 64)>(make_span(t_n14, img, n1a, n1e, img_bytes, true), l); }
         else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, n2a, n2e, img_bytes, true), l);
                if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, sta, ste, img_bytes, true), l); }
@@ -169,10 +169,10 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         uint32_t len = 0, n1 = 0, n2 = 0, sl = 0, md = 0, prevlen = 0, sp = 0, qp_ = 0, o7 = 0, o8 = 0, o9 = 0; int ov = 0; uint32_t toff = 0;
         if (on) {
             const uint32_t g_ = f + r; const uint2 t2 = F.tpl[g_]; const U4 p4 = F.pvl[fp + r];
-            toff = to2 ? tb.b + t2.y : tb.a + t2.x; sp = p4.d - s0; qp_ = F.pql[fp + r] - q0; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9;
+            toff = (to2 ? tb.b : tb.a) + t2.x; sp = p4.d - s0; qp_ = F.pql[fp + r] - q0; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9;
             len = F.len[g_]; ov = F.ov[g_]; prevlen = odd ? F.len[g_ - 1] : 0u;
             n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)]; n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
-            sl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)]; md = F.mid[(size_t)g_ * 40 + 39];
+            sl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)]; md = t2.y;
         }
         // ---- the next tile's parameters (consumed a tile from now)
         const uint32_t nxt = cur + cnt; TileP tp_n = tp;
@@ -218,7 +218,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
                 // on - and stores it once.  (Piece by piece this was ~10 partial stores per read: 1.4 ms of the kernel's 5.1 on 2 x 4 GB.)
                 const uint32_t L = e0 + 1u; const bool nfast = L >= 16u, jfast = sl == 1u && len >= 16u;
                 const uint8_t* const src1 = (const uint8_t*)t_n14 + (uint32_t)(n1a & 15ull) + (same1 ? 0u : o7);
-                const uint8_t* const src2 = (const uint8_t*)t_mid4 + (uint32_t)(((uint64_t)g0 * 40) & 15ull) + 40u * j;
+                const uint8_t* const src2 = (const uint8_t*)t_mid4 + (uint32_t)(((uint64_t)g0 * E3_MIDROW) & 15ull) + E3_MIDROW * j;
                 const uint8_t* const src3 = (const uint8_t*)t_n24 + (uint32_t)(n2a & 15ull) + (same2 ? 0u : o8);
                 const uint8_t* const src4 = (const uint8_t*)t_st4 + (uint32_t)(sta & 15ull) + (same3 ? 0u : o9);
                 const int pat2 = (same2 && rc && dch != 0 && dpos < n2) ? (int)dpos : -1;

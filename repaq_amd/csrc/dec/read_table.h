@@ -34,11 +34,13 @@ __global__ void k_dec_readtab(const uint8_t* __restrict__ img, const DChunk* __r
 // 2.0 GB of traffic per 8 GB of text for prefixes of which the emitter only ever uses differences INSIDE one chunk.  Here a workgroup owns a chunk
 // and walks its reads 1024 at a time (four consecutive reads per thread, one block scan per step, the step's total carried): the prefixes restart at 0 in every
 // chunk and every chunk gets one entry more than it has reads - its totals - so chunk c's entries sit at [rbase + c, rbase + c + reads].
+#define E3_MIDROW 32u
 struct DFused {
     const uint32_t* len; const int32_t* ov;
     const uint32_t* pql;        // [rbase + c + r]: qualities (= bases) of the chunk in front of read r; entry `reads` = the chunk's total
     const U4* pvl;              // ... (name1, name2, strand piece bytes; stored bases) in front of read r
-    const uint2* tpl;           // [rbase + r]: text bytes of the chunk in front of read r, per output (x: out1, y: out2)
+    const uint2* tpl;           // [rbase + r]: x = text bytes of the chunk in front of read r in ITS output (out1, or out2 for a split decode's mates), y = bytes of its name middle
+    // mid: [g][E3_MIDROW]: the formatted ":lane:tile:x:y" middle of the name, zero-padded (":255:65535:4294967295:4294967295" is 32 bytes: the row; its length rides in tpl.y)
     const U4* tbase;            // [c]: text bytes in front of chunk c (a: out1, b: out2); entry n_chunks = the range's totals
     const uint8_t* mid;
 };

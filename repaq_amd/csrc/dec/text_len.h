@@ -60,32 +60,33 @@ __global__ void k_dec_textlen(const uint8_t* __restrict__ img, const DChunk* __r
     }
 }
 // fused path: the same per read - formatted middle, text bytes - with the text prefix made CHUNK-LOCAL on the spot (a workgroup per chunk, 256 reads per step, one block
-// scan of the (out1, out2) byte pair per step) and the chunk's totals left for one small scan over the chunks; no per-read tin / tp arrays, no batch-wide scan.
+// scan of the (out1, out2) byte pair per step) and the chunk's totals left for one small scan over the chunks; no per-read tin / tp arrays, no batch-wide scan.  A read keeps the
+// offset of ITS output only, and the length of its middle beside it (tpl: 8 bytes per read); the middle's row is 32 bytes (E3_MIDROW), not 40.
 __global__ void __launch_bounds__(256) k_dec_textlen2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, const uint32_t* __restrict__ len_i,
                                                       uint8_t* __restrict__ mid, const uint32_t* __restrict__ xv, const uint32_t* __restrict__ yv, int split,
                                                       uint2* __restrict__ tpl, U4* __restrict__ ctext, DecStatus* st) {
-    __shared__ unsigned long long s_mid[256 * 5];                     // a 40-byte row per thread
+    __shared__ unsigned long long s_mid[256 * 4];                     // a 32-byte row per thread
     const uint32_t c = blockIdx.x; const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint32_t hf = D->flags;
     unsigned long long carry = 0;                                    // (out1 bytes | out2 bytes << 32: a chunk's text is far below 4 GiB per output)
     for (uint32_t r0 = 0; r0 < d.reads; r0 += blockDim.x) {           // block-uniform
-        const uint32_t r = r0 + threadIdx.x; unsigned long long mine = 0;
+        const uint32_t r = r0 + threadIdx.x; unsigned long long mine = 0; uint32_t k = 0; bool second = false;
         if (r < d.reads) {
             const size_t g = (size_t)d.rbase + r;
             const DName m = dec_name_parts(cp, d, D, xv, yv, r);
-            uint8_t* buf = (uint8_t*)(s_mid + 5u * threadIdx.x); uint32_t k = 0;
-            { unsigned long long* z = (unsigned long long*)buf; z[0] = z[1] = z[2] = z[3] = z[4] = 0ull; }
+            uint8_t* buf = (uint8_t*)(s_mid + 4u * threadIdx.x);
+            { unsigned long long* z = (unsigned long long*)buf; z[0] = z[1] = z[2] = z[3] = 0ull; }
             if (hf & H_LANE) { buf[k++] = ':'; k += dec_put(buf + k, m.lane); }
             if (hf & H_TILE) { buf[k++] = ':'; k += dec_put(buf + k, m.tile); }
             if (hf & H_X) { buf[k++] = ':'; k += dec_put(buf + k, m.x); }
             if (hf & H_Y) { buf[k++] = ':'; k += dec_put(buf + k, m.y); }
-            buf[39] = (uint8_t)k;
-            { const unsigned long long* z = (const unsigned long long*)buf; unsigned long long* mp = (unsigned long long*)(mid + g * 40);
-              const unsigned long long a0 = z[0], a1 = z[1], a2 = z[2], a3 = z[3], a4 = z[4]; mp[0] = a0; mp[1] = a1; mp[2] = a2; mp[3] = a3; mp[4] = a4; }
+            { const unsigned long long* z = (const unsigned long long*)buf; unsigned long long* mp = (unsigned long long*)(mid + g * E3_MIDROW);
+              const unsigned long long a0 = z[0], a1 = z[1], a2 = z[2], a3 = z[3]; mp[0] = a0; mp[1] = a1; mp[2] = a2; mp[3] = a3; }
             const uint32_t len = len_i[g]; const uint32_t text = m.n1 + m.n2 + k + 1 + len + 1 + m.st + 1 + len + 1;
-            mine = (split && (r & 1u)) ? ((unsigned long long)text << 32) : (unsigned long long)text;
+            second = split && (r & 1u);
+            mine = second ? ((unsigned long long)text << 32) : (unsigned long long)text;
         }
         unsigned long long tot; const unsigned long long ex = carry + block_excl_sum<unsigned long long>(mine, &tot);
-        if (r < d.reads) tpl[(size_t)d.rbase + r] = make_uint2((uint32_t)ex, (uint32_t)(ex >> 32));
+        if (r < d.reads) tpl[(size_t)d.rbase + r] = make_uint2(second ? (uint32_t)(ex >> 32) : (uint32_t)ex, k);
         carry += tot;
     }
     if (threadIdx.x == 0) {
