@@ -429,7 +429,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     const uint32_t max_rec = hs.max_rec;
     const uint32_t np = reads_used / 2;
     ctx->timer.begin("header", S);
-    hipLaunchKernelGGL(k_chunk_ids, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, C, R);
+    if (!fast) hipLaunchKernelGGL(k_chunk_ids, dim3((max_reads + 255) / 256, n_chunks), dim3(256), 0, S, C, R);   // (a read's chunk: only the byte-wise path's k_overlap_apply asks)
     // parsed names ahead of the gather: chunk 0's for the file header of a first batch; every read's on the byte-wise path
     const uint32_t c0_reads = std::max(1u, std::min(max_reads, reads_used));
     if (!fast) hipLaunchKernelGGL(k_read_table, dim3((n_reads + 255) / 256), dim3(256), 0, S, T, R, n_reads);
