@@ -15,15 +15,9 @@
 #define POS2_CELL 1024u
 // A list entry is the LOW 16 BITS of a coded position (round 5; u32 before: 1.17 GB written and read back per 8 GB of text).  The emitter asks the cell index for the
 // entries of [tile start, tile start + tile + a cell) - a window far below 65536 positions - so an entry e is position q0 + ((e - q0) & 0xFFFF), q0 = the tile's first position.
-#define PLIST_BITS 16
-#if PLIST_BITS == 16
-typedef uint16_t plist_t;
+typedef uint16_t plist_t;           // (32-bit entries were A/B'd on one box - profiles/r05_ab.txt: 0.15 ms slower in the emitter, twice the list traffic - and are gone)
 // the position an entry stands for, seen from a window that starts at position w0 (0xFFFFFFFF: none - `e` is the 32-bit register an entry was loaded into, or its "no entry" preset)
 __device__ __forceinline__ uint32_t plist_pos(uint32_t e, uint32_t w0) { return e == 0xFFFFFFFFu ? e : w0 + ((e - w0) & 0xFFFFu); }
-#else
-typedef uint32_t plist_t;
-__device__ __forceinline__ uint32_t plist_pos(uint32_t e, uint32_t w0) { return e < w0 ? 0xFFFFFFFFu : e; }
-#endif
 struct PosSrc { const uint8_t* sp; uint32_t slen; uint8_t q; };
 // stream jj of a chunk: jj < nn = quality value stream, jj == nn = N positions.  slen = 0 when absent; corrupt length tables are flagged.
 __device__ __forceinline__ PosSrc pos_src_of(const uint8_t* __restrict__ img, const DChunk& d, const DevHeader* __restrict__ D, uint32_t jj, DecStatus* st) {

@@ -106,6 +106,10 @@ __device__ __host__ __forceinline__ U4 operator-(const U4& x, const U4& y) { U4 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
+// CONTRACT of every wave_* / quad_* / lane_* primitive below: all 64 lanes of the wave call it together (full EXEC mask: call it outside lane-divergent branches, or
+// under a condition that is the same in every lane).  The shuffle forms of the interpreter build read an idle lane's last value; a DPP move reads NOTHING from a lane
+// that is switched off (the destination keeps `old`), so a call under divergent EXEC gives different answers on the GPU and under the interpreter - the interpreter
+// aborts on a divergent rendezvous, the GPU does not.  tests/test_wave_primitives.py sweeps every primitive lane by lane on the GPU.
 // Wave scans and reductions run on DPP (row_shr:1/2/4/8 inside the rows of 16 lanes, row_bcast:15 / row_bcast:31 across them): six VALU
 // instructions with a DPP source operand per 32-bit scan.  The __shfl forms they replace went through ds_bpermute_b32 - address VALU + LDS crossbar
 // + s_waitcnt per step - in kernels that are VALU-issue-bound (1,505 bpermute sites, no DPP).  The SIMT interpreter of the test build
