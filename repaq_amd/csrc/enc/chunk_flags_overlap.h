@@ -335,19 +335,26 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
                 if (!__any(cand >= 0)) break;                    // wave-uniform
                 const uint32_t pa = cand >= 0 ? (uint32_t)cand : 0u, o = cand >= 0 ? (uint32_t)(wl - cand) : 0u;
                 unsigned long long diff = 0;
+                // 64 bits of a row from any bit offset: three ALIGNED dwords and two funnel shifts (rows start on dwords; the word behind a row's last is the next row's or
+                // the array's slack, and masked off).  An 8-byte LDS read at a byte offset - or at a dword that is not an 8-byte boundary: every other lane's row - is served one lane
+                // per clock (rfq_common.h, lds_get16f): it was most of this loop.
+                auto bits64 = [](const uint8_t* row, uint32_t bit) -> unsigned long long {
+                    const uint32_t* q = (const uint32_t*)row + (bit >> 5); const uint32_t sh = bit & 31u; const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+                    return ((unsigned long long)lds_funnel(w2, w1, sh) << 32) | lds_funnel(w1, w0, sh);
+                };
+                auto word64 = [](const uint8_t* row, uint32_t c) -> unsigned long long { const uint32_t* q = (const uint32_t*)row + 2u * c; const uint32_t w0 = q[0], w1 = q[1];
+                        return ((unsigned long long)w1 << 32) | w0; };
                 for (uint32_t c = 0; c < nch; c++) {
                     if (32u * c >= o) continue;
-                    const uint32_t bit = 2u * (pa + 32u * c), off = bit >> 3, sh = bit & 7u;
-                    unsigned long long x = lds_get8(wc, off) >> sh; if (sh) x |= (unsigned long long)wc[off + 8u] << (64u - sh);
+                    const unsigned long long x = bits64(wc, 2u * (pa + 32u * c));
                     const uint32_t nb = o - 32u * c;
-                    diff |= (x ^ lds_get8(oc, 8u * c)) & (nb >= 32u ? ~0ull : (1ull << (2u * nb)) - 1ull);
+                    diff |= (x ^ word64(oc, c)) & (nb >= 32u ? ~0ull : (1ull << (2u * nb)) - 1ull);
                 }
                 for (uint32_t c = 0; c < nch2; c++) {
                     if (64u * c >= o) continue;
-                    const uint32_t bit = pa + 64u * c, off = bit >> 3, sh = bit & 7u;
-                    unsigned long long x = lds_get8(wn, off) >> sh; if (sh) x |= (unsigned long long)wn[off + 8u] << (64u - sh);
+                    const unsigned long long x = bits64(wn, pa + 64u * c);
                     const uint32_t nb = o - 64u * c;
-                    diff |= (x ^ lds_get8(on_, 8u * c)) & (nb >= 64u ? ~0ull : (1ull << nb) - 1ull);
+                    diff |= (x ^ word64(on_, c)) & (nb >= 64u ? ~0ull : (1ull << nb) - 1ull);
                 }
                 if (cand >= 0) {
                     if (diff == 0) { done = true; ov = dir ? -(int)o : (int)o;

@@ -242,9 +242,12 @@ __device__ __forceinline__ uint8_t comp_base(uint8_t b) {
     switch (b) { case 'A': case 'a': return 'T'; case 'T': case 't': return 'A'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; default: return 'N'; }
 }
 
-// 16 / 4 consecutive bytes starting at an arbitrary LDS byte address, as little-endian words: ONE ds_read_b128 / ds_read_b32 at a
-// byte-granular address (gfx950 LDS runs in unaligned access mode; the compiler emits the wide read for an align-1 type).  The
-// earlier form - five aligned word reads + v_alignbit funnel shifts - cost ~10 instructions per group in VALU-bound copy loops.
+// 16 / 8 / 4 consecutive bytes starting at an arbitrary LDS byte address, as little-endian words: ONE ds_read_b128 / _b64 / _b32 at a byte-granular address (gfx950 LDS runs in
+// unaligned access mode; the compiler emits the wide read for an align-1 type).  What that costs was measured in round 5 (tools/micro/lds_align.hip, profiles/r05_lds_align.txt): the
+// LDS serves an access that is not naturally aligned ONE LANE PER CLOCK - 64 clocks of the CU's LDS pipeline per wave instruction, whatever its width (16 bytes per lane at
+// record-strided byte offsets: 15.8 B/clk/CU; the same rows 16-aligned: 81; unaligned 16-byte WRITES: 10).  Aligned dwords + a funnel shift per word (lds_funnel; round 2's form of
+// these helpers) are 2.5 - 3.5 times faster on the LDS side and cost two to nine more instructions per read: they pay where a kernel waits for the LDS (k_overlap's window words), not
+// where it is bound by its instructions (k_gather2: +0.4 ms with them) or by its stores (k_dec_emit3: no change) - those keep the one-instruction form.
 struct __attribute__((packed, aligned(1))) LdsU16 { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) LdsU4 { uint32_t a; };
 __device__ __forceinline__ void lds_get16(const uint8_t* base, uint32_t a, uint32_t (&w)[4]) {
@@ -253,6 +256,7 @@ __device__ __forceinline__ void lds_get16(const uint8_t* base, uint32_t a, uint3
 __device__ __forceinline__ uint32_t lds_get4(const uint8_t* base, uint32_t a) { return ((const LdsU4*)(base + a))->a; }
 struct __attribute__((packed, aligned(1))) LdsU8 { unsigned long long a; };
 __device__ __forceinline__ unsigned long long lds_get8(const uint8_t* base, uint32_t a) { return ((const LdsU8*)(base + a))->a; }
+__device__ __forceinline__ uint32_t lds_funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh); }   // sh < 32: v_alignbit_b32
 // a wave-uniform value the compiler cannot prove uniform (it was loaded through a vector address, or derives from the wave's index): into an SGPR
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
