@@ -119,13 +119,16 @@ __device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m,
     for (uint32_t gi = part; gi < ng; gi += P) {
         uint32_t w[4], code = 0, nbits = 0;
         const uint32_t nv0 = m.len - 16u * gi;                             // valid bases of this step
-        // (the bytes of a last, partial step that lie outside the line would fail the all-ACGT test in some lane of nearly every wave - and a wave
-        // runs the exact path if any of its lanes does: they are made 'A' first; their codes are masked off below)
+        // A last, partial step of a line of >= 16 bases takes the 16 bases that END the line (that begin it, for a mate stored back to front) and shifts the ones it owns down:
+        // every byte it looks at is a base of the read.  (Bytes outside the line would fail the all-ACGT test in some lane of nearly every wave - and a wave runs the exact path if
+        // any of its lanes does; they used to be made 'A' by a loop over the bytes, ~20 instructions each: two hundred for the last step of a 150-base line, in every wave that
+        // holds one - k_gather2 3.64 -> 3.54 ms.)  Only reads of fewer than 16 bases still take that loop.
+        const bool tail = nv0 < 16u && m.len >= 16u; const uint32_t tsh = tail ? 16u - nv0 : 0u;
         auto blank = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) { uint32_t& x = w[k >> 2]; const uint32_t sh = 8u * (k & 3u);
                 x = (x & ~(0xFFu << sh)) | (0x41u << sh); } };
         if (!m.rc) {
-            lds_get16(s_text, m.ssrc + 16u * gi, w);
-            if (nv0 < 16u) blank(nv0, 16u);
+            lds_get16(s_text, m.ssrc + (tail ? m.len - 16u : 16u * gi), w);
+            if (nv0 < 16u && !tail) blank(nv0, 16u);
             if (!pack16_fast(w, code)) {                                    // (an N, a lower-case or any other byte among the 16)
                 uint32_t bad = 0; code = 0;
 #pragma unroll
@@ -134,8 +137,8 @@ __device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m,
                 if (bad) rflag[m.gi] = 1;
             }
         } else {
-            lds_get16(s_text, m.ssrc + m.len - 16u * gi - 16u, w);           // the 16 file bases that END at len - 16 gi (the last step reaches in front of the line)
-            if (nv0 < 16u) blank(0u, 16u - nv0);
+            lds_get16(s_text, tail ? m.ssrc : m.ssrc + m.len - 16u * gi - 16u, w);   // the 16 file bases that END at len - 16 gi
+            if (nv0 < 16u && !tail) blank(0u, 16u - nv0);
             if (pack16_fast(w, code)) code = ~g2_rev2x16(code);             // reverse complement in 2-bit space: the fields back to front, G 0 <-> C 3, A 1 <-> T 2
             else {
                 const uint32_t x0 = bswap32(w[3]), x1 = bswap32(w[2]), x2 = bswap32(w[1]), x3 = bswap32(w[0]); w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3; code = 0;
@@ -143,6 +146,7 @@ __device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m,
                 for (int i = 0; i < 4; i++) { uint32_t c4, n4; pack4_codes_rc(w[i], c4, n4); code |= c4 << (8 * i); nbits |= n4 << (4 * i); }
             }
         }
+        code >>= 2u * tsh; nbits >>= tsh;
         if (nv0 < 16u) { code &= (1u << (2u * nv0)) - 1u; nbits &= (1u << nv0) - 1u; }   // (what lies outside the line is not the read's)
         lpk[m.ld + gi] = code; lnb[m.ld + gi] = (uint16_t)nbits;
     }
