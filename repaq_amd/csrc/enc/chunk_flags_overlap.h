@@ -134,10 +134,13 @@ __device__ __forceinline__ int wave_overlap(const uint8_t* __restrict__ r1, int 
 // arithmetic on the row held in registers; the few that pass are verified in full (codes and N bits) by the same lane.
 // Forward before backward, smallest o first (src/rfqcodec.cpp:1391-1438).  The former wave-per-pair search cost ~600
 // wave-instructions per pair, the per-candidate filter (one 64-bit window per 16 candidates) with wave-wide verification ~35.
-#define OV2_CAP 256u              // bases per read held in a row
-#define OV2_CROW 68u              // code row: 64 bytes + 4 of slack for the last unaligned word; 17 dwords, so that lanes reading their own rows at one offset hit 64 different banks
-#define OV2_NROW 36u              // N-bit row: 32 bytes + 4; 9 dwords
-#define OV2_WAVE_BYTES (128u * (OV2_CROW + OV2_NROW))
+// Row geometry by the longest read a launch has to hold (template parameter CAPB: 256, or 160 for the common short-read files).  The rows are most of what a wave
+// needs of the CU - LDS decides how many waves are resident, and the search is a chain of LDS round trips that other waves hide: 160-base rows (9.2 KB per wave) let a CU hold
+// sixteen waves where 256-base rows (13.3 KB) allow twelve, and the unrolled filter stops at ten dwords instead of sixteen.
+//   code row: CAPB / 4 bytes + 4 of slack for the word behind the last; an ODD number of dwords, so that lanes reading their own rows at one offset hit different banks
+//   N-bit row: CAPB / 8 bytes + slack, odd dwords again
+#define OV2_CROW_OF(capb) ((capb) / 4u + 4u)
+#define OV2_NROW_OF(capb) ((capb) == 256u ? 36u : (capb) / 8u + 8u)
 #define OV2_FILTER 8              // bases of the head the candidate filter compares (any number <= 12, the smallest o: what passes is verified in full)
 __device__ __forceinline__ uint32_t bfe_u32(uint32_t v, uint32_t off, uint32_t wid) { return (v >> off) & ((1u << wid) - 1u); }
 // 16 bytes at base + off (any alignment); bytes outside [0, n) read as 0
@@ -169,7 +172,9 @@ __device__ __forceinline__ void ov2_pack_rc(uint32_t w, uint32_t& code, uint32_t
 // valid for the pairs of interleaved chunks - the only ones whose result is used): lengths and slots come from the quality prefix pq, the
 // "R1 holds a byte outside A/C/G/T/N" verdict from rflag.  The search then runs behind the gather, beside the position coder.
 struct OvLoose { const uint32_t* pq; const uint32_t* lpk; const uint16_t* lnb; const uint8_t* rflag; };
-template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, OvLoose Z, int16_t* __restrict__ ovraw, uint32_t n_pairs) {
+template <bool LOOSE, uint32_t CAPB = 256u> __global__ void __launch_bounds__(256) k_overlap(Text T, OvLoose Z, int16_t* __restrict__ ovraw, uint32_t n_pairs) {
+    constexpr uint32_t OV2_CAP = CAPB, OV2_CROW = OV2_CROW_OF(CAPB), OV2_NROW = OV2_NROW_OF(CAPB), OV2_WAVE_BYTES = 128u * (OV2_CROW + OV2_NROW); constexpr int OV2_ND = (int)(CAPB / 16u);
+    static_assert((OV2_CROW / 4u) % 2u == 1u && (OV2_NROW / 4u) % 2u == 1u && OV2_WAVE_BYTES % 16u == 0u, "row geometry");
     // (+4: a verification step reads 9 bytes from a byte offset inside the last row)
     __shared__ uint32_t s_rows[4 * (OV2_WAVE_BYTES / 4) + 4]; __shared__ uint32_t s_bad[4][2];
     const int l = lane_id(), w = wave_id();
@@ -299,16 +304,16 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
             // in every 2-bit group) has a zero group at i iff base i + k matches; OR over k leaves a zero group exactly at the starts that
             // pass.  3 instructions per 16 candidates and head base (funnel shift, xor, or) instead of 7 per candidate; 8 bases let a
             // random start through once in 65536 - 0.3 extra verifications per 64 pairs.
-            uint32_t W[17], Dm[16];
+            uint32_t W[OV2_ND + 1], Dm[OV2_ND];
 #pragma unroll
-            for (int d = 0; d < 17; d++) W[d] = (uint32_t)d <= nd ? ((const uint32_t*)wc)[d] : 0u;
+            for (int d = 0; d < OV2_ND + 1; d++) W[d] = (uint32_t)d <= nd ? ((const uint32_t*)wc)[d] : 0u;
 #pragma unroll
-            for (int d = 0; d < 16; d++) Dm[d] = 0u;
+            for (int d = 0; d < OV2_ND; d++) Dm[d] = 0u;
 #pragma unroll
             for (int k = 0; k < OV2_FILTER; k++) {
                 const uint32_t rep = ((head >> (2 * k)) & 3u) * 0x55555555u;
 #pragma unroll
-                for (int d = 0; d < 16; d++) if ((uint32_t)d < nd) {
+                for (int d = 0; d < OV2_ND; d++) if ((uint32_t)d < nd) {
                     const uint32_t sk = k ? (uint32_t)(((((unsigned long long)W[d + 1]) << 32) | W[d]) >> (2 * k)) : W[d];
                     Dm[d] |= sk ^ rep;
                 }
@@ -318,7 +323,7 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
             // sub-byte funnel shift.  (The whole wave used to verify ONE candidate at a time: ~27 rounds of ~45 instructions for 64 pairs.)
             const int i_lo = wl - minlen, i_hi = wl - 12;       // starts that exist for this pair (12 <= o <= minlen)
 #pragma unroll
-            for (int d = 0; d < 16; d++) {
+            for (int d = 0; d < OV2_ND; d++) {
                 if ((uint32_t)d >= nd) { Dm[d] = 0u; continue; }
                 const int a0 = i_lo - 16 * d, a1 = i_hi - 16 * d + 1;            // valid starts of this dword: [a0, a1)
                 const int e0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0), e1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
@@ -331,7 +336,7 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
             for (;;) {
                 int cand = -1;
 #pragma unroll
-                for (int d = 15; d >= 0; d--) if ((uint32_t)d < nd && cand < 0 && Dm[d]) cand = 16 * d + ((31 - __clz((int)Dm[d])) >> 1);
+                for (int d = OV2_ND - 1; d >= 0; d--) if ((uint32_t)d < nd && cand < 0 && Dm[d]) cand = 16 * d + ((31 - __clz((int)Dm[d])) >> 1);
                 if (!__any(cand >= 0)) break;                    // wave-uniform
                 const uint32_t pa = cand >= 0 ? (uint32_t)cand : 0u, o = cand >= 0 ? (uint32_t)(wl - cand) : 0u;
                 unsigned long long diff = 0;
@@ -359,10 +364,10 @@ template <bool LOOSE> __global__ void __launch_bounds__(256) k_overlap(Text T, O
                 if (cand >= 0) {
                     if (diff == 0) { done = true; ov = dir ? -(int)o : (int)o;
 #pragma unroll
-                        for (int d = 0; d < 16; d++) Dm[d] = 0u; }
+                        for (int d = 0; d < OV2_ND; d++) Dm[d] = 0u; }
                     else {
 #pragma unroll
-                        for (int d = 0; d < 16; d++) if (d == (cand >> 4)) Dm[d] &= ~(1u << (2 * (cand & 15)));
+                        for (int d = 0; d < OV2_ND; d++) if (d == (cand >> 4)) Dm[d] &= ~(1u << (2 * (cand & 15)));
                     }
                 }
             }

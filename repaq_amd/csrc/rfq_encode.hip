@@ -581,7 +581,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         if (is_pe) {
             const OvLoose Z = { (const uint32_t*)R.pq, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), (const uint8_t*)B[B_RFLAG].as<uint8_t>() };
             const uint32_t ob = std::min<uint32_t>((np + 255) / 256, 65535u * 16u);
-            hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np);
+            // (rows of 160 bases where no read is longer: sixteen resident waves per CU instead of twelve)
+            if (hs.max_len <= 160u) hipLaunchKernelGGL((k_overlap<true, 160u>), dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np);
+            else hipLaunchKernelGGL(k_overlap<true>, dim3(ob), dim3(256), 0, A, T, Z, B[B_OVRAW].as<int16_t>(), np);
             // The search and the position coder are both VALU-bound: side by side they only share the issue slots, and the latency-bound chain behind the search
             // (stored prefix -> sequence packer -> N plan -> N coder) then runs alone, with nothing to hide its round trips (round 4's timeline: coder 1.6 ms and
             // search 2.5 ms together, then 1.9 ms of that chain on an empty device).  The coder waits for the search instead and runs beside the chain
