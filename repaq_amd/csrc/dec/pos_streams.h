@@ -69,9 +69,12 @@ struct PosFront { unsigned long long v; uint32_t bt[4], fn[4], Fin; };
 #define POS_ID 0x03020100u
 __device__ __forceinline__ PosFront pos_front(const PosStep& w, const uint8_t* __restrict__ sp, uint32_t slen, uint32_t i0, int l) {
     PosFront f; f.v = pos_bytes8(w, sp, slen, i0);
+    // the four bytes' token lengths - 1 with ONE table look-up: a byte's top three bits select from (0, 0, 0, 0 | 1, 1, 0, 3)  (pos_tok_len: 0xxxxxxx 1, 10xxxxxx 2, 110xxxxx 1, 111xxxxx 4;
+    // three compare-and-select chains per byte before)
+    const uint32_t lm1 = __builtin_amdgcn_perm(0x03000101u, 0x00000000u, ((uint32_t)f.v >> 5) & 0x07070707u);
 #pragma unroll
     for (int k = 0; k < 4; k++) { const bool valid = i0 + (uint32_t)k < slen; f.bt[k] = (uint32_t)(f.v >> (8 * k)) & 0xFFu;
-            f.fn[k] = valid ? fn_of_len(pos_tok_len(f.bt[k])) : POS_ID; }
+            f.fn[k] = valid ? (0x02010000u | ((lm1 >> (8 * k)) & 0xFFu)) : POS_ID; }
     uint32_t F = fn_compose(fn_compose(fn_compose(f.fn[0], f.fn[1]), f.fn[2]), f.fn[3]);
     (void)l;
     f.Fin = wave_scan_compose(F);
