@@ -131,12 +131,13 @@ def scan_and_encode_in_ranges(make_codec, fq1, fq2, paired, chunk_bases, parts):
     return out, nc
 
 
-def overlap_search_paths(codec):
+def overlap_search_paths(codec, lengths=(150, 150, 151, 100, 256, 257, 300, 40, 13, 12, 11), seed=99):
     """k_overlap's three paths against the oracle: packed 2-bit rows (reads <= 256 bases; N inside and beside the overlap, lower-case
     bases in R2, homopolymers that pass the 12-base filter at many candidates), the byte-wise search for reads > 256 bases, and the
-    byte-wise search for an R1 that holds a character outside A/C/G/T/N in a later chunk (the header only vets chunk 0)."""
+    byte-wise search for an R1 that holds a character outside A/C/G/T/N in a later chunk (the header only vets chunk 0).
+    `lengths`: the read lengths drawn from - with none above 151 (+ 9 for the mate) the launch takes the 160-base row geometry (k_overlap<true, 160>)."""
     import random
-    rng = random.Random(99)
+    rng = random.Random(seed)
     comp = {65: 84, 84: 65, 67: 71, 71: 67, 78: 78}
 
     def rc(s):
@@ -144,7 +145,7 @@ def overlap_search_paths(codec):
 
     r1, r2 = [], []
     for i in range(900):
-        ln = rng.choice([150, 150, 151, 100, 256, 257, 300, 40, 13, 12, 11])
+        ln = rng.choice(lengths)
         kind = rng.random()
         seq = bytearray(rng.choice(b"ACGT") for _ in range(ln))
         if kind < 0.15:

@@ -302,6 +302,11 @@ def test_overlap_search_paths(codec):
     E.overlap_search_paths(codec)
 
 
+def test_overlap_search_paths_short_rows(codec):
+    """the same adversarial pairs with no read above 160 bases: the launch takes the 160-base row geometry (k_overlap<true, 160>; lengths up to the row's last base)"""
+    E.overlap_search_paths(codec, lengths=(150, 150, 151, 100, 145, 40, 13, 12, 11), seed=77)
+
+
 def test_sliced_calls_equal_one_shot():
     """Texts of >= 4 GiB per stream are encoded slice by slice, images of > ~1.6 G bases decoded range by range (32-bit offsets inside one
     pass).  RFQ_SLICE_BYTES / RFQ_SLICE_BASES shrink the slices so that the same code runs on small inputs (subprocess: read once)."""

@@ -129,3 +129,8 @@ def test_scan_then_chunk_parallel_encode_equals_one_shot(label):
 def test_overlap_search_paths(codec):
     """k_overlap: packed 2-bit rows, the > 256-base path and the odd-character path (see tests/_engine.py)."""
     E.overlap_search_paths(codec)
+
+
+def test_overlap_search_paths_short_rows(codec):
+    """the same adversarial pairs with no read above 160 bases: the launch takes the 160-base row geometry (k_overlap<true, 160>)"""
+    E.overlap_search_paths(codec, lengths=(150, 150, 151, 100, 145, 40, 13, 12, 11), seed=77)
