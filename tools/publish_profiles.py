@@ -27,8 +27,10 @@ for a, b in pairs:
         print("profiles/%s_%s_%s" % (rnd, letter, b))
 pj = os.path.join(src, "pmc_traffic.json")
 if os.path.exists(pj):
-    out = {"cfg2": {"kernels": json.load(open(pj)), "units": units,
-                    "source": "profiles/%s_%s_pmc_traffic_cfg2.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, KB units, FETCH_SIZE x2 on gfx950)" % (rnd, letter)}}
+    prev = os.path.join(dst, "%s_pmc_traffic.json" % rnd)
+    out = json.load(open(prev)) if os.path.exists(prev) else {}          # (a kernels-only set re-measures configs[2] alone: the other workloads' entries stay)
+    out["cfg2"] = {"kernels": json.load(open(pj)), "units": units,
+                    "source": "profiles/%s_%s_pmc_traffic_cfg2.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, KB units, FETCH_SIZE x2 on gfx950)" % (rnd, letter)}
     for wl, wunits in (("cfg1", 2800000), ("cfg4", 1400000)):            # (the secondary workloads' own PMC passes, at bench.py's sizes)
         pw = os.path.join(src, "pmc_traffic_%s.json" % wl)
         if os.path.exists(pw):
