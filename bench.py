@@ -176,7 +176,7 @@ class Workload:
         self.t1 = torch.from_numpy(self.a1).to(dev); self.t2 = torch.from_numpy(self.a2).to(dev) if self.paired else None
         self.o1 = torch.empty(self.n1 + 64, dtype=torch.uint8, device=dev); self.o2 = torch.empty(self.n2 + 64, dtype=torch.uint8, device=dev) if self.paired else None
         self.codec, self.mode, self.cb, self.do_decode = codec, (PE_TWO_FILES if self.paired else SE), max(100, chunk_kb) * 1000, decode
-        self.stage = {}; self.enc_s = 0.0; self.dec_s = 0.0; self.rfq_len = 0; self.chunks = 0; self.r = None
+        self.stage = {}; self.enc_s = 0.0; self.dec_s = 0.0; self.rfq_len = 0; self.chunks = 0; self.r = None; self.step_s = []
 
     def step(self, collect):
         c = self.codec
@@ -190,18 +190,18 @@ class Workload:
         self.r, self.rfq_len, self.chunks = r, r.rfq_len, r.n_chunks
         t2 = t1
         if self.do_decode:
-            # the host that has just encoded the image holds its chunk offsets and passes them on (rfq_decode_args.h_chunk_off): the
-            # .rfq format has no index, and walking the chain is a dependent load per chunk; every extent is still verified on the device
+            # the decode gets the image and nothing else, like a .rfq file gives it (the format has no chunk index, src/rfqchunk.cpp:161-228): the library finds
+            # the chunk starts itself (guess and verify: k_dec_gw_find / walk / stitch + the verifying parse).  A host that has just encoded the image could pass
+            # its chunk offsets on (rfq_decode_args.h_chunk_off): that rate is reported beside this one as decode_MBps_indexed (value = what a file allows)
             d = c.decode(r.d_rfq, r.rfq_len, split_pe=self.paired, d_out1=self.o1.data_ptr(), cap1=self.n1 + 64,
-                         d_out2=self.o2.data_ptr() if self.paired else None, cap2=(self.n2 + 64) if self.paired else 0,
-                         chunk_off=r.h_chunk_off, n_chunks=r.n_chunks)
+                         d_out2=self.o2.data_ptr() if self.paired else None, cap2=(self.n2 + 64) if self.paired else 0)
             t2 = time.perf_counter()
             self.d = d
             if collect:
                 for name, ms in c.timings():
                     self.stage["dec:" + name] = self.stage.get("dec:" + name, 0.0) + ms
         if collect:
-            self.enc_s += t1 - t0; self.dec_s += t2 - t1
+            self.enc_s += t1 - t0; self.dec_s += t2 - t1; self.step_s.append(t2 - t0)
         return r
 
     def check(self):
@@ -245,11 +245,13 @@ class Workload:
         sync(); barrier()
         return time.perf_counter() - t0
 
-    def decode_walk(self, steps, sync):
-        """Decode throughput WITHOUT the encoder's chunk index (a .rfq file has none, src/rfqchunk.cpp:161-228): the library finds the chunk
-        starts itself (guess and verify: k_dec_gw_find / walk / stitch + the verifying parse).  Returns (MB/s, walk stage ms)."""
+    def decode_indexed(self, steps, sync):
+        """Decode throughput WITH the encoder's chunk index handed over (rfq_decode_args.h_chunk_off: what a host that has just encoded the image, or walked the
+        chunk headers while the image was on its way to the GPU, can pass; every extent is still verified on the device).  The headline decode runs without it.
+        Returns (MB/s, walk stage ms)."""
         c = self.codec; r = self.r
-        kw = dict(split_pe=self.paired, d_out1=self.o1.data_ptr(), cap1=self.n1 + 64, d_out2=self.o2.data_ptr() if self.paired else None, cap2=(self.n2 + 64) if self.paired else 0)
+        kw = dict(split_pe=self.paired, d_out1=self.o1.data_ptr(), cap1=self.n1 + 64, d_out2=self.o2.data_ptr() if self.paired else None, cap2=(self.n2 + 64) if self.paired else 0,
+                  chunk_off=r.h_chunk_off, n_chunks=r.n_chunks)
         c.decode(r.d_rfq, r.rfq_len, **kw); sync()
         walk = 0.0; t0 = time.perf_counter()
         for _ in range(steps):
@@ -356,6 +358,52 @@ def pmc_traffic_live(workload, chunk_kb, units, seed, timeout_s=300):
         nf, vf = got["FETCH_SIZE"].get(k, (0, 0.0)); nw, vw = got["WRITE_SIZE"].get(k, (0, 0.0))
         ker[k] = {"fetch_bytes": 2.0 * vf * 1024 / passes, "write_bytes": vw * 1024 / passes, "launches_per_step": max(nf, nw) / passes}
     return ker, "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of this script, --kernel-trace only, one step each; KB units, FETCH_SIZE x 2 on gfx950)"
+
+
+def blocks_of(step_s, bytes_per_step, nblocks=4):
+    """The timed steps cut into `nblocks` consecutive blocks: each block's rate, their median and spread (one number per run hides the
+    box's clock behaviour; `value` stays the contract's K steps in one bracket)."""
+    if len(step_s) < nblocks:
+        nblocks = max(1, len(step_s))
+    if not step_s:
+        return None
+    per = len(step_s) // nblocks
+    rates = [round(bytes_per_step * per / sum(step_s[i * per:(i + 1) * per]) / 1e6, 1) for i in range(nblocks)]
+    srt = sorted(rates); med = srt[len(srt) // 2] if len(srt) % 2 else round((srt[len(srt) // 2 - 1] + srt[len(srt) // 2]) / 2, 1)
+    return {"steps_per_block": per, "MBps": rates, "median_MBps": med, "min_MBps": srt[0], "max_MBps": srt[-1]}
+
+
+def smi_clocks(local):
+    """Current shader / memory clock of the device as the SMI reports them right after the timed steps (sysfs first, rocm-smi as a fallback); None where
+    neither can be read (an unprivileged container)."""
+    import glob
+    import re
+    out = {}
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        for key, f in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+            for path in glob.glob("/sys/bus/pci/devices/%s/%s" % (bdf, f)):
+                cur = [l for l in open(path).read().splitlines() if l.strip().endswith("*")]
+                if cur:
+                    out[key + "_MHz"] = int(re.search(r"(\d+)\s*Mhz", cur[0], re.I).group(1))
+    except Exception:                                    # noqa: BLE001
+        pass
+    if not out:
+        try:
+            r = subprocess.run(["rocm-smi", "-d", str(local), "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20, text=True)
+            j = json.loads(r.stdout)
+            for card in j.values():
+                for k, v in card.items():
+                    m = re.search(r"\((\d+)Mhz\)", str(v))
+                    if m and "sclk" in k.lower():
+                        out["sclk_MHz"] = int(m.group(1))
+                    if m and "mclk" in k.lower():
+                        out["mclk_MHz"] = int(m.group(1))
+        except Exception:                                # noqa: BLE001
+            pass
+    return out or None
 
 
 def side_of(kernel):
@@ -806,7 +854,7 @@ def main():
     head, stage, enc_ms, dec_ms = line_of(w, args.steps, dt, w.n, parity)
     if args.pmc_child:
         print(json.dumps({"pmc_child": True, "value": head["value_MBps"]})); codec.close(); return
-    walk = w.decode_walk(args.steps, sync) if w.do_decode else None
+    indexed = w.decode_indexed(args.steps, sync) if w.do_decode else None
     live, live_note = (None, "--no-pmc") if args.no_pmc else pmc_traffic_live(args.workload, args.chunk_kb, args.units, args.seed)
     out = {
         "metric": "raw FASTQ MB/s encode+decode" if w.do_decode else "raw FASTQ MB/s encode",
@@ -815,9 +863,11 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": w.label, "chunks_per_gpu": w.chunks, "rfq_over_fastq": head["rfq_over_fastq"],
                    "encode_MBps_per_gpu": head["encode_MBps"], "decode_MBps_per_gpu": head["decode_MBps"],
-                   # the headline decode is handed the encoder's chunk offsets (a round trip holds them); the same decode finding the chunks itself:
-                   "decode_MBps_walk": walk[0] if walk else None, "walk_ms": walk[1] if walk else None,
-                   "value_MBps_walk": round(2 * w.n / (w.n / (head["encode_MBps"] * 1e6) + w.n / (walk[0] * 1e6)) / 1e6, 1) if walk and head["encode_MBps"] else None,
+                   # the headline decode finds the chunk starts itself (a .rfq file has no index); the same decode handed the encoder's chunk offsets:
+                   "decode_MBps_indexed": indexed[0] if indexed else None, "walk_ms_indexed": indexed[1] if indexed else None,
+                   "value_MBps_indexed": round(2 * w.n / (w.n / (head["encode_MBps"] * 1e6) + w.n / (indexed[0] * 1e6)) / 1e6, 1) if indexed and head["encode_MBps"] else None,
+                   # the K timed steps again as blocks (every step ends with the host holding its result, so a step's wall time is its own): median block rate, spread, device clocks
+                   "blocks": blocks_of(w.step_s, w.n * (2 if w.do_decode else 1)), "clocks": smi_clocks(local),
                    "parity": parity, "stage_ms": head["stage_ms"]},
         "roofline": roofline_of(w, stage, enc_ms, dec_ms, args.workload, live, live_note),
     }

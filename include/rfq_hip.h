@@ -47,20 +47,23 @@ extern "C" {
 
 typedef struct rfq_ctx rfq_ctx;
 
+/* the library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table */
+#define RFQ_API __attribute__((visibility("default")))
+
 /* RfqCodec::RfqCodec / ~RfqCodec (src/rfqcodec.cpp:9-14).  device_id: HIP ordinal. */
-int         rfq_create(rfq_ctx** out, int device_id);
-void        rfq_destroy(rfq_ctx* ctx);
-const char* rfq_last_error(const rfq_ctx* ctx);
+RFQ_API int         rfq_create(rfq_ctx** out, int device_id);
+RFQ_API void        rfq_destroy(rfq_ctx* ctx);
+RFQ_API const char* rfq_last_error(const rfq_ctx* ctx);
 /* all work of this context is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream) */
-int         rfq_set_stream(rfq_ctx* ctx, void* hip_stream);
+RFQ_API int         rfq_set_stream(rfq_ctx* ctx, void* hip_stream);
 
 /* RfqCodec::setHeader (src/rfqcodec.cpp:16-18) from the on-disk header bytes (RfqHeader::read, src/rfqheader.cpp:19-43).
  * mSupportInterleaved is not stored on disk; it is re-derived from BIT_ENCODE_PE_BY_OVERLAP, which makeHeader sets
  * exactly when it is true (src/rfqcodec.cpp:117-122). */
-int rfq_set_header(rfq_ctx* ctx, const uint8_t* h_header, size_t header_len);
+RFQ_API int rfq_set_header(rfq_ctx* ctx, const uint8_t* h_header, size_t header_len);
 /* the header currently set / made: RfqHeader::write (src/rfqheader.cpp:84-97) */
-int rfq_get_header(rfq_ctx* ctx, uint8_t* h_out /* >= RFQ_HEADER_MAX */, size_t* header_len);
-void rfq_clear_header(rfq_ctx* ctx);
+RFQ_API int rfq_get_header(rfq_ctx* ctx, uint8_t* h_out /* >= RFQ_HEADER_MAX */, size_t* header_len);
+RFQ_API void rfq_clear_header(rfq_ctx* ctx);
 
 typedef struct {
     const uint8_t* d_fq1; size_t n1;      /* stream 1 (R1, or the only / interleaved stream)                          */
@@ -105,7 +108,7 @@ typedef struct {
 /* RfqCodec::makeHeader (first call without a header; src/rfqcodec.cpp:20-145) + RfqCodec::encodeChunk + RfqChunk::write
  * for every chunk of the batch (src/rfqcodec.cpp:147-586, src/rfqchunk.cpp:230-311), with the chunk cut rule of
  * Repaq::compress (src/repaq.cpp:546-553): cut after the read that brings the running base count to >= chunk_bases. */
-int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_encode_result* res);
+RFQ_API int rfq_encode_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_encode_result* res);
 
 /* The plan pass of a chunk-parallel encode: line index, read lengths and the cut rule of Repaq::compress
  * (src/repaq.cpp:546-553) only — no header, no coding.  h_end1/2[c] = offset in the caller's stream(s) just past the last
@@ -123,7 +126,7 @@ typedef struct {
     uint32_t unit_bases;                  /* bases of every cut unit (a read, or a pair) when they are all the same, else 0: with equal units the
                                              chunk cuts of a share follow from the number of units in front of it (repaq_amd/dist.py)      */
 } rfq_scan_result;
-int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_scan_result* res);
+RFQ_API int rfq_scan_batch(rfq_ctx* ctx, const rfq_encode_args* args, rfq_scan_result* res);
 
 typedef struct {
     const uint8_t* d_rfq; size_t n;       /* .rfq bytes in HBM                                                          */
@@ -158,57 +161,57 @@ typedef struct {
 /* RfqChunk::read + RfqCodec::decodeChunk + Read::toString for every chunk of the image
  * (src/rfqchunk.cpp:161-228, src/rfqcodec.cpp:826-1260, src/read.cpp:170-172).  Images whose header lacks
  * BIT_ENCODE_QUAL_BY_COL (legacy run-length quality coding, src/rfqcodec.cpp:919-955; v0.5.1 never writes one) decode too. */
-int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* args, rfq_decode_result* res);
+RFQ_API int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* args, rfq_decode_result* res);
 
 /* stage timings of the last batch call, in milliseconds, measured with HIP events on the context's stream.
  * names[i] is a static string; returns the number of stages written (<= cap). */
-int rfq_last_timings(const rfq_ctx* ctx, const char** names, float* ms, int cap);
+RFQ_API int rfq_last_timings(const rfq_ctx* ctx, const char** names, float* ms, int cap);
 
 /* device-memory helpers for hosts that do not bring their own allocator (the C++ driver, ctypes tests): thin wrappers
  * over hipMalloc / hipFree / hipMemcpy on the context's device.  Buffers from rfq_dev_malloc are 256-byte aligned. */
-int rfq_dev_malloc(rfq_ctx* ctx, void** d_ptr, size_t n);
-int rfq_dev_free(rfq_ctx* ctx, void* d_ptr);
-int rfq_copy_h2d(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n);
+RFQ_API int rfq_dev_malloc(rfq_ctx* ctx, void** d_ptr, size_t n);
+RFQ_API int rfq_dev_free(rfq_ctx* ctx, void* d_ptr);
+RFQ_API int rfq_copy_h2d(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n);
 /* The same without waiting: the copy is queued on the context's copy stream (h_src page-locked: rfq_host_alloc) and runs beside whatever the
  * context's own stream does.  *ticket (optional) identifies it: rfq_copy_done says whether it has finished (the host buffer may be reused),
  * rfq_copy_sync waits for everything queued so far - call it before handing the destination to rfq_encode_batch / rfq_decode_batch. */
-int rfq_copy_h2d_async(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n, uint64_t* ticket);
-int rfq_copy_done(rfq_ctx* ctx, uint64_t ticket);      /* 1: finished, 0: still running, < 0: error */
-int rfq_copy_sync(rfq_ctx* ctx);
-int rfq_copy_d2h(rfq_ctx* ctx, void* h_dst, const void* d_src, size_t n);
-int rfq_copy_d2d(rfq_ctx* ctx, void* d_dst, const void* d_src, size_t n);
+RFQ_API int rfq_copy_h2d_async(rfq_ctx* ctx, void* d_dst, const void* h_src, size_t n, uint64_t* ticket);
+RFQ_API int rfq_copy_done(rfq_ctx* ctx, uint64_t ticket);      /* 1: finished, 0: still running, < 0: error */
+RFQ_API int rfq_copy_sync(rfq_ctx* ctx);
+RFQ_API int rfq_copy_d2h(rfq_ctx* ctx, void* h_dst, const void* d_src, size_t n);
+RFQ_API int rfq_copy_d2d(rfq_ctx* ctx, void* d_dst, const void* d_src, size_t n);
 /* d_dst on ctx's GPU <- d_src on src_ctx's GPU (hipMemcpyPeerAsync): how a worker of a multi-GPU host queue pulls its byte range */
-int rfq_copy_peer(rfq_ctx* ctx, void* d_dst, const rfq_ctx* src_ctx, const void* d_src, size_t n);
+RFQ_API int rfq_copy_peer(rfq_ctx* ctx, void* d_dst, const rfq_ctx* src_ctx, const void* d_src, size_t n);
 /* page-locked host buffers (hipHostMalloc): H2D / D2H copies from them run at full PCIe rate */
-int rfq_host_alloc(rfq_ctx* ctx, void** h_ptr, size_t n);
-int rfq_host_free(rfq_ctx* ctx, void* h_ptr);
+RFQ_API int rfq_host_alloc(rfq_ctx* ctx, void** h_ptr, size_t n);
+RFQ_API int rfq_host_free(rfq_ctx* ctx, void* h_ptr);
 /* the same for memory the caller owns (hipHostRegister / hipHostUnregister): buffers a host filled before the context existed */
-int rfq_host_register(rfq_ctx* ctx, void* h_ptr, size_t n);
-int rfq_host_unregister(rfq_ctx* ctx, void* h_ptr);
+RFQ_API int rfq_host_register(rfq_ctx* ctx, void* h_ptr, size_t n);
+RFQ_API int rfq_host_unregister(rfq_ctx* ctx, void* h_ptr);
 
 /* --compare on the device (Repaq::compare / comparePE, src/repaq.cpp:36-233): the first offset at which two device texts differ,
  * *first_diff = n when they are identical.  A decoded batch equal byte for byte to the same span of the FASTQ text passes the
  * reference's four per-read tests (name, sequence, strand, quality; :85-108) for every read in it; the host cuts records only in
  * a batch that differs, to word the reference's message. */
-int rfq_compare_bytes(rfq_ctx* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first_diff);
+RFQ_API int rfq_compare_bytes(rfq_ctx* ctx, const void* d_a, const void* d_b, size_t n, uint64_t* first_diff);
 
 /* Test / diagnostic switches of one context: name = the RFQ_* environment variable of the same meaning (RFQ_GATHER=old, RFQ_QUAL=bytes|masks, RFQ_CODER=list|mask, RFQ_INDEX=2pass,
  * RFQ_IDX_TILES, RFQ_STREAMS=1, RFQ_SLICE_BYTES, RFQ_SLICE_BASES, RFQ_WALK=exact, RFQ_GW_SHIFT, RFQ_MATERIALISE=1, RFQ_TRACE, RFQ_G2_PAD, RFQ_SP_PAD; see RfqOpts in
  * repaq_amd/csrc/rfq_ctx.h), value NULL or "" = default.  Every switch selects another formulation of the same, bit-identical result - they exist so that
  * the tests can pin each one (tests/test_gpu_formulations.py forces every one of them on the GPU).  Unknown names and values that are not of the switch's
  * form or range are RFQ_E_ARG.  The environment is read once, by rfq_create; the batch calls never call getenv. */
-int rfq_set_option(rfq_ctx* ctx, const char* name, const char* value);
+RFQ_API int rfq_set_option(rfq_ctx* ctx, const char* name, const char* value);
 /* the switch's current value in the form rfq_set_option takes ("" = default), so that a caller can put back what it found */
-int rfq_get_option(const rfq_ctx* ctx, const char* name, char* out, size_t cap);
+RFQ_API int rfq_get_option(const rfq_ctx* ctx, const char* name, char* out, size_t cap);
 /* the switches' names: i = 0, 1, ... until NULL */
-const char* rfq_option_name(int i);
+RFQ_API const char* rfq_option_name(int i);
 
 /* self test of the wave-level scans / reductions every kernel is built on (DPP row shifts and broadcasts on gfx950): h_in holds 64 * n_waves lane
  * values, h_out receives 12 u64 per lane (see k_selftest_wave in rfq_api.hip); tests/test_wave_primitives.py checks them against a serial reference. */
-int rfq_selftest_wave(rfq_ctx* ctx, const uint64_t* h_in, uint32_t n_waves, uint64_t* h_out);
+RFQ_API int rfq_selftest_wave(rfq_ctx* ctx, const uint64_t* h_in, uint32_t n_waves, uint64_t* h_out);
 
 /* library / build info: "rfq_hip <version> gfx950" (or "... simt-emulation" for the test build) */
-const char* rfq_version(void);
+RFQ_API const char* rfq_version(void);
 
 #ifdef __cplusplus
 }

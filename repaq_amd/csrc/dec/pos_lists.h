@@ -74,6 +74,8 @@ __device__ __forceinline__ void pos_lane_adv_cnt4(const PosFront& f, uint32_t sl
 #pragma unroll
     for (int s = 0; s < 4; s++) { const bool on = (uint32_t)s < nv; adv[s] = on ? ca[s] : 0; cnt[s] = on ? cc[s] : 0; }
 }
+#define POS_ADV_MAX 0x3FFFFFFFull   // advances are summed saturating at this value (two saturated terms still fit an int)
+__device__ __forceinline__ int pos_adv_sat(int v) { return v > (int)POS_ADV_MAX ? (int)POS_ADV_MAX : v; }
 // grid (ceil(maxseg / 4), streams, n_chunks) x 256 threads: one wave per segment; index arrays are [chunk][nstr][maxseg]; segA[8 * idx + s] =
 // positions advanced, segA[8 * idx + 4 + s] = positions emitted for entry state s
 __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
@@ -99,8 +101,12 @@ __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __
         for (int e = 0; e < 4; e++) { const uint32_t t_ = fn_apply(G, e); a[e] += sel4(la, t_); n[e] += sel4(lc, t_); }
         Fcum = fn_compose(Fcum, wave_last(f.Fin));
     }
+    // (a lane's four steps advance less than 4 x 2^30 positions: no wrap as 32 bits; the wave's sum is taken in 64 bits and SATURATED at POS_ADV_MAX - a corrupt
+    // stream advances up to 2^29 per token, a wrapped sum went negative, slipped through k_dec_pos_link2's "beyond the chunk" test and aliased 16-bit list entries:
+    // ADVICE r5.  Saturated sums stay sums for every position a chunk the fused path takes can hold - rfq_decode.hip sends larger chunks to the expanded path.)
 #pragma unroll
-    for (int e = 0; e < 4; e++) { a[e] = wave_sum(a[e]); n[e] = wave_sum(n[e]); }
+    for (int e = 0; e < 4; e++) { const unsigned long long w64 = wave_sum<unsigned long long>((unsigned long long)(uint32_t)a[e]); a[e] = (int)(w64 > POS_ADV_MAX ? POS_ADV_MAX : w64);
+            n[e] = wave_sum(n[e]); }
     if (l == 0) { const size_t idx = ((size_t)c * nstr + jj) * maxseg + g; segF[idx] = (uint8_t)fn_pack8(Fcum);
 #pragma unroll
                   for (int e = 0; e < 4; e++) { segA[8 * idx + e] = a[e]; segA[8 * idx + 4 + e] = n[e]; } }
@@ -111,7 +117,7 @@ struct PosLink { uint32_t F; int a[4], n[4]; };
 __device__ __forceinline__ PosLink poslink_then(const PosLink& x, const PosLink& y) {   // x first, then y
     PosLink r; r.F = fn_compose(x.F, y.F);
 #pragma unroll
-    for (int s = 0; s < 4; s++) { const uint32_t t = fn_apply(x.F, s); r.a[s] = x.a[s] + sel4(y.a, t); r.n[s] = x.n[s] + sel4(y.n, t); }
+    for (int s = 0; s < 4; s++) { const uint32_t t = fn_apply(x.F, s); r.a[s] = pos_adv_sat(x.a[s] + sel4(y.a, t)); r.n[s] = x.n[s] + sel4(y.n, t); }
     return r;
 }
 __device__ __forceinline__ PosLink poslink_shfl_up(const PosLink& v, unsigned dd) {
@@ -142,11 +148,11 @@ __global__ void k_dec_pos_link2(const uint8_t* __restrict__ segF, const int* __r
         if (l == 0) { ex.F = POS_ID;
 #pragma unroll
                       for (int s = 0; s < 4; s++) { ex.a[s] = 0; ex.n[s] = 0; } }
-        if (g < n) { segS[idx] = (uint8_t)(fn_apply(ex.F, cs)); segP[idx] = cp + sel4(ex.a, cs); segK[idx] = ck + (uint32_t)sel4(ex.n, cs); }
+        if (g < n) { segS[idx] = (uint8_t)(fn_apply(ex.F, cs)); segP[idx] = pos_adv_sat(cp + sel4(ex.a, cs)); segK[idx] = ck + (uint32_t)sel4(ex.n, cs); }
         const uint32_t Fl = wave_last(inc.F); int al[4], nl[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) { al[s] = wave_last(inc.a[s]); nl[s] = wave_last(inc.n[s]); }
-        cp += sel4(al, cs); ck += (uint32_t)sel4(nl, cs); cs = fn_apply(Fl, cs);
+        cp = pos_adv_sat(cp + sel4(al, cs)); ck += (uint32_t)sel4(nl, cs); cs = fn_apply(Fl, cs);
     }
     if (l == 0) {
         nent[t] = ck;

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_dec_readtab2(const uint8_t* __restrict_
         carry = carry + tot; qcarry += qtot;
     }
     if (threadIdx.x == 0) { pvl[fp + d.reads] = carry; pql[fp + d.reads] = qcarry; }
-    if (__any(bad != 0) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT);
+    if (__any(bad != 0) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT_OV);
 }
 // aligned bases of each chunk inside the concatenated quality / stored-sequence buffers
 __global__ void k_dec_bases(const DChunk* __restrict__ CH, DReadTab R, uint64_t* __restrict__ qbase, uint64_t* __restrict__ sbase, uint32_t n_chunks) {

@@ -67,7 +67,10 @@ __global__ void __launch_bounds__(256) k_dec_textlen2(const uint8_t* __restrict_
                                                       uint2* __restrict__ tpl, U4* __restrict__ ctext, DecStatus* st) {
     __shared__ unsigned long long s_mid[256 * 4];                     // a 32-byte row per thread
     const uint32_t c = blockIdx.x; const DChunk d = CH[c]; const uint8_t* cp = img + d.off; const uint32_t hf = D->flags;
-    unsigned long long carry = 0;                                    // (out1 bytes | out2 bytes << 32: a chunk's text is far below 4 GiB per output)
+    // (out1 bytes | out2 bytes << 32 for the block scan: a STEP's 256 reads are far below 4 GiB; the chunk's running totals are kept as two 64-bit sums - a chunk of
+    // 4 GiB of text or more in one output (a large -k, a crafted image) must reach the host as what it is: it refuses the range, RFQ_RANGE_TOO_BIG; packed, the out1
+    // half carried into the out2 half and the host saw small totals - ADVICE r5)
+    unsigned long long carry = 0, sum1 = 0, sum2 = 0;
     for (uint32_t r0 = 0; r0 < d.reads; r0 += blockDim.x) {           // block-uniform
         const uint32_t r = r0 + threadIdx.x; unsigned long long mine = 0; uint32_t k = 0; bool second = false;
         if (r < d.reads) {
@@ -87,13 +90,14 @@ __global__ void __launch_bounds__(256) k_dec_textlen2(const uint8_t* __restrict_
         }
         unsigned long long tot; const unsigned long long ex = carry + block_excl_sum<unsigned long long>(mine, &tot);
         if (r < d.reads) tpl[(size_t)d.rbase + r] = make_uint2(second ? (uint32_t)(ex >> 32) : (uint32_t)ex, k);
-        carry += tot;
+        sum1 += tot & 0xFFFFFFFFull; sum2 += tot >> 32;
+        carry = (sum1 & 0xFFFFFFFFull) | (sum2 << 32);                   // (the two halves wrap on their own; the totals below tell the host when they did)
     }
     if (threadIdx.x == 0) {
-        U4 t; t.a = (uint32_t)carry; t.b = (uint32_t)(carry >> 32); t.c = 0; t.d = 0; ctext[c] = t;
+        U4 t; t.a = (uint32_t)sum1; t.b = (uint32_t)sum2; t.c = 0; t.d = 0; ctext[c] = t;
         // 64-bit totals of the range (the text offsets are 32-bit: the host refuses a range that would wrap them); spread over 64 slots
         const uint32_t slot = (c * 7u) & 63u;
-        if (t.a) atomicAdd((unsigned long long*)&st->text_slots[0][slot], (unsigned long long)t.a);
-        if (t.b) atomicAdd((unsigned long long*)&st->text_slots[1][slot], (unsigned long long)t.b);
+        if (sum1) atomicAdd((unsigned long long*)&st->text_slots[0][slot], sum1);
+        if (sum2) atomicAdd((unsigned long long*)&st->text_slots[1][slot], sum2);
     }
 }

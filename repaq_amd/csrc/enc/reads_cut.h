@@ -211,7 +211,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
 }
 // carry: bases the chunk that is open at unit 0 has taken from the text in front of this batch (plan pass of a share, rfq_encode_args.carry_bases)
 __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, uint32_t carry, int final_batch,
-                            const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st) {
+                            const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st, const uint32_t* __restrict__ uni) {
     const int l = lane_id();
     // shortest / longest unit: every thread of the workgroup (1024: a single wave walked 44 k block entries in 158 us), then wave 0 goes on alone
     __shared__ uint32_t s_mn[16], s_mx[16], s_rc[16], s_ml[16];
@@ -240,6 +240,9 @@ __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, ui
         max_units = head ? K0 : 0u; if (full > 1u && K > max_units) max_units = K; if (rem && final_batch && rem > max_units) max_units = rem;
                 max_bases = (uint64_t)max_units * L;
     } else {
+        // (the unit prefix P exists only when the scans ran: k_lens_uniform's "every read has L bases" lets them return at once, and implies the closed branch
+        // above - the coupling is stated here instead of being left to two predicates that happen to agree)
+        if (uni[0]) { if (l == 0) atomicOr(&st->err, (uint32_t)DE_INTERNAL); return; }
         uint32_t guess = 0;
         while (start < n_units) {
             const uint64_t target = prevP + chunk_bases - (c == 0 ? carry : 0u);

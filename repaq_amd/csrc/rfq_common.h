@@ -47,6 +47,8 @@
 #define DE_CORRUPT         (1u << 8)  // decode: inconsistent chunk image
 #define DE_E3_RETRY        (1u << 29) // decode, k_dec_emit3: a tile's per-read name pieces do not fit its LDS tiles: the range is emitted again by the expanded path (k_dec_emit)
 #define DE_INDEX_RETRY     (1u << 30) // encode, one-pass line index: more lines than the table sized in advance holds (or a wait that did not end): index in two passes
+#define DE_CORRUPT_OV      (1u << 10) // decode, fused path: an overlap byte that exceeds a mate's length (k_dec_readtab2; "corrupt overlap buffer" - DE_CORRUPT is the quality / stream verdict there)
+#define DE_INTERNAL        (1u << 11) // encode: two kernels disagree about an invariant they share (k_partition: reads of one length whose units are not) - a bug, reported as one
 #define DE_TAIL_BLANK      (1u << 9)  // an empty line in the \n-only text right behind the encoded records: blank or empty is for the normaliser to say
 
 // Device-resident file header + derived tables (RfqHeader, src/rfqheader.h:44-108)

@@ -67,7 +67,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         if (need1 > ET_N1CAP) { if (e3k == 6 && need1 <= E3_N1BIG) n1big = true; else e3k = 0; }
     }
     const bool e3_ok = e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed);
-    const bool fused = !force_expanded && !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u && e3_ok;
+    // (chunks of 2^30 bases and more: the list chain's saturating position sums - POS_ADV_MAX, dec/pos_lists.h - would no longer be exact)
+    const bool fused = !force_expanded && !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u && e3_ok && g.max_bases < (1u << 30) - 65536u;
     uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S;
             const uint32_t f_nstr = HH.n_normal + 1;
     // (an early return must not leave the chain running over buffers the next call reuses)
@@ -227,7 +228,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     HIPCHK(ctx, ctx->fetch(&tt, fused ? B[DB_TBASE].as<U4>() + n_chunks : R.tp + n_reads, 16, S));
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
     HIPCHK(ctx, ctx->fetch_sync(S));
-    if (fused && (hs.err & DE_CORRUPT)) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");   // (k_dec_readtab2's verdict: nothing reads the status in between)
+    if (hs.err & DE_CORRUPT_OV) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt overlap buffer");   // (k_dec_readtab2's verdict, a bit of its own: nothing reads the status in between, and the list chain's DE_CORRUPT means the quality buffer - the same two messages as on the expanded path)
     // a stream codes positions far beyond its chunk's length table (k_dec_pos_link2): 16-bit list entries would alias - the range goes to the expanded path
     if (fused && (hs.err & DE_E3_RETRY)) return decode_range(ctx, a, g, out1, ocap1, out2, ocap2, p1, p2, n1, n2, nbases, true);
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_FORMAT, "corrupt quality buffer");

@@ -355,7 +355,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (a->carry_bases && !scan_only) return rfq_fail(ctx, RFQ_E_ARG, "carry_bases is for the plan pass (rfq_scan_batch): an encode starts on a chunk boundary");
     if (a->carry_bases >= a->chunk_bases) return rfq_fail(ctx, RFQ_E_ARG, "carry_bases must be < chunk_bases");
     hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->carry_bases, fin ? 1 : 0,
-                       (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst);
+                       (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst, (const uint32_t*)uni);
     KCHK(ctx, "k_partition");
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
     HIPCHK(ctx, ctx->fetch_sync(S));
@@ -367,6 +367,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         ovl_guard.sync();                                                   // (the repeat rebuilds nothing, but starts its own search over the same buffers)
         return encode_impl(ctx, a, res, nm, hs.first_empty / T.upr, true, scan_only, skip);
     }
+    if (hs.err & DE_INTERNAL) return rfq_fail(ctx, RFQ_E_HIP, "internal: reads of one length, units of several (k_lens_uniform / k_partition disagree)");
     if (hs.err & DE_QUAL_SHORT) return rfq_fail(ctx, RFQ_E_UNPINNED, "a quality line is shorter than its sequence line (the reference reads past the string: undefined)");
     const uint32_t n_chunks = hs.n_chunks;
     if (n_chunks > cap_chunks) return rfq_fail(ctx, RFQ_E_HIP, "internal: chunk table overflow (%u > %u)", n_chunks, cap_chunks);

@@ -35,6 +35,15 @@ def test_library_exports_every_declared_symbol(product_lib):
         assert hasattr(product_lib, sym), "librfq_hip.so does not export %s" % sym
 
 
+def test_library_exports_nothing_else(product_lib):
+    """-fvisibility=hidden + RFQ_API: the dynamic symbol table holds the C entry points and nothing of the implementation
+    (no __device_stub__ kernels, no internal C++ helpers)"""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", E.PRODUCT_LIB], text=True)
+    syms = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert syms == _declared_symbols(), sorted(set(syms) ^ set(_declared_symbols()))
+
+
 def test_version_string_is_gfx950(product_lib):
     product_lib.rfq_version.restype = C.c_char_p
     assert b"gfx950" in product_lib.rfq_version()

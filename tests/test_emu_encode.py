@@ -315,3 +315,14 @@ def test_sliced_calls_equal_one_shot():
     env = dict(os.environ, RFQ_SLICE_BYTES="150000", RFQ_SLICE_BASES="60000", PYTHONPATH=os.pathsep.join([E.ROOT, os.path.join(E.ROOT, "tests"), os.path.join(E.ROOT, "tests", "golden")]))
     r = subprocess.run([sys.executable, os.path.join(E.ROOT, "tests", "_slice_probe.py"), E.build_emu()], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "SLICES_OK 7" in r.stdout, r.stdout + r.stderr
+
+
+import _shapes as SH
+
+_SHAPES = SH.cases(260, 9000)
+
+
+@pytest.mark.parametrize("label,fq1,fq2,paired,cb", _SHAPES, ids=[c[0] for c in _SHAPES])
+def test_uniform_and_almost_uniform_read_lengths(codec, label, fq1, fq2, paired, cb):
+    """closed-form prefixes / cuts where every read has one length, the scans everywhere else - and nothing in between (tests/_shapes.py)"""
+    assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)

@@ -134,3 +134,18 @@ def test_overlap_search_paths(codec):
 def test_overlap_search_paths_short_rows(codec):
     """the same adversarial pairs with no read above 160 bases: the launch takes the 160-base row geometry (k_overlap<true, 160>)"""
     E.overlap_search_paths(codec, lengths=(150, 150, 151, 100, 145, 40, 13, 12, 11), seed=77)
+
+
+import _shapes as SH
+
+_SHAPES = SH.cases(9000, 100000)
+
+
+@pytest.mark.parametrize("label,fq1,fq2,paired,cb", _SHAPES, ids=[c[0] for c in _SHAPES])
+def test_uniform_and_almost_uniform_read_lengths(codec, label, fq1, fq2, paired, cb):
+    """closed-form prefixes / cuts where every read has one length, the scans everywhere else - and nothing in between (tests/_shapes.py; ADVICE r5);
+    -k 100 is a chunk size the reference binary takes: where it travelled, the oracle's image is checked against its own first"""
+    want = O.encode_file(fq1, fq2, paired, cb)
+    if O.have_ref():
+        assert O.ref_encode(fq1, fq2, paired, k=cb // 1000) == want
+    assert E.encode(codec, fq1, fq2, paired, cb) == want

@@ -140,3 +140,13 @@ def test_bug_compat_decode_equals_the_reference_binarys_output(name):
         assert g["flagged_not_last"] >= 1 and got == fq1                                  # (flagged chunks that are not the last, and nothing lost)
     if O.have_ref():
         assert O.ref_decode(rfq, split_pe=split) == got
+
+
+def test_oracle_equals_reference_binary_on_almost_uniform_read_lengths():
+    """tests/_shapes.py (reads of one length, or of one length but for one read, or of one length per file only) - what the GPU suite checks the encoder's
+    closed forms with: the oracle's image of each against the reference binary's, where the binary exists (this container)"""
+    if not O.have_ref():
+        pytest.skip("the reference binary does not travel with -m 'not gpu' on a box without /root/reference")
+    import _shapes as SH
+    for label, fq1, fq2, paired, cb in SH.cases(2400, 100000):
+        assert O.ref_encode(fq1, fq2, paired, k=cb // 1000) == O.encode_file(fq1, fq2, paired, cb), label

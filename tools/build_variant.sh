@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")/.."; name=$1; shift; T=$(mktemp -d); mkdir -p variants $T/repaq_amd; cp -r repaq_amd/csrc $T/repaq_amd/; cp -r include $T/
 for e in "$@"; do f=${e%%:*}; kv=${e#*:}; m=${kv%%=*}; v=${kv#*=}; grep -qE "^#define $m " $T/repaq_amd/csrc/$f || { echo "no #define $m in $f"; exit 1; }; sed -i -E "s/^(#define $m )[^ ]+/\1$v/" $T/repaq_amd/csrc/$f; done
 C=$T/repaq_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -I$T/include $C/rfq_api.hip $C/rfq_encode.hip $C/rfq_decode.hip -o variants/$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -Wl,--version-script=repaq_amd/csrc/exports.map -Wno-unused-result -I$T/include $C/rfq_api.hip $C/rfq_encode.hip $C/rfq_decode.hip -o variants/$name.so
 rm -rf $T; ls -la variants/$name.so
