@@ -644,7 +644,7 @@ def run_multi(args, rank, world, local):
     dist.destroy_process_group()
 
 
-def run_queue(args, rank, world, local):
+def run_queue(args, rank, world, local, emit=True):
     """--queue: the host work queue north_star names, in bench form.  ONE configs[3]-shaped logical input (--segs-per-gpu x N segments; N = 8: 2 x 64 GB) is resident in
     the HBM of EVERY GPU (128 GB of text at N = 8: it fits 288 GB), planned once (rfq_scan_batch: where every chunk ends), and cut into batches of --queue-chunks whole
     chunks.  A step: every rank pulls batch numbers from ONE shared counter (the rendezvous store's atomic add; a local counter for N = 1) until none are left, and
@@ -660,7 +660,11 @@ def run_queue(args, rank, world, local):
     from repaq_amd import RfqCodec, PE_TWO_FILES, dist as D
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    codec = RfqCodec(device=local)
+    # --queue-workers contexts per GPU, each on a host thread of its own (one rfq_ctx per (host thread, GPU): include/rfq_hip.h): a batch's chain of small kernels
+    # and its host round trips - about half of a 256-chunk batch's 1.4 ms, profiles/r06_b_queue_timeline_256.txt - run under another batch's large kernels
+    W = max(1, args.queue_workers)
+    codecs = [RfqCodec(device=local) for _ in range(W)]
+    codec = codecs[0]
     seg_pairs, nseg = args.seg_pairs, args.segs_per_gpu * (1 if args.strong else world)
     cb = max(100, args.chunk_kb) * 1000
     numa = pin_to_gpu_numa(local)
@@ -678,37 +682,39 @@ def run_queue(args, rank, world, local):
     cut1 = [0] + [e1[min(nc, (b + 1) * B) - 1] for b in range(nb)]; cut2 = [0] + [e2[min(nc, (b + 1) * B) - 1] for b in range(nb)]
     cut1[-1], cut2[-1] = n1, n2                                                   # (the last batch runs to the end of the input: final)
     big1 = max(cut1[b + 1] - cut1[b] for b in range(nb)); big2 = max(cut2[b + 1] - cut2[b] for b in range(nb))
-    o1 = torch.empty(big1 + 64, dtype=torch.uint8, device=dev); o2 = torch.empty(big2 + 64, dtype=torch.uint8, device=dev)
+    outs = [(torch.empty(big1 + 64, dtype=torch.uint8, device=dev), torch.empty(big2 + 64, dtype=torch.uint8, device=dev)) for _ in range(W)]
     store = dist.distributed_c10d._get_default_store() if world > 1 else None
-    local_ctr = {}
+    local_ctr = {}; ctr_lock = threading.Lock()
 
     def take(key):                                                                # the shared counter: the next batch nobody has taken yet
         if store is not None:
             return int(store.add(key, 1)) - 1
-        local_ctr[key] = local_ctr.get(key, -1) + 1
-        return local_ctr[key]
+        with ctr_lock:
+            local_ctr[key] = local_ctr.get(key, -1) + 1
+            return local_ctr[key]
 
     state = {"stage": {}, "enc_s": 0.0, "dec_s": 0.0, "batches": 0, "bytes": 0}
+    st_lock = threading.Lock()
 
-    def one(b, collect, check=None):
+    def one(b, collect, check=None, w=0):
+        codec = codecs[w]; o1, o2 = outs[w]
         last = b == nb - 1
         a1, a2 = cut1[b], cut2[b]; m1, m2 = cut1[b + 1] - a1, cut2[b + 1] - a2
         t_a = time.perf_counter()
         r = codec.encode(t1.data_ptr() + a1, m1, t2.data_ptr() + a2, m2, PE_TWO_FILES, cb, final=last, emit_header=(b == 0), file_off1=a1, file_off2=a2, flush_all=not last)
         t_b = time.perf_counter()
-        if collect:
-            for name, ms in codec.timings():
-                state["stage"][name] = state["stage"].get(name, 0.0) + ms
+        stages = list(codec.timings()) if collect else []
         d = None
         if not args.encode_only:
-            d = codec.decode(r.d_rfq, r.rfq_len, has_header=(b == 0), split_pe=True, final=last, d_out1=o1.data_ptr(), cap1=big1 + 64, d_out2=o2.data_ptr(), cap2=big2 + 64,
-                             chunk_off=r.h_chunk_off, n_chunks=r.n_chunks)
+            d = codec.decode(r.d_rfq, r.rfq_len, has_header=(b == 0), split_pe=True, final=last, d_out1=o1.data_ptr(), cap1=big1 + 64, d_out2=o2.data_ptr(), cap2=big2 + 64)
             if collect:
-                for name, ms in codec.timings():
-                    state["stage"]["dec:" + name] = state["stage"].get("dec:" + name, 0.0) + ms
+                stages += [("dec:" + name, ms) for name, ms in codec.timings()]
         if collect:
             t_c = time.perf_counter()
-            state["enc_s"] += t_b - t_a; state["dec_s"] += t_c - t_b; state["batches"] += 1; state["bytes"] += m1 + m2
+            with st_lock:
+                for name, ms in stages:
+                    state["stage"][name] = state["stage"].get(name, 0.0) + ms
+                state["enc_s"] += t_b - t_a; state["dec_s"] += t_c - t_b; state["batches"] += 1; state["bytes"] += m1 + m2
         if check is not None:
             assert r.consumed1 == m1 and r.consumed2 == m2, "batch %d was not encoded whole" % b
             img = codec.dev_get(r.d_rfq, r.rfq_len); offs = [r.h_chunk_off[i] for i in range(r.n_chunks + 1)]
@@ -718,19 +724,43 @@ def run_queue(args, rank, world, local):
         return r
 
     def drain(key, collect, check=None):
-        """pull batches until the counter runs past the last one; the next ticket is on its way while this one is worked on"""
-        nxt = {"b": take(key)}
-        while nxt["b"] < nb:
-            b = nxt["b"]
-            th = threading.Thread(target=lambda: nxt.__setitem__("b", take(key)))
-            th.start()
-            one(b, collect, check)
-            th.join()
+        """pull batches until the counter runs past the last one: every worker thread of this rank with its own context; a worker's next ticket is on its way while
+        it works on the current batch"""
+        errs = []
+
+        def worker(w):
+            try:
+                torch.cuda.set_device(local)
+                nxt = {"b": take(key)}
+                while nxt["b"] < nb:
+                    b = nxt["b"]
+                    th = threading.Thread(target=lambda: nxt.__setitem__("b", take(key))) if store is not None else None
+                    if th:
+                        th.start()
+                    one(b, collect, check, w)
+                    if th:
+                        th.join()
+                    else:
+                        nxt["b"] = take(key)
+            except BaseException as e:                                            # noqa: BLE001
+                errs.append(e)
+        if W == 1:
+            worker(0)
+        else:
+            ths = [threading.Thread(target=worker, args=(w,)) for w in range(W)]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+        if errs:
+            raise errs[0]
 
     # ---- header: batch 0 on rank 0 makes it (RfqCodec::makeHeader), every rank sets it
     if rank == 0:
         codec.clearHeader(); one(0, False)
     hdr = D.share_header(codec)
+    for c_ in codecs[1:]:
+        c_.setHeader(hdr)
     # ---- parity of what is being measured: one untimed pass over the queue
     parity = "unchecked"
     if not args.no_verify:
@@ -779,6 +809,18 @@ def run_queue(args, rank, world, local):
     torch.cuda.synchronize(); D.barrier()
     dt = time.perf_counter() - t0
     dt = D.reduce_max_sum(dt, 0)[0]
+    # the encode direction alone, by the wall clock (with several worker contexts side by side a worker's own call times overlap: only a pass of its own tells the encode rate)
+    enc_wall = None
+    if not args.encode_only:
+        keep_eo, args.encode_only = args.encode_only, True
+        D.barrier(); torch.cuda.synchronize()
+        t1_ = time.perf_counter()
+        for k_ in range(args.steps):
+            drain("enc%d" % k_, False)
+            D.barrier()
+        torch.cuda.synchronize(); D.barrier()
+        enc_wall = D.reduce_max_sum(time.perf_counter() - t1_, 0)[0]
+        args.encode_only = keep_eo
     K = args.steps; passes = 1 if args.encode_only else 2
     mine_line = {"rank": rank, "gpu": local, "numa_node": numa, "batches_per_step": round(state["batches"] / K, 1), "fastq_bytes_per_step": state["bytes"] // K,
                  "encode_MBps": round(state["bytes"] / state["enc_s"] / 1e6, 1) if state["enc_s"] else None, "decode_MBps": round(state["bytes"] / state["dec_s"] / 1e6, 1) if (state["dec_s"] and not args.encode_only) else None,
@@ -794,14 +836,17 @@ def run_queue(args, rank, world, local):
                "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
                "config": {"workload": "configs[3] shape through the host work QUEUE: ONE synthetic NovaSeq PE150 input of 2 x %.1f GB FASTQ (%d segments: fqgen profile 1, %d pairs, seed %d + s), -k %d, "
-                                      "resident in every GPU's HBM; batches of %d chunks pulled from one shared counter by %d rank(s) (encode%s per batch; plan + header over the host, no RCCL)"
-                                      % (total / 2e9, nseg, seg_pairs, SEG_SEED0, args.chunk_kb, B, world, "" if args.encode_only else " + decode"),
-                          "queue": True, "batches": nb, "chunks": nc, "parity": parity, "plan": "scan of the whole input on every rank", "plan_ms": round(plan_ms, 2), "strong": bool(args.strong), "ranks": ranks},
+                                      "resident in every GPU's HBM; batches of %d chunks pulled from one shared counter by %d rank(s) x %d worker context(s) (encode%s per batch; plan + header over the host, no RCCL)"
+                                      % (total / 2e9, nseg, seg_pairs, SEG_SEED0, args.chunk_kb, B, world, W, "" if args.encode_only else " + decode"),
+                          "queue": True, "workers_per_gpu": W, "encode_MBps_wall": round(total * K / (enc_wall if enc_wall else dt) / 1e6, 1), "batches": nb, "chunks": nc, "parity": parity, "plan": "scan of the whole input on every rank", "plan_ms": round(plan_ms, 2), "strong": bool(args.strong), "ranks": ranks},
                "roofline": None}
-        print(json.dumps(out))
-    codec.close()
+        if emit:
+            print(json.dumps(out))
+    for c_ in codecs:
+        c_.close()
     if world > 1:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 def main():
@@ -816,6 +861,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads / pairs of the workload the CPU baseline is timed on")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] secondary lines")
+    ap.add_argument("--no-queue-line", action="store_true", help="skip the host-work-queue secondary line (one GPU's share of configs[3] through bench.py --queue)")
     ap.add_argument("--encode-only", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity assertions (A/B runs of a switch or a macro that changes nothing but time)")
     ap.add_argument("--seg-pairs", type=int, default=SEG_PAIRS, help="N>1: pairs per segment of the logical input (test aid: smaller inputs)")
@@ -823,7 +869,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two extra passes of one step under rocprofv3 --pmc): take the committed profiles/*_pmc_traffic.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the counter passes: one warm-up + one step, nothing else
     ap.add_argument("--queue", action="store_true", help="the host work queue: the whole logical input resident on every GPU, batches of --queue-chunks chunks pulled from one shared counter (see run_queue); works with --gpus 1 too")
-    ap.add_argument("--queue-chunks", type=int, default=256, help="--queue: chunks per batch")
+    ap.add_argument("--queue-chunks", type=int, default=512, help="--queue: chunks per batch (profiles/r06_*_queue_sweep.txt)")
+    ap.add_argument("--queue-workers", type=int, default=2, help="--queue: worker contexts (host threads) per GPU")
     ap.add_argument("--strong", action="store_true", help="N>1: strong scaling - the input is --segs-per-gpu segments IN ALL (default 8 = 2 x 8 GB), split over the N GPUs")
     args = ap.parse_args()
 
@@ -892,8 +939,19 @@ def main():
             del w2
             torch.cuda.empty_cache()
         out["secondary"] = sec
+        if not args.no_queue_line:
+            # the host work queue on this GPU (what a multi-GPU run multiplies): one GPU's share of the configs[3] input - 8 segments, 2 x 8 GB - in batches of
+            # --queue-chunks chunks pulled from the counter by --queue-workers contexts; its own parity pass (every chunk image against the reference's table)
+            import copy
+            qa = copy.copy(args); qa.steps, qa.warmup = 3, 1
+            codec.close(); codec = None
+            q = run_queue(qa, 0, 1, local, emit=False)
+            sec["queue"] = {"workload": q["config"]["workload"], "value_MBps": q["value"], "ms_per_step": q["ms_per_step"], "batches": q["config"]["batches"], "chunks": q["config"]["chunks"],
+                            "queue_chunks": args.queue_chunks, "workers_per_gpu": q["config"]["workers_per_gpu"], "encode_MBps": q["config"]["encode_MBps_wall"], "parity": q["config"]["parity"], "plan_ms": q["config"]["plan_ms"],
+                            "note": "value_MBps: encode + decode of every batch, wall clock; encode_MBps: a pass of encodes alone, wall clock"}
     print(json.dumps(out))
-    codec.close()
+    if codec is not None:
+        codec.close()
 
 
 if __name__ == "__main__":

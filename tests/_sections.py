@@ -29,10 +29,12 @@ class Chunk:
         q = 18; self.npos_size = 0
         if h.flags & H_N_POS:
             self.npos_size = u32(q); q += 4
+        self.fixed = q                                   # bytes of the fixed fields (size, reads, flags, seq / quality / N-position sizes)
         s, fl, rlb = self.reads, self.flags, h.read_len_bytes
         cnt = 1 if fl & C_READ_LEN_SAME else s
         fmt = {1: "B", 2: "<H", 4: "<I"}[rlb]
         self.read_lens = [struct.unpack_from(fmt, p, q + i * rlb)[0] for i in range(cnt)]; q += cnt * rlb
+        self.marks = [self.fixed, q]                     # offsets at which a section ends (hostile-image tests cut and scribble there)
 
         def lenarr(lenflag, sameflag):
             nonlocal q
@@ -42,9 +44,10 @@ class Chunk:
             if (fl & lenflag) and not (fl & sameflag):
                 tot *= s
             return arr, tot
-        self.n1_lens, n1_size = lenarr(C_NAME1_LEN_SAME, C_NAME1_SAME)
-        self.n2_lens, n2_size = (lenarr(C_NAME2_LEN_SAME, C_NAME2_SAME) if h.flags & H_NAME2 else ([], 0))
-        self.st_lens, st_size = lenarr(C_STRAND_LEN_SAME, C_STRAND_SAME)
+        self.n1_lens, n1_size = lenarr(C_NAME1_LEN_SAME, C_NAME1_SAME); self.marks.append(q)
+        self.n2_lens, n2_size = (lenarr(C_NAME2_LEN_SAME, C_NAME2_SAME) if h.flags & H_NAME2 else ([], 0)); self.marks.append(q)
+        self.st_lens, st_size = lenarr(C_STRAND_LEN_SAME, C_STRAND_SAME); self.marks.append(q)
+        self.len_arrays_end = q                          # fixed fields + the four length arrays: what RfqChunk::read sizes everything else from
         hc = s // 2 if fl & C_PE_INTERLEAVED else s
         self.lanes = self.tiles = []; self.x = self.y = b""
         if h.flags & H_LANE:
@@ -55,18 +58,20 @@ class Chunk:
             n = u32(q); q += 4; self.x = p[q:q + n]; q += n
         if h.flags & H_Y:
             n = u32(q); q += 4; self.y = p[q:q + n]; q += n
-        self.n1 = p[q:q + n1_size]; q += n1_size
+        self.marks.append(q); self.coords_end = q
+        self.n1 = p[q:q + n1_size]; q += n1_size; self.marks.append(q)
         self.n2 = b""
         if h.flags & H_NAME2:
             self.n2 = p[q:q + n2_size]; q += n2_size
-        self.st = p[q:q + st_size]; q += st_size
-        self.seq = p[q:q + self.seq_size]; q += self.seq_size
-        self.qual = p[q:q + self.qual_size]; q += self.qual_size
+        self.st = p[q:q + st_size]; q += st_size; self.marks.append(q)
+        self.seq = p[q:q + self.seq_size]; q += self.seq_size; self.marks.append(q)
+        self.qual_off = q
+        self.qual = p[q:q + self.qual_size]; q += self.qual_size; self.marks.append(q)
         self.ov = b""
         if (fl & C_PE_INTERLEAVED) and (h.flags & H_PE_OVERLAP):
             self.ov = p[q:q + s // 2]; q += s // 2
         self.npos = p[q:q + self.npos_size] if h.flags & H_N_POS else b""; q += self.npos_size
-        self.total = q
+        self.total = q; self.marks.append(q); self.marks = sorted(set(self.marks))
         assert q <= len(p), "truncated chunk"
         self.h = h
 
@@ -85,5 +90,6 @@ def parse(rfq: bytes):
         c = Chunk(h, rfq, k)
         if c.reads == 0:
             break
+        c.off = k                                        # where the chunk starts in the image
         chunks.append(c); k += c.total
     return h, chunks
