@@ -869,7 +869,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two extra passes of one step under rocprofv3 --pmc): take the committed profiles/*_pmc_traffic.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the counter passes: one warm-up + one step, nothing else
     ap.add_argument("--queue", action="store_true", help="the host work queue: the whole logical input resident on every GPU, batches of --queue-chunks chunks pulled from one shared counter (see run_queue); works with --gpus 1 too")
-    ap.add_argument("--queue-chunks", type=int, default=512, help="--queue: chunks per batch (profiles/r06_*_queue_sweep.txt)")
+    ap.add_argument("--queue-chunks", type=int, default=1024, help="--queue: chunks per batch (profiles/r06_d_queue_sweep_workers.txt: 256 / 512 / 1024 chunks x 1 / 2 / 3 worker contexts)")
     ap.add_argument("--queue-workers", type=int, default=2, help="--queue: worker contexts (host threads) per GPU")
     ap.add_argument("--strong", action="store_true", help="N>1: strong scaling - the input is --segs-per-gpu segments IN ALL (default 8 = 2 x 8 GB), split over the N GPUs")
     args = ap.parse_args()

@@ -13,6 +13,6 @@ if [ "$WHAT" = small ]; then
   run 2 --queue --segs-per-gpu 1 --queue-chunks 64 --steps 2 --warmup 1 > $OUT/queue_gpus2_single_device.json.log 2> $OUT/q2.err; tail -c 1500 $OUT/queue_gpus2_single_device.json.log
   run 2 --segs-per-gpu 2 --steps 2 --warmup 1 > $OUT/gpus2_single_device.json.log 2> $OUT/m2.err; tail -c 1500 $OUT/gpus2_single_device.json.log
 else
-  timeout 1500 python bench.py --gpus 1 --queue --segs-per-gpu 64 --queue-chunks 256 --steps 2 --warmup 1 --encode-only > $OUT/queue_cfg3_whole_one_gpu.json.log 2> $OUT/q3.err; tail -c 2000 $OUT/queue_cfg3_whole_one_gpu.json.log
+  timeout 1500 python bench.py --gpus 1 --queue --segs-per-gpu 64 --queue-chunks 1024 --steps 2 --warmup 1 --encode-only > $OUT/queue_cfg3_whole_one_gpu.json.log 2> $OUT/q3.err; tail -c 2000 $OUT/queue_cfg3_whole_one_gpu.json.log
 fi
 for f in $OUT/*.err; do echo "== $f"; grep -v 'amdgpu.ids' $f | tail -n 5; done; true
