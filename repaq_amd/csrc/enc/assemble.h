@@ -87,6 +87,7 @@ __global__ void k_assemble(Text T, ReadTab R, ChunkTab C, const DevHeader* __res
                            uint8_t* __restrict__ img, uint64_t img_cap, uint64_t img_base, uint64_t off1, uint64_t off2, uint64_t nolb1, uint64_t nolb2,
                            const uint32_t* __restrict__ segb, const uint32_t* __restrict__ segd, const uint32_t* __restrict__ segs, uint32_t n_seg, DevStatus* st,
                            uint32_t tail_bases, uint32_t tail_units, uint32_t tail_nl1, uint32_t tail_nl2, uint64_t tail_n1, uint64_t tail_n2) {
+    if (enc_arena_small(st)) return;                                       // (the streams were not coded: the host repeats the batch)
     const uint32_t c = blockIdx.y; const Layout o = L[c];
     const uint64_t at = img_base + C.img_off[c];
     if (at + o.total > img_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&st->err, 1u << 31); return; }
@@ -214,9 +215,12 @@ __global__ void k_assemble_names(Text T, ReadTab R, ChunkTab C, const DevHeader*
         if (need3) copy_piece8(out + o.off_st + (p.c - a.c), line_ptr(T, g, 2), line_len(T, g, 2), part);
     }
 }
-__global__ void k_enc_totals(ChunkTab C, const uint64_t* __restrict__ ctotal_prefix, uint32_t n_chunks, int which, DevStatus* st) {
+// cap: bytes the arena of `which` holds (the host sizes it BEFORE the counts exist - no read-back between the gather and the coders; ~0 = exact sizing, the byte-wise path):
+// a total beyond it raises DE_SCRATCH(N)_SMALL, at which every kernel that would touch the arena leaves (enc_arena_small) and the host repeats the batch with room
+__global__ void k_enc_totals(ChunkTab C, const uint64_t* __restrict__ ctotal_prefix, uint32_t n_chunks, int which, DevStatus* st, uint64_t cap) {
     if (threadIdx.x || blockIdx.x) return;
-    if (which == 0) { st->total_scratch = ctotal_prefix[n_chunks]; }                     // ctotal_prefix: the quality arena's
-    else if (which == 2) { st->total_scratch_n = ctotal_prefix[n_chunks]; st->image_bound = C.img_off[n_chunks]; }   // ... the N arena's
+    if (which == 0) { st->total_scratch = ctotal_prefix[n_chunks]; if (ctotal_prefix[n_chunks] + 256ull > cap) atomicOr(&st->err, (uint32_t)DE_SCRATCH_SMALL); }   // ctotal_prefix: the quality arena's
+    else if (which == 2) { st->total_scratch_n = ctotal_prefix[n_chunks]; st->image_bound = C.img_off[n_chunks];                                     // ... the N arena's
+            if (ctotal_prefix[n_chunks] + 256ull > cap) atomicOr(&st->err, (uint32_t)DE_SCRATCHN_SMALL); }
     else st->total_image = C.img_off[n_chunks];
 }

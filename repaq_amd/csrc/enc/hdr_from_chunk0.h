@@ -105,7 +105,7 @@ __global__ void k_hdr_pe(Text T, ReadTab R, const uint32_t* __restrict__ first, 
     if (p == 0) { H->dpos = dpos; H->dch = dch; }
 }
 // derived tables shared by "made" and "set" headers: majorQual / normalQualBins / normalQualBuf (src/rfqheader.cpp:263,308-328)
-__device__ __forceinline__ void hdr_derive(DevHeader* D) {
+__host__ __device__ __forceinline__ void hdr_derive(DevHeader* D) {
     const uint8_t* b = D->bytes;
     D->read_len_bytes = b[9]; D->flags = (uint32_t)b[10] | ((uint32_t)b[11] << 8);
     D->name2_diff_pos = b[12]; D->name2_diff_char = b[13]; D->n_base_qual = b[14]; D->overlap_shift = (int32_t)(int8_t)b[15];

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64, PL_WAVES) k_pos_coder_list(ReadTab R, Chun
     __shared__ PlLds S;
     // [stream][lane]: matches among the lane's 64 positions, then the lane's next free entry in the stream's part (n_normal x 64 u16: dynamic)
     RFQ_DYN_SHARED(uint16_t, pl_base);
+    if (enc_arena_small(st)) return;
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3;       // (a chunk's workgroups on one XCD, as in k_pos_coder)
     const uint32_t c = (idx / n_seg) * 8u + xcd, seg = idx % n_seg;
     if (c >= n_chunks) return;

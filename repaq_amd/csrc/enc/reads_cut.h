@@ -211,8 +211,12 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
 }
 // carry: bases the chunk that is open at unit 0 has taken from the text in front of this batch (plan pass of a share, rfq_encode_args.carry_bases)
 __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, uint32_t carry, int final_batch,
-                            const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st, const uint32_t* __restrict__ uni) {
+                            const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st, const uint32_t* __restrict__ uni,
+                            int have_scans) {
     const int l = lane_id();
+    // have_scans = 0: the host launched neither prefix scan (it expects reads of one length - what a sequencer writes - and saves their six launches); reads of
+    // several lengths say so and leave: the host runs the scans and this kernel once more
+    if (!have_scans && !uni[0]) { if (threadIdx.x == 0) atomicOr(&st->err, (uint32_t)DE_NEED_SCAN); return; }
     // shortest / longest unit: every thread of the workgroup (1024: a single wave walked 44 k block entries in 158 us), then wave 0 goes on alone
     __shared__ uint32_t s_mn[16], s_mx[16], s_rc[16], s_ml[16];
     uint32_t len_minmax[2], max_rec, max_len;

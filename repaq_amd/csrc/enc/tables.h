@@ -57,3 +57,5 @@ struct ChunkTab {                // per-chunk arrays
     uint64_t* img_off;           // exclusive prefix (n_chunks + 1)
     U4*       ptot;              // the chunk's totals of (name1_len, name2_len, strand_len, stored): ReadTab::pv[g] - pv[first] is read g's offset inside the chunk
 };
+// an arena the host sized before the counts existed turned out too small (k_enc_totals): whoever would touch it leaves, the host repeats the batch with room
+__device__ __forceinline__ bool enc_arena_small(const DevStatus* st) { return (st->err & (DE_SCRATCH_SMALL | DE_SCRATCHN_SMALL)) != 0u; }

@@ -104,6 +104,8 @@ extern "C" void rfq_destroy(rfq_ctx* c) {
     if (c->copy) { (void)hipStreamDestroy(c->copy); for (auto& e : c->copy_ev) if (e) (void)hipEventDestroy(e); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_up) (void)hipHostFree(c->pin_up);
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -140,7 +142,7 @@ extern "C" int rfq_get_header(rfq_ctx* c, uint8_t* out, size_t* len) {
     memcpy(out, c->h_hdr.bytes, c->h_hdr.len); *len = c->h_hdr.len;
     return RFQ_OK;
 }
-extern "C" void rfq_clear_header(rfq_ctx* c) { if (c) { c->have_hdr = false; c->dense_ok = false; c->e3_pieces_failed = false; memset(&c->h_hdr, 0, sizeof c->h_hdr); } }
+extern "C" void rfq_clear_header(rfq_ctx* c) { if (c) { c->have_hdr = false; c->hdr_on_device = false; c->dense_ok = false; c->e3_pieces_failed = false; c->mixed_lengths = false; memset(&c->h_hdr, 0, sizeof c->h_hdr); } }
 
 extern "C" int rfq_last_timings(const rfq_ctx* c, const char** names, float* ms, int cap) {
     if (!c) return 0;

@@ -49,6 +49,9 @@
 #define DE_INDEX_RETRY     (1u << 30) // encode, one-pass line index: more lines than the table sized in advance holds (or a wait that did not end): index in two passes
 #define DE_CORRUPT_OV      (1u << 10) // decode, fused path: an overlap byte that exceeds a mate's length (k_dec_readtab2; "corrupt overlap buffer" - DE_CORRUPT is the quality / stream verdict there)
 #define DE_INTERNAL        (1u << 11) // encode: two kernels disagree about an invariant they share (k_partition: reads of one length whose units are not) - a bug, reported as one
+#define DE_SCRATCH_SMALL   (1u << 12) // encode: the stream scratch the host sized in advance (no read-back between gather and coder) is too small: the coders and the assembler leave, the host grows it and repeats the batch
+#define DE_SCRATCHN_SMALL  (1u << 13) // ... the N-position streams' arena
+#define DE_NEED_SCAN       (1u << 14) // encode: reads of several lengths - the closed-form prefixes do not apply, the host runs the scans and the partition again
 #define DE_TAIL_BLANK      (1u << 9)  // an empty line in the \n-only text right behind the encoded records: blank or empty is for the normaliser to say
 
 // Device-resident file header + derived tables (RfqHeader, src/rfqheader.h:44-108)

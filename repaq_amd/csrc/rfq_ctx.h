@@ -7,6 +7,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstdarg>
+#include <algorithm>
 
 struct DBuf {
     void* p = nullptr; size_t cap = 0;
@@ -133,11 +134,15 @@ struct rfq_ctx {
     // header
     DBuf d_hdr;                 // DevHeader
     DevHeader h_hdr; bool have_hdr = false;
+    // rfq_upload_header: the device copy of h_hdr is current (a header MADE by the encoder lives on the device first and is fetched); the page-locked block uploads go through
+    bool hdr_on_device = false; uint8_t* pin_up = nullptr; hipEvent_t ev_up = nullptr; bool ev_up_pending = false;
     DBuf d_status; DevStatus h_status;
     DBuf d_cmp;                 // rfq_compare_bytes: one u64 (first differing offset)
     // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
     DBuf b[120];
     DBuf out_img, out_fq1, out_fq2, out_acc, out_acc1, out_acc2;       // out_acc*: the results of a sliced encode / decode call, appended
+    bool retried_room = false;             // encode: the call in progress repeats a batch whose arenas were too small (a marker for rfq_last_timings)
+    bool mixed_lengths = false;            // encode: this file has reads of several lengths (the prefix scans are launched up front; reset with the header)
     bool dense_ok = false;                 // encode, match-mask mode: DevHeader::dense of the device header is set (k_dense_order; reset with the header)
     // encode, match-mask mode: the rare planes of b[B_QPLANE] may hold bits (fresh buffer, or a call that left early): zero them whole
     bool qplane_dirty = true;
@@ -217,4 +222,23 @@ template <class T> static inline void scan_exclusive(hipStream_t s, const T* in,
     hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, tmp, n, skip);
     hipLaunchKernelGGL((k_scan_partials<T>), dim3(1), dim3(SCAN_TPB), 0, s, tmp, nb, (T*)nullptr, skip);
     hipLaunchKernelGGL((k_scan_apply<T>), dim3(nb), dim3(SCAN_TPB), 0, s, in, out, (const T*)tmp, n, write_total, skip);
+}
+
+// ---------------------------------------------------------------- several fills in one launch
+// The per-batch tables that start all-zero / all-ones, in ONE launch (they were up to eight hipMemsetAsync calls - a fill kernel each, ~5 us on the device and ~10 us of
+// host enqueue apiece, in chains where the GPU waits for the host: profiles/r06_b_queue_timeline_256.txt).  words: 32-bit words of each region; val: the word it is filled with.
+#define CLEAR_MAX 8
+struct ClearList { uint32_t* p[CLEAR_MAX]; uint64_t words[CLEAR_MAX]; uint32_t val[CLEAR_MAX]; uint32_t n;
+    void add(void* p_, size_t bytes, uint32_t v) { p[n] = (uint32_t*)p_; words[n] = (bytes + 3) / 4; val[n] = v; n++; } };
+template <int UNUSED> __global__ void k_clear_list(ClearList z) {
+    const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, NT = (uint64_t)gridDim.x * blockDim.x;
+    for (uint32_t r = 0; r < z.n; r++) {                                    // (uniform)
+        uint32_t* const p = z.p[r]; const uint32_t v = z.val[r]; const uint64_t n4 = z.words[r] >> 2;
+        for (uint64_t i = t0; i < n4; i += NT) ((uint4*)p)[i] = make_uint4(v, v, v, v);                       // (regions start on 16-byte boundaries)
+        for (uint64_t i = (n4 << 2) + t0; i < z.words[r]; i += NT) p[i] = v;
+    }
+}
+static inline void clear_list(hipStream_t s, const ClearList& z) {
+    size_t words = 0; for (uint32_t i = 0; i < z.n; i++) words = std::max<size_t>(words, (size_t)z.words[i]);
+    if (z.n) hipLaunchKernelGGL((k_clear_list<0>), dim3((uint32_t)std::min<size_t>(2048, words / 1024 + 1)), dim3(256), 0, s, z);
 }

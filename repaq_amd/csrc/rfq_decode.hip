@@ -92,8 +92,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
             // 2 bytes per base up front: 6.7 GB on 2 x 4 GB of text)
             if (B[DB_PLIST].ensure((size_t)(g.bases / 8 + 1024) * sizeof(plist_t)) != hipSuccess) { (void)hipGetLastError();
                     HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 32 + 1024) * sizeof(plist_t))); }
-            HIPCHK(ctx, hipMemsetAsync(B[DB_SEGN].p, 0, nst * 4, A)); HIPCHK(ctx, hipMemsetAsync(B[DB_NENT].p, 0, nst * 4, A));
-                    HIPCHK(ctx, hipMemsetAsync(B[DB_CELL].p, 0xFF, ncl * 4, A));
+            { ClearList z; memset(&z, 0, sizeof z); z.add(B[DB_SEGN].p, nst * 4, 0u); z.add(B[DB_NENT].p, nst * 4, 0u); z.add(B[DB_CELL].p, ncl * 4, 0xFFFFFFFFu); clear_list(A, z); }
 #define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
             if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);
             if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr);
@@ -320,10 +319,11 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
     for (;;) {
         if (use_table && a->n_chunk_off + 1u > cap) cap = a->n_chunk_off + 1u;
         HIPCHK(ctx, B[DB_CHUNKS].ensure((size_t)cap * sizeof(DChunk)));
-        HIPCHK(ctx, hipMemsetAsync(dst, 0, sizeof(DecStatus), S));
+        ClearList wz; memset(&wz, 0, sizeof wz); wz.add(dst, sizeof(DecStatus), 0u);       // (the walk's fills in one launch: status, candidates, the "no candidate" count)
         const bool indexed = use_table || guess;                             // chunk starts that have to verify
         if (use_table) {
             const size_t tb = ((size_t)a->n_chunk_off + 1) * 8;
+            clear_list(S, wz);
             HIPCHK(ctx, B[DB_OFFT].ensure(tb));
             HIPCHK(ctx, hipMemcpyAsync(B[DB_OFFT].p, a->h_chunk_off, tb, hipMemcpyHostToDevice, S));
             hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), a->n_chunk_off,
@@ -333,7 +333,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             HIPCHK(ctx, B[DB_GWCAND].ensure(GW_SEGS * 8 + 64)); HIPCHK(ctx, B[DB_GWLIST].ensure((size_t)GW_SEGS * GW_LCAP * 8));
                     HIPCHK(ctx, B[DB_GWCNT].ensure(GW_SEGS * 4 + 64)); HIPCHK(ctx, B[DB_GWLAND].ensure(GW_SEGS * 8 + 64));
             unsigned long long* cand = B[DB_GWCAND].as<unsigned long long>(); uint32_t* gbad = B[DB_GWCNT].as<uint32_t>() + GW_SEGS;
-            HIPCHK(ctx, hipMemsetAsync(cand, 0xFF, GW_SEGS * 8, S)); HIPCHK(ctx, hipMemsetAsync(gbad, 0, 4, S));
+            wz.add(cand, GW_SEGS * 8, 0xFFFFFFFFu); wz.add(gbad, 4, 0u); clear_list(S, wz);
             // (a segment is 16 chunks or more: no use in more segments than 64 KB pieces; RFQ_GW_SHIFT: test aid)
             const uint32_t mseg = (uint32_t)std::min<uint64_t>(GW_SEGS, std::max<uint64_t>(1, (a->n - start) >> ctx->opt.gw_shift));
             if (mseg > 1) hipLaunchKernelGGL(k_dec_gw_find, dim3(16, mseg - 1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, start, D, cand, mseg);
@@ -345,7 +345,7 @@ extern "C" int rfq_decode_batch(rfq_ctx* ctx, const rfq_decode_args* a, rfq_deco
             hipLaunchKernelGGL(k_dec_table, dim3(1), dim3(256), 0, S, a->d_rfq, (uint64_t)a->n, (const uint64_t*)B[DB_OFFT].as<uint64_t>(), 0xFFFFFFFFu,
                     B[DB_CHUNKS].as<DChunk>(), dst);
         }
-        else hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0);
+        else { clear_list(S, wz); hipLaunchKernelGGL(k_dec_walk, dim3(1), dim3(64), 0, S, a->d_rfq, (uint64_t)a->n, start, D, B[DB_CHUNKS].as<DChunk>(), cap, dst, a->final ? 1 : 0); }
         KCHK(ctx, "k_dec_walk");
         // the verifying parse rides behind the index without a host round trip in between (its grid covers the first
         // PARSE_AHEAD chunks; the walk's own verdict is in the status words it reads)

@@ -40,13 +40,23 @@ int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n) {
     if (h[0] != 'R' || h[1] != 'F' || h[2] != 'Q') return rfq_fail(c, RFQ_E_FORMAT, "Not a valid repaq file!");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, c->d_hdr.ensure(sizeof(DevHeader)));
-    DevHeader tmp; memset(&tmp, 0, sizeof tmp); memcpy(tmp.bytes, h, len);
-    HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, &tmp, sizeof tmp, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_hdr_from_bytes, dim3(1), dim3(64), 0, c->stream, c->d_hdr.as<DevHeader>());
-    KCHK(c, "k_hdr_from_bytes");
-    HIPCHK(c, c->fetch(&c->h_hdr, c->d_hdr.p, sizeof(DevHeader), c->stream));
-    HIPCHK(c, c->fetch_sync(c->stream));
-    c->have_hdr = true; c->dense_ok = false; c->e3_pieces_failed = false;   // (another file: what its name pieces fit is not known yet)
+    // The derived tables (hdr_derive: the same function the header kernels call) are made HERE, on the host, and the whole DevHeader goes to the device in one
+    // stream-ordered copy from a page-locked block: no kernel, no read-back, no wait (round 5: upload, k_hdr_from_bytes, fetch, synchronise - two round trips in
+    // front of every decode that starts with a header).  Bytes equal to the header the device already holds: nothing is sent.
+    DevHeader tmp; memset(&tmp, 0, sizeof tmp); memcpy(tmp.bytes, h, len); hdr_derive(&tmp);
+    const bool same = c->have_hdr && c->hdr_on_device && c->h_hdr.len == tmp.len && !memcmp(c->h_hdr.bytes, tmp.bytes, tmp.len);
+    if (!same) {
+        if (!c->pin_up) { if (hipHostMalloc((void**)&c->pin_up, sizeof(DevHeader), 0) != hipSuccess) { c->pin_up = nullptr; (void)hipGetLastError(); } }
+        if (c->pin_up) {
+            if (c->ev_up_pending) { HIPCHK(c, hipEventSynchronize(c->ev_up)); c->ev_up_pending = false; }       // (the block's previous copy)
+            if (!c->ev_up) HIPCHK(c, hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+            memcpy(c->pin_up, &tmp, sizeof tmp);
+            HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, c->pin_up, sizeof tmp, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_up, c->stream)); c->ev_up_pending = true;
+        } else { HIPCHK(c, hipMemcpyAsync(c->d_hdr.p, &tmp, sizeof tmp, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+        c->h_hdr = tmp; c->hdr_on_device = true;
+    }
+    c->have_hdr = true; c->dense_ok = false; c->e3_pieces_failed = false; c->mixed_lengths = false;   // (another file: what its name pieces fit / whether its reads have one length is not known yet)
     return RFQ_OK;
 }
 
@@ -54,6 +64,7 @@ int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n) {
 // Mapping of a normalised stream (see k_norm_classify) back to the caller's text
 struct NormMap { const uint32_t* ot[2]; const uint32_t* onx[2]; size_t orig_n[2]; };
 #define RFQ_NEED_NORM 1            // internal: the '\n'-only indexer met '\r' or an empty line; redo on normalised text
+#define RFQ_RETRY_ROOM 3           // internal: an arena sized in advance was too small (it has been grown): encode the batch again
 
 // FastqReader::getLine semantics for text with '\r' / blank lines: rewrite stream s as '\n'-terminated text + the line maps
 static int normalize_stream(rfq_ctx* ctx, const uint8_t* fq, size_t n, uint64_t file_off, bool final, int s, NormMap& nm, const uint8_t** out, size_t* out_n) {
@@ -97,7 +108,9 @@ static int encode_one(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result*
             al.file_off1 = a->file_off1 - skip[0]; }
     if (a->paired == RFQ_PE_TWO_FILES && a->n2 && a->d_fq2) { skip[1] = (uint32_t)((uintptr_t)a->d_fq2 & 15u); al.d_fq2 = a->d_fq2 - skip[1]; al.n2 = a->n2 + skip[1];
             al.file_off2 = a->file_off2 - skip[1]; }
-    int rc = encode_impl(ctx, &al, res, nullptr, ~0u, false, scan_only, skip);
+    int rc = RFQ_RETRY_ROOM;
+    for (int attempt = 0; attempt < 3 && rc == RFQ_RETRY_ROOM; attempt++) rc = encode_impl(ctx, &al, res, nullptr, ~0u, false, scan_only, skip);
+    if (rc == RFQ_RETRY_ROOM) return rfq_fail(ctx, RFQ_E_HIP, "internal: the stream arenas did not settle");
     if (rc != RFQ_NEED_NORM) return rc;
     // slow path: '\r' line ends or blank lines (src/fastqreader.cpp:94-196)
     NormMap nm; memset(&nm, 0, sizeof nm);
@@ -110,7 +123,9 @@ static int encode_one(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result*
         a2.d_fq2 = p; a2.n2 = pn;
     }
     memset(res, 0, sizeof *res);
-    rc = encode_impl(ctx, &a2, res, &nm, ~0u, false, scan_only, noskip);
+    rc = RFQ_RETRY_ROOM;
+    for (int attempt = 0; attempt < 3 && rc == RFQ_RETRY_ROOM; attempt++) rc = encode_impl(ctx, &a2, res, &nm, ~0u, false, scan_only, noskip);
+    if (rc == RFQ_RETRY_ROOM) return rfq_fail(ctx, RFQ_E_HIP, "internal: the stream arenas did not settle");
     if (rc == RFQ_NEED_NORM) return rfq_fail(ctx, RFQ_E_HIP, "internal: normalised text still needs normalisation");
     return rc;
 }
@@ -219,6 +234,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     ctx->timer.reset();
     ctx->pend.clear(); ctx->pin_used = 0;                                   // (read-backs an earlier call left behind on an error path)
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // (a marker, not a phase: this is the repeat of a batch whose arenas were too small - tests look for it)
+    if (ctx->retried_room) { ctx->timer.begin("retry_room", S); ctx->timer.end(S); ctx->retried_room = false; }
 
     // ---- status block
     DevStatus hs; memset(&hs, 0, sizeof hs); hs.err_key = ~0ull; hs.coord_key = ~0ull; hs.first_empty = ~0u;
@@ -344,8 +361,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // every read the same length (sequencer output): both prefixes have a closed form - the scans see the flag and return, k_fill_pq writes g x L (no host round trip)
     uint32_t* const uni = B[B_MINMAX].as<uint32_t>() + (size_t)ublocks * LENS_BLK;
     hipLaunchKernelGGL(k_lens_uniform, dim3(1), dim3(1024), 0, S, (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, n_units, uni);
-    scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1, uni);
-    scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1, uni);
+    // The two prefix scans (units for the cut, reads for the base prefix: six launches) see `uni` and return at once when every read has L bases.  A context that has
+    // not met reads of several lengths in this file does not even launch them: k_partition says DE_NEED_SCAN if they were needed after all, and scans + partition run
+    // then - one more round trip, once per file (ctx->mixed_lengths stays up until the header is cleared).
+    auto prefix_scans = [&]() {
+        scan_exclusive<uint64_t>(S, B[B_ULEN].as<uint64_t>(), B[B_P].as<uint64_t>(), n_units, B[B_SCANTMP].as<uint64_t>(), 1, uni);
+        scan_exclusive<uint32_t>(S, R.len, R.pq, n_reads, B[B_SCANTMP].as<uint32_t>(), 1, uni);
+    };
+    bool have_scans = ctx->mixed_lengths;
+    if (have_scans) prefix_scans();
     hipLaunchKernelGGL(k_fill_pq, dim3(n_reads / 256 + 1), dim3(256), 0, S, R.pq, n_reads, (const uint32_t*)uni);
     const uint64_t cap64 = (uint64_t)(nbytes[0] + nbytes[1]) / (2ull * a->chunk_bases) + 3;
     const uint32_t cap_chunks = (uint32_t)std::min<uint64_t>(cap64, (uint64_t)n_units + 1);
@@ -354,11 +378,16 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     C.first = B[B_FIRST].as<uint32_t>();
     if (a->carry_bases && !scan_only) return rfq_fail(ctx, RFQ_E_ARG, "carry_bases is for the plan pass (rfq_scan_batch): an encode starts on a chunk boundary");
     if (a->carry_bases >= a->chunk_bases) return rfq_fail(ctx, RFQ_E_ARG, "carry_bases must be < chunk_bases");
-    hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->carry_bases, fin ? 1 : 0,
-                       (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst, (const uint32_t*)uni);
-    KCHK(ctx, "k_partition");
-    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-    HIPCHK(ctx, ctx->fetch_sync(S));
+    for (;;) {
+        hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->carry_bases, fin ? 1 : 0,
+                           (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst, (const uint32_t*)uni, have_scans ? 1 : 0);
+        KCHK(ctx, "k_partition");
+        HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
+        if (have_scans || !(hs.err & DE_NEED_SCAN)) break;
+        ctx->mixed_lengths = true; have_scans = true; prefix_scans();       // (the bit stays in the device's status word: nobody else reads it)
+    }
+    hs.err &= ~(uint32_t)DE_NEED_SCAN;
     ctx->timer.end(S);
     if (hs.err & DE_EMPTY_LINE) {
         // "\n\n" is a swallowed blank line, not an empty one: classify the text properly first.  On normalised text an empty line is
@@ -464,9 +493,24 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // the tile gather is instantiated by the header (match masks for <= 4 coded quality values, bytes otherwise): a first batch waits for it here
         if (hdr_aside) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_mid, 0));
         HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
-        HIPCHK(ctx, ctx->fetch_sync(S));
+        { DevStatus h2; HIPCHK(ctx, ctx->fetch(&h2, dst, sizeof h2, S)); HIPCHK(ctx, ctx->fetch_sync(S)); hs.err |= h2.err; hs.err_read = h2.err_read; hs.err_key = h2.err_key; }
     }
     ctx->timer.end(S);
+    // RfqHeader::makeQualityTable's refusals (src/rfqheader.cpp:140-166), as soon as the header kernels' verdict is on the host (tile path: here; byte-wise path: behind its gather)
+    auto header_errors = [&]() -> int {
+        if (hs.err & (DE_BAD_QUAL | DE_BAD_BASE)) {
+            const uint32_t g = hs.err_read, i = (uint32_t)hs.err_key; std::string ln;
+            if (hs.err & DE_BAD_QUAL) { if (fetch_line(ctx, T, g, 3, ln)) return RFQ_E_HIP; return rfq_fail(ctx, RFQ_E_DATA, "bad quality value: %d", (int)(int8_t)ln[i]); }
+            if (fetch_line(ctx, T, g, 1, ln)) return RFQ_E_HIP;
+            const char b = ln[i];
+            if (b == 'a' || b == 't' || b == 'c') return rfq_fail(ctx, RFQ_E_DATA, "repaq doesn't support FASTQ with lowercase bases (a/t/c/g)\nbut we get:\n%s", ln.c_str());
+            return rfq_fail(ctx, RFQ_E_DATA, "repaq only supports FASTQ with uppercase bases (A/T/C/G/N)\nbut we get:\n%s", ln.c_str());
+        }
+        if (hs.err & DE_NO_QUAL_BINS) return rfq_fail(ctx, RFQ_E_DATA, "bad quality string, is this a valid FASTQ file?");
+        if (make_header) { if (!ctx->h_hdr.valid) return rfq_fail(ctx, RFQ_E_HIP, "internal: header was not finalised"); ctx->have_hdr = true; ctx->hdr_on_device = true; }
+        return RFQ_OK;
+    };
+    if (fast && make_header) { ovl_guard.sync(); const int rc = header_errors(); if (rc) return rc; }
     // match masks for files with at most four coded quality values (a NovaSeq-binned file: ':' ',' '#' and the 0xFF entry the reference's table gets when the
     // N bases have no quality of their own); the most frequent two or three get planes built in LDS, the others are set bit by bit
     const bool masks = fast && !ctx->opt.qual_bytes && ctx->h_hdr.valid && (ctx->h_hdr.flags & H_QUAL_BY_COL) && !(ctx->h_hdr.flags & H_DONT_QUAL) && ctx->h_hdr.n_normal >= 1u && ctx->h_hdr.n_normal <= 4u;
@@ -480,7 +524,18 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // fills them itself (and the flags follow it); the byte-wise path needs the flags first (overlap search on the text, stored prefix).
     HIPCHK(ctx, B[B_ADJ].ensure(3 * nc * 4));
     uint32_t* cbits = B[B_ADJ].as<uint32_t>(); uint32_t* cfail = cbits + nc; uint32_t* redo = cfail + nc;
-    HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
+    // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
+    const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
+    const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
+    HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
+    if (fast) {
+        // every table of the batch that starts all-zero / all-ones, in one launch (k_clear_list)
+        HIPCHK(ctx, B[B_RFLAG].ensure((nr + 15) & ~(size_t)15));
+        ClearList z; memset(&z, 0, sizeof z);
+        z.add(cbits, 2 * nc * 4, 0xFFFFFFFFu); z.add(C.ncount, nc * 4, 0u); z.add(C.nmap, nc * NMAP_WORDS * 4, 0u);
+        z.add(B[B_SEGB].p, nsb * 4, 0u); z.add(B[B_SEGM].p, nsb * 4, 0u); z.add(B[B_SEGC].p, nsb * 4, 0xFFFFFFFFu); z.add(B[B_RFLAG].p, nr, 0u);
+        clear_list(S, z);
+    } else HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
     ctx->timer.begin("chunk_flags", S);
     hipLaunchKernelGGL(k_chunk_bases, dim3((n_chunks + 255) / 256), dim3(256), 0, S, R, C, n_chunks, 1);
     // the stored-base prefix (it needs the mates' overlaps): k_overlap_apply, per-read prefix inputs, their scan, the chunks' bases in the tight streams
@@ -511,21 +566,18 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // (a marker, not a phase: k_gather2 leaves match masks instead of quality bytes - tests and the bench look for it)
     if (masks) { ctx->timer.begin("quality_masks", S); ctx->timer.end(S); }
     ctx->timer.begin(fast ? "gather" : "gather_bytes", S);                  // (which formulation ran: tests and the bench look at it)
-    // the position coder's per-(chunk, stream, 32768-position segment) tables: match counts and last matches are left by the gather
-    const uint32_t pc_max_steps = (hs.max_chunk_bases + 4095u) / 4096u; const uint32_t n_seg = std::max(1u, (pc_max_steps + PC_SEG_STEPS - 1) / PC_SEG_STEPS);
-    const size_t nsb = nc * MAX_STREAMS * (size_t)n_seg;
-    HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
     HIPCHK(ctx, B[B_SPK].ensure((catbytes >> 4) * 4 + 64)); HIPCHK(ctx, B[B_SNM].ensure((catbytes >> 4) * 2 + 64));
-    HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
-    HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S));
-            HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
+    if (!fast) {
+        HIPCHK(ctx, hipMemsetAsync(C.ncount, 0, nc * 4, S)); HIPCHK(ctx, hipMemsetAsync(C.nmap, 0, nc * NMAP_WORDS * 4, S));
+        HIPCHK(ctx, hipMemsetAsync(B[B_SEGB].p, 0, nsb * 4, S)); HIPCHK(ctx, hipMemsetAsync(B[B_SEGM].p, 0, nsb * 4, S));
+                HIPCHK(ctx, hipMemsetAsync(B[B_SEGC].p, 0xFF, nsb * 4, S));
+    }
     uint64_t* const ctot = B[B_CTOTAL].as<uint64_t>(); uint64_t* const cbase = B[B_CBASE].as<uint64_t>(); uint64_t* const ctot_n = B[B_CTOTALN].as<uint64_t>();
             uint64_t* const cbase_n = B[B_CBASEN].as<uint64_t>();
     bool aux_chain = false, coder_waits = false;
     if (fast) {
         const size_t nld = (size_t)(total_bases >> 4) + reads_used + 16;
-        HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2)); HIPCHK(ctx, B[B_RFLAG].ensure(nr));
-        HIPCHK(ctx, hipMemsetAsync(B[B_RFLAG].p, 0, nr, S));
+        HIPCHK(ctx, B[B_LPK].ensure(nld * 4)); HIPCHK(ctx, B[B_LNB].ensure(nld * 2));
         const uint32_t K = 1u << kshift;
         const uint32_t bx = grid_x_for(n_chunks, (max_reads + K - 1) / K, 6u * ctx->n_cu);      // (26 KB of LDS: six workgroups per CU)
         // dynamic LDS of k_gather2: the staged text of K of the batch's longest records (+ slack), read 0's name / strand line, and - match-mask mode - three
@@ -570,10 +622,15 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
                     (const uint32_t*)cfail, redo);
         }
         // the quality streams' scratch plan needs nothing else: the position coder can start as soon as the host has sized its arena
+        // The arenas of the coded streams and the image are sized BEFORE their sizes exist (what the context holds from earlier batches, or a guess from the bases): no
+        // read-back between the gather and the coders, none behind the second chain.  A total beyond its arena raises DE_SCRATCH(N)_SMALL on the device - the coders and
+        // the assembler leave at once - and the batch is repeated with room (RFQ_RETRY_ROOM: once per context as a rule, the arenas keep their size).
+        HIPCHK(ctx, B[B_SCRATCH].ensure(std::max<size_t>(B[B_SCRATCH].cap, (size_t)(total_bases / 8) + nc * 4096 + 256)));
+        HIPCHK(ctx, B[B_SCRATCHN].ensure(std::max<size_t>(B[B_SCRATCHN].cap, (size_t)(total_bases / 64) + nc * 1024 + 256)));
         hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(),
                 n_seg, 1);
         scan_exclusive<uint64_t>(S, ctot, cbase, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst, (uint64_t)B[B_SCRATCH].cap);
         // Second chain (aux stream), beside the position coder: overlap search on the loose slots the gather has just left, stored prefix, sequence packer
         // (tight 2-bit stream + N mask + N counts), the N streams' plan, the image's upper bound.  These are chains of small latency-bound kernels
         // and a search that is VALU-bound; the coder hides them.
@@ -610,7 +667,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         scan_exclusive<uint64_t>(A, ctot_n, cbase_n, n_chunks, tmp2, 1);
         hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, A, T, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
         scan_exclusive<uint64_t>(A, C.img_size, C.img_off, n_chunks, tmp2, 1);
-        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, A, C, (const uint64_t*)cbase_n, n_chunks, 2, dst);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, A, C, (const uint64_t*)cbase_n, n_chunks, 2, dst, (uint64_t)B[B_SCRATCHN].cap);
         KCHK(ctx, "k_gather2");
     } else {
         HIPCHK(ctx, B[B_SCAT].ensure(catbytes));
@@ -628,29 +685,22 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         scan_exclusive<uint64_t>(S, ctot_n, cbase_n, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
         hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, T, R, C, (const DevHeader*)D, L, n_chunks, 0, dst);
         scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst);
-        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase_n, n_chunks, 2, dst);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 0, dst, ~0ull);
+        hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase_n, n_chunks, 2, dst, ~0ull);
         KCHK(ctx, "k_gather");
     }
-    HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
-    if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
-    HIPCHK(ctx, ctx->fetch_sync(S));
-    ctx->timer.end(S);
-    if (hs.err & (DE_BAD_QUAL | DE_BAD_BASE)) {
-        // RfqHeader::makeQualityTable error_exit texts, src/rfqheader.cpp:140-166
-        const uint32_t g = hs.err_read, i = (uint32_t)hs.err_key; std::string ln;
-        if (hs.err & DE_BAD_QUAL) { if (fetch_line(ctx, T, g, 3, ln)) return RFQ_E_HIP; return rfq_fail(ctx, RFQ_E_DATA, "bad quality value: %d", (int)(int8_t)ln[i]); }
-        if (fetch_line(ctx, T, g, 1, ln)) return RFQ_E_HIP;
-        const char b = ln[i];
-        if (b == 'a' || b == 't' || b == 'c') return rfq_fail(ctx, RFQ_E_DATA, "repaq doesn't support FASTQ with lowercase bases (a/t/c/g)\nbut we get:\n%s", ln.c_str());
-        return rfq_fail(ctx, RFQ_E_DATA, "repaq only supports FASTQ with uppercase bases (A/T/C/G/N)\nbut we get:\n%s", ln.c_str());
+    if (!fast) {
+        // byte-wise path: arenas by their exact sizes (a read-back here), the header's verdict with them
+        HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
+        if (make_header) HIPCHK(ctx, ctx->fetch(&ctx->h_hdr, D, sizeof(DevHeader), S));
+        HIPCHK(ctx, ctx->fetch_sync(S));
     }
-    if (hs.err & DE_NO_QUAL_BINS) return rfq_fail(ctx, RFQ_E_DATA, "bad quality string, is this a valid FASTQ file?");
-    if (make_header) { if (!ctx->h_hdr.valid) return rfq_fail(ctx, RFQ_E_HIP, "internal: header was not finalised"); ctx->have_hdr = true; }
+    ctx->timer.end(S);
+    if (!fast) { const int rc = header_errors(); if (rc) return rc; }
     const DevHeader& HH = ctx->h_hdr;
 
     // ---- phase 4: code streams, exact layout, assemble
-    HIPCHK(ctx, B[B_SCRATCH].ensure((size_t)hs.total_scratch + 256));
+    if (!fast) HIPCHK(ctx, B[B_SCRATCH].ensure((size_t)hs.total_scratch + 256));
     HIPCHK(ctx, B[B_XS].ensure(3 * nr + 64)); HIPCHK(ctx, B[B_YS].ensure(3 * nr + 64));
     const uint32_t nqg = (std::min<uint32_t>(HH.n_normal, NPOS_SLOT) + PC_G - 1) / PC_G;              // quality-value streams, PC_G per wave
     // the value streams of a file with many coded quality values (no match masks): the list coder - one wave per (chunk, segment) for all of them, work
@@ -680,19 +730,20 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (!fast && fork_coords) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0)); }
     if (fast) {
         // the quality / exception streams now; the N streams when the second chain has planned them (its totals come back while the coder runs)
-        if (!aux_chain) HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));   // (one stream: the N plan is already in)
         if (coder_waits) HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_ovl, 0));
         { const int rc = launch_coder(S, 0, nqg + 1); if (rc) return rc; }
         // the coordinate coder (one dependent chain of ~100 steps per (axis, chunk)) needs nothing of either chain: behind the coder on the main stream
         hipLaunchKernelGGL(k_coords, dim3(2, n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, B[B_XS].as<uint8_t>(), B[B_YS].as<uint8_t>(), dst);
-        if (aux_chain) { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, ctx->aux)); HIPCHK(ctx, ctx->fetch_sync(ctx->aux)); ovl_guard.armed = false; }
-        else { HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S)); HIPCHK(ctx, ctx->fetch_sync(S)); }
     }
-    HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));
+    if (!fast) HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));
     const uint64_t hdr_bytes = a->emit_header ? HH.len : 0;
     uint8_t* img; uint64_t img_cap;
     if (a->d_out) { img = a->d_out; img_cap = a->out_cap; }
-    else { HIPCHK(ctx, ctx->out_img.ensure((size_t)(hs.image_bound + hdr_bytes + 64))); img = ctx->out_img.as<uint8_t>(); img_cap = ctx->out_img.cap; }
+    else {
+        // (tile path: the image's bound is not on the host - what the context holds, or a third of the text to begin with; k_assemble checks every chunk against the room)
+        const size_t want = fast ? std::max<size_t>(ctx->out_img.cap, (nbytes[0] + nbytes[1]) / 3 + (1u << 20)) : (size_t)(hs.image_bound + hdr_bytes + 64);
+        HIPCHK(ctx, ctx->out_img.ensure(want)); img = ctx->out_img.as<uint8_t>(); img_cap = ctx->out_img.cap;
+    }
     if (hdr_bytes) {
         if (img_cap < hdr_bytes) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small for the header");
         HIPCHK(ctx, hipMemcpyAsync(img, HH.bytes, hdr_bytes, hipMemcpyHostToDevice, S));
@@ -720,7 +771,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             (const uint32_t*)B[B_SEGM].as<uint32_t>(), n_seg, B[B_SEGD].as<uint32_t>(), B[B_SEGS].as<uint32_t>());
     hipLaunchKernelGGL(k_chunk_layout, dim3((n_chunks + 63) / 64), dim3(64), 0, S, T, R, C, (const DevHeader*)D, L, n_chunks, 1, dst);
     scan_exclusive<uint64_t>(S, C.img_size, C.img_off, n_chunks, B[B_SCANTMP].as<uint64_t>(), 1);
-    hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 1, dst);
+    hipLaunchKernelGGL(k_enc_totals, dim3(1), dim3(64), 0, S, C, (const uint64_t*)cbase, n_chunks, 1, dst, ~0ull);
     KCHK(ctx, "k_coords");
     ctx->timer.end(S);
     ctx->timer.begin("assemble", S);
@@ -753,6 +804,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
     HIPCHK(ctx, ctx->fetch_sync(S));
+    ovl_guard.armed = false;                                                // (the second chain was joined in front of the assembler)
     ctx->timer.collect();
     if (hs.err & DE_COORD_RANGE) {
         // RfqCodec::encodeCoords error_exit, src/rfqcodec.cpp:1315-1317: first offender in (chunk, x-before-y, index) order
@@ -764,6 +816,14 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     // (rare: the tail chunk's line-break bits need the normaliser's verdict on a blank line behind the records)
     if ((hs.err & DE_TAIL_BLANK) && !nm) return RFQ_NEED_NORM;
+    if (fast && ((hs.err & (DE_SCRATCH_SMALL | DE_SCRATCHN_SMALL)) || ((hs.err & (1u << 31)) && !a->d_out))) {
+        // an arena (or the context's own image buffer) sized in advance was too small: now that the sizes are known, make room and repeat the batch
+        ovl_guard.sync();
+        HIPCHK(ctx, B[B_SCRATCH].ensure((size_t)hs.total_scratch + 256)); HIPCHK(ctx, B[B_SCRATCHN].ensure((size_t)hs.total_scratch_n + 256));
+        if (!a->d_out) HIPCHK(ctx, ctx->out_img.ensure((size_t)(hs.image_bound + hdr_bytes + 64)));
+        ctx->retried_room = true;
+        return RFQ_RETRY_ROOM;
+    }
     if (hs.err & DE_QUAL_OVERFLOW) return rfq_fail(ctx, RFQ_E_UNPINNED, "quality payload exceeds the reference's 1.5x scratch buffer (reference heap overflow, SURVEY.md App. C Q6)");
     if (hs.err & DE_CORRUPT) return rfq_fail(ctx, RFQ_E_HIP, "internal: a stream exceeded its scratch capacity");
     if (hs.err & (1u << 31)) return rfq_fail(ctx, RFQ_E_NOSPACE, "output buffer too small: need %llu bytes", (unsigned long long)(hs.total_image + hdr_bytes));

@@ -326,3 +326,22 @@ _SHAPES = SH.cases(260, 9000)
 def test_uniform_and_almost_uniform_read_lengths(codec, label, fq1, fq2, paired, cb):
     """closed-form prefixes / cuts where every read has one length, the scans everywhere else - and nothing in between (tests/_shapes.py)"""
     assert E.encode(codec, fq1, fq2, paired, cb) == O.encode_file(fq1, fq2, paired, cb)
+
+
+def test_arenas_sized_in_advance_grow_and_the_batch_repeats():
+    """The tile path sizes the stream arenas and its own image buffer before their sizes exist (no read-back between gather and coders); a fresh context meets a file
+    that codes most positions (forty quality values: image 0.77 of the text, scratch far beyond bases / 8): DE_SCRATCH_SMALL -> room is made, the batch repeated
+    (marker `retry_room`), the image is the oracle's; the next batch of the same context has room and does not repeat."""
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    try:
+        fq1, fq2 = O.gen(O.BGI_PE100, 300, seed=5, n_quals=40)
+        want = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 10000)
+        assert E.encode(c, fq1, fq2, O.PE_TWO_FILES, 10000) == want
+        assert "retry_room" in dict(c.timings())
+        assert E.encode(c, fq1, fq2, O.PE_TWO_FILES, 10000) == want
+        assert "retry_room" not in dict(c.timings())
+        se, _ = O.gen(O.SE_VAR, 600, seed=3)                        # reads of several lengths on a context that expected one: the scans run after all
+        assert E.encode(c, se, b"", O.SE, 15000) == O.encode_file(se, b"", O.SE, 15000)
+    finally:
+        c.close()
