@@ -13,6 +13,7 @@
 // Everything else - the lists' exact entry ranges from the cell index, wave-per-list rounds, the next tile's metadata requested a tile ahead - carries over from the tile
 // emitter this kernel replaced.
 #define E3_QCAP 10240u            // quality tile: K reads' qualities (64 x 160)
+#define E3_SHARED_OK 1             // 0: never take the SHARED instantiation (A/B on the box: tools/build_variant.sh)
 #define E3_N1BIG 13312u           // name1 tile of the second instantiation: 64 per-read names of 200 bytes (34 KB of LDS, four workgroups per CU)
 struct __attribute__((packed, aligned(1))) GU16d { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) GU8d { uint32_t a, b; };
@@ -49,7 +50,11 @@ __device__ __forceinline__ uint32_t e3_rev1x16(uint32_t v) {
 __device__ __forceinline__ uint32_t e3_from(int t, int i) { const int k = t - 4 * i; return k <= 0 ? 0xFFFFFFFFu : (k >= 4 ? 0u : 0xFFFFFFFFu << (8 * k)); }
 // v_alignbyte_b32
 __device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes) { return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * bytes)); }
-template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds__(256, N1CAP == ET_N1CAP ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img,
+// SHARED: every chunk of the range shares its three name pieces among its reads (C_NAME1_SAME, C_NAME2_SAME, C_STRAND_SAME: what FastqMeta::parse leaves of a sequencer's
+// names; the walk's summary knows - DecStatus::per_read_pieces == 0).  That instantiation carries no per-read piece prefixes: a tile's uniform parameters are four words
+// instead of ten, three of the four staging waves' branches, the piece offsets and the fit tests of the pieces are gone - the tile loop kept ~110 wave-uniform values
+// alive, more than a wave has SGPRs.
+template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ void __launch_bounds__(256, N1CAP == ET_N1CAP ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img,
         const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DFused F,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const plist_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
@@ -74,12 +79,13 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
     uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + K - 1u) & ~(K - 1u);                 // whole tiles per workgroup (K is even: pairs stay together)
     const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
     if (rs >= re) return;
-    const bool raw = (hf & H_DONT_QUAL) != 0, bycol = !raw && (hf & H_QUAL_BY_COL);
+    // (SHARED is only taken for files with coded qualities: raw quality bytes - more than 64 values, rare - keep the general instantiation)
+    const bool raw = !SHARED && (hf & H_DONT_QUAL) != 0, bycol = SHARED || (!raw && (hf & H_QUAL_BY_COL));
     const uint32_t nn = bycol ? (D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT) : 0u; const bool hasn = (hf & H_N_POS) != 0;
     const uint32_t T = nn + (hasn ? 1u : 0u);                                // streams of the tile: t < nn quality value t, t == nn the N positions
     const uint32_t major4 = (D->major & 0xFFu) * 0x01010101u;
     const uint32_t qlen_c = F.pql[fp + d.reads], slen_c = F.pvl[fp + d.reads].d;                // qualities / stored bases of the chunk
-    const bool same1 = (fl & C_NAME1_SAME) != 0, same2 = (fl & C_NAME2_SAME) != 0, same3 = (fl & C_STRAND_SAME) != 0;
+    const bool same1 = SHARED || (fl & C_NAME1_SAME) != 0, same2 = SHARED || (fl & C_NAME2_SAME) != 0, same3 = SHARED || (fl & C_STRAND_SAME) != 0;
     if (tid < T) { const uint32_t jj = tid < nn ? tid : D->n_normal; const size_t t_ = (size_t)c * nstr + jj; s_loff[tid] = loff[t_]; s_nent[tid] = nent[t_];
             s_val[tid] = tid < nn ? (uint32_t)D->normal[tid] : (uint32_t)'N'; }
     // exception records behind the streams (src/rfqcodec.cpp:1034-1043)
@@ -98,9 +104,10 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
     // a tile's uniform parameters: quality / stored-base / name-piece prefixes at its first read and behind its last
     struct TileP { uint32_t q0, q1, s0, s1, a7, a8, a9, e7, e8, e9; };
     auto tile_params = [&](uint32_t r0, uint32_t r1) -> TileP {
-        TileP t; const U4 a = F.pvl[fp + r0], b = F.pvl[fp + r1];
-        t.q0 = uni32(F.pql[fp + r0]); t.q1 = uni32(F.pql[fp + r1]); t.s0 = uni32(a.d); t.s1 = uni32(b.d);
-        t.a7 = uni32(a.a); t.a8 = uni32(a.b); t.a9 = uni32(a.c); t.e7 = uni32(b.a); t.e8 = uni32(b.b); t.e9 = uni32(b.c);
+        TileP t; t.q0 = uni32(F.pql[fp + r0]); t.q1 = uni32(F.pql[fp + r1]);
+        if constexpr (SHARED) { t.s0 = uni32(F.pvl[fp + r0].d); t.s1 = uni32(F.pvl[fp + r1].d); t.a7 = t.a8 = t.a9 = t.e7 = t.e8 = t.e9 = 0u; }
+        else { const U4 a = F.pvl[fp + r0], b = F.pvl[fp + r1]; t.s0 = uni32(a.d); t.s1 = uni32(b.d);
+               t.a7 = uni32(a.a); t.a8 = uni32(a.b); t.a9 = uni32(a.c); t.e7 = uni32(b.a); t.e8 = uni32(b.b); t.e9 = uni32(b.c); }
         return t;
     };
     uint32_t cur = rs, pb = 0;
@@ -168,8 +175,10 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP> __global__ void __launch_bounds_
         const uint32_t r = cur + j; const bool on = j < cnt; const bool odd = (r & 1u) != 0, rc = il && odd, to2 = split && odd;
         uint32_t len = 0, n1 = 0, n2 = 0, sl = 0, md = 0, prevlen = 0, sp = 0, qp_ = 0, o7 = 0, o8 = 0, o9 = 0; int ov = 0; uint32_t toff = 0;
         if (on) {
-            const uint32_t g_ = f + r; const uint2 t2 = F.tpl[g_]; const U4 p4 = F.pvl[fp + r];
-            toff = (to2 ? tb.b : tb.a) + t2.x; sp = p4.d - s0; qp_ = F.pql[fp + r] - q0; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9;
+            const uint32_t g_ = f + r; const uint2 t2 = F.tpl[g_];
+            if constexpr (SHARED) sp = F.pvl[fp + r].d - s0;
+            else { const U4 p4 = F.pvl[fp + r]; sp = p4.d - s0; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9; }
+            toff = (to2 ? tb.b : tb.a) + t2.x; qp_ = F.pql[fp + r] - q0;
             len = F.len[g_]; ov = F.ov[g_]; prevlen = odd ? F.len[g_ - 1] : 0u;
             n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)]; n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
             sl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)]; md = t2.y;

@@ -255,6 +255,10 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
                 if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
                 else hipLaunchKernelGGL((k_dec_emit3<true, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             }
+            else if (E3_SHARED_OK && !g.pieces && !(HH.flags & H_DONT_QUAL)) {                                          // (every chunk shares its name pieces among its reads: the instantiation without per-read piece prefixes)
+                if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, ET_N1CAP, true>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+                else hipLaunchKernelGGL((k_dec_emit3<true, ET_N1CAP, true>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
+            }
             else if (HH.flags & H_N_POS) hipLaunchKernelGGL(k_dec_emit3<false>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             else hipLaunchKernelGGL(k_dec_emit3<true>, dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
 #undef RFQ_EMIT3_ARGS
