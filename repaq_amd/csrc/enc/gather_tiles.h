@@ -13,6 +13,7 @@
 //     src/rfqcodec.cpp:590-604) and the same u16 slots of `lnb`.  No stored-base prefix and no overlap result is needed here:
 //     k_seqpack applies them (overlap trim, compaction to the chunk's tight 2-bit stream + N bit mask).
 #define G2_CAP 23552u             // staged text of a tile (64 x 357-byte records are 22.9 KB)
+#define G2_SE_OK 1                // 0: never take the single-end instantiation (A/B on the box: tools/build_variant.sh)
 #define G2_CNT 256u               // replicated quality counters (see QualCount)
 struct __attribute__((packed, aligned(1))) GU16g { uint32_t a, b, c, d; };
 // four bases -> four 2-bit codes (exact upper-case A/C/G/T, anything else 0), four "is N" bits, four "neither" bits
@@ -447,7 +448,8 @@ __global__ void k_mask_bounds(const uint32_t* __restrict__ pq, const uint32_t* _
 // phase 1: every chunk, mates taken for interleaved wherever the header allows it (the names that decide are parsed in this very pass), names parsed and
 // compared; phase 2: only the chunks k_chunk_flags_b marked in `only` - their interleave test failed somewhere - once more with the mates as they stand.
 // Dynamic LDS: [text4 x 16 bytes of staged text, slack included][read 0's name and strand line][MASKS: three planes of M.pw words].
-template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
+// PE = false: single-end input - no second stream, no mates, nothing stored back to front: the instantiation drops those paths and the values they keep alive
+template <bool MASKS, bool PE = true> __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
                                                  uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, uint32_t text4, G2Planes M) {
@@ -472,7 +474,7 @@ template <bool MASKS> __global__ void __launch_bounds__(256, 6) k_gather2(Text T
         if (tid < 4u) s_carry[tid] = 0u;
     }
     const uint32_t f = first[c], e = first[c + 1];
-    const bool two = T.paired == 1, can0 = T.paired != 0 && D->support_interleaved != 0, il = can0 && !redo;
+    const bool two = PE && T.paired == 1, can0 = PE && T.paired != 0 && D->support_interleaved != 0, il = can0 && !redo;
     const uint32_t dpos = D->name2_diff_pos, dch = D->name2_diff_char;
     uint8_t* const qd = qcat + qbase[c]; const uint32_t pq0 = pq[f];
     uint32_t per = ((e - f) + gridDim.x - 1) / gridDim.x; per = (per + 1u) & ~1u;       // whole pairs per workgroup

@@ -615,7 +615,10 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
                     M.planes, M.pstride, (const DevHeader*)D, M.nd, bx, only);
 #define RFQ_G2_ARGS T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_RFLAG].as<uint8_t>(), \
                     B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, cbits, cfail, only, text4, M
-            if (masks) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
+            // (single-end input with match masks: the instantiation without mates - 132 spilled SGPRs instead of 182, no VGPR in scratch; the byte-stream form of it
+            // spills 64 VGPRs instead and is not used)
+            if (masks && !is_pe && G2_SE_OK) hipLaunchKernelGGL((k_gather2<true, false>), dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
+            else if (masks) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
             else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
 #undef RFQ_G2_ARGS
             if (phase == 1) hipLaunchKernelGGL(k_chunk_flags_b, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, is_pe ? 1 : 0, (const uint32_t*)cbits,
