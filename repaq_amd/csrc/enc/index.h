@@ -160,6 +160,25 @@ template <int NLF_T> __global__ void __launch_bounds__(256) k_line_index(const u
     }
     if (blk == 0 && threadIdx.x == 0) lo[0] = skip;
 }
+// What the host used to read back behind the index (line totals, last bytes) and do with it (k_line_tail, records -> units), on the device: the kernels up to the
+// partition take their unit count from st->idx_units, the host learns everything with the partition's results - one round trip less per batch.  guess: the units the
+// host sized the per-read tables for (from the bytes per record of the context's earlier batches); more than that: DE_UNITS_GUESS, the batch is repeated the slow way.
+__global__ void k_index_totals(const uint32_t* __restrict__ tot0, const uint32_t* __restrict__ tot1, const uint8_t* __restrict__ fq0, uint32_t n0, const uint8_t* __restrict__ fq1, uint32_t n1,
+                               uint32_t* lo0, uint32_t* lo1, int final_batch, int paired, uint32_t unit_cap, uint32_t guess, DevStatus* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t rec[2] = { 0, 0 };
+    for (int s = 0; s < (paired == 1 ? 2 : 1); s++) {
+        const uint32_t nl = s ? *tot1 : *tot0, n = s ? n1 : n0; const uint8_t* fq = s ? fq1 : fq0; uint32_t* lo = s ? lo1 : lo0;
+        // (an unterminated tail is the file's last line only in the final batch)
+        const uint32_t unterm = (final_batch && n > 0 && fq[n - 1] != '\n') ? 1u : 0u;
+        if (unterm) lo[nl + 1] = n + 1;
+        st->idx_lines[s] = n ? nl + unterm : 0u; rec[s] = n ? (nl + unterm) / 4 : 0u;
+    }
+    uint32_t units = paired == 0 ? rec[0] : (paired == 1 ? (rec[0] < rec[1] ? rec[0] : rec[1]) : rec[0] / 2);
+    if (units > unit_cap) units = unit_cap;
+    st->idx_units_true = units; st->idx_units = units < guess ? units : guess;
+    if (units > guess) atomicOr(&st->err, (uint32_t)DE_UNITS_GUESS);
+}
 __global__ void k_line_tail(uint32_t* lo, uint32_t n_newlines, uint32_t n, int unterminated) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && unterminated) lo[n_newlines + 1] = n + 1;
 }

@@ -147,7 +147,9 @@ __global__ void k_chunk_ends(Text T, const uint32_t* __restrict__ first, uint32_
 // Every read of the batch has the same number of bases L - sequencer output, as a rule - : the base prefix of read g is g x L, no scan needed.  One workgroup reduces
 // k_read_lens' block summaries to uni[0] = 1 / 0, uni[1] = L; the two prefix scans behind it (units, reads: six launches over 11 M / 22 M elements on the headline
 // workload, 0.25 ms) look at uni[0] and leave at once, k_fill_pq writes the closed form instead, and k_partition's uniform branch never needs the unit prefix.
-__global__ void k_lens_uniform(const uint32_t* __restrict__ blk, uint32_t n_blk, uint32_t n_units, uint32_t* __restrict__ uni) {
+// (nu, here and in the kernels below: null, or the device word that holds the unit count - k_index_totals' st->idx_units - when the host launched without it)
+__global__ void k_lens_uniform(const uint32_t* __restrict__ blk, uint32_t n_blk, uint32_t n_units, uint32_t* __restrict__ uni, const uint32_t* __restrict__ nu) {
+    if (nu) n_units = *nu;
     __shared__ uint32_t s_a[16], s_b[16];
     uint32_t ml = 0, msl = 0xFFFFFFFFu;
     for (uint32_t i = threadIdx.x; i < n_blk; i += blockDim.x) { const uint32_t a = blk[LENS_BLK * i + 3], b = blk[LENS_BLK * i + 4]; if (a > ml) ml = a; if (b < msl) msl = b; }
@@ -157,13 +159,15 @@ __global__ void k_lens_uniform(const uint32_t* __restrict__ blk, uint32_t n_blk,
     if (threadIdx.x == 0) { for (uint32_t i = 1; i < (blockDim.x >> 6); i++) { if (s_a[i] > ml) ml = s_a[i]; if (s_b[i] < msl) msl = s_b[i]; }
             uni[0] = (n_units > 0 && ml == msl && ml > 0) ? 1u : 0u; uni[1] = ml; }
 }
-__global__ void k_fill_pq(uint32_t* __restrict__ pq, uint32_t n_reads, const uint32_t* __restrict__ uni) {
+__global__ void k_fill_pq(uint32_t* __restrict__ pq, uint32_t n_reads, const uint32_t* __restrict__ uni, const uint32_t* __restrict__ nu, uint32_t upr) {
+    if (nu) n_reads = *nu * upr;
     if (!uni[0]) return;                                                     // (uniform: mixed lengths took the scan)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, L = uni[1];
     if (g <= n_reads) pq[g] = g * L;                                         // (entry n_reads: the total; < 2^32: a call's stream is < 4 GiB of text)
 }
 __global__ void k_read_lens(Text T, uint32_t* __restrict__ len, uint32_t* __restrict__ stored, uint64_t* __restrict__ ulen, uint32_t n_units, uint32_t upr,
-        uint32_t* __restrict__ blk_minmax, DevStatus* st) {
+        uint32_t* __restrict__ blk_minmax, DevStatus* st, const uint32_t* __restrict__ nu) {
+    if (nu) n_units = *nu;
     __shared__ uint32_t s_mn[4], s_mx[4], s_rc[4], s_ml[4], s_sl[4];
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t tot = 0; uint32_t rec = 0, ml = 0, msl = 0xFFFFFFFFu, err = 0, fe = 0xFFFFFFFFu;   // rec: bytes of the unit's longest record, ml: bases of its longest read
@@ -212,7 +216,8 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
 // carry: bases the chunk that is open at unit 0 has taken from the text in front of this batch (plan pass of a share, rfq_encode_args.carry_bases)
 __global__ void k_partition(const uint64_t* __restrict__ P, uint32_t n_units, uint32_t upr, uint32_t chunk_bases, uint32_t carry, int final_batch,
                             const uint32_t* __restrict__ blk_minmax, uint32_t n_blk, uint32_t* __restrict__ first, uint32_t cap_chunks, DevStatus* st, const uint32_t* __restrict__ uni,
-                            int have_scans) {
+                            int have_scans, const uint32_t* __restrict__ nu) {
+    if (nu) n_units = *nu;
     const int l = lane_id();
     // have_scans = 0: the host launched neither prefix scan (it expects reads of one length - what a sequencer writes - and saves their six launches); reads of
     // several lengths say so and leave: the host runs the scans and this kernel once more

@@ -283,8 +283,15 @@ struct Gpu {
     // one job runs at a time, and a job's other contexts (verifier, per-device workers and ingestion of --devices) are still its own
     explicit Gpu(int dev, bool main_ctx = false) {
         static std::map<int, rfq_ctx*> kept; static std::mutex km;
+        // what the switches were when the context was made (the RFQ_* environment at rfq_create): a lent context goes to every job in that state, whatever
+        // a job before it set (only the header was reset between jobs)
+        static std::map<int, std::vector<std::pair<std::string, std::string>>> made;
         if (g_serve && main_ctx) { std::unique_lock<std::mutex> lk(km); auto it = kept.find(dev);
-                if (it == kept.end()) { if (rfq_create(&c, dev) != RFQ_OK) error_exit("no usable MI355X / HIP device (repaq_hip has no CPU fallback)"); kept[dev] = c; } else c = it->second;
+                if (it == kept.end()) {
+                    if (rfq_create(&c, dev) != RFQ_OK) error_exit("no usable MI355X / HIP device (repaq_hip has no CPU fallback)");
+                    kept[dev] = c;
+                    for (int i = 0; rfq_option_name(i); i++) { char v[64] = ""; if (rfq_get_option(c, rfq_option_name(i), v, sizeof v) == RFQ_OK) made[dev].emplace_back(rfq_option_name(i), v); }
+                } else { c = it->second; for (auto& kv : made[dev]) (void)rfq_set_option(c, kv.first.c_str(), kv.second.empty() ? nullptr : kv.second.c_str()); }
                 leased = true; rfq_clear_header(c); return; }
         if (rfq_create(&c, dev) != RFQ_OK) error_exit("no usable MI355X / HIP device (repaq_hip has no CPU fallback)");
     }

@@ -52,6 +52,7 @@
 #define DE_SCRATCH_SMALL   (1u << 12) // encode: the stream scratch the host sized in advance (no read-back between gather and coder) is too small: the coders and the assembler leave, the host grows it and repeats the batch
 #define DE_SCRATCHN_SMALL  (1u << 13) // ... the N-position streams' arena
 #define DE_NEED_SCAN       (1u << 14) // encode: reads of several lengths - the closed-form prefixes do not apply, the host runs the scans and the partition again
+#define DE_UNITS_GUESS     (1u << 15) // encode: the batch holds more units than the host sized its tables for without waiting for the index's totals: once more, with the totals
 #define DE_TAIL_BLANK      (1u << 9)  // an empty line in the \n-only text right behind the encoded records: blank or empty is for the normaliser to say
 
 // Device-resident file header + derived tables (RfqHeader, src/rfqheader.h:44-108)
@@ -94,6 +95,9 @@ struct DevStatus {
     uint32_t max_rec;           // longest record (four lines with their terminators) in bytes
     uint32_t unit_bases;        // bases of every cut unit when they are all the same, else 0
     uint32_t max_len;           // longest read (bases)
+    // k_index_totals (no read-back behind the line index): lines of each stream (an unterminated last line of a final batch included), the units they hold, and
+    // the units the batch's kernels work on - min(true, what the host sized its tables for)
+    uint32_t idx_lines[2], idx_units_true, idx_units;
 };
 
 struct U4 { uint32_t a, b, c, d; };

@@ -141,6 +141,9 @@ struct rfq_ctx {
     // generic named buffers (see rfq_encode.hip / rfq_decode.hip)
     DBuf b[120];
     DBuf out_img, out_fq1, out_fq2, out_acc, out_acc1, out_acc2;       // out_acc*: the results of a sliced encode / decode call, appended
+    // encode without a read-back behind the line index: records per byte of the last batch (0: not known yet - the first batch of a context reads back), and
+    // "this call repeats a batch the lazy form could not take"
+    double rec_per_byte = 0.0; bool lazy_block = false;
     bool retried_room = false;             // encode: the call in progress repeats a batch whose arenas were too small (a marker for rfq_last_timings)
     bool mixed_lengths = false;            // encode: this file has reads of several lengths (the prefix scans are launched up front; reset with the header)
     bool dense_ok = false;                 // encode, match-mask mode: DevHeader::dense of the device header is set (k_dense_order; reset with the header)

@@ -254,6 +254,19 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     for (int s = 0; s < nstreams; s++) nidx[s] = (uint32_t)((nbytes[s] + idx_tiles * 16384u - 1) / (idx_tiles * 16384u));
     uint32_t n_newlines[2] = { 0, 0 }; uint8_t lastbyte[2] = { '\n', '\n' };
     bool one_pass = !ctx->opt.index_2pass;
+    // LAZY: no read-back behind the index.  The per-read tables are sized for a unit count guessed from the records per byte of the context's earlier batches; the
+    // index's totals stay on the device (k_index_totals: lines, units, the unterminated tail) and reach the host with the partition's results.  A batch that holds
+    // more units than guessed, an index that has to fall back to two passes: once more with the read-back (ctx->lazy_block).
+    const bool lazy_allowed = !ctx->lazy_block; ctx->lazy_block = false;
+    bool lazy = one_pass && lazy_allowed && ctx->rec_per_byte > 0.0 && !ctx->mixed_lengths && unit_cap == ~0u && !ended;
+    uint32_t guess_units = 0;
+    if (lazy) {
+        double g = 1e300;
+        for (int s = 0; s < nstreams; s++) g = std::min(g, (double)nbytes[s] * ctx->rec_per_byte * 1.03 + 64.0);
+        if (a->paired == RFQ_PE_INTERLEAVED) g *= 0.5;
+        if (g > 2.0e9 || g < 1.0) lazy = false; else guess_units = (uint32_t)g;
+        for (int s = 0; s < nstreams; s++) if (!nblk[s]) lazy = false;
+    }
     if (one_pass) {
         size_t cap[2] = { 0, 0 };
         for (int s = 0; s < nstreams; s++) {
@@ -268,12 +281,21 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             auto kern = idx_tiles == 16 ? k_line_index<16> : (idx_tiles == 4 ? k_line_index<4> : k_line_index<8>);
             hipLaunchKernelGGL(kern, dim3(nidx[s]), dim3(256), 0, S, fq[s], (uint32_t)nbytes[s], skip[s], B[B_LO0 + s].as<uint32_t>(), lo_cap, state, tt, tt + 1, dst);
             KCHK(ctx, "k_line_index");
+            if (lazy) continue;
             HIPCHK(ctx, ctx->fetch(&n_newlines[s], tt + 1, 4, S));
             HIPCHK(ctx, ctx->fetch(&lastbyte[s], fq[s] + nbytes[s] - 1, 1, S));
         }
+        if (lazy) {
+            const uint32_t* t0 = (const uint32_t*)(B[B_BLK0].as<unsigned long long>() + nidx[0]) + 1;
+            const uint32_t* t1 = nstreams == 2 ? (const uint32_t*)(B[B_BLK1].as<unsigned long long>() + nidx[1]) + 1 : t0;
+            hipLaunchKernelGGL(k_index_totals, dim3(1), dim3(64), 0, S, t0, t1, fq[0], (uint32_t)nbytes[0], fq[1], (uint32_t)nbytes[1], B[B_LO0].as<uint32_t>(),
+                               nstreams == 2 ? B[B_LO1].as<uint32_t>() : (uint32_t*)nullptr, a->final ? 1 : 0, (int)a->paired, unit_cap, guess_units, dst);
+            KCHK(ctx, "k_index_totals");
+        } else {
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
-        if (hs.err & DE_INDEX_RETRY) {                                                    // start over with a clean status block
+        }
+        if (!lazy && (hs.err & DE_INDEX_RETRY)) {                                                    // start over with a clean status block
             one_pass = false;
             memset(&hs, 0, sizeof hs); hs.err_key = ~0ull; hs.coord_key = ~0ull; hs.first_empty = ~0u;
             HIPCHK(ctx, hipMemcpyAsync(dst, &hs, sizeof hs, hipMemcpyHostToDevice, S));
@@ -305,9 +327,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
     }
-    if (hs.err & DE_HAS_CR) return nm ? rfq_fail(ctx, RFQ_E_HIP, "internal: '\\r' in normalised text") : RFQ_NEED_NORM;
+    if (!lazy && (hs.err & DE_HAS_CR)) return nm ? rfq_fail(ctx, RFQ_E_HIP, "internal: '\\r' in normalised text") : RFQ_NEED_NORM;
     uint32_t nlines[2] = { 0, 0 }, nrec[2] = { 0, 0 };
-    for (int s = 0; s < nstreams; s++) {
+    for (int s = 0; s < nstreams && !lazy; s++) {
         // an unterminated tail is the file's last line only in the final batch; in a non-final batch it is a line cut by the
         // batch boundary and belongs to the next batch
         const int unterm = a->final && nbytes[s] > 0 && lastbyte[s] != '\n';
@@ -321,6 +343,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         }
     }
     ctx->timer.end(S);
+    // (a marker, not a phase: the index's totals stay on the device until the partition's read-back - tests look for it)
+    if (lazy) { ctx->timer.begin("lazy_index", S); ctx->timer.end(S); }
 
     // ---- phase 2: read table, chunk cuts
     Text T; memset(&T, 0, sizeof T);
@@ -329,7 +353,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     T.paired = a->paired; T.upr = a->paired == RFQ_SE ? 1u : 2u;
     uint32_t n_units = a->paired == RFQ_SE ? nrec[0] : (a->paired == RFQ_PE_TWO_FILES ? std::min(nrec[0], nrec[1]) : nrec[0] / 2);
     if (n_units > unit_cap) n_units = unit_cap;                       // the reader stopped at an empty line (src/fastqreader.cpp:180-191)
-    const uint32_t n_reads = n_units * T.upr; T.n_reads = n_reads;
+    if (lazy) n_units = guess_units;                                  // (what the tables are sized for; the true count comes back with the partition)
+    uint32_t n_reads = n_units * T.upr; T.n_reads = n_reads;
+    const uint32_t* const nu = lazy ? &dst->idx_units : (const uint32_t*)nullptr;      // where the kernels up to the partition find the unit count
     res->d_rfq = nullptr;
     if (n_units == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
     const bool is_pe = a->paired != RFQ_SE;
@@ -356,11 +382,11 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     // the reads that need them earlier (chunk 0 of a first batch: the file header) / on the byte-wise gather path (all of them)
     const uint32_t ublocks = (n_units + 255) / 256;
     HIPCHK(ctx, B[B_MINMAX].ensure(((size_t)ublocks + 2) * LENS_BLK * 4));
-    hipLaunchKernelGGL(k_read_lens, dim3(ublocks), dim3(256), 0, S, T, R.len, R.stored, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>(), dst);
+    hipLaunchKernelGGL(k_read_lens, dim3(ublocks), dim3(256), 0, S, T, R.len, R.stored, B[B_ULEN].as<uint64_t>(), n_units, T.upr, B[B_MINMAX].as<uint32_t>(), dst, nu);
     KCHK(ctx, "k_read_lens");
     // every read the same length (sequencer output): both prefixes have a closed form - the scans see the flag and return, k_fill_pq writes g x L (no host round trip)
     uint32_t* const uni = B[B_MINMAX].as<uint32_t>() + (size_t)ublocks * LENS_BLK;
-    hipLaunchKernelGGL(k_lens_uniform, dim3(1), dim3(1024), 0, S, (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, n_units, uni);
+    hipLaunchKernelGGL(k_lens_uniform, dim3(1), dim3(1024), 0, S, (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, n_units, uni, nu);
     // The two prefix scans (units for the cut, reads for the base prefix: six launches) see `uni` and return at once when every read has L bases.  A context that has
     // not met reads of several lengths in this file does not even launch them: k_partition says DE_NEED_SCAN if they were needed after all, and scans + partition run
     // then - one more round trip, once per file (ctx->mixed_lengths stays up until the header is cleared).
@@ -370,7 +396,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     };
     bool have_scans = ctx->mixed_lengths;
     if (have_scans) prefix_scans();
-    hipLaunchKernelGGL(k_fill_pq, dim3(n_reads / 256 + 1), dim3(256), 0, S, R.pq, n_reads, (const uint32_t*)uni);
+    hipLaunchKernelGGL(k_fill_pq, dim3(n_reads / 256 + 1), dim3(256), 0, S, R.pq, n_reads, (const uint32_t*)uni, nu, T.upr);
     const uint64_t cap64 = (uint64_t)(nbytes[0] + nbytes[1]) / (2ull * a->chunk_bases) + 3;
     const uint32_t cap_chunks = (uint32_t)std::min<uint64_t>(cap64, (uint64_t)n_units + 1);
     HIPCHK(ctx, B[B_FIRST].ensure(((size_t)cap_chunks + 2) * 4));
@@ -380,7 +406,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     if (a->carry_bases >= a->chunk_bases) return rfq_fail(ctx, RFQ_E_ARG, "carry_bases must be < chunk_bases");
     for (;;) {
         hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, S, (const uint64_t*)(B[B_P].as<uint64_t>() + 1), n_units, T.upr, a->chunk_bases, a->carry_bases, fin ? 1 : 0,
-                           (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst, (const uint32_t*)uni, have_scans ? 1 : 0);
+                           (const uint32_t*)B[B_MINMAX].as<uint32_t>(), ublocks, C.first, cap_chunks + 1, dst, (const uint32_t*)uni, have_scans ? 1 : 0, nu);
         KCHK(ctx, "k_partition");
         HIPCHK(ctx, ctx->fetch(&hs, dst, sizeof hs, S));
         HIPCHK(ctx, ctx->fetch_sync(S));
@@ -389,6 +415,16 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     }
     hs.err &= ~(uint32_t)DE_NEED_SCAN;
     ctx->timer.end(S);
+    if (lazy) {
+        // the index's verdict, which the other form reads right behind it
+        if (hs.err & (DE_INDEX_RETRY | DE_UNITS_GUESS | DE_NEED_SCAN)) { ctx->lazy_block = true; if (hs.err & DE_NEED_SCAN) ctx->mixed_lengths = true;
+                return encode_impl(ctx, a, res, nm, unit_cap, ended, scan_only, skip); }
+        if (hs.err & DE_HAS_CR) return nm ? rfq_fail(ctx, RFQ_E_HIP, "internal: '\\r' in normalised text") : RFQ_NEED_NORM;
+        for (int s = 0; s < nstreams; s++) { nlines[s] = hs.idx_lines[s]; nrec[s] = nlines[s] / 4; }
+        n_units = hs.idx_units_true; n_reads = n_units * T.upr; T.n_reads = n_reads;
+        if (n_units == 0) { ctx->chunk_off.assign(1, 0); res->h_chunk_off = ctx->chunk_off.data(); return RFQ_OK; }
+    }
+    { double r = 0.0; for (int s = 0; s < nstreams; s++) if (nbytes[s]) r = std::max(r, (double)nrec[s] / (double)nbytes[s]); if (r > 0.0) ctx->rec_per_byte = r; }
     if (hs.err & DE_EMPTY_LINE) {
         // "\n\n" is a swallowed blank line, not an empty one: classify the text properly first.  On normalised text an empty line is
         // where FastqReader::read returns NULL (src/fastqreader.cpp:180-191): the record and everything after it are never read.

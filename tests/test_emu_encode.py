@@ -345,3 +345,29 @@ def test_arenas_sized_in_advance_grow_and_the_batch_repeats():
         assert E.encode(c, se, b"", O.SE, 15000) == O.encode_file(se, b"", O.SE, 15000)
     finally:
         c.close()
+
+
+def test_no_read_back_behind_the_index_from_the_second_batch_on():
+    """A context that knows the records per byte of an earlier batch sizes its per-read tables from that and leaves the index's totals on the device (marker
+    `lazy_index`: one round trip less); a batch that holds more units than guessed - much shorter records - is encoded again with the read-back, and the
+    guess follows the new shape.  Every image is the oracle's."""
+    from repaq_amd import RfqCodec
+    c = RfqCodec(device=0, library=E.build_emu())
+    try:
+        fq1, fq2 = O.gen(O.NOVA_PE150, 400, seed=4, nonl=2)
+        want = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 20000)
+        assert E.encode(c, fq1, fq2, O.PE_TWO_FILES, 20000) == want and "lazy_index" not in dict(c.timings())      # the first batch of a context reads back
+        assert E.encode(c, fq1, fq2, O.PE_TWO_FILES, 20000) == want and "lazy_index" in dict(c.timings())
+        import _shapes as SH
+        short, _ = SH.fastq([20] * 3000, None, 31)                                    # records of ~100 bytes instead of ~360: three times the units per byte
+        assert E.encode(c, short, b"", O.SE, 9000) == O.encode_file(short, b"", O.SE, 9000)
+        assert "lazy_index" not in dict(c.timings())                                  # (the repeat took the read-back)
+        assert E.encode(c, short, b"", O.SE, 9000) == O.encode_file(short, b"", O.SE, 9000) and "lazy_index" in dict(c.timings())
+        se, _ = O.gen(O.NOVA_SE150, 500, seed=9)                                     # fewer units than guessed: fine
+        assert E.encode(c, se, b"", O.SE, 30000) == O.encode_file(se, b"", O.SE, 30000) and "lazy_index" in dict(c.timings())
+        il, _ = O.gen(O.NOVA_PE150, 300, seed=4, interleaved=True)
+        assert E.encode(c, il, b"", O.PE_INTERLEAVED, 20000) == O.encode_file(il, b"", O.PE_INTERLEAVED, 20000)
+        crlf = se.replace(b"\n", b"\r\n")                                             # '\r' is only seen behind the partition now: the normalising path all the same
+        assert E.encode(c, crlf, b"", O.SE, 30000) == O.encode_file(crlf, b"", O.SE, 30000)
+    finally:
+        c.close()
