@@ -449,10 +449,14 @@ __global__ void k_mask_bounds(const uint32_t* __restrict__ pq, const uint32_t* _
 // compared; phase 2: only the chunks k_chunk_flags_b marked in `only` - their interleave test failed somewhere - once more with the mates as they stand.
 // Dynamic LDS: [text4 x 16 bytes of staged text, slack included][read 0's name and strand line][MASKS: three planes of M.pw words].
 // PE = false: single-end input - no second stream, no mates, nothing stored back to front: the instantiation drops those paths and the values they keep alive
-template <bool MASKS, bool PE = true> __global__ void __launch_bounds__(256, 6) k_gather2(Text T, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
+// PAIRED = 0 / 1 / 2: the input's pairing (RFQ_SE / RFQ_PE_TWO_FILES / RFQ_PE_INTERLEAVED) as a compile-time constant - every read_loc, every "which stream" select and, for
+// single-end input, the mates' whole path fold away; -1: taken from the argument
+template <bool MASKS, int PAIRED = -1> __global__ void __launch_bounds__(256, 6) k_gather2(Text T_, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
                                                  uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
                                                  uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, uint32_t text4, G2Planes M) {
+    Text T = T_; if (PAIRED >= 0) T.paired = PAIRED;
+    constexpr bool PE = PAIRED != 0;
     RFQ_DYN_SHARED(uint4, g2_lds);
     __shared__ uint32_t sh[MASKS ? 1 : G2_CNT]; __shared__ int sh_last[MASKS ? 1 : G2_CNT]; __shared__ uint8_t s_slot[MASKS ? 16 : 256];
             __shared__ uint32_t s_r0[8], s_carry[4];

@@ -653,7 +653,8 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
                     B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, cbits, cfail, only, text4, M
             // (single-end input with match masks: the instantiation without mates - 132 spilled SGPRs instead of 182, no VGPR in scratch; the byte-stream form of it
             // spills 64 VGPRs instead and is not used)
-            if (masks && !is_pe && G2_SE_OK) hipLaunchKernelGGL((k_gather2<true, false>), dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
+            if (masks && !is_pe && G2_SE_OK) hipLaunchKernelGGL((k_gather2<true, 0>), dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
+            else if (masks && a->paired == RFQ_PE_TWO_FILES && G2_SE_OK) hipLaunchKernelGGL((k_gather2<true, 1>), dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
             else if (masks) hipLaunchKernelGGL(k_gather2<true>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
             else hipLaunchKernelGGL(k_gather2<false>, dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
 #undef RFQ_G2_ARGS
