@@ -347,12 +347,13 @@ def pmc_traffic_live(workload, chunk_kb, units, seed, timeout_s=300):
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
-            got[counter] = P.per_kernel(dbs[0], counter)
+            got[counter] = P.per_kernel(dbs[0], counter, last_step=True)
     except Exception as e:                               # noqa: BLE001
         return None, "%s: %s" % (type(e).__name__, e)
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    passes = 2.0                                         # the child runs the step twice (one warm-up, one timed); counters are summed over both
+    passes = 1.0                                         # the child runs the step twice (one warm-up, one timed); the counters of the LAST step are taken (a warm-up step
+                                                         # of a fresh context may repeat a batch whose arenas it sized too small)
     ker = {}
     for k in set(got["FETCH_SIZE"]) | set(got["WRITE_SIZE"]):
         nf, vf = got["FETCH_SIZE"].get(k, (0, 0.0)); nw, vw = got["WRITE_SIZE"].get(k, (0, 0.0))

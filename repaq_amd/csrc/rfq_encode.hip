@@ -665,7 +665,9 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
         // The arenas of the coded streams and the image are sized BEFORE their sizes exist (what the context holds from earlier batches, or a guess from the bases): no
         // read-back between the gather and the coders, none behind the second chain.  A total beyond its arena raises DE_SCRATCH(N)_SMALL on the device - the coders and
         // the assembler leave at once - and the batch is repeated with room (RFQ_RETRY_ROOM: once per context as a rule, the arenas keep their size).
-        HIPCHK(ctx, B[B_SCRATCH].ensure(std::max<size_t>(B[B_SCRATCH].cap, (size_t)(total_bases / 8) + nc * 4096 + 256)));
+        // (the header tells the two shapes apart: a file with at most four coded quality values - match masks - codes a few percent of its positions; one with
+        // forty codes most of them, a byte or so each)
+        HIPCHK(ctx, B[B_SCRATCH].ensure(std::max<size_t>(B[B_SCRATCH].cap, (size_t)(masks ? total_bases / 8 : total_bases + total_bases / 4) + nc * 4096 + 256)));
         HIPCHK(ctx, B[B_SCRATCHN].ensure(std::max<size_t>(B[B_SCRATCHN].cap, (size_t)(total_bases / 64) + nc * 1024 + 256)));
         hipLaunchKernelGGL(k_stream_plan, dim3(n_chunks), dim3(64), 0, S, R, C, (const DevHeader*)D, ctot, ctot_n, n_chunks, (const uint32_t*)B[B_SEGM].as<uint32_t>(),
                 n_seg, 1);
@@ -780,8 +782,10 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     uint8_t* img; uint64_t img_cap;
     if (a->d_out) { img = a->d_out; img_cap = a->out_cap; }
     else {
-        // (tile path: the image's bound is not on the host - what the context holds, or a third of the text to begin with; k_assemble checks every chunk against the room)
-        const size_t want = fast ? std::max<size_t>(ctx->out_img.cap, (nbytes[0] + nbytes[1]) / 3 + (1u << 20)) : (size_t)(hs.image_bound + hdr_bytes + 64);
+        // (tile path: the image's bound is not on the host - what the context holds, or a third of the text to begin with (7/8 of it for a file with many coded quality
+        // values); k_assemble checks every chunk against the room)
+        const size_t nb_all = nbytes[0] + nbytes[1];
+        const size_t want = fast ? std::max<size_t>(ctx->out_img.cap, (masks ? nb_all / 3 : nb_all - nb_all / 8) + (1u << 20)) : (size_t)(hs.image_bound + hdr_bytes + 64);
         HIPCHK(ctx, ctx->out_img.ensure(want)); img = ctx->out_img.as<uint8_t>(); img_cap = ctx->out_img.cap;
     }
     if (hdr_bytes) {

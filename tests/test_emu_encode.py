@@ -329,20 +329,33 @@ def test_uniform_and_almost_uniform_read_lengths(codec, label, fq1, fq2, paired,
 
 
 def test_arenas_sized_in_advance_grow_and_the_batch_repeats():
-    """The tile path sizes the stream arenas and its own image buffer before their sizes exist (no read-back between gather and coders); a fresh context meets a file
-    that codes most positions (forty quality values: image 0.77 of the text, scratch far beyond bases / 8): DE_SCRATCH_SMALL -> room is made, the batch repeated
-    (marker `retry_room`), the image is the oracle's; the next batch of the same context has room and does not repeat."""
+    """The tile path sizes the stream arenas and its own image buffer before their sizes exist (no read-back between gather and coders) - from what the context holds,
+    or from the header's shape (few coded quality values: a few percent of the positions are coded).  A fresh context meets a file whose four quality values are equally
+    frequent - three positions in four are coded, far beyond bases / 8: DE_SCRATCH_SMALL -> room is made, the batch repeated (marker `retry_room`), the image is the
+    oracle's; the next batch of the same context has room and does not repeat.  The forty-value shape is sized right at once (its header says so)."""
+    import random
     from repaq_amd import RfqCodec
+    rng = random.Random(5)
+    recs = []
+    for i in range(2400):
+        seq = bytes(rng.choice(b"ACGT") for _ in range(150)); q = bytes(rng.choice(b"F:,5") for _ in range(150))
+        recs.append(b"@M:1:FC:1:%d:%d:%d 1:N:0:AC\n" % (1101 + i // 500, rng.randrange(1000, 30000), rng.randrange(1000, 60000)) + seq + b"\n+\n" + q + b"\n")
+    fq = b"".join(recs)
     c = RfqCodec(device=0, library=E.build_emu())
     try:
-        fq1, fq2 = O.gen(O.BGI_PE100, 300, seed=5, n_quals=40)
-        want = O.encode_file(fq1, fq2, O.PE_TWO_FILES, 10000)
-        assert E.encode(c, fq1, fq2, O.PE_TWO_FILES, 10000) == want
-        assert "retry_room" in dict(c.timings())
-        assert E.encode(c, fq1, fq2, O.PE_TWO_FILES, 10000) == want
+        want = O.encode_file(fq, b"", O.SE, 100000)
+        assert E.encode(c, fq, b"", O.SE, 100000) == want
+        assert "retry_room" in dict(c.timings()) and "quality_masks" in dict(c.timings())
+        assert E.encode(c, fq, b"", O.SE, 100000) == want
         assert "retry_room" not in dict(c.timings())
         se, _ = O.gen(O.SE_VAR, 600, seed=3)                        # reads of several lengths on a context that expected one: the scans run after all
         assert E.encode(c, se, b"", O.SE, 15000) == O.encode_file(se, b"", O.SE, 15000)
+    finally:
+        c.close()
+    c = RfqCodec(device=0, library=E.build_emu())
+    try:
+        fq1, fq2 = O.gen(O.BGI_PE100, 300, seed=5, n_quals=40)
+        assert E.encode(c, fq1, fq2, O.PE_TWO_FILES, 10000) == O.encode_file(fq1, fq2, O.PE_TWO_FILES, 10000) and "retry_room" not in dict(c.timings())
     finally:
         c.close()
 

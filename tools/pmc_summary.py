@@ -8,9 +8,21 @@ import sqlite3
 import sys
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, last_step=False):
+    """{kernel: (dispatches, sum of the counter)}.  last_step: only the dispatches of the LAST bench step (from its first line-index kernel on) - a warm-up step may hold
+    work a timed step never does (round 6: the repeat of a batch whose arenas a fresh context sized too small)."""
     cur = sqlite3.connect(path).cursor()
-    rows = cur.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name", (counter,)).fetchall()
+    if last_step:
+        allr = cur.execute("select name, start, counter_value from pmc_events where counter_name=? order by start", (counter,)).fetchall()
+        idx = [i for i, r in enumerate(allr) if "k_line_index" in r[0] or "k_nl_bitmap" in r[0]]
+        starts = [i for k, i in enumerate(idx) if k == 0 or i - idx[k - 1] > 6]
+        i0 = starts[-1] if starts else 0
+        agg = {}
+        for name, _, v in allr[i0:]:
+            a = agg.get(name, (0, 0.0)); agg[name] = (a[0] + 1, a[1] + (v or 0.0))
+        rows = [(k, n, v) for k, (n, v) in agg.items()]
+    else:
+        rows = cur.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name", (counter,)).fetchall()
     # (kernels templated on switches are reported under their plain name - k_gather2<false, 23552u> -> k_gather2 -, launches of several
     # instantiations of one kernel are added up; the scans keep their element type: k_scan_apply<U4>)
     import re
