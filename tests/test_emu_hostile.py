@@ -5,7 +5,7 @@ import pytest
 import _engine as E
 import _hostile as H
 
-COUNTS = dict(flip=20, header=8, fixed=16, lengths=10, quality=8, index=12)
+COUNTS = dict(flip=12, header=6, fixed=10, lengths=6, quality=6, index=12)
 
 
 @pytest.fixture(scope="module")
@@ -19,5 +19,5 @@ def codec():
 
 @pytest.mark.parametrize("mode", [(), (("RFQ_MATERIALISE", "1"), ("RFQ_WALK", "exact"))], ids=["default", "materialise+exact_walk"])
 def test_hostile_images_are_refused_or_decoded_and_leave_no_state(codec, mode):
-    s = H.run(codec, modes=(mode,), counts=COUNTS, good_every=6, tame=True, time_bound_s=30.0)
-    assert s["mutants"] >= 300 and s["good_checks"] >= 50 and s["errors"].get("FORMAT", 0) > 50 and s["decoded"] > 50, s
+    s = H.run(codec, modes=(mode,), counts=COUNTS, good_every=8, tame=True, time_bound_s=30.0)
+    assert s["mutants"] >= 250 and s["good_checks"] >= 30 and s["errors"].get("FORMAT", 0) > 50 and s["decoded"] > 50, s
