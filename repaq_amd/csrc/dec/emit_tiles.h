@@ -84,7 +84,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
     const uint32_t nn = bycol ? (D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT) : 0u; const bool hasn = (hf & H_N_POS) != 0;
     const uint32_t T = nn + (hasn ? 1u : 0u);                                // streams of the tile: t < nn quality value t, t == nn the N positions
     const uint32_t major4 = (D->major & 0xFFu) * 0x01010101u;
-    const uint32_t qlen_c = F.pql[fp + d.reads], slen_c = F.pvl[fp + d.reads].d;                // qualities / stored bases of the chunk
+    const uint32_t qlen_c = F.pql[fp + d.reads], slen_c = F.sdl[fp + d.reads];                // qualities / stored bases of the chunk
     const bool same1 = SHARED || (fl & C_NAME1_SAME) != 0, same2 = SHARED || (fl & C_NAME2_SAME) != 0, same3 = SHARED || (fl & C_STRAND_SAME) != 0;
     if (tid < T) { const uint32_t jj = tid < nn ? tid : D->n_normal; const size_t t_ = (size_t)c * nstr + jj; s_loff[tid] = loff[t_]; s_nent[tid] = nent[t_];
             s_val[tid] = tid < nn ? (uint32_t)D->normal[tid] : (uint32_t)'N'; }
@@ -105,8 +105,9 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
     struct TileP { uint32_t q0, q1, s0, s1, a7, a8, a9, e7, e8, e9; };
     auto tile_params = [&](uint32_t r0, uint32_t r1) -> TileP {
         TileP t; t.q0 = uni32(F.pql[fp + r0]); t.q1 = uni32(F.pql[fp + r1]);
-        if constexpr (SHARED) { t.s0 = uni32(F.pvl[fp + r0].d); t.s1 = uni32(F.pvl[fp + r1].d); t.a7 = t.a8 = t.a9 = t.e7 = t.e8 = t.e9 = 0u; }
-        else { const U4 a = F.pvl[fp + r0], b = F.pvl[fp + r1]; t.s0 = uni32(a.d); t.s1 = uni32(b.d);
+        t.s0 = uni32(F.sdl[fp + r0]); t.s1 = uni32(F.sdl[fp + r1]);
+        if constexpr (SHARED) { t.a7 = t.a8 = t.a9 = t.e7 = t.e8 = t.e9 = 0u; }
+        else { const U4 a = F.pvl[fp + r0], b = F.pvl[fp + r1];
                t.a7 = uni32(a.a); t.a8 = uni32(a.b); t.a9 = uni32(a.c); t.e7 = uni32(b.a); t.e8 = uni32(b.b); t.e9 = uni32(b.c); }
         return t;
     };
@@ -176,8 +177,8 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
         uint32_t len = 0, n1 = 0, n2 = 0, sl = 0, md = 0, prevlen = 0, sp = 0, qp_ = 0, o7 = 0, o8 = 0, o9 = 0; int ov = 0; uint32_t toff = 0;
         if (on) {
             const uint32_t g_ = f + r; const uint2 t2 = F.tpl[g_];
-            if constexpr (SHARED) sp = F.pvl[fp + r].d - s0;
-            else { const U4 p4 = F.pvl[fp + r]; sp = p4.d - s0; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9; }
+            sp = F.sdl[fp + r] - s0;
+            if constexpr (!SHARED) { const U4 p4 = F.pvl[fp + r]; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9; }
             toff = (to2 ? tb.b : tb.a) + t2.x; qp_ = F.pql[fp + r] - q0;
             len = F.len[g_]; ov = F.ov[g_]; prevlen = odd ? F.len[g_ - 1] : 0u;
             n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)]; n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;

@@ -38,14 +38,15 @@ __global__ void k_dec_readtab(const uint8_t* __restrict__ img, const DChunk* __r
 struct DFused {
     const uint32_t* len; const int32_t* ov;
     const uint32_t* pql;        // [rbase + c + r]: qualities (= bases) of the chunk in front of read r; entry `reads` = the chunk's total
-    const U4* pvl;              // ... (name1, name2, strand piece bytes; stored bases) in front of read r
+    const U4* pvl;              // ... (name1, name2, strand piece bytes; stored bases) in front of read r; null where every chunk shares its name pieces (the three sums are all zero there)
+    const uint32_t* sdl;        // ... the stored bases alone (pvl[].d): what the emitter's SHARED instantiation reads - 4 bytes per read instead of 16
     const uint2* tpl;           // [rbase + r]: x = text bytes of the chunk in front of read r in ITS output (out1, or out2 for a split decode's mates), y = bytes of its name middle
     // mid: [g][E3_MIDROW]: the formatted ":lane:tile:x:y" middle of the name, zero-padded (":255:65535:4294967295:4294967295" is 32 bytes: the row; its length rides in tpl.y)
     const U4* tbase;            // [c]: text bytes in front of chunk c (a: out1, b: out2); entry n_chunks = the range's totals
     const uint8_t* mid;
 };
 __global__ void __launch_bounds__(256) k_dec_readtab2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
-                                                      uint32_t* __restrict__ len_o, int32_t* __restrict__ ov_o, uint32_t* __restrict__ pql, U4* __restrict__ pvl, DecStatus* st) {
+                                                      uint32_t* __restrict__ len_o, int32_t* __restrict__ ov_o, uint32_t* __restrict__ pql, U4* __restrict__ pvl, uint32_t* __restrict__ sdl, DecStatus* st) {
     const uint32_t c = blockIdx.x; const DChunk d = CH[c];
     const uint8_t* cp = img + d.off; const uint32_t fl = d.flags, hf = D->flags, rlb = D->read_len_bytes, shift = (uint32_t)D->overlap_shift;
     const bool ovl = (fl & C_PE_INTERLEAVED) && (hf & H_PE_OVERLAP);
@@ -77,10 +78,10 @@ __global__ void __launch_bounds__(256) k_dec_readtab2(const uint8_t* __restrict_
         U4 tot; uint32_t qtot;
         U4 run = carry + block_excl_sum<U4>(sum, &tot); uint32_t qrun = qcarry + block_excl_sum<uint32_t>(qsum, &qtot);
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const uint32_t r = rb + (uint32_t)i; if (r < d.reads) { pvl[fp + r] = run; pql[fp + r] = qrun; } run = run + v[i]; qrun += ln[i]; }
+        for (int i = 0; i < 4; i++) { const uint32_t r = rb + (uint32_t)i; if (r < d.reads) { if (pvl) pvl[fp + r] = run; sdl[fp + r] = run.d; pql[fp + r] = qrun; } run = run + v[i]; qrun += ln[i]; }
         carry = carry + tot; qcarry += qtot;
     }
-    if (threadIdx.x == 0) { pvl[fp + d.reads] = carry; pql[fp + d.reads] = qcarry; }
+    if (threadIdx.x == 0) { if (pvl) pvl[fp + d.reads] = carry; sdl[fp + d.reads] = carry.d; pql[fp + d.reads] = qcarry; }
     if (__any(bad != 0) && lane_id() == 0) atomicOr(&st->err, (uint32_t)DE_CORRUPT_OV);
 }
 // aligned bases of each chunk inside the concatenated quality / stored-sequence buffers

@@ -11,7 +11,7 @@
 int rfq_upload_header(rfq_ctx* c, const uint8_t* h, size_t n);   // rfq_encode.hip
 
 enum DecBuf {   // indices into rfq_ctx::b (disjoint from the encoder's, so one context can alternate encode / decode)
-    DB_CHUNKS = 80, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_SEGK, DB_NENT, DB_LOFF, DB_PLIST, DB_GWCAND, DB_GWLIST, DB_GWCNT, DB_GWLAND, DB_PQL, DB_PVL, DB_TPL, DB_CTEXT, DB_TBASE, DB_END
+    DB_CHUNKS = 80, DB_STATUS, DB_LEN, DB_CHUNKID, DB_OV, DB_PVIN, DB_PV, DB_PQ, DB_TIN, DB_TP, DB_QBASE, DB_SBASE, DB_QDEC, DB_SDEC, DB_XV, DB_YV, DB_SCAN, DB_MID, DB_SEGF, DB_SEGA, DB_SEGN, DB_SEGS, DB_SEGP, DB_OFFT, DB_CELL, DB_SEGK, DB_NENT, DB_LOFF, DB_PLIST, DB_GWCAND, DB_GWLIST, DB_GWCNT, DB_GWLAND, DB_PQL, DB_PVL, DB_TPL, DB_CTEXT, DB_TBASE, DB_SDL, DB_END
 };
 static_assert(DB_END <= 120, "rfq_ctx::b too small");
 
@@ -120,10 +120,16 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     if (fused) {
         // chunk-local prefixes made where the per-read values are made (k_dec_readtab2): no per-read scan inputs, no batch-wide scans, no read-back here - the
         // status word is looked at with the next one, the range's bases are the walk's 64-bit total
-        HIPCHK(ctx, B[DB_PQL].ensure((nr + nc) * 4)); HIPCHK(ctx, B[DB_PVL].ensure((nr + nc) * 16)); HIPCHK(ctx, B[DB_TPL].ensure(nr * 8));
+        HIPCHK(ctx, B[DB_PQL].ensure((nr + nc) * 4)); HIPCHK(ctx, B[DB_TPL].ensure(nr * 8));
+        if (g.pieces || !E3_SHARED_OK || (HH.flags & H_DONT_QUAL)) HIPCHK(ctx, B[DB_PVL].ensure((nr + nc) * 16));
         HIPCHK(ctx, B[DB_CTEXT].ensure(nc * 16)); HIPCHK(ctx, B[DB_TBASE].ensure(nc * 16)); HIPCHK(ctx, B[DB_SCAN].ensure((nc / SCAN_TILE + 2) * 16 + 1024));
-        F.len = R.len; F.ov = R.ov; F.pql = B[DB_PQL].as<uint32_t>(); F.pvl = B[DB_PVL].as<U4>(); F.tpl = B[DB_TPL].as<uint2>(); F.tbase = B[DB_TBASE].as<U4>(); F.mid = R.mid;
-        hipLaunchKernelGGL(k_dec_readtab2, dim3(n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R.len, R.ov, B[DB_PQL].as<uint32_t>(), B[DB_PVL].as<U4>(), dst);
+        // (the per-read piece prefixes only where some chunk stores pieces per read: sequencer names leave none, and the stored-base prefix alone is 4 bytes per read instead of 16)
+        const bool shared_pieces = E3_SHARED_OK && !g.pieces && !(HH.flags & H_DONT_QUAL);
+        HIPCHK(ctx, B[DB_SDL].ensure((nr + nc) * 4));
+        F.len = R.len; F.ov = R.ov; F.pql = B[DB_PQL].as<uint32_t>(); F.pvl = shared_pieces ? (const U4*)nullptr : B[DB_PVL].as<U4>(); F.sdl = B[DB_SDL].as<uint32_t>();
+        F.tpl = B[DB_TPL].as<uint2>(); F.tbase = B[DB_TBASE].as<U4>(); F.mid = R.mid;
+        hipLaunchKernelGGL(k_dec_readtab2, dim3(n_chunks), dim3(256), 0, S, a->d_rfq, CH, D, R.len, R.ov, B[DB_PQL].as<uint32_t>(), shared_pieces ? (U4*)nullptr : B[DB_PVL].as<U4>(),
+                           B[DB_SDL].as<uint32_t>(), dst);
         KCHK(ctx, "k_dec_readtab2");
         ctx->timer.end(S);
         *nbases = g.bases;
@@ -255,7 +261,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
                 if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
                 else hipLaunchKernelGGL((k_dec_emit3<true, E3_N1BIG>), dim3(b4, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             }
-            else if (E3_SHARED_OK && !g.pieces && !(HH.flags & H_DONT_QUAL)) {                                          // (every chunk shares its name pieces among its reads: the instantiation without per-read piece prefixes)
+            else if (F.pvl == nullptr) {                                          // (every chunk shares its name pieces among its reads: the instantiation without per-read piece prefixes)
                 if (HH.flags & H_N_POS) hipLaunchKernelGGL((k_dec_emit3<false, ET_N1CAP, true>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
                 else hipLaunchKernelGGL((k_dec_emit3<true, ET_N1CAP, true>), dim3(b3, n_chunks), dim3(256), 0, S, RFQ_EMIT3_ARGS);
             }
