@@ -415,6 +415,10 @@ __global__ void __launch_bounds__(256) k_chunk_prefix(Text T, ReadTab R, ChunkTa
         int8_t* __restrict__ ovb) {
     const uint32_t c = blockIdx.x, f = C.first[c], e = C.first[c + 1], tid = threadIdx.x;
     const bool enc = C.il[c] != 0 && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
+    // the three name-piece prefixes only where the chunk stores a piece per read (k_assemble_names' test): a sequencer's names leave none, and the line table, the
+    // parsed name lengths and the 16-byte prefix entries are then neither read nor written - the stored-base prefix alone (R.sd) is what k_seqpack needs
+    const uint32_t fl = C.flags[c];
+    const bool pieces = !(fl & C_NAME1_SAME) || ((D->flags & H_NAME2) && !(fl & C_NAME2_SAME)) || !(fl & C_STRAND_SAME);
     U4 carry; carry.a = carry.b = carry.c = carry.d = 0;
     for (uint32_t base = f; base < e; base += 1024u) {                     // block-uniform
         U4 v[4]; U4 acc; acc.a = acc.b = acc.c = acc.d = 0;
@@ -422,7 +426,6 @@ __global__ void __launch_bounds__(256) k_chunk_prefix(Text T, ReadTab R, ChunkTa
         for (int i = 0; i < 4; i++) {
             const uint32_t g = base + 4u * tid + (uint32_t)i; v[i].a = v[i].b = v[i].c = v[i].d = 0;
             if (g < e) {
-                int s_; uint32_t r_; read_loc(T, g, s_, r_); const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);
                 uint32_t st = R.len[g];
                 if (enc && ((g - f) & 1u)) {
                     int ov = ovraw[g >> 1];
@@ -430,13 +433,15 @@ __global__ void __launch_bounds__(256) k_chunk_prefix(Text T, ReadTab R, ChunkTa
                     if (ov + shift < -127) ov = 0;
                     ovb[g >> 1] = (int8_t)(ov + shift); st -= (uint32_t)(ov < 0 ? -ov : ov); R.stored[g] = st;
                 }
-                v[i].a = R.name1_len[g]; v[i].b = (lo4.y - 1u - lo4.x) - R.name2_off[g]; v[i].c = lo4.w - 1u - lo4.z; v[i].d = st;
+                if (pieces) { int s_; uint32_t r_; read_loc(T, g, s_, r_); const uint4 lo4 = *(const uint4*)(t_lo(T, s_) + 4 * (size_t)r_);
+                        v[i].a = R.name1_len[g]; v[i].b = (lo4.y - 1u - lo4.x) - R.name2_off[g]; v[i].c = lo4.w - 1u - lo4.z; }
+                v[i].d = st;
                 acc = acc + v[i];
             }
         }
         U4 tot; U4 run = carry + block_excl_sum<U4>(acc, &tot);
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const uint32_t g = base + 4u * tid + (uint32_t)i; if (g < e) { R.pv[g] = run; run = run + v[i]; } }
+        for (int i = 0; i < 4; i++) { const uint32_t g = base + 4u * tid + (uint32_t)i; if (g < e) { if (pieces) R.pv[g] = run; R.sd[g] = run.d; run = run + v[i]; } }
         carry = carry + tot;
     }
     if (tid == 0) { C.ptot[c] = carry; C.sbase[c] = C.qbase[c]; }          // (the tight streams are laid out like the qualities: stored <= len)

@@ -606,14 +606,14 @@ __device__ __forceinline__ uint32_t loose_nbits(const uint16_t* __restrict__ lnb
 #define SP_U 3                    // tight dwords per thread whose loads are in flight together (1 .. 3 measure the same beside the coder, 4 and more cost the stage 0.15 ms: registers)
 struct __attribute__((packed, aligned(4))) SpU8 { uint32_t a, b; };
 struct __attribute__((packed, aligned(2))) SpU4 { uint32_t a; };
-__global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const U4* __restrict__ pv, const U4* __restrict__ ptot,
+__global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const uint32_t* __restrict__ sd, const U4* __restrict__ ptot,
         const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
                                                  const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
                                                  uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
                                                  uint32_t rshift) {
     __shared__ uint32_t s_sd[256 + SP_EXTRA + 1], s_ld[256 + SP_EXTRA], s_sk[256 + SP_EXTRA]; __shared__ uint8_t s_own[SP_OWN];
     const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1], tid = threadIdx.x;
-    const uint32_t ps0 = pv[f].d, S = ptot[c].d;
+    const uint32_t ps0 = sd[f], S = ptot[c].d;
     const bool il = ilv[c] != 0, enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
     uint32_t* const ok = spk + (size_t)(sbase[c] >> 4); uint16_t* const on = snm + (size_t)(sbase[c] >> 4);
     const uint32_t nshift = nmap_shift(S); uint32_t* const nm = nmap + (size_t)c * NMAP_WORDS;
@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
         const uint32_t nr = e - r0 < R ? e - r0 : R, nx = e - r0 < R + SP_EXTRA ? e - r0 : R + SP_EXTRA;    // my reads; reads with LDS entries
         // ---- phase 1
         for (uint32_t t = tid; t <= nx; t += blockDim.x) {
-            const uint32_t g = r0 + t; s_sd[t] = g < e ? pv[g].d - ps0 : S;  // (pv[e] belongs to the next chunk)
+            const uint32_t g = r0 + t; s_sd[t] = g < e ? sd[g] - ps0 : S;  // (sd[e] belongs to the next chunk)
             if (t < nx) { s_ld[t] = (pq[g] >> 4) + g; s_sk[t] = skip_of(g); }
         }
         __syncthreads();
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
                 while (filled < need) {                                         // (rare) reads of a few bases in a row, or reads beyond the step's LDS entries
                     uint32_t a, b, l2, s2;
                     if (jj < nx) { a = s_sd[jj]; b = s_sd[jj + 1]; l2 = s_ld[jj]; s2 = s_sk[jj]; }
-                    else { const uint32_t gg = r0 + jj; a = pv[gg].d - ps0; b = gg + 1u < e ? pv[gg + 1].d - ps0 : S; l2 = (pq[gg] >> 4) + gg; s2 = skip_of(gg); }
+                    else { const uint32_t gg = r0 + jj; a = sd[gg] - ps0; b = gg + 1u < e ? sd[gg + 1] - ps0 : S; l2 = (pq[gg] >> 4) + gg; s2 = skip_of(gg); }
                     const uint32_t avail = b - a;
                     if (avail) {
                         const uint32_t take = avail < need - filled ? avail : need - filled;

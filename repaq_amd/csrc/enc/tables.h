@@ -40,6 +40,8 @@ struct ReadTab {                 // per-read arrays, indexed by g (interleaved o
     U4*       pv;                // exclusive prefix of (name1_len, name2_len, strand_len, stored): only differences inside one chunk are ever used (pv[g] - pv[first[c]];
                                  // the chunk's totals: ChunkTab::ptot) - the tile path restarts it at 0 in every chunk (k_chunk_prefix), the byte-wise path scans the
                                  // whole batch
+    uint32_t* sd;                // tile path: the stored-base component of pv alone (chunk-local; k_seqpack reads 4 bytes per read instead of one word of every 16); pv itself
+                                 // is written only for chunks that store a name piece per read (k_chunk_prefix)
 };
 
 struct ChunkTab {                // per-chunk arrays

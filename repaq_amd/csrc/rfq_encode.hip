@@ -13,7 +13,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_QPLANE, B_SEGD, B_SEGS, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_QPLANE, B_SEGD, B_SEGS, B_SD, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 80, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -378,6 +378,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     R.tile = B[B_TILE].as<uint16_t>(); R.lane = B[B_LANE].as<uint8_t>(); R.ok = B[B_OK].as<uint8_t>(); R.chunk = B[B_CHUNK].as<uint32_t>();
             R.stored = B[B_STORED].as<uint32_t>();
     R.eq2 = B[B_EQ2].as<uint8_t>(); R.pq = B[B_PQ].as<uint32_t>(); R.pv = B[B_PV].as<U4>();
+    HIPCHK(ctx, B[B_SD].ensure(nr * 4)); R.sd = B[B_SD].as<uint32_t>();
     // sequence lengths come from the line table alone; the names are parsed where the text is staged anyway (k_gather2), or by k_read_table for
     // the reads that need them earlier (chunk 0 of a first batch: the file header) / on the byte-wise gather path (all of them)
     const uint32_t ublocks = (n_units + 255) / 256;
@@ -698,7 +699,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             // reads per step of k_seqpack: as many as keep the step's tight dwords inside its owner table (a read of L bases owns at most L / 16 + 1)
             uint32_t rshift = 8; while (rshift && ((uint64_t)(max_len / 16u + 1u) << rshift) > SP_OWN) rshift--;
             uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
-            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), aux_chain ? ctx->opt.sp_pad : 0u, A, (const uint32_t*)R.pq, (const U4*)R.pv, (const U4*)C.ptot,
+            hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), aux_chain ? ctx->opt.sp_pad : 0u, A, (const uint32_t*)R.pq, (const uint32_t*)R.sd, (const U4*)C.ptot,
                     (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
                                (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
                                C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift);
