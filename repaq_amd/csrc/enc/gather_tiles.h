@@ -115,7 +115,7 @@ __device__ __forceinline__ G2Read g2_read(const Text& T, const G2MRaw& r, const 
 // my share (groups part, part + P, ...) of my read's sequence line: 16 bases per step -> one dword of codes + 16 N bits into the read's loose slot, in STORED
 // orientation (an interleaved chunk's mate reverse-complemented, src/rfqcodec.cpp:371-407) but untrimmed: k_seqpack skips what the overlap with R1 implies
 __device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb,
-        uint8_t* __restrict__ rflag) {
+        uint8_t* __restrict__ rflag, uint8_t* __restrict__ rn) {
     const uint32_t ng = (m.len + 15u) >> 4;
     for (uint32_t gi = part; gi < ng; gi += P) {
         uint32_t w[4], code = 0, nbits = 0;
@@ -150,11 +150,12 @@ __device__ __forceinline__ void g2_bases(const uint8_t* s_text, const G2Read& m,
         code >>= 2u * tsh; nbits >>= tsh;
         if (nv0 < 16u) { code &= (1u << (2u * nv0)) - 1u; nbits &= (1u << nv0) - 1u; }   // (what lies outside the line is not the read's)
         lpk[m.ld + gi] = code; lnb[m.ld + gi] = (uint16_t)nbits;
+        if (nbits) rn[m.gi] = 1;                                           // (the read holds an N: whoever reads the loose slots' N bits asks this first - one read in a few hundred does)
     }
 }
 // my share (groups part, part + P, ...) of my read's two lines: qualities -> qcat, bases -> the loose slot
 __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& m, uint32_t part, uint32_t P, uint8_t* qd, uint32_t* __restrict__ lpk,
-        uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag, QualCount& qc) {
+        uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag, uint8_t* __restrict__ rn, QualCount& qc) {
     if (!m.on) return;
     {
         // ---- qualities: text -> qcat (an interleaved chunk's mate back to front), counted on the way
@@ -172,7 +173,7 @@ __device__ __forceinline__ void g2_compose(const uint8_t* s_text, const G2Read& 
             }
         } else for (uint32_t i = part; i < n; i += P) { const uint8_t q = s_text[rc ? m.qsrc + n - 1u - i : m.qsrc + i]; o[i] = q; qc(m.qpos + i, q); }
     }
-    g2_bases(s_text, m, part, P, lpk, lnb, rflag);
+    g2_bases(s_text, m, part, P, lpk, lnb, rflag, rn);
 }
 // FastqMeta::parse + RfqCodec::encodeChunk's pass 1 (src/fastqmeta.cpp:22-80, src/rfqcodec.cpp:220-263) for the reads of the tile k_gather2 has staged:
 // the name line is in LDS already, so the text is not fetched a third time for the names (the separate read-table pass cost 8.1 GB / 1.9 ms
@@ -453,7 +454,7 @@ __global__ void k_mask_bounds(const uint32_t* __restrict__ pq, const uint32_t* _
 // single-end input, the mates' whole path fold away; -1: taken from the argument
 template <bool MASKS, int PAIRED = -1> __global__ void __launch_bounds__(256, 6) k_gather2(Text T_, ReadTab R, const uint32_t* __restrict__ first, const uint64_t* __restrict__ qbase,
                                                  const DevHeader* __restrict__ D, uint8_t* __restrict__ qcat, uint32_t* __restrict__ lpk, uint16_t* __restrict__ lnb, uint8_t* __restrict__ rflag,
-                                                 uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
+                                                 uint8_t* __restrict__ rn, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg, uint32_t kshift,
                                                  uint32_t* __restrict__ cbits, uint32_t* __restrict__ cfail, const uint32_t* __restrict__ only, uint32_t text4, G2Planes M) {
     Text T = T_; if (PAIRED >= 0) T.paired = PAIRED;
     constexpr bool PE = PAIRED != 0;
@@ -534,8 +535,8 @@ template <bool MASKS, int PAIRED = -1> __global__ void __launch_bounds__(256, 6)
             if (tid < nd && s_carry[tid]) atomicOr(&pl[tid * M.pw], s_carry[tid]);       // the word the tile in front left unfinished
             g2_quals_masks(tx, m, part, P, pl, M.pw, qbeg & ~31u, nd, pat0, pat1, pat2, patm, D, qd, gpl, M.pstride, segm + (size_t)c * MAX_STREAMS * n_seg,
                     segc + (size_t)c * MAX_STREAMS * n_seg, n_seg, M.rare + (size_t)c * (1u + G2_RARE_LIST));
-            g2_bases(tx, m, part, P, lpk, lnb, rflag);
-        } else g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, qc);
+            g2_bases(tx, m, part, P, lpk, lnb, rflag, rn);
+        } else g2_compose(tx, m, part, P, qd, lpk, lnb, rflag, rn, qc);
         __syncthreads();                                                    // the text is free for the next tile; the tile's counts / planes are complete
         if (t + 1u < ntile) g2_stage(T, two, g2_geo(b1, b2, two), buf4, tid);  // the next tile's text is on its way while the planes / counters of this one leave
         if (MASKS) {
@@ -608,10 +609,13 @@ struct __attribute__((packed, aligned(4))) SpU8 { uint32_t a, b; };
 struct __attribute__((packed, aligned(2))) SpU4 { uint32_t a; };
 __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq, const uint32_t* __restrict__ sd, const U4* __restrict__ ptot,
         const uint32_t* __restrict__ first, const uint32_t* __restrict__ ilv, const int8_t* __restrict__ ovb,
-                                                 const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb,
+                                                 const DevHeader* __restrict__ D, const uint64_t* __restrict__ sbase, const uint32_t* __restrict__ lpk, const uint16_t* __restrict__ lnb, const uint8_t* __restrict__ rn,
                                                  uint32_t* __restrict__ spk, uint16_t* __restrict__ snm, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmap, uint32_t* __restrict__ segm, int* __restrict__ segc, uint32_t n_seg,
                                                  uint32_t rshift) {
     __shared__ uint32_t s_sd[256 + SP_EXTRA + 1], s_ld[256 + SP_EXTRA], s_sk[256 + SP_EXTRA]; __shared__ uint8_t s_own[SP_OWN];
+    // "this read holds an N" (k_gather2 leaves it): the N bits of the others' slots are all zero and are not fetched - half of the packer's loads (a probe that fetched none
+    // of them: the phase beside the coder 3.31 -> 3.12 ms, profiles/r06_x_probe_no_n.txt)
+    __shared__ uint8_t s_hn[256 + SP_EXTRA + 8];
     const uint32_t c = blockIdx.y, f = first[c], e = first[c + 1], tid = threadIdx.x;
     const uint32_t ps0 = sd[f], S = ptot[c].d;
     const bool il = ilv[c] != 0, enc = il && (D->flags & H_PE_OVERLAP); const int shift = D->overlap_shift;
@@ -629,7 +633,7 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
         // ---- phase 1
         for (uint32_t t = tid; t <= nx; t += blockDim.x) {
             const uint32_t g = r0 + t; s_sd[t] = g < e ? sd[g] - ps0 : S;  // (sd[e] belongs to the next chunk)
-            if (t < nx) { s_ld[t] = (pq[g] >> 4) + g; s_sk[t] = skip_of(g); }
+            if (t < nx) { s_ld[t] = (pq[g] >> 4) + g; s_sk[t] = skip_of(g); s_hn[t] = rn[g]; } else s_hn[t] = 0;
         }
         __syncthreads();
         const uint32_t kbase = (s_sd[0] + 15u) >> 4, kend = (s_sd[nr] + 15u) >> 4;    // the step's dwords: those whose first base belongs to one of my reads
@@ -640,7 +644,9 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
         // round trips: 1.29 ms for a kernel with 0.47 ms of instructions)
         const uint32_t ndw = kend - kbase;
         for (uint32_t i0 = 0; i0 < ndw; i0 += blockDim.x * SP_U) {
-            struct Dw { uint32_t k, need, t1, jj, sh, sh2, take2, n, n2; unsigned long long c, c2; } q[SP_U];
+            struct Dw { uint32_t k, need, t1, jj, sh, sh2, take2, n, n2; unsigned long long c, c2; } q[SP_U]; uint32_t nres[SP_U];
+#pragma unroll
+            for (int u = 0; u < SP_U; u++) nres[u] = 0;
 #pragma unroll
             for (int u = 0; u < SP_U; u++) {
                 Dw& x = q[u]; x.need = 0; x.take2 = 0; x.k = x.t1 = x.jj = x.sh = x.sh2 = x.n = x.n2 = 0; x.c = x.c2 = 0;
@@ -650,12 +656,12 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
                     const uint32_t B = 16u * k, si = B - s_sd[j], need = S - B < 16u ? S - B : 16u, av = s_sd[j + 1] - B, t1 = need < av ? need : av;
                     const uint32_t b0 = s_sk[j] + si, d = s_ld[j] + (b0 >> 4);
                     x.k = k; x.need = need; x.t1 = t1; x.sh = b0 & 15u; x.jj = j + 1u;
-                    { const SpU8 v = *(const SpU8*)(lpk + d); x.c = (((unsigned long long)v.b) << 32) | v.a; x.n = ((const SpU4*)(lnb + d))->a; }
+                    { const SpU8 v = *(const SpU8*)(lpk + d); x.c = (((unsigned long long)v.b) << 32) | v.a; x.n = s_hn[j] ? ((const SpU4*)(lnb + d))->a : 0u; }
                     if (t1 < need && j + 1u < nx) {                          // the read behind: its LDS entries are there
                         const uint32_t avail = s_sd[j + 2] - s_sd[j + 1]; x.jj = j + 2u;
                         if (avail) {
                             const uint32_t s2 = s_sk[j + 1], d2 = s_ld[j + 1] + (s2 >> 4); x.sh2 = s2 & 15u; x.take2 = avail < need - t1 ? avail : need - t1;
-                            const SpU8 v = *(const SpU8*)(lpk + d2); x.c2 = (((unsigned long long)v.b) << 32) | v.a; x.n2 = ((const SpU4*)(lnb + d2))->a;
+                            const SpU8 v = *(const SpU8*)(lpk + d2); x.c2 = (((unsigned long long)v.b) << 32) | v.a; x.n2 = s_hn[j + 1] ? ((const SpU4*)(lnb + d2))->a : 0u;
                         }
                     }
                 }
@@ -680,13 +686,30 @@ __global__ void __launch_bounds__(256) k_seqpack(const uint32_t* __restrict__ pq
                     if (avail) {
                         const uint32_t take = avail < need - filled ? avail : need - filled;
                         acc |= (unsigned long long)(loose_codes(lpk, l2, s2) & (take >= 16u ? 0xFFFFFFFFu : (1u << (2u * take)) - 1u)) << (2u * filled);
-                        nacc |= (loose_nbits(lnb, l2, s2) & ((1u << take) - 1u)) << filled; filled += take;
+                        if (jj < nx ? s_hn[jj] : rn[r0 + jj]) nacc |= (loose_nbits(lnb, l2, s2) & ((1u << take) - 1u)) << filled;
+                        filled += take;
                     }
                     jj++;
                 }
-                ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc;
-                if (nacc) { const uint32_t n = (uint32_t)__popc(nacc); nsum += n; nmap_mark(nm, nshift, B); atomicAdd(&segm[nsi + B / PC_SEG_POS], n);
-                        atomicMax(&segc[nsi + B / PC_SEG_POS], (int)(B + 31u - (uint32_t)__clz((int)nacc))); }
+                ok[k] = (uint32_t)acc; on[k] = (uint16_t)nacc; nres[u] = nacc;
+            }
+            // the N of these dwords into the coder's segment counters, the chunk's N map and total.  A wave's dwords are neighbours - nearly always one segment, one bit of
+            // the map: ONE atomic of each kind per wave, by the first lane that has an N (files with runs of N - the configs[4] shape - had every such dword send three
+            // atomics to the same few words); lanes in another segment / at another bit send their own.
+#pragma unroll
+            for (int u = 0; u < SP_U; u++) {
+                const uint32_t na = q[u].need ? nres[u] : 0u;
+                const unsigned long long hn = __ballot(na != 0u);
+                if (!hn) continue;                                              // wave-uniform
+                const uint32_t B = 16u * q[u].k, sg = B / PC_SEG_POS, mb = (B >> 12) >> nshift, n = (uint32_t)__popc(na);
+                const int lead = __ffsll((long long)hn) - 1;
+                const uint32_t sg0 = (uint32_t)__shfl((int)sg, lead), mb0 = (uint32_t)__shfl((int)mb, lead);
+                const bool mine = na != 0u && sg == sg0; const int last = na ? (int)(B + 31u - (uint32_t)__clz((int)na)) : -1;
+                const uint32_t sum = wave_sum<uint32_t>(mine ? n : 0u); const int mx = wave_max<int>(mine ? last : -1);
+                if (lane_id() == lead) { atomicAdd(&segm[nsi + sg0], sum); atomicMax(&segc[nsi + sg0], mx); atomicOr(&nm[mb0 >> 5], 1u << (mb0 & 31u)); }
+                if (na != 0u && !mine) { atomicAdd(&segm[nsi + sg], n); atomicMax(&segc[nsi + sg], last); }
+                if (na != 0u && mb != mb0) atomicOr(&nm[mb >> 5], 1u << (mb & 31u));
+                nsum += n;
             }
         }
         __syncthreads();                                                    // (the LDS tables are rewritten by the next step)

@@ -13,7 +13,7 @@ enum EncBuf {   // indices into rfq_ctx::b
     B_LEN, B_N1LEN, B_N2OFF, B_X, B_Y, B_TILE, B_LANE, B_OK, B_CHUNK, B_STORED, B_EQ2, B_PQ, B_PV, B_PVIN,
     B_ULEN, B_P, B_MINMAX, B_FIRST, B_CFLAGS, B_IL, B_HIST, B_NCOUNT, B_SCAP, B_SOFF, B_SSIZE, B_XSIZE, B_YSIZE, B_QBASE, B_SBASE,
     B_IMGSIZE, B_IMGOFF, B_CTOTAL, B_CBASE, B_LAYOUT, B_HSTATS, B_OVB, B_OVRAW, B_QCAT, B_SCAT, B_SCRATCH, B_XS, B_YS, B_SEGB, B_SEGC,
-    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_QPLANE, B_SEGD, B_SEGS, B_SD, B_ENC_END
+    B_NORM0, B_NORM1, B_OT0, B_OT1, B_ONX0, B_ONX1, B_TBITS, B_SBITS, B_NKEEP, B_NTERM, B_NMAP, B_ADJ, B_PINFO, B_SEGM, B_LPK, B_LNB, B_SPK, B_SNM, B_RFLAG, B_SCANTMP2, B_CTOTALN, B_CBASEN, B_SCRATCHN, B_PTOT, B_QPLANE, B_SEGD, B_SEGS, B_SD, B_RN, B_ENC_END
 };
 
 static_assert(B_ENC_END <= 80, "encode buffers must stay below the decode buffer indices of rfq_ctx::b");
@@ -567,10 +567,11 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
     HIPCHK(ctx, B[B_SEGB].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGC].ensure(nsb * 4)); HIPCHK(ctx, B[B_SEGM].ensure(nsb * 4));
     if (fast) {
         // every table of the batch that starts all-zero / all-ones, in one launch (k_clear_list)
-        HIPCHK(ctx, B[B_RFLAG].ensure((nr + 15) & ~(size_t)15));
+        HIPCHK(ctx, B[B_RFLAG].ensure((nr + 15) & ~(size_t)15)); HIPCHK(ctx, B[B_RN].ensure((nr + 15) & ~(size_t)15));
         ClearList z; memset(&z, 0, sizeof z);
         z.add(cbits, 2 * nc * 4, 0xFFFFFFFFu); z.add(C.ncount, nc * 4, 0u); z.add(C.nmap, nc * NMAP_WORDS * 4, 0u);
         z.add(B[B_SEGB].p, nsb * 4, 0u); z.add(B[B_SEGM].p, nsb * 4, 0u); z.add(B[B_SEGC].p, nsb * 4, 0xFFFFFFFFu); z.add(B[B_RFLAG].p, nr, 0u);
+        z.add(B[B_RN].p, nr, 0u);
         clear_list(S, z);
     } else HIPCHK(ctx, hipMemsetAsync(cbits, 0xFF, 2 * nc * 4, S));
     ctx->timer.begin("chunk_flags", S);
@@ -651,7 +652,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             if (masks) hipLaunchKernelGGL(k_mask_bounds, dim3(n_chunks), dim3(64), 0, S, (const uint32_t*)R.pq, (const uint32_t*)C.first, (const uint64_t*)C.qbase,
                     M.planes, M.pstride, (const DevHeader*)D, M.nd, bx, only);
 #define RFQ_G2_ARGS T, R, (const uint32_t*)C.first, (const uint64_t*)C.qbase, (const DevHeader*)D, B[B_QCAT].as<uint8_t>(), B[B_LPK].as<uint32_t>(), B[B_LNB].as<uint16_t>(), B[B_RFLAG].as<uint8_t>(), \
-                    B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, cbits, cfail, only, text4, M
+                    B[B_RN].as<uint8_t>(), B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, kshift, cbits, cfail, only, text4, M
             // (single-end input with match masks: the instantiation without mates - 132 spilled SGPRs instead of 182, no VGPR in scratch; the byte-stream form of it
             // spills 64 VGPRs instead and is not used)
             if (masks && !is_pe && G2_SE_OK) hipLaunchKernelGGL((k_gather2<true, 0>), dim3(bx, n_chunks), dim3(256), dyn, S, RFQ_G2_ARGS);
@@ -701,7 +702,7 @@ static int encode_impl(rfq_ctx* ctx, const rfq_encode_args* a, rfq_encode_result
             uint32_t sx = grid_x_for(n_chunks, (max_reads >> rshift) + 1u, 8u * ctx->n_cu);
             hipLaunchKernelGGL(k_seqpack, dim3(sx, n_chunks), dim3(256), aux_chain ? ctx->opt.sp_pad : 0u, A, (const uint32_t*)R.pq, (const uint32_t*)R.sd, (const U4*)C.ptot,
                     (const uint32_t*)C.first, (const uint32_t*)C.il, (const int8_t*)ovb, (const DevHeader*)D,
-                               (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
+                               (const uint64_t*)C.sbase, (const uint32_t*)B[B_LPK].as<uint32_t>(), (const uint16_t*)B[B_LNB].as<uint16_t>(), (const uint8_t*)B[B_RN].as<uint8_t>(), B[B_SPK].as<uint32_t>(), B[B_SNM].as<uint16_t>(),
                                C.ncount, C.nmap, B[B_SEGM].as<uint32_t>(), B[B_SEGC].as<int>(), n_seg, rshift);
         }
         uint64_t* tmp2 = B[B_SCANTMP2].as<uint64_t>() + (nr / SCAN_TILE + 2) * 2;   // (behind the U4 scan's part of the buffer)
