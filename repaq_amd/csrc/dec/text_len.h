@@ -4,6 +4,24 @@
 // ---- text
 __device__ __forceinline__ uint32_t dec_digits(uint32_t v) { uint32_t n = 1; while (v >= 10) { v /= 10; n++; } return n; }
 __device__ __forceinline__ uint32_t dec_put(uint8_t* dst, uint32_t v) { const uint32_t n = dec_digits(v); for (uint32_t k = 0; k < n; k++) { dst[n - 1 - k] = (uint8_t)('0' + v % 10); v /= 10; } return n; }
+// ':' and the decimal digits of v at buf[k ..) of a row of `cap` bytes in LDS: the bytes written.  A sequencer's lane / tile / x / y are below 10^8: two 4-digit halves, split
+// into digit pairs and digits by multiplies (x * 5243 >> 19 = x / 100 below 10000, y * 103 >> 10 = y / 10 below 100, both pairs of a half in one register), leading zeros
+// shifted out, ':' and seven digits in ONE 8-byte store.  (dec_put's loop - a division and a byte store per digit, ~22 instructions each with the quarter-rate multiplies, and
+// every byte store an eight-way bank conflict at 32 bytes per lane - was most of k_dec_textlen2's 3.6 M issued VALU instructions per SE: the kernel ran in 0.49 ms beside the
+// list chain on configs[2].)  Larger values, or a row with less than nine bytes left: the loop.
+__device__ __forceinline__ uint32_t mid_put(uint8_t* buf, uint32_t k, uint32_t cap, uint32_t v) {
+    if (v >= 100000000u || k + 9u > cap) { buf[k] = ':'; return 1u + dec_put(buf + k + 1u, v); }
+    const uint32_t hi = v / 10000u, lo = v - hi * 10000u;
+    const uint32_t a = mul24(hi, 5243u) >> 19, b = hi - mul24(a, 100u), c = mul24(lo, 5243u) >> 19, d = lo - mul24(c, 100u);
+    const uint32_t P = a | (b << 16), Q = c | (d << 16);
+    const uint32_t pt = ((P * 103u) >> 10) & 0x000F000Fu, po = P - pt * 10u, qt = ((Q * 103u) >> 10) & 0x000F000Fu, qo = Q - qt * 10u;
+    const unsigned long long dg = (unsigned long long)(pt | (po << 8)) | ((unsigned long long)(qt | (qo << 8)) << 32);      // the eight digits, the most significant in byte 0
+    const uint32_t lz = dg ? (uint32_t)(__ffsll((long long)dg) - 1) >> 3 : 7u, n = 8u - lz;
+    const unsigned long long asc = (dg | 0x3030303030303030ull) >> (8u * lz);
+    LdsU8 w; w.a = (asc << 8) | 0x3Aull; *(LdsU8*)(buf + k) = w;
+    if (n == 8u) buf[k + 8u] = (uint8_t)(asc >> 56);
+    return 1u + n;
+}
 struct DName { uint32_t n1, n2, st, lane, tile, x, y; };
 __device__ __forceinline__ DName dec_name_parts(const uint8_t* cp, const DChunk& d, const DevHeader* D, const uint32_t* xv, const uint32_t* yv, uint32_t r) {
     const uint32_t fl = d.flags, hf = D->flags; DName m;
@@ -25,10 +43,10 @@ __device__ __forceinline__ uint32_t dec_textlen_one(const uint8_t* __restrict__ 
     // row went out byte by byte - VERDICT r3)
     uint32_t k = 0;                                                  // ":255:65535:4294967295:4294967295" is 32 bytes
     { unsigned long long* z = (unsigned long long*)buf; z[0] = z[1] = z[2] = z[3] = z[4] = 0ull; }
-    if (hf & H_LANE) { buf[k++] = ':'; k += dec_put(buf + k, m.lane); }
-    if (hf & H_TILE) { buf[k++] = ':'; k += dec_put(buf + k, m.tile); }
-    if (hf & H_X) { buf[k++] = ':'; k += dec_put(buf + k, m.x); }
-    if (hf & H_Y) { buf[k++] = ':'; k += dec_put(buf + k, m.y); }
+    if (hf & H_LANE) k += mid_put(buf, k, 39u, m.lane);                // (byte 39 is the length's)
+    if (hf & H_TILE) k += mid_put(buf, k, 39u, m.tile);
+    if (hf & H_X) k += mid_put(buf, k, 39u, m.x);
+    if (hf & H_Y) k += mid_put(buf, k, 39u, m.y);
     buf[39] = (uint8_t)k;
     { const unsigned long long* z = (const unsigned long long*)buf; unsigned long long* mp = (unsigned long long*)(R.mid + (size_t)g * 40);
       const unsigned long long a0 = z[0], a1 = z[1], a2 = z[2], a3 = z[3], a4 = z[4]; mp[0] = a0; mp[1] = a1; mp[2] = a2; mp[3] = a3; mp[4] = a4; }
@@ -78,10 +96,10 @@ __global__ void __launch_bounds__(256) k_dec_textlen2(const uint8_t* __restrict_
             const DName m = dec_name_parts(cp, d, D, xv, yv, r);
             uint8_t* buf = (uint8_t*)(s_mid + 4u * threadIdx.x);
             { unsigned long long* z = (unsigned long long*)buf; z[0] = z[1] = z[2] = z[3] = 0ull; }
-            if (hf & H_LANE) { buf[k++] = ':'; k += dec_put(buf + k, m.lane); }
-            if (hf & H_TILE) { buf[k++] = ':'; k += dec_put(buf + k, m.tile); }
-            if (hf & H_X) { buf[k++] = ':'; k += dec_put(buf + k, m.x); }
-            if (hf & H_Y) { buf[k++] = ':'; k += dec_put(buf + k, m.y); }
+            if (hf & H_LANE) k += mid_put(buf, k, E3_MIDROW, m.lane);
+            if (hf & H_TILE) k += mid_put(buf, k, E3_MIDROW, m.tile);
+            if (hf & H_X) k += mid_put(buf, k, E3_MIDROW, m.x);
+            if (hf & H_Y) k += mid_put(buf, k, E3_MIDROW, m.y);
             { const unsigned long long* z = (const unsigned long long*)buf; unsigned long long* mp = (unsigned long long*)(mid + g * E3_MIDROW);
               const unsigned long long a0 = z[0], a1 = z[1], a2 = z[2], a3 = z[3]; mp[0] = a0; mp[1] = a1; mp[2] = a2; mp[3] = a3; }
             const uint32_t len = len_i[g]; const uint32_t text = m.n1 + m.n2 + k + 1 + len + 1 + m.st + 1 + len + 1;
