@@ -11,7 +11,11 @@
 //   k_dec_pos_link2  per stream, a wave scan over those summaries: entry state / entry position / entry list index of every segment
 //   k_dec_pos_list   decodes every segment from its now-known entry and writes its positions; records for every POS2_CELL positions the
 //                    index of the first list entry at or beyond the cell (the emitter starts there)
-#define POS2_SEG 1024u            // bytes of a stream per wave: POS2_SEG / 256 steps of 4 bytes per lane
+// bytes of a stream per wave (segb / 256 steps of 4 bytes per lane): the host takes POS2_SEG_BIG for files whose largest stream is 32 KB or more - a NovaSeq-binned file's three streams of
+// 40 - 70 KB per chunk: half the waves, each setting up once for eight steps, dec:streams 1.30 -> 1.22 ms on configs[2] - and POS2_SEG for many short streams (forty quality values: the
+// configs[4] shape is 6 % slower with the larger segments; 512 and 4096 lose on both - profiles/r06_ze_pos2seg.txt)
+#define POS2_SEG 1024u
+#define POS2_SEG_BIG 2048u
 #define POS2_CELL 1024u
 // A list entry is the LOW 16 BITS of a coded position (round 5; u32 before: 1.17 GB written and read back per 8 GB of text).  The emitter asks the cell index for the
 // entries of [tile start, tile start + tile + a cell) - a window far below 65536 positions - so an entry e is position q0 + ((e - q0) & 0xFFFF), q0 = the tile's first position.
@@ -79,14 +83,15 @@ __device__ __forceinline__ int pos_adv_sat(int v) { return v > (int)POS_ADV_MAX 
 // grid (ceil(maxseg / 4), streams, n_chunks) x 256 threads: one wave per segment; index arrays are [chunk][nstr][maxseg]; segA[8 * idx + s] =
 // positions advanced, segA[8 * idx + 4 + s] = positions emitted for entry state s
 __global__ void k_dec_pos_sum2(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
-                               uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes, uint32_t jj0, uint32_t nstr) {
+                               uint8_t* __restrict__ segF, int* __restrict__ segA, uint32_t* __restrict__ segN, uint32_t maxseg, DecStatus* st, uint64_t img_bytes, uint32_t jj0, uint32_t nstr,
+                               uint32_t segb) {
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id();
             const uint8_t* lim = img + img_bytes;
     const DChunk d = CH[c];
     const PosSrc s = pos_src_of(img, d, D, jj, g == 0 ? st : nullptr);
-    if (g == 0 && l == 0) segN[(size_t)c * nstr + jj] = (s.slen + POS2_SEG - 1) / POS2_SEG;
-    const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
-    const uint32_t b1 = b0 + POS2_SEG < s.slen ? b0 + POS2_SEG : s.slen;
+    if (g == 0 && l == 0) segN[(size_t)c * nstr + jj] = (s.slen + segb - 1) / segb;
+    const uint32_t b0 = g * segb; if (b0 >= s.slen) return;
+    const uint32_t b1 = b0 + segb < s.slen ? b0 + segb : s.slen;
     uint32_t Fcum = POS_ID; int a[4] = { 0, 0, 0, 0 }, n[4] = { 0, 0, 0, 0 };
     PosStep nxt = pos_fetch(s.sp, s.slen, b0 + 4u * (uint32_t)l, lim);
     for (uint32_t base = b0; base < b1; base += 256u) {                    // (wave-uniform)
@@ -177,17 +182,18 @@ __global__ void k_dec_pos_off(const uint32_t* __restrict__ nent, unsigned long l
 // it codes go to plist[loff + k ...] in stream order; cellidx[cell] = index (within the stream's list) of the first entry >= cell * POS2_CELL
 __global__ void k_dec_pos_list(const uint8_t* __restrict__ img, const DChunk* __restrict__ CH, const DevHeader* __restrict__ D,
                                const uint8_t* __restrict__ segS, const int* __restrict__ segP, const uint32_t* __restrict__ segK, const unsigned long long* __restrict__ loff,
-                               plist_t* __restrict__ plist, unsigned long long cap, uint32_t* __restrict__ cellidx, uint32_t maxseg, uint32_t ncell, uint64_t img_bytes, uint32_t jj0, uint32_t nstr, const DecStatus* st) {
+                               plist_t* __restrict__ plist, unsigned long long cap, uint32_t* __restrict__ cellidx, uint32_t maxseg, uint32_t ncell, uint64_t img_bytes, uint32_t jj0, uint32_t nstr, const DecStatus* st,
+                               uint32_t segb) {
     if (st->list_need > cap) return;                                      // (uniform) the arena is too small: the host repeats the pass
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_id(), jj = jj0 + blockIdx.y, c = blockIdx.z; const int l = lane_id();
             const uint8_t* lim = img + img_bytes;
     const DChunk d = CH[c];
     const PosSrc s = pos_src_of(img, d, D, jj, nullptr);
-    const uint32_t b0 = g * POS2_SEG; if (b0 >= s.slen) return;
+    const uint32_t b0 = g * segb; if (b0 >= s.slen) return;
     const size_t t = (size_t)c * nstr + jj, idx = t * maxseg + g;
     uint32_t carry = segS[idx]; int last = segP[idx]; uint32_t k0 = segK[idx];
     plist_t* const out = plist + loff[t]; uint32_t* const cells = cellidx + t * ncell;
-    const uint32_t b1 = b0 + POS2_SEG < s.slen ? b0 + POS2_SEG : s.slen;
+    const uint32_t b1 = b0 + segb < s.slen ? b0 + segb : s.slen;
     PosStep nxt = pos_fetch(s.sp, s.slen, b0 + 4u * (uint32_t)l, lim);
     for (uint32_t base = b0; base < b1; base += 256u) {                    // (wave-uniform) a step = 256 bytes; state, position and list index carry over
         const uint32_t i0 = base + 4u * (uint32_t)l;

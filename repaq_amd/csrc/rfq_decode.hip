@@ -17,13 +17,13 @@ static_assert(DB_END <= 120, "rfq_ctx::b too small");
 
 // fused path: k_dec_pos_list for the quality streams and the N-position stream (the arena is whatever B[DB_PLIST] holds)
 static void launch_pos_list(rfq_ctx* ctx, const rfq_decode_args* a, const DChunk* CH, uint32_t n_chunks, uint32_t maxseg, uint32_t ncell, uint32_t nstr,
-                            uint32_t mq, uint32_t mn, uint32_t nn, bool hasn, hipStream_t LS) {
+                            uint32_t mq, uint32_t mn, uint32_t nn, bool hasn, uint32_t segb, hipStream_t LS) {
     DBuf* B = ctx->b; const DevHeader* D = ctx->d_hdr.as<DevHeader>(); const DecStatus* dst = B[DB_STATUS].as<DecStatus>();
     const unsigned long long cap = B[DB_PLIST].cap / sizeof(plist_t);
 #define RFQ_LIST_ARGS a->d_rfq, CH, D, (const uint8_t*)B[DB_SEGS].as<uint8_t>(), (const int*)B[DB_SEGP].as<int>(), (const uint32_t*)B[DB_SEGK].as<uint32_t>(), \
                       (const unsigned long long*)B[DB_LOFF].as<unsigned long long>(), B[DB_PLIST].as<plist_t>(), cap, B[DB_CELL].as<uint32_t>(), maxseg, ncell, (uint64_t)a->n
-    if (nn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, 0u, nstr, dst);
-    if (hasn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, ctx->h_hdr.n_normal, nstr, dst);
+    if (nn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, 0u, nstr, dst, segb);
+    if (hasn) hipLaunchKernelGGL(k_dec_pos_list, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, LS, RFQ_LIST_ARGS, ctx->h_hdr.n_normal, nstr, dst, segb);
 #undef RFQ_LIST_ARGS
 }
 #define RFQ_RANGE_TOO_BIG 2          // internal: the range's text would not fit the 32-bit text offsets of one pass
@@ -69,7 +69,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     const bool e3_ok = e3k >= (g.pieces ? 6u : 1u) && !(g.pieces && ctx->e3_pieces_failed);
     // (chunks of 2^30 bases and more: the list chain's saturating position sums - POS_ADV_MAX, dec/pos_lists.h - would no longer be exact)
     const bool fused = !force_expanded && !(tune & 2048) && !rle_h && g.max_len <= 2000u && g.max_nrec <= 4096u && e3_ok && g.max_bases < (1u << 30) - 65536u;
-    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S;
+    uint32_t f_maxseg = 1, f_ncell = 1, f_mq = 0, f_mn = 0, f_nn = 0, f_segb = POS2_SEG; bool f_lists = false, f_hasn = false, f_join = false; hipStream_t f_aux = S;
             const uint32_t f_nstr = HH.n_normal + 1;
     // (an early return must not leave the chain running over buffers the next call reuses)
     struct AuxJoin { rfq_ctx* c; bool armed; ~AuxJoin() { if (armed) (void)hipStreamSynchronize(c->aux); } } aux_guard = { ctx, false };
@@ -78,7 +78,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
         const bool forked = ctx->aux_ready(); hipStream_t A = forked ? ctx->aux : S;
         if (nn || hasn) {
             if (forked) { HIPCHK(ctx, hipEventRecord(ctx->ev_fork, S)); HIPCHK(ctx, hipStreamWaitEvent(A, ctx->ev_fork, 0)); aux_guard.armed = true; }
-            const uint32_t mq = nn ? g.max_one / POS2_SEG + 1 : 0u, mn = hasn ? g.max_npos / POS2_SEG + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
+            f_segb = ctx->opt.pos_seg ? (uint32_t)ctx->opt.pos_seg : (std::max(g.max_one, g.max_npos) >= 32768u ? POS2_SEG_BIG : POS2_SEG);
+            const uint32_t mq = nn ? g.max_one / f_segb + 1 : 0u, mn = hasn ? g.max_npos / f_segb + 1 : 0u; f_maxseg = std::max(1u, std::max(mq, mn));
             f_ncell = g.max_bases / POS2_CELL + 2;
             const size_t nst = (size_t)n_chunks * f_nstr, nseg = nst * f_maxseg, ncl = nst * f_ncell;
             HIPCHK(ctx, B[DB_SEGF].ensure(nseg + 16)); HIPCHK(ctx, B[DB_SEGA].ensure(nseg * 32 + 16)); HIPCHK(ctx, B[DB_SEGN].ensure(nst * 4 + 16));
@@ -94,8 +95,8 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
                     HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(g.bases / 32 + 1024) * sizeof(plist_t))); }
             { ClearList z; memset(&z, 0, sizeof z); z.add(B[DB_SEGN].p, nst * 4, 0u); z.add(B[DB_NENT].p, nst * 4, 0u); z.add(B[DB_CELL].p, ncl * 4, 0xFFFFFFFFu); clear_list(A, z); }
 #define RFQ_SUM2_ARGS a->d_rfq, CH, D, B[DB_SEGF].as<uint8_t>(), B[DB_SEGA].as<int>(), B[DB_SEGN].as<uint32_t>(), f_maxseg, dst, (uint64_t)a->n
-            if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr);
-            if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr);
+            if (nn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mq + 3) / 4, nn, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, 0u, f_nstr, f_segb);
+            if (hasn) hipLaunchKernelGGL(k_dec_pos_sum2, dim3((mn + 3) / 4, 1, n_chunks), dim3(256), 0, A, RFQ_SUM2_ARGS, HH.n_normal, f_nstr, f_segb);
 #undef RFQ_SUM2_ARGS
             hipLaunchKernelGGL(k_dec_pos_link2, dim3((uint32_t)((nst + 3) / 4)), dim3(256), 0, A, (const uint8_t*)B[DB_SEGF].as<uint8_t>(),
                     (const int*)B[DB_SEGA].as<int>(),
@@ -103,7 +104,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
                                CH, f_nstr, dst);
             hipLaunchKernelGGL(k_dec_pos_off, dim3(1), dim3(256), 0, A, (const uint32_t*)B[DB_NENT].as<uint32_t>(), B[DB_LOFF].as<unsigned long long>(), (uint32_t)nst,
                     dst);
-            launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, A);
+            launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, mq, mn, nn, hasn, f_segb, A);
             f_lists = true; f_mq = mq; f_mn = mn; f_nn = nn; f_hasn = hasn;
             f_join = forked; f_aux = A;
             KCHK(ctx, "k_dec_pos_*");
@@ -240,7 +241,7 @@ static int decode_range(rfq_ctx* ctx, const rfq_decode_args* a, const DecRange& 
     // text prefix sums are 32-bit: one decode call emits < 4 GiB per output stream
     if (fused && f_lists && hs.list_need > B[DB_PLIST].cap / sizeof(plist_t)) {            // the lists did not fit the arena: now that their size is known, build them
         HIPCHK(ctx, B[DB_PLIST].ensure((size_t)(hs.list_need + 1024) * sizeof(plist_t)));
-        launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, f_mq, f_mn, f_nn, f_hasn, S);
+        launch_pos_list(ctx, a, CH, n_chunks, f_maxseg, f_ncell, f_nstr, f_mq, f_mn, f_nn, f_hasn, f_segb, S);
         KCHK(ctx, "k_dec_pos_list");
     }
     hs.text1 = hs.text2 = 0; for (int i = 0; i < 64; i++) { hs.text1 += hs.text_slots[0][i]; hs.text2 += hs.text_slots[1][i]; }

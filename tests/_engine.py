@@ -237,6 +237,8 @@ DEC_FORMS = {
     "walk_exact": ({"RFQ_WALK": "exact"}, "emit_expanded"),                                  # k_dec_walk; it does not look into the payloads: the expanded path behind it
     "materialise": ({"RFQ_MATERIALISE": "1"}, "emit_expanded"),                              # k_dec_fill / unpack / pos_sum / pos_link / pos_emit / except + k_dec_emit
     "one_stream": ({"RFQ_STREAMS": "1"}, None),
+    "pos_seg_2048": ({"RFQ_POS_SEG": "2048"}, None),                                         # the list chain's larger segments (default only for streams of 32 KB and more)
+    "pos_seg_1024": ({"RFQ_POS_SEG": "1024"}, None),
     "slice_bases": ({"RFQ_SLICE_BASES": None}, None),                                        # ranges of two or three chunks
     "gw_small": ({"RFQ_GW_SHIFT": "12"}, None),                                              # many guess-and-verify segments
     "exact_materialise_slices": ({"RFQ_WALK": "exact", "RFQ_MATERIALISE": "1", "RFQ_SLICE_BASES": None}, None),
