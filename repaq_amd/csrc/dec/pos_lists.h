@@ -302,18 +302,26 @@ __global__ void k_dec_coords(const uint8_t* __restrict__ img, const DChunk* __re
     const uint32_t num = (d.flags & C_PE_INTERLEAVED) ? d.reads / 2 : d.reads;
     uint32_t* out = (axis ? yv : xv) + d.rbase;
     const int l = lane_id(); uint32_t carry = 0, cur = 1000u, produced = 0;
+    // (a step's bytes - mine and the two behind it, a token's tail - are requested two steps before they are decoded: the steps are one dependent chain, and a load in
+    // it costs a round trip to memory per 64 bytes of the stream)
+    auto fetch = [&](uint32_t base_) -> uint32_t { const uint32_t i_ = base_ + (uint32_t)l; return i_ < slen ? (uint32_t)sp[i_] : 0u; };
+    uint32_t w1 = fetch(0u), w2 = fetch(64u);
     for (uint32_t base = 0; base < slen; base += 64) {
         const uint32_t i = base + (uint32_t)l; const bool valid = i < slen;
-        const uint32_t b0 = valid ? sp[i] : 0u;
+        const uint32_t b0 = w1; w1 = w2; w2 = fetch(base + 128u);
+        // the two bytes behind mine: the next lanes', for the last two lanes the next step's first (bytes past the stream read as 0)
+        const uint32_t n0 = wave_read(w1, 0u), n1 = wave_read(w1, 1u);
+        uint32_t b1 = (uint32_t)__shfl_down((int)b0, 1u), b2 = (uint32_t)__shfl_down((int)b0, 2u);
+        if (l == 63) { b1 = n0; b2 = n1; } else if (l == 62) b2 = n0;
         const uint32_t tl = (b0 & 0x80u) == 0 ? 2u : ((b0 & 0xE0u) == 0xE0u ? 3u : 1u);
         const uint32_t before = wave_token_states(tl, valid, carry);
         const bool start = valid && before == 0;
         uint32_t cnt = 0, isabs = 0, val = 0;                      // val: absolute value, or the +diff
         if (start) {
-            if ((b0 & 0x80u) == 0) { isabs = 1; val = (b0 << 8) | (i + 1 < slen ? sp[i + 1] : 0u); cnt = 1; }
+            if ((b0 & 0x80u) == 0) { isabs = 1; val = (b0 << 8) | b1; cnt = 1; }
             else if ((b0 & 0x40u) == 0) { val = (b0 & 0x3Fu) + 1; cnt = 1; }
             else if ((b0 & 0x20u) == 0) { val = 0; cnt = (b0 & 0x1Fu) + 1; }
-            else { isabs = 1; val = ((b0 & 0x1Fu) << 16) | ((i + 1 < slen ? sp[i + 1] : 0u) << 8) | (i + 2 < slen ? sp[i + 2] : 0u); cnt = 1; }
+            else { isabs = 1; val = ((b0 & 0x1Fu) << 16) | (b1 << 8) | b2; cnt = 1; }
         }
         // segmented prefix: value after this token = last absolute at or before it + diffs since
         uint32_t v = val, a = isabs;

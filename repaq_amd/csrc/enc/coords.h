@@ -13,12 +13,18 @@ __global__ void k_coords(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D,
     uint8_t* out = (axis ? ys : xs) + 3ull * f;
     const int l = lane_id();
     uint32_t outpos = 0, carry_prev = 1000u, carry_rep = 0; long long carry_start = -1;
+    // (a step's values are requested two steps before they are coded: the steps are one dependent chain - carries, output position - and a load in it costs the
+    // chain a round trip to memory per 64 values: 145 us for a chunk of 6,700 reads, alone at the end of the phase on a small input)
+    auto fetch = [&](uint32_t base_) -> uint32_t { const uint32_t i_ = base_ + (uint32_t)l; return i_ < num ? V[(size_t)i_ * stride] : 0u; };
+    uint32_t v1 = fetch(0u), v2 = fetch(64u);
     for (uint32_t base = 0; base < num; base += 64) {
         const uint32_t i = base + (uint32_t)l; const bool valid = i < num;
-        const uint32_t v = valid ? V[(size_t)i * stride] : 0u;
+        const uint32_t v = v1; v1 = v2; v2 = fetch(base + 128u);
         const uint32_t p = wave_shr1(v, carry_prev);
         const uint32_t rep = (valid && v == p) ? 1u : 0u;
-        const bool rep_next = (i + 1 < num) && V[(size_t)(i + 1) * stride] == v;
+        // the element behind mine: the next lane's, for the last lane the next step's first
+        uint32_t vnx = (uint32_t)__shfl_down((int)v, 1u); { const uint32_t first_next = wave_read(v1, 0u); if (l == 63) vnx = first_next; }
+        const bool rep_next = (i + 1 < num) && vnx == v;
         const uint32_t rep_prev = wave_shr1(rep, carry_rep);
         long long sidx = (rep && !rep_prev) ? (long long)i : -1;
         sidx = wave_incl_max(sidx); if (carry_start > sidx) sidx = carry_start;
