@@ -42,14 +42,19 @@ __global__ void k_hdr_stats(Text T, ReadTab R, const uint32_t* __restrict__ firs
         }
     }
     ncnt = wave_sum(ncnt); notok = wave_or(notok); mxl = wave_max(mxl); fn = wave_min(fn); fe = wave_min(fe);
-    if (l == 0) {
+    // one atomic of each kind per WORKGROUP (every wave sent its own: four thousand atomics in a row on each of five words - most of the kernel's 53 us, and the header of a
+    // file's first batch is a chain the gather waits for)
+    __shared__ uint32_t s_n[4], s_ok[4], s_mx[4]; __shared__ unsigned long long s_fn[4], s_fe[4];
+    if (l == 0) { const int w = wave_id(); s_n[w] = ncnt; s_ok[w] = notok; s_mx[w] = mxl; s_fn[w] = fn; s_fe[w] = fe; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < wpb; w++) { ncnt += s_n[w]; notok |= s_ok[w]; if (s_mx[w] > mxl) mxl = s_mx[w]; if (s_fn[w] < fn) fn = s_fn[w]; if (s_fe[w] < fe) fe = s_fe[w]; }
         if (ncnt) atomicAdd(&H->n_count, ncnt);
         if (notok) atomicOr(&H->any_not_ok, 1u);
-        atomicMax(&H->max_len, mxl);
+        if (mxl) atomicMax(&H->max_len, mxl);
         if (fn != ~0ull) atomicMin((unsigned long long*)&H->first_n_key, (unsigned long long)fn);
         if (fe != ~0ull) atomicMin((unsigned long long*)&H->first_err_key, (unsigned long long)fe);
     }
-    __syncthreads();
     for (int i = threadIdx.x; i < 128; i += blockDim.x) if (sh[i]) atomicAdd(&H->hist[i], sh[i]);
 }
 __global__ void k_hdr_q0(Text T, HdrStats* H) {
