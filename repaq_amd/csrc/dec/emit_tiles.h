@@ -14,6 +14,9 @@
 // emitter this kernel replaced.
 #define E3_QCAP 10240u            // quality tile: K reads' qualities (64 x 160)
 #define E3_SHARED_OK 1             // 0: never take the SHARED instantiation (A/B on the box: tools/build_variant.sh)
+#define E3_ALIGNED 1               // 0: the two long lines in line-relative 16-byte groups (A/B on the box: tools/build_variant.sh)
+#define E3_PROBE_WRAP 0            // measurement aid (tools/build_variant.sh): a mask, e.g. 0xFFFFFu = every record is written into the first MiB of its output - WRONG text,
+                                   // the emitter's time with its stores kept inside the L2 (profiles/r06_zn_emit_wrap_probe.txt: 2.53 instead of 3.67 ms)
 #define E3_N1BIG 13312u           // name1 tile of the second instantiation: 64 per-read names of 200 bytes (34 KB of LDS, four workgroups per CU)
 struct __attribute__((packed, aligned(1))) GU16d { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) GU8d { uint32_t a, b; };
@@ -219,7 +222,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
         __syncthreads();
         // ---- compose: my share of my read's four lines, straight to the output (src/rfqcodec.cpp:1141-1254, Read::toString src/read.cpp:170)
         if (on) {
-            uint8_t* const rec = (to2 ? out2 : out1) + toff; const uint64_t capo = to2 ? cap2 : cap1;
+            uint8_t* const rec = (to2 ? out2 : out1) + (E3_PROBE_WRAP ? (toff & (uint32_t)E3_PROBE_WRAP) : toff); const uint64_t capo = to2 ? cap2 : cap1;
             const uint32_t e0 = n1 + md + n2, oseq = e0 + 1u, ost = oseq + len + 1u, oq = ost + sl + 1u, total = oq + len + 1u;
             if ((uint64_t)toff + total > capo) { if (part == 0) atomicOr(&st->err, 1u << 31); }
             else {
@@ -270,17 +273,20 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
                     if (byte + 5u > have) { uint32_t lim_ = 4u * have > sbit0 / 2u + si ? 4u * have - sbit0 / 2u - si : 0u;
                             if (lim_ < 16u) nw |= (0xFFFFu << lim_) & 0xFFFFu; }
                 };
-                auto group = [&](uint32_t k0, uint32_t (&qw)[4], uint32_t (&sw)[4]) {   // output positions [k0, k0 + 16) of both lines (k0 + 16 <= len)
+                auto group_q = [&](uint32_t k0, uint32_t (&qw)[4]) {                  // output positions [k0, k0 + 16) of the quality line (k0 + 16 <= len)
                     const uint32_t pa = rc ? len - k0 - 16u : k0;
                     lds_get16(q_t, qp_ + pa, qw);
+                    if (rc) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2; qw[3] = x3; }
+                };
+                // ... of the bases' line; qw: the qualities of the same positions (group_q's), looked at by files whose N bases are implied by their quality
+                auto group_s = [&](uint32_t k0, const uint32_t (&qw)[4], uint32_t (&sw)[4]) {
+                    const uint32_t pa = rc ? len - k0 - 16u : k0;
                     uint32_t cw, nw;
                     if (pa + 16u <= xa) fetch(A + pa, cw, nw);
                     else if (pa >= xa) fetch(Bs + (pa - xa), cw, nw);
                     else { uint32_t c2, n2_; const uint32_t t1 = xa - pa; fetch(A + pa, cw, nw); fetch(Bs, c2, n2_);
                             cw = (cw & ((1u << (2u * t1)) - 1u)) | (c2 << (2u * t1)); nw = (nw & ((1u << t1) - 1u)) | ((n2_ << t1) & 0xFFFFu); }
-                    if (rc) { const uint32_t x0 = bswap32(qw[3]), x1 = bswap32(qw[2]), x2 = bswap32(qw[1]), x3 = bswap32(qw[0]); qw[0] = x0; qw[1] = x1; qw[2] = x2;
-                            qw[3] = x3;
-                              cw = ~e3_rev2x16(cw); if (nw) nw = e3_rev1x16(nw); }
+                    if (rc) { cw = ~e3_rev2x16(cw); if (nw) nw = e3_rev1x16(nw); }
 #pragma unroll
                     for (int i = 0; i < 4; i++) { const uint32_t b = (cw >> (8 * i)) & 0xFFu, y = (b | (b << 12)) & 0x000F000Fu, idx = (y | (y << 6)) & 0x03030303u;
                             sw[i] = __builtin_amdgcn_perm(0u, 0x43544147u, idx); }
@@ -294,19 +300,45 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
                         for (int i = 0; i < 4; i++) { const uint32_t mk = eq_bytes_full(qw[i], nq4); sw[i] = (sw[i] & ~mk) | (0x4E4E4E4Eu & mk); }
                     }
                 };
+                auto group = [&](uint32_t k0, uint32_t (&qw)[4], uint32_t (&sw)[4]) { group_q(k0, qw); group_s(k0, qw, sw); };     // both lines' positions [k0, k0 + 16)
+                auto st16 = [&](uint32_t at, const uint32_t (&x)[4]) { GU16d v; v.a = x[0]; v.b = x[1]; v.c = x[2]; v.d = x[3]; *(GU16d*)(rec + at) = v; };
                 auto put = [&](uint32_t at_q, uint32_t at_s, const uint32_t (&qw)[4], const uint32_t (&sw)[4], bool both) {
                     GU16d v;
                     if (both) { v.a = qw[0]; v.b = qw[1]; v.c = qw[2]; v.d = qw[3]; *(GU16d*)(rec + at_q) = v; }
                     v.a = sw[0]; v.b = sw[1]; v.c = sw[2]; v.d = sw[3]; *(GU16d*)(rec + at_s) = v;
                 };
                 if (len >= 16u) {
-                    const uint32_t nfull = len >> 4, rem = len & 15u; uint32_t qw[4], sw[4];
-                    for (uint32_t gi = part; gi < nfull; gi += P) { group(16u * gi, qw, sw); put(oq + 16u * gi, oseq + 16u * gi, qw, sw, true); }
-                    if ((nfull & (P - 1u)) == part && (rem || jfast)) {       // the lines' tails: positions [len - 16, len)
+                    uint32_t qw[4], sw[4];
+                    // Where the lines' 16-byte groups are cut.  By the OUTPUT address (E3_ALIGNED, lines of 32 bases and more): one group at the line's start, then groups at the
+                    // 16-aligned addresses inside it, then the tail that ends with the line - the body's stores are aligned, which is what the memory side wants: byte-granular
+                    // 16-byte stores in this record shape reach 2.7 TB/s, with the two long lines' bodies aligned 3.8 (tools/micro/store_align.hip, profiles/r06_zo_store_align.txt),
+                    // and the emitter with its writes kept inside the L2 runs 2.5 instead of 3.7 ms (profiles/r06_zn_emit_wrap_probe.txt): a third of it is the store path.  The two
+                    // lines start at different alignments, so each has its own groups (bases first, then qualities: one path per wave at a time).
+                    const bool al = E3_ALIGNED && len >= 32u;
+                    uint32_t rs, tail_part;                                  // bases between the last whole group and the line's end; the lane that writes the tails
+                    if (al) {
+                        const uint32_t hs = (16u - (uint32_t)((uintptr_t)(rec + oseq) & 15u)) & 15u, hq = (16u - (uint32_t)((uintptr_t)(rec + oq) & 15u)) & 15u;
+                        const uint32_t nts = ((len - hs) >> 4) + (hs ? 1u : 0u), ntq = ((len - hq) >> 4) + (hq ? 1u : 0u);       // head (if the line does not start aligned) + body
+                        for (uint32_t t = part; t < nts; t += P) { const uint32_t k0 = hs ? (t ? hs + 16u * (t - 1u) : 0u) : 16u * t;
+                                if (implied_n) group_q(k0, qw);
+                                group_s(k0, qw, sw); st16(oseq + k0, sw); }
+                        const uint32_t p2 = (part + P - (nts & (P - 1u))) & (P - 1u);                            // (the lane behind the bases' last group takes the qualities' first)
+                        for (uint32_t t = p2; t < ntq; t += P) { const uint32_t k0 = hq ? (t ? hq + 16u * (t - 1u) : 0u) : 16u * t; group_q(k0, qw); st16(oq + k0, qw); }
+                        rs = (len - hs) & 15u; tail_part = (nts + ntq) & (P - 1u);
+                        if (!jfast && tail_part == part) {                    // (a strand line of its own: plain tails where the body left bytes)
+                            const uint32_t rq = (len - hq) & 15u;
+                            if (rs || rq) { group(len - 16u, qw, sw); if (rq) st16(oq + len - 16u, qw); if (rs) st16(oseq + len - 16u, sw); }
+                        }
+                    } else {
+                        const uint32_t nfull = len >> 4;
+                        for (uint32_t gi = part; gi < nfull; gi += P) { group(16u * gi, qw, sw); put(oq + 16u * gi, oseq + 16u * gi, qw, sw, true); }
+                        rs = len & 15u; tail_part = nfull & (P - 1u);
+                        if (!jfast && tail_part == part && rs) { group(len - 16u, qw, sw); put(oq + len - 16u, oseq + len - 16u, qw, sw, true); }
+                    }
+                    if (jfast && tail_part == part) {                         // the lines' tails, positions [len - 16, len), with what follows the lines riding on them
                         group(len - 16u, qw, sw);
-                        if (!jfast) put(oq + len - 16u, oseq + len - 16u, qw, sw, true);
-                        else {
-                            if (rem > 13u) put(0u, oseq + len - 16u, qw, sw, false);                       // (the shifted store below starts behind position 16 * nfull)
+                        {
+                            if (rs > 13u) put(0u, oseq + len - 16u, qw, sw, false);                        // (the shifted store below starts behind the last whole group)
                             const uint32_t jd = 0x000A000Au | ((uint32_t)src4[0] << 8);                    // '\n', the strand character, '\n'
                             uint32_t qs[4], ss[4];
                             ss[0] = e3_align(sw[1], sw[0], 3); ss[1] = e3_align(sw[2], sw[1], 3); ss[2] = e3_align(sw[3], sw[2], 3); ss[3] = e3_align(jd, sw[3], 3);
