@@ -77,9 +77,22 @@ template <int U> __device__ __forceinline__ void span_dma(const StageSpan& sp) {
         if (sp.ng > (uint32_t)U * blockDim.x) stage_span_slow(sp.g, sp.a0, sp.ng, sp.l, sp.lim, (uint32_t)U * blockDim.x);   // (never with the tile sizes above)
     } else stage_span_slow(sp.g, sp.a0, sp.ng, sp.l, sp.lim, 0u);
 }
+// 16 global bytes per lane -> 64 consecutive 16-byte groups at a wave-uniform LDS address, as the builtin issues it - but out of the compiler's sight (HIDDEN): it orders every
+// later LDS access of the wave behind an LDS-DMA it knows of with s_waitcnt vmcnt(0), which is right for a tile's own data and defeats a request made a tile AHEAD, into
+// buffers nothing reads until the next barrier but one.  The caller waits (any later load's wait covers it: the counter is in order) and synchronises.
+template <bool HIDDEN> __device__ __forceinline__ void dma16(const uint8_t* g, uint4* lds) {
+#ifndef RFQ_SIMT_EMULATION
+    if (HIDDEN) {
+        const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(la) : "memory", "m0");
+        return;
+    }
+#endif
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
 // The same by ONE wave (lane l of it): R rounds of 64 groups.  A tile's small spans are dealt out one per wave - a wave then runs the
 // address arithmetic and the issue of its own span only.
-template <int R> __device__ __forceinline__ void span_dma_wave(const StageSpan& sp, int l) {
+template <int R, bool HIDDEN = false> __device__ __forceinline__ void span_dma_wave(const StageSpan& sp, int l) {
     const bool inside = sp.a0 + 16ull * sp.ng <= sp.lim;                     // wave-uniform
     const uint8_t* const gp = sp.g + sp.a0;
     uint32_t done = 0;
@@ -87,8 +100,7 @@ template <int R> __device__ __forceinline__ void span_dma_wave(const StageSpan& 
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t i = (uint32_t)l + 64u * (uint32_t)r;
-            if (i < sp.ng) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + 16u * i),
-                                                            (__attribute__((address_space(3))) void*)(sp.l + 64u * (uint32_t)r), 16, 0, 0);
+            if (i < sp.ng) dma16<HIDDEN>(gp + 16u * i, sp.l + 64u * (uint32_t)r);
         }
         done = 64u * (uint32_t)R;
     }

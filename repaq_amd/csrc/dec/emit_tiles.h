@@ -17,6 +17,9 @@
 #define E3_ALIGNED 1               // 0: the two long lines in line-relative 16-byte groups (A/B on the box: tools/build_variant.sh)
 #define E3_PROBE_WRAP 0            // measurement aid (tools/build_variant.sh): a mask, e.g. 0xFFFFFu = every record is written into the first MiB of its output - WRONG text,
                                    // the emitter's time with its stores kept inside the L2 (profiles/r06_zn_emit_wrap_probe.txt: 2.53 instead of 3.67 ms)
+#define E3_PREFETCH 0              // 1: the shared-pieces instantiation requests a tile's loads a tile AHEAD (below).  Built, bit-exact, measured (profiles/r06_zv*): the registers
+                                   // it keeps across the compose take the kernel from six waves per SIMD to four (114 VGPRs; at five it spills, and a spill's reload is a wait), and
+                                   // there it only wins back what the occupancy lost - 3.91 against 3.86 ms.  Off.
 #define E3_N1BIG 13312u           // name1 tile of the second instantiation: 64 per-read names of 200 bytes (34 KB of LDS, four workgroups per CU)
 struct __attribute__((packed, aligned(1))) GU16d { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) GU8d { uint32_t a, b; };
@@ -57,18 +60,20 @@ __device__ __forceinline__ uint32_t e3_align(uint32_t hi, uint32_t lo, int bytes
 // names; the walk's summary knows - DecStatus::per_read_pieces == 0).  That instantiation carries no per-read piece prefixes: a tile's uniform parameters are four words
 // instead of ten, three of the four staging waves' branches, the piece offsets and the fit tests of the pieces are gone - the tile loop kept ~110 wave-uniform values
 // alive, more than a wave has SGPRs.
-template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ void __launch_bounds__(256, N1CAP == ET_N1CAP ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img,
+template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ void __launch_bounds__(256, (N1CAP == ET_N1CAP && !(SHARED && E3_PREFETCH)) ? 5 : 4) k_dec_emit3(const uint8_t* __restrict__ img,
         const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DFused F,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const plist_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
                            uint32_t ncell, uint32_t nstr, uint32_t kshift) {
     __shared__ uint4 t_q4[E3_QCAP / 16 + 6];                                // quality tile (16 bytes of slack in front, the rest behind)
-    __shared__ uint4 t_pk4[E3_QCAP / 64 + 6];                               // the tile's packed bases
+    constexpr uint32_t NB = (SHARED && E3_PREFETCH) ? 2u : 1u;               // staging buffers of the packed bases and the middles: two where the next tile's are requested a tile ahead
+    __shared__ uint4 t_pk4[NB][E3_QCAP / 64 + 6];                           // the tile's packed bases
     __shared__ uint32_t t_nb[E3_QCAP / 32 + 8];                             // one bit per stored base of the tile: is N
     // (N1CAP: E3_N1BIG for files with long per-read names)
-    __shared__ uint4 t_mid4_[64 * E3_MIDROW / 16 + 5], t_n14_[N1CAP / 16 + 5], t_n24_[ET_N2CAP / 16 + 5], t_st4[ET_STCAP / 16 + 4];
+    // (the shared-pieces instantiation stages ONE name1 / name2 / strand piece of at most 255 bytes each)
+    __shared__ uint4 t_mid4_[NB][64 * E3_MIDROW / 16 + 5], t_n14_[(SHARED ? 256u : N1CAP) / 16 + 5], t_n24_[(SHARED ? 256u : ET_N2CAP) / 16 + 5], t_st4[(SHARED ? 256u : ET_STCAP) / 16 + 4];
     // (16 readable bytes in front of each: a 16-byte group of the name line may start before a piece)
-    uint4* const t_mid4 = t_mid4_ + 1; uint4* const t_n14 = t_n14_ + 1; uint4* const t_n24 = t_n24_ + 1;
+    uint4* const t_n14 = t_n14_ + 1; uint4* const t_n24 = t_n24_ + 1;
     __shared__ unsigned long long s_loff[NPOS_SLOT + 2]; __shared__ uint32_t s_nent[NPOS_SLOT + 2], s_val[NPOS_SLOT + 2];
     __shared__ uint32_t s_g[2][NPOS_SLOT + 2], s_kb[2][NPOS_SLOT + 2];
     const uint32_t c = blockIdx.y; const DChunk d = CH[c]; const uint8_t* cp = img + d.off;
@@ -114,6 +119,12 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
                t.a7 = uni32(a.a); t.a8 = uni32(a.b); t.a9 = uni32(a.c); t.e7 = uni32(b.a); t.e8 = uni32(b.b); t.e9 = uni32(b.c); }
         return t;
     };
+    // ---- PREFETCH (the shared-pieces instantiation): everything a tile reads from global memory - its packed bases and middles (LDS-DMA into the other pair of staging
+    // buffers), its reads' table entries, the first rounds of its list entries - is requested BEFORE the tile in front of it is composed, and has landed when its turn comes.
+    // Requested at the top of its own tile, the wait for it was 37 - 41 % of the kernel: one round trip to memory per tile - 5 us under the emitter's own store traffic - with
+    // every wave of the workgroup in it at the same time (profiles/r06_zt_emit_phase_probe.txt, r06_zt2_emit_drain_time.txt: the drain of a tile's stores is 5 %, the rest is
+    // the loads).  The other instantiations stage per-read name pieces too and keep the order they had.
+    constexpr bool PF = SHARED && E3_PREFETCH;
     uint32_t cur = rs, pb = 0;
     TileP tp_cur = tile_params(cur, cur + K < re ? cur + K : re);
     if (tid < T) { s_g[0][tid] = cell_lookup(tid, tp_cur.q0, tp_cur.s0, false); s_kb[0][tid] = cell_lookup(tid, tp_cur.q0, tp_cur.s0, true); }
@@ -126,83 +137,118 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
     // thread -> (read of the tile, part of it): the even reads first, then the odd ones - an interleaved chunk's mates are written back to front and
     // complemented, their R1 as stored, and a wave that holds both runs both paths
     const uint32_t jj = tid >> pshift, j = ((jj << 1) & (K - 1u)) | (jj >> (kshift - 1u)), part = tid & (P - 1u);
+    // a tile's spans in the image
+    struct TileD { uint64_t n1a, n1e, n2a, n2e, sta, ste, pka, pke, rqa, rqe; };
+    auto tile_spans = [&](const TileP& tp) -> TileD {
+        TileD t; const uint64_t ib = d.off;
+        t.n1a = ib + d.o_n1 + (same1 ? 0u : tp.a7); t.n1e = same1 ? t.n1a + d.n1_size : ib + d.o_n1 + tp.e7;
+        t.n2a = ib + d.o_n2 + (same2 ? 0u : tp.a8); t.n2e = same2 ? t.n2a + d.n2_size : ib + d.o_n2 + tp.e8;
+        t.sta = ib + d.o_st + (same3 ? 0u : tp.a9); t.ste = same3 ? t.sta + d.st_size : ib + d.o_st + tp.e9;
+        t.pka = ib + d.o_seq + (tp.s0 >> 2); t.pke = ib + d.o_seq + ((tp.s1 + 3u) >> 2); { const uint64_t pend = ib + d.o_seq + d.seq_size; if (t.pke > pend) t.pke = pend;
+                if (t.pka > t.pke) t.pka = t.pke; }
+        t.rqa = ib + d.o_qual + tp.q0; t.rqe = ib + d.o_qual + tp.q1; { const uint64_t qend = ib + d.o_qual + d.qual_size; if (t.rqe > qend) t.rqe = qend;
+                if (t.rqa > t.rqe) t.rqa = t.rqe; }
+        return t;
+    };
+    auto tile_fits = [&](const TileP& tp) -> bool {
+        return tp.q1 - tp.q0 <= E3_QCAP && (same1 || tp.e7 - tp.a7 + 32u <= N1CAP) && (same2 || tp.e8 - tp.a8 + 32u <= ET_N2CAP) && (same3 || tp.e9 - tp.a9 + 32u <= ET_STCAP);
+    };
+    // ---- stage: packed bases, middles, per-read name pieces (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
+    auto stage = [&](const TileD& t, uint32_t g0_, uint32_t g1_, uint32_t bsel) {
+        if (raw) span_dma<(int)((E3_QCAP / 16 + 4 + 255) / 256)>(make_span(t_q4 + 1, img, t.rqa, t.rqe, img_bytes, true));
+        if (w == 0) span_dma_wave<(int)((E3_QCAP / 64 + 4 + 63) / 64), PF>(make_span(t_pk4[bsel], img, t.pka, t.pke, img_bytes, true), l);
+        else if (w == 1) span_dma_wave<(int)((64 * E3_MIDROW / 16 + 4 + 63) / 64), PF>(make_span(t_mid4_[bsel] + 1, F.mid, (uint64_t)g0_ * E3_MIDROW, (uint64_t)g1_ * E3_MIDROW, ~0ull >> 1, true), l);
+        else if (w == 2) { if (!same1) span_dma_wave<(int)((N1CAP / 16 + 4 + 63) / 64)>(make_span(t_n14, img, t.n1a, t.n1e, img_bytes, true), l); }
+        else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, t.n2a, t.n2e, img_bytes, true), l);
+               if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, t.sta, t.ste, img_bytes, true), l); }
+    };
+    // ---- my read of a tile (P lanes share one): its table entries as they are stored (the tile's bases are taken off when the tile is composed)
+    struct ReadM { uint32_t len, md, prevlen, sdl, pql, tx; int ov; U4 p4; uint8_t n1, n2, sl; };       // (the bytes stay bytes: widening them where they are loaded is a use - a wait)
+    auto load_read = [&](uint32_t cur_, uint32_t cnt_) -> ReadM {
+        ReadM m; m.len = m.n1 = m.n2 = m.sl = m.md = m.prevlen = m.sdl = m.pql = m.tx = 0; m.ov = 0; m.p4.a = m.p4.b = m.p4.c = m.p4.d = 0;
+        const uint32_t r = cur_ + j;
+        if (j < cnt_) {
+            const uint32_t g_ = f + r; const uint2 t2 = F.tpl[g_];
+            m.sdl = F.sdl[fp + r];
+            if constexpr (!SHARED) m.p4 = F.pvl[fp + r];
+            m.tx = t2.x; m.pql = F.pql[fp + r];
+            m.len = F.len[g_]; m.ov = F.ov[g_]; m.prevlen = (r & 1u) ? F.len[g_ - 1] : 0u;
+            m.n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)]; m.n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
+            m.sl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)]; m.md = t2.y;
+        }
+        return m;
+    };
+    // ---- a tile's list entries: the first eight rounds of the quality lists (wave w takes the lists w, w + 4, ...) and two of the N list are requested here and scattered
+    // behind the tile's first barrier; what is left of longer lists is fetched there
+    struct ListS { uint32_t fe[8], fv[8], pn[2], nk0, nke, t, base, k0, ke, val; const plist_t* p; };
+    auto ls_open = [&](ListS& L, uint32_t pb_, uint32_t t_) {
+        const uint32_t g_ = uni32(s_g[pb_][t_]), b_ = uni32(s_kb[pb_][t_]), n_ = uni32(s_nent[t_]);
+        L.k0 = g_ == 0xFFFFFFFFu ? 0u : g_; L.ke = g_ == 0xFFFFFFFFu ? 0u : (b_ < n_ ? b_ : n_); L.base = 0;
+        L.val = uni32(s_val[t_]); L.p = plist + uni64(s_loff[t_]);
+    };
+    auto ls_round = [&](ListS& L, uint32_t pb_, uint32_t& e_, uint32_t& v_) {
+        while (L.t < nn && L.k0 + L.base >= L.ke) { L.t += 4u; if (L.t < nn) ls_open(L, pb_, L.t); }
+        if (L.t < nn) { const uint32_t kk = L.k0 + L.base + (uint32_t)l; if (kk < L.ke) e_ = L.p[kk]; v_ = L.val; L.base += 64u; }
+    };
+    auto load_lists = [&](uint32_t pb_) -> ListS {
+        ListS L; L.t = (uint32_t)w; L.base = L.k0 = L.ke = L.val = 0; L.p = plist;
+        if (L.t < nn) ls_open(L, pb_, L.t); else L.t = nn;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { L.fe[i] = 0xFFFFFFFFu; L.fv[i] = 0; ls_round(L, pb_, L.fe[i], L.fv[i]); }
+        L.pn[0] = L.pn[1] = 0xFFFFFFFFu; L.nk0 = 0xFFFFFFFFu; L.nke = 0;
+        if (hasn) {
+            L.nk0 = s_g[pb_][nn]; L.nke = s_kb[pb_][nn]; if (L.nke > s_nent[nn]) L.nke = s_nent[nn];
+            const plist_t* lp = plist + s_loff[nn];
+#pragma unroll
+            for (int i = 0; i < 2; i++) { const uint32_t kk = L.nk0 + tid + 256u * (uint32_t)i; if (L.nk0 != 0xFFFFFFFFu && kk < L.nke) L.pn[i] = lp[kk]; }
+        }
+        return L;
+    };
     __syncthreads();
+    ReadM mN; ListS lN;
+    if constexpr (PF) {
+        if (tile_fits(tp_cur)) { const uint32_t cnt0 = re - cur < K ? re - cur : K; stage(tile_spans(tp_cur), f + cur, f + cur + cnt0, 0u); mN = load_read(cur, cnt0); lN = load_lists(0u); }
+        else { mN = load_read(cur, 0u); lN = load_lists(0u); }
+    }
     while (cur < re) {                                                       // block-uniform
         const uint32_t cnt = re - cur < K ? re - cur : K, g0 = f + cur, g1 = g0 + cnt;
         const TileP tp = tp_cur; const uint32_t q0 = tp.q0, q1 = tp.q1, s0 = tp.s0, s1 = tp.s1;
-        const bool fits = q1 - q0 <= E3_QCAP && (same1 || tp.e7 - tp.a7 + 32u <= N1CAP) && (same2 || tp.e8 - tp.a8 + 32u <= ET_N2CAP) && (same3 || tp.e9 - tp.a9 + 32u <= ET_STCAP);
         // (the host sizes K by the longest read and by the chunks' average piece sizes; a tile whose pieces are longer than that allowed for: the host repeats the range
         // on the expanded path, k_dec_emit)
-        if (!fits) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_E3_RETRY); break; }
-        // ---- stage: packed bases, middles, per-read name pieces (LDS-DMA); raw qualities for DONT_ENCODE_QUAL files
-        const uint64_t ib = d.off;
-        const uint64_t n1a = ib + d.o_n1 + (same1 ? 0u : tp.a7), n1e = same1 ? n1a + d.n1_size : ib + d.o_n1 + tp.e7;
-        const uint64_t n2a = ib + d.o_n2 + (same2 ? 0u : tp.a8), n2e = same2 ? n2a + d.n2_size : ib + d.o_n2 + tp.e8;
-        const uint64_t sta = ib + d.o_st + (same3 ? 0u : tp.a9), ste = same3 ? sta + d.st_size : ib + d.o_st + tp.e9;
-        uint64_t pka = ib + d.o_seq + (s0 >> 2), pke = ib + d.o_seq + ((s1 + 3u) >> 2); { const uint64_t pend = ib + d.o_seq + d.seq_size; if (pke > pend) pke = pend;
-                if (pka > pke) pka = pke; }
-        uint64_t rqa = ib + d.o_qual + q0, rqe = ib + d.o_qual + q1; { const uint64_t qend = ib + d.o_qual + d.qual_size; if (rqe > qend) rqe = qend;
-                if (rqa > rqe) rqa = rqe; }
-        if (raw) span_dma<(int)((E3_QCAP / 16 + 4 + 255) / 256)>(make_span(t_q4 + 1, img, rqa, rqe, img_bytes, true));
-        if (w == 0) span_dma_wave<(int)((E3_QCAP / 64 + 4 + 63) / 64)>(make_span(t_pk4, img, pka, pke, img_bytes, true), l);
-        else if (w == 1) span_dma_wave<(int)((64 * E3_MIDROW / 16 + 4 + 63) / 64)>(make_span(t_mid4, F.mid, (uint64_t)g0 * E3_MIDROW, (uint64_t)g1 * E3_MIDROW, ~0ull >> 1, true), l);
-        else if (w == 2) { if (!same1) span_dma_wave<(int)((N1CAP / 16 + 4 + 63) / 64)>(make_span(t_n14, img, n1a, n1e, img_bytes, true), l); }
-        else { if (!same2) span_dma_wave<(int)((ET_N2CAP / 16 + 4 + 63) / 64)>(make_span(t_n24, img, n2a, n2e, img_bytes, true), l);
-               if (!same3) span_dma_wave<(int)((ET_STCAP / 16 + 4 + 63) / 64)>(make_span(t_st4, img, sta, ste, img_bytes, true), l); }
+        if (!tile_fits(tp)) { if (tid == 0) atomicOr(&st->err, (uint32_t)DE_E3_RETRY); break; }
+        const TileD td = tile_spans(tp); const uint32_t bs = PF ? pb : 0u;       // this tile's staging buffers
+        const uint64_t n1a = td.n1a, n2a = td.n2a, sta = td.sta, pka = td.pka, pke = td.pke, rqa = td.rqa;
+        if constexpr (!PF) { stage(td, g0, g1, 0u); mN = load_read(cur, cnt); lN = load_lists(pb); }
+        const ReadM m = mN; ListS ls = lN;
         // qualities start as the major value (src/rfqcodec.cpp:1089), the N bits as none
         if (bycol) { uint4* qt = t_q4 + 1; const uint32_t ng = (q1 - q0 + 15u) >> 4;
                 for (uint32_t i = tid; i < ng; i += blockDim.x) qt[i] = make_uint4(major4, major4, major4, major4); }
         for (uint32_t i = tid; i < ((s1 - s0 + 31u) >> 5) + 1u; i += blockDim.x) t_nb[i] = 0;
-        // ---- the tile's list entries, requested now and scattered after the barrier (wave w takes the lists w, w + 4, ...)
-        uint32_t ls_t = (uint32_t)w, ls_base = 0, ls_k0 = 0, ls_ke = 0, ls_val = 0; const plist_t* ls_p = plist;
-        auto ls_open = [&](uint32_t t_) {
-            const uint32_t g_ = uni32(s_g[pb][t_]), b_ = uni32(s_kb[pb][t_]), n_ = uni32(s_nent[t_]);
-            ls_k0 = g_ == 0xFFFFFFFFu ? 0u : g_; ls_ke = g_ == 0xFFFFFFFFu ? 0u : (b_ < n_ ? b_ : n_); ls_base = 0;
-            ls_val = uni32(s_val[t_]); ls_p = plist + uni64(s_loff[t_]);
-        };
-        auto ls_round = [&](uint32_t& e_, uint32_t& v_) {
-            while (ls_t < nn && ls_k0 + ls_base >= ls_ke) { ls_t += 4u; if (ls_t < nn) ls_open(ls_t); }
-            if (ls_t < nn) { const uint32_t kk = ls_k0 + ls_base + (uint32_t)l; if (kk < ls_ke) e_ = ls_p[kk]; v_ = ls_val; ls_base += 64u; }
-        };
-        if (ls_t < nn) ls_open(ls_t); else ls_t = nn;
-        uint32_t fe[8], fv[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { fe[i] = 0xFFFFFFFFu; fv[i] = 0; ls_round(fe[i], fv[i]); }
-        uint32_t pn[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }; uint32_t nk0 = 0xFFFFFFFFu, nke = 0;
-        if (hasn) {
-            nk0 = s_g[pb][nn]; nke = s_kb[pb][nn]; if (nke > s_nent[nn]) nke = s_nent[nn];
-            const plist_t* lp = plist + s_loff[nn];
-#pragma unroll
-            for (int i = 0; i < 2; i++) { const uint32_t kk = nk0 + tid + 256u * (uint32_t)i; if (nk0 != 0xFFFFFFFFu && kk < nke) pn[i] = lp[kk]; }
-        }
-        // ---- my read (P lanes share one)
+        // ---- my read
         const uint32_t r = cur + j; const bool on = j < cnt; const bool odd = (r & 1u) != 0, rc = il && odd, to2 = split && odd;
-        uint32_t len = 0, n1 = 0, n2 = 0, sl = 0, md = 0, prevlen = 0, sp = 0, qp_ = 0, o7 = 0, o8 = 0, o9 = 0; int ov = 0; uint32_t toff = 0;
-        if (on) {
-            const uint32_t g_ = f + r; const uint2 t2 = F.tpl[g_];
-            sp = F.sdl[fp + r] - s0;
-            if constexpr (!SHARED) { const U4 p4 = F.pvl[fp + r]; o7 = p4.a - tp.a7; o8 = p4.b - tp.a8; o9 = p4.c - tp.a9; }
-            toff = (to2 ? tb.b : tb.a) + t2.x; qp_ = F.pql[fp + r] - q0;
-            len = F.len[g_]; ov = F.ov[g_]; prevlen = odd ? F.len[g_ - 1] : 0u;
-            n1 = cp[d.o_n1lens + ((fl & C_NAME1_LEN_SAME) ? 0u : r)]; n2 = (hf & H_NAME2) ? cp[d.o_n2lens + ((fl & C_NAME2_LEN_SAME) ? 0u : r)] : 0u;
-            sl = cp[d.o_stlens + ((fl & C_STRAND_LEN_SAME) ? 0u : r)]; md = t2.y;
-        }
+        const uint32_t len = m.len, n1 = m.n1, n2 = m.n2, sl = m.sl, md = m.md, prevlen = m.prevlen; const int ov = m.ov;
+        uint32_t sp = 0, qp_ = 0, o7 = 0, o8 = 0, o9 = 0, toff = 0;
+        if (on) { sp = m.sdl - s0; qp_ = m.pql - q0; toff = (to2 ? tb.b : tb.a) + m.tx; if constexpr (!SHARED) { o7 = m.p4.a - tp.a7; o8 = m.p4.b - tp.a8; o9 = m.p4.c - tp.a9; } }
         // ---- the next tile's parameters (consumed a tile from now)
         const uint32_t nxt = cur + cnt; TileP tp_n = tp;
         if (nxt < re) tp_n = tile_params(nxt, nxt + K < re ? nxt + K : re);
+#ifndef RFQ_SIMT_EMULATION
+        if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the hidden LDS-DMA of this tile's staging buffers (requested a tile ago) has landed
+#endif
         __syncthreads();
         uint8_t* const q_t = (uint8_t*)(t_q4 + 1) + (raw ? (uint32_t)(rqa & 15ull) : 0u);              // quality of chunk position q0 + i at q_t[i]
-        const uint8_t* const pk = (const uint8_t*)t_pk4 + (uint32_t)(pka & 15ull);                     // packed byte (s0 >> 2) + i at pk[i]
+        const uint8_t* const pk = (const uint8_t*)t_pk4[bs] + (uint32_t)(pka & 15ull);                 // packed byte (s0 >> 2) + i at pk[i]
+        const uint4* const t_mid4 = t_mid4_[bs] + 1;
         const uint32_t have = (uint32_t)(pke - pka), sbit0 = 2u * (s0 & 3u);                              // staged packed bytes; bit offset of stored base s0 in pk
         // ---- quality lists, exception records, N list into the tiles
         {
 #pragma unroll
             // (an entry holds the low 16 bits of its position: see plist_t; 0xFFFFFFFF = no entry)
-            for (int i = 0; i < 8; i++) { const uint32_t p = plist_pos(fe[i], q0); if (p < q1) q_t[p - q0] = (uint8_t)fv[i]; }
-            while (ls_t < nn) {
+            for (int i = 0; i < 8; i++) { const uint32_t p = plist_pos(ls.fe[i], q0); if (p < q1) q_t[p - q0] = (uint8_t)ls.fv[i]; }
+            while (ls.t < nn) {
                 uint32_t e_[4], v_[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) { e_[i] = 0xFFFFFFFFu; v_[i] = 0; ls_round(e_[i], v_[i]); }
+                for (int i = 0; i < 4; i++) { e_[i] = 0xFFFFFFFFu; v_[i] = 0; ls_round(ls, pb, e_[i], v_[i]); }
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const uint32_t p = plist_pos(e_[i], q0); if (p < q1) q_t[p - q0] = (uint8_t)v_[i]; }
             }
@@ -211,15 +257,22 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
             if (hasn) {
                 const uint32_t send = s1 < slen_c ? s1 : slen_c;
 #pragma unroll
-                for (int i = 0; i < 2; i++) { const uint32_t p = plist_pos(pn[i], s0); if (p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); }
-                if (nk0 != 0xFFFFFFFFu && nk0 + 512u < nke) { const plist_t* lp = plist + s_loff[nn];
-                        for (uint32_t kk = nk0 + 512u + tid; kk < nke; kk += 256u) { const uint32_t p = plist_pos((uint32_t)lp[kk], s0);
+                for (int i = 0; i < 2; i++) { const uint32_t p = plist_pos(ls.pn[i], s0); if (p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); }
+                if (ls.nk0 != 0xFFFFFFFFu && ls.nk0 + 512u < ls.nke) { const plist_t* lp = plist + s_loff[nn];
+                        for (uint32_t kk = ls.nk0 + 512u + tid; kk < ls.nke; kk += 256u) { const uint32_t p = plist_pos((uint32_t)lp[kk], s0);
                         if (p < send) atomicOr(&t_nb[(p - s0) >> 5], 1u << ((p - s0) & 31u)); } }
             }
         }
         // the next tile's list cells (its parameters have come back by now)
         if (nxt < re && tid < T) { s_g[pb ^ 1u][tid] = cell_lookup(tid, tp_n.q0, tp_n.s0, false); s_kb[pb ^ 1u][tid] = cell_lookup(tid, tp_n.q0, tp_n.s0, true); }
         __syncthreads();
+        // the next tile's loads: on their way while this one is composed (the staging buffers this tile reads from are the other pair)
+        if constexpr (PF) {
+            if (nxt < re) {
+                const uint32_t cntn = re - nxt < K ? re - nxt : K;
+                if (tile_fits(tp_n)) { stage(tile_spans(tp_n), f + nxt, f + nxt + cntn, pb ^ 1u); mN = load_read(nxt, cntn); lN = load_lists(pb ^ 1u); }
+            }
+        }
         // ---- compose: my share of my read's four lines, straight to the output (src/rfqcodec.cpp:1141-1254, Read::toString src/read.cpp:170)
         if (on) {
             uint8_t* const rec = (to2 ? out2 : out1) + (E3_PROBE_WRAP ? (toff & (uint32_t)E3_PROBE_WRAP) : toff); const uint64_t capo = to2 ? cap2 : cap1;
