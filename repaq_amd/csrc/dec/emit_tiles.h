@@ -20,6 +20,7 @@
 #define E3_PREFETCH 0              // 1: the shared-pieces instantiation requests a tile's loads a tile AHEAD (below).  Built, bit-exact, measured (profiles/r06_zv*): the registers
                                    // it keeps across the compose take the kernel from six waves per SIMD to four (114 VGPRs; at five it spills, and a spill's reload is a wait), and
                                    // there it only wins back what the occupancy lost - 3.91 against 3.86 ms.  Off.
+#define E3_L2PF 1                  // 0: no warming of the L2 for the next tile (A/B on the box: tools/build_variant.sh)
 #define E3_N1BIG 13312u           // name1 tile of the second instantiation: 64 per-read names of 200 bytes (34 KB of LDS, four workgroups per CU)
 struct __attribute__((packed, aligned(1))) GU16d { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(1))) GU8d { uint32_t a, b; };
@@ -125,7 +126,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
     // every wave of the workgroup in it at the same time (profiles/r06_zt_emit_phase_probe.txt, r06_zt2_emit_drain_time.txt: the drain of a tile's stores is 5 %, the rest is
     // the loads).  The other instantiations stage per-read name pieces too and keep the order they had.
     constexpr bool PF = SHARED && E3_PREFETCH;
-    uint32_t cur = rs, pb = 0;
+    uint32_t cur = rs, pb = 0; uint32_t l2pf = 0; (void)l2pf;
     TileP tp_cur = tile_params(cur, cur + K < re ? cur + K : re);
     if (tid < T) { s_g[0][tid] = cell_lookup(tid, tp_cur.q0, tp_cur.s0, false); s_kb[0][tid] = cell_lookup(tid, tp_cur.q0, tp_cur.s0, true); }
     {   // pieces every read of the chunk shares: staged once
@@ -236,6 +237,9 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
         if constexpr (PF) __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the hidden LDS-DMA of this tile's staging buffers (requested a tile ago) has landed
 #endif
         __syncthreads();
+#if E3_L2PF && !defined(RFQ_SIMT_EMULATION)
+        if (SHARED) asm volatile("" :: "v"(l2pf));                                      // (the warming load of a tile ago has returned: every load of this tile behind it has)
+#endif
         uint8_t* const q_t = (uint8_t*)(t_q4 + 1) + (raw ? (uint32_t)(rqa & 15ull) : 0u);              // quality of chunk position q0 + i at q_t[i]
         const uint8_t* const pk = (const uint8_t*)t_pk4[bs] + (uint32_t)(pka & 15ull);                 // packed byte (s0 >> 2) + i at pk[i]
         const uint4* const t_mid4 = t_mid4_[bs] + 1;
@@ -273,6 +277,38 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
                 if (tile_fits(tp_n)) { stage(tile_spans(tp_n), f + nxt, f + nxt + cntn, pb ^ 1u); mN = load_read(nxt, cntn); lN = load_lists(pb ^ 1u); }
             }
         }
+        // ---- the next tile's lines into the L2, on their way while this tile is composed: one 4-byte load per thread and 128-byte line of what the next tile will ask for at its
+        // top - packed bases, middles, its reads' table entries, its lists' ranges (the first four streams and the N list) - into a register nothing reads.  The round trip at the
+        // top of a tile - 37 - 41 % of the kernel, see above - then ends in the L2 instead of behind the emitter's own stores in the queue to memory; unlike E3_PREFETCH this keeps
+        // ONE register across the compose (the load's target must stay allocated until the load has returned: it is "used" behind the next tile's first wait).
+#if E3_L2PF && !defined(RFQ_SIMT_EMULATION)
+        if (SHARED && nxt < re) {                                           // (the shared-pieces instantiation has the register to spare at six waves per SIMD)
+            const uint32_t cntn = re - nxt < K ? re - nxt : K; const TileD tn = tile_spans(tp_n);
+            const uint8_t* pb_ = nullptr; uint32_t nbytes = 0;              // my region: nbytes from pb_ on; my line of it
+            const uint32_t grp = tid >> 5, li = tid & 31u; uint32_t line = li;  // 32 threads = 32 lines = 4 KiB per region
+            if (grp == 0) { pb_ = img + tn.pka; nbytes = (uint32_t)(tn.pke - tn.pka); }
+            else if (grp == 1) { pb_ = F.mid + (size_t)(f + nxt) * E3_MIDROW; nbytes = cntn * E3_MIDROW; }
+            else if (grp == 2) {                                             // the reads' table entries: five arrays, four lines of each
+                const uint32_t a = li >> 2; line = li & 3u;
+                if (a == 0) { pb_ = (const uint8_t*)(F.tpl + f + nxt); nbytes = cntn * 8u; }
+                else if (a == 1) { pb_ = (const uint8_t*)(F.sdl + fp + nxt); nbytes = cntn * 4u; }
+                else if (a == 2) { pb_ = (const uint8_t*)(F.pql + fp + nxt); nbytes = cntn * 4u; }
+                else if (a == 3) { pb_ = (const uint8_t*)(F.len + f + nxt); nbytes = cntn * 4u; }
+                else if (a == 4) { pb_ = (const uint8_t*)(F.ov + f + nxt); nbytes = cntn * 4u; }
+            }
+            else {                                                           // groups 3 .. 7: the lists of streams 0 .. 3 and the N list
+                const uint32_t t_ = grp - 3u, st_ = t_ < 4u ? t_ : nn;       // (index among the tile's streams; group 7 = the N list)
+                if ((t_ < 4u && t_ < nn) || (t_ == 4u && hasn)) {
+                    const uint32_t g_ = s_g[pb ^ 1u][st_], b_ = s_kb[pb ^ 1u][st_], n_ = s_nent[st_]; const uint32_t ke = b_ < n_ ? b_ : n_;
+                    if (g_ != 0xFFFFFFFFu && g_ < ke) { pb_ = (const uint8_t*)(plist + s_loff[st_] + g_); nbytes = (ke - g_) * (uint32_t)sizeof(plist_t); }
+                }
+            }
+            if (nbytes) {
+                const uint8_t* const a0 = (const uint8_t*)((uintptr_t)pb_ & ~(uintptr_t)127); const uint32_t span = (uint32_t)(pb_ - a0) + nbytes;
+                if (128u * line < span) { const uint8_t* q = a0 + 128u * line; asm volatile("global_load_dword %0, %1, off" : "=v"(l2pf) : "v"(q)); }
+            }
+        }
+#endif
         // ---- compose: my share of my read's four lines, straight to the output (src/rfqcodec.cpp:1141-1254, Read::toString src/read.cpp:170)
         if (on) {
             uint8_t* const rec = (to2 ? out2 : out1) + (E3_PROBE_WRAP ? (toff & (uint32_t)E3_PROBE_WRAP) : toff); const uint64_t capo = to2 ? cap2 : cap1;
