@@ -140,7 +140,9 @@ typedef struct {
                                              the R1 bit, the flagged chunk's R2 text).  0 (default): every read is kept.  With final = 0 a flagged chunk
                                              at the very end of the range stays unconsumed (what follows it decides).  Repaq::decompress (split_pe = 0,
                                              :262-328) keeps the chunk it peeks at and loses nothing: the flag changes nothing there.               */
-    uint8_t* d_out1; size_t cap1;         /* optional caller buffers; NULL = context-owned results                     */
+    uint8_t* d_out1; size_t cap1;         /* optional caller buffers (16-byte aligned); NULL = context-owned results.  cap must cover the text plus its last line break (a
+                                             file that ends without one is trimmed in the result's count, not in the buffer).  When the call fails, what the buffers hold is
+                                             unspecified: with caller buffers the text is written before the host has looked at the image's verdict.               */
     uint8_t* d_out2; size_t cap2;
     /* optional chunk index (the .rfq format has none: RfqChunk::read finds chunk c+1 only by parsing chunk c, src/rfqchunk.cpp:161-228,
      * a dependent load per chunk).  A host that has the offsets - it encoded the image (rfq_encode_result.h_chunk_off), or it walked

@@ -162,15 +162,22 @@ class RfqCodec:
             if d2:
                 self.dev_free(d2)
 
-    def decode_bytes(self, rfq: bytes, split_pe=False, **kw):
-        d = self.dev_put(rfq)
+    def decode_bytes(self, rfq: bytes, split_pe=False, out_caps=None, **kw):
+        """out_caps = (cap1, cap2): decode into buffers of the caller (allocated here, of those sizes) instead of the context's own result buffers - the path a
+        pipelined host takes (rfq_decode_args.d_out1 / d_out2), on which the emitter is launched ahead of the host's look at the status."""
+        d = self.dev_put(rfq); o1 = o2 = None
         try:
+            if out_caps is not None:
+                o1 = self.dev_put(b"\0" * max(int(out_caps[0]), 1)); o2 = self.dev_put(b"\0" * max(int(out_caps[1]), 1)) if split_pe else None
+                kw = dict(kw, d_out1=o1, cap1=int(out_caps[0]), d_out2=o2, cap2=int(out_caps[1]) if split_pe else 0)
             r = self.decode(d, len(rfq), split_pe=split_pe, **kw)
             a = self.dev_get(r.d_fq1, r.n1) if r.n1 else b""
             b = self.dev_get(r.d_fq2, r.n2) if (split_pe and r.n2) else b""
             return (a, b) if split_pe else a
         finally:
             self.dev_free(d)
+            if o1 is not None: self.dev_free(o1)
+            if o2 is not None: self.dev_free(o2)
 
 
 def nolb_threshold(file_size: int, ends_with_newline: bool) -> int:

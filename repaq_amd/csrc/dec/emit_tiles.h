@@ -65,7 +65,7 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
         const DChunk* __restrict__ CH, const DevHeader* __restrict__ D, DFused F,
                            uint64_t img_bytes, int split, uint8_t* __restrict__ out1, uint64_t cap1, uint8_t* __restrict__ out2, uint64_t cap2, DecStatus* st,
                            const plist_t* __restrict__ plist, const unsigned long long* __restrict__ loff, const uint32_t* __restrict__ nent, const uint32_t* __restrict__ cellidx,
-                           uint32_t ncell, uint32_t nstr, uint32_t kshift) {
+                           uint32_t ncell, uint32_t nstr, uint32_t kshift, unsigned long long list_cap) {
     __shared__ uint4 t_q4[E3_QCAP / 16 + 6];                                // quality tile (16 bytes of slack in front, the rest behind)
     constexpr uint32_t NB = (SHARED && E3_PREFETCH) ? 2u : 1u;               // staging buffers of the packed bases and the middles: two where the next tile's are requested a tile ahead
     __shared__ uint4 t_pk4[NB][E3_QCAP / 64 + 6];                           // the tile's packed bases
@@ -88,6 +88,9 @@ template <bool IMPL, uint32_t N1CAP = ET_N1CAP, bool SHARED = false> __global__ 
     uint32_t per = (d.reads + gridDim.x - 1) / gridDim.x; per = (per + K - 1u) & ~(K - 1u);                 // whole tiles per workgroup (K is even: pairs stay together)
     const uint32_t rs = blockIdx.x * per; const uint32_t re = rs + per < d.reads ? rs + per : d.reads;
     if (rs >= re) return;
+    // (list_cap != 0: launched WITHOUT the host having looked at the status behind the list chain and the read table - rfq_decode.hip, "speculative" - : whatever the host
+    // would have stopped at stops the kernel; the host looks afterwards, once, and takes the path it would have taken)
+    if (list_cap && ((st->err & (uint32_t)(DE_CORRUPT | DE_CORRUPT_OV | DE_E3_RETRY)) || st->list_need > list_cap)) return;
     // (SHARED is only taken for files with coded qualities: raw quality bytes - more than 64 values, rare - keep the general instantiation)
     const bool raw = !SHARED && (hf & H_DONT_QUAL) != 0, bycol = SHARED || (!raw && (hf & H_QUAL_BY_COL));
     const uint32_t nn = bycol ? (D->n_normal < NPOS_SLOT ? D->n_normal : NPOS_SLOT) : 0u; const bool hasn = (hf & H_N_POS) != 0;

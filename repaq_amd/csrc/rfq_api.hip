@@ -44,11 +44,12 @@ extern "C" int rfq_set_option(rfq_ctx* c, const char* name, const char* value) {
     else if (n == "RFQ_G2_PAD") { RFQ_OPT_NUM(0, 150000, "0 .. 150000 bytes of LDS") c->opt.g2_pad = set ? (uint32_t)num : 0u; }
     else if (n == "RFQ_SP_PAD") { RFQ_OPT_NUM(0, 150000, "0 .. 150000 bytes of LDS") c->opt.sp_pad = set ? (uint32_t)num : d.sp_pad; }
     else if (n == "RFQ_POS_SEG") { if (set && v != "1024" && v != "2048") return rfq_fail(c, RFQ_E_ARG, "RFQ_POS_SEG is 1024 or 2048"); c->opt.pos_seg = set ? atoi(v.c_str()) : 0; }
+    else if (n == "RFQ_SPEC") { if (set && v != "0" && v != "1") return rfq_fail(c, RFQ_E_ARG, "RFQ_SPEC is 0 or 1"); c->opt.no_spec = v == "0"; }
     else return rfq_fail(c, RFQ_E_ARG, "unknown option %s", name);
 #undef RFQ_OPT_NUM
     return RFQ_OK;
 }
-static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD", "RFQ_SP_PAD", "RFQ_POS_SEG" };
+static const char* const RFQ_OPTION_NAMES[] = { "RFQ_GATHER", "RFQ_QUAL", "RFQ_CODER", "RFQ_INDEX", "RFQ_IDX_TILES", "RFQ_STREAMS", "RFQ_SLICE_BYTES", "RFQ_SLICE_BASES", "RFQ_WALK", "RFQ_GW_SHIFT", "RFQ_MATERIALISE", "RFQ_TRACE", "RFQ_G2_PAD", "RFQ_SP_PAD", "RFQ_POS_SEG", "RFQ_SPEC" };
 extern "C" const char* rfq_option_name(int i) { return (i >= 0 && i < (int)(sizeof RFQ_OPTION_NAMES / sizeof RFQ_OPTION_NAMES[0])) ? RFQ_OPTION_NAMES[i] : nullptr; }
 // the switch's current value in the form rfq_set_option takes ("" = its default): what a caller saves before it changes a switch for a while
 extern "C" int rfq_get_option(const rfq_ctx* c, const char* name, char* out, size_t cap) {
@@ -69,6 +70,7 @@ extern "C" int rfq_get_option(const rfq_ctx* c, const char* name, char* out, siz
     else if (n == "RFQ_G2_PAD") v = o.g2_pad ? std::to_string(o.g2_pad) : "";
     else if (n == "RFQ_SP_PAD") v = o.sp_pad != d.sp_pad ? std::to_string(o.sp_pad) : "";
     else if (n == "RFQ_POS_SEG") v = o.pos_seg ? std::to_string(o.pos_seg) : "";
+    else if (n == "RFQ_SPEC") v = o.no_spec ? "0" : "";
     else return RFQ_E_ARG;
     if (v.size() + 1 > cap) return RFQ_E_NOSPACE;
     memcpy(out, v.c_str(), v.size() + 1);

@@ -85,6 +85,7 @@ struct RfqOpts {
     uint32_t g2_pad = 0;              // RFQ_G2_PAD         profiling aid: bytes of unused dynamic LDS added to k_gather2 (fewer resident workgroups)
     // RFQ_SP_PAD         bytes of unused dynamic LDS added to k_seqpack: caps its resident workgroups so that the position coder beside it keeps its share
     uint32_t sp_pad = 0;
+    bool no_spec = false;             // RFQ_SPEC=0         decode: the emitter only behind the host's look at the status (default: launched ahead of it where the caller gave the output buffers)
     int  pos_seg = 0;                 // RFQ_POS_SEG=1024|2048   decode, list chain: bytes of a position stream per wave (default: by the largest stream, dec/pos_lists.h)
 };
 struct rfq_ctx {

@@ -239,6 +239,7 @@ DEC_FORMS = {
     "one_stream": ({"RFQ_STREAMS": "1"}, None),
     "pos_seg_2048": ({"RFQ_POS_SEG": "2048"}, None),                                         # the list chain's larger segments (default only for streams of 32 KB and more)
     "pos_seg_1024": ({"RFQ_POS_SEG": "1024"}, None),
+    "no_spec": ({"RFQ_SPEC": "0"}, None),                                                    # the emitter behind the host's look at the status, not ahead of it
     "slice_bases": ({"RFQ_SLICE_BASES": None}, None),                                        # ranges of two or three chunks
     "gw_small": ({"RFQ_GW_SHIFT": "12"}, None),                                              # many guess-and-verify segments
     "exact_materialise_slices": ({"RFQ_WALK": "exact", "RFQ_MATERIALISE": "1", "RFQ_SLICE_BASES": None}, None),

@@ -122,7 +122,9 @@ def run(codec, modes=((),), counts=None, seed=7, time_bound_s=60.0, good_every=1
                 for k, (mlabel, mimg, index) in enumerate(muts):
                     t0 = time.perf_counter()
                     try:
-                        codec.decode_bytes(mimg, split_pe=split, **({"chunk_off": index} if index else {}))
+                        # (every other mutant into buffers of the caller - the size the good image needs -: the emitter is then launched ahead of the host's look at the status)
+                        caps = {"out_caps": ((len(want[0]) if split else len(want)) + 4096, (len(want[1]) if split else 0) + 4096)} if k % 2 else {}
+                        codec.decode_bytes(mimg, split_pe=split, **caps, **({"chunk_off": index} if index else {}))
                         summary["decoded"] += 1; what = "decoded"
                     except RfqError as e:
                         # (an allocation the device cannot make is a refusal, not a fault: a few bytes of image may claim more text than the device holds)

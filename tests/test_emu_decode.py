@@ -32,6 +32,19 @@ DECODABLE = sorted(n for n in CASES if n != "se_name_over_255" and _oracle_rfq(C
 
 
 @pytest.mark.parametrize("name", DECODABLE)
+def test_case_decodes_into_the_callers_buffers(codec, name):
+    """the same through rfq_decode_args.d_out1 / d_out2 - the emitter launched ahead of the host's look at the status -, and into buffers one byte too small"""
+    from repaq_amd import RfqError
+    rfq = _oracle_rfq(CASES[name]); split = CASES[name]["paired"] != 0
+    want = O.decode_file(rfq, split); w1, w2 = (want if split else (want, b""))
+    assert codec.decode_bytes(rfq, split_pe=split, out_caps=(len(w1) + 64, len(w2) + 64)) == want
+    if len(w1) > 1:
+        with pytest.raises(RfqError):
+            codec.decode_bytes(rfq, split_pe=split, out_caps=(len(w1) - 1, len(w2) + 64))
+        assert codec.decode_bytes(rfq, split_pe=split, out_caps=(len(w1) + 64, len(w2) + 64)) == want      # (the context is as good as new behind the refusal)
+
+
+@pytest.mark.parametrize("name", DECODABLE)
 def test_case_decodes_like_oracle(codec, name):
     rfq = _oracle_rfq(CASES[name]); split = CASES[name]["paired"] != 0
     assert codec.decode_bytes(rfq, split_pe=split) == O.decode_file(rfq, split)
