@@ -424,7 +424,9 @@ __global__ void k_pos_sizes(ChunkTab C, const DevHeader* __restrict__ D, const u
             if (C.scap[k]) for (uint32_t s = 0; s < n_seg; s++) segd[k * n_seg + s] += total; }
 }
 // g0, gn: the groups this launch codes (the quality / exception groups run behind the gather, the N group behind the sequence packer)
-__global__ void k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint16_t* __restrict__ snm,
+// (six waves per SIMD: 80 VGPRs, 22 of the fattest path's spilled - the byte-stream / exception / N instantiations share the kernel -; uncapped the kernel took 106 and ran at four:
+// the phase beside the packer 3.27 -> 3.15 ms, five waves 3.21, seven 3.20, eight 3.60: profiles/r06_zze_pos_coder_waves.txt)
+__global__ void __launch_bounds__(64, 6) k_pos_coder(ReadTab R, ChunkTab C, const DevHeader* __restrict__ D, const uint8_t* __restrict__ qcat, const uint16_t* __restrict__ snm,
                             uint8_t* __restrict__ scratch, const uint64_t* __restrict__ cbase, uint8_t* __restrict__ scratch_n, const uint64_t* __restrict__ cbase_n,
                             uint32_t* __restrict__ segb, const int* __restrict__ segc, const uint32_t* __restrict__ segm, uint32_t n_seg, uint32_t n_chunks,
                             uint32_t n_qgroups, uint32_t g0, uint32_t gn, DevStatus* st, const uint32_t* __restrict__ planes, uint64_t pstride) {
